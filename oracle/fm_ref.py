@@ -1,0 +1,146 @@
+"""Eager-PyTorch CPU restatement of the flow-matching wrapper around the network.
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).
+
+Follows:
+  * particle_fm/models/components/time_emb.py:49-96     (cosine_encoding)
+  * particle_fm/models/flow_matching_module.py:191-233  (CNF.forward / time_embedding)
+  * particle_fm/models/flow_matching_module.py:62-71    (ode_wrapper.forward, FM branch)
+  * particle_fm/models/flow_matching_module.py:245-259, 283-287 (CNF.decode, "midpoint")
+  * particle_fm/models/flow_matching_module.py:637-677  (SetFlowMatchingLitModule.sample)
+  * particle_fm/models/components/losses.py:38-77       (FlowMatchingLoss.forward)
+  * particle_fm/models/components/losses.py:101-136     (ConditionalFlowMatchingLoss.forward)
+  * torchdyn (requirements.txt:25, unpinned, NOT vendored): fixed-step ``odeint`` driver and
+    ``Midpoint.step`` restated from the published algorithm of torchdyn 1.0.x:
+        k1 = f(t, x); x_mid = x + 0.5*dt*k1; x_new = x + dt * f(t + 0.5*dt, x_mid)
+        t <- t + dt; dt <- t_span[k+1] - t          (t, dt 0-dim fp32 from torch.linspace)
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Mapping, Optional
+
+import torch
+
+from .epic_ref import epic_encoder
+
+
+def cosine_encoding(x: torch.Tensor, outp_dim: int = 32, min_value: float = 0.0, max_value: float = 1.0):
+    """time_emb.py:79-96, exponential frequencies; exact fp32 op order
+    ``((x + min) * exp(arange(D))) * pi / (max + min)``."""
+    if x.shape[-1] != 1 or x.dim() == 1:
+        x = x.unsqueeze(-1)
+    freqs = torch.arange(outp_dim, device=x.device).exp()
+    return torch.cos((x + min_value) * freqs * math.pi / (max_value + min_value))
+
+
+def time_embedding_cosine(t: torch.Tensor, x: torch.Tensor, t_dim: int) -> torch.Tensor:
+    """flow_matching_module.py:223-228.  t is (B,N) in training, 0-dim in sampling."""
+    if t.dim() == 0:
+        t = t.unsqueeze(0)
+    emb = cosine_encoding(t, t_dim)
+    return emb.expand(*x.shape[:-1], -1)
+
+
+class EpicVectorField:
+    """CNF.forward for model="epic", t_emb="cosine" (flow_matching_module.py:191-204)."""
+
+    def __init__(self, state: Mapping[str, torch.Tensor], prefix: str, hp: Mapping):
+        self.state = state
+        self.prefix = prefix
+        self.hp = dict(hp)
+
+    def __call__(self, t, x, cond=None, mask=None):
+        hp = self.hp
+        t_dim = 2 * hp["frequencies"]
+        temb = time_embedding_cosine(t, x, t_dim)
+        if hp.get("add_time_to_input", False):
+            x = torch.cat((temb, x), dim=-1)  # :199-200
+        return epic_encoder(
+            self.state,
+            self.prefix,
+            temb,
+            x,
+            cond,
+            mask,
+            layers=hp["layers"],
+            t_local_cat=hp.get("t_local_cat", True),
+            t_global_cat=hp.get("t_global_cat", True),
+            global_cond_dim=hp.get("global_cond_dim", 0),
+            local_cond_dim=hp.get("local_cond_dim", 0),
+            sum_scale=hp.get("sum_scale", 1e-2),
+        )
+
+
+def fm_ot_targets(x, mask, t, z, sigma: float):
+    """losses.py:41-62 with the random draws (t per jet, z) made explicit."""
+    if mask is None:
+        mask = torch.ones_like(x[..., 0]).unsqueeze(-1)
+    tt = t.unsqueeze(-1).repeat_interleave(x.shape[1], dim=1).unsqueeze(-1).type_as(x)  # :47,50
+    y = (1 - tt) * x + (sigma + (1 - sigma) * tt) * z  # :56
+    u_t = ((1 - sigma) * z - x) * mask  # :61-62
+    return tt, y, u_t, mask
+
+
+def fm_ot_loss(vf: Callable, x, mask, cond, t, z, sigma: float = 1e-4):
+    """FlowMatchingLoss.forward (losses.py:38-77) for set data, draws given.
+    Returns (loss, y, u_t, v_t)."""
+    tt, y, u_t, m = fm_ot_targets(x, mask, t, z, sigma)
+    v_t = vf(tt.squeeze(-1), y, mask=m, cond=cond)  # :66-69 (single flow)
+    loss = (v_t - u_t).square().sum() / m.sum()  # :75-76
+    return loss, y, u_t, v_t
+
+
+def cfm_loss(vf: Callable, x, mask, cond, t, x0, eps, sigma: float = 1e-4):
+    """ConditionalFlowMatchingLoss.forward (losses.py:101-136), draws given
+    (x0 = prior sample, eps = the second randn_like).  mask must not be None (:119)."""
+    tt = t.unsqueeze(-1).repeat_interleave(x.shape[1], dim=1).unsqueeze(-1).type_as(x)
+    mu_t = (1 - tt) * x + tt * x0
+    y = mu_t + sigma * eps
+    u_t = (x0 - x) * mask
+    v_t = vf(tt.squeeze(-1), y, mask=mask, cond=cond)
+    loss = torch.nn.functional.mse_loss(v_t, u_t, reduction="sum") / mask.sum()
+    return loss, y, u_t, v_t
+
+
+def midpoint_trajectory_end(f: Callable, x: torch.Tensor, t_span: torch.Tensor) -> torch.Tensor:
+    """Fixed-step explicit midpoint over ``t_span`` (torchdyn 1.0.x semantics, restated).
+    Returns the final state only (the reference takes ``traj[-1]``, :285-287)."""
+    t = t_span[0]
+    dt = t_span[1] - t
+    steps = len(t_span)
+    for k in range(1, steps):
+        k1 = f(t, x)
+        x_mid = x + 0.5 * dt * k1
+        x = x + dt * f(t + 0.5 * dt, x_mid)
+        t = t + dt
+        if k < steps - 1:
+            dt = t_span[k + 1] - t
+    return x
+
+
+def midpoint_time_grid(ode_steps: int):
+    """The 2*(ode_steps-1) evaluation times (t_k, t_k + dt_k/2) and the dt_k the
+    restated driver visits, as fp32 tensors -- the same arithmetic as above."""
+    t_span = torch.linspace(1.0, 0.0, ode_steps)
+    t = t_span[0]
+    dt = t_span[1] - t
+    ts, dts = [], []
+    for k in range(1, ode_steps):
+        ts.append(t.clone())
+        ts.append(t + 0.5 * dt)
+        dts.append(dt.clone())
+        t = t + dt
+        if k < ode_steps - 1:
+            dt = t_span[k + 1] - t
+    return torch.stack(ts), torch.stack(dts)
+
+
+def sample_midpoint(vf: Callable, z, cond, mask, ode_steps: int = 100):
+    """SetFlowMatchingLitModule.sample + CNF.decode("midpoint") with z given
+    (flow_matching_module.py:659-674, 253-259, 283-287)."""
+    if mask is not None:
+        z = z * mask  # :668-671
+    t_span = torch.linspace(1.0, 0.0, ode_steps)
+    with torch.no_grad():
+        return midpoint_trajectory_end(lambda t, x: vf(t, x, mask=mask, cond=cond), z, t_span)

@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own hot-path modules.
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  Runs only in the build
+container, where ``/root/reference`` is mounted; the GPU box never sees the
+reference, only the committed ``.npz`` vectors this script writes.  Nothing
+from the reference is copied: its files are imported *where they lie* and only
+numeric inputs/outputs are stored.
+
+Loader recipe: the reference package's ``__init__``
+pulls plotting / jetnet / lightning, none of which is installed, so the five
+hot-path files are loaded by path behind empty parent packages, with inert
+stand-ins for the third-party names they import but the path never calls
+(``ot``, ``pytorch_lightning.LightningModule``, ``torchdyn.core.NeuralODE``,
+``zuko.utils.odeint``).  Consequence: ``CNF.decode`` (torchdyn) cannot run, so
+the "midpoint" vectors are *reference vector field + restated integrator*
+(``oracle/fm_ref.py::midpoint_trajectory_end``).
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("PFM_REFERENCE_ROOT", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+
+from oracle.fm_ref import midpoint_trajectory_end  # noqa: E402
+
+
+def _pkg(name):
+    m = types.ModuleType(name)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def load_reference():
+    """Import the reference hot-path modules by file path.  Returns a namespace."""
+    for name in ("particle_fm", "particle_fm.utils", "particle_fm.models", "particle_fm.models.components"):
+        _pkg(name)
+    pl = types.ModuleType("particle_fm.utils.pylogger")
+    pl.get_pylogger = logging.getLogger
+    sys.modules["particle_fm.utils.pylogger"] = pl
+    sys.modules["ot"] = types.ModuleType("ot")
+    plm = types.ModuleType("pytorch_lightning")
+    plm.LightningModule = torch.nn.Module
+    sys.modules["pytorch_lightning"] = plm
+    td, tdc = _pkg("torchdyn"), types.ModuleType("torchdyn.core")
+    tdc.NeuralODE = None
+    sys.modules["torchdyn.core"] = tdc
+    zk, zku = _pkg("zuko"), types.ModuleType("zuko.utils")
+    zku.odeint = None
+    sys.modules["zuko.utils"] = zku
+
+    def load(mod, rel):
+        spec = importlib.util.spec_from_file_location(mod, os.path.join(REF, rel))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[mod] = m
+        spec.loader.exec_module(m)
+        return m
+
+    comp = sys.modules["particle_fm.models.components"]
+    base = "particle_fm/models/components/"
+    mods = {}
+    for name in ("diffusion", "epic", "time_emb", "droid_transformer", "norm_layer", "solver", "mdma", "losses", "mlp"):
+        mods[name] = load(f"particle_fm.models.components.{name}", base + name + ".py")
+    comp.EPiC_encoder = mods["epic"].EPiC_encoder
+    comp.MDMA = mods["mdma"].MDMA
+    comp.IterativeNormLayer = mods["norm_layer"].IterativeNormLayer
+    fmm = load("particle_fm.models.flow_matching_module", "particle_fm/models/flow_matching_module.py")
+    ns = types.SimpleNamespace(**mods)
+    ns.fmm = fmm
+    return ns
+
+
+# ----------------------------------------------------------------------------------------------
+# configurations (reference yaml: configs/model/flow_matching.yaml + experiment overrides)
+# ----------------------------------------------------------------------------------------------
+BASE = dict(
+    model="epic", features=3, hidden_dim=128, frequencies=16, layers=6, latent=10,
+    activation="leaky_relu", wrapper_func="weight_norm", t_local_cat=True, t_global_cat=True,
+    add_time_to_input=False, t_emb="cosine", loss_type="FM-OT", global_cond_dim=0, local_cond_dim=0,
+    dropout=0.0, sum_scale=1e-2,
+)
+CONFIGS = {
+    # BASELINE cfg 2 (experiment/jetnet/fm_tops30.yaml) and cfg 3 (fm_tops150.yaml): same net, N differs
+    "jetnet30": dict(BASE, num_particles=30),
+    "jetnet150": dict(BASE, num_particles=150),
+    # conditioned variants of the same operator at reduced depth (keeps the fixture small):
+    # fm_tops150_cond.yaml style (global 2 / local 2) and jetclass_cond.yaml style (global 12 / local 0, F=13, L=16)
+    "cond_gl": dict(BASE, num_particles=40, layers=2, global_cond_dim=2, local_cond_dim=2),
+    "cond_jetclass": dict(BASE, num_particles=48, layers=2, features=13, latent=16, global_cond_dim=12),
+}
+
+
+def make_mask(B, N, kind, gen):
+    if kind == "none":
+        return None
+    n = torch.randint(max(2, N // 5), N + 1, (B,), generator=gen)
+    n[0] = N  # one full jet
+    if B > 1:
+        n[1] = max(2, N // 5)  # one with a long padded tail
+    m = (torch.arange(N)[None, :] < n[:, None]).unsqueeze(-1)
+    return m.to(torch.int64) if kind == "int64" else m.to(torch.float32)
+
+
+def gen_config(ref, name, hp, out_dir, B=4, seed=12345):
+    torch.manual_seed(seed)
+    cnf = ref.fmm.CNF(**hp)
+    # default init leaves weight_g = ||v|| (identity reparam); perturb g and bias so g matters
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for k, p in cnf.named_parameters():
+            if k.endswith("weight_g"):
+                p.mul_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+            elif k.endswith("bias"):
+                p.add_(0.05 * torch.randn(p.shape, generator=gen))
+    flows = torch.nn.ModuleList([cnf])
+    state = {f"flows.0.{k}": v.detach().clone() for k, v in cnf.state_dict().items()}
+    N, Fe, Cg = hp["num_particles"], hp["features"], hp["global_cond_dim"]
+    out = {"_keys": np.array(list(state.keys()))}
+    for k, v in state.items():
+        out["sd/" + k] = v.numpy()
+    out["hp_json"] = np.array(__import__("json").dumps(hp))
+
+    for mk in ("f32", "int64", "none"):
+        mask = make_mask(B, N, mk, gen)
+        x = torch.randn(B, N, Fe, generator=gen)
+        if mask is not None:
+            x = x * mask
+        cond = torch.randn(B, Cg, generator=gen) if Cg > 0 else None
+        t = torch.rand(B, generator=gen)
+        tag = f"nfe_{mk}/"
+        with torch.no_grad():
+            # training-style call: t is (B,N)
+            tt = t.unsqueeze(-1).repeat_interleave(N, dim=1)
+            temb = cnf.time_embedding(tt, x, hp["t_emb"])
+            v_vec = cnf(tt, x, cond=cond, mask=mask)
+            # sampling-style call: 0-dim t (same value for every jet)
+            ts = t[0].clone()
+            v_sca = cnf(ts, x, cond=cond, mask=mask)
+        out[tag + "x"] = x.numpy()
+        out[tag + "t"] = t.numpy()
+        out[tag + "temb"] = temb[:, 0, :].numpy()
+        if mask is not None:
+            out[tag + "mask"] = mask.numpy()
+        if cond is not None:
+            out[tag + "cond"] = cond.numpy()
+        out[tag + "v_vec_t"] = v_vec.numpy()
+        out[tag + "v_scalar_t"] = v_sca.numpy()
+
+    # ---- loss + grads through the reference's own FlowMatchingLoss (draws replayed by seed) ----
+    for mk in ("f32", "none"):
+        mask = make_mask(B, N, mk, gen)
+        x = torch.randn(B, N, Fe, generator=gen)
+        if mask is not None:
+            x = x * mask
+        cond = torch.randn(B, Cg, generator=gen) if Cg > 0 else None
+        loss_mod = ref.losses.FlowMatchingLoss(flows=flows, sigma=1e-4)
+        s = 9999
+        torch.manual_seed(s)
+        cnf.zero_grad()
+        loss = loss_mod(x, mask=mask, cond=cond)
+        loss.backward()
+        torch.manual_seed(s)  # replay the same draws, same order (losses.py:46, 53)
+        t = torch.rand_like(torch.ones(B))
+        z = torch.randn_like(x)
+        tag = f"loss_{mk}/"
+        out[tag + "x"], out[tag + "t"], out[tag + "z"] = x.numpy(), t.numpy(), z.numpy()
+        if mask is not None:
+            out[tag + "mask"] = mask.numpy()
+        if cond is not None:
+            out[tag + "cond"] = cond.numpy()
+        out[tag + "loss"] = loss.detach().numpy()
+        for k, p in cnf.named_parameters():
+            out[tag + "grad/flows.0." + k] = p.grad.detach().clone().numpy()
+
+    # ---- CFM loss (losses.py:101-136), mask required ----
+    mask = make_mask(B, N, "f32", gen)
+    x = torch.randn(B, N, Fe, generator=gen) * mask
+    cond = torch.randn(B, Cg, generator=gen) if Cg > 0 else None
+    loss_mod = ref.losses.ConditionalFlowMatchingLoss(flows=flows, sigma=1e-4)
+    torch.manual_seed(4242)
+    cnf.zero_grad()
+    loss = loss_mod(x, mask=mask, cond=cond)
+    torch.manual_seed(4242)  # losses.py:104, 108, 116
+    t = torch.rand_like(torch.ones(B))
+    x0 = torch.randn_like(x)
+    eps = torch.randn_like(x)
+    tag = "cfm/"
+    out[tag + "x"], out[tag + "t"], out[tag + "x0"], out[tag + "eps"] = x.numpy(), t.numpy(), x0.numpy(), eps.numpy()
+    out[tag + "mask"] = mask.numpy()
+    if cond is not None:
+        out[tag + "cond"] = cond.numpy()
+    out[tag + "loss"] = loss.detach().numpy()
+
+    # ---- midpoint: reference vector field (imported CNF.forward via the imported ode_wrapper)
+    #      + restated integrator ----
+    for steps in (3, 10, 100):
+        mask = make_mask(B, N, "f32", gen)
+        cond = torch.randn(B, Cg, generator=gen) if Cg > 0 else None
+        z = torch.randn(B, N, Fe, generator=gen)
+        z0 = z * mask
+        wrapped = ref.fmm.ode_wrapper(model=cnf, cond=cond, mask=mask, loss_type="FM-OT")
+        with torch.no_grad():
+            xe = midpoint_trajectory_end(wrapped, z0, torch.linspace(1.0, 0.0, steps))
+        tag = f"midpoint_{steps}/"
+        out[tag + "z"], out[tag + "mask"], out[tag + "x_end"] = z.numpy(), mask.numpy(), xe.numpy()
+        if cond is not None:
+            out[tag + "cond"] = cond.numpy()
+
+    path = os.path.join(out_dir, f"epic_{name}.npz")
+    np.savez(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
+
+
+def gen_no_sets(ref, out_dir, seed=12345):
+    """BASELINE cfg 1: fully-connected FM vector field (flow_matching_no_sets.py:41-66 + mlp.py:24-68).
+    flow_matching_no_sets.py itself imports torchdyn at module top but only CNF.decode uses it."""
+    spec = importlib.util.spec_from_file_location(
+        "particle_fm.models.flow_matching_no_sets", os.path.join(REF, "particle_fm/models/flow_matching_no_sets.py")
+    )
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = m
+    spec.loader.exec_module(m)
+    torch.manual_seed(seed)
+    cnf = m.CNF(features=2, freqs=3)
+    gen = torch.Generator().manual_seed(seed + 7)
+    B = 16
+    x = torch.randn(B, 2, generator=gen)
+    cond = torch.zeros(B, 1)
+    t = torch.rand(B, generator=gen)
+    with torch.no_grad():
+        v = cnf(t, x, cond=cond)
+    flows = torch.nn.ModuleList([cnf])
+    loss_mod = ref.losses.FlowMatchingLoss(flows=flows, sigma=1e-4)
+    torch.manual_seed(77)
+    loss = loss_mod(x, mask=None, cond=cond)
+    loss.backward()
+    torch.manual_seed(77)  # losses.py:49, 53 (non-set branch: t per sample)
+    tl = torch.rand_like(x[..., 0]).unsqueeze(-1)
+    zl = torch.randn_like(x)
+    out = {"_keys": np.array(list(cnf.state_dict().keys()))}
+    for k, v_ in cnf.state_dict().items():
+        out["sd/" + k] = v_.detach().numpy()
+    out.update(x=x.numpy(), cond=cond.numpy(), t=t.numpy(), v=v.numpy(), loss_t=tl.numpy(), loss_z=zl.numpy(),
+               loss=loss.detach().numpy())
+    for k, p in cnf.named_parameters():
+        out["grad/" + k] = p.grad.numpy()
+    # midpoint with restated integrator
+    z = torch.randn(B, 2, generator=gen)
+    wrapped = m.ode_wrapper(cnf, mask=None, cond=cond)
+    with torch.no_grad():
+        xe = midpoint_trajectory_end(wrapped, z, torch.linspace(1.0, 0.0, 20))
+    out.update(mid_z=z.numpy(), mid_x_end=xe.numpy())
+    path = os.path.join(out_dir, "no_sets_moons.npz")
+    np.savez(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = load_reference()
+    for name, hp in CONFIGS.items():
+        gen_config(ref, name, hp, args.out)
+    gen_no_sets(ref, args.out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+"""The CPU oracle (oracle/*.py) against vectors recorded from the REFERENCE's own modules
+(tests/golden/*.npz, written by oracle/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.epic_ref import epic_param_shapes, wn_linear
+from oracle.fm_ref import (
+    EpicVectorField,
+    cfm_loss,
+    cosine_encoding,
+    fm_ot_loss,
+    midpoint_time_grid,
+    sample_midpoint,
+)
+
+# fp32 NFE tolerance (fp32-vs-fp64 floor 2.3e-7 on |v|~0.12)
+ATOL, RTOL = 1e-5, 1e-4
+
+
+def vf_of(g):
+    return EpicVectorField(g.state, "flows.0.net", g.hp)
+
+
+def test_state_dict_keys_and_shapes(golden):
+    hp = golden.hp
+    T = 2 * hp["frequencies"]
+    expect = epic_param_shapes(
+        features=hp["features"], input_dim=hp["features"], hidden=hp["hidden_dim"], latent=hp["latent"],
+        layers=hp["layers"], t_dim_local=T, t_dim_global=T,
+        global_cond_dim=hp["global_cond_dim"], local_cond_dim=hp["local_cond_dim"],
+    )
+    keys = ["flows.0.frequencies"] + ["flows.0.net." + k for k, _ in expect]
+    assert golden.keys == keys
+    for k, shp in expect:
+        assert tuple(golden.state["flows.0.net." + k].shape) == shp
+
+
+@pytest.mark.parametrize("mk", ["f32", "int64", "none"])
+def test_time_embedding_bitwise(golden, mk):
+    t = golden.get(f"nfe_{mk}/t")
+    temb = cosine_encoding(t, 2 * golden.hp["frequencies"])
+    # same torch CPU kernels, same op order -> bit-identical
+    assert torch.equal(temb, golden.get(f"nfe_{mk}/temb"))
+
+
+@pytest.mark.parametrize("mk", ["f32", "int64", "none"])
+def test_nfe_vector_and_scalar_t(golden, mk):
+    tag = f"nfe_{mk}/"
+    x, t = golden.get(tag + "x"), golden.get(tag + "t")
+    mask, cond = golden.get(tag + "mask"), golden.get(tag + "cond")
+    vf = vf_of(golden)
+    N = x.shape[1]
+    with torch.no_grad():
+        v = vf(t.unsqueeze(-1).repeat_interleave(N, dim=1), x, cond=cond, mask=mask)
+        vs = vf(t[0], x, cond=cond, mask=mask)
+    torch.testing.assert_close(v, golden.get(tag + "v_vec_t"), atol=ATOL, rtol=RTOL)
+    torch.testing.assert_close(vs, golden.get(tag + "v_scalar_t"), atol=ATOL, rtol=RTOL)
+    # scalar-t call == vector-t call on the jet whose t it took
+    torch.testing.assert_close(vs[0], v[0], atol=ATOL, rtol=RTOL)
+    if mask is not None:
+        assert torch.all(v[mask.squeeze(-1) == 0] == 0)
+
+
+@pytest.mark.parametrize("mk", ["f32", "none"])
+def test_fm_loss_and_grads(golden, mk):
+    tag = f"loss_{mk}/"
+    x, t, z = golden.get(tag + "x"), golden.get(tag + "t"), golden.get(tag + "z")
+    mask, cond = golden.get(tag + "mask"), golden.get(tag + "cond")
+    state = {k: v.clone().requires_grad_(v.is_floating_point() and "frequencies" not in k) for k, v in golden.state.items()}
+    vf = EpicVectorField(state, "flows.0.net", golden.hp)
+    loss, *_ = fm_ot_loss(vf, x, mask, cond, t, z, sigma=1e-4)
+    torch.testing.assert_close(loss.detach(), golden.get(tag + "loss"), atol=1e-6, rtol=1e-5)
+    loss.backward()
+    ref = golden.grads(tag)
+    assert len(ref) == len(golden.keys) - 1
+    for k, gref in ref.items():
+        got = state[k].grad
+        scale = max(gref.abs().max().item(), 1e-8)
+        assert (got - gref).abs().max().item() <= 2e-5 * scale + 1e-7, k
+
+
+def test_cfm_loss(golden):
+    tag = "cfm/"
+    vf = vf_of(golden)
+    with torch.no_grad():
+        loss, *_ = cfm_loss(vf, golden.get(tag + "x"), golden.get(tag + "mask"), golden.get(tag + "cond"),
+                            golden.get(tag + "t"), golden.get(tag + "x0"), golden.get(tag + "eps"), sigma=1e-4)
+    torch.testing.assert_close(loss, golden.get(tag + "loss"), atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("steps", [3, 10, 100])
+def test_midpoint_reference_vf_restated_integrator(golden, steps):
+    tag = f"midpoint_{steps}/"
+    vf = vf_of(golden)
+    xe = sample_midpoint(vf, golden.get(tag + "z"), golden.get(tag + "cond"), golden.get(tag + "mask"), ode_steps=steps)
+    # fp32 noise floor after 99 steps is 2.7e-6 abs on |x|~3.9
+    torch.testing.assert_close(xe, golden.get(tag + "x_end"), atol=5e-5, rtol=1e-4)
+
+
+def test_midpoint_grid_matches_driver():
+    ts, dts = midpoint_time_grid(100)
+    assert ts.shape == (198,) and dts.shape == (99,)
+    assert ts[0].item() == 1.0
+    assert abs(ts[-1].item() - (1.0 / 99) * 0.5) < 1e-6
+
+
+def test_weight_norm_rowwise():
+    torch.manual_seed(0)
+    lin = torch.nn.utils.weight_norm(torch.nn.Linear(7, 5))
+    with torch.no_grad():
+        lin.weight_g.mul_(1.3)
+    st = {"l." + k: v.detach() for k, v in lin.state_dict().items()}
+    x = torch.randn(3, 7)
+    torch.testing.assert_close(wn_linear(st, "l", x), lin(x).detach())
