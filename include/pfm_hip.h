@@ -1,0 +1,151 @@
+/*
+ * pfm_hip.h -- C ABI of libpfm_hip.so: the MI355X (gfx950) flow-matching hot path of particle_fm.
+ *
+ * Plain pointers and sizes only; every pointer except `desc` is a DEVICE pointer owned by the
+ * caller, `stream` is a hipStream_t passed as void*.  Every entry point returns 0 on success or a
+ * hipError_t / PFM_E_* code; pfm_last_error() gives the text.  Nothing here allocates or
+ * synchronises, so calls may be captured into a hipGraph.
+ *
+ * Reference interface each entry point replaces (paths relative to the particle_fm repository):
+ *   pfm_epic_forward            CNF.forward(t, x, cond, mask) with model="epic", t_emb="cosine"
+ *                               particle_fm/models/flow_matching_module.py:191-233
+ *                               -> EPiC_encoder.forward   models/components/epic.py:304-391
+ *                               -> EPiC_layer.forward     models/components/epic.py:85-203
+ *                               -> cosine_encoding        models/components/time_emb.py:49-96
+ *   pfm_epic_sample_midpoint    CNF.decode(z, cond, mask, ode_solver="midpoint", ode_steps)
+ *                               flow_matching_module.py:245-259, 283-287 (torchdyn fixed-step midpoint)
+ *                               incl. the `z * mask` of SetFlowMatchingLitModule.sample (:668-671)
+ *   pfm_epic_fm_loss_forward /  FlowMatchingLoss.forward / ConditionalFlowMatchingLoss.forward
+ *   pfm_epic_fm_loss_backward   models/components/losses.py:38-77, 101-136 and their autograd
+ *   pfm_optim_step              clip_grad_norm_(gradient_clip_val) + AdamW + EMA
+ *                               configs/experiment/jetnet/fm_tops150.yaml:24, configs/model/flow_matching.yaml:3-7,
+ *                               particle_fm/callbacks/ema.py:73-81
+ *
+ * Weights travel as ONE fp32 "blob": the effective (weight-normalised) matrices W = g*v/||v||
+ * re-ordered for the kernels.  The host builds it from the reference's state_dict
+ * (weight_g / weight_v / bias per Linear) -- particle_fm_amd/layout.py -- and fills the offsets below.
+ *
+ * Blob formats (H = hidden = 128, T = time-embedding width, C = cond width, L = latent):
+ *   KMAJOR[K][OUT]   row k holds column k of the nn.Linear weight for all OUT outputs (coalesced GEMV).
+ *   MFMA_A           the H x H block that multiplies the per-particle activations, pre-arranged as the
+ *                    A operand of v_mfma_f32_16x16x4_f32: float4 at ((w*8 + kt)*64 + lane) holds
+ *                    W[16*w + (lane&15)][16*kt + 4*(lane>>4) + r], r = 0..3   (w = output slice 0..7).
+ *   MFMA_AT          the same block transposed (used by the backward dX products):
+ *                    float4 at ((w*8 + kt)*64 + lane) holds W[16*kt + 4*(lane>>4) + r][16*w + (lane&15)].
+ * Column order of the "extras" (per-jet) inputs is [temb(T) ; cond(C) ; g(L)] (g only for fc_local1),
+ * of the global MLP inputs [temb(T) ; cond(C) ; mean(H) ; sum*scale(H) ; g(L)].
+ */
+#ifndef PFM_HIP_H
+#define PFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFM_ABI_VERSION 1
+#define PFM_MAX_LAYERS 24
+#define PFM_HIDDEN 128
+
+#define PFM_E_BADARG 10001   /* descriptor / shape the kernels are not built for */
+#define PFM_E_LDS 10002      /* set does not fit the 160 KiB LDS tile */
+
+/* flags */
+#define PFM_F_SKIP_MASKED_TAIL 1u /* do not compute particle tiles that lie wholly behind the last valid particle */
+
+typedef struct pfm_local_lin {
+    int64_t A;  /* MFMA_A  block, H*H floats */
+    int64_t AT; /* MFMA_AT block, H*H floats (or -1 if the blob carries no backward copies) */
+    int64_t We; /* KMAJOR [Ke][H] extras block */
+    int64_t b;  /* [H] bias */
+} pfm_local_lin;
+
+typedef struct pfm_dense_lin {
+    int64_t W; /* KMAJOR [K][OUT] */
+    int64_t b; /* [OUT] */
+} pfm_dense_lin;
+
+typedef struct pfm_epic_layer {
+    pfm_dense_lin gl1; /* fc_global1: K = T + C + 2H + L, OUT = H */
+    pfm_dense_lin gl2; /* fc_global2: K = T + C + H,      OUT = L */
+    pfm_local_lin lc1; /* fc_local1 : Ke = T + Cl + L */
+    pfm_local_lin lc2; /* fc_local2 : Ke = T + Cl */
+} pfm_epic_layer;
+
+typedef struct pfm_epic_desc {
+    int32_t abi_version; /* PFM_ABI_VERSION */
+    int32_t n_points;    /* N: particles per jet (padded set size) */
+    int32_t features;    /* F: per-particle features in and out */
+    int32_t hidden;      /* H: must equal PFM_HIDDEN in this build */
+    int32_t latent;      /* L <= 16 */
+    int32_t layers;      /* EPiC layers <= PFM_MAX_LAYERS */
+    int32_t t_dim;       /* T = 2*frequencies (t_local_cat and t_global_cat both on), <= 64 */
+    int32_t cond_global; /* Cg <= 16 */
+    int32_t cond_local;  /* Cl in {0, Cg} */
+    uint32_t flags;
+    float sum_scale;     /* epic.py sum_scale (1e-2) */
+    float neg_slope;     /* leaky_relu slope (0.01) */
+    int64_t blob_floats; /* total length of the blob */
+    int64_t freqs;       /* [T] exp(arange(T)) as torch computes it (time_emb.py:90) */
+    pfm_dense_lin l1x;   /* fc_l1 particle block: KMAJOR [F][H]; b unused (-1) */
+    int64_t l1_We;       /* fc_l1 extras KMAJOR [T+Cl][H] */
+    int64_t l1_b;        /* [H] */
+    pfm_local_lin l2;    /* fc_l2 */
+    pfm_dense_lin g1;    /* fc_g1: K = T + C + 2H (mean, sum order), OUT = H */
+    pfm_dense_lin g2;    /* fc_g2: K = T + C + H, OUT = L */
+    pfm_epic_layer layer[PFM_MAX_LAYERS];
+    int64_t l3_W;        /* fc_l3 particle block, row-major [F][H] */
+    int64_t l3_We;       /* fc_l3 extras KMAJOR [T+Cl][F] */
+    int64_t l3_b;        /* [F] */
+} pfm_epic_desc;
+
+int pfm_abi_version(void);
+const char *pfm_last_error(void);
+
+/* bytes of LDS one workgroup (= one jet) needs; > 163840 means PFM_E_LDS */
+int64_t pfm_epic_lds_bytes(const pfm_epic_desc *desc);
+/* floats of activation workspace per jet that pfm_epic_fm_loss_forward writes for the backward */
+int64_t pfm_epic_saved_floats_per_jet(const pfm_epic_desc *desc);
+
+/* v[b,n,:] = EPiC(t[b], x[b], cond[b], mask[b]);  t[B], x[B,N,F], cond[B,Cg]|NULL, mask[B,N]|NULL (float 0/1) */
+int pfm_epic_forward(const pfm_epic_desc *desc, const float *blob, const float *t, const float *x,
+                     const float *cond, const float *mask, float *v, int32_t B, void *stream);
+
+/* Fixed-step explicit midpoint over n_intervals steps, all inside one launch:
+ *   x <- z*mask;  for k: k1 = f(t_eval[2k], x); xm = x + 0.5*dt[k]*k1; x <- x + dt[k]*f(t_eval[2k+1], xm)
+ * t_eval[2*n_intervals], dt[n_intervals] are the fp32 values the reference's driver visits. */
+int pfm_epic_sample_midpoint(const pfm_epic_desc *desc, const float *blob, const float *t_eval,
+                             const float *dt, int32_t n_intervals, const float *z, const float *cond,
+                             const float *mask, float *x_out, int32_t B, void *stream);
+
+/* Flow-matching loss, forward.  kind 0 = "FM-OT" (losses.py:56-62: y=(1-t)x+(sigma+(1-sigma)t)z, u=((1-sigma)z-x)*mask),
+ * kind 1 = "CFM" (losses.py:115-119: y=(1-t)x+t*z+sigma*eps, u=(z-x)*mask; eps required).
+ * Writes loss_parts[B] = sum_n,f (v-u)^2 of each jet, mask_count[B] = sum_n mask, and the activations the
+ * backward needs into saved[B * pfm_epic_saved_floats_per_jet]. */
+int pfm_epic_fm_loss_forward(const pfm_epic_desc *desc, const float *blob, int32_t kind, float sigma,
+                             const float *t, const float *x, const float *z, const float *eps,
+                             const float *cond, const float *mask, float *saved, float *loss_parts,
+                             float *mask_count, int32_t B, void *stream);
+
+/* Backward of the above w.r.t. the blob: grad_blob += d(loss)/d(blob) with loss = sum(loss_parts)/sum(mask_count)
+ * scaled by grad_scale (the incoming dL).  inv_mask_total = 1/sum(mask_count) is passed as a device scalar. */
+int pfm_epic_fm_loss_backward(const pfm_epic_desc *desc, const float *blob, const float *t,
+                              const float *cond, const float *mask, const float *saved,
+                              const float *inv_mask_total, const float *grad_scale, float *grad_blob,
+                              int32_t B, void *stream);
+
+/* Optimiser tail on flat fp32 buffers of n elements:
+ *   gnorm = ||grad * grad_mul||_2 ; c = min(1, max_norm/(gnorm+1e-6)) (clip_grad_norm_) ; g = grad*grad_mul*c
+ *   AdamW (decoupled weight decay, torch.optim.AdamW defaults eps/betas passed in) ; ema = decay*ema + (1-decay)*p
+ * `scratch` needs >= 1024 floats and must be zeroed by pfm_optim_step itself (it does).  step is 1-based. */
+int pfm_optim_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema,
+                   float *scratch, int64_t n, float grad_mul, float max_norm, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float ema_decay, int32_t step,
+                   void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFM_HIP_H */

@@ -25,35 +25,43 @@ import torch
 from .epic_ref import epic_encoder
 
 
-def cosine_encoding(x: torch.Tensor, outp_dim: int = 32, min_value: float = 0.0, max_value: float = 1.0):
+def cosine_encoding(x: torch.Tensor, outp_dim: int = 32, min_value: float = 0.0, max_value: float = 1.0,
+                    freqs: Optional[torch.Tensor] = None):
     """time_emb.py:79-96, exponential frequencies; exact fp32 op order
-    ``((x + min) * exp(arange(D))) * pi / (max + min)``."""
+    ``((x + min) * exp(arange(D))) * pi / (max + min)``.
+
+    ``freqs`` overrides ``torch.arange(D).exp()``: that fp32 ``exp`` is NOT the same on every host
+    (measured: element 15 differs by 1 ulp between an Intel Xeon and an AMD EPYC build of the same
+    torch), and because the arguments reach 1e13 a 1-ulp change of a frequency changes cos() by O(1).
+    Golden vectors carry the table of the machine that recorded them."""
     if x.shape[-1] != 1 or x.dim() == 1:
         x = x.unsqueeze(-1)
-    freqs = torch.arange(outp_dim, device=x.device).exp()
+    if freqs is None:
+        freqs = torch.arange(outp_dim, device=x.device).exp()
     return torch.cos((x + min_value) * freqs * math.pi / (max_value + min_value))
 
 
-def time_embedding_cosine(t: torch.Tensor, x: torch.Tensor, t_dim: int) -> torch.Tensor:
+def time_embedding_cosine(t: torch.Tensor, x: torch.Tensor, t_dim: int, freqs=None) -> torch.Tensor:
     """flow_matching_module.py:223-228.  t is (B,N) in training, 0-dim in sampling."""
     if t.dim() == 0:
         t = t.unsqueeze(0)
-    emb = cosine_encoding(t, t_dim)
+    emb = cosine_encoding(t, t_dim, freqs=freqs)
     return emb.expand(*x.shape[:-1], -1)
 
 
 class EpicVectorField:
     """CNF.forward for model="epic", t_emb="cosine" (flow_matching_module.py:191-204)."""
 
-    def __init__(self, state: Mapping[str, torch.Tensor], prefix: str, hp: Mapping):
+    def __init__(self, state: Mapping[str, torch.Tensor], prefix: str, hp: Mapping, freqs=None):
         self.state = state
         self.prefix = prefix
         self.hp = dict(hp)
+        self.freqs = freqs
 
     def __call__(self, t, x, cond=None, mask=None):
         hp = self.hp
         t_dim = 2 * hp["frequencies"]
-        temb = time_embedding_cosine(t, x, t_dim)
+        temb = time_embedding_cosine(t, x, t_dim, self.freqs)
         if hp.get("add_time_to_input", False):
             x = torch.cat((temb, x), dim=-1)  # :199-200
         return epic_encoder(

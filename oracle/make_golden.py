@@ -133,6 +133,8 @@ def gen_config(ref, name, hp, out_dir, B=4, seed=12345):
     for k, v in state.items():
         out["sd/" + k] = v.numpy()
     out["hp_json"] = np.array(__import__("json").dumps(hp))
+    # the table time_emb.py:90 evaluates on THIS machine (fp32 exp is host-dependent, see oracle/fm_ref.py)
+    out["freqs"] = torch.arange(2 * hp["frequencies"]).exp().numpy()
 
     for mk in ("f32", "int64", "none"):
         mask = make_mask(B, N, mk, gen)

@@ -1,0 +1,61 @@
+"""ctypes binding of libpfm_hip.so (C ABI in include/pfm_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+from .layout import EpicDesc
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libpfm_hip.so")
+
+_lib = None
+
+# every symbol include/pfm_hip.h declares: name -> (restype, argtypes)
+_fp = c_void_p  # device pointers travel as integers (tensor.data_ptr())
+SYMBOLS = {
+    "pfm_abi_version": (c_int, []),
+    "pfm_last_error": (c_char_p, []),
+    "pfm_epic_lds_bytes": (c_int64, [POINTER(EpicDesc)]),
+    "pfm_epic_saved_floats_per_jet": (c_int64, [POINTER(EpicDesc)]),
+    "pfm_epic_forward": (c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
+    "pfm_epic_sample_midpoint": (
+        c_int, [POINTER(EpicDesc), _fp, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
+    "pfm_epic_fm_loss_forward": (
+        c_int, [POINTER(EpicDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
+    "pfm_epic_fm_loss_backward": (
+        c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
+    "pfm_optim_step": (
+        c_int, [_fp, _fp, _fp, _fp, _fp, _fp, c_int64, c_float, c_float, c_float, c_float, c_float, c_float,
+                c_float, c_float, c_int32, c_void_p]),
+}
+
+
+def load():
+    """dlopen the in-tree library (once) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m particle_fm_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pfm_abi_version() != 1:
+        raise RuntimeError("libpfm_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().pfm_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

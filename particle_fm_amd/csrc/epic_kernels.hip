@@ -1,0 +1,166 @@
+// gfx950 kernels + C ABI: EPiC vector-field evaluation and the persistent midpoint sampler.
+// One workgroup (512 threads) per jet; see epic_nfe.h for the on-chip mapping.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "epic_nfe.h"
+
+namespace pfm {
+
+thread_local char g_err[512] = "";
+
+int set_err(int code, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s", what);
+    return code;
+}
+int check_hip(hipError_t e, const char* where) {
+    if (e == hipSuccess) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return (int)e;
+}
+
+int validate(const pfm_epic_desc* d) {
+    if (!d) return set_err(PFM_E_BADARG, "desc is NULL");
+    if (d->abi_version != PFM_ABI_VERSION) return set_err(PFM_E_BADARG, "desc.abi_version mismatch");
+    if (d->hidden != H) return set_err(PFM_E_BADARG, "this build is specialised for hidden = 128");
+    if (d->layers < 0 || d->layers > PFM_MAX_LAYERS) return set_err(PFM_E_BADARG, "layers out of range");
+    if (d->latent < 1 || d->latent > MAXL) return set_err(PFM_E_BADARG, "latent must be in 1..16");
+    if (d->features < 1 || d->features > MAXF) return set_err(PFM_E_BADARG, "features must be in 1..16");
+    if (d->t_dim < 0 || d->t_dim > MAXT) return set_err(PFM_E_BADARG, "t_dim must be in 0..64");
+    if (d->cond_global < 0 || d->cond_global > MAXC) return set_err(PFM_E_BADARG, "cond_global must be in 0..16");
+    if (d->cond_local != 0 && d->cond_local != d->cond_global)
+        return set_err(PFM_E_BADARG, "cond_local must be 0 or cond_global");
+    if (d->n_points < 13) return set_err(PFM_E_BADARG, "n_points must be >= 13");
+    if ((int64_t)make_carve(d->n_points, d->features).total * 4 > 163840)
+        return set_err(PFM_E_LDS, "set does not fit the 160 KiB LDS tile (n_points too large for fp32, hidden 128)");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// v = f(t, x): one evaluation per jet
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 2) void epic_forward_kernel(const pfm_epic_desc d, const float* __restrict__ blob,
+                                                             const float* __restrict__ t, const float* __restrict__ x,
+                                                             const float* __restrict__ cond,
+                                                             const float* __restrict__ mask, float* __restrict__ v) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const JetDims j = dims_of(d);
+    const Carve c = make_carve(j.N, j.F);
+    const int jet = blockIdx.x, tid = threadIdx.x;
+    const int n_rows = epic_jet_setup(d, j, blob, lds, c, cond ? cond + (size_t)jet * j.C : nullptr,
+                                      mask ? mask + (size_t)jet * j.N : nullptr);
+    const float* xj = x + (size_t)jet * j.N * j.F;
+    for (int i = tid; i < j.N * j.F; i += NT) lds[c.yin + i] = xj[i];
+    epic_time_embedding(d, j, blob, lds, c, t[jet]);
+    __syncthreads();
+    const SavedLayout sl = make_saved(j.N, j.F, j.layers);
+    epic_body<false>(d, j, blob, lds, c, n_rows, nullptr, sl);
+    float* vj = v + (size_t)jet * j.N * j.F;
+    const int F = j.F;
+    epic_head(d, j, blob, lds, c, n_rows, [=](int p, int f, float val) { vj[p * F + f] = val; });
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent fixed-step midpoint integrator: all 2*n_intervals evaluations of a jet in one launch,
+// state and activations never leave the CU.  (torchdyn Midpoint.step restated in oracle/fm_ref.py)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
+    const pfm_epic_desc d, const float* __restrict__ blob, const float* __restrict__ t_eval,
+    const float* __restrict__ dt, int n_intervals, const float* __restrict__ z, const float* __restrict__ cond,
+    const float* __restrict__ mask, float* __restrict__ x_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const JetDims j = dims_of(d);
+    const Carve c = make_carve(j.N, j.F);
+    const int jet = blockIdx.x, tid = threadIdx.x;
+    const int n_rows = epic_jet_setup(d, j, blob, lds, c, cond ? cond + (size_t)jet * j.C : nullptr,
+                                      mask ? mask + (size_t)jet * j.N : nullptr);
+    const float* zj = z + (size_t)jet * j.N * j.F;
+    for (int i = tid; i < j.N * j.F; i += NT) {
+        const float z0 = zj[i] * lds[c.maskf + i / j.F];  // flow_matching_module.py:668-671
+        lds[c.xs + i] = z0;
+        lds[c.yin + i] = z0;
+    }
+    const SavedLayout sl = make_saved(j.N, j.F, j.layers);
+    float* xs = lds + c.xs;
+    float* yin = lds + c.yin;
+    const int F = j.F;
+    // 2*n_intervals evaluations; even = k1 at t_k, odd = slope at the midpoint (one inlined body)
+    for (int e = 0; e < 2 * n_intervals; ++e) {
+        const int stage = e & 1;
+        const float h = dt[e >> 1];
+        const float hs = stage ? h : __fmul_rn(0.5f, h);
+        epic_time_embedding(d, j, blob, lds, c, t_eval[e]);
+        __syncthreads();
+        epic_body<false>(d, j, blob, lds, c, n_rows, nullptr, sl);
+        // stage 0: x_mid = x + 0.5*dt*k1 -> next input;  stage 1: x = x + dt*f(t+dt/2, x_mid)
+        epic_head(d, j, blob, lds, c, n_rows, [=](int p, int f, float val) {
+            const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
+            yin[p * F + f] = xn;
+            if (stage) xs[p * F + f] = xn;
+        });
+        __syncthreads();
+    }
+    float* oj = x_out + (size_t)jet * j.N * j.F;
+    for (int i = tid; i < j.N * j.F; i += NT) oj[i] = xs[i];
+}
+
+template <typename K>
+int prepare(K kernel, const pfm_epic_desc* d, int* lds_bytes) {
+    int rc = validate(d);
+    if (rc) return rc;
+    *lds_bytes = make_carve(d->n_points, d->features).total * 4;
+    return check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, *lds_bytes),
+                     "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+}
+
+}  // namespace pfm
+
+using namespace pfm;
+
+extern "C" {
+
+int pfm_abi_version(void) { return PFM_ABI_VERSION; }
+const char* pfm_last_error(void) { return g_err; }
+
+int64_t pfm_epic_lds_bytes(const pfm_epic_desc* d) {
+    if (!d) return -1;
+    return (int64_t)make_carve(d->n_points, d->features).total * 4;
+}
+
+int64_t pfm_epic_saved_floats_per_jet(const pfm_epic_desc* d) {
+    if (!d) return -1;
+    return make_saved(d->n_points, d->features, d->layers).total;
+}
+
+int pfm_epic_forward(const pfm_epic_desc* d, const float* blob, const float* t, const float* x,
+                     const float* cond, const float* mask, float* v, int32_t B, void* stream) {
+    int lds = 0;
+    int rc = prepare(epic_forward_kernel, d, &lds);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    if (!blob || !t || !x || !v) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
+    hipLaunchKernelGGL(epic_forward_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, *d, blob, t, x, cond,
+                       mask, v);
+    return check_hip(hipGetLastError(), "epic_forward_kernel launch");
+}
+
+int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const float* t_eval, const float* dt,
+                             int32_t n_intervals, const float* z, const float* cond, const float* mask,
+                             float* x_out, int32_t B, void* stream) {
+    int lds = 0;
+    int rc = prepare(epic_sample_midpoint_kernel, d, &lds);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    if (!blob || !t_eval || !dt || !z || !x_out) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (n_intervals < 0) return set_err(PFM_E_BADARG, "n_intervals < 0");
+    if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
+    hipLaunchKernelGGL(epic_sample_midpoint_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, *d, blob, t_eval,
+                       dt, n_intervals, z, cond, mask, x_out);
+    return check_hip(hipGetLastError(), "epic_sample_midpoint_kernel launch");
+}
+
+}  // extern "C"

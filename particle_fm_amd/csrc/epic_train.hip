@@ -1,0 +1,109 @@
+// gfx950 kernels + C ABI: flow-matching loss forward (with saved activations) and backward.
+//
+// Reference: particle_fm/models/components/losses.py:38-77 (FlowMatchingLoss.forward, "FM-OT"),
+// :101-136 (ConditionalFlowMatchingLoss.forward, "CFM") and the autograd of the EPiC network
+// (epic.py:85-203, 304-391).  The random draws (t per jet, z, eps) are inputs: the host draws them
+// exactly as the reference does (t on the CPU generator, z on the device generator).
+#include <hip/hip_runtime.h>
+
+#include "epic_nfe.h"
+
+namespace pfm {
+int set_err(int code, const char* what);
+int check_hip(hipError_t e, const char* where);
+int validate(const pfm_epic_desc* d);
+
+// ------------------------------------------------------------------------------------------------
+// forward: y, u from (x, z, t); v = f(t, y); loss_parts[jet] = sum (v-u)^2; activations -> saved
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 2) void epic_fm_loss_forward_kernel(
+    const pfm_epic_desc d, const float* __restrict__ blob, int kind, float sigma, const float* __restrict__ t,
+    const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ eps,
+    const float* __restrict__ cond, const float* __restrict__ mask, float* __restrict__ saved,
+    float* __restrict__ loss_parts, float* __restrict__ mask_count) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const JetDims j = dims_of(d);
+    const Carve c = make_carve(j.N, j.F);
+    const SavedLayout sl = make_saved(j.N, j.F, j.layers);
+    const int jet = blockIdx.x, tid = threadIdx.x;
+    const int n_rows = epic_jet_setup(d, j, blob, lds, c, cond ? cond + (size_t)jet * j.C : nullptr,
+                                      mask ? mask + (size_t)jet * j.N : nullptr);
+    float* sv = saved + (size_t)jet * sl.total;
+    const size_t base = (size_t)jet * j.N * j.F;
+    const float tj = t[jet];
+    const float one_m_sigma = (float)(1.0 - (double)sigma);  // python computes (1 - sigma) in double
+    for (int i = tid; i < j.N * j.F; i += NT) {
+        const float xv = x[base + i], zv = z[base + i], m = lds[c.maskf + i / j.F];
+        float y, u;
+        if (kind == 0) {
+            // losses.py:56  y = (1 - t) * x + (sigma + (1 - sigma) * t) * z ; :61-62 u = ((1 - sigma) * z - x) * mask
+            const float a = __fmul_rn(__fsub_rn(1.0f, tj), xv);
+            const float b = __fmul_rn(__fadd_rn(sigma, __fmul_rn(one_m_sigma, tj)), zv);
+            y = __fadd_rn(a, b);
+            u = __fmul_rn(__fsub_rn(__fmul_rn(one_m_sigma, zv), xv), m);
+        } else {
+            // losses.py:115-119  mu = (1 - t) * x + t * x0 ; y = mu + sigma * eps ; u = (x0 - x) * mask
+            const float mu = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, tj), xv), __fmul_rn(tj, zv));
+            y = __fadd_rn(mu, __fmul_rn(sigma, eps[base + i]));
+            u = __fmul_rn(__fsub_rn(zv, xv), m);
+        }
+        lds[c.yin + i] = y;
+        sv[sl.y + i] = y;
+        sv[sl.u + i] = u;
+    }
+    epic_time_embedding(d, j, blob, lds, c, tj);
+    __syncthreads();
+    if (tid < j.T) sv[sl.temb + tid] = lds[c.temb + tid];
+    epic_body<true>(d, j, blob, lds, c, n_rows, sv, sl);
+    float sq = 0.f;
+    const int F = j.F;
+    float* svv = sv + sl.v;
+    const float* svu = sv + sl.u;
+    epic_head(d, j, blob, lds, c, n_rows, [&](int p, int f, float val) {
+        svv[p * F + f] = val;
+        const float dlt = val - svu[p * F + f];
+        sq += dlt * dlt;
+    });
+    for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
+    __syncthreads();
+    float* red = lds + c.s_part;
+    if ((tid & 63) == 0) red[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int i = 0; i < NW; ++i) s += red[i];
+        loss_parts[jet] = s;
+        mask_count[jet] = lds[c.misc];
+    }
+}
+
+}  // namespace pfm
+
+using namespace pfm;
+
+extern "C" int pfm_epic_fm_loss_forward(const pfm_epic_desc* d, const float* blob, int32_t kind, float sigma,
+                                        const float* t, const float* x, const float* z, const float* eps,
+                                        const float* cond, const float* mask, float* saved, float* loss_parts,
+                                        float* mask_count, int32_t B, void* stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    const int lds = make_carve(d->n_points, d->features).total * 4;
+    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(epic_fm_loss_forward_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                   "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    if (kind != 0 && kind != 1) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT) or 1 (CFM)");
+    if (!blob || !t || !x || !z || !saved || !loss_parts || !mask_count)
+        return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (kind == 1 && !eps) return set_err(PFM_E_BADARG, "CFM needs eps");
+    if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
+    hipLaunchKernelGGL(epic_fm_loss_forward_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, *d, blob, kind,
+                       sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count);
+    return check_hip(hipGetLastError(), "epic_fm_loss_forward_kernel launch");
+}
+
+extern "C" int pfm_epic_fm_loss_backward(const pfm_epic_desc*, const float*, const float*, const float*, const float*,
+                                         const float*, const float*, const float*, float*, int32_t, void*) {
+    return pfm::set_err(PFM_E_BADARG, "pfm_epic_fm_loss_backward: not built yet");
+}

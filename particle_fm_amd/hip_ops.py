@@ -1,0 +1,133 @@
+"""Thin tensor-level wrappers over the C ABI (device pointers + current HIP stream).
+
+PyTorch is plumbing here: it owns device memory and the stream; every number comes out of
+libpfm_hip.so.  All functions require ROCm device tensors and raise otherwise (no CPU path).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .layout import EpicLayout
+
+
+def _stream_ptr(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dev_f32(name: str, t: Optional[torch.Tensor], device, shape=None) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the ROCm device (got {t.device}); the HIP path has no CPU fallback")
+    if t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device}")
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    t = t.contiguous()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _prep_common(layout: EpicLayout, blob, x, cond, mask):
+    cfg = layout.cfg
+    if not x.is_cuda:
+        raise RuntimeError("HIP backend needs tensors on a ROCm device; there is no CPU fallback")
+    dev = x.device
+    B, N, F = x.shape
+    if N != cfg.num_particles or F != cfg.features:
+        raise ValueError(f"x has shape {tuple(x.shape)}, model expects (*, {cfg.num_particles}, {cfg.features})")
+    blob = _dev_f32("blob", blob, dev, (layout.desc.blob_floats,))
+    x = _dev_f32("x", x, dev)
+    if cfg.global_cond_dim > 0 or cfg.local_cond_dim > 0:
+        if cond is None:
+            raise ValueError("global_cond_dim/local_cond_dim > 0 but no cond given")  # epic.py:313-317
+        cond = _dev_f32("cond", cond, dev, (B, cfg.global_cond_dim))
+    else:
+        cond = None
+    if mask is not None:
+        mask = _dev_f32("mask", mask.reshape(B, N), dev, (B, N))
+    return dev, B, blob, x, cond, mask
+
+
+def epic_forward(layout: EpicLayout, blob: torch.Tensor, t: torch.Tensor, x: torch.Tensor,
+                 cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """v = EPiC(t, x, cond, mask).  t: (B,) one time per jet."""
+    lib = _lib.load()
+    dev, B, blob, x, cond, mask = _prep_common(layout, blob, x, cond, mask)
+    t = _dev_f32("t", t, dev, (B,))
+    v = torch.empty_like(x)
+    rc = lib.pfm_epic_forward(ctypes.byref(layout.desc), _ptr(blob), _ptr(t), _ptr(x), _ptr(cond), _ptr(mask),
+                              _ptr(v), B, _stream_ptr(dev))
+    _lib.check(rc, "pfm_epic_forward")
+    return v
+
+
+def midpoint_grid(ode_steps: int):
+    """Times and step sizes the fixed-step driver visits for t_span = linspace(1, 0, ode_steps)
+    (flow_matching_module.py:285; torchdyn driver: t += dt; dt = t_span[k+1] - t), in fp32 on the host."""
+    t_span = torch.linspace(1.0, 0.0, ode_steps)
+    t = t_span[0]
+    dt = t_span[1] - t
+    ts, dts = [], []
+    for k in range(1, ode_steps):
+        ts += [t, t + 0.5 * dt]
+        dts.append(dt)
+        t = t + dt
+        if k < ode_steps - 1:
+            dt = t_span[k + 1] - t
+    return torch.stack(ts), torch.stack(dts)
+
+
+def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor,
+                         cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                         ode_steps: int = 100) -> torch.Tensor:
+    """x(0) from x(1) = z*mask by ode_steps-1 explicit-midpoint intervals, one persistent launch."""
+    lib = _lib.load()
+    dev, B, blob, z, cond, mask = _prep_common(layout, blob, z, cond, mask)
+    if ode_steps < 2:
+        raise ValueError("ode_steps must be >= 2")
+    ts, dts = midpoint_grid(ode_steps)
+    ts, dts = ts.to(dev), dts.to(dev)
+    out = torch.empty_like(z)
+    rc = lib.pfm_epic_sample_midpoint(ctypes.byref(layout.desc), _ptr(blob), _ptr(ts), _ptr(dts), ode_steps - 1,
+                                      _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, _stream_ptr(dev))
+    _lib.check(rc, "pfm_epic_sample_midpoint")
+    return out
+
+
+def epic_fm_loss_forward(layout: EpicLayout, blob: torch.Tensor, x: torch.Tensor, t: torch.Tensor, z: torch.Tensor,
+                         cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                         sigma: float = 1e-4, kind: str = "FM-OT", eps: Optional[torch.Tensor] = None):
+    """Flow-matching loss forward with the draws (t, z[, eps]) given.
+    Returns (loss_parts (B,), mask_count (B,), saved (B, floats_per_jet))."""
+    lib = _lib.load()
+    dev, B, blob, x, cond, mask = _prep_common(layout, blob, x, cond, mask)
+    t = _dev_f32("t", t, dev, (B,))
+    z = _dev_f32("z", z, dev, tuple(x.shape))
+    kinds = {"FM-OT": 0, "CFM": 1}
+    if kind not in kinds:
+        raise NotImplementedError(f"loss kind {kind} has no HIP kernel")
+    if kind == "CFM":
+        if eps is None:
+            raise ValueError("CFM needs the second noise draw eps")
+        if mask is None:
+            raise ValueError("CFM loss needs a mask (losses.py:119)")
+        eps = _dev_f32("eps", eps, dev, tuple(x.shape))
+    per_jet = lib.pfm_epic_saved_floats_per_jet(ctypes.byref(layout.desc))
+    saved = torch.empty(B, per_jet, device=dev, dtype=torch.float32)
+    parts = torch.empty(B, device=dev, dtype=torch.float32)
+    count = torch.empty(B, device=dev, dtype=torch.float32)
+    rc = lib.pfm_epic_fm_loss_forward(ctypes.byref(layout.desc), _ptr(blob), kinds[kind], float(sigma), _ptr(t),
+                                      _ptr(x), _ptr(z), _ptr(eps), _ptr(cond), _ptr(mask), _ptr(saved), _ptr(parts),
+                                      _ptr(count), B, _stream_ptr(dev))
+    _lib.check(rc, "pfm_epic_fm_loss_forward")
+    return parts, count, saved

@@ -1,0 +1,334 @@
+"""Host-side weight layout for libpfm_hip.so (see include/pfm_hip.h for the formats).
+
+The reference stores every Linear of the EPiC network weight-normalised
+(``weight_g (out,1)``, ``weight_v (out,in)``, ``bias (out)``; epic.py:66-81,
+262-300) with the input columns in concatenation order ``[t ; payload ; cond]``
+(SURVEY.md Appendix A).  The kernels want the *effective* matrices
+``W = g * v / ||v||`` split into the block that multiplies per-particle
+activations (MFMA operand order) and the blocks that multiply per-jet vectors
+(K-major, folded into a per-jet bias).  This module computes, once per model
+configuration and in numpy, the descriptor (offsets) and one int64 gather map
+so that ``blob = source[index_map]`` where ``source`` is the concatenation of
+all effective matrices, all biases, the time-embedding frequencies and a zero.
+Building the blob is therefore a handful of differentiable torch ops
+(``pack_blob``), and the gradient of the blob flows back to
+``weight_g / weight_v / bias`` through the same map.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Mapping, Sequence, Tuple
+
+import numpy as np
+import torch
+
+PFM_ABI_VERSION = 1
+PFM_MAX_LAYERS = 24
+PFM_HIDDEN = 128
+PFM_F_SKIP_MASKED_TAIL = 1
+
+
+class LocalLin(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_int64), ("AT", ctypes.c_int64), ("We", ctypes.c_int64), ("b", ctypes.c_int64)]
+
+
+class DenseLin(ctypes.Structure):
+    _fields_ = [("W", ctypes.c_int64), ("b", ctypes.c_int64)]
+
+
+class EpicLayer(ctypes.Structure):
+    _fields_ = [("gl1", DenseLin), ("gl2", DenseLin), ("lc1", LocalLin), ("lc2", LocalLin)]
+
+
+class EpicDesc(ctypes.Structure):
+    """ctypes mirror of ``pfm_epic_desc`` (include/pfm_hip.h)."""
+
+    _fields_ = [
+        ("abi_version", ctypes.c_int32),
+        ("n_points", ctypes.c_int32),
+        ("features", ctypes.c_int32),
+        ("hidden", ctypes.c_int32),
+        ("latent", ctypes.c_int32),
+        ("layers", ctypes.c_int32),
+        ("t_dim", ctypes.c_int32),
+        ("cond_global", ctypes.c_int32),
+        ("cond_local", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("sum_scale", ctypes.c_float),
+        ("neg_slope", ctypes.c_float),
+        ("blob_floats", ctypes.c_int64),
+        ("freqs", ctypes.c_int64),
+        ("l1x", DenseLin),
+        ("l1_We", ctypes.c_int64),
+        ("l1_b", ctypes.c_int64),
+        ("l2", LocalLin),
+        ("g1", DenseLin),
+        ("g2", DenseLin),
+        ("layer", EpicLayer * PFM_MAX_LAYERS),
+        ("l3_W", ctypes.c_int64),
+        ("l3_We", ctypes.c_int64),
+        ("l3_b", ctypes.c_int64),
+    ]
+
+
+def _round4(x: int) -> int:
+    return (x + 3) & ~3
+
+
+def saved_layout(N: int, F: int, layers: int, H: int = PFM_HIDDEN) -> Dict[str, int]:
+    """Mirror of ``make_saved`` (csrc/epic_nfe.h): float offsets inside one jet's saved-activation
+    record written by pfm_epic_fm_loss_forward."""
+    s: Dict[str, int] = {}
+    o = 0
+    for k in ("y", "v", "u"):
+        s[k] = o
+        o += _round4(N * F)
+    s["x1"] = o; o += N * H
+    s["x2"] = o; o += N * H
+    s["l1"] = o; s["xo"] = o + N * H; s["lstride"] = 2 * N * H; o += layers * 2 * N * H
+    s["gstem1"] = o; o += H
+    s["gstem"] = o; o += 16
+    s["glayer"] = o; s["gstride"] = H + 16; o += layers * (H + 16)
+    s["pool"] = o; s["pstride"] = H; o += (layers + 1) * H
+    s["temb"] = o; o += 64
+    s["total"] = o
+    return s
+
+
+@dataclass
+class EpicConfig:
+    """The subset of SetFlowMatchingLitModule kwargs that shapes the EPiC network
+    (flow_matching_module.py:100-148)."""
+
+    num_particles: int
+    features: int = 3
+    hidden_dim: int = 128
+    latent: int = 16
+    layers: int = 8
+    frequencies: int = 6
+    t_local_cat: bool = False
+    t_global_cat: bool = False
+    global_cond_dim: int = 0
+    local_cond_dim: int = 0
+    sum_scale: float = 1e-2
+    neg_slope: float = 0.01  # F.leaky_relu default (epic.py:180)
+
+    @property
+    def t_local(self) -> int:
+        return 2 * self.frequencies if self.t_local_cat else 0
+
+    @property
+    def t_global(self) -> int:
+        return 2 * self.frequencies if self.t_global_cat else 0
+
+    @property
+    def t_dim(self) -> int:
+        return 2 * self.frequencies if (self.t_local_cat or self.t_global_cat) else 0
+
+    def linear_shapes(self) -> List[Tuple[str, int, int]]:
+        """(name, in, out) of every Linear in the reference's registration order."""
+        H, L, F = self.hidden_dim, self.latent, self.features
+        Tl, Tg, Cg, Cl = self.t_local, self.t_global, self.global_cond_dim, self.local_cond_dim
+        out = [
+            ("fc_l1", F + Tl + Cl, H),
+            ("fc_l2", H + Tl + Cl, H),
+            ("fc_g1", 2 * H + Tg + Cg, H),
+            ("fc_g2", H + Tg + Cg, L),
+        ]
+        for k in range(self.layers):
+            out += [
+                (f"nn_list.{k}.fc_global1", 2 * H + L + Tg + Cg, H),
+                (f"nn_list.{k}.fc_global2", H + Tg + Cg, L),
+                (f"nn_list.{k}.fc_local1", H + L + Tl + Cl, H),
+                (f"nn_list.{k}.fc_local2", H + Tl + Cl, H),
+            ]
+        out.append(("fc_l3", H + Tl + Cl, F))
+        return out
+
+    def param_count(self) -> int:
+        return sum(o * i + 2 * o for _, i, o in self.linear_shapes())
+
+
+class EpicLayout:
+    """Descriptor + gather map for one EpicConfig."""
+
+    def __init__(self, cfg: EpicConfig, with_backward: bool = True, flags: int = 0):
+        if cfg.hidden_dim != PFM_HIDDEN:
+            raise NotImplementedError(
+                f"the HIP kernels of this build are specialised for hidden_dim={PFM_HIDDEN}, got {cfg.hidden_dim}"
+            )
+        if cfg.layers > PFM_MAX_LAYERS:
+            raise NotImplementedError(f"layers > {PFM_MAX_LAYERS}")
+        if cfg.local_cond_dim not in (0, cfg.global_cond_dim):
+            raise NotImplementedError("local_cond_dim must be 0 or equal to global_cond_dim (epic.py:122,354)")
+        self.cfg = cfg
+        self.with_backward = with_backward
+        self.linears = cfg.linear_shapes()
+        # ---- source vector: [W_eff of every linear (row-major) | biases | freqs | 0] ----
+        self.w_off: Dict[str, int] = {}
+        self.b_off: Dict[str, int] = {}
+        o = 0
+        for name, i, oo in self.linears:
+            self.w_off[name] = o
+            o += i * oo
+        self.n_weight = o
+        for name, i, oo in self.linears:
+            self.b_off[name] = o
+            o += oo
+        self.freq_off = o
+        o += cfg.t_dim
+        self.zero_off = o
+        o += 1
+        self.n_source = o
+        self._in = {name: i for name, i, _ in self.linears}
+        self._out = {name: oo for name, _, oo in self.linears}
+        self._build()
+        self.desc.flags = flags
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _w(self, name: str, rows: np.ndarray, cols: np.ndarray) -> np.ndarray:
+        """source indices of W[name][rows, cols] (broadcast); cols < 0 -> the zero slot."""
+        idx = self.w_off[name] + rows * self._in[name] + np.maximum(cols, 0)
+        return np.where(cols < 0, self.zero_off, idx)
+
+    def _alloc(self, n: int) -> int:
+        off = self._cursor
+        self._cursor += (n + 3) & ~3
+        return off
+
+    def _put(self, off: int, idx: np.ndarray):
+        flat = np.asarray(idx, dtype=np.int64).reshape(-1)
+        self._segments.append((off, flat))
+
+    def _kmajor(self, name: str, cols: Sequence[int]) -> int:
+        """KMAJOR [K][OUT]: element [k][o] = W[o][cols[k]]"""
+        OUT = self._out[name]
+        cols = np.asarray(cols, dtype=np.int64)
+        off = self._alloc(len(cols) * OUT)
+        self._put(off, self._w(name, np.arange(OUT)[None, :], cols[:, None]))
+        return off
+
+    def _bias(self, name: str) -> int:
+        OUT = self._out[name]
+        off = self._alloc(OUT)
+        self._put(off, self.b_off[name] + np.arange(OUT))
+        return off
+
+    def _mfma_a(self, name: str, c0: int, transposed: bool) -> int:
+        w = np.arange(8)[:, None, None, None]
+        kt = np.arange(8)[None, :, None, None]
+        lane = np.arange(64)[None, None, :, None]
+        r = np.arange(4)[None, None, None, :]
+        i = 16 * w + (lane & 15)
+        k = 16 * kt + 4 * (lane >> 4) + r
+        off = self._alloc(PFM_HIDDEN * PFM_HIDDEN)
+        if not transposed:
+            self._put(off, self._w(name, i + 0 * k, c0 + k + 0 * i))
+        else:
+            self._put(off, self._w(name, k + 0 * i, c0 + i + 0 * k))
+        return off
+
+    def _local(self, name: str, tcols, xc0: int, ccols, gcols=()) -> LocalLin:
+        ll = LocalLin()
+        ll.A = self._mfma_a(name, xc0, False)
+        ll.AT = self._mfma_a(name, xc0, True) if self.with_backward else -1
+        ll.We = self._kmajor(name, list(tcols) + list(ccols) + list(gcols))
+        ll.b = self._bias(name)
+        return ll
+
+    def _build(self):
+        cfg = self.cfg
+        H, L, F = cfg.hidden_dim, cfg.latent, cfg.features
+        T, Tl, Tg, Cg, Cl = cfg.t_dim, cfg.t_local, cfg.t_global, cfg.global_cond_dim, cfg.local_cond_dim
+        self._cursor = 0
+        self._segments: List[Tuple[int, np.ndarray]] = []
+        d = EpicDesc()
+        d.abi_version = PFM_ABI_VERSION
+        d.n_points, d.features, d.hidden, d.latent, d.layers = cfg.num_particles, F, H, L, cfg.layers
+        d.t_dim, d.cond_global, d.cond_local = T, Cg, Cl
+        d.sum_scale, d.neg_slope = cfg.sum_scale, cfg.neg_slope
+
+        def tcols(present: int):  # the T temb columns, or the zero slot if this group gets no time
+            return list(range(T)) if present else [-1] * T
+
+        d.freqs = self._alloc(T)
+        self._put(d.freqs, self.freq_off + np.arange(T))
+        # fc_l1: [t_l ; x(F) ; c_l]
+        d.l1x.W = self._kmajor("fc_l1", range(Tl, Tl + F))
+        d.l1x.b = -1
+        d.l1_We = self._kmajor("fc_l1", tcols(Tl) + list(range(Tl + F, Tl + F + Cl)))
+        d.l1_b = self._bias("fc_l1")
+        # fc_l2: [t_l ; x(H) ; c_l]
+        d.l2 = self._local("fc_l2", tcols(Tl), Tl, range(Tl + H, Tl + H + Cl))
+        # fc_g1: reference order [t_g ; sum ; mean ; c_g] -> kernel order [temb ; cond ; mean ; sum]
+        d.g1.W = self._kmajor(
+            "fc_g1",
+            tcols(Tg) + list(range(Tg + 2 * H, Tg + 2 * H + Cg)) + list(range(Tg + H, Tg + 2 * H)) + list(range(Tg, Tg + H)),
+        )
+        d.g1.b = self._bias("fc_g1")
+        # fc_g2: [t_g ; g(H) ; c_g] -> [temb ; cond ; g1]
+        d.g2.W = self._kmajor("fc_g2", tcols(Tg) + list(range(Tg + H, Tg + H + Cg)) + list(range(Tg, Tg + H)))
+        d.g2.b = self._bias("fc_g2")
+        for k in range(cfg.layers):
+            p = f"nn_list.{k}."
+            ly = d.layer[k]
+            # fc_global1: [t_g ; mean ; sum ; g(L) ; c_g] -> [temb ; cond ; mean ; sum ; g]
+            ly.gl1.W = self._kmajor(
+                p + "fc_global1",
+                tcols(Tg) + list(range(Tg + 2 * H + L, Tg + 2 * H + L + Cg)) + list(range(Tg, Tg + 2 * H + L)),
+            )
+            ly.gl1.b = self._bias(p + "fc_global1")
+            ly.gl2.W = self._kmajor(
+                p + "fc_global2", tcols(Tg) + list(range(Tg + H, Tg + H + Cg)) + list(range(Tg, Tg + H))
+            )
+            ly.gl2.b = self._bias(p + "fc_global2")
+            # fc_local1: [t_l ; x(H) ; g(L) ; c_l] -> A | extras [temb ; cond_l ; g]
+            ly.lc1 = self._local(
+                p + "fc_local1", tcols(Tl), Tl, range(Tl + H + L, Tl + H + L + Cl), range(Tl + H, Tl + H + L)
+            )
+            # fc_local2: [t_l ; l1(H) ; c_l]
+            ly.lc2 = self._local(p + "fc_local2", tcols(Tl), Tl, range(Tl + H, Tl + H + Cl))
+        # fc_l3: [t_l ; x(H) ; c_l]; particle block row-major [F][H]
+        d.l3_W = self._alloc(F * H)
+        self._put(d.l3_W, self._w("fc_l3", np.arange(F)[:, None], Tl + np.arange(H)[None, :]))
+        d.l3_We = self._kmajor("fc_l3", tcols(Tl) + list(range(Tl + H, Tl + H + Cl)))
+        d.l3_b = self._bias("fc_l3")
+        d.blob_floats = self._cursor
+        index_map = np.full(self._cursor, self.zero_off, dtype=np.int64)
+        for off, flat in self._segments:
+            index_map[off : off + flat.size] = flat
+        self.index_map = index_map
+        self.desc = d
+        del self._segments
+
+    # -- torch side ------------------------------------------------------------------------------
+    def default_freqs(self) -> torch.Tensor:
+        """exp(0..T-1) of time_emb.py:90 as correctly rounded fp32 (via float64).  The reference's own
+        fp32 ``torch.arange(T).exp()`` differs between hosts by 1 ulp in some elements, which the
+        1e13-sized cosine arguments amplify to O(1); the product therefore fixes the table."""
+        return torch.arange(self.cfg.t_dim, dtype=torch.float64).exp().to(torch.float32)
+
+    def source_vector(self, state: Mapping[str, torch.Tensor], prefix: str = "", freqs: torch.Tensor = None) -> torch.Tensor:
+        """[W_eff ... | bias ... | freqs | 0] from reference-named tensors (differentiable).
+        W_eff[o,:] = g[o] * v[o,:] / ||v[o,:]||  (old-style nn.utils.weight_norm, dim=0)."""
+        ws, bs = [], []
+        any_t = None
+        for name, _, _ in self.linears:
+            v = state[prefix + name + ".weight_v"]
+            g = state[prefix + name + ".weight_g"]
+            ws.append((v * (g / v.norm(dim=1, keepdim=True))).reshape(-1))
+            bs.append(state[prefix + name + ".bias"].reshape(-1))
+            any_t = v
+        if freqs is None:
+            freqs = self.default_freqs()
+        freqs = freqs.to(device=any_t.device, dtype=any_t.dtype)
+        zero = torch.zeros(1, device=any_t.device, dtype=any_t.dtype)
+        return torch.cat(ws + bs + [freqs, zero])
+
+    def pack_blob(self, state: Mapping[str, torch.Tensor], prefix: str = "", index_map: torch.Tensor = None,
+                  freqs: torch.Tensor = None):
+        src = self.source_vector(state, prefix, freqs)
+        if index_map is None:
+            index_map = torch.from_numpy(self.index_map).to(src.device)
+        return src[index_map]

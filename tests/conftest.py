@@ -26,6 +26,8 @@ class Golden:
         self.hp = json.loads(str(self.z["hp_json"]))
         self.keys = [str(k) for k in self.z["_keys"]]
         self.state = {k: torch.from_numpy(self.z["sd/" + k]) for k in self.keys}
+        # frequency table of the machine that recorded the vectors (see oracle/fm_ref.py::cosine_encoding)
+        self.freqs = torch.from_numpy(self.z["freqs"])
 
     def get(self, key, default=None):
         if key in self.z.files:

@@ -19,7 +19,7 @@ ATOL, RTOL = 1e-5, 1e-4
 
 
 def vf_of(g):
-    return EpicVectorField(g.state, "flows.0.net", g.hp)
+    return EpicVectorField(g.state, "flows.0.net", g.hp, freqs=g.freqs)
 
 
 def test_state_dict_keys_and_shapes(golden):
@@ -39,7 +39,7 @@ def test_state_dict_keys_and_shapes(golden):
 @pytest.mark.parametrize("mk", ["f32", "int64", "none"])
 def test_time_embedding_bitwise(golden, mk):
     t = golden.get(f"nfe_{mk}/t")
-    temb = cosine_encoding(t, 2 * golden.hp["frequencies"])
+    temb = cosine_encoding(t, 2 * golden.hp["frequencies"], freqs=golden.freqs)
     # same torch CPU kernels, same op order -> bit-identical
     assert torch.equal(temb, golden.get(f"nfe_{mk}/temb"))
 
@@ -68,7 +68,7 @@ def test_fm_loss_and_grads(golden, mk):
     x, t, z = golden.get(tag + "x"), golden.get(tag + "t"), golden.get(tag + "z")
     mask, cond = golden.get(tag + "mask"), golden.get(tag + "cond")
     state = {k: v.clone().requires_grad_(v.is_floating_point() and "frequencies" not in k) for k, v in golden.state.items()}
-    vf = EpicVectorField(state, "flows.0.net", golden.hp)
+    vf = EpicVectorField(state, "flows.0.net", golden.hp, freqs=golden.freqs)
     loss, *_ = fm_ot_loss(vf, x, mask, cond, t, z, sigma=1e-4)
     torch.testing.assert_close(loss.detach(), golden.get(tag + "loss"), atol=1e-6, rtol=1e-5)
     loss.backward()
