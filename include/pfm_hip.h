@@ -26,12 +26,17 @@
  * (weight_g / weight_v / bias per Linear) -- particle_fm_amd/layout.py -- and fills the offsets below.
  *
  * Blob formats (H = hidden = 128, T = time-embedding width, C = cond width, L = latent):
- *   KMAJOR[K][OUT]   row k holds column k of the nn.Linear weight for all OUT outputs (coalesced GEMV).
+ *   KMAJOR[K][OUT]   row k holds column k of the nn.Linear weight for all OUT outputs (coalesced GEMV);
+ *                    blocks with OUT = 128 are zero-padded to a multiple of 16 rows.
  *   MFMA_A           the H x H block that multiplies the per-particle activations, pre-arranged as the
  *                    A operand of v_mfma_f32_16x16x4_f32: float4 at ((w*8 + kt)*64 + lane) holds
  *                    W[16*w + (lane&15)][16*kt + 4*(lane>>4) + r], r = 0..3   (w = output slice 0..7).
  *   MFMA_AT          the same block transposed (used by the backward dX products):
  *                    float4 at ((w*8 + kt)*64 + lane) holds W[16*kt + 4*(lane>>4) + r][16*w + (lane&15)].
+ * The blob carries a copy of the descriptor in its tail: element blob[desc.blob_floats] starts
+ * PFM_DESC_FLOATS floats holding the bytes of the pfm_epic_desc itself, so a device buffer of
+ * desc.blob_floats + PFM_DESC_FLOATS floats is what every entry point expects (the kernels read
+ * the offsets from there instead of a 2.5 KB kernel argument).
  * Column order of the "extras" (per-jet) inputs is [temb(T) ; cond(C) ; g(L)] (g only for fc_local1),
  * of the global MLP inputs [temb(T) ; cond(C) ; mean(H) ; sum*scale(H) ; g(L)].
  */
@@ -100,6 +105,8 @@ typedef struct pfm_epic_desc {
     int64_t l3_We;       /* fc_l3 extras KMAJOR [T+Cl][F] */
     int64_t l3_b;        /* [F] */
 } pfm_epic_desc;
+
+#define PFM_DESC_FLOATS ((int64_t)((sizeof(pfm_epic_desc) + 15) / 16 * 4))
 
 int pfm_abi_version(void);
 const char *pfm_last_error(void);

@@ -7,6 +7,21 @@
 
 #include "epic_nfe.h"
 
+#ifdef PFM_DIAG
+namespace pfm {
+__device__ unsigned long long g_pfm_stamps[512];
+__device__ int g_pfm_nstamp;
+}
+extern "C" int pfm_diag_read_stamps(unsigned long long* out, int* n) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(n, HIP_SYMBOL(pfm::g_pfm_nstamp), sizeof(int));
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(pfm::g_pfm_stamps), sizeof(unsigned long long) * 512);
+    int zero = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(pfm::g_pfm_nstamp), &zero, sizeof(int));
+    return 0;
+}
+#endif
+
 namespace pfm {
 
 thread_local char g_err[512] = "";
@@ -41,11 +56,12 @@ int validate(const pfm_epic_desc* d) {
 // ------------------------------------------------------------------------------------------------
 // v = f(t, x): one evaluation per jet
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT, 2) void epic_forward_kernel(const pfm_epic_desc d, const float* __restrict__ blob,
+__global__ __launch_bounds__(NT, 2) void epic_forward_kernel(const float* __restrict__ blob, int64_t desc_off,
                                                              const float* __restrict__ t, const float* __restrict__ x,
                                                              const float* __restrict__ cond,
                                                              const float* __restrict__ mask, float* __restrict__ v) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
     const Carve c = make_carve(j.N, j.F);
     const int jet = blockIdx.x, tid = threadIdx.x;
@@ -56,10 +72,12 @@ __global__ __launch_bounds__(NT, 2) void epic_forward_kernel(const pfm_epic_desc
     epic_time_embedding(d, j, blob, lds, c, t[jet]);
     __syncthreads();
     const SavedLayout sl = make_saved(j.N, j.F, j.layers);
+    PFM_STAMP(0);
     epic_body<false>(d, j, blob, lds, c, n_rows, nullptr, sl);
     float* vj = v + (size_t)jet * j.N * j.F;
     const int F = j.F;
     epic_head(d, j, blob, lds, c, n_rows, [=](int p, int f, float val) { vj[p * F + f] = val; });
+    PFM_STAMP(30);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -67,14 +85,15 @@ __global__ __launch_bounds__(NT, 2) void epic_forward_kernel(const pfm_epic_desc
 // state and activations never leave the CU.  (torchdyn Midpoint.step restated in oracle/fm_ref.py)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
-    const pfm_epic_desc d, const float* __restrict__ blob, const float* __restrict__ t_eval,
+    const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ t_eval,
     const float* __restrict__ dt, int n_intervals, const float* __restrict__ z, const float* __restrict__ cond,
     const float* __restrict__ mask, float* __restrict__ x_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const JetDims j = dims_of(d);
+    const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
+    const JetDims j = dims_of(d0);
     const Carve c = make_carve(j.N, j.F);
     const int jet = blockIdx.x, tid = threadIdx.x;
-    const int n_rows = epic_jet_setup(d, j, blob, lds, c, cond ? cond + (size_t)jet * j.C : nullptr,
+    const int n_rows = epic_jet_setup(d0, j, blob, lds, c, cond ? cond + (size_t)jet * j.C : nullptr,
                                       mask ? mask + (size_t)jet * j.N : nullptr);
     const float* zj = z + (size_t)jet * j.N * j.F;
     for (int i = tid; i < j.N * j.F; i += NT) {
@@ -88,14 +107,19 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
     const int F = j.F;
     // 2*n_intervals evaluations; even = k1 at t_k, odd = slope at the midpoint (one inlined body)
     for (int e = 0; e < 2 * n_intervals; ++e) {
+        // launder the weight pointer once per evaluation: otherwise every (loop-invariant) weight address
+        // and load is hoisted out of this loop and lives in spilled registers for the whole kernel
+        const float* wb = blob;
+        asm volatile("" : "+s"(wb) : : "memory");
+        const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(wb + desc_off);
         const int stage = e & 1;
         const float h = dt[e >> 1];
         const float hs = stage ? h : __fmul_rn(0.5f, h);
-        epic_time_embedding(d, j, blob, lds, c, t_eval[e]);
+        epic_time_embedding(d, j, wb, lds, c, t_eval[e]);
         __syncthreads();
-        epic_body<false>(d, j, blob, lds, c, n_rows, nullptr, sl);
+        epic_body<false>(d, j, wb, lds, c, n_rows, nullptr, sl);
         // stage 0: x_mid = x + 0.5*dt*k1 -> next input;  stage 1: x = x + dt*f(t+dt/2, x_mid)
-        epic_head(d, j, blob, lds, c, n_rows, [=](int p, int f, float val) {
+        epic_head(d, j, wb, lds, c, n_rows, [=](int p, int f, float val) {
             const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
             yin[p * F + f] = xn;
             if (stage) xs[p * F + f] = xn;
@@ -143,7 +167,7 @@ int pfm_epic_forward(const pfm_epic_desc* d, const float* blob, const float* t, 
     if (B <= 0) return 0;
     if (!blob || !t || !x || !v) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
-    hipLaunchKernelGGL(epic_forward_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, *d, blob, t, x, cond,
+    hipLaunchKernelGGL(epic_forward_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, t, x, cond,
                        mask, v);
     return check_hip(hipGetLastError(), "epic_forward_kernel launch");
 }
@@ -158,7 +182,7 @@ int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const fl
     if (!blob || !t_eval || !dt || !z || !x_out) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (n_intervals < 0) return set_err(PFM_E_BADARG, "n_intervals < 0");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
-    hipLaunchKernelGGL(epic_sample_midpoint_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, *d, blob, t_eval,
+    hipLaunchKernelGGL(epic_sample_midpoint_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, t_eval,
                        dt, n_intervals, z, cond, mask, x_out);
     return check_hip(hipGetLastError(), "epic_sample_midpoint_kernel launch");
 }

@@ -17,11 +17,12 @@ int validate(const pfm_epic_desc* d);
 // forward: y, u from (x, z, t); v = f(t, y); loss_parts[jet] = sum (v-u)^2; activations -> saved
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT, 2) void epic_fm_loss_forward_kernel(
-    const pfm_epic_desc d, const float* __restrict__ blob, int kind, float sigma, const float* __restrict__ t,
+    const float* __restrict__ blob, int64_t desc_off, int kind, float sigma, const float* __restrict__ t,
     const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ eps,
     const float* __restrict__ cond, const float* __restrict__ mask, float* __restrict__ saved,
     float* __restrict__ loss_parts, float* __restrict__ mask_count) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
     const Carve c = make_carve(j.N, j.F);
     const SavedLayout sl = make_saved(j.N, j.F, j.layers);
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_forward_kernel(
     }
     epic_time_embedding(d, j, blob, lds, c, tj);
     __syncthreads();
-    if (tid < j.T) sv[sl.temb + tid] = lds[c.temb + tid];
+    if (tid < j.T) sv[sl.temb + tid] = lds[c.vin + tid];
     epic_body<true>(d, j, blob, lds, c, n_rows, sv, sl);
     float sq = 0.f;
     const int F = j.F;
@@ -98,7 +99,7 @@ extern "C" int pfm_epic_fm_loss_forward(const pfm_epic_desc* d, const float* blo
         return set_err(PFM_E_BADARG, "NULL device pointer");
     if (kind == 1 && !eps) return set_err(PFM_E_BADARG, "CFM needs eps");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
-    hipLaunchKernelGGL(epic_fm_loss_forward_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, *d, blob, kind,
+    hipLaunchKernelGGL(epic_fm_loss_forward_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, kind,
                        sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count);
     return check_hip(hipGetLastError(), "epic_fm_loss_forward_kernel launch");
 }

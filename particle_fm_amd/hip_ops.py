@@ -45,7 +45,7 @@ def _prep_common(layout: EpicLayout, blob, x, cond, mask):
     B, N, F = x.shape
     if N != cfg.num_particles or F != cfg.features:
         raise ValueError(f"x has shape {tuple(x.shape)}, model expects (*, {cfg.num_particles}, {cfg.features})")
-    blob = _dev_f32("blob", blob, dev, (layout.desc.blob_floats,))
+    blob = _dev_f32("blob", blob, dev, (layout.blob_total,))
     x = _dev_f32("x", x, dev)
     if cfg.global_cond_dim > 0 or cfg.local_cond_dim > 0:
         if cond is None:

@@ -202,8 +202,12 @@ class EpicLayout:
         self._segments.append((off, flat))
 
     def _kmajor(self, name: str, cols: Sequence[int]) -> int:
-        """KMAJOR [K][OUT]: element [k][o] = W[o][cols[k]]"""
+        """KMAJOR [K][OUT]: element [k][o] = W[o][cols[k]].  Blocks with OUT = 128 are padded with zero
+        rows to a multiple of 16 rows: the GEMV kernels read them in 16-row steps without bounds checks."""
         OUT = self._out[name]
+        cols = list(cols)
+        if OUT == PFM_HIDDEN:
+            cols += [-1] * ((-len(cols)) % 16)
         cols = np.asarray(cols, dtype=np.int64)
         off = self._alloc(len(cols) * OUT)
         self._put(off, self._w(name, np.arange(OUT)[None, :], cols[:, None]))
@@ -326,9 +330,24 @@ class EpicLayout:
         zero = torch.zeros(1, device=any_t.device, dtype=any_t.dtype)
         return torch.cat(ws + bs + [freqs, zero])
 
+    @property
+    def desc_floats(self) -> int:
+        """PFM_DESC_FLOATS of include/pfm_hip.h"""
+        return (ctypes.sizeof(EpicDesc) + 15) // 16 * 4
+
+    @property
+    def blob_total(self) -> int:
+        return int(self.desc.blob_floats) + self.desc_floats
+
+    def desc_tail(self) -> torch.Tensor:
+        """The descriptor's bytes as fp32 words: the tail of every blob (read by the kernels)."""
+        raw = bytes(self.desc)
+        raw += b"\0" * (self.desc_floats * 4 - len(raw))
+        return torch.from_numpy(np.frombuffer(raw, dtype=np.float32).copy())
+
     def pack_blob(self, state: Mapping[str, torch.Tensor], prefix: str = "", index_map: torch.Tensor = None,
                   freqs: torch.Tensor = None):
         src = self.source_vector(state, prefix, freqs)
         if index_map is None:
             index_map = torch.from_numpy(self.index_map).to(src.device)
-        return src[index_map]
+        return torch.cat([src[index_map], self.desc_tail().to(src.device)])

@@ -1,0 +1,46 @@
+"""Diagnostic (not a test, not shipped): build a -DPFM_DIAG copy of the library into gpurun_out/,
+run ONE forward launch and print where workgroup 0 spent its cycles (s_memtime, 100 MHz ticks)."""
+import ctypes, os, subprocess, sys
+sys.path.insert(0, ".")
+import torch
+from tests.conftest import load_golden
+from tests.test_layout_cpu import cfg_of
+from particle_fm_amd.layout import EpicLayout
+from particle_fm_amd import build as B
+
+out = "/tmp/libpfm_diag.so"
+os.makedirs("gpurun_out", exist_ok=True)
+VAR = os.environ.get("PFM_VAR", "0")
+cmd = [B._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPFM_DIAG", "-DPFM_VAR=" + VAR, "-fgpu-rdc",
+       "-Iinclude", "-Iparticle_fm_amd/csrc", *B.sources(), "-o", out]
+subprocess.check_call(cmd)
+lib = ctypes.CDLL(out)
+g = load_golden("jetnet150")
+NP = int(os.environ.get("PFM_N", "150"))
+hp = dict(g.hp); hp["num_particles"] = NP
+lay = EpicLayout(cfg_of(hp), flags=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+blob = lay.pack_blob(g.state, "flows.0.net.").cuda()
+Bn = 256
+gen = torch.Generator().manual_seed(0)
+x = torch.randn(Bn, NP, 3, generator=gen).cuda(); t = torch.rand(Bn, generator=gen).cuda(); v = torch.empty_like(x)
+P = ctypes.c_void_p
+for it in range(3):
+    rc = lib.pfm_epic_forward(ctypes.byref(lay.desc), P(blob.data_ptr()), P(t.data_ptr()), P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, P(0))
+    assert rc == 0, rc
+    buf = (ctypes.c_ulonglong * 512)(); n = ctypes.c_int(0)
+    lib.pfm_diag_read_stamps(buf, ctypes.byref(n))
+names = {0: "start", 1: "body", 2: "stem-bias done", 3: "fc_l1 done", 4: "fc_l2+pool done", 10: "layer: global start", 11: "layer: global done",
+         12: "layer: bias done", 13: "layer: phase1 done", 20: "layers done", 30: "head done"}
+prev = None; tot = {}
+for i in range(n.value):
+    sid, tk = buf[2 * i] >> 48, buf[2 * i + 1]
+    if prev is not None:
+        key = f"{names.get(prev[0], prev[0])} -> {names.get(sid, sid)}"
+        tot.setdefault(key, []).append(tk - prev[1])
+    prev = (sid, tk)
+total = buf[2 * (n.value - 1) + 1] - buf[1]
+rt = (buf[2 * (n.value - 1)] & 0xFFFFFFFFFFFF) - (buf[0] & 0xFFFFFFFFFFFF)
+print(f"s_memrealtime ticks {rt} (100 MHz => {rt/100:.1f} us); s_memtime/s_memrealtime*100MHz = {total/rt*100:.0f} MHz")
+print(f"total ticks {total} (100 MHz => {total/100:.1f} us)")
+for k, v_ in tot.items():
+    print(f"{k:50s} n={len(v_):2d} mean {sum(v_)/len(v_):8.1f} ticks  sum {sum(v_):7d}  ({100*sum(v_)/total:.1f}%)")

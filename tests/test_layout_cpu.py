@@ -30,7 +30,8 @@ def test_param_count_matches_reference():
 def test_blob_interpreter_matches_reference_vectors(golden, mk):
     lay = EpicLayout(cfg_of(golden.hp))
     blob = lay.pack_blob(golden.state, "flows.0.net.", freqs=golden.freqs)
-    assert blob.shape == (lay.desc.blob_floats,)
+    assert blob.shape == (lay.blob_total,)
+    assert bytes(lay.desc) == blob[lay.desc.blob_floats:].numpy().tobytes()[: len(bytes(lay.desc))]
     tag = f"nfe_{mk}/"
     x, t = golden.get(tag + "x"), golden.get(tag + "t")
     v = interp_forward(lay, blob, t, x, golden.get(tag + "cond"), golden.get(tag + "mask"))
