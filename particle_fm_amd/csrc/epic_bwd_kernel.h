@@ -1,0 +1,278 @@
+// The backward kernel body (included by epic_train.hip).  See epic_bwd.h for the on-chip mapping.
+#pragma once
+#include "epic_bwd.h"
+
+namespace pfm {
+
+// vin = [temb ; cond ; mean ; sum*s ; g_in]; temb / cond are already in place
+__device__ __forceinline__ void build_vin(const JetDims& j, float* __restrict__ lds, const BCarve& c,
+                                          const float* __restrict__ pool_raw, const float* __restrict__ g_in,
+                                          bool has_g) {
+    const int tid = threadIdx.x, TC = j.T + j.C;
+    const float nvalid = lds[c.misc];
+    if (tid < H) {
+        const float s = pool_raw[tid];
+        lds[c.vin + TC + tid] = s / nvalid;
+        lds[c.vin + TC + H + tid] = s * j.sscale;
+    } else if (has_g && tid < H + j.L) {
+        lds[c.vin + TC + 2 * H + (tid - H)] = g_in[tid - H];
+    }
+}
+
+// gblob += d(loss)/d(blob), loss = sum(loss_parts) / sum(mask_count), times *grad_scale
+__global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
+    const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ cond,
+    const float* __restrict__ mask, const float* __restrict__ saved, const float* __restrict__ inv_mask_total,
+    const float* __restrict__ grad_scale, float* __restrict__ gblob) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
+    const JetDims j = dims_of(d);
+    const BCarve c = make_bcarve(j.N, j.F);
+    const SavedLayout sl = make_saved(j.N, j.F, j.layers);
+    const int jet = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int pl = lane & 15, q = lane >> 4, oslot = 4 * w + q;
+    const float* sv = saved + (size_t)jet * sl.total;
+    const float slope = j.slope;
+    const int Ke = j.T + j.Cl;
+    float* G = lds + c.G;
+    float* Hb = lds + c.Hb;
+    // ---- setup: mask, n_valid, n_rows, temb, cond, head weights ----
+    {
+        const float* mj = mask ? mask + (size_t)jet * j.N : nullptr;
+        int last = -1;
+        float cnt = 0.f;
+        for (int p = tid; p < j.N; p += NT) {
+            const float m = mj ? mj[p] : 1.0f;
+            lds[c.maskf + p] = m;
+            cnt += m;
+            if (m != 0.f) last = p;
+        }
+        for (int i = tid; i < j.F * H; i += NT) lds[c.w3 + i] = blob[d.l3_W + i];
+        if (tid < j.T) lds[c.vin + tid] = sv[sl.temb + tid];
+        if (tid >= 64 && tid < 64 + j.C) lds[c.vin + j.T + (tid - 64)] = cond[(size_t)jet * j.C + (tid - 64)];
+        if (tid >= 128 && tid < 128 + MAXL) lds[c.dg + (tid - 128)] = 0.f;
+        for (int m = 32; m >= 1; m >>= 1) {
+            cnt += __shfl_xor(cnt, m);
+            last = max(last, __shfl_xor(last, m));
+        }
+        float* red = lds + c.dg1;  // scratch
+        if (lane == 0) { red[w] = cnt; red[8 + w] = (float)last; }
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f, l = -1.f;
+            for (int i = 0; i < NW; ++i) { s += red[i]; l = fmaxf(l, red[8 + i]); }
+            lds[c.misc] = s;
+            lds[c.misc + 1] = l;
+        }
+        __syncthreads();
+    }
+    int n_rows = j.N;
+    if (d.flags & PFM_F_SKIP_MASKED_TAIL) n_rows = max(1, (int)lds[c.misc + 1] + 1);
+    const int ntiles = (n_rows + TILE - 1) / TILE;
+    const float gscale = 2.0f * inv_mask_total[0] * grad_scale[0];  // d/dv of sum (v-u)^2 / M
+    const float* maskf = lds + c.maskf;
+    const float* evec = lds + c.vin;  // [temb ; cond_l] is a prefix of vin (Cl in {0, C})
+
+    // ---- head backward (epic.py:387-391): da3 = dv * mask * phi'(v);  G = W3^T da3 ----
+    for (int i = tid; i < j.N * j.F; i += NT) {
+        const int p = i / j.F;
+        float val = 0.f;
+        if (p < n_rows) {
+            const float v = sv[sl.v + i], u = sv[sl.u + i];
+            val = gscale * (v - u) * maskf[p] * dlrelu(v, slope);
+        }
+        lds[c.da3 + i] = val;
+    }
+    __syncthreads();
+    {
+        const float* hL = sv + (j.layers > 0 ? sl.xo + (j.layers - 1) * sl.lstride : sl.x2);
+        // dW3[f][k] += sum_p da3[p][f] * hL[p][k]: k = tid & 127, particles split 4 ways
+        for (int f0 = 0; f0 < j.F; f0 += 4) {
+            const int k = tid & (H - 1), pt = tid >> 7;
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int p = pt; p < n_rows; p += 4) {
+                const float hv = hL[p * H + k];
+#pragma unroll
+                for (int jf = 0; jf < 4; ++jf)
+                    if (f0 + jf < j.F) a[jf] = fmaf(lds[c.da3 + p * j.F + f0 + jf], hv, a[jf]);
+            }
+#pragma unroll
+            for (int jf = 0; jf < 4; ++jf)
+                if (f0 + jf < j.F) atomicAdd(gblob + d.l3_W + (f0 + jf) * H + k, a[jf]);
+        }
+        // db3j[f] = sum_p da3[p][f]; dWe3[k][f] += e[k] * db3j[f]   (wave f)
+        for (int f = w; f < j.F; f += NW) {
+            float a = 0.f;
+            for (int p = lane; p < n_rows; p += 64) a += lds[c.da3 + p * j.F + f];
+            for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+            if (lane == 0) atomicAdd(gblob + d.l3_b + f, a);
+            for (int k = lane; k < Ke; k += 64) atomicAdd(gblob + d.l3_We + k * j.F + f, evec[k] * a);
+        }
+        // G[p][4slot..] = sum_f W3[f][4slot..] * da3[p][f]
+        const int slot = tid & 31;
+        for (int p = tid >> 5; p < n_rows; p += NT / 32) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int f = 0; f < j.F; ++f)
+                acc += *reinterpret_cast<const f32x4*>(lds + c.w3 + f * H + 4 * slot) * lds[c.da3 + p * j.F + f];
+            *reinterpret_cast<f32x4*>(G + lds_off(p, slot)) = acc;
+        }
+    }
+    __syncthreads();
+
+    f32x4 a1[8], a2[8];
+    // ---- EPiC layers, last to first ----
+    for (int k = j.layers - 1; k >= 0; --k) {
+        const pfm_epic_layer& ly = d.layer[k];
+        const float* xo = sv + sl.xo + k * sl.lstride;                           // h_{k+1}
+        const float* l1 = sv + sl.l1 + k * sl.lstride;                           // inner activation
+        const float* hin = sv + (k > 0 ? sl.xo + (k - 1) * sl.lstride : sl.x2);  // h_k
+        const float* g1 = sv + sl.glayer + k * sl.gstride;
+        const float* gout = g1 + H;
+        const float* gin = (k > 0) ? sv + sl.glayer + (k - 1) * sl.gstride + H : sv + sl.gstem;
+        load_afrag(a2, blob + ly.lc2.AT, w, lane);
+        load_afrag(a1, blob + ly.lc1.AT, w, lane);
+        // (1) da2 = G * phi'(h_{k+1}) in place; db2j = column sums
+        {
+            f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+            for (int tile = 0; tile < ntiles; ++tile) {
+                const int p = tile * TILE + pl;
+                if (p < n_rows) {
+                    const f32x4 hv = *reinterpret_cast<const f32x4*>(xo + p * H + 4 * oslot);
+                    f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, oslot));
+                    gv *= dlrelu4(hv, slope);
+                    *reinterpret_cast<f32x4*>(G + lds_off(p, oslot)) = gv;
+                    ps += gv;
+                }
+            }
+            ps = colsum16(ps);
+            if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj2 + 4 * oslot) = ps;
+        }
+        __syncthreads();
+        // (2) dW_lc2 += da2^T . l1   (epic.py:198-200)
+        gemm_dw(G, l1, n_rows, gblob + ly.lc2.A);
+        // (3) da1 = (W_lc2^T da2) * phi'(l1) -> Hb; db1j = column sums
+        {
+            f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+            gemm_dx(a2, G, n_rows, [&](int p, int os, f32x4 acc) {
+                const f32x4 lv = *reinterpret_cast<const f32x4*>(l1 + p * H + 4 * os);
+                acc *= dlrelu4(lv, slope);
+                *reinterpret_cast<f32x4*>(Hb + lds_off(p, os)) = acc;
+                ps += acc;
+            });
+            ps = colsum16(ps);
+            if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj1 + 4 * oslot) = ps;
+        }
+        // vin of this stage (for the global backward): [temb;cond;mean_k;sum_k;g_k]
+        build_vin(j, lds, c, sv + sl.pool + k * sl.pstride, gin, true);
+        __syncthreads();
+        // (4) per-jet pieces: bias / extras gradients of both local linears; dg_{k+1} += We_lc1[g rows] . db1j
+        {
+            float* e1 = lds + c.vin2;  // [temb ; cond_l ; g_{k+1}] (scratch until global_backward rebuilds vin2)
+            if (tid < Ke) e1[tid] = evec[tid];
+            else if (tid < Ke + j.L) e1[tid] = gout[tid - Ke];
+            if (tid >= 128 && tid < 128 + j.L) {
+                const int jj = tid - 128;
+                const f32x4* row = reinterpret_cast<const f32x4*>(blob + ly.lc1.We + (Ke + jj) * H);
+                float a = 0.f;
+                for (int i = 0; i < H / 4; ++i) {
+                    const f32x4 wv = row[i];
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(lds + c.dbj1 + 4 * i);
+                    a += wv.x * dv.x + wv.y * dv.y + wv.z * dv.z + wv.w * dv.w;
+                }
+                lds[c.dg + jj] += a;
+            }
+            __syncthreads();
+            rank1_atomic(gblob + ly.lc1.We, gblob + ly.lc1.b, Ke + j.L, H, e1, lds + c.dbj1);
+            rank1_atomic(gblob + ly.lc2.We, gblob + ly.lc2.b, Ke, H, e1, lds + c.dbj2);
+            __syncthreads();
+        }
+        // (5) global MLP backward -> dP_k, dg_k
+        global_backward<false>(j, blob, gblob, ly.gl1, ly.gl2, lds, c, g1, gout);
+        // (6) dW_lc1 += da1^T . h_k   (epic.py:194-196)
+        gemm_dw(Hb, hin, n_rows, gblob + ly.lc1.A);
+        // (7) dh_k = W_lc1^T da1 + da2 (residual) + mask * dP_k (pooling) -> G in place
+        {
+            const f32x4 dP4 = *reinterpret_cast<const f32x4*>(lds + c.dP + 4 * oslot);
+            gemm_dx(a1, Hb, n_rows, [&](int p, int os, f32x4 acc) {
+                f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, os));
+                gv += acc + dP4 * maskf[p];
+                *reinterpret_cast<f32x4*>(G + lds_off(p, os)) = gv;
+            });
+        }
+        __syncthreads();
+    }
+
+    // ---- stem ----
+    // global stem backward (fc_g1 / fc_g2): dg_0 -> dP (the pool of x2 as seen by the stem MLP)
+    build_vin(j, lds, c, sv + sl.pool, nullptr, false);
+    __syncthreads();
+    global_backward<true>(j, blob, gblob, d.g1, d.g2, lds, c, sv + sl.gstem1, sv + sl.gstem);
+    load_afrag(a2, blob + d.l2.AT, w, lane);
+    // da2s = (G + mask * dP) * phi'(x2) in place; db2j
+    {
+        const float* x2 = sv + sl.x2;
+        const f32x4 dP4 = *reinterpret_cast<const f32x4*>(lds + c.dP + 4 * oslot);
+        f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int p = tile * TILE + pl;
+            if (p < n_rows) {
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(x2 + p * H + 4 * oslot);
+                f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, oslot));
+                gv = (gv + dP4 * maskf[p]) * dlrelu4(hv, slope);
+                *reinterpret_cast<f32x4*>(G + lds_off(p, oslot)) = gv;
+                ps += gv;
+            }
+        }
+        ps = colsum16(ps);
+        if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj2 + 4 * oslot) = ps;
+    }
+    __syncthreads();
+    // dW_l2 += da2s^T . x1 ; da1s = (W_l2^T da2s + da2s) * phi'(x1) -> Hb   (epic.py:364-366, 360-362)
+    gemm_dw(G, sv + sl.x1, n_rows, gblob + d.l2.A);
+    {
+        const float* x1 = sv + sl.x1;
+        f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+        gemm_dx(a2, G, n_rows, [&](int p, int os, f32x4 acc) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x1 + p * H + 4 * os);
+            acc += *reinterpret_cast<const f32x4*>(G + lds_off(p, os));
+            acc *= dlrelu4(xv, slope);
+            *reinterpret_cast<f32x4*>(Hb + lds_off(p, os)) = acc;
+            ps += acc;
+        });
+        ps = colsum16(ps);
+        if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj1 + 4 * oslot) = ps;
+    }
+    __syncthreads();
+    rank1_atomic(gblob + d.l1_We, gblob + d.l1_b, Ke, H, evec, lds + c.dbj1);
+    rank1_atomic(gblob + d.l2.We, gblob + d.l2.b, Ke, H, evec, lds + c.dbj2);
+    // dWx_l1[f][o] += sum_p y[p][f] * da1s[p][o]   (K-major [F][H])
+    for (int f0 = 0; f0 < j.F; f0 += 4) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int jf = 0; jf < 4; ++jf) acc[jf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int p = tile * TILE + pl;
+            if (p < n_rows) {
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(Hb + lds_off(p, oslot));
+#pragma unroll
+                for (int jf = 0; jf < 4; ++jf)
+                    if (f0 + jf < j.F) acc[jf] += dv * sv[sl.y + p * j.F + f0 + jf];
+            }
+        }
+#pragma unroll
+        for (int jf = 0; jf < 4; ++jf) {
+            if (f0 + jf < j.F) {
+                const f32x4 s4 = colsum16(acc[jf]);
+                if (pl == 0) {
+                    float* g = gblob + d.l1x.W + (f0 + jf) * H + 4 * oslot;
+                    atomicAdd(g, s4.x);
+                    atomicAdd(g + 1, s4.y);
+                    atomicAdd(g + 2, s4.z);
+                    atomicAdd(g + 3, s4.w);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace pfm

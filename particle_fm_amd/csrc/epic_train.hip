@@ -6,7 +6,7 @@
 // exactly as the reference does (t on the CPU generator, z on the device generator).
 #include <hip/hip_runtime.h>
 
-#include "epic_nfe.h"
+#include "epic_bwd_kernel.h"
 
 namespace pfm {
 int set_err(int code, const char* what);
@@ -104,7 +104,23 @@ extern "C" int pfm_epic_fm_loss_forward(const pfm_epic_desc* d, const float* blo
     return check_hip(hipGetLastError(), "epic_fm_loss_forward_kernel launch");
 }
 
-extern "C" int pfm_epic_fm_loss_backward(const pfm_epic_desc*, const float*, const float*, const float*, const float*,
-                                         const float*, const float*, const float*, float*, int32_t, void*) {
-    return pfm::set_err(PFM_E_BADARG, "pfm_epic_fm_loss_backward: not built yet");
+extern "C" int pfm_epic_fm_loss_backward(const pfm_epic_desc* d, const float* blob, const float* t, const float* cond,
+                                         const float* mask, const float* saved, const float* inv_mask_total,
+                                         const float* grad_scale, float* grad_blob, int32_t B, void* stream) {
+    (void)t;  // the time embedding is part of `saved`
+    int rc = validate(d);
+    if (rc) return rc;
+    const int64_t lds = (int64_t)make_bcarve(d->n_points, d->features).total * 4;
+    if (lds > 163840) return set_err(PFM_E_LDS, "set does not fit the 160 KiB LDS tile of the backward kernel");
+    if (d->l2.AT < 0) return set_err(PFM_E_BADARG, "blob was packed without the transposed (backward) weight copies");
+    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(epic_fm_loss_backward_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                   "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    if (!blob || !saved || !inv_mask_total || !grad_scale || !grad_blob) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
+    hipLaunchKernelGGL(epic_fm_loss_backward_kernel, dim3(B), dim3(NT), (int)lds, (hipStream_t)stream, blob,
+                       d->blob_floats, cond, mask, saved, inv_mask_total, grad_scale, grad_blob);
+    return check_hip(hipGetLastError(), "epic_fm_loss_backward_kernel launch");
 }

@@ -1,0 +1,88 @@
+"""Flow-matching loss of the EPiC vector field as a torch.autograd.Function over the HIP kernels.
+
+Mirrors FlowMatchingLoss / ConditionalFlowMatchingLoss of the reference
+(particle_fm/models/components/losses.py:38-77, 101-136) with the random draws passed in.  The
+differentiable input is the layout's *source vector* (effective weights | biases | freqs | 0,
+layout.EpicLayout.source_vector); the gather into the kernel blob happens inside forward(), and
+backward() scatters the kernel's gradient blob back with one index_add_.  Autograd then continues
+through the weight-norm reparametrisation to weight_g / weight_v / bias, so DDP / Lightning hooks
+see ordinary .grad accumulation on the real parameters.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib, hip_ops
+from .layout import EpicLayout
+
+
+class _Maps:
+    """device copies of the (constant) gather maps, cached on the layout object per device"""
+
+    @classmethod
+    def get(cls, layout: EpicLayout, device):
+        cache = layout.__dict__.setdefault("_device_maps", {})
+        key = str(device)
+        ent = cache.get(key)
+        if ent is None:
+            ent = (
+                torch.from_numpy(layout.index_map).to(device),
+                torch.from_numpy(layout.grad_index_map).to(device),
+                layout.desc_tail().to(device),
+            )
+            cache[key] = ent
+        return ent
+
+
+def pack_blob_from_source(layout: EpicLayout, src: torch.Tensor) -> torch.Tensor:
+    imap, _, tail = _Maps.get(layout, src.device)
+    return torch.cat([src.detach()[imap], tail])
+
+
+class EpicFMLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, layout, x, t, z, eps, cond, mask, sigma, kind):
+        blob = pack_blob_from_source(layout, src)
+        parts, count, saved = hip_ops.epic_fm_loss_forward(layout, blob, x, t, z, cond, mask, sigma, kind, eps)
+        total = count.sum()
+        loss = parts.sum() / total  # losses.py:75-76 / :130
+        ctx.layout = layout
+        ctx.mask = mask
+        ctx.cond = cond
+        ctx.save_for_backward(blob, saved, total)
+        ctx.n_source = src.numel()
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        layout = ctx.layout
+        blob, saved, total = ctx.saved_tensors
+        dev = blob.device
+        lib = _lib.load()
+        B = saved.shape[0]
+        gblob = torch.zeros_like(blob)
+        inv_total = (1.0 / total).reshape(1).contiguous()
+        gscale = grad_loss.to(torch.float32).reshape(1).contiguous()
+        cond, mask = ctx.cond, ctx.mask
+        if layout.cfg.global_cond_dim == 0:
+            cond = None
+        cond = None if cond is None else cond.to(torch.float32).contiguous()
+        maskf = None if mask is None else mask.reshape(B, -1).to(torch.float32).contiguous()
+        P = hip_ops._ptr
+        rc = lib.pfm_epic_fm_loss_backward(ctypes.byref(layout.desc), P(blob), P(None), P(cond), P(maskf), P(saved),
+                                           P(inv_total), P(gscale), P(gblob), B, hip_ops._stream_ptr(dev))
+        _lib.check(rc, "pfm_epic_fm_loss_backward")
+        _, gmap, _ = _Maps.get(layout, dev)
+        d_src = torch.zeros(ctx.n_source, device=dev, dtype=torch.float32)
+        d_src.index_add_(0, gmap, gblob[: layout.desc.blob_floats])
+        return d_src, None, None, None, None, None, None, None, None, None
+
+
+def epic_fm_loss(layout: EpicLayout, src: torch.Tensor, x: torch.Tensor, t: torch.Tensor, z: torch.Tensor,
+                 cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None, sigma: float = 1e-4,
+                 kind: str = "FM-OT", eps: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """loss = sum((v - u)^2) / sum(mask) with v = EPiC(t, y); differentiable w.r.t. ``src``."""
+    return EpicFMLossFn.apply(src, layout, x, t, z, eps, cond, mask, float(sigma), kind)

@@ -237,6 +237,7 @@ class EpicLayout:
         ll = LocalLin()
         ll.A = self._mfma_a(name, xc0, False)
         ll.AT = self._mfma_a(name, xc0, True) if self.with_backward else -1
+        self._local_blocks.append((name, xc0, int(ll.A), int(ll.AT)))
         ll.We = self._kmajor(name, list(tcols) + list(ccols) + list(gcols))
         ll.b = self._bias(name)
         return ll
@@ -244,9 +245,11 @@ class EpicLayout:
     def _build(self):
         cfg = self.cfg
         H, L, F = cfg.hidden_dim, cfg.latent, cfg.features
+        self._H = H
         T, Tl, Tg, Cg, Cl = cfg.t_dim, cfg.t_local, cfg.t_global, cfg.global_cond_dim, cfg.local_cond_dim
         self._cursor = 0
         self._segments: List[Tuple[int, np.ndarray]] = []
+        self._local_blocks: List[Tuple[str, int, int, int]] = []
         d = EpicDesc()
         d.abi_version = PFM_ABI_VERSION
         d.n_points, d.features, d.hidden, d.latent, d.layers = cfg.num_particles, F, H, L, cfg.layers
@@ -305,6 +308,21 @@ class EpicLayout:
         self.index_map = index_map
         self.desc = d
         del self._segments
+        # Gradient blob (written by pfm_epic_fm_loss_backward): same offsets, but every 128x128 block is in
+        # the accumulator-native GRAD_D order  float ((w*8 + it)*4 + r)*64 + lane  <->
+        # dW[16w + 4(lane>>4) + r][c0 + 8(lane&15) + it]; the transposed copies receive nothing.
+        gmap = index_map.copy()
+        w = np.arange(8)[:, None, None, None]
+        it = np.arange(8)[None, :, None, None]
+        r = np.arange(4)[None, None, :, None]
+        lane = np.arange(64)[None, None, None, :]
+        rows = 16 * w + 4 * (lane >> 4) + r + 0 * it
+        cols = 8 * (lane & 15) + it + 0 * (w + r)
+        for name, c0, offA, offAT in self._local_blocks:
+            gmap[offA : offA + H * H] = self._w(name, rows, c0 + cols).reshape(-1)
+            if offAT >= 0:
+                gmap[offAT : offAT + H * H] = self.zero_off
+        self.grad_index_map = gmap
 
     # -- torch side ------------------------------------------------------------------------------
     def default_freqs(self) -> torch.Tensor:
