@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: jets/sec of EPiC-FM JetNet N=150 -- one training step plus one 100-step midpoint
+ODE sample per "step", on N MI355X of one node (BASELINE.json `metric`; workload = BASELINE `configs[2]`,
+the configuration the metric is quoted on: N=150, F=3, H=128, L=10, 6 EPiC layers, batch 256 per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One step, per GPU (SURVEY.md §8d definitions):
+  (T) train step on 256 jets: FM-OT loss forward + hand-written backward (HIP), flat gradient all-reduce (RCCL,
+      N>1), clip_grad_norm 0.5 + AdamW(1e-3, wd 5e-5) + EMA 0.999 (HIP);
+  (S) decode of 256 jets: z -> x by 99 explicit-midpoint intervals = 198 network evaluations (HIP, one launch).
+Inputs are synthetic (x ~ N(0,1)*mask, multiplicities U{30..150}, seeds 12345 / 9999), resident in HBM before
+the timed region.  value = (jets per step over all ranks) / (max-over-ranks step time); weak scaling.
+The JSON line also carries `roofline` (dominant kernel = the persistent sampler, against the fp32 MFMA peak) and,
+at N=1, `cpu_baseline` (the eager-PyTorch oracle on the host cores, on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NFE_FLOP_PER_JET = 84.22e6     # algorithmic fwd FLOP / jet, dense over the padded N=150
+FP32_MFMA_PEAK = 157.3e12      # MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
+HP = dict(model="epic", features=3, hidden_dim=128, num_particles=150, frequencies=16, layers=6, latent=10,
+          activation="leaky_relu", wrapper_func="weight_norm", t_local_cat=True, t_global_cat=True,
+          add_time_to_input=False, t_emb="cosine", loss_type="FM-OT", sigma=1e-4, global_cond_dim=0,
+          local_cond_dim=0, dropout=0.0, sum_scale=1e-2)  # configs/model/flow_matching.yaml + fm_tops150.yaml
+
+
+def synthetic_batch(B, N, F, seed):
+    gen = torch.Generator().manual_seed(seed)
+    n = torch.randint(30, N + 1, (B,), generator=gen)
+    mask = (torch.arange(N)[None] < n[:, None]).to(torch.int64).unsqueeze(-1)  # JetNet masks are int64
+    x = torch.randn(B, N, F, generator=gen) * mask
+    return x, mask, torch.zeros(B)
+
+
+def cpu_baseline(state, freqs, ode_steps, jets=64):
+    """The oracle (eager PyTorch restatement of the reference graph) on the host cores, bounded sample."""
+    from oracle.fm_ref import EpicVectorField, fm_ot_loss, sample_midpoint
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ohp = dict(HP)
+    st = {k: v.clone().requires_grad_(v.is_floating_point() and "frequencies" not in k) for k, v in state.items()}
+    params = [v for v in st.values() if v.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=5e-5)
+    x, mask, _ = synthetic_batch(jets, HP["num_particles"], HP["features"], 4242)
+    maskf = mask.float()
+    vf = EpicVectorField(st, "flows.0.net", ohp, freqs=freqs)
+
+    def train_step():
+        t = torch.rand(jets)
+        z = torch.randn_like(x)
+        opt.zero_grad()
+        loss, *_ = fm_ot_loss(vf, x, maskf, None, t, z, sigma=1e-4)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 0.5)
+        opt.step()
+
+    train_step()  # warm-up
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        train_step()
+    t_train = (time.perf_counter() - t0) / reps
+    z = torch.randn(jets, HP["num_particles"], HP["features"])
+    with torch.no_grad():
+        vf_ng = EpicVectorField({k: v.detach() for k, v in st.items()}, "flows.0.net", ohp, freqs=freqs)
+        t0 = time.perf_counter()
+        sample_midpoint(vf_ng, z, None, maskf, ode_steps=ode_steps)
+        t_sample = time.perf_counter() - t0
+    return {
+        "value": jets / (t_train + t_sample), "unit": "jets/s", "cores": cores, "kind": "port",
+        "sample": f"{jets} jets: {reps} train steps (fwd+bwd+clip+AdamW) averaged + 1 full {ode_steps}-step midpoint "
+                  f"sample ({2 * (ode_steps - 1)} NFE); eager-PyTorch oracle, fp32, torch threads = {cores}",
+        "train_jets_per_s": jets / t_train, "sample_jets_per_s": jets / t_sample,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="jets per GPU (BASELINE config: 256)")
+    ap.add_argument("--ode-steps", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs MI355X GPUs (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    from particle_fm_amd.engine import FusedFMTrainer
+    from particle_fm_amd.models import SetFlowMatchingLitModule
+
+    torch.manual_seed(12345)  # fm_tops150.yaml:19 -- identical replicas on every rank
+    model = SetFlowMatchingLitModule(optimizer=None, **HP).to(dev)
+    state_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if k.startswith("flows.")}
+    trainer = FusedFMTrainer(model, lr=1e-3, weight_decay=5e-5, max_grad_norm=0.5, ema_decay=0.999)
+    B, N, F = args.batch, HP["num_particles"], HP["features"]
+    x, mask, cond = synthetic_batch(B, N, F, 12345 + rank)
+    x, mask, cond = x.to(dev), mask.to(dev), cond.to(dev)
+    gz = torch.Generator().manual_seed(9999 + rank)  # jetnet_eval.py:146
+    z = (torch.randn(B, N, F, generator=gz) * mask.cpu()).to(dev)  # sample(): CPU draw, masked (:659-671)
+    n_nfe = 2 * (args.ode_steps - 1)
+
+    def step():
+        trainer.step((x, mask, cond))
+        with torch.no_grad():
+            return model(z, cond=None, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        e0, e1, e2 = ev[i]
+        e0.record()
+        trainer.step((x, mask, cond))
+        e1.record()
+        with torch.no_grad():
+            out = model(z, cond=None, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps)
+        e2.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    train_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / args.steps
+    sample_ms = sum(b.elapsed_time(c) for _, b, c in ev) / args.steps
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        jets_per_step = B * world
+        value = jets_per_step * args.steps / elapsed
+        achieved = B * n_nfe * NFE_FLOP_PER_JET / (sample_ms * 1e-3)
+        res = {
+            "metric": "jets/sec (train step + 100-step ODE sample), EPiC-FM JetNet N=150",
+            "value": value, "unit": "jets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "EPiC-FM JetNet150 (N=150, F=3, H=128, L=10, 6 EPiC layers, 561330 params): per step "
+                            "1 train step (FM-OT fwd+bwd, grad all-reduce, clip 0.5, AdamW, EMA) + 1 midpoint "
+                            f"ODE sample (ode_steps={args.ode_steps}, {n_nfe} NFE) on the same number of jets",
+                "jets_per_gpu": B, "global_batch": jets_per_step, "parallelism": f"dp{world}",
+                "multiplicity": "U{30..150} per jet (masked tail tiles are skipped; results identical)",
+            },
+            "train_ms": train_ms, "sample_ms": sample_ms,
+            "train_jets_per_s": B * world / (train_ms * 1e-3), "sample_jets_per_s": B * world / (sample_ms * 1e-3),
+            "roofline": {
+                "bound": "mfma", "kernel": "epic_sample_midpoint_kernel", "achieved": achieved / 1e12,
+                "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK, "traffic": None,
+                "note": f"algorithmic {NFE_FLOP_PER_JET/1e6:.2f} MFLOP/jet/NFE x {n_nfe} NFE x {B} jets per launch "
+                        "(dense over padded N, concatenated t/cond columns counted) / HIP-event launch time",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            freqs = model.flows[0].net.layout().default_freqs()
+            res["cpu_baseline"] = cpu_baseline(state_cpu, freqs, args.ode_steps)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,8 @@
  *   MFMA_A           the H x H block that multiplies the per-particle activations, pre-arranged as the
  *                    A operand of v_mfma_f32_16x16x4_f32: float4 at ((w*8 + kt)*64 + lane) holds
  *                    W[16*w + (lane&15)][16*kt + 4*(lane>>4) + r], r = 0..3   (w = output slice 0..7).
+ *   GRAD_D           (gradient blob only) a 128x128 block in accumulator order: float ((w*8 + it)*4 + r)*64 + lane
+ *                    holds dW[16*w + 4*(lane>>4) + r][8*(lane&15) + it].
  *   MFMA_AT          the same block transposed (used by the backward dX products):
  *                    float4 at ((w*8 + kt)*64 + lane) holds W[16*kt + 4*(lane>>4) + r][16*w + (lane&15)].
  * The blob carries a copy of the descriptor in its tail: element blob[desc.blob_floats] starts
@@ -120,6 +122,11 @@ int64_t pfm_epic_saved_floats_per_jet(const pfm_epic_desc *desc);
 int pfm_epic_forward(const pfm_epic_desc *desc, const float *blob, const float *t, const float *x,
                      const float *cond, const float *mask, float *v, int32_t B, void *stream);
 
+/* Same with the time embedding supplied by the caller: temb[B,T] (the reference's EPiC_encoder.forward takes the
+ * embedded time, epic.py:304-310; only the row of the first particle is used there too, :342). */
+int pfm_epic_forward_temb(const pfm_epic_desc *desc, const float *blob, const float *temb, const float *x,
+                          const float *cond, const float *mask, float *v, int32_t B, void *stream);
+
 /* Fixed-step explicit midpoint over n_intervals steps, all inside one launch:
  *   x <- z*mask;  for k: k1 = f(t_eval[2k], x); xm = x + 0.5*dt[k]*k1; x <- x + dt[k]*f(t_eval[2k+1], xm)
  * t_eval[2*n_intervals], dt[n_intervals] are the fp32 values the reference's driver visits. */
@@ -137,7 +144,9 @@ int pfm_epic_fm_loss_forward(const pfm_epic_desc *desc, const float *blob, int32
                              float *mask_count, int32_t B, void *stream);
 
 /* Backward of the above w.r.t. the blob: grad_blob += d(loss)/d(blob) with loss = sum(loss_parts)/sum(mask_count)
- * scaled by grad_scale (the incoming dL).  inv_mask_total = 1/sum(mask_count) is passed as a device scalar. */
+ * scaled by grad_scale (the incoming dL).  inv_mask_total = 1/sum(mask_count) is passed as a device scalar.
+ * grad_blob has the offsets (and length) of the blob and must be zeroed by the caller; MFMA_A blocks come back in
+ * GRAD_D order, MFMA_AT blocks are not written, everything else is in blob order.  `t` is unused (may be NULL). */
 int pfm_epic_fm_loss_backward(const pfm_epic_desc *desc, const float *blob, const float *t,
                               const float *cond, const float *mask, const float *saved,
                               const float *inv_mask_total, const float *grad_scale, float *grad_blob,

@@ -57,7 +57,8 @@ int validate(const pfm_epic_desc* d) {
 // v = f(t, x): one evaluation per jet
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT, 2) void epic_forward_kernel(const float* __restrict__ blob, int64_t desc_off,
-                                                             const float* __restrict__ t, const float* __restrict__ x,
+                                                             const float* __restrict__ t, const float* __restrict__ temb,
+                                                             const float* __restrict__ x,
                                                              const float* __restrict__ cond,
                                                              const float* __restrict__ mask, float* __restrict__ v) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -69,7 +70,11 @@ __global__ __launch_bounds__(NT, 2) void epic_forward_kernel(const float* __rest
                                       mask ? mask + (size_t)jet * j.N : nullptr);
     const float* xj = x + (size_t)jet * j.N * j.F;
     for (int i = tid; i < j.N * j.F; i += NT) lds[c.yin + i] = xj[i];
-    epic_time_embedding(d, j, blob, lds, c, t[jet]);
+    if (temb) {  // caller-supplied embedding (EPiC_encoder.forward(t_in, ...) signature, epic.py:304-310)
+        if (tid < j.T) lds[c.vin + tid] = temb[(size_t)jet * j.T + tid];
+    } else {
+        epic_time_embedding(d, j, blob, lds, c, t[jet]);
+    }
     __syncthreads();
     const SavedLayout sl = make_saved(j.N, j.F, j.layers);
     PFM_STAMP(0);
@@ -167,8 +172,21 @@ int pfm_epic_forward(const pfm_epic_desc* d, const float* blob, const float* t, 
     if (B <= 0) return 0;
     if (!blob || !t || !x || !v) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
-    hipLaunchKernelGGL(epic_forward_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, t, x, cond,
-                       mask, v);
+    hipLaunchKernelGGL(epic_forward_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, t,
+                       (const float*)nullptr, x, cond, mask, v);
+    return check_hip(hipGetLastError(), "epic_forward_kernel launch");
+}
+
+int pfm_epic_forward_temb(const pfm_epic_desc* d, const float* blob, const float* temb, const float* x,
+                          const float* cond, const float* mask, float* v, int32_t B, void* stream) {
+    int lds = 0;
+    int rc = prepare(epic_forward_kernel, d, &lds);
+    if (rc) return rc;
+    if (B <= 0) return 0;
+    if (!blob || !temb || !x || !v) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
+    hipLaunchKernelGGL(epic_forward_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats,
+                       (const float*)nullptr, temb, x, cond, mask, v);
     return check_hip(hipGetLastError(), "epic_forward_kernel launch");
 }
 

@@ -71,6 +71,19 @@ def epic_forward(layout: EpicLayout, blob: torch.Tensor, t: torch.Tensor, x: tor
     return v
 
 
+def epic_forward_temb(layout: EpicLayout, blob: torch.Tensor, temb: torch.Tensor, x: torch.Tensor,
+                      cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """v = EPiC(temb, x, cond, mask) with the time embedding given: temb (B,T)."""
+    lib = _lib.load()
+    dev, B, blob, x, cond, mask = _prep_common(layout, blob, x, cond, mask)
+    temb = _dev_f32("temb", temb, dev, (B, layout.cfg.t_dim))
+    v = torch.empty_like(x)
+    rc = lib.pfm_epic_forward_temb(ctypes.byref(layout.desc), _ptr(blob), _ptr(temb), _ptr(x), _ptr(cond),
+                                   _ptr(mask), _ptr(v), B, _stream_ptr(dev))
+    _lib.check(rc, "pfm_epic_forward_temb")
+    return v
+
+
 def midpoint_grid(ode_steps: int):
     """Times and step sizes the fixed-step driver visits for t_span = linspace(1, 0, ode_steps)
     (flow_matching_module.py:285; torchdyn driver: t += dt; dt = t_span[k+1] - t), in fp32 on the host."""
@@ -89,8 +102,10 @@ def midpoint_grid(ode_steps: int):
 
 def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor,
                          cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-                         ode_steps: int = 100) -> torch.Tensor:
-    """x(0) from x(1) = z*mask by ode_steps-1 explicit-midpoint intervals, one persistent launch."""
+                         ode_steps: int = 100, premask: bool = True) -> torch.Tensor:
+    """x(0) from x(1) = z*mask by ode_steps-1 explicit-midpoint intervals, one persistent launch.
+    The kernel multiplies the start state by the mask (SetFlowMatchingLitModule.sample does, :668-671);
+    ``premask`` is informational: masking twice is idempotent for a 0/1 mask."""
     lib = _lib.load()
     dev, B, blob, z, cond, mask = _prep_common(layout, blob, z, cond, mask)
     if ode_steps < 2:

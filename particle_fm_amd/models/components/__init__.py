@@ -1,0 +1,3 @@
+from .epic import EPiC_encoder, EPiC_layer  # noqa: F401
+from .losses import ConditionalFlowMatchingLoss, FlowMatchingLoss  # noqa: F401
+from .time_emb import CosineEncoding, cosine_encoding  # noqa: F401

@@ -1,0 +1,161 @@
+"""EPiC network: parameter containers with the reference's state_dict layout + the HIP evaluation.
+
+Mirrors particle_fm/models/components/epic.py:17-391 (EPiC_layer, EPiC_encoder): same constructor
+arguments, same parameter names (``fc_*.bias / weight_g / weight_v`` -- old-style
+``nn.utils.weight_norm`` on every Linear), same initialisation stream, same ``forward(t_in, x_local,
+global_cond_in, mask)`` signature and error behaviour.  The arithmetic runs in libpfm_hip.so; there is
+no PyTorch fallback: calling ``forward`` with CPU tensors raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import fm_loss, hip_ops
+from ...layout import EpicConfig, EpicLayout
+
+
+class WNLinear(nn.Module):
+    """Parameters of ``nn.utils.weight_norm(nn.Linear(in, out))``: bias, weight_g (out,1), weight_v (out,in),
+    registered in that order and initialised exactly like the reference (nn.Linear's default init, then
+    g = ||v|| row-wise)."""
+
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__()
+        lin = nn.Linear(in_features, out_features)  # consumes the RNG like the reference does
+        w = lin.weight.detach()
+        self.in_features, self.out_features = in_features, out_features
+        self.bias = nn.Parameter(lin.bias.detach().clone())
+        self.weight_g = nn.Parameter(w.norm(dim=1, keepdim=True).clone())
+        self.weight_v = nn.Parameter(w.clone())
+
+    def extra_repr(self) -> str:
+        return f"in_features={self.in_features}, out_features={self.out_features}, weight_norm=True"
+
+
+def _check_supported(activation: str, wrapper_func: str, dropout: float):
+    if activation != "leaky_relu":
+        raise NotImplementedError(f"activation={activation!r}: the HIP kernels implement leaky_relu (slope 0.01)")
+    if wrapper_func != "weight_norm":
+        raise NotImplementedError(f"wrapper_func={wrapper_func!r}: the HIP path expects weight_norm Linears")
+    if dropout != 0.0:
+        raise NotImplementedError("dropout > 0 is not implemented in the HIP kernels (all shipped configs use 0.0)")
+
+
+class EPiC_layer(nn.Module):
+    """Parameter container of one EPiC layer (epic.py:37-83); evaluated inside EPiC_encoder's kernel."""
+
+    def __init__(self, local_in_dim: int = 3, hid_dim: int = 256, latent_dim: int = 16, global_cond_dim: int = 0,
+                 local_cond_dim: int = 0, t_local_cat: bool = False, t_global_cat: bool = False,
+                 activation: str = "leaky_relu", wrapper_func: str = "weight_norm", frequencies: int = 6,
+                 num_points: int = 30, dropout: float = 0.0, sum_scale: float = 1e-2):
+        super().__init__()
+        _check_supported(activation, wrapper_func, dropout)
+        tl = 2 * frequencies if t_local_cat else 0
+        tg = 2 * frequencies if t_global_cat else 0
+        self.fc_global1 = WNLinear(2 * hid_dim + latent_dim + tg + global_cond_dim, hid_dim)
+        self.fc_global2 = WNLinear(hid_dim + tg + global_cond_dim, latent_dim)
+        self.fc_local1 = WNLinear(local_in_dim + latent_dim + tl + local_cond_dim, hid_dim)
+        self.fc_local2 = WNLinear(hid_dim + tl + local_cond_dim, hid_dim)
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("EPiC_layer is evaluated by the fused EPiC_encoder kernel, not on its own")
+
+
+class EPiC_encoder(nn.Module):
+    """epic.py:206-391.  ``forward(t_in, x_local, global_cond_in, mask)`` with t_in the (B,N,T) time
+    embedding, like the reference; ``vector_field(t, x, cond, mask)`` takes the time itself (B,) and lets
+    the kernel embed it (what CNF.forward uses)."""
+
+    def __init__(self, latent: int = 16, input_dim: int = 3, hid_d: int = 256, feats: int = 128,
+                 equiv_layers: int = 8, global_cond_dim: int = 0, local_cond_dim: int = 0,
+                 activation: str = "leaky_relu", wrapper_func: str = "weight_norm", frequencies: int = 6,
+                 num_points: int = 30, t_local_cat: bool = False, t_global_cat: bool = False,
+                 dropout: float = 0.0, sum_scale: float = 1e-2):
+        super().__init__()
+        _check_supported(activation, wrapper_func, dropout)
+        if input_dim != feats:
+            raise NotImplementedError(
+                "add_time_to_input=True (input_dim != feats) is not implemented for the EPiC HIP kernels; "
+                "configs/model/flow_matching.yaml uses add_time_to_input: False")
+        self.latent, self.input_dim, self.hid_d, self.feats = latent, input_dim, hid_d, feats
+        self.equiv_layers, self.global_cond_dim, self.local_cond_dim = equiv_layers, global_cond_dim, local_cond_dim
+        self.num_points, self.sum_scale = num_points, sum_scale
+        self.t_local_cat, self.t_global_cat, self.frequencies = t_local_cat, t_global_cat, frequencies
+        tl = 2 * frequencies if t_local_cat else 0
+        tg = 2 * frequencies if t_global_cat else 0
+        self.fc_l1 = WNLinear(input_dim + tl + local_cond_dim, hid_d)
+        self.fc_l2 = WNLinear(hid_d + tl + local_cond_dim, hid_d)
+        self.fc_g1 = WNLinear(2 * hid_d + tg + global_cond_dim, hid_d)
+        self.fc_g2 = WNLinear(hid_d + tg + global_cond_dim, latent)
+        self.nn_list = nn.ModuleList()
+        for _ in range(equiv_layers):
+            self.nn_list.append(EPiC_layer(hid_d, hid_d, latent, activation=activation, wrapper_func=wrapper_func,
+                                           num_points=num_points, t_global_cat=t_global_cat, t_local_cat=t_local_cat,
+                                           global_cond_dim=global_cond_dim, local_cond_dim=local_cond_dim,
+                                           frequencies=frequencies, dropout=dropout, sum_scale=sum_scale))
+        self.fc_l3 = WNLinear(hid_d + tl + local_cond_dim, feats)
+        self._layouts: Dict[int, EpicLayout] = {}
+        self.skip_masked_tail = True
+
+    # -- layout / weights ------------------------------------------------------------------------
+    def config(self, num_points: Optional[int] = None) -> EpicConfig:
+        return EpicConfig(num_particles=num_points or self.num_points, features=self.feats, hidden_dim=self.hid_d,
+                          latent=self.latent, layers=self.equiv_layers, frequencies=self.frequencies,
+                          t_local_cat=self.t_local_cat, t_global_cat=self.t_global_cat,
+                          global_cond_dim=self.global_cond_dim, local_cond_dim=self.local_cond_dim,
+                          sum_scale=self.sum_scale)
+
+    def layout(self, num_points: Optional[int] = None) -> EpicLayout:
+        n = num_points or self.num_points
+        lay = self._layouts.get(n)
+        if lay is None:
+            lay = EpicLayout(self.config(n), flags=1 if self.skip_masked_tail else 0)
+            self._layouts[n] = lay
+        return lay
+
+    def source_vector(self, layout: Optional[EpicLayout] = None) -> torch.Tensor:
+        """effective weights | biases | freqs | 0 from the live parameters (differentiable)."""
+        lay = layout or self.layout()
+        return lay.source_vector(dict(self.named_parameters()), "")
+
+    def packed_weights(self, num_points: Optional[int] = None) -> torch.Tensor:
+        """The kernel blob for the current parameter values (no autograd).  Cheap (a few small launches);
+        rebuilt on every call, so it can never go stale after an optimizer step, load_state_dict or an EMA
+        swap (callbacks/ema.py:145-157), and nothing extra ever appears in state_dict()."""
+        lay = self.layout(num_points)
+        with torch.no_grad():
+            return fm_loss.pack_blob_from_source(lay, self.source_vector(lay))
+
+    # -- evaluation --------------------------------------------------------------------------------
+    def _check_inputs(self, t, x_local, global_cond_in):
+        if x_local is None:
+            raise ValueError("x_local is None")
+        if global_cond_in is None and (self.global_cond_dim > 0 or self.local_cond_dim > 0):
+            raise ValueError(f"global_cond_dim is {self.global_cond_dim} and local_cond_dim is"
+                             f" {self.local_cond_dim} but no global_cond is given")
+        if t is None and (self.t_local_cat or self.t_global_cat):
+            raise ValueError(f"t_local_cat is {self.t_local_cat} and t_global_cat is {self.t_global_cat} but no"
+                             " t is given")
+
+    def forward(self, t_in: torch.Tensor = None, x_local: torch.Tensor = None,
+                global_cond_in: torch.Tensor = None, mask: torch.Tensor = None) -> torch.Tensor:
+        self._check_inputs(t_in, x_local, global_cond_in)
+        lay = self.layout(x_local.shape[1])
+        B = x_local.shape[0]
+        if t_in is None:
+            temb = torch.zeros(B, lay.cfg.t_dim, device=x_local.device)
+        else:
+            temb = t_in[:, 0, :] if t_in.dim() == 3 else t_in  # epic.py:342: one embedding per jet
+        return hip_ops.epic_forward_temb(lay, self.packed_weights(x_local.shape[1]), temb, x_local, global_cond_in, mask)
+
+    def vector_field(self, t: torch.Tensor, x_local: torch.Tensor, global_cond_in: torch.Tensor = None,
+                     mask: torch.Tensor = None, blob: torch.Tensor = None) -> torch.Tensor:
+        """t: (B,) one time per jet; the cosine embedding is evaluated in the kernel."""
+        self._check_inputs(t, x_local, global_cond_in)
+        lay = self.layout(x_local.shape[1])
+        if blob is None:
+            blob = self.packed_weights(x_local.shape[1])
+        return hip_ops.epic_forward(lay, blob, t, x_local, global_cond_in, mask)

@@ -1,0 +1,284 @@
+"""Drop-in for particle_fm/models/flow_matching_module.py (ode_wrapper, CNF, SetFlowMatchingLitModule).
+
+Same class names, constructor keywords, ``state_dict`` keys and call signatures as the reference
+(flow_matching_module.py:34-71, 74-347, 350-677), so that the Hydra target
+``particle_fm.models.flow_matching_module.SetFlowMatchingLitModule`` can be pointed here and the rest of the
+pipeline (Lightning Trainer, EMA callback, evaluation callbacks -> ``sample``) keeps working.  The compute
+of the hot path -- EPiC vector field, FM/CFM loss forward+backward, fixed-step midpoint sampling -- runs in
+libpfm_hip.so.  What the native path does not cover raises NotImplementedError at construction or call time
+(never a silent PyTorch fallback): models other than "epic", losses other than FM-OT / CFM, solvers other
+than "midpoint", t_emb other than "cosine", use_normaliser=True.
+"""
+from __future__ import annotations
+
+from typing import Any, Mapping, Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import fm_loss as _fm_loss
+from .. import hip_ops
+from .components.epic import EPiC_encoder
+from .components.losses import ConditionalFlowMatchingLoss, FlowMatchingLoss
+from .components.time_emb import CosineEncoding
+
+try:  # Lightning is optional: present in the reference's environment, absent in the build container
+    import pytorch_lightning as pl
+
+    _LitBase = pl.LightningModule
+    HAVE_LIGHTNING = True
+except Exception:  # pragma: no cover - depends on the environment
+    try:
+        import lightning.pytorch as pl
+
+        _LitBase = pl.LightningModule
+        HAVE_LIGHTNING = True
+    except Exception:
+        pl = None
+        HAVE_LIGHTNING = False
+
+        class _AttrDict(dict):
+            __getattr__ = dict.__getitem__
+            __setattr__ = dict.__setitem__
+
+        class _LitBase(nn.Module):
+            """The few LightningModule services the hot path touches, for environments without Lightning."""
+
+            def __init__(self):
+                super().__init__()
+                self._hparams = _AttrDict()
+                self.trainer = None
+                self.current_epoch = 0
+                self.logged = {}
+
+            def save_hyperparameters(self, *args, logger: bool = True, **kwargs):
+                import inspect
+
+                frame = inspect.currentframe().f_back
+                init_args = {k: v for k, v in frame.f_locals.items() if k not in ("self", "__class__")}
+                self._hparams.update(init_args)
+
+            @property
+            def hparams(self):
+                return self._hparams
+
+            @property
+            def device(self):
+                try:
+                    return next(self.parameters()).device
+                except StopIteration:
+                    return torch.device("cpu")
+
+            def log(self, name, value, **kwargs):
+                self.logged[name] = value.detach() if isinstance(value, torch.Tensor) else value
+
+
+class ode_wrapper(torch.nn.Module):
+    """flow_matching_module.py:34-71 -- binds mask / cond so that a solver can call ``f(t, x)``."""
+
+    def __init__(self, model: nn.Module, mask: torch.Tensor = None, cond: torch.Tensor = None,
+                 loss_type: str = "FM-OT", diff_config: Mapping = {"max_sr": 0.999, "min_sr": 0.02}):
+        super().__init__()
+        if loss_type == "diffusion":
+            raise NotImplementedError("loss_type='diffusion' has no HIP path")
+        self.model = model
+        self.mask = mask
+        self.cond = cond
+        self.loss_type = loss_type
+
+    def forward(self, t, x, *args, **kwargs):
+        return self.model(t, x, mask=self.mask, cond=self.cond)
+
+
+class CNF(nn.Module):
+    """Continuous normalizing flow around the EPiC vector field (flow_matching_module.py:74-347)."""
+
+    def __init__(self, model: str = "epic", features: int = 3, num_particles: int = 150, frequencies: int = 6,
+                 hidden_dim: int = 128, layers: int = 8, global_cond_dim: int = 0, local_cond_dim: int = 0,
+                 dropout: float = 0.0, latent: int = 16, activation: str = "leaky_relu",
+                 wrapper_func: str = "weight_norm", t_local_cat: bool = False, t_global_cat: bool = False,
+                 add_time_to_input: bool = True, t_emb: str = "sincos", loss_type: str = "FM-OT",
+                 diff_config: Mapping[str, Any] = {"max_sr": 0.999, "min_sr": 0.02}, sum_scale: float = 1e-2,
+                 net_config: Mapping[str, Any] = {}):
+        super().__init__()
+        self.latent = latent
+        self.add_time_to_input = add_time_to_input
+        input_dim = features + 2 * frequencies if add_time_to_input else features
+        if model == "epic":
+            self.net = EPiC_encoder(input_dim=input_dim, feats=features, latent=latent, equiv_layers=layers,
+                                    hid_d=hidden_dim, activation=activation, wrapper_func=wrapper_func,
+                                    frequencies=frequencies, num_points=num_particles, t_local_cat=t_local_cat,
+                                    t_global_cat=t_global_cat, global_cond_dim=global_cond_dim,
+                                    local_cond_dim=local_cond_dim, dropout=dropout, sum_scale=sum_scale)
+        elif model in ("droid_fulltransformer", "droid_fullcrossattention", "mdma"):
+            raise NotImplementedError(f"Model {model} has no HIP path in this build (only 'epic').")
+        else:
+            raise NotImplementedError(f"Model {model} not implemented.")  # flow_matching_module.py:170
+        self.register_buffer("frequencies", 2 ** torch.arange(frequencies) * torch.pi)  # :172
+        self.activation = activation
+        self.t_emb = t_emb
+        self.loss_type = loss_type
+        self.diff_config = diff_config
+        if t_emb == "cosine":
+            self.embed = CosineEncoding(outp_dim=2 * frequencies, min_value=0.0, max_value=1.0,
+                                        frequency_scaling="exponential")
+        elif t_emb in ("sincos", "gaussian"):
+            raise NotImplementedError(f"t_emb={t_emb} has no HIP path in this build (only 'cosine').")
+        else:
+            raise NotImplementedError(f"t_emb={t_emb} not implemented")  # :231
+
+    # -- helpers -----------------------------------------------------------------------------------
+    @staticmethod
+    def _per_jet_time(t: Tensor, x: Tensor) -> Tensor:
+        """(B,N) in training (one value repeated over the particles, losses.py:47), 0-dim in sampling
+        (:225-226), or already (B,)."""
+        if t.dim() == 0:
+            return t.reshape(1).expand(x.shape[0]).to(x.device, torch.float32)
+        if t.dim() == 2:
+            t = t[:, 0]
+        if t.dim() != 1 or t.shape[0] != x.shape[0]:
+            raise ValueError(f"t has shape {tuple(t.shape)}; expected (), (B,) or (B,N) with B={x.shape[0]}")
+        return t.to(x.device, torch.float32)
+
+    def time_embedding(self, t: Tensor, x: Tensor, t_emb: str = "cosine") -> Tensor:
+        if t_emb != "cosine":
+            raise NotImplementedError(f"t_emb={t_emb} not implemented")
+        if t.dim() == 0:
+            t = t.unsqueeze(0)
+        return self.embed(t).expand(*x.shape[:-1], -1)
+
+    # -- reference surface -------------------------------------------------------------------------
+    def forward(self, t: Tensor, x: Tensor, cond: Tensor = None, mask: Tensor = None) -> Tensor:
+        """v = f(t, x) (flow_matching_module.py:191-204); one HIP launch, embedding included."""
+        return self.net.vector_field(self._per_jet_time(t, x), x, cond, mask)
+
+    def fm_loss(self, x, t, z, mask=None, cond=None, sigma: float = 1e-4, kind: str = "FM-OT", eps=None) -> Tensor:
+        """Differentiable FM / CFM loss with the draws given (the body of losses.py:38-77 / 101-136)."""
+        lay = self.net.layout(x.shape[1])
+        src = self.net.source_vector(lay)
+        return _fm_loss.epic_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps)
+
+    def decode(self, z: Tensor, cond: Tensor, mask: Tensor = None, ode_solver: str = "dopri5_zuko",
+               ode_steps: int = 100) -> Tensor:
+        """flow_matching_module.py:245-328.  "midpoint" = t_span linspace(1, 0, ode_steps), ode_steps-1
+        explicit-midpoint intervals (torchdyn), here one persistent kernel launch."""
+        if ode_solver == "midpoint":
+            # mask is applied to the ODE right-hand side by the network itself; z arrives already masked
+            return hip_ops.epic_sample_midpoint(self.net.layout(z.shape[1]), self.net.packed_weights(z.shape[1]), z,
+                                                cond, mask, ode_steps=ode_steps, premask=False)
+        if ode_solver in ("em", "ddim"):
+            raise SyntaxError(f"Solver {ode_solver} is only implemented for diffusion loss")  # :326
+        if ode_solver in ("dopri5_zuko", "rk4", "dopri5", "euler", "tsit5", "ieuler", "alf"):
+            raise NotImplementedError(f"Solver {ode_solver} has no HIP path in this build (only 'midpoint').")
+        raise NotImplementedError(f"Solver {ode_solver} not implemented")  # :328
+
+    def encode(self, *args, **kwargs):
+        raise NotImplementedError("CNF.encode (rk4 forward in time) has no HIP path in this build")
+
+    def log_prob(self, *args, **kwargs):
+        raise NotImplementedError("CNF.log_prob (zuko adaptive solver) has no HIP path in this build")
+
+
+class SetFlowMatchingLitModule(_LitBase):
+    """flow_matching_module.py:350-677.  Keyword-for-keyword the reference's constructor; every argument is
+    captured by ``save_hyperparameters`` so checkpoints re-materialise with ``load_from_checkpoint``."""
+
+    def __init__(self, optimizer: torch.optim.Optimizer = None, scheduler: torch.optim.lr_scheduler = None,
+                 model: str = "epic", features: int = 3, hidden_dim: int = 128, num_particles: int = 150,
+                 frequencies: int = 6, layers: int = 8, n_transforms: int = 1, activation: str = "leaky_relu",
+                 wrapper_func: str = "weight_norm", use_normaliser: bool = False, normaliser_config: Mapping = {},
+                 net_config: Mapping = {}, latent: int = 16, t_local_cat: bool = False, t_global_cat: bool = False,
+                 add_time_to_input: bool = True, global_cond_dim: int = 0, local_cond_dim: int = 0,
+                 dropout: float = 0.0, sum_scale: float = 1e-2, loss_type: str = "FM-OT", sigma: float = 1e-4,
+                 t_emb: str = "sincos", diff_config: Mapping = {"max_sr": 1, "min_sr": 1e-8},
+                 criterion: str = "mse"):
+        super().__init__()
+        self.save_hyperparameters(logger=False)
+        flows = nn.ModuleList()
+        for _ in range(n_transforms):
+            flows.append(CNF(model=model, net_config=net_config, features=features, hidden_dim=hidden_dim,
+                             num_particles=num_particles, frequencies=frequencies, layers=layers,
+                             global_cond_dim=global_cond_dim, local_cond_dim=local_cond_dim, latent=latent,
+                             dropout=dropout, activation=activation, wrapper_func=wrapper_func,
+                             t_global_cat=t_global_cat, t_local_cat=t_local_cat,
+                             add_time_to_input=add_time_to_input, t_emb=t_emb, loss_type=loss_type,
+                             diff_config=diff_config, sum_scale=sum_scale))
+        self.flows = flows
+        self.conditioned = global_cond_dim > 0
+        if loss_type == "FM-OT":
+            self.loss = FlowMatchingLoss(flows=self.flows, sigma=sigma, criterion=criterion)
+        elif loss_type == "CFM":
+            self.loss = ConditionalFlowMatchingLoss(flows=self.flows, sigma=sigma, criterion=criterion)
+        elif loss_type in ("CFM-OT", "diffusion", "droid"):
+            raise NotImplementedError(f"Loss type {loss_type} has no HIP path in this build (FM-OT and CFM do).")
+        else:
+            raise NotImplementedError(f"Loss type {loss_type} not implemented.")  # :465
+        if use_normaliser:
+            raise NotImplementedError("use_normaliser=True (IterativeNormLayer) is not implemented; every model yaml "
+                                      "of the reference sets use_normaliser: False")
+
+    # -- sampling ------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, cond: torch.Tensor = None, mask: torch.Tensor = None, reverse: bool = False,
+                ode_solver: str = "dopri5_zuko", ode_steps: int = 100):
+        if reverse:
+            for f in reversed(self.flows):
+                x = f.decode(x, cond, mask, ode_solver=ode_solver, ode_steps=ode_steps)
+        else:
+            for f in self.flows:
+                x = f.encode(x, mask, ode_solver=ode_solver, ode_steps=ode_steps)
+        return x
+
+    @torch.no_grad()
+    def sample(self, n_samples: int, cond: torch.Tensor = None, mask: torch.Tensor = None,
+               ode_solver: str = "midpoint", ode_steps: int = 100, num_points: int = None):
+        """flow_matching_module.py:637-677: z ~ N(0,1) drawn on the CPU generator, masked, integrated 1 -> 0."""
+        z = torch.randn(n_samples, num_points if num_points else self.hparams.num_particles,
+                        self.hparams.features).to(self.device)
+        if cond is not None:
+            cond = cond.to(self.device)
+        if mask is not None:
+            mask = mask[:n_samples].to(self.device)
+            z = z * mask
+        return self.forward(z, cond=cond, mask=mask, reverse=True, ode_solver=ode_solver, ode_steps=ode_steps)
+
+    # -- training ------------------------------------------------------------------------------------
+    def _variable_jet_sizes(self) -> bool:
+        dm = getattr(getattr(self, "trainer", None), "datamodule", None)
+        if dm is None:
+            return True
+        return bool(dm.hparams.variable_jet_sizes)
+
+    def training_step(self, batch, batch_idx):
+        x, mask, cond = batch
+        if not self._variable_jet_sizes():  # flow_matching_module.py:519-520
+            mask = None
+        loss = self.loss(x, mask=mask, cond=cond)
+        self.log("train/loss", loss, on_step=False, on_epoch=True, prog_bar=True, sync_dist=True)
+        return {"loss": loss}
+
+    def on_validation_epoch_start(self) -> None:
+        torch.manual_seed(9999)  # :555-557
+
+    def on_validation_epoch_end(self) -> None:
+        torch.manual_seed(torch.seed())
+
+    def validation_step(self, batch: Any, batch_idx: int):
+        x, mask, cond = batch
+        if not self._variable_jet_sizes():
+            mask = None
+        with torch.no_grad():
+            loss = self.loss(x, mask, cond=cond)
+        self.log("val/loss", loss, on_step=False, on_epoch=True, prog_bar=True, sync_dist=True)
+        return {"loss": loss}
+
+    def test_step(self, batch: Any, batch_idx: int):
+        pass
+
+    def configure_optimizers(self):
+        optimizer = self.hparams.optimizer(params=self.parameters())
+        if self.hparams.scheduler is not None:
+            scheduler = self.hparams.scheduler(optimizer=optimizer)
+            return {"optimizer": optimizer,
+                    "lr_scheduler": {"scheduler": scheduler, "monitor": "val/loss", "interval": "epoch", "frequency": 1}}
+        return {"optimizer": optimizer}

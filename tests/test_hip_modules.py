@@ -1,0 +1,129 @@
+"""The drop-in modules on the GPU: reference call signatures in, reference numbers out."""
+import copy
+
+import pytest
+import torch
+
+from oracle.fm_ref import EpicVectorField, fm_ot_loss, sample_midpoint
+from tests.test_modules_cpu import _yaml_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+def _module(golden, **over):
+    from particle_fm_amd.models import SetFlowMatchingLitModule
+    kw = _yaml_kwargs(golden.hp)
+    kw.update(over)
+    m = SetFlowMatchingLitModule(optimizer=None, sigma=1e-4, **kw)
+    full = dict(golden.state)
+    full.update({"loss." + k: v for k, v in golden.state.items()})
+    m.load_state_dict(full)
+    return m.cuda()
+
+
+def _oracle(golden, m):
+    # the product fixes the frequency table (layout.default_freqs); give the oracle the same one
+    return EpicVectorField(golden.state, "flows.0.net", golden.hp, freqs=m.flows[0].net.layout().default_freqs())
+
+
+def _dev(t):
+    return None if t is None else t.cuda()
+
+
+@pytest.mark.parametrize("mk", ["f32", "int64", "none"])
+def test_cnf_forward_reference_signature(golden, mk):
+    m = _module(golden)
+    tag = f"nfe_{mk}/"
+    x, t, mask, cond = golden.get(tag + "x"), golden.get(tag + "t"), golden.get(tag + "mask"), golden.get(tag + "cond")
+    N = x.shape[1]
+    vf = _oracle(golden, m)
+    with torch.no_grad():
+        ref = vf(t[:, None].expand(-1, N), x, cond=cond, mask=mask)
+        ref_s = vf(t[0], x, cond=cond, mask=mask)
+    tt = t.unsqueeze(-1).repeat_interleave(N, dim=1)  # losses.py:47 shape (B,N)
+    v = m.flows[0](_dev(tt), _dev(x), cond=_dev(cond), mask=_dev(mask)).cpu()
+    torch.testing.assert_close(v, ref, atol=1e-5, rtol=1e-4)
+    vs = m.flows[0](_dev(t[0]), _dev(x), cond=_dev(cond), mask=_dev(mask)).cpu()  # 0-dim t (sampling)
+    torch.testing.assert_close(vs, ref_s, atol=1e-5, rtol=1e-4)
+    # EPiC_encoder.forward takes the embedded time (B,N,T) like the reference
+    temb = m.flows[0].time_embedding(_dev(tt), _dev(x), "cosine")
+    v2 = m.flows[0].net(temb, _dev(x), _dev(cond), _dev(mask)).cpu()
+    torch.testing.assert_close(v2, ref, atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("steps", [5, 100])
+def test_sample_matches_oracle(golden, steps):
+    m = _module(golden)
+    tag = "midpoint_100/"
+    mask, cond = golden.get(tag + "mask"), golden.get(tag + "cond")
+    B, N, F = mask.shape[0], golden.hp["num_particles"], golden.hp["features"]
+    torch.manual_seed(9999)  # callbacks/jetnet_eval.py:146
+    out = m.sample(B, cond=cond, mask=mask, ode_solver="midpoint", ode_steps=steps).cpu()
+    torch.manual_seed(9999)
+    z = torch.randn(B, N, F)  # flow_matching_module.py:659-663 draws on the CPU generator
+    ref = sample_midpoint(_oracle(golden, m), z, cond, mask, ode_steps=steps)
+    torch.testing.assert_close(out, ref, atol=5e-5, rtol=1e-4)
+    assert torch.all(out[mask.squeeze(-1) == 0] == 0)
+
+
+def test_training_step_replays_reference_draws(golden):
+    m = _module(golden)
+    tag = "loss_f32/"
+    x, mask, cond = golden.get(tag + "x"), golden.get(tag + "mask"), golden.get(tag + "cond")
+    xc = x.cuda()
+    cond_b = torch.zeros(x.shape[0]) if cond is None else cond  # JetNet datamodule passes zeros(B) when unconditioned
+    torch.manual_seed(4321)
+    out = m.training_step((xc, mask.cuda(), cond_b.cuda()), 0)
+    loss = out["loss"]
+    torch.manual_seed(4321)
+    t = torch.rand_like(torch.ones(x.shape[0]))  # losses.py:46 (CPU generator)
+    z = torch.randn_like(xc).cpu()               # losses.py:53 (device generator)
+    ref, *_ = fm_ot_loss(_oracle(golden, m), x, mask, cond, t, z, sigma=1e-4)
+    torch.testing.assert_close(loss.detach().cpu(), ref, atol=2e-6, rtol=2e-5)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    assert "train/loss" in getattr(m, "logged", {"train/loss": 0})
+
+
+def test_fused_trainer_matches_torch_adamw_clip_ema():
+    """3 steps of FusedFMTrainer vs clip_grad_norm_(0.5) + torch.optim.AdamW + the EMA recurrence on the oracle."""
+    from particle_fm_amd.engine import FusedFMTrainer
+    from tests.conftest import load_golden
+    g = load_golden("jetnet30")
+    m = _module(g)
+    tr = FusedFMTrainer(m, lr=1e-3, weight_decay=5e-5, max_grad_norm=0.5, ema_decay=0.999)
+    freqs = m.flows[0].net.layout().default_freqs()
+    ref = {k: v.clone().requires_grad_(True) for k, v in g.state.items() if "frequencies" not in k}
+    ref["flows.0.frequencies"] = g.state["flows.0.frequencies"]
+    params = [v for k, v in ref.items() if v.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=5e-5)
+    ema = [p.detach().clone() for p in params]
+    gen = torch.Generator().manual_seed(5)
+    B, N = 8, 30
+    for step in range(3):
+        n = torch.randint(6, 31, (B,), generator=gen)
+        mask = (torch.arange(N)[None] < n[:, None]).float().unsqueeze(-1)
+        x = torch.randn(B, N, 3, generator=gen) * mask
+        torch.manual_seed(100 + step)
+        loss = tr.step((x.cuda(), mask.cuda(), torch.zeros(B).cuda()))
+        torch.manual_seed(100 + step)
+        t = torch.rand_like(torch.ones(B))
+        z = torch.randn_like(x.cuda()).cpu()
+        vf = EpicVectorField(ref, "flows.0.net", g.hp, freqs=freqs)
+        opt.zero_grad()
+        l_ref, *_ = fm_ot_loss(vf, x, mask, None, t, z, sigma=1e-4)
+        l_ref.backward()
+        torch.testing.assert_close(loss.cpu(), l_ref.detach(), atol=5e-6, rtol=5e-5)
+        gn = torch.nn.utils.clip_grad_norm_(params, 0.5)
+        torch.testing.assert_close(tr.grad_norm().cpu(), gn, atol=1e-5, rtol=2e-4)
+        opt.step()
+        for e, p in zip(ema, params):
+            e.sub_((e - p.detach()) * (1.0 - 0.999))  # callbacks/ema.py:78-81
+    got = dict(m.named_parameters())
+    k_list = [k for k in ref if ref[k].requires_grad]
+    for k in k_list:
+        torch.testing.assert_close(got[k].detach().cpu(), ref[k].detach(), atol=2e-6, rtol=2e-4, msg=lambda s: f"{k}: {s}")
+    # EMA buffer (flat, parameter order)
+    fp = tr.fp
+    for p, off, e in zip(fp.params, fp.offsets, ema):
+        torch.testing.assert_close(tr.ema[off:off + p.numel()].view_as(p).cpu(), e, atol=2e-6, rtol=2e-4)

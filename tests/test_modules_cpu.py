@@ -1,0 +1,125 @@
+"""Host logic of the drop-in boundary (no GPU): reference state_dict layout, initialisation stream,
+error behaviour, C ABI exports, flat-parameter aliasing."""
+import ctypes
+import re
+
+import pytest
+import torch
+
+from particle_fm_amd import _lib
+from particle_fm_amd.engine import FlatParams
+from particle_fm_amd.models import CNF, SetFlowMatchingLitModule
+from tests.conftest import ROOT, load_golden
+
+
+def _yaml_kwargs(hp):
+    keys = ["model", "features", "hidden_dim", "num_particles", "frequencies", "layers", "latent", "activation",
+            "wrapper_func", "t_local_cat", "t_global_cat", "add_time_to_input", "t_emb", "loss_type",
+            "global_cond_dim", "local_cond_dim", "dropout", "sum_scale"]
+    return {k: hp[k] for k in keys}
+
+
+def test_state_dict_keys_shapes_and_init_match_reference(golden):
+    # oracle/make_golden.py builds the reference CNF under manual_seed(12345); same stream here
+    torch.manual_seed(12345)
+    cnf = CNF(**_yaml_kwargs(golden.hp))
+    sd = {f"flows.0.{k}": v for k, v in cnf.state_dict().items()}
+    assert list(sd.keys()) == golden.keys
+    for k in golden.keys:
+        assert sd[k].shape == golden.state[k].shape, k
+        if k.endswith("weight_v") or k.endswith("frequencies"):
+            # weight_v and the buffer are untouched by the fixture's perturbation: bit-identical init
+            assert torch.equal(sd[k], golden.state[k]), k
+
+
+def test_lit_module_surface():
+    m = SetFlowMatchingLitModule(optimizer=None, features=3, hidden_dim=128, num_particles=30, frequencies=16,
+                                 layers=2, latent=10, t_local_cat=True, t_global_cat=True, add_time_to_input=False,
+                                 t_emb="cosine", sigma=1e-4)
+    for name in ("num_particles", "features", "loss_type", "sigma", "use_normaliser", "optimizer", "scheduler"):
+        assert name in m.hparams
+    assert m.hparams.num_particles == 30
+    g = load_golden("jetnet30")
+    # strict load of a reference-shaped state_dict (checkpoint / EMA swap path, callbacks/ema.py:145-157)
+    m6 = SetFlowMatchingLitModule(optimizer=None, **{k: v for k, v in _yaml_kwargs(g.hp).items()})
+    # the reference registers the flows twice (self.flows and self.loss.flows, flow_matching_module.py:445-449),
+    # so its checkpoints carry every tensor under "flows." and under "loss.flows."
+    full = dict(g.state)
+    full.update({"loss." + k: v for k, v in g.state.items()})
+    m6.load_state_dict(full, strict=True)
+    assert list(m6.state_dict().keys()) == g.keys + ["loss." + k for k in g.keys]  # and nothing cached leaks in
+    assert sum(p.numel() for p in m6.parameters()) == 561330
+    for fn in ("training_step", "validation_step", "sample", "configure_optimizers", "forward"):
+        assert callable(getattr(m6, fn))
+
+
+@pytest.mark.parametrize("kw,exc", [
+    (dict(model="transformer"), NotImplementedError),           # flow_matching_module.py:170
+    (dict(loss_type="nope"), NotImplementedError),              # :465
+    (dict(t_emb="nope"), NotImplementedError),                  # :231
+    (dict(criterion="l1"), NotImplementedError),                # losses.py:36
+    (dict(use_normaliser=True), NotImplementedError),
+    (dict(model="droid_fulltransformer"), NotImplementedError),
+])
+def test_constructor_errors(kw, exc):
+    base = dict(optimizer=None, features=3, hidden_dim=128, num_particles=30, frequencies=16, layers=1, latent=10,
+                t_local_cat=True, t_global_cat=True, add_time_to_input=False, t_emb="cosine")
+    base.update(kw)
+    with pytest.raises(exc):
+        SetFlowMatchingLitModule(**base)
+
+
+def test_no_cpu_fallback():
+    m = SetFlowMatchingLitModule(optimizer=None, features=3, hidden_dim=128, num_particles=30, frequencies=16,
+                                 layers=1, latent=10, t_local_cat=True, t_global_cat=True, add_time_to_input=False,
+                                 t_emb="cosine")
+    x = torch.randn(2, 30, 3)
+    with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
+        m.flows[0](torch.rand(2), x)
+    with pytest.raises(NotImplementedError):
+        m.flows[0].decode(x, None, None, ode_solver="rk4")
+    with pytest.raises(NotImplementedError):
+        m.flows[0].decode(x, None, None, ode_solver="bogus")
+    with pytest.raises(SyntaxError):
+        m.flows[0].decode(x, None, None, ode_solver="em")  # flow_matching_module.py:326
+    with pytest.raises(ValueError):
+        mc = CNF(features=3, hidden_dim=128, num_particles=30, frequencies=16, layers=1, latent=10, t_local_cat=True,
+                 t_global_cat=True, add_time_to_input=False, t_emb="cosine", global_cond_dim=2)
+        mc(torch.rand(2), x)  # cond missing: epic.py:313-317
+
+
+def test_c_abi_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(f"{ROOT}/include/pfm_hip.h").read()
+    declared = set(re.findall(r"\b(pfm_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.pfm_abi_version() == 1
+    from particle_fm_amd.layout import EpicConfig, EpicDesc, EpicLayout
+    lay = EpicLayout(EpicConfig(num_particles=150, features=3, latent=10, layers=6, frequencies=16, t_local_cat=True,
+                                t_global_cat=True))
+    assert lib.pfm_epic_lds_bytes(ctypes.byref(lay.desc)) <= 163840
+    assert lay.desc_floats * 4 >= ctypes.sizeof(EpicDesc)
+    # host-side validation errors come back as codes + text, no GPU needed
+    bad = EpicLayout(EpicConfig(num_particles=400, features=3, latent=10, layers=1, frequencies=16, t_local_cat=True,
+                                t_global_cat=True))
+    rc = lib.pfm_epic_forward(ctypes.byref(bad.desc), None, None, None, None, None, None, 1, None)
+    assert rc == 10002 and b"LDS" in lib.pfm_last_error()
+
+
+def test_flat_params_alias_and_survive_load_state_dict():
+    m = SetFlowMatchingLitModule(optimizer=None, features=3, hidden_dim=128, num_particles=30, frequencies=16,
+                                 layers=1, latent=10, t_local_cat=True, t_global_cat=True, add_time_to_input=False,
+                                 t_emb="cosine")
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    fp = FlatParams(m.parameters())
+    assert fp.is_intact()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    m.load_state_dict({k: v + 1 if v.is_floating_point() and "freq" not in k else v for k, v in before.items()})
+    assert fp.is_intact()
+    p0 = next(m.parameters())
+    assert torch.equal(fp.flat[: p0.numel()].view_as(p0), p0.data)
+    fp.grad.fill_(2.0)
+    assert float(p0.grad.sum()) == 2.0 * p0.numel()
