@@ -38,6 +38,13 @@ HP = dict(model="epic", features=3, hidden_dim=128, num_particles=150, frequenci
           local_cond_dim=0, dropout=0.0, sum_scale=1e-2)  # configs/model/flow_matching.yaml + fm_tops150.yaml
 
 
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
 def synthetic_batch(B, N, F, seed):
     gen = torch.Generator().manual_seed(seed)
     n = torch.randint(30, N + 1, (B,), generator=gen)
@@ -46,11 +53,33 @@ def synthetic_batch(B, N, F, seed):
     return x, mask, torch.zeros(B)
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually run on: affinity mask, capped by the cgroup CPU quota (a GPU box hands
+    a 1-GPU job a 16-core share of a 128-thread host; spinning 128 OpenMP threads on it is 100x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, int(os.environ.get("PFM_BENCH_CPU_THREADS", "32"))))
+
+
 def cpu_baseline(state, freqs, ode_steps, jets=64):
     """The oracle (eager PyTorch restatement of the reference graph) on the host cores, bounded sample."""
     from oracle.fm_ref import EpicVectorField, fm_ot_loss, sample_midpoint
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    log(f"  cpu: {cores} threads (os.cpu_count()={os.cpu_count()})")
     ohp = dict(HP)
     st = {k: v.clone().requires_grad_(v.is_floating_point() and "frequencies" not in k) for k, v in state.items()}
     params = [v for v in st.values() if v.requires_grad]
@@ -69,11 +98,13 @@ def cpu_baseline(state, freqs, ode_steps, jets=64):
         opt.step()
 
     train_step()  # warm-up
+    log("  cpu: train warm-up done")
     t0 = time.perf_counter()
     reps = 2
     for _ in range(reps):
         train_step()
     t_train = (time.perf_counter() - t0) / reps
+    log(f"  cpu: train step {t_train*1e3:.1f} ms")
     z = torch.randn(jets, HP["num_particles"], HP["features"])
     with torch.no_grad():
         vf_ng = EpicVectorField({k: v.detach() for k, v in st.items()}, "flows.0.net", ohp, freqs=freqs)
@@ -135,8 +166,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"rank {rank}/{world}: model + data ready, {args.warmup} warm-up steps")
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    log("warm-up done, timing")
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
            torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     fence()
@@ -151,6 +185,7 @@ def main():
         e2.record()
     fence()
     elapsed = time.perf_counter() - t0
+    log(f"timed {args.steps} steps in {elapsed:.3f}s")
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -186,7 +221,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             freqs = model.flows[0].net.layout().default_freqs()
+            log("cpu baseline (oracle on the host cores) ...")
             res["cpu_baseline"] = cpu_baseline(state_cpu, freqs, args.ode_steps)
+            log("cpu baseline done")
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
