@@ -161,6 +161,18 @@ int pfm_optim_step(float *param, const float *grad, float *exp_avg, float *exp_a
                    float beta2, float eps, float weight_decay, float ema_decay, int32_t step,
                    void *stream);
 
+/* Weight-norm reparametrisation on FLAT buffers (old-style nn.utils.weight_norm, epic.py:66-81, 262-300):
+ *   pack:   W[o,:] = g[o] * v[o,:] / ||v[o,:]||  written to blob[dst1[s]] and blob[dst2[s]] (s = source index of the
+ *           element, -1 = no destination), biases copied params[bias_from[i]] -> blob[bias_to[i]].
+ *   unpack: grad[g] += <dW,v>/||v||, grad[v] += (g/||v||)(dW - v<dW,v>/||v||^2) with dW[s] = gblob[gsrc[s]],
+ *           grad[bias_to[i]] += gblob[bias_from[i]].
+ * rows[n_rows][4] = {v_off, g_off, in_dim, src_off} (int32, device), one entry per weight row. */
+int pfm_wn_pack(const float *params, const int32_t *rows, int32_t n_rows, const int32_t *dst1, const int32_t *dst2,
+                const int32_t *bias_from, const int32_t *bias_to, int32_t n_bias, float *blob, void *stream);
+int pfm_wn_unpack_grad(const float *params, const float *gblob, const int32_t *rows, int32_t n_rows,
+                       const int32_t *gsrc, const int32_t *bias_from, const int32_t *bias_to, int32_t n_bias,
+                       float *grad, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,8 @@ SYMBOLS = {
     "pfm_optim_step": (
         c_int, [_fp, _fp, _fp, _fp, _fp, _fp, c_int64, c_float, c_float, c_float, c_float, c_float, c_float,
                 c_float, c_float, c_int32, c_void_p]),
+    "pfm_wn_pack": (c_int, [_fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_wn_unpack_grad": (c_int, [_fp, _fp, _fp, c_int32, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
 }
 
 

@@ -90,6 +90,35 @@ class GradSync:
         return value
 
 
+class FusedEpicTables:
+    """Device-side index tables that let the weight-norm kernels read the FLAT parameter buffer and write the
+    kernel blob (and back for gradients).  Built once per (module, FlatParams)."""
+
+    def __init__(self, net, layout, fp: "FlatParams"):
+        import numpy as np
+
+        dev = fp.flat.device
+        off = {id(p): o for p, o in zip(fp.params, fp.offsets)}
+        named = dict(net.named_parameters())
+        rows, bfrom, bsrc = [], [], []
+        for name, in_dim, out_dim in layout.linears:
+            vo, go, bo = (off[id(named[f"{name}.{k}"])] for k in ("weight_v", "weight_g", "bias"))
+            o = np.arange(out_dim)
+            rows.append(np.stack([vo + o * in_dim, go + o, np.full(out_dim, in_dim), layout.w_off[name] + o * in_dim], 1))
+            bfrom.append(bo + o)
+            bsrc.append(layout.b_off[name] + o)
+        rows = np.concatenate(rows).astype(np.int32)
+        bfrom = np.concatenate(bfrom).astype(np.int32)
+        bsrc = np.concatenate(bsrc)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.rows, self.n_rows = t(rows), len(rows)
+        self.dst1, self.dst2, self.gsrc = t(layout.src_dst1), t(layout.src_dst2), t(layout.src_gpos)
+        self.bias_param = t(bfrom)                                  # flat-parameter offsets of the biases
+        self.bias_blob = t(layout.src_dst1[bsrc].astype(np.int32))  # their place in the blob
+        self.bias_gblob = t(layout.src_gpos[bsrc].astype(np.int32))  # and in the gradient blob
+        self.n_bias = len(bfrom)
+
+
 class FusedFMTrainer:
     """One training step = HIP loss forward + backward, flat all-reduce, fused clip/AdamW/EMA.
 
@@ -113,6 +142,11 @@ class FusedFMTrainer:
         self.scratch = torch.zeros(1024, device=dev, dtype=torch.float32)
         self.sync = GradSync(process_group)
         self.step_count = 0
+        # fully fused path (no autograd): single EPiC flow with an FM-OT / CFM loss
+        self._fused = None
+        flows = getattr(module, "flows", None)
+        if flows is not None and len(flows) == 1 and hasattr(flows[0], "net") and hasattr(flows[0].net, "layout"):
+            self._fused = {}
 
     def optimizer_step(self, grad_mul: float = 1.0):
         self.step_count += 1
@@ -126,13 +160,63 @@ class FusedFMTrainer:
             hip_ops._stream_ptr(fp.flat.device))
         _lib.check(rc, "pfm_optim_step")
 
-    def step(self, batch) -> torch.Tensor:
+    def _fused_state(self, n_points: int):
+        st = self._fused.get(n_points)
+        if st is None:
+            from . import fm_loss
+            net = self.module.flows[0].net
+            lay = net.layout(n_points)
+            st = {"layout": lay, "tables": FusedEpicTables(net, lay, self.fp),
+                  "blob": net.packed_weights(n_points).contiguous(),  # freqs + descriptor tail stay as packed here
+                  "one": torch.ones(1, device=self.fp.flat.device)}
+            st["gblob"] = torch.zeros_like(st["blob"])
+            self._fused[n_points] = st
+        return st
+
+    def fused_loss_and_grad(self, x, mask, cond) -> torch.Tensor:
+        """pack -> loss forward -> backward -> d(weight_g, weight_v, bias) accumulated into the flat gradient;
+        six launches plus three scalar torch ops, no autograd graph."""
+        lib = _lib.load()
+        P, S = hip_ops._ptr, hip_ops._stream_ptr(self.fp.flat.device)
+        loss_mod = self.module.loss
+        kind = "CFM" if type(loss_mod).__name__ == "ConditionalFlowMatchingLoss" else "FM-OT"
+        if kind == "CFM":
+            if mask is None:
+                raise TypeError("ConditionalFlowMatchingLoss needs a mask (losses.py:119)")
+            t, z, eps = loss_mod.draw(x)
+        else:
+            (t, z), eps = loss_mod.draw(x), None
+        st = self._fused_state(x.shape[1])
+        lay, tb, blob, gblob = st["layout"], st["tables"], st["blob"], st["gblob"]
+        _lib.check(lib.pfm_wn_pack(P(self.fp.flat), P(tb.rows), tb.n_rows, P(tb.dst1), P(tb.dst2), P(tb.bias_param),
+                                   P(tb.bias_blob), tb.n_bias, P(blob), S), "pfm_wn_pack")
+        parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x, t, z, cond, mask, loss_mod.sigma, kind, eps)
+        total = count.sum()
+        loss = parts.sum() / total
+        inv_total = (1.0 / total).reshape(1)
+        gblob.zero_()
+        B = x.shape[0]
+        condf = None if lay.cfg.global_cond_dim == 0 else cond.to(torch.float32).contiguous()
+        maskf = None if mask is None else mask.reshape(B, -1).to(torch.float32).contiguous()
+        _lib.check(lib.pfm_epic_fm_loss_backward(ctypes.byref(lay.desc), P(blob), P(None), P(condf), P(maskf), P(saved),
+                                                 P(inv_total), P(st["one"]), P(gblob), B, S), "pfm_epic_fm_loss_backward")
+        _lib.check(lib.pfm_wn_unpack_grad(P(self.fp.flat), P(gblob), P(tb.rows), tb.n_rows, P(tb.gsrc), P(tb.bias_gblob),
+                                          P(tb.bias_param), tb.n_bias, P(self.fp.grad), S), "pfm_wn_unpack_grad")
+        return loss
+
+    def step(self, batch, fused: bool = True) -> torch.Tensor:
         x, mask, cond = batch
         if not self.fp.is_intact():
             self.fp.rebuild()
-        self.fp.zero_grad()
-        loss = self.module.loss(x, mask=mask, cond=cond)
-        loss.backward()
+            if self._fused is not None:
+                self._fused = {}
+        self.fp.grad.zero_()
+        if fused and self._fused is not None:
+            loss = self.fused_loss_and_grad(x, mask, cond)
+        else:
+            self.fp.zero_grad()
+            loss = self.module.loss(x, mask=mask, cond=cond)
+            loss.backward()
         mul = self.sync.sync(self.fp.grad)
         self.optimizer_step(mul)
         return loss.detach()

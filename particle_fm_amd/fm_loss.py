@@ -4,7 +4,7 @@ Mirrors FlowMatchingLoss / ConditionalFlowMatchingLoss of the reference
 (particle_fm/models/components/losses.py:38-77, 101-136) with the random draws passed in.  The
 differentiable input is the layout's *source vector* (effective weights | biases | freqs | 0,
 layout.EpicLayout.source_vector); the gather into the kernel blob happens inside forward(), and
-backward() scatters the kernel's gradient blob back with one index_add_.  Autograd then continues
+backward() gathers the kernel's gradient blob back with one index op.  Autograd then continues
 through the weight-norm reparametrisation to weight_g / weight_v / bias, so DDP / Lightning hooks
 see ordinary .grad accumulation on the real parameters.
 """
@@ -30,7 +30,7 @@ class _Maps:
         if ent is None:
             ent = (
                 torch.from_numpy(layout.index_map).to(device),
-                torch.from_numpy(layout.grad_index_map).to(device),
+                torch.from_numpy(layout.src_gpos.astype("int64")).to(device),
                 layout.desc_tail().to(device),
             )
             cache[key] = ent
@@ -75,9 +75,11 @@ class EpicFMLossFn(torch.autograd.Function):
         rc = lib.pfm_epic_fm_loss_backward(ctypes.byref(layout.desc), P(blob), P(None), P(cond), P(maskf), P(saved),
                                            P(inv_total), P(gscale), P(gblob), B, hip_ops._stream_ptr(dev))
         _lib.check(rc, "pfm_epic_fm_loss_backward")
-        _, gmap, _ = _Maps.get(layout, dev)
+        _, gpos, _ = _Maps.get(layout, dev)
+        # every weight / bias has exactly one gradient slot in the blob (layout.src_gpos): a plain gather;
+        # freqs and the zero pad get no gradient
         d_src = torch.zeros(ctx.n_source, device=dev, dtype=torch.float32)
-        d_src.index_add_(0, gmap, gblob[: layout.desc.blob_floats])
+        d_src[: gpos.numel()] = gblob[gpos]
         return d_src, None, None, None, None, None, None, None, None, None
 
 

@@ -323,6 +323,25 @@ class EpicLayout:
             if offAT >= 0:
                 gmap[offAT : offAT + H * H] = self.zero_off
         self.grad_index_map = gmap
+        # inverse maps, per source element (weights then biases): where it lands in the blob (one or two places:
+        # MFMA_A and MFMA_AT), and the single place of the gradient blob that carries its gradient
+        n_wb = self.freq_off
+        d1 = np.full(n_wb, -1, dtype=np.int32)
+        d2 = np.full(n_wb, -1, dtype=np.int32)
+        pos = np.nonzero(index_map < n_wb)[0]
+        order = np.argsort(index_map[pos], kind="stable")
+        pos, srcs = pos[order], index_map[pos][order]
+        first = np.ones(len(srcs), dtype=bool)
+        first[1:] = srcs[1:] != srcs[:-1]
+        d1[srcs[first]] = pos[first]
+        second = ~first
+        d2[srcs[second]] = pos[second]
+        assert np.all(np.bincount(srcs, minlength=n_wb) <= 2) and np.all(d1 >= 0)
+        gp = np.full(n_wb, -1, dtype=np.int32)
+        gpos = np.nonzero(gmap < n_wb)[0]
+        assert len(np.unique(gmap[gpos])) == len(gpos) == n_wb, "every weight/bias has exactly one gradient slot"
+        gp[gmap[gpos]] = gpos
+        self.src_dst1, self.src_dst2, self.src_gpos = d1, d2, gp
 
     # -- torch side ------------------------------------------------------------------------------
     def default_freqs(self) -> torch.Tensor:
