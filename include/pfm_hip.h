@@ -26,8 +26,11 @@
  * (weight_g / weight_v / bias per Linear) -- particle_fm_amd/layout.py -- and fills the offsets below.
  *
  * Blob formats (H = hidden = 128, T = time-embedding width, C = cond width, L = latent):
- *   KMAJOR[K][OUT]   row k holds column k of the nn.Linear weight for all OUT outputs (coalesced GEMV);
- *                    blocks with OUT = 128 are zero-padded to a multiple of 16 rows.
+ *   KMAJOR[K][OUT]   row k holds column k of the nn.Linear weight for all OUT outputs (plain, small blocks).
+ *   KM16             K-major block with OUT = 128, rows zero-padded to a multiple of 16 and stored in 16-row panels so
+ *                    that thread t of 512 reads float4 number t of a panel: element (k, o) lives at float
+ *                    ((k>>4)*32 + (o>>2))*64 + (k&15)*4 + (o&3).  Used for every per-jet GEMV with 128 outputs.
+ *   KP16             [K16][16]: K-major with the OUT <= 16 outputs zero-padded to 16 columns, rows to a multiple of 16.
  *   MFMA_A           the H x H block that multiplies the per-particle activations, pre-arranged as the
  *                    A operand of v_mfma_f32_16x16x4_f32: float4 at ((w*8 + kt)*64 + lane) holds
  *                    W[16*w + (lane&15)][16*kt + 4*(lane>>4) + r], r = 0..3   (w = output slice 0..7).
@@ -65,12 +68,12 @@ extern "C" {
 typedef struct pfm_local_lin {
     int64_t A;  /* MFMA_A  block, H*H floats */
     int64_t AT; /* MFMA_AT block, H*H floats (or -1 if the blob carries no backward copies) */
-    int64_t We; /* KMAJOR [Ke][H] extras block */
+    int64_t We; /* KM16 [Ke][H] extras block */
     int64_t b;  /* [H] bias */
 } pfm_local_lin;
 
 typedef struct pfm_dense_lin {
-    int64_t W; /* KMAJOR [K][OUT] */
+    int64_t W; /* KM16 (OUT = 128) or KP16 (OUT = latent) */
     int64_t b; /* [OUT] */
 } pfm_dense_lin;
 
@@ -97,7 +100,7 @@ typedef struct pfm_epic_desc {
     int64_t blob_floats; /* total length of the blob */
     int64_t freqs;       /* [T] exp(arange(T)) as torch computes it (time_emb.py:90) */
     pfm_dense_lin l1x;   /* fc_l1 particle block: KMAJOR [F][H]; b unused (-1) */
-    int64_t l1_We;       /* fc_l1 extras KMAJOR [T+Cl][H] */
+    int64_t l1_We;       /* fc_l1 extras KM16 [T+Cl][H] */
     int64_t l1_b;        /* [H] */
     pfm_local_lin l2;    /* fc_l2 */
     pfm_dense_lin g1;    /* fc_g1: K = T + C + 2H (mean, sum order), OUT = H */

@@ -66,16 +66,7 @@ __device__ __forceinline__ f32x4 dlrelu4(f32x4 y, float s) {
     return r;
 }
 
-__device__ __forceinline__ f32x4 colsum16(f32x4 v) {
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-        v.x += __shfl_xor(v.x, m);
-        v.y += __shfl_xor(v.y, m);
-        v.z += __shfl_xor(v.z, m);
-        v.w += __shfl_xor(v.w, m);
-    }
-    return v;
-}
+__device__ __forceinline__ f32x4 colsum16(f32x4 v) { return row_sum16(v); }
 
 // dX product: for every row p < n_rows, epi(p, oslot, acc) with
 //   acc[r] = sum_k AT-block[16w + 4q + r][k] * src[p][k]        (a = MFMA_AT fragments of this wave)
@@ -142,19 +133,39 @@ __device__ __forceinline__ void gemm_dw(const float* __restrict__ da, const floa
     }
 }
 
-// gW[k*OUT + o] += x[k] * dy[o] for k < K (K-major block), gb[o] += dy[o].  x, dy in LDS.
+// Rank-1 gradient of a per-jet GEMV block: gW[(k,o)] += x[k] * dy[o] for k < K, gb[o] += dy[o]  (x, dy in LDS).
+// OUT = 128: KM16 block, walked in storage order (coalesced atomics); OUT <= 16: KP16 block.
 __device__ __forceinline__ void rank1_atomic(float* __restrict__ gW, float* __restrict__ gb, int K, int OUT,
                                              const float* __restrict__ x, const float* __restrict__ dy) {
     const int tid = threadIdx.x;
     if (OUT == H) {
-        const int o = tid & (H - 1);
-        const float d = dy[o];
-        for (int k = tid >> 7; k < K; k += NT / H) atomicAdd(gW + k * H + o, x[k] * d);
-        if (tid < H && gb) atomicAdd(gb + tid, d);
+        const int K16 = (K + 15) & ~15;
+        for (int lin = tid; lin < K16 * H; lin += NT) {
+            const int k = ((lin >> 11) << 4) + ((lin >> 2) & 15);
+            const int o = (((lin >> 6) & 31) << 2) + (lin & 3);
+            if (k < K) atomicAdd(gW + lin, x[k] * dy[o]);
+        }
+        if (tid < H && gb) atomicAdd(gb + tid, dy[tid]);
     } else {
-        for (int i = tid; i < K * OUT; i += NT) atomicAdd(gW + i, x[i / OUT] * dy[i % OUT]);
+        for (int i = tid; i < K * 16; i += NT) {
+            const int o = i & 15;
+            if (o < OUT) atomicAdd(gW + i, x[i >> 4] * dy[o]);
+        }
         if (tid < OUT && gb) atomicAdd(gb + tid, dy[tid]);
     }
+}
+
+// dot of row k of a KM16 block with a 128-vector in LDS
+__device__ __forceinline__ float km16_rowdot(const float* __restrict__ W, int k, const float* __restrict__ v) {
+    const f32x4* row = reinterpret_cast<const f32x4*>(W) + (k >> 4) * 512 + (k & 15);
+    float a = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < H / 4; ++i) {
+        const f32x4 wv = row[i * 16];
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(v + 4 * i);
+        a += wv.x * dv.x + wv.y * dv.y + wv.z * dv.z + wv.w * dv.w;
+    }
+    return a;
 }
 
 // Backward of the global MLP of one stage (epic.py:180-186 / :375-380).
@@ -178,24 +189,14 @@ __device__ __forceinline__ void global_backward(const JetDims& j, const float* _
     rank1_atomic(gblob + gl2.W, gblob + gl2.b, K2, j.L, lds + c.vin2, lds + c.dag2);
     if (tid < H) {
         float a = 0.f;
-        for (int jj = 0; jj < j.L; ++jj) a = fmaf(blob[gl2.W + (TC + tid) * j.L + jj], lds[c.dag2 + jj], a);
+        for (int jj = 0; jj < j.L; ++jj) a = fmaf(blob[gl2.W + (TC + tid) * 16 + jj], lds[c.dag2 + jj], a);
         lds[c.dag1 + tid] = a * dlrelu(sv_g1[tid], j.slope);  // dag1 = dg1 * phi'(g1)
     }
     __syncthreads();
     // dW_gl1 += vin (x) dag1 ; db_gl1 += dag1
     rank1_atomic(gblob + gl1.W, gblob + gl1.b, K1, H, lds + c.vin, lds + c.dag1);
     // dvin[k] = W_gl1[k][:] . dag1 for k >= TC  -> dmean, dsum (-> dP), dg_in
-    auto rowdot = [&](int k) {
-        const f32x4* row = reinterpret_cast<const f32x4*>(blob + gl1.W + k * H);
-        float a = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < H / 4; ++i) {
-            const f32x4 wv = row[i];
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(lds + c.dag1 + 4 * i);
-            a += wv.x * dv.x + wv.y * dv.y + wv.z * dv.z + wv.w * dv.w;
-        }
-        return a;
-    };
+    auto rowdot = [&](int k) { return km16_rowdot(blob + gl1.W, k, lds + c.dag1); };
     if (tid < H) {
         // pooled mean = sum / n (epic.py:161), pooled sum * scale (:162)
         lds[c.dP + tid] = rowdot(TC + tid) / nvalid + rowdot(TC + H + tid) * j.sscale;

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     __syncthreads();
 
     f32x4 a1[8], a2[8];
+    const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
     // ---- EPiC layers, last to first ----
     for (int k = j.layers - 1; k >= 0; --k) {
         const pfm_epic_layer& ly = d.layer[k];
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         const float* g1 = sv + sl.glayer + k * sl.gstride;
         const float* gout = g1 + H;
         const float* gin = (k > 0) ? sv + sl.glayer + (k - 1) * sl.gstride + H : sv + sl.gstem;
-        load_afrag(a2, blob + ly.lc2.AT, w, lane);
-        load_afrag(a1, blob + ly.lc1.AT, w, lane);
+        load_afrag(a2, rs, ly.lc2.AT, w, lane);
+        load_afrag(a1, rs, ly.lc1.AT, w, lane);
         // (1) da2 = G * phi'(h_{k+1}) in place; db2j = column sums
         {
             f32x4 ps = {0.f, 0.f, 0.f, 0.f};
@@ -172,13 +173,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
             else if (tid < Ke + j.L) e1[tid] = gout[tid - Ke];
             if (tid >= 128 && tid < 128 + j.L) {
                 const int jj = tid - 128;
-                const f32x4* row = reinterpret_cast<const f32x4*>(blob + ly.lc1.We + (Ke + jj) * H);
-                float a = 0.f;
-                for (int i = 0; i < H / 4; ++i) {
-                    const f32x4 wv = row[i];
-                    const f32x4 dv = *reinterpret_cast<const f32x4*>(lds + c.dbj1 + 4 * i);
-                    a += wv.x * dv.x + wv.y * dv.y + wv.z * dv.z + wv.w * dv.w;
-                }
+                const float a = km16_rowdot(blob + ly.lc1.We, Ke + jj, lds + c.dbj1);
                 lds[c.dg + jj] += a;
             }
             __syncthreads();
@@ -207,7 +202,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     build_vin(j, lds, c, sv + sl.pool, nullptr, false);
     __syncthreads();
     global_backward<true>(j, blob, gblob, d.g1, d.g2, lds, c, sv + sl.gstem1, sv + sl.gstem);
-    load_afrag(a2, blob + d.l2.AT, w, lane);
+    load_afrag(a2, rs, d.l2.AT, w, lane);
     // da2s = (G + mask * dP) * phi'(x2) in place; db2j
     {
         const float* x2 = sv + sl.x2;

@@ -66,10 +66,10 @@ __host__ __device__ inline SavedLayout make_saved(int N, int F, int layers) {
 }
 
 // A operand of one 128x128 block for this wave: 8 x float4 = 32 VGPRs (MFMA_A format of pfm_hip.h)
-__device__ __forceinline__ void load_afrag(f32x4 (&a)[8], const float* __restrict__ A, int w, int lane) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(A) + (w * 8) * 64 + lane;
+__device__ __forceinline__ void load_afrag(f32x4 (&a)[8], blob_rsrc rs, int64_t A_off, int w, int lane) {
+    const int lb = ((w * 8) * 64 + lane) * 16;
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt) a[kt] = p[kt * 64];
+    for (int kt = 0; kt < 8; ++kt) a[kt] = bload4(rs, A_off + kt * 256, lb);
 }
 
 // two independent accumulator chains, alternated instruction by instruction (a dependent
@@ -80,16 +80,12 @@ __device__ __forceinline__ void load_afrag(f32x4 (&a)[8], const float* __restric
 #define PFM_MFMA_PAIR(acc0, acc1, av, bv0, bv1)                                       \
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).x, (bv0).x, acc0, 0, 0, 0);      \
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).x, (bv1).x, acc1, 0, 0, 0);      \
-    __builtin_amdgcn_sched_barrier(0);                                                \
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).y, (bv0).y, acc0, 0, 0, 0);      \
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).y, (bv1).y, acc1, 0, 0, 0);      \
-    __builtin_amdgcn_sched_barrier(0);                                                \
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).z, (bv0).z, acc0, 0, 0, 0);      \
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).z, (bv1).z, acc1, 0, 0, 0);      \
-    __builtin_amdgcn_sched_barrier(0);                                                \
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).w, (bv0).w, acc0, 0, 0, 0);      \
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).w, (bv1).w, acc1, 0, 0, 0);      \
-    __builtin_amdgcn_sched_barrier(0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).w, (bv1).w, acc1, 0, 0, 0);
 
 template <bool SAVE>
 __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float* __restrict__ lds, const Carve& c,
@@ -97,9 +93,13 @@ __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float*
 
 // One particle phase: for every row p < n_rows
 //   dst[p][16w..16w+16) = lrelu( W[16w.., :] . src[p][:] + bj[16w..] (+ resid[p][16w..] if RESID) )
-// Each wave walks the particle tiles two at a time (two accumulator chains).  The B operands are
-// staged through registers in two halves of the K range so that the LDS reads of one half are in
-// flight while the MFMAs of the other half issue (hipcc on its own serialises read -> wait -> 4 MFMAs).
+// Each wave walks the particle tiles two at a time (two accumulator chains).  Software pipeline, one
+// straight-line basic block per pair so that hipcc can interleave the three kinds of work:
+//   * B operands are staged through registers in two halves of the K range: the ds_reads of one half are in
+//     flight while the MFMAs of the other half issue;
+//   * the epilogue of pair i-1 (leaky-relu, ds_write, pooling FMAs) sits next to the MFMAs of pair i.
+// Rows are NOT clamped: tiles may run up to 31 rows past n_rows / N (the carve keeps that window inside LDS);
+// such rows only produce garbage in their own output columns, which are never stored or pooled.
 // POOL: masked column sums -> vin (mean | sum*scale).  SAVE: rows also go to `save` (global).
 template <bool RESID, bool POOL, bool SAVE>
 __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __restrict__ src,
@@ -107,101 +107,101 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
                                            const float* __restrict__ bj, const float* __restrict__ maskf,
                                            const JetDims& j, float* __restrict__ lds, const Carve& c,
                                            float* __restrict__ save, float* __restrict__ save_pool, int n_rows) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int tid_ = launder(threadIdx.x);
+    const int lane = tid_ & 63, w = tid_ >> 6;
     const int pl = lane & 15, q = lane >> 4;
     const int oslot = 4 * w + q;  // 16-byte slot of this lane's 4 output features
     const float slope = j.slope;
     const f32x4 bias = *reinterpret_cast<const f32x4*>(bj + 4 * oslot);
     f32x4 psum = {0.f, 0.f, 0.f, 0.f};
     const int npairs = (n_rows + 2 * TILE - 1) / (2 * TILE);
-    f32x4 bA0[4], bA1[4], bB0[4], bB1[4];
+    // (row & 15) == pl for every tile, so the swizzled slot offsets are per-lane constants
+    int koff[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) koff[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
+    const int ooff = pl * H + ((oslot ^ pl) << 2);
+    float* const sink = lds + c.dummy;
+    const bool late = __builtin_amdgcn_readfirstlane(w) >= 4;
+    // operand staging: two register sets X / Y of one K-quarter (2 kt x 2 tiles = 16 VGPRs each)
+    f32x4 X0[2], X1[2], Y0[2], Y1[2];
     f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
-    // prologue: first half of pair 0
-    {
-        const int pc0 = min(pl, n_rows - 1), pc1 = min(pl + TILE, n_rows - 1);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            bA0[kt] = *reinterpret_cast<const f32x4*>(src + lds_off(pc0, 4 * kt + q));
-            bA1[kt] = *reinterpret_cast<const f32x4*>(src + lds_off(pc1, 4 * kt + q));
-        }
-        if (RESID) {
-            r0 = *reinterpret_cast<const f32x4*>(resid + lds_off(pc0, oslot));
-            r1 = *reinterpret_cast<const f32x4*>(resid + lds_off(pc1, oslot));
-        }
+    f32x4 pacc0 = {0.f, 0.f, 0.f, 0.f}, pacc1 = {0.f, 0.f, 0.f, 0.f};
+#define PFM_LOADQ(B0, B1, base, qq)                                                        \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                    \
+        B0[kk] = *reinterpret_cast<const f32x4*>((base) + koff[2 * (qq) + kk]);            \
+        B1[kk] = *reinterpret_cast<const f32x4*>((base) + TILE * H + koff[2 * (qq) + kk]); \
     }
-    for (int pair = 0; pair < npairs; ++pair) {
+#define PFM_MFMAQ(B0, B1, qq)                                                              \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) { PFM_MFMA_PAIR(acc0, acc1, a[2 * (qq) + kk], B0[kk], B1[kk]); }
+    PFM_LOADQ(X0, X1, src, 0);
+    if (RESID) {
+        r0 = *reinterpret_cast<const f32x4*>(resid + ooff);
+        r1 = *reinterpret_cast<const f32x4*>(resid + TILE * H + ooff);
+    }
+    // epilogue of one pair (straight-line: invalid rows store to a sink and add 0 to the pool)
+    auto epilogue = [&](f32x4 e0, f32x4 e1, int pair) {
         const int p0 = pair * 2 * TILE + pl, p1 = p0 + TILE;
-        const int pc0 = min(p0, n_rows - 1), pc1 = min(p1, n_rows - 1);
-        // second half of this pair: issue, then run the first half's MFMAs underneath
-#if PFM_VAR == 3
-        if (pair == 0)
-#endif
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            bB0[kt] = *reinterpret_cast<const f32x4*>(src + lds_off(pc0, 4 * (kt + 4) + q));
-            bB1[kt] = *reinterpret_cast<const f32x4*>(src + lds_off(pc1, 4 * (kt + 4) + q));
+        const bool v0 = p0 < n_rows, v1 = p1 < n_rows;
+        e0 = lrelu4(e0, slope);
+        e1 = lrelu4(e1, slope);
+        float* d0 = v0 ? dst + pair * 2 * TILE * H + ooff : sink;
+        float* d1 = v1 ? dst + (pair * 2 + 1) * TILE * H + ooff : sink;
+        *reinterpret_cast<f32x4*>(d0) = e0;
+        *reinterpret_cast<f32x4*>(d1) = e1;
+        if (SAVE) {
+            if (v0) *reinterpret_cast<f32x4*>(save + p0 * H + 4 * oslot) = e0;
+            if (v1) *reinterpret_cast<f32x4*>(save + p1 * H + 4 * oslot) = e1;
         }
+        if (POOL) {
+            const float m0 = maskf[v0 ? p0 : 0], m1 = maskf[v1 ? p1 : 0];
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            psum += v0 ? e0 * m0 : z;
+            psum += v1 ? e1 * m1 : z;
+        }
+    };
+    for (int pair = 0; pair < npairs; ++pair) {
+        const float* s0 = src + pair * 2 * TILE * H;
+        PFM_LOADQ(Y0, Y1, s0, 1);
+        // The two waves that share a SIMD (w and w+4) run the same program in lockstep, so their VALU/LDS
+        // bursts would coincide and leave the matrix pipe idle.  Stagger: waves 4-7 do the previous pair's
+        // epilogue half a pair later, next to the partner's MFMAs (MI355X_MICROARCH.md, two waves per SIMD #9).
+        if (!late && pair > 0) epilogue(pacc0, pacc1, pair - 1);
         f32x4 acc0 = bias, acc1 = bias;
         if (RESID) { acc0 += r0; acc1 += r1; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) { PFM_MFMA_PAIR(acc0, acc1, a[kt], bA0[kt], bA1[kt]); }
-        __builtin_amdgcn_sched_barrier(0);
-        // first half of the NEXT pair (rows clamp, so the last iteration just re-reads valid rows)
-#if PFM_VAR == 3
-        if (pair < 0)
-#endif
-        {
-            const int n0 = min(p0 + 2 * TILE, n_rows - 1), n1 = min(p1 + 2 * TILE, n_rows - 1);
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                bA0[kt] = *reinterpret_cast<const f32x4*>(src + lds_off(n0, 4 * kt + q));
-                bA1[kt] = *reinterpret_cast<const f32x4*>(src + lds_off(n1, 4 * kt + q));
-            }
-            if (RESID) {
-                r0 = *reinterpret_cast<const f32x4*>(resid + lds_off(n0, oslot));
-                r1 = *reinterpret_cast<const f32x4*>(resid + lds_off(n1, oslot));
-            }
+        PFM_MFMAQ(X0, X1, 0);
+        PFM_LOADQ(X0, X1, s0, 2);
+        PFM_MFMAQ(Y0, Y1, 1);
+        if (late && pair > 0) epilogue(pacc0, pacc1, pair - 1);
+        PFM_LOADQ(Y0, Y1, s0, 3);
+        PFM_MFMAQ(X0, X1, 2);
+        // first quarter of the NEXT pair (one pair past the end on the last iteration: inside the LDS window)
+        PFM_LOADQ(X0, X1, s0 + 2 * TILE * H, 0);
+        if (RESID) {
+            const float* rn = resid + (pair + 1) * 2 * TILE * H;
+            r0 = *reinterpret_cast<const f32x4*>(rn + ooff);
+            r1 = *reinterpret_cast<const f32x4*>(rn + TILE * H + ooff);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) { PFM_MFMA_PAIR(acc0, acc1, a[kt + 4], bB0[kt], bB1[kt]); }
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = lrelu4(acc0, slope);
-        acc1 = lrelu4(acc1, slope);
-#if PFM_VAR == 2
-        if (acc0.x == 12345.678f) *reinterpret_cast<f32x4*>(dst + lds_off(p0, oslot)) = acc0 + acc1;
-#else
-        if (p0 < n_rows) {
-            *reinterpret_cast<f32x4*>(dst + lds_off(p0, oslot)) = acc0;
-            if (SAVE) *reinterpret_cast<f32x4*>(save + p0 * H + 4 * oslot) = acc0;
-            if (POOL) psum += acc0 * maskf[p0];
-        }
-        if (p1 < n_rows) {
-            *reinterpret_cast<f32x4*>(dst + lds_off(p1, oslot)) = acc1;
-            if (SAVE) *reinterpret_cast<f32x4*>(save + p1 * H + 4 * oslot) = acc1;
-            if (POOL) psum += acc1 * maskf[p1];
-        }
-#endif
+        PFM_MFMAQ(Y0, Y1, 3);
+        pacc0 = acc0;
+        pacc1 = acc1;
     }
+#undef PFM_LOADQ
+#undef PFM_MFMAQ
+    epilogue(pacc0, pacc1, npairs - 1);
     if (POOL) pool_finish<SAVE>(psum, j, lds, c, oslot, pl, save_pool);
 }
 
 // ---- per-jet GEMVs (global MLP, per-jet biases) ------------------------------------------------
-// All KMAJOR [K][128] matrices are read as float4 over 4 consecutive outputs: thread (og, pt) with
-// og = tid & 31 (output group), pt = tid >> 5 (one of 16 k-partitions, k = pt, pt+16, ...).  The loads
-// of a round are all issued before the first FMA so that one L2 round trip covers the whole GEMV.
-// GEMV over a KMAJOR [K16][128] block (rows zero-padded to a multiple of 16, see pfm_hip.h).
-// Thread (og, pt) owns outputs 4*og..4*og+3 and rows k = pt + 16*i.  Loads and FMAs are two steps so
-// that several GEMVs can have their loads in flight together; `row` = pt*32 + og is the only per-lane
-// address term, everything else is a wave-uniform offset.
+// Every 128-output block is KM16 (pfm_hip.h): thread t of 512 reads float4 number t of each 16-row panel, i.e.
+// thread (og = t >> 4, pt = t & 15) owns outputs 4*og..4*og+3 and rows k = 16*i + pt.  The 16 partial sums of
+// one output group sit in 16 adjacent lanes of ONE wave, so the reduction is four xor-shuffles -- no LDS round
+// trip, no barrier -- and wave w ends up with exactly its own output slice [16w, 16w+16).
 template <int U>
-__device__ __forceinline__ void gemv4_load(f32x4 (&wv)[U], const float* __restrict__ W, int K, int base, int row) {
-    const f32x4* W4 = reinterpret_cast<const f32x4*>(W) + row;
+__device__ __forceinline__ void gemv4_load(f32x4 (&wv)[U], blob_rsrc rs, int64_t W_off, int K, int base, int tid) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = base + u;
-        if (16 * i < K) wv[u] = W4[i * 16 * (H / 4)];  // uniform predicate
+        if (16 * i < K) wv[u] = bload4(rs, W_off + i * (NT * 4), tid * 16);  // uniform predicate; one 8 KB panel
         else wv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
@@ -210,142 +210,173 @@ __device__ __forceinline__ void gemv4_fma(f32x4& acc, const f32x4 (&wv)[U], cons
                                           int base, int pt) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int k = pt + 16 * (base + u);
+        const int k = 16 * (base + u) + pt;
         const float x = k < K ? vin[k] : 0.f;
         acc += wv[u] * x;
     }
 }
+__device__ __forceinline__ f32x4 reduce_pt(f32x4 v) { return row_sum16(v); }  // the 16 lanes of an output group
 
 struct LocalBiasSrc {  // the two local linears whose per-jet bias a stage prepares
     int64_t We1, b1, We2, b2;
 };
 
-// t/cond part of both local biases (K = T + Cl <= 96) -> partials
-__device__ __forceinline__ void local_bias_tc_part(const float* __restrict__ blob, const LocalBiasSrc& lb, int Ke,
-                                                   const float* __restrict__ vin, float* __restrict__ lds,
-                                                   const Carve& c) {
-    const int tid = threadIdx.x, og = tid & 31, pt = tid >> 5;
-    f32x4 w1[6], w2[6];
-    gemv4_load<6>(w1, blob + lb.We1, Ke, 0, tid);
-    gemv4_load<6>(w2, blob + lb.We2, Ke, 0, tid);
+// Stem: bj1 / bj2 = b + We^T [temb ; cond_l] for fc_l1 / fc_l2 (K = T + Cl <= 96).  Ends with a barrier.
+__device__ __forceinline__ void stem_bias(const float* __restrict__ blob, blob_rsrc rs, const LocalBiasSrc& lb, int Ke,
+                                          float* __restrict__ lds, const Carve& c) {
+    const int tid = launder(threadIdx.x), og = tid >> 4, pt = tid & 15;
+    const float* vin = lds + c.vin;
+    f32x4 w1[2], w2[2];
+    const f32x4 b1 = bload4(rs, lb.b1, og * 16);
+    const f32x4 b2 = bload4(rs, lb.b2, og * 16);
     f32x4 p1 = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f};
-    gemv4_fma<6>(p1, w1, vin, Ke, 0, pt);
-    gemv4_fma<6>(p2, w2, vin, Ke, 0, pt);
-    *reinterpret_cast<f32x4*>(lds + c.s_pb1 + pt * H + 4 * og) = p1;
-    *reinterpret_cast<f32x4*>(lds + c.s_pb2 + pt * H + 4 * og) = p2;
+    for (int base = 0; 16 * base < Ke; base += 2) {
+        gemv4_load<2>(w1, rs, lb.We1, Ke, base, tid);
+        gemv4_load<2>(w2, rs, lb.We2, Ke, base, tid);
+        gemv4_fma<2>(p1, w1, vin, Ke, base, pt);
+        gemv4_fma<2>(p2, w2, vin, Ke, base, pt);
+    }
+    p1 = reduce_pt(p1);
+    p2 = reduce_pt(p2);
+    if (pt == 0) {
+        *reinterpret_cast<f32x4*>(lds + c.bj1 + 4 * og) = p1 + b1;
+        *reinterpret_cast<f32x4*>(lds + c.bj2 + 4 * og) = p2 + b2;
+    }
+    __syncthreads();
 }
 
-__device__ __forceinline__ float sum16(const float* __restrict__ part, int o) {
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int pt = 0; pt < 16; pt += 2) { s0 += part[pt * H + o]; s1 += part[(pt + 1) * H + o]; }
-    return s0 + s1;
+constexpr int GW = 12;   // panels of fc_global1 prefetched into registers across the particle phase (48 VGPRs)
+constexpr int GW2 = 8;   // further panels issued at the start of the per-jet phase (K1 <= 16*(GW+GW2) = 320)
+
+// issue the loads of this thread's fc_global1 rows: they do not depend on data, so the caller issues them BEFORE
+// the particle phase whose pooled output the GEMV consumes; the 152 KB stream from L2 (64 B/clk/CU = 2.4k cycles)
+// then hides behind that phase's MFMAs instead of sitting on the serial path.
+__device__ __forceinline__ void prefetch_gl1(f32x4 (&gw)[GW], blob_rsrc rs, const pfm_dense_lin& gl1, int K1) {
+    gemv4_load<GW>(gw, rs, gl1.W, K1, 0, launder(threadIdx.x));
 }
 
 // The per-jet phase between two particle phases:
 //   g1 = lrelu(Wg1.[temb;cond;mean;sum;g] + b)            epic.py:180-182 / :375-377
 //   g  = lrelu(Wg2.[temb;cond;g1] + b (+ g))              epic.py:184-186 / :378-380
 //   bj1 = b1 + We1.[temb;cond_l;g],  bj2 = b2 + We2.[temb;cond_l]     (folded t/cond/global columns)
-// In : vin = [temb;cond;mean;sum;g_old] complete (the pooled part was written by the previous
-//      particle phase), barrier already passed.  Out: vin.g = g_new, bj1/bj2 ready, barrier passed.
-// STEM: fc_g1/fc_g2 (no g input, no residual) and no local biases.
+// In : vin = [temb;cond;mean;sum;g_old] complete (pooled part written by the previous particle phase, barrier
+//      passed), vin2[0..T+C) = [temb;cond], gw = this thread's fc_global1 rows (prefetched).
+// One workgroup barrier (after g1); everything after it is wave-local: every wave evaluates the small fc_global2
+// redundantly and finishes the bias slice [16w,16w+16) that its own MFMA phase reads, so the next particle phase
+// starts without another barrier.  Out: vin.g = g_new (written by wave 0), bj1/bj2 ready.
+// STEM: fc_g1/fc_g2 (no g input, no residual, no local biases) and a trailing barrier (vin.g is read next).
 template <bool STEM, bool SAVE>
-__device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __restrict__ blob,
+__device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __restrict__ blob, blob_rsrc rs,
                                               const pfm_dense_lin& gl1, const pfm_dense_lin& gl2,
                                               const LocalBiasSrc& lb, float* __restrict__ lds, const Carve& c,
-                                              float* __restrict__ save_g1, float* __restrict__ save_g) {
-    const int tid = threadIdx.x, og = tid & 31, pt = tid >> 5;
+                                              float* __restrict__ save_g1, float* __restrict__ save_g,
+                                              const f32x4 (&gw)[GW], f32x4 (&a_next)[8], int64_t a_next_off) {
+    const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
+    const int og = tid >> 4, pt = tid & 15;   // fc_global1 / bias GEMVs
+    const int o4 = lane >> 4, part = lane & 15;  // fc_global2: DPP row o4 owns outputs 4*o4.., lanes = rows 16 i + part
     float* vin = lds + c.vin;
-    float* vin2 = lds + c.s_vin2;
+    float* vin2 = lds + c.vin2;
     const int TC = j.T + j.C, Ke = j.T + j.Cl;
     const int K1 = TC + 2 * H + (STEM ? 0 : j.L);
     const int K2 = TC + H;
-    // ---- prefetch everything whose address does not depend on data ----
-    float w2[7];  // fc_global2 weights of thread (o2 = tid & 15, pt2 = tid >> 4): k = pt2 + 32 i
-    const int o2 = tid & 15, pt2 = tid >> 4;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int k = pt2 + 32 * i;
-        w2[i] = (o2 < j.L && k < K2) ? blob[gl2.W + k * j.L + o2] : 0.f;
-    }
-    float wg[MAXL];  // g rows of local linear 1 for output o = tid (threads < H)
-    float bias_pre = 0.f;
+    if (!STEM) PFM_MARK(0);
+    // ---- loads whose address does not depend on data, all issued up front (gw already holds 80 VGPRs) ----
+    constexpr int KA = 3, KBp = 2;  // panels kept in registers: local-1 extras (T+Cl+L <= 48), local-2 extras (<= 32)
+    const int Ka = Ke + j.L;        // rows of local linear 1's extras: [temb ; cond_l ; g]
+    f32x4 wbA[KA], wbB[KBp];
     if (!STEM) {
+        gemv4_load<KA>(wbA, rs, lb.We1, Ka, 0, tid);
+        gemv4_load<KBp>(wbB, rs, lb.We2, Ke, 0, tid);
+    }
+    constexpr int K2P = 11;  // fc_global2 panels kept in registers (K2 <= 176); wider ones the slow way
+    f32x4 w2[K2P];  // KP16 [k][16]: row k = 16 i + part, outputs 4*o4..4*o4+3
 #pragma unroll
-        for (int jj = 0; jj < MAXL; ++jj) wg[jj] = (tid < H && jj < j.L) ? blob[lb.We1 + (Ke + jj) * H + tid] : 0.f;
+    for (int i = 0; i < K2P; ++i)
+        w2[i] = (16 * i < K2) ? bload4(rs, gl2.W + i * 256, (part * 16 + 4 * o4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 bg1 = bload4(rs, gl1.b, og * 16);
+    f32x4 gold = {0.f, 0.f, 0.f, 0.f};
+    if (!STEM) gold = *reinterpret_cast<const f32x4*>(vin + TC + 2 * H + 4 * o4);  // g_old, before anyone overwrites it
+    f32x4 gw2[GW2];  // the panels of fc_global1 beyond the prefetch window: land behind the first GW panels' FMAs
+    gemv4_load<GW2>(gw2, rs, gl1.W, K1, GW, tid);
+    if (!STEM) PFM_MARK(1);
+    // ---- fc_global1 ----
+    f32x4 p = {0.f, 0.f, 0.f, 0.f};
+    gemv4_fma<GW>(p, gw, vin, K1, 0, pt);
+    gemv4_fma<GW2>(p, gw2, vin, K1, GW, pt);
+    if (K1 > 16 * (GW + GW2)) {  // wider models: the rest the slow way
+        f32x4 wa[4];
+        gemv4_load<4>(wa, rs, gl1.W, K1, GW + GW2, tid);
+        gemv4_fma<4>(p, wa, vin, K1, GW + GW2, pt);
     }
-    if (tid < H) bias_pre = blob[gl1.b + tid];
-    else if (!STEM && tid < 2 * H) bias_pre = blob[lb.b1 + (tid - H)];
-    else if (!STEM && tid < 3 * H) bias_pre = blob[lb.b2 + (tid - 2 * H)];
-    // ---- S2: fc_global1 partials (+ t/cond part of the local biases); K1 <= 352 < 16 * 24 ----
-    {
-        f32x4 wa[8], wb[6];
-        f32x4 p = {0.f, 0.f, 0.f, 0.f};
-        gemv4_load<8>(wa, blob + gl1.W, K1, 0, tid);
-        if (!STEM) gemv4_load<6>(wb, blob + lb.We1, Ke, 0, tid);
-        gemv4_fma<8>(p, wa, vin, K1, 0, pt);
-        gemv4_load<8>(wa, blob + gl1.W, K1, 8, tid);
-        if (!STEM) {
-            f32x4 p1 = {0.f, 0.f, 0.f, 0.f};
-            gemv4_fma<6>(p1, wb, vin, Ke, 0, pt);
-            *reinterpret_cast<f32x4*>(lds + c.s_pb1 + pt * H + 4 * og) = p1;
-            gemv4_load<6>(wb, blob + lb.We2, Ke, 0, tid);
-        }
-        gemv4_fma<8>(p, wa, vin, K1, 8, pt);
-        if (K1 > 256) gemv4_load<8>(wa, blob + gl1.W, K1, 16, tid);
-        if (!STEM) {
-            f32x4 p2 = {0.f, 0.f, 0.f, 0.f};
-            gemv4_fma<6>(p2, wb, vin, Ke, 0, pt);
-            *reinterpret_cast<f32x4*>(lds + c.s_pb2 + pt * H + 4 * og) = p2;
-        }
-        if (K1 > 256) gemv4_fma<8>(p, wa, vin, K1, 16, pt);
-        *reinterpret_cast<f32x4*>(lds + c.s_part + pt * H + 4 * og) = p;
+    if (!STEM) PFM_MARK(2);
+    // gw is dead now: the MFMA A fragments of the particle phase that follows land behind the rest of this phase
+    if (a_next_off >= 0) load_afrag(a_next, rs, a_next_off, w, lane);
+    // 16-lane reductions; g1 -> vin2; local bias 2 (t / cond only) for this wave's own output slice
+    p = reduce_pt(p);
+    if (pt == 0) {
+        const f32x4 g1 = lrelu4(p + bg1, j.slope);
+        *reinterpret_cast<f32x4*>(vin2 + TC + 4 * og) = g1;
+        if (SAVE) *reinterpret_cast<f32x4*>(save_g1 + 4 * og) = g1;
     }
-    __syncthreads();
-    // ---- S3: reduce ----
-    if (tid < H) {
-        const float g1 = lrelu(bias_pre + sum16(lds + c.s_part, tid), j.slope);
-        vin2[TC + tid] = g1;
-        if (SAVE) save_g1[tid] = g1;
-    } else if (!STEM && tid < 2 * H) {
-        lds[c.s_bj1p + (tid - H)] = bias_pre + sum16(lds + c.s_pb1, tid - H);
-    } else if (!STEM && tid < 3 * H) {
-        lds[c.bj2 + (tid - 2 * H)] = bias_pre + sum16(lds + c.s_pb2, tid - 2 * H);
-    } else if (tid >= 3 * H && tid < 3 * H + TC) {
-        vin2[tid - 3 * H] = vin[tid - 3 * H];
-    }
-    __syncthreads();
-    // ---- S4: fc_global2 partials from the prefetched weights ----
-    {
-        float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int k = pt2 + 32 * i;
-            acc = fmaf(w2[i], k < K2 ? vin2[k] : 0.f, acc);
-        }
-        lds[c.s_part2 + pt2 * 16 + o2] = acc;
-    }
-    __syncthreads();
-    // ---- S5: g_new ----
-    if (tid < j.L) {
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int p2 = 0; p2 < 32; p2 += 2) { a0 += lds[c.s_part2 + p2 * 16 + tid]; a1 += lds[c.s_part2 + (p2 + 1) * 16 + tid]; }
-        float a = blob[gl2.b + tid] + (a0 + a1);
-        if (!STEM) a += vin[TC + 2 * H + tid];  // residual before the activation, epic.py:184-186
-        const float g = lrelu(a, j.slope);
-        vin[TC + 2 * H + tid] = g;
-        if (SAVE) save_g[tid] = g;
-    }
-    __syncthreads();
-    // ---- S6: add the g part to bias 1 ----
     if (!STEM) {
-        if (tid < H) {
-            float a = lds[c.s_bj1p + tid];
-#pragma unroll
-            for (int jj = 0; jj < MAXL; ++jj) a = fmaf(wg[jj], jj < j.L ? vin[TC + 2 * H + jj] : 0.f, a);
-            lds[c.bj1 + tid] = a;
+        f32x4 p2 = {0.f, 0.f, 0.f, 0.f};
+        gemv4_fma<KBp>(p2, wbB, vin, Ke, 0, pt);
+        for (int base = KBp; 16 * base < Ke; base += KBp) {
+            gemv4_load<KBp>(wbB, rs, lb.We2, Ke, base, tid);
+            gemv4_fma<KBp>(p2, wbB, vin, Ke, base, pt);
         }
+        p2 = reduce_pt(p2);
+        if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.bj2 + 4 * og) = p2 + bload4(rs, lb.b2, og * 16);
+    }
+    const f32x4 bg2 = bload4(rs, gl2.b, o4 * 16);  // padded to 16 entries
+    f32x4 bl1 = {0.f, 0.f, 0.f, 0.f};
+    if (!STEM) bl1 = bload4(rs, lb.b1, og * 16);
+    if (!STEM) PFM_MARK(3);
+    __syncthreads();
+    if (!STEM) PFM_MARK(4);
+    // ---- fc_global2, redundantly in every wave (wave-local from here on) ----
+    f32x4 gn = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < K2P; ++i) {
+        const int k = 16 * i + part;
+        gn += w2[i] * (k < K2 ? vin2[k] : 0.f);
+    }
+    for (int i = K2P; 16 * i < K2; ++i) {
+        const int k = 16 * i + part;
+        gn += bload4(rs, gl2.W + i * 256, (part * 16 + 4 * o4) * 4) * (k < K2 ? vin2[k] : 0.f);
+    }
+    gn = row_sum16(gn);  // every lane of DPP row o4 now holds outputs 4*o4..4*o4+3
+    if (!STEM) PFM_MARK(5);
+    gn += bg2;
+    if (!STEM) gn += gold;  // residual before the activation, epic.py:184-186
+    gn = lrelu4(gn, j.slope);
+    // each wave keeps its own copy of g_new in LDS (read back below as the tail of the extras vector); wave 0's
+    // copy is vin.g itself, the input of the next stage
+    float* gcopy = (w == 0) ? vin + TC + 2 * H : lds + c.gcopy + MAXL * w;
+    if (part == 0) {
+        *reinterpret_cast<f32x4*>(gcopy + 4 * o4) = gn;
+        if (SAVE && w == 0) *reinterpret_cast<f32x4*>(save_g + 4 * o4) = gn;
+    }
+    if (!STEM) {
+        // local bias 1 = b1 + We1 . [temb ; cond_l ; g_new] for this wave's slice: row k = 16 i + pt of the extras
+        // takes temb/cond from vin (k < Ke) or g_new[k - Ke] from the wave's copy (same wave wrote it: LDS is in order)
+        f32x4 p1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KA; ++i) {
+            const int k = 16 * i + pt;
+            const float x = k < Ke ? vin[k] : (k < Ka ? gcopy[k - Ke] : 0.f);
+            p1 += wbA[i] * x;
+        }
+        for (int base = KA; 16 * base < Ka; ++base) {  // wider extras than the register window
+            f32x4 wx[1];
+            gemv4_load<1>(wx, rs, lb.We1, Ka, base, tid);
+            const int k = 16 * base + pt;
+            p1 += wx[0] * (k < Ke ? vin[k] : (k < Ka ? gcopy[k - Ke] : 0.f));
+        }
+        p1 = reduce_pt(p1);
+        if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.bj1 + 4 * og) = p1 + bl1;
+        PFM_MARK(6);
+    } else {
         __syncthreads();
     }
 }
@@ -354,13 +385,7 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
 template <bool SAVE>
 __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float* __restrict__ lds, const Carve& c,
                                             int oslot, int pl, float* __restrict__ save_pool) {
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-        psum.x += __shfl_xor(psum.x, m);
-        psum.y += __shfl_xor(psum.y, m);
-        psum.z += __shfl_xor(psum.z, m);
-        psum.w += __shfl_xor(psum.w, m);
-    }
+    psum = row_sum16(psum);
     if (pl == 0) {
         const float nvalid = lds[c.misc];
         const int TC = j.T + j.C;
@@ -376,7 +401,7 @@ template <int FM, bool SAVE>
 __device__ __forceinline__ void stem_l1(const pfm_epic_desc& d, const JetDims& j, const float* __restrict__ blob,
                                         float* __restrict__ lds, const Carve& c, int n_rows,
                                         float* __restrict__ save_x1) {
-    const int tid = threadIdx.x, slot = tid & 31;
+    const int tid = launder(threadIdx.x), slot = tid & 31;
     const float* Wx = blob + d.l1x.W;
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds + c.bj1 + 4 * slot);
     f32x4 wv[FM];
@@ -412,16 +437,15 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     if (TC > j.T + j.Cl) { /* cond_local == 0 while cond_global > 0: local extras use only temb */ }
 
     f32x4 a1[8], a2[8];
+    f32x4 gw[GW];  // fc_global1 rows of the NEXT per-jet phase, in flight during the particle phase before it
+    const int K1s = TC + 2 * H, K1l = TC + 2 * H + j.L;
     PFM_STAMP(1);
     // ---- stem: per-jet biases of fc_l1 / fc_l2 (t / cond columns) ------------------------------
-    load_afrag(a2, blob + d.l2.A, w, lane);
+    const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
+    load_afrag(a2, rs, d.l2.A, w, lane);
     {
         LocalBiasSrc lb; lb.We1 = d.l1_We; lb.b1 = d.l1_b; lb.We2 = d.l2.We; lb.b2 = d.l2.b;
-        local_bias_tc_part(blob, lb, Ke, vin, lds, c);
-        __syncthreads();
-        if (tid < H) bj1[tid] = blob[lb.b1 + tid] + sum16(lds + c.s_pb1, tid);
-        else if (tid < 2 * H) bj2[tid - H] = blob[lb.b2 + (tid - H)] + sum16(lds + c.s_pb2, tid - H);
-        __syncthreads();
+        stem_bias(blob, rs, lb, Ke, lds, c);
     }
     PFM_STAMP(2);
     // ---- fc_l1 (K = F, VALU): bufA[p][o] = lrelu(bj1[o] + sum_f Wx[f][o] * y[p][f])  epic.py:360-362
@@ -430,13 +454,15 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     __syncthreads();
     PFM_STAMP(3);
     // ---- fc_l2: bufB = lrelu(W.bufA + bj2 + bufA)  epic.py:364-366 (residual from the source buffer)
+    prefetch_gl1(gw, rs, d.g1, K1s);
     gemm_phase<true, true, SAVE>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, saved + sl.x2, saved + sl.pool, n_rows);
     __syncthreads();
     PFM_STAMP(4);
     // ---- fc_g1 / fc_g2 (epic.py:369-380) ---------------------------------------------------------
     {
         LocalBiasSrc none; none.We1 = none.b1 = none.We2 = none.b2 = 0;
-        per_jet_phase<true, SAVE>(j, blob, d.g1, d.g2, none, lds, c, saved + sl.gstem1, saved + sl.gstem);
+        per_jet_phase<true, SAVE>(j, blob, rs, d.g1, d.g2, none, lds, c, saved + sl.gstem1, saved + sl.gstem, gw, a1, -1);
+        if (j.layers > 0) prefetch_gl1(gw, rs, d.layer[0].gl1, K1l);  // no particle phase in between: exposed once
     }
     // ---- EPiC layers (epic.py:382-385 -> :159-203) -----------------------------------------------
     for (int k = 0; k < j.layers; ++k) {
@@ -444,16 +470,16 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
         PFM_STAMP(10);
         // vin still holds mean / sum of the current hidden state (bufB) and g
         LocalBiasSrc lb; lb.We1 = ly.lc1.We; lb.b1 = ly.lc1.b; lb.We2 = ly.lc2.We; lb.b2 = ly.lc2.b;
-        per_jet_phase<false, SAVE>(j, blob, ly.gl1, ly.gl2, lb, lds, c, saved + sl.glayer + k * sl.gstride,
-                                   saved + sl.glayer + k * sl.gstride + H);
+        per_jet_phase<false, SAVE>(j, blob, rs, ly.gl1, ly.gl2, lb, lds, c, saved + sl.glayer + k * sl.gstride,
+                                   saved + sl.glayer + k * sl.gstride + H, gw, a1, ly.lc1.A);
         PFM_STAMP(12);
-        load_afrag(a1, blob + ly.lc1.A, w, lane);
-        load_afrag(a2, blob + ly.lc2.A, w, lane);  // lands behind phase 1's MFMAs
+        load_afrag(a2, rs, ly.lc2.A, w, lane);  // lands behind phase 1's MFMAs
         // phase 1: bufA = lrelu(W1 . bufB + bj1)                       epic.py:194-196
         gemm_phase<false, false, SAVE>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, saved + sl.l1 + k * sl.lstride,
                                        nullptr, n_rows);
         __syncthreads();
         PFM_STAMP(13);
+        if (k + 1 < j.layers) prefetch_gl1(gw, rs, d.layer[k + 1].gl1, K1l);
         // phase 2: bufB = lrelu(W2 . bufA + bj2 + bufB), pooled -> vin    epic.py:198-200, :160-162
         gemm_phase<true, true, SAVE>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, saved + sl.xo + k * sl.lstride,
                                      saved + sl.pool + (k + 1) * sl.pstride, n_rows);
@@ -468,7 +494,7 @@ template <typename Emit>
 __device__ __forceinline__ void epic_head(const pfm_epic_desc& d, const JetDims& j,
                                           const float* __restrict__ blob, float* __restrict__ lds,
                                           const Carve& c, int n_rows, Emit emit) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const float* bufB = lds + c.bufB;
     const float* vin = lds + c.vin;
     float* bj3 = lds + c.bj1;  // reuse
@@ -535,13 +561,16 @@ __device__ __forceinline__ int epic_jet_setup(const pfm_epic_desc& d, const JetD
         if (m != 0.f) last = p;
     }
     for (int i = tid; i < j.F * H; i += NT) lds[c.w3 + i] = blob[d.l3_W + i];
-    if (tid < j.C) lds[c.vin + j.T + tid] = cond_jet[tid];
+    if (tid < j.C) {
+        lds[c.vin + j.T + tid] = cond_jet[tid];
+        lds[c.vin2 + j.T + tid] = cond_jet[tid];
+    }
     if (tid >= 64 && tid < 64 + MAXL) lds[c.vin + j.T + j.C + 2 * H + (tid - 64)] = 0.f;
     for (int m = 32; m >= 1; m >>= 1) {
         cnt += __shfl_xor(cnt, m);
         last = max(last, __shfl_xor(last, m));
     }
-    float* red = lds + c.s_part;
+    float* red = lds + c.misc + 8;
     if ((tid & 63) == 0) { red[tid >> 6] = cnt; red[8 + (tid >> 6)] = (float)last; }
     __syncthreads();
     if (tid == 0) {
@@ -564,7 +593,9 @@ __device__ __forceinline__ void epic_time_embedding(const pfm_epic_desc& d, cons
     if (tid < j.T) {
         const float f = blob[d.freqs + tid];
         const float arg = __fdiv_rn(__fmul_rn(__fmul_rn(__fadd_rn(t, 0.0f), f), 3.14159274101257324f), 1.0f);
-        lds[c.vin + tid] = cosf(arg);
+        const float e = cosf(arg);
+        lds[c.vin + tid] = e;
+        lds[c.vin2 + tid] = e;
     }
 }
 

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_forward_kernel(
     });
     for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
     __syncthreads();
-    float* red = lds + c.s_part;
+    float* red = lds + c.misc + 8;
     if ((tid & 63) == 0) red[tid >> 6] = sq;
     __syncthreads();
     if (tid == 0) {

@@ -34,8 +34,14 @@ extern __device__ int g_pfm_nstamp;
             }                                                                               \
         }                                                                                   \
     } while (0)
+// light stamp: one fire-and-forget store to a fixed slot (last writer wins), no counter traffic
+#define PFM_MARK(slot)                                                                      \
+    do {                                                                                    \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_pfm_stamps[384 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
 #else
 #define PFM_STAMP(id) do { } while (0)
+#define PFM_MARK(slot) do { } while (0)
 #endif
 
 // ---- LDS carve (floats).  One workgroup = one jet. -------------------------------------------
@@ -49,21 +55,18 @@ struct Carve {
     int maskf;       // N (rounded to 4)
     int w3;          // F*H  head weights
     int bj1, bj2;    // H each: per-jet bias of the two local linears of the current layer
-    int vin;         // 352: [temb(T) ; cond(C) ; mean(H) ; sum*scale(H) ; g(L)]  input of the global MLP
-    int misc;        // 16 : [0]=n_valid, [1]=last valid index
+    int vin;         // 352: [temb(T) ; cond(C) ; mean(H) ; sum*scale(H) ; g(L)]  input of fc_global1
+    int vin2;        // 208: [temb ; cond ; g1]  input of fc_global2
+    int gcopy;       // NW*MAXL: per-wave copy of g_new (wave 0 uses vin.g)
+    int misc;        // 32 : [0]=n_valid, [1]=last valid index, [8..24) reduction scratch
+    int dummy;       // 4 : sink for the (predicated-off) stores of rows >= N
     int total;
-    // scratch inside bufA while it is dead (between a layer's phase 2 and the next phase 1)
-    int s_part;      // [16][H]  GEMV partials of fc_global1
-    int s_pb1, s_pb2;  // [16][H] each: partials of the two local-bias GEMVs
-    int s_vin2;      // 208: [temb ; cond ; g1]
-    int s_part2;     // [32][16] partials of fc_global2
-    int s_bj1p;      // H : bias of local linear 1 without its g part
 };
 
 __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 
 constexpr int VIN_FLOATS = MAXT + MAXC + 2 * H + MAXL;  // 352
-constexpr int SCRATCH_FLOATS = 3 * 16 * H + 208 + 512 + H;  // 6992 -> n_points >= 55? no: see below
+constexpr int VIN2_FLOATS = MAXT + MAXC + H;            // 208
 
 __host__ __device__ inline Carve make_carve(int N, int F) {
     Carve c;
@@ -77,20 +80,58 @@ __host__ __device__ inline Carve make_carve(int N, int F) {
     c.bj1 = o; o += H;
     c.bj2 = o; o += H;
     c.vin = o; o += VIN_FLOATS;
-    c.misc = o; o += 16;
-    // the scratch wants SCRATCH_FLOATS; bufA provides N*H.  For small sets (N < 55) the scratch
-    // simply extends past bufA into a dedicated tail so that any N >= 1 works.
-    const int need = SCRATCH_FLOATS > N * H ? SCRATCH_FLOATS - N * H : 0;
-    int sbase = c.bufA;
-    if (need > 0) { sbase = o; o += SCRATCH_FLOATS; }
+    c.vin2 = o; o += VIN2_FLOATS;
+    c.gcopy = o; o += NW * MAXL;
+    c.misc = o; o += 32;
+    c.dummy = o; o += 4;
+    // the MFMA phases read particle rows in pairs of 16-row tiles WITHOUT clamping: up to 31 rows past the end of
+    // bufB may be touched (read only; their results are never stored).  Keep that window inside the allocation.
+    {
+        const int over = ((32 - N % 32) % 32) * H;
+        const int tail = o - (c.bufB + N * H);
+        if (over > tail) o += over - tail;
+    }
     c.total = o;
-    c.s_part = sbase;
-    c.s_pb1 = sbase + 16 * H;
-    c.s_pb2 = sbase + 32 * H;
-    c.s_vin2 = sbase + 48 * H;
-    c.s_part2 = c.s_vin2 + 208;
-    c.s_bj1p = c.s_part2 + 512;
     return c;
+}
+
+// index of element (k, o) of a KM16 block (K-major, OUT = 128, rows in blocks of 16; see pfm_hip.h)
+__host__ __device__ inline int km16(int k, int o) { return ((k >> 4) * 32 + (o >> 2)) * 64 + (k & 15) * 4 + (o & 3); }
+
+// Opaque copy of a per-lane value.  Every phase of the kernel derives a dozen per-lane constants (swizzled LDS
+// offsets, GEMV row indices) from threadIdx.x; without this hipcc hoists ALL of them out of the layer loop and
+// keeps them live (and spilled) for the whole kernel.  Laundering the seed makes each phase recompute its own.
+__device__ __forceinline__ int launder(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// ---- DPP row reductions: sum over the 16 lanes of a DPP row with four v_add_f32_dpp (no LDS, no address math)
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);  // row_half_mirror
+    v += dpp_move<0x140>(v);  // row_mirror
+    return v;                 // every lane of the row holds the row's sum
+}
+__device__ __forceinline__ f32x4 row_sum16(f32x4 v) {
+    v.x = row_sum16(v.x); v.y = row_sum16(v.y); v.z = row_sum16(v.z); v.w = row_sum16(v.w);
+    return v;
+}
+
+// ---- weight blob through a buffer resource: address = SGPR base + SGPR offset + one per-lane VGPR + immediate,
+//      so streaming a panel costs no per-load 64-bit VALU address arithmetic (cdna_hip_programming.md T8)
+typedef __amdgpu_buffer_rsrc_t blob_rsrc;
+__device__ __forceinline__ blob_rsrc make_blob_rsrc(const float* blob, int64_t total_floats) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blob), 0, (int)(total_floats * 4), 0x00020000);
+}
+// 16 bytes at  blob + 4*elem_off (wave-uniform) + lane_bytes (per lane)
+__device__ __forceinline__ f32x4 bload4(blob_rsrc rs, int64_t elem_off, int lane_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes, (int)(elem_off << 2), 0));
 }
 
 __device__ __forceinline__ int lds_off(int p, int slot) { return p * H + ((slot ^ (p & 15)) << 2); }

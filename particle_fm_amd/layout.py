@@ -202,21 +202,46 @@ class EpicLayout:
         self._segments.append((off, flat))
 
     def _kmajor(self, name: str, cols: Sequence[int]) -> int:
-        """KMAJOR [K][OUT]: element [k][o] = W[o][cols[k]].  Blocks with OUT = 128 are padded with zero
-        rows to a multiple of 16 rows: the GEMV kernels read them in 16-row steps without bounds checks."""
+        """Per-jet GEMV block: element [k][o] = W[o][cols[k]].
+        OUT = 128 -> KM16 (16-row panels, float ((k>>4)*32 + (o>>2))*64 + (k&15)*4 + (o&3)), rows zero-padded to 16;
+        OUT <= 16 -> KP16 ([K16][16], outputs zero-padded to 16 columns)."""
         OUT = self._out[name]
         cols = list(cols)
-        if OUT == PFM_HIDDEN:
-            cols += [-1] * ((-len(cols)) % 16)
+        cols += [-1] * ((-len(cols)) % 16)
         cols = np.asarray(cols, dtype=np.int64)
+        K16 = len(cols)
+        if OUT == PFM_HIDDEN:
+            k = np.arange(K16)[:, None]
+            o = np.arange(OUT)[None, :]
+            pos = ((k >> 4) * 32 + (o >> 2)) * 64 + (k & 15) * 4 + (o & 3)
+            src = self._w(name, o + 0 * k, cols[:, None] + 0 * o)
+            flat = np.empty(K16 * OUT, dtype=np.int64)
+            flat[pos.reshape(-1)] = src.reshape(-1)
+            off = self._alloc(K16 * OUT)
+            self._put(off, flat)
+            return off
+        assert OUT <= 16
+        flat = np.full((K16, 16), self.zero_off, dtype=np.int64)
+        flat[:, :OUT] = self._w(name, np.arange(OUT)[None, :], cols[:, None])
+        off = self._alloc(K16 * 16)
+        self._put(off, flat)
+        return off
+
+    def _plain_kmajor(self, name: str, cols: Sequence[int]) -> int:
+        """plain K-major [K][OUT] (fc_l1's particle block, fc_l3's extras)"""
+        OUT = self._out[name]
+        cols = np.asarray(list(cols), dtype=np.int64)
         off = self._alloc(len(cols) * OUT)
         self._put(off, self._w(name, np.arange(OUT)[None, :], cols[:, None]))
         return off
 
     def _bias(self, name: str) -> int:
         OUT = self._out[name]
-        off = self._alloc(OUT)
-        self._put(off, self.b_off[name] + np.arange(OUT))
+        n = max(OUT, 16) if OUT <= 16 else OUT  # small outputs padded to 16 (read as float4 groups)
+        idx = np.full(n, self.zero_off, dtype=np.int64)
+        idx[:OUT] = self.b_off[name] + np.arange(OUT)
+        off = self._alloc(n)
+        self._put(off, idx)
         return off
 
     def _mfma_a(self, name: str, c0: int, transposed: bool) -> int:
@@ -262,7 +287,7 @@ class EpicLayout:
         d.freqs = self._alloc(T)
         self._put(d.freqs, self.freq_off + np.arange(T))
         # fc_l1: [t_l ; x(F) ; c_l]
-        d.l1x.W = self._kmajor("fc_l1", range(Tl, Tl + F))
+        d.l1x.W = self._plain_kmajor("fc_l1", range(Tl, Tl + F))
         d.l1x.b = -1
         d.l1_We = self._kmajor("fc_l1", tcols(Tl) + list(range(Tl + F, Tl + F + Cl)))
         d.l1_b = self._bias("fc_l1")
@@ -299,7 +324,7 @@ class EpicLayout:
         # fc_l3: [t_l ; x(H) ; c_l]; particle block row-major [F][H]
         d.l3_W = self._alloc(F * H)
         self._put(d.l3_W, self._w("fc_l3", np.arange(F)[:, None], Tl + np.arange(H)[None, :]))
-        d.l3_We = self._kmajor("fc_l3", tcols(Tl) + list(range(Tl + H, Tl + H + Cl)))
+        d.l3_We = self._plain_kmajor("fc_l3", tcols(Tl) + list(range(Tl + H, Tl + H + Cl)))
         d.l3_b = self._bias("fc_l3")
         d.blob_floats = self._cursor
         index_map = np.full(self._cursor, self.zero_off, dtype=np.int64)

@@ -11,8 +11,19 @@ import torch.nn.functional as F
 H = 128
 
 
-def _kmajor(blob, off, K, OUT):
+def _plain(blob, off, K, OUT):
     return blob[off: off + K * OUT].view(K, OUT)
+
+
+def _kmajor(blob, off, K, OUT):
+    """decode a KM16 (OUT=128) or KP16 (OUT<=16) block back to [K][OUT]"""
+    K16 = (K + 15) // 16 * 16
+    if OUT == H:
+        k = torch.arange(K16).view(-1, 1)
+        o = torch.arange(OUT).view(1, -1)
+        pos = ((k >> 4) * 32 + (o >> 2)) * 64 + (k & 15) * 4 + (o & 3)
+        return blob[off: off + K16 * OUT][pos][:K]
+    return blob[off: off + K16 * 16].view(K16, 16)[:K, :OUT]
 
 
 def _mfma_a(blob, off, transposed=False):
@@ -50,7 +61,7 @@ def interp_forward(layout, blob, t, x, cond, mask, trace=None):
 
     bj1 = bvec(d.l1_b, H) + e_loc @ _kmajor(blob, d.l1_We, Ke, H)
     bj2 = bvec(d.l2.b, H) + e_loc @ _kmajor(blob, d.l2.We, Ke, H)
-    x1 = act(x @ _kmajor(blob, d.l1x.W, Fe, H) + bj1[:, None, :])
+    x1 = act(x @ _plain(blob, d.l1x.W, Fe, H) + bj1[:, None, :])
     h = act(x1 @ _mfma_a(blob, d.l2.A).T + bj2[:, None, :] + x1)
     if trace is not None:
         trace.update(temb=temb, x1=x1, x2=h, bj1_stem=bj1, bj2_stem=bj2)
@@ -85,6 +96,6 @@ def interp_forward(layout, blob, t, x, cond, mask, trace=None):
         if trace is not None:
             trace[f'l1_{k}'] = l1; trace[f'xo_{k}'] = h; trace[f'g1_{k}'] = g1; trace[f'g_{k}'] = g
     W3 = blob[d.l3_W: d.l3_W + Fe * H].view(Fe, H)
-    bj3 = bvec(d.l3_b, Fe) + e_loc @ _kmajor(blob, d.l3_We, Ke, Fe)
+    bj3 = bvec(d.l3_b, Fe) + e_loc @ _plain(blob, d.l3_We, Ke, Fe)
     out = act(h @ W3.T + bj3[:, None, :])
     return out * maskf[..., None]

@@ -24,13 +24,21 @@ Bn = 256
 gen = torch.Generator().manual_seed(0)
 x = torch.randn(Bn, NP, 3, generator=gen).cuda(); t = torch.rand(Bn, generator=gen).cuda(); v = torch.empty_like(x)
 P = ctypes.c_void_p
+MODE = os.environ.get("PFM_MODE", "sample")
+from particle_fm_amd.hip_ops import midpoint_grid
+ts, dts = midpoint_grid(6)
+ts, dts = ts.cuda(), dts.cuda()
 for it in range(3):
-    rc = lib.pfm_epic_forward(ctypes.byref(lay.desc), P(blob.data_ptr()), P(t.data_ptr()), P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, P(0))
+    if MODE == "forward":
+        rc = lib.pfm_epic_forward(ctypes.byref(lay.desc), P(blob.data_ptr()), P(t.data_ptr()), P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, P(0))
+    else:  # stamps of the LAST of 10 evaluations inside the persistent sampler (warm scalar cache, steady state)
+        rc = lib.pfm_epic_sample_midpoint(ctypes.byref(lay.desc), P(blob.data_ptr()), P(ts.data_ptr()), P(dts.data_ptr()), 5,
+                                          P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, P(0))
     assert rc == 0, rc
     buf = (ctypes.c_ulonglong * 512)(); n = ctypes.c_int(0)
     lib.pfm_diag_read_stamps(buf, ctypes.byref(n))
 names = {0: "start", 1: "body", 2: "stem-bias done", 3: "fc_l1 done", 4: "fc_l2+pool done", 10: "layer: global start", 11: "layer: global done",
-         12: "layer: bias done", 13: "layer: phase1 done", 20: "layers done", 30: "head done"}
+         12: "layer: bias done", 41: "pj: S2 done", 42: "pj: S3 done", 43: "pj: S4 done", 44: "pj: S5 done", 13: "layer: phase1 done", 20: "layers done", 30: "head done"}
 prev = None; tot = {}
 for i in range(n.value):
     sid, tk = buf[2 * i] >> 48, buf[2 * i + 1]
@@ -44,3 +52,6 @@ print(f"s_memrealtime ticks {rt} (100 MHz => {rt/100:.1f} us); s_memtime/s_memre
 print(f"total ticks {total} (100 MHz => {total/100:.1f} us)")
 for k, v_ in tot.items():
     print(f"{k:50s} n={len(v_):2d} mean {sum(v_)/len(v_):8.1f} ticks  sum {sum(v_):7d}  ({100*sum(v_)/total:.1f}%)")
+
+marks = [buf[384 + i] for i in range(8)]
+print("per-jet marks (last layer), deltas:", [marks[i + 1] - marks[i] for i in range(6)])
