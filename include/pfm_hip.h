@@ -109,6 +109,8 @@ typedef struct pfm_epic_desc {
     int64_t l3_W;        /* fc_l3 particle block, row-major [F][H] */
     int64_t l3_We;       /* fc_l3 extras KMAJOR [T+Cl][F] */
     int64_t l3_b;        /* [F] */
+    int64_t l3_A;        /* fc_l3 particle block as ONE 16-row MFMA_A panel: float4 at (kt*64 + lane) holds
+                            W3[lane&15][16*kt + 4*(lane>>4) + r] (rows >= F are zero), 2048 floats */
 } pfm_epic_desc;
 
 #define PFM_DESC_FLOATS ((int64_t)((sizeof(pfm_epic_desc) + 15) / 16 * 4))

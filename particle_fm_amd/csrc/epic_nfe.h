@@ -121,7 +121,6 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
     for (int kt = 0; kt < 8; ++kt) koff[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
     const int ooff = pl * H + ((oslot ^ pl) << 2);
     float* const sink = lds + c.dummy;
-    const bool late = __builtin_amdgcn_readfirstlane(w) >= 4;
     // operand staging: two register sets X / Y of one K-quarter (2 kt x 2 tiles = 16 VGPRs each)
     f32x4 X0[2], X1[2], Y0[2], Y1[2];
     f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
@@ -161,18 +160,19 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
     };
     for (int pair = 0; pair < npairs; ++pair) {
         const float* s0 = src + pair * 2 * TILE * H;
+        // hipcc sinks every ds_read down to its first use (read -> wait -> MFMA); the sched_barriers pin each
+        // quarter's reads BEFORE the MFMA block of the previous quarter so their latency hides behind 16 MFMAs.
         PFM_LOADQ(Y0, Y1, s0, 1);
-        // The two waves that share a SIMD (w and w+4) run the same program in lockstep, so their VALU/LDS
-        // bursts would coincide and leave the matrix pipe idle.  Stagger: waves 4-7 do the previous pair's
-        // epilogue half a pair later, next to the partner's MFMAs (MI355X_MICROARCH.md, two waves per SIMD #9).
-        if (!late && pair > 0) epilogue(pacc0, pacc1, pair - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pair > 0) epilogue(pacc0, pacc1, pair - 1);
         f32x4 acc0 = bias, acc1 = bias;
         if (RESID) { acc0 += r0; acc1 += r1; }
         PFM_MFMAQ(X0, X1, 0);
         PFM_LOADQ(X0, X1, s0, 2);
+        __builtin_amdgcn_sched_barrier(0);
         PFM_MFMAQ(Y0, Y1, 1);
-        if (late && pair > 0) epilogue(pacc0, pacc1, pair - 1);
         PFM_LOADQ(Y0, Y1, s0, 3);
+        __builtin_amdgcn_sched_barrier(0);
         PFM_MFMAQ(X0, X1, 2);
         // first quarter of the NEXT pair (one pair past the end on the last iteration: inside the LDS window)
         PFM_LOADQ(X0, X1, s0 + 2 * TILE * H, 0);
@@ -181,6 +181,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
             r0 = *reinterpret_cast<const f32x4*>(rn + ooff);
             r1 = *reinterpret_cast<const f32x4*>(rn + TILE * H + ooff);
         }
+        __builtin_amdgcn_sched_barrier(0);
         PFM_MFMAQ(Y0, Y1, 3);
         pacc0 = acc0;
         pacc1 = acc1;
@@ -490,59 +491,61 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
 
 // fc_l3 head: emit(p, f, lrelu(b3[f] + We3.[temb;cond_l] + W3[f].x[p]) * mask[p]) for every p < N
 // (rows >= n_rows are emitted as 0: they are masked).  epic.py:387-391
+// The F <= 16 outputs are one 16-row MFMA panel: wave w takes the particle tiles w, w+8, ...; lane (particle, q)
+// ends up with features 4q..4q+3 of its particle.
 template <typename Emit>
 __device__ __forceinline__ void epic_head(const pfm_epic_desc& d, const JetDims& j,
                                           const float* __restrict__ blob, float* __restrict__ lds,
                                           const Carve& c, int n_rows, Emit emit) {
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
+    const int pl = lane & 15, q = lane >> 4;
     const float* bufB = lds + c.bufB;
     const float* vin = lds + c.vin;
     float* bj3 = lds + c.bj1;  // reuse
     const int Ke = j.T + j.Cl;
+    const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
+    f32x4 a[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) a[kt] = bload4(rs, d.l3_A + kt * 256, lane * 16);
     // bj3[f] = b3[f] + sum_k We3[k][f] * e[k]: wave w takes features w, w+8; lanes split k
     for (int f = w; f < j.F; f += NW) {
-        float a = 0.f;
-        for (int k = lane; k < Ke; k += 64) a = fmaf(blob[d.l3_We + k * j.F + f], vin[k], a);
-        for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
-        if (lane == 0) bj3[f] = a + blob[d.l3_b + f];
+        float s = 0.f;
+        for (int k = lane; k < Ke; k += 64) s = fmaf(blob[d.l3_We + k * j.F + f], vin[k], s);
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        if (lane == 0) bj3[f] = s + blob[d.l3_b + f];
     }
     __syncthreads();
-    const int part = tid & 3;
-    for (int base = 0; base < j.N; base += NT / 4) {
-        const int p = base + (tid >> 2);
-        const bool live = p < n_rows;
-        const int pc = live ? p : 0;
-        for (int f0 = 0; f0 < j.F; f0 += 4) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int koff[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int slot = 4 * s + part;
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(bufB + lds_off(pc, slot));
+    for (int kt = 0; kt < 8; ++kt) koff[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
+    const int ntiles = (n_rows + TILE - 1) / TILE;
+    f32x4 b3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int jf = 0; jf < 4; ++jf) {
-                    if (f0 + jf < j.F) {
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(lds + c.w3 + (f0 + jf) * H + 4 * slot);
-                        acc[jf] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
-                    }
-                }
-            }
+    for (int r = 0; r < 4; ++r) b3[r] = (4 * q + r < j.F) ? bj3[4 * q + r] : 0.f;
+    for (int tile = w; tile < ntiles; tile += NW) {
+        const int p = tile * TILE + pl;
+        const float* s0 = bufB + tile * TILE * H;
+        f32x4 acc = b3;
 #pragma unroll
-            for (int jf = 0; jf < 4; ++jf) {
-                acc[jf] += __shfl_xor(acc[jf], 1);
-                acc[jf] += __shfl_xor(acc[jf], 2);
-            }
-            if (part == 0 && p < j.N) {
+        for (int kt = 0; kt < 8; ++kt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(s0 + koff[kt]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].w, b.w, acc, 0, 0, 0);
+        }
+        if (p < j.N) {
+            const bool live = p < n_rows;
+            const float m = live ? lds[c.maskf + p] : 0.f;
 #pragma unroll
-                for (int jf = 0; jf < 4; ++jf) {
-                    if (f0 + jf < j.F) {
-                        float val = 0.f;
-                        if (live) val = lrelu(acc[jf] + bj3[f0 + jf], j.slope) * lds[c.maskf + p];
-                        emit(p, f0 + jf, val);
-                    }
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int f = 4 * q + r;
+                if (f < j.F) emit(p, f, live ? lrelu(acc[r], j.slope) * m : 0.f);
             }
         }
     }
+    // rows behind the last computed tile (skip mode): masked, emit zeros
+    for (int i = ntiles * TILE * j.F + tid; i < j.N * j.F; i += NT) emit(i / j.F, i % j.F, 0.f);
 }
 
 // Loads that are constant over all evaluations of a jet: mask, cond, head weights; n_valid, n_rows.

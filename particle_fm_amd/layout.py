@@ -69,6 +69,7 @@ class EpicDesc(ctypes.Structure):
         ("l3_W", ctypes.c_int64),
         ("l3_We", ctypes.c_int64),
         ("l3_b", ctypes.c_int64),
+        ("l3_A", ctypes.c_int64),
     ]
 
 
@@ -326,6 +327,16 @@ class EpicLayout:
         self._put(d.l3_W, self._w("fc_l3", np.arange(F)[:, None], Tl + np.arange(H)[None, :]))
         d.l3_We = self._plain_kmajor("fc_l3", tcols(Tl) + list(range(Tl + H, Tl + H + Cl)))
         d.l3_b = self._bias("fc_l3")
+        # the same particle block once more as a single 16-row MFMA_A panel (the head runs on the matrix cores too)
+        kt = np.arange(8)[:, None, None]
+        lane = np.arange(64)[None, :, None]
+        r = np.arange(4)[None, None, :]
+        f = (lane & 15) + 0 * (kt + r)
+        k = 16 * kt + 4 * (lane >> 4) + r
+        idx = self._w("fc_l3", np.minimum(f, F - 1), Tl + k + 0 * f)
+        idx = np.where(f < F, idx, self.zero_off)
+        d.l3_A = self._alloc(2048)
+        self._put(d.l3_A, idx)
         d.blob_floats = self._cursor
         index_map = np.full(self._cursor, self.zero_off, dtype=np.int64)
         for off, flat in self._segments:
@@ -347,6 +358,7 @@ class EpicLayout:
             gmap[offA : offA + H * H] = self._w(name, rows, c0 + cols).reshape(-1)
             if offAT >= 0:
                 gmap[offAT : offAT + H * H] = self.zero_off
+        gmap[d.l3_A : d.l3_A + 2048] = self.zero_off  # forward-only copy of fc_l3's particle block
         self.grad_index_map = gmap
         # inverse maps, per source element (weights then biases): where it lands in the blob (one or two places:
         # MFMA_A and MFMA_AT), and the single place of the gradient blob that carries its gradient
