@@ -199,12 +199,12 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
 // trip, no barrier -- and wave w ends up with exactly its own output slice [16w, 16w+16).
 template <int U>
 __device__ __forceinline__ void gemv4_load(f32x4 (&wv)[U], blob_rsrc rs, int64_t W_off, int K, int base, int tid) {
+    // Unconditional: panels past K read whatever follows in the blob (finite weights; past the end the buffer
+    // resource returns 0) and are multiplied by x = 0 in gemv4_fma.  A predicate here costs a branch, four v_mov
+    // and, worse, a vmcnt(0) per load in hipcc's code.
+    (void)K;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int i = base + u;
-        if (16 * i < K) wv[u] = bload4(rs, W_off + i * (NT * 4), tid * 16);  // uniform predicate; one 8 KB panel
-        else wv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int u = 0; u < U; ++u) wv[u] = bload4(rs, W_off + (base + u) * (NT * 4), tid * 16);
 }
 template <int U>
 __device__ __forceinline__ void gemv4_fma(f32x4& acc, const f32x4 (&wv)[U], const float* __restrict__ vin, int K,
@@ -292,8 +292,7 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
     constexpr int K2P = 11;  // fc_global2 panels kept in registers (K2 <= 176); wider ones the slow way
     f32x4 w2[K2P];  // KP16 [k][16]: row k = 16 i + part, outputs 4*o4..4*o4+3
 #pragma unroll
-    for (int i = 0; i < K2P; ++i)
-        w2[i] = (16 * i < K2) ? bload4(rs, gl2.W + i * 256, (part * 16 + 4 * o4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < K2P; ++i) w2[i] = bload4(rs, gl2.W + i * 256, (part * 16 + 4 * o4) * 4);  // unconditional, see gemv4_load
     const f32x4 bg1 = bload4(rs, gl1.b, og * 16);
     f32x4 gold = {0.f, 0.f, 0.f, 0.f};
     if (!STEM) gold = *reinterpret_cast<const f32x4*>(vin + TC + 2 * H + 4 * o4);  // g_old, before anyone overwrites it
@@ -310,8 +309,7 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
         gemv4_fma<4>(p, wa, vin, K1, GW + GW2, pt);
     }
     if (!STEM) PFM_MARK(2);
-    // gw is dead now: the MFMA A fragments of the particle phase that follows land behind the rest of this phase
-    if (a_next_off >= 0) load_afrag(a_next, rs, a_next_off, w, lane);
+    (void)a_next; (void)a_next_off;  // the next phase's A fragments were issued before the previous particle phase
     // 16-lane reductions; g1 -> vin2; local bias 2 (t / cond only) for this wave's own output slice
     p = reduce_pt(p);
     if (pt == 0) {
@@ -456,6 +454,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     PFM_STAMP(3);
     // ---- fc_l2: bufB = lrelu(W.bufA + bj2 + bufA)  epic.py:364-366 (residual from the source buffer)
     prefetch_gl1(gw, rs, d.g1, K1s);
+    if (j.layers > 0) load_afrag(a1, rs, d.layer[0].lc1.A, w, lane);  // first layer's phase-1 weights: in flight across fc_l2
     gemm_phase<true, true, SAVE>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, saved + sl.x2, saved + sl.pool, n_rows);
     __syncthreads();
     PFM_STAMP(4);
@@ -467,7 +466,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     }
     // ---- EPiC layers (epic.py:382-385 -> :159-203) -----------------------------------------------
     for (int k = 0; k < j.layers; ++k) {
-        const pfm_epic_layer& ly = d.layer[k];
+        const pfm_epic_layer ly = d.layer[k];  // by value: all 24 offset dwords in one batch of scalar loads
         PFM_STAMP(10);
         // vin still holds mean / sum of the current hidden state (bufB) and g
         LocalBiasSrc lb; lb.We1 = ly.lc1.We; lb.b1 = ly.lc1.b; lb.We2 = ly.lc2.We; lb.b2 = ly.lc2.b;
@@ -480,7 +479,10 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
                                        nullptr, n_rows);
         __syncthreads();
         PFM_STAMP(13);
-        if (k + 1 < j.layers) prefetch_gl1(gw, rs, d.layer[k + 1].gl1, K1l);
+        if (k + 1 < j.layers) {
+            prefetch_gl1(gw, rs, d.layer[k + 1].gl1, K1l);
+            load_afrag(a1, rs, d.layer[k + 1].lc1.A, w, lane);  // next layer's phase-1 weights, in flight across phase 2
+        }
         // phase 2: bufB = lrelu(W2 . bufA + bj2 + bufB), pooled -> vin    epic.py:198-200, :160-162
         gemm_phase<true, true, SAVE>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, saved + sl.xo + k * sl.lstride,
                                      saved + sl.pool + (k + 1) * sl.pstride, n_rows);
