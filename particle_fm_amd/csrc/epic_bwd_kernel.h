@@ -67,7 +67,8 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         __syncthreads();
     }
     int n_rows = j.N;
-    if (d.flags & PFM_F_SKIP_MASKED_TAIL) n_rows = max(1, (int)lds[c.misc + 1] + 1);
+    // a jet without any valid particle is NaN in the reference (epic.py:370 divides by 0): compute all rows then too
+    if ((d.flags & PFM_F_SKIP_MASKED_TAIL) && lds[c.misc + 1] >= 0.f) n_rows = (int)lds[c.misc + 1] + 1;
     const int ntiles = (n_rows + TILE - 1) / TILE;
     const float gscale = 2.0f * inv_mask_total[0] * grad_scale[0];  // d/dv of sum (v-u)^2 / M
     const float* maskf = lds + c.maskf;

@@ -586,7 +586,8 @@ __device__ __forceinline__ int epic_jet_setup(const pfm_epic_desc& d, const JetD
     }
     __syncthreads();
     int n_rows = j.N;
-    if (d.flags & PFM_F_SKIP_MASKED_TAIL) n_rows = max(1, (int)lds[c.misc + 1] + 1);
+    // a jet without any valid particle is NaN in the reference (epic.py:370 divides by 0): compute all rows then too
+    if ((d.flags & PFM_F_SKIP_MASKED_TAIL) && lds[c.misc + 1] >= 0.f) n_rows = (int)lds[c.misc + 1] + 1;
     return n_rows;
 }
 
