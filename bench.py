@@ -198,6 +198,16 @@ def main():
         jets_per_step = B * world
         value = jets_per_step * args.steps / elapsed
         achieved = B * n_nfe * NFE_FLOP_PER_JET / (sample_ms * 1e-3)
+        # what the matrix cores actually execute: 13 Linears of 128x128 per evaluation on 32-row tile pairs up to the
+        # last valid particle of each jet (folded t/cond/g columns and fully masked tiles are not computed)
+        rows = ((mask.sum((1, 2)).cpu() + 31) // 32 * 32).sum().item()
+        executed = rows * 13 * 2 * 128 * 128 * n_nfe / (sample_ms * 1e-3)
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")))["pfm::epic_sample_midpoint_kernel"]
+            traffic = (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        except Exception:
+            pass
         res = {
             "metric": "jets/sec (train step + 100-step ODE sample), EPiC-FM JetNet N=150",
             "value": value, "unit": "jets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -214,9 +224,12 @@ def main():
             "train_jets_per_s": B * world / (train_ms * 1e-3), "sample_jets_per_s": B * world / (sample_ms * 1e-3),
             "roofline": {
                 "bound": "mfma", "kernel": "epic_sample_midpoint_kernel", "achieved": achieved / 1e12,
-                "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK, "traffic": None,
+                "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK, "traffic": traffic,
+                "executed_on_mfma": executed / 1e12,
                 "note": f"algorithmic {NFE_FLOP_PER_JET/1e6:.2f} MFLOP/jet/NFE x {n_nfe} NFE x {B} jets per launch "
-                        "(dense over padded N, concatenated t/cond columns counted) / HIP-event launch time",
+                        "(dense over padded N, concatenated t/cond columns counted) / HIP-event launch time; executed_on_mfma = "
+                        "TFLOP/s the matrix cores really ran (tile pairs up to each jet's last valid particle); traffic = "
+                        "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/round1_pmc_summary.json",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

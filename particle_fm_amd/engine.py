@@ -147,6 +147,7 @@ class FusedFMTrainer:
         flows = getattr(module, "flows", None)
         if flows is not None and len(flows) == 1 and hasattr(flows[0], "net") and hasattr(flows[0].net, "layout"):
             self._fused = {}
+            flows[0].net._fast_pack = self.packed_blob  # sampling re-packs with one HIP launch instead of ~100 torch ops
 
     def optimizer_step(self, grad_mul: float = 1.0):
         self.step_count += 1
@@ -167,11 +168,27 @@ class FusedFMTrainer:
             net = self.module.flows[0].net
             lay = net.layout(n_points)
             st = {"layout": lay, "tables": FusedEpicTables(net, lay, self.fp),
-                  "blob": net.packed_weights(n_points).contiguous(),  # freqs + descriptor tail stay as packed here
+                  # initial blob the slow (torch) way: fixes freqs + descriptor tail; the pack kernel rewrites the rest
+                  "blob": fm_loss.pack_blob_from_source(lay, net.source_vector(lay).detach()).contiguous(),
                   "one": torch.ones(1, device=self.fp.flat.device)}
             st["gblob"] = torch.zeros_like(st["blob"])
             self._fused[n_points] = st
         return st
+
+    def _pack(self, st):
+        tb = st["tables"]
+        P = hip_ops._ptr
+        _lib.check(_lib.load().pfm_wn_pack(P(self.fp.flat), P(tb.rows), tb.n_rows, P(tb.dst1), P(tb.dst2),
+                                           P(tb.bias_param), P(tb.bias_blob), tb.n_bias, P(st["blob"]),
+                                           hip_ops._stream_ptr(self.fp.flat.device)), "pfm_wn_pack")
+        return st["blob"]
+
+    def packed_blob(self, n_points: int):
+        """The kernel blob for the CURRENT flat parameters (weight-norm pack kernel); None if the parameters no
+        longer alias the flat buffer (e.g. after module.to()), in which case the caller packs the slow way."""
+        if self._fused is None or not self.fp.is_intact():
+            return None
+        return self._pack(self._fused_state(n_points))
 
     def fused_loss_and_grad(self, x, mask, cond) -> torch.Tensor:
         """pack -> loss forward -> backward -> d(weight_g, weight_v, bias) accumulated into the flat gradient;
@@ -187,9 +204,8 @@ class FusedFMTrainer:
         else:
             (t, z), eps = loss_mod.draw(x), None
         st = self._fused_state(x.shape[1])
-        lay, tb, blob, gblob = st["layout"], st["tables"], st["blob"], st["gblob"]
-        _lib.check(lib.pfm_wn_pack(P(self.fp.flat), P(tb.rows), tb.n_rows, P(tb.dst1), P(tb.dst2), P(tb.bias_param),
-                                   P(tb.bias_blob), tb.n_bias, P(blob), S), "pfm_wn_pack")
+        lay, tb, gblob = st["layout"], st["tables"], st["gblob"]
+        blob = self._pack(st)
         parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x, t, z, cond, mask, loss_mod.sigma, kind, eps)
         total = count.sum()
         loss = parts.sum() / total

@@ -99,6 +99,7 @@ class EPiC_encoder(nn.Module):
         self.fc_l3 = WNLinear(hid_d + tl + local_cond_dim, feats)
         self._layouts: Dict[int, EpicLayout] = {}
         self.skip_masked_tail = True
+        self._fast_pack = None  # set by engine.FusedFMTrainer: one-launch weight-norm pack from the flat buffer
 
     # -- layout / weights ------------------------------------------------------------------------
     def config(self, num_points: Optional[int] = None) -> EpicConfig:
@@ -125,6 +126,10 @@ class EPiC_encoder(nn.Module):
         """The kernel blob for the current parameter values (no autograd).  Cheap (a few small launches);
         rebuilt on every call, so it can never go stale after an optimizer step, load_state_dict or an EMA
         swap (callbacks/ema.py:145-157), and nothing extra ever appears in state_dict()."""
+        if self._fast_pack is not None:
+            blob = self._fast_pack(num_points or self.num_points)
+            if blob is not None:
+                return blob
         lay = self.layout(num_points)
         with torch.no_grad():
             return fm_loss.pack_blob_from_source(lay, self.source_vector(lay))
