@@ -190,6 +190,19 @@ class FusedFMTrainer:
             return None
         return self._pack(self._fused_state(n_points))
 
+    def snapshot_blob(self, n_points: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """A private copy of the kernel blob for the current parameters (e.g. to sample with on another stream while
+        training goes on).  Pass the previous snapshot as ``out`` to refresh it in place (one launch)."""
+        st = self._fused_state(n_points)
+        if out is None:
+            out = st["blob"].clone()  # carries the frequency table and the descriptor tail
+        tb = st["tables"]
+        P = hip_ops._ptr
+        _lib.check(_lib.load().pfm_wn_pack(P(self.fp.flat), P(tb.rows), tb.n_rows, P(tb.dst1), P(tb.dst2),
+                                           P(tb.bias_param), P(tb.bias_blob), tb.n_bias, P(out),
+                                           hip_ops._stream_ptr(self.fp.flat.device)), "pfm_wn_pack")
+        return out
+
     def fused_loss_and_grad(self, x, mask, cond) -> torch.Tensor:
         """pack -> loss forward -> backward -> d(weight_g, weight_v, bias) accumulated into the flat gradient;
         six launches plus three scalar torch ops, no autograd graph."""

@@ -160,13 +160,15 @@ class CNF(nn.Module):
         return _fm_loss.epic_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps)
 
     def decode(self, z: Tensor, cond: Tensor, mask: Tensor = None, ode_solver: str = "dopri5_zuko",
-               ode_steps: int = 100) -> Tensor:
+               ode_steps: int = 100, weights: Tensor = None) -> Tensor:
         """flow_matching_module.py:245-328.  "midpoint" = t_span linspace(1, 0, ode_steps), ode_steps-1
         explicit-midpoint intervals (torchdyn), here one persistent kernel launch."""
         if ode_solver == "midpoint":
             # mask is applied to the ODE right-hand side by the network itself; z arrives already masked
-            return hip_ops.epic_sample_midpoint(self.net.layout(z.shape[1]), self.net.packed_weights(z.shape[1]), z,
-                                                cond, mask, ode_steps=ode_steps, premask=False)
+            # `weights` (extension): an already packed kernel blob, e.g. a snapshot taken on another stream
+            blob = weights if weights is not None else self.net.packed_weights(z.shape[1])
+            return hip_ops.epic_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
+                                                ode_steps=ode_steps, premask=False)
         if ode_solver in ("em", "ddim"):
             raise SyntaxError(f"Solver {ode_solver} is only implemented for diffusion loss")  # :326
         if ode_solver in ("dopri5_zuko", "rk4", "dopri5", "euler", "tsit5", "ieuler", "alf"):
@@ -220,10 +222,10 @@ class SetFlowMatchingLitModule(_LitBase):
 
     # -- sampling ------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, cond: torch.Tensor = None, mask: torch.Tensor = None, reverse: bool = False,
-                ode_solver: str = "dopri5_zuko", ode_steps: int = 100):
+                ode_solver: str = "dopri5_zuko", ode_steps: int = 100, weights: torch.Tensor = None):
         if reverse:
             for f in reversed(self.flows):
-                x = f.decode(x, cond, mask, ode_solver=ode_solver, ode_steps=ode_steps)
+                x = f.decode(x, cond, mask, ode_solver=ode_solver, ode_steps=ode_steps, weights=weights)
         else:
             for f in self.flows:
                 x = f.encode(x, mask, ode_solver=ode_solver, ode_steps=ode_steps)
