@@ -74,9 +74,6 @@ __device__ __forceinline__ void load_afrag(f32x4 (&a)[8], blob_rsrc rs, int64_t 
 
 // two independent accumulator chains, alternated instruction by instruction (a dependent
 // v_mfma_f32_16x16x4_f32 needs 40 cycles, the pipe issues one every 32)
-#ifndef PFM_VAR
-#define PFM_VAR 0
-#endif
 #define PFM_MFMA_PAIR(acc0, acc1, av, bv0, bv1)                                       \
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).x, (bv0).x, acc0, 0, 0, 0);      \
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).x, (bv1).x, acc1, 0, 0, 0);      \
@@ -137,7 +134,25 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
         r0 = *reinterpret_cast<const f32x4*>(resid + ooff);
         r1 = *reinterpret_cast<const f32x4*>(resid + TILE * H + ooff);
     }
-    // epilogue of one pair (straight-line: invalid rows store to a sink and add 0 to the pool)
+    // epilogue of an INTERIOR pair: all 32 rows are < n_rows, no predication at all
+    auto epilogue_full = [&](f32x4 e0, f32x4 e1, int pair) {
+        e0 = lrelu4(e0, slope);
+        e1 = lrelu4(e1, slope);
+        float* d0 = dst + pair * 2 * TILE * H + ooff;
+        *reinterpret_cast<f32x4*>(d0) = e0;
+        *reinterpret_cast<f32x4*>(d0 + TILE * H) = e1;
+        if (SAVE) {
+            const int p0 = pair * 2 * TILE + pl;
+            *reinterpret_cast<f32x4*>(save + p0 * H + 4 * oslot) = e0;
+            *reinterpret_cast<f32x4*>(save + (p0 + TILE) * H + 4 * oslot) = e1;
+        }
+        if (POOL) {
+            const float* mp = maskf + pair * 2 * TILE + pl;
+            psum += e0 * mp[0];
+            psum += e1 * mp[TILE];
+        }
+    };
+    // epilogue of the LAST pair (straight-line too: rows >= n_rows store to a sink and add 0 to the pool)
     auto epilogue = [&](f32x4 e0, f32x4 e1, int pair) {
         const int p0 = pair * 2 * TILE + pl, p1 = p0 + TILE;
         const bool v0 = p0 < n_rows, v1 = p1 < n_rows;
@@ -164,7 +179,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
         // quarter's reads BEFORE the MFMA block of the previous quarter so their latency hides behind 16 MFMAs.
         PFM_LOADQ(Y0, Y1, s0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (pair > 0) epilogue(pacc0, pacc1, pair - 1);
+        if (pair > 0) epilogue_full(pacc0, pacc1, pair - 1);  // pair - 1 <= npairs - 2: every row valid
         f32x4 acc0 = bias, acc1 = bias;
         if (RESID) { acc0 += r0; acc1 += r1; }
         PFM_MFMAQ(X0, X1, 0);

@@ -1,6 +1,6 @@
 """ad-hoc GPU debug: compare every saved activation of the HIP forward with the CPU blob interpreter."""
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repository root
 from tests.conftest import load_golden
 from tests.test_layout_cpu import cfg_of
 from tests.blob_interp import interp_forward

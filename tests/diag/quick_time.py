@@ -1,6 +1,6 @@
 """ad-hoc timing helper (not a test): python tests/quick_time.py [B] [steps]"""
 import sys, time, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repository root
 from tests.conftest import load_golden
 from tests.test_layout_cpu import cfg_of
 from particle_fm_amd.layout import EpicLayout
