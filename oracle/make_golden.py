@@ -271,16 +271,148 @@ def gen_no_sets(ref, out_dir, seed=12345):
     print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB")
 
 
+# ----------------------------------------------------------------------------------------------
+# BASELINE cfg 4: Full-Transformer vector field (configs/model/fm_droid_transformer.yaml:15-44)
+# ----------------------------------------------------------------------------------------------
+def tf_net_config(model_dim, num_layers, num_heads, ctxt_out=64):
+    return dict(
+        node_embd_config=dict(act_h="lrlu", nrm="layer"),
+        ctxt_embd_config=dict(outp_dim=ctxt_out, act_h="lrlu", nrm="layer"),
+        te_config=dict(model_dim=model_dim, num_layers=num_layers,
+                       mha_config=dict(num_heads=num_heads, init_zeros=True, do_layer_norm=True),
+                       dense_config=dict(act_h="lrlu", nrm="layer", output_init_zeros=True)),
+        outp_embd_config=dict(act_h="lrlu", nrm="layer", output_init_zeros=True),
+    )
+
+
+TF_BASE = dict(model="droid_fulltransformer", features=3, frequencies=16, add_time_to_input=True, t_emb="cosine",
+               loss_type="FM-OT")
+TF_CONFIGS = {
+    # reduced width/depth: every array (weights, all parameter gradients) is stored
+    "small": (dict(TF_BASE, num_particles=40, global_cond_dim=3, net_config=tf_net_config(128, 2, 8)), 4, True),
+    # the yaml's own sizes (experiment/lhco/jets_transformer.yaml:26-31): weights are re-derived from the seed
+    # by oracle/seeded.py instead of being stored; gradients are stored sub-sampled
+    "lhco": (dict(TF_BASE, num_particles=279, global_cond_dim=5, net_config=tf_net_config(256, 3, 16)), 2, False),
+}
+
+
+def gen_transformer(ref, name, hp, B, store_all, out_dir, seed=2024):
+    import copy
+    import json
+
+    from oracle.seeded import seeded_state, subsample
+
+    torch.manual_seed(seed)
+    cnf = ref.fmm.CNF(**copy.deepcopy(hp))
+    # init_zeros / output_init_zeros make the untrained field identically 0: every tensor is
+    # replaced by a seeded, machine-independent draw (numpy PCG64) with the usual fan-in scale
+    shapes = {k: tuple(v.shape) for k, v in cnf.state_dict().items() if k != "frequencies"}
+    new = seeded_state(shapes, seed)
+    sd = cnf.state_dict()
+    for k, v in new.items():
+        sd[k] = torch.from_numpy(v)
+    cnf.load_state_dict(sd)
+    flows = torch.nn.ModuleList([cnf])
+    N, Fe, Cg = hp["num_particles"], hp["features"], hp["global_cond_dim"]
+    out = {"_keys": np.array(["flows.0." + k for k in cnf.state_dict().keys()])}
+    out["_shapes_json"] = np.array(json.dumps({"flows.0." + k: list(s) for k, s in shapes.items()}))
+    out["seed"] = np.array(seed)
+    out["hp_json"] = np.array(json.dumps(hp))
+    out["freqs"] = torch.arange(2 * hp["frequencies"]).exp().numpy()
+    out["abs_sum"] = np.array(sum(float(np.abs(v).sum(dtype=np.float64)) for v in new.values()))
+    if store_all:
+        for k, v in cnf.state_dict().items():
+            out["sd/flows.0." + k] = v.detach().numpy()
+    gen = torch.Generator().manual_seed(seed + 1)
+
+    for mk in ("f32", "int64", "ones"):
+        mask = make_mask(B, N, "f32" if mk == "ones" else mk, gen)
+        if mk == "ones":
+            mask = torch.ones_like(mask)
+        x = torch.randn(B, N, Fe, generator=gen) * mask
+        cond = torch.randn(B, Cg, generator=gen)
+        t = torch.rand(B, generator=gen)
+        tag = f"nfe_{mk}/"
+        with torch.no_grad():
+            tt = t.unsqueeze(-1).repeat_interleave(N, dim=1)
+            temb = cnf.time_embedding(tt, x, hp["t_emb"])
+            v_vec = cnf(tt, x, cond=cond, mask=mask)
+            v_sca = cnf(t[0].clone(), x, cond=cond, mask=mask)
+        out[tag + "x"], out[tag + "t"], out[tag + "temb"] = x.numpy(), t.numpy(), temb[:, 0, :].numpy()
+        out[tag + "mask"], out[tag + "cond"] = mask.numpy(), cond.numpy()
+        out[tag + "v_vec_t"], out[tag + "v_scalar_t"] = v_vec.numpy(), v_sca.numpy()
+
+    def put_grads(tag):
+        for k, p in cnf.named_parameters():
+            g = p.grad.detach().clone().numpy()
+            out[tag + "grad/flows.0." + k] = g if store_all else subsample(g)
+
+    mask = make_mask(B, N, "f32", gen)
+    x = torch.randn(B, N, Fe, generator=gen) * mask
+    cond = torch.randn(B, Cg, generator=gen)
+    loss_mod = ref.losses.FlowMatchingLoss(flows=flows, sigma=1e-4)
+    torch.manual_seed(9999)
+    cnf.zero_grad()
+    loss = loss_mod(x, mask=mask, cond=cond)
+    loss.backward()
+    torch.manual_seed(9999)  # losses.py:46, 53
+    t = torch.rand_like(torch.ones(B))
+    z = torch.randn_like(x)
+    tag = "loss_f32/"
+    out[tag + "x"], out[tag + "t"], out[tag + "z"] = x.numpy(), t.numpy(), z.numpy()
+    out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
+    put_grads(tag)
+
+    mask = make_mask(B, N, "f32", gen)
+    x = torch.randn(B, N, Fe, generator=gen) * mask
+    cond = torch.randn(B, Cg, generator=gen)
+    loss_mod = ref.losses.ConditionalFlowMatchingLoss(flows=flows, sigma=1e-4)
+    torch.manual_seed(4242)
+    cnf.zero_grad()
+    loss = loss_mod(x, mask=mask, cond=cond)
+    loss.backward()
+    torch.manual_seed(4242)  # losses.py:104, 108, 116
+    t = torch.rand_like(torch.ones(B))
+    x0 = torch.randn_like(x)
+    eps = torch.randn_like(x)
+    tag = "cfm/"
+    out[tag + "x"], out[tag + "t"], out[tag + "x0"], out[tag + "eps"] = x.numpy(), t.numpy(), x0.numpy(), eps.numpy()
+    out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
+    put_grads(tag)
+
+    for steps in ((3, 10, 100) if store_all else (3, 10)):
+        mask = make_mask(B, N, "f32", gen)
+        cond = torch.randn(B, Cg, generator=gen)
+        z = torch.randn(B, N, Fe, generator=gen)
+        wrapped = ref.fmm.ode_wrapper(model=cnf, cond=cond, mask=mask, loss_type="FM-OT")
+        with torch.no_grad():
+            xe = midpoint_trajectory_end(wrapped, z * mask, torch.linspace(1.0, 0.0, steps))
+        tag = f"midpoint_{steps}/"
+        out[tag + "z"], out[tag + "mask"], out[tag + "cond"], out[tag + "x_end"] = (
+            z.numpy(), mask.numpy(), cond.numpy(), xe.numpy())
+
+    path = os.path.join(out_dir, f"tf_{name}.npz")
+    np.savez(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
+    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf}; default all")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
+    ap2 = args.only.split(",") if args.only else None
     for name, hp in CONFIGS.items():
-        gen_config(ref, name, hp, args.out)
-    gen_no_sets(ref, args.out)
+        if ap2 is None or "epic" in ap2:
+            gen_config(ref, name, hp, args.out)
+    if ap2 is None or "no_sets" in ap2:
+        gen_no_sets(ref, args.out)
+    for name, (hp, B, store_all) in TF_CONFIGS.items():
+        if ap2 is None or "tf" in ap2:
+            gen_transformer(ref, name, hp, B, store_all, args.out)
 
 
 if __name__ == "__main__":

@@ -51,3 +51,47 @@ def load_golden(name):
 @pytest.fixture(params=["jetnet30", "jetnet150", "cond_gl", "cond_jetclass"])
 def golden(request):
     return load_golden(request.param)
+
+
+class TfGolden:
+    """tests/golden/tf_<name>.npz (BASELINE cfg 4 family).  The large fixture does not store the weights: they are
+    re-derived from the stored seed (oracle/seeded.py) and checked against the stored |w| sum."""
+
+    def __init__(self, name):
+        from oracle.seeded import seeded_state
+
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN, f"tf_{name}.npz"), allow_pickle=False)
+        self.hp = json.loads(str(self.z["hp_json"]))
+        self.keys = [str(k) for k in self.z["_keys"]]
+        self.freqs = torch.from_numpy(self.z["freqs"])
+        shapes = {k: tuple(s) for k, s in json.loads(str(self.z["_shapes_json"])).items()}
+        self.subsampled = "sd/" + next(iter(shapes)) not in self.z.files
+        if self.subsampled:
+            new = seeded_state(shapes, int(self.z["seed"]))
+            assert abs(sum(float(np.abs(v).sum(dtype=np.float64)) for v in new.values()) - float(self.z["abs_sum"])) < 1e-6
+            self.state = {k: torch.from_numpy(v) for k, v in new.items()}
+        else:
+            self.state = {k: torch.from_numpy(self.z["sd/" + k]) for k in shapes}
+        self.state["flows.0.frequencies"] = 2 ** torch.arange(self.hp["frequencies"]) * torch.pi
+
+    get = Golden.get
+    grads = Golden.grads
+
+    def pick(self, g):
+        """Bring a full gradient to what the fixture stores."""
+        from oracle.seeded import subsample
+
+        return torch.from_numpy(subsample(g.detach().cpu().numpy())) if self.subsampled else g.detach().cpu()
+
+
+def load_tf_golden(name):
+    key = "tf_" + name
+    if key not in _cache:
+        _cache[key] = TfGolden(name)
+    return _cache[key]
+
+
+@pytest.fixture(params=["small", "lhco"])
+def tf_golden(request):
+    return load_tf_golden(request.param)
