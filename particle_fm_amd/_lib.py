@@ -1,4 +1,4 @@
-"""ctypes binding of libpfm_hip.so (C ABI in include/pfm_hip.h).
+"""ctypes binding of libpfm_hip.so (C ABI in include/pfm_hip.h and include/pfm_tf.h).
 
 There is no CPU fallback: if the library is missing or a call fails this raises."""
 from __future__ import annotations
@@ -8,13 +8,14 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 from .layout import EpicDesc
+from .layout_tf import TfDesc
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpfm_hip.so")
 
 _lib = None
 
-# every symbol include/pfm_hip.h declares: name -> (restype, argtypes)
+# every symbol include/pfm_hip.h and include/pfm_tf.h declare: name -> (restype, argtypes)
 _fp = c_void_p  # device pointers travel as integers (tensor.data_ptr())
 SYMBOLS = {
     "pfm_abi_version": (c_int, []),
@@ -34,6 +35,11 @@ SYMBOLS = {
                 c_float, c_float, c_int32, c_void_p]),
     "pfm_wn_pack": (c_int, [_fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_wn_unpack_grad": (c_int, [_fp, _fp, _fp, c_int32, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    # include/pfm_tf.h
+    "pfm_tf_workspace_floats": (c_int64, [POINTER(TfDesc), c_int32, c_int32]),
+    "pfm_tf_forward": (c_int, [POINTER(TfDesc), _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_tf_sample_midpoint": (
+        c_int, [POINTER(TfDesc), _fp, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),
 }
 
 

@@ -1,0 +1,68 @@
+// Shared pieces of the Full-Transformer kernels (gfx950): workspace layout, launch geometry, small device helpers.
+#pragma once
+#include "pfm_common.h"
+#include "pfm_tf.h"
+
+namespace pfm {
+namespace tf {
+
+constexpr int BM = 64;    // rows (particles) per workgroup tile of the Linear kernels
+constexpr int BN = 128;   // outputs per workgroup tile: 4 waves x 32
+constexpr int LT = 256;   // threads of a Linear workgroup (one wave per SIMD; two workgroups share a CU)
+constexpr int HD = 16;    // head_dim this build is specialised for
+constexpr int MAXK = 512; // widest Linear input
+
+// Float offsets of the activation workspace.  Rows = n_jets * n_points.  In the train layout every layer owns
+// its buffers (lstride > 0) and the residual stream is written out of place; at inference the layers share
+// one set and the stream is updated in place.
+struct Ws {
+    int64_t temb, chid, ctxt, jb;  // per jet: [T] | [CH] (post-activation, pre-norm) | [CO] | [(layers+2)][hidden]
+    int64_t h1;                    // rows x hidden: node_embd hidden (post-activation)
+    int64_t x0;                    // rows x D: input of layer 0
+    int64_t layer0, lstride;       // per layer: qkv | att | xmid | dh | xout
+    int64_t o_qkv, o_att, o_xmid, o_dh, o_xout;
+    int64_t oh;                    // rows x hidden: outp_embd hidden
+    int64_t total;
+};
+
+__host__ __device__ inline int64_t round64(int64_t x) { return (x + 63) & ~(int64_t)63; }
+
+__host__ inline Ws make_ws(const pfm_tf_desc& d, int n_jets, bool train) {
+    Ws w;
+    const int64_t M = (int64_t)n_jets * d.n_points, D = d.model_dim, Hd = d.hidden;
+    int64_t o = 0;
+    w.temb = o; o += round64((int64_t)n_jets * 64);
+    w.chid = o; o += round64((int64_t)n_jets * d.ctxt_hidden);
+    w.ctxt = o; o += round64((int64_t)n_jets * d.ctxt_dim);
+    w.jb = o; o += round64((int64_t)n_jets * (d.layers + 2) * Hd);
+    w.h1 = o; o += round64(M * Hd);
+    w.x0 = o; o += round64(M * D);
+    w.layer0 = o;
+    w.o_qkv = 0;
+    w.o_att = round64(M * 3 * D);
+    w.o_dh = w.o_att + round64(M * D);
+    if (train) {
+        w.o_xmid = w.o_dh + round64(M * Hd);
+        w.o_xout = w.o_xmid + round64(M * D);
+        w.lstride = w.o_xout + round64(M * D);
+        o += w.lstride * d.layers;
+    } else {
+        w.o_xmid = w.o_xout = w.x0 - w.layer0;  // in place
+        w.lstride = 0;
+        o += w.o_dh + round64(M * Hd);
+    }
+    w.oh = o; o += round64(M * Hd);
+    w.total = o;
+    return w;
+}
+
+// 16 lanes of a DPP row cooperate on one matrix row: lane pl holds columns 4*pl + 64*i.
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+    return fmaxf(v, dpp_move<CTRL>(v));
+}
+
+__device__ __forceinline__ float hsum4(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
+
+}  // namespace tf
+}  // namespace pfm

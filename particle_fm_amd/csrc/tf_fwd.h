@@ -1,0 +1,487 @@
+// Forward kernels of the Full-Transformer vector field (gfx950, fp32 MFMA).
+//
+// Reference graph: particle_fm/models/components/droid_transformer.py:529-548 (FullTransformerEncoder.forward),
+// :331-344 (TransformerEncoderLayer), :231-284 (MultiHeadedAttentionBlock), :793-813 / :958-981 (MLPBlock /
+// DenseNetwork); time embedding time_emb.py:79-96.
+//
+// Kernels (one NFE = ctxt, embed, then Linear / attention launches on the caller's stream):
+//   tf_ctxt_kernel    one workgroup per jet: cosine embedding, ctxt_emdb, and the "jet bias" rows of every Linear
+//                     that takes the context (their context / time columns times the per-jet vectors).
+//   tf_embed_kernel   node_embd input block: K = F particle columns on the VALU (+ jet bias), LeakyReLU.
+//   tf_linear_kernel  out = epi( LN?(A) . W^T + b + jetbias ) (+ residual): 64 rows x 128 outputs per workgroup,
+//                     K streamed in chunks of 128 through LDS, weights are the MFMA A operand straight from
+//                     L2 (MFMA_AK blocks), activations the B operand via ds_read_b128 (k permuted so that one
+//                     16-byte read feeds four v_mfma_f32_16x16x4_f32).
+//   tf_attn_kernel    one workgroup per (jet, head): K and V^T of the head in LDS, S^T = K Q^T and O^T = V^T P^T
+//                     on MFMA with the whole score row of a query kept in registers (exact two-pass softmax); the
+//                     accumulator layout of S^T is already the B-operand layout of P^T, so P never leaves the VGPRs.
+//   tf_head_kernel    outp_embd output block (F <= 16 outputs): LayerNorm + F dot products per row, 16 lanes per
+//                     row, fused with the midpoint state update when sampling.
+#pragma once
+#include "tf_common.h"
+
+namespace pfm {
+namespace tf {
+
+// ------------------------------------------------------------------------------------------------
+// block-wide sum for the 512-thread per-jet kernel
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float block_sum512(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += red[i];
+    return s;
+}
+
+struct CtxtArgs {
+    const float* blob;
+    const float* t;
+    const float* cond;
+    float *temb, *chid, *ctxt, *jb;
+    int t_stride, T, C, CH, CO, Hd, nb;
+    float slope, eps;
+    int64_t freqs, c1W, c1b, cg, cb, c2W, c2b, n1Wt;
+    int64_t Wc[PFM_TF_MAX_LAYERS + 2], bb[PFM_TF_MAX_LAYERS + 2];
+};
+
+__global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
+    __shared__ float cin[96];
+    __shared__ float hb[512];
+    __shared__ float cx[64];
+    __shared__ float part[512];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, jet = blockIdx.x;
+    const float* __restrict__ blob = a.blob;
+    if (tid < a.T) {
+        // time_emb.py:90-96, exact fp32 op order ((t + min) * f) * pi / (max + min)
+        const float t = a.t[(int64_t)jet * a.t_stride];
+        const float f = blob[a.freqs + tid];
+        const float arg = __fdiv_rn(__fmul_rn(__fmul_rn(__fadd_rn(t, 0.0f), f), 3.14159274101257324f), 1.0f);
+        const float e = cosf(arg);
+        cin[tid] = e;
+        a.temb[(int64_t)jet * 64 + tid] = e;
+    } else if (tid < a.T + a.C) {
+        cin[tid] = a.cond[(int64_t)jet * a.C + tid - a.T];
+    }
+    __syncthreads();
+    const int Kc = a.T + a.C;
+    // ctxt_emdb input block: Linear, LeakyReLU (the LayerNorm follows)
+    for (int o = tid; o < a.CH; o += 512) {
+        float acc = blob[a.c1b + o];
+        for (int k = 0; k < Kc; ++k) acc = fmaf(blob[a.c1W + (int64_t)k * a.CH + o], cin[k], acc);
+        acc = lrelu(acc, a.slope);
+        hb[o] = acc;
+        a.chid[(int64_t)jet * a.CH + o] = acc;
+    }
+    __syncthreads();
+    float s = 0.f;
+    for (int o = tid; o < a.CH; o += 512) s += hb[o];
+    const float mean = block_sum512(s, red) / (float)a.CH;
+    float ss = 0.f;
+    for (int o = tid; o < a.CH; o += 512) {
+        const float dlt = hb[o] - mean;
+        ss = fmaf(dlt, dlt, ss);
+    }
+    const float rstd = 1.0f / sqrtf(block_sum512(ss, red) / (float)a.CH + a.eps);
+    for (int o = tid; o < a.CH; o += 512) hb[o] = (hb[o] - mean) * rstd * blob[a.cg + o] + blob[a.cb + o];
+    __syncthreads();
+    // ctxt_emdb output block: CO <= 64 outputs, 8 partial sums each
+    {
+        const int j = tid & 63, p = tid >> 6;
+        float acc = 0.f;
+        if (j < a.CO)
+            for (int o = p; o < a.CH; o += 8) acc = fmaf(blob[a.c2W + (int64_t)o * a.CO + j], hb[o], acc);
+        part[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < a.CO) {
+        float acc = blob[a.c2b + tid];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc += part[p * 64 + tid];
+        cx[tid] = acc;
+        a.ctxt[(int64_t)jet * a.CO + tid] = acc;
+    }
+    __syncthreads();
+    // jet-bias rows: b + Wc . ctxt (+ Wt . temb for node_embd)
+    for (int c = 0; c < a.nb; ++c) {
+        for (int o = tid; o < a.Hd; o += 512) {
+            float acc = blob[a.bb[c] + o];
+            for (int j = 0; j < a.CO; ++j) acc = fmaf(blob[a.Wc[c] + (int64_t)j * a.Hd + o], cx[j], acc);
+            if (c == 0 && a.n1Wt >= 0)
+                for (int k = 0; k < a.T; ++k) acc = fmaf(blob[a.n1Wt + (int64_t)k * a.Hd + o], cin[k], acc);
+            a.jb[((int64_t)jet * a.nb + c) * a.Hd + o] = acc;
+        }
+    }
+}
+
+// node_embd input block (droid_transformer.py:793-813 on cat(temb, x, ctxt)): the F particle columns
+__global__ __launch_bounds__(256) void tf_embed_kernel(const float* __restrict__ blob, int64_t Wx,
+                                                       const float* __restrict__ x, const float* __restrict__ jb,
+                                                       int64_t jb_stride, float* __restrict__ h1, int M, int N, int F,
+                                                       int Hd, float slope) {
+    const int nc4 = Hd >> 2;
+    const int row0 = blockIdx.x * 32;
+    for (int idx = threadIdx.x; idx < 32 * nc4; idx += 256) {
+        const int r = idx / nc4, c4 = idx - r * nc4;
+        const int row = row0 + r;
+        if (row >= M) break;
+        const int jet = row / N;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(jb + (int64_t)jet * jb_stride + 4 * c4);
+        for (int f = 0; f < F; ++f) {
+            const float xv = x[(int64_t)row * F + f];
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(blob + Wx + (int64_t)f * Hd + 4 * c4);
+            acc.x = fmaf(wv.x, xv, acc.x); acc.y = fmaf(wv.y, xv, acc.y);
+            acc.z = fmaf(wv.z, xv, acc.z); acc.w = fmaf(wv.w, xv, acc.w);
+        }
+        *reinterpret_cast<f32x4*>(h1 + (int64_t)row * Hd + 4 * c4) = lrelu4(acc, slope);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Linear
+// ------------------------------------------------------------------------------------------------
+struct LinArgs {
+    const float* A;     // [M][lda], first K columns
+    const float* blob;
+    const float* jb;    // jet-bias rows (already contain the bias) or nullptr
+    const float* R;     // residual [M][ldr] or nullptr
+    float* out;         // [M][ldo]
+    int64_t blob_floats, W, b, gamma, beta, jb_stride;
+    int lda, ldr, ldo, M, K, NO, N, act, row_tiles;
+    float slope, eps;
+};
+
+// row statistics of a BM-row tile: 16 lanes per row, two-pass (mean, then centred sum of squares)
+__device__ __forceinline__ void ln_stats_tile(const float* __restrict__ A, int lda, int M, int K, int row0, float eps,
+                                              float* __restrict__ stat, int tid) {
+    const int lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
+    constexpr int RPW = BM / (LT / 64);  // rows per wave
+#pragma unroll 1
+    for (int pass = 0; pass < RPW / 4; ++pass) {
+        const int r = RPW * w + 4 * pass + q;
+        const int row = min(row0 + r, M - 1);
+        const float* ap = A + (int64_t)row * lda + 4 * pl;
+        f32x4 v[MAXK / 64];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXK / 64; ++i)
+            if (64 * i < K) {
+                v[i] = *reinterpret_cast<const f32x4*>(ap + 64 * i);
+                s += hsum4(v[i]);
+            }
+        const float mean = row_sum16(s) / (float)K;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXK / 64; ++i)
+            if (64 * i < K) {
+                const f32x4 dl = v[i] - mean;
+                ss += hsum4(dl * dl);
+            }
+        const float rstd = 1.0f / sqrtf(row_sum16(ss) / (float)K + eps);
+        if (pl == 0) {
+            stat[2 * r] = mean;
+            stat[2 * r + 1] = rstd;
+        }
+    }
+}
+
+// XCD-aware tile order: consecutive workgroup ids land on different XCDs (round-robin), so the column chunks of
+// one row tile -- which re-read the same activation rows -- are given ids that are congruent mod 8 and share an L2.
+__device__ __forceinline__ bool tile_of_block(int bid, int row_tiles, int nchunk, int& rt, int& ch) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    rt = (slot / nchunk) * 8 + xcd;
+    ch = slot % nchunk;
+    return rt < row_tiles;
+}
+
+template <bool LN>
+__global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const tile = lds;             // BM x 128, 16-byte slots XOR-swizzled with (row & 15)
+    float* const stat = lds + BM * 128;  // BM x (mean, rstd)
+    int rt, ch;
+    if (!tile_of_block(blockIdx.x, a.row_tiles, a.NO / BN, rt, ch)) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
+    const int row0 = rt * BM;
+    const int ob = ch * BN + 32 * w;  // this wave: outputs [ob, ob + 32) as two 16-row A operands
+    const blob_rsrc rs = make_blob_rsrc(a.blob, a.blob_floats);
+    const int nkc = a.K >> 7;
+
+    if (LN) {
+        ln_stats_tile(a.A, a.lda, a.M, a.K, row0, a.eps, stat, tid);
+        __syncthreads();
+    }
+
+    // accumulators start from the bias (+ the jet-bias row of the particle's jet)
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int o = ob + 16 * s + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (a.jb) {
+                const int row = min(row0 + 16 * t + pl, a.M - 1);
+                acc[s][t] = *reinterpret_cast<const f32x4*>(a.jb + (int64_t)(row / a.N) * a.jb_stride + o);
+            } else {
+                acc[s][t] = *reinterpret_cast<const f32x4*>(a.blob + a.b + o);
+            }
+        }
+    }
+
+    const int sc4 = tid & 31, sr = tid >> 5;  // staging: 16-byte column slot, first row
+#pragma unroll 1
+    for (int kc = 0; kc < nkc; ++kc) {
+        f32x4 af[2][8];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int64_t base = a.W + ((int64_t)((ob >> 4) + s) * nkc + kc) * 2048;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) af[s][kt] = bload4(rs, base + kt * 256, lane * 16);
+        }
+        f32x4 st[8];
+        {
+            const int col = 128 * kc + 4 * sc4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = min(row0 + sr + 8 * i, a.M - 1);
+                st[i] = *reinterpret_cast<const f32x4*>(a.A + (int64_t)row * a.lda + col);
+            }
+            if (LN) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + col);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + col);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = sr + 8 * i;
+                    const float mean = stat[2 * r], rstd = stat[2 * r + 1];
+                    st[i] = (st[i] - mean) * rstd * g4 + b4;
+                }
+            }
+        }
+        if (kc > 0) __syncthreads();  // everyone is done reading the previous chunk
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = sr + 8 * i;
+            *reinterpret_cast<f32x4*>(tile + r * 128 + ((sc4 ^ (r & 15)) << 2)) = st[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+            const float* b0p = tile + (32 * tp + pl) * 128;
+            const float* b1p = b0p + 16 * 128;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+                const int so = ((4 * kt + q) ^ pl) << 2;
+                const f32x4 B0 = *reinterpret_cast<const f32x4*>(b0p + so);
+                const f32x4 B1 = *reinterpret_cast<const f32x4*>(b1p + so);
+#define PFM_TF_STEP(c)                                                                                         \
+    acc[0][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B0.c, acc[0][2 * tp], 0, 0, 0);         \
+    acc[1][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][kt].c, B0.c, acc[1][2 * tp], 0, 0, 0);         \
+    acc[0][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B1.c, acc[0][2 * tp + 1], 0, 0, 0); \
+    acc[1][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][kt].c, B1.c, acc[1][2 * tp + 1], 0, 0, 0);
+                PFM_TF_STEP(x) PFM_TF_STEP(y) PFM_TF_STEP(z) PFM_TF_STEP(w)
+#undef PFM_TF_STEP
+            }
+        }
+    }
+
+    // epilogue: lane (particle pl of tile t, q) holds 4 consecutive outputs
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int o = ob + 16 * s + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = row0 + 16 * t + pl;
+            if (row < a.M) {
+                f32x4 v = acc[s][t];
+                if (a.act) v = lrelu4(v, a.slope);
+                if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+                *reinterpret_cast<f32x4*>(a.out + (int64_t)row * a.ldo + o) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention: softmax(Q K^T / sqrt(hd) + keymask) V for one (jet, head); hd = 16
+// ------------------------------------------------------------------------------------------------
+constexpr int KROW = 20;  // floats per K row in LDS (16 + 4 pad: conflict-free ds_read_b128 of the A operand)
+
+__host__ __device__ inline int attn_np16(int N) { return (N + 15) & ~15; }
+__host__ __device__ inline int attn_lds_floats(int N) {
+    const int np = attn_np16(N);
+    return np * KROW + HD * (np + 4) + np;
+}
+
+template <int MAXKT>
+__global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
+                                                         float* __restrict__ out, int N, int D, int heads) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int np = attn_np16(N), nkt = np >> 4, npv = np + 4;
+    float* const Ks = lds;              // [np][KROW]
+    float* const Vt = Ks + np * KROW;   // [HD][npv]
+    float* const mb = Vt + HD * npv;    // [np]: 0 for a valid key, -inf for a padded one
+    const int jet = blockIdx.x / heads, h = blockIdx.x - jet * heads;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
+    const int ld = 3 * D;
+    const float* base = qkv + (int64_t)jet * N * ld + h * HD;
+
+    for (int idx = tid; idx < np * 4; idx += 256) {
+        const int key = idx >> 2, part = idx & 3;
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+        if (key < N) {
+            kv = *reinterpret_cast<const f32x4*>(base + (int64_t)key * ld + D + 4 * part);
+            vv = *reinterpret_cast<const f32x4*>(base + (int64_t)key * ld + 2 * D + 4 * part);
+        }
+        *reinterpret_cast<f32x4*>(Ks + key * KROW + 4 * part) = kv;
+        Vt[(4 * part + 0) * npv + key] = vv.x;
+        Vt[(4 * part + 1) * npv + key] = vv.y;
+        Vt[(4 * part + 2) * npv + key] = vv.z;
+        Vt[(4 * part + 3) * npv + key] = vv.w;
+    }
+    for (int key = tid; key < np; key += 256) {
+        const bool ok = key < N && (mask == nullptr || mask[(int64_t)jet * N + key] != 0.f);
+        mb[key] = ok ? 0.f : -__builtin_inff();
+    }
+    __syncthreads();
+
+    for (int qt = w; qt < nkt; qt += 4) {
+        const int qrow = min(qt * 16 + pl, N - 1);
+        f32x4 Qf = *reinterpret_cast<const f32x4*>(base + (int64_t)qrow * ld + 4 * q);
+        Qf *= 0.25f;  // 1/sqrt(16), exact
+        f32x4 s[MAXKT];
+        // S^T tile kt: rows = keys 16kt + 4q + r, column = query pl
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt) {
+            if (kt < nkt) {
+                const f32x4 Kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + pl) * KROW + 4 * q);
+                f32x4 c = *reinterpret_cast<const f32x4*>(mb + 16 * kt + 4 * q);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(Kf.x, Qf.x, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(Kf.y, Qf.y, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(Kf.z, Qf.z, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(Kf.w, Qf.w, c, 0, 0, 0);
+                s[kt] = c;
+            }
+        }
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt)
+            if (kt < nkt) m = fmaxf(fmaxf(fmaxf(s[kt].x, s[kt].y), fmaxf(s[kt].z, s[kt].w)), m);
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt)
+            if (kt < nkt) {
+                s[kt].x = __expf(s[kt].x - m); s[kt].y = __expf(s[kt].y - m);
+                s[kt].z = __expf(s[kt].z - m); s[kt].w = __expf(s[kt].w - m);
+                l += hsum4(s[kt]);
+            }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        // O^T = V^T P^T: A = Vt rows (d = pl) x keys, B = this lane's own P values
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt) {
+            if (kt < nkt) {
+                const f32x4 Vf = *reinterpret_cast<const f32x4*>(Vt + pl * npv + 16 * kt + 4 * q);
+                const f32x4 p = s[kt] * inv;
+                if (kt & 1) {
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.x, p.x, o1, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.y, p.y, o1, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.z, p.z, o1, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.w, p.w, o1, 0, 0, 0);
+                } else {
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.x, p.x, o0, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.y, p.y, o0, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.z, p.z, o0, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.w, p.w, o0, 0, 0, 0);
+                }
+            }
+        }
+        const int orow = qt * 16 + pl;
+        if (orow < N)
+            *reinterpret_cast<f32x4*>(out + ((int64_t)jet * N + orow) * D + h * HD + 4 * q) = o0 + o1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Output head: LayerNorm(hidden) then F dot products; optional fused state update  dst = base + coef*dt*v
+// ------------------------------------------------------------------------------------------------
+struct HeadArgs {
+    const float* A;  // [M][Hd] outp_embd hidden (post-activation)
+    const float* blob;
+    const float* base;  // state the update starts from, or nullptr: dst = v
+    const float* dt;    // device scalar (with base)
+    float* dst;
+    float* v_out;  // optional raw field
+    int64_t gamma, beta, W, b;
+    int M, Hd, F;
+    float eps, coef;
+};
+
+__global__ __launch_bounds__(256) void tf_head_kernel(HeadArgs a) {
+    const int tid = threadIdx.x, pl = tid & 15;
+    const int row = blockIdx.x * 16 + (tid >> 4);
+    const int rowc = min(row, a.M - 1);
+    const float* ap = a.A + (int64_t)rowc * a.Hd + 4 * pl;
+    f32x4 v[MAXK / 64];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXK / 64; ++i)
+        if (64 * i < a.Hd) {
+            v[i] = *reinterpret_cast<const f32x4*>(ap + 64 * i);
+            s += hsum4(v[i]);
+        }
+    const float mean = row_sum16(s) / (float)a.Hd;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXK / 64; ++i)
+        if (64 * i < a.Hd) {
+            const f32x4 dl = v[i] - mean;
+            ss += hsum4(dl * dl);
+        }
+    const float rstd = 1.0f / sqrtf(row_sum16(ss) / (float)a.Hd + a.eps);
+#pragma unroll
+    for (int i = 0; i < MAXK / 64; ++i)
+        if (64 * i < a.Hd) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + 4 * pl + 64 * i);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 4 * pl + 64 * i);
+            v[i] = (v[i] - mean) * rstd * g4 + b4;
+        }
+    for (int f = 0; f < a.F; ++f) {
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXK / 64; ++i)
+            if (64 * i < a.Hd) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.blob + a.W + (int64_t)f * a.Hd + 4 * pl + 64 * i);
+                d += hsum4(v[i] * w4);
+            }
+        d = row_sum16(d) + a.blob[a.b + f];
+        if (pl == (f & 15) && row < a.M) {
+            const int64_t e = (int64_t)row * a.F + f;
+            if (a.v_out) a.v_out[e] = d;
+            if (a.base) a.dst[e] = __fadd_rn(a.base[e], __fmul_rn(__fmul_rn(a.coef, a.dt[0]), d));
+            else if (a.dst) a.dst[e] = d;
+        }
+    }
+}
+
+// x = z * mask (SetFlowMatchingLitModule.sample, flow_matching_module.py:668-671)
+__global__ void tf_premask_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
+                                  int64_t n, int F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = mask ? z[i] * mask[i / F] : z[i];
+}
+
+}  // namespace tf
+}  // namespace pfm

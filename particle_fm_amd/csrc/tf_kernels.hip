@@ -1,0 +1,202 @@
+// gfx950 kernels + C ABI (include/pfm_tf.h): Full-Transformer vector field, midpoint sampler, FM/CFM loss.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "tf_fwd.h"
+#include "tf_bwd.h"
+
+namespace pfm {
+int set_err(int code, const char* what);
+int check_hip(hipError_t e, const char* where);
+
+namespace tf {
+
+int validate(const pfm_tf_desc* d) {
+    if (!d) return set_err(PFM_E_BADARG, "desc is NULL");
+    if (d->abi_version != PFM_TF_ABI_VERSION) return set_err(PFM_E_BADARG, "tf desc.abi_version mismatch");
+    if (d->model_dim < 128 || d->model_dim > MAXK || d->model_dim % 128)
+        return set_err(PFM_E_BADARG, "model_dim must be a multiple of 128 in 128..512");
+    if (d->hidden < 128 || d->hidden > MAXK || d->hidden % 128)
+        return set_err(PFM_E_BADARG, "hidden must be a multiple of 128 in 128..512");
+    if (d->head_dim != HD || d->heads * HD != d->model_dim)
+        return set_err(PFM_E_BADARG, "this build is specialised for head_dim = 16 (heads = model_dim / 16)");
+    if (d->layers < 1 || d->layers > PFM_TF_MAX_LAYERS) return set_err(PFM_E_BADARG, "layers out of range");
+    if (d->features < 1 || d->features > 16) return set_err(PFM_E_BADARG, "features must be in 1..16");
+    if (d->t_dim < 1 || d->t_dim > 64) return set_err(PFM_E_BADARG, "t_dim must be in 1..64");
+    if (d->cond_dim < 0 || d->cond_dim > 16) return set_err(PFM_E_BADARG, "cond_dim must be in 0..16");
+    if (d->ctxt_dim < 4 || d->ctxt_dim > 64 || d->ctxt_dim % 4) return set_err(PFM_E_BADARG, "ctxt_dim must be a multiple of 4 in 4..64");
+    if (d->ctxt_hidden < 4 || d->ctxt_hidden > 512 || d->ctxt_hidden % 4)
+        return set_err(PFM_E_BADARG, "ctxt_hidden must be a multiple of 4 in 4..512");
+    if (d->n_points < 1 || d->n_points > 512) return set_err(PFM_E_BADARG, "n_points must be in 1..512");
+    return 0;
+}
+
+struct Plan {
+    const pfm_tf_desc* d;
+    const float* blob;
+    float* ws;
+    Ws w;
+    int n_jets, M;
+    hipStream_t s;
+};
+
+int launch_linear(const Plan& p, const float* A, int lda, int K, const pfm_tf_lin& lin, const pfm_tf_norm* ln, int NO,
+                  const float* jb, const float* R, int ldr, float* out, int ldo, bool act) {
+    LinArgs a;
+    a.A = A; a.blob = p.blob; a.jb = jb; a.R = R; a.out = out;
+    a.blob_floats = p.d->blob_floats; a.W = lin.W; a.b = lin.b;
+    a.gamma = ln ? ln->gamma : -1; a.beta = ln ? ln->beta : -1;
+    a.jb_stride = (int64_t)(p.d->layers + 2) * p.d->hidden;
+    a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.M = p.M; a.K = K; a.NO = NO; a.N = p.d->n_points; a.act = act ? 1 : 0;
+    a.row_tiles = (p.M + BM - 1) / BM;
+    a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
+    const int grid = ((a.row_tiles + 7) / 8) * 8 * (NO / BN);
+    const size_t lds = (BM * 128 + 2 * BM) * sizeof(float);
+    if (ln && ln->gamma >= 0)
+        hipLaunchKernelGGL(tf_linear_kernel<true>, dim3(grid), dim3(LT), lds, p.s, a);
+    else
+        hipLaunchKernelGGL(tf_linear_kernel<false>, dim3(grid), dim3(LT), lds, p.s, a);
+    return check_hip(hipGetLastError(), "tf_linear_kernel launch");
+}
+
+int launch_attn(const Plan& p, const float* qkv, const float* mask, float* out) {
+    const int N = p.d->n_points, D = p.d->model_dim, heads = p.d->heads;
+    const size_t lds = (size_t)attn_lds_floats(N) * sizeof(float);
+    const int nkt = attn_np16(N) / 16;
+    const dim3 grid(p.n_jets * heads), block(256);
+    if (nkt <= 12)
+        hipLaunchKernelGGL(tf_attn_kernel<12>, grid, block, lds, p.s, qkv, mask, out, N, D, heads);
+    else if (nkt <= 18)
+        hipLaunchKernelGGL(tf_attn_kernel<18>, grid, block, lds, p.s, qkv, mask, out, N, D, heads);
+    else
+        hipLaunchKernelGGL(tf_attn_kernel<32>, grid, block, lds, p.s, qkv, mask, out, N, D, heads);
+    return check_hip(hipGetLastError(), "tf_attn_kernel launch");
+}
+
+int set_attn_lds() {
+    static bool done = false;
+    if (done) return 0;
+    const int big = attn_lds_floats(512) * 4;
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(tf_attn_kernel<32>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, big), "hipFuncSetAttribute(attn)");
+    if (rc) return rc;
+    rc = attn_bwd_set_lds();
+    if (rc) return rc;
+    done = true;
+    return 0;
+}
+
+// One evaluation of the field for all jets.  x: network input [M][F].  The head either writes v (head.dst = v,
+// base = nullptr) or applies a state update.
+int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const float* cond, const float* mask,
+            const HeadArgs& head_tpl) {
+    const pfm_tf_desc& d = *p.d;
+    const Ws& w = p.w;
+    float* ws = p.ws;
+    const int D = d.model_dim, Hd = d.hidden, nb = d.layers + 2;
+    int rc;
+    {
+        CtxtArgs a;
+        a.blob = p.blob; a.t = t; a.cond = cond;
+        a.temb = ws + w.temb; a.chid = ws + w.chid; a.ctxt = ws + w.ctxt; a.jb = ws + w.jb;
+        a.t_stride = t_stride; a.T = d.t_dim; a.C = d.cond_dim; a.CH = d.ctxt_hidden; a.CO = d.ctxt_dim; a.Hd = Hd; a.nb = nb;
+        a.slope = d.neg_slope; a.eps = d.ln_eps;
+        a.freqs = d.freqs; a.c1W = d.c1.W; a.c1b = d.c1.b; a.cg = d.c_norm.gamma; a.cb = d.c_norm.beta;
+        a.c2W = d.c2.W; a.c2b = d.c2.b; a.n1Wt = d.time_in_input ? d.n1.Wt : -1;
+        a.Wc[0] = d.n1.Wc; a.bb[0] = d.n1.b;
+        for (int l = 0; l < d.layers; ++l) { a.Wc[1 + l] = d.layer[l].d1.Wc; a.bb[1 + l] = d.layer[l].d1.b; }
+        a.Wc[nb - 1] = d.o1.Wc; a.bb[nb - 1] = d.o1.b;
+        hipLaunchKernelGGL(tf_ctxt_kernel, dim3(p.n_jets), dim3(512), 0, p.s, a);
+        if ((rc = check_hip(hipGetLastError(), "tf_ctxt_kernel launch"))) return rc;
+    }
+    const float* jb = ws + w.jb;
+    hipLaunchKernelGGL(tf_embed_kernel, dim3((p.M + 31) / 32), dim3(256), 0, p.s, p.blob, d.n1.W, x, jb, (int64_t)nb * Hd,
+                       ws + w.h1, p.M, d.n_points, d.features, Hd, d.neg_slope);
+    if ((rc = check_hip(hipGetLastError(), "tf_embed_kernel launch"))) return rc;
+    if ((rc = launch_linear(p, ws + w.h1, Hd, Hd, d.n2, &d.n_norm, D, nullptr, nullptr, 0, ws + w.x0, D, false))) return rc;
+    const float* xin = ws + w.x0;
+    for (int l = 0; l < d.layers; ++l) {
+        const pfm_tf_layer& L = d.layer[l];
+        float* lb = ws + w.layer0 + w.lstride * l;
+        float *qkv = lb + w.o_qkv, *att = lb + w.o_att, *xmid = lb + w.o_xmid, *dh = lb + w.o_dh, *xout = lb + w.o_xout;
+        if ((rc = launch_linear(p, xin, D, D, L.qkv, &L.norm1, 3 * D, nullptr, nullptr, 0, qkv, 3 * D, false))) return rc;
+        if ((rc = launch_attn(p, qkv, mask, att))) return rc;
+        if ((rc = launch_linear(p, att, D, D, L.out, &L.attn_norm, D, nullptr, xin, D, xmid, D, false))) return rc;
+        if ((rc = launch_linear(p, xmid, D, D, L.d1, &L.norm2, Hd, jb + (int64_t)(1 + l) * Hd, nullptr, 0, dh, Hd, true))) return rc;
+        if ((rc = launch_linear(p, dh, Hd, Hd, L.d2, &L.d_norm, D, nullptr, xmid, D, xout, D, false))) return rc;
+        xin = xout;
+    }
+    if ((rc = launch_linear(p, xin, D, D, d.o1, &d.final_norm, Hd, jb + (int64_t)(nb - 1) * Hd, nullptr, 0, ws + w.oh, Hd, true)))
+        return rc;
+    HeadArgs h = head_tpl;
+    h.A = ws + w.oh; h.blob = p.blob;
+    h.gamma = d.o_norm.gamma; h.beta = d.o_norm.beta; h.W = d.o2.W; h.b = d.o2.b;
+    h.M = p.M; h.Hd = Hd; h.F = d.features; h.eps = d.ln_eps;
+    hipLaunchKernelGGL(tf_head_kernel, dim3((p.M + 15) / 16), dim3(256), 0, p.s, h);
+    return check_hip(hipGetLastError(), "tf_head_kernel launch");
+}
+
+int make_plan(Plan& p, const pfm_tf_desc* d, const float* blob, float* ws, int n_jets, bool train, void* stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    if ((rc = set_attn_lds())) return rc;
+    p.d = d; p.blob = blob; p.ws = ws; p.n_jets = n_jets; p.M = n_jets * d->n_points; p.s = (hipStream_t)stream;
+    p.w = make_ws(*d, n_jets, train);
+    return 0;
+}
+
+}  // namespace tf
+}  // namespace pfm
+
+using namespace pfm;
+using namespace pfm::tf;
+
+extern "C" {
+
+int64_t pfm_tf_workspace_floats(const pfm_tf_desc* d, int32_t n_jets, int32_t train) {
+    if (validate(d)) return -1;
+    return make_ws(*d, n_jets < 1 ? 1 : n_jets, train != 0).total;
+}
+
+int pfm_tf_forward(const pfm_tf_desc* d, const float* blob, const float* t, int32_t t_stride, const float* x,
+                   const float* cond, const float* mask, float* v, int32_t n_jets, float* workspace, void* stream) {
+    Plan p;
+    int rc = make_plan(p, d, blob, workspace, n_jets, false, stream);
+    if (rc) return rc;
+    if (n_jets <= 0) return 0;
+    if (!blob || !t || !x || !v || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
+    HeadArgs h{};
+    h.dst = v;
+    return run_nfe(p, t, t_stride ? 1 : 0, x, cond, mask, h);
+}
+
+int pfm_tf_sample_midpoint(const pfm_tf_desc* d, const float* blob, const float* t_eval, const float* dt,
+                           int32_t n_steps, const float* z, const float* cond, const float* mask, float* x_out,
+                           int32_t n_jets, int32_t premask, float* state, float* workspace, void* stream) {
+    Plan p;
+    int rc = make_plan(p, d, blob, workspace, n_jets, false, stream);
+    if (rc) return rc;
+    if (n_jets <= 0) return 0;
+    if (!blob || !t_eval || !dt || !z || !x_out || !state || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (n_steps < 0) return set_err(PFM_E_BADARG, "n_steps < 0");
+    if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
+    const int64_t n = (int64_t)p.M * d->features;
+    float* xs = state;
+    float* xm = state + n;
+    hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, xs, n,
+                       d->features);
+    if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+    for (int k = 0; k < n_steps; ++k) {
+        // k1 = f(t_k, x); x_mid = x + 0.5 dt k1; x <- x + dt f(t_k + dt/2, x_mid)
+        HeadArgs h{};
+        h.base = xs; h.dt = dt + k; h.coef = 0.5f; h.dst = xm;
+        if ((rc = run_nfe(p, t_eval + 2 * k, 0, xs, cond, mask, h))) return rc;
+        h.coef = 1.0f; h.dst = xs;
+        if ((rc = run_nfe(p, t_eval + 2 * k + 1, 0, xm, cond, mask, h))) return rc;
+    }
+    return check_hip(hipMemcpyAsync(x_out, xs, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_out");
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+"""Tensor-level wrappers over the transformer part of the C ABI (include/pfm_tf.h).
+
+PyTorch owns device memory and the stream; every number comes out of libpfm_hip.so.  No CPU path."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .hip_ops import _dev_f32, _ptr, _stream_ptr, midpoint_grid
+from .layout_tf import TfLayout
+
+
+def _prep(layout: TfLayout, blob, x, cond, mask):
+    cfg = layout.cfg
+    if not x.is_cuda:
+        raise RuntimeError("HIP backend needs tensors on a ROCm device; there is no CPU fallback")
+    dev = x.device
+    B, N, F = x.shape
+    if N != cfg.num_particles or F != cfg.features:
+        raise ValueError(f"x has shape {tuple(x.shape)}, model expects (*, {cfg.num_particles}, {cfg.features})")
+    blob = _dev_f32("blob", blob, dev, (layout.blob_total,))
+    x = _dev_f32("x", x, dev)
+    if cfg.global_cond_dim > 0:
+        if cond is None:
+            raise ValueError("global_cond_dim > 0 but no cond given")
+        cond = _dev_f32("cond", cond, dev, (B, cfg.global_cond_dim))
+    else:
+        cond = None
+    if mask is not None:
+        mask = _dev_f32("mask", mask.reshape(B, N), dev, (B, N))
+    return dev, B, blob, x, cond, mask
+
+
+def workspace(layout: TfLayout, n_jets: int, device, train: bool = False) -> torch.Tensor:
+    """Activation workspace; cached per (n_jets, train) on the layout (the kernels fully overwrite what they read)."""
+    lib = _lib.load()
+    cache = layout.__dict__.setdefault("_ws", {})
+    key = (n_jets, bool(train), str(device))
+    if key not in cache:
+        n = lib.pfm_tf_workspace_floats(ctypes.byref(layout.desc), n_jets, int(train))
+        if n < 0:
+            _lib.check(1, "pfm_tf_workspace_floats")
+        for k in [k for k in cache if k[1] == key[1] and k[2] == key[2]]:
+            del cache[k]
+        cache[key] = torch.empty(n, device=device, dtype=torch.float32)
+    return cache[key]
+
+
+def tf_forward(layout: TfLayout, blob, t, x, cond=None, mask=None) -> torch.Tensor:
+    """v = FullTransformer(t, x, cond, mask).  t: (B,) one time per jet, or 0-dim / (1,) for one shared time."""
+    lib = _lib.load()
+    dev, B, blob, x, cond, mask = _prep(layout, blob, x, cond, mask)
+    t = _dev_f32("t", t.reshape(-1), dev)
+    if t.numel() not in (1, B):
+        raise ValueError(f"t has {t.numel()} elements, expected 1 or {B}")
+    v = torch.empty_like(x)
+    ws = workspace(layout, B, dev)
+    rc = lib.pfm_tf_forward(ctypes.byref(layout.desc), _ptr(blob), _ptr(t), 1 if (t.numel() == B and B > 1) else 0, _ptr(x),
+                            _ptr(cond), _ptr(mask), _ptr(v), B, _ptr(ws), _stream_ptr(dev))
+    _lib.check(rc, "pfm_tf_forward")
+    return v
+
+
+def tf_sample_midpoint(layout: TfLayout, blob, z, cond=None, mask=None, ode_steps: int = 100,
+                       premask: bool = True) -> torch.Tensor:
+    """x(0) from x(1) = z (*mask) by ode_steps-1 explicit-midpoint intervals (2 NFE each), all launches queued on
+    the current stream without a host sync."""
+    lib = _lib.load()
+    dev, B, blob, z, cond, mask = _prep(layout, blob, z, cond, mask)
+    if ode_steps < 2:
+        raise ValueError("ode_steps must be >= 2")
+    ts, dts = midpoint_grid(ode_steps)
+    ts, dts = ts.to(dev), dts.to(dev)
+    out = torch.empty_like(z)
+    state = torch.empty(2 * z.numel(), device=dev, dtype=torch.float32)
+    ws = workspace(layout, B, dev)
+    rc = lib.pfm_tf_sample_midpoint(ctypes.byref(layout.desc), _ptr(blob), _ptr(ts), _ptr(dts), ode_steps - 1, _ptr(z),
+                                    _ptr(cond), _ptr(mask), _ptr(out), B, int(bool(premask and mask is not None)),
+                                    _ptr(state), _ptr(ws), _stream_ptr(dev))
+    _lib.check(rc, "pfm_tf_sample_midpoint")
+    return out

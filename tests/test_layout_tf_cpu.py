@@ -1,0 +1,54 @@
+"""layout_tf.py: descriptor, gather maps and blob formats, checked on the CPU against the reference vectors."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from particle_fm_amd.layout_tf import TfConfig, TfDesc, TfLayout
+from tests import tf_blob_interp
+
+
+def _layout(g):
+    return TfLayout(TfConfig.from_hparams(g.hp))
+
+
+def test_state_dict_order_and_count(tf_golden):
+    lay = _layout(tf_golden)
+    assert lay.keys("flows.0.") == [k for k in tf_golden.keys if not k.endswith("frequencies")]
+    assert lay.n_params == sum(v.numel() for k, v in tf_golden.state.items() if not k.endswith("frequencies"))
+    if tf_golden.name == "lhco":
+        assert lay.n_params == 2_088_515
+
+
+def test_blob_evaluates_to_reference(tf_golden):
+    g = tf_golden
+    lay = _layout(g)
+    blob = lay.pack_blob(g.state, "flows.0.", g.freqs)
+    assert blob.numel() == lay.blob_total
+    tag = "nfe_f32/"
+    x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))
+    v = tf_blob_interp.forward(lay.desc, blob, t, x, cond, mask.reshape(x.shape[0], -1).float())
+    torch.testing.assert_close(v, g.get(tag + "v_vec_t"), rtol=2e-4, atol=2e-5)
+
+
+def test_grad_pos_is_a_bijection_onto_primary_slots(tf_golden):
+    lay = _layout(tf_golden)
+    gp = lay.grad_pos
+    assert gp.shape == (lay.n_params,) and len(np.unique(gp)) == lay.n_params
+    # a gradient blob that holds "its own source index" at every slot gathers back to arange
+    assert np.array_equal(lay.index_map[gp], np.arange(lay.n_params))
+
+
+def test_desc_size_matches_header():
+    # pfm_tf_desc: 14 int32 + 2 float + 2 int64 + 6 lin + 4 norm + 12 layers (4 norm + 4 lin) + ...
+    lin, nrm = 5 * 8, 2 * 8
+    expect = 14 * 4 + 2 * 4 + 2 * 8 + (3 * lin + nrm * 1) + (2 * lin + nrm) + 12 * (4 * nrm + 4 * lin) + (nrm + lin + nrm + lin)
+    assert ctypes.sizeof(TfDesc) == expect - (3 * lin + nrm) + (2 * lin + nrm)
+
+
+def test_unsupported_configs_are_rejected():
+    with pytest.raises(NotImplementedError):
+        TfLayout(TfConfig(num_particles=30, model_dim=64, num_heads=4, hidden=128))
+    with pytest.raises(NotImplementedError):
+        TfLayout(TfConfig(num_particles=30, model_dim=256, num_heads=8))
