@@ -1,9 +1,615 @@
-// Backward kernels of the Full-Transformer vector field (gfx950).
+// Backward kernels of the Full-Transformer vector field under the FM / CFM loss (gfx950, fp32 MFMA).
+//
+// The forward keeps, per layer, x_in, qkv, att (pre-norm attention output), x_mid, dh (dense hidden, post-
+// activation) in the train workspace; LayerNorm statistics, attention probabilities and the normalised operands are
+// recomputed.  For every Linear  Z = LN(A) W^T + b (+ jet bias)  with upstream gradient dZ:
+//   db   column sums                      tf_colsum_kernel (one workgroup per jet; also the per-jet sums that feed the
+//                                         context path, and the F-column products of node_embd / the output head)
+//   dW   dZ^T LN(A)   (k = particles)     tf_dw_kernel: 128 x 128 tile of dW per workgroup, both operands staged
+//                                         through LDS row-major so that ONE ds_read_b128 per operand feeds 16 MFMAs
+//                                         (4 output groups x 4 feature groups); partial sums -> fp32 atomics on the
+//                                         gradient blob, in the weight's own MFMA_AK order
+//   dLN  dZ W          (k = outputs)      the forward Linear kernel on the MFMA_AKT copy of W
+//   dA   LayerNorm backward (+ residual gradient, + LeakyReLU' of the producer)   tf_ln_bwd_kernel, 16 lanes per row
+// Attention backward is two kernels per (jet, head): A recomputes S^T / P^T per query tile (as the forward), forms
+// dS^T in registers and accumulates dQ; B walks key tiles with S / P in the transposed register layout so that dK
+// and dV reduce over queries on MFMA.  Row statistics (max, sum, delta) travel from A to B through the scratch.
 #pragma once
-#include "tf_common.h"
+#include "tf_fwd.h"
 
 namespace pfm {
 namespace tf {
-inline int attn_bwd_set_lds() { return 0; }
+
+// ------------------------------------------------------------------------------------------------
+// loss pieces (losses.py:38-77, 101-136)
+// ------------------------------------------------------------------------------------------------
+__global__ void tf_yu_kernel(int kind, float sigma, const float* __restrict__ t, const float* __restrict__ x,
+                             const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mask,
+                             float* __restrict__ y, float* __restrict__ u, int64_t n, int NF, int F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float tj = t[i / NF];
+    const float m = mask ? mask[i / F] : 1.0f;
+    const float xv = x[i], zv = a[i];
+    const float one_m_sigma = (float)(1.0 - (double)sigma);  // python computes (1 - sigma) in double
+    if (kind == 0) {
+        const float p = __fmul_rn(__fsub_rn(1.0f, tj), xv);
+        const float q = __fmul_rn(__fadd_rn(sigma, __fmul_rn(one_m_sigma, tj)), zv);
+        y[i] = __fadd_rn(p, q);
+        u[i] = __fmul_rn(__fsub_rn(__fmul_rn(one_m_sigma, zv), xv), m);
+    } else {
+        const float mu = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, tj), xv), __fmul_rn(tj, zv));
+        y[i] = __fadd_rn(mu, __fmul_rn(sigma, b[i]));
+        u[i] = __fmul_rn(__fsub_rn(zv, xv), m);
+    }
+}
+
+// sums[0] += sum (v-u)^2 ; sums[1] += sum mask
+__global__ __launch_bounds__(256) void tf_loss_kernel(const float* __restrict__ v, const float* __restrict__ u,
+                                                      const float* __restrict__ mask, float* __restrict__ sums,
+                                                      int64_t n, int64_t rows) {
+    __shared__ float red[8];
+    float sq = 0.f, mc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = v[i] - u[i];
+        sq = fmaf(d, d, sq);
+        if (i < rows) mc += mask ? mask[i] : 1.0f;
+    }
+    sq = wave_sum(sq);
+    mc = wave_sum(mc);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sq; red[4 + (threadIdx.x >> 6)] = mc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sums, red[0] + red[1] + red[2] + red[3]);
+        atomicAdd(sums + 1, red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm row statistics (mean, rstd) of A[M][K]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tf_rowstats_kernel(const float* __restrict__ A, int lda, int M, int K, float eps,
+                                                          float* __restrict__ stats) {
+    const int tid = threadIdx.x, pl = tid & 15;
+    const int row = blockIdx.x * 16 + (tid >> 4);
+    const float* ap = A + (int64_t)min(row, M - 1) * lda + 4 * pl;
+    f32x4 v[MAXK / 64];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXK / 64; ++i)
+        if (64 * i < K) { v[i] = *reinterpret_cast<const f32x4*>(ap + 64 * i); s += hsum4(v[i]); }
+    const float mean = row_sum16(s) / (float)K;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXK / 64; ++i)
+        if (64 * i < K) { const f32x4 dl = v[i] - mean; ss += hsum4(dl * dl); }
+    const float rstd = 1.0f / sqrtf(row_sum16(ss) / (float)K + eps);
+    if (pl == 0 && row < M) { stats[2 * (int64_t)row] = mean; stats[2 * (int64_t)row + 1] = rstd; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward (row-wise), optionally fed by the output head
+// ------------------------------------------------------------------------------------------------
+struct LnBwdArgs {
+    const float* A;      // [M][K] input of the LayerNorm (a saved activation)
+    const float* G;      // [M][K] gradient w.r.t. the LayerNorm output; unused when HEAD
+    const float* add;    // [M][K] gradient joining from the residual path, or nullptr (may alias out)
+    float* out;          // [M][K] gradient w.r.t. A, times LeakyReLU'(A) when act
+    float* nout;         // HEAD: the normalised rows (input of the head's Linear), [M][K]
+    const float *v, *u, *gscale;  // HEAD: field, target, scalar grad_out / sum(mask)
+    float* dv;           // HEAD: 2 (v-u) gscale, [M][F]
+    const float* blob;
+    float* gblob;
+    int64_t gamma, beta, W3, b3;
+    int M, K, F, act;
+    float slope, eps;
+};
+
+template <bool HEAD>
+__global__ __launch_bounds__(256) void tf_ln_bwd_kernel(LnBwdArgs a) {
+    __shared__ float red[16 * MAXK];
+    __shared__ float db3[16];
+    const int tid = threadIdx.x, pl = tid & 15, rg = tid >> 4;
+    if (HEAD) {
+        if (tid < 16) db3[tid] = 0.f;
+        __syncthreads();
+    }
+    constexpr int NI = MAXK / 64;
+    f32x4 gsum[NI], bsum[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { gsum[i] = f32x4{0.f, 0.f, 0.f, 0.f}; bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const float invK = 1.0f / (float)a.K;
+    const float gs = HEAD ? a.gscale[0] : 0.f;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = blockIdx.x * 64 + 16 * pass + rg;
+        const bool ok = row < a.M;
+        const int64_t ro = (int64_t)min(row, a.M - 1) * a.K + 4 * pl;
+        f32x4 x[NI], dn[NI];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (64 * i < a.K) { x[i] = *reinterpret_cast<const f32x4*>(a.A + ro + 64 * i); s += hsum4(x[i]); }
+        const float mean = row_sum16(s) * invK;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (64 * i < a.K) { const f32x4 dl = x[i] - mean; ss += hsum4(dl * dl); }
+        const float rstd = 1.0f / sqrtf(row_sum16(ss) * invK + a.eps);
+        if (HEAD) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) dn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int f = 0; f < a.F; ++f) {
+                const int64_t e = (int64_t)min(row, a.M - 1) * a.F + f;
+                const float d = ok ? 2.0f * (a.v[e] - a.u[e]) * gs : 0.f;
+                if (pl == 0 && ok) { a.dv[e] = d; atomicAdd(db3 + f, d); }
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (64 * i < a.K)
+                        dn[i] += d * *reinterpret_cast<const f32x4*>(a.blob + a.W3 + (int64_t)f * a.K + 4 * pl + 64 * i);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (64 * i < a.K) {
+                    dn[i] = *reinterpret_cast<const f32x4*>(a.G + ro + 64 * i);
+                    if (!ok) dn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        float c1 = 0.f, c2 = 0.f;
+        f32x4 xh[NI], g[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (64 * i < a.K) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + 4 * pl + 64 * i);
+                xh[i] = (x[i] - mean) * rstd;
+                if (HEAD && ok) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 4 * pl + 64 * i);
+                    *reinterpret_cast<f32x4*>(a.nout + ro + 64 * i) = xh[i] * g4 + b4;
+                }
+                g[i] = dn[i] * g4;
+                c1 += hsum4(g[i]);
+                c2 += hsum4(g[i] * xh[i]);
+                gsum[i] += dn[i] * xh[i];
+                bsum[i] += dn[i];
+            }
+        c1 = row_sum16(c1) * invK;
+        c2 = row_sum16(c2) * invK;
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (64 * i < a.K) {
+                    f32x4 dA = (g[i] - c1 - xh[i] * c2) * rstd;
+                    if (a.add) dA += *reinterpret_cast<const f32x4*>(a.add + ro + 64 * i);
+                    if (a.act) {
+                        dA.x *= x[i].x > 0.f ? 1.f : a.slope; dA.y *= x[i].y > 0.f ? 1.f : a.slope;
+                        dA.z *= x[i].z > 0.f ? 1.f : a.slope; dA.w *= x[i].w > 0.f ? 1.f : a.slope;
+                    }
+                    *reinterpret_cast<f32x4*>(a.out + ro + 64 * i) = dA;
+                }
+        }
+    }
+    if (HEAD) {
+        __syncthreads();
+        if (tid < a.F) atomicAdd(a.gblob + a.b3 + tid, db3[tid]);
+    }
+    // d gamma / d beta: reduce the 16 row groups through LDS, one atomic per column per workgroup
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (64 * i < a.K) *reinterpret_cast<f32x4*>(red + rg * a.K + 4 * pl + 64 * i) = which ? bsum[i] : gsum[i];
+        __syncthreads();
+        for (int c = tid; c < a.K; c += 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += red[r * a.K + c];
+            atomicAdd(a.gblob + (which ? a.beta : a.gamma) + c, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums per jet:  out[o] = sum_{rows of the jet} w(row) Z[row][o],  w = X[row][f] (f = blockIdx.y) or 1
+// ------------------------------------------------------------------------------------------------
+struct ColsumArgs {
+    const float* Z;
+    const float* X;     // [M][F] or nullptr
+    float* jet_out;     // [jet][jet_stride] plain store, or nullptr
+    float* gblob;
+    int64_t gb;         // gblob offset of an [F or 1][NO] block receiving the sum over all jets (atomic), or -1
+    int64_t jet_stride;
+    int ldz, NO, N, F;
+};
+
+__global__ __launch_bounds__(256) void tf_colsum_kernel(ColsumArgs a) {
+    __shared__ float red[4 * 768];
+    const int tid = threadIdx.x, cg = tid & 63, rg = tid >> 6;
+    const int jet = blockIdx.x, f = blockIdx.y;
+    const int col0 = blockIdx.z * 768;
+    const int ncol = min(768, a.NO - col0), nc4 = ncol >> 2;
+    f32x4 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = rg; r < a.N; r += 4) {
+        const int64_t row = (int64_t)jet * a.N + r;
+        const float w = a.X ? a.X[row * a.F + f] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (cg + 64 * i < nc4) acc[i] += w * *reinterpret_cast<const f32x4*>(a.Z + row * a.ldz + col0 + 4 * (cg + 64 * i));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (cg + 64 * i < nc4) *reinterpret_cast<f32x4*>(red + rg * 768 + 4 * (cg + 64 * i)) = acc[i];
+    __syncthreads();
+    for (int c = tid; c < ncol; c += 256) {
+        const float s = (red[c] + red[768 + c]) + (red[2 * 768 + c] + red[3 * 768 + c]);
+        if (a.jet_out) a.jet_out[(int64_t)jet * a.jet_stride + col0 + c] = s;
+        if (a.gb >= 0) atomicAdd(a.gblob + a.gb + (int64_t)f * a.NO + col0 + c, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW += dZ^T LN(A): one 128 x 128 tile of dW per workgroup, particles split over `nsplit` workgroups
+// ------------------------------------------------------------------------------------------------
+struct DwArgs {
+    const float* Z;      // [M][ldz] upstream gradient
+    const float* A;      // [M][lda] LayerNorm input
+    const float* stats;  // [M][2] mean, rstd of A's rows
+    const float* blob;
+    float* gblob;
+    int64_t gamma, beta, gW;
+    int ldz, lda, M, NO, K, nsplit, row_tiles;
+};
+
+constexpr int DWS = 132;  // LDS row stride (floats)
+
+__global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const zt = lds;             // [64][DWS]
+    float* const at = lds + 64 * DWS;  // [64][DWS]
+    const int nkc = a.K >> 7;
+    const int split = blockIdx.x % a.nsplit, tile = blockIdx.x / a.nsplit;
+    const int to = tile / nkc, tk = tile - to * nkc;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
+    const int wo = w >> 1, wk = w & 1;
+    const int sc4 = tid & 31, sr = tid >> 5;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[c][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + 128 * tk + 4 * sc4);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 128 * tk + 4 * sc4);
+#pragma unroll 1
+    for (int rt = split; rt < a.row_tiles; rt += a.nsplit) {
+        f32x4 zs[8], as[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = rt * BM + sr + 8 * i;
+            const int rc = min(row, a.M - 1);
+            zs[i] = *reinterpret_cast<const f32x4*>(a.Z + (int64_t)rc * a.ldz + 128 * to + 4 * sc4);
+            if (row >= a.M) zs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a.A + (int64_t)rc * a.lda + 128 * tk + 4 * sc4);
+            const float mean = a.stats[2 * (int64_t)rc], rstd = a.stats[2 * (int64_t)rc + 1];
+            as[i] = (av - mean) * rstd * g4 + b4;
+        }
+        __syncthreads();  // the previous tile has been consumed
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            *reinterpret_cast<f32x4*>(zt + (sr + 8 * i) * DWS + 4 * sc4) = zs[i];
+            *reinterpret_cast<f32x4*>(at + (sr + 8 * i) * DWS + 4 * sc4) = as[i];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const f32x4 dz = *reinterpret_cast<const f32x4*>(zt + (4 * ks + q) * DWS + 64 * wo + 4 * pl);
+            const f32x4 an = *reinterpret_cast<const f32x4*>(at + (4 * ks + q) * DWS + 64 * wk + 4 * pl);
+#define PFM_DW_ROW(c, zc)                                                                   \
+    acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc, an.x, acc[c][0], 0, 0, 0);         \
+    acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc, an.y, acc[c][1], 0, 0, 0);         \
+    acc[c][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc, an.z, acc[c][2], 0, 0, 0);         \
+    acc[c][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc, an.w, acc[c][3], 0, 0, 0);
+            PFM_DW_ROW(0, dz.x) PFM_DW_ROW(1, dz.y) PFM_DW_ROW(2, dz.z) PFM_DW_ROW(3, dz.w)
+#undef PFM_DW_ROW
+        }
+    }
+    // acc[c][e].r = dW[o][k] with o = 128 to + 64 wo + 4 (4q + r) + c, k = 128 tk + 64 wk + 4 pl + e
+    const int kb = 128 * tk + 64 * wk + 4 * pl;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 128 * to + 64 * wo + 4 * (4 * q + r) + c;
+            float* gp = a.gblob + a.gW + ((int64_t)((o >> 4) * nkc + (kb >> 7)) * 8 + ((kb >> 4) & 7)) * 256 +
+                        (((kb >> 2) & 3) * 16 + (o & 15)) * 4;
+            atomicAdd(gp + 0, acc[c][0][r]);
+            atomicAdd(gp + 1, acc[c][1][r]);
+            atomicAdd(gp + 2, acc[c][2][r]);
+            atomicAdd(gp + 3, acc[c][3][r]);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention backward
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline int attn_bwd_lds_floats(int N) {
+    const int np = attn_np16(N);
+    return 2 * HD * (np + 4) + 3 * np;
+}
+
+// A: per query tile, dQ and the row statistics (max, sum, delta = sum_d dO O)
+template <int MAXKT>
+__global__ __launch_bounds__(256, 2) void tf_attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
+                                                               const float* __restrict__ O, const float* __restrict__ dO,
+                                                               float* __restrict__ dqkv, float* __restrict__ stats,
+                                                               int N, int D, int heads) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int np = attn_np16(N), nkt = np >> 4, npv = np + 4;
+    float* const Kt = lds;             // [HD][npv]
+    float* const Vt = Kt + HD * npv;   // [HD][npv]
+    float* const mb = Vt + HD * npv;   // [np]
+    const int jet = blockIdx.x / heads, h = blockIdx.x - jet * heads;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
+    const int ld = 3 * D;
+    const float* base = qkv + (int64_t)jet * N * ld + h * HD;
+    for (int idx = tid; idx < np * 4; idx += 256) {
+        const int key = idx >> 2, part = idx & 3;
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+        if (key < N) {
+            kv = *reinterpret_cast<const f32x4*>(base + (int64_t)key * ld + D + 4 * part);
+            vv = *reinterpret_cast<const f32x4*>(base + (int64_t)key * ld + 2 * D + 4 * part);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Kt[(4 * part + e) * npv + key] = kv[e];
+            Vt[(4 * part + e) * npv + key] = vv[e];
+        }
+    }
+    for (int key = tid; key < np; key += 256) {
+        const bool ok = key < N && (mask == nullptr || mask[(int64_t)jet * N + key] != 0.f);
+        mb[key] = ok ? 0.f : -__builtin_inff();
+    }
+    __syncthreads();
+    float* const st = stats + (int64_t)blockIdx.x * 3 * np;
+    for (int qt = w; qt < nkt; qt += 4) {
+        const int qrow = min(qt * 16 + pl, N - 1);
+        const int64_t grow = (int64_t)jet * N + qrow;
+        f32x4 Qf = *reinterpret_cast<const f32x4*>(base + (int64_t)qrow * ld + 4 * q);
+        Qf *= 0.25f;
+        const f32x4 dOf = *reinterpret_cast<const f32x4*>(dO + grow * D + h * HD + 4 * q);
+        const f32x4 Of = *reinterpret_cast<const f32x4*>(O + grow * D + h * HD + 4 * q);
+        float delta = hsum4(dOf * Of);
+        delta += __shfl_xor(delta, 16);
+        delta += __shfl_xor(delta, 32);
+        f32x4 s[MAXKT];
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt)
+            if (kt < nkt) {
+                f32x4 c = *reinterpret_cast<const f32x4*>(mb + 16 * kt + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(Kt[(4 * q + e) * npv + 16 * kt + pl], Qf[e], c, 0, 0, 0);
+                s[kt] = c;
+            }
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt)
+            if (kt < nkt) m = fmaxf(fmaxf(fmaxf(s[kt].x, s[kt].y), fmaxf(s[kt].z, s[kt].w)), m);
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt)
+            if (kt < nkt) {
+                s[kt].x = __expf(s[kt].x - m); s[kt].y = __expf(s[kt].y - m);
+                s[kt].z = __expf(s[kt].z - m); s[kt].w = __expf(s[kt].w - m);
+                l += hsum4(s[kt]);
+            }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        if (q == 0 && qt * 16 + pl < N) {
+            st[qt * 16 + pl] = m;
+            st[np + qt * 16 + pl] = l;
+            st[2 * np + qt * 16 + pl] = delta;
+        }
+        f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < MAXKT; ++kt)
+            if (kt < nkt) {
+                // dP^T tile: rows = keys, column = query
+                f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    dp = __builtin_amdgcn_mfma_f32_16x16x4f32(Vt[(4 * q + e) * npv + 16 * kt + pl], dOf[e], dp, 0, 0, 0);
+                const f32x4 ds = s[kt] * inv * (dp - delta) * 0.25f;
+                const f32x4 Kf = *reinterpret_cast<const f32x4*>(Kt + pl * npv + 16 * kt + 4 * q);
+                if (kt & 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Kf[e], ds[e], dq1, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Kf[e], ds[e], dq0, 0, 0, 0);
+                }
+            }
+        if (qt * 16 + pl < N) *reinterpret_cast<f32x4*>(dqkv + grow * ld + h * HD + 4 * q) = dq0 + dq1;
+    }
+}
+
+// B: per key tile, dK and dV (reductions over the queries)
+__global__ __launch_bounds__(256, 2) void tf_attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
+                                                                const float* __restrict__ dO, const float* __restrict__ stats,
+                                                                float* __restrict__ dqkv, int N, int D, int heads) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int np = attn_np16(N), nkt = np >> 4, npv = np + 4;
+    float* const Qt = lds;              // [HD][npv]
+    float* const dOt = Qt + HD * npv;   // [HD][npv]
+    float* const sm = dOt + HD * npv;   // [np] row max (+inf for padded queries: their P is 0)
+    float* const sl = sm + np;          // [np] 1 / row sum
+    float* const sd = sl + np;          // [np] delta
+    const int jet = blockIdx.x / heads, h = blockIdx.x - jet * heads;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
+    const int ld = 3 * D;
+    const float* base = qkv + (int64_t)jet * N * ld + h * HD;
+    for (int idx = tid; idx < np * 4; idx += 256) {
+        const int qr = idx >> 2, part = idx & 3;
+        f32x4 qv = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+        if (qr < N) {
+            qv = *reinterpret_cast<const f32x4*>(base + (int64_t)qr * ld + 4 * part);
+            dv = *reinterpret_cast<const f32x4*>(dO + ((int64_t)jet * N + qr) * D + h * HD + 4 * part);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Qt[(4 * part + e) * npv + qr] = qv[e];
+            dOt[(4 * part + e) * npv + qr] = dv[e];
+        }
+    }
+    const float* st = stats + (int64_t)blockIdx.x * 3 * np;
+    for (int i = tid; i < np; i += 256) {
+        const bool ok = i < N;
+        sm[i] = ok ? st[i] : __builtin_inff();
+        sl[i] = ok ? 1.0f / st[np + i] : 1.0f;
+        sd[i] = ok ? st[2 * np + i] : 0.f;
+    }
+    __syncthreads();
+    for (int kt = w; kt < nkt; kt += 4) {
+        const int key = kt * 16 + pl;
+        const int krow = min(key, N - 1);
+        f32x4 Kf = *reinterpret_cast<const f32x4*>(base + (int64_t)krow * ld + D + 4 * q);
+        Kf *= 0.25f;
+        const f32x4 Vf = *reinterpret_cast<const f32x4*>(base + (int64_t)krow * ld + 2 * D + 4 * q);
+        const bool kok = key < N && (mask == nullptr || mask[(int64_t)jet * N + key] != 0.f);
+        const float kb = kok ? 0.f : -__builtin_inff();
+        f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
+#pragma unroll 2
+        for (int qt = 0; qt < nkt; ++qt) {
+            // S / dP tiles: rows = queries 16 qt + 4q + r, column = key pl
+            f32x4 s = {kb, kb, kb, kb}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(Qt[(4 * q + e) * npv + 16 * qt + pl], Kf[e], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(dOt[(4 * q + e) * npv + 16 * qt + pl], Vf[e], dp, 0, 0, 0);
+            }
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(sm + 16 * qt + 4 * q);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + 16 * qt + 4 * q);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + 16 * qt + 4 * q);
+            f32x4 p;
+            p.x = __expf(s.x - m4.x) * l4.x; p.y = __expf(s.y - m4.y) * l4.y;
+            p.z = __expf(s.z - m4.z) * l4.z; p.w = __expf(s.w - m4.w) * l4.w;
+            const f32x4 ds = p * (dp - d4) * 0.25f;
+            const f32x4 dOa = *reinterpret_cast<const f32x4*>(dOt + pl * npv + 16 * qt + 4 * q);
+            const f32x4 Qa = *reinterpret_cast<const f32x4*>(Qt + pl * npv + 16 * qt + 4 * q);
+            if (qt & 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dv1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dOa[e], p[e], dv1, 0, 0, 0);
+                    dk1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Qa[e], ds[e], dk1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dv0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dOa[e], p[e], dv0, 0, 0, 0);
+                    dk0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Qa[e], ds[e], dk0, 0, 0, 0);
+                }
+            }
+        }
+        if (key < N) {
+            float* gp = dqkv + ((int64_t)jet * N + key) * ld + h * HD + 4 * q;
+            *reinterpret_cast<f32x4*>(gp + D) = dk0 + dk1;
+            *reinterpret_cast<f32x4*>(gp + 2 * D) = dv0 + dv1;
+        }
+    }
+}
+
+inline int attn_bwd_set_lds() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tf_attn_bwd_q_kernel<32>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, attn_bwd_lds_floats(512) * 4);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(tf_attn_bwd_kv_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, attn_bwd_lds_floats(512) * 4);
+    return (int)e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context path: per-jet chain back to ctxt_emdb, then sums over jets of outer products
+// ------------------------------------------------------------------------------------------------
+struct CtxtBwdArgs {
+    const float* blob;
+    const float *djb, *chid;  // [jet][nb][Hd], [jet][CH]
+    float *dctxt, *dhn, *dhnx, *dpre, *hn;  // [jet][CO], [jet][CH] x 4
+    int CH, CO, Hd, nb;
+    float slope, eps;
+    int64_t cg, cb, c2W;
+    int64_t Wc[PFM_TF_MAX_LAYERS + 2];
+};
+
+__global__ __launch_bounds__(512) void tf_ctxt_bwd_kernel(CtxtBwdArgs a) {
+    __shared__ float part[512];
+    __shared__ float dcx[64];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, jet = blockIdx.x;
+    const float* __restrict__ blob = a.blob;
+    // d ctxt[j] = sum_c sum_o Wc[c][j][o] djb[c][o]
+    {
+        const int j = tid & 63, p = tid >> 6;
+        float acc = 0.f;
+        if (j < a.CO) {
+            const int o0 = p * (a.Hd >> 3), o1 = o0 + (a.Hd >> 3);
+            for (int c = 0; c < a.nb; ++c) {
+                const float* dj = a.djb + ((int64_t)jet * a.nb + c) * a.Hd;
+                const float* wr = blob + a.Wc[c] + (int64_t)j * a.Hd;
+                for (int o = o0; o < o1; ++o) acc = fmaf(wr[o], dj[o], acc);
+            }
+        }
+        part[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < a.CO) {
+        float acc = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc += part[p * 64 + tid];
+        dcx[tid] = acc;
+        a.dctxt[(int64_t)jet * a.CO + tid] = acc;
+    }
+    __syncthreads();
+    // back through the output Linear and the LayerNorm of ctxt_emdb (CH <= 512: one element per thread)
+    const int o = tid;
+    const bool ok = o < a.CH;
+    const float h = ok ? a.chid[(int64_t)jet * a.CH + o] : 0.f;
+    const float mean = block_sum512(h, red) / (float)a.CH;
+    const float dl = ok ? h - mean : 0.f;
+    const float rstd = 1.0f / sqrtf(block_sum512(dl * dl, red) / (float)a.CH + a.eps);
+    const float xh = dl * rstd;
+    float dn = 0.f;
+    if (ok)
+        for (int j = 0; j < a.CO; ++j) dn = fmaf(blob[a.c2W + (int64_t)o * a.CO + j], dcx[j], dn);
+    const float gam = ok ? blob[a.cg + o] : 0.f;
+    const float g = dn * gam;
+    const float c1 = block_sum512(g, red) / (float)a.CH;
+    const float c2 = block_sum512(g * xh, red) / (float)a.CH;
+    if (ok) {
+        const float dh = (g - c1 - xh * c2) * rstd;
+        const int64_t e = (int64_t)jet * a.CH + o;
+        a.dhn[e] = dn;
+        a.dhnx[e] = dn * xh;
+        a.hn[e] = xh * gam + blob[a.cb + o];
+        a.dpre[e] = dh * (h > 0.f ? 1.f : a.slope);
+    }
+}
+
+// G[k][o] += sum_jet U[jet][k] V[jet][o]   (U == nullptr: K = 1, weight 1).  Each element has one owner thread.
+__global__ __launch_bounds__(256) void tf_outer_sum_kernel(const float* __restrict__ U, int64_t ldu, int K,
+                                                           const float* __restrict__ V, int64_t ldv, int NO, int n_jets,
+                                                           float* __restrict__ G) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)K * NO) return;
+    const int k = (int)(e / NO), o = (int)(e - (int64_t)k * NO);
+    float acc = 0.f;
+    for (int j = 0; j < n_jets; ++j) acc = fmaf(U ? U[j * ldu + k] : 1.0f, V[j * ldv + o], acc);
+    G[e] += acc;
+}
+
 }  // namespace tf
 }  // namespace pfm

@@ -231,8 +231,10 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
             if (a.jb) {
                 const int row = min(row0 + 16 * t + pl, a.M - 1);
                 acc[s][t] = *reinterpret_cast<const f32x4*>(a.jb + (int64_t)(row / a.N) * a.jb_stride + o);
-            } else {
+            } else if (a.b >= 0) {
                 acc[s][t] = *reinterpret_cast<const f32x4*>(a.blob + a.b + o);
+            } else {
+                acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     }
@@ -458,6 +460,7 @@ __global__ __launch_bounds__(256) void tf_head_kernel(HeadArgs a) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 4 * pl + 64 * i);
             v[i] = (v[i] - mean) * rstd * g4 + b4;
         }
+#pragma unroll 1
     for (int f = 0; f < a.F; ++f) {
         float d = 0.f;
 #pragma unroll

@@ -81,7 +81,7 @@ int set_attn_lds() {
     int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(tf_attn_kernel<32>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, big), "hipFuncSetAttribute(attn)");
     if (rc) return rc;
-    rc = attn_bwd_set_lds();
+    rc = check_hip((hipError_t)attn_bwd_set_lds(), "hipFuncSetAttribute(attn backward)");
     if (rc) return rc;
     done = true;
     return 0;
@@ -146,6 +146,209 @@ int make_plan(Plan& p, const pfm_tf_desc* d, const float* blob, float* ws, int n
     return 0;
 }
 
+
+// ---- backward scratch (floats) -------------------------------------------------------------------
+struct Bs {
+    int64_t dv, gh, gh2, gx, ga, gqkv, gatt, stats, rstat, djb, dctxt, dhn, dhnx, dpre, hn, total;
+};
+
+Bs make_bs(const pfm_tf_desc& d, int n_jets) {
+    Bs b;
+    const int64_t M = (int64_t)n_jets * d.n_points, D = d.model_dim, Hd = d.hidden;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { const int64_t at = o; o += round64(n); return at; };
+    b.dv = take(M * d.features);
+    b.gh = take(M * Hd);
+    b.gh2 = take(M * Hd);
+    b.gx = take(M * D);
+    b.ga = take(M * D);
+    b.gqkv = take(M * 3 * D);
+    b.gatt = take(M * D);
+    b.stats = take((int64_t)n_jets * d.heads * 3 * attn_np16(d.n_points));
+    b.rstat = take(M * 2);
+    b.djb = take((int64_t)n_jets * (d.layers + 2) * Hd);
+    b.dctxt = take((int64_t)n_jets * d.ctxt_dim);
+    b.dhn = take((int64_t)n_jets * d.ctxt_hidden);
+    b.dhnx = take((int64_t)n_jets * d.ctxt_hidden);
+    b.dpre = take((int64_t)n_jets * d.ctxt_hidden);
+    b.hn = take((int64_t)n_jets * d.ctxt_hidden);
+    b.total = o;
+    return b;
+}
+
+struct Bwd {
+    Plan p;
+    float* gblob;
+    float* sc;
+    Bs b;
+
+    int colsum(const float* Z, int ldz, int NO, const float* X, int F, float* jet_out, int64_t gb) const {
+        ColsumArgs a;
+        a.Z = Z; a.X = X; a.jet_out = jet_out; a.gblob = gblob; a.gb = gb;
+        a.jet_stride = (int64_t)(p.d->layers + 2) * p.d->hidden;
+        a.ldz = ldz; a.NO = NO; a.N = p.d->n_points; a.F = F;
+        hipLaunchKernelGGL(tf_colsum_kernel, dim3(p.n_jets, X ? F : 1, (NO + 767) / 768), dim3(256), 0, p.s, a);
+        return check_hip(hipGetLastError(), "tf_colsum_kernel launch");
+    }
+    int rowstats(const float* A, int K) const {
+        hipLaunchKernelGGL(tf_rowstats_kernel, dim3((p.M + 15) / 16), dim3(256), 0, p.s, A, K, p.M, K, p.d->ln_eps, sc + b.rstat);
+        return check_hip(hipGetLastError(), "tf_rowstats_kernel launch");
+    }
+    // dW += Z^T LN(A)
+    int dw(const float* Z, int NO, const float* A, int K, const pfm_tf_norm& ln, int64_t gW) const {
+        int rc = rowstats(A, K);
+        if (rc) return rc;
+        DwArgs a;
+        a.Z = Z; a.A = A; a.stats = sc + b.rstat; a.blob = p.blob; a.gblob = gblob;
+        a.gamma = ln.gamma; a.beta = ln.beta; a.gW = gW;
+        a.ldz = NO; a.lda = K; a.M = p.M; a.NO = NO; a.K = K;
+        a.row_tiles = (p.M + BM - 1) / BM;
+        const int tiles = (NO / 128) * (K / 128);
+        int ns = 1024 / tiles;
+        if (ns < 1) ns = 1;
+        if (ns > a.row_tiles) ns = a.row_tiles;
+        a.nsplit = ns;
+        hipLaunchKernelGGL(tf_dw_kernel, dim3(tiles * ns), dim3(LT), 2 * 64 * DWS * sizeof(float), p.s, a);
+        return check_hip(hipGetLastError(), "tf_dw_kernel launch");
+    }
+    // out[M][K] = Z[M][NO] W   (gradient w.r.t. the Linear's normalised input)
+    int dx(const float* Z, int NO, const pfm_tf_lin& lin, int K, float* out) const {
+        pfm_tf_lin t = lin;
+        t.W = lin.WT;
+        t.b = -1;
+        return launch_linear(p, Z, NO, NO, t, nullptr, K, nullptr, nullptr, 0, out, K, false);
+    }
+    int lnbwd(const float* A, int K, const float* G, const float* add, float* out, const pfm_tf_norm& ln, bool act) const {
+        LnBwdArgs a{};
+        a.A = A; a.G = G; a.add = add; a.out = out; a.blob = p.blob; a.gblob = gblob;
+        a.gamma = ln.gamma; a.beta = ln.beta; a.M = p.M; a.K = K; a.act = act ? 1 : 0;
+        a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
+        hipLaunchKernelGGL(tf_ln_bwd_kernel<false>, dim3((p.M + 63) / 64), dim3(256), 0, p.s, a);
+        return check_hip(hipGetLastError(), "tf_ln_bwd_kernel launch");
+    }
+    int outer(const float* U, int64_t ldu, int K, const float* V, int64_t ldv, int NO, int64_t g) const {
+        const int64_t n = (int64_t)K * NO;
+        hipLaunchKernelGGL(tf_outer_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, U, ldu, K, V, ldv, NO,
+                           p.n_jets, gblob + g);
+        return check_hip(hipGetLastError(), "tf_outer_sum_kernel launch");
+    }
+};
+
+#define PFM_TRY(x) do { if ((rc = (x))) return rc; } while (0)
+
+int run_backward(const Bwd& B, const float* cond, const float* mask, const float* y, const float* u, const float* v,
+                 const float* gscale) {
+    const Plan& p = B.p;
+    const pfm_tf_desc& d = *p.d;
+    const Ws& w = p.w;
+    float* ws = p.ws;
+    float* sc = B.sc;
+    const Bs& b = B.b;
+    const int D = d.model_dim, Hd = d.hidden, nb = d.layers + 2, F = d.features;
+    float *gh = sc + b.gh, *gh2 = sc + b.gh2, *gx = sc + b.gx, *ga = sc + b.ga, *gqkv = sc + b.gqkv, *gatt = sc + b.gatt;
+    float* djb = sc + b.djb;
+    int rc;
+    // ---- output head: v = LN(oh) W3^T + b3 ----
+    {
+        LnBwdArgs a{};
+        a.A = ws + w.oh; a.out = gh; a.nout = gh2; a.v = v; a.u = u; a.gscale = gscale; a.dv = sc + b.dv;
+        a.blob = p.blob; a.gblob = B.gblob;
+        a.gamma = d.o_norm.gamma; a.beta = d.o_norm.beta; a.W3 = d.o2.W; a.b3 = d.o2.b;
+        a.M = p.M; a.K = Hd; a.F = F; a.act = 1; a.slope = d.neg_slope; a.eps = d.ln_eps;
+        hipLaunchKernelGGL(tf_ln_bwd_kernel<true>, dim3((p.M + 63) / 64), dim3(256), 0, p.s, a);
+        PFM_TRY(check_hip(hipGetLastError(), "tf_ln_bwd_kernel<head> launch"));
+        PFM_TRY(B.colsum(gh2, Hd, Hd, sc + b.dv, F, nullptr, d.o2.W));
+    }
+    const float* xL = d.layers ? ws + w.layer0 + w.lstride * (d.layers - 1) + w.o_xout : ws + w.x0;
+    // ---- outp_embd input block ----
+    PFM_TRY(B.colsum(gh, Hd, Hd, nullptr, 0, djb + (int64_t)(nb - 1) * Hd, -1));
+    PFM_TRY(B.dw(gh, Hd, xL, D, d.final_norm, d.o1.W));
+    PFM_TRY(B.dx(gh, Hd, d.o1, D, ga));
+    PFM_TRY(B.lnbwd(xL, D, ga, nullptr, gx, d.final_norm, false));
+    // ---- encoder layers, last to first ----
+    for (int l = d.layers - 1; l >= 0; --l) {
+        const pfm_tf_layer& L = d.layer[l];
+        float* lb = ws + w.layer0 + w.lstride * l;
+        const float *qkv = lb + w.o_qkv, *att = lb + w.o_att, *xmid = lb + w.o_xmid, *dh = lb + w.o_dh;
+        const float* xin = l ? ws + w.layer0 + w.lstride * (l - 1) + w.o_xout : ws + w.x0;
+        // x_out = x_mid + d2(LN(dh))
+        PFM_TRY(B.colsum(gx, D, D, nullptr, 0, nullptr, L.d2.b));
+        PFM_TRY(B.dw(gx, D, dh, Hd, L.d_norm, L.d2.W));
+        PFM_TRY(B.dx(gx, D, L.d2, Hd, gh2));
+        PFM_TRY(B.lnbwd(dh, Hd, gh2, nullptr, gh, L.d_norm, true));
+        // dh = lrelu(d1(LN2(x_mid)) + jet bias)
+        PFM_TRY(B.colsum(gh, Hd, Hd, nullptr, 0, djb + (int64_t)(1 + l) * Hd, -1));
+        PFM_TRY(B.dw(gh, Hd, xmid, D, L.norm2, L.d1.W));
+        PFM_TRY(B.dx(gh, Hd, L.d1, D, ga));
+        PFM_TRY(B.lnbwd(xmid, D, ga, gx, gx, L.norm2, false));
+        // x_mid = x_in + out(LN(att))
+        PFM_TRY(B.colsum(gx, D, D, nullptr, 0, nullptr, L.out.b));
+        PFM_TRY(B.dw(gx, D, att, D, L.attn_norm, L.out.W));
+        PFM_TRY(B.dx(gx, D, L.out, D, ga));
+        PFM_TRY(B.lnbwd(att, D, ga, nullptr, gatt, L.attn_norm, false));
+        // attention
+        {
+            const int N = d.n_points, heads = d.heads;
+            const size_t lds = (size_t)attn_bwd_lds_floats(N) * sizeof(float);
+            const int nkt = attn_np16(N) / 16;
+            const dim3 grid(p.n_jets * heads), block(256);
+            float* st = sc + b.stats;
+            if (nkt <= 12)
+                hipLaunchKernelGGL(tf_attn_bwd_q_kernel<12>, grid, block, lds, p.s, qkv, mask, att, gatt, gqkv, st, N, D, heads);
+            else if (nkt <= 18)
+                hipLaunchKernelGGL(tf_attn_bwd_q_kernel<18>, grid, block, lds, p.s, qkv, mask, att, gatt, gqkv, st, N, D, heads);
+            else
+                hipLaunchKernelGGL(tf_attn_bwd_q_kernel<32>, grid, block, lds, p.s, qkv, mask, att, gatt, gqkv, st, N, D, heads);
+            PFM_TRY(check_hip(hipGetLastError(), "tf_attn_bwd_q_kernel launch"));
+            hipLaunchKernelGGL(tf_attn_bwd_kv_kernel, grid, block, lds, p.s, qkv, mask, gatt, st, gqkv, N, D, heads);
+            PFM_TRY(check_hip(hipGetLastError(), "tf_attn_bwd_kv_kernel launch"));
+        }
+        // qkv = all_linear(LN1(x_in))
+        PFM_TRY(B.colsum(gqkv, 3 * D, 3 * D, nullptr, 0, nullptr, L.qkv.b));
+        PFM_TRY(B.dw(gqkv, 3 * D, xin, D, L.norm1, L.qkv.W));
+        PFM_TRY(B.dx(gqkv, 3 * D, L.qkv, D, ga));
+        PFM_TRY(B.lnbwd(xin, D, ga, gx, gx, L.norm1, false));
+    }
+    // ---- node_embd ----
+    PFM_TRY(B.colsum(gx, D, D, nullptr, 0, nullptr, d.n2.b));
+    PFM_TRY(B.dw(gx, D, ws + w.h1, Hd, d.n_norm, d.n2.W));
+    PFM_TRY(B.dx(gx, D, d.n2, Hd, gh2));
+    PFM_TRY(B.lnbwd(ws + w.h1, Hd, gh2, nullptr, gh, d.n_norm, true));
+    PFM_TRY(B.colsum(gh, Hd, Hd, nullptr, 0, djb, -1));
+    PFM_TRY(B.colsum(gh, Hd, Hd, y, F, nullptr, d.n1.W));
+    // ---- context path ----
+    {
+        CtxtBwdArgs a;
+        a.blob = p.blob; a.djb = djb; a.chid = ws + w.chid;
+        a.dctxt = sc + b.dctxt; a.dhn = sc + b.dhn; a.dhnx = sc + b.dhnx; a.dpre = sc + b.dpre; a.hn = sc + b.hn;
+        a.CH = d.ctxt_hidden; a.CO = d.ctxt_dim; a.Hd = Hd; a.nb = nb; a.slope = d.neg_slope; a.eps = d.ln_eps;
+        a.cg = d.c_norm.gamma; a.cb = d.c_norm.beta; a.c2W = d.c2.W;
+        a.Wc[0] = d.n1.Wc;
+        for (int l = 0; l < d.layers; ++l) a.Wc[1 + l] = d.layer[l].d1.Wc;
+        a.Wc[nb - 1] = d.o1.Wc;
+        hipLaunchKernelGGL(tf_ctxt_bwd_kernel, dim3(p.n_jets), dim3(512), 0, p.s, a);
+        PFM_TRY(check_hip(hipGetLastError(), "tf_ctxt_bwd_kernel launch"));
+        const int64_t jbs = (int64_t)nb * Hd;
+        const float* ctxt = ws + w.ctxt;
+        for (int c = 0; c < nb; ++c) {
+            const pfm_tf_lin& lin = c == 0 ? d.n1 : (c == nb - 1 ? d.o1 : d.layer[c - 1].d1);
+            PFM_TRY(B.outer(ctxt, d.ctxt_dim, d.ctxt_dim, djb + (int64_t)c * Hd, jbs, Hd, lin.Wc));
+            PFM_TRY(B.outer(nullptr, 0, 1, djb + (int64_t)c * Hd, jbs, Hd, lin.b));
+        }
+        if (d.time_in_input) PFM_TRY(B.outer(ws + w.temb, 64, d.t_dim, djb, jbs, Hd, d.n1.Wt));
+        PFM_TRY(B.outer(sc + b.hn, d.ctxt_hidden, d.ctxt_hidden, sc + b.dctxt, d.ctxt_dim, d.ctxt_dim, d.c2.W));
+        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dctxt, d.ctxt_dim, d.ctxt_dim, d.c2.b));
+        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dhnx, d.ctxt_hidden, d.ctxt_hidden, d.c_norm.gamma));
+        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dhn, d.ctxt_hidden, d.ctxt_hidden, d.c_norm.beta));
+        PFM_TRY(B.outer(ws + w.temb, 64, d.t_dim, sc + b.dpre, d.ctxt_hidden, d.ctxt_hidden, d.c1.W));
+        if (d.cond_dim > 0)
+            PFM_TRY(B.outer(cond, d.cond_dim, d.cond_dim, sc + b.dpre, d.ctxt_hidden, d.ctxt_hidden,
+                            d.c1.W + (int64_t)d.t_dim * d.ctxt_hidden));
+        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dpre, d.ctxt_hidden, d.ctxt_hidden, d.c1.b));
+    }
+    return 0;
+}
+
 }  // namespace tf
 }  // namespace pfm
 
@@ -197,6 +400,53 @@ int pfm_tf_sample_midpoint(const pfm_tf_desc* d, const float* blob, const float*
         if ((rc = run_nfe(p, t_eval + 2 * k + 1, 0, xm, cond, mask, h))) return rc;
     }
     return check_hip(hipMemcpyAsync(x_out, xs, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_out");
+}
+
+int pfm_tf_fm_loss_forward(const pfm_tf_desc* d, const float* blob, int32_t kind, float sigma, const float* t,
+                           const float* x, const float* a, const float* b, const float* cond, const float* mask,
+                           float* y_out, float* u_out, float* v_out, float* loss_sums, int32_t n_jets,
+                           float* workspace, void* stream) {
+    Plan p;
+    int rc = make_plan(p, d, blob, workspace, n_jets, true, stream);
+    if (rc) return rc;
+    if (n_jets <= 0) return 0;
+    if (kind != 0 && kind != 1) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT) or 1 (CFM)");
+    if (!blob || !t || !x || !a || !y_out || !u_out || !v_out || !loss_sums || !workspace)
+        return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (kind == 1 && !b) return set_err(PFM_E_BADARG, "CFM needs eps");
+    if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
+    const int64_t n = (int64_t)p.M * d->features;
+    hipLaunchKernelGGL(tf_yu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, kind, sigma, t, x, a, b, mask, y_out,
+                       u_out, n, d->n_points * d->features, d->features);
+    if ((rc = check_hip(hipGetLastError(), "tf_yu_kernel launch"))) return rc;
+    HeadArgs h{};
+    h.dst = v_out;
+    if ((rc = run_nfe(p, t, 1, y_out, cond, mask, h))) return rc;
+    hipLaunchKernelGGL(tf_loss_kernel, dim3(256), dim3(256), 0, p.s, (const float*)v_out, (const float*)u_out, mask, loss_sums, n,
+                       (int64_t)p.M);
+    return check_hip(hipGetLastError(), "tf_loss_kernel launch");
+}
+
+int64_t pfm_tf_backward_scratch_floats(const pfm_tf_desc* d, int32_t n_jets) {
+    if (validate(d)) return -1;
+    return make_bs(*d, n_jets < 1 ? 1 : n_jets).total;
+}
+
+int pfm_tf_fm_loss_backward(const pfm_tf_desc* d, const float* blob, const float* t, const float* cond,
+                            const float* mask, const float* y, const float* u, const float* v, const float* gscale,
+                            float* gblob, int32_t n_jets, float* workspace, float* scratch, void* stream) {
+    (void)t;  // the time embedding is part of the workspace
+    Bwd B;
+    int rc = make_plan(B.p, d, blob, workspace, n_jets, true, stream);
+    if (rc) return rc;
+    if (n_jets <= 0) return 0;
+    if (!blob || !y || !u || !v || !gscale || !gblob || !workspace || !scratch) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
+    if (d->n2.WT < 0) return set_err(PFM_E_BADARG, "blob was packed without the transposed (backward) weight copies");
+    B.gblob = gblob;
+    B.sc = scratch;
+    B.b = make_bs(*d, n_jets);
+    return run_backward(B, cond, mask, y, u, v, gscale);
 }
 
 }  // extern "C"

@@ -141,9 +141,9 @@ class TfConfig:
 
 
 def default_freqs(t_dim: int) -> torch.Tensor:
-    from .layout import default_freqs as _df
-
-    return _df(t_dim)
+    """exp(0..T-1) of time_emb.py:90 as correctly rounded fp32 (see EpicLayout.default_freqs: the reference's fp32
+    ``arange(T).exp()`` is host-dependent in the last bit, so the product fixes the table)."""
+    return torch.arange(t_dim, dtype=torch.float64).exp().to(torch.float32)
 
 
 class TfLayout:
