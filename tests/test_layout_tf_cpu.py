@@ -1,11 +1,9 @@
 """layout_tf.py: descriptor, gather maps and blob formats, checked on the CPU against the reference vectors."""
-import ctypes
-
 import numpy as np
 import pytest
 import torch
 
-from particle_fm_amd.layout_tf import TfConfig, TfDesc, TfLayout
+from particle_fm_amd.layout_tf import TfConfig, TfLayout
 from tests import tf_blob_interp
 
 
@@ -38,13 +36,6 @@ def test_grad_pos_is_a_bijection_onto_primary_slots(tf_golden):
     assert gp.shape == (lay.n_params,) and len(np.unique(gp)) == lay.n_params
     # a gradient blob that holds "its own source index" at every slot gathers back to arange
     assert np.array_equal(lay.index_map[gp], np.arange(lay.n_params))
-
-
-def test_desc_size_matches_header():
-    # pfm_tf_desc: 14 int32 + 2 float + 2 int64 + 6 lin + 4 norm + 12 layers (4 norm + 4 lin) + ...
-    lin, nrm = 5 * 8, 2 * 8
-    expect = 14 * 4 + 2 * 4 + 2 * 8 + (3 * lin + nrm * 1) + (2 * lin + nrm) + 12 * (4 * nrm + 4 * lin) + (nrm + lin + nrm + lin)
-    assert ctypes.sizeof(TfDesc) == expect - (3 * lin + nrm) + (2 * lin + nrm)
 
 
 def test_unsupported_configs_are_rejected():

@@ -90,8 +90,8 @@ def test_no_cpu_fallback():
 
 def test_c_abi_exports_every_declared_symbol():
     lib = _lib.load()
-    header = open(f"{ROOT}/include/pfm_hip.h").read()
-    declared = set(re.findall(r"\b(pfm_[a-z0-9_]+)\s*\(", header))
+    header = open(f"{ROOT}/include/pfm_hip.h").read() + open(f"{ROOT}/include/pfm_tf.h").read()
+    declared = set(re.findall(r"^(?:int64_t|int|const char \*)\s*\*?(pfm_[a-z0-9_]+)\s*\(", header, flags=re.M))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
@@ -106,6 +106,28 @@ def test_c_abi_exports_every_declared_symbol():
                                 t_global_cat=True))
     rc = lib.pfm_epic_forward(ctypes.byref(bad.desc), None, None, None, None, None, None, 1, None)
     assert rc == 10002 and b"LDS" in lib.pfm_last_error()
+
+
+def test_tf_desc_mirror_matches_the_c_struct(tmp_path):
+    """sizeof / offsetof of pfm_tf_desc as gcc sees them vs the ctypes mirror; host-side validation of the tf entry points."""
+    import subprocess
+    from particle_fm_amd.layout_tf import TfConfig, TfDesc, TfLayer, TfLayout
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pfm_tf.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n",'
+                   'sizeof(pfm_tf_desc), offsetof(pfm_tf_desc, layer), sizeof(pfm_tf_layer), offsetof(pfm_tf_desc, final_norm),'
+                   'offsetof(pfm_tf_desc, o2));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", f"{ROOT}/include", str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [ctypes.sizeof(TfDesc), TfDesc.layer.offset, ctypes.sizeof(TfLayer), TfDesc.final_norm.offset, TfDesc.o2.offset]
+    lib = _lib.load()
+    lay = TfLayout(TfConfig(num_particles=279, global_cond_dim=5))
+    assert lib.pfm_tf_workspace_floats(ctypes.byref(lay.desc), 128, 0) > 0
+    assert lib.pfm_tf_workspace_floats(ctypes.byref(lay.desc), 128, 1) > lib.pfm_tf_workspace_floats(ctypes.byref(lay.desc), 128, 0)
+    lay.desc.head_dim = 32
+    assert lib.pfm_tf_workspace_floats(ctypes.byref(lay.desc), 1, 0) == -1
+    rc = lib.pfm_tf_forward(ctypes.byref(lay.desc), None, None, 0, None, None, None, None, 1, None, None)
+    assert rc == 10001 and b"head_dim" in lib.pfm_last_error()
 
 
 def test_flat_params_alias_and_survive_load_state_dict():
