@@ -307,6 +307,9 @@ def gen_transformer(ref, name, hp, B, store_all, out_dir, seed=2024):
     # init_zeros / output_init_zeros make the untrained field identically 0: every tensor is
     # replaced by a seeded, machine-independent draw (numpy PCG64) with the usual fan-in scale
     shapes = {k: tuple(v.shape) for k, v in cnf.state_dict().items() if k != "frequencies"}
+    # default initialisation under the seed (incl. init_zeros / output_init_zeros): per-tensor sum and |.| sum
+    init = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for k, v in cnf.state_dict().items()
+                     if k != "frequencies"])
     new = seeded_state(shapes, seed)
     sd = cnf.state_dict()
     for k, v in new.items():
@@ -320,6 +323,7 @@ def gen_transformer(ref, name, hp, B, store_all, out_dir, seed=2024):
     out["hp_json"] = np.array(json.dumps(hp))
     out["freqs"] = torch.arange(2 * hp["frequencies"]).exp().numpy()
     out["abs_sum"] = np.array(sum(float(np.abs(v).sum(dtype=np.float64)) for v in new.values()))
+    out["init_sums"] = init
     if store_all:
         for k, v in cnf.state_dict().items():
             out["sd/flows.0." + k] = v.detach().numpy()

@@ -142,10 +142,11 @@ class FusedFMTrainer:
         self.scratch = torch.zeros(1024, device=dev, dtype=torch.float32)
         self.sync = GradSync(process_group)
         self.step_count = 0
-        # fully fused path (no autograd): single EPiC flow with an FM-OT / CFM loss
+        # fully fused path (no autograd): single EPiC flow with an FM-OT / CFM loss.  The transformer's parameters are
+        # plain (no weight norm): its autograd node already is two launches + two gathers, so it takes the generic path
         self._fused = None
         flows = getattr(module, "flows", None)
-        if flows is not None and len(flows) == 1 and hasattr(flows[0], "net") and hasattr(flows[0].net, "layout"):
+        if flows is not None and len(flows) == 1 and hasattr(flows[0], "net") and hasattr(flows[0].net, "source_vector"):
             self._fused = {}
             flows[0].net._fast_pack = self.packed_blob  # sampling re-packs with one HIP launch instead of ~100 torch ops
 

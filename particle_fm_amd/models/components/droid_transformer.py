@@ -1,0 +1,226 @@
+"""Drop-in for the classes of particle_fm/models/components/droid_transformer.py that model
+"droid_fulltransformer" instantiates: ``FullTransformerEncoder`` and its parameter containers.
+
+Same class names, constructor keywords, parameter names / shapes / registration order (hence the same
+``state_dict`` keys and, under a fixed seed, bit-identical default initialisation incl. ``init_zeros`` /
+``output_init_zeros``) as the reference (droid_transformer.py:117-229, 287-329, 400-527, 714-1051).  The sub-blocks
+own parameters only: one evaluation of the whole encoder is a fixed sequence of HIP launches
+(``FullTransformerEncoder.forward`` / ``vector_field``), there is no per-block PyTorch compute and no CPU fallback.
+Configurations the kernels do not cover raise NotImplementedError at construction.
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+from typing import Mapping, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from ... import hip_ops_tf
+from ...layout_tf import TfConfig, TfLayout
+
+
+def _container_only(name):
+    def forward(self, *a, **k):
+        raise RuntimeError(f"{name} is evaluated inside the fused FullTransformerEncoder HIP path, not on its own")
+    return forward
+
+
+def get_act(name: str) -> nn.Module:
+    if name == "lrlu":
+        return nn.LeakyReLU(0.1)  # droid_transformer.py:1022
+    raise NotImplementedError(f"activation {name!r} has no HIP path in this build (only 'lrlu')")
+
+
+def get_nrm(name: str, outp_dim: int) -> nn.Module:
+    if name == "layer":
+        return nn.LayerNorm(outp_dim)
+    raise NotImplementedError(f"normalisation {name!r} has no HIP path in this build (only 'layer')")
+
+
+class MLPBlock(nn.Module):
+    """droid_transformer.py:714-827: ``block`` = [Linear, act, norm] (n_layers = 1)."""
+
+    def __init__(self, inpt_dim: int, outp_dim: int, ctxt_dim: int = 0, n_layers: int = 1, act: str = "lrlu",
+                 nrm: str = "none", drp: float = 0, do_res: bool = False, init_zeros: bool = False) -> None:
+        super().__init__()
+        if n_layers != 1 or drp > 0 or do_res:
+            raise NotImplementedError("MLPBlock: the HIP path implements n_layers=1, no dropout, no residual")
+        self.inpt_dim, self.outp_dim, self.ctxt_dim = inpt_dim, outp_dim, ctxt_dim
+        self.block = nn.ModuleList([nn.Linear(inpt_dim + ctxt_dim, outp_dim)])
+        if init_zeros:
+            self.block[-1].weight.data.fill_(0)
+            self.block[-1].bias.data.fill_(0)
+        if act != "none":
+            self.block.append(get_act(act))
+        if nrm != "none":
+            self.block.append(get_nrm(nrm, outp_dim))
+
+    forward = _container_only("MLPBlock")
+
+
+class DenseNetwork(nn.Module):
+    """droid_transformer.py:830-1011 with one hidden block: input_block (Linear, act_h, nrm) -> output_block (Linear)."""
+
+    def __init__(self, inpt_dim: int, outp_dim: int = 0, ctxt_dim: int = 0, hddn_dim: Union[int, list] = 32,
+                 num_blocks: int = 1, n_lyr_pbk: int = 1, act_h: str = "lrlu", act_o: str = "none", do_out: bool = True,
+                 nrm: str = "none", drp: float = 0, drp_on_output: bool = False, nrm_on_output: bool = False,
+                 do_res: bool = False, ctxt_in_inpt: bool = True, ctxt_in_hddn: bool = False,
+                 output_init_zeros: bool = False) -> None:
+        super().__init__()
+        if not isinstance(hddn_dim, int) or num_blocks != 1 or act_o != "none" or not do_out or drp > 0 \
+                or nrm_on_output or not ctxt_in_inpt or ctxt_in_hddn or nrm != "layer" or act_h != "lrlu":
+            raise NotImplementedError(
+                "DenseNetwork: the HIP path implements one hidden block (int hddn_dim), act_h='lrlu', nrm='layer', "
+                "act_o='none', context in the input block only, no dropout (configs/model/fm_droid_transformer.yaml)")
+        self.inpt_dim, self.hddn_dim, self.num_blocks = inpt_dim, [hddn_dim], 1
+        self.outp_dim = outp_dim or inpt_dim
+        self.ctxt_dim, self.do_out = ctxt_dim, do_out
+        self.hidden_features = hddn_dim
+        self.input_block = MLPBlock(inpt_dim=inpt_dim, outp_dim=hddn_dim, ctxt_dim=ctxt_dim, act=act_h, nrm=nrm)
+        self.hidden_blocks = []
+        self.output_block = MLPBlock(inpt_dim=hddn_dim, outp_dim=self.outp_dim, act=act_o, init_zeros=output_init_zeros)
+
+    forward = _container_only("DenseNetwork")
+
+
+class MultiHeadedAttentionBlock(nn.Module):
+    """droid_transformer.py:117-284 (self-attention flavour): all_linear, layer_norm, out_linear."""
+
+    def __init__(self, model_dim: int, num_heads: int = 1, drp: float = 0, init_zeros: bool = False,
+                 do_selfattn: bool = False, do_layer_norm: bool = False, attn_act=None) -> None:
+        super().__init__()
+        if not do_selfattn or not do_layer_norm or drp > 0 or attn_act is not None:
+            raise NotImplementedError("MultiHeadedAttentionBlock: the HIP path implements self-attention with "
+                                      "do_layer_norm=True, softmax, no dropout")
+        self.model_dim, self.num_heads, self.head_dim = model_dim, num_heads, model_dim // num_heads
+        if self.head_dim * num_heads != model_dim:
+            raise ValueError("Model dimension must be divisible by number of heads!")  # droid_transformer.py:191
+        self.do_selfattn, self.drp, self.do_layer_norm, self.attn_act = do_selfattn, drp, do_layer_norm, attn_act
+        self.all_linear = nn.Linear(model_dim, 3 * model_dim)
+        self.layer_norm = nn.LayerNorm(model_dim)
+        self.out_linear = nn.Linear(model_dim, model_dim)
+        if init_zeros:
+            self.out_linear.weight.data.fill_(0)
+            self.out_linear.bias.data.fill_(0)
+
+    forward = _container_only("MultiHeadedAttentionBlock")
+
+
+class TransformerEncoderLayer(nn.Module):
+    """droid_transformer.py:287-344."""
+
+    def __init__(self, model_dim: int, mha_config: Mapping | None = None, dense_config: Mapping | None = None,
+                 ctxt_dim: int = 0) -> None:
+        super().__init__()
+        self.model_dim, self.ctxt_dim = model_dim, ctxt_dim
+        self.self_attn = MultiHeadedAttentionBlock(model_dim, do_selfattn=True, **(mha_config or {}))
+        self.dense = DenseNetwork(model_dim, outp_dim=model_dim, ctxt_dim=ctxt_dim, **(dense_config or {}))
+        self.norm1 = nn.LayerNorm(model_dim)
+        self.norm2 = nn.LayerNorm(model_dim)
+
+    forward = _container_only("TransformerEncoderLayer")
+
+
+class TransformerEncoder(nn.Module):
+    """droid_transformer.py:400-437."""
+
+    def __init__(self, model_dim: int = 64, num_layers: int = 3, mha_config: Mapping | None = None,
+                 dense_config: Mapping | None = None, ctxt_dim: int = 0) -> None:
+        super().__init__()
+        self.model_dim, self.num_layers = model_dim, num_layers
+        self.layers = nn.ModuleList([TransformerEncoderLayer(model_dim, mha_config, dense_config, ctxt_dim)
+                                     for _ in range(num_layers)])
+        self.final_norm = nn.LayerNorm(model_dim)
+
+    forward = _container_only("TransformerEncoder")
+
+
+class FullTransformerEncoder(nn.Module):
+    """droid_transformer.py:440-548.  ``forward(t, x, ctxt, mask)`` keeps the reference's call (t = the (B,N,T)
+    time embedding, x already time-concatenated); ``vector_field(t, x, cond, mask)`` takes the time itself (B,)
+    and the bare particle features and lets the kernels embed (what CNF.forward uses)."""
+
+    def __init__(self, inpt_dim: int, outp_dim: int, edge_dim: int = 0, ctxt_dim: int = 0,
+                 te_config: Mapping | None = None, node_embd_config: Mapping | None = None,
+                 outp_embd_config: Mapping | None = None, edge_embd_config: Mapping | None = None,
+                 ctxt_embd_config: Mapping | None = None, *, num_points: int = 0, frequencies: int = 0,
+                 add_time_to_input: bool = True) -> None:
+        super().__init__()
+        if edge_dim:
+            raise NotImplementedError("edge features (attn_bias) have no HIP path in this build")
+        if not ctxt_dim:
+            raise NotImplementedError("the HIP transformer path needs the context network (ctxt_dim > 0: it always is, "
+                                      "CNF passes global_cond_dim + 2*frequencies)")
+        self.inpt_dim, self.outp_dim, self.ctxt_dim, self.edge_dim = inpt_dim, outp_dim, ctxt_dim, edge_dim
+        te_config = deepcopy(te_config) or {}
+        node_embd_config = deepcopy(node_embd_config) or {}
+        outp_embd_config = deepcopy(outp_embd_config) or {}
+        ctxt_embd_config = deepcopy(ctxt_embd_config) or {}
+        te_config.setdefault("dense_config", {})
+        if "model_dim" in te_config:  # droid_transformer.py:478-488: dense nets default to twice the width
+            model_dim = te_config["model_dim"]
+            for cfg in (node_embd_config, ctxt_embd_config, outp_embd_config, te_config["dense_config"]):
+                cfg.setdefault("hddn_dim", 2 * model_dim)
+        self.ctxt_emdb = DenseNetwork(inpt_dim=self.ctxt_dim, **ctxt_embd_config)
+        self.ctxt_out = self.ctxt_emdb.outp_dim
+        self.te = TransformerEncoder(**te_config, ctxt_dim=self.ctxt_out)
+        self.model_dim = self.te.model_dim
+        self.node_embd = DenseNetwork(inpt_dim=self.inpt_dim, outp_dim=self.model_dim, ctxt_dim=self.ctxt_out,
+                                      **node_embd_config)
+        self.outp_embd = DenseNetwork(inpt_dim=self.model_dim, outp_dim=self.outp_dim, ctxt_dim=self.ctxt_out,
+                                      **outp_embd_config)
+        # what the kernels need to know beyond the reference's own arguments
+        self.num_points, self.frequencies, self.add_time_to_input = num_points, frequencies, add_time_to_input
+        self._layouts = {}
+        self.cfg = self.config(num_points or 1)
+        TfLayout(self.cfg)  # rejects unsupported sizes at construction
+
+    # -- layout / weights --------------------------------------------------------------------------
+    def config(self, num_points: Optional[int] = None) -> TfConfig:
+        t_dim = 2 * self.frequencies
+        dense = self.te.layers[0].dense
+        hid = {dense.hddn_dim[0], self.node_embd.hddn_dim[0], self.outp_embd.hddn_dim[0]}
+        if len(hid) != 1:
+            raise NotImplementedError("the HIP transformer path needs one hddn_dim for node_embd / dense / outp_embd")
+        return TfConfig(num_particles=num_points or self.num_points, features=self.outp_dim, model_dim=self.model_dim,
+                        num_layers=self.te.num_layers, num_heads=self.te.layers[0].self_attn.num_heads, hidden=hid.pop(),
+                        ctxt_hidden=self.ctxt_emdb.hddn_dim[0], ctxt_dim=self.ctxt_out, frequencies=self.frequencies,
+                        global_cond_dim=self.ctxt_dim - t_dim, add_time_to_input=self.add_time_to_input)
+
+    def layout(self, num_points: Optional[int] = None) -> TfLayout:
+        n = num_points or self.num_points
+        lay = self._layouts.get(n)
+        if lay is None:
+            lay = self._layouts[n] = TfLayout(self.config(n))
+        return lay
+
+    def flat_parameters(self, layout: Optional[TfLayout] = None) -> torch.Tensor:
+        """All parameters in the layout's (= state_dict) order as one differentiable vector."""
+        lay = layout or self.layout()
+        named = dict(self.named_parameters())
+        return torch.cat([named[k[len("net."):]].reshape(-1) for k in lay.keys()])
+
+    def packed_weights(self, num_points: Optional[int] = None) -> torch.Tensor:
+        """Kernel blob of the current parameter values (no autograd); rebuilt on every call so it can never go stale
+        after an optimizer step, load_state_dict or an EMA swap, and never appears in state_dict()."""
+        lay = self.layout(num_points)
+        with torch.no_grad():
+            flat = self.flat_parameters(lay)
+            from ...layout_tf import default_freqs
+            src = torch.cat([flat.float(), default_freqs(lay.cfg.t_dim).to(flat.device), torch.zeros(1, device=flat.device)])
+            return src[lay.index_map_on(flat.device)]
+
+    # -- evaluation --------------------------------------------------------------------------------
+    def vector_field(self, t: torch.Tensor, x: torch.Tensor, cond: torch.Tensor = None, mask: torch.Tensor = None,
+                     blob: torch.Tensor = None) -> torch.Tensor:
+        lay = self.layout(x.shape[1])
+        if blob is None:
+            blob = self.packed_weights(x.shape[1])
+        return hip_ops_tf.tf_forward(lay, blob, t, x, cond, mask)
+
+    def forward(self, t: torch.Tensor, x: torch.Tensor, ctxt: torch.Tensor | None = None,
+                mask: Optional[torch.Tensor] = None, attn_bias=None, attn_mask=None) -> torch.Tensor:
+        raise RuntimeError(
+            "FullTransformerEncoder.forward(t_emb, x_cat, ...) of the reference takes the already embedded time; the HIP "
+            "path embeds in-kernel: call vector_field(t, x, cond, mask) (CNF.forward does)")

@@ -4,9 +4,9 @@ Same class names, constructor keywords, ``state_dict`` keys and call signatures 
 (flow_matching_module.py:34-71, 74-347, 350-677), so that the Hydra target
 ``particle_fm.models.flow_matching_module.SetFlowMatchingLitModule`` can be pointed here and the rest of the
 pipeline (Lightning Trainer, EMA callback, evaluation callbacks -> ``sample``) keeps working.  The compute
-of the hot path -- EPiC vector field, FM/CFM loss forward+backward, fixed-step midpoint sampling -- runs in
+of the hot path -- EPiC or Full-Transformer vector field, FM/CFM loss forward+backward, fixed-step midpoint sampling -- runs in
 libpfm_hip.so.  What the native path does not cover raises NotImplementedError at construction or call time
-(never a silent PyTorch fallback): models other than "epic", losses other than FM-OT / CFM, solvers other
+(never a silent PyTorch fallback): models other than "epic" / "droid_fulltransformer", losses other than FM-OT / CFM, solvers other
 than "midpoint", t_emb other than "cosine", use_normaliser=True.
 """
 from __future__ import annotations
@@ -18,7 +18,9 @@ import torch.nn as nn
 from torch import Tensor
 
 from .. import fm_loss as _fm_loss
-from .. import hip_ops
+from .. import fm_loss_tf as _fm_loss_tf
+from .. import hip_ops, hip_ops_tf
+from .components.droid_transformer import FullTransformerEncoder
 from .components.epic import EPiC_encoder
 from .components.losses import ConditionalFlowMatchingLoss, FlowMatchingLoss
 from .components.time_emb import CosineEncoding
@@ -111,10 +113,16 @@ class CNF(nn.Module):
                                     frequencies=frequencies, num_points=num_particles, t_local_cat=t_local_cat,
                                     t_global_cat=t_global_cat, global_cond_dim=global_cond_dim,
                                     local_cond_dim=local_cond_dim, dropout=dropout, sum_scale=sum_scale)
-        elif model in ("droid_fulltransformer", "droid_fullcrossattention", "mdma"):
-            raise NotImplementedError(f"Model {model} has no HIP path in this build (only 'epic').")
+        elif model == "droid_fulltransformer":  # flow_matching_module.py:152-158
+            self.net = FullTransformerEncoder(inpt_dim=input_dim, outp_dim=features,
+                                              ctxt_dim=global_cond_dim + 2 * frequencies, **net_config,
+                                              num_points=num_particles, frequencies=frequencies,
+                                              add_time_to_input=add_time_to_input)
+        elif model in ("droid_fullcrossattention", "mdma"):
+            raise NotImplementedError(f"Model {model} has no HIP path in this build ('epic' and 'droid_fulltransformer' do).")
         else:
             raise NotImplementedError(f"Model {model} not implemented.")  # flow_matching_module.py:170
+        self.is_transformer = model == "droid_fulltransformer"
         self.register_buffer("frequencies", 2 ** torch.arange(frequencies) * torch.pi)  # :172
         self.activation = activation
         self.t_emb = t_emb
@@ -156,6 +164,9 @@ class CNF(nn.Module):
     def fm_loss(self, x, t, z, mask=None, cond=None, sigma: float = 1e-4, kind: str = "FM-OT", eps=None) -> Tensor:
         """Differentiable FM / CFM loss with the draws given (the body of losses.py:38-77 / 101-136)."""
         lay = self.net.layout(x.shape[1])
+        if self.is_transformer:
+            return _fm_loss_tf.tf_fm_loss(lay, self.net.flat_parameters(lay), x, t, z, cond=cond, mask=mask, sigma=sigma,
+                                          kind=kind, eps=eps)
         src = self.net.source_vector(lay)
         return _fm_loss.epic_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps)
 
@@ -167,6 +178,9 @@ class CNF(nn.Module):
             # mask is applied to the ODE right-hand side by the network itself; z arrives already masked
             # `weights` (extension): an already packed kernel blob, e.g. a snapshot taken on another stream
             blob = weights if weights is not None else self.net.packed_weights(z.shape[1])
+            if self.is_transformer:
+                return hip_ops_tf.tf_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
+                                                     ode_steps=ode_steps, premask=False)
             return hip_ops.epic_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
                                                 ode_steps=ode_steps, premask=False)
         if ode_solver in ("em", "ddim"):

@@ -59,7 +59,9 @@ def test_lit_module_surface():
     (dict(t_emb="nope"), NotImplementedError),                  # :231
     (dict(criterion="l1"), NotImplementedError),                # losses.py:36
     (dict(use_normaliser=True), NotImplementedError),
-    (dict(model="droid_fulltransformer"), NotImplementedError),
+    (dict(model="mdma"), NotImplementedError),
+    (dict(model="droid_fulltransformer", net_config={"te_config": {"model_dim": 64, "mha_config": {"num_heads": 4}}}),
+     NotImplementedError),
 ])
 def test_constructor_errors(kw, exc):
     base = dict(optimizer=None, features=3, hidden_dim=128, num_particles=30, frequencies=16, layers=1, latent=10,

@@ -1,0 +1,66 @@
+"""Host logic of the transformer drop-in (no GPU): state_dict layout, default initialisation, error behaviour."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from particle_fm_amd.models import CNF, SetFlowMatchingLitModule
+
+
+def test_state_dict_keys_shapes_and_default_init_match_reference(tf_golden):
+    g = tf_golden
+    torch.manual_seed(int(g.z["seed"]))  # oracle/make_golden.py builds the reference CNF under this seed
+    cnf = CNF(**copy.deepcopy(g.hp))
+    sd = {f"flows.0.{k}": v for k, v in cnf.state_dict().items()}
+    assert list(sd.keys()) == g.keys
+    par = [k for k in g.keys if not k.endswith("frequencies")]
+    for k in par:
+        assert tuple(sd[k].shape) == tuple(g.state[k].shape), k
+    # same RNG stream, same zero-initialised tensors (init_zeros / output_init_zeros): per-tensor sums agree
+    got = np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in par])
+    np.testing.assert_allclose(got, g.z["init_sums"], rtol=1e-12, atol=1e-12)
+    zeroed = [k for k, row in zip(par, got) if row[1] == 0.0 and ("linear" in k or "block.0" in k)]
+    assert len(zeroed) == 2 * (2 * g.hp["net_config"]["te_config"]["num_layers"] + 1)  # out_linear + dense out per layer, outp_embd
+
+
+def test_lit_module_surface_and_strict_load(tf_golden):
+    g = tf_golden
+    m = SetFlowMatchingLitModule(optimizer=None, **copy.deepcopy(g.hp))
+    assert m.hparams.model == "droid_fulltransformer" and m.hparams.num_particles == g.hp["num_particles"]
+    full = dict(g.state)
+    full.update({"loss." + k: v for k, v in g.state.items()})
+    m.load_state_dict(full, strict=True)
+    assert list(m.state_dict().keys()) == g.keys + ["loss." + k for k in g.keys]
+    lay = m.flows[0].net.layout()
+    flat = m.flows[0].net.flat_parameters(lay)
+    assert flat.numel() == lay.n_params == sum(p.numel() for p in m.parameters())
+    # parameters() order == layout order (what engine.FlatParams relies on)
+    assert torch.equal(flat.detach(), torch.cat([p.detach().reshape(-1) for p in m.parameters()]))
+
+
+def test_errors():
+    base = dict(optimizer=None, model="droid_fulltransformer", features=3, num_particles=30, frequencies=16,
+                global_cond_dim=2, add_time_to_input=True, t_emb="cosine")
+    nc = dict(node_embd_config=dict(act_h="lrlu", nrm="layer"), ctxt_embd_config=dict(outp_dim=64, act_h="lrlu", nrm="layer"),
+              te_config=dict(model_dim=128, num_layers=1, mha_config=dict(num_heads=8, do_layer_norm=True),
+                             dense_config=dict(act_h="lrlu", nrm="layer")),
+              outp_embd_config=dict(act_h="lrlu", nrm="layer"))
+    m = SetFlowMatchingLitModule(**base, net_config=copy.deepcopy(nc))
+    x = torch.randn(2, 30, 3)
+    with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
+        m.flows[0](torch.rand(2), x, cond=torch.zeros(2, 2), mask=torch.ones(2, 30, 1))
+    with pytest.raises(NotImplementedError):
+        m.flows[0].decode(x, None, None, ode_solver="rk4")
+    for patch in (("te_config", "mha_config", "num_heads", 4),          # head_dim 32
+                  ("te_config", "mha_config", "do_layer_norm", False),
+                  ("node_embd_config", "act_h", "relu"),
+                  ("te_config", "dense_config", "nrm", "batch"),
+                  ("te_config", "model_dim", 96)):
+        bad = copy.deepcopy(nc)
+        d = bad
+        for k in patch[:-2]:
+            d = d[k]
+        d[patch[-2]] = patch[-1]
+        with pytest.raises((NotImplementedError, ValueError)):
+            SetFlowMatchingLitModule(**base, net_config=bad)
