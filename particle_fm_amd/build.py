@@ -40,6 +40,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cmd = [
         _hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+        # fp32 atomicAdd as the hardware instruction instead of a CAS loop: every buffer the kernels add into is
+        # ordinary (coarse-grained) device memory owned by the caller
+        "-munsafe-fp-atomics",
         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
         *sources(), "-o", LIB + ".tmp",
     ]

@@ -68,58 +68,48 @@ __global__ __launch_bounds__(256) void tf_loss_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm row statistics (mean, rstd) of A[M][K]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tf_rowstats_kernel(const float* __restrict__ A, int lda, int M, int K, float eps,
+template <int NI>
+__global__ __launch_bounds__(256) void tf_rowstats_kernel(const float* __restrict__ A, int M, float eps,
                                                           float* __restrict__ stats) {
+    constexpr int K = 64 * NI;
     const int tid = threadIdx.x, pl = tid & 15;
     const int row = blockIdx.x * 16 + (tid >> 4);
-    const float* ap = A + (int64_t)min(row, M - 1) * lda + 4 * pl;
-    f32x4 v[MAXK / 64];
+    const float* ap = A + (int64_t)min(row, M - 1) * K + 4 * pl;
+    f32x4 v[NI];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXK / 64; ++i)
-        if (64 * i < K) { v[i] = *reinterpret_cast<const f32x4*>(ap + 64 * i); s += hsum4(v[i]); }
+    for (int i = 0; i < NI; ++i) { v[i] = *reinterpret_cast<const f32x4*>(ap + 64 * i); s += hsum4(v[i]); }
     const float mean = row_sum16(s) / (float)K;
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXK / 64; ++i)
-        if (64 * i < K) { const f32x4 dl = v[i] - mean; ss += hsum4(dl * dl); }
+    for (int i = 0; i < NI; ++i) { const f32x4 dl = v[i] - mean; ss += hsum4(dl * dl); }
     const float rstd = 1.0f / sqrtf(row_sum16(ss) / (float)K + eps);
     if (pl == 0 && row < M) { stats[2 * (int64_t)row] = mean; stats[2 * (int64_t)row + 1] = rstd; }
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm backward (row-wise), optionally fed by the output head
+// LayerNorm backward (row-wise)
 // ------------------------------------------------------------------------------------------------
 struct LnBwdArgs {
     const float* A;      // [M][K] input of the LayerNorm (a saved activation)
-    const float* G;      // [M][K] gradient w.r.t. the LayerNorm output; unused when HEAD
+    const float* G;      // [M][K] gradient w.r.t. the LayerNorm output
     const float* add;    // [M][K] gradient joining from the residual path, or nullptr (may alias out)
     float* out;          // [M][K] gradient w.r.t. A, times LeakyReLU'(A) when act
-    float* nout;         // HEAD: the normalised rows (input of the head's Linear), [M][K]
-    const float *v, *u, *gscale;  // HEAD: field, target, scalar grad_out / sum(mask)
-    float* dv;           // HEAD: 2 (v-u) gscale, [M][F]
     const float* blob;
     float* gblob;
-    int64_t gamma, beta, W3, b3;
-    int M, K, F, act;
+    int64_t gamma, beta;
+    int M, K, act;
     float slope, eps;
 };
 
-template <bool HEAD>
+template <int NI>
 __global__ __launch_bounds__(256) void tf_ln_bwd_kernel(LnBwdArgs a) {
-    __shared__ float red[16 * MAXK];
-    __shared__ float db3[16];
+    __shared__ float red[16 * 64 * NI];
     const int tid = threadIdx.x, pl = tid & 15, rg = tid >> 4;
-    if (HEAD) {
-        if (tid < 16) db3[tid] = 0.f;
-        __syncthreads();
-    }
-    constexpr int NI = MAXK / 64;
     f32x4 gsum[NI], bsum[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) { gsum[i] = f32x4{0.f, 0.f, 0.f, 0.f}; bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float invK = 1.0f / (float)a.K;
-    const float gs = HEAD ? a.gscale[0] : 0.f;
 #pragma unroll 1
     for (int pass = 0; pass < 4; ++pass) {
         const int row = blockIdx.x * 64 + 16 * pass + rg;
@@ -129,57 +119,36 @@ __global__ __launch_bounds__(256) void tf_ln_bwd_kernel(LnBwdArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            if (64 * i < a.K) { x[i] = *reinterpret_cast<const f32x4*>(a.A + ro + 64 * i); s += hsum4(x[i]); }
+            { x[i] = *reinterpret_cast<const f32x4*>(a.A + ro + 64 * i); s += hsum4(x[i]); }
         const float mean = row_sum16(s) * invK;
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            if (64 * i < a.K) { const f32x4 dl = x[i] - mean; ss += hsum4(dl * dl); }
+            { const f32x4 dl = x[i] - mean; ss += hsum4(dl * dl); }
         const float rstd = 1.0f / sqrtf(row_sum16(ss) * invK + a.eps);
-        if (HEAD) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) dn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int f = 0; f < a.F; ++f) {
-                const int64_t e = (int64_t)min(row, a.M - 1) * a.F + f;
-                const float d = ok ? 2.0f * (a.v[e] - a.u[e]) * gs : 0.f;
-                if (pl == 0 && ok) { a.dv[e] = d; atomicAdd(db3 + f, d); }
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-                    if (64 * i < a.K)
-                        dn[i] += d * *reinterpret_cast<const f32x4*>(a.blob + a.W3 + (int64_t)f * a.K + 4 * pl + 64 * i);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-                if (64 * i < a.K) {
-                    dn[i] = *reinterpret_cast<const f32x4*>(a.G + ro + 64 * i);
-                    if (!ok) dn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-        }
         float c1 = 0.f, c2 = 0.f;
-        f32x4 xh[NI], g[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            if (64 * i < a.K) {
+            {
+                dn[i] = *reinterpret_cast<const f32x4*>(a.G + ro + 64 * i);
+                if (!ok) dn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + 4 * pl + 64 * i);
-                xh[i] = (x[i] - mean) * rstd;
-                if (HEAD && ok) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 4 * pl + 64 * i);
-                    *reinterpret_cast<f32x4*>(a.nout + ro + 64 * i) = xh[i] * g4 + b4;
-                }
-                g[i] = dn[i] * g4;
-                c1 += hsum4(g[i]);
-                c2 += hsum4(g[i] * xh[i]);
-                gsum[i] += dn[i] * xh[i];
+                const f32x4 xh = (x[i] - mean) * rstd;
+                const f32x4 g = dn[i] * g4;
+                c1 += hsum4(g);
+                c2 += hsum4(g * xh);
+                gsum[i] += dn[i] * xh;
                 bsum[i] += dn[i];
+                dn[i] = g;
             }
         c1 = row_sum16(c1) * invK;
         c2 = row_sum16(c2) * invK;
         if (ok) {
 #pragma unroll
             for (int i = 0; i < NI; ++i)
-                if (64 * i < a.K) {
-                    f32x4 dA = (g[i] - c1 - xh[i] * c2) * rstd;
+                {
+                    const f32x4 xh = (x[i] - mean) * rstd;
+                    f32x4 dA = (dn[i] - c1 - xh * c2) * rstd;
                     if (a.add) dA += *reinterpret_cast<const f32x4*>(a.add + ro + 64 * i);
                     if (a.act) {
                         dA.x *= x[i].x > 0.f ? 1.f : a.slope; dA.y *= x[i].y > 0.f ? 1.f : a.slope;
@@ -189,17 +158,13 @@ __global__ __launch_bounds__(256) void tf_ln_bwd_kernel(LnBwdArgs a) {
                 }
         }
     }
-    if (HEAD) {
-        __syncthreads();
-        if (tid < a.F) atomicAdd(a.gblob + a.b3 + tid, db3[tid]);
-    }
     // d gamma / d beta: reduce the 16 row groups through LDS, one atomic per column per workgroup
 #pragma unroll 1
     for (int which = 0; which < 2; ++which) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            if (64 * i < a.K) *reinterpret_cast<f32x4*>(red + rg * a.K + 4 * pl + 64 * i) = which ? bsum[i] : gsum[i];
+            *reinterpret_cast<f32x4*>(red + rg * a.K + 4 * pl + 64 * i) = which ? bsum[i] : gsum[i];
         __syncthreads();
         for (int c = tid; c < a.K; c += 256) {
             float s = 0.f;
@@ -208,6 +173,70 @@ __global__ __launch_bounds__(256) void tf_ln_bwd_kernel(LnBwdArgs a) {
             atomicAdd(a.gblob + (which ? a.beta : a.gamma) + c, s);
         }
     }
+}
+
+// Output head backward, first half: dv = 2 (v-u) gscale, d b3, the gradient w.r.t. the head's (normalised) input
+// dn = dv W3, and the normalised rows themselves (for d W3).  16 lanes per row.
+struct HeadBwdArgs {
+    const float* A;   // [M][K] outp_embd hidden (post-activation)
+    const float *v, *u, *gscale;
+    float *dv, *dn, *nout;
+    const float* blob;
+    float* gblob;
+    int64_t gamma, beta, W3, b3;
+    int M, K, F;
+    float eps;
+};
+
+template <int NI>
+__global__ __launch_bounds__(256) void tf_head_bwd_kernel(HeadBwdArgs a) {
+    __shared__ float db3[16];
+    const int tid = threadIdx.x, pl = tid & 15;
+    if (tid < 16) db3[tid] = 0.f;
+    __syncthreads();
+    const int row = blockIdx.x * 16 + (tid >> 4);
+    const bool ok = row < a.M;
+    const int64_t ro = (int64_t)min(row, a.M - 1) * a.K + 4 * pl;
+    const float gs = a.gscale[0];
+    f32x4 x[NI];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        { x[i] = *reinterpret_cast<const f32x4*>(a.A + ro + 64 * i); s += hsum4(x[i]); }
+    const float mean = row_sum16(s) / (float)a.K;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        { const f32x4 dl = x[i] - mean; ss += hsum4(dl * dl); }
+    const float rstd = 1.0f / sqrtf(row_sum16(ss) / (float)a.K + a.eps);
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            {
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + 4 * pl + 64 * i);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 4 * pl + 64 * i);
+                *reinterpret_cast<f32x4*>(a.nout + ro + 64 * i) = (x[i] - mean) * rstd * g4 + b4;
+            }
+    }
+    f32x4 dn[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) dn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int f = 0; f < a.F; ++f) {
+        const int64_t e = (int64_t)min(row, a.M - 1) * a.F + f;
+        const float d = ok ? 2.0f * (a.v[e] - a.u[e]) * gs : 0.f;
+        if (pl == 0 && ok) { a.dv[e] = d; atomicAdd(db3 + f, d); }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+                dn[i] += d * *reinterpret_cast<const f32x4*>(a.blob + a.W3 + (int64_t)f * a.K + 4 * pl + 64 * i);
+    }
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            *reinterpret_cast<f32x4*>(a.dn + ro + 64 * i) = dn[i];
+    }
+    __syncthreads();
+    if (tid < a.F) atomicAdd(a.gblob + a.b3 + tid, db3[tid]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -258,8 +287,8 @@ struct DwArgs {
     const float* A;      // [M][lda] LayerNorm input
     const float* stats;  // [M][2] mean, rstd of A's rows
     const float* blob;
-    float* gblob;
-    int64_t gamma, beta, gW;
+    float* part;         // [tiles][nsplit][128*128] partial tiles
+    int64_t gamma, beta;
     int ldz, lda, M, NO, K, nsplit, row_tiles;
 };
 
@@ -315,20 +344,32 @@ __global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
 #undef PFM_DW_ROW
         }
     }
-    // acc[c][e].r = dW[o][k] with o = 128 to + 64 wo + 4 (4q + r) + c, k = 128 tk + 64 wk + 4 pl + e
-    const int kb = 128 * tk + 64 * wk + 4 * pl;
+    // partial tile -> scratch, accumulator order: float4 (e = 0..3) at (((w*4 + c)*4 + r)*64 + lane); summed over the
+    // splits and scattered into the gradient blob by tf_dw_reduce_kernel (atomics on the blob were 10x the GEMM time)
+    float* pp = a.part + ((int64_t)tile * a.nsplit + split) * 16384;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int o = 128 * to + 64 * wo + 4 * (4 * q + r) + c;
-            float* gp = a.gblob + a.gW + ((int64_t)((o >> 4) * nkc + (kb >> 7)) * 8 + ((kb >> 4) & 7)) * 256 +
-                        (((kb >> 2) & 3) * 16 + (o & 15)) * 4;
-            atomicAdd(gp + 0, acc[c][0][r]);
-            atomicAdd(gp + 1, acc[c][1][r]);
-            atomicAdd(gp + 2, acc[c][2][r]);
-            atomicAdd(gp + 3, acc[c][3][r]);
+            const f32x4 v = {acc[c][0][r], acc[c][1][r], acc[c][2][r], acc[c][3][r]};
+            *reinterpret_cast<f32x4*>(pp + ((((w * 4 + c) * 4 + r) * 64 + lane) << 2)) = v;
         }
+}
+
+// gblob[W block] += sum over splits of the partial tiles.  Element p of a tile: w = p>>12, c = (p>>10)&3, r = (p>>8)&3,
+// lane = (p>>2)&63, e = p&3  ->  dW[o][k], o = 128 to + 64 (w>>1) + 4 (4 (lane>>4) + r) + c, k = 128 tk + 64 (w&1) + 4 (lane&15) + e
+__global__ __launch_bounds__(256) void tf_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ gblob,
+                                                           int64_t gW, int nkc, int nsplit) {
+    const int tile = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const float* pp = part + (int64_t)tile * nsplit * 16384 + p;
+    float s = 0.f;
+    for (int i = 0; i < nsplit; ++i) s += pp[(int64_t)i * 16384];
+    const int to = tile / nkc, tk = tile - to * nkc;
+    const int w = p >> 12, c = (p >> 10) & 3, r = (p >> 8) & 3, lane = (p >> 2) & 63, e = p & 3;
+    const int o = 128 * to + 64 * (w >> 1) + 4 * (4 * (lane >> 4) + r) + c;
+    const int k = 128 * tk + 64 * (w & 1) + 4 * (lane & 15) + e;
+    gblob[gW + ((int64_t)((o >> 4) * nkc + (k >> 7)) * 8 + ((k >> 4) & 7)) * 256 + (((k >> 2) & 3) * 16 + (o & 15)) * 4 + (k & 3)] += s;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
     // ctxt_emdb input block: Linear, LeakyReLU (the LayerNorm follows)
     for (int o = tid; o < a.CH; o += 512) {
         float acc = blob[a.c1b + o];
+#pragma unroll 8
         for (int k = 0; k < Kc; ++k) acc = fmaf(blob[a.c1W + (int64_t)k * a.CH + o], cin[k], acc);
         acc = lrelu(acc, a.slope);
         hb[o] = acc;
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
         const int j = tid & 63, p = tid >> 6;
         float acc = 0.f;
         if (j < a.CO)
+#pragma unroll 8
             for (int o = p; o < a.CH; o += 8) acc = fmaf(blob[a.c2W + (int64_t)o * a.CO + j], hb[o], acc);
         part[tid] = acc;
     }
@@ -115,8 +117,10 @@ __global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
     for (int c = 0; c < a.nb; ++c) {
         for (int o = tid; o < a.Hd; o += 512) {
             float acc = blob[a.bb[c] + o];
+#pragma unroll 8
             for (int j = 0; j < a.CO; ++j) acc = fmaf(blob[a.Wc[c] + (int64_t)j * a.Hd + o], cx[j], acc);
             if (c == 0 && a.n1Wt >= 0)
+#pragma unroll 8
                 for (int k = 0; k < a.T; ++k) acc = fmaf(blob[a.n1Wt + (int64_t)k * a.Hd + o], cin[k], acc);
             a.jb[((int64_t)jet * a.nb + c) * a.Hd + o] = acc;
         }
@@ -161,8 +165,10 @@ struct LinArgs {
 };
 
 // row statistics of a BM-row tile: 16 lanes per row, two-pass (mean, then centred sum of squares)
-__device__ __forceinline__ void ln_stats_tile(const float* __restrict__ A, int lda, int M, int K, int row0, float eps,
+template <int NI>
+__device__ __forceinline__ void ln_stats_tile(const float* __restrict__ A, int lda, int M, int row0, float eps,
                                               float* __restrict__ stat, int tid) {
+    constexpr int K = 64 * NI;
     const int lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
     constexpr int RPW = BM / (LT / 64);  // rows per wave
 #pragma unroll 1
@@ -170,22 +176,20 @@ __device__ __forceinline__ void ln_stats_tile(const float* __restrict__ A, int l
         const int r = RPW * w + 4 * pass + q;
         const int row = min(row0 + r, M - 1);
         const float* ap = A + (int64_t)row * lda + 4 * pl;
-        f32x4 v[MAXK / 64];
+        f32x4 v[NI];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXK / 64; ++i)
-            if (64 * i < K) {
-                v[i] = *reinterpret_cast<const f32x4*>(ap + 64 * i);
-                s += hsum4(v[i]);
-            }
+        for (int i = 0; i < NI; ++i) {
+            v[i] = *reinterpret_cast<const f32x4*>(ap + 64 * i);
+            s += hsum4(v[i]);
+        }
         const float mean = row_sum16(s) / (float)K;
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXK / 64; ++i)
-            if (64 * i < K) {
-                const f32x4 dl = v[i] - mean;
-                ss += hsum4(dl * dl);
-            }
+        for (int i = 0; i < NI; ++i) {
+            const f32x4 dl = v[i] - mean;
+            ss += hsum4(dl * dl);
+        }
         const float rstd = 1.0f / sqrtf(row_sum16(ss) / (float)K + eps);
         if (pl == 0) {
             stat[2 * r] = mean;
@@ -203,8 +207,10 @@ __device__ __forceinline__ bool tile_of_block(int bid, int row_tiles, int nchunk
     return rt < row_tiles;
 }
 
-template <bool LN>
+// NI = K / 64 of the LayerNorm prologue (0: no LayerNorm)
+template <int NI>
 __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
+    constexpr bool LN = NI > 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const tile = lds;             // BM x 128, 16-byte slots XOR-swizzled with (row & 15)
     float* const stat = lds + BM * 128;  // BM x (mean, rstd)
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     const int nkc = a.K >> 7;
 
     if (LN) {
-        ln_stats_tile(a.A, a.lda, a.M, a.K, row0, a.eps, stat, tid);
+        ln_stats_tile<LN ? NI : 2>(a.A, a.lda, a.M, row0, a.eps, stat, tid);
         __syncthreads();
     }
 
@@ -431,44 +437,42 @@ struct HeadArgs {
     float eps, coef;
 };
 
+template <int NI>
 __global__ __launch_bounds__(256) void tf_head_kernel(HeadArgs a) {
+    constexpr int Hd = 64 * NI;
     const int tid = threadIdx.x, pl = tid & 15;
     const int row = blockIdx.x * 16 + (tid >> 4);
     const int rowc = min(row, a.M - 1);
-    const float* ap = a.A + (int64_t)rowc * a.Hd + 4 * pl;
-    f32x4 v[MAXK / 64];
+    const float* ap = a.A + (int64_t)rowc * Hd + 4 * pl;
+    f32x4 v[NI];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXK / 64; ++i)
-        if (64 * i < a.Hd) {
-            v[i] = *reinterpret_cast<const f32x4*>(ap + 64 * i);
-            s += hsum4(v[i]);
-        }
-    const float mean = row_sum16(s) / (float)a.Hd;
+    for (int i = 0; i < NI; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(ap + 64 * i);
+        s += hsum4(v[i]);
+    }
+    const float mean = row_sum16(s) / (float)Hd;
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXK / 64; ++i)
-        if (64 * i < a.Hd) {
-            const f32x4 dl = v[i] - mean;
-            ss += hsum4(dl * dl);
-        }
-    const float rstd = 1.0f / sqrtf(row_sum16(ss) / (float)a.Hd + a.eps);
+    for (int i = 0; i < NI; ++i) {
+        const f32x4 dl = v[i] - mean;
+        ss += hsum4(dl * dl);
+    }
+    const float rstd = 1.0f / sqrtf(row_sum16(ss) / (float)Hd + a.eps);
 #pragma unroll
-    for (int i = 0; i < MAXK / 64; ++i)
-        if (64 * i < a.Hd) {
-            const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + 4 * pl + 64 * i);
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 4 * pl + 64 * i);
-            v[i] = (v[i] - mean) * rstd * g4 + b4;
-        }
+    for (int i = 0; i < NI; ++i) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + 4 * pl + 64 * i);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 4 * pl + 64 * i);
+        v[i] = (v[i] - mean) * rstd * g4 + b4;
+    }
 #pragma unroll 1
     for (int f = 0; f < a.F; ++f) {
         float d = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXK / 64; ++i)
-            if (64 * i < a.Hd) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.blob + a.W + (int64_t)f * a.Hd + 4 * pl + 64 * i);
-                d += hsum4(v[i] * w4);
-            }
+        for (int i = 0; i < NI; ++i) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.blob + a.W + (int64_t)f * Hd + 4 * pl + 64 * i);
+            d += hsum4(v[i] * w4);
+        }
         d = row_sum16(d) + a.blob[a.b + f];
         if (pl == (f & 15) && row < a.M) {
             const int64_t e = (int64_t)row * a.F + f;

@@ -53,10 +53,17 @@ int launch_linear(const Plan& p, const float* A, int lda, int K, const pfm_tf_li
     a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
     const int grid = ((a.row_tiles + 7) / 8) * 8 * (NO / BN);
     const size_t lds = (BM * 128 + 2 * BM) * sizeof(float);
-    if (ln && ln->gamma >= 0)
-        hipLaunchKernelGGL(tf_linear_kernel<true>, dim3(grid), dim3(LT), lds, p.s, a);
-    else
-        hipLaunchKernelGGL(tf_linear_kernel<false>, dim3(grid), dim3(LT), lds, p.s, a);
+    if (ln && ln->gamma >= 0) {
+        switch (K / 64) {
+            case 2: hipLaunchKernelGGL(tf_linear_kernel<2>, dim3(grid), dim3(LT), lds, p.s, a); break;
+            case 4: hipLaunchKernelGGL(tf_linear_kernel<4>, dim3(grid), dim3(LT), lds, p.s, a); break;
+            case 6: hipLaunchKernelGGL(tf_linear_kernel<6>, dim3(grid), dim3(LT), lds, p.s, a); break;
+            case 8: hipLaunchKernelGGL(tf_linear_kernel<8>, dim3(grid), dim3(LT), lds, p.s, a); break;
+            default: return set_err(PFM_E_BADARG, "LayerNorm width must be 128, 256, 384 or 512");
+        }
+    } else {
+        hipLaunchKernelGGL(tf_linear_kernel<0>, dim3(grid), dim3(LT), lds, p.s, a);
+    }
     return check_hip(hipGetLastError(), "tf_linear_kernel launch");
 }
 
@@ -133,7 +140,13 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
     h.A = ws + w.oh; h.blob = p.blob;
     h.gamma = d.o_norm.gamma; h.beta = d.o_norm.beta; h.W = d.o2.W; h.b = d.o2.b;
     h.M = p.M; h.Hd = Hd; h.F = d.features; h.eps = d.ln_eps;
-    hipLaunchKernelGGL(tf_head_kernel, dim3((p.M + 15) / 16), dim3(256), 0, p.s, h);
+    const dim3 hg((p.M + 15) / 16), hb(256);
+    switch (Hd / 64) {
+        case 2: hipLaunchKernelGGL(tf_head_kernel<2>, hg, hb, 0, p.s, h); break;
+        case 4: hipLaunchKernelGGL(tf_head_kernel<4>, hg, hb, 0, p.s, h); break;
+        case 6: hipLaunchKernelGGL(tf_head_kernel<6>, hg, hb, 0, p.s, h); break;
+        default: hipLaunchKernelGGL(tf_head_kernel<8>, hg, hb, 0, p.s, h); break;
+    }
     return check_hip(hipGetLastError(), "tf_head_kernel launch");
 }
 
@@ -148,8 +161,10 @@ int make_plan(Plan& p, const pfm_tf_desc* d, const float* blob, float* ws, int n
 
 
 // ---- backward scratch (floats) -------------------------------------------------------------------
+constexpr int DW_MAX_PARTS = 1024;  // partial 128x128 dW tiles in flight per Linear
+
 struct Bs {
-    int64_t dv, gh, gh2, gx, ga, gqkv, gatt, stats, rstat, djb, dctxt, dhn, dhnx, dpre, hn, total;
+    int64_t dv, gh, gh2, gx, ga, gqkv, gatt, stats, rstat, djb, dctxt, dhn, dhnx, dpre, hn, dwpart, total;
 };
 
 Bs make_bs(const pfm_tf_desc& d, int n_jets) {
@@ -162,7 +177,7 @@ Bs make_bs(const pfm_tf_desc& d, int n_jets) {
     b.gh2 = take(M * Hd);
     b.gx = take(M * D);
     b.ga = take(M * D);
-    b.gqkv = take(M * 3 * D);
+    b.gqkv = take(M * (3 * D > Hd ? 3 * D : Hd));  // also the head's M x hidden scratch
     b.gatt = take(M * D);
     b.stats = take((int64_t)n_jets * d.heads * 3 * attn_np16(d.n_points));
     b.rstat = take(M * 2);
@@ -172,6 +187,7 @@ Bs make_bs(const pfm_tf_desc& d, int n_jets) {
     b.dhnx = take((int64_t)n_jets * d.ctxt_hidden);
     b.dpre = take((int64_t)n_jets * d.ctxt_hidden);
     b.hn = take((int64_t)n_jets * d.ctxt_hidden);
+    b.dwpart = take((int64_t)DW_MAX_PARTS * 16384);
     b.total = o;
     return b;
 }
@@ -191,7 +207,14 @@ struct Bwd {
         return check_hip(hipGetLastError(), "tf_colsum_kernel launch");
     }
     int rowstats(const float* A, int K) const {
-        hipLaunchKernelGGL(tf_rowstats_kernel, dim3((p.M + 15) / 16), dim3(256), 0, p.s, A, K, p.M, K, p.d->ln_eps, sc + b.rstat);
+        const dim3 g((p.M + 15) / 16), bl(256);
+        float* st = sc + b.rstat;
+        switch (K / 64) {
+            case 2: hipLaunchKernelGGL(tf_rowstats_kernel<2>, g, bl, 0, p.s, A, p.M, p.d->ln_eps, st); break;
+            case 4: hipLaunchKernelGGL(tf_rowstats_kernel<4>, g, bl, 0, p.s, A, p.M, p.d->ln_eps, st); break;
+            case 6: hipLaunchKernelGGL(tf_rowstats_kernel<6>, g, bl, 0, p.s, A, p.M, p.d->ln_eps, st); break;
+            default: hipLaunchKernelGGL(tf_rowstats_kernel<8>, g, bl, 0, p.s, A, p.M, p.d->ln_eps, st); break;
+        }
         return check_hip(hipGetLastError(), "tf_rowstats_kernel launch");
     }
     // dW += Z^T LN(A)
@@ -199,17 +222,19 @@ struct Bwd {
         int rc = rowstats(A, K);
         if (rc) return rc;
         DwArgs a;
-        a.Z = Z; a.A = A; a.stats = sc + b.rstat; a.blob = p.blob; a.gblob = gblob;
-        a.gamma = ln.gamma; a.beta = ln.beta; a.gW = gW;
+        a.Z = Z; a.A = A; a.stats = sc + b.rstat; a.blob = p.blob; a.part = sc + b.dwpart;
+        a.gamma = ln.gamma; a.beta = ln.beta;
         a.ldz = NO; a.lda = K; a.M = p.M; a.NO = NO; a.K = K;
         a.row_tiles = (p.M + BM - 1) / BM;
         const int tiles = (NO / 128) * (K / 128);
-        int ns = 1024 / tiles;
+        int ns = DW_MAX_PARTS / tiles;
         if (ns < 1) ns = 1;
         if (ns > a.row_tiles) ns = a.row_tiles;
         a.nsplit = ns;
         hipLaunchKernelGGL(tf_dw_kernel, dim3(tiles * ns), dim3(LT), 2 * 64 * DWS * sizeof(float), p.s, a);
-        return check_hip(hipGetLastError(), "tf_dw_kernel launch");
+        if ((rc = check_hip(hipGetLastError(), "tf_dw_kernel launch"))) return rc;
+        hipLaunchKernelGGL(tf_dw_reduce_kernel, dim3(64, tiles), dim3(256), 0, p.s, (const float*)a.part, gblob, gW, K / 128, ns);
+        return check_hip(hipGetLastError(), "tf_dw_reduce_kernel launch");
     }
     // out[M][K] = Z[M][NO] W   (gradient w.r.t. the Linear's normalised input)
     int dx(const float* Z, int NO, const pfm_tf_lin& lin, int K, float* out) const {
@@ -223,7 +248,13 @@ struct Bwd {
         a.A = A; a.G = G; a.add = add; a.out = out; a.blob = p.blob; a.gblob = gblob;
         a.gamma = ln.gamma; a.beta = ln.beta; a.M = p.M; a.K = K; a.act = act ? 1 : 0;
         a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
-        hipLaunchKernelGGL(tf_ln_bwd_kernel<false>, dim3((p.M + 63) / 64), dim3(256), 0, p.s, a);
+        const dim3 g((p.M + 63) / 64), bl(256);
+        switch (K / 64) {
+            case 2: hipLaunchKernelGGL(tf_ln_bwd_kernel<2>, g, bl, 0, p.s, a); break;
+            case 4: hipLaunchKernelGGL(tf_ln_bwd_kernel<4>, g, bl, 0, p.s, a); break;
+            case 6: hipLaunchKernelGGL(tf_ln_bwd_kernel<6>, g, bl, 0, p.s, a); break;
+            default: hipLaunchKernelGGL(tf_ln_bwd_kernel<8>, g, bl, 0, p.s, a); break;
+        }
         return check_hip(hipGetLastError(), "tf_ln_bwd_kernel launch");
     }
     int outer(const float* U, int64_t ldu, int K, const float* V, int64_t ldv, int NO, int64_t g) const {
@@ -250,14 +281,21 @@ int run_backward(const Bwd& B, const float* cond, const float* mask, const float
     int rc;
     // ---- output head: v = LN(oh) W3^T + b3 ----
     {
-        LnBwdArgs a{};
-        a.A = ws + w.oh; a.out = gh; a.nout = gh2; a.v = v; a.u = u; a.gscale = gscale; a.dv = sc + b.dv;
+        HeadBwdArgs a;
+        a.A = ws + w.oh; a.v = v; a.u = u; a.gscale = gscale; a.dv = sc + b.dv; a.dn = gqkv; a.nout = gh2;
         a.blob = p.blob; a.gblob = B.gblob;
         a.gamma = d.o_norm.gamma; a.beta = d.o_norm.beta; a.W3 = d.o2.W; a.b3 = d.o2.b;
-        a.M = p.M; a.K = Hd; a.F = F; a.act = 1; a.slope = d.neg_slope; a.eps = d.ln_eps;
-        hipLaunchKernelGGL(tf_ln_bwd_kernel<true>, dim3((p.M + 63) / 64), dim3(256), 0, p.s, a);
-        PFM_TRY(check_hip(hipGetLastError(), "tf_ln_bwd_kernel<head> launch"));
+        a.M = p.M; a.K = Hd; a.F = F; a.eps = d.ln_eps;
+        const dim3 g((p.M + 15) / 16), bl(256);
+        switch (Hd / 64) {
+            case 2: hipLaunchKernelGGL(tf_head_bwd_kernel<2>, g, bl, 0, p.s, a); break;
+            case 4: hipLaunchKernelGGL(tf_head_bwd_kernel<4>, g, bl, 0, p.s, a); break;
+            case 6: hipLaunchKernelGGL(tf_head_bwd_kernel<6>, g, bl, 0, p.s, a); break;
+            default: hipLaunchKernelGGL(tf_head_bwd_kernel<8>, g, bl, 0, p.s, a); break;
+        }
+        PFM_TRY(check_hip(hipGetLastError(), "tf_head_bwd_kernel launch"));
         PFM_TRY(B.colsum(gh2, Hd, Hd, sc + b.dv, F, nullptr, d.o2.W));
+        PFM_TRY(B.lnbwd(ws + w.oh, Hd, gqkv, nullptr, gh, d.o_norm, true));
     }
     const float* xL = d.layers ? ws + w.layer0 + w.lstride * (d.layers - 1) + w.o_xout : ws + w.x0;
     // ---- outp_embd input block ----

@@ -36,3 +36,17 @@ if steps > 1:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"sample {steps} steps: {dt*1e3:.1f} ms  {B/dt:.1f} jets/s  {fl*2*(steps-1)/dt/1e12:.1f} TFLOP/s")
+if len(sys.argv) > 3 and sys.argv[3] == "train":
+    from particle_fm_amd.fm_loss_tf import tf_fm_loss
+    flat = torch.cat([st[k].reshape(-1) for k in lay.keys()]).cuda().requires_grad_(True)
+    z = torch.randn(B, 279, 3, generator=gen).cuda()
+    for _ in range(2):
+        loss = tf_fm_loss(lay, flat, x, t, z, cond, mask.unsqueeze(-1)); loss.backward()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        flat.grad = None
+        loss = tf_fm_loss(lay, flat, x, t, z, cond, mask.unsqueeze(-1)); loss.backward()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print(f"loss fwd+bwd: {dt*1e3:.2f} ms  {B/dt:.0f} jets/s  {3*fl/dt/1e12:.1f} TFLOP/s algorithmic")
