@@ -400,10 +400,89 @@ def gen_transformer(ref, name, hp, B, store_all, out_dir, seed=2024):
     print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
 
 
+# ----------------------------------------------------------------------------------------------
+# BASELINE cfg 5: EPiC at JetClass width (experiment/jetclass_cond.yaml:32-42): weights re-derived from the seed
+# ----------------------------------------------------------------------------------------------
+WIDE_BASE = dict(BASE, features=13, hidden_dim=300, latent=16, global_cond_dim=12, local_cond_dim=0)
+WIDE_CONFIGS = {
+    "small": (dict(WIDE_BASE, num_particles=24, layers=2), 4),
+    "jetclass": (dict(WIDE_BASE, num_particles=128, layers=20), 2),
+}
+
+
+def gen_epic_wide(ref, name, hp, B, out_dir, seed=777):
+    import json
+
+    from oracle.seeded import seeded_state, subsample
+
+    torch.manual_seed(seed)
+    cnf = ref.fmm.CNF(**hp)
+    shapes = {k: tuple(v.shape) for k, v in cnf.state_dict().items() if k != "frequencies"}
+    new = seeded_state(shapes, seed)
+    sd = cnf.state_dict()
+    for k, v in new.items():
+        sd[k] = torch.from_numpy(v)
+    cnf.load_state_dict(sd)
+    flows = torch.nn.ModuleList([cnf])
+    N, Fe, Cg = hp["num_particles"], hp["features"], hp["global_cond_dim"]
+    out = {"_keys": np.array(["flows.0." + k for k in cnf.state_dict().keys()])}
+    out["_shapes_json"] = np.array(json.dumps({"flows.0." + k: list(s) for k, s in shapes.items()}))
+    out["seed"] = np.array(seed)
+    out["hp_json"] = np.array(json.dumps(hp))
+    out["freqs"] = torch.arange(2 * hp["frequencies"]).exp().numpy()
+    out["abs_sum"] = np.array(sum(float(np.abs(v).sum(dtype=np.float64)) for v in new.values()))
+    gen = torch.Generator().manual_seed(seed + 1)
+    for mk in ("f32", "int64", "none"):
+        mask = make_mask(B, N, mk, gen)
+        x = torch.randn(B, N, Fe, generator=gen)
+        if mask is not None:
+            x = x * mask
+        cond = torch.randn(B, Cg, generator=gen)
+        t = torch.rand(B, generator=gen)
+        tag = f"nfe_{mk}/"
+        with torch.no_grad():
+            tt = t.unsqueeze(-1).repeat_interleave(N, dim=1)
+            v_vec = cnf(tt, x, cond=cond, mask=mask)
+            v_sca = cnf(t[0].clone(), x, cond=cond, mask=mask)
+        out[tag + "x"], out[tag + "t"], out[tag + "cond"] = x.numpy(), t.numpy(), cond.numpy()
+        if mask is not None:
+            out[tag + "mask"] = mask.numpy()
+        out[tag + "v_vec_t"], out[tag + "v_scalar_t"] = v_vec.numpy(), v_sca.numpy()
+    mask = make_mask(B, N, "f32", gen)
+    x = torch.randn(B, N, Fe, generator=gen) * mask
+    cond = torch.randn(B, Cg, generator=gen)
+    loss_mod = ref.losses.FlowMatchingLoss(flows=flows, sigma=1e-4)
+    torch.manual_seed(9999)
+    cnf.zero_grad()
+    loss = loss_mod(x, mask=mask, cond=cond)
+    loss.backward()
+    torch.manual_seed(9999)
+    t = torch.rand_like(torch.ones(B))
+    z = torch.randn_like(x)
+    tag = "loss_f32/"
+    out[tag + "x"], out[tag + "t"], out[tag + "z"] = x.numpy(), t.numpy(), z.numpy()
+    out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
+    for k, p in cnf.named_parameters():
+        out[tag + "grad/flows.0." + k] = subsample(p.grad.detach().clone().numpy())
+    for steps in (3, 10):
+        mask = make_mask(B, N, "f32", gen)
+        cond = torch.randn(B, Cg, generator=gen)
+        z = torch.randn(B, N, Fe, generator=gen)
+        wrapped = ref.fmm.ode_wrapper(model=cnf, cond=cond, mask=mask, loss_type="FM-OT")
+        with torch.no_grad():
+            xe = midpoint_trajectory_end(wrapped, z * mask, torch.linspace(1.0, 0.0, steps))
+        tag = f"midpoint_{steps}/"
+        out[tag + "z"], out[tag + "mask"], out[tag + "cond"], out[tag + "x_end"] = (
+            z.numpy(), mask.numpy(), cond.numpy(), xe.numpy())
+    path = os.path.join(out_dir, f"epicw_{name}.npz")
+    np.savez(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf}; default all")
+    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide}; default all")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
@@ -414,6 +493,9 @@ def main():
             gen_config(ref, name, hp, args.out)
     if ap2 is None or "no_sets" in ap2:
         gen_no_sets(ref, args.out)
+    for name, (hp, B) in WIDE_CONFIGS.items():
+        if ap2 is None or "wide" in ap2:
+            gen_epic_wide(ref, name, hp, B, args.out)
     for name, (hp, B, store_all) in TF_CONFIGS.items():
         if ap2 is None or "tf" in ap2:
             gen_transformer(ref, name, hp, B, store_all, args.out)

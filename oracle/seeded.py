@@ -12,11 +12,14 @@ import numpy as np
 
 def seeded_state(shapes: dict, seed: int) -> dict:
     """shapes: ordered {key: shape}.  2-D tensors: U(-1,1)/sqrt(fan_in); 1-D ``*.weight`` (LayerNorm gain):
-    1 + 0.1 N(0,1); every bias: 0.05 N(0,1)."""
+    1 + 0.1 N(0,1); every bias: 0.05 N(0,1); ``*.weight_g`` (weight-norm gain, (out,1)): 0.577 (1 + 0.2 N(0,1)),
+    i.e. the norm of a default-initialised row, perturbed."""
     rng = np.random.default_rng(seed)
     out = {}
     for k, shp in shapes.items():
-        if len(shp) == 2:
+        if k.endswith("weight_g"):
+            w = 0.577 * (1.0 + 0.2 * rng.standard_normal(shp))
+        elif len(shp) == 2:
             w = rng.uniform(-1.0, 1.0, size=shp) / np.sqrt(shp[1])
         elif k.endswith(".weight"):
             w = 1.0 + 0.1 * rng.standard_normal(shp)

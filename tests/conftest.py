@@ -57,11 +57,13 @@ class TfGolden:
     """tests/golden/tf_<name>.npz (BASELINE cfg 4 family).  The large fixture does not store the weights: they are
     re-derived from the stored seed (oracle/seeded.py) and checked against the stored |w| sum."""
 
+    FILE = "tf_{}.npz"
+
     def __init__(self, name):
         from oracle.seeded import seeded_state
 
         self.name = name
-        self.z = np.load(os.path.join(GOLDEN, f"tf_{name}.npz"), allow_pickle=False)
+        self.z = np.load(os.path.join(GOLDEN, self.FILE.format(name)), allow_pickle=False)
         self.hp = json.loads(str(self.z["hp_json"]))
         self.keys = [str(k) for k in self.z["_keys"]]
         self.freqs = torch.from_numpy(self.z["freqs"])
@@ -83,6 +85,24 @@ class TfGolden:
         from oracle.seeded import subsample
 
         return torch.from_numpy(subsample(g.detach().cpu().numpy())) if self.subsampled else g.detach().cpu()
+
+
+class WideGolden(TfGolden):
+    """tests/golden/epicw_<name>.npz: EPiC at the JetClass width (BASELINE cfg 5), weights re-derived from the seed."""
+
+    FILE = "epicw_{}.npz"
+
+
+def load_wide_golden(name):
+    key = "epicw_" + name
+    if key not in _cache:
+        _cache[key] = WideGolden(name)
+    return _cache[key]
+
+
+@pytest.fixture(params=["small", "jetclass"])
+def wide_golden(request):
+    return load_wide_golden(request.param)
 
 
 def load_tf_golden(name):
