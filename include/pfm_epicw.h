@@ -1,0 +1,66 @@
+/*
+ * pfm_epicw.h -- C ABI of libpfm_hip.so, part 3: the EPiC vector field at widths the jet-resident kernel of
+ * pfm_hip.h cannot hold in LDS (hidden_dim != 128, e.g. the JetClass configuration: hidden 300, latent 16,
+ * 20 layers, 13 features, 12 conditioning values; configs/experiment/jetclass_cond.yaml:32-42).
+ *
+ * Same conventions as pfm_hip.h / pfm_tf.h.  Reference interface replaced:
+ *   pfm_ew_forward           CNF.forward with model="epic"      flow_matching_module.py:191-233
+ *                            -> EPiC_encoder.forward / EPiC_layer.forward   components/epic.py:304-391, 85-203
+ *   pfm_ew_sample_midpoint   CNF.decode(ode_solver="midpoint")  flow_matching_module.py:245-259, 283-287, 668-671
+ *
+ * Data layout.  Particles of all jets form one row matrix (M = n_jets * n_points rows) of Hp = hidden rounded up
+ * to a multiple of 128 columns (padding columns are exactly 0 everywhere: zero weight rows / columns, zero bias);
+ * per-jet quantities live in P[n_jets][256 + Hp] = [temb | cond | 0 .. (128) ; g | 0 .. (128) ; g1 (Hp)] and
+ * Q[n_jets][2 Hp] = [masked mean | masked sum * sum_scale].  Every Linear is the fp32-MFMA GEMM of pfm_tf.h
+ * (MFMA_AK weights); the columns that multiply per-jet vectors (time, conditioning, broadcast global vector) are
+ * evaluated once per jet by small GEMMs over the P rows into "jet bias" rows.
+ *   fc_local1 / fc_local2 / fc_l2   [Hp][Hp]           particle block
+ *   jb  (per layer)                 [2 Hp][256]        rows: fc_local1 extras | fc_local2 extras, cols: the first 256 of P; bias = the layers' biases
+ *   sjb (once per evaluation)       [2 Hp + 128][256]  rows: fc_l1 extras | fc_l2 extras | fc_l3 extras (F rows)
+ *   fc_global1 / fc_g1              [Hp][256 + 2 Hp]   cols: first 256 of P, then Q (the reference's (sum, mean) / (mean, sum) order is a column permutation)
+ *   fc_global2 / fc_g2              [128][256 + Hp]    cols: P; rows 0..L-1
+ */
+#ifndef PFM_EPICW_H
+#define PFM_EPICW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFM_EW_ABI_VERSION 1
+#define PFM_EW_MAX_LAYERS 24
+
+typedef struct { int64_t W, b, WT; } pfm_ew_lin; /* MFMA_AK weights, bias (-1: none), MFMA_AKT copy (-1: none) */
+
+typedef struct { pfm_ew_lin g1, g2, jb, l1, l2; } pfm_ew_layer;
+
+typedef struct {
+    int32_t abi_version;
+    int32_t n_points, features, hidden, hidden_pad, latent, layers, t_dim, cond_global, cond_local, flags, pad_;
+    float sum_scale, neg_slope;
+    int64_t blob_floats;
+    int64_t freqs;  /* [t_dim] */
+    int64_t l1x;    /* fc_l1 particle columns, KMAJOR [F][Hp] */
+    int64_t l3;     /* fc_l3 particle block, ROWMAJOR [F][Hp] */
+    pfm_ew_lin sjb, l2, sg1, sg2;
+    pfm_ew_layer layer[PFM_EW_MAX_LAYERS];
+} pfm_ew_desc;
+
+int64_t pfm_ew_workspace_floats(const pfm_ew_desc *desc, int32_t n_jets, int32_t train);
+
+/* v[n_jets][N][F] = f(t, x); t_stride 1: one time per jet, 0: one time for all.  mask [n_jets][N] fp32 or NULL. */
+int pfm_ew_forward(const pfm_ew_desc *desc, const float *blob, const float *t, int32_t t_stride, const float *x,
+                   const float *cond, const float *mask, float *v, int32_t n_jets, float *workspace, void *stream);
+
+/* see pfm_tf_sample_midpoint */
+int pfm_ew_sample_midpoint(const pfm_ew_desc *desc, const float *blob, const float *t_eval, const float *dt,
+                           int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
+                           int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFM_EPICW_H */

@@ -9,6 +9,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 from .layout import EpicDesc
 from .layout_tf import TfDesc
+from .layout_wide import EwDesc
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpfm_hip.so")
@@ -40,6 +41,11 @@ SYMBOLS = {
     "pfm_tf_forward": (c_int, [POINTER(TfDesc), _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_tf_sample_midpoint": (
         c_int, [POINTER(TfDesc), _fp, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),
+    # include/pfm_epicw.h
+    "pfm_ew_workspace_floats": (c_int64, [POINTER(EwDesc), c_int32, c_int32]),
+    "pfm_ew_forward": (c_int, [POINTER(EwDesc), _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_ew_sample_midpoint": (
+        c_int, [POINTER(EwDesc), _fp, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),
     "pfm_tf_fm_loss_forward": (
         c_int, [POINTER(TfDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_tf_backward_scratch_floats": (c_int64, [POINTER(TfDesc), c_int32]),

@@ -53,7 +53,7 @@ struct CtxtArgs {
     int64_t Wc[PFM_TF_MAX_LAYERS + 2], bb[PFM_TF_MAX_LAYERS + 2];
 };
 
-__global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
+static __global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
     __shared__ float cin[96];
     __shared__ float hb[512];
     __shared__ float cx[64];
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
 }
 
 // node_embd input block (droid_transformer.py:793-813 on cat(temb, x, ctxt)): the F particle columns
-__global__ __launch_bounds__(256) void tf_embed_kernel(const float* __restrict__ blob, int64_t Wx,
+static __global__ __launch_bounds__(256) void tf_embed_kernel(const float* __restrict__ blob, int64_t Wx,
                                                        const float* __restrict__ x, const float* __restrict__ jb,
                                                        int64_t jb_stride, float* __restrict__ h1, int M, int N, int F,
                                                        int Hd, float slope) {
@@ -154,13 +154,14 @@ __global__ __launch_bounds__(256) void tf_embed_kernel(const float* __restrict__
 // Linear
 // ------------------------------------------------------------------------------------------------
 struct LinArgs {
-    const float* A;     // [M][lda], first K columns
+    const float* A;     // [M][lda], first K columns (first K1 when a second segment A2 is given)
+    const float* A2;    // optional second input segment [M][lda2]: columns K1.. of the input come from A2[:, 0..K-K1)
     const float* blob;
     const float* jb;    // jet-bias rows (already contain the bias) or nullptr
     const float* R;     // residual [M][ldr] or nullptr
     float* out;         // [M][ldo]
     int64_t blob_floats, W, b, gamma, beta, jb_stride;
-    int lda, ldr, ldo, M, K, NO, N, act, row_tiles;
+    int lda, lda2, K1, ldr, ldo, M, K, NO, N, act, row_tiles;  // act: 0 none, 1 lrelu(acc) (+R after), 2 lrelu(acc + R)
     float slope, eps;
 };
 
@@ -258,10 +259,13 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         f32x4 st[8];
         {
             const int col = 128 * kc + 4 * sc4;
+            const bool seg2 = a.A2 != nullptr && 128 * kc >= a.K1;  // wave-uniform
+            const float* src = seg2 ? a.A2 + (col - a.K1) : a.A + col;
+            const int ld = seg2 ? a.lda2 : a.lda;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = min(row0 + sr + 8 * i, a.M - 1);
-                st[i] = *reinterpret_cast<const f32x4*>(a.A + (int64_t)row * a.lda + col);
+                st[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)row * ld);
             }
             if (LN) {
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + col);
@@ -310,8 +314,9 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
             const int row = row0 + 16 * t + pl;
             if (row < a.M) {
                 f32x4 v = acc[s][t];
+                if (a.act == 2) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
                 if (a.act) v = lrelu4(v, a.slope);
-                if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+                if (a.R && a.act != 2) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
                 *reinterpret_cast<f32x4*>(a.out + (int64_t)row * a.ldo + o) = v;
             }
         }
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(256) void tf_head_kernel(HeadArgs a) {
 }
 
 // x = z * mask (SetFlowMatchingLitModule.sample, flow_matching_module.py:668-671)
-__global__ void tf_premask_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
+static __global__ void tf_premask_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
                                   int64_t n, int F) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = mask ? z[i] * mask[i / F] : z[i];

@@ -92,7 +92,7 @@ def test_no_cpu_fallback():
 
 def test_c_abi_exports_every_declared_symbol():
     lib = _lib.load()
-    header = open(f"{ROOT}/include/pfm_hip.h").read() + open(f"{ROOT}/include/pfm_tf.h").read()
+    header = open(f"{ROOT}/include/pfm_hip.h").read() + open(f"{ROOT}/include/pfm_tf.h").read() + open(f"{ROOT}/include/pfm_epicw.h").read()
     declared = set(re.findall(r"^(?:int64_t|int|const char \*)\s*\*?(pfm_[a-z0-9_]+)\s*\(", header, flags=re.M))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
