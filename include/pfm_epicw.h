@@ -44,7 +44,7 @@ typedef struct {
     int64_t blob_floats;
     int64_t freqs;  /* [t_dim] */
     int64_t l1x;    /* fc_l1 particle columns, KMAJOR [F][Hp] */
-    int64_t l3;     /* fc_l3 particle block, ROWMAJOR [F][Hp] */
+    int64_t l3;     /* fc_l3 particle block, ROWMAJOR [16][Hp] (rows >= F zero) */
     pfm_ew_lin sjb, l2, sg1, sg2;
     pfm_ew_layer layer[PFM_EW_MAX_LAYERS];
 } pfm_ew_desc;
@@ -59,6 +59,18 @@ int pfm_ew_forward(const pfm_ew_desc *desc, const float *blob, const float *t, i
 int pfm_ew_sample_midpoint(const pfm_ew_desc *desc, const float *blob, const float *t_eval, const float *dt,
                            int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
                            int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);
+
+/* Loss forward / backward, as pfm_tf_fm_loss_forward / pfm_tf_fm_loss_backward (losses.py:38-77, 101-136): the forward
+ * keeps every stage's activations in `workspace` (train layout); the backward adds d loss / d(blob entry) * gscale
+ * into gblob (zeroed by the caller; MFMA_AK blocks in MFMA_AK order; padding slots receive values nobody reads). */
+int pfm_ew_fm_loss_forward(const pfm_ew_desc *desc, const float *blob, int32_t kind, float sigma, const float *t,
+                           const float *x, const float *a, const float *b, const float *cond, const float *mask,
+                           float *y_out, float *u_out, float *v_out, float *loss_sums, int32_t n_jets,
+                           float *workspace, void *stream);
+int64_t pfm_ew_backward_scratch_floats(const pfm_ew_desc *desc, int32_t n_jets);
+int pfm_ew_fm_loss_backward(const pfm_ew_desc *desc, const float *blob, const float *mask, const float *y,
+                            const float *u, const float *v, const float *gscale, float *gblob, int32_t n_jets,
+                            float *workspace, float *scratch, void *stream);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 
 #include "pfm_epicw.h"
 #include "tf_fwd.h"
+#include "tf_bwd.h"
 
 namespace pfm {
 int set_err(int code, const char* what);
@@ -18,9 +19,9 @@ using namespace pfm::tf;
 // P[jet][0 .. 256 + Hp) = [temb | cond | 0 ; 0 (g) ; 0 (g1)]
 __global__ __launch_bounds__(256) void ew_prep_kernel(const float* __restrict__ blob, int64_t freqs, const float* __restrict__ t,
                                                       int t_stride, const float* __restrict__ cond, float* __restrict__ P, int T,
-                                                      int C, int ldp) {
+                                                      int C, int ldp, int64_t pstride) {
     const int jet = blockIdx.x;
-    float* row = P + (int64_t)jet * ldp;
+    float* row = P + (int64_t)blockIdx.y * pstride + (int64_t)jet * ldp;  // blockIdx.y: stage copy (train layout)
     for (int c = threadIdx.x; c < ldp; c += 256) {
         float v = 0.f;
         if (c < T) {
@@ -101,24 +102,29 @@ __global__ __launch_bounds__(256) void ew_head_kernel(HeadArgs a) {
     }
 }
 
+// Workspace (floats).  Inference: one P row set, one Q, one X / L1.  Train: every stage keeps its own copies
+// (stage 0 = stem, stage l+1 = layer l): P_s, Q_s (pool of X_s), X_s, L1_l -- what the backward re-reads.
 struct Ws {
-    int64_t P, Q, SJB, JB, X1, X, L1, lstride, total;  // lstride: per-layer stride of (X, L1) in the train layout
+    int64_t P, pstride, Q, qstride, SJB, JB, X1, X, xstride, L1, lstride, total;
 };
 
 __host__ inline Ws make_ws(const pfm_ew_desc& d, int n_jets, bool train) {
     Ws w;
     const int64_t M = (int64_t)n_jets * d.n_points, Hp = d.hidden_pad;
+    const int stages = train ? d.layers + 1 : 1;
     int64_t o = 0;
     auto take = [&](int64_t n) { const int64_t at = o; o += round64(n); return at; };
-    w.P = take((int64_t)n_jets * (256 + Hp));
-    w.Q = take((int64_t)n_jets * 2 * Hp);
+    w.pstride = train ? round64((int64_t)n_jets * (256 + Hp)) : 0;
+    w.P = take((int64_t)n_jets * (256 + Hp)); o += w.pstride * (stages - 1);
+    w.qstride = train ? round64((int64_t)n_jets * 2 * Hp) : 0;
+    w.Q = take((int64_t)n_jets * 2 * Hp); o += w.qstride * (stages - 1);
     w.SJB = take((int64_t)n_jets * (2 * Hp + 128));
     w.JB = take((int64_t)n_jets * 2 * Hp);
     w.X1 = take(M * Hp);
-    w.X = take(M * Hp);
-    w.L1 = take(M * Hp);
-    w.lstride = 0;
-    (void)train;
+    w.xstride = train ? round64(M * Hp) : 0;
+    w.X = take(M * Hp); o += w.xstride * (stages - 1);
+    w.lstride = train ? round64(M * Hp) : 0;
+    w.L1 = take(M * Hp); o += w.lstride * (stages > 2 ? stages - 2 : 0);
     w.total = o;
     return w;
 }
@@ -149,9 +155,10 @@ struct Plan {
 
 // out[Mrows][ldo] = epi(A (+A2) W^T + b / jb)
 int linear(const Plan& p, int Mrows, const float* A, int lda, int K1, const float* A2, int lda2, int K, const pfm_ew_lin& lin,
-           int NO, const float* jb, int64_t jb_stride, int jbN, const float* R, int ldr, float* out, int ldo, int act) {
+           int NO, const float* jb, int64_t jb_stride, int jbN, const float* R, int ldr, float* out, int ldo, int act,
+           const float* Y = nullptr, int ldy = 0) {
     LinArgs a;
-    a.A = A; a.A2 = A2; a.lda = lda; a.lda2 = lda2; a.K1 = K1; a.blob = p.blob; a.jb = jb; a.R = R; a.out = out;
+    a.A = A; a.A2 = A2; a.lda = lda; a.lda2 = lda2; a.K1 = K1; a.blob = p.blob; a.jb = jb; a.R = R; a.Y = Y; a.ldy = ldy; a.out = out;
     a.blob_floats = p.d->blob_floats; a.W = lin.W; a.b = lin.b; a.gamma = -1; a.beta = -1; a.jb_stride = jb_stride;
     a.ldr = ldr; a.ldo = ldo; a.M = Mrows; a.K = K; a.NO = NO; a.N = jbN; a.act = act;
     a.row_tiles = (Mrows + BM - 1) / BM;
@@ -169,34 +176,41 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
     float* ws = p.ws;
     const int Hp = d.hidden_pad, ldp = 256 + Hp, B = p.n_jets, N = d.n_points;
     const int64_t sjbs = 2 * Hp + 128;
-    float *P = ws + w.P, *Q = ws + w.Q, *SJB = ws + w.SJB, *JB = ws + w.JB, *X1 = ws + w.X1, *X = ws + w.X, *L1 = ws + w.L1;
+    float *SJB = ws + w.SJB, *JB = ws + w.JB, *X1 = ws + w.X1;
+    auto Pst = [&](int s) { return ws + w.P + w.pstride * s; };
+    auto Qst = [&](int s) { return ws + w.Q + w.qstride * s; };
+    auto Xst = [&](int s) { return ws + w.X + w.xstride * s; };
     int rc;
-    hipLaunchKernelGGL(ew_prep_kernel, dim3(B), dim3(256), 0, p.s, p.blob, d.freqs, t, t_stride, cond, P, d.t_dim, d.cond_global, ldp);
+    const int stages = w.pstride ? d.layers + 1 : 1;
+    hipLaunchKernelGGL(ew_prep_kernel, dim3(B, stages), dim3(256), 0, p.s, p.blob, d.freqs, t, t_stride, cond, Pst(0), d.t_dim,
+                       d.cond_global, ldp, w.pstride);
     PFM_TRY(check_hip(hipGetLastError(), "ew_prep_kernel launch"));
-    PFM_TRY(linear(p, B, P, ldp, 256, nullptr, 0, 256, d.sjb, 2 * Hp + 128, nullptr, 0, 1, nullptr, 0, SJB, (int)sjbs, 0));
+    PFM_TRY(linear(p, B, Pst(0), ldp, 256, nullptr, 0, 256, d.sjb, 2 * Hp + 128, nullptr, 0, 1, nullptr, 0, SJB, (int)sjbs, 0));
     // stem: fc_l1 (F columns on the VALU), fc_l2 (residual inside the activation, epic.py:327-328)
     hipLaunchKernelGGL(tf_embed_kernel, dim3((p.M + 31) / 32), dim3(256), 0, p.s, p.blob, d.l1x, x, (const float*)SJB, sjbs, X1, p.M, N,
                        d.features, Hp, d.neg_slope);
     PFM_TRY(check_hip(hipGetLastError(), "tf_embed_kernel launch (epicw)"));
-    PFM_TRY(linear(p, p.M, X1, Hp, Hp, nullptr, 0, Hp, d.l2, Hp, SJB + Hp, sjbs, N, X1, Hp, X, Hp, 2));
-    auto pool = [&]() {
-        hipLaunchKernelGGL(ew_pool_kernel, dim3(B), dim3(256), 0, p.s, (const float*)X, mask, Q, N, Hp, d.sum_scale);
+    PFM_TRY(linear(p, p.M, X1, Hp, Hp, nullptr, 0, Hp, d.l2, Hp, SJB + Hp, sjbs, N, X1, Hp, Xst(0), Hp, 2));
+    auto pool = [&](int s) {
+        hipLaunchKernelGGL(ew_pool_kernel, dim3(B), dim3(256), 0, p.s, (const float*)Xst(s), mask, Qst(s), N, Hp, d.sum_scale);
         return check_hip(hipGetLastError(), "ew_pool_kernel launch");
     };
-    PFM_TRY(pool());
-    PFM_TRY(linear(p, B, P, ldp, 256, Q, 2 * Hp, 256 + 2 * Hp, d.sg1, Hp, nullptr, 0, 1, nullptr, 0, P + 256, ldp, 1));
-    PFM_TRY(linear(p, B, P, ldp, ldp, nullptr, 0, ldp, d.sg2, 128, nullptr, 0, 1, nullptr, 0, P + 128, ldp, 1));
+    PFM_TRY(pool(0));
+    PFM_TRY(linear(p, B, Pst(0), ldp, 256, Qst(0), 2 * Hp, 256 + 2 * Hp, d.sg1, Hp, nullptr, 0, 1, nullptr, 0, Pst(0) + 256, ldp, 1));
+    PFM_TRY(linear(p, B, Pst(0), ldp, ldp, nullptr, 0, ldp, d.sg2, 128, nullptr, 0, 1, nullptr, 0, Pst(0) + 128, ldp, 1));
     for (int l = 0; l < d.layers; ++l) {
         const pfm_ew_layer& L = d.layer[l];
-        if (l) PFM_TRY(pool());
-        PFM_TRY(linear(p, B, P, ldp, 256, Q, 2 * Hp, 256 + 2 * Hp, L.g1, Hp, nullptr, 0, 1, nullptr, 0, P + 256, ldp, 1));
-        PFM_TRY(linear(p, B, P, ldp, ldp, nullptr, 0, ldp, L.g2, 128, nullptr, 0, 1, P + 128, ldp, P + 128, ldp, 2));
-        PFM_TRY(linear(p, B, P, ldp, 256, nullptr, 0, 256, L.jb, 2 * Hp, nullptr, 0, 1, nullptr, 0, JB, 2 * Hp, 0));
-        PFM_TRY(linear(p, p.M, X, Hp, Hp, nullptr, 0, Hp, L.l1, Hp, JB, 2 * Hp, N, nullptr, 0, L1, Hp, 1));
-        PFM_TRY(linear(p, p.M, L1, Hp, Hp, nullptr, 0, Hp, L.l2, Hp, JB + Hp, 2 * Hp, N, X, Hp, X, Hp, 2));
+        float *Pin = Pst(l), *Pout = Pst(l + 1);  // the same row set at inference
+        if (l) PFM_TRY(pool(l));
+        PFM_TRY(linear(p, B, Pin, ldp, 256, Qst(l), 2 * Hp, 256 + 2 * Hp, L.g1, Hp, nullptr, 0, 1, nullptr, 0, Pout + 256, ldp, 1));
+        PFM_TRY(linear(p, B, Pout, ldp, ldp, nullptr, 0, ldp, L.g2, 128, nullptr, 0, 1, Pin + 128, ldp, Pout + 128, ldp, 2));
+        PFM_TRY(linear(p, B, Pout, ldp, 256, nullptr, 0, 256, L.jb, 2 * Hp, nullptr, 0, 1, nullptr, 0, JB, 2 * Hp, 0));
+        float* L1 = ws + w.L1 + w.lstride * l;
+        PFM_TRY(linear(p, p.M, Xst(l), Hp, Hp, nullptr, 0, Hp, L.l1, Hp, JB, 2 * Hp, N, nullptr, 0, L1, Hp, 1));
+        PFM_TRY(linear(p, p.M, L1, Hp, Hp, nullptr, 0, Hp, L.l2, Hp, JB + Hp, 2 * Hp, N, Xst(l), Hp, Xst(l + 1), Hp, 2));
     }
     HeadArgs h = head_tpl;
-    h.X = X; h.blob = p.blob; h.jb = SJB + 2 * Hp; h.jb_stride = sjbs; h.mask = mask; h.W3 = d.l3;
+    h.X = Xst(w.xstride ? d.layers : 0); h.blob = p.blob; h.jb = SJB + 2 * Hp; h.jb_stride = sjbs; h.mask = mask; h.W3 = d.l3;
     h.M = p.M; h.N = N; h.F = d.features; h.slope = d.neg_slope;
     const dim3 g((p.M + 15) / 16), bl(256);
     switch (Hp / 64) {
@@ -206,6 +220,221 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         default: hipLaunchKernelGGL(ew_head_kernel<8>, g, bl, 0, p.s, h); break;
     }
     return check_hip(hipGetLastError(), "ew_head_kernel launch");
+}
+
+
+// ---- backward pieces -------------------------------------------------------------------------------
+// out[r][c] = (a[r][c] + b[r][c]) * lrelu'(y[r][c])   (b, y optional; row strides given)
+__global__ __launch_bounds__(256) void ew_actbwd_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                        const float* __restrict__ y, int ldy, float* __restrict__ out, int ldo,
+                                                        int64_t rows, int cols, float slope) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    float v = a[r * lda + c];
+    if (b) v += b[r * ldb + c];
+    if (y) v *= y[r * ldy + c] > 0.f ? 1.f : slope;
+    out[r * ldo + c] = v;
+}
+
+// dpre[row][0..16) = 2 (v - u) gscale * mask * lrelu'(v)   (v = lrelu(pre) * mask: same sign as pre on valid rows)
+__global__ __launch_bounds__(256) void ew_head_bwd_kernel(const float* __restrict__ v, const float* __restrict__ u,
+                                                          const float* __restrict__ mask, const float* __restrict__ gscale,
+                                                          float* __restrict__ dpre, int64_t M, int F, float slope) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * 16) return;
+    const int64_t row = i >> 4;
+    const int f = (int)(i & 15);
+    float d = 0.f;
+    if (f < F) {
+        const float vv = v[row * F + f];
+        d = 2.0f * (vv - u[row * F + f]) * gscale[0] * (mask ? mask[row] : 1.0f) * (vv > 0.f ? 1.f : slope);
+    }
+    dpre[i] = d;
+}
+
+// dX[row][c] += mask[row] * ( dmean[jet][c] / n_jet + dsum[jet][c] * scale )
+__global__ __launch_bounds__(256) void ew_pool_bwd_kernel(const float* __restrict__ dQ, int ldq, const float* __restrict__ mask,
+                                                          float* __restrict__ dX, int N, int Hp, float scale) {
+    __shared__ float cnt[4];
+    const int tid = threadIdx.x, jet = blockIdx.x;
+    float n = 0.f;
+    for (int r = tid; r < N; r += 256) n += mask ? mask[(int64_t)jet * N + r] : 1.0f;
+    n = wave_sum(n);
+    if ((tid & 63) == 0) cnt[tid >> 6] = n;
+    __syncthreads();
+    const float inv = 1.0f / ((cnt[0] + cnt[1]) + (cnt[2] + cnt[3]));
+    const int nc4 = Hp >> 2;
+    const float* dq = dQ + (int64_t)jet * ldq;
+    for (int idx = tid; idx < N * nc4; idx += 256) {
+        const int r = idx / nc4, c4 = idx - r * nc4;
+        const int64_t row = (int64_t)jet * N + r;
+        const float m = mask ? mask[row] : 1.0f;
+        if (m != 0.f) {
+            const f32x4 g = (*reinterpret_cast<const f32x4*>(dq + 4 * c4) * inv + *reinterpret_cast<const f32x4*>(dq + Hp + 4 * c4) * scale) * m;
+            *reinterpret_cast<f32x4*>(dX + row * Hp + 4 * c4) += g;
+        }
+    }
+}
+
+struct Bs {
+    int64_t dX, dZ, dT, dpre, DJB, DSJB, dPj, dP2, dP1, dG, dZg2, dZg1, zeros, dwpart, total;
+};
+constexpr int DW_MAX_PARTS = 1024;
+
+Bs make_bs(const pfm_ew_desc& d, int n_jets) {
+    Bs b;
+    const int64_t M = (int64_t)n_jets * d.n_points, Hp = d.hidden_pad, B = n_jets;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { const int64_t at = o; o += round64(n); return at; };
+    b.dX = take(M * Hp); b.dZ = take(M * Hp); b.dT = take(M * Hp); b.dpre = take(M * 16);
+    b.DJB = take(B * 2 * Hp); b.DSJB = take(B * (2 * Hp + 128)); b.dPj = take(B * 256);
+    b.dP2 = take(B * (256 + Hp)); b.dP1 = take(B * (256 + 2 * Hp)); b.dG = take(B * 128);
+    b.dZg2 = take(B * 128); b.dZg1 = take(B * Hp); b.zeros = take(B * Hp);
+    b.dwpart = take((int64_t)DW_MAX_PARTS * 16384);
+    b.total = o;
+    return b;
+}
+
+struct Bwd {
+    Plan p;
+    float *gblob, *sc;
+    Bs b;
+
+    // column sums of Z[rows][NO]: per group of `group` rows into jet_out (stride), and/or over everything into gblob[gb]
+    int colsum(const float* Z, int ldz, int NO, int64_t rows, int group, const float* X, int F, float* jet_out, int64_t jet_stride,
+               int64_t gb) const {
+        ColsumArgs a;
+        a.Z = Z; a.X = X; a.jet_out = jet_out; a.gblob = gblob; a.gb = gb; a.jet_stride = jet_stride;
+        a.ldz = ldz; a.NO = NO; a.N = group; a.F = X ? 16 : 1;
+        hipLaunchKernelGGL(tf_colsum_kernel, dim3((unsigned)(rows / group), X ? F : 1, (NO + 767) / 768), dim3(256), 0, p.s, a);
+        return check_hip(hipGetLastError(), "tf_colsum_kernel launch (epicw)");
+    }
+    // gblob[W] += Z^T [A | A2]
+    int dw(int Mrows, const float* Z, int ldz, int NO, const float* A, int lda, int K1, const float* A2, int lda2, int K, int64_t gW) const {
+        DwArgs a;
+        a.Z = Z; a.A = A; a.A2 = A2; a.stats = nullptr; a.blob = p.blob; a.part = sc + b.dwpart; a.gamma = -1; a.beta = -1;
+        a.ldz = ldz; a.lda = lda; a.lda2 = lda2; a.K1 = K1; a.M = Mrows; a.NO = NO; a.K = K;
+        a.row_tiles = (Mrows + BM - 1) / BM;
+        const int tiles = (NO / 128) * (K / 128);
+        int ns = DW_MAX_PARTS / tiles;
+        if (ns < 1) ns = 1;
+        if (ns > a.row_tiles) ns = a.row_tiles;
+        a.nsplit = ns;
+        int rc;
+        hipLaunchKernelGGL(tf_dw_kernel, dim3(tiles * ns), dim3(LT), 2 * 64 * DWS * sizeof(float), p.s, a);
+        if ((rc = check_hip(hipGetLastError(), "tf_dw_kernel launch (epicw)"))) return rc;
+        hipLaunchKernelGGL(tf_dw_reduce_kernel, dim3(64, tiles), dim3(256), 0, p.s, (const float*)a.part, gblob, gW, K / 128, ns);
+        return check_hip(hipGetLastError(), "tf_dw_reduce_kernel launch (epicw)");
+    }
+    // out[Mrows][K] = (Z W (+R)) (* lrelu'(Y))
+    int dx(int Mrows, const float* Z, int ldz, int NO, const pfm_ew_lin& lin, int K, const float* R, int ldr, const float* Y, int ldy,
+           float* out, int ldo) const {
+        pfm_ew_lin t = lin;
+        t.W = lin.WT;
+        t.b = -1;
+        return linear(p, Mrows, Z, ldz, NO, nullptr, 0, NO, t, K, nullptr, 0, 1, R, ldr, out, ldo, Y ? 3 : 0, Y, ldy);
+    }
+    int actbwd(const float* a, int lda, const float* bb, int ldb, const float* y, int ldy, float* out, int ldo, int64_t rows, int cols) const {
+        const int64_t n = rows * cols;
+        hipLaunchKernelGGL(ew_actbwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, a, lda, bb, ldb, y, ldy, out, ldo, rows,
+                           cols, p.d->neg_slope);
+        return check_hip(hipGetLastError(), "ew_actbwd_kernel launch");
+    }
+};
+
+int run_backward(const Bwd& W, const float* mask, const float* y, const float* u, const float* v, const float* gscale) {
+    const Plan& p = W.p;
+    const pfm_ew_desc& d = *p.d;
+    const Ws& w = p.w;
+    float* ws = p.ws;
+    float* sc = W.sc;
+    const Bs& b = W.b;
+    const int Hp = d.hidden_pad, ldp = 256 + Hp, B = p.n_jets, N = d.n_points, F = d.features, M = p.M;
+    const int64_t sjbs = 2 * Hp + 128;
+    float *dX = sc + b.dX, *dZ = sc + b.dZ, *dT = sc + b.dT, *dpre = sc + b.dpre, *DJB = sc + b.DJB, *DSJB = sc + b.DSJB;
+    float *dPj = sc + b.dPj, *dP2 = sc + b.dP2, *dP1 = sc + b.dP1, *dG = sc + b.dG, *dZg2 = sc + b.dZg2, *dZg1 = sc + b.dZg1;
+    float* zeros = sc + b.zeros;
+    auto Pst = [&](int s) { return ws + w.P + w.pstride * s; };
+    auto Qst = [&](int s) { return ws + w.Q + w.qstride * s; };
+    auto Xst = [&](int s) { return ws + w.X + w.xstride * s; };
+    float* X1 = ws + w.X1;
+    int rc;
+    PFM_TRY(check_hip(hipMemsetAsync(zeros, 0, (size_t)B * Hp * sizeof(float), p.s), "memset zeros"));
+    PFM_TRY(check_hip(hipMemsetAsync(dG, 0, (size_t)B * 128 * sizeof(float), p.s), "memset dG"));
+    // ---- head: v = lrelu(W3 X_L + jb3) mask ----
+    hipLaunchKernelGGL(ew_head_bwd_kernel, dim3((unsigned)(((int64_t)M * 16 + 255) / 256)), dim3(256), 0, p.s, v, u, mask, gscale, dpre,
+                       (int64_t)M, F, d.neg_slope);
+    PFM_TRY(check_hip(hipGetLastError(), "ew_head_bwd_kernel launch"));
+    const float* XL = Xst(d.layers);
+    PFM_TRY(W.colsum(XL, Hp, Hp, M, N, dpre, F, nullptr, 0, d.l3));                       // d W3[f][k]
+    PFM_TRY(W.colsum(dpre, 16, 16, M, N, nullptr, 0, DSJB + 2 * Hp, sjbs, -1));            // d jb3 per jet (16 of its 128 columns)
+    hipLaunchKernelGGL(tf_embed_kernel, dim3((M + 31) / 32), dim3(256), 0, p.s, p.blob, d.l3, (const float*)dpre, (const float*)zeros,
+                       (int64_t)Hp, dX, M, N, 16, Hp, 1.0f);                                // dX_L = dpre W3
+    PFM_TRY(check_hip(hipGetLastError(), "tf_embed_kernel launch (head backward)"));
+    // ---- layers, last to first ----
+    for (int l = d.layers - 1; l >= 0; --l) {
+        const pfm_ew_layer& L = d.layer[l];
+        const float *Xin = Xst(l), *Xout = Xst(l + 1), *L1 = ws + w.L1 + w.lstride * l;
+        const float *Pin = Pst(l), *Pout = Pst(l + 1);
+        PFM_TRY(W.actbwd(dX, Hp, nullptr, 0, Xout, Hp, dZ, Hp, M, Hp));                                      // dZ2
+        PFM_TRY(W.colsum(dZ, Hp, Hp, M, N, nullptr, 0, DJB + Hp, 2 * Hp, -1));
+        PFM_TRY(W.dw(M, dZ, Hp, Hp, L1, Hp, Hp, nullptr, 0, Hp, L.l2.W));
+        PFM_TRY(W.dx(M, dZ, Hp, Hp, L.l2, Hp, nullptr, 0, L1, Hp, dT, Hp));                                   // dZ1
+        PFM_TRY(W.colsum(dT, Hp, Hp, M, N, nullptr, 0, DJB, 2 * Hp, -1));
+        PFM_TRY(W.dw(M, dT, Hp, Hp, Xin, Hp, Hp, nullptr, 0, Hp, L.l1.W));
+        PFM_TRY(W.dx(M, dT, Hp, Hp, L.l1, Hp, dZ, Hp, nullptr, 0, dX, Hp));                                   // dX_l = dZ2 + dZ1 W1
+        // jet-bias GEMM
+        PFM_TRY(W.dw(B, DJB, 2 * Hp, 2 * Hp, Pout, ldp, 256, nullptr, 0, 256, L.jb.W));
+        PFM_TRY(W.colsum(DJB, 2 * Hp, 2 * Hp, B, B, nullptr, 0, nullptr, 0, L.jb.b));
+        PFM_TRY(W.dx(B, DJB, 2 * Hp, 2 * Hp, L.jb, 256, nullptr, 0, nullptr, 0, dPj, 256));
+        // fc_global2: g_new = lrelu(W [P | g1] + b + g_old)
+        PFM_TRY(W.actbwd(dG, 128, dPj + 128, 256, Pout + 128, ldp, dZg2, 128, B, 128));
+        PFM_TRY(W.dw(B, dZg2, 128, 128, Pout, ldp, ldp, nullptr, 0, ldp, L.g2.W));
+        PFM_TRY(W.colsum(dZg2, 128, 128, B, B, nullptr, 0, nullptr, 0, L.g2.b));
+        PFM_TRY(W.dx(B, dZg2, 128, 128, L.g2, ldp, nullptr, 0, nullptr, 0, dP2, ldp));
+        // fc_global1: g1 = lrelu(W [P256 | Q] + b)
+        PFM_TRY(W.actbwd(dP2 + 256, ldp, nullptr, 0, Pout + 256, ldp, dZg1, Hp, B, Hp));
+        PFM_TRY(W.dw(B, dZg1, Hp, Hp, Pin, ldp, 256, Qst(l), 2 * Hp, 256 + 2 * Hp, L.g1.W));
+        PFM_TRY(W.colsum(dZg1, Hp, Hp, B, B, nullptr, 0, nullptr, 0, L.g1.b));
+        PFM_TRY(W.dx(B, dZg1, Hp, Hp, L.g1, 256 + 2 * Hp, nullptr, 0, nullptr, 0, dP1, 256 + 2 * Hp));
+        PFM_TRY(W.actbwd(dZg2, 128, dP1 + 128, 256 + 2 * Hp, nullptr, 0, dG, 128, B, 128));                   // d g_old
+        hipLaunchKernelGGL(ew_pool_bwd_kernel, dim3(B), dim3(256), 0, p.s, (const float*)(dP1 + 256), 256 + 2 * Hp, mask, dX, N, Hp,
+                           d.sum_scale);
+        PFM_TRY(check_hip(hipGetLastError(), "ew_pool_bwd_kernel launch"));
+    }
+    // ---- stem globals: g_0 = lrelu(fc_g2 [P | g1]), g1 = lrelu(fc_g1 [P256 | Q_0]) ----
+    {
+        const float* P0 = Pst(0);
+        PFM_TRY(W.actbwd(dG, 128, nullptr, 0, P0 + 128, ldp, dZg2, 128, B, 128));
+        PFM_TRY(W.dw(B, dZg2, 128, 128, P0, ldp, ldp, nullptr, 0, ldp, d.sg2.W));
+        PFM_TRY(W.colsum(dZg2, 128, 128, B, B, nullptr, 0, nullptr, 0, d.sg2.b));
+        PFM_TRY(W.dx(B, dZg2, 128, 128, d.sg2, ldp, nullptr, 0, nullptr, 0, dP2, ldp));
+        PFM_TRY(W.actbwd(dP2 + 256, ldp, nullptr, 0, P0 + 256, ldp, dZg1, Hp, B, Hp));
+        PFM_TRY(W.dw(B, dZg1, Hp, Hp, P0, ldp, 256, Qst(0), 2 * Hp, 256 + 2 * Hp, d.sg1.W));
+        PFM_TRY(W.colsum(dZg1, Hp, Hp, B, B, nullptr, 0, nullptr, 0, d.sg1.b));
+        PFM_TRY(W.dx(B, dZg1, Hp, Hp, d.sg1, 256 + 2 * Hp, nullptr, 0, nullptr, 0, dP1, 256 + 2 * Hp));
+        hipLaunchKernelGGL(ew_pool_bwd_kernel, dim3(B), dim3(256), 0, p.s, (const float*)(dP1 + 256), 256 + 2 * Hp, mask, dX, N, Hp,
+                           d.sum_scale);
+        PFM_TRY(check_hip(hipGetLastError(), "ew_pool_bwd_kernel launch"));
+    }
+    // ---- stem locals: X_0 = lrelu(fc_l2 X1 + jb + X1), X1 = lrelu(fc_l1 y + jb) ----
+    PFM_TRY(W.actbwd(dX, Hp, nullptr, 0, Xst(0), Hp, dZ, Hp, M, Hp));
+    PFM_TRY(W.colsum(dZ, Hp, Hp, M, N, nullptr, 0, DSJB + Hp, sjbs, -1));
+    PFM_TRY(W.dw(M, dZ, Hp, Hp, X1, Hp, Hp, nullptr, 0, Hp, d.l2.W));
+    PFM_TRY(W.dx(M, dZ, Hp, Hp, d.l2, Hp, dZ, Hp, X1, Hp, dT, Hp));                                           // (dZ W + dZ) lrelu'(X1)
+    PFM_TRY(W.colsum(dT, Hp, Hp, M, N, nullptr, 0, DSJB, sjbs, -1));
+    {
+        ColsumArgs a;  // d fc_l1 particle columns [F][Hp] = sum_rows y[row][f] dZ1[row][:]
+        a.Z = dT; a.X = y; a.jet_out = nullptr; a.gblob = W.gblob; a.gb = d.l1x; a.jet_stride = 0; a.ldz = Hp; a.NO = Hp; a.N = N; a.F = F;
+        hipLaunchKernelGGL(tf_colsum_kernel, dim3(B, F, 1), dim3(256), 0, p.s, a);
+        PFM_TRY(check_hip(hipGetLastError(), "tf_colsum_kernel launch (fc_l1)"));
+    }
+    // static jet-bias GEMM (the 112 padding columns of the fc_l3 block of DSJB were never written: clear them first)
+    PFM_TRY(W.dw(B, DSJB, (int)sjbs, 2 * Hp + 128, Pst(0), ldp, 256, nullptr, 0, 256, d.sjb.W));
+    PFM_TRY(W.colsum(DSJB, (int)sjbs, 2 * Hp + 128, B, B, nullptr, 0, nullptr, 0, d.sjb.b));
+    return 0;
 }
 
 int make_plan(Plan& p, const pfm_ew_desc* d, const float* blob, float* ws, int n_jets, bool train, void* stream) {
@@ -266,6 +495,54 @@ int pfm_ew_sample_midpoint(const pfm_ew_desc* d, const float* blob, const float*
         if ((rc = ew::run_nfe(p, t_eval + 2 * k + 1, 0, xm, cond, mask, h))) return rc;
     }
     return check_hip(hipMemcpyAsync(x_out, xs, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_out");
+}
+
+int pfm_ew_fm_loss_forward(const pfm_ew_desc* d, const float* blob, int32_t kind, float sigma, const float* t,
+                           const float* x, const float* a, const float* b, const float* cond, const float* mask,
+                           float* y_out, float* u_out, float* v_out, float* loss_sums, int32_t n_jets,
+                           float* workspace, void* stream) {
+    ew::Plan p;
+    int rc = ew::make_plan(p, d, blob, workspace, n_jets, true, stream);
+    if (rc) return rc;
+    if (n_jets <= 0) return 0;
+    if (kind != 0 && kind != 1) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT) or 1 (CFM)");
+    if (!blob || !t || !x || !a || !y_out || !u_out || !v_out || !loss_sums || !workspace)
+        return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (kind == 1 && !b) return set_err(PFM_E_BADARG, "CFM needs eps");
+    if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
+    const int64_t n = (int64_t)p.M * d->features;
+    hipLaunchKernelGGL(tf_yu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, kind, sigma, t, x, a, b, mask, y_out,
+                       u_out, n, d->n_points * d->features, d->features);
+    if ((rc = check_hip(hipGetLastError(), "tf_yu_kernel launch"))) return rc;
+    ew::HeadArgs h{};
+    h.dst = v_out;
+    if ((rc = ew::run_nfe(p, t, 1, y_out, cond, mask, h))) return rc;
+    hipLaunchKernelGGL(tf_loss_kernel, dim3(256), dim3(256), 0, p.s, (const float*)v_out, (const float*)u_out, mask, loss_sums, n,
+                       (int64_t)p.M);
+    return check_hip(hipGetLastError(), "tf_loss_kernel launch");
+}
+
+int64_t pfm_ew_backward_scratch_floats(const pfm_ew_desc* d, int32_t n_jets) {
+    if (ew::validate(d)) return -1;
+    return ew::make_bs(*d, n_jets < 1 ? 1 : n_jets).total;
+}
+
+int pfm_ew_fm_loss_backward(const pfm_ew_desc* d, const float* blob, const float* mask, const float* y, const float* u,
+                            const float* v, const float* gscale, float* gblob, int32_t n_jets, float* workspace,
+                            float* scratch, void* stream) {
+    ew::Bwd W;
+    int rc = ew::make_plan(W.p, d, blob, workspace, n_jets, true, stream);
+    if (rc) return rc;
+    if (n_jets <= 0) return 0;
+    if (!blob || !y || !u || !v || !gscale || !gblob || !workspace || !scratch) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (d->l2.WT < 0) return set_err(PFM_E_BADARG, "blob was packed without the transposed (backward) weight copies");
+    W.gblob = gblob;
+    W.sc = scratch;
+    W.b = ew::make_bs(*d, n_jets);
+    if ((rc = check_hip(hipMemsetAsync(scratch + W.b.DSJB, 0, (size_t)n_jets * (2 * d->hidden_pad + 128) * sizeof(float),
+                                       (hipStream_t)stream), "memset DSJB")))
+        return rc;
+    return ew::run_backward(W, mask, y, u, v, gscale);
 }
 
 }  // extern "C"

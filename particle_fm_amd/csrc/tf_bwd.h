@@ -23,7 +23,7 @@ namespace tf {
 // ------------------------------------------------------------------------------------------------
 // loss pieces (losses.py:38-77, 101-136)
 // ------------------------------------------------------------------------------------------------
-__global__ void tf_yu_kernel(int kind, float sigma, const float* __restrict__ t, const float* __restrict__ x,
+static __global__ void tf_yu_kernel(int kind, float sigma, const float* __restrict__ t, const float* __restrict__ x,
                              const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mask,
                              float* __restrict__ y, float* __restrict__ u, int64_t n, int NF, int F) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,7 +45,7 @@ __global__ void tf_yu_kernel(int kind, float sigma, const float* __restrict__ t,
 }
 
 // sums[0] += sum (v-u)^2 ; sums[1] += sum mask
-__global__ __launch_bounds__(256) void tf_loss_kernel(const float* __restrict__ v, const float* __restrict__ u,
+static __global__ __launch_bounds__(256) void tf_loss_kernel(const float* __restrict__ v, const float* __restrict__ u,
                                                       const float* __restrict__ mask, float* __restrict__ sums,
                                                       int64_t n, int64_t rows) {
     __shared__ float red[8];
@@ -252,7 +252,7 @@ struct ColsumArgs {
     int ldz, NO, N, F;
 };
 
-__global__ __launch_bounds__(256) void tf_colsum_kernel(ColsumArgs a) {
+static __global__ __launch_bounds__(256) void tf_colsum_kernel(ColsumArgs a) {
     __shared__ float red[4 * 768];
     const int tid = threadIdx.x, cg = tid & 63, rg = tid >> 6;
     const int jet = blockIdx.x, f = blockIdx.y;
@@ -284,17 +284,18 @@ __global__ __launch_bounds__(256) void tf_colsum_kernel(ColsumArgs a) {
 // ------------------------------------------------------------------------------------------------
 struct DwArgs {
     const float* Z;      // [M][ldz] upstream gradient
-    const float* A;      // [M][lda] LayerNorm input
-    const float* stats;  // [M][2] mean, rstd of A's rows
+    const float* A;      // [M][lda] the Linear's input (before its LayerNorm prologue, if any)
+    const float* A2;     // optional second input segment [M][lda2]: input columns K1.. (see LinArgs)
+    const float* stats;  // [M][2] mean, rstd of A's rows; nullptr: the Linear has no LayerNorm prologue
     const float* blob;
     float* part;         // [tiles][nsplit][128*128] partial tiles
     int64_t gamma, beta;
-    int ldz, lda, M, NO, K, nsplit, row_tiles;
+    int ldz, lda, lda2, K1, M, NO, K, nsplit, row_tiles;
 };
 
 constexpr int DWS = 132;  // LDS row stride (floats)
 
-__global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
+static __global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const zt = lds;             // [64][DWS]
     float* const at = lds + 64 * DWS;  // [64][DWS]
@@ -309,8 +310,15 @@ __global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[c][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + 128 * tk + 4 * sc4);
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 128 * tk + 4 * sc4);
+    const bool ln = a.stats != nullptr;
+    f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+    if (ln) {
+        g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + 128 * tk + 4 * sc4);
+        b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 128 * tk + 4 * sc4);
+    }
+    const bool seg2 = a.A2 != nullptr && 128 * tk >= a.K1;
+    const float* asrc = seg2 ? a.A2 + (128 * tk - a.K1) + 4 * sc4 : a.A + 128 * tk + 4 * sc4;
+    const int ald = seg2 ? a.lda2 : a.lda;
 #pragma unroll 1
     for (int rt = split; rt < a.row_tiles; rt += a.nsplit) {
         f32x4 zs[8], as[8];
@@ -320,9 +328,13 @@ __global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
             const int rc = min(row, a.M - 1);
             zs[i] = *reinterpret_cast<const f32x4*>(a.Z + (int64_t)rc * a.ldz + 128 * to + 4 * sc4);
             if (row >= a.M) zs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 av = *reinterpret_cast<const f32x4*>(a.A + (int64_t)rc * a.lda + 128 * tk + 4 * sc4);
-            const float mean = a.stats[2 * (int64_t)rc], rstd = a.stats[2 * (int64_t)rc + 1];
-            as[i] = (av - mean) * rstd * g4 + b4;
+            const f32x4 av = *reinterpret_cast<const f32x4*>(asrc + (int64_t)rc * ald);
+            if (ln) {
+                const float mean = a.stats[2 * (int64_t)rc], rstd = a.stats[2 * (int64_t)rc + 1];
+                as[i] = (av - mean) * rstd * g4 + b4;
+            } else {
+                as[i] = av;
+            }
         }
         __syncthreads();  // the previous tile has been consumed
 #pragma unroll
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
 
 // gblob[W block] += sum over splits of the partial tiles.  Element p of a tile: w = p>>12, c = (p>>10)&3, r = (p>>8)&3,
 // lane = (p>>2)&63, e = p&3  ->  dW[o][k], o = 128 to + 64 (w>>1) + 4 (4 (lane>>4) + r) + c, k = 128 tk + 64 (w&1) + 4 (lane&15) + e
-__global__ __launch_bounds__(256) void tf_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ gblob,
+static __global__ __launch_bounds__(256) void tf_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ gblob,
                                                            int64_t gW, int nkc, int nsplit) {
     const int tile = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void tf_attn_bwd_q_kernel(const float* __re
 }
 
 // B: per key tile, dK and dV (reductions over the queries)
-__global__ __launch_bounds__(256, 2) void tf_attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
+static __global__ __launch_bounds__(256, 2) void tf_attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
                                                                 const float* __restrict__ dO, const float* __restrict__ stats,
                                                                 float* __restrict__ dqkv, int N, int D, int heads) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -586,7 +598,7 @@ struct CtxtBwdArgs {
     int64_t Wc[PFM_TF_MAX_LAYERS + 2];
 };
 
-__global__ __launch_bounds__(512) void tf_ctxt_bwd_kernel(CtxtBwdArgs a) {
+static __global__ __launch_bounds__(512) void tf_ctxt_bwd_kernel(CtxtBwdArgs a) {
     __shared__ float part[512];
     __shared__ float dcx[64];
     __shared__ float red[8];
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(512) void tf_ctxt_bwd_kernel(CtxtBwdArgs a) {
 }
 
 // G[k][o] += sum_jet U[jet][k] V[jet][o]   (U == nullptr: K = 1, weight 1).  Each element has one owner thread.
-__global__ __launch_bounds__(256) void tf_outer_sum_kernel(const float* __restrict__ U, int64_t ldu, int K,
+static __global__ __launch_bounds__(256) void tf_outer_sum_kernel(const float* __restrict__ U, int64_t ldu, int K,
                                                            const float* __restrict__ V, int64_t ldv, int NO, int n_jets,
                                                            float* __restrict__ G) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;

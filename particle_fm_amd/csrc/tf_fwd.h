@@ -159,9 +159,10 @@ struct LinArgs {
     const float* blob;
     const float* jb;    // jet-bias rows (already contain the bias) or nullptr
     const float* R;     // residual [M][ldr] or nullptr
+    const float* Y;     // act 3: activation output [M][ldy] whose LeakyReLU' scales the result
     float* out;         // [M][ldo]
     int64_t blob_floats, W, b, gamma, beta, jb_stride;
-    int lda, lda2, K1, ldr, ldo, M, K, NO, N, act, row_tiles;  // act: 0 none, 1 lrelu(acc) (+R after), 2 lrelu(acc + R)
+    int lda, lda2, K1, ldr, ldy, ldo, M, K, NO, N, act, row_tiles;  // act: 0 none (+R), 1 lrelu(acc) (+R after), 2 lrelu(acc + R), 3 (acc + R) * lrelu'(Y)
     float slope, eps;
 };
 
@@ -314,9 +315,16 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
             const int row = row0 + 16 * t + pl;
             if (row < a.M) {
                 f32x4 v = acc[s][t];
-                if (a.act == 2) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
-                if (a.act) v = lrelu4(v, a.slope);
-                if (a.R && a.act != 2) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+                if (a.act == 3) {
+                    if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(a.Y + (int64_t)row * a.ldy + o);
+                    v.x *= y.x > 0.f ? 1.f : a.slope; v.y *= y.y > 0.f ? 1.f : a.slope;
+                    v.z *= y.z > 0.f ? 1.f : a.slope; v.w *= y.w > 0.f ? 1.f : a.slope;
+                } else {
+                    if (a.act == 2) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+                    if (a.act) v = lrelu4(v, a.slope);
+                    if (a.R && a.act != 2) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+                }
                 *reinterpret_cast<f32x4*>(a.out + (int64_t)row * a.ldo + o) = v;
             }
         }

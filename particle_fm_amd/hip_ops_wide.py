@@ -10,15 +10,16 @@ from .hip_ops import _dev_f32, _prep_common, _ptr, _stream_ptr, midpoint_grid
 from .layout_wide import EpicWideLayout
 
 
-def workspace(layout: EpicWideLayout, n_jets: int, device) -> torch.Tensor:
+def workspace(layout: EpicWideLayout, n_jets: int, device, train: bool = False) -> torch.Tensor:
     lib = _lib.load()
     cache = layout.__dict__.setdefault("_ws", {})
-    key = (n_jets, str(device))
+    key = (n_jets, bool(train), str(device))
     if key not in cache:
-        n = lib.pfm_ew_workspace_floats(ctypes.byref(layout.desc), n_jets, 0)
+        n = lib.pfm_ew_workspace_floats(ctypes.byref(layout.desc), n_jets, int(train))
         if n < 0:
             _lib.check(1, "pfm_ew_workspace_floats")
-        cache.clear()
+        for k in [k for k in cache if k[1] == key[1]]:
+            del cache[k]
         cache[key] = torch.empty(n, device=device, dtype=torch.float32)
     return cache[key]
 
@@ -51,3 +52,50 @@ def ew_sample_midpoint(layout: EpicWideLayout, blob, z, cond=None, mask=None, od
                                     _ptr(state), _ptr(workspace(layout, B, dev)), _stream_ptr(dev))
     _lib.check(rc, "pfm_ew_sample_midpoint")
     return out
+
+
+_KINDS = {"FM-OT": 0, "CFM": 1}
+
+
+def ew_fm_loss_forward(layout: EpicWideLayout, blob, x, t, a, cond=None, mask=None, sigma: float = 1e-4, kind: str = "FM-OT",
+                       eps=None):
+    """Loss forward with the draws given.  Returns (sums (2,) = [sum (v-u)^2, sum mask], saved = (y, u, v, workspace, mask))."""
+    lib = _lib.load()
+    dev, B, blob, x, cond, mask = _prep_common(layout, blob, x, cond, mask)
+    if kind not in _KINDS:
+        raise NotImplementedError(f"loss kind {kind} has no HIP kernel")
+    t = _dev_f32("t", t, dev, (B,))
+    a = _dev_f32("a", a, dev, tuple(x.shape))
+    if kind == "CFM":
+        if eps is None:
+            raise ValueError("CFM needs the second noise draw eps")
+        if mask is None:
+            raise ValueError("CFM loss needs a mask (losses.py:119)")
+        eps = _dev_f32("eps", eps, dev, tuple(x.shape))
+    y, u, v = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    sums = torch.zeros(2, device=dev, dtype=torch.float32)
+    ws = workspace(layout, B, dev, train=True)
+    rc = lib.pfm_ew_fm_loss_forward(ctypes.byref(layout.desc), _ptr(blob), _KINDS[kind], float(sigma), _ptr(t), _ptr(x),
+                                    _ptr(a), _ptr(eps), _ptr(cond), _ptr(mask), _ptr(y), _ptr(u), _ptr(v), _ptr(sums), B,
+                                    _ptr(ws), _stream_ptr(dev))
+    _lib.check(rc, "pfm_ew_fm_loss_forward")
+    return sums, (y, u, v, ws, mask)
+
+
+def ew_fm_loss_backward(layout: EpicWideLayout, blob, saved, gscale: torch.Tensor) -> torch.Tensor:
+    """Gradient blob (layout.blob_total floats); gscale: 0-dim device tensor grad_output / sum(mask)."""
+    lib = _lib.load()
+    y, u, v, ws, mask = saved
+    dev, B = y.device, y.shape[0]
+    cache = layout.__dict__.setdefault("_bscratch", {})
+    key = (B, str(dev))
+    if key not in cache:
+        n = lib.pfm_ew_backward_scratch_floats(ctypes.byref(layout.desc), B)
+        cache.clear()
+        cache[key] = torch.empty(n, device=dev, dtype=torch.float32)
+    gblob = torch.zeros(layout.blob_total, device=dev, dtype=torch.float32)
+    gs = gscale.to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+    rc = lib.pfm_ew_fm_loss_backward(ctypes.byref(layout.desc), _ptr(blob), _ptr(mask), _ptr(y), _ptr(u), _ptr(v), _ptr(gs),
+                                     _ptr(gblob), B, _ptr(ws), _ptr(cache[key]), _stream_ptr(dev))
+    _lib.check(rc, "pfm_ew_fm_loss_backward")
+    return gblob

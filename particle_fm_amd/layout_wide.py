@@ -166,7 +166,7 @@ class EpicWideLayout(EpicLayout):
         d.l1x = self._put(self._src("fc_l1", ar(Hp)[None, :], (Tl + ar(F))[:, None]))
         # fc_l3 [t_l ; x(H) ; c_l]: particle block row-major [F][Hp]
         kk = ar(Hp)[None, :]
-        d.l3 = self._put(self._src("fc_l3", ar(F)[:, None], np.where(kk < H, Tl + kk, -1)))
+        d.l3 = self._put(self._src("fc_l3", ar(16)[:, None], np.where(kk < H, Tl + kk, -1)))  # [16][Hp], rows >= F zero
         ext_l1 = self._pcols(t(Tl), list(range(Tl + F, Tl + F + Cl)))
         ext_h = self._pcols(t(Tl), list(range(Tl + H, Tl + H + Cl)))  # fc_l2 / fc_local2 / fc_l3 share [t ; x(H) ; c]
         d.sjb = self._lin([("fc_l1", 0, Hp, ext_l1), ("fc_l2", Hp, Hp, ext_h), ("fc_l3", 2 * Hp, 128, ext_h)],
