@@ -146,7 +146,8 @@ class FusedFMTrainer:
         # plain (no weight norm): its autograd node already is two launches + two gathers, so it takes the generic path
         self._fused = None
         flows = getattr(module, "flows", None)
-        if flows is not None and len(flows) == 1 and hasattr(flows[0], "net") and hasattr(flows[0].net, "source_vector"):
+        if flows is not None and len(flows) == 1 and hasattr(flows[0], "net") and hasattr(flows[0].net, "source_vector") \
+                and not getattr(flows[0].net, "wide", False):
             self._fused = {}
             flows[0].net._fast_pack = self.packed_blob  # sampling re-packs with one HIP launch instead of ~100 torch ops
 

@@ -13,8 +13,9 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
-from ... import fm_loss, hip_ops
-from ...layout import EpicConfig, EpicLayout
+from ... import fm_loss, fm_loss_wide, hip_ops, hip_ops_wide
+from ...layout import PFM_HIDDEN, EpicConfig, EpicLayout
+from ...layout_wide import EpicWideLayout
 
 
 class WNLinear(nn.Module):
@@ -98,6 +99,9 @@ class EPiC_encoder(nn.Module):
                                            frequencies=frequencies, dropout=dropout, sum_scale=sum_scale))
         self.fc_l3 = WNLinear(hid_d + tl + local_cond_dim, feats)
         self._layouts: Dict[int, EpicLayout] = {}
+        # hidden 128: one workgroup per jet, activations resident in LDS (pfm_hip.h).  Any other width (JetClass: 300):
+        # the multi-kernel GEMM path over all particles (pfm_epicw.h).
+        self.wide = hid_d != PFM_HIDDEN
         self.skip_masked_tail = True
         self._fast_pack = None  # set by engine.FusedFMTrainer: one-launch weight-norm pack from the flat buffer
 
@@ -113,7 +117,7 @@ class EPiC_encoder(nn.Module):
         n = num_points or self.num_points
         lay = self._layouts.get(n)
         if lay is None:
-            lay = EpicLayout(self.config(n), flags=1 if self.skip_masked_tail else 0)
+            lay = EpicWideLayout(self.config(n)) if self.wide else EpicLayout(self.config(n), flags=1 if self.skip_masked_tail else 0)
             self._layouts[n] = lay
         return lay
 
@@ -132,7 +136,8 @@ class EPiC_encoder(nn.Module):
                 return blob
         lay = self.layout(num_points)
         with torch.no_grad():
-            return fm_loss.pack_blob_from_source(lay, self.source_vector(lay))
+            pack = fm_loss_wide.pack_blob_from_source if self.wide else fm_loss.pack_blob_from_source
+            return pack(lay, self.source_vector(lay))
 
     # -- evaluation --------------------------------------------------------------------------------
     def _check_inputs(self, t, x_local, global_cond_in):
@@ -148,6 +153,9 @@ class EPiC_encoder(nn.Module):
     def forward(self, t_in: torch.Tensor = None, x_local: torch.Tensor = None,
                 global_cond_in: torch.Tensor = None, mask: torch.Tensor = None) -> torch.Tensor:
         self._check_inputs(t_in, x_local, global_cond_in)
+        if self.wide:
+            raise NotImplementedError("EPiC_encoder.forward(t_emb, ...) with hid_d != 128: the wide HIP path embeds the time "
+                                      "in-kernel; call vector_field(t, x, cond, mask) (CNF.forward does)")
         lay = self.layout(x_local.shape[1])
         B = x_local.shape[0]
         if t_in is None:
@@ -163,4 +171,6 @@ class EPiC_encoder(nn.Module):
         lay = self.layout(x_local.shape[1])
         if blob is None:
             blob = self.packed_weights(x_local.shape[1])
+        if self.wide:
+            return hip_ops_wide.ew_forward(lay, blob, t, x_local, global_cond_in, mask)
         return hip_ops.epic_forward(lay, blob, t, x_local, global_cond_in, mask)

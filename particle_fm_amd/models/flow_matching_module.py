@@ -19,7 +19,8 @@ from torch import Tensor
 
 from .. import fm_loss as _fm_loss
 from .. import fm_loss_tf as _fm_loss_tf
-from .. import hip_ops, hip_ops_tf
+from .. import fm_loss_wide as _fm_loss_wide
+from .. import hip_ops, hip_ops_tf, hip_ops_wide
 from .components.droid_transformer import FullTransformerEncoder
 from .components.epic import EPiC_encoder
 from .components.losses import ConditionalFlowMatchingLoss, FlowMatchingLoss
@@ -168,6 +169,8 @@ class CNF(nn.Module):
             return _fm_loss_tf.tf_fm_loss(lay, self.net.flat_parameters(lay), x, t, z, cond=cond, mask=mask, sigma=sigma,
                                           kind=kind, eps=eps)
         src = self.net.source_vector(lay)
+        if self.net.wide:
+            return _fm_loss_wide.epic_wide_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps)
         return _fm_loss.epic_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps)
 
     def decode(self, z: Tensor, cond: Tensor, mask: Tensor = None, ode_solver: str = "dopri5_zuko",
@@ -181,6 +184,9 @@ class CNF(nn.Module):
             if self.is_transformer:
                 return hip_ops_tf.tf_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
                                                      ode_steps=ode_steps, premask=False)
+            if self.net.wide:
+                return hip_ops_wide.ew_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
+                                                       ode_steps=ode_steps, premask=False)
             return hip_ops.epic_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
                                                 ode_steps=ode_steps, premask=False)
         if ode_solver in ("em", "ddim"):
