@@ -65,9 +65,93 @@ __global__ __launch_bounds__(256) void ew_pool_kernel(const float* __restrict__ 
     }
 }
 
+// ---- row compaction (inference): rows = valid particles only, in (jet, particle) order -----------------------
+__global__ __launch_bounds__(256) void ew_count_kernel(const float* __restrict__ mask, int* __restrict__ cnt, int N) {
+    __shared__ int red[4];
+    const int jet = blockIdx.x;
+    int c = 0;
+    for (int r = threadIdx.x; r < N; r += 256) c += mask[(int64_t)jet * N + r] != 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[jet] = red[0] + red[1] + red[2] + red[3];
+}
+// off[0..B] = exclusive scan of cnt; m_valid = off[B]   (one workgroup; B is a batch size)
+__global__ __launch_bounds__(1024) void ew_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ m_valid, int B) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    int s = 0;
+    for (int i = 0; i < per; ++i) { const int j = tid * per + i; if (j < B) s += cnt[j]; }
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (int i = 0; i < per; ++i) { const int j = tid * per + i; if (j < B) { off[j] = run; run += cnt[j]; } }
+    if (tid == 1023) { off[B] = part[1023]; *m_valid = part[1023]; }
+}
+// rowsrc / rowjet of every valid particle (wave 0 of the jet's workgroup walks the mask in order)
+__global__ __launch_bounds__(64) void ew_rowmap_kernel(const float* __restrict__ mask, const int* __restrict__ off,
+                                                       int* __restrict__ rowsrc, int* __restrict__ rowjet, int N) {
+    const int jet = blockIdx.x, lane = threadIdx.x;
+    int base = off[jet];
+    for (int r0 = 0; r0 < N; r0 += 64) {
+        const int r = r0 + lane;
+        const bool ok = r < N && mask[(int64_t)jet * N + r] != 0.f;
+        const unsigned long long bal = __ballot(ok);
+        if (ok) {
+            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            rowsrc[pos] = jet * N + r;
+            rowjet[pos] = jet;
+        }
+        base += __popcll(bal);
+    }
+}
+// compact pooling: the jet's rows are [off[jet], off[jet+1]), all valid
+__global__ __launch_bounds__(256) void ew_pool_compact_kernel(const float* __restrict__ X, const int* __restrict__ off,
+                                                              float* __restrict__ Q, int Hp, float scale) {
+    __shared__ float red[4 * 512];
+    const int tid = threadIdx.x, cg = tid & 63, rg = tid >> 6, jet = blockIdx.x;
+    const int nc4 = Hp >> 2, r0 = off[jet], r1 = off[jet + 1];
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int r = r0 + rg; r < r1; r += 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (cg + 64 * i < nc4) acc[i] += *reinterpret_cast<const f32x4*>(X + (int64_t)r * Hp + 4 * (cg + 64 * i));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        if (cg + 64 * i < nc4) *reinterpret_cast<f32x4*>(red + rg * 512 + 4 * (cg + 64 * i)) = acc[i];
+    __syncthreads();
+    const float nv = (float)(r1 - r0);
+    for (int c = tid; c < Hp; c += 256) {
+        const float s = (red[c] + red[512 + c]) + (red[1024 + c] + red[1536 + c]);
+        Q[(int64_t)jet * 2 * Hp + c] = s / nv;
+        Q[(int64_t)jet * 2 * Hp + Hp + c] = s * scale;
+    }
+}
+// masked rows of the output: 0 (or the state they start from), NaN for a jet without any valid particle (the
+// reference's 0/0 mean poisons the whole jet, epic.py:331-339)
+__global__ __launch_bounds__(256) void ew_fill_masked_kernel(const float* __restrict__ mask, const int* __restrict__ cnt,
+                                                             const float* __restrict__ base, float* __restrict__ dst, int64_t M,
+                                                             int N, int F) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * F) return;
+    const int64_t row = i / F;
+    if (mask[row] != 0.f) return;
+    dst[i] = cnt[row / N] == 0 ? __builtin_nanf("") : (base ? base[i] : 0.f);
+}
+
 // v[row][f] = lrelu( W3[f] . X[row] + jb3[jet][f] ) * mask[row]   (epic.py:386-389); optional fused state update
 struct HeadArgs {
     const float *X, *blob, *jb, *mask, *base, *dt;
+    const int *rowsrc, *rowjet, *m_dev;  // compacted rows (then mask == nullptr) or nullptr
     float* dst;
     int64_t W3, jb_stride;
     int M, N, F;
@@ -79,13 +163,16 @@ __global__ __launch_bounds__(256) void ew_head_kernel(HeadArgs a) {
     constexpr int Hp = 64 * NI;
     const int tid = threadIdx.x, pl = tid & 15;
     const int row = blockIdx.x * 16 + (tid >> 4);
+    if (a.m_dev) a.M = *a.m_dev;
+    if (blockIdx.x * 16 >= a.M) return;
     const int rowc = min(row, a.M - 1);
     const float* xp = a.X + (int64_t)rowc * Hp + 4 * pl;
     f32x4 v[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) v[i] = *reinterpret_cast<const f32x4*>(xp + 64 * i);
     const float m = a.mask ? a.mask[rowc] : 1.0f;
-    const int jet = rowc / a.N;
+    const int jet = a.rowjet ? a.rowjet[rowc] : rowc / a.N;
+    const int64_t orow = a.rowsrc ? a.rowsrc[rowc] : row;
 #pragma unroll 1
     for (int f = 0; f < a.F; ++f) {
         float d = 0.f;
@@ -95,7 +182,7 @@ __global__ __launch_bounds__(256) void ew_head_kernel(HeadArgs a) {
         d = row_sum16(d) + a.jb[(int64_t)jet * a.jb_stride + f];
         d = lrelu(d, a.slope) * m;
         if (pl == (f & 15) && row < a.M) {
-            const int64_t e = (int64_t)row * a.F + f;
+            const int64_t e = orow * a.F + f;
             if (a.base) a.dst[e] = __fadd_rn(a.base[e], __fmul_rn(__fmul_rn(a.coef, a.dt[0]), d));
             else a.dst[e] = d;
         }
@@ -105,7 +192,7 @@ __global__ __launch_bounds__(256) void ew_head_kernel(HeadArgs a) {
 // Workspace (floats).  Inference: one P row set, one Q, one X / L1.  Train: every stage keeps its own copies
 // (stage 0 = stem, stage l+1 = layer l): P_s, Q_s (pool of X_s), X_s, L1_l -- what the backward re-reads.
 struct Ws {
-    int64_t P, pstride, Q, qstride, SJB, JB, X1, X, xstride, L1, lstride, total;
+    int64_t P, pstride, Q, qstride, SJB, JB, X1, X, xstride, L1, lstride, imaps, total;  // imaps: int32 cnt[B] off[B+1] m[1] rowsrc[M] rowjet[M]
 };
 
 __host__ inline Ws make_ws(const pfm_ew_desc& d, int n_jets, bool train) {
@@ -125,6 +212,7 @@ __host__ inline Ws make_ws(const pfm_ew_desc& d, int n_jets, bool train) {
     w.X = take(M * Hp); o += w.xstride * (stages - 1);
     w.lstride = train ? round64(M * Hp) : 0;
     w.L1 = take(M * Hp); o += w.lstride * (stages > 2 ? stages - 2 : 0);
+    w.imaps = take(2 * (int64_t)n_jets + 64 + 2 * M);
     w.total = o;
     return w;
 }
@@ -151,6 +239,8 @@ struct Plan {
     Ws w;
     int n_jets, M;
     hipStream_t s;
+    // compacted rows (inference with a mask): only valid particles are rows; nullptr = dense rows
+    const int *rowsrc = nullptr, *rowjet = nullptr, *off = nullptr, *m_dev = nullptr;
 };
 
 // out[Mrows][ldo] = epi(A (+A2) W^T + b / jb)
@@ -159,6 +249,7 @@ int linear(const Plan& p, int Mrows, const float* A, int lda, int K1, const floa
            const float* Y = nullptr, int ldy = 0) {
     LinArgs a;
     a.A = A; a.A2 = A2; a.lda = lda; a.lda2 = lda2; a.K1 = K1; a.blob = p.blob; a.jb = jb; a.R = R; a.Y = Y; a.ldy = ldy; a.out = out;
+    a.rowjet = (jb && p.rowjet) ? p.rowjet : nullptr; a.m_dev = (jb && p.m_dev) ? p.m_dev : nullptr;  // particle-row GEMMs are the ones with a jet bias
     a.blob_floats = p.d->blob_floats; a.W = lin.W; a.b = lin.b; a.gamma = -1; a.beta = -1; a.jb_stride = jb_stride;
     a.ldr = ldr; a.ldo = ldo; a.M = Mrows; a.K = K; a.NO = NO; a.N = jbN; a.act = act;
     a.row_tiles = (Mrows + BM - 1) / BM;
@@ -188,11 +279,14 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
     PFM_TRY(linear(p, B, Pst(0), ldp, 256, nullptr, 0, 256, d.sjb, 2 * Hp + 128, nullptr, 0, 1, nullptr, 0, SJB, (int)sjbs, 0));
     // stem: fc_l1 (F columns on the VALU), fc_l2 (residual inside the activation, epic.py:327-328)
     hipLaunchKernelGGL(tf_embed_kernel, dim3((p.M + 31) / 32), dim3(256), 0, p.s, p.blob, d.l1x, x, (const float*)SJB, sjbs, X1, p.M, N,
-                       d.features, Hp, d.neg_slope);
+                       d.features, Hp, d.neg_slope, p.rowsrc, p.rowjet, p.m_dev);
     PFM_TRY(check_hip(hipGetLastError(), "tf_embed_kernel launch (epicw)"));
     PFM_TRY(linear(p, p.M, X1, Hp, Hp, nullptr, 0, Hp, d.l2, Hp, SJB + Hp, sjbs, N, X1, Hp, Xst(0), Hp, 2));
     auto pool = [&](int s) {
-        hipLaunchKernelGGL(ew_pool_kernel, dim3(B), dim3(256), 0, p.s, (const float*)Xst(s), mask, Qst(s), N, Hp, d.sum_scale);
+        if (p.off)
+            hipLaunchKernelGGL(ew_pool_compact_kernel, dim3(B), dim3(256), 0, p.s, (const float*)Xst(s), p.off, Qst(s), Hp, d.sum_scale);
+        else
+            hipLaunchKernelGGL(ew_pool_kernel, dim3(B), dim3(256), 0, p.s, (const float*)Xst(s), mask, Qst(s), N, Hp, d.sum_scale);
         return check_hip(hipGetLastError(), "ew_pool_kernel launch");
     };
     PFM_TRY(pool(0));
@@ -210,9 +304,16 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         PFM_TRY(linear(p, p.M, L1, Hp, Hp, nullptr, 0, Hp, L.l2, Hp, JB + Hp, 2 * Hp, N, Xst(l), Hp, Xst(l + 1), Hp, 2));
     }
     HeadArgs h = head_tpl;
-    h.X = Xst(w.xstride ? d.layers : 0); h.blob = p.blob; h.jb = SJB + 2 * Hp; h.jb_stride = sjbs; h.mask = mask; h.W3 = d.l3;
+    h.X = Xst(w.xstride ? d.layers : 0); h.blob = p.blob; h.jb = SJB + 2 * Hp; h.jb_stride = sjbs; h.W3 = d.l3;
+    h.mask = p.rowsrc ? nullptr : mask; h.rowsrc = p.rowsrc; h.rowjet = p.rowjet; h.m_dev = p.m_dev;
     h.M = p.M; h.N = N; h.F = d.features; h.slope = d.neg_slope;
     const dim3 g((p.M + 15) / 16), bl(256);
+    if (p.rowsrc) {  // rows the compacted evaluation never touches
+        const int64_t n = (int64_t)p.M * d.features;
+        hipLaunchKernelGGL(ew_fill_masked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, mask,
+                           reinterpret_cast<const int*>(ws + w.imaps), h.base, h.dst, (int64_t)p.M, N, d.features);
+        PFM_TRY(check_hip(hipGetLastError(), "ew_fill_masked_kernel launch"));
+    }
     switch (Hp / 64) {
         case 2: hipLaunchKernelGGL(ew_head_kernel<2>, g, bl, 0, p.s, h); break;
         case 4: hipLaunchKernelGGL(ew_head_kernel<4>, g, bl, 0, p.s, h); break;
@@ -445,6 +546,19 @@ int make_plan(Plan& p, const pfm_ew_desc* d, const float* blob, float* ws, int n
     return 0;
 }
 
+// Inference with a mask: evaluate only the valid particles (they are the only rows that can influence an output the
+// reference does not multiply by zero).  Row maps are built once per call; the mask is constant over an ODE solve.
+int setup_compaction(Plan& p, const float* mask) {
+    int* im = reinterpret_cast<int*>(p.ws + p.w.imaps);
+    const int B = p.n_jets, N = p.d->n_points;
+    int *cnt = im, *off = im + B, *mv = im + 2 * B + 1, *rowsrc = im + 2 * B + 64, *rowjet = rowsrc + p.M;
+    hipLaunchKernelGGL(ew_count_kernel, dim3(B), dim3(256), 0, p.s, mask, cnt, N);
+    hipLaunchKernelGGL(ew_scan_kernel, dim3(1), dim3(1024), 0, p.s, (const int*)cnt, off, mv, B);
+    hipLaunchKernelGGL(ew_rowmap_kernel, dim3(B), dim3(64), 0, p.s, mask, (const int*)off, rowsrc, rowjet, N);
+    p.rowsrc = rowsrc; p.rowjet = rowjet; p.off = off; p.m_dev = mv;
+    return check_hip(hipGetLastError(), "row compaction launch");
+}
+
 }  // namespace ew
 }  // namespace pfm
 
@@ -466,6 +580,7 @@ int pfm_ew_forward(const pfm_ew_desc* d, const float* blob, const float* t, int3
     if (n_jets <= 0) return 0;
     if (!blob || !t || !x || !v || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
+    if (mask && (rc = ew::setup_compaction(p, mask))) return rc;
     ew::HeadArgs h{};
     h.dst = v;
     return ew::run_nfe(p, t, t_stride ? 1 : 0, x, cond, mask, h);
@@ -487,6 +602,7 @@ int pfm_ew_sample_midpoint(const pfm_ew_desc* d, const float* blob, const float*
     hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, xs, n,
                        d->features);
     if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+    if (mask && (rc = ew::setup_compaction(p, mask))) return rc;
     for (int k = 0; k < n_steps; ++k) {
         ew::HeadArgs h{};
         h.base = xs; h.dt = dt + k; h.coef = 0.5f; h.dst = xm;

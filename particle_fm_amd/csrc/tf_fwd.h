@@ -131,17 +131,21 @@ static __global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
 static __global__ __launch_bounds__(256) void tf_embed_kernel(const float* __restrict__ blob, int64_t Wx,
                                                        const float* __restrict__ x, const float* __restrict__ jb,
                                                        int64_t jb_stride, float* __restrict__ h1, int M, int N, int F,
-                                                       int Hd, float slope) {
+                                                       int Hd, float slope, const int* __restrict__ rowsrc = nullptr,
+                                                       const int* __restrict__ rowjet = nullptr,
+                                                       const int* __restrict__ m_dev = nullptr) {
     const int nc4 = Hd >> 2;
     const int row0 = blockIdx.x * 32;
+    if (m_dev) M = *m_dev;
     for (int idx = threadIdx.x; idx < 32 * nc4; idx += 256) {
         const int r = idx / nc4, c4 = idx - r * nc4;
         const int row = row0 + r;
         if (row >= M) break;
-        const int jet = row / N;
+        const int jet = rowjet ? rowjet[row] : row / N;
+        const int64_t xrow = rowsrc ? rowsrc[row] : row;
         f32x4 acc = *reinterpret_cast<const f32x4*>(jb + (int64_t)jet * jb_stride + 4 * c4);
         for (int f = 0; f < F; ++f) {
-            const float xv = x[(int64_t)row * F + f];
+            const float xv = x[xrow * F + f];
             const f32x4 wv = *reinterpret_cast<const f32x4*>(blob + Wx + (int64_t)f * Hd + 4 * c4);
             acc.x = fmaf(wv.x, xv, acc.x); acc.y = fmaf(wv.y, xv, acc.y);
             acc.z = fmaf(wv.z, xv, acc.z); acc.w = fmaf(wv.w, xv, acc.w);
@@ -160,6 +164,8 @@ struct LinArgs {
     const float* jb;    // jet-bias rows (already contain the bias) or nullptr
     const float* R;     // residual [M][ldr] or nullptr
     const float* Y;     // act 3: activation output [M][ldy] whose LeakyReLU' scales the result
+    const int* rowjet;  // row -> jet for the jet-bias lookup (compacted rows), or nullptr: jet = row / N
+    const int* m_dev;   // device-side row count overriding M (compacted rows), or nullptr
     float* out;         // [M][ldo]
     int64_t blob_floats, W, b, gamma, beta, jb_stride;
     int lda, lda2, K1, ldr, ldy, ldo, M, K, NO, N, act, row_tiles;  // act: 0 none (+R), 1 lrelu(acc) (+R after), 2 lrelu(acc + R), 3 (acc + R) * lrelu'(Y)
@@ -220,6 +226,10 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     if (!tile_of_block(blockIdx.x, a.row_tiles, a.NO / BN, rt, ch)) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
     const int row0 = rt * BM;
+    if (a.m_dev) {
+        a.M = *a.m_dev;
+        if (row0 >= a.M) return;
+    }
     const int ob = ch * BN + 32 * w;  // this wave: outputs [ob, ob + 32) as two 16-row A operands
     const blob_rsrc rs = make_blob_rsrc(a.blob, a.blob_floats);
     const int nkc = a.K >> 7;
@@ -238,7 +248,8 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         for (int t = 0; t < 4; ++t) {
             if (a.jb) {
                 const int row = min(row0 + 16 * t + pl, a.M - 1);
-                acc[s][t] = *reinterpret_cast<const f32x4*>(a.jb + (int64_t)(row / a.N) * a.jb_stride + o);
+                const int jet = a.rowjet ? a.rowjet[row] : row / a.N;
+                acc[s][t] = *reinterpret_cast<const f32x4*>(a.jb + (int64_t)jet * a.jb_stride + o);
             } else if (a.b >= 0) {
                 acc[s][t] = *reinterpret_cast<const f32x4*>(a.blob + a.b + o);
             } else {
