@@ -42,3 +42,23 @@ if steps > 1:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"sample {steps} steps: {dt*1e3:.1f} ms  {B/dt:.1f} jets/s  {fl*2*(steps-1)/dt/1e12:.1f} TFLOP/s")
+if len(sys.argv) > 3 and sys.argv[3] == "train":
+    from particle_fm_amd.fm_loss_wide import epic_wide_fm_loss
+    layb = EpicWideLayout(cfg)
+    stg = {k: v.cuda().requires_grad_(True) for k, v in st.items()}
+    z = torch.randn(B, 128, 13, generator=gen).cuda()
+    def step():
+        for v_ in stg.values():
+            v_.grad = None
+        loss = epic_wide_fm_loss(layb, layb.source_vector(stg), x, t, z, cond, mask.unsqueeze(-1))
+        loss.backward()
+        return loss
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print(f"loss fwd+bwd (incl. weight-norm autograd): {dt*1e3:.2f} ms  {B/dt:.0f} jets/s  {3*fl/dt/1e12:.1f} TFLOP/s algorithmic")
