@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void ew_head_kernel(HeadArgs a) {
 // Workspace (floats).  Inference: one P row set, one Q, one X / L1.  Train: every stage keeps its own copies
 // (stage 0 = stem, stage l+1 = layer l): P_s, Q_s (pool of X_s), X_s, L1_l -- what the backward re-reads.
 struct Ws {
-    int64_t P, pstride, Q, qstride, SJB, JB, X1, X, xstride, L1, lstride, imaps, total;  // imaps: int32 cnt[B] off[B+1] m[1] rowsrc[M] rowjet[M]
+    int64_t P, pstride, Q, qstride, SJB, JB, X1, X, xstride, L1, lstride, imaps, part, part_floats, total;  // imaps: int32 cnt[B] off[B+1] m[1] rowsrc[M] rowjet[M]
 };
 
 __host__ inline Ws make_ws(const pfm_ew_desc& d, int n_jets, bool train) {
@@ -213,6 +213,8 @@ __host__ inline Ws make_ws(const pfm_ew_desc& d, int n_jets, bool train) {
     w.lstride = train ? round64(M * Hp) : 0;
     w.L1 = take(M * Hp); o += w.lstride * (stages > 2 ? stages - 2 : 0);
     w.imaps = take(2 * (int64_t)n_jets + 64 + 2 * M);
+    w.part_floats = n_jets <= 1024 ? 8 * (int64_t)n_jets * (2 * Hp + 128) : 0;
+    w.part = take(w.part_floats);
     w.total = o;
     return w;
 }
@@ -241,6 +243,8 @@ struct Plan {
     hipStream_t s;
     // compacted rows (inference with a mask): only valid particles are rows; nullptr = dense rows
     const int *rowsrc = nullptr, *rowjet = nullptr, *off = nullptr, *m_dev = nullptr;
+    float* part = nullptr;  // split-K partial sums of the per-jet GEMMs
+    int64_t part_floats = 0;
 };
 
 // out[Mrows][ldo] = epi(A (+A2) W^T + b / jb)
@@ -254,9 +258,21 @@ int linear(const Plan& p, int Mrows, const float* A, int lda, int K1, const floa
     a.ldr = ldr; a.ldo = ldo; a.M = Mrows; a.K = K; a.NO = NO; a.N = jbN; a.act = act;
     a.row_tiles = (Mrows + BM - 1) / BM;
     a.slope = p.d->neg_slope; a.eps = 0.f;
-    const int grid = ((a.row_tiles + 7) / 8) * 8 * (NO / BN);
+    // per-jet GEMMs (a few hundred rows) are latency chains over K: split K over workgroups, reduce in a second launch
+    a.part = nullptr; a.ksplit = 1;
+    if (!jb && Mrows <= 1024 && p.part) {
+        const int nkc = K / 128;
+        int ks = nkc;
+        while (ks > 8 || nkc % ks) --ks;
+        if (ks > 1 && (int64_t)ks * Mrows * NO <= p.part_floats) { a.part = p.part; a.ksplit = ks; }
+    }
+    const int grid = ((a.row_tiles + 7) / 8) * 8 * (NO / BN) * a.ksplit;
     hipLaunchKernelGGL(tf_linear_kernel<0>, dim3(grid), dim3(LT), (BM * 128 + 2 * BM) * sizeof(float), p.s, a);
-    return check_hip(hipGetLastError(), "tf_linear_kernel launch (epicw)");
+    int rc = check_hip(hipGetLastError(), "tf_linear_kernel launch (epicw)");
+    if (rc || a.ksplit == 1) return rc;
+    const int64_t n4 = (int64_t)Mrows * (NO / 4);
+    hipLaunchKernelGGL(tf_splitk_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, p.s, a);
+    return check_hip(hipGetLastError(), "tf_splitk_kernel launch");
 }
 
 #define PFM_TRY(x) do { if ((rc = (x))) return rc; } while (0)
@@ -543,6 +559,8 @@ int make_plan(Plan& p, const pfm_ew_desc* d, const float* blob, float* ws, int n
     if (rc) return rc;
     p.d = d; p.blob = blob; p.ws = ws; p.n_jets = n_jets; p.M = n_jets * d->n_points; p.s = (hipStream_t)stream;
     p.w = make_ws(*d, n_jets, train);
+    p.part = ws + p.w.part;
+    p.part_floats = p.w.part_floats;
     return 0;
 }
 

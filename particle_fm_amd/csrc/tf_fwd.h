@@ -166,6 +166,8 @@ struct LinArgs {
     const float* Y;     // act 3: activation output [M][ldy] whose LeakyReLU' scales the result
     const int* rowjet;  // row -> jet for the jet-bias lookup (compacted rows), or nullptr: jet = row / N
     const int* m_dev;   // device-side row count overriding M (compacted rows), or nullptr
+    float* part;        // split-K: raw partial sums [ksplit][M][NO] (bias / activation / residual applied by tf_splitk_kernel)
+    int ksplit;         // 1: the whole K in one workgroup
     float* out;         // [M][ldo]
     int64_t blob_floats, W, b, gamma, beta, jb_stride;
     int lda, lda2, K1, ldr, ldy, ldo, M, K, NO, N, act, row_tiles;  // act: 0 none (+R), 1 lrelu(acc) (+R after), 2 lrelu(acc + R), 3 (acc + R) * lrelu'(Y)
@@ -220,10 +222,11 @@ template <int NI>
 __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     constexpr bool LN = NI > 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* const tile = lds;             // BM x 128, 16-byte slots XOR-swizzled with (row & 15)
+    float* const tile = lds;             // two BM x 64 slices, 16-byte slots XOR-swizzled with (row & 15)
     float* const stat = lds + BM * 128;  // BM x (mean, rstd)
     int rt, ch;
-    if (!tile_of_block(blockIdx.x, a.row_tiles, a.NO / BN, rt, ch)) return;
+    const int ks = a.ksplit > 1 ? blockIdx.x % a.ksplit : 0;
+    if (!tile_of_block(a.ksplit > 1 ? blockIdx.x / a.ksplit : blockIdx.x, a.row_tiles, a.NO / BN, rt, ch)) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
     const int row0 = rt * BM;
     if (a.m_dev) {
@@ -246,7 +249,9 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         const int o = ob + 16 * s + 4 * q;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            if (a.jb) {
+            if (a.ksplit > 1) {
+                acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else if (a.jb) {
                 const int row = min(row0 + 16 * t + pl, a.M - 1);
                 const int jet = a.rowjet ? a.rowjet[row] : row / a.N;
                 acc[s][t] = *reinterpret_cast<const f32x4*>(a.jb + (int64_t)jet * a.jb_stride + o);
@@ -258,51 +263,58 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         }
     }
 
-    const int sc4 = tid & 31, sr = tid >> 5;  // staging: 16-byte column slot, first row
-#pragma unroll 1
-    for (int kc = 0; kc < nkc; ++kc) {
-        f32x4 af[2][8];
+    // Software pipeline over K in steps of 64: the weights (A operand: 2 x 4 float4 per lane) and the activation slice
+    // (4 float4 per lane) of step s+1 are requested right after step s's slice has been published to LDS, so their
+    // L2 / HBM latency runs under step s's 128 MFMAs.  Two LDS slices alternate: one barrier per step.  The
+    // LayerNorm transform is applied on the way into LDS.
+    const int sc4 = tid & 15, sr = tid >> 4;  // staging: 16-byte column slot (16 per 64-column step), first row
+    const int nst_all = a.K >> 6;
+    const int st0 = a.ksplit > 1 ? ks * (nst_all / a.ksplit) : 0;       // K / 128 is a multiple of ksplit (host)
+    const int nst = a.ksplit > 1 ? st0 + nst_all / a.ksplit : nst_all;  // one past this workgroup's last step
+    auto request = [&](f32x4 (&af)[2][4], f32x4 (&st)[4], int step) {
+        const int kc = step >> 1, half = step & 1;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int64_t base = a.W + ((int64_t)((ob >> 4) + s) * nkc + kc) * 2048;
+            const int64_t base = a.W + ((int64_t)((ob >> 4) + s) * nkc + kc) * 2048 + half * 1024;
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) af[s][kt] = bload4(rs, base + kt * 256, lane * 16);
+            for (int kt = 0; kt < 4; ++kt) af[s][kt] = bload4(rs, base + kt * 256, lane * 16);
         }
-        f32x4 st[8];
-        {
-            const int col = 128 * kc + 4 * sc4;
-            const bool seg2 = a.A2 != nullptr && 128 * kc >= a.K1;  // wave-uniform
-            const float* src = seg2 ? a.A2 + (col - a.K1) : a.A + col;
-            const int ld = seg2 ? a.lda2 : a.lda;
+        const int col = 64 * step + 4 * sc4;
+        const bool seg2 = a.A2 != nullptr && 64 * step >= a.K1;  // wave-uniform
+        const float* src = seg2 ? a.A2 + (col - a.K1) : a.A + col;
+        const int ld = seg2 ? a.lda2 : a.lda;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = min(row0 + sr + 8 * i, a.M - 1);
-                st[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)row * ld);
+        for (int i = 0; i < 4; ++i) {
+            const int row = min(row0 + sr + 16 * i, a.M - 1);
+            st[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)row * ld);
+        }
+    };
+    auto step_fn = [&](f32x4 (&af)[2][4], f32x4 (&st)[4], f32x4 (&afn)[2][4], f32x4 (&stn)[4], int step) {
+        float* const buf = tile + (step & 1) * (BM * 64);
+        if (LN) {
+            const int col = 64 * step + 4 * sc4;
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + col);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = sr + 16 * i;
+                const float mean = stat[2 * r], rstd = stat[2 * r + 1];
+                st[i] = (st[i] - mean) * rstd * g4 + b4;
             }
-            if (LN) {
-                const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + col);
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + col);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int r = sr + 8 * i;
-                    const float mean = stat[2 * r], rstd = stat[2 * r + 1];
-                    st[i] = (st[i] - mean) * rstd * g4 + b4;
-                }
-            }
         }
-        if (kc > 0) __syncthreads();  // everyone is done reading the previous chunk
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = sr + 8 * i;
-            *reinterpret_cast<f32x4*>(tile + r * 128 + ((sc4 ^ (r & 15)) << 2)) = st[i];
+        for (int i = 0; i < 4; ++i) {
+            const int r = sr + 16 * i;
+            *reinterpret_cast<f32x4*>(buf + r * 64 + ((sc4 ^ (r & 15)) << 2)) = st[i];
         }
-        __syncthreads();
+        __syncthreads();  // also orders this write after every wave's reads of the same slice two steps ago
+        if (step + 1 < nst) request(afn, stn, step + 1);
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
-            const float* b0p = tile + (32 * tp + pl) * 128;
-            const float* b1p = b0p + 16 * 128;
+            const float* b0p = buf + (32 * tp + pl) * 64;
+            const float* b1p = b0p + 16 * 64;
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) {
+            for (int kt = 0; kt < 4; ++kt) {
                 const int so = ((4 * kt + q) ^ pl) << 2;
                 const f32x4 B0 = *reinterpret_cast<const f32x4*>(b0p + so);
                 const f32x4 B1 = *reinterpret_cast<const f32x4*>(b1p + so);
@@ -315,6 +327,15 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
 #undef PFM_TF_STEP
             }
         }
+    };
+    {
+        f32x4 afA[2][4], afB[2][4], stA[4], stB[4];
+        request(afA, stA, st0);
+#pragma unroll 1
+        for (int step = st0; step < nst; step += 2) {
+            step_fn(afA, stA, afB, stB, step);
+            step_fn(afB, stB, afA, stA, step + 1);  // K is a multiple of 128: the number of steps is even
+        }
     }
 
     // epilogue: lane (particle pl of tile t, q) holds 4 consecutive outputs
@@ -324,7 +345,9 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int row = row0 + 16 * t + pl;
-            if (row < a.M) {
+            if (row < a.M && a.ksplit > 1) {
+                *reinterpret_cast<f32x4*>(a.part + ((int64_t)ks * a.M + row) * a.NO + o) = acc[s][t];
+            } else if (row < a.M) {
                 f32x4 v = acc[s][t];
                 if (a.act == 3) {
                     if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
@@ -340,6 +363,27 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
             }
         }
     }
+}
+
+// split-K epilogue: out = epi( sum_ks part[ks] + b ) with the same activation / residual modes as the Linear kernel
+static __global__ __launch_bounds__(256) void tf_splitk_kernel(LinArgs a) {
+    const int nc4 = a.NO >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)a.M * nc4) return;
+    const int row = (int)(i / nc4), o = 4 * (int)(i - (int64_t)row * nc4);
+    f32x4 v = a.b >= 0 ? *reinterpret_cast<const f32x4*>(a.blob + a.b + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < a.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(a.part + ((int64_t)k * a.M + row) * a.NO + o);
+    if (a.act == 3) {
+        if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(a.Y + (int64_t)row * a.ldy + o);
+        v.x *= y.x > 0.f ? 1.f : a.slope; v.y *= y.y > 0.f ? 1.f : a.slope;
+        v.z *= y.z > 0.f ? 1.f : a.slope; v.w *= y.w > 0.f ? 1.f : a.slope;
+    } else {
+        if (a.act == 2) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+        if (a.act) v = lrelu4(v, a.slope);
+        if (a.R && a.act != 2) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+    }
+    *reinterpret_cast<f32x4*>(a.out + (int64_t)row * a.ldo + o) = v;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -44,7 +44,7 @@ struct Plan {
 int launch_linear(const Plan& p, const float* A, int lda, int K, const pfm_tf_lin& lin, const pfm_tf_norm* ln, int NO,
                   const float* jb, const float* R, int ldr, float* out, int ldo, bool act) {
     LinArgs a;
-    a.A = A; a.A2 = nullptr; a.lda2 = 0; a.K1 = K; a.blob = p.blob; a.jb = jb; a.R = R; a.Y = nullptr; a.ldy = 0; a.rowjet = nullptr; a.m_dev = nullptr; a.out = out;
+    a.A = A; a.A2 = nullptr; a.lda2 = 0; a.K1 = K; a.blob = p.blob; a.jb = jb; a.R = R; a.Y = nullptr; a.ldy = 0; a.rowjet = nullptr; a.m_dev = nullptr; a.part = nullptr; a.ksplit = 1; a.out = out;
     a.blob_floats = p.d->blob_floats; a.W = lin.W; a.b = lin.b;
     a.gamma = ln ? ln->gamma : -1; a.beta = ln ? ln->beta : -1;
     a.jb_stride = (int64_t)(p.d->layers + 2) * p.d->hidden;
