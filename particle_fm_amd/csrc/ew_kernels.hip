@@ -120,10 +120,23 @@ __global__ __launch_bounds__(256) void ew_pool_compact_kernel(const float* __res
     const int tid = threadIdx.x, cg = tid & 63, rg = tid >> 6, jet = blockIdx.x;
     const int nc4 = Hp >> 2, r0 = off[jet], r1 = off[jet + 1];
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    for (int r = r0 + rg; r < r1; r += 4) {
+    const bool c0 = cg < nc4, c1 = cg + 64 < nc4;
+    int r = r0 + rg;
+    for (; r + 12 < r1; r += 16) {  // four rows in flight per thread
+        f32x4 v[4][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (cg + 64 * i < nc4) acc[i] += *reinterpret_cast<const f32x4*>(X + (int64_t)r * Hp + 4 * (cg + 64 * i));
+        for (int u = 0; u < 4; ++u) {
+            const float* xp = X + (int64_t)(r + 4 * u) * Hp + 4 * cg;
+            v[u][0] = c0 ? *reinterpret_cast<const f32x4*>(xp) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v[u][1] = c1 ? *reinterpret_cast<const f32x4*>(xp + 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        acc[0] += (v[0][0] + v[1][0]) + (v[2][0] + v[3][0]);
+        acc[1] += (v[0][1] + v[1][1]) + (v[2][1] + v[3][1]);
+    }
+    for (; r < r1; r += 4) {
+        const float* xp = X + (int64_t)r * Hp + 4 * cg;
+        if (c0) acc[0] += *reinterpret_cast<const f32x4*>(xp);
+        if (c1) acc[1] += *reinterpret_cast<const f32x4*>(xp + 256);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
