@@ -17,6 +17,7 @@
  *                               incl. the `z * mask` of SetFlowMatchingLitModule.sample (:668-671)
  *   pfm_epic_fm_loss_forward /  FlowMatchingLoss.forward / ConditionalFlowMatchingLoss.forward
  *   pfm_epic_fm_loss_backward   models/components/losses.py:38-77, 101-136 and their autograd
+ *   pfm_sample_epilogue         the per-batch post-processing of generate_data   utils/data_generation.py:94-123
  *   pfm_optim_step              clip_grad_norm_(gradient_clip_val) + AdamW + EMA
  *                               configs/experiment/jetnet/fm_tops150.yaml:24, configs/model/flow_matching.yaml:3-7,
  *                               particle_fm/callbacks/ema.py:73-81
@@ -165,6 +166,13 @@ int pfm_optim_step(float *param, const float *grad, float *exp_avg, float *exp_a
                    float *scratch, int64_t n, float grad_mul, float max_norm, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float ema_decay, int32_t step,
                    void *stream);
+
+/* Post-processing of a generated batch in place, on the device (utils/data_generation.py:94-123 does it on the host
+ * after a D2H copy per batch): x[row][f] = x * scale[f] + shift[f] (inverse_normalize_tensor, data/components/utils.py:
+ * 183-199; scale = std/sigma, shift = mean; NULL/NULL = skip), then x[row][log_pt_col] = 1 - exp(x) (log_pt_col < 0:
+ * skip), then x *= mask[row] (NULL: skip).  x [rows][features], mask [rows], scale / shift [features] device pointers. */
+int pfm_sample_epilogue(float *x, const float *mask, const float *scale, const float *shift, int32_t log_pt_col,
+                        int64_t rows, int32_t features, void *stream);
 
 /* Weight-norm reparametrisation on FLAT buffers (old-style nn.utils.weight_norm, epic.py:66-81, 262-300):
  *   pack:   W[o,:] = g[o] * v[o,:] / ||v[o,:]||  written to blob[dst1[s]] and blob[dst2[s]] (s = source index of the

@@ -152,3 +152,24 @@ def sample_midpoint(vf: Callable, z, cond, mask, ode_steps: int = 100):
     t_span = torch.linspace(1.0, 0.0, ode_steps)
     with torch.no_grad():
         return midpoint_trajectory_end(lambda t, x: vf(t, x, mask=mask, cond=cond), z, t_span)
+
+
+def generate_epilogue(x, mask, normalized_data, normalize_sigma, means, stds, log_pt, pt_standardization, variable_set_sizes):
+    """The per-batch post-processing of generate_data (utils/data_generation.py:94-123) on a CPU tensor, op for op:
+    inverse_normalize_tensor (data/components/utils.py:183-199), log_pt through numpy's exp, mask multiply."""
+    import numpy as np
+
+    x = x.clone()
+    if normalized_data:
+        if pt_standardization:
+            for i in range(2):
+                x[..., i] = (x[..., i] * (stds[i] / 10)) + means[i]
+            x[..., 2] = (x[..., 2] * (stds[2] / 5)) + means[2]
+        else:
+            for i in range(len(means)):
+                x[..., i] = (x[..., i] * (stds[i] / normalize_sigma)) + means[i]
+        if log_pt:
+            x[..., 2] = torch.from_numpy(1.0 - np.exp(x[..., 2].numpy()))
+    if variable_set_sizes:
+        x = x * mask
+    return x

@@ -11,7 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libpfm_hip.so")
-SOURCES = ["epic_kernels.hip", "epic_train.hip", "optim.hip", "wn.hip", "tf_kernels.hip", "ew_kernels.hip"]  # missing files are skipped until they exist
+SOURCES = ["epic_kernels.hip", "epic_train.hip", "optim.hip", "wn.hip", "post.hip", "tf_kernels.hip", "ew_kernels.hip"]  # missing files are skipped until they exist
 ARCH = "gfx950"
 
 

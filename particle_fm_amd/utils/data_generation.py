@@ -1,0 +1,109 @@
+"""Drop-in for particle_fm/utils/data_generation.py::generate_data (utils/data_generation.py:17-176).
+
+Same signature, same batching (full batches, then the remainder with the LAST rows of cond / mask), same timing
+convention (the clock starts with the second batch and stops before the remainder batch), same return value
+(numpy array, seconds).  Differences, all on purpose: the batches stay in HBM -- inverse normalisation, log_pt and the
+mask multiply run as one HIP launch per batch (pfm_sample_epilogue) instead of after a D2H copy -- and there is a
+single D2H copy of the concatenated result at the end; the clock is bracketed by a device synchronisation so that it
+measures the generation, not the enqueue.
+"""
+from __future__ import annotations
+
+import ctypes
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..hip_ops import _ptr, _stream_ptr
+
+
+def sample_epilogue_(x: torch.Tensor, mask: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+                     shift: Optional[torch.Tensor] = None, log_pt_col: int = -1) -> torch.Tensor:
+    """In place on a device tensor x (B,N,F): x*scale+shift, 1-exp on one column, *mask."""
+    if not x.is_cuda:
+        raise RuntimeError("sample_epilogue_ needs a ROCm device tensor (no CPU fallback)")
+    lib = _lib.load()
+    assert x.is_contiguous() and x.dtype == torch.float32
+    B, N, F = x.shape
+    dev = x.device
+    m = None if mask is None else mask.reshape(B, N).to(device=dev, dtype=torch.float32).contiguous()
+    sc = None if scale is None else scale.to(device=dev, dtype=torch.float32).contiguous()
+    sh = None if shift is None else shift.to(device=dev, dtype=torch.float32).contiguous()
+    rc = lib.pfm_sample_epilogue(_ptr(x), _ptr(m), _ptr(sc), _ptr(sh), int(log_pt_col), ctypes.c_int64(B * N), F, _stream_ptr(dev))
+    _lib.check(rc, "pfm_sample_epilogue")
+    return x
+
+
+def _affine(means, stds, F, normalize_sigma, pt_standardization):
+    """(scale, shift) of inverse_normalize_tensor as fp32 tensors: tensor * (std / sigma) + mean, the quotient taken in
+    double like the reference's python arithmetic (data/components/utils.py:197-198)."""
+    scale, shift = np.ones(F, dtype=np.float64), np.zeros(F, dtype=np.float64)
+    if pt_standardization:  # data_generation.py:98-105: sigma 10 for (eta, phi), 5 for pt
+        for i in range(2):
+            scale[i], shift[i] = float(stds[i]) / 10, float(means[i])
+        scale[2], shift[2] = float(stds[2]) / 5, float(means[2])
+    else:
+        for i in range(len(means)):
+            scale[i], shift[i] = float(stds[i]) / normalize_sigma, float(means[i])
+    return torch.from_numpy(scale.astype(np.float32)), torch.from_numpy(shift.astype(np.float32))
+
+
+def generate_data(model, num_jet_samples: int, batch_size: int = 256, cond: torch.Tensor = None, device: str = "cuda",
+                  variable_set_sizes: bool = False, mask: torch.Tensor = None, normalized_data: bool = False,
+                  normalize_sigma: int = 5, means=None, stds=None, log_pt: bool = False, pt_standardization: bool = False,
+                  shuffle_mask: bool = False, verbose: bool = True, ode_solver: str = "midpoint", ode_steps: int = 100):
+    if variable_set_sizes and mask is None:
+        raise ValueError("Please use mask when using variable_set_sizes=True")  # data_generation.py:62-63
+    if mask is not None and len(mask) != num_jet_samples:
+        raise ValueError(f"Mask should have the same length as num_jet_samples ({len(mask)} != {num_jet_samples})")
+    dev = torch.device(device)
+    if verbose:
+        print(f"Generating data ({num_jet_samples} samples). Device: {dev}")
+    model = model.to(dev)
+    n_full = num_jet_samples // batch_size
+    rem = num_jet_samples - n_full * batch_size
+    scale = shift = None
+    outs = []
+    start_time = 0.0
+
+    def one_batch(n, cond_b, mask_b):
+        nonlocal scale, shift
+        with torch.no_grad():
+            x = model.sample(n_samples=n, cond=cond_b, mask=mask_b, ode_solver=ode_solver, ode_steps=ode_steps)
+        x = x.contiguous()
+        if normalized_data and scale is None:
+            scale, shift = (t.to(dev) for t in _affine(means, stds, x.shape[-1], normalize_sigma, pt_standardization))
+        sample_epilogue_(x, mask_b if variable_set_sizes else None, scale if normalized_data else None,
+                         shift if normalized_data else None, 2 if (normalized_data and log_pt) else -1)
+        outs.append(x)
+
+    for i in range(n_full):
+        cond_b = None if cond is None else cond[i * batch_size:(i + 1) * batch_size]
+        if i == 1:  # the reference's convention: the first (warm-up) batch is not timed (data_generation.py:82-83)
+            torch.cuda.synchronize(dev)
+            start_time = time.time()
+        if variable_set_sizes:
+            if shuffle_mask:
+                mask = mask[np.random.permutation(len(mask))]
+                mask_b = mask[:batch_size]
+            else:
+                mask_b = mask[i * batch_size:(i + 1) * batch_size]
+        else:
+            mask_b = None
+        one_batch(batch_size, cond_b, mask_b)
+    torch.cuda.synchronize(dev)
+    end_time = time.time()
+    if rem:
+        cond_b = None if cond is None else cond[-rem:]
+        if variable_set_sizes:
+            if shuffle_mask:
+                mask = mask[np.random.permutation(len(mask))]
+            mask_b = mask[-rem:]
+        else:
+            mask_b = None
+        one_batch(rem, cond_b, mask_b)
+    data = torch.cat(outs).cpu().numpy() if outs else np.zeros((0,), dtype=np.float32)
+    return data, end_time - start_time
