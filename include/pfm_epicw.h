@@ -9,7 +9,7 @@
  *   pfm_ew_sample_midpoint   CNF.decode(ode_solver="midpoint")  flow_matching_module.py:245-259, 283-287, 668-671
  *
  * Data layout.  Particles of all jets form one row matrix (M = n_jets * n_points rows) of Hp = hidden rounded up
- * to a multiple of 128 columns (padding columns are exactly 0 everywhere: zero weight rows / columns, zero bias);
+ * to a multiple of 64 columns (padding columns are exactly 0 everywhere: zero weight rows / columns, zero bias);
  * per-jet quantities live in P[n_jets][256 + Hp] = [temb | cond | 0 .. (128) ; g | 0 .. (128) ; g1 (Hp)] and
  * Q[n_jets][2 Hp] = [masked mean | masked sum * sum_scale].  Every Linear is the fp32-MFMA GEMM of pfm_tf.h
  * (MFMA_AK weights); the columns that multiply per-jet vectors (time, conditioning, broadcast global vector) are

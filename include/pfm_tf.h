@@ -24,9 +24,9 @@
  * LeakyReLU(0.1) and the residual.
  *
  * Weight blob formats (fp32):
- *   MFMA_AK [NO][K]   NO, K multiples of 16 / 128: 16-output x 128-k blocks, block (ob, kc) at float
- *                     ((ob * (K/128) + kc) * 8 + kt) * 256 + lane * 4 + r  holds
- *                     W[16*ob + (lane&15)][128*kc + 16*kt + 4*(lane>>4) + r]      (A operand of the forward GEMM)
+ *   MFMA_AK [NO][K]   NO multiple of 32, K multiple of 64: 16-output x 64-k blocks, block (ob, st) at float
+ *                     ((ob * (K/64) + st) * 4 + kt) * 256 + lane * 4 + r  holds
+ *                     W[16*ob + (lane&15)][64*st + 16*kt + 4*(lane>>4) + r]       (A operand of the forward GEMM)
  *   MFMA_AKT          the MFMA_AK packing of W^T ([K][NO] seen as outputs x k): A operand of the backward dX GEMM
  *   KMAJOR [K][NO]    row k = column k of the nn.Linear weight (per-jet GEMVs: context / time columns, ctxt_emdb)
  *   ROWMAJOR [F][K]   the nn.Linear weight as stored (output head, F <= 16)

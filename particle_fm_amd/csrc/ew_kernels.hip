@@ -235,8 +235,8 @@ __host__ inline Ws make_ws(const pfm_ew_desc& d, int n_jets, bool train) {
 int validate(const pfm_ew_desc* d) {
     if (!d) return set_err(PFM_E_BADARG, "desc is NULL");
     if (d->abi_version != PFM_EW_ABI_VERSION) return set_err(PFM_E_BADARG, "epicw desc.abi_version mismatch");
-    if (d->hidden < 1 || d->hidden_pad != (d->hidden + 127) / 128 * 128 || d->hidden_pad > 512)
-        return set_err(PFM_E_BADARG, "hidden_pad must be hidden rounded up to a multiple of 128, at most 512");
+    if (d->hidden < 1 || d->hidden_pad != (d->hidden + 63) / 64 * 64 || d->hidden_pad > 512)
+        return set_err(PFM_E_BADARG, "hidden_pad must be hidden rounded up to a multiple of 64, at most 512");
     if (d->layers < 0 || d->layers > PFM_EW_MAX_LAYERS) return set_err(PFM_E_BADARG, "layers out of range");
     if (d->latent < 1 || d->latent > 128) return set_err(PFM_E_BADARG, "latent must be in 1..128");
     if (d->features < 1 || d->features > 16) return set_err(PFM_E_BADARG, "features must be in 1..16");
@@ -274,12 +274,12 @@ int linear(const Plan& p, int Mrows, const float* A, int lda, int K1, const floa
     // per-jet GEMMs (a few hundred rows) are latency chains over K: split K over workgroups, reduce in a second launch
     a.part = nullptr; a.ksplit = 1;
     if (!jb && Mrows <= 1024 && p.part) {
-        const int nkc = K / 128;
-        int ks = nkc;
-        while (ks > 8 || nkc % ks) --ks;
+        const int nstep = K / 64;
+        int ks = nstep < 8 ? nstep : 8;
+        while (nstep % ks) --ks;
         if (ks > 1 && (int64_t)ks * Mrows * NO <= p.part_floats) { a.part = p.part; a.ksplit = ks; }
     }
-    const int grid = ((a.row_tiles + 7) / 8) * 8 * (NO / BN) * a.ksplit;
+    const int grid = ((a.row_tiles + 7) / 8) * 8 * ((NO + BN - 1) / BN) * a.ksplit;
     hipLaunchKernelGGL(tf_linear_kernel<0>, dim3(grid), dim3(LT), (BM * 128 + 2 * BM) * sizeof(float), p.s, a);
     int rc = check_hip(hipGetLastError(), "tf_linear_kernel launch (epicw)");
     if (rc || a.ksplit == 1) return rc;
@@ -345,8 +345,12 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
     }
     switch (Hp / 64) {
         case 2: hipLaunchKernelGGL(ew_head_kernel<2>, g, bl, 0, p.s, h); break;
+        case 1: hipLaunchKernelGGL(ew_head_kernel<1>, g, bl, 0, p.s, h); break;
+        case 3: hipLaunchKernelGGL(ew_head_kernel<3>, g, bl, 0, p.s, h); break;
         case 4: hipLaunchKernelGGL(ew_head_kernel<4>, g, bl, 0, p.s, h); break;
+        case 5: hipLaunchKernelGGL(ew_head_kernel<5>, g, bl, 0, p.s, h); break;
         case 6: hipLaunchKernelGGL(ew_head_kernel<6>, g, bl, 0, p.s, h); break;
+        case 7: hipLaunchKernelGGL(ew_head_kernel<7>, g, bl, 0, p.s, h); break;
         default: hipLaunchKernelGGL(ew_head_kernel<8>, g, bl, 0, p.s, h); break;
     }
     return check_hip(hipGetLastError(), "ew_head_kernel launch");
@@ -447,7 +451,7 @@ struct Bwd {
         a.Z = Z; a.A = A; a.A2 = A2; a.stats = nullptr; a.blob = p.blob; a.part = sc + b.dwpart; a.gamma = -1; a.beta = -1;
         a.ldz = ldz; a.lda = lda; a.lda2 = lda2; a.K1 = K1; a.M = Mrows; a.NO = NO; a.K = K;
         a.row_tiles = (Mrows + BM - 1) / BM;
-        const int tiles = (NO / 128) * (K / 128);
+        const int tiles = ((NO + 127) / 128) * ((K + 127) / 128);
         int ns = DW_MAX_PARTS / tiles;
         if (ns < 1) ns = 1;
         if (ns > a.row_tiles) ns = a.row_tiles;
@@ -455,7 +459,7 @@ struct Bwd {
         int rc;
         hipLaunchKernelGGL(tf_dw_kernel, dim3(tiles * ns), dim3(LT), 2 * 64 * DWS * sizeof(float), p.s, a);
         if ((rc = check_hip(hipGetLastError(), "tf_dw_kernel launch (epicw)"))) return rc;
-        hipLaunchKernelGGL(tf_dw_reduce_kernel, dim3(64, tiles), dim3(256), 0, p.s, (const float*)a.part, gblob, gW, K / 128, ns);
+        hipLaunchKernelGGL(tf_dw_reduce_kernel, dim3(64, tiles), dim3(256), 0, p.s, (const float*)a.part, gblob, gW, NO, K, ns);
         return check_hip(hipGetLastError(), "tf_dw_reduce_kernel launch (epicw)");
     }
     // out[Mrows][K] = (Z W (+R)) (* lrelu'(Y))

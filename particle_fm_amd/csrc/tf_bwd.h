@@ -299,9 +299,10 @@ static __global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const zt = lds;             // [64][DWS]
     float* const at = lds + 64 * DWS;  // [64][DWS]
-    const int nkc = a.K >> 7;
+    const int nkc = (a.K + 127) >> 7;  // 128-wide tiles over K and NO; partial last tiles are zero-filled
     const int split = blockIdx.x % a.nsplit, tile = blockIdx.x / a.nsplit;
     const int to = tile / nkc, tk = tile - to * nkc;
+    const bool zin = 128 * to + 4 * (threadIdx.x & 31) < a.NO, ain = 128 * tk + 4 * (threadIdx.x & 31) < a.K;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
     const int wo = w >> 1, wk = w & 1;
     const int sc4 = tid & 31, sr = tid >> 5;
@@ -312,7 +313,7 @@ static __global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
         for (int e = 0; e < 4; ++e) acc[c][e] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool ln = a.stats != nullptr;
     f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
-    if (ln) {
+    if (ln && ain) {
         g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + 128 * tk + 4 * sc4);
         b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 128 * tk + 4 * sc4);
     }
@@ -326,9 +327,9 @@ static __global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
         for (int i = 0; i < 8; ++i) {
             const int row = rt * BM + sr + 8 * i;
             const int rc = min(row, a.M - 1);
-            zs[i] = *reinterpret_cast<const f32x4*>(a.Z + (int64_t)rc * a.ldz + 128 * to + 4 * sc4);
-            if (row >= a.M) zs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 av = *reinterpret_cast<const f32x4*>(asrc + (int64_t)rc * ald);
+            zs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < a.M && zin) zs[i] = *reinterpret_cast<const f32x4*>(a.Z + (int64_t)rc * a.ldz + 128 * to + 4 * sc4);
+            const f32x4 av = ain ? *reinterpret_cast<const f32x4*>(asrc + (int64_t)rc * ald) : f32x4{0.f, 0.f, 0.f, 0.f};
             if (ln) {
                 const float mean = a.stats[2 * (int64_t)rc], rstd = a.stats[2 * (int64_t)rc + 1];
                 as[i] = (av - mean) * rstd * g4 + b4;
@@ -371,7 +372,8 @@ static __global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
 // gblob[W block] += sum over splits of the partial tiles.  Element p of a tile: w = p>>12, c = (p>>10)&3, r = (p>>8)&3,
 // lane = (p>>2)&63, e = p&3  ->  dW[o][k], o = 128 to + 64 (w>>1) + 4 (4 (lane>>4) + r) + c, k = 128 tk + 64 (w&1) + 4 (lane&15) + e
 static __global__ __launch_bounds__(256) void tf_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ gblob,
-                                                           int64_t gW, int nkc, int nsplit) {
+                                                           int64_t gW, int NO, int K, int nsplit) {
+    const int nkc = (K + 127) >> 7, nst = K >> 6;
     const int tile = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
     const float* pp = part + (int64_t)tile * nsplit * 16384 + p;
@@ -381,7 +383,8 @@ static __global__ __launch_bounds__(256) void tf_dw_reduce_kernel(const float* _
     const int w = p >> 12, c = (p >> 10) & 3, r = (p >> 8) & 3, lane = (p >> 2) & 63, e = p & 3;
     const int o = 128 * to + 64 * (w >> 1) + 4 * (4 * (lane >> 4) + r) + c;
     const int k = 128 * tk + 64 * (w & 1) + 4 * (lane & 15) + e;
-    gblob[gW + ((int64_t)((o >> 4) * nkc + (k >> 7)) * 8 + ((k >> 4) & 7)) * 256 + (((k >> 2) & 3) * 16 + (o & 15)) * 4 + (k & 3)] += s;
+    if (o < NO && k < K)
+        gblob[gW + ((int64_t)((o >> 4) * nst + (k >> 6)) * 4 + ((k >> 4) & 3)) * 256 + (((k >> 2) & 3) * 16 + (o & 15)) * 4 + (k & 3)] += s;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     float* const stat = lds + BM * 128;  // BM x (mean, rstd)
     int rt, ch;
     const int ks = a.ksplit > 1 ? blockIdx.x % a.ksplit : 0;
-    if (!tile_of_block(a.ksplit > 1 ? blockIdx.x / a.ksplit : blockIdx.x, a.row_tiles, a.NO / BN, rt, ch)) return;
+    if (!tile_of_block(a.ksplit > 1 ? blockIdx.x / a.ksplit : blockIdx.x, a.row_tiles, (a.NO + BN - 1) / BN, rt, ch)) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
     const int row0 = rt * BM;
     if (a.m_dev) {
@@ -235,7 +235,8 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     }
     const int ob = ch * BN + 32 * w;  // this wave: outputs [ob, ob + 32) as two 16-row A operands
     const blob_rsrc rs = make_blob_rsrc(a.blob, a.blob_floats);
-    const int nkc = a.K >> 7;
+    // NO is a multiple of 32: in a partial last column chunk the waves past NO only help staging
+    const bool active = ob < a.NO;
 
     if (LN) {
         ln_stats_tile<LN ? NI : 2>(a.A, a.lda, a.M, row0, a.eps, stat, tid);
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         const int o = ob + 16 * s + 4 * q;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            if (a.ksplit > 1) {
+            if (a.ksplit > 1 || !active) {
                 acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
             } else if (a.jb) {
                 const int row = min(row0 + 16 * t + pl, a.M - 1);
@@ -269,15 +270,16 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     // LayerNorm transform is applied on the way into LDS.
     const int sc4 = tid & 15, sr = tid >> 4;  // staging: 16-byte column slot (16 per 64-column step), first row
     const int nst_all = a.K >> 6;
-    const int st0 = a.ksplit > 1 ? ks * (nst_all / a.ksplit) : 0;       // K / 128 is a multiple of ksplit (host)
+    const int st0 = a.ksplit > 1 ? ks * (nst_all / a.ksplit) : 0;       // K / 64 is a multiple of ksplit (host)
     const int nst = a.ksplit > 1 ? st0 + nst_all / a.ksplit : nst_all;  // one past this workgroup's last step
     auto request = [&](f32x4 (&af)[2][4], f32x4 (&st)[4], int step) {
-        const int kc = step >> 1, half = step & 1;
+        if (active) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int64_t base = a.W + ((int64_t)((ob >> 4) + s) * nkc + kc) * 2048 + half * 1024;
+            for (int s = 0; s < 2; ++s) {
+                const int64_t base = a.W + ((int64_t)((ob >> 4) + s) * nst_all + step) * 1024;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) af[s][kt] = bload4(rs, base + kt * 256, lane * 16);
+                for (int kt = 0; kt < 4; ++kt) af[s][kt] = bload4(rs, base + kt * 256, lane * 16);
+            }
         }
         const int col = 64 * step + 4 * sc4;
         const bool seg2 = a.A2 != nullptr && 64 * step >= a.K1;  // wave-uniform
@@ -309,6 +311,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         }
         __syncthreads();  // also orders this write after every wave's reads of the same slice two steps ago
         if (step + 1 < nst) request(afn, stn, step + 1);
+        if (!active) return;
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
             const float* b0p = buf + (32 * tp + pl) * 64;
@@ -331,11 +334,13 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     {
         f32x4 afA[2][4], afB[2][4], stA[4], stB[4];
         request(afA, stA, st0);
+        int step = st0;
 #pragma unroll 1
-        for (int step = st0; step < nst; step += 2) {
+        for (; step + 1 < nst; step += 2) {
             step_fn(afA, stA, afB, stB, step);
-            step_fn(afB, stB, afA, stA, step + 1);  // K is a multiple of 128: the number of steps is even
+            step_fn(afB, stB, afA, stA, step + 1);
         }
+        if (step < nst) step_fn(afA, stA, afB, stB, step);  // odd number of 64-wide steps
     }
 
     // epilogue: lane (particle pl of tile t, q) holds 4 consecutive outputs
@@ -345,6 +350,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int row = row0 + 16 * t + pl;
+            if (!active) continue;
             if (row < a.M && a.ksplit > 1) {
                 *reinterpret_cast<f32x4*>(a.part + ((int64_t)ks * a.M + row) * a.NO + o) = acc[s][t];
             } else if (row < a.M) {

@@ -226,14 +226,14 @@ struct Bwd {
         a.gamma = ln.gamma; a.beta = ln.beta;
         a.ldz = NO; a.lda = K; a.M = p.M; a.NO = NO; a.K = K;
         a.row_tiles = (p.M + BM - 1) / BM;
-        const int tiles = (NO / 128) * (K / 128);
+        const int tiles = ((NO + 127) / 128) * ((K + 127) / 128);
         int ns = DW_MAX_PARTS / tiles;
         if (ns < 1) ns = 1;
         if (ns > a.row_tiles) ns = a.row_tiles;
         a.nsplit = ns;
         hipLaunchKernelGGL(tf_dw_kernel, dim3(tiles * ns), dim3(LT), 2 * 64 * DWS * sizeof(float), p.s, a);
         if ((rc = check_hip(hipGetLastError(), "tf_dw_kernel launch"))) return rc;
-        hipLaunchKernelGGL(tf_dw_reduce_kernel, dim3(64, tiles), dim3(256), 0, p.s, (const float*)a.part, gblob, gW, K / 128, ns);
+        hipLaunchKernelGGL(tf_dw_reduce_kernel, dim3(64, tiles), dim3(256), 0, p.s, (const float*)a.part, gblob, gW, NO, K, ns);
         return check_hip(hipGetLastError(), "tf_dw_reduce_kernel launch");
     }
     // out[M][K] = Z[M][NO] W   (gradient w.r.t. the Linear's normalised input)

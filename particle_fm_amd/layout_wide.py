@@ -2,7 +2,7 @@
 
 Same source vector as ``layout.EpicLayout`` -- ``[W_eff of every Linear (row-major) | biases | freqs | 0]`` with
 ``W_eff = g * v / ||v||`` -- and the same idea (one int64 gather map, ``blob = source[index_map]``), but every
-matrix is an fp32-MFMA GEMM operand (MFMA_AK, pfm_tf.h) zero-padded to multiples of 128, and the columns that
+matrix is an fp32-MFMA GEMM operand (MFMA_AK, pfm_tf.h) zero-padded to multiples of 64, and the columns that
 multiply per-jet vectors are regrouped to address the per-jet row ``P = [temb | cond | 0.. (128) ; g | 0.. (128) ;
 g1 (Hp)]`` and the pooled row ``Q = [mean (Hp) | sum*scale (Hp)]`` (column orders of the reference: SURVEY.md
 Appendix A; epic.py:63-81, 259-300).
@@ -73,7 +73,7 @@ class EpicWideLayout(EpicLayout):
         self.n_source = o + 1
         self._in = {name: i for name, i, _ in self.linears}
         self._out = {name: oo for name, _, oo in self.linears}
-        self.Hp = (cfg.hidden_dim + 127) // 128 * 128
+        self.Hp = (cfg.hidden_dim + 63) // 64 * 64
         self._build()
 
     # ---- helpers ------------------------------------------------------------------------------
@@ -93,13 +93,14 @@ class EpicWideLayout(EpicLayout):
 
     def _mfma_ak(self, rowsrc, NO: int, K: int) -> np.ndarray:
         """MFMA_AK order of the NO x K matrix whose element (o, k) has source index rowsrc(o, k)."""
+        assert NO % 32 == 0 and K % 64 == 0, (NO, K)
         ob = np.arange(NO // 16)[:, None, None, None, None]
-        kc = np.arange(K // 128)[None, :, None, None, None]
-        kt = np.arange(8)[None, None, :, None, None]
+        st = np.arange(K // 64)[None, :, None, None, None]  # 64-wide k steps (two per 128-wide chunk of pfm_tf.h)
+        kt = np.arange(4)[None, None, :, None, None]
         lane = np.arange(64)[None, None, None, :, None]
         r = np.arange(4)[None, None, None, None, :]
-        o = 16 * ob + (lane & 15) + 0 * (kc + kt + r)
-        k = 128 * kc + 16 * kt + 4 * (lane >> 4) + r + 0 * ob
+        o = 16 * ob + (lane & 15) + 0 * (st + kt + r)
+        k = 64 * st + 16 * kt + 4 * (lane >> 4) + r + 0 * ob
         return rowsrc(o, k)
 
     def _lin(self, blocks: Sequence, NO: int, K: int, bias_rows: Sequence) -> EwLin:

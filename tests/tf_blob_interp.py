@@ -10,13 +10,13 @@ import torch.nn.functional as F
 
 def mfma_ak(blob, off, NO, K):
     """inverse of the MFMA_AK packing -> W [NO][K]"""
-    nkc = K // 128
+    nst = K // 64  # 64-wide k steps; two consecutive steps are one 128-wide chunk of the header's description
     n = NO * K
-    a = blob[off:off + n].reshape(NO // 16, nkc, 8, 64, 4)
+    a = blob[off:off + n].reshape(NO // 16, nst, 4, 64, 4)
     W = torch.empty(NO, K)
-    ob, kc, kt, lane, r = np.meshgrid(np.arange(NO // 16), np.arange(nkc), np.arange(8), np.arange(64), np.arange(4),
+    ob, st, kt, lane, r = np.meshgrid(np.arange(NO // 16), np.arange(nst), np.arange(4), np.arange(64), np.arange(4),
                                       indexing="ij")
-    W[16 * ob + (lane & 15), 128 * kc + 16 * kt + 4 * (lane >> 4) + r] = a
+    W[16 * ob + (lane & 15), 64 * st + 16 * kt + 4 * (lane >> 4) + r] = a
     return W
 
 
