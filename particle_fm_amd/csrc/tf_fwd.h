@@ -175,12 +175,12 @@ struct LinArgs {
 };
 
 // row statistics of a BM-row tile: 16 lanes per row, two-pass (mean, then centred sum of squares)
-template <int NI>
+template <int NI, int ROWS>
 __device__ __forceinline__ void ln_stats_tile(const float* __restrict__ A, int lda, int M, int row0, float eps,
                                               float* __restrict__ stat, int tid) {
     constexpr int K = 64 * NI;
     const int lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
-    constexpr int RPW = BM / (LT / 64);  // rows per wave
+    constexpr int RPW = ROWS / (LT / 64);  // rows per wave
 #pragma unroll 1
     for (int pass = 0; pass < RPW / 4; ++pass) {
         const int r = RPW * w + 4 * pass + q;
@@ -217,18 +217,20 @@ __device__ __forceinline__ bool tile_of_block(int bid, int row_tiles, int nchunk
     return rt < row_tiles;
 }
 
-// NI = K / 64 of the LayerNorm prologue (0: no LayerNorm)
-template <int NI>
+// NI = K / 64 of the LayerNorm prologue (0: no LayerNorm); TPW = 16-row tiles per wave: the workgroup's row tile is
+// RB = 16 TPW rows (64, or 32 when 64-row tiles would leave the last round of workgroups mostly empty)
+template <int NI, int TPW = 4>
 __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     constexpr bool LN = NI > 0;
+    constexpr int RB = 16 * TPW, SI = RB / 16;  // SI: float4 staged per thread and 64-wide step
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* const tile = lds;             // two BM x 64 slices, 16-byte slots XOR-swizzled with (row & 15)
-    float* const stat = lds + BM * 128;  // BM x (mean, rstd)
+    float* const tile = lds;             // two RB x 64 slices, 16-byte slots XOR-swizzled with (row & 15)
+    float* const stat = lds + RB * 128;  // RB x (mean, rstd)
     int rt, ch;
     const int ks = a.ksplit > 1 ? blockIdx.x % a.ksplit : 0;
     if (!tile_of_block(a.ksplit > 1 ? blockIdx.x / a.ksplit : blockIdx.x, a.row_tiles, (a.NO + BN - 1) / BN, rt, ch)) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
-    const int row0 = rt * BM;
+    const int row0 = rt * RB;
     if (a.m_dev) {
         a.M = *a.m_dev;
         if (row0 >= a.M) return;
@@ -239,17 +241,17 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     const bool active = ob < a.NO;
 
     if (LN) {
-        ln_stats_tile<LN ? NI : 2>(a.A, a.lda, a.M, row0, a.eps, stat, tid);
+        ln_stats_tile<LN ? NI : 2, RB>(a.A, a.lda, a.M, row0, a.eps, stat, tid);
         __syncthreads();
     }
 
     // accumulators start from the bias (+ the jet-bias row of the particle's jet)
-    f32x4 acc[2][4];
+    f32x4 acc[2][TPW];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int o = ob + 16 * s + 4 * q;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < TPW; ++t) {
             if (a.ksplit > 1 || !active) {
                 acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
             } else if (a.jb) {
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     const int nst_all = a.K >> 6;
     const int st0 = a.ksplit > 1 ? ks * (nst_all / a.ksplit) : 0;       // K / 64 is a multiple of ksplit (host)
     const int nst = a.ksplit > 1 ? st0 + nst_all / a.ksplit : nst_all;  // one past this workgroup's last step
-    auto request = [&](f32x4 (&af)[2][4], f32x4 (&st)[4], int step) {
+    auto request = [&](f32x4 (&af)[2][4], f32x4 (&st)[SI], int step) {
         if (active) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -286,26 +288,26 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         const float* src = seg2 ? a.A2 + (col - a.K1) : a.A + col;
         const int ld = seg2 ? a.lda2 : a.lda;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < SI; ++i) {
             const int row = min(row0 + sr + 16 * i, a.M - 1);
             st[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)row * ld);
         }
     };
-    auto step_fn = [&](f32x4 (&af)[2][4], f32x4 (&st)[4], f32x4 (&afn)[2][4], f32x4 (&stn)[4], int step) {
-        float* const buf = tile + (step & 1) * (BM * 64);
+    auto step_fn = [&](f32x4 (&af)[2][4], f32x4 (&st)[SI], f32x4 (&afn)[2][4], f32x4 (&stn)[SI], int step) {
+        float* const buf = tile + (step & 1) * (RB * 64);
         if (LN) {
             const int col = 64 * step + 4 * sc4;
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + col);
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + col);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < SI; ++i) {
                 const int r = sr + 16 * i;
                 const float mean = stat[2 * r], rstd = stat[2 * r + 1];
                 st[i] = (st[i] - mean) * rstd * g4 + b4;
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < SI; ++i) {
             const int r = sr + 16 * i;
             *reinterpret_cast<f32x4*>(buf + r * 64 + ((sc4 ^ (r & 15)) << 2)) = st[i];
         }
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         if (step + 1 < nst) request(afn, stn, step + 1);
         if (!active) return;
 #pragma unroll
-        for (int tp = 0; tp < 2; ++tp) {
+        for (int tp = 0; tp < TPW / 2; ++tp) {
             const float* b0p = buf + (32 * tp + pl) * 64;
             const float* b1p = b0p + 16 * 64;
 #pragma unroll
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         }
     };
     {
-        f32x4 afA[2][4], afB[2][4], stA[4], stB[4];
+        f32x4 afA[2][4], afB[2][4], stA[SI], stB[SI];
         request(afA, stA, st0);
         int step = st0;
 #pragma unroll 1
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     for (int s = 0; s < 2; ++s) {
         const int o = ob + 16 * s + 4 * q;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < TPW; ++t) {
             const int row = row0 + 16 * t + pl;
             if (!active) continue;
             if (row < a.M && a.ksplit > 1) {
@@ -398,16 +400,34 @@ static __global__ __launch_bounds__(256) void tf_splitk_kernel(LinArgs a) {
 constexpr int KROW = 20;  // floats per K row in LDS (16 + 4 pad: conflict-free ds_read_b128 of the A operand)
 
 __host__ __device__ inline int attn_np16(int N) { return (N + 15) & ~15; }
+__host__ __device__ inline int attn_np32(int N) { return (N + 31) & ~31; }  // the forward walks key tiles in pairs
 __host__ __device__ inline int attn_lds_floats(int N) {
-    const int np = attn_np16(N);
+    const int np = attn_np32(N);
     return np * KROW + HD * (np + 4) + np;
 }
+
+#define PFM_MFMA4(acc, A, B)                                          \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A.x, B.x, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A.y, B.y, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A.z, B.z, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A.w, B.w, acc, 0, 0, 0);
+// two independent accumulator chains, alternated instruction by instruction (a dependent MFMA stalls the pipe)
+#define PFM_MFMA4x2(acc0, A0, B0, acc1, A1, B1)                          \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0.x, B0.x, acc0, 0, 0, 0); \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1.x, B1.x, acc1, 0, 0, 0); \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0.y, B0.y, acc0, 0, 0, 0); \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1.y, B1.y, acc1, 0, 0, 0); \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0.z, B0.z, acc0, 0, 0, 0); \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1.z, B1.z, acc1, 0, 0, 0); \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0.w, B0.w, acc0, 0, 0, 0); \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1.w, B1.w, acc1, 0, 0, 0);
 
 template <int MAXKT>
 __global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
                                                          float* __restrict__ out, int N, int D, int heads) {
+    static_assert(MAXKT % 2 == 0, "key tiles are processed in pairs");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int np = attn_np16(N), nkt = np >> 4, npv = np + 4;
+    const int np = attn_np32(N), nkt = np >> 4, npv = np + 4, nqt = attn_np16(N) >> 4;
     float* const Ks = lds;              // [np][KROW]
     float* const Vt = Ks + np * KROW;   // [HD][npv]
     float* const mb = Vt + HD * npv;    // [np]: 0 for a valid key, -inf for a padded one
@@ -435,37 +455,43 @@ __global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict
     }
     __syncthreads();
 
-    for (int qt = w; qt < nkt; qt += 4) {
+    for (int qt = w; qt < nqt; qt += 4) {
         const int qrow = min(qt * 16 + pl, N - 1);
         f32x4 Qf = *reinterpret_cast<const f32x4*>(base + (int64_t)qrow * ld + 4 * q);
         Qf *= 0.25f;  // 1/sqrt(16), exact
         f32x4 s[MAXKT];
-        // S^T tile kt: rows = keys 16kt + 4q + r, column = query pl
+        // S^T tiles kt, kt+1: rows = keys 16kt + 4q + r, column = query pl
 #pragma unroll
-        for (int kt = 0; kt < MAXKT; ++kt) {
+        for (int kt = 0; kt < MAXKT; kt += 2) {
             if (kt < nkt) {
-                const f32x4 Kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + pl) * KROW + 4 * q);
-                f32x4 c = *reinterpret_cast<const f32x4*>(mb + 16 * kt + 4 * q);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(Kf.x, Qf.x, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(Kf.y, Qf.y, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(Kf.z, Qf.z, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(Kf.w, Qf.w, c, 0, 0, 0);
-                s[kt] = c;
+                const f32x4 K0 = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + pl) * KROW + 4 * q);
+                const f32x4 K1 = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + 16 + pl) * KROW + 4 * q);
+                f32x4 c0 = *reinterpret_cast<const f32x4*>(mb + 16 * kt + 4 * q);
+                f32x4 c1 = *reinterpret_cast<const f32x4*>(mb + 16 * kt + 16 + 4 * q);
+                PFM_MFMA4x2(c0, K0, Qf, c1, K1, Qf)
+                s[kt] = c0;
+                s[kt + 1] = c1;
             }
         }
         float m = -__builtin_inff();
 #pragma unroll
-        for (int kt = 0; kt < MAXKT; ++kt)
-            if (kt < nkt) m = fmaxf(fmaxf(fmaxf(s[kt].x, s[kt].y), fmaxf(s[kt].z, s[kt].w)), m);
+        for (int kt = 0; kt < MAXKT; kt += 2)
+            if (kt < nkt) {
+                m = fmaxf(fmaxf(fmaxf(s[kt].x, s[kt].y), fmaxf(s[kt].z, s[kt].w)), m);
+                m = fmaxf(fmaxf(fmaxf(s[kt + 1].x, s[kt + 1].y), fmaxf(s[kt + 1].z, s[kt + 1].w)), m);
+            }
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
         float l = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < MAXKT; ++kt)
+        for (int kt = 0; kt < MAXKT; kt += 2)
             if (kt < nkt) {
-                s[kt].x = __expf(s[kt].x - m); s[kt].y = __expf(s[kt].y - m);
-                s[kt].z = __expf(s[kt].z - m); s[kt].w = __expf(s[kt].w - m);
-                l += hsum4(s[kt]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    s[kt + e].x = __expf(s[kt + e].x - m); s[kt + e].y = __expf(s[kt + e].y - m);
+                    s[kt + e].z = __expf(s[kt + e].z - m); s[kt + e].w = __expf(s[kt + e].w - m);
+                    l += hsum4(s[kt + e]);
+                }
             }
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
@@ -473,21 +499,12 @@ __global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict
         // O^T = V^T P^T: A = Vt rows (d = pl) x keys, B = this lane's own P values
         f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < MAXKT; ++kt) {
+        for (int kt = 0; kt < MAXKT; kt += 2) {
             if (kt < nkt) {
-                const f32x4 Vf = *reinterpret_cast<const f32x4*>(Vt + pl * npv + 16 * kt + 4 * q);
-                const f32x4 p = s[kt] * inv;
-                if (kt & 1) {
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.x, p.x, o1, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.y, p.y, o1, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.z, p.z, o1, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.w, p.w, o1, 0, 0, 0);
-                } else {
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.x, p.x, o0, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.y, p.y, o0, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.z, p.z, o0, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vf.w, p.w, o0, 0, 0, 0);
-                }
+                const f32x4 V0 = *reinterpret_cast<const f32x4*>(Vt + pl * npv + 16 * kt + 4 * q);
+                const f32x4 V1 = *reinterpret_cast<const f32x4*>(Vt + pl * npv + 16 * kt + 16 + 4 * q);
+                const f32x4 p0 = s[kt] * inv, p1 = s[kt + 1] * inv;
+                PFM_MFMA4x2(o0, V0, p0, o1, V1, p1)
             }
         }
         const int orow = qt * 16 + pl;

@@ -32,6 +32,17 @@ int validate(const pfm_tf_desc* d) {
     return 0;
 }
 
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 struct Plan {
     const pfm_tf_desc* d;
     const float* blob;
@@ -49,28 +60,37 @@ int launch_linear(const Plan& p, const float* A, int lda, int K, const pfm_tf_li
     a.gamma = ln ? ln->gamma : -1; a.beta = ln ? ln->beta : -1;
     a.jb_stride = (int64_t)(p.d->layers + 2) * p.d->hidden;
     a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.M = p.M; a.K = K; a.NO = NO; a.N = p.d->n_points; a.act = act ? 1 : 0;
-    a.row_tiles = (p.M + BM - 1) / BM;
     a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
-    const int grid = ((a.row_tiles + 7) / 8) * 8 * (NO / BN);
-    const size_t lds = (BM * 128 + 2 * BM) * sizeof(float);
-    if (ln && ln->gamma >= 0) {
-        switch (K / 64) {
-            case 2: hipLaunchKernelGGL(tf_linear_kernel<2>, dim3(grid), dim3(LT), lds, p.s, a); break;
-            case 4: hipLaunchKernelGGL(tf_linear_kernel<4>, dim3(grid), dim3(LT), lds, p.s, a); break;
-            case 6: hipLaunchKernelGGL(tf_linear_kernel<6>, dim3(grid), dim3(LT), lds, p.s, a); break;
-            case 8: hipLaunchKernelGGL(tf_linear_kernel<8>, dim3(grid), dim3(LT), lds, p.s, a); break;
-            default: return set_err(PFM_E_BADARG, "LayerNorm width must be 128, 256, 384 or 512");
-        }
-    } else {
-        hipLaunchKernelGGL(tf_linear_kernel<0>, dim3(grid), dim3(LT), lds, p.s, a);
+    // Row tile: 64 rows, or 32 when that shortens the schedule on this GPU's 2 x CU workgroup slots (a launch of
+    // 1120 64-row workgroups needs 3 rounds of 512 for 2.2 rounds of work; 2240 half-size ones need 2.5 round-times)
+    const int chunks = NO / BN;
+    const int64_t slots = 2 * (int64_t)num_cus();
+    const int64_t w64 = (int64_t)((p.M + 63) / 64) * chunks, w32 = (int64_t)((p.M + 31) / 32) * chunks;
+    const bool half = ((w32 + slots - 1) / slots) < 2 * ((w64 + slots - 1) / slots);
+    const int rb = half ? 32 : 64;
+    a.row_tiles = (p.M + rb - 1) / rb;
+    const int grid = ((a.row_tiles + 7) / 8) * 8 * chunks;
+    const size_t lds = (rb * 128 + 2 * rb) * sizeof(float);
+    const int ni = (ln && ln->gamma >= 0) ? K / 64 : 0;
+#define PFM_LAUNCH_LIN(NI)                                                                          \
+    if (half) hipLaunchKernelGGL((tf_linear_kernel<NI, 2>), dim3(grid), dim3(LT), lds, p.s, a);     \
+    else hipLaunchKernelGGL((tf_linear_kernel<NI, 4>), dim3(grid), dim3(LT), lds, p.s, a);
+    switch (ni) {
+        case 0: PFM_LAUNCH_LIN(0) break;
+        case 2: PFM_LAUNCH_LIN(2) break;
+        case 4: PFM_LAUNCH_LIN(4) break;
+        case 6: PFM_LAUNCH_LIN(6) break;
+        case 8: PFM_LAUNCH_LIN(8) break;
+        default: return set_err(PFM_E_BADARG, "LayerNorm width must be 128, 256, 384 or 512");
     }
+#undef PFM_LAUNCH_LIN
     return check_hip(hipGetLastError(), "tf_linear_kernel launch");
 }
 
 int launch_attn(const Plan& p, const float* qkv, const float* mask, float* out) {
     const int N = p.d->n_points, D = p.d->model_dim, heads = p.d->heads;
     const size_t lds = (size_t)attn_lds_floats(N) * sizeof(float);
-    const int nkt = attn_np16(N) / 16;
+    const int nkt = attn_np32(N) / 16;
     const dim3 grid(p.n_jets * heads), block(256);
     if (nkt <= 12)
         hipLaunchKernelGGL(tf_attn_kernel<12>, grid, block, lds, p.s, qkv, mask, out, N, D, heads);
