@@ -441,8 +441,8 @@ struct Bwd {
                int64_t gb) const {
         ColsumArgs a;
         a.Z = Z; a.X = X; a.jet_out = jet_out; a.gblob = gblob; a.gb = gb; a.jet_stride = jet_stride;
-        a.ldz = ldz; a.NO = NO; a.N = group; a.F = X ? 16 : 1;
-        hipLaunchKernelGGL(tf_colsum_kernel, dim3((unsigned)(rows / group), X ? F : 1, (NO + 767) / 768), dim3(256), 0, p.s, a);
+        a.ldz = ldz; a.NO = NO; a.N = group; a.F = X ? 16 : 1; a.rows = rows;
+        hipLaunchKernelGGL(tf_colsum_kernel, dim3((unsigned)((rows + group - 1) / group), X ? F : 1, (NO + 767) / 768), dim3(256), 0, p.s, a);
         return check_hip(hipGetLastError(), "tf_colsum_kernel launch (epicw)");
     }
     // gblob[W] += Z^T [A | A2]
@@ -521,17 +521,17 @@ int run_backward(const Bwd& W, const float* mask, const float* y, const float* u
         PFM_TRY(W.dx(M, dT, Hp, Hp, L.l1, Hp, dZ, Hp, nullptr, 0, dX, Hp));                                   // dX_l = dZ2 + dZ1 W1
         // jet-bias GEMM
         PFM_TRY(W.dw(B, DJB, 2 * Hp, 2 * Hp, Pout, ldp, 256, nullptr, 0, 256, L.jb.W));
-        PFM_TRY(W.colsum(DJB, 2 * Hp, 2 * Hp, B, B, nullptr, 0, nullptr, 0, L.jb.b));
+        PFM_TRY(W.colsum(DJB, 2 * Hp, 2 * Hp, B, 16, nullptr, 0, nullptr, 0, L.jb.b));
         PFM_TRY(W.dx(B, DJB, 2 * Hp, 2 * Hp, L.jb, 256, nullptr, 0, nullptr, 0, dPj, 256));
         // fc_global2: g_new = lrelu(W [P | g1] + b + g_old)
         PFM_TRY(W.actbwd(dG, 128, dPj + 128, 256, Pout + 128, ldp, dZg2, 128, B, 128));
         PFM_TRY(W.dw(B, dZg2, 128, 128, Pout, ldp, ldp, nullptr, 0, ldp, L.g2.W));
-        PFM_TRY(W.colsum(dZg2, 128, 128, B, B, nullptr, 0, nullptr, 0, L.g2.b));
+        PFM_TRY(W.colsum(dZg2, 128, 128, B, 16, nullptr, 0, nullptr, 0, L.g2.b));
         PFM_TRY(W.dx(B, dZg2, 128, 128, L.g2, ldp, nullptr, 0, nullptr, 0, dP2, ldp));
         // fc_global1: g1 = lrelu(W [P256 | Q] + b)
         PFM_TRY(W.actbwd(dP2 + 256, ldp, nullptr, 0, Pout + 256, ldp, dZg1, Hp, B, Hp));
         PFM_TRY(W.dw(B, dZg1, Hp, Hp, Pin, ldp, 256, Qst(l), 2 * Hp, 256 + 2 * Hp, L.g1.W));
-        PFM_TRY(W.colsum(dZg1, Hp, Hp, B, B, nullptr, 0, nullptr, 0, L.g1.b));
+        PFM_TRY(W.colsum(dZg1, Hp, Hp, B, 16, nullptr, 0, nullptr, 0, L.g1.b));
         PFM_TRY(W.dx(B, dZg1, Hp, Hp, L.g1, 256 + 2 * Hp, nullptr, 0, nullptr, 0, dP1, 256 + 2 * Hp));
         PFM_TRY(W.actbwd(dZg2, 128, dP1 + 128, 256 + 2 * Hp, nullptr, 0, dG, 128, B, 128));                   // d g_old
         hipLaunchKernelGGL(ew_pool_bwd_kernel, dim3(B), dim3(256), 0, p.s, (const float*)(dP1 + 256), 256 + 2 * Hp, mask, dX, N, Hp,
@@ -543,11 +543,11 @@ int run_backward(const Bwd& W, const float* mask, const float* y, const float* u
         const float* P0 = Pst(0);
         PFM_TRY(W.actbwd(dG, 128, nullptr, 0, P0 + 128, ldp, dZg2, 128, B, 128));
         PFM_TRY(W.dw(B, dZg2, 128, 128, P0, ldp, ldp, nullptr, 0, ldp, d.sg2.W));
-        PFM_TRY(W.colsum(dZg2, 128, 128, B, B, nullptr, 0, nullptr, 0, d.sg2.b));
+        PFM_TRY(W.colsum(dZg2, 128, 128, B, 16, nullptr, 0, nullptr, 0, d.sg2.b));
         PFM_TRY(W.dx(B, dZg2, 128, 128, d.sg2, ldp, nullptr, 0, nullptr, 0, dP2, ldp));
         PFM_TRY(W.actbwd(dP2 + 256, ldp, nullptr, 0, P0 + 256, ldp, dZg1, Hp, B, Hp));
         PFM_TRY(W.dw(B, dZg1, Hp, Hp, P0, ldp, 256, Qst(0), 2 * Hp, 256 + 2 * Hp, d.sg1.W));
-        PFM_TRY(W.colsum(dZg1, Hp, Hp, B, B, nullptr, 0, nullptr, 0, d.sg1.b));
+        PFM_TRY(W.colsum(dZg1, Hp, Hp, B, 16, nullptr, 0, nullptr, 0, d.sg1.b));
         PFM_TRY(W.dx(B, dZg1, Hp, Hp, d.sg1, 256 + 2 * Hp, nullptr, 0, nullptr, 0, dP1, 256 + 2 * Hp));
         hipLaunchKernelGGL(ew_pool_bwd_kernel, dim3(B), dim3(256), 0, p.s, (const float*)(dP1 + 256), 256 + 2 * Hp, mask, dX, N, Hp,
                            d.sum_scale);
@@ -561,13 +561,13 @@ int run_backward(const Bwd& W, const float* mask, const float* y, const float* u
     PFM_TRY(W.colsum(dT, Hp, Hp, M, N, nullptr, 0, DSJB, sjbs, -1));
     {
         ColsumArgs a;  // d fc_l1 particle columns [F][Hp] = sum_rows y[row][f] dZ1[row][:]
-        a.Z = dT; a.X = y; a.jet_out = nullptr; a.gblob = W.gblob; a.gb = d.l1x; a.jet_stride = 0; a.ldz = Hp; a.NO = Hp; a.N = N; a.F = F;
+        a.Z = dT; a.X = y; a.jet_out = nullptr; a.gblob = W.gblob; a.gb = d.l1x; a.jet_stride = 0; a.ldz = Hp; a.NO = Hp; a.N = N; a.F = F; a.rows = 0;
         hipLaunchKernelGGL(tf_colsum_kernel, dim3(B, F, 1), dim3(256), 0, p.s, a);
         PFM_TRY(check_hip(hipGetLastError(), "tf_colsum_kernel launch (fc_l1)"));
     }
     // static jet-bias GEMM (the 112 padding columns of the fc_l3 block of DSJB were never written: clear them first)
     PFM_TRY(W.dw(B, DSJB, (int)sjbs, 2 * Hp + 128, Pst(0), ldp, 256, nullptr, 0, 256, d.sjb.W));
-    PFM_TRY(W.colsum(DSJB, (int)sjbs, 2 * Hp + 128, B, B, nullptr, 0, nullptr, 0, d.sjb.b));
+    PFM_TRY(W.colsum(DSJB, (int)sjbs, 2 * Hp + 128, B, 16, nullptr, 0, nullptr, 0, d.sjb.b));
     return 0;
 }
 

@@ -250,6 +250,7 @@ struct ColsumArgs {
     int64_t gb;         // gblob offset of an [F or 1][NO] block receiving the sum over all jets (atomic), or -1
     int64_t jet_stride;
     int ldz, NO, N, F;
+    int64_t rows;       // total rows of Z (the last group may be short); 0: every group has N rows
 };
 
 static __global__ __launch_bounds__(256) void tf_colsum_kernel(ColsumArgs a) {
@@ -261,7 +262,8 @@ static __global__ __launch_bounds__(256) void tf_colsum_kernel(ColsumArgs a) {
     f32x4 acc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int r = rg; r < a.N; r += 4) {
+    const int nrows = a.rows ? (int)min((int64_t)a.N, a.rows - (int64_t)jet * a.N) : a.N;
+    for (int r = rg; r < nrows; r += 4) {
         const int64_t row = (int64_t)jet * a.N + r;
         const float w = a.X ? a.X[row * a.F + f] : 1.0f;
 #pragma unroll

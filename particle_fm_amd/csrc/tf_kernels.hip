@@ -222,7 +222,7 @@ struct Bwd {
         ColsumArgs a;
         a.Z = Z; a.X = X; a.jet_out = jet_out; a.gblob = gblob; a.gb = gb;
         a.jet_stride = (int64_t)(p.d->layers + 2) * p.d->hidden;
-        a.ldz = ldz; a.NO = NO; a.N = p.d->n_points; a.F = F;
+        a.ldz = ldz; a.NO = NO; a.N = p.d->n_points; a.F = F; a.rows = 0;
         hipLaunchKernelGGL(tf_colsum_kernel, dim3(p.n_jets, X ? F : 1, (NO + 767) / 768), dim3(256), 0, p.s, a);
         return check_hip(hipGetLastError(), "tf_colsum_kernel launch");
     }
