@@ -84,6 +84,20 @@ __device__ __forceinline__ void load_afrag(f32x4 (&a)[8], blob_rsrc rs, int64_t 
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).w, (bv0).w, acc0, 0, 0, 0);      \
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).w, (bv1).w, acc1, 0, 0, 0);
 
+// bf16 operands for v_mfma_f32_16x16x16_bf16 (PFM_F_BF16_MFMA): the fp32 float4 a lane already holds -- four
+// consecutive k of one row / column -- is exactly that instruction's operand after rounding, so one MFMA replaces four.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// (plain vector conversion, not inline asm: the compiler must see the VALU write to insert the MFMA read hazard nop)
+__device__ __forceinline__ s16x4 pack_bf16(f32x4 v) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};  // one v_cvt_pk_bf16_f32 each (round-to-nearest-even, gfx950)
+    const u32x2 u = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)),
+                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2))};
+    return __builtin_bit_cast(s16x4, u);
+}
+
 template <bool SAVE>
 __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float* __restrict__ lds, const Carve& c,
                                             int oslot, int pl, float* __restrict__ save_pool);
@@ -98,7 +112,7 @@ __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float*
 // Rows are NOT clamped: tiles may run up to 31 rows past n_rows / N (the carve keeps that window inside LDS);
 // such rows only produce garbage in their own output columns, which are never stored or pooled.
 // POOL: masked column sums -> vin (mean | sum*scale).  SAVE: rows also go to `save` (global).
-template <bool RESID, bool POOL, bool SAVE>
+template <bool RESID, bool POOL, bool SAVE, bool BF16 = false>
 __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __restrict__ src,
                                            float* __restrict__ dst, const float* __restrict__ resid,
                                            const float* __restrict__ bj, const float* __restrict__ maskf,
@@ -127,8 +141,20 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
         B0[kk] = *reinterpret_cast<const f32x4*>((base) + koff[2 * (qq) + kk]);            \
         B1[kk] = *reinterpret_cast<const f32x4*>((base) + TILE * H + koff[2 * (qq) + kk]); \
     }
-#define PFM_MFMAQ(B0, B1, qq)                                                              \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) { PFM_MFMA_PAIR(acc0, acc1, a[2 * (qq) + kk], B0[kk], B1[kk]); }
+    s16x4 ab[8];
+    if (BF16) {
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) ab[kt] = pack_bf16(a[kt]);
+    }
+#define PFM_MFMAQ(B0, B1, qq)                                                                                  \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                        \
+        if (BF16) {                                                                                            \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[2 * (qq) + kk], pack_bf16(B0[kk]), acc0, 0, 0, 0); \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[2 * (qq) + kk], pack_bf16(B1[kk]), acc1, 0, 0, 0); \
+        } else {                                                                                               \
+            PFM_MFMA_PAIR(acc0, acc1, a[2 * (qq) + kk], B0[kk], B1[kk]);                                        \
+        }                                                                                                      \
+    }
     PFM_LOADQ(X0, X1, src, 0);
     if (RESID) {
         r0 = *reinterpret_cast<const f32x4*>(resid + ooff);
@@ -434,7 +460,7 @@ __device__ __forceinline__ void stem_l1(const pfm_epic_desc& d, const JetDims& j
 
 // Full network body up to (excluding) the fc_l3 head.  Preconditions (in LDS): yin (N x F input),
 // maskf, misc[0] = sum(mask), vin.temb, vin.cond.  Postcondition: bufB holds the last hidden state.
-template <bool SAVE>
+template <bool SAVE, bool BF16 = false>
 __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims& j,
                                           const float* __restrict__ blob, float* __restrict__ lds,
                                           const Carve& c, int n_rows, float* __restrict__ saved,
@@ -470,7 +496,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     // ---- fc_l2: bufB = lrelu(W.bufA + bj2 + bufA)  epic.py:364-366 (residual from the source buffer)
     prefetch_gl1(gw, rs, d.g1, K1s);
     if (j.layers > 0) load_afrag(a1, rs, d.layer[0].lc1.A, w, lane);  // first layer's phase-1 weights: in flight across fc_l2
-    gemm_phase<true, true, SAVE>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, saved + sl.x2, saved + sl.pool, n_rows);
+    gemm_phase<true, true, SAVE, BF16>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, saved + sl.x2, saved + sl.pool, n_rows);
     __syncthreads();
     PFM_STAMP(4);
     // ---- fc_g1 / fc_g2 (epic.py:369-380) ---------------------------------------------------------
@@ -490,7 +516,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
         PFM_STAMP(12);
         load_afrag(a2, rs, ly.lc2.A, w, lane);  // lands behind phase 1's MFMAs
         // phase 1: bufA = lrelu(W1 . bufB + bj1)                       epic.py:194-196
-        gemm_phase<false, false, SAVE>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, saved + sl.l1 + k * sl.lstride,
+        gemm_phase<false, false, SAVE, BF16>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, saved + sl.l1 + k * sl.lstride,
                                        nullptr, n_rows);
         __syncthreads();
         PFM_STAMP(13);
@@ -499,7 +525,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
             load_afrag(a1, rs, d.layer[k + 1].lc1.A, w, lane);  // next layer's phase-1 weights, in flight across phase 2
         }
         // phase 2: bufB = lrelu(W2 . bufA + bj2 + bufB), pooled -> vin    epic.py:198-200, :160-162
-        gemm_phase<true, true, SAVE>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, saved + sl.xo + k * sl.lstride,
+        gemm_phase<true, true, SAVE, BF16>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, saved + sl.xo + k * sl.lstride,
                                      saved + sl.pool + (k + 1) * sl.pstride, n_rows);
         __syncthreads();
     }

@@ -27,6 +27,7 @@ PFM_ABI_VERSION = 1
 PFM_MAX_LAYERS = 24
 PFM_HIDDEN = 128
 PFM_F_SKIP_MASKED_TAIL = 1
+PFM_F_BF16_MFMA = 2
 
 
 class LocalLin(ctypes.Structure):

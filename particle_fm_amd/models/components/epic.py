@@ -103,6 +103,10 @@ class EPiC_encoder(nn.Module):
         # the multi-kernel GEMM path over all particles (pfm_epicw.h).
         self.wide = hid_d != PFM_HIDDEN
         self.skip_masked_tail = True
+        # "bf16": the inference kernels of the jet-resident path (forward, midpoint sampler) run the particle Linears on
+        # bf16 MFMA with fp32 accumulate and fp32 activations (PFM_F_BF16_MFMA) -- what trainer.precision="bf16-mixed"
+        # means for this model in the reference.  Training kernels and the wide path stay fp32.
+        self.mfma_dtype = "fp32"
         self._fast_pack = None  # set by engine.FusedFMTrainer: one-launch weight-norm pack from the flat buffer
 
     # -- layout / weights ------------------------------------------------------------------------
@@ -115,11 +119,17 @@ class EPiC_encoder(nn.Module):
 
     def layout(self, num_points: Optional[int] = None) -> EpicLayout:
         n = num_points or self.num_points
-        lay = self._layouts.get(n)
+        bf = self.mfma_dtype == "bf16" and not self.wide
+        lay = self._layouts.get((n, bf))
         if lay is None:
-            lay = EpicWideLayout(self.config(n)) if self.wide else EpicLayout(self.config(n), flags=1 if self.skip_masked_tail else 0)
-            self._layouts[n] = lay
+            flags = (1 if self.skip_masked_tail else 0) | (2 if bf else 0)
+            lay = EpicWideLayout(self.config(n)) if self.wide else EpicLayout(self.config(n), flags=flags)
+            self._layouts[(n, bf)] = lay
         return lay
+
+    def set_precision(self, precision) -> None:
+        """Accepts Lightning's spellings: "bf16", "bf16-mixed", "bf16-true" -> bf16 MFMA for inference; anything else fp32."""
+        self.mfma_dtype = "bf16" if str(precision).startswith("bf16") else "fp32"
 
     def source_vector(self, layout: Optional[EpicLayout] = None) -> torch.Tensor:
         """effective weights | biases | freqs | 0 from the live parameters (differentiable)."""

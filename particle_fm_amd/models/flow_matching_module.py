@@ -255,6 +255,11 @@ class SetFlowMatchingLitModule(_LitBase):
     def sample(self, n_samples: int, cond: torch.Tensor = None, mask: torch.Tensor = None,
                ode_solver: str = "midpoint", ode_steps: int = 100, num_points: int = None):
         """flow_matching_module.py:637-677: z ~ N(0,1) drawn on the CPU generator, masked, integrated 1 -> 0."""
+        prec = getattr(getattr(self, "trainer", None), "precision", None)
+        if prec is not None:  # trainer.precision = "bf16-mixed" -> bf16 MFMA in the sampler (EPiC jet-resident path)
+            for f in self.flows:
+                if hasattr(f.net, "set_precision"):
+                    f.net.set_precision(prec)
         z = torch.randn(n_samples, num_points if num_points else self.hparams.num_particles,
                         self.hparams.features).to(self.device)
         if cond is not None:

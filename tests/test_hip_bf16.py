@@ -1,0 +1,75 @@
+"""PFM_F_BF16_MFMA: the jet-resident inference kernels with bf16 matrix operands (BASELINE cfg 2: "EPiC-FM JetNet30 bf16").
+
+There is no bit-level reference for reduced precision; the bar is the reference's own bf16 path: the oracle (eager
+PyTorch, the reference graph) under torch.autocast(bfloat16) against the same oracle in fp32.  The HIP kernel keeps
+activations and accumulation in fp32 and only rounds the MFMA operands, so it must not be further from the fp32 result
+than autocast is."""
+import pytest
+import torch
+
+from oracle.fm_ref import EpicVectorField, sample_midpoint
+from tests.test_layout_cpu import cfg_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["jetnet30", "jetnet150", "cond_gl"])
+def test_bf16_forward_within_the_reference_bf16_error(name):
+    from particle_fm_amd import hip_ops
+    from particle_fm_amd.layout import EpicLayout
+    from tests.conftest import load_golden
+    g = load_golden(name)
+    lay = EpicLayout(cfg_of(g.hp), flags=1 | 2)
+    lay32 = EpicLayout(cfg_of(g.hp), flags=1)
+    blob = lay.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    blob32 = lay32.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    tag = "nfe_f32/"
+    x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))
+    ref = g.get(tag + "v_vec_t")
+    dev = lambda a: None if a is None else a.cuda()
+    v16 = hip_ops.epic_forward(lay, blob, dev(t), dev(x), dev(cond), dev(mask)).cpu()
+    v32 = hip_ops.epic_forward(lay32, blob32, dev(t), dev(x), dev(cond), dev(mask)).cpu()
+    vf = EpicVectorField(g.state, "flows.0.net", g.hp, freqs=g.freqs)
+    N = x.shape[1]
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        vac = vf(t[:, None].expand(-1, N), x, cond=cond, mask=mask).float()
+    e16, eac = (v16 - ref).abs(), (vac - ref).abs()
+    assert (v32 - ref).abs().max() < 2e-5                     # the flag really selects another kernel ...
+    assert e16.max() > 1e-5                                     # ... whose operands are rounded
+    assert e16.max() <= 1.5 * eac.max() + 1e-3, (e16.max(), eac.max())
+    assert e16.mean() <= 1.5 * eac.mean() + 1e-4, (e16.mean(), eac.mean())
+    assert e16.max() < 5e-2
+    assert torch.all(v16[mask.squeeze(-1) == 0] == 0)
+
+
+def test_bf16_sampler_and_module_switch():
+    from particle_fm_amd.models import SetFlowMatchingLitModule
+    from tests.conftest import load_golden
+    from tests.test_modules_cpu import _yaml_kwargs
+    g = load_golden("jetnet30")
+    m = SetFlowMatchingLitModule(optimizer=None, sigma=1e-4, **_yaml_kwargs(g.hp))
+    full = dict(g.state)
+    full.update({"loss." + k: v for k, v in g.state.items()})
+    m.load_state_dict(full)
+    m = m.cuda()
+    tag = "midpoint_100/"
+    mask = g.get(tag + "mask")
+    B, N, F = mask.shape[0], g.hp["num_particles"], g.hp["features"]
+    torch.manual_seed(9999)
+    x32 = m.sample(B, cond=None, mask=mask, ode_solver="midpoint", ode_steps=100).cpu()
+    m.flows[0].net.set_precision("bf16-mixed")
+    torch.manual_seed(9999)
+    x16 = m.sample(B, cond=None, mask=mask, ode_solver="midpoint", ode_steps=100).cpu()
+    torch.manual_seed(9999)
+    z = torch.randn(B, N, F)
+    vf = EpicVectorField(g.state, "flows.0.net", g.hp, freqs=m.flows[0].net.layout().default_freqs())
+    ref = sample_midpoint(vf, z, None, mask, ode_steps=100)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        rac = sample_midpoint(vf, z, None, mask, ode_steps=100).float()
+    assert (x32 - ref).abs().max() < 5e-5
+    e16, eac = (x16 - ref).abs(), (rac - ref).abs()
+    assert 1e-5 < e16.max() <= 1.5 * eac.max() + 2e-3, (e16.max(), eac.max())
+    assert torch.all(x16[mask.squeeze(-1) == 0] == 0)
+    # training is untouched by the switch (fp32 kernels)
+    loss = m.training_step((g.get("loss_f32/x").cuda(), g.get("loss_f32/mask").cuda(), torch.zeros(B).cuda()), 0)["loss"]
+    assert torch.isfinite(loss)
