@@ -256,6 +256,28 @@ def main():
                         "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/round1_pmc_summary.json",
             },
         }
+        if world == 1:
+            # informational, outside the timed region and NOT part of `value`: the same sampler launch with bf16 MFMA
+            # operands (PFM_F_BF16_MFMA; fp32 accumulate and activations), and how far its result is from the fp32 one
+            net = model.flows[0].net
+            with torch.no_grad():
+                ref32 = model(z, cond=None, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps)
+                net.set_precision("bf16")
+                o16 = model(z, cond=None, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    o16 = model(z, cond=None, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                net.set_precision("fp32")
+            ms16 = e0.elapsed_time(e1) / 3
+            res["bf16_mfma_sampler"] = {
+                "sample_ms": ms16, "sample_jets_per_s": B / (ms16 * 1e-3), "max_abs_dev_from_f32": float((o16 - ref32).abs().max()),
+                "note": "not the headline: same launch with the particle Linears on v_mfma_f32_16x16x16_bf16 (operands rounded "
+                        "to bf16, fp32 accumulate, fp32 activations); tests/test_hip_bf16.py bounds it by the reference's "
+                        "autocast-bf16 error",
+            }
         if world == 1 and not args.no_cpu_baseline:
             freqs = model.flows[0].net.layout().default_freqs()
             log("cpu baseline (oracle on the host cores) ...")
