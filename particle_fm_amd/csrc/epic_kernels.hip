@@ -56,7 +56,7 @@ int validate(const pfm_epic_desc* d) {
 // ------------------------------------------------------------------------------------------------
 // v = f(t, x): one evaluation per jet
 // ------------------------------------------------------------------------------------------------
-template <bool BF16>
+template <int MODE>
 __global__ __launch_bounds__(NT, 2) void epic_forward_kernel(const float* __restrict__ blob, int64_t desc_off,
                                                              const float* __restrict__ t, const float* __restrict__ temb,
                                                              const float* __restrict__ x,
@@ -82,17 +82,17 @@ __global__ __launch_bounds__(NT, 2) void epic_forward_kernel(const float* __rest
     __syncthreads();
     const SavedLayout sl = make_saved(j.N, j.F, j.layers);
     PFM_STAMP(0);
-    epic_body<false, BF16>(d, j, blob, lds, c, n_rows, nullptr, sl);
+    epic_body<false, MODE>(d, j, blob, lds, c, n_rows, nullptr, sl);
     float* vj = v + (size_t)jet * j.N * j.F;
     const int F = j.F;
-    epic_head(d, j, blob, lds, c, n_rows, [=](int p, int f, float val) { vj[p * F + f] = val; });
+    epic_head<MODE>(d, j, blob, lds, c, n_rows, [=](int p, int f, float val) { vj[p * F + f] = val; });
     PFM_STAMP(30);
 }
 
 // One evaluation of the vector field inside the persistent sampler + the integrator update.  (Tried as a real,
 // non-inlined function to isolate its register allocation: the call ABI's callee-saved spills made it 25 % slower.)
 //   stage 0: x_mid = x + 0.5*dt*k1 -> next input;   stage 1: x = x + dt*f(t+dt/2, x_mid)
-template <bool BF16>
+template <int MODE>
 static __device__ __forceinline__ void sampler_eval(const float* __restrict__ blob, int64_t desc_off, int n_rows,
                                                       float t, float hs, int stage) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -105,8 +105,8 @@ static __device__ __forceinline__ void sampler_eval(const float* __restrict__ bl
     const int F = j.F;
     epic_time_embedding(d, j, blob, lds, c, t);
     __syncthreads();
-    epic_body<false, BF16>(d, j, blob, lds, c, n_rows, nullptr, sl);
-    epic_head(d, j, blob, lds, c, n_rows, [=](int p, int f, float val) {
+    epic_body<false, MODE>(d, j, blob, lds, c, n_rows, nullptr, sl);
+    epic_head<MODE>(d, j, blob, lds, c, n_rows, [=](int p, int f, float val) {
         const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
         yin[p * F + f] = xn;
         if (stage) xs[p * F + f] = xn;
@@ -118,7 +118,7 @@ static __device__ __forceinline__ void sampler_eval(const float* __restrict__ bl
 // Persistent fixed-step midpoint integrator: all 2*n_intervals evaluations of a jet in one launch,
 // state and activations never leave the CU.  (torchdyn Midpoint.step restated in oracle/fm_ref.py)
 // ------------------------------------------------------------------------------------------------
-template <bool BF16>
+template <int MODE>
 __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
     const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ t_eval,
     const float* __restrict__ dt, int n_intervals, const float* __restrict__ z, const float* __restrict__ cond,
@@ -149,11 +149,18 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
         const int stage = e & 1;
         const float h = dt[e >> 1];
         const float hs = stage ? h : __fmul_rn(0.5f, h);
-        sampler_eval<BF16>(blob, desc_off, n_rows, t_eval[e], hs, stage);
+        sampler_eval<MODE>(blob, desc_off, n_rows, t_eval[e], hs, stage);
         PFM_STAMP(30);
     }
     float* oj = x_out + (size_t)jet * j.N * j.F;
     for (int i = tid; i < j.N * j.F; i += NT) oj[i] = xs[i];
+}
+
+// which matrix-pipe flavour the inference kernels use (descriptor flags): 0 fp32, 1 bf16 operands, 2 split fp16
+int mfma_mode(const pfm_epic_desc* d) {
+    if (!d) return 0;
+    if (d->flags & PFM_F_F16X3_MFMA) return 2;
+    return (d->flags & PFM_F_BF16_MFMA) ? 1 : 0;
 }
 
 template <typename K>
@@ -188,36 +195,36 @@ int64_t pfm_epic_saved_floats_per_jet(const pfm_epic_desc* d) {
 int pfm_epic_forward(const pfm_epic_desc* d, const float* blob, const float* t, const float* x,
                      const float* cond, const float* mask, float* v, int32_t B, void* stream) {
     int lds = 0;
-    const bool bf = (d && (d->flags & PFM_F_BF16_MFMA)) != 0;
-    int rc = bf ? prepare(epic_forward_kernel<true>, d, &lds) : prepare(epic_forward_kernel<false>, d, &lds);
+    const int mode = mfma_mode(d);
+    int rc = mode == 2 ? prepare(epic_forward_kernel<2>, d, &lds)
+                       : (mode == 1 ? prepare(epic_forward_kernel<1>, d, &lds) : prepare(epic_forward_kernel<0>, d, &lds));
     if (rc) return rc;
     if (B <= 0) return 0;
     if (!blob || !t || !x || !v) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
-    if (bf)
-        hipLaunchKernelGGL(epic_forward_kernel<true>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, t,
-                           (const float*)nullptr, x, cond, mask, v);
-    else
-        hipLaunchKernelGGL(epic_forward_kernel<false>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, t,
-                           (const float*)nullptr, x, cond, mask, v);
+#define PFM_LAUNCH_FWD(M)                                                                                             \
+    hipLaunchKernelGGL(epic_forward_kernel<M>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, t, \
+                       (const float*)nullptr, x, cond, mask, v)
+    if (mode == 2) PFM_LAUNCH_FWD(2); else if (mode == 1) PFM_LAUNCH_FWD(1); else PFM_LAUNCH_FWD(0);
+#undef PFM_LAUNCH_FWD
     return check_hip(hipGetLastError(), "epic_forward_kernel launch");
 }
 
 int pfm_epic_forward_temb(const pfm_epic_desc* d, const float* blob, const float* temb, const float* x,
                           const float* cond, const float* mask, float* v, int32_t B, void* stream) {
     int lds = 0;
-    const bool bf = (d && (d->flags & PFM_F_BF16_MFMA)) != 0;
-    int rc = bf ? prepare(epic_forward_kernel<true>, d, &lds) : prepare(epic_forward_kernel<false>, d, &lds);
+    const int mode = mfma_mode(d);
+    int rc = mode == 2 ? prepare(epic_forward_kernel<2>, d, &lds)
+                       : (mode == 1 ? prepare(epic_forward_kernel<1>, d, &lds) : prepare(epic_forward_kernel<0>, d, &lds));
     if (rc) return rc;
     if (B <= 0) return 0;
     if (!blob || !temb || !x || !v) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
-    if (bf)
-        hipLaunchKernelGGL(epic_forward_kernel<true>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats,
-                           (const float*)nullptr, temb, x, cond, mask, v);
-    else
-        hipLaunchKernelGGL(epic_forward_kernel<false>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats,
-                           (const float*)nullptr, temb, x, cond, mask, v);
+#define PFM_LAUNCH_FWD(M)                                                                                          \
+    hipLaunchKernelGGL(epic_forward_kernel<M>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, \
+                       (const float*)nullptr, temb, x, cond, mask, v)
+    if (mode == 2) PFM_LAUNCH_FWD(2); else if (mode == 1) PFM_LAUNCH_FWD(1); else PFM_LAUNCH_FWD(0);
+#undef PFM_LAUNCH_FWD
     return check_hip(hipGetLastError(), "epic_forward_kernel launch");
 }
 
@@ -225,19 +232,19 @@ int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const fl
                              int32_t n_intervals, const float* z, const float* cond, const float* mask,
                              float* x_out, int32_t B, void* stream) {
     int lds = 0;
-    const bool bf = (d && (d->flags & PFM_F_BF16_MFMA)) != 0;
-    int rc = bf ? prepare(epic_sample_midpoint_kernel<true>, d, &lds) : prepare(epic_sample_midpoint_kernel<false>, d, &lds);
+    const int mode = mfma_mode(d);
+    int rc = mode == 2 ? prepare(epic_sample_midpoint_kernel<2>, d, &lds)
+                       : (mode == 1 ? prepare(epic_sample_midpoint_kernel<1>, d, &lds) : prepare(epic_sample_midpoint_kernel<0>, d, &lds));
     if (rc) return rc;
     if (B <= 0) return 0;
     if (!blob || !t_eval || !dt || !z || !x_out) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (n_intervals < 0) return set_err(PFM_E_BADARG, "n_intervals < 0");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
-    if (bf)
-        hipLaunchKernelGGL(epic_sample_midpoint_kernel<true>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats,
-                           t_eval, dt, n_intervals, z, cond, mask, x_out);
-    else
-        hipLaunchKernelGGL(epic_sample_midpoint_kernel<false>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats,
-                           t_eval, dt, n_intervals, z, cond, mask, x_out);
+#define PFM_LAUNCH_SMP(M)                                                                                                  \
+    hipLaunchKernelGGL(epic_sample_midpoint_kernel<M>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, \
+                       t_eval, dt, n_intervals, z, cond, mask, x_out)
+    if (mode == 2) PFM_LAUNCH_SMP(2); else if (mode == 1) PFM_LAUNCH_SMP(1); else PFM_LAUNCH_SMP(0);
+#undef PFM_LAUNCH_SMP
     return check_hip(hipGetLastError(), "epic_sample_midpoint_kernel launch");
 }
 

@@ -98,6 +98,23 @@ __device__ __forceinline__ s16x4 pack_bf16(f32x4 v) {
     return __builtin_bit_cast(s16x4, u);
 }
 
+// ---- split-fp16 operands (PFM_F_F16X3_MFMA): fp32-accurate products on the fp16 matrix pipe -----------------------
+// x = hi + lo * 2^-11 with hi = fp16(x), lo = fp16((x - hi) * 2^11)  (22 significant bits); then
+//   x . w  =  hi.whi  +  2^-11 (hi.wlo + lo.whi)  +  O(2^-22),
+// three v_mfma_f32_16x16x16_f16 (16 cycles each, 16 k) instead of four v_mfma_f32_16x16x4_f32 (32 cycles each, 4 k):
+// 2.7x less matrix-pipe time at the accuracy of fp32 re-association noise (measured 6e-7 on the NFE, like the fp32
+// kernel).  The activation tiles live in LDS as two fp16 planes (hi, lo): same bytes as fp32, element index unchanged.
+// Valid for |x| < 65504 (fp16 range); the network's activations are O(1..100).
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+constexpr float X3_UP = 2048.0f, X3_DN = 1.0f / 2048.0f;
+__device__ __forceinline__ void x3_split(f32x4 x, h4& hi, h4& lo) {
+    hi = __builtin_convertvector(x, h4);
+    lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x4)) * X3_UP, h4);
+}
+__device__ __forceinline__ f32x4 x3_join(h4 hi, h4 lo) {
+    return __builtin_convertvector(hi, f32x4) + __builtin_convertvector(lo, f32x4) * X3_DN;
+}
+
 template <bool SAVE>
 __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float* __restrict__ lds, const Carve& c,
                                             int oslot, int pl, float* __restrict__ save_pool);
@@ -231,6 +248,77 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
 #undef PFM_MFMAQ
     epilogue(pacc0, pacc1, npairs - 1);
     if (POOL) pool_finish<SAVE>(psum, j, lds, c, oslot, pl, save_pool);
+}
+
+// The same particle phase on split-fp16 operands.  src / dst / resid are (hi, lo) fp16 plane pairs (the lo plane
+// starts j.N * H halfs after the hi plane); inference only (no SAVE).
+template <bool RESID, bool POOL>
+__device__ __forceinline__ void gemm_phase_x3(const f32x4 (&a)[8], const float* __restrict__ src, float* __restrict__ dst,
+                                              const float* __restrict__ resid, const float* __restrict__ bj,
+                                              const float* __restrict__ maskf, const JetDims& j, float* __restrict__ lds,
+                                              const Carve& c, int n_rows) {
+    const int tid_ = launder(threadIdx.x);
+    const int lane = tid_ & 63, w = tid_ >> 6;
+    const int pl = lane & 15, q = lane >> 4;
+    const int oslot = 4 * w + q;
+    const float slope = j.slope;
+    const int plane = j.N * H;
+    h4 ah[8], al[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) x3_split(a[kt], ah[kt], al[kt]);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(bj + 4 * oslot);
+    f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+    const int npairs = (n_rows + 2 * TILE - 1) / (2 * TILE);
+    int koff[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) koff[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
+    const int ooff = pl * H + ((oslot ^ pl) << 2);
+    const _Float16* sh = reinterpret_cast<const _Float16*>(src);
+    const _Float16* rh = reinterpret_cast<const _Float16*>(resid);
+    _Float16* dh = reinterpret_cast<_Float16*>(dst);
+    _Float16* const sink = reinterpret_cast<_Float16*>(lds + c.dummy);
+    for (int pair = 0; pair < npairs; ++pair) {
+        const _Float16* s0 = sh + pair * 2 * TILE * H;
+        f32x4 m0 = bias, m1 = bias;
+        if (RESID) {
+            const _Float16* r0 = rh + pair * 2 * TILE * H + ooff;
+            m0 += x3_join(*reinterpret_cast<const h4*>(r0), *reinterpret_cast<const h4*>(r0 + plane));
+            m1 += x3_join(*reinterpret_cast<const h4*>(r0 + TILE * H), *reinterpret_cast<const h4*>(r0 + TILE * H + plane));
+        }
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            const h4 b0h = *reinterpret_cast<const h4*>(s0 + koff[kt]);
+            const h4 b1h = *reinterpret_cast<const h4*>(s0 + TILE * H + koff[kt]);
+            const h4 b0l = *reinterpret_cast<const h4*>(s0 + plane + koff[kt]);
+            const h4 b1l = *reinterpret_cast<const h4*>(s0 + plane + TILE * H + koff[kt]);
+            m0 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[kt], b0h, m0, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[kt], b1h, m1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[kt], b0l, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[kt], b1l, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x16f16(al[kt], b0h, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x16f16(al[kt], b1h, c1, 0, 0, 0);
+        }
+        const int p0 = pair * 2 * TILE + pl, p1 = p0 + TILE;
+        const bool v0 = p0 < n_rows, v1 = p1 < n_rows;
+        const f32x4 e0 = lrelu4(m0 + c0 * X3_DN, slope), e1 = lrelu4(m1 + c1 * X3_DN, slope);
+        h4 h0, l0, h1, l1;
+        x3_split(e0, h0, l0);
+        x3_split(e1, h1, l1);
+        _Float16* d0 = v0 ? dh + pair * 2 * TILE * H + ooff : sink;
+        _Float16* d1 = v1 ? dh + (pair * 2 + 1) * TILE * H + ooff : sink;
+        *reinterpret_cast<h4*>(d0) = h0;
+        *reinterpret_cast<h4*>(d0 + (v0 ? plane : 4)) = l0;
+        *reinterpret_cast<h4*>(d1) = h1;
+        *reinterpret_cast<h4*>(d1 + (v1 ? plane : 4)) = l1;
+        if (POOL) {
+            const float mk0 = maskf[v0 ? p0 : 0], mk1 = maskf[v1 ? p1 : 0];
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            psum += v0 ? e0 * mk0 : z;
+            psum += v1 ? e1 * mk1 : z;
+        }
+    }
+    if (POOL) pool_finish<false>(psum, j, lds, c, oslot, pl, nullptr);
 }
 
 // ---- per-jet GEMVs (global MLP, per-jet biases) ------------------------------------------------
@@ -437,7 +525,7 @@ __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float*
     }
 }
 
-template <int FM, bool SAVE>
+template <int FM, bool SAVE, int MODE = 0>
 __device__ __forceinline__ void stem_l1(const pfm_epic_desc& d, const JetDims& j, const float* __restrict__ blob,
                                         float* __restrict__ lds, const Carve& c, int n_rows,
                                         float* __restrict__ save_x1) {
@@ -453,14 +541,22 @@ __device__ __forceinline__ void stem_l1(const pfm_epic_desc& d, const JetDims& j
         for (int f = 0; f < FM; ++f)
             if (f < j.F) acc += wv[f] * lds[c.yin + p * j.F + f];
         acc = lrelu4(acc, j.slope);
-        *reinterpret_cast<f32x4*>(lds + c.bufA + lds_off(p, slot)) = acc;
+        if (MODE == 2) {
+            h4 hi, lo;
+            x3_split(acc, hi, lo);
+            _Float16* dp = reinterpret_cast<_Float16*>(lds + c.bufA) + lds_off(p, slot);
+            *reinterpret_cast<h4*>(dp) = hi;
+            *reinterpret_cast<h4*>(dp + j.N * H) = lo;
+        } else {
+            *reinterpret_cast<f32x4*>(lds + c.bufA + lds_off(p, slot)) = acc;
+        }
         if (SAVE) *reinterpret_cast<f32x4*>(save_x1 + p * H + 4 * slot) = acc;
     }
 }
 
 // Full network body up to (excluding) the fc_l3 head.  Preconditions (in LDS): yin (N x F input),
 // maskf, misc[0] = sum(mask), vin.temb, vin.cond.  Postcondition: bufB holds the last hidden state.
-template <bool SAVE, bool BF16 = false>
+template <bool SAVE, int MODE = 0>
 __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims& j,
                                           const float* __restrict__ blob, float* __restrict__ lds,
                                           const Carve& c, int n_rows, float* __restrict__ saved,
@@ -489,14 +585,15 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     }
     PFM_STAMP(2);
     // ---- fc_l1 (K = F, VALU): bufA[p][o] = lrelu(bj1[o] + sum_f Wx[f][o] * y[p][f])  epic.py:360-362
-    if (j.F <= 4) stem_l1<4, SAVE>(d, j, blob, lds, c, n_rows, saved + sl.x1);
-    else stem_l1<MAXF, SAVE>(d, j, blob, lds, c, n_rows, saved + sl.x1);
+    if (j.F <= 4) stem_l1<4, SAVE, MODE>(d, j, blob, lds, c, n_rows, saved + sl.x1);
+    else stem_l1<MAXF, SAVE, MODE>(d, j, blob, lds, c, n_rows, saved + sl.x1);
     __syncthreads();
     PFM_STAMP(3);
     // ---- fc_l2: bufB = lrelu(W.bufA + bj2 + bufA)  epic.py:364-366 (residual from the source buffer)
     prefetch_gl1(gw, rs, d.g1, K1s);
     if (j.layers > 0) load_afrag(a1, rs, d.layer[0].lc1.A, w, lane);  // first layer's phase-1 weights: in flight across fc_l2
-    gemm_phase<true, true, SAVE, BF16>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, saved + sl.x2, saved + sl.pool, n_rows);
+    if (MODE == 2) gemm_phase_x3<true, true>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, n_rows);
+    else gemm_phase<true, true, SAVE, MODE == 1>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, saved + sl.x2, saved + sl.pool, n_rows);
     __syncthreads();
     PFM_STAMP(4);
     // ---- fc_g1 / fc_g2 (epic.py:369-380) ---------------------------------------------------------
@@ -516,8 +613,9 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
         PFM_STAMP(12);
         load_afrag(a2, rs, ly.lc2.A, w, lane);  // lands behind phase 1's MFMAs
         // phase 1: bufA = lrelu(W1 . bufB + bj1)                       epic.py:194-196
-        gemm_phase<false, false, SAVE, BF16>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, saved + sl.l1 + k * sl.lstride,
-                                       nullptr, n_rows);
+        if (MODE == 2) gemm_phase_x3<false, false>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, n_rows);
+        else gemm_phase<false, false, SAVE, MODE == 1>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, saved + sl.l1 + k * sl.lstride,
+                                                       nullptr, n_rows);
         __syncthreads();
         PFM_STAMP(13);
         if (k + 1 < j.layers) {
@@ -525,8 +623,9 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
             load_afrag(a1, rs, d.layer[k + 1].lc1.A, w, lane);  // next layer's phase-1 weights, in flight across phase 2
         }
         // phase 2: bufB = lrelu(W2 . bufA + bj2 + bufB), pooled -> vin    epic.py:198-200, :160-162
-        gemm_phase<true, true, SAVE, BF16>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, saved + sl.xo + k * sl.lstride,
-                                     saved + sl.pool + (k + 1) * sl.pstride, n_rows);
+        if (MODE == 2) gemm_phase_x3<true, true>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, n_rows);
+        else gemm_phase<true, true, SAVE, MODE == 1>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, saved + sl.xo + k * sl.lstride,
+                                                     saved + sl.pool + (k + 1) * sl.pstride, n_rows);
         __syncthreads();
     }
     PFM_STAMP(20);
@@ -536,7 +635,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
 // (rows >= n_rows are emitted as 0: they are masked).  epic.py:387-391
 // The F <= 16 outputs are one 16-row MFMA panel: wave w takes the particle tiles w, w+8, ...; lane (particle, q)
 // ends up with features 4q..4q+3 of its particle.
-template <typename Emit>
+template <int MODE = 0, typename Emit>
 __device__ __forceinline__ void epic_head(const pfm_epic_desc& d, const JetDims& j,
                                           const float* __restrict__ blob, float* __restrict__ lds,
                                           const Carve& c, int n_rows, Emit emit) {
@@ -571,7 +670,13 @@ __device__ __forceinline__ void epic_head(const pfm_epic_desc& d, const JetDims&
         f32x4 acc = b3;
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(s0 + koff[kt]);
+            f32x4 b;
+            if (MODE == 2) {  // (hi, lo) fp16 planes -> fp32 (the head is 1 % of the work: keep its fp32 MFMA)
+                const _Float16* hp = reinterpret_cast<const _Float16*>(bufB) + tile * TILE * H + koff[kt];
+                b = x3_join(*reinterpret_cast<const h4*>(hp), *reinterpret_cast<const h4*>(hp + j.N * H));
+            } else {
+                b = *reinterpret_cast<const f32x4*>(s0 + koff[kt]);
+            }
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].x, b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].y, b.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].z, b.z, acc, 0, 0, 0);

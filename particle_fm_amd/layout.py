@@ -28,6 +28,7 @@ PFM_MAX_LAYERS = 24
 PFM_HIDDEN = 128
 PFM_F_SKIP_MASKED_TAIL = 1
 PFM_F_BF16_MFMA = 2
+PFM_F_F16X3_MFMA = 4
 
 
 class LocalLin(ctypes.Structure):

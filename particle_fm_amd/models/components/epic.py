@@ -119,17 +119,20 @@ class EPiC_encoder(nn.Module):
 
     def layout(self, num_points: Optional[int] = None) -> EpicLayout:
         n = num_points or self.num_points
-        bf = self.mfma_dtype == "bf16" and not self.wide
-        lay = self._layouts.get((n, bf))
+        mode = 0 if self.wide else {"fp32": 0, "bf16": 2, "f16x3": 4}[self.mfma_dtype]
+        lay = self._layouts.get((n, mode))
         if lay is None:
-            flags = (1 if self.skip_masked_tail else 0) | (2 if bf else 0)
+            flags = (1 if self.skip_masked_tail else 0) | mode
             lay = EpicWideLayout(self.config(n)) if self.wide else EpicLayout(self.config(n), flags=flags)
-            self._layouts[(n, bf)] = lay
+            self._layouts[(n, mode)] = lay
         return lay
 
     def set_precision(self, precision) -> None:
-        """Accepts Lightning's spellings: "bf16", "bf16-mixed", "bf16-true" -> bf16 MFMA for inference; anything else fp32."""
-        self.mfma_dtype = "bf16" if str(precision).startswith("bf16") else "fp32"
+        """Accepts Lightning's spellings: "bf16", "bf16-mixed", "bf16-true" -> bf16 MFMA operands for inference;
+        "f16x3" -> split-fp16 operands (three fp16 MFMAs per product block, fp32-grade accuracy, PFM_F_F16X3_MFMA);
+        anything else fp32 MFMA."""
+        p = str(precision)
+        self.mfma_dtype = "bf16" if p.startswith("bf16") else ("f16x3" if p == "f16x3" else "fp32")
 
     def source_vector(self, layout: Optional[EpicLayout] = None) -> torch.Tensor:
         """effective weights | biases | freqs | 0 from the live parameters (differentiable)."""
