@@ -101,8 +101,8 @@ __device__ __forceinline__ s16x4 pack_bf16(f32x4 v) {
 // ---- split-fp16 operands (PFM_F_F16X3_MFMA): fp32-accurate products on the fp16 matrix pipe -----------------------
 // x = hi + lo * 2^-11 with hi = fp16(x), lo = fp16((x - hi) * 2^11)  (22 significant bits); then
 //   x . w  =  hi.whi  +  2^-11 (hi.wlo + lo.whi)  +  O(2^-22),
-// three v_mfma_f32_16x16x16_f16 (16 cycles each, 16 k) instead of four v_mfma_f32_16x16x4_f32 (32 cycles each, 4 k):
-// 2.7x less matrix-pipe time at the accuracy of fp32 re-association noise (measured 6e-7 on the NFE, like the fp32
+// three v_mfma_f32_16x16x32_f16 (16 cycles each, 32 k) instead of eight v_mfma_f32_16x16x4_f32 (32 cycles each, 4 k):
+// 5.3x less matrix-pipe time at the accuracy of fp32 re-association noise (measured 6e-7 on the NFE, like the fp32
 // kernel).  The activation tiles live in LDS as two fp16 planes (hi, lo): same bytes as fp32, element index unchanged.
 // Valid for |x| < 65504 (fp16 range); the network's activations are O(1..100).
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -114,6 +114,36 @@ __device__ __forceinline__ void x3_split(f32x4 x, h4& hi, h4& lo) {
 __device__ __forceinline__ f32x4 x3_join(h4 hi, h4 lo) {
     return __builtin_convertvector(hi, f32x4) + __builtin_convertvector(lo, f32x4) * X3_DN;
 }
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void x3_split8(f32x4 x0, f32x4 x1, h8& hi, h8& lo) {
+    h4 h0, l0, h1, l1;
+    x3_split(x0, h0, l0);
+    x3_split(x1, h1, l1);
+    hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// Element index inside an fp16 plane: rows of 16 sixteen-byte slots (8 halfs = 8 consecutive k), slot index XOR-ed
+// with (row & 15): the ds_read_b128 of v_mfma_f32_16x16x32_f16's B operand (lane (row, q) reads slot 4 kt + q) and
+// the 8-byte stores of the epilogue are bank-conflict free.  `slot4` counts groups of 4 features, like lds_off.
+__device__ __forceinline__ int x3_off(int p, int slot4) { return p * H + (((slot4 >> 1) ^ (p & 15)) << 3) + ((slot4 & 1) << 2); }
+// A operand of v_mfma_f32_16x16x32_f16 from the MFMA_A block: lane (i, q) needs k = 32 kt' + 8 q .. + 7, i.e. the two
+// float4 that lanes (i, 2(q&1)) and (i, 2(q&1)+1) of k-tile 2 kt' + (q>>1) hold in the fp32 format: a[2 kt' + h].
+__device__ __forceinline__ void load_afrag_k8(f32x4 (&a)[8], blob_rsrc rs, int64_t A_off, int w, int lane) {
+    const int pl = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kt = 2 * kp + (q >> 1), src = pl + 16 * (2 * (q & 1) + h);
+            a[2 * kp + h] = bload4(rs, A_off, (((w * 8 + kt) * 64) + src) * 16);
+        }
+}
+template <int MODE>
+__device__ __forceinline__ void load_afrag_m(f32x4 (&a)[8], blob_rsrc rs, int64_t A_off, int w, int lane) {
+    if (MODE == 2) load_afrag_k8(a, rs, A_off, w, lane);
+    else load_afrag(a, rs, A_off, w, lane);
+}
+
 
 template <bool SAVE>
 __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float* __restrict__ lds, const Carve& c,
@@ -263,45 +293,52 @@ __device__ __forceinline__ void gemm_phase_x3(const f32x4 (&a)[8], const float* 
     const int oslot = 4 * w + q;
     const float slope = j.slope;
     const int plane = j.N * H;
-    h4 ah[8], al[8];
+    h8 ah[4], al[4];  // a[] arrives in the k8 order of load_afrag_k8
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt) x3_split(a[kt], ah[kt], al[kt]);
+    for (int kp = 0; kp < 4; ++kp) x3_split8(a[2 * kp], a[2 * kp + 1], ah[kp], al[kp]);
     const f32x4 bias = *reinterpret_cast<const f32x4*>(bj + 4 * oslot);
     f32x4 psum = {0.f, 0.f, 0.f, 0.f};
     const int npairs = (n_rows + 2 * TILE - 1) / (2 * TILE);
-    int koff[8];
+    int koff[4];  // (row & 15) == pl for every tile: per-lane constants
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt) koff[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
-    const int ooff = pl * H + ((oslot ^ pl) << 2);
+    for (int kp = 0; kp < 4; ++kp) koff[kp] = pl * H + (((4 * kp + q) ^ pl) << 3);
+    const int ooff = pl * H + (((oslot >> 1) ^ pl) << 3) + ((oslot & 1) << 2);
     const _Float16* sh = reinterpret_cast<const _Float16*>(src);
     const _Float16* rh = reinterpret_cast<const _Float16*>(resid);
     _Float16* dh = reinterpret_cast<_Float16*>(dst);
     _Float16* const sink = reinterpret_cast<_Float16*>(lds + c.dummy);
-    for (int pair = 0; pair < npairs; ++pair) {
-        const _Float16* s0 = sh + pair * 2 * TILE * H;
-        f32x4 m0 = bias, m1 = bias;
-        if (RESID) {
-            const _Float16* r0 = rh + pair * 2 * TILE * H + ooff;
-            m0 += x3_join(*reinterpret_cast<const h4*>(r0), *reinterpret_cast<const h4*>(r0 + plane));
-            m1 += x3_join(*reinterpret_cast<const h4*>(r0 + TILE * H), *reinterpret_cast<const h4*>(r0 + TILE * H + plane));
-        }
-        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    // Software pipeline, one straight-line block per pair of tiles: the operand reads of one K half are in flight while
+    // the 12 MFMAs of the other half issue, and the epilogue of pair i-1 (split, ds_write, pooling) sits between the
+    // reads and the MFMAs of pair i.  Rows are not clamped (see gemm_phase).
+    struct Half { h8 b0h[2], b1h[2], b0l[2], b1l[2]; };
+    auto load_half = [&](Half& hf, const _Float16* s0, int h) {
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-            const h4 b0h = *reinterpret_cast<const h4*>(s0 + koff[kt]);
-            const h4 b1h = *reinterpret_cast<const h4*>(s0 + TILE * H + koff[kt]);
-            const h4 b0l = *reinterpret_cast<const h4*>(s0 + plane + koff[kt]);
-            const h4 b1l = *reinterpret_cast<const h4*>(s0 + plane + TILE * H + koff[kt]);
-            m0 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[kt], b0h, m0, 0, 0, 0);
-            m1 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[kt], b1h, m1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[kt], b0l, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[kt], b1l, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x16f16(al[kt], b0h, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x16f16(al[kt], b1h, c1, 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk) {
+            const int o = koff[2 * h + kk];
+            hf.b0h[kk] = *reinterpret_cast<const h8*>(s0 + o);
+            hf.b1h[kk] = *reinterpret_cast<const h8*>(s0 + TILE * H + o);
+            hf.b0l[kk] = *reinterpret_cast<const h8*>(s0 + plane + o);
+            hf.b1l[kk] = *reinterpret_cast<const h8*>(s0 + plane + TILE * H + o);
         }
+    };
+    f32x4 m0, m1, c0, c1;
+    auto mfma_half = [&](const Half& hf, int h) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int kp = 2 * h + kk;
+            m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kp], hf.b0h[kk], m0, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kp], hf.b1h[kk], m1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kp], hf.b0l[kk], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kp], hf.b1l[kk], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kp], hf.b0h[kk], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kp], hf.b1h[kk], c1, 0, 0, 0);
+        }
+    };
+    auto epilogue = [&](f32x4 e0, f32x4 e1, int pair) {
         const int p0 = pair * 2 * TILE + pl, p1 = p0 + TILE;
         const bool v0 = p0 < n_rows, v1 = p1 < n_rows;
-        const f32x4 e0 = lrelu4(m0 + c0 * X3_DN, slope), e1 = lrelu4(m1 + c1 * X3_DN, slope);
+        e0 = lrelu4(e0, slope);
+        e1 = lrelu4(e1, slope);
         h4 h0, l0, h1, l1;
         x3_split(e0, h0, l0);
         x3_split(e1, h1, l1);
@@ -317,7 +354,35 @@ __device__ __forceinline__ void gemm_phase_x3(const f32x4 (&a)[8], const float* 
             psum += v0 ? e0 * mk0 : z;
             psum += v1 ? e1 * mk1 : z;
         }
+    };
+    Half X, Y;
+    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, pe0 = r0, pe1 = r0;
+    load_half(X, sh, 0);
+    if (RESID) {
+        r0 = x3_join(*reinterpret_cast<const h4*>(rh + ooff), *reinterpret_cast<const h4*>(rh + ooff + plane));
+        r1 = x3_join(*reinterpret_cast<const h4*>(rh + TILE * H + ooff), *reinterpret_cast<const h4*>(rh + TILE * H + ooff + plane));
     }
+    for (int pair = 0; pair < npairs; ++pair) {
+        const _Float16* s0 = sh + pair * 2 * TILE * H;
+        load_half(Y, s0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pair > 0) epilogue(pe0, pe1, pair - 1);
+        m0 = bias; m1 = bias;
+        if (RESID) { m0 += r0; m1 += r1; }
+        c0 = f32x4{0.f, 0.f, 0.f, 0.f}; c1 = c0;
+        mfma_half(X, 0);
+        load_half(X, s0 + 2 * TILE * H, 0);  // next pair (one pair past the end on the last iteration: inside the LDS window)
+        if (RESID) {
+            const _Float16* rn = rh + (pair + 1) * 2 * TILE * H + ooff;
+            r0 = x3_join(*reinterpret_cast<const h4*>(rn), *reinterpret_cast<const h4*>(rn + plane));
+            r1 = x3_join(*reinterpret_cast<const h4*>(rn + TILE * H), *reinterpret_cast<const h4*>(rn + TILE * H + plane));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(Y, 1);
+        pe0 = m0 + c0 * X3_DN;
+        pe1 = m1 + c1 * X3_DN;
+    }
+    epilogue(pe0, pe1, npairs - 1);
     if (POOL) pool_finish<false>(psum, j, lds, c, oslot, pl, nullptr);
 }
 
@@ -544,7 +609,7 @@ __device__ __forceinline__ void stem_l1(const pfm_epic_desc& d, const JetDims& j
         if (MODE == 2) {
             h4 hi, lo;
             x3_split(acc, hi, lo);
-            _Float16* dp = reinterpret_cast<_Float16*>(lds + c.bufA) + lds_off(p, slot);
+            _Float16* dp = reinterpret_cast<_Float16*>(lds + c.bufA) + x3_off(p, slot);
             *reinterpret_cast<h4*>(dp) = hi;
             *reinterpret_cast<h4*>(dp + j.N * H) = lo;
         } else {
@@ -578,7 +643,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     PFM_STAMP(1);
     // ---- stem: per-jet biases of fc_l1 / fc_l2 (t / cond columns) ------------------------------
     const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
-    load_afrag(a2, rs, d.l2.A, w, lane);
+    load_afrag_m<MODE>(a2, rs, d.l2.A, w, lane);
     {
         LocalBiasSrc lb; lb.We1 = d.l1_We; lb.b1 = d.l1_b; lb.We2 = d.l2.We; lb.b2 = d.l2.b;
         stem_bias(blob, rs, lb, Ke, lds, c);
@@ -591,7 +656,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     PFM_STAMP(3);
     // ---- fc_l2: bufB = lrelu(W.bufA + bj2 + bufA)  epic.py:364-366 (residual from the source buffer)
     prefetch_gl1(gw, rs, d.g1, K1s);
-    if (j.layers > 0) load_afrag(a1, rs, d.layer[0].lc1.A, w, lane);  // first layer's phase-1 weights: in flight across fc_l2
+    if (j.layers > 0) load_afrag_m<MODE>(a1, rs, d.layer[0].lc1.A, w, lane);  // first layer's phase-1 weights: in flight across fc_l2
     if (MODE == 2) gemm_phase_x3<true, true>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, n_rows);
     else gemm_phase<true, true, SAVE, MODE == 1>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, saved + sl.x2, saved + sl.pool, n_rows);
     __syncthreads();
@@ -611,7 +676,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
         per_jet_phase<false, SAVE>(j, blob, rs, ly.gl1, ly.gl2, lb, lds, c, saved + sl.glayer + k * sl.gstride,
                                    saved + sl.glayer + k * sl.gstride + H, gw, a1, ly.lc1.A);
         PFM_STAMP(12);
-        load_afrag(a2, rs, ly.lc2.A, w, lane);  // lands behind phase 1's MFMAs
+        load_afrag_m<MODE>(a2, rs, ly.lc2.A, w, lane);  // lands behind phase 1's MFMAs
         // phase 1: bufA = lrelu(W1 . bufB + bj1)                       epic.py:194-196
         if (MODE == 2) gemm_phase_x3<false, false>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, n_rows);
         else gemm_phase<false, false, SAVE, MODE == 1>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, saved + sl.l1 + k * sl.lstride,
@@ -620,7 +685,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
         PFM_STAMP(13);
         if (k + 1 < j.layers) {
             prefetch_gl1(gw, rs, d.layer[k + 1].gl1, K1l);
-            load_afrag(a1, rs, d.layer[k + 1].lc1.A, w, lane);  // next layer's phase-1 weights, in flight across phase 2
+            load_afrag_m<MODE>(a1, rs, d.layer[k + 1].lc1.A, w, lane);  // next layer's phase-1 weights, in flight across phase 2
         }
         // phase 2: bufB = lrelu(W2 . bufA + bj2 + bufB), pooled -> vin    epic.py:198-200, :160-162
         if (MODE == 2) gemm_phase_x3<true, true>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, n_rows);
@@ -672,7 +737,7 @@ __device__ __forceinline__ void epic_head(const pfm_epic_desc& d, const JetDims&
         for (int kt = 0; kt < 8; ++kt) {
             f32x4 b;
             if (MODE == 2) {  // (hi, lo) fp16 planes -> fp32 (the head is 1 % of the work: keep its fp32 MFMA)
-                const _Float16* hp = reinterpret_cast<const _Float16*>(bufB) + tile * TILE * H + koff[kt];
+                const _Float16* hp = reinterpret_cast<const _Float16*>(bufB) + x3_off(tile * TILE + pl, 4 * kt + q);
                 b = x3_join(*reinterpret_cast<const h4*>(hp), *reinterpret_cast<const h4*>(hp + j.N * H));
             } else {
                 b = *reinterpret_cast<const f32x4*>(s0 + koff[kt]);

@@ -12,7 +12,7 @@ for N, B in ((30, 1024), (150, 256), (150, 1024)):
     n = torch.randint(max(10, N // 5), N + 1, (B,), generator=gen)
     mask = (torch.arange(N)[None] < n[:, None]).float().unsqueeze(-1).cuda()
     z = torch.randn(B, N, 3, generator=gen).cuda() * mask
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "f16x3", "bf16"):
         m.flows[0].net.set_precision(prec)
         with torch.no_grad():
             for _ in range(2):
