@@ -105,23 +105,6 @@ __device__ __forceinline__ s16x4 pack_bf16(f32x4 v) {
 // 5.3x less matrix-pipe time at the accuracy of fp32 re-association noise (measured 6e-7 on the NFE, like the fp32
 // kernel).  The activation tiles live in LDS as two fp16 planes (hi, lo): same bytes as fp32, element index unchanged.
 // Valid for |x| < 65504 (fp16 range); the network's activations are O(1..100).
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-constexpr float X3_UP = 2048.0f, X3_DN = 1.0f / 2048.0f;
-__device__ __forceinline__ void x3_split(f32x4 x, h4& hi, h4& lo) {
-    hi = __builtin_convertvector(x, h4);
-    lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x4)) * X3_UP, h4);
-}
-__device__ __forceinline__ f32x4 x3_join(h4 hi, h4 lo) {
-    return __builtin_convertvector(hi, f32x4) + __builtin_convertvector(lo, f32x4) * X3_DN;
-}
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void x3_split8(f32x4 x0, f32x4 x1, h8& hi, h8& lo) {
-    h4 h0, l0, h1, l1;
-    x3_split(x0, h0, l0);
-    x3_split(x1, h1, l1);
-    hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-    lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-}
 // Element index inside an fp16 plane: rows of 16 sixteen-byte slots (8 halfs = 8 consecutive k), slot index XOR-ed
 // with (row & 15): the ds_read_b128 of v_mfma_f32_16x16x32_f16's B operand (lane (row, q) reads slot 4 kt + q) and
 // the 8-byte stores of the epilogue are bank-conflict free.  `slot4` counts groups of 4 features, like lds_off.

@@ -280,7 +280,11 @@ int linear(const Plan& p, int Mrows, const float* A, int lda, int K1, const floa
         if (ks > 1 && (int64_t)ks * Mrows * NO <= p.part_floats) { a.part = p.part; a.ksplit = ks; }
     }
     const int grid = ((a.row_tiles + 7) / 8) * 8 * ((NO + BN - 1) / BN) * a.ksplit;
-    hipLaunchKernelGGL(tf_linear_kernel<0>, dim3(grid), dim3(LT), (BM * 128 + 2 * BM) * sizeof(float), p.s, a);
+    if (p.d->flags & PFM_EW_F_F16X3)
+        hipLaunchKernelGGL((tf_linear_kernel<0, 4, true>), dim3(grid), dim3(LT), (size_t)BM * X3ROW * 2 * 2 * 2 + 2 * BM * sizeof(float),
+                           p.s, a);
+    else
+        hipLaunchKernelGGL(tf_linear_kernel<0>, dim3(grid), dim3(LT), (BM * 128 + 2 * BM) * sizeof(float), p.s, a);
     int rc = check_hip(hipGetLastError(), "tf_linear_kernel launch (epicw)");
     if (rc || a.ksplit == 1) return rc;
     const int64_t n4 = (int64_t)Mrows * (NO / 4);

@@ -134,6 +134,24 @@ __device__ __forceinline__ f32x4 bload4(blob_rsrc rs, int64_t elem_off, int lane
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes, (int)(elem_off << 2), 0));
 }
 
+// split-fp16 operand helpers (PFM_F_F16X3_MFMA; see epic_nfe.h): x = hi + lo * 2^-11, hi = fp16(x), lo = fp16((x - hi) * 2^11)
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+constexpr float X3_UP = 2048.0f, X3_DN = 1.0f / 2048.0f;
+__device__ __forceinline__ void x3_split(f32x4 x, h4& hi, h4& lo) {
+    hi = __builtin_convertvector(x, h4);
+    lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x4)) * X3_UP, h4);
+}
+__device__ __forceinline__ f32x4 x3_join(h4 hi, h4 lo) {
+    return __builtin_convertvector(hi, f32x4) + __builtin_convertvector(lo, f32x4) * X3_DN;
+}
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void x3_split8(f32x4 x0, f32x4 x1, h8& hi, h8& lo) {
+    h4 h0, l0, h1, l1;
+    x3_split(x0, h0, l0);
+    x3_split(x1, h1, l1);
+    hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 __device__ __forceinline__ int lds_off(int p, int slot) { return p * H + ((slot ^ (p & 15)) << 2); }
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return fmaxf(x, x * slope); }

@@ -219,13 +219,18 @@ __device__ __forceinline__ bool tile_of_block(int bid, int row_tiles, int nchunk
 
 // NI = K / 64 of the LayerNorm prologue (0: no LayerNorm); TPW = 16-row tiles per wave: the workgroup's row tile is
 // RB = 16 TPW rows (64, or 32 when 64-row tiles would leave the last round of workgroups mostly empty)
-template <int NI, int TPW = 4>
+// X3: products on the fp16 matrix pipe with split operands (pfm_common.h: x = hi + lo 2^-11): per 64-wide step the
+// activation slice is published as two fp16 planes (rows of 72 halfs: conflict-free ds_read_b128 of 8 consecutive k),
+// the weights are split per wave from the same fp32 MFMA_AK block read in k8 order, three v_mfma_f32_16x16x32_f16
+// per (output tile, row tile, 32 k) accumulate into a main and a correction accumulator.
+constexpr int X3ROW = 72;  // halfs per LDS row of an X3 slice (64 + 8 pad)
+template <int NI, int TPW = 4, bool X3 = false>
 __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     constexpr bool LN = NI > 0;
     constexpr int RB = 16 * TPW, SI = RB / 16;  // SI: float4 staged per thread and 64-wide step
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const tile = lds;             // two RB x 64 slices, 16-byte slots XOR-swizzled with (row & 15)
-    float* const stat = lds + RB * 128;  // RB x (mean, rstd)
+    float* const stat = lds + (X3 ? RB * X3ROW * 2 : RB * 128);  // RB x (mean, rstd), behind the slices
     int rt, ch;
     const int ks = a.ksplit > 1 ? blockIdx.x % a.ksplit : 0;
     if (!tile_of_block(a.ksplit > 1 ? blockIdx.x / a.ksplit : blockIdx.x, a.row_tiles, (a.NO + BN - 1) / BN, rt, ch)) return;
@@ -247,6 +252,13 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
 
     // accumulators start from the bias (+ the jet-bias row of the particle's jet)
     f32x4 acc[2][TPW];
+    f32x4 cor[2][X3 ? TPW : 1];  // X3: correction accumulators (hi.wlo + lo.whi), scaled by 2^-11 at the end
+    if (X3) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < (X3 ? TPW : 1); ++t) cor[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int o = ob + 16 * s + 4 * q;
@@ -279,8 +291,16 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int64_t base = a.W + ((int64_t)((ob >> 4) + s) * nst_all + step) * 1024;
+                if (X3) {  // k8 order: af[2 kp + h] = k-tile 2 kp + (q >> 1), lane (pl, 2 (q & 1) + h)  (see load_afrag_k8)
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt) af[s][kt] = bload4(rs, base + kt * 256, lane * 16);
+                    for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            af[s][2 * kp + h] = bload4(rs, base + (2 * kp + (q >> 1)) * 256, (pl + 16 * (2 * (q & 1) + h)) * 16);
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) af[s][kt] = bload4(rs, base + kt * 256, lane * 16);
+                }
             }
         }
         const int col = 64 * step + 4 * sc4;
@@ -294,7 +314,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         }
     };
     auto step_fn = [&](f32x4 (&af)[2][4], f32x4 (&st)[SI], f32x4 (&afn)[2][4], f32x4 (&stn)[SI], int step) {
-        float* const buf = tile + (step & 1) * (RB * 64);
+        float* const buf = tile + (step & 1) * (X3 ? RB * X3ROW : RB * 64);  // X3: hi plane, lo plane RB * X3ROW halfs later
         if (LN) {
             const int col = 64 * step + 4 * sc4;
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + col);
@@ -306,14 +326,50 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
                 st[i] = (st[i] - mean) * rstd * g4 + b4;
             }
         }
+        if (X3) {
+            _Float16* hb = reinterpret_cast<_Float16*>(buf);
 #pragma unroll
-        for (int i = 0; i < SI; ++i) {
-            const int r = sr + 16 * i;
-            *reinterpret_cast<f32x4*>(buf + r * 64 + ((sc4 ^ (r & 15)) << 2)) = st[i];
+            for (int i = 0; i < SI; ++i) {
+                h4 hi, lo;
+                x3_split(st[i], hi, lo);
+                _Float16* dp = hb + (sr + 16 * i) * X3ROW + 4 * sc4;
+                *reinterpret_cast<h4*>(dp) = hi;
+                *reinterpret_cast<h4*>(dp + RB * X3ROW) = lo;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < SI; ++i) {
+                const int r = sr + 16 * i;
+                *reinterpret_cast<f32x4*>(buf + r * 64 + ((sc4 ^ (r & 15)) << 2)) = st[i];
+            }
         }
         __syncthreads();  // also orders this write after every wave's reads of the same slice two steps ago
         if (step + 1 < nst) request(afn, stn, step + 1);
         if (!active) return;
+        if (X3) {
+            const _Float16* hb = reinterpret_cast<const _Float16*>(buf);
+            h8 wh[2][2], wl[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp) x3_split8(af[s][2 * kp], af[s][2 * kp + 1], wh[s][kp], wl[s][kp]);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp) {
+                    const _Float16* bp = hb + (16 * t + pl) * X3ROW + 32 * kp + 8 * q;
+                    const h8 bh = *reinterpret_cast<const h8*>(bp);
+                    const h8 bl = *reinterpret_cast<const h8*>(bp + RB * X3ROW);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][kp], bh, acc[s][t], 0, 0, 0);
+                        cor[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][kp], bl, cor[s][t], 0, 0, 0);
+                        cor[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s][kp], bh, cor[s][t], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int tp = 0; tp < TPW / 2; ++tp) {
             const float* b0p = buf + (32 * tp + pl) * 64;
@@ -353,6 +409,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         for (int t = 0; t < TPW; ++t) {
             const int row = row0 + 16 * t + pl;
             if (!active) continue;
+            if (X3) acc[s][t] += cor[s][X3 ? t : 0] * X3_DN;
             if (row < a.M && a.ksplit > 1) {
                 *reinterpret_cast<f32x4*>(a.part + ((int64_t)ks * a.M + row) * a.NO + o) = acc[s][t];
             } else if (row < a.M) {

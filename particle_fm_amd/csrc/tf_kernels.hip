@@ -70,10 +70,14 @@ int launch_linear(const Plan& p, const float* A, int lda, int K, const pfm_tf_li
     const int rb = half ? 32 : 64;
     a.row_tiles = (p.M + rb - 1) / rb;
     const int grid = ((a.row_tiles + 7) / 8) * 8 * chunks;
-    const size_t lds = (rb * 128 + 2 * rb) * sizeof(float);
+    const bool x3 = (p.d->flags & PFM_TF_F_F16X3) != 0;
+    const size_t lds = x3 ? (size_t)rb * X3ROW * 2 * 2 * 2 + 2 * rb * sizeof(float) : (rb * 128 + 2 * rb) * sizeof(float);
     const int ni = (ln && ln->gamma >= 0) ? K / 64 : 0;
-#define PFM_LAUNCH_LIN(NI)                                                                          \
-    if (half) hipLaunchKernelGGL((tf_linear_kernel<NI, 2>), dim3(grid), dim3(LT), lds, p.s, a);     \
+#define PFM_LAUNCH_LIN(NI)                                                                                        \
+    if (x3) {                                                                                                     \
+        if (half) hipLaunchKernelGGL((tf_linear_kernel<NI, 2, true>), dim3(grid), dim3(LT), lds, p.s, a);         \
+        else hipLaunchKernelGGL((tf_linear_kernel<NI, 4, true>), dim3(grid), dim3(LT), lds, p.s, a);              \
+    } else if (half) hipLaunchKernelGGL((tf_linear_kernel<NI, 2>), dim3(grid), dim3(LT), lds, p.s, a);            \
     else hipLaunchKernelGGL((tf_linear_kernel<NI, 4>), dim3(grid), dim3(LT), lds, p.s, a);
     switch (ni) {
         case 0: PFM_LAUNCH_LIN(0) break;

@@ -20,6 +20,7 @@ import torch
 PFM_TF_ABI_VERSION = 1
 PFM_TF_MAX_LAYERS = 12
 HEAD_DIM = 16
+PFM_TF_F_F16X3 = 1
 
 
 class TfNorm(ctypes.Structure):
@@ -149,7 +150,8 @@ def default_freqs(t_dim: int) -> torch.Tensor:
 class TfLayout:
     """Descriptor + gather maps for one TfConfig."""
 
-    def __init__(self, cfg: TfConfig):
+    def __init__(self, cfg: TfConfig, flags: int = 0):
+        self.flags = flags
         D, Hd = cfg.model_dim, cfg.hidden
         if D % 128 or Hd % 128 or D > 512 or Hd > 512:
             raise NotImplementedError("the HIP transformer kernels need model_dim and hddn_dim to be multiples of 128, at most 512")
@@ -226,7 +228,7 @@ class TfLayout:
         d.abi_version = PFM_TF_ABI_VERSION
         d.n_points, d.features, d.model_dim, d.hidden, d.layers = cfg.num_particles, F, D, Hd, cfg.num_layers
         d.heads, d.head_dim, d.t_dim, d.cond_dim = cfg.num_heads, HEAD_DIM, T, cfg.global_cond_dim
-        d.ctxt_dim, d.ctxt_hidden, d.time_in_input, d.flags = CO, cfg.ctxt_hidden, int(cfg.add_time_to_input), 0
+        d.ctxt_dim, d.ctxt_hidden, d.time_in_input, d.flags = CO, cfg.ctxt_hidden, int(cfg.add_time_to_input), self.flags
         d.neg_slope, d.ln_eps = 0.1, 1e-5
         d.freqs = self._put(self.freq_off + np.arange(T), primary=False)
 

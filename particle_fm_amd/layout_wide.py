@@ -18,6 +18,7 @@ from .layout import EpicConfig, EpicLayout
 
 PFM_EW_ABI_VERSION = 1
 PFM_EW_MAX_LAYERS = 24
+PFM_EW_F_F16X3 = 1
 
 
 class EwLin(ctypes.Structure):
@@ -46,7 +47,8 @@ class EwDesc(ctypes.Structure):
 class EpicWideLayout(EpicLayout):
     """Descriptor + gather maps for one EpicConfig of any hidden_dim <= 512."""
 
-    def __init__(self, cfg: EpicConfig, with_backward: bool = True):
+    def __init__(self, cfg: EpicConfig, with_backward: bool = True, flags: int = 0):
+        self.flags = flags
         if cfg.hidden_dim > 512:
             raise NotImplementedError("hidden_dim > 512 is beyond this build's Linear kernel (K <= 512 per segment)")
         if cfg.layers > PFM_EW_MAX_LAYERS:
@@ -155,7 +157,7 @@ class EpicWideLayout(EpicLayout):
         d = EwDesc()
         d.abi_version = PFM_EW_ABI_VERSION
         d.n_points, d.features, d.hidden, d.hidden_pad, d.latent, d.layers = cfg.num_particles, F, H, Hp, L, cfg.layers
-        d.t_dim, d.cond_global, d.cond_local, d.flags = T, Cg, Cl, 0
+        d.t_dim, d.cond_global, d.cond_local, d.flags = T, Cg, Cl, self.flags
         d.sum_scale, d.neg_slope = cfg.sum_scale, cfg.neg_slope
         d.freqs = self._put(self.freq_off + np.arange(T), primary=False)
         ar = np.arange
