@@ -173,6 +173,7 @@ class FullTransformerEncoder(nn.Module):
         # what the kernels need to know beyond the reference's own arguments
         self.num_points, self.frequencies, self.add_time_to_input = num_points, frequencies, add_time_to_input
         self._layouts = {}
+        self.mfma_dtype = "fp32"  # "f16x3": every Linear on split-fp16 operands (PFM_TF_F_F16X3), fp32-grade accuracy
         self.cfg = self.config(num_points or 1)
         TfLayout(self.cfg)  # rejects unsupported sizes at construction
 
@@ -190,10 +191,15 @@ class FullTransformerEncoder(nn.Module):
 
     def layout(self, num_points: Optional[int] = None) -> TfLayout:
         n = num_points or self.num_points
-        lay = self._layouts.get(n)
+        flags = 1 if self.mfma_dtype == "f16x3" else 0
+        lay = self._layouts.get((n, flags))
         if lay is None:
-            lay = self._layouts[n] = TfLayout(self.config(n))
+            lay = self._layouts[(n, flags)] = TfLayout(self.config(n), flags=flags)
         return lay
+
+    def set_precision(self, precision) -> None:
+        """"f16x3" -> split-fp16 Linears; anything else (incl. Lightning's "bf16-mixed": no bf16 kernels on this path) fp32."""
+        self.mfma_dtype = "f16x3" if str(precision) == "f16x3" else "fp32"
 
     def flat_parameters(self, layout: Optional[TfLayout] = None) -> torch.Tensor:
         """All parameters in the layout's (= state_dict) order as one differentiable vector."""

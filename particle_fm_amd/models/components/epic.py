@@ -119,11 +119,16 @@ class EPiC_encoder(nn.Module):
 
     def layout(self, num_points: Optional[int] = None) -> EpicLayout:
         n = num_points or self.num_points
-        mode = 0 if self.wide else {"fp32": 0, "bf16": 2, "f16x3": 4}[self.mfma_dtype]
+        if self.wide:  # row-matrix GEMM path: only the split-fp16 flavour exists besides fp32
+            mode = 1 if self.mfma_dtype == "f16x3" else 0
+        else:
+            mode = {"fp32": 0, "bf16": 2, "f16x3": 4}[self.mfma_dtype]
         lay = self._layouts.get((n, mode))
         if lay is None:
-            flags = (1 if self.skip_masked_tail else 0) | mode
-            lay = EpicWideLayout(self.config(n)) if self.wide else EpicLayout(self.config(n), flags=flags)
+            if self.wide:
+                lay = EpicWideLayout(self.config(n), flags=mode)
+            else:
+                lay = EpicLayout(self.config(n), flags=(1 if self.skip_masked_tail else 0) | mode)
             self._layouts[(n, mode)] = lay
         return lay
 

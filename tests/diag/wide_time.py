@@ -11,7 +11,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 cfg = EpicConfig(num_particles=128, features=13, hidden_dim=300, latent=16, layers=20, frequencies=16, t_local_cat=True,
                  t_global_cat=True, global_cond_dim=12, local_cond_dim=0)
-lay = EpicWideLayout(cfg, with_backward=False)
+lay = EpicWideLayout(cfg, with_backward=False, flags=1 if "x3" in sys.argv else 0)
 shapes = {}
 for name, i, o in cfg.linear_shapes():
     shapes[name + ".bias"] = (o,); shapes[name + ".weight_g"] = (o, 1); shapes[name + ".weight_v"] = (o, i)
