@@ -1,0 +1,59 @@
+"""The numerical claim behind PFM_F_F16X3_MFMA, checked on the CPU: every Linear of the oracle evaluated as
+hi.whi + 2^-11 (hi.wlo + lo.whi) on (hi, lo) fp16 splits of BOTH operands (fp32 accumulate) reproduces the reference
+vectors at the level of fp32 re-association noise -- while a single fp16 product, or bf16 operands, do not."""
+import pytest
+import torch
+
+import oracle.epic_ref as er
+from oracle.fm_ref import EpicVectorField, sample_midpoint
+
+
+def _split(x, dt):
+    h = x.to(dt).float()
+    return h, ((x - h) * 2048.0).to(dt).float()
+
+
+def _linear(dt, terms):
+    def wn_linear(state, prefix, inp):
+        v, g, b = state[prefix + ".weight_v"], state[prefix + ".weight_g"], state[prefix + ".bias"]
+        w = v * (g / v.norm(dim=1, keepdim=True))
+        xh, xl = _split(inp, dt)
+        wh, wl = _split(w, dt)
+        y = xh @ wh.t()
+        if terms == 3:
+            y = y + (xh @ wl.t() + xl @ wh.t()) / 2048.0
+        return y + b
+    return wn_linear
+
+
+@pytest.fixture
+def patched(monkeypatch):
+    def use(dt, terms):
+        monkeypatch.setattr(er, "wn_linear", _linear(dt, terms))
+    return use
+
+
+def _errors(g):
+    vf = EpicVectorField(g.state, "flows.0.net", g.hp, freqs=g.freqs)
+    x, t, mask, cond = (g.get("nfe_f32/" + k) for k in ("x", "t", "mask", "cond"))
+    z, mm, cm = (g.get("midpoint_100/" + k) for k in ("z", "mask", "cond"))
+    with torch.no_grad():
+        v = vf(t[:, None].expand(-1, x.shape[1]), x, cond=cond, mask=mask)
+        xe = sample_midpoint(vf, z, cm, mm, 100)
+    return float((v - g.get("nfe_f32/v_vec_t")).abs().max()), float((xe - g.get("midpoint_100/x_end")).abs().max())
+
+
+def test_split_fp16_products_are_fp32_grade(golden, patched):
+    patched(torch.float16, 3)
+    e_nfe, e_smp = _errors(golden)
+    assert e_nfe < 3e-6 and e_smp < 5e-6, (e_nfe, e_smp)   # measured 3e-7 .. 6e-7, the fp32 oracle itself is at 1e-7 .. 4e-7
+
+
+def test_what_does_not_work(patched):
+    from tests.conftest import load_golden
+    g = load_golden("jetnet150")
+    patched(torch.float16, 1)        # one fp16 product per term: 1e-4 class
+    assert _errors(g)[0] > 5e-5
+    patched(torch.bfloat16, 3)       # split bf16 (16 significant bits): an order of magnitude worse than split fp16
+    e = _errors(g)[0]
+    assert 2e-6 < e < 1e-4
