@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Secondary benchmark lines: the BASELINE configurations bench.py does not run (it measures cfg 3, the one the
+metric is quoted on).  One JSON line per workload, same schema as bench.py, single GPU:
+
+    python bench_secondary.py [--workload jetnet30|lhco_transformer|jetclass|all] [--steps K] [--warmup W] [--precision fp32|f16x3]
+
+step = 1 train step (loss forward + backward through the HIP kernels, clip 0.5 + AdamW + EMA) + 1 midpoint sample
+(ode_steps = 100, 198 NFE) on the configuration's batch; inputs synthetic and resident in HBM.  `roofline.achieved` is
+the algorithmic FLOP rate of the sampling launches (dense over the padded N) against the fp32 MFMA peak.
+`cpu_baseline` = the oracle on the host cores on a bounded sample (a few jets, 3-step sample scaled to 100 steps: stated).
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from bench import FP32_MFMA_PEAK, usable_cores  # noqa: E402
+
+EPIC = dict(model="epic", frequencies=16, activation="leaky_relu", wrapper_func="weight_norm", t_local_cat=True,
+            t_global_cat=True, add_time_to_input=False, t_emb="cosine", loss_type="FM-OT", sigma=1e-4, dropout=0.0, sum_scale=1e-2)
+TF_NET = dict(
+    node_embd_config=dict(act_h="lrlu", nrm="layer"), ctxt_embd_config=dict(outp_dim=64, act_h="lrlu", nrm="layer"),
+    te_config=dict(model_dim=256, num_layers=3, mha_config=dict(num_heads=16, init_zeros=True, do_layer_norm=True),
+                   dense_config=dict(act_h="lrlu", nrm="layer", output_init_zeros=True)),
+    outp_embd_config=dict(act_h="lrlu", nrm="layer", output_init_zeros=True))
+WORKLOADS = {
+    # name: (hparams, batch, n_min, Cg, algorithmic fwd FLOP / jet / NFE, description)
+    "jetnet30": (dict(EPIC, features=3, hidden_dim=128, num_particles=30, layers=6, latent=10, global_cond_dim=0, local_cond_dim=0),
+                 1024, 10, 0, 17.29e6, "cfg 2: EPiC-FM JetNet30 (N=30, F=3, H=128, 6 layers), batch 1024 (fp32 here; bf16 operands: bench.py / tests/diag/bf16_time.py)"),
+    "lhco_transformer": (dict(model="droid_fulltransformer", features=3, num_particles=279, frequencies=16, global_cond_dim=5,
+                              add_time_to_input=True, t_emb="cosine", loss_type="FM-OT", sigma=1e-4, net_config=TF_NET),
+                         128, 20, 5, 1365e6, "cfg 4: Full-Transformer LHCO (N=279, D=256, 3 layers, 16 heads, 2088515 params), batch 128"),
+    "jetclass": (dict(EPIC, features=13, hidden_dim=300, num_particles=128, layers=20, latent=16, global_cond_dim=12, local_cond_dim=0),
+                 256, 20, 12, 1083.1e6, "cfg 5: EPiC-FM JetClass (N=128, F=13, H=300, L=16, 20 layers, Cg=12, 8504698 params), batch 256"),
+}
+
+
+def make_batch(B, N, F, C, n_min, seed):
+    gen = torch.Generator().manual_seed(seed)
+    n = torch.randint(n_min, N + 1, (B,), generator=gen)
+    mask = (torch.arange(N)[None] < n[:, None]).float().unsqueeze(-1)
+    x = torch.randn(B, N, F, generator=gen) * mask
+    cond = torch.randn(B, C, generator=gen) if C else torch.zeros(B)
+    return x, mask, cond
+
+
+def cpu_baseline(name, hp, state, jets, C, n_min):
+    """Oracle (eager PyTorch restatement of the reference graph) on the host cores: 1 train step + a 3-step midpoint
+    sample (4 NFE) scaled to the 198 NFE of ode_steps = 100."""
+    from oracle.fm_ref import EpicVectorField, fm_ot_loss, sample_midpoint
+    from oracle.tf_ref import TransformerVectorField
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    N, F = hp["num_particles"], hp["features"]
+    x, mask, cond = make_batch(jets, N, F, C, n_min, 4242)
+    cond = cond if C else None
+    st = {k: v.clone().requires_grad_(v.is_floating_point() and "frequencies" not in k) for k, v in state.items()}
+    params = [v for v in st.values() if v.requires_grad]
+    if hp["model"] == "epic":
+        vf = EpicVectorField(st, "flows.0.net", dict(hp, sum_scale=1e-2))
+    else:
+        vf = TransformerVectorField(st, "flows.0.", hp)
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=5e-5)
+    t0 = time.perf_counter()
+    opt.zero_grad()
+    loss, *_ = fm_ot_loss(vf, x, mask, cond, torch.rand(jets), torch.randn_like(x), sigma=1e-4)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(params, 0.5)
+    opt.step()
+    t_train = time.perf_counter() - t0
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        sample_midpoint(vf, torch.randn(jets, N, F), cond, mask, ode_steps=3)
+        t_sample = (time.perf_counter() - t0) * 198 / 4
+    return {"value": jets / (t_train + t_sample), "unit": "jets/s", "cores": cores, "kind": "port",
+            "sample": f"{jets} jets: 1 train step + a 3-step midpoint sample (4 NFE) scaled x 198/4 to ode_steps=100; eager-PyTorch "
+                      f"oracle, fp32, torch threads = {cores}",
+            "train_jets_per_s": jets / t_train, "sample_jets_per_s": jets / t_sample}
+
+
+def run(name, args):
+    from particle_fm_amd.engine import FusedFMTrainer
+    from particle_fm_amd.models import SetFlowMatchingLitModule
+    hp, B, n_min, C, flop, what = WORKLOADS[name]
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(12345)
+    model = SetFlowMatchingLitModule(optimizer=None, **copy.deepcopy(hp))
+    if hp["model"] != "epic":  # init_zeros / output_init_zeros make an untrained transformer's field identically 0
+        with torch.no_grad():
+            for p in model.parameters():
+                if float(p.abs().sum()) == 0.0 and p.dim() == 2:
+                    p.uniform_(-1.0, 1.0).div_(p.shape[1] ** 0.5)
+    model = model.to(dev)
+    state_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if k.startswith("flows.")}
+    net = model.flows[0].net
+    if args.precision != "fp32":
+        net.set_precision(args.precision)
+    trainer = FusedFMTrainer(model, lr=1e-3, weight_decay=5e-5, max_grad_norm=0.5, ema_decay=0.999)
+    N, F = hp["num_particles"], hp["features"]
+    x, mask, cond = (a.to(dev) for a in make_batch(B, N, F, C, n_min, 12345))
+    z = (torch.randn(B, N, F, generator=torch.Generator().manual_seed(9999)) * mask.cpu()).to(dev)
+    cnd = cond if C else None
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        trainer.step((x, mask, cond))
+        if ev:
+            ev[1].record()
+        with torch.no_grad():
+            out = model(z, cond=cnd, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps)
+        if ev:
+            ev[2].record()
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for e in evs:
+        out = step(e)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out[mask.squeeze(-1) > 0]).all()
+    train_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
+    sample_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
+    n_nfe = 2 * (args.ode_steps - 1)
+    achieved = B * n_nfe * flop / (sample_ms * 1e-3)
+    res = {
+        "metric": "jets/sec (train step + 100-step ODE sample)", "value": B * args.steps / elapsed, "unit": "jets/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else f"f32 ({args.precision} matrix operands)",
+        "data": "synthetic",
+        "config": {"workload": what, "jets_per_gpu": B, "parallelism": "dp1", "ode_steps": args.ode_steps,
+                   "multiplicity": f"U{{{n_min}..{N}}} per jet"},
+        "train_ms": train_ms, "sample_ms": sample_ms, "train_jets_per_s": B / (train_ms * 1e-3),
+        "sample_jets_per_s": B / (sample_ms * 1e-3),
+        "roofline": {"bound": "mfma", "kernel": "sampling launches (tf_linear_kernel dominates)" if name != "jetnet30" else "epic_sample_midpoint_kernel",
+                     "achieved": achieved / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK,
+                     "traffic": None,
+                     "note": f"algorithmic {flop/1e6:.1f} MFLOP/jet/NFE x {n_nfe} NFE x {B} jets / HIP-event time of the sampling launches"},
+    }
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(name, hp, state_cpu, 8 if name != "jetnet30" else 64, C, n_min)
+    print(json.dumps(res), flush=True)
+    del trainer, model
+    torch.cuda.empty_cache()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="all", choices=list(WORKLOADS) + ["all"])
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ode-steps", type=int, default=100)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_secondary.py needs an MI355X (the HIP path has no CPU fallback)")
+    for name in (WORKLOADS if args.workload == "all" else [args.workload]):
+        run(name, args)
+
+
+if __name__ == "__main__":
+    main()
