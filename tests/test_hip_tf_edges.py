@@ -82,3 +82,31 @@ def test_empty_batch_and_bad_arguments():
         ref = vf(t[0], x, cond=None, mask=None)
     v = opw.ew_forward(wl, wblob, t.cuda(), x.cuda(), None, None).cpu()
     torch.testing.assert_close(v, ref, atol=2e-5, rtol=2e-4)
+
+
+def test_wide_compaction_with_many_jets():
+    """1300 jets (> 1024: the single-workgroup scan walks several jets per thread), random masks incl. empty jets."""
+    from particle_fm_amd import hip_ops_wide as opw
+    from particle_fm_amd.layout import EpicConfig
+    from particle_fm_amd.layout_wide import EpicWideLayout
+    cfg = EpicConfig(num_particles=8, features=3, hidden_dim=64, latent=4, layers=1, frequencies=16, t_local_cat=True,
+                     t_global_cat=True, global_cond_dim=0, local_cond_dim=0)
+    wl = EpicWideLayout(cfg)
+    shapes = {}
+    for name, i, o in cfg.linear_shapes():
+        shapes[name + ".bias"], shapes[name + ".weight_g"], shapes[name + ".weight_v"] = (o,), (o, 1), (o, i)
+    st = {k: torch.from_numpy(v) for k, v in seeded_state(shapes, 9).items()}
+    blob = wl.pack_blob(st).cuda()
+    gen = torch.Generator().manual_seed(4)
+    B, N = 1300, 8
+    mask = (torch.rand(B, N, 1, generator=gen) < 0.5).float()
+    x = torch.randn(B, N, 3, generator=gen) * mask
+    t = torch.rand(B, generator=gen)
+    hp = dict(frequencies=16, layers=1, t_local_cat=True, t_global_cat=True, global_cond_dim=0, local_cond_dim=0, sum_scale=1e-2)
+    vf = EpicVectorField(st, "", hp, freqs=wl.default_freqs())
+    with torch.no_grad():
+        ref = vf(t[:, None].expand(B, N), x, cond=None, mask=mask)
+    v = opw.ew_forward(wl, blob, t.cuda(), x.cuda(), None, mask.cuda()).cpu()
+    empty = mask.sum((1, 2)) == 0
+    assert empty.any() and torch.isnan(v[empty]).all() and torch.isnan(ref[empty]).all()
+    torch.testing.assert_close(v[~empty], ref[~empty], atol=2e-5, rtol=2e-4)
