@@ -46,6 +46,7 @@ extern "C" {
 
 #define PFM_TF_ABI_VERSION 1
 #define PFM_TF_MAX_LAYERS 12
+#define PFM_TF_F_TEMB_SINCOS 2 /* t_emb="sincos": temb = [cos(f t) ; sin(f t)], freqs table = [f ; f] (flow_matching_module.py:208-211) */
 #define PFM_TF_F_F16X3 1 /* desc.flags: every Linear (forward and dX) as three fp16 MFMAs on (hi, lo) splits of both operands,
                             fp32 accumulate: fp32-grade products (see PFM_F_F16X3_MFMA in pfm_hip.h); needs |x| < 65504 */
 

@@ -49,6 +49,20 @@ def time_embedding_cosine(t: torch.Tensor, x: torch.Tensor, t_dim: int, freqs=No
     return emb.expand(*x.shape[:-1], -1)
 
 
+def time_embedding(t: torch.Tensor, x: torch.Tensor, hp: Mapping, freqs=None) -> torch.Tensor:
+    """CNF.time_embedding (flow_matching_module.py:206-233) for t_emb in {"cosine", "sincos"}.
+    sincos (:208-211): t = frequencies * t[..., None]; cat(cos, sin); frequencies = 2**arange(F) * pi (:172) -- pass the
+    module's buffer as ``freqs`` (F values) or leave None to rebuild it."""
+    kind = hp.get("t_emb", "cosine")
+    if kind == "cosine":
+        return time_embedding_cosine(t, x, 2 * hp["frequencies"], freqs)
+    if kind != "sincos":
+        raise NotImplementedError(kind)
+    f = 2 ** torch.arange(hp["frequencies"]) * torch.pi if freqs is None else freqs[: hp["frequencies"]]  # ([f ; f] tables too)
+    a = f * t[..., None]
+    return torch.cat((a.cos(), a.sin()), dim=-1).expand(*x.shape[:-1], -1)
+
+
 class EpicVectorField:
     """CNF.forward for model="epic", t_emb="cosine" (flow_matching_module.py:191-204)."""
 
@@ -61,7 +75,7 @@ class EpicVectorField:
     def __call__(self, t, x, cond=None, mask=None):
         hp = self.hp
         t_dim = 2 * hp["frequencies"]
-        temb = time_embedding_cosine(t, x, t_dim, self.freqs)
+        temb = time_embedding(t, x, hp, self.freqs)
         if hp.get("add_time_to_input", False):
             x = torch.cat((temb, x), dim=-1)  # :199-200
         return epic_encoder(

@@ -293,6 +293,8 @@ TF_CONFIGS = {
     # the yaml's own sizes (experiment/lhco/jets_transformer.yaml:26-31): weights are re-derived from the seed
     # by oracle/seeded.py instead of being stored; gradients are stored sub-sampled
     "lhco": (dict(TF_BASE, num_particles=279, global_cond_dim=5, net_config=tf_net_config(256, 3, 16)), 2, False),
+    "sincos": (dict(TF_BASE, num_particles=20, global_cond_dim=2, t_emb="sincos", frequencies=6,
+                    net_config=tf_net_config(128, 1, 8)), 3, False),
 }
 
 
@@ -321,7 +323,8 @@ def gen_transformer(ref, name, hp, B, store_all, out_dir, seed=2024):
     out["_shapes_json"] = np.array(json.dumps({"flows.0." + k: list(s) for k, s in shapes.items()}))
     out["seed"] = np.array(seed)
     out["hp_json"] = np.array(json.dumps(hp))
-    out["freqs"] = torch.arange(2 * hp["frequencies"]).exp().numpy()
+    # cosine: the exp(arange) table of THIS machine (host-dependent, see oracle/fm_ref.py); sincos: the module buffer (:172)
+    out["freqs"] = (torch.arange(2 * hp["frequencies"]).exp() if hp["t_emb"] == "cosine" else cnf.frequencies.clone()).numpy()
     out["abs_sum"] = np.array(sum(float(np.abs(v).sum(dtype=np.float64)) for v in new.values()))
     out["init_sums"] = init
     if store_all:
@@ -407,6 +410,8 @@ WIDE_BASE = dict(BASE, features=13, hidden_dim=300, latent=16, global_cond_dim=1
 WIDE_CONFIGS = {
     "small": (dict(WIDE_BASE, num_particles=24, layers=2), 4),
     "jetclass": (dict(WIDE_BASE, num_particles=128, layers=20), 2),
+    # the class default t_emb="sincos" (flow_matching_module.py:104, 208-211) at hidden 128: both EPiC kernels
+    "sincos": (dict(BASE, num_particles=24, layers=2, global_cond_dim=2, local_cond_dim=2, t_emb="sincos", frequencies=6), 4),
 }
 
 
@@ -429,7 +434,8 @@ def gen_epic_wide(ref, name, hp, B, out_dir, seed=777):
     out["_shapes_json"] = np.array(json.dumps({"flows.0." + k: list(s) for k, s in shapes.items()}))
     out["seed"] = np.array(seed)
     out["hp_json"] = np.array(json.dumps(hp))
-    out["freqs"] = torch.arange(2 * hp["frequencies"]).exp().numpy()
+    # cosine: the exp(arange) table of THIS machine (host-dependent, see oracle/fm_ref.py); sincos: the module buffer (:172)
+    out["freqs"] = (torch.arange(2 * hp["frequencies"]).exp() if hp["t_emb"] == "cosine" else cnf.frequencies.clone()).numpy()
     out["abs_sum"] = np.array(sum(float(np.abs(v).sum(dtype=np.float64)) for v in new.values()))
     gen = torch.Generator().manual_seed(seed + 1)
     for mk in ("f32", "int64", "none"):

@@ -26,7 +26,7 @@ from typing import Mapping, Optional
 import torch
 import torch.nn.functional as F
 
-from .fm_ref import time_embedding_cosine
+from .fm_ref import time_embedding
 
 LRLU_SLOPE = 0.1  # droid_transformer.py:1022
 
@@ -110,7 +110,7 @@ class TransformerVectorField:
 
     def __call__(self, t, x, cond=None, mask=None, intermediates=None):
         hp = self.hp
-        temb = time_embedding_cosine(t, x, 2 * hp["frequencies"], self.freqs)
+        temb = time_embedding(t, x, hp, self.freqs)
         if hp.get("add_time_to_input", True):
             x = torch.cat((temb, x), dim=-1)
         te = hp["net_config"]["te_config"]

@@ -792,8 +792,14 @@ __device__ __forceinline__ void epic_time_embedding(const pfm_epic_desc& d, cons
     const int tid = threadIdx.x;
     if (tid < j.T) {
         const float f = blob[d.freqs + tid];
-        const float arg = __fdiv_rn(__fmul_rn(__fmul_rn(__fadd_rn(t, 0.0f), f), 3.14159274101257324f), 1.0f);
-        const float e = cosf(arg);
+        float e;
+        if (d.flags & PFM_F_TEMB_SINCOS) {  // flow_matching_module.py:208-211: cat(cos(f t), sin(f t)), f = 2^k pi (table holds [f ; f])
+            const float arg = __fmul_rn(f, t);
+            e = 2 * tid < j.T ? cosf(arg) : sinf(arg);
+        } else {
+            const float arg = __fdiv_rn(__fmul_rn(__fmul_rn(__fadd_rn(t, 0.0f), f), 3.14159274101257324f), 1.0f);
+            e = cosf(arg);
+        }
         lds[c.vin + tid] = e;
         lds[c.vin2 + tid] = e;
     }

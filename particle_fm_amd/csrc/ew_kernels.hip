@@ -19,15 +19,20 @@ using namespace pfm::tf;
 // P[jet][0 .. 256 + Hp) = [temb | cond | 0 ; 0 (g) ; 0 (g1)]
 __global__ __launch_bounds__(256) void ew_prep_kernel(const float* __restrict__ blob, int64_t freqs, const float* __restrict__ t,
                                                       int t_stride, const float* __restrict__ cond, float* __restrict__ P, int T,
-                                                      int C, int ldp, int64_t pstride) {
+                                                      int C, int ldp, int64_t pstride, int sincos) {
     const int jet = blockIdx.x;
     float* row = P + (int64_t)blockIdx.y * pstride + (int64_t)jet * ldp;  // blockIdx.y: stage copy (train layout)
     for (int c = threadIdx.x; c < ldp; c += 256) {
         float v = 0.f;
         if (c < T) {
             // time_emb.py:90-96, exact fp32 op order ((t + min) * f) * pi / (max + min)
-            const float tj = t[(int64_t)jet * t_stride];
-            v = cosf(__fdiv_rn(__fmul_rn(__fmul_rn(__fadd_rn(tj, 0.0f), blob[freqs + c]), 3.14159274101257324f), 1.0f));
+            const float tj = t[(int64_t)jet * t_stride], f = blob[freqs + c];
+            if (sincos) {  // flow_matching_module.py:208-211 (table = [f ; f], f = 2^k pi)
+                const float arg = __fmul_rn(f, tj);
+                v = 2 * c < T ? cosf(arg) : sinf(arg);
+            } else {
+                v = cosf(__fdiv_rn(__fmul_rn(__fmul_rn(__fadd_rn(tj, 0.0f), f), 3.14159274101257324f), 1.0f));
+            }
         } else if (c < T + C) {
             v = cond[(int64_t)jet * C + c - T];
         }
@@ -307,7 +312,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
     int rc;
     const int stages = w.pstride ? d.layers + 1 : 1;
     hipLaunchKernelGGL(ew_prep_kernel, dim3(B, stages), dim3(256), 0, p.s, p.blob, d.freqs, t, t_stride, cond, Pst(0), d.t_dim,
-                       d.cond_global, ldp, w.pstride);
+                       d.cond_global, ldp, w.pstride, (d.flags & PFM_EW_F_TEMB_SINCOS) ? 1 : 0);
     PFM_TRY(check_hip(hipGetLastError(), "ew_prep_kernel launch"));
     PFM_TRY(linear(p, B, Pst(0), ldp, 256, nullptr, 0, 256, d.sjb, 2 * Hp + 128, nullptr, 0, 1, nullptr, 0, SJB, (int)sjbs, 0));
     // stem: fc_l1 (F columns on the VALU), fc_l2 (residual inside the activation, epic.py:327-328)

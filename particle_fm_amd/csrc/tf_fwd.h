@@ -47,7 +47,7 @@ struct CtxtArgs {
     const float* t;
     const float* cond;
     float *temb, *chid, *ctxt, *jb;
-    int t_stride, T, C, CH, CO, Hd, nb;
+    int t_stride, T, C, CH, CO, Hd, nb, sincos;
     float slope, eps;
     int64_t freqs, c1W, c1b, cg, cb, c2W, c2b, n1Wt;
     int64_t Wc[PFM_TF_MAX_LAYERS + 2], bb[PFM_TF_MAX_LAYERS + 2];
@@ -65,8 +65,13 @@ static __global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
         // time_emb.py:90-96, exact fp32 op order ((t + min) * f) * pi / (max + min)
         const float t = a.t[(int64_t)jet * a.t_stride];
         const float f = blob[a.freqs + tid];
-        const float arg = __fdiv_rn(__fmul_rn(__fmul_rn(__fadd_rn(t, 0.0f), f), 3.14159274101257324f), 1.0f);
-        const float e = cosf(arg);
+        float e;
+        if (a.sincos) {  // flow_matching_module.py:208-211 (table = [f ; f], f = 2^k pi)
+            const float arg = __fmul_rn(f, t);
+            e = 2 * tid < a.T ? cosf(arg) : sinf(arg);
+        } else {
+            e = cosf(__fdiv_rn(__fmul_rn(__fmul_rn(__fadd_rn(t, 0.0f), f), 3.14159274101257324f), 1.0f));
+        }
         cin[tid] = e;
         a.temb[(int64_t)jet * 64 + tid] = e;
     } else if (tid < a.T + a.C) {

@@ -132,7 +132,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         a.blob = p.blob; a.t = t; a.cond = cond;
         a.temb = ws + w.temb; a.chid = ws + w.chid; a.ctxt = ws + w.ctxt; a.jb = ws + w.jb;
         a.t_stride = t_stride; a.T = d.t_dim; a.C = d.cond_dim; a.CH = d.ctxt_hidden; a.CO = d.ctxt_dim; a.Hd = Hd; a.nb = nb;
-        a.slope = d.neg_slope; a.eps = d.ln_eps;
+        a.slope = d.neg_slope; a.eps = d.ln_eps; a.sincos = (d.flags & PFM_TF_F_TEMB_SINCOS) ? 1 : 0;
         a.freqs = d.freqs; a.c1W = d.c1.W; a.c1b = d.c1.b; a.cg = d.c_norm.gamma; a.cb = d.c_norm.beta;
         a.c2W = d.c2.W; a.c2b = d.c2.b; a.n1Wt = d.time_in_input ? d.n1.Wt : -1;
         a.Wc[0] = d.n1.Wc; a.bb[0] = d.n1.b;

@@ -40,5 +40,7 @@ def tf_fm_loss(layout: TfLayout, flat_params: torch.Tensor, x, t, a, cond=None, 
     """flat_params: concatenation of the parameters in layout.keys() order (requires_grad as the caller wishes)."""
     from .layout_tf import default_freqs
 
-    f = default_freqs(layout.cfg.t_dim) if freqs is None else freqs
+    f = default_freqs(layout.cfg.t_dim, layout.cfg.t_emb) if freqs is None else freqs
+    if layout.cfg.t_emb == "sincos" and f.numel() == layout.cfg.frequencies:
+        f = torch.cat([f, f])
     return TfFMLossFn.apply(flat_params, layout, f, x, t, a, eps, cond, mask, float(sigma), kind)

@@ -29,6 +29,7 @@ PFM_HIDDEN = 128
 PFM_F_SKIP_MASKED_TAIL = 1
 PFM_F_BF16_MFMA = 2
 PFM_F_F16X3_MFMA = 4
+PFM_F_TEMB_SINCOS = 8
 
 
 class LocalLin(ctypes.Structure):
@@ -116,6 +117,7 @@ class EpicConfig:
     local_cond_dim: int = 0
     sum_scale: float = 1e-2
     neg_slope: float = 0.01  # F.leaky_relu default (epic.py:180)
+    t_emb: str = "cosine"   # or "sincos" (flow_matching_module.py:208-211)
 
     @property
     def t_local(self) -> int:
@@ -187,7 +189,7 @@ class EpicLayout:
         self._in = {name: i for name, i, _ in self.linears}
         self._out = {name: oo for name, _, oo in self.linears}
         self._build()
-        self.desc.flags = flags
+        self.desc.flags = flags | (PFM_F_TEMB_SINCOS if cfg.t_emb == "sincos" else 0)
 
     # -- helpers -------------------------------------------------------------------------------
     def _w(self, name: str, rows: np.ndarray, cols: np.ndarray) -> np.ndarray:
@@ -387,6 +389,9 @@ class EpicLayout:
         """exp(0..T-1) of time_emb.py:90 as correctly rounded fp32 (via float64).  The reference's own
         fp32 ``torch.arange(T).exp()`` differs between hosts by 1 ulp in some elements, which the
         1e13-sized cosine arguments amplify to O(1); the product therefore fixes the table."""
+        if self.cfg.t_emb == "sincos":  # [f ; f] with f = 2^k pi, exactly the module buffer (flow_matching_module.py:172)
+            f = 2 ** torch.arange(self.cfg.frequencies) * torch.pi
+            return torch.cat([f, f]).to(torch.float32)
         return torch.arange(self.cfg.t_dim, dtype=torch.float64).exp().to(torch.float32)
 
     def source_vector(self, state: Mapping[str, torch.Tensor], prefix: str = "", freqs: torch.Tensor = None) -> torch.Tensor:
@@ -402,6 +407,8 @@ class EpicLayout:
             any_t = v
         if freqs is None:
             freqs = self.default_freqs()
+        elif self.cfg.t_emb == "sincos" and freqs.numel() == self.cfg.frequencies:
+            freqs = torch.cat([freqs, freqs])  # the module buffer holds f once
         freqs = freqs.to(device=any_t.device, dtype=any_t.dtype)
         zero = torch.zeros(1, device=any_t.device, dtype=any_t.dtype)
         return torch.cat(ws + bs + [freqs, zero])

@@ -21,6 +21,7 @@ PFM_TF_ABI_VERSION = 1
 PFM_TF_MAX_LAYERS = 12
 HEAD_DIM = 16
 PFM_TF_F_F16X3 = 1
+PFM_TF_F_TEMB_SINCOS = 2
 
 
 class TfNorm(ctypes.Structure):
@@ -71,6 +72,7 @@ class TfConfig:
     frequencies: int = 16
     global_cond_dim: int = 0
     add_time_to_input: bool = True
+    t_emb: str = "cosine"   # or "sincos" (flow_matching_module.py:208-211)
 
     @property
     def t_dim(self) -> int:
@@ -102,7 +104,7 @@ class TfConfig:
             num_layers=int(te.get("num_layers", 3)), num_heads=int(mha.get("num_heads", 1)), hidden=hid.pop(),
             ctxt_hidden=int(ctxt.get("hddn_dim", 2 * D)), ctxt_dim=int(ctxt["outp_dim"]),
             frequencies=int(hp.get("frequencies", 6)), global_cond_dim=int(hp.get("global_cond_dim", 0)),
-            add_time_to_input=bool(hp.get("add_time_to_input", False)),
+            add_time_to_input=bool(hp.get("add_time_to_input", False)), t_emb=str(hp.get("t_emb", "cosine")),
         )
 
     def param_shapes(self) -> List[Tuple[str, Tuple[int, ...]]]:
@@ -141,9 +143,13 @@ class TfConfig:
         return sum(int(np.prod(s)) for _, s in self.param_shapes())
 
 
-def default_freqs(t_dim: int) -> torch.Tensor:
-    """exp(0..T-1) of time_emb.py:90 as correctly rounded fp32 (see EpicLayout.default_freqs: the reference's fp32
-    ``arange(T).exp()`` is host-dependent in the last bit, so the product fixes the table)."""
+def default_freqs(t_dim: int, t_emb: str = "cosine") -> torch.Tensor:
+    """cosine: exp(0..T-1) of time_emb.py:90 as correctly rounded fp32 (see EpicLayout.default_freqs: the reference's fp32
+    ``arange(T).exp()`` is host-dependent in the last bit, so the product fixes the table).
+    sincos: [f ; f] with f = 2^k pi, the module buffer of flow_matching_module.py:172."""
+    if t_emb == "sincos":
+        f = (2 ** torch.arange(t_dim // 2) * torch.pi).to(torch.float32)
+        return torch.cat([f, f])
     return torch.arange(t_dim, dtype=torch.float64).exp().to(torch.float32)
 
 
@@ -228,7 +234,7 @@ class TfLayout:
         d.abi_version = PFM_TF_ABI_VERSION
         d.n_points, d.features, d.model_dim, d.hidden, d.layers = cfg.num_particles, F, D, Hd, cfg.num_layers
         d.heads, d.head_dim, d.t_dim, d.cond_dim = cfg.num_heads, HEAD_DIM, T, cfg.global_cond_dim
-        d.ctxt_dim, d.ctxt_hidden, d.time_in_input, d.flags = CO, cfg.ctxt_hidden, int(cfg.add_time_to_input), self.flags
+        d.ctxt_dim, d.ctxt_hidden, d.time_in_input, d.flags = CO, cfg.ctxt_hidden, int(cfg.add_time_to_input), self.flags | (PFM_TF_F_TEMB_SINCOS if cfg.t_emb == "sincos" else 0)
         d.neg_slope, d.ln_eps = 0.1, 1e-5
         d.freqs = self._put(self.freq_off + np.arange(T), primary=False)
 
@@ -294,7 +300,9 @@ class TfLayout:
     def source_vector(self, state: Mapping[str, torch.Tensor], prefix: str = "", freqs=None) -> torch.Tensor:
         parts = [state[prefix + k].reshape(-1).to(torch.float32) for k, _ in self.shapes]
         dev = parts[0].device
-        f = default_freqs(self.cfg.t_dim) if freqs is None else freqs
+        f = default_freqs(self.cfg.t_dim, self.cfg.t_emb) if freqs is None else freqs
+        if self.cfg.t_emb == "sincos" and f.numel() == self.cfg.frequencies:
+            f = torch.cat([f, f])  # the module buffer holds f once
         parts.append(f.to(device=dev, dtype=torch.float32).reshape(-1))
         parts.append(torch.zeros(1, device=dev))
         return torch.cat(parts)

@@ -145,7 +145,7 @@ class FullTransformerEncoder(nn.Module):
                  te_config: Mapping | None = None, node_embd_config: Mapping | None = None,
                  outp_embd_config: Mapping | None = None, edge_embd_config: Mapping | None = None,
                  ctxt_embd_config: Mapping | None = None, *, num_points: int = 0, frequencies: int = 0,
-                 add_time_to_input: bool = True) -> None:
+                 add_time_to_input: bool = True, t_emb: str = "cosine") -> None:
         super().__init__()
         if edge_dim:
             raise NotImplementedError("edge features (attn_bias) have no HIP path in this build")
@@ -171,7 +171,7 @@ class FullTransformerEncoder(nn.Module):
         self.outp_embd = DenseNetwork(inpt_dim=self.model_dim, outp_dim=self.outp_dim, ctxt_dim=self.ctxt_out,
                                       **outp_embd_config)
         # what the kernels need to know beyond the reference's own arguments
-        self.num_points, self.frequencies, self.add_time_to_input = num_points, frequencies, add_time_to_input
+        self.num_points, self.frequencies, self.add_time_to_input, self.t_emb = num_points, frequencies, add_time_to_input, t_emb
         self._layouts = {}
         self.mfma_dtype = "fp32"  # "f16x3": every Linear on split-fp16 operands (PFM_TF_F_F16X3), fp32-grade accuracy
         self.cfg = self.config(num_points or 1)
@@ -187,7 +187,7 @@ class FullTransformerEncoder(nn.Module):
         return TfConfig(num_particles=num_points or self.num_points, features=self.outp_dim, model_dim=self.model_dim,
                         num_layers=self.te.num_layers, num_heads=self.te.layers[0].self_attn.num_heads, hidden=hid.pop(),
                         ctxt_hidden=self.ctxt_emdb.hddn_dim[0], ctxt_dim=self.ctxt_out, frequencies=self.frequencies,
-                        global_cond_dim=self.ctxt_dim - t_dim, add_time_to_input=self.add_time_to_input)
+                        global_cond_dim=self.ctxt_dim - t_dim, add_time_to_input=self.add_time_to_input, t_emb=self.t_emb)
 
     def layout(self, num_points: Optional[int] = None) -> TfLayout:
         n = num_points or self.num_points
@@ -214,7 +214,7 @@ class FullTransformerEncoder(nn.Module):
         with torch.no_grad():
             flat = self.flat_parameters(lay)
             from ...layout_tf import default_freqs
-            src = torch.cat([flat.float(), default_freqs(lay.cfg.t_dim).to(flat.device), torch.zeros(1, device=flat.device)])
+            src = torch.cat([flat.float(), default_freqs(lay.cfg.t_dim, lay.cfg.t_emb).to(flat.device), torch.zeros(1, device=flat.device)])
             return src[lay.index_map_on(flat.device)]
 
     # -- evaluation --------------------------------------------------------------------------------

@@ -74,9 +74,10 @@ class EPiC_encoder(nn.Module):
                  equiv_layers: int = 8, global_cond_dim: int = 0, local_cond_dim: int = 0,
                  activation: str = "leaky_relu", wrapper_func: str = "weight_norm", frequencies: int = 6,
                  num_points: int = 30, t_local_cat: bool = False, t_global_cat: bool = False,
-                 dropout: float = 0.0, sum_scale: float = 1e-2):
+                 dropout: float = 0.0, sum_scale: float = 1e-2, t_emb: str = "cosine"):
         super().__init__()
         _check_supported(activation, wrapper_func, dropout)
+        self.t_emb = t_emb  # what CNF embeds the time with: the kernels embed in place of CNF.time_embedding
         if input_dim != feats:
             raise NotImplementedError(
                 "add_time_to_input=True (input_dim != feats) is not implemented for the EPiC HIP kernels; "
@@ -115,7 +116,7 @@ class EPiC_encoder(nn.Module):
                           latent=self.latent, layers=self.equiv_layers, frequencies=self.frequencies,
                           t_local_cat=self.t_local_cat, t_global_cat=self.t_global_cat,
                           global_cond_dim=self.global_cond_dim, local_cond_dim=self.local_cond_dim,
-                          sum_scale=self.sum_scale)
+                          sum_scale=self.sum_scale, t_emb=self.t_emb)
 
     def layout(self, num_points: Optional[int] = None) -> EpicLayout:
         n = num_points or self.num_points

@@ -113,12 +113,14 @@ class CNF(nn.Module):
                                     hid_d=hidden_dim, activation=activation, wrapper_func=wrapper_func,
                                     frequencies=frequencies, num_points=num_particles, t_local_cat=t_local_cat,
                                     t_global_cat=t_global_cat, global_cond_dim=global_cond_dim,
-                                    local_cond_dim=local_cond_dim, dropout=dropout, sum_scale=sum_scale)
+                                    local_cond_dim=local_cond_dim, dropout=dropout, sum_scale=sum_scale,
+                                    t_emb=t_emb if t_emb in ("cosine", "sincos") else "cosine")
         elif model == "droid_fulltransformer":  # flow_matching_module.py:152-158
             self.net = FullTransformerEncoder(inpt_dim=input_dim, outp_dim=features,
                                               ctxt_dim=global_cond_dim + 2 * frequencies, **net_config,
                                               num_points=num_particles, frequencies=frequencies,
-                                              add_time_to_input=add_time_to_input)
+                                              add_time_to_input=add_time_to_input,
+                                              t_emb=t_emb if t_emb in ("cosine", "sincos") else "cosine")
         elif model in ("droid_fullcrossattention", "mdma"):
             raise NotImplementedError(f"Model {model} has no HIP path in this build ('epic' and 'droid_fulltransformer' do).")
         else:
@@ -132,8 +134,10 @@ class CNF(nn.Module):
         if t_emb == "cosine":
             self.embed = CosineEncoding(outp_dim=2 * frequencies, min_value=0.0, max_value=1.0,
                                         frequency_scaling="exponential")
-        elif t_emb in ("sincos", "gaussian"):
-            raise NotImplementedError(f"t_emb={t_emb} has no HIP path in this build (only 'cosine').")
+        elif t_emb == "sincos":
+            self.embed = None  # frequencies * t -> cat(cos, sin), in-kernel (flow_matching_module.py:208-211)
+        elif t_emb == "gaussian":
+            raise NotImplementedError("t_emb=gaussian has no HIP path in this build ('cosine' and 'sincos' do).")
         else:
             raise NotImplementedError(f"t_emb={t_emb} not implemented")  # :231
 
@@ -151,6 +155,9 @@ class CNF(nn.Module):
         return t.to(x.device, torch.float32)
 
     def time_embedding(self, t: Tensor, x: Tensor, t_emb: str = "cosine") -> Tensor:
+        if t_emb == "sincos":  # :208-211
+            a = self.frequencies * t[..., None]
+            return torch.cat((a.cos(), a.sin()), dim=-1).expand(*x.shape[:-1], -1)
         if t_emb != "cosine":
             raise NotImplementedError(f"t_emb={t_emb} not implemented")
         if t.dim() == 0:

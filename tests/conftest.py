@@ -100,7 +100,7 @@ def load_wide_golden(name):
     return _cache[key]
 
 
-@pytest.fixture(params=["small", "jetclass"])
+@pytest.fixture(params=["small", "jetclass", "sincos"])
 def wide_golden(request):
     return load_wide_golden(request.param)
 
@@ -112,6 +112,6 @@ def load_tf_golden(name):
     return _cache[key]
 
 
-@pytest.fixture(params=["small", "lhco"])
+@pytest.fixture(params=["small", "lhco", "sincos"])
 def tf_golden(request):
     return load_tf_golden(request.param)

@@ -24,7 +24,7 @@ def _module(g, **over):
 def _oracle(g, state=None):
     from particle_fm_amd.layout_tf import default_freqs
     # the product fixes the frequency table; give the oracle the same one
-    return TransformerVectorField(state or g.state, "flows.0.", g.hp, freqs=default_freqs(2 * g.hp["frequencies"]))
+    return TransformerVectorField(state or g.state, "flows.0.", g.hp, freqs=default_freqs(2 * g.hp["frequencies"], g.hp.get("t_emb", "cosine")))
 
 
 def test_cnf_forward_reference_signature(tf_golden):

@@ -3,6 +3,7 @@ own dataflow (P / Q rows, jet-bias GEMMs), against the reference vectors."""
 import math
 
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -28,7 +29,12 @@ def interp_forward(d, blob, t, x, cond, mask):
     Hp, T, C, s = d.hidden_pad, d.t_dim, d.cond_global, d.neg_slope
     act = lambda a: F.leaky_relu(a, s)
     P = torch.zeros(B, 256 + Hp)
-    P[:, :T] = torch.cos((t[:, None] + 0.0) * blob[d.freqs:d.freqs + T] * math.pi / 1.0)
+    fr = blob[d.freqs:d.freqs + T]
+    if d.flags & 2:  # PFM_EW_F_TEMB_SINCOS: table = [f ; f]
+        a = fr * t[:, None]
+        P[:, :T] = torch.cat([a[:, :T // 2].cos(), a[:, T // 2:].sin()], -1)
+    else:
+        P[:, :T] = torch.cos((t[:, None] + 0.0) * fr * math.pi / 1.0)
     if C:
         P[:, T:T + C] = cond
     m = torch.ones(B, N) if mask is None else mask.reshape(B, N).float()
@@ -55,9 +61,10 @@ def interp_forward(d, blob, t, x, cond, mask):
     return act(X @ W3.t() + sjb[:, None, 2 * Hp:2 * Hp + Fe]) * m[..., None]
 
 
-def test_blob_evaluates_to_reference():
+@pytest.mark.parametrize("name", ["small", "sincos"])
+def test_blob_evaluates_to_reference(name):
     from tests.conftest import load_wide_golden
-    g = load_wide_golden("small")
+    g = load_wide_golden(name)
     lay = _layout(g)
     blob = lay.pack_blob(g.state, "flows.0.net.", freqs=g.freqs)
     assert blob.numel() == lay.blob_total

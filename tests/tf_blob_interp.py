@@ -38,7 +38,11 @@ def forward(desc, blob, t, x, cond, mask):
     B, N, Fe = x.shape
     D, Hd, T, C, CO, CH = d.model_dim, d.hidden, d.t_dim, d.cond_dim, d.ctxt_dim, d.ctxt_hidden
     freqs = vec(blob, d.freqs, T)
-    temb = torch.cos((t[:, None] + 0.0) * freqs * math.pi / 1.0)
+    if d.flags & 2:  # PFM_TF_F_TEMB_SINCOS: table = [f ; f]
+        a = freqs * t[:, None]
+        temb = torch.cat([a[:, :T // 2].cos(), a[:, T // 2:].sin()], -1)
+    else:
+        temb = torch.cos((t[:, None] + 0.0) * freqs * math.pi / 1.0)
     cin = temb if C == 0 else torch.cat([temb, cond], -1)
     h = F.leaky_relu(cin @ kmajor(blob, d.c1.W, T + C, CH).t() + vec(blob, d.c1.b, CH), d.neg_slope)
     h = ln(blob, d.c_norm, CH, h, d.ln_eps)
