@@ -125,6 +125,15 @@ def cfm_loss(vf: Callable, x, mask, cond, t, x0, eps, sigma: float = 1e-4):
     return loss, y, u_t, v_t
 
 
+def droid_loss(vf: Callable, x, mask, cond, t, z):
+    """DroidLoss.forward (losses.py:326-342), draws given: y = x + t z, u = z mask."""
+    tt = t.unsqueeze(-1).repeat_interleave(x.shape[1], dim=1).unsqueeze(-1).type_as(x)
+    y = x + tt * z
+    u_t = z * mask
+    v_t = vf(tt.squeeze(-1), y, mask=mask, cond=cond)
+    return (v_t - u_t).square().sum() / mask.sum(), y, u_t, v_t
+
+
 def midpoint_trajectory_end(f: Callable, x: torch.Tensor, t_span: torch.Tensor) -> torch.Tensor:
     """Fixed-step explicit midpoint over ``t_span`` (torchdyn 1.0.x semantics, restated).
     Returns the final state only (the reference takes ``traj[-1]``, :285-287)."""

@@ -398,6 +398,24 @@ def gen_transformer(ref, name, hp, B, store_all, out_dir, seed=2024):
         out[tag + "z"], out[tag + "mask"], out[tag + "cond"], out[tag + "x_end"] = (
             z.numpy(), mask.numpy(), cond.numpy(), xe.numpy())
 
+
+    # ---- DroidLoss (losses.py:304-342): y = x + t z, u = z mask ----
+    mask = make_mask(B, N, "f32", gen)
+    x = torch.randn(B, N, Fe, generator=gen) * mask
+    cond = torch.randn(B, Cg, generator=gen)
+    loss_mod = ref.losses.DroidLoss(flows=flows, sigma=1e-4)
+    torch.manual_seed(777)
+    cnf.zero_grad()
+    loss = loss_mod(x, mask=mask, cond=cond)
+    loss.backward()
+    torch.manual_seed(777)  # losses.py:330, 335
+    t = torch.rand_like(torch.ones(B))
+    z = torch.randn_like(x)
+    tag = "droid/"
+    out[tag + "x"], out[tag + "t"], out[tag + "z"] = x.numpy(), t.numpy(), z.numpy()
+    out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
+    for k, p in list(cnf.named_parameters())[:6]:
+        out[tag + "grad/flows.0." + k] = subsample(p.grad.detach().clone().numpy())
     path = os.path.join(out_dir, f"tf_{name}.npz")
     np.savez(path, **out)
     print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
@@ -480,6 +498,24 @@ def gen_epic_wide(ref, name, hp, B, out_dir, seed=777):
         tag = f"midpoint_{steps}/"
         out[tag + "z"], out[tag + "mask"], out[tag + "cond"], out[tag + "x_end"] = (
             z.numpy(), mask.numpy(), cond.numpy(), xe.numpy())
+
+    # ---- DroidLoss (losses.py:304-342): y = x + t z, u = z mask ----
+    mask = make_mask(B, N, "f32", gen)
+    x = torch.randn(B, N, Fe, generator=gen) * mask
+    cond = torch.randn(B, Cg, generator=gen)
+    loss_mod = ref.losses.DroidLoss(flows=flows, sigma=1e-4)
+    torch.manual_seed(777)
+    cnf.zero_grad()
+    loss = loss_mod(x, mask=mask, cond=cond)
+    loss.backward()
+    torch.manual_seed(777)  # losses.py:330, 335
+    t = torch.rand_like(torch.ones(B))
+    z = torch.randn_like(x)
+    tag = "droid/"
+    out[tag + "x"], out[tag + "t"], out[tag + "z"] = x.numpy(), t.numpy(), z.numpy()
+    out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
+    for k, p in list(cnf.named_parameters())[:6]:
+        out[tag + "grad/flows.0." + k] = subsample(p.grad.detach().clone().numpy())
     path = os.path.join(out_dir, f"epicw_{name}.npz")
     np.savez(path, **out)
     print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")

@@ -42,6 +42,10 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_forward_kernel(
             const float b = __fmul_rn(__fadd_rn(sigma, __fmul_rn(one_m_sigma, tj)), zv);
             y = __fadd_rn(a, b);
             u = __fmul_rn(__fsub_rn(__fmul_rn(one_m_sigma, zv), xv), m);
+        } else if (kind == 2) {
+            // DroidLoss, losses.py:332-336:  y = x + t * z ; u = z * mask
+            y = __fadd_rn(xv, __fmul_rn(tj, zv));
+            u = __fmul_rn(zv, m);
         } else {
             // losses.py:115-119  mu = (1 - t) * x + t * x0 ; y = mu + sigma * eps ; u = (x0 - x) * mask
             const float mu = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, tj), xv), __fmul_rn(tj, zv));
@@ -94,7 +98,7 @@ extern "C" int pfm_epic_fm_loss_forward(const pfm_epic_desc* d, const float* blo
                    "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
     if (B <= 0) return 0;
-    if (kind != 0 && kind != 1) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT) or 1 (CFM)");
+    if (kind < 0 || kind > 2) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT), 1 (CFM) or 2 (droid)");
     if (!blob || !t || !x || !z || !saved || !loss_parts || !mask_count)
         return set_err(PFM_E_BADARG, "NULL device pointer");
     if (kind == 1 && !eps) return set_err(PFM_E_BADARG, "CFM needs eps");

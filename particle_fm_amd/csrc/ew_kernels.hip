@@ -665,7 +665,7 @@ int pfm_ew_fm_loss_forward(const pfm_ew_desc* d, const float* blob, int32_t kind
     int rc = ew::make_plan(p, d, blob, workspace, n_jets, true, stream);
     if (rc) return rc;
     if (n_jets <= 0) return 0;
-    if (kind != 0 && kind != 1) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT) or 1 (CFM)");
+    if (kind < 0 || kind > 2) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT), 1 (CFM) or 2 (droid)");
     if (!blob || !t || !x || !a || !y_out || !u_out || !v_out || !loss_sums || !workspace)
         return set_err(PFM_E_BADARG, "NULL device pointer");
     if (kind == 1 && !b) return set_err(PFM_E_BADARG, "CFM needs eps");

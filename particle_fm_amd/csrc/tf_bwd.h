@@ -37,6 +37,9 @@ static __global__ void tf_yu_kernel(int kind, float sigma, const float* __restri
         const float q = __fmul_rn(__fadd_rn(sigma, __fmul_rn(one_m_sigma, tj)), zv);
         y[i] = __fadd_rn(p, q);
         u[i] = __fmul_rn(__fsub_rn(__fmul_rn(one_m_sigma, zv), xv), m);
+    } else if (kind == 2) {  // DroidLoss, losses.py:332-336: y = x + t z, u = z mask
+        y[i] = __fadd_rn(xv, __fmul_rn(tj, zv));
+        u[i] = __fmul_rn(zv, m);
     } else {
         const float mu = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, tj), xv), __fmul_rn(tj, zv));
         y[i] = __fadd_rn(mu, __fmul_rn(sigma, b[i]));

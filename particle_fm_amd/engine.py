@@ -211,7 +211,7 @@ class FusedFMTrainer:
         lib = _lib.load()
         P, S = hip_ops._ptr, hip_ops._stream_ptr(self.fp.flat.device)
         loss_mod = self.module.loss
-        kind = "CFM" if type(loss_mod).__name__ == "ConditionalFlowMatchingLoss" else "FM-OT"
+        kind = {"ConditionalFlowMatchingLoss": "CFM", "DroidLoss": "droid"}.get(type(loss_mod).__name__, "FM-OT")
         if kind == "CFM":
             if mask is None:
                 raise TypeError("ConditionalFlowMatchingLoss needs a mask (losses.py:119)")

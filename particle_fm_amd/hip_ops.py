@@ -128,7 +128,7 @@ def epic_fm_loss_forward(layout: EpicLayout, blob: torch.Tensor, x: torch.Tensor
     dev, B, blob, x, cond, mask = _prep_common(layout, blob, x, cond, mask)
     t = _dev_f32("t", t, dev, (B,))
     z = _dev_f32("z", z, dev, tuple(x.shape))
-    kinds = {"FM-OT": 0, "CFM": 1}
+    kinds = {"FM-OT": 0, "CFM": 1, "droid": 2}
     if kind not in kinds:
         raise NotImplementedError(f"loss kind {kind} has no HIP kernel")
     if kind == "CFM":

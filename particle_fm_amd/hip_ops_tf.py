@@ -84,7 +84,7 @@ def tf_sample_midpoint(layout: TfLayout, blob, z, cond=None, mask=None, ode_step
     return out
 
 
-_KINDS = {"FM-OT": 0, "CFM": 1}
+_KINDS = {"FM-OT": 0, "CFM": 1, "droid": 2}
 
 
 def tf_fm_loss_forward(layout: TfLayout, blob, x, t, a, cond=None, mask=None, sigma: float = 1e-4, kind: str = "FM-OT",

@@ -54,7 +54,7 @@ def ew_sample_midpoint(layout: EpicWideLayout, blob, z, cond=None, mask=None, od
     return out
 
 
-_KINDS = {"FM-OT": 0, "CFM": 1}
+_KINDS = {"FM-OT": 0, "CFM": 1, "droid": 2}
 
 
 def ew_fm_loss_forward(layout: EpicWideLayout, blob, x, t, a, cond=None, mask=None, sigma: float = 1e-4, kind: str = "FM-OT",

@@ -63,3 +63,26 @@ class ConditionalFlowMatchingLoss(nn.Module):
             raise TypeError("ConditionalFlowMatchingLoss needs a mask (losses.py:119 multiplies by it)")
         t, x0, eps = self.draw(x)
         return _single_flow(self.flows).fm_loss(x, t, x0, mask=mask, cond=cond, sigma=self.sigma, kind="CFM", eps=eps)
+
+
+class DroidLoss(nn.Module):
+    """losses.py:304-342: y = x + t z, target u = z * mask, sum of squares / sum(mask) (the criterion object is built but,
+    as in the reference, never called)."""
+
+    def __init__(self, flows: nn.ModuleList, sigma: float = 1e-4, criterion: str = "mse"):
+        super().__init__()
+        self.flows = flows
+        self.sigma = sigma
+        if criterion not in ("mse", "huber"):
+            raise NotImplementedError(f"criterion {criterion} not supported")
+
+    def draw(self, x: torch.Tensor):
+        t = torch.rand_like(torch.ones(x.shape[0])).type_as(x)  # :330
+        z = torch.randn_like(x)                                  # :335
+        return t, z
+
+    def forward(self, x: torch.Tensor, mask: torch.Tensor = None, cond: torch.Tensor = None) -> torch.Tensor:
+        if mask is None:
+            raise TypeError("DroidLoss needs a mask (losses.py:339 multiplies by it)")
+        t, z = self.draw(x)
+        return _single_flow(self.flows).fm_loss(x, t, z, mask=mask, cond=cond, sigma=self.sigma, kind="droid")

@@ -23,7 +23,7 @@ from .. import fm_loss_wide as _fm_loss_wide
 from .. import hip_ops, hip_ops_tf, hip_ops_wide
 from .components.droid_transformer import FullTransformerEncoder
 from .components.epic import EPiC_encoder
-from .components.losses import ConditionalFlowMatchingLoss, FlowMatchingLoss
+from .components.losses import ConditionalFlowMatchingLoss, DroidLoss, FlowMatchingLoss
 from .components.time_emb import CosineEncoding
 
 try:  # Lightning is optional: present in the reference's environment, absent in the build container
@@ -239,8 +239,10 @@ class SetFlowMatchingLitModule(_LitBase):
             self.loss = FlowMatchingLoss(flows=self.flows, sigma=sigma, criterion=criterion)
         elif loss_type == "CFM":
             self.loss = ConditionalFlowMatchingLoss(flows=self.flows, sigma=sigma, criterion=criterion)
-        elif loss_type in ("CFM-OT", "diffusion", "droid"):
-            raise NotImplementedError(f"Loss type {loss_type} has no HIP path in this build (FM-OT and CFM do).")
+        elif loss_type == "droid":
+            self.loss = DroidLoss(flows=self.flows, sigma=sigma, criterion=criterion)
+        elif loss_type in ("CFM-OT", "diffusion"):
+            raise NotImplementedError(f"Loss type {loss_type} has no HIP path in this build (FM-OT, CFM and droid do).")
         else:
             raise NotImplementedError(f"Loss type {loss_type} not implemented.")  # :465
         if use_normaliser:
