@@ -298,7 +298,7 @@ TF_CONFIGS = {
 }
 
 
-def gen_transformer(ref, name, hp, B, store_all, out_dir, seed=2024):
+def gen_transformer(ref, name, hp, B, store_all, out_dir, seed=2024, file_prefix="tf"):
     import copy
     import json
 
@@ -416,7 +416,7 @@ def gen_transformer(ref, name, hp, B, store_all, out_dir, seed=2024):
     out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
     for k, p in list(cnf.named_parameters())[:6]:
         out[tag + "grad/flows.0." + k] = subsample(p.grad.detach().clone().numpy())
-    path = os.path.join(out_dir, f"tf_{name}.npz")
+    path = os.path.join(out_dir, f"{file_prefix}_{name}.npz")
     np.savez(path, **out)
     print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
 
@@ -521,10 +521,33 @@ def gen_epic_wide(ref, name, hp, B, out_dir, seed=777):
     print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
 
 
+# ----------------------------------------------------------------------------------------------
+# model "droid_fullcrossattention" (configs/model/fm_droid_crossattention.yaml): same recorder as the transformer's
+# ----------------------------------------------------------------------------------------------
+def ca_net_config(model_dim, num_layers, num_heads, hddn):
+    return dict(
+        node_embd_config=dict(act_h="lrlu", nrm="layer"),
+        ctxt_embd_config=dict(outp_dim=64, act_h="lrlu", nrm="layer"),
+        cae_config=dict(model_dim=model_dim, num_layers=num_layers,
+                        mha_config=dict(num_heads=num_heads, init_zeros=True, do_layer_norm=True),
+                        dense_config=dict(hddn_dim=hddn, act_h="lrlu", nrm="layer", output_init_zeros=True)),
+        outp_embd_config=dict(act_h="lrlu", nrm="layer", output_init_zeros=True),
+    )
+
+
+CA_BASE = dict(model="droid_fullcrossattention", features=3, frequencies=16, add_time_to_input=True, t_emb="cosine",
+               loss_type="FM-OT")
+CA_CONFIGS = {
+    "small": (dict(CA_BASE, num_particles=40, global_cond_dim=3, net_config=ca_net_config(128, 2, 16, 256)), 4, False),
+    # the yaml's own sizes with experiment/lhco/jets_crossattention.yaml:28-29
+    "lhco": (dict(CA_BASE, num_particles=279, global_cond_dim=5, net_config=ca_net_config(128, 8, 16, 256)), 2, False),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide}; default all")
+    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca}; default all")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
@@ -541,6 +564,9 @@ def main():
     for name, (hp, B, store_all) in TF_CONFIGS.items():
         if ap2 is None or "tf" in ap2:
             gen_transformer(ref, name, hp, B, store_all, args.out)
+    for name, (hp, B, store_all) in CA_CONFIGS.items():
+        if ap2 is None or "ca" in ap2:
+            gen_transformer(ref, name, hp, B, store_all, args.out, seed=4048, file_prefix="ca")
 
 
 if __name__ == "__main__":

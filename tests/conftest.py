@@ -105,6 +105,24 @@ def wide_golden(request):
     return load_wide_golden(request.param)
 
 
+class CaGolden(TfGolden):
+    """tests/golden/ca_<name>.npz: the cross-attention encoder (model "droid_fullcrossattention"), seed-derived weights."""
+
+    FILE = "ca_{}.npz"
+
+
+def load_ca_golden(name):
+    key = "ca_" + name
+    if key not in _cache:
+        _cache[key] = CaGolden(name)
+    return _cache[key]
+
+
+@pytest.fixture(params=["small", "lhco"])
+def ca_golden(request):
+    return load_ca_golden(request.param)
+
+
 def load_tf_golden(name):
     key = "tf_" + name
     if key not in _cache:
