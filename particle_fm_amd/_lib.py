@@ -1,4 +1,4 @@
-"""ctypes binding of libpfm_hip.so (C ABI in include/pfm_hip.h and include/pfm_tf.h).
+"""ctypes binding of libpfm_hip.so (C ABI in include/pfm_hip.h, pfm_tf.h, pfm_epicw.h and pfm_ca.h).
 
 There is no CPU fallback: if the library is missing or a call fails this raises."""
 from __future__ import annotations
@@ -8,6 +8,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 from .layout import EpicDesc
+from .layout_ca import CaDesc
 from .layout_tf import TfDesc
 from .layout_wide import EwDesc
 
@@ -16,7 +17,7 @@ LIB_PATH = os.path.join(_PKG, "libpfm_hip.so")
 
 _lib = None
 
-# every symbol include/pfm_hip.h and include/pfm_tf.h declare: name -> (restype, argtypes)
+# every symbol the headers under include/ declare: name -> (restype, argtypes)
 _fp = c_void_p  # device pointers travel as integers (tensor.data_ptr())
 SYMBOLS = {
     "pfm_abi_version": (c_int, []),
@@ -51,6 +52,15 @@ SYMBOLS = {
         c_int, [POINTER(EwDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_ew_backward_scratch_floats": (c_int64, [POINTER(EwDesc), c_int32]),
     "pfm_ew_fm_loss_backward": (c_int, [POINTER(EwDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
+    # include/pfm_ca.h
+    "pfm_ca_workspace_floats": (c_int64, [POINTER(CaDesc), c_int32, c_int32]),
+    "pfm_ca_forward": (c_int, [POINTER(CaDesc), _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_ca_sample_midpoint": (
+        c_int, [POINTER(CaDesc), _fp, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),
+    "pfm_ca_fm_loss_forward": (
+        c_int, [POINTER(CaDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_ca_backward_scratch_floats": (c_int64, [POINTER(CaDesc), c_int32]),
+    "pfm_ca_fm_loss_backward": (c_int, [POINTER(CaDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
     "pfm_tf_fm_loss_forward": (
         c_int, [POINTER(TfDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_tf_backward_scratch_floats": (c_int64, [POINTER(TfDesc), c_int32]),

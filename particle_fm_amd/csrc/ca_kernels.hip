@@ -1,0 +1,558 @@
+// gfx950 kernels + C ABI (include/pfm_ca.h): cross-attention vector field (model "droid_fullcrossattention"), midpoint
+// sampler, FM / CFM / droid loss forward and backward.  Linears, LayerNorm backward, dW / dX, the context path and the
+// output head are the kernels of tf_fwd.h / tf_bwd.h on two row matrices (particles, global tokens); the attention
+// shapes are in ca_attn.h.
+#include <hip/hip_runtime.h>
+
+#include "pfm_ca.h"
+#include "tf_fwd.h"
+#include "tf_bwd.h"
+#include "ca_attn.h"
+
+namespace pfm {
+int set_err(int code, const char* what);
+int check_hip(hipError_t e, const char* where);
+
+namespace ca {
+using namespace pfm::tf;
+
+int validate(const pfm_ca_desc* d) {
+    if (!d) return set_err(PFM_E_BADARG, "desc is NULL");
+    if (d->abi_version != PFM_CA_ABI_VERSION) return set_err(PFM_E_BADARG, "ca desc.abi_version mismatch");
+    if (d->model_dim < 128 || d->model_dim > MAXK || d->model_dim % 128) return set_err(PFM_E_BADARG, "model_dim must be a multiple of 128 in 128..512");
+    if (d->hidden < 128 || d->hidden > MAXK || d->hidden % 128) return set_err(PFM_E_BADARG, "hidden must be a multiple of 128 in 128..512");
+    if ((d->head_dim != 8 && d->head_dim != 16) || d->heads * d->head_dim != d->model_dim || d->heads > 64)
+        return set_err(PFM_E_BADARG, "head_dim must be 8 or 16 with heads * head_dim = model_dim");
+    if (d->tokens < 1 || d->tokens > PFM_CA_MAX_TOKENS || d->tokens * d->head_dim > 64)
+        return set_err(PFM_E_BADARG, "tokens must be in 1..8 with tokens * head_dim <= 64");
+    if (d->layers < 1 || d->layers > PFM_CA_MAX_LAYERS) return set_err(PFM_E_BADARG, "layers out of range");
+    if (d->features < 1 || d->features > 16) return set_err(PFM_E_BADARG, "features must be in 1..16");
+    if (d->t_dim < 1 || d->t_dim > 64 || d->cond_dim < 0 || d->cond_dim > 16) return set_err(PFM_E_BADARG, "t_dim / cond_dim out of range");
+    if (d->ctxt_dim < 4 || d->ctxt_dim > 64 || d->ctxt_dim % 4 || d->ctxt_hidden < 4 || d->ctxt_hidden > 512 || d->ctxt_hidden % 4)
+        return set_err(PFM_E_BADARG, "ctxt_dim / ctxt_hidden out of range");
+    if (d->n_points < 1) return set_err(PFM_E_BADARG, "n_points must be >= 1");
+    return 0;
+}
+
+// Workspace (floats).  Train: every layer keeps its buffers; inference: one set, streams updated in place.
+struct Ws {
+    int64_t temb, chid, ctxt, jb, h1, seq0, tok0, layer0, lstride;
+    int64_t f_kv, f_q, f_att, f_mid, f_dh, f_out;  // from-layer: kv [M][2D], q / att / mid / out [Mt][D], dh [Mt][Hd]
+    int64_t t_q, t_kv, t_att, t_mid, t_dh, t_out;  // to-layer:   q / att / mid / out [M][D], kv [Mt][2D], dh [M][Hd]
+    int64_t oh, total;
+};
+
+Ws make_ws(const pfm_ca_desc& d, int n_jets, bool train) {
+    Ws w;
+    const int64_t M = (int64_t)n_jets * d.n_points, Mt = (int64_t)n_jets * d.tokens, D = d.model_dim, Hd = d.hidden;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { const int64_t at = o; o += round64(n); return at; };
+    w.temb = take((int64_t)n_jets * 64);
+    w.chid = take((int64_t)n_jets * d.ctxt_hidden);
+    w.ctxt = take((int64_t)n_jets * d.ctxt_dim);
+    w.jb = take((int64_t)n_jets * (2 * d.layers + 2) * Hd);
+    w.h1 = take(M * Hd);
+    w.seq0 = take(M * D);
+    w.tok0 = take(Mt * D);
+    w.layer0 = o;
+    int64_t p = 0;
+    auto sub = [&](int64_t n) { const int64_t at = p; p += round64(n); return at; };
+    w.f_kv = sub(M * 2 * D); w.f_q = sub(Mt * D); w.f_att = sub(Mt * D); w.f_dh = sub(Mt * Hd);
+    w.t_q = sub(M * D); w.t_kv = sub(Mt * 2 * D); w.t_att = sub(M * D); w.t_dh = sub(M * Hd);
+    if (train) {
+        w.f_mid = sub(Mt * D); w.f_out = sub(Mt * D); w.t_mid = sub(M * D); w.t_out = sub(M * D);
+        w.lstride = p;
+        o += p * d.layers;
+    } else {
+        w.f_mid = w.f_out = w.tok0 - w.layer0;  // in place
+        w.t_mid = w.t_out = w.seq0 - w.layer0;
+        w.lstride = 0;
+        o += p;
+    }
+    w.oh = take(M * Hd);
+    w.total = o;
+    return w;
+}
+
+struct Plan {
+    const pfm_ca_desc* d;
+    const float* blob;
+    float* ws;
+    Ws w;
+    int n_jets, M, Mt;
+    hipStream_t s;
+};
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// out[rows][ldo] = epi(LN?(A) W^T + b / jet bias) (+R); per_jet = rows per jet of this row matrix (jet-bias lookup)
+int linear(const Plan& p, int rows, int per_jet, const float* A, int lda, int K, const pfm_tf_lin& lin, const pfm_tf_norm* ln, int NO,
+           const float* jb, const float* R, int ldr, float* out, int ldo, int act) {
+    LinArgs a;
+    a.A = A; a.A2 = nullptr; a.lda2 = 0; a.K1 = K; a.blob = p.blob; a.jb = jb; a.R = R; a.Y = nullptr; a.ldy = 0;
+    a.rowjet = nullptr; a.m_dev = nullptr; a.part = nullptr; a.ksplit = 1; a.out = out;
+    a.blob_floats = p.d->blob_floats; a.W = lin.W; a.b = lin.b;
+    a.gamma = ln ? ln->gamma : -1; a.beta = ln ? ln->beta : -1;
+    a.jb_stride = (int64_t)(2 * p.d->layers + 2) * p.d->hidden;
+    a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.M = rows; a.K = K; a.NO = NO; a.N = per_jet; a.act = act;
+    a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
+    const int chunks = NO / BN;
+    const int64_t slots = 2 * (int64_t)num_cus();
+    const int64_t w64 = (int64_t)((rows + 63) / 64) * chunks, w32 = (int64_t)((rows + 31) / 32) * chunks;
+    const bool half = ((w32 + slots - 1) / slots) < 2 * ((w64 + slots - 1) / slots);
+    const int rb = half ? 32 : 64;
+    a.row_tiles = (rows + rb - 1) / rb;
+    const int grid = ((a.row_tiles + 7) / 8) * 8 * chunks;
+    const bool x3 = (p.d->flags & PFM_CA_F_F16X3) != 0;
+    const size_t lds = x3 ? (size_t)rb * X3ROW * 2 * 2 * 2 + 2 * rb * sizeof(float) : (rb * 128 + 2 * rb) * sizeof(float);
+    const int ni = (ln && ln->gamma >= 0) ? K / 64 : 0;
+#define PFM_LAUNCH_LIN(NI)                                                                                        \
+    if (x3) {                                                                                                     \
+        if (half) hipLaunchKernelGGL((tf_linear_kernel<NI, 2, true>), dim3(grid), dim3(LT), lds, p.s, a);         \
+        else hipLaunchKernelGGL((tf_linear_kernel<NI, 4, true>), dim3(grid), dim3(LT), lds, p.s, a);              \
+    } else if (half) hipLaunchKernelGGL((tf_linear_kernel<NI, 2>), dim3(grid), dim3(LT), lds, p.s, a);            \
+    else hipLaunchKernelGGL((tf_linear_kernel<NI, 4>), dim3(grid), dim3(LT), lds, p.s, a);
+    switch (ni) {
+        case 0: PFM_LAUNCH_LIN(0) break;
+        case 2: PFM_LAUNCH_LIN(2) break;
+        case 4: PFM_LAUNCH_LIN(4) break;
+        case 6: PFM_LAUNCH_LIN(6) break;
+        case 8: PFM_LAUNCH_LIN(8) break;
+        default: return set_err(PFM_E_BADARG, "LayerNorm width must be 128, 256, 384 or 512");
+    }
+#undef PFM_LAUNCH_LIN
+    return check_hip(hipGetLastError(), "tf_linear_kernel launch (ca)");
+}
+
+#define PFM_TRY(x) do { if ((rc = (x))) return rc; } while (0)
+#define PFM_ATTN(KERNEL, grid, lds, ...)                                                                 \
+    do {                                                                                                 \
+        if (d.head_dim == 8) hipLaunchKernelGGL((KERNEL<8, 8>), grid, dim3(256), lds, p.s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<16, 4>), grid, dim3(256), lds, p.s, __VA_ARGS__);                \
+    } while (0)
+
+struct LayerBufs {
+    float *kv, *q, *att, *mid, *dh, *out;
+};
+
+int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const float* cond, const float* mask, const HeadArgs& head_tpl) {
+    const pfm_ca_desc& d = *p.d;
+    const Ws& w = p.w;
+    float* ws = p.ws;
+    const int D = d.model_dim, Hd = d.hidden, nb = 2 * d.layers + 2, N = d.n_points, Tk = d.tokens, heads = d.heads;
+    int rc;
+    {
+        CtxtArgs a;
+        a.blob = p.blob; a.t = t; a.cond = cond;
+        a.temb = ws + w.temb; a.chid = ws + w.chid; a.ctxt = ws + w.ctxt; a.jb = ws + w.jb;
+        a.t_stride = t_stride; a.T = d.t_dim; a.C = d.cond_dim; a.CH = d.ctxt_hidden; a.CO = d.ctxt_dim; a.Hd = Hd; a.nb = nb;
+        a.slope = d.neg_slope; a.eps = d.ln_eps; a.sincos = (d.flags & PFM_CA_F_TEMB_SINCOS) ? 1 : 0;
+        a.freqs = d.freqs; a.c1W = d.c1.W; a.c1b = d.c1.b; a.cg = d.c_norm.gamma; a.cb = d.c_norm.beta;
+        a.c2W = d.c2.W; a.c2b = d.c2.b; a.n1Wt = d.time_in_input ? d.n1.Wt : -1;
+        a.Wc[0] = d.n1.Wc; a.bb[0] = d.n1.b;
+        for (int l = 0; l < d.layers; ++l) {
+            a.Wc[1 + 2 * l] = d.from_layer[l].d1.Wc; a.bb[1 + 2 * l] = d.from_layer[l].d1.b;
+            a.Wc[2 + 2 * l] = d.to_layer[l].d1.Wc; a.bb[2 + 2 * l] = d.to_layer[l].d1.b;
+        }
+        a.Wc[nb - 1] = d.o1.Wc; a.bb[nb - 1] = d.o1.b;
+        hipLaunchKernelGGL(tf_ctxt_kernel, dim3(p.n_jets), dim3(512), 0, p.s, a);
+        PFM_TRY(check_hip(hipGetLastError(), "tf_ctxt_kernel launch (ca)"));
+    }
+    const float* jb = ws + w.jb;
+    hipLaunchKernelGGL(tf_embed_kernel, dim3((p.M + 31) / 32), dim3(256), 0, p.s, p.blob, d.n1.W, x, jb, (int64_t)nb * Hd, ws + w.h1, p.M,
+                       N, d.features, Hd, d.neg_slope);
+    PFM_TRY(check_hip(hipGetLastError(), "tf_embed_kernel launch (ca)"));
+    PFM_TRY(linear(p, p.M, N, ws + w.h1, Hd, Hd, d.n2, &d.n_norm, D, nullptr, nullptr, 0, ws + w.seq0, D, 0));
+    {
+        const int64_t n = (int64_t)p.Mt * D;
+        hipLaunchKernelGGL(ca_tokens_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, p.blob, d.global_tokens,
+                           ws + w.tok0, n, Tk * D);
+        PFM_TRY(check_hip(hipGetLastError(), "ca_tokens_init_kernel launch"));
+    }
+    const float *seq = ws + w.seq0, *tok = ws + w.tok0;
+    for (int l = 0; l < d.layers; ++l) {
+        float* lb = ws + w.layer0 + w.lstride * l;
+        const pfm_ca_layer& Fl = d.from_layer[l];
+        const pfm_ca_layer& Tl = d.to_layer[l];
+        // tokens <- particles
+        PFM_TRY(linear(p, p.M, N, seq, D, D, Fl.kv, &Fl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.f_kv, 2 * D, 0));
+        PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Fl.q, &Fl.norm1, D, nullptr, nullptr, 0, lb + w.f_q, D, 0));
+        PFM_ATTN(ca_attn_from_kernel, dim3(p.n_jets), 0, (const float*)(lb + w.f_q), (const float*)(lb + w.f_kv), mask, lb + w.f_att, N, D,
+                 heads, Tk);
+        PFM_TRY(check_hip(hipGetLastError(), "ca_attn_from_kernel launch"));
+        PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_att, D, D, Fl.out, &Fl.attn_norm, D, nullptr, tok, D, lb + w.f_mid, D, 0));
+        PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_mid, D, D, Fl.d1, &Fl.norm2, Hd, jb + (int64_t)(1 + 2 * l) * Hd, nullptr, 0, lb + w.f_dh, Hd, 1));
+        PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_dh, Hd, Hd, Fl.d2, &Fl.d_norm, D, nullptr, lb + w.f_mid, D, lb + w.f_out, D, 0));
+        tok = lb + w.f_out;
+        // particles <- tokens
+        PFM_TRY(linear(p, p.M, N, seq, D, D, Tl.q, &Tl.norm1, D, nullptr, nullptr, 0, lb + w.t_q, D, 0));
+        PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Tl.kv, &Tl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.t_kv, 2 * D, 0));
+        PFM_ATTN(ca_attn_to_kernel, dim3(p.n_jets), (size_t)Tk * 2 * D * sizeof(float), (const float*)(lb + w.t_q),
+                 (const float*)(lb + w.t_kv), lb + w.t_att, N, D, heads, Tk);
+        PFM_TRY(check_hip(hipGetLastError(), "ca_attn_to_kernel launch"));
+        PFM_TRY(linear(p, p.M, N, lb + w.t_att, D, D, Tl.out, &Tl.attn_norm, D, nullptr, seq, D, lb + w.t_mid, D, 0));
+        PFM_TRY(linear(p, p.M, N, lb + w.t_mid, D, D, Tl.d1, &Tl.norm2, Hd, jb + (int64_t)(2 + 2 * l) * Hd, nullptr, 0, lb + w.t_dh, Hd, 1));
+        PFM_TRY(linear(p, p.M, N, lb + w.t_dh, Hd, Hd, Tl.d2, &Tl.d_norm, D, nullptr, lb + w.t_mid, D, lb + w.t_out, D, 0));
+        seq = lb + w.t_out;
+    }
+    // outp_embd: Linear on cat(seq, ctxt) without a LayerNorm in front (FullCrossAttentionEncoder has no final norm)
+    PFM_TRY(linear(p, p.M, N, seq, D, D, d.o1, nullptr, Hd, jb + (int64_t)(nb - 1) * Hd, nullptr, 0, ws + w.oh, Hd, 1));
+    HeadArgs h = head_tpl;
+    h.A = ws + w.oh; h.blob = p.blob;
+    h.gamma = d.o_norm.gamma; h.beta = d.o_norm.beta; h.W = d.o2.W; h.b = d.o2.b;
+    h.M = p.M; h.Hd = Hd; h.F = d.features; h.eps = d.ln_eps;
+    const dim3 hg((p.M + 15) / 16), hb(256);
+    switch (Hd / 64) {
+        case 2: hipLaunchKernelGGL(tf_head_kernel<2>, hg, hb, 0, p.s, h); break;
+        case 4: hipLaunchKernelGGL(tf_head_kernel<4>, hg, hb, 0, p.s, h); break;
+        case 6: hipLaunchKernelGGL(tf_head_kernel<6>, hg, hb, 0, p.s, h); break;
+        default: hipLaunchKernelGGL(tf_head_kernel<8>, hg, hb, 0, p.s, h); break;
+    }
+    return check_hip(hipGetLastError(), "tf_head_kernel launch (ca)");
+}
+
+int make_plan(Plan& p, const pfm_ca_desc* d, const float* blob, float* ws, int n_jets, bool train, void* stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    p.d = d; p.blob = blob; p.ws = ws; p.n_jets = n_jets; p.M = n_jets * d->n_points; p.Mt = n_jets * d->tokens;
+    p.s = (hipStream_t)stream;
+    p.w = make_ws(*d, n_jets, train);
+    return 0;
+}
+
+// ---- backward ------------------------------------------------------------------------------------------
+struct Bs {
+    int64_t dv, gh, gh2, gseq, gtok, ga, gat, gkv, gkvt, gq, gqt, gatt, gattt, ght, rstat, djb, dctxt, dhn, dhnx, dpre, hn, dwpart, total;
+};
+constexpr int DW_MAX_PARTS = 1024;
+
+Bs make_bs(const pfm_ca_desc& d, int n_jets) {
+    Bs b;
+    const int64_t M = (int64_t)n_jets * d.n_points, Mt = (int64_t)n_jets * d.tokens, D = d.model_dim, Hd = d.hidden;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { const int64_t at = o; o += round64(n); return at; };
+    b.dv = take(M * d.features);
+    const int64_t Mx = M > Mt ? M : Mt;  // gh2 and gkv double as scratch of the token rows and of the head backward
+    b.gh = take(M * Hd); b.gh2 = take(Mx * Hd);
+    b.gseq = take(M * D); b.gtok = take(Mt * D);
+    b.ga = take(M * D); b.gat = take(Mt * D);
+    b.gkv = take(M * (2 * D > Hd ? 2 * D : Hd)); b.gkvt = take(Mt * 2 * D);
+    b.gq = take(M * D); b.gqt = take(Mt * D);
+    b.gatt = take(M * D); b.gattt = take(Mt * D);
+    b.ght = take(Mt * Hd);
+    b.rstat = take(Mx * 2);
+    b.djb = take((int64_t)n_jets * (2 * d.layers + 2) * Hd);
+    b.dctxt = take((int64_t)n_jets * d.ctxt_dim);
+    b.dhn = take((int64_t)n_jets * d.ctxt_hidden); b.dhnx = take((int64_t)n_jets * d.ctxt_hidden);
+    b.dpre = take((int64_t)n_jets * d.ctxt_hidden); b.hn = take((int64_t)n_jets * d.ctxt_hidden);
+    b.dwpart = take((int64_t)DW_MAX_PARTS * 16384);
+    b.total = o;
+    return b;
+}
+
+struct Bwd {
+    Plan p;
+    float *gblob, *sc;
+    Bs b;
+
+    int colsum(const float* Z, int ldz, int NO, int64_t rows, int group, const float* X, int F, float* jet_out, int64_t gb) const {
+        ColsumArgs a;
+        a.Z = Z; a.X = X; a.jet_out = jet_out; a.gblob = gblob; a.gb = gb;
+        a.jet_stride = (int64_t)(2 * p.d->layers + 2) * p.d->hidden;
+        a.ldz = ldz; a.NO = NO; a.N = group; a.F = F; a.rows = rows;
+        hipLaunchKernelGGL(tf_colsum_kernel, dim3((unsigned)((rows + group - 1) / group), X ? F : 1, (NO + 767) / 768), dim3(256), 0, p.s, a);
+        return check_hip(hipGetLastError(), "tf_colsum_kernel launch (ca)");
+    }
+    // dW += Z^T LN(A) over `rows` rows (ln == nullptr: no LayerNorm prologue)
+    int dw(int rows, const float* Z, int NO, const float* A, int K, const pfm_tf_norm* ln, int64_t gW) const {
+        float* st = sc + b.rstat;
+        if (ln) {
+            const dim3 g((rows + 15) / 16), bl(256);
+            switch (K / 64) {
+                case 2: hipLaunchKernelGGL(tf_rowstats_kernel<2>, g, bl, 0, p.s, A, rows, p.d->ln_eps, st); break;
+                case 4: hipLaunchKernelGGL(tf_rowstats_kernel<4>, g, bl, 0, p.s, A, rows, p.d->ln_eps, st); break;
+                case 6: hipLaunchKernelGGL(tf_rowstats_kernel<6>, g, bl, 0, p.s, A, rows, p.d->ln_eps, st); break;
+                default: hipLaunchKernelGGL(tf_rowstats_kernel<8>, g, bl, 0, p.s, A, rows, p.d->ln_eps, st); break;
+            }
+        }
+        DwArgs a;
+        a.Z = Z; a.A = A; a.A2 = nullptr; a.lda2 = 0; a.K1 = K; a.stats = ln ? st : nullptr; a.blob = p.blob; a.part = sc + b.dwpart;
+        a.gamma = ln ? ln->gamma : -1; a.beta = ln ? ln->beta : -1;
+        a.ldz = NO; a.lda = K; a.M = rows; a.NO = NO; a.K = K;
+        a.row_tiles = (rows + BM - 1) / BM;
+        const int tiles = ((NO + 127) / 128) * ((K + 127) / 128);
+        int ns = DW_MAX_PARTS / tiles;
+        if (ns < 1) ns = 1;
+        if (ns > a.row_tiles) ns = a.row_tiles;
+        a.nsplit = ns;
+        int rc;
+        hipLaunchKernelGGL(tf_dw_kernel, dim3(tiles * ns), dim3(LT), 2 * 64 * DWS * sizeof(float), p.s, a);
+        if ((rc = check_hip(hipGetLastError(), "tf_dw_kernel launch (ca)"))) return rc;
+        hipLaunchKernelGGL(tf_dw_reduce_kernel, dim3(64, tiles), dim3(256), 0, p.s, (const float*)a.part, gblob, gW, NO, K, ns);
+        return check_hip(hipGetLastError(), "tf_dw_reduce_kernel launch (ca)");
+    }
+    int dx(int rows, const float* Z, int NO, const pfm_tf_lin& lin, int K, float* out) const {
+        pfm_tf_lin t = lin;
+        t.W = lin.WT;
+        t.b = -1;
+        return linear(p, rows, 1, Z, NO, NO, t, nullptr, K, nullptr, nullptr, 0, out, K, 0);
+    }
+    int lnbwd(int rows, const float* A, int K, const float* G, const float* add, float* out, const pfm_tf_norm& ln, bool act) const {
+        LnBwdArgs a{};
+        a.A = A; a.G = G; a.add = add; a.out = out; a.blob = p.blob; a.gblob = gblob;
+        a.gamma = ln.gamma; a.beta = ln.beta; a.M = rows; a.K = K; a.act = act ? 1 : 0;
+        a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
+        const dim3 g((rows + 63) / 64), bl(256);
+        switch (K / 64) {
+            case 2: hipLaunchKernelGGL(tf_ln_bwd_kernel<2>, g, bl, 0, p.s, a); break;
+            case 4: hipLaunchKernelGGL(tf_ln_bwd_kernel<4>, g, bl, 0, p.s, a); break;
+            case 6: hipLaunchKernelGGL(tf_ln_bwd_kernel<6>, g, bl, 0, p.s, a); break;
+            default: hipLaunchKernelGGL(tf_ln_bwd_kernel<8>, g, bl, 0, p.s, a); break;
+        }
+        return check_hip(hipGetLastError(), "tf_ln_bwd_kernel launch (ca)");
+    }
+    int outer(const float* U, int64_t ldu, int K, const float* V, int64_t ldv, int NO, int64_t g) const {
+        const int64_t n = (int64_t)K * NO;
+        hipLaunchKernelGGL(tf_outer_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, U, ldu, K, V, ldv, NO, p.n_jets, gblob + g);
+        return check_hip(hipGetLastError(), "tf_outer_sum_kernel launch (ca)");
+    }
+    // the block  q <- q + out(LN_a(att));  q <- q + d2(LN_d(lrelu(d1(LN2(q)) + jet bias)))  of one cross-attention layer,
+    // backwards: in: g = d loss / d q_out (rows x D); out: g = d loss / d q_in excluding the query path of the attention,
+    // gatt = d loss / d att.  `per_jet` rows per jet, jb_row = index of the layer's jet-bias row.
+    int layer_tail_bwd(int rows, int per_jet, const pfm_ca_layer& L, int jb_row, const float* q_in, const float* att, const float* mid,
+                       const float* dh, float* g, float* gh_, float* gh2_, float* ga_, float* gatt_) const {
+        const int D = p.d->model_dim, Hd = p.d->hidden;
+        (void)q_in;
+        int rc;
+        PFM_TRY(colsum(g, D, D, rows, per_jet, nullptr, 0, nullptr, L.d2.b));
+        PFM_TRY(dw(rows, g, D, dh, Hd, &L.d_norm, L.d2.W));
+        PFM_TRY(dx(rows, g, D, L.d2, Hd, gh2_));
+        PFM_TRY(lnbwd(rows, dh, Hd, gh2_, nullptr, gh_, L.d_norm, true));
+        PFM_TRY(colsum(gh_, Hd, Hd, rows, per_jet, nullptr, 0, sc + b.djb + (int64_t)jb_row * Hd, -1));
+        PFM_TRY(dw(rows, gh_, Hd, mid, D, &L.norm2, L.d1.W));
+        PFM_TRY(dx(rows, gh_, Hd, L.d1, D, ga_));
+        PFM_TRY(lnbwd(rows, mid, D, ga_, g, g, L.norm2, false));  // g = d loss / d mid
+        PFM_TRY(colsum(g, D, D, rows, per_jet, nullptr, 0, nullptr, L.out.b));
+        PFM_TRY(dw(rows, g, D, att, D, &L.attn_norm, L.out.W));
+        PFM_TRY(dx(rows, g, D, L.out, D, ga_));
+        PFM_TRY(lnbwd(rows, att, D, ga_, nullptr, gatt_, L.attn_norm, false));
+        return 0;
+    }
+    // a projection  y = lin(LN(x))  backwards: gy -> bias / weight gradients, and g_x += LN backward of (gy W)
+    int proj_bwd(int rows, int per_jet, const pfm_tf_lin& lin, const pfm_tf_norm& ln, int NO, const float* x, const float* gy, float* tmp,
+                 float* gx) const {
+        const int D = p.d->model_dim;
+        int rc;
+        PFM_TRY(colsum(gy, NO, NO, rows, per_jet, nullptr, 0, nullptr, lin.b));
+        PFM_TRY(dw(rows, gy, NO, x, D, &ln, lin.W));
+        PFM_TRY(dx(rows, gy, NO, lin, D, tmp));
+        return lnbwd(rows, x, D, tmp, gx, gx, ln, false);
+    }
+};
+
+int run_backward(const Bwd& B, const float* cond, const float* mask, const float* y, const float* u, const float* v, const float* gscale) {
+    const Plan& p = B.p;
+    const pfm_ca_desc& d = *p.d;
+    const Ws& w = p.w;
+    float* ws = p.ws;
+    float* sc = B.sc;
+    const Bs& b = B.b;
+    const int D = d.model_dim, Hd = d.hidden, nb = 2 * d.layers + 2, F = d.features, N = d.n_points, Tk = d.tokens, heads = d.heads;
+    float *gh = sc + b.gh, *gh2 = sc + b.gh2, *gseq = sc + b.gseq, *gtok = sc + b.gtok, *ga = sc + b.ga, *gat = sc + b.gat;
+    float *gkv = sc + b.gkv, *gkvt = sc + b.gkvt, *gq = sc + b.gq, *gqt = sc + b.gqt, *gatt = sc + b.gatt, *gattt = sc + b.gattt, *ght = sc + b.ght;
+    float* djb = sc + b.djb;
+    int rc;
+    auto layer_base = [&](int l) { return ws + w.layer0 + w.lstride * l; };
+    const float* seqL = layer_base(d.layers - 1) + w.t_out;
+    // ---- output head + outp_embd input block (no LayerNorm in front of it) ----
+    {
+        HeadBwdArgs a;
+        a.A = ws + w.oh; a.v = v; a.u = u; a.gscale = gscale; a.dv = sc + b.dv; a.dn = gkv; a.nout = gh2;  // gkv: M x 2D >= M x Hd scratch
+        a.blob = p.blob; a.gblob = B.gblob;
+        a.gamma = d.o_norm.gamma; a.beta = d.o_norm.beta; a.W3 = d.o2.W; a.b3 = d.o2.b;
+        a.M = p.M; a.K = Hd; a.F = F; a.eps = d.ln_eps;
+        const dim3 g((p.M + 15) / 16), bl(256);
+        switch (Hd / 64) {
+            case 2: hipLaunchKernelGGL(tf_head_bwd_kernel<2>, g, bl, 0, p.s, a); break;
+            case 4: hipLaunchKernelGGL(tf_head_bwd_kernel<4>, g, bl, 0, p.s, a); break;
+            case 6: hipLaunchKernelGGL(tf_head_bwd_kernel<6>, g, bl, 0, p.s, a); break;
+            default: hipLaunchKernelGGL(tf_head_bwd_kernel<8>, g, bl, 0, p.s, a); break;
+        }
+        PFM_TRY(check_hip(hipGetLastError(), "tf_head_bwd_kernel launch (ca)"));
+        PFM_TRY(B.colsum(gh2, Hd, Hd, p.M, N, sc + b.dv, F, nullptr, d.o2.W));
+        PFM_TRY(B.lnbwd(p.M, ws + w.oh, Hd, gkv, nullptr, gh, d.o_norm, true));
+        PFM_TRY(B.colsum(gh, Hd, Hd, p.M, N, nullptr, 0, djb + (int64_t)(nb - 1) * Hd, -1));
+        PFM_TRY(B.dw(p.M, gh, Hd, seqL, D, nullptr, d.o1.W));
+        PFM_TRY(B.dx(p.M, gh, Hd, d.o1, D, gseq));
+    }
+    PFM_TRY(check_hip(hipMemsetAsync(gtok, 0, (size_t)p.Mt * D * sizeof(float), p.s), "memset gtok"));
+    for (int l = d.layers - 1; l >= 0; --l) {
+        float* lb = layer_base(l);
+        const pfm_ca_layer& Fl = d.from_layer[l];
+        const pfm_ca_layer& Tl = d.to_layer[l];
+        const float* seq_in = l ? layer_base(l - 1) + w.t_out : ws + w.seq0;
+        const float* tok_in = l ? layer_base(l - 1) + w.f_out : ws + w.tok0;
+        const float* tok_out = lb + w.f_out;
+        // ---- to-layer: seq_out = f(seq_in, tok_out) ----
+        PFM_TRY(B.layer_tail_bwd(p.M, N, Tl, 2 + 2 * l, seq_in, lb + w.t_att, lb + w.t_mid, lb + w.t_dh, gseq, gh, gh2, ga, gatt));
+        PFM_ATTN(ca_attn_to_bwd_kernel, dim3(p.n_jets), (size_t)2 * Tk * 2 * D * sizeof(float), (const float*)(lb + w.t_q),
+                 (const float*)(lb + w.t_kv), (const float*)gatt, gq, gkvt, N, D, heads, Tk);
+        PFM_TRY(check_hip(hipGetLastError(), "ca_attn_to_bwd_kernel launch"));
+        PFM_TRY(B.proj_bwd(p.M, N, Tl.q, Tl.norm1, D, seq_in, gq, ga, gseq));           // gseq = d loss / d seq_in
+        PFM_TRY(B.proj_bwd(p.Mt, Tk, Tl.kv, Tl.norm0, 2 * D, tok_out, gkvt, gat, gtok)); // gtok = d loss / d tok_out
+        // ---- from-layer: tok_out = f(tok_in, seq_in) ----
+        PFM_TRY(B.layer_tail_bwd(p.Mt, Tk, Fl, 1 + 2 * l, tok_in, lb + w.f_att, lb + w.f_mid, lb + w.f_dh, gtok, ght, gh2, gat, gattt));
+        PFM_ATTN(ca_attn_from_bwd_kernel, dim3(p.n_jets), 0, (const float*)(lb + w.f_q), (const float*)(lb + w.f_kv), mask,
+                 (const float*)(lb + w.f_att), (const float*)gattt, gqt, gkv, N, D, heads, Tk);
+        PFM_TRY(check_hip(hipGetLastError(), "ca_attn_from_bwd_kernel launch"));
+        PFM_TRY(B.proj_bwd(p.Mt, Tk, Fl.q, Fl.norm1, D, tok_in, gqt, gat, gtok));        // gtok = d loss / d tok_in
+        PFM_TRY(B.proj_bwd(p.M, N, Fl.kv, Fl.norm0, 2 * D, seq_in, gkv, ga, gseq));      // gseq += keys / values path
+    }
+    // ---- global tokens: every jet starts from the same rows ----
+    PFM_TRY(B.colsum(gtok, Tk * D, Tk * D, p.n_jets, 16, nullptr, 0, nullptr, d.global_tokens));
+    // ---- node_embd ----
+    PFM_TRY(B.colsum(gseq, D, D, p.M, N, nullptr, 0, nullptr, d.n2.b));
+    PFM_TRY(B.dw(p.M, gseq, D, ws + w.h1, Hd, &d.n_norm, d.n2.W));
+    PFM_TRY(B.dx(p.M, gseq, D, d.n2, Hd, gh2));
+    PFM_TRY(B.lnbwd(p.M, ws + w.h1, Hd, gh2, nullptr, gh, d.n_norm, true));
+    PFM_TRY(B.colsum(gh, Hd, Hd, p.M, N, nullptr, 0, djb, -1));
+    PFM_TRY(B.colsum(gh, Hd, Hd, p.M, N, y, F, nullptr, d.n1.W));
+    // ---- context path ----
+    {
+        CtxtBwdArgs a;
+        a.blob = p.blob; a.djb = djb; a.chid = ws + w.chid;
+        a.dctxt = sc + b.dctxt; a.dhn = sc + b.dhn; a.dhnx = sc + b.dhnx; a.dpre = sc + b.dpre; a.hn = sc + b.hn;
+        a.CH = d.ctxt_hidden; a.CO = d.ctxt_dim; a.Hd = Hd; a.nb = nb; a.slope = d.neg_slope; a.eps = d.ln_eps;
+        a.cg = d.c_norm.gamma; a.cb = d.c_norm.beta; a.c2W = d.c2.W;
+        auto lin_of = [&](int c) -> const pfm_tf_lin& {
+            if (c == 0) return d.n1;
+            if (c == nb - 1) return d.o1;
+            return ((c - 1) & 1) ? d.to_layer[(c - 1) / 2].d1 : d.from_layer[(c - 1) / 2].d1;
+        };
+        for (int c = 0; c < nb; ++c) a.Wc[c] = lin_of(c).Wc;
+        hipLaunchKernelGGL(tf_ctxt_bwd_kernel, dim3(p.n_jets), dim3(512), 0, p.s, a);
+        PFM_TRY(check_hip(hipGetLastError(), "tf_ctxt_bwd_kernel launch (ca)"));
+        const int64_t jbs = (int64_t)nb * Hd;
+        const float* ctxt = ws + w.ctxt;
+        for (int c = 0; c < nb; ++c) {
+            PFM_TRY(B.outer(ctxt, d.ctxt_dim, d.ctxt_dim, djb + (int64_t)c * Hd, jbs, Hd, lin_of(c).Wc));
+            PFM_TRY(B.outer(nullptr, 0, 1, djb + (int64_t)c * Hd, jbs, Hd, lin_of(c).b));
+        }
+        if (d.time_in_input) PFM_TRY(B.outer(ws + w.temb, 64, d.t_dim, djb, jbs, Hd, d.n1.Wt));
+        PFM_TRY(B.outer(sc + b.hn, d.ctxt_hidden, d.ctxt_hidden, sc + b.dctxt, d.ctxt_dim, d.ctxt_dim, d.c2.W));
+        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dctxt, d.ctxt_dim, d.ctxt_dim, d.c2.b));
+        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dhnx, d.ctxt_hidden, d.ctxt_hidden, d.c_norm.gamma));
+        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dhn, d.ctxt_hidden, d.ctxt_hidden, d.c_norm.beta));
+        PFM_TRY(B.outer(ws + w.temb, 64, d.t_dim, sc + b.dpre, d.ctxt_hidden, d.ctxt_hidden, d.c1.W));
+        if (d.cond_dim > 0)
+            PFM_TRY(B.outer(cond, d.cond_dim, d.cond_dim, sc + b.dpre, d.ctxt_hidden, d.ctxt_hidden, d.c1.W + (int64_t)d.t_dim * d.ctxt_hidden));
+        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dpre, d.ctxt_hidden, d.ctxt_hidden, d.c1.b));
+    }
+    return 0;
+}
+
+}  // namespace ca
+}  // namespace pfm
+
+using namespace pfm;
+
+extern "C" {
+
+int64_t pfm_ca_workspace_floats(const pfm_ca_desc* d, int32_t n_jets, int32_t train) {
+    if (ca::validate(d)) return -1;
+    return ca::make_ws(*d, n_jets < 1 ? 1 : n_jets, train != 0).total;
+}
+
+int pfm_ca_forward(const pfm_ca_desc* d, const float* blob, const float* t, int32_t t_stride, const float* x, const float* cond,
+                   const float* mask, float* v, int32_t n_jets, float* workspace, void* stream) {
+    ca::Plan p;
+    int rc = ca::make_plan(p, d, blob, workspace, n_jets, false, stream);
+    if (rc) return rc;
+    if (n_jets <= 0) return 0;
+    if (!blob || !t || !x || !v || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
+    tf::HeadArgs h{};
+    h.dst = v;
+    return ca::run_nfe(p, t, t_stride ? 1 : 0, x, cond, mask, h);
+}
+
+int pfm_ca_sample_midpoint(const pfm_ca_desc* d, const float* blob, const float* t_eval, const float* dt, int32_t n_steps,
+                           const float* z, const float* cond, const float* mask, float* x_out, int32_t n_jets, int32_t premask,
+                           float* state, float* workspace, void* stream) {
+    ca::Plan p;
+    int rc = ca::make_plan(p, d, blob, workspace, n_jets, false, stream);
+    if (rc) return rc;
+    if (n_jets <= 0) return 0;
+    if (!blob || !t_eval || !dt || !z || !x_out || !state || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (n_steps < 0) return set_err(PFM_E_BADARG, "n_steps < 0");
+    if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
+    const int64_t n = (int64_t)p.M * d->features;
+    float* xs = state;
+    float* xm = state + n;
+    hipLaunchKernelGGL(tf::tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, xs, n,
+                       d->features);
+    if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+    for (int k = 0; k < n_steps; ++k) {
+        tf::HeadArgs h{};
+        h.base = xs; h.dt = dt + k; h.coef = 0.5f; h.dst = xm;
+        if ((rc = ca::run_nfe(p, t_eval + 2 * k, 0, xs, cond, mask, h))) return rc;
+        h.coef = 1.0f; h.dst = xs;
+        if ((rc = ca::run_nfe(p, t_eval + 2 * k + 1, 0, xm, cond, mask, h))) return rc;
+    }
+    return check_hip(hipMemcpyAsync(x_out, xs, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_out");
+}
+
+int pfm_ca_fm_loss_forward(const pfm_ca_desc* d, const float* blob, int32_t kind, float sigma, const float* t, const float* x,
+                           const float* a, const float* b, const float* cond, const float* mask, float* y_out, float* u_out,
+                           float* v_out, float* loss_sums, int32_t n_jets, float* workspace, void* stream) {
+    ca::Plan p;
+    int rc = ca::make_plan(p, d, blob, workspace, n_jets, true, stream);
+    if (rc) return rc;
+    if (n_jets <= 0) return 0;
+    if (kind < 0 || kind > 2) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT), 1 (CFM) or 2 (droid)");
+    if (!blob || !t || !x || !a || !y_out || !u_out || !v_out || !loss_sums || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (kind == 1 && !b) return set_err(PFM_E_BADARG, "CFM needs eps");
+    if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
+    const int64_t n = (int64_t)p.M * d->features;
+    hipLaunchKernelGGL(tf::tf_yu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, kind, sigma, t, x, a, b, mask, y_out, u_out, n,
+                       d->n_points * d->features, d->features);
+    if ((rc = check_hip(hipGetLastError(), "tf_yu_kernel launch"))) return rc;
+    tf::HeadArgs h{};
+    h.dst = v_out;
+    if ((rc = ca::run_nfe(p, t, 1, y_out, cond, mask, h))) return rc;
+    hipLaunchKernelGGL(tf::tf_loss_kernel, dim3(256), dim3(256), 0, p.s, (const float*)v_out, (const float*)u_out, mask, loss_sums, n,
+                       (int64_t)p.M);
+    return check_hip(hipGetLastError(), "tf_loss_kernel launch");
+}
+
+int64_t pfm_ca_backward_scratch_floats(const pfm_ca_desc* d, int32_t n_jets) {
+    if (ca::validate(d)) return -1;
+    return ca::make_bs(*d, n_jets < 1 ? 1 : n_jets).total;
+}
+
+int pfm_ca_fm_loss_backward(const pfm_ca_desc* d, const float* blob, const float* cond, const float* mask, const float* y,
+                            const float* u, const float* v, const float* gscale, float* gblob, int32_t n_jets, float* workspace,
+                            float* scratch, void* stream) {
+    ca::Bwd B;
+    int rc = ca::make_plan(B.p, d, blob, workspace, n_jets, true, stream);
+    if (rc) return rc;
+    if (n_jets <= 0) return 0;
+    if (!blob || !y || !u || !v || !gscale || !gblob || !workspace || !scratch) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
+    if (d->n2.WT < 0) return set_err(PFM_E_BADARG, "blob was packed without the transposed (backward) weight copies");
+    B.gblob = gblob;
+    B.sc = scratch;
+    B.b = ca::make_bs(*d, n_jets);
+    return ca::run_backward(B, cond, mask, y, u, v, gscale);
+}
+
+}  // extern "C"

@@ -603,7 +603,7 @@ struct CtxtBwdArgs {
     int CH, CO, Hd, nb;
     float slope, eps;
     int64_t cg, cb, c2W;
-    int64_t Wc[PFM_TF_MAX_LAYERS + 2];
+    int64_t Wc[CTXT_MAX_NB];
 };
 
 static __global__ __launch_bounds__(512) void tf_ctxt_bwd_kernel(CtxtBwdArgs a) {

@@ -42,6 +42,8 @@ __device__ __forceinline__ float block_sum512(float v, float* red) {
     return s;
 }
 
+constexpr int CTXT_MAX_NB = 34;  // jet-bias rows one context kernel can produce (transformer: layers + 2; cross-attention: 2 * pairs + 2)
+
 struct CtxtArgs {
     const float* blob;
     const float* t;
@@ -50,7 +52,7 @@ struct CtxtArgs {
     int t_stride, T, C, CH, CO, Hd, nb, sincos;
     float slope, eps;
     int64_t freqs, c1W, c1b, cg, cb, c2W, c2b, n1Wt;
-    int64_t Wc[PFM_TF_MAX_LAYERS + 2], bb[PFM_TF_MAX_LAYERS + 2];
+    int64_t Wc[CTXT_MAX_NB], bb[CTXT_MAX_NB];
 };
 
 static __global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {

@@ -169,6 +169,11 @@ class TfLayout:
             raise NotImplementedError("ctxt_emdb: outp_dim must be a multiple of 4 (<= 64), hddn_dim a multiple of 4 (<= 512)")
         if cfg.num_particles > 512 or cfg.features > 16 or cfg.global_cond_dim > 16 or cfg.t_dim > 64:
             raise NotImplementedError("limits of this build: num_particles <= 512, features <= 16, global_cond_dim <= 16, frequencies <= 32")
+        self._init_params(cfg)
+        self._build()
+
+    def _init_params(self, cfg):
+        """Offsets of the parameters in the source vector (state_dict order), then the frequency table and a zero."""
         self.cfg = cfg
         self.shapes = cfg.param_shapes()
         self.p_off: Dict[str, int] = {}
@@ -184,7 +189,6 @@ class TfLayout:
         self._shape = dict(self.shapes)
         self._cursor = 0
         self._segments: List[Tuple[int, np.ndarray, bool]] = []
-        self._build()
 
     # ---- helpers ------------------------------------------------------------------------------
     def _alloc(self, n: int) -> int:
@@ -275,6 +279,9 @@ class TfLayout:
         k = "net.outp_embd.output_block.block.0"
         d.o2 = TfLin(self._put(self._w(k, np.arange(F)[:, None], np.arange(Hd)[None, :])), -1, -1, self._vec(k + ".bias"), -1)
 
+        self._finish(d)
+
+    def _finish(self, d):
         d.blob_floats = self._cursor
         self.desc = d
         idx = np.full(self._cursor, self.zero_off, dtype=np.int64)

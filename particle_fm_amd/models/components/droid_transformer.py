@@ -1,9 +1,10 @@
-"""Drop-in for the classes of particle_fm/models/components/droid_transformer.py that model
-"droid_fulltransformer" instantiates: ``FullTransformerEncoder`` and its parameter containers.
+"""Drop-in for the classes of particle_fm/models/components/droid_transformer.py that the models
+"droid_fulltransformer" and "droid_fullcrossattention" instantiate: ``FullTransformerEncoder``,
+``FullCrossAttentionEncoder`` and their parameter containers.
 
 Same class names, constructor keywords, parameter names / shapes / registration order (hence the same
 ``state_dict`` keys and, under a fixed seed, bit-identical default initialisation incl. ``init_zeros`` /
-``output_init_zeros``) as the reference (droid_transformer.py:117-229, 287-329, 400-527, 714-1051).  The sub-blocks
+``output_init_zeros``) as the reference (droid_transformer.py:117-229, 287-397, 400-527, 551-700, 714-1051).  The sub-blocks
 own parameters only: one evaluation of the whole encoder is a fixed sequence of HIP launches
 (``FullTransformerEncoder.forward`` / ``vector_field``), there is no per-block PyTorch compute and no CPU fallback.
 Configurations the kernels do not cover raise NotImplementedError at construction.
@@ -16,8 +17,9 @@ from typing import Mapping, Optional, Union
 import torch
 import torch.nn as nn
 
-from ... import hip_ops_tf
-from ...layout_tf import TfConfig, TfLayout
+from ... import hip_ops_ca, hip_ops_tf
+from ...layout_ca import CaConfig, CaLayout
+from ...layout_tf import TfConfig, TfLayout, default_freqs
 
 
 def _container_only(name):
@@ -85,19 +87,24 @@ class DenseNetwork(nn.Module):
 
 
 class MultiHeadedAttentionBlock(nn.Module):
-    """droid_transformer.py:117-284 (self-attention flavour): all_linear, layer_norm, out_linear."""
+    """droid_transformer.py:117-284: all_linear (self-attention) or q_linear / k_linear / v_linear (cross-attention),
+    layer_norm, out_linear."""
 
     def __init__(self, model_dim: int, num_heads: int = 1, drp: float = 0, init_zeros: bool = False,
                  do_selfattn: bool = False, do_layer_norm: bool = False, attn_act=None) -> None:
         super().__init__()
-        if not do_selfattn or not do_layer_norm or drp > 0 or attn_act is not None:
-            raise NotImplementedError("MultiHeadedAttentionBlock: the HIP path implements self-attention with "
-                                      "do_layer_norm=True, softmax, no dropout")
+        if not do_layer_norm or drp > 0 or attn_act is not None:
+            raise NotImplementedError("MultiHeadedAttentionBlock: the HIP path implements do_layer_norm=True, softmax, no dropout")
         self.model_dim, self.num_heads, self.head_dim = model_dim, num_heads, model_dim // num_heads
         if self.head_dim * num_heads != model_dim:
             raise ValueError("Model dimension must be divisible by number of heads!")  # droid_transformer.py:191
         self.do_selfattn, self.drp, self.do_layer_norm, self.attn_act = do_selfattn, drp, do_layer_norm, attn_act
-        self.all_linear = nn.Linear(model_dim, 3 * model_dim)
+        if do_selfattn:
+            self.all_linear = nn.Linear(model_dim, 3 * model_dim)
+        else:
+            self.q_linear = nn.Linear(model_dim, model_dim)
+            self.k_linear = nn.Linear(model_dim, model_dim)
+            self.v_linear = nn.Linear(model_dim, model_dim)
         self.layer_norm = nn.LayerNorm(model_dim)
         self.out_linear = nn.Linear(model_dim, model_dim)
         if init_zeros:
@@ -136,7 +143,95 @@ class TransformerEncoder(nn.Module):
     forward = _container_only("TransformerEncoder")
 
 
-class FullTransformerEncoder(nn.Module):
+class TransformerCrossAttentionLayer(nn.Module):
+    """droid_transformer.py:347-397: q <- q + cross_attn(norm1 q, norm0 kv); q <- q + dense(norm2 q, ctxt)."""
+
+    def __init__(self, model_dim: int, mha_config: Mapping | None = None, dense_config: Mapping | None = None,
+                 ctxt_dim: int = 0) -> None:
+        super().__init__()
+        self.model_dim, self.ctxt_dim = model_dim, ctxt_dim
+        self.cross_attn = MultiHeadedAttentionBlock(model_dim, do_selfattn=False, **(mha_config or {}))
+        self.dense = DenseNetwork(model_dim, outp_dim=model_dim, ctxt_dim=ctxt_dim, **(dense_config or {}))
+        self.norm0 = nn.LayerNorm(model_dim)
+        self.norm1 = nn.LayerNorm(model_dim)
+        self.norm2 = nn.LayerNorm(model_dim)
+
+    forward = _container_only("TransformerCrossAttentionLayer")
+
+
+class CrossAttentionEncoder(nn.Module):
+    """droid_transformer.py:551-618: learned global tokens, ``num_layers`` there-and-back cross-attention layer pairs."""
+
+    def __init__(self, model_dim: int = 64, num_tokens: int = 4, num_layers: int = 5, mha_config: Mapping | None = None,
+                 dense_config: Mapping | None = None, ctxt_dim: int = 0) -> None:
+        super().__init__()
+        self.model_dim, self.num_layers, self.num_tokens = model_dim, num_layers, num_tokens
+        self.global_tokens = nn.Parameter(torch.randn((1, num_tokens, model_dim)))
+        self.from_layers = nn.ModuleList([TransformerCrossAttentionLayer(model_dim, mha_config, dense_config, ctxt_dim)
+                                          for _ in range(num_layers)])
+        self.to_layers = nn.ModuleList([TransformerCrossAttentionLayer(model_dim, mha_config, dense_config, ctxt_dim)
+                                        for _ in range(num_layers)])
+
+    forward = _container_only("CrossAttentionEncoder")
+
+
+class _FusedEncoder(nn.Module):
+    """What the two full encoders share: the kernel layout per (num_points, precision), the flat parameter vector and
+    the packed weight blob.  Subclasses provide ``config()``, ``_LAYOUT`` and ``_forward_op``."""
+
+    _LAYOUT = None
+    _forward_op = None
+
+    def _init_fused(self, num_points, frequencies, add_time_to_input, t_emb):
+        # what the kernels need to know beyond the reference's own arguments
+        self.num_points, self.frequencies, self.add_time_to_input, self.t_emb = num_points, frequencies, add_time_to_input, t_emb
+        self._layouts = {}
+        self.mfma_dtype = "fp32"  # "f16x3": every Linear on split-fp16 operands, fp32-grade accuracy
+        self.cfg = self.config(num_points or 1)
+        self._LAYOUT(self.cfg)  # rejects unsupported sizes at construction
+
+    def layout(self, num_points: Optional[int] = None):
+        n = num_points or self.num_points
+        flags = 1 if self.mfma_dtype == "f16x3" else 0
+        lay = self._layouts.get((n, flags))
+        if lay is None:
+            lay = self._layouts[(n, flags)] = self._LAYOUT(self.config(n), flags=flags)
+        return lay
+
+    def set_precision(self, precision) -> None:
+        """"f16x3" -> split-fp16 Linears; anything else (incl. Lightning's "bf16-mixed": no bf16 kernels on this path) fp32."""
+        self.mfma_dtype = "f16x3" if str(precision) == "f16x3" else "fp32"
+
+    def flat_parameters(self, layout=None) -> torch.Tensor:
+        """All parameters in the layout's (= state_dict) order as one differentiable vector."""
+        lay = layout or self.layout()
+        named = dict(self.named_parameters())
+        return torch.cat([named[k[len("net."):]].reshape(-1) for k in lay.keys()])
+
+    def packed_weights(self, num_points: Optional[int] = None) -> torch.Tensor:
+        """Kernel blob of the current parameter values (no autograd); rebuilt on every call so it can never go stale
+        after an optimizer step, load_state_dict or an EMA swap, and never appears in state_dict()."""
+        lay = self.layout(num_points)
+        with torch.no_grad():
+            flat = self.flat_parameters(lay)
+            src = torch.cat([flat.float(), default_freqs(lay.cfg.t_dim, lay.cfg.t_emb).to(flat.device), torch.zeros(1, device=flat.device)])
+            return src[lay.index_map_on(flat.device)]
+
+    def vector_field(self, t: torch.Tensor, x: torch.Tensor, cond: torch.Tensor = None, mask: torch.Tensor = None,
+                     blob: torch.Tensor = None) -> torch.Tensor:
+        lay = self.layout(x.shape[1])
+        if blob is None:
+            blob = self.packed_weights(x.shape[1])
+        return type(self)._forward_op(lay, blob, t, x, cond, mask)
+
+    def forward(self, t: torch.Tensor, x: torch.Tensor, ctxt: torch.Tensor | None = None,
+                mask: Optional[torch.Tensor] = None, attn_bias=None, attn_mask=None) -> torch.Tensor:
+        raise RuntimeError(
+            f"{type(self).__name__}.forward(t_emb, x_cat, ...) of the reference takes the already embedded time; the HIP "
+            "path embeds in-kernel: call vector_field(t, x, cond, mask) (CNF.forward does)")
+
+
+class FullTransformerEncoder(_FusedEncoder):
     """droid_transformer.py:440-548.  ``forward(t, x, ctxt, mask)`` keeps the reference's call (t = the (B,N,T)
     time embedding, x already time-concatenated); ``vector_field(t, x, cond, mask)`` takes the time itself (B,)
     and the bare particle features and lets the kernels embed (what CNF.forward uses)."""
@@ -170,12 +265,7 @@ class FullTransformerEncoder(nn.Module):
                                       **node_embd_config)
         self.outp_embd = DenseNetwork(inpt_dim=self.model_dim, outp_dim=self.outp_dim, ctxt_dim=self.ctxt_out,
                                       **outp_embd_config)
-        # what the kernels need to know beyond the reference's own arguments
-        self.num_points, self.frequencies, self.add_time_to_input, self.t_emb = num_points, frequencies, add_time_to_input, t_emb
-        self._layouts = {}
-        self.mfma_dtype = "fp32"  # "f16x3": every Linear on split-fp16 operands (PFM_TF_F_F16X3), fp32-grade accuracy
-        self.cfg = self.config(num_points or 1)
-        TfLayout(self.cfg)  # rejects unsupported sizes at construction
+        self._init_fused(num_points, frequencies, add_time_to_input, t_emb)
 
     # -- layout / weights --------------------------------------------------------------------------
     def config(self, num_points: Optional[int] = None) -> TfConfig:
@@ -189,44 +279,52 @@ class FullTransformerEncoder(nn.Module):
                         ctxt_hidden=self.ctxt_emdb.hddn_dim[0], ctxt_dim=self.ctxt_out, frequencies=self.frequencies,
                         global_cond_dim=self.ctxt_dim - t_dim, add_time_to_input=self.add_time_to_input, t_emb=self.t_emb)
 
-    def layout(self, num_points: Optional[int] = None) -> TfLayout:
-        n = num_points or self.num_points
-        flags = 1 if self.mfma_dtype == "f16x3" else 0
-        lay = self._layouts.get((n, flags))
-        if lay is None:
-            lay = self._layouts[(n, flags)] = TfLayout(self.config(n), flags=flags)
-        return lay
+    _LAYOUT = TfLayout
+    _forward_op = staticmethod(hip_ops_tf.tf_forward)
 
-    def set_precision(self, precision) -> None:
-        """"f16x3" -> split-fp16 Linears; anything else (incl. Lightning's "bf16-mixed": no bf16 kernels on this path) fp32."""
-        self.mfma_dtype = "f16x3" if str(precision) == "f16x3" else "fp32"
 
-    def flat_parameters(self, layout: Optional[TfLayout] = None) -> torch.Tensor:
-        """All parameters in the layout's (= state_dict) order as one differentiable vector."""
-        lay = layout or self.layout()
-        named = dict(self.named_parameters())
-        return torch.cat([named[k[len("net."):]].reshape(-1) for k in lay.keys()])
+class FullCrossAttentionEncoder(_FusedEncoder):
+    """droid_transformer.py:620-711; evaluation as FullTransformerEncoder (``vector_field``)."""
 
-    def packed_weights(self, num_points: Optional[int] = None) -> torch.Tensor:
-        """Kernel blob of the current parameter values (no autograd); rebuilt on every call so it can never go stale
-        after an optimizer step, load_state_dict or an EMA swap, and never appears in state_dict()."""
-        lay = self.layout(num_points)
-        with torch.no_grad():
-            flat = self.flat_parameters(lay)
-            from ...layout_tf import default_freqs
-            src = torch.cat([flat.float(), default_freqs(lay.cfg.t_dim, lay.cfg.t_emb).to(flat.device), torch.zeros(1, device=flat.device)])
-            return src[lay.index_map_on(flat.device)]
+    def __init__(self, inpt_dim: int, outp_dim: int, ctxt_dim: int = 0, cae_config: Mapping | None = None,
+                 node_embd_config: Mapping | None = None, outp_embd_config: Mapping | None = None,
+                 ctxt_embd_config: Mapping | None = None, *, num_points: int = 0, frequencies: int = 0,
+                 add_time_to_input: bool = True, t_emb: str = "cosine") -> None:
+        super().__init__()
+        if not ctxt_dim:
+            raise NotImplementedError("the HIP cross-attention path needs the context network (ctxt_dim > 0: it always is, "
+                                      "CNF passes global_cond_dim + 2*frequencies)")
+        self.inpt_dim, self.outp_dim, self.ctxt_dim = inpt_dim, outp_dim, ctxt_dim
+        cae_config = deepcopy(cae_config) or {}
+        node_embd_config = deepcopy(node_embd_config) or {}
+        outp_embd_config = deepcopy(outp_embd_config) or {}
+        ctxt_embd_config = deepcopy(ctxt_embd_config) or {}
+        cae_config.setdefault("dense_config", {})
+        if "model_dim" in cae_config:  # droid_transformer.py:660-669: dense nets default to twice the width
+            model_dim = cae_config["model_dim"]
+            for cfg in (node_embd_config, ctxt_embd_config, outp_embd_config, cae_config["dense_config"]):
+                cfg.setdefault("hddn_dim", 2 * model_dim)
+        self.ctxt_emdb = DenseNetwork(inpt_dim=self.ctxt_dim, **ctxt_embd_config)
+        self.ctxt_out = self.ctxt_emdb.outp_dim
+        self.cae = CrossAttentionEncoder(**cae_config, ctxt_dim=self.ctxt_out)
+        self.model_dim = self.cae.model_dim
+        self.node_embd = DenseNetwork(inpt_dim=self.inpt_dim, outp_dim=self.model_dim, ctxt_dim=self.ctxt_out,
+                                      **node_embd_config)
+        self.outp_embd = DenseNetwork(inpt_dim=self.model_dim, outp_dim=self.outp_dim, ctxt_dim=self.ctxt_out,
+                                      **outp_embd_config)
+        self._init_fused(num_points, frequencies, add_time_to_input, t_emb)
 
-    # -- evaluation --------------------------------------------------------------------------------
-    def vector_field(self, t: torch.Tensor, x: torch.Tensor, cond: torch.Tensor = None, mask: torch.Tensor = None,
-                     blob: torch.Tensor = None) -> torch.Tensor:
-        lay = self.layout(x.shape[1])
-        if blob is None:
-            blob = self.packed_weights(x.shape[1])
-        return hip_ops_tf.tf_forward(lay, blob, t, x, cond, mask)
+    def config(self, num_points: Optional[int] = None) -> CaConfig:
+        t_dim = 2 * self.frequencies
+        dense = self.cae.from_layers[0].dense
+        hid = {dense.hddn_dim[0], self.node_embd.hddn_dim[0], self.outp_embd.hddn_dim[0]}
+        if len(hid) != 1:
+            raise NotImplementedError("the HIP cross-attention path needs one hddn_dim for node_embd / dense / outp_embd")
+        return CaConfig(num_particles=num_points or self.num_points, features=self.outp_dim, model_dim=self.model_dim,
+                        num_layers=self.cae.num_layers, num_heads=self.cae.from_layers[0].cross_attn.num_heads,
+                        num_tokens=self.cae.num_tokens, hidden=hid.pop(), ctxt_hidden=self.ctxt_emdb.hddn_dim[0],
+                        ctxt_dim=self.ctxt_out, frequencies=self.frequencies, global_cond_dim=self.ctxt_dim - t_dim,
+                        add_time_to_input=self.add_time_to_input, t_emb=self.t_emb)
 
-    def forward(self, t: torch.Tensor, x: torch.Tensor, ctxt: torch.Tensor | None = None,
-                mask: Optional[torch.Tensor] = None, attn_bias=None, attn_mask=None) -> torch.Tensor:
-        raise RuntimeError(
-            "FullTransformerEncoder.forward(t_emb, x_cat, ...) of the reference takes the already embedded time; the HIP "
-            "path embeds in-kernel: call vector_field(t, x, cond, mask) (CNF.forward does)")
+    _LAYOUT = CaLayout
+    _forward_op = staticmethod(hip_ops_ca.ca_forward)

@@ -4,10 +4,10 @@ Same class names, constructor keywords, ``state_dict`` keys and call signatures 
 (flow_matching_module.py:34-71, 74-347, 350-677), so that the Hydra target
 ``particle_fm.models.flow_matching_module.SetFlowMatchingLitModule`` can be pointed here and the rest of the
 pipeline (Lightning Trainer, EMA callback, evaluation callbacks -> ``sample``) keeps working.  The compute
-of the hot path -- EPiC or Full-Transformer vector field, FM/CFM loss forward+backward, fixed-step midpoint sampling -- runs in
-libpfm_hip.so.  What the native path does not cover raises NotImplementedError at construction or call time
-(never a silent PyTorch fallback): models other than "epic" / "droid_fulltransformer", losses other than FM-OT / CFM, solvers other
-than "midpoint", t_emb other than "cosine", use_normaliser=True.
+of the hot path -- EPiC, Full-Transformer or cross-attention vector field, FM / CFM / droid loss forward+backward,
+fixed-step midpoint sampling -- runs in libpfm_hip.so.  What the native path does not cover raises NotImplementedError at construction or call time
+(never a silent PyTorch fallback): model "mdma", losses other than FM-OT / CFM / droid, solvers other than "midpoint",
+t_emb="gaussian", use_normaliser=True.
 """
 from __future__ import annotations
 
@@ -18,10 +18,11 @@ import torch.nn as nn
 from torch import Tensor
 
 from .. import fm_loss as _fm_loss
+from .. import fm_loss_ca as _fm_loss_ca
 from .. import fm_loss_tf as _fm_loss_tf
 from .. import fm_loss_wide as _fm_loss_wide
-from .. import hip_ops, hip_ops_tf, hip_ops_wide
-from .components.droid_transformer import FullTransformerEncoder
+from .. import hip_ops, hip_ops_ca, hip_ops_tf, hip_ops_wide
+from .components.droid_transformer import FullCrossAttentionEncoder, FullTransformerEncoder
 from .components.epic import EPiC_encoder
 from .components.losses import ConditionalFlowMatchingLoss, DroidLoss, FlowMatchingLoss
 from .components.time_emb import CosineEncoding
@@ -121,11 +122,19 @@ class CNF(nn.Module):
                                               num_points=num_particles, frequencies=frequencies,
                                               add_time_to_input=add_time_to_input,
                                               t_emb=t_emb if t_emb in ("cosine", "sincos") else "cosine")
-        elif model in ("droid_fullcrossattention", "mdma"):
-            raise NotImplementedError(f"Model {model} has no HIP path in this build ('epic' and 'droid_fulltransformer' do).")
+        elif model == "droid_fullcrossattention":  # flow_matching_module.py:159-165
+            self.net = FullCrossAttentionEncoder(inpt_dim=input_dim, outp_dim=features,
+                                                 ctxt_dim=global_cond_dim + 2 * frequencies, **net_config,
+                                                 num_points=num_particles, frequencies=frequencies,
+                                                 add_time_to_input=add_time_to_input,
+                                                 t_emb=t_emb if t_emb in ("cosine", "sincos") else "cosine")
+        elif model == "mdma":
+            raise NotImplementedError(f"Model {model} has no HIP path in this build ('epic', 'droid_fulltransformer' and "
+                                      "'droid_fullcrossattention' do).")
         else:
             raise NotImplementedError(f"Model {model} not implemented.")  # flow_matching_module.py:170
         self.is_transformer = model == "droid_fulltransformer"
+        self.is_cross_attention = model == "droid_fullcrossattention"
         self.register_buffer("frequencies", 2 ** torch.arange(frequencies) * torch.pi)  # :172
         self.activation = activation
         self.t_emb = t_emb
@@ -175,6 +184,9 @@ class CNF(nn.Module):
         if self.is_transformer:
             return _fm_loss_tf.tf_fm_loss(lay, self.net.flat_parameters(lay), x, t, z, cond=cond, mask=mask, sigma=sigma,
                                           kind=kind, eps=eps)
+        if self.is_cross_attention:
+            return _fm_loss_ca.ca_fm_loss(lay, self.net.flat_parameters(lay), x, t, z, cond=cond, mask=mask, sigma=sigma,
+                                          kind=kind, eps=eps)
         src = self.net.source_vector(lay)
         if self.net.wide:
             return _fm_loss_wide.epic_wide_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps)
@@ -190,6 +202,9 @@ class CNF(nn.Module):
             blob = weights if weights is not None else self.net.packed_weights(z.shape[1])
             if self.is_transformer:
                 return hip_ops_tf.tf_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
+                                                     ode_steps=ode_steps, premask=False)
+            if self.is_cross_attention:
+                return hip_ops_ca.ca_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
                                                      ode_steps=ode_steps, premask=False)
             if self.net.wide:
                 return hip_ops_wide.ew_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,

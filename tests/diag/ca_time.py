@@ -1,0 +1,67 @@
+"""Timing of the cross-attention NFE / sampler / loss at the LHCO configuration of fm_droid_crossattention.yaml
+(B=128, N=279, D=128, 8 layer pairs, 4 tokens).  Diagnostic, not a test."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from particle_fm_amd import hip_ops_ca as ops
+from particle_fm_amd.layout_ca import CaConfig, CaLayout
+from oracle.seeded import seeded_state
+
+
+def flop_per_jet(c):
+    """Algorithmic forward FLOP of one network evaluation of one jet (dense over the padded N; 2 FLOP per MAC)."""
+    N, D, Hd, Tk, L = c.num_particles, c.model_dim, c.hidden, c.num_tokens, c.num_layers
+    f_in = c.features + (c.t_dim if c.add_time_to_input else 0)
+    row = 2 * f_in * Hd + 2 * Hd * D                                              # node_embd
+    row += L * (2 * D * 2 * D + 2 * D * D + 2 * D * D + 2 * D * Hd + 2 * Hd * D)  # from.kv, to.q, to.out, to.d1, to.d2
+    row += L * 2 * (2 * Tk * D + 2 * Tk * D)                                      # both attentions: Q K^T and P V
+    row += 2 * D * Hd + 2 * Hd * c.features                                       # outp_embd
+    tok = L * (2 * D * D + 2 * D * D + 2 * D * Hd + 2 * Hd * D + 2 * D * 2 * D)   # from.q, from.out, d1, d2, to.kv
+    return N * row + Tk * tok
+
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+cfg = CaConfig(num_particles=279, global_cond_dim=5)
+lay = CaLayout(cfg, flags=1 if "x3" in sys.argv else 0)
+st = {k: torch.from_numpy(v) for k, v in seeded_state(dict(cfg.param_shapes()), 1).items()}
+blob = lay.pack_blob(st).cuda()
+gen = torch.Generator().manual_seed(0)
+n = torch.randint(20, 280, (B,), generator=gen)
+mask = (torch.arange(279)[None] < n[:, None]).float().cuda()
+x = torch.randn(B, 279, 3, generator=gen).cuda()
+cond = torch.randn(B, 5, generator=gen).cuda()
+t = torch.rand(B, generator=gen).cuda()
+for _ in range(3):
+    v = ops.ca_forward(lay, blob, t, x, cond, mask)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    v = ops.ca_forward(lay, blob, t, x, cond, mask)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 20
+fl = flop_per_jet(cfg) * B
+print(f"params {cfg.param_count()}  {flop_per_jet(cfg)/1e6:.1f} MFLOP/jet/NFE")
+print(f"NFE: {dt*1e3:.3f} ms  {fl/dt/1e12:.1f} TFLOP/s algorithmic ({B} jets)")
+if steps > 1:
+    xs = ops.ca_sample_midpoint(lay, blob, x, cond, mask, ode_steps=3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    xs = ops.ca_sample_midpoint(lay, blob, x, cond, mask, ode_steps=steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"sample {steps} steps: {dt*1e3:.1f} ms  {B/dt:.1f} jets/s  {fl*2*(steps-1)/dt/1e12:.1f} TFLOP/s")
+if len(sys.argv) > 3 and sys.argv[3] == "train":
+    from particle_fm_amd.fm_loss_ca import ca_fm_loss
+    flat = torch.cat([st[k].reshape(-1) for k in lay.keys()]).cuda().requires_grad_(True)
+    z = torch.randn(B, 279, 3, generator=gen).cuda()
+    for _ in range(2):
+        loss = ca_fm_loss(lay, flat, x, t, z, cond, mask.unsqueeze(-1)); loss.backward()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        flat.grad = None
+        loss = ca_fm_loss(lay, flat, x, t, z, cond, mask.unsqueeze(-1)); loss.backward()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print(f"loss fwd+bwd: {dt*1e3:.2f} ms  {B/dt:.0f} jets/s  {3*fl/dt/1e12:.1f} TFLOP/s algorithmic")

@@ -92,7 +92,8 @@ def test_no_cpu_fallback():
 
 def test_c_abi_exports_every_declared_symbol():
     lib = _lib.load()
-    header = open(f"{ROOT}/include/pfm_hip.h").read() + open(f"{ROOT}/include/pfm_tf.h").read() + open(f"{ROOT}/include/pfm_epicw.h").read()
+    import glob
+    header = "".join(open(h).read() for h in sorted(glob.glob(f"{ROOT}/include/*.h")))
     declared = set(re.findall(r"^(?:int64_t|int|const char \*)\s*\*?(pfm_[a-z0-9_]+)\s*\(", header, flags=re.M))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
@@ -130,6 +131,30 @@ def test_tf_desc_mirror_matches_the_c_struct(tmp_path):
     assert lib.pfm_tf_workspace_floats(ctypes.byref(lay.desc), 1, 0) == -1
     rc = lib.pfm_tf_forward(ctypes.byref(lay.desc), None, None, 0, None, None, None, None, 1, None, None)
     assert rc == 10001 and b"head_dim" in lib.pfm_last_error()
+
+
+def test_ca_desc_mirror_matches_the_c_struct(tmp_path):
+    """pfm_ca_desc as gcc lays it out vs the ctypes mirror; host-side validation of the cross-attention entry points."""
+    import subprocess
+    from particle_fm_amd.layout_ca import CaConfig, CaDesc, CaLayer, CaLayout
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pfm_ca.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(pfm_ca_desc), offsetof(pfm_ca_desc, from_layer), sizeof(pfm_ca_layer), offsetof(pfm_ca_desc, to_layer),'
+                   'offsetof(pfm_ca_desc, global_tokens), offsetof(pfm_ca_desc, o2));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", f"{ROOT}/include", str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [ctypes.sizeof(CaDesc), CaDesc.from_layer.offset, ctypes.sizeof(CaLayer), CaDesc.to_layer.offset,
+                   CaDesc.global_tokens.offset, CaDesc.o2.offset]
+    lib = _lib.load()
+    lay = CaLayout(CaConfig(num_particles=279, global_cond_dim=5))
+    n0, n1 = (lib.pfm_ca_workspace_floats(ctypes.byref(lay.desc), 128, tr) for tr in (0, 1))
+    assert 0 < n0 < n1
+    assert lib.pfm_ca_backward_scratch_floats(ctypes.byref(lay.desc), 128) > 0
+    lay.desc.tokens = 9
+    assert lib.pfm_ca_workspace_floats(ctypes.byref(lay.desc), 1, 0) == -1
+    rc = lib.pfm_ca_forward(ctypes.byref(lay.desc), None, None, 0, None, None, None, None, 1, None, None)
+    assert rc == 10001 and b"tokens" in lib.pfm_last_error()
 
 
 def test_flat_params_alias_and_survive_load_state_dict():
