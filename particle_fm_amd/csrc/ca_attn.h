@@ -1,9 +1,11 @@
 // Attention kernels of the cross-attention encoder (droid_transformer.py:442-472): a handful of global tokens attend to
 // all particles of the jet (key mask), then every particle attends to the tokens.  Both shapes are tiny next to the
-// Linears (2 * 2 * N * tokens * D FLOP per jet and layer), so they run on the VALU, one workgroup per jet:
-//   *_from_* : wave per head, lanes over the keys (particles); softmax statistics by wave reductions
-//   *_to_*   : thread per (particle, head); the jet's token keys / values sit in LDS
-// HD = head_dim (8 in fm_droid_crossattention.yaml, 16 supported), TK = compile-time bound on the number of tokens.
+// Linears (2 * 2 * N * tokens * D FLOP per jet and layer), so they run on the VALU:
+//   *_from_* : grid (jets, heads / 4): wave per head, lanes over the keys (particles), ONE pass with a running softmax
+//              per lane (max, sum, weighted values for every token), merged over the wave by shuffles.  The four heads
+//              of a workgroup read neighbouring 32..64-byte pieces of the same key rows, so every fetched line is used.
+//   *_to_*   : grid (jets, ceil(N / 64)): thread per (particle, head); the jet's token keys / values sit in LDS
+// HD = head_dim (8 in fm_droid_crossattention.yaml, 16 supported), TK = compile-time bound on the number of tokens (4 or 8).
 #pragma once
 #include "tf_common.h"
 
@@ -37,80 +39,82 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&r
     for (int i = 0; i < HD / 4; ++i) *reinterpret_cast<f32x4*>(p + 4 * i) = f32x4{r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]};
 }
 
+constexpr int TO_ROWS = 64;  // particles per workgroup of the *_to_* kernels
+
+// running softmax of one lane over its keys, for TK query tokens
+template <int HD, int TK>
+struct Running {
+    float m[TK], l[TK], o[TK][HD];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int tk = 0; tk < TK; ++tk) {
+            m[tk] = -__builtin_inff();
+            l[tk] = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) o[tk][d] = 0.f;
+        }
+    }
+};
+
+template <int HD, int TK>
+__device__ __forceinline__ void load_queries(float (&qr)[TK][HD], const float* __restrict__ q, int Tk, int D, float scale) {
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk) {
+        if (tk < Tk) {
+            load_row<HD>(qr[tk], q + (int64_t)tk * D);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) qr[tk][d] *= scale;
+        } else {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) qr[tk][d] = 0.f;
+        }
+    }
+}
+
 // ---- tokens <- particles ---------------------------------------------------------------------------
 // q [n_jets*Tk][D]; kv [n_jets*N][2D] (k | v); mask [n_jets][N] or nullptr; out [n_jets*Tk][D]
 template <int HD, int TK>
 __global__ __launch_bounds__(256) void ca_attn_from_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                            const float* __restrict__ mask, float* __restrict__ out, int N,
                                                            int D, int heads, int Tk) {
-    const int jet = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const float scale = 1.0f / sqrtf((float)HD);
-    for (int h = w; h < heads; h += 4) {
-        float qr[TK][HD];
+    const int jet = blockIdx.x, lane = threadIdx.x & 63, h = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (h >= heads) return;
+    float qr[TK][HD];  // pre-scaled by 1 / sqrt(HD)
+    load_queries<HD, TK>(qr, q + (int64_t)jet * Tk * D + h * HD, Tk, D, 1.0f / sqrtf((float)HD));
+    Running<HD, TK> st;
+    st.init();
+    const float* base = kv + (int64_t)jet * N * 2 * D + h * HD;
+#pragma unroll 2
+    for (int n = lane; n < N; n += 64) {
+        if (mask && mask[(int64_t)jet * N + n] == 0.f) continue;
+        float kr[HD], vr[HD];
+        load_row<HD>(kr, base + (int64_t)n * 2 * D);
+        load_row<HD>(vr, base + (int64_t)n * 2 * D + D);
 #pragma unroll
         for (int tk = 0; tk < TK; ++tk) {
-            if (tk < Tk) load_row<HD>(qr[tk], q + ((int64_t)jet * Tk + tk) * D + h * HD);
-            else {
+            float s = 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) qr[tk][d] = 0.f;
-            }
+            for (int d = 0; d < HD; ++d) s = fmaf(qr[tk][d], kr[d], s);
+            const float mn = fmaxf(st.m[tk], s);
+            const float corr = __expf(st.m[tk] - mn), p = __expf(s - mn);  // first key: exp(-inf) = 0
+            st.m[tk] = mn;
+            st.l[tk] = fmaf(st.l[tk], corr, p);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) st.o[tk][d] = fmaf(st.o[tk][d], corr, p * vr[d]);
         }
-        float m[TK];
+    }
+    // merge the 64 lanes; all keys masked: max = -inf -> NaN like torch's softmax over an empty row
 #pragma unroll
-        for (int tk = 0; tk < TK; ++tk) m[tk] = -__builtin_inff();
-        for (int n = lane; n < N; n += 64) {
-            if (mask && mask[(int64_t)jet * N + n] == 0.f) continue;
-            float kr[HD];
-            load_row<HD>(kr, kv + ((int64_t)jet * N + n) * 2 * D + h * HD);
+    for (int tk = 0; tk < TK; ++tk) {
+        const float M = wmax(st.m[tk]);
+        const float w = st.m[tk] == -__builtin_inff() ? 0.f : __expf(st.m[tk] - M);
+        const float L = wsum(st.l[tk] * w);
 #pragma unroll
-            for (int tk = 0; tk < TK; ++tk) {
-                float s = 0.f;
-#pragma unroll
-                for (int d = 0; d < HD; ++d) s = fmaf(qr[tk][d], kr[d], s);
-                m[tk] = fmaxf(m[tk], s * scale);
-            }
+        for (int d = 0; d < HD; ++d) {
+            const float o = wsum(st.o[tk][d] * w);
+            if (lane == tk * HD + d && tk < Tk)
+                out[((int64_t)jet * Tk + tk) * D + h * HD + d] = (M == -__builtin_inff()) ? __builtin_nanf("") : o / L;
         }
-#pragma unroll
-        for (int tk = 0; tk < TK; ++tk) m[tk] = wmax(m[tk]);
-        float l[TK], o[TK][HD];
-#pragma unroll
-        for (int tk = 0; tk < TK; ++tk) {
-            l[tk] = 0.f;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) o[tk][d] = 0.f;
-        }
-        for (int n = lane; n < N; n += 64) {
-            if (mask && mask[(int64_t)jet * N + n] == 0.f) continue;
-            float kr[HD], vr[HD];
-            const float* row = kv + ((int64_t)jet * N + n) * 2 * D + h * HD;
-            load_row<HD>(kr, row);
-            load_row<HD>(vr, row + D);
-#pragma unroll
-            for (int tk = 0; tk < TK; ++tk) {
-                float s = 0.f;
-#pragma unroll
-                for (int d = 0; d < HD; ++d) s = fmaf(qr[tk][d], kr[d], s);
-                const float p = __expf(s * scale - m[tk]);
-                l[tk] += p;
-#pragma unroll
-                for (int d = 0; d < HD; ++d) o[tk][d] = fmaf(p, vr[d], o[tk][d]);
-            }
-        }
-#pragma unroll
-        for (int tk = 0; tk < TK; ++tk) {
-            l[tk] = wsum(l[tk]);
-#pragma unroll
-            for (int d = 0; d < HD; ++d) o[tk][d] = wsum(o[tk][d]);
-        }
-        // lane (tk, d) writes one element; all keys masked: m = -inf, l = 0 -> NaN like torch's softmax
-#pragma unroll
-        for (int tk = 0; tk < TK; ++tk)
-#pragma unroll
-            for (int d = 0; d < HD; ++d)
-                if (lane == tk * HD + d && tk < Tk) {
-                    const float mm = m[tk];
-                    out[((int64_t)jet * Tk + tk) * D + h * HD + d] = (mm == -__builtin_inff()) ? __builtin_nanf("") : o[tk][d] / l[tk];
-                }
     }
 }
 
@@ -120,98 +124,94 @@ __global__ __launch_bounds__(256) void ca_attn_from_bwd_kernel(const float* __re
                                                                const float* __restrict__ mask, const float* __restrict__ O,
                                                                const float* __restrict__ dO, float* __restrict__ dq,
                                                                float* __restrict__ dkv, int N, int D, int heads, int Tk) {
-    const int jet = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int jet = blockIdx.x, lane = threadIdx.x & 63, h = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (h >= heads) return;
     const float scale = 1.0f / sqrtf((float)HD);
-    for (int h = w; h < heads; h += 4) {
-        float qr[TK][HD], dor[TK][HD], delta[TK];
+    float qr[TK][HD], dor[TK][HD], delta[TK];
+    load_queries<HD, TK>(qr, q + (int64_t)jet * Tk * D + h * HD, Tk, D, scale);
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk) {
+        delta[tk] = 0.f;
+        if (tk < Tk) {
+            const int64_t e = ((int64_t)jet * Tk + tk) * D + h * HD;
+            load_row<HD>(dor[tk], dO + e);
+            float orow[HD];
+            load_row<HD>(orow, O + e);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) delta[tk] = fmaf(dor[tk][d], orow[d], delta[tk]);
+        } else {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dor[tk][d] = 0.f;
+        }
+    }
+    const float* base = kv + (int64_t)jet * N * 2 * D + h * HD;
+    // pass 1: softmax statistics (running max and sum per lane, merged over the wave)
+    float m[TK], l[TK];
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk) { m[tk] = -__builtin_inff(); l[tk] = 0.f; }
+#pragma unroll 2
+    for (int n = lane; n < N; n += 64) {
+        if (mask && mask[(int64_t)jet * N + n] == 0.f) continue;
+        float kr[HD];
+        load_row<HD>(kr, base + (int64_t)n * 2 * D);
 #pragma unroll
         for (int tk = 0; tk < TK; ++tk) {
-            delta[tk] = 0.f;
-            if (tk < Tk) {
-                const int64_t e = ((int64_t)jet * Tk + tk) * D + h * HD;
-                load_row<HD>(qr[tk], q + e);
-                load_row<HD>(dor[tk], dO + e);
-                float orow[HD];
-                load_row<HD>(orow, O + e);
+            float s = 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) delta[tk] = fmaf(dor[tk][d], orow[d], delta[tk]);
-            } else {
-#pragma unroll
-                for (int d = 0; d < HD; ++d) { qr[tk][d] = 0.f; dor[tk][d] = 0.f; }
-            }
+            for (int d = 0; d < HD; ++d) s = fmaf(qr[tk][d], kr[d], s);
+            const float mn = fmaxf(m[tk], s);
+            l[tk] = fmaf(l[tk], __expf(m[tk] - mn), __expf(s - mn));
+            m[tk] = mn;
         }
-        float m[TK], l[TK];
+    }
 #pragma unroll
-        for (int tk = 0; tk < TK; ++tk) { m[tk] = -__builtin_inff(); l[tk] = 0.f; }
-        for (int n = lane; n < N; n += 64) {
-            if (mask && mask[(int64_t)jet * N + n] == 0.f) continue;
-            float kr[HD];
-            load_row<HD>(kr, kv + ((int64_t)jet * N + n) * 2 * D + h * HD);
+    for (int tk = 0; tk < TK; ++tk) {
+        const float M = wmax(m[tk]);
+        const float w = m[tk] == -__builtin_inff() ? 0.f : __expf(m[tk] - M);
+        l[tk] = 1.0f / wsum(l[tk] * w);
+        m[tk] = M;
+    }
+    // pass 2: gradients
+    float dqa[TK][HD];
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk)
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dqa[tk][d] = 0.f;
+    float* gbase = dkv + (int64_t)jet * N * 2 * D + h * HD;
+#pragma unroll 2
+    for (int n = lane; n < N; n += 64) {
+        float dk[HD], dv[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+        if (!(mask && mask[(int64_t)jet * N + n] == 0.f)) {
+            float kr[HD], vr[HD];
+            load_row<HD>(kr, base + (int64_t)n * 2 * D);
+            load_row<HD>(vr, base + (int64_t)n * 2 * D + D);
 #pragma unroll
             for (int tk = 0; tk < TK; ++tk) {
-                float s = 0.f;
+                float s = 0.f, dp = 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) s = fmaf(qr[tk][d], kr[d], s);
-                m[tk] = fmaxf(m[tk], s * scale);
-            }
-        }
+                for (int d = 0; d < HD; ++d) { s = fmaf(qr[tk][d], kr[d], s); dp = fmaf(dor[tk][d], vr[d], dp); }
+                const float p = __expf(s - m[tk]) * l[tk];
+                const float ds = p * (dp - delta[tk]);  // d loss / d (scaled score); qr carries the 1 / sqrt(HD)
 #pragma unroll
-        for (int tk = 0; tk < TK; ++tk) m[tk] = wmax(m[tk]);
-        for (int n = lane; n < N; n += 64) {
-            if (mask && mask[(int64_t)jet * N + n] == 0.f) continue;
-            float kr[HD];
-            load_row<HD>(kr, kv + ((int64_t)jet * N + n) * 2 * D + h * HD);
-#pragma unroll
-            for (int tk = 0; tk < TK; ++tk) {
-                float s = 0.f;
-#pragma unroll
-                for (int d = 0; d < HD; ++d) s = fmaf(qr[tk][d], kr[d], s);
-                l[tk] += __expf(s * scale - m[tk]);
-            }
-        }
-#pragma unroll
-        for (int tk = 0; tk < TK; ++tk) l[tk] = 1.0f / wsum(l[tk]);
-        float dqa[TK][HD];
-#pragma unroll
-        for (int tk = 0; tk < TK; ++tk)
-#pragma unroll
-            for (int d = 0; d < HD; ++d) dqa[tk][d] = 0.f;
-        for (int n = lane; n < N; n += 64) {
-            float* grow = dkv + ((int64_t)jet * N + n) * 2 * D + h * HD;
-            float dk[HD], dv[HD];
-#pragma unroll
-            for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-            if (!(mask && mask[(int64_t)jet * N + n] == 0.f)) {
-                float kr[HD], vr[HD];
-                const float* row = kv + ((int64_t)jet * N + n) * 2 * D + h * HD;
-                load_row<HD>(kr, row);
-                load_row<HD>(vr, row + D);
-#pragma unroll
-                for (int tk = 0; tk < TK; ++tk) {
-                    float s = 0.f, dp = 0.f;
-#pragma unroll
-                    for (int d = 0; d < HD; ++d) { s = fmaf(qr[tk][d], kr[d], s); dp = fmaf(dor[tk][d], vr[d], dp); }
-                    const float p = __expf(s * scale - m[tk]) * l[tk];
-                    const float ds = p * (dp - delta[tk]) * scale;
-#pragma unroll
-                    for (int d = 0; d < HD; ++d) {
-                        dqa[tk][d] = fmaf(ds, kr[d], dqa[tk][d]);
-                        dk[d] = fmaf(ds, qr[tk][d], dk[d]);
-                        dv[d] = fmaf(p, dor[tk][d], dv[d]);
-                    }
+                for (int d = 0; d < HD; ++d) {
+                    dqa[tk][d] = fmaf(ds, kr[d], dqa[tk][d]);
+                    dk[d] = fmaf(ds, qr[tk][d], dk[d]);
+                    dv[d] = fmaf(p, dor[tk][d], dv[d]);
                 }
             }
-            store_row<HD>(grow, dk);
-            store_row<HD>(grow + D, dv);
         }
-#pragma unroll
-        for (int tk = 0; tk < TK; ++tk)
-#pragma unroll
-            for (int d = 0; d < HD; ++d) {
-                const float s = wsum(dqa[tk][d]);
-                if (lane == tk * HD + d && tk < Tk) dq[((int64_t)jet * Tk + tk) * D + h * HD + d] = s;
-            }
+        store_row<HD>(gbase + (int64_t)n * 2 * D, dk);
+        store_row<HD>(gbase + (int64_t)n * 2 * D + D, dv);
     }
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk)
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            const float s = wsum(dqa[tk][d]) * scale;
+            if (lane == tk * HD + d && tk < Tk) dq[((int64_t)jet * Tk + tk) * D + h * HD + d] = s;
+        }
 }
 
 // ---- particles <- tokens ---------------------------------------------------------------------------
@@ -220,12 +220,12 @@ template <int HD, int TK>
 __global__ __launch_bounds__(256) void ca_attn_to_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                          float* __restrict__ out, int N, int D, int heads, int Tk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [Tk][2D]
-    const int jet = blockIdx.x;
+    const int jet = blockIdx.x, r0 = blockIdx.y * TO_ROWS, nr = min(TO_ROWS, N - r0);
     for (int i = threadIdx.x; i < Tk * 2 * D; i += 256) lds[i] = kv[(int64_t)jet * Tk * 2 * D + i];
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)HD);
-    for (int idx = threadIdx.x; idx < N * heads; idx += 256) {
-        const int r = idx / heads, h = idx - r * heads;
+    for (int idx = threadIdx.x; idx < nr * heads; idx += 256) {
+        const int r = r0 + idx / heads, h = idx % heads;
         const int64_t e = ((int64_t)jet * N + r) * D + h * HD;
         float qr[HD];
         load_row<HD>(qr, q + e);
@@ -234,9 +234,11 @@ __global__ __launch_bounds__(256) void ca_attn_to_kernel(const float* __restrict
         for (int tk = 0; tk < TK; ++tk) {
             s[tk] = -__builtin_inff();
             if (tk < Tk) {
+                float kr[HD];
+                load_row<HD>(kr, lds + tk * 2 * D + h * HD);
                 float a = 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) a = fmaf(qr[d], lds[tk * 2 * D + h * HD + d], a);
+                for (int d = 0; d < HD; ++d) a = fmaf(qr[d], kr[d], a);
                 s[tk] = a * scale;
             }
             mx = fmaxf(mx, s[tk]);
@@ -249,8 +251,10 @@ __global__ __launch_bounds__(256) void ca_attn_to_kernel(const float* __restrict
             if (tk < Tk) {
                 const float p = __expf(s[tk] - mx);
                 l += p;
+                float vr[HD];
+                load_row<HD>(vr, lds + tk * 2 * D + D + h * HD);
 #pragma unroll
-                for (int d = 0; d < HD; ++d) o[d] = fmaf(p, lds[tk * 2 * D + D + h * HD + d], o[d]);
+                for (int d = 0; d < HD; ++d) o[d] = fmaf(p, vr[d], o[d]);
             }
         const float inv = 1.0f / l;
 #pragma unroll
@@ -259,14 +263,14 @@ __global__ __launch_bounds__(256) void ca_attn_to_kernel(const float* __restrict
     }
 }
 
-// backward: dq [n_jets*N][D]; dkv [n_jets*Tk][2D] (sum over the jet's particles, accumulated in LDS)
+// backward: dq [n_jets*N][D]; dkv [n_jets*Tk][2D] += this workgroup's rows (zeroed by the caller; LDS, then global atomics)
 template <int HD, int TK>
 __global__ __launch_bounds__(256) void ca_attn_to_bwd_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                              const float* __restrict__ dO, float* __restrict__ dq,
                                                              float* __restrict__ dkv, int N, int D, int heads, int Tk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // kv [Tk][2D] | dkv accumulators [Tk][2D]
     float* acc = lds + Tk * 2 * D;
-    const int jet = blockIdx.x;
+    const int jet = blockIdx.x, r0 = blockIdx.y * TO_ROWS, nr = min(TO_ROWS, N - r0);
     for (int i = threadIdx.x; i < Tk * 2 * D; i += 256) {
         lds[i] = kv[(int64_t)jet * Tk * 2 * D + i];
         acc[i] = 0.f;
@@ -275,13 +279,13 @@ __global__ __launch_bounds__(256) void ca_attn_to_bwd_kernel(const float* __rest
     const float scale = 1.0f / sqrtf((float)HD);
     // thread (head h, row group g): every thread of a head walks a different subset of the rows
     const int h = threadIdx.x % heads, g = threadIdx.x / heads, ng = 256 / heads;
-    float dk[TK][HD], dv[TK][HD];
-#pragma unroll
-    for (int tk = 0; tk < TK; ++tk)
-#pragma unroll
-        for (int d = 0; d < HD; ++d) { dk[tk][d] = 0.f; dv[tk][d] = 0.f; }
     if (g < ng) {
-        for (int r = g; r < N; r += ng) {
+        float dk[TK][HD], dv[TK][HD];
+#pragma unroll
+        for (int tk = 0; tk < TK; ++tk)
+#pragma unroll
+            for (int d = 0; d < HD; ++d) { dk[tk][d] = 0.f; dv[tk][d] = 0.f; }
+        for (int r = r0 + g; r < r0 + nr; r += ng) {
             const int64_t e = ((int64_t)jet * N + r) * D + h * HD;
             float qr[HD], dor[HD];
             load_row<HD>(qr, q + e);
@@ -292,12 +296,12 @@ __global__ __launch_bounds__(256) void ca_attn_to_bwd_kernel(const float* __rest
                 s[tk] = -__builtin_inff();
                 dp[tk] = 0.f;
                 if (tk < Tk) {
+                    float kr[HD], vr[HD];
+                    load_row<HD>(kr, lds + tk * 2 * D + h * HD);
+                    load_row<HD>(vr, lds + tk * 2 * D + D + h * HD);
                     float a = 0.f, b = 0.f;
 #pragma unroll
-                    for (int d = 0; d < HD; ++d) {
-                        a = fmaf(qr[d], lds[tk * 2 * D + h * HD + d], a);
-                        b = fmaf(dor[d], lds[tk * 2 * D + D + h * HD + d], b);
-                    }
+                    for (int d = 0; d < HD; ++d) { a = fmaf(qr[d], kr[d], a); b = fmaf(dor[d], vr[d], b); }
                     s[tk] = a * scale;
                     dp[tk] = b;
                 }
@@ -317,9 +321,11 @@ __global__ __launch_bounds__(256) void ca_attn_to_bwd_kernel(const float* __rest
             for (int tk = 0; tk < TK; ++tk)
                 if (tk < Tk) {
                     const float ds = p[tk] * (dp[tk] - delta) * scale;
+                    float kr[HD];
+                    load_row<HD>(kr, lds + tk * 2 * D + h * HD);
 #pragma unroll
                     for (int d = 0; d < HD; ++d) {
-                        dqr[d] = fmaf(ds, lds[tk * 2 * D + h * HD + d], dqr[d]);
+                        dqr[d] = fmaf(ds, kr[d], dqr[d]);
                         dk[tk][d] = fmaf(ds, qr[d], dk[tk][d]);
                         dv[tk][d] = fmaf(p[tk], dor[d], dv[tk][d]);
                     }
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(256) void ca_attn_to_bwd_kernel(const float* __rest
             }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < Tk * 2 * D; i += 256) dkv[(int64_t)jet * Tk * 2 * D + i] = acc[i];
+    for (int i = threadIdx.x; i < Tk * 2 * D; i += 256) atomicAdd(dkv + (int64_t)jet * Tk * 2 * D + i, acc[i]);
 }
 
 // tok[jet][k][:] = global_tokens[k][:]   (droid_transformer.py:465)

@@ -83,17 +83,6 @@ struct Plan {
     hipStream_t s;
 };
 
-int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
 // out[rows][ldo] = epi(LN?(A) W^T + b / jet bias) (+R); per_jet = rows per jet of this row matrix (jet-bias lookup)
 int linear(const Plan& p, int rows, int per_jet, const float* A, int lda, int K, const pfm_tf_lin& lin, const pfm_tf_norm* ln, int NO,
            const float* jb, const float* R, int ldr, float* out, int ldo, int act) {
@@ -134,15 +123,12 @@ int linear(const Plan& p, int rows, int per_jet, const float* A, int lda, int K,
 }
 
 #define PFM_TRY(x) do { if ((rc = (x))) return rc; } while (0)
-#define PFM_ATTN(KERNEL, grid, lds, ...)                                                                 \
-    do {                                                                                                 \
-        if (d.head_dim == 8) hipLaunchKernelGGL((KERNEL<8, 8>), grid, dim3(256), lds, p.s, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<16, 4>), grid, dim3(256), lds, p.s, __VA_ARGS__);                \
+#define PFM_ATTN(KERNEL, grid, lds, ...)                                                                   \
+    do {                                                                                                   \
+        if (d.head_dim == 16) hipLaunchKernelGGL((KERNEL<16, 4>), grid, dim3(256), lds, p.s, __VA_ARGS__); \
+        else if (d.tokens <= 4) hipLaunchKernelGGL((KERNEL<8, 4>), grid, dim3(256), lds, p.s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<8, 8>), grid, dim3(256), lds, p.s, __VA_ARGS__);                   \
     } while (0)
-
-struct LayerBufs {
-    float *kv, *q, *att, *mid, *dh, *out;
-};
 
 int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const float* cond, const float* mask, const HeadArgs& head_tpl) {
     const pfm_ca_desc& d = *p.d;
@@ -186,7 +172,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         // tokens <- particles
         PFM_TRY(linear(p, p.M, N, seq, D, D, Fl.kv, &Fl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.f_kv, 2 * D, 0));
         PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Fl.q, &Fl.norm1, D, nullptr, nullptr, 0, lb + w.f_q, D, 0));
-        PFM_ATTN(ca_attn_from_kernel, dim3(p.n_jets), 0, (const float*)(lb + w.f_q), (const float*)(lb + w.f_kv), mask, lb + w.f_att, N, D,
+        PFM_ATTN(ca_attn_from_kernel, dim3(p.n_jets, (heads + 3) / 4), 0, (const float*)(lb + w.f_q), (const float*)(lb + w.f_kv), mask, lb + w.f_att, N, D,
                  heads, Tk);
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_from_kernel launch"));
         PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_att, D, D, Fl.out, &Fl.attn_norm, D, nullptr, tok, D, lb + w.f_mid, D, 0));
@@ -196,7 +182,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         // particles <- tokens
         PFM_TRY(linear(p, p.M, N, seq, D, D, Tl.q, &Tl.norm1, D, nullptr, nullptr, 0, lb + w.t_q, D, 0));
         PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Tl.kv, &Tl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.t_kv, 2 * D, 0));
-        PFM_ATTN(ca_attn_to_kernel, dim3(p.n_jets), (size_t)Tk * 2 * D * sizeof(float), (const float*)(lb + w.t_q),
+        PFM_ATTN(ca_attn_to_kernel, dim3(p.n_jets, (N + TO_ROWS - 1) / TO_ROWS), (size_t)Tk * 2 * D * sizeof(float), (const float*)(lb + w.t_q),
                  (const float*)(lb + w.t_kv), lb + w.t_att, N, D, heads, Tk);
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_to_kernel launch"));
         PFM_TRY(linear(p, p.M, N, lb + w.t_att, D, D, Tl.out, &Tl.attn_norm, D, nullptr, seq, D, lb + w.t_mid, D, 0));
@@ -233,7 +219,6 @@ int make_plan(Plan& p, const pfm_ca_desc* d, const float* blob, float* ws, int n
 struct Bs {
     int64_t dv, gh, gh2, gseq, gtok, ga, gat, gkv, gkvt, gq, gqt, gatt, gattt, ght, rstat, djb, dctxt, dhn, dhnx, dpre, hn, dwpart, total;
 };
-constexpr int DW_MAX_PARTS = 1024;
 
 Bs make_bs(const pfm_ca_desc& d, int n_jets) {
     Bs b;
@@ -290,14 +275,12 @@ struct Bwd {
         a.ldz = NO; a.lda = K; a.M = rows; a.NO = NO; a.K = K;
         a.row_tiles = (rows + BM - 1) / BM;
         const int tiles = ((NO + 127) / 128) * ((K + 127) / 128);
-        int ns = DW_MAX_PARTS / tiles;
-        if (ns < 1) ns = 1;
-        if (ns > a.row_tiles) ns = a.row_tiles;
+        const int ns = dw_splits(a.row_tiles, tiles, num_cus());
         a.nsplit = ns;
         int rc;
         hipLaunchKernelGGL(tf_dw_kernel, dim3(tiles * ns), dim3(LT), 2 * 64 * DWS * sizeof(float), p.s, a);
         if ((rc = check_hip(hipGetLastError(), "tf_dw_kernel launch (ca)"))) return rc;
-        hipLaunchKernelGGL(tf_dw_reduce_kernel, dim3(64, tiles), dim3(256), 0, p.s, (const float*)a.part, gblob, gW, NO, K, ns);
+        launch_dw_reduce(p.s, a.part, gblob, gW, NO, K, tiles, ns);
         return check_hip(hipGetLastError(), "tf_dw_reduce_kernel launch (ca)");
     }
     int dx(int rows, const float* Z, int NO, const pfm_tf_lin& lin, int K, float* out) const {
@@ -404,14 +387,15 @@ int run_backward(const Bwd& B, const float* cond, const float* mask, const float
         const float* tok_out = lb + w.f_out;
         // ---- to-layer: seq_out = f(seq_in, tok_out) ----
         PFM_TRY(B.layer_tail_bwd(p.M, N, Tl, 2 + 2 * l, seq_in, lb + w.t_att, lb + w.t_mid, lb + w.t_dh, gseq, gh, gh2, ga, gatt));
-        PFM_ATTN(ca_attn_to_bwd_kernel, dim3(p.n_jets), (size_t)2 * Tk * 2 * D * sizeof(float), (const float*)(lb + w.t_q),
+        PFM_TRY(check_hip(hipMemsetAsync(gkvt, 0, (size_t)p.Mt * 2 * D * sizeof(float), p.s), "memset gkvt"));
+        PFM_ATTN(ca_attn_to_bwd_kernel, dim3(p.n_jets, (N + TO_ROWS - 1) / TO_ROWS), (size_t)2 * Tk * 2 * D * sizeof(float), (const float*)(lb + w.t_q),
                  (const float*)(lb + w.t_kv), (const float*)gatt, gq, gkvt, N, D, heads, Tk);
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_to_bwd_kernel launch"));
         PFM_TRY(B.proj_bwd(p.M, N, Tl.q, Tl.norm1, D, seq_in, gq, ga, gseq));           // gseq = d loss / d seq_in
         PFM_TRY(B.proj_bwd(p.Mt, Tk, Tl.kv, Tl.norm0, 2 * D, tok_out, gkvt, gat, gtok)); // gtok = d loss / d tok_out
         // ---- from-layer: tok_out = f(tok_in, seq_in) ----
         PFM_TRY(B.layer_tail_bwd(p.Mt, Tk, Fl, 1 + 2 * l, tok_in, lb + w.f_att, lb + w.f_mid, lb + w.f_dh, gtok, ght, gh2, gat, gattt));
-        PFM_ATTN(ca_attn_from_bwd_kernel, dim3(p.n_jets), 0, (const float*)(lb + w.f_q), (const float*)(lb + w.f_kv), mask,
+        PFM_ATTN(ca_attn_from_bwd_kernel, dim3(p.n_jets, (heads + 3) / 4), 0, (const float*)(lb + w.f_q), (const float*)(lb + w.f_kv), mask,
                  (const float*)(lb + w.f_att), (const float*)gattt, gqt, gkv, N, D, heads, Tk);
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_from_bwd_kernel launch"));
         PFM_TRY(B.proj_bwd(p.Mt, Tk, Fl.q, Fl.norm1, D, tok_in, gqt, gat, gtok));        // gtok = d loss / d tok_in

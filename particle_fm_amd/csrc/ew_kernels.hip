@@ -424,7 +424,6 @@ __global__ __launch_bounds__(256) void ew_pool_bwd_kernel(const float* __restric
 struct Bs {
     int64_t dX, dZ, dT, dpre, DJB, DSJB, dPj, dP2, dP1, dG, dZg2, dZg1, zeros, dwpart, total;
 };
-constexpr int DW_MAX_PARTS = 1024;
 
 Bs make_bs(const pfm_ew_desc& d, int n_jets) {
     Bs b;
@@ -461,14 +460,12 @@ struct Bwd {
         a.ldz = ldz; a.lda = lda; a.lda2 = lda2; a.K1 = K1; a.M = Mrows; a.NO = NO; a.K = K;
         a.row_tiles = (Mrows + BM - 1) / BM;
         const int tiles = ((NO + 127) / 128) * ((K + 127) / 128);
-        int ns = DW_MAX_PARTS / tiles;
-        if (ns < 1) ns = 1;
-        if (ns > a.row_tiles) ns = a.row_tiles;
+        const int ns = dw_splits(a.row_tiles, tiles, num_cus());
         a.nsplit = ns;
         int rc;
         hipLaunchKernelGGL(tf_dw_kernel, dim3(tiles * ns), dim3(LT), 2 * 64 * DWS * sizeof(float), p.s, a);
         if ((rc = check_hip(hipGetLastError(), "tf_dw_kernel launch (epicw)"))) return rc;
-        hipLaunchKernelGGL(tf_dw_reduce_kernel, dim3(64, tiles), dim3(256), 0, p.s, (const float*)a.part, gblob, gW, NO, K, ns);
+        launch_dw_reduce(p.s, a.part, gblob, gW, NO, K, tiles, ns);
         return check_hip(hipGetLastError(), "tf_dw_reduce_kernel launch (epicw)");
     }
     // out[Mrows][K] = (Z W (+R)) (* lrelu'(Y))

@@ -376,20 +376,52 @@ static __global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
 
 // gblob[W block] += sum over splits of the partial tiles.  Element p of a tile: w = p>>12, c = (p>>10)&3, r = (p>>8)&3,
 // lane = (p>>2)&63, e = p&3  ->  dW[o][k], o = 128 to + 64 (w>>1) + 4 (4 (lane>>4) + r) + c, k = 128 tk + 64 (w&1) + 4 (lane&15) + e
+// grid (256, tiles): a workgroup owns 64 consecutive floats of the tile; 16 thread groups stride over the splits with
+// 16-byte loads (16 lanes = 256 contiguous bytes per split), LDS sums the groups.
 static __global__ __launch_bounds__(256) void tf_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ gblob,
                                                            int64_t gW, int NO, int K, int nsplit) {
+    __shared__ f32x4 red[256];
     const int nkc = (K + 127) >> 7, nst = K >> 6;
     const int tile = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const float* pp = part + (int64_t)tile * nsplit * 16384 + p;
-    float s = 0.f;
-    for (int i = 0; i < nsplit; ++i) s += pp[(int64_t)i * 16384];
-    const int to = tile / nkc, tk = tile - to * nkc;
-    const int w = p >> 12, c = (p >> 10) & 3, r = (p >> 8) & 3, lane = (p >> 2) & 63, e = p & 3;
-    const int o = 128 * to + 64 * (w >> 1) + 4 * (4 * (lane >> 4) + r) + c;
-    const int k = 128 * tk + 64 * (w & 1) + 4 * (lane & 15) + e;
-    if (o < NO && k < K)
-        gblob[gW + ((int64_t)((o >> 4) * nst + (k >> 6)) * 4 + ((k >> 4) & 3)) * 256 + (((k >> 2) & 3) * 16 + (o & 15)) * 4 + (k & 3)] += s;
+    const int c4 = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const float* pp = part + (int64_t)tile * nsplit * 16384 + blockIdx.x * 64 + 4 * c4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int i = g;
+    for (; i + 16 < nsplit; i += 32) {
+        s0 += *reinterpret_cast<const f32x4*>(pp + (int64_t)i * 16384);
+        s1 += *reinterpret_cast<const f32x4*>(pp + (int64_t)(i + 16) * 16384);
+    }
+    if (i < nsplit) s0 += *reinterpret_cast<const f32x4*>(pp + (int64_t)i * 16384);
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int cc = threadIdx.x >> 2, e = threadIdx.x & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) s += red[gg * 16 + cc][e];
+        const int p = blockIdx.x * 64 + threadIdx.x;
+        const int to = tile / nkc, tk = tile - to * nkc;
+        const int w = p >> 12, c = (p >> 10) & 3, r = (p >> 8) & 3, lane = (p >> 2) & 63;
+        const int o = 128 * to + 64 * (w >> 1) + 4 * (4 * (lane >> 4) + r) + c;
+        const int k = 128 * tk + 64 * (w & 1) + 4 * (lane & 15) + e;
+        if (o < NO && k < K)
+            gblob[gW + ((int64_t)((o >> 4) * nst + (k >> 6)) * 4 + ((k >> 4) & 3)) * 256 + (((k >> 2) & 3) * 16 + (o & 15)) * 4 + (k & 3)] += s;
+    }
+}
+
+constexpr int DW_MAX_PARTS = 1024;  // partial 128 x 128 dW tiles in flight per Linear (scratch: DW_MAX_PARTS * 64 KB)
+
+// number of row splits of one dW GEMM: ~2 workgroups per CU over all tiles, every split with the same number of row tiles
+inline int dw_splits(int row_tiles, int tiles, int cus) {
+    int target = 2 * cus / tiles;
+    if (target > DW_MAX_PARTS / tiles) target = DW_MAX_PARTS / tiles;
+    if (target < 1) target = 1;
+    const int per = (row_tiles + target - 1) / target;
+    return (row_tiles + per - 1) / per;
+}
+
+inline void launch_dw_reduce(hipStream_t s, const float* part, float* gblob, int64_t gW, int NO, int K, int tiles, int ns) {
+    hipLaunchKernelGGL(tf_dw_reduce_kernel, dim3(256, tiles), dim3(256), 0, s, part, gblob, gW, NO, K, ns);
 }
 
 // ------------------------------------------------------------------------------------------------

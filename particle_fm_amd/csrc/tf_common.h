@@ -25,6 +25,18 @@ struct Ws {
     int64_t total;
 };
 
+// compute units of the current device (launch geometry: Linear row-tile height, dW splits)
+inline int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 __host__ __device__ inline int64_t round64(int64_t x) { return (x + 63) & ~(int64_t)63; }
 
 __host__ inline Ws make_ws(const pfm_tf_desc& d, int n_jets, bool train) {

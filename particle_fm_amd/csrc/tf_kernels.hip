@@ -32,17 +32,6 @@ int validate(const pfm_tf_desc* d) {
     return 0;
 }
 
-int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
 struct Plan {
     const pfm_tf_desc* d;
     const float* blob;
@@ -185,7 +174,6 @@ int make_plan(Plan& p, const pfm_tf_desc* d, const float* blob, float* ws, int n
 
 
 // ---- backward scratch (floats) -------------------------------------------------------------------
-constexpr int DW_MAX_PARTS = 1024;  // partial 128x128 dW tiles in flight per Linear
 
 struct Bs {
     int64_t dv, gh, gh2, gx, ga, gqkv, gatt, stats, rstat, djb, dctxt, dhn, dhnx, dpre, hn, dwpart, total;
@@ -251,13 +239,11 @@ struct Bwd {
         a.ldz = NO; a.lda = K; a.M = p.M; a.NO = NO; a.K = K;
         a.row_tiles = (p.M + BM - 1) / BM;
         const int tiles = ((NO + 127) / 128) * ((K + 127) / 128);
-        int ns = DW_MAX_PARTS / tiles;
-        if (ns < 1) ns = 1;
-        if (ns > a.row_tiles) ns = a.row_tiles;
+        const int ns = dw_splits(a.row_tiles, tiles, num_cus());
         a.nsplit = ns;
         hipLaunchKernelGGL(tf_dw_kernel, dim3(tiles * ns), dim3(LT), 2 * 64 * DWS * sizeof(float), p.s, a);
         if ((rc = check_hip(hipGetLastError(), "tf_dw_kernel launch"))) return rc;
-        hipLaunchKernelGGL(tf_dw_reduce_kernel, dim3(64, tiles), dim3(256), 0, p.s, (const float*)a.part, gblob, gW, NO, K, ns);
+        launch_dw_reduce(p.s, a.part, gblob, gW, NO, K, tiles, ns);
         return check_hip(hipGetLastError(), "tf_dw_reduce_kernel launch");
     }
     // out[M][K] = Z[M][NO] W   (gradient w.r.t. the Linear's normalised input)
