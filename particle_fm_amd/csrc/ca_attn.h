@@ -263,87 +263,100 @@ __global__ __launch_bounds__(256) void ca_attn_to_kernel(const float* __restrict
     }
 }
 
-// backward: dq [n_jets*N][D]; dkv [n_jets*Tk][2D] += this workgroup's rows (zeroed by the caller; LDS, then global atomics)
+// backward, workgroup = (jet, block of `rpb` particles):
+//   phase 1, thread per (particle, head): softmax weights p and score gradients ds -> LDS, dq -> global
+//   phase 2, thread per model column: dk / dv of the block = sums over its particles of ds * q and p * dO (coalesced
+//            re-reads of the q / dO rows, p / ds broadcast from LDS) -> part [jet][block][Tk][2D]; no atomics.
+// ca_attn_to_bwd_sum_kernel adds the blocks of a jet.  dynamic LDS: (Tk * 2D + rpb * heads * 2 * TK) floats
 template <int HD, int TK>
 __global__ __launch_bounds__(256) void ca_attn_to_bwd_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                              const float* __restrict__ dO, float* __restrict__ dq,
-                                                             float* __restrict__ dkv, int N, int D, int heads, int Tk) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // kv [Tk][2D] | dkv accumulators [Tk][2D]
-    float* acc = lds + Tk * 2 * D;
-    const int jet = blockIdx.x, r0 = blockIdx.y * TO_ROWS, nr = min(TO_ROWS, N - r0);
-    for (int i = threadIdx.x; i < Tk * 2 * D; i += 256) {
-        lds[i] = kv[(int64_t)jet * Tk * 2 * D + i];
-        acc[i] = 0.f;
-    }
+                                                             float* __restrict__ part, int N, int D, int heads, int Tk, int rpb) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // kv [Tk][2D] | pd [rpb][heads][2 TK] (p | ds)
+    float* pd = lds + Tk * 2 * D;
+    const int jet = blockIdx.x, r0 = blockIdx.y * rpb, nr = min(rpb, N - r0);
+    for (int i = threadIdx.x; i < Tk * 2 * D; i += 256) lds[i] = kv[(int64_t)jet * Tk * 2 * D + i];
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)HD);
-    // thread (head h, row group g): every thread of a head walks a different subset of the rows
-    const int h = threadIdx.x % heads, g = threadIdx.x / heads, ng = 256 / heads;
-    if (g < ng) {
-        float dk[TK][HD], dv[TK][HD];
+    for (int idx = threadIdx.x; idx < nr * heads; idx += 256) {
+        const int rl = idx / heads, h = idx % heads;
+        const int64_t e = ((int64_t)jet * N + r0 + rl) * D + h * HD;
+        float qr[HD], dor[HD];
+        load_row<HD>(qr, q + e);
+        load_row<HD>(dor, dO + e);
+        float s[TK], dp[TK], mx = -__builtin_inff();
 #pragma unroll
-        for (int tk = 0; tk < TK; ++tk)
+        for (int tk = 0; tk < TK; ++tk) {
+            s[tk] = -__builtin_inff();
+            dp[tk] = 0.f;
+            if (tk < Tk) {
+                float kr[HD], vr[HD];
+                load_row<HD>(kr, lds + tk * 2 * D + h * HD);
+                load_row<HD>(vr, lds + tk * 2 * D + D + h * HD);
+                float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) { dk[tk][d] = 0.f; dv[tk][d] = 0.f; }
-        for (int r = r0 + g; r < r0 + nr; r += ng) {
-            const int64_t e = ((int64_t)jet * N + r) * D + h * HD;
-            float qr[HD], dor[HD];
-            load_row<HD>(qr, q + e);
-            load_row<HD>(dor, dO + e);
-            float s[TK], dp[TK], mx = -__builtin_inff();
-#pragma unroll
-            for (int tk = 0; tk < TK; ++tk) {
-                s[tk] = -__builtin_inff();
-                dp[tk] = 0.f;
-                if (tk < Tk) {
-                    float kr[HD], vr[HD];
-                    load_row<HD>(kr, lds + tk * 2 * D + h * HD);
-                    load_row<HD>(vr, lds + tk * 2 * D + D + h * HD);
-                    float a = 0.f, b = 0.f;
-#pragma unroll
-                    for (int d = 0; d < HD; ++d) { a = fmaf(qr[d], kr[d], a); b = fmaf(dor[d], vr[d], b); }
-                    s[tk] = a * scale;
-                    dp[tk] = b;
-                }
-                mx = fmaxf(mx, s[tk]);
+                for (int d = 0; d < HD; ++d) { a = fmaf(qr[d], kr[d], a); b = fmaf(dor[d], vr[d], b); }
+                s[tk] = a * scale;
+                dp[tk] = b;
             }
-            float l = 0.f, p[TK];
+            mx = fmaxf(mx, s[tk]);
+        }
+        float l = 0.f, p[TK], ds[TK];
 #pragma unroll
-            for (int tk = 0; tk < TK; ++tk) { p[tk] = tk < Tk ? __expf(s[tk] - mx) : 0.f; l += p[tk]; }
-            const float inv = 1.0f / l;
-            float delta = 0.f;
+        for (int tk = 0; tk < TK; ++tk) { p[tk] = tk < Tk ? __expf(s[tk] - mx) : 0.f; l += p[tk]; }
+        const float inv = 1.0f / l;
+        float delta = 0.f;
 #pragma unroll
-            for (int tk = 0; tk < TK; ++tk) { p[tk] *= inv; delta = fmaf(p[tk], dp[tk], delta); }
-            float dqr[HD];
+        for (int tk = 0; tk < TK; ++tk) { p[tk] *= inv; delta = fmaf(p[tk], dp[tk], delta); }
+        float dqr[HD];
 #pragma unroll
-            for (int d = 0; d < HD; ++d) dqr[d] = 0.f;
+        for (int d = 0; d < HD; ++d) dqr[d] = 0.f;
 #pragma unroll
-            for (int tk = 0; tk < TK; ++tk)
-                if (tk < Tk) {
-                    const float ds = p[tk] * (dp[tk] - delta) * scale;
-                    float kr[HD];
-                    load_row<HD>(kr, lds + tk * 2 * D + h * HD);
+        for (int tk = 0; tk < TK; ++tk) {
+            ds[tk] = p[tk] * (dp[tk] - delta) * scale;
+            if (tk < Tk) {
+                float kr[HD];
+                load_row<HD>(kr, lds + tk * 2 * D + h * HD);
 #pragma unroll
-                    for (int d = 0; d < HD; ++d) {
-                        dqr[d] = fmaf(ds, kr[d], dqr[d]);
-                        dk[tk][d] = fmaf(ds, qr[d], dk[tk][d]);
-                        dv[tk][d] = fmaf(p[tk], dor[d], dv[tk][d]);
-                    }
-                }
-            store_row<HD>(dq + e, dqr);
+                for (int d = 0; d < HD; ++d) dqr[d] = fmaf(ds[tk], kr[d], dqr[d]);
+            }
+        }
+        store_row<HD>(dq + e, dqr);
+        store_row<TK>(pd + (rl * heads + h) * 2 * TK, p);
+        store_row<TK>(pd + (rl * heads + h) * 2 * TK + TK, ds);
+    }
+    __syncthreads();
+    float* out = part + ((int64_t)jet * gridDim.y + blockIdx.y) * Tk * 2 * D;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const int h = c / HD;
+        float dk[TK], dv[TK];
+#pragma unroll
+        for (int tk = 0; tk < TK; ++tk) { dk[tk] = 0.f; dv[tk] = 0.f; }
+        const float* qc = q + ((int64_t)jet * N + r0) * D + c;
+        const float* doc = dO + ((int64_t)jet * N + r0) * D + c;
+#pragma unroll 4
+        for (int rl = 0; rl < nr; ++rl) {
+            const float qv = qc[(int64_t)rl * D], dov = doc[(int64_t)rl * D];
+            float pr[TK], dsr[TK];
+            load_row<TK>(pr, pd + (rl * heads + h) * 2 * TK);
+            load_row<TK>(dsr, pd + (rl * heads + h) * 2 * TK + TK);
+#pragma unroll
+            for (int tk = 0; tk < TK; ++tk) { dk[tk] = fmaf(dsr[tk], qv, dk[tk]); dv[tk] = fmaf(pr[tk], dov, dv[tk]); }
         }
 #pragma unroll
         for (int tk = 0; tk < TK; ++tk)
-            if (tk < Tk) {
-#pragma unroll
-                for (int d = 0; d < HD; ++d) {
-                    atomicAdd(acc + tk * 2 * D + h * HD + d, dk[tk][d]);
-                    atomicAdd(acc + tk * 2 * D + D + h * HD + d, dv[tk][d]);
-                }
-            }
+            if (tk < Tk) { out[tk * 2 * D + c] = dk[tk]; out[tk * 2 * D + D + c] = dv[tk]; }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < Tk * 2 * D; i += 256) atomicAdd(dkv + (int64_t)jet * Tk * 2 * D + i, acc[i]);
+}
+
+// dkv [jet][Tk * 2D] = sum over the nblk row blocks of part [jet][nblk][Tk * 2D]
+static __global__ void ca_attn_to_bwd_sum_kernel(const float* __restrict__ part, float* __restrict__ dkv, int64_t n, int per_jet, int nblk) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t jet = i / per_jet, e = i - jet * per_jet;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(jet * nblk + b) * per_jet + e];
+    dkv[i] = s;
 }
 
 // tok[jet][k][:] = global_tokens[k][:]   (droid_transformer.py:465)

@@ -217,8 +217,16 @@ int make_plan(Plan& p, const pfm_ca_desc* d, const float* blob, float* ws, int n
 
 // ---- backward ------------------------------------------------------------------------------------------
 struct Bs {
-    int64_t dv, gh, gh2, gseq, gtok, ga, gat, gkv, gkvt, gq, gqt, gatt, gattt, ght, rstat, djb, dctxt, dhn, dhnx, dpre, hn, dwpart, total;
+    int64_t dv, gh, gh2, gseq, gtok, ga, gat, gkv, gkvt, kvpart, gq, gqt, gatt, gattt, ght, rstat, djb, dctxt, dhn, dhnx, dpre, hn, dwpart, total;
 };
+
+// particles per workgroup of ca_attn_to_bwd_kernel: its p / ds staging ([rows][heads][2 TK] floats) stays under 24 KB
+// (with the token keys / values, <= 32 KB, inside the 64 KB a kernel gets without opting in to more)
+inline int to_bwd_rows(const pfm_ca_desc& d) {
+    const int tk = (d.head_dim == 8 && d.tokens > 4) ? 8 : 4;
+    int r = 6144 / (d.heads * 2 * tk);
+    return r > 64 ? 64 : r;
+}
 
 Bs make_bs(const pfm_ca_desc& d, int n_jets) {
     Bs b;
@@ -231,6 +239,7 @@ Bs make_bs(const pfm_ca_desc& d, int n_jets) {
     b.gseq = take(M * D); b.gtok = take(Mt * D);
     b.ga = take(M * D); b.gat = take(Mt * D);
     b.gkv = take(M * (2 * D > Hd ? 2 * D : Hd)); b.gkvt = take(Mt * 2 * D);
+    b.kvpart = take(Mt * 2 * D * ((d.n_points + to_bwd_rows(d) - 1) / to_bwd_rows(d)));
     b.gq = take(M * D); b.gqt = take(Mt * D);
     b.gatt = take(M * D); b.gattt = take(Mt * D);
     b.ght = take(Mt * Hd);
@@ -303,11 +312,6 @@ struct Bwd {
         }
         return check_hip(hipGetLastError(), "tf_ln_bwd_kernel launch (ca)");
     }
-    int outer(const float* U, int64_t ldu, int K, const float* V, int64_t ldv, int NO, int64_t g) const {
-        const int64_t n = (int64_t)K * NO;
-        hipLaunchKernelGGL(tf_outer_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, U, ldu, K, V, ldv, NO, p.n_jets, gblob + g);
-        return check_hip(hipGetLastError(), "tf_outer_sum_kernel launch (ca)");
-    }
     // the block  q <- q + out(LN_a(att));  q <- q + d2(LN_d(lrelu(d1(LN2(q)) + jet bias)))  of one cross-attention layer,
     // backwards: in: g = d loss / d q_out (rows x D); out: g = d loss / d q_in excluding the query path of the attention,
     // gatt = d loss / d att.  `per_jet` rows per jet, jb_row = index of the layer's jet-bias row.
@@ -350,6 +354,7 @@ int run_backward(const Bwd& B, const float* cond, const float* mask, const float
     float* sc = B.sc;
     const Bs& b = B.b;
     const int D = d.model_dim, Hd = d.hidden, nb = 2 * d.layers + 2, F = d.features, N = d.n_points, Tk = d.tokens, heads = d.heads;
+    const int rpb = to_bwd_rows(d);
     float *gh = sc + b.gh, *gh2 = sc + b.gh2, *gseq = sc + b.gseq, *gtok = sc + b.gtok, *ga = sc + b.ga, *gat = sc + b.gat;
     float *gkv = sc + b.gkv, *gkvt = sc + b.gkvt, *gq = sc + b.gq, *gqt = sc + b.gqt, *gatt = sc + b.gatt, *gattt = sc + b.gattt, *ght = sc + b.ght;
     float* djb = sc + b.djb;
@@ -387,9 +392,15 @@ int run_backward(const Bwd& B, const float* cond, const float* mask, const float
         const float* tok_out = lb + w.f_out;
         // ---- to-layer: seq_out = f(seq_in, tok_out) ----
         PFM_TRY(B.layer_tail_bwd(p.M, N, Tl, 2 + 2 * l, seq_in, lb + w.t_att, lb + w.t_mid, lb + w.t_dh, gseq, gh, gh2, ga, gatt));
-        PFM_TRY(check_hip(hipMemsetAsync(gkvt, 0, (size_t)p.Mt * 2 * D * sizeof(float), p.s), "memset gkvt"));
-        PFM_ATTN(ca_attn_to_bwd_kernel, dim3(p.n_jets, (N + TO_ROWS - 1) / TO_ROWS), (size_t)2 * Tk * 2 * D * sizeof(float), (const float*)(lb + w.t_q),
-                 (const float*)(lb + w.t_kv), (const float*)gatt, gq, gkvt, N, D, heads, Tk);
+        {
+            const int nblk = (N + rpb - 1) / rpb;
+            const size_t lds = ((size_t)Tk * 2 * D + (size_t)rpb * heads * 2 * (d.head_dim == 8 && Tk > 4 ? 8 : 4)) * sizeof(float);
+            PFM_ATTN(ca_attn_to_bwd_kernel, dim3(p.n_jets, nblk), lds, (const float*)(lb + w.t_q), (const float*)(lb + w.t_kv),
+                     (const float*)gatt, gq, sc + b.kvpart, N, D, heads, Tk, rpb);
+            const int64_t n = (int64_t)p.Mt * 2 * D;
+            hipLaunchKernelGGL(ca_attn_to_bwd_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s,
+                               (const float*)(sc + b.kvpart), gkvt, n, Tk * 2 * D, nblk);
+        }
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_to_bwd_kernel launch"));
         PFM_TRY(B.proj_bwd(p.M, N, Tl.q, Tl.norm1, D, seq_in, gq, ga, gseq));           // gseq = d loss / d seq_in
         PFM_TRY(B.proj_bwd(p.Mt, Tk, Tl.kv, Tl.norm0, 2 * D, tok_out, gkvt, gat, gtok)); // gtok = d loss / d tok_out
@@ -425,21 +436,16 @@ int run_backward(const Bwd& B, const float* cond, const float* mask, const float
         for (int c = 0; c < nb; ++c) a.Wc[c] = lin_of(c).Wc;
         hipLaunchKernelGGL(tf_ctxt_bwd_kernel, dim3(p.n_jets), dim3(512), 0, p.s, a);
         PFM_TRY(check_hip(hipGetLastError(), "tf_ctxt_bwd_kernel launch (ca)"));
-        const int64_t jbs = (int64_t)nb * Hd;
-        const float* ctxt = ws + w.ctxt;
-        for (int c = 0; c < nb; ++c) {
-            PFM_TRY(B.outer(ctxt, d.ctxt_dim, d.ctxt_dim, djb + (int64_t)c * Hd, jbs, Hd, lin_of(c).Wc));
-            PFM_TRY(B.outer(nullptr, 0, 1, djb + (int64_t)c * Hd, jbs, Hd, lin_of(c).b));
-        }
-        if (d.time_in_input) PFM_TRY(B.outer(ws + w.temb, 64, d.t_dim, djb, jbs, Hd, d.n1.Wt));
-        PFM_TRY(B.outer(sc + b.hn, d.ctxt_hidden, d.ctxt_hidden, sc + b.dctxt, d.ctxt_dim, d.ctxt_dim, d.c2.W));
-        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dctxt, d.ctxt_dim, d.ctxt_dim, d.c2.b));
-        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dhnx, d.ctxt_hidden, d.ctxt_hidden, d.c_norm.gamma));
-        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dhn, d.ctxt_hidden, d.ctxt_hidden, d.c_norm.beta));
-        PFM_TRY(B.outer(ws + w.temb, 64, d.t_dim, sc + b.dpre, d.ctxt_hidden, d.ctxt_hidden, d.c1.W));
-        if (d.cond_dim > 0)
-            PFM_TRY(B.outer(cond, d.cond_dim, d.cond_dim, sc + b.dpre, d.ctxt_hidden, d.ctxt_hidden, d.c1.W + (int64_t)d.t_dim * d.ctxt_hidden));
-        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dpre, d.ctxt_hidden, d.ctxt_hidden, d.c1.b));
+        CtxtGradIn g;
+        g.ctxt = ws + w.ctxt; g.djb = djb; g.temb = ws + w.temb; g.cond = cond;
+        g.hn = sc + b.hn; g.dctxt = sc + b.dctxt; g.dhnx = sc + b.dhnx; g.dhn = sc + b.dhn; g.dpre = sc + b.dpre;
+        g.gblob = B.gblob; g.n_jets = p.n_jets; g.nb = nb; g.Hd = Hd; g.CO = d.ctxt_dim; g.CH = d.ctxt_hidden; g.T = d.t_dim;
+        g.C = d.cond_dim;
+        for (int c = 0; c < nb; ++c) { g.gW[c] = lin_of(c).Wc; g.gb[c] = lin_of(c).b; }
+        g.n1Wt = d.time_in_input ? d.n1.Wt : -1;
+        g.c2W = d.c2.W; g.c2b = d.c2.b; g.cgamma = d.c_norm.gamma; g.cbeta = d.c_norm.beta; g.c1W = d.c1.W; g.c1b = d.c1.b;
+        launch_ctxt_param_grads(g, p.s);
+        PFM_TRY(check_hip(hipGetLastError(), "context parameter gradient launches"));
     }
     return 0;
 }

@@ -692,16 +692,103 @@ static __global__ __launch_bounds__(512) void tf_ctxt_bwd_kernel(CtxtBwdArgs a) 
     }
 }
 
-// G[k][o] += sum_jet U[jet][k] V[jet][o]   (U == nullptr: K = 1, weight 1).  Each element has one owner thread.
-static __global__ __launch_bounds__(256) void tf_outer_sum_kernel(const float* __restrict__ U, int64_t ldu, int K,
-                                                           const float* __restrict__ V, int64_t ldv, int NO, int n_jets,
-                                                           float* __restrict__ G) {
+// G[k][o] += sum_jet U[jet][k] V[jet][o]   (U == nullptr: K = 1, weight 1).  Each element has one owner thread; four
+// independent partial sums keep four loads of the (latency-bound) walk over the jets in flight.
+__device__ __forceinline__ float outer_sum_elem(const float* __restrict__ U, int64_t ldu, int k, const float* __restrict__ V,
+                                                int64_t ldv, int o, int n_jets) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = 0;
+    if (U) {
+        for (; j + 4 <= n_jets; j += 4) {
+            a0 = fmaf(U[j * ldu + k], V[j * ldv + o], a0);
+            a1 = fmaf(U[(j + 1) * ldu + k], V[(j + 1) * ldv + o], a1);
+            a2 = fmaf(U[(j + 2) * ldu + k], V[(j + 2) * ldv + o], a2);
+            a3 = fmaf(U[(j + 3) * ldu + k], V[(j + 3) * ldv + o], a3);
+        }
+        for (; j < n_jets; ++j) a0 = fmaf(U[j * ldu + k], V[j * ldv + o], a0);
+    } else {
+        for (; j + 4 <= n_jets; j += 4) {
+            a0 += V[j * ldv + o]; a1 += V[(j + 1) * ldv + o]; a2 += V[(j + 2) * ldv + o]; a3 += V[(j + 3) * ldv + o];
+        }
+        for (; j < n_jets; ++j) a0 += V[j * ldv + o];
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+// a list of independent outer sums in one launch: grid (blocks of the largest job, jobs)
+struct OuterJob {
+    const float* U;
+    const float* V;
+    float* G;
+    int64_t ldu, ldv;
+    int K, NO;
+};
+constexpr int OUTER_MAX_JOBS = 12;
+struct OuterJobs {
+    OuterJob job[OUTER_MAX_JOBS];
+    int n_jets;
+};
+static __global__ __launch_bounds__(256) void tf_outer_jobs_kernel(OuterJobs a) {
+    const OuterJob& jb = a.job[blockIdx.y];
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (int64_t)K * NO) return;
-    const int k = (int)(e / NO), o = (int)(e - (int64_t)k * NO);
-    float acc = 0.f;
-    for (int j = 0; j < n_jets; ++j) acc = fmaf(U ? U[j * ldu + k] : 1.0f, V[j * ldv + o], acc);
-    G[e] += acc;
+    if (e >= (int64_t)jb.K * jb.NO) return;
+    const int k = (int)(e / jb.NO), o = (int)(e - (int64_t)k * jb.NO);
+    jb.G[e] += outer_sum_elem(jb.U, jb.ldu, k, jb.V, jb.ldv, o, a.n_jets);
+}
+
+// the jet-bias rows: for every row c of djb [jet][nb][Hd]:  gblob[gW[c]] ([CO][Hd], K-major) += ctxt^T djb[:, c]  (z = 0)
+// and gblob[gb[c]] ([Hd]) += sum_jet djb[:, c]  (z = 1).  grid (ceil(CO * Hd / 256), nb, 2)
+struct OuterRowsArgs {
+    const float* U;   // ctxt [jet][CO]
+    const float* V;   // djb [jet][nb][Hd]
+    float* gblob;
+    int K, NO, nb, n_jets;
+    int64_t gW[CTXT_MAX_NB], gb[CTXT_MAX_NB];
+};
+static __global__ __launch_bounds__(256) void tf_outer_rows_kernel(OuterRowsArgs a) {
+    const int c = blockIdx.y;
+    const bool bias = blockIdx.z == 1;
+    const int K = bias ? 1 : a.K;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)K * a.NO) return;
+    const int k = (int)(e / a.NO), o = (int)(e - (int64_t)k * a.NO);
+    const float s = outer_sum_elem(bias ? nullptr : a.U, a.K, k, a.V + (int64_t)c * a.NO, (int64_t)a.nb * a.NO, o, a.n_jets);
+    a.gblob[(bias ? a.gb[c] : a.gW[c]) + e] += s;
+}
+
+// Parameter gradients of the per-jet context path in two launches: the jet-bias rows (Wc, bias of every Linear that
+// takes the context) and the context network itself (+ the time columns of node_embd).
+struct CtxtGradIn {
+    const float *ctxt, *djb, *temb, *cond;             // [jet][CO], [jet][nb][Hd], [jet][64], [jet][C]
+    const float *hn, *dctxt, *dhnx, *dhn, *dpre;       // outputs of tf_ctxt_bwd_kernel
+    float* gblob;
+    int n_jets, nb, Hd, CO, CH, T, C;
+    int64_t gW[CTXT_MAX_NB], gb[CTXT_MAX_NB];          // Wc / bias blocks of the nb jet-bias rows
+    int64_t n1Wt, c2W, c2b, cgamma, cbeta, c1W, c1b;   // n1Wt < 0: no time columns
+};
+
+inline void launch_ctxt_param_grads(const CtxtGradIn& g, hipStream_t s) {
+    OuterRowsArgs r;
+    r.U = g.ctxt; r.V = g.djb; r.gblob = g.gblob; r.K = g.CO; r.NO = g.Hd; r.nb = g.nb; r.n_jets = g.n_jets;
+    for (int c = 0; c < g.nb; ++c) { r.gW[c] = g.gW[c]; r.gb[c] = g.gb[c]; }
+    hipLaunchKernelGGL(tf_outer_rows_kernel, dim3((g.CO * g.Hd + 255) / 256, g.nb, 2), dim3(256), 0, s, r);
+    OuterJobs j;
+    j.n_jets = g.n_jets;
+    int n = 0, most = 0;
+    auto add = [&](const float* U, int64_t ldu, int K, const float* V, int64_t ldv, int NO, int64_t off) {
+        j.job[n++] = OuterJob{U, V, g.gblob + off, ldu, ldv, K, NO};
+        if (K * NO > most) most = K * NO;
+    };
+    const int64_t jbs = (int64_t)g.nb * g.Hd;
+    if (g.n1Wt >= 0) add(g.temb, 64, g.T, g.djb, jbs, g.Hd, g.n1Wt);
+    add(g.hn, g.CH, g.CH, g.dctxt, g.CO, g.CO, g.c2W);
+    add(nullptr, 0, 1, g.dctxt, g.CO, g.CO, g.c2b);
+    add(nullptr, 0, 1, g.dhnx, g.CH, g.CH, g.cgamma);
+    add(nullptr, 0, 1, g.dhn, g.CH, g.CH, g.cbeta);
+    add(g.temb, 64, g.T, g.dpre, g.CH, g.CH, g.c1W);
+    if (g.C > 0) add(g.cond, g.C, g.C, g.dpre, g.CH, g.CH, g.c1W + (int64_t)g.T * g.CH);
+    add(nullptr, 0, 1, g.dpre, g.CH, g.CH, g.c1b);
+    hipLaunchKernelGGL(tf_outer_jobs_kernel, dim3((most + 255) / 256, n), dim3(256), 0, s, j);
 }
 
 }  // namespace tf

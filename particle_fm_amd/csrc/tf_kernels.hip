@@ -267,12 +267,6 @@ struct Bwd {
         }
         return check_hip(hipGetLastError(), "tf_ln_bwd_kernel launch");
     }
-    int outer(const float* U, int64_t ldu, int K, const float* V, int64_t ldv, int NO, int64_t g) const {
-        const int64_t n = (int64_t)K * NO;
-        hipLaunchKernelGGL(tf_outer_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, U, ldu, K, V, ldv, NO,
-                           p.n_jets, gblob + g);
-        return check_hip(hipGetLastError(), "tf_outer_sum_kernel launch");
-    }
 };
 
 #define PFM_TRY(x) do { if ((rc = (x))) return rc; } while (0)
@@ -376,23 +370,19 @@ int run_backward(const Bwd& B, const float* cond, const float* mask, const float
         a.Wc[nb - 1] = d.o1.Wc;
         hipLaunchKernelGGL(tf_ctxt_bwd_kernel, dim3(p.n_jets), dim3(512), 0, p.s, a);
         PFM_TRY(check_hip(hipGetLastError(), "tf_ctxt_bwd_kernel launch"));
-        const int64_t jbs = (int64_t)nb * Hd;
-        const float* ctxt = ws + w.ctxt;
+        CtxtGradIn g;
+        g.ctxt = ws + w.ctxt; g.djb = djb; g.temb = ws + w.temb; g.cond = cond;
+        g.hn = sc + b.hn; g.dctxt = sc + b.dctxt; g.dhnx = sc + b.dhnx; g.dhn = sc + b.dhn; g.dpre = sc + b.dpre;
+        g.gblob = B.gblob; g.n_jets = p.n_jets; g.nb = nb; g.Hd = Hd; g.CO = d.ctxt_dim; g.CH = d.ctxt_hidden; g.T = d.t_dim;
+        g.C = d.cond_dim;
         for (int c = 0; c < nb; ++c) {
             const pfm_tf_lin& lin = c == 0 ? d.n1 : (c == nb - 1 ? d.o1 : d.layer[c - 1].d1);
-            PFM_TRY(B.outer(ctxt, d.ctxt_dim, d.ctxt_dim, djb + (int64_t)c * Hd, jbs, Hd, lin.Wc));
-            PFM_TRY(B.outer(nullptr, 0, 1, djb + (int64_t)c * Hd, jbs, Hd, lin.b));
+            g.gW[c] = lin.Wc; g.gb[c] = lin.b;
         }
-        if (d.time_in_input) PFM_TRY(B.outer(ws + w.temb, 64, d.t_dim, djb, jbs, Hd, d.n1.Wt));
-        PFM_TRY(B.outer(sc + b.hn, d.ctxt_hidden, d.ctxt_hidden, sc + b.dctxt, d.ctxt_dim, d.ctxt_dim, d.c2.W));
-        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dctxt, d.ctxt_dim, d.ctxt_dim, d.c2.b));
-        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dhnx, d.ctxt_hidden, d.ctxt_hidden, d.c_norm.gamma));
-        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dhn, d.ctxt_hidden, d.ctxt_hidden, d.c_norm.beta));
-        PFM_TRY(B.outer(ws + w.temb, 64, d.t_dim, sc + b.dpre, d.ctxt_hidden, d.ctxt_hidden, d.c1.W));
-        if (d.cond_dim > 0)
-            PFM_TRY(B.outer(cond, d.cond_dim, d.cond_dim, sc + b.dpre, d.ctxt_hidden, d.ctxt_hidden,
-                            d.c1.W + (int64_t)d.t_dim * d.ctxt_hidden));
-        PFM_TRY(B.outer(nullptr, 0, 1, sc + b.dpre, d.ctxt_hidden, d.ctxt_hidden, d.c1.b));
+        g.n1Wt = d.time_in_input ? d.n1.Wt : -1;
+        g.c2W = d.c2.W; g.c2b = d.c2.b; g.cgamma = d.c_norm.gamma; g.cbeta = d.c_norm.beta; g.c1W = d.c1.W; g.c1b = d.c1.b;
+        launch_ctxt_param_grads(g, p.s);
+        PFM_TRY(check_hip(hipGetLastError(), "context parameter gradient launches"));
     }
     return 0;
 }
