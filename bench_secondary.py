@@ -2,7 +2,7 @@
 """Secondary benchmark lines: the BASELINE configurations bench.py does not run (it measures cfg 3, the one the
 metric is quoted on).  One JSON line per workload, same schema as bench.py, single GPU:
 
-    python bench_secondary.py [--workload jetnet30|lhco_transformer|jetclass|all] [--steps K] [--warmup W] [--precision fp32|f16x3]
+    python bench_secondary.py [--workload jetnet30|lhco_transformer|lhco_crossattention|jetclass|all] [--steps K] [--warmup W] [--precision fp32|f16x3]
 
 step = 1 train step (loss forward + backward through the HIP kernels, clip 0.5 + AdamW + EMA) + 1 midpoint sample
 (ode_steps = 100, 198 NFE) on the configuration's batch; inputs synthetic and resident in HBM.  `roofline.achieved` is
@@ -31,6 +31,11 @@ TF_NET = dict(
     te_config=dict(model_dim=256, num_layers=3, mha_config=dict(num_heads=16, init_zeros=True, do_layer_norm=True),
                    dense_config=dict(act_h="lrlu", nrm="layer", output_init_zeros=True)),
     outp_embd_config=dict(act_h="lrlu", nrm="layer", output_init_zeros=True))
+CA_NET = dict(
+    node_embd_config=dict(act_h="lrlu", nrm="layer"), ctxt_embd_config=dict(outp_dim=64, act_h="lrlu", nrm="layer"),
+    cae_config=dict(model_dim=128, num_layers=8, mha_config=dict(num_heads=16, init_zeros=True, do_layer_norm=True),
+                    dense_config=dict(hddn_dim=256, act_h="lrlu", nrm="layer", output_init_zeros=True)),
+    outp_embd_config=dict(act_h="lrlu", nrm="layer", output_init_zeros=True))
 WORKLOADS = {
     # name: (hparams, batch, n_min, Cg, algorithmic fwd FLOP / jet / NFE, description)
     "jetnet30": (dict(EPIC, features=3, hidden_dim=128, num_particles=30, layers=6, latent=10, global_cond_dim=0, local_cond_dim=0),
@@ -38,6 +43,10 @@ WORKLOADS = {
     "lhco_transformer": (dict(model="droid_fulltransformer", features=3, num_particles=279, frequencies=16, global_cond_dim=5,
                               add_time_to_input=True, t_emb="cosine", loss_type="FM-OT", sigma=1e-4, net_config=TF_NET),
                          128, 20, 5, 1365e6, "cfg 4: Full-Transformer LHCO (N=279, D=256, 3 layers, 16 heads, 2088515 params), batch 128"),
+    "lhco_crossattention": (dict(model="droid_fullcrossattention", features=3, num_particles=279, frequencies=16, global_cond_dim=5,
+                                 add_time_to_input=True, t_emb="cosine", loss_type="FM-OT", sigma=1e-4, net_config=CA_NET),
+                            128, 20, 5, 644.6e6, "SURVEY 8(f)-4: cross-attention encoder, configs/model/fm_droid_crossattention.yaml on LHCO "
+                            "(N=279, D=128, 8 layer pairs, 16 heads, 4 global tokens, 2535107 params), batch 128"),
     "jetclass": (dict(EPIC, features=13, hidden_dim=300, num_particles=128, layers=20, latent=16, global_cond_dim=12, local_cond_dim=0),
                  256, 20, 12, 1083.1e6, "cfg 5: EPiC-FM JetClass (N=128, F=13, H=300, L=16, 20 layers, Cg=12, 8504698 params), batch 256"),
 }
@@ -56,6 +65,7 @@ def cpu_baseline(name, hp, state, jets, C, n_min):
     """Oracle (eager PyTorch restatement of the reference graph) on the host cores: 1 train step + a 3-step midpoint
     sample (4 NFE) scaled to the 198 NFE of ode_steps = 100."""
     from oracle.fm_ref import EpicVectorField, fm_ot_loss, sample_midpoint
+    from oracle.ca_ref import CrossAttentionVectorField
     from oracle.tf_ref import TransformerVectorField
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -66,6 +76,8 @@ def cpu_baseline(name, hp, state, jets, C, n_min):
     params = [v for v in st.values() if v.requires_grad]
     if hp["model"] == "epic":
         vf = EpicVectorField(st, "flows.0.net", dict(hp, sum_scale=1e-2))
+    elif hp["model"] == "droid_fullcrossattention":
+        vf = CrossAttentionVectorField(st, "flows.0.", hp)
     else:
         vf = TransformerVectorField(st, "flows.0.", hp)
     opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=5e-5)

@@ -59,6 +59,10 @@ int pfm_ca_forward(const pfm_ca_desc *desc, const float *blob, const float *t, i
 int pfm_ca_sample_midpoint(const pfm_ca_desc *desc, const float *blob, const float *t_eval, const float *dt,
                            int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
                            int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);
+/* see pfm_tf_sample_rk */
+int pfm_ca_sample_rk(const pfm_ca_desc *desc, const float *blob, const pfm_rk_tableau *tab, const float *t_eval,
+                     const float *dt, int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
+                     int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);
 int pfm_ca_fm_loss_forward(const pfm_ca_desc *desc, const float *blob, int32_t kind, float sigma, const float *t,
                            const float *x, const float *a, const float *b, const float *cond, const float *mask,
                            float *y_out, float *u_out, float *v_out, float *loss_sums, int32_t n_jets,

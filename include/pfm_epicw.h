@@ -62,6 +62,11 @@ int pfm_ew_sample_midpoint(const pfm_ew_desc *desc, const float *blob, const flo
                            int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
                            int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);
 
+/* see pfm_tf_sample_rk */
+int pfm_ew_sample_rk(const pfm_ew_desc *desc, const float *blob, const pfm_rk_tableau *tab, const float *t_eval,
+                     const float *dt, int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
+                     int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);
+
 /* Loss forward / backward, as pfm_tf_fm_loss_forward / pfm_tf_fm_loss_backward (losses.py:38-77, 101-136): the forward
  * keeps every stage's activations in `workspace` (train layout); the backward adds d loss / d(blob entry) * gscale
  * into gblob (zeroed by the caller; MFMA_AK blocks in MFMA_AK order; padding slots receive values nobody reads). */

@@ -15,6 +15,8 @@
  *   pfm_epic_sample_midpoint    CNF.decode(z, cond, mask, ode_solver="midpoint", ode_steps)
  *                               flow_matching_module.py:245-259, 283-287 (torchdyn fixed-step midpoint)
  *                               incl. the `z * mask` of SetFlowMatchingLitModule.sample (:668-671)
+ *   pfm_epic_sample_rk          CNF.decode(..., ode_solver="euler" | "rk4" | "midpoint") and CNF.encode (rk4, t: 0 -> 1)
+ *                               flow_matching_module.py:235-243, 261-287 (torchdyn fixed-step solvers; tableau given by the caller)
  *   pfm_epic_fm_loss_forward /  FlowMatchingLoss.forward / ConditionalFlowMatchingLoss.forward
  *   pfm_epic_fm_loss_backward   models/components/losses.py:38-77, 101-136 and their autograd
  *   pfm_sample_epilogue         the per-batch post-processing of generate_data   utils/data_generation.py:94-123
@@ -145,6 +147,26 @@ int pfm_epic_forward_temb(const pfm_epic_desc *desc, const float *blob, const fl
 int pfm_epic_sample_midpoint(const pfm_epic_desc *desc, const float *blob, const float *t_eval,
                              const float *dt, int32_t n_intervals, const float *z, const float *cond,
                              const float *mask, float *x_out, int32_t B, void *stream);
+
+/* Explicit Runge-Kutta scheme with up to 4 stages (a strictly lower triangular; row s of `a` feeds stage s):
+ *   k_s = f(t + c[s] dt, x + dt * (a[s][0] k_0 + ... + a[s][s-1] k_{s-1}));   x <- x + dt * (b[0] k_0 + ... + b[S-1] k_{S-1})
+ * with the sums formed left to right in fp32 before the multiplication by dt (the op order of torchdyn's solver steps).
+ * euler: S=1, b={1}.  midpoint: S=2, c={0,1/2}, a[1]={1/2}, b={0,1}.  torchdyn's "rk4" is the 3/8 rule:
+ * c={0,1/3,2/3,1}, a[1]={1/3}, a[2]={-1/3,1}, a[3]={1,-1,1}, b={1/8,3/8,3/8,1/8}. */
+#define PFM_RK_MAX_STAGES 4
+typedef struct {
+    int32_t stages, pad_;
+    float c[PFM_RK_MAX_STAGES];
+    float a[PFM_RK_MAX_STAGES][PFM_RK_MAX_STAGES];
+    float b[PFM_RK_MAX_STAGES];
+} pfm_rk_tableau;
+
+/* Fixed-step explicit Runge-Kutta over n_intervals steps, all inside one launch: x <- z*mask, then the scheme above per
+ * interval.  t_eval[n_intervals * stages] = the stage times t_k + c[s] dt_k, dt[n_intervals]: the fp32 values the reference's
+ * driver visits.  kbuf: B * stages * N * F floats of scratch (the stage slopes of every jet). */
+int pfm_epic_sample_rk(const pfm_epic_desc *desc, const float *blob, const pfm_rk_tableau *tab, const float *t_eval,
+                       const float *dt, int32_t n_intervals, const float *z, const float *cond, const float *mask,
+                       float *x_out, int32_t B, float *kbuf, void *stream);
 
 /* Flow-matching loss, forward.  kind 0 = "FM-OT" (losses.py:56-62: y=(1-t)x+(sigma+(1-sigma)t)z, u=((1-sigma)z-x)*mask),
  * kind 1 = "CFM" (losses.py:115-119: y=(1-t)x+t*z+sigma*eps, u=(z-x)*mask; eps required).

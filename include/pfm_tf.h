@@ -119,6 +119,13 @@ int pfm_tf_sample_midpoint(const pfm_tf_desc *desc, const float *blob, const flo
                            int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
                            int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);
 
+/* Fixed-step explicit Runge-Kutta (pfm_rk_tableau, pfm_hip.h): t_eval[n_steps * stages], dt[n_steps];
+ * state: (2 + stages) * n_jets*N*F floats of scratch.  ode_solver "euler" / "rk4" of CNF.decode and the rk4 of CNF.encode
+ * (flow_matching_module.py:235-243, 261-282). */
+int pfm_tf_sample_rk(const pfm_tf_desc *desc, const float *blob, const pfm_rk_tableau *tab, const float *t_eval,
+                     const float *dt, int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
+                     int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);
+
 /* Loss forward: kind 0 = FM-OT (a = z), 1 = CFM (a = x0, b = eps), 2 = droid (DroidLoss, losses.py:304-342: y = x + t z, u = z mask).  Builds y, u; evaluates v = f(t, y) keeping
  * the activations in `workspace` (train layout); loss_sums[0] += sum (v-u)^2, loss_sums[1] += sum mask
  * (the caller zeroes loss_sums and divides).  y_out/u_out/v_out [n_jets][N][F] are written for the backward. */

@@ -150,7 +150,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
             a.Wc[2 + 2 * l] = d.to_layer[l].d1.Wc; a.bb[2 + 2 * l] = d.to_layer[l].d1.b;
         }
         a.Wc[nb - 1] = d.o1.Wc; a.bb[nb - 1] = d.o1.b;
-        hipLaunchKernelGGL(tf_ctxt_kernel, dim3(p.n_jets), dim3(512), 0, p.s, a);
+        launch_ctxt(a, p.n_jets, p.s);
         PFM_TRY(check_hip(hipGetLastError(), "tf_ctxt_kernel launch (ca)"));
     }
     const float* jb = ws + w.jb;

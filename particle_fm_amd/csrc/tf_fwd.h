@@ -5,8 +5,9 @@
 // DenseNetwork); time embedding time_emb.py:79-96.
 //
 // Kernels (one NFE = ctxt, embed, then Linear / attention launches on the caller's stream):
-//   tf_ctxt_kernel    one workgroup per jet: cosine embedding, ctxt_emdb, and the "jet bias" rows of every Linear
-//                     that takes the context (their context / time columns times the per-jet vectors).
+//   tf_ctxt_kernel    one workgroup per jet: time embedding and ctxt_emdb.
+//   tf_jetbias_kernel one workgroup per (jet, Linear that takes the context): its "jet bias" row = bias + the context
+//                     (/ time) columns times the per-jet vectors.
 //   tf_embed_kernel   node_embd input block: K = F particle columns on the VALU (+ jet bias), LeakyReLU.
 //   tf_linear_kernel  out = epi( LN?(A) . W^T + b + jetbias ) (+ residual): 64 rows x 128 outputs per workgroup,
 //                     K streamed in chunks of 128 through LDS, weights are the MFMA A operand straight from
@@ -58,7 +59,6 @@ struct CtxtArgs {
 static __global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
     __shared__ float cin[96];
     __shared__ float hb[512];
-    __shared__ float cx[64];
     __shared__ float part[512];
     __shared__ float red[8];
     const int tid = threadIdx.x, jet = blockIdx.x;
@@ -116,22 +116,39 @@ static __global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
         float acc = blob[a.c2b + tid];
 #pragma unroll
         for (int p = 0; p < 8; ++p) acc += part[p * 64 + tid];
-        cx[tid] = acc;
         a.ctxt[(int64_t)jet * a.CO + tid] = acc;
     }
+}
+
+// jet-bias rows: jb[jet][c][:] = b_c + Wc_c . ctxt (+ Wt . temb for node_embd, c = 0).  grid (n_jets, nb): one row per
+// workgroup, so the nb * Hd dot products of a jet run side by side instead of one row after the other.
+static __global__ __launch_bounds__(256) void tf_jetbias_kernel(CtxtArgs a) {
+    __shared__ float cx[64];
+    __shared__ float te[64];
+    const int tid = threadIdx.x, jet = blockIdx.x, c = blockIdx.y;
+    const float* __restrict__ blob = a.blob;
+    const bool with_t = c == 0 && a.n1Wt >= 0;
+    if (tid < a.CO) cx[tid] = a.ctxt[(int64_t)jet * a.CO + tid];
+    if (with_t && tid >= 64 && tid < 64 + a.T) te[tid - 64] = a.temb[(int64_t)jet * 64 + tid - 64];
     __syncthreads();
-    // jet-bias rows: b + Wc . ctxt (+ Wt . temb for node_embd)
-    for (int c = 0; c < a.nb; ++c) {
-        for (int o = tid; o < a.Hd; o += 512) {
-            float acc = blob[a.bb[c] + o];
+    for (int o = tid; o < a.Hd; o += 256) {
+        float acc = blob[a.bb[c] + o], acc2 = 0.f;
 #pragma unroll 8
-            for (int j = 0; j < a.CO; ++j) acc = fmaf(blob[a.Wc[c] + (int64_t)j * a.Hd + o], cx[j], acc);
-            if (c == 0 && a.n1Wt >= 0)
-#pragma unroll 8
-                for (int k = 0; k < a.T; ++k) acc = fmaf(blob[a.n1Wt + (int64_t)k * a.Hd + o], cin[k], acc);
-            a.jb[((int64_t)jet * a.nb + c) * a.Hd + o] = acc;
+        for (int j = 0; j < a.CO; j += 2) {
+            acc = fmaf(blob[a.Wc[c] + (int64_t)j * a.Hd + o], cx[j], acc);
+            acc2 = fmaf(blob[a.Wc[c] + (int64_t)(j + 1) * a.Hd + o], cx[j + 1], acc2);
         }
+        acc += acc2;
+        if (with_t)
+#pragma unroll 8
+            for (int k = 0; k < a.T; ++k) acc = fmaf(blob[a.n1Wt + (int64_t)k * a.Hd + o], te[k], acc);
+        a.jb[((int64_t)jet * a.nb + c) * a.Hd + o] = acc;
     }
+}
+
+inline void launch_ctxt(const CtxtArgs& a, int n_jets, hipStream_t s) {
+    hipLaunchKernelGGL(tf_ctxt_kernel, dim3(n_jets), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(tf_jetbias_kernel, dim3(n_jets, a.nb), dim3(256), 0, s, a);
 }
 
 // node_embd input block (droid_transformer.py:793-813 on cat(temb, x, ctxt)): the F particle columns

@@ -127,7 +127,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         a.Wc[0] = d.n1.Wc; a.bb[0] = d.n1.b;
         for (int l = 0; l < d.layers; ++l) { a.Wc[1 + l] = d.layer[l].d1.Wc; a.bb[1 + l] = d.layer[l].d1.b; }
         a.Wc[nb - 1] = d.o1.Wc; a.bb[nb - 1] = d.o1.b;
-        hipLaunchKernelGGL(tf_ctxt_kernel, dim3(p.n_jets), dim3(512), 0, p.s, a);
+        launch_ctxt(a, p.n_jets, p.s);
         if ((rc = check_hip(hipGetLastError(), "tf_ctxt_kernel launch"))) return rc;
     }
     const float* jb = ws + w.jb;
