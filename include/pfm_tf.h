@@ -39,6 +39,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include "pfm_hip.h" /* pfm_rk_tableau */
 
 #ifdef __cplusplus
 extern "C" {

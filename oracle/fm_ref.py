@@ -150,6 +150,54 @@ def midpoint_trajectory_end(f: Callable, x: torch.Tensor, t_span: torch.Tensor) 
     return x
 
 
+# torchdyn's fixed-step solvers as explicit Runge-Kutta tableaus (c, rows of a, b).  torchdyn is not vendored (requirements.txt:25):
+# restated from its published solver steps -- Euler.step (x + dt*k1), Midpoint.step, RungeKutta4.step with construct_rk4 = the
+# 3/8 rule -- and UNPINNED at the torchdyn boundary like the midpoint driver above.
+RK_TABLEAUS = {
+    "euler": ([0.0], [[]], [1.0]),
+    "midpoint": ([0.0, 0.5], [[], [0.5]], [0.0, 1.0]),
+    "rk4": ([0.0, 1 / 3, 2 / 3, 1.0], [[], [1 / 3], [-1 / 3, 1.0], [1.0, -1.0, 1.0]], [1 / 8, 3 / 8, 3 / 8, 1 / 8]),
+}
+
+
+def rk_trajectory_end(f: Callable, x: torch.Tensor, t_span: torch.Tensor, solver: str) -> torch.Tensor:
+    """Fixed-step explicit Runge-Kutta over ``t_span`` with the driver of ``midpoint_trajectory_end``; a stage input is
+    x + dt * (a_0 k_0 + a_1 k_1 + ...), the update x + dt * (b_0 k_0 + ...), fp32 tableau entries, sums left to right."""
+    c, a, b = (RK_TABLEAUS[solver][0], RK_TABLEAUS[solver][1], RK_TABLEAUS[solver][2])
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32)
+    t = t_span[0]
+    dt = t_span[1] - t
+    steps = len(t_span)
+    for k in range(1, steps):
+        ks = []
+        for s in range(len(b)):
+            if s == 0:
+                ks.append(f(t, x))
+                continue
+            acc = f32(a[s][0]) * ks[0]
+            for j in range(1, s):
+                acc = acc + f32(a[s][j]) * ks[j]
+            ks.append(f(t + f32(c[s]) * dt, x + dt * acc))
+        acc = f32(b[0]) * ks[0]
+        for j in range(1, len(b)):
+            acc = acc + f32(b[j]) * ks[j]
+        x = x + dt * acc
+        t = t + dt
+        if k < steps - 1:
+            dt = t_span[k + 1] - t
+    return x
+
+
+def sample_fixed_step(vf: Callable, z, cond, mask, ode_steps: int = 100, solver: str = "rk4", t0: float = 1.0, t1: float = 0.0):
+    """CNF.decode with ode_solver "euler" / "rk4" / "midpoint" (flow_matching_module.py:261-287) behind sample's z * mask
+    (:668-671); t0 = 0, t1 = 1, solver "rk4", ode_steps 100, cond None = CNF.encode (:235-243)."""
+    if mask is not None:
+        z = z * mask
+    t_span = torch.linspace(t0, t1, ode_steps)
+    with torch.no_grad():
+        return rk_trajectory_end(lambda t, x: vf(t, x, mask=mask, cond=cond), z, t_span, solver)
+
+
 def midpoint_time_grid(ode_steps: int):
     """The 2*(ode_steps-1) evaluation times (t_k, t_k + dt_k/2) and the dt_k the
     restated driver visits, as fp32 tensors -- the same arithmetic as above."""

@@ -38,6 +38,13 @@ SYMBOLS = {
     "pfm_wn_pack": (c_int, [_fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_wn_unpack_grad": (c_int, [_fp, _fp, _fp, c_int32, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_sample_epilogue": (c_int, [_fp, _fp, _fp, _fp, c_int32, c_int64, c_int32, c_void_p]),
+    "pfm_epic_sample_rk": (c_int, [POINTER(EpicDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_tf_sample_rk": (
+        c_int, [POINTER(TfDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),
+    "pfm_ew_sample_rk": (
+        c_int, [POINTER(EwDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),
+    "pfm_ca_sample_rk": (
+        c_int, [POINTER(CaDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),
     # include/pfm_tf.h
     "pfm_tf_workspace_floats": (c_int64, [POINTER(TfDesc), c_int32, c_int32]),
     "pfm_tf_forward": (c_int, [POINTER(TfDesc), _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),

@@ -501,6 +501,31 @@ int pfm_ca_sample_midpoint(const pfm_ca_desc* d, const float* blob, const float*
     return check_hip(hipMemcpyAsync(x_out, xs, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_out");
 }
 
+int pfm_ca_sample_rk(const pfm_ca_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
+                     int32_t n_steps, const float* z, const float* cond, const float* mask, float* x_out, int32_t n_jets,
+                     int32_t premask, float* state, float* workspace, void* stream) {
+    ca::Plan p;
+    int rc = ca::make_plan(p, d, blob, workspace, n_jets, false, stream);
+    if (rc) return rc;
+    if (const char* e = tf::rk_tableau_error(tab)) return set_err(PFM_E_BADARG, e);
+    if (n_jets <= 0) return 0;
+    if (!blob || !t_eval || !dt || !z || !x_out || !state || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (n_steps < 0) return set_err(PFM_E_BADARG, "n_steps < 0");
+    if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
+    const int64_t n = (int64_t)p.M * d->features;
+    hipLaunchKernelGGL(tf::tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, state, n,
+                       d->features);
+    if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+    rc = tf::sample_rk_rows(*tab, t_eval, dt, n_steps, state, n, p.s, [&](const float* t, const float* x, float* v) {
+        tf::HeadArgs h{};
+        h.dst = v;
+        return ca::run_nfe(p, t, 0, x, cond, mask, h);
+    });
+    if (rc) return rc;
+    if ((rc = check_hip(hipGetLastError(), "tf_rk_combine_kernel launch"))) return rc;
+    return check_hip(hipMemcpyAsync(x_out, state, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_out");
+}
+
 int pfm_ca_fm_loss_forward(const pfm_ca_desc* d, const float* blob, int32_t kind, float sigma, const float* t, const float* x,
                            const float* a, const float* b, const float* cond, const float* mask, float* y_out, float* u_out,
                            float* v_out, float* loss_sums, int32_t n_jets, float* workspace, void* stream) {

@@ -156,6 +156,58 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
     for (int i = tid; i < j.N * j.F; i += NT) oj[i] = xs[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent fixed-step explicit Runge-Kutta integrator (pfm_rk_tableau: euler, midpoint, torchdyn's rk4 = 3/8 rule):
+// as above, with the stage slopes of the jet parked in global scratch (every element is written and read back by the
+// same lane; the LDS carve has no room for four more N x F tiles at N = 150).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(NT, 2) void epic_sample_rk_kernel(
+    const float* __restrict__ blob, int64_t desc_off, pfm_rk_tableau tab, const float* __restrict__ t_eval,
+    const float* __restrict__ dt, int n_intervals, const float* __restrict__ z, const float* __restrict__ cond,
+    const float* __restrict__ mask, float* __restrict__ x_out, float* __restrict__ kbuf) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
+    const JetDims j = dims_of(d0);
+    const Carve c = make_carve(j.N, j.F);
+    const int jet = blockIdx.x, tid = threadIdx.x;
+    const int n_rows = epic_jet_setup(d0, j, blob, lds, c, cond ? cond + (size_t)jet * j.C : nullptr,
+                                      mask ? mask + (size_t)jet * j.N : nullptr);
+    const int NF = j.N * j.F, F = j.F, S = tab.stages;
+    const float* zj = z + (size_t)jet * NF;
+    for (int i = tid; i < NF; i += NT) {
+        const float z0 = zj[i] * lds[c.maskf + i / F];
+        lds[c.xs + i] = z0;
+        lds[c.yin + i] = z0;
+    }
+    const SavedLayout sl = make_saved(j.N, j.F, j.layers);
+    float* xs = lds + c.xs;
+    float* yin = lds + c.yin;
+    float* kj = kbuf + (size_t)jet * S * NF;
+    int st = 0;
+    for (int e = 0; e < S * n_intervals; ++e) {
+        const float h = dt[e / S];
+        const bool last = st == S - 1;
+        const float* coef = last ? tab.b : tab.a[st + 1 < PFM_RK_MAX_STAGES ? st + 1 : 0];
+        epic_time_embedding(d0, j, blob, lds, c, t_eval[e]);
+        __syncthreads();
+        epic_body<false, MODE>(d0, j, blob, lds, c, n_rows, nullptr, sl);
+        epic_head<MODE>(d0, j, blob, lds, c, n_rows, [=](int p, int f, float val) {
+            const int i = p * F + f;
+            if (!last) kj[st * NF + i] = val;
+            float acc = __fmul_rn(coef[0], st == 0 ? val : kj[i]);
+            for (int q = 1; q <= st; ++q) acc = __fadd_rn(acc, __fmul_rn(coef[q], q == st ? val : kj[q * NF + i]));
+            const float xn = __fadd_rn(xs[i], __fmul_rn(h, acc));
+            yin[i] = xn;
+            if (last) xs[i] = xn;
+        });
+        __syncthreads();
+        st = last ? 0 : st + 1;
+    }
+    float* oj = x_out + (size_t)jet * NF;
+    for (int i = tid; i < NF; i += NT) oj[i] = xs[i];
+}
+
 // which matrix-pipe flavour the inference kernels use (descriptor flags): 0 fp32, 1 bf16 operands, 2 split fp16
 int mfma_mode(const pfm_epic_desc* d) {
     if (!d) return 0;
@@ -246,6 +298,27 @@ int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const fl
     if (mode == 2) PFM_LAUNCH_SMP(2); else if (mode == 1) PFM_LAUNCH_SMP(1); else PFM_LAUNCH_SMP(0);
 #undef PFM_LAUNCH_SMP
     return check_hip(hipGetLastError(), "epic_sample_midpoint_kernel launch");
+}
+
+int pfm_epic_sample_rk(const pfm_epic_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
+                       int32_t n_intervals, const float* z, const float* cond, const float* mask, float* x_out, int32_t B,
+                       float* kbuf, void* stream) {
+    int lds = 0;
+    const int mode = mfma_mode(d);
+    int rc = mode == 2 ? prepare(epic_sample_rk_kernel<2>, d, &lds)
+                       : (mode == 1 ? prepare(epic_sample_rk_kernel<1>, d, &lds) : prepare(epic_sample_rk_kernel<0>, d, &lds));
+    if (rc) return rc;
+    if (!tab || tab->stages < 1 || tab->stages > PFM_RK_MAX_STAGES) return set_err(PFM_E_BADARG, "tableau.stages must be in 1..4");
+    if (B <= 0) return 0;
+    if (!blob || !t_eval || !dt || !z || !x_out || !kbuf) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (n_intervals < 0) return set_err(PFM_E_BADARG, "n_intervals < 0");
+    if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
+#define PFM_LAUNCH_RK(M)                                                                                                    \
+    hipLaunchKernelGGL(epic_sample_rk_kernel<M>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, *tab, \
+                       t_eval, dt, n_intervals, z, cond, mask, x_out, kbuf)
+    if (mode == 2) PFM_LAUNCH_RK(2); else if (mode == 1) PFM_LAUNCH_RK(1); else PFM_LAUNCH_RK(0);
+#undef PFM_LAUNCH_RK
+    return check_hip(hipGetLastError(), "epic_sample_rk_kernel launch");
 }
 
 }  // extern "C"

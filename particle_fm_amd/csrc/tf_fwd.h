@@ -662,5 +662,57 @@ static __global__ void tf_premask_kernel(const float* __restrict__ z, const floa
     if (i < n) x[i] = mask ? z[i] * mask[i / F] : z[i];
 }
 
+// out = x + dt * (c0 k0 + c1 k1 + ...): one stage input / the step update of an explicit Runge-Kutta scheme, products
+// and sums rounded one by one, left to right (torchdyn's solver steps are unfused elementwise torch ops)
+struct RkCombineArgs {
+    const float* x;
+    const float* dt;  // device scalar
+    const float* k[PFM_RK_MAX_STAGES];
+    float coef[PFM_RK_MAX_STAGES];
+    float* out;
+    int64_t n;
+    int terms;
+};
+static __global__ void tf_rk_combine_kernel(RkCombineArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    float acc = __fmul_rn(a.coef[0], a.k[0][i]);
+    for (int j = 1; j < a.terms; ++j) acc = __fadd_rn(acc, __fmul_rn(a.coef[j], a.k[j][i]));
+    a.out[i] = __fadd_rn(a.x[i], __fmul_rn(*a.dt, acc));
+}
+
+// Host loop of the fixed-step explicit Runge-Kutta samplers of the row-matrix paths.  state = xs | ys | k_0 .. k_{S-1}
+// (n floats each; xs holds the start state).  nfe(t, x_in, v_out) queues one network evaluation.
+template <class Nfe>
+int sample_rk_rows(const pfm_rk_tableau& tab, const float* t_eval, const float* dt, int n_steps, float* state, int64_t n,
+                   hipStream_t s, Nfe nfe) {
+    const int S = tab.stages;
+    float* xs = state;
+    float* ys = state + n;
+    float* K = state + 2 * n;
+    for (int k = 0; k < n_steps; ++k)
+        for (int st = 0; st < S; ++st) {
+            int rc = nfe(t_eval + (int64_t)k * S + st, st ? ys : xs, K + st * n);
+            if (rc) return rc;
+            RkCombineArgs a;
+            a.x = xs; a.dt = dt + k; a.n = n;
+            const bool last = st == S - 1;
+            a.out = last ? xs : ys;
+            a.terms = st + 1;
+            for (int j = 0; j <= st; ++j) {
+                a.k[j] = K + j * n;
+                a.coef[j] = last ? tab.b[j] : tab.a[st + 1][j];
+            }
+            hipLaunchKernelGGL(tf_rk_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+        }
+    return 0;
+}
+
+inline const char* rk_tableau_error(const pfm_rk_tableau* t) {
+    if (!t) return "tableau is NULL";
+    if (t->stages < 1 || t->stages > PFM_RK_MAX_STAGES) return "tableau.stages must be in 1..4";
+    return nullptr;
+}
+
 }  // namespace tf
 }  // namespace pfm

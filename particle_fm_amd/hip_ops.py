@@ -100,6 +100,75 @@ def midpoint_grid(ode_steps: int):
     return torch.stack(ts), torch.stack(dts)
 
 
+class RkTableau(ctypes.Structure):
+    """ctypes mirror of ``pfm_rk_tableau`` (include/pfm_hip.h)."""
+
+    _fields_ = [("stages", ctypes.c_int32), ("pad_", ctypes.c_int32), ("c", ctypes.c_float * 4),
+                ("a", (ctypes.c_float * 4) * 4), ("b", ctypes.c_float * 4)]
+
+
+# The fixed-step torchdyn solvers CNF.decode / CNF.encode name (flow_matching_module.py:235-243, 261-287), as explicit
+# Runge-Kutta tableaus (c, rows of a, b).  torchdyn's "rk4" is the 3/8 rule (its construct_rk4), not the classical scheme.
+RK_TABLEAUS = {
+    "euler": ([0.0], [[]], [1.0]),
+    "midpoint": ([0.0, 0.5], [[], [0.5]], [0.0, 1.0]),
+    "rk4": ([0.0, 1 / 3, 2 / 3, 1.0], [[], [1 / 3], [-1 / 3, 1.0], [1.0, -1.0, 1.0]], [1 / 8, 3 / 8, 3 / 8, 1 / 8]),
+}
+
+
+def rk_tableau(solver: str) -> RkTableau:
+    if solver not in RK_TABLEAUS:
+        raise NotImplementedError(f"Solver {solver} has no HIP path in this build (fixed-step 'euler', 'midpoint', 'rk4' do).")
+    c, a, b = RK_TABLEAUS[solver]
+    t = RkTableau()
+    t.stages = len(b)
+    for i, v in enumerate(c):
+        t.c[i] = v
+    for i, row in enumerate(a):
+        for j, v in enumerate(row):
+            t.a[i][j] = v
+    for i, v in enumerate(b):
+        t.b[i] = v
+    return t
+
+
+def rk_grid(ode_steps: int, solver: str, t0: float = 1.0, t1: float = 0.0):
+    """Stage times and step sizes the fixed-step driver visits for t_span = linspace(t0, t1, ode_steps) (torchdyn driver:
+    t += dt; dt = t_span[k+1] - t; stage s is evaluated at t + c[s] * dt), in fp32 on the host."""
+    c = torch.tensor(RK_TABLEAUS[solver][0], dtype=torch.float32)
+    t_span = torch.linspace(t0, t1, ode_steps)
+    t = t_span[0]
+    dt = t_span[1] - t
+    ts, dts = [], []
+    for k in range(1, ode_steps):
+        ts += [t if s == 0 else t + c[s] * dt for s in range(len(c))]
+        dts.append(dt)
+        t = t + dt
+        if k < ode_steps - 1:
+            dt = t_span[k + 1] - t
+    return torch.stack(ts), torch.stack(dts)
+
+
+def epic_sample_rk(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor, cond: Optional[torch.Tensor] = None,
+                   mask: Optional[torch.Tensor] = None, ode_steps: int = 100, solver: str = "rk4", t0: float = 1.0,
+                   t1: float = 0.0) -> torch.Tensor:
+    """x(t1) from x(t0) = z*mask with the fixed-step explicit Runge-Kutta scheme ``solver`` over linspace(t0, t1, ode_steps),
+    one persistent launch."""
+    lib = _lib.load()
+    dev, B, blob, z, cond, mask = _prep_common(layout, blob, z, cond, mask)
+    if ode_steps < 2:
+        raise ValueError("ode_steps must be >= 2")
+    tab = rk_tableau(solver)
+    ts, dts = rk_grid(ode_steps, solver, t0, t1)
+    ts, dts = ts.to(dev), dts.to(dev)
+    out = torch.empty_like(z)
+    kbuf = torch.empty(tab.stages * z.numel(), device=dev, dtype=torch.float32)
+    rc = lib.pfm_epic_sample_rk(ctypes.byref(layout.desc), _ptr(blob), ctypes.byref(tab), _ptr(ts), _ptr(dts), ode_steps - 1,
+                                _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, _ptr(kbuf), _stream_ptr(dev))
+    _lib.check(rc, "pfm_epic_sample_rk")
+    return out
+
+
 def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor,
                          cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
                          ode_steps: int = 100, premask: bool = True) -> torch.Tensor:

@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .hip_ops import _dev_f32, _prep_common, _ptr, _stream_ptr, midpoint_grid
+from .hip_ops import _dev_f32, _prep_common, _ptr, _stream_ptr, midpoint_grid, rk_grid, rk_tableau
 from .layout_wide import EpicWideLayout
 
 
@@ -51,6 +51,26 @@ def ew_sample_midpoint(layout: EpicWideLayout, blob, z, cond=None, mask=None, od
                                     _ptr(cond), _ptr(mask), _ptr(out), B, int(bool(premask and mask is not None)),
                                     _ptr(state), _ptr(workspace(layout, B, dev)), _stream_ptr(dev))
     _lib.check(rc, "pfm_ew_sample_midpoint")
+    return out
+
+
+def ew_sample_rk(layout: EpicWideLayout, blob, z, cond=None, mask=None, ode_steps: int = 100, solver: str = "rk4",
+                 premask: bool = True, t0: float = 1.0, t1: float = 0.0) -> torch.Tensor:
+    """x(t1) from x(t0) = z (*mask) with the fixed-step explicit Runge-Kutta scheme ``solver`` ("euler", "midpoint", "rk4" =
+    torchdyn's 3/8 rule) over linspace(t0, t1, ode_steps); all launches queued on the current stream."""
+    lib = _lib.load()
+    dev, B, blob, z, cond, mask = _prep_common(layout, blob, z, cond, mask)
+    if ode_steps < 2:
+        raise ValueError("ode_steps must be >= 2")
+    tab = rk_tableau(solver)
+    ts, dts = rk_grid(ode_steps, solver, t0, t1)
+    ts, dts = ts.to(dev), dts.to(dev)
+    out = torch.empty_like(z)
+    state = torch.empty((2 + tab.stages) * z.numel(), device=dev, dtype=torch.float32)
+    rc = lib.pfm_ew_sample_rk(ctypes.byref(layout.desc), _ptr(blob), ctypes.byref(tab), _ptr(ts), _ptr(dts), ode_steps - 1,
+                              _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, int(bool(premask and mask is not None)),
+                              _ptr(state), _ptr(workspace(layout, B, dev)), _stream_ptr(dev))
+    _lib.check(rc, "pfm_ew_sample_rk")
     return out
 
 

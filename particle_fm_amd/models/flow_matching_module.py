@@ -211,14 +211,33 @@ class CNF(nn.Module):
                                                        ode_steps=ode_steps, premask=False)
             return hip_ops.epic_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
                                                 ode_steps=ode_steps, premask=False)
+        if ode_solver in ("euler", "rk4"):  # torchdyn fixed-step solvers over the same t_span (:261-282)
+            blob = weights if weights is not None else self.net.packed_weights(z.shape[1])
+            return self._sample_rk(blob, z, cond, mask, ode_steps, ode_solver, 1.0, 0.0)
         if ode_solver in ("em", "ddim"):
             raise SyntaxError(f"Solver {ode_solver} is only implemented for diffusion loss")  # :326
-        if ode_solver in ("dopri5_zuko", "rk4", "dopri5", "euler", "tsit5", "ieuler", "alf"):
-            raise NotImplementedError(f"Solver {ode_solver} has no HIP path in this build (only 'midpoint').")
+        if ode_solver in ("dopri5_zuko", "dopri5", "tsit5", "ieuler", "alf"):
+            raise NotImplementedError(f"Solver {ode_solver} has no HIP path in this build (fixed-step 'midpoint', 'euler', 'rk4' do).")
         raise NotImplementedError(f"Solver {ode_solver} not implemented")  # :328
 
-    def encode(self, *args, **kwargs):
-        raise NotImplementedError("CNF.encode (rk4 forward in time) has no HIP path in this build")
+    def _sample_rk(self, blob, z, cond, mask, ode_steps, solver, t0, t1):
+        lay = self.net.layout(z.shape[1])
+        kw = dict(ode_steps=ode_steps, solver=solver, t0=t0, t1=t1)
+        if self.is_transformer:
+            return hip_ops_tf.tf_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
+        if self.is_cross_attention:
+            return hip_ops_ca.ca_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
+        if self.net.wide:
+            return hip_ops_wide.ew_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
+        return hip_ops.epic_sample_rk(lay, blob, z, cond, mask, **kw)
+
+    def encode(self, x: Tensor, mask: Tensor = None, ode_solver: str = "dopri5_zuko", ode_steps: int = 100) -> Tensor:
+        """flow_matching_module.py:235-243: whatever ``ode_solver`` / ``ode_steps`` say, the reference integrates data -> latent
+        with torchdyn's rk4 over linspace(0, 1, 100) and WITHOUT the conditioning (cond=None)."""
+        if self.net.layout(x.shape[1]).cfg.global_cond_dim > 0:
+            raise ValueError("CNF.encode evaluates the network with cond=None (flow_matching_module.py:239); a conditioned "
+                             "network cannot be encoded")
+        return self._sample_rk(self.net.packed_weights(x.shape[1]), x, None, mask, 100, "rk4", 0.0, 1.0)
 
     def log_prob(self, *args, **kwargs):
         raise NotImplementedError("CNF.log_prob (zuko adaptive solver) has no HIP path in this build")

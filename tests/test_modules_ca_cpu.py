@@ -53,8 +53,10 @@ def test_errors():
     x = torch.randn(2, 30, 3)
     with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
         m.flows[0](torch.rand(2), x, cond=torch.zeros(2, 2), mask=torch.ones(2, 30, 1))
+    with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
+        m.flows[0].decode(x, None, None, ode_solver="rk4")  # has a HIP path, not a CPU one
     with pytest.raises(NotImplementedError):
-        m.flows[0].decode(x, None, None, ode_solver="rk4")
+        m.flows[0].decode(x, None, None, ode_solver="dopri5")
     for patch in (("cae_config", "mha_config", "num_heads", 4),          # head_dim 32
                   ("cae_config", "mha_config", "do_layer_norm", False),
                   ("cae_config", "num_tokens", 9),

@@ -78,8 +78,10 @@ def test_no_cpu_fallback():
     x = torch.randn(2, 30, 3)
     with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
         m.flows[0](torch.rand(2), x)
+    with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
+        m.flows[0].decode(x, None, None, ode_solver="rk4")  # has a HIP path, not a CPU one
     with pytest.raises(NotImplementedError):
-        m.flows[0].decode(x, None, None, ode_solver="rk4")
+        m.flows[0].decode(x, None, None, ode_solver="dopri5")
     with pytest.raises(NotImplementedError):
         m.flows[0].decode(x, None, None, ode_solver="bogus")
     with pytest.raises(SyntaxError):
