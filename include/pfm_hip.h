@@ -19,6 +19,8 @@
  *                               flow_matching_module.py:235-243, 261-287 (torchdyn fixed-step solvers; tableau given by the caller)
  *   pfm_epic_fm_loss_forward /  FlowMatchingLoss.forward / ConditionalFlowMatchingLoss.forward
  *   pfm_epic_fm_loss_backward   models/components/losses.py:38-77, 101-136 and their autograd
+ *   pfm_epic_diffusion_loss_*   DiffusionLoss.forward and its autograd   models/components/losses.py:207-290
+ *   pfm_diffusion_update        the state update of ddim_sampler / euler_maruyama_sampler   models/components/solver.py:81-93, 126-132
  *   pfm_sample_epilogue         the per-batch post-processing of generate_data   utils/data_generation.py:94-123
  *   pfm_optim_step              clip_grad_norm_(gradient_clip_val) + AdamW + EMA
  *                               configs/experiment/jetnet/fm_tops150.yaml:24, configs/model/flow_matching.yaml:3-7,
@@ -163,10 +165,13 @@ typedef struct {
 
 /* Fixed-step explicit Runge-Kutta over n_intervals steps, all inside one launch: x <- z*mask, then the scheme above per
  * interval.  t_eval[n_intervals * stages] = the stage times t_k + c[s] dt_k, dt[n_intervals]: the fp32 values the reference's
- * driver visits.  kbuf: B * stages * N * F floats of scratch (the stage slopes of every jet). */
+ * driver visits.  kbuf: B * stages * N * F floats of scratch (the stage slopes of every jet).
+ * rhs (NULL for flow matching): [n_intervals * stages][2] = (-0.5 beta(t), noise_rate(t)) at every stage time: the ODE
+ * right-hand side becomes rhs0 * (x - f(t, x) / rhs1), the probability-flow ODE of a noise-predicting network
+ * (ode_wrapper.forward for loss_type="diffusion", flow_matching_module.py:62-69). */
 int pfm_epic_sample_rk(const pfm_epic_desc *desc, const float *blob, const pfm_rk_tableau *tab, const float *t_eval,
                        const float *dt, int32_t n_intervals, const float *z, const float *cond, const float *mask,
-                       float *x_out, int32_t B, float *kbuf, void *stream);
+                       float *x_out, int32_t B, float *kbuf, const float *rhs, void *stream);
 
 /* Flow-matching loss, forward.  kind 0 = "FM-OT" (losses.py:56-62: y=(1-t)x+(sigma+(1-sigma)t)z, u=((1-sigma)z-x)*mask),
  * kind 1 = "CFM" (losses.py:115-119: y=(1-t)x+t*z+sigma*eps, u=(z-x)*mask; eps required).
@@ -185,6 +190,25 @@ int pfm_epic_fm_loss_backward(const pfm_epic_desc *desc, const float *blob, cons
                               const float *cond, const float *mask, const float *saved,
                               const float *inv_mask_total, const float *grad_scale, float *grad_blob,
                               int32_t B, void *stream);
+
+/* DiffusionLoss (models/components/losses.py:207-290, configs/model/diffusion.yaml): noisy = rates[b][0] * x + rates[b][1] * z
+ * (signal / noise rate of the jet's diffusion time, models/components/diffusion.py:21-52; z arrives multiplied by the mask),
+ * v = f(t, noisy) predicts z.  criterion 0 = mse, 1 = huber (delta 1).  loss_parts[b] = sum_n,f criterion(v - z) of the jet
+ * (the caller applies the per-jet weight 1 + 0.001 beta / noise_rate, losses.py:275-281); the rest as pfm_epic_fm_loss_forward. */
+int pfm_epic_diffusion_loss_forward(const pfm_epic_desc *desc, const float *blob, int32_t criterion, const float *rates,
+                                    const float *t, const float *x, const float *z, const float *cond, const float *mask,
+                                    float *saved, float *loss_parts, float *mask_count, int32_t B, void *stream);
+
+/* Backward of loss = sum_b jet_weight[b] * loss_parts[b] / sum(mask_count), as pfm_epic_fm_loss_backward. */
+int pfm_epic_diffusion_loss_backward(const pfm_epic_desc *desc, const float *blob, int32_t criterion, const float *jet_weight,
+                                     const float *cond, const float *mask, const float *saved, const float *inv_mask_total,
+                                     const float *grad_scale, float *grad_blob, int32_t B, void *stream);
+
+/* One in-place state update of the diffusion samplers (models/components/solver.py): mode 0 = ddim_sampler :81-93
+ * (c = noise rate, signal rate, next signal rate, next noise rate; data_out, optional, receives the predicted data),
+ * mode 1 = euler_maruyama_sampler :126-132 (c = noise rate, beta, delta_t, sqrt(beta delta_t); noise = the step's normal draw). */
+int pfm_diffusion_update(int32_t mode, float *x, const float *pred, const float *noise, float c0, float c1, float c2, float c3,
+                         float *data_out, int64_t n, void *stream);
 
 /* Optimiser tail on flat fp32 buffers of n elements:
  *   gnorm = ||grad * grad_mul||_2 ; c = min(1, max_norm/(gnorm+1e-6)) (clip_grad_norm_) ; g = grad*grad_mul*c

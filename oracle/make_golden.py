@@ -544,10 +544,85 @@ CA_CONFIGS = {
 }
 
 
+# ----------------------------------------------------------------------------------------------
+# loss_type="diffusion" (configs/model/diffusion.yaml: EPiC, hidden 128, cosine embedding, huber criterion)
+# ----------------------------------------------------------------------------------------------
+DIFF_HP = dict(BASE, num_particles=30, layers=2, global_cond_dim=2, loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02})
+
+
+def gen_diffusion(ref, out_dir, B=4, seed=2468):
+    import json
+
+    hp = DIFF_HP
+    torch.manual_seed(seed)
+    cnf = ref.fmm.CNF(**hp)
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for k, p in cnf.named_parameters():
+            if k.endswith("weight_g"):
+                p.mul_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+            elif k.endswith("bias"):
+                p.add_(0.05 * torch.randn(p.shape, generator=gen))
+    flows = torch.nn.ModuleList([cnf])
+    state = {f"flows.0.{k}": v.detach().clone() for k, v in cnf.state_dict().items()}
+    N, Fe, Cg, dc = hp["num_particles"], hp["features"], hp["global_cond_dim"], hp["diff_config"]
+    out = {"_keys": np.array(list(state.keys()))}
+    for k, v in state.items():
+        out["sd/" + k] = v.numpy()
+    out["hp_json"] = np.array(json.dumps(hp))
+    out["freqs"] = torch.arange(2 * hp["frequencies"]).exp().numpy()
+    # ---- DiffusionLoss (losses.py:207-290), both criteria; draws replayed by seed (:241, :247) ----
+    for crit in ("huber", "mse"):
+        mask = make_mask(B, N, "f32", gen)
+        x = 2.0 * torch.randn(B, N, Fe, generator=gen) * mask  # scale 2: some residuals beyond the huber knee
+        cond = torch.randn(B, Cg, generator=gen)
+        loss_mod = ref.losses.DiffusionLoss(flows=flows, criterion=crit, diff_config=dc)
+        torch.manual_seed(1357)
+        cnf.zero_grad()
+        loss = loss_mod(x, mask=mask, cond=cond)
+        loss.backward()
+        torch.manual_seed(1357)
+        t = torch.rand_like(torch.ones(B))
+        z = torch.randn_like(x) * mask
+        tag = f"loss_{crit}/"
+        out[tag + "x"], out[tag + "t"], out[tag + "z"] = x.numpy(), t.numpy(), z.numpy()
+        out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
+        for k, p in cnf.named_parameters():
+            out[tag + "grad/flows.0." + k] = p.grad.detach().clone().numpy()
+    # ---- probability-flow ODE right-hand side (ode_wrapper, flow_matching_module.py:62-69) and the midpoint sampler on it ----
+    mask = make_mask(B, N, "f32", gen)
+    z = torch.randn(B, N, Fe, generator=gen)
+    cond = torch.randn(B, Cg, generator=gen)
+    wrapped = ref.fmm.ode_wrapper(model=cnf, mask=mask, cond=cond, loss_type="diffusion", diff_config=dc)
+    with torch.no_grad():
+        t0 = torch.tensor(0.37)
+        out["rhs/t"], out["rhs/x"], out["rhs/mask"], out["rhs/cond"] = t0.numpy(), (z * mask).numpy(), mask.numpy(), cond.numpy()
+        out["rhs/f"] = wrapped(t0, z * mask).numpy()
+        for steps in (3, 10):
+            xe = midpoint_trajectory_end(wrapped, z * mask, torch.linspace(1.0, 0.0, steps))
+            tag = f"midpoint_{steps}/"
+            out[tag + "z"], out[tag + "mask"], out[tag + "cond"], out[tag + "x_end"] = z.numpy(), mask.numpy(), cond.numpy(), xe.numpy()
+    # ---- DDIM and Euler-Maruyama samplers (solver.py:22-143) ----
+    sched = ref.diffusion.VPDiffusionSchedule(**dc)
+    n_steps = 6
+    x_ddim, _ = ref.solver.ddim_sampler(cnf, sched, (z * mask).clone(), n_steps=n_steps, mask=mask, cond=cond)
+    out["ddim/z"], out["ddim/mask"], out["ddim/cond"], out["ddim/x_end"] = z.numpy(), mask.numpy(), cond.numpy(), x_ddim.numpy()
+    torch.manual_seed(8642)
+    x_em, _ = ref.solver.euler_maruyama_sampler(cnf, sched, (z * mask).clone(), n_steps=n_steps, mask=mask, cond=cond)
+    torch.manual_seed(8642)
+    noise = torch.stack([torch.randn_like(z) for _ in range(n_steps)])  # solver.py:131, the sampler's only draws
+    out["em/z"], out["em/mask"], out["em/cond"], out["em/noise"], out["em/x_end"] = (
+        z.numpy(), mask.numpy(), cond.numpy(), noise.numpy(), x_em.numpy())
+    out["n_steps"] = np.array(n_steps)
+    path = os.path.join(out_dir, "epic_diffusion.npz")
+    np.savez(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca}; default all")
+    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,diffusion}; default all")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
@@ -558,6 +633,8 @@ def main():
             gen_config(ref, name, hp, args.out)
     if ap2 is None or "no_sets" in ap2:
         gen_no_sets(ref, args.out)
+    if ap2 is None or "diffusion" in ap2:
+        gen_diffusion(ref, args.out)
     for name, (hp, B) in WIDE_CONFIGS.items():
         if ap2 is None or "wide" in ap2:
             gen_epic_wide(ref, name, hp, B, args.out)

@@ -38,7 +38,12 @@ SYMBOLS = {
     "pfm_wn_pack": (c_int, [_fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_wn_unpack_grad": (c_int, [_fp, _fp, _fp, c_int32, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_sample_epilogue": (c_int, [_fp, _fp, _fp, _fp, c_int32, c_int64, c_int32, c_void_p]),
-    "pfm_epic_sample_rk": (c_int, [POINTER(EpicDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_epic_sample_rk": (c_int, [POINTER(EpicDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
+    "pfm_epic_diffusion_loss_forward": (
+        c_int, [POINTER(EpicDesc), _fp, c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
+    "pfm_epic_diffusion_loss_backward": (
+        c_int, [POINTER(EpicDesc), _fp, c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
+    "pfm_diffusion_update": (c_int, [c_int32, _fp, _fp, _fp, c_float, c_float, c_float, c_float, _fp, c_int64, c_void_p]),
     "pfm_tf_sample_rk": (
         c_int, [POINTER(TfDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),
     "pfm_ew_sample_rk": (

@@ -23,7 +23,7 @@ __device__ __forceinline__ void build_vin(const JetDims& j, float* __restrict__ 
 __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ cond,
     const float* __restrict__ mask, const float* __restrict__ saved, const float* __restrict__ inv_mask_total,
-    const float* __restrict__ grad_scale, float* __restrict__ gblob) {
+    const float* __restrict__ grad_scale, float* __restrict__ gblob, int crit, const float* __restrict__ jet_w) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     // a jet without any valid particle is NaN in the reference (epic.py:370 divides by 0): compute all rows then too
     if ((d.flags & PFM_F_SKIP_MASKED_TAIL) && lds[c.misc + 1] >= 0.f) n_rows = (int)lds[c.misc + 1] + 1;
     const int ntiles = (n_rows + TILE - 1) / TILE;
-    const float gscale = 2.0f * inv_mask_total[0] * grad_scale[0];  // d/dv of sum (v-u)^2 / M
+    // d/dv of  w_jet * sum crit(v - u) / M:  mse (crit 0) 2 (v - u);  huber (crit 1, delta 1) clamp(v - u, -1, 1)
+    const float gscale = (crit ? 1.0f : 2.0f) * inv_mask_total[0] * grad_scale[0] * (jet_w ? jet_w[jet] : 1.0f);
     const float* maskf = lds + c.maskf;
     const float* evec = lds + c.vin;  // [temb ; cond_l] is a prefix of vin (Cl in {0, C})
 
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         float val = 0.f;
         if (p < n_rows) {
             const float v = sv[sl.v + i], u = sv[sl.u + i];
-            val = gscale * (v - u) * maskf[p] * dlrelu(v, slope);
+            const float dl = crit ? fminf(fmaxf(v - u, -1.0f), 1.0f) : v - u;
+            val = gscale * dl * maskf[p] * dlrelu(v, slope);
         }
         lds[c.da3 + i] = val;
     }

@@ -165,7 +165,7 @@ template <int MODE>
 __global__ __launch_bounds__(NT, 2) void epic_sample_rk_kernel(
     const float* __restrict__ blob, int64_t desc_off, pfm_rk_tableau tab, const float* __restrict__ t_eval,
     const float* __restrict__ dt, int n_intervals, const float* __restrict__ z, const float* __restrict__ cond,
-    const float* __restrict__ mask, float* __restrict__ x_out, float* __restrict__ kbuf) {
+    const float* __restrict__ mask, float* __restrict__ x_out, float* __restrict__ kbuf, const float* __restrict__ rhs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d0);
@@ -192,8 +192,10 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_rk_kernel(
         epic_time_embedding(d0, j, blob, lds, c, t_eval[e]);
         __syncthreads();
         epic_body<false, MODE>(d0, j, blob, lds, c, n_rows, nullptr, sl);
+        const float r0 = rhs ? rhs[2 * e] : 0.f, r1 = rhs ? rhs[2 * e + 1] : 1.f;
         epic_head<MODE>(d0, j, blob, lds, c, n_rows, [=](int p, int f, float val) {
             const int i = p * F + f;
+            if (rhs) val = __fmul_rn(r0, __fsub_rn(yin[i], __fdiv_rn(val, r1)));  // -0.5 beta (x - eps_theta / noise_rate)
             if (!last) kj[st * NF + i] = val;
             float acc = __fmul_rn(coef[0], st == 0 ? val : kj[i]);
             for (int q = 1; q <= st; ++q) acc = __fadd_rn(acc, __fmul_rn(coef[q], q == st ? val : kj[q * NF + i]));
@@ -302,7 +304,7 @@ int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const fl
 
 int pfm_epic_sample_rk(const pfm_epic_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
                        int32_t n_intervals, const float* z, const float* cond, const float* mask, float* x_out, int32_t B,
-                       float* kbuf, void* stream) {
+                       float* kbuf, const float* rhs, void* stream) {
     int lds = 0;
     const int mode = mfma_mode(d);
     int rc = mode == 2 ? prepare(epic_sample_rk_kernel<2>, d, &lds)
@@ -315,7 +317,7 @@ int pfm_epic_sample_rk(const pfm_epic_desc* d, const float* blob, const pfm_rk_t
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
 #define PFM_LAUNCH_RK(M)                                                                                                    \
     hipLaunchKernelGGL(epic_sample_rk_kernel<M>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, *tab, \
-                       t_eval, dt, n_intervals, z, cond, mask, x_out, kbuf)
+                       t_eval, dt, n_intervals, z, cond, mask, x_out, kbuf, rhs)
     if (mode == 2) PFM_LAUNCH_RK(2); else if (mode == 1) PFM_LAUNCH_RK(1); else PFM_LAUNCH_RK(0);
 #undef PFM_LAUNCH_RK
     return check_hip(hipGetLastError(), "epic_sample_rk_kernel launch");

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_forward_kernel(
     const float* __restrict__ blob, int64_t desc_off, int kind, float sigma, const float* __restrict__ t,
     const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ eps,
     const float* __restrict__ cond, const float* __restrict__ mask, float* __restrict__ saved,
-    float* __restrict__ loss_parts, float* __restrict__ mask_count) {
+    float* __restrict__ loss_parts, float* __restrict__ mask_count, int crit, const float* __restrict__ rates) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
@@ -46,6 +46,10 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_forward_kernel(
             // DroidLoss, losses.py:332-336:  y = x + t * z ; u = z * mask
             y = __fadd_rn(xv, __fmul_rn(tj, zv));
             u = __fmul_rn(zv, m);
+        } else if (kind == 3) {
+            // DiffusionLoss, losses.py:260, 272:  noisy = signal_rate * x + noise_rate * z ; target = z (z arrives masked, :244)
+            y = __fadd_rn(__fmul_rn(rates[2 * jet], xv), __fmul_rn(rates[2 * jet + 1], zv));
+            u = zv;
         } else {
             // losses.py:115-119  mu = (1 - t) * x + t * x0 ; y = mu + sigma * eps ; u = (x0 - x) * mask
             const float mu = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, tj), xv), __fmul_rn(tj, zv));
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_forward_kernel(
     epic_head(d, j, blob, lds, c, n_rows, [&](int p, int f, float val) {
         svv[p * F + f] = val;
         const float dlt = val - svu[p * F + f];
-        sq += dlt * dlt;
+        // crit 1 = nn.HuberLoss(delta = 1): d^2 / 2 inside the knee, |d| - 1/2 outside
+        sq += crit ? (fabsf(dlt) < 1.0f ? 0.5f * dlt * dlt : fabsf(dlt) - 0.5f) : dlt * dlt;
     });
     for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
     __syncthreads();
@@ -86,10 +91,9 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_forward_kernel(
 
 using namespace pfm;
 
-extern "C" int pfm_epic_fm_loss_forward(const pfm_epic_desc* d, const float* blob, int32_t kind, float sigma,
-                                        const float* t, const float* x, const float* z, const float* eps,
-                                        const float* cond, const float* mask, float* saved, float* loss_parts,
-                                        float* mask_count, int32_t B, void* stream) {
+static int loss_forward(const pfm_epic_desc* d, const float* blob, int kind, float sigma, const float* t, const float* x,
+                        const float* z, const float* eps, const float* cond, const float* mask, float* saved,
+                        float* loss_parts, float* mask_count, int crit, const float* rates, int B, void* stream) {
     int rc = validate(d);
     if (rc) return rc;
     const int lds = make_carve(d->n_points, d->features).total * 4;
@@ -98,20 +102,35 @@ extern "C" int pfm_epic_fm_loss_forward(const pfm_epic_desc* d, const float* blo
                    "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
     if (B <= 0) return 0;
-    if (kind < 0 || kind > 2) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT), 1 (CFM) or 2 (droid)");
     if (!blob || !t || !x || !z || !saved || !loss_parts || !mask_count)
         return set_err(PFM_E_BADARG, "NULL device pointer");
     if (kind == 1 && !eps) return set_err(PFM_E_BADARG, "CFM needs eps");
+    if (kind == 3 && !rates) return set_err(PFM_E_BADARG, "the diffusion loss needs the signal / noise rates");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
     hipLaunchKernelGGL(epic_fm_loss_forward_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, kind,
-                       sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count);
+                       sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, crit, rates);
     return check_hip(hipGetLastError(), "epic_fm_loss_forward_kernel launch");
 }
 
-extern "C" int pfm_epic_fm_loss_backward(const pfm_epic_desc* d, const float* blob, const float* t, const float* cond,
-                                         const float* mask, const float* saved, const float* inv_mask_total,
-                                         const float* grad_scale, float* grad_blob, int32_t B, void* stream) {
-    (void)t;  // the time embedding is part of `saved`
+extern "C" int pfm_epic_fm_loss_forward(const pfm_epic_desc* d, const float* blob, int32_t kind, float sigma,
+                                        const float* t, const float* x, const float* z, const float* eps,
+                                        const float* cond, const float* mask, float* saved, float* loss_parts,
+                                        float* mask_count, int32_t B, void* stream) {
+    if (kind < 0 || kind > 2) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT), 1 (CFM) or 2 (droid)");
+    return loss_forward(d, blob, kind, sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, 0, nullptr, B, stream);
+}
+
+extern "C" int pfm_epic_diffusion_loss_forward(const pfm_epic_desc* d, const float* blob, int32_t criterion, const float* rates,
+                                               const float* t, const float* x, const float* z, const float* cond,
+                                               const float* mask, float* saved, float* loss_parts, float* mask_count,
+                                               int32_t B, void* stream) {
+    if (criterion < 0 || criterion > 1) return set_err(PFM_E_BADARG, "criterion must be 0 (mse) or 1 (huber)");
+    return loss_forward(d, blob, 3, 0.f, t, x, z, nullptr, cond, mask, saved, loss_parts, mask_count, criterion, rates, B, stream);
+}
+
+static int loss_backward(const pfm_epic_desc* d, const float* blob, const float* cond, const float* mask, const float* saved,
+                         const float* inv_mask_total, const float* grad_scale, float* grad_blob, int crit, const float* jet_w,
+                         int B, void* stream) {
     int rc = validate(d);
     if (rc) return rc;
     const int64_t lds = (int64_t)make_bcarve(d->n_points, d->features).total * 4;
@@ -125,6 +144,21 @@ extern "C" int pfm_epic_fm_loss_backward(const pfm_epic_desc* d, const float* bl
     if (!blob || !saved || !inv_mask_total || !grad_scale || !grad_blob) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
     hipLaunchKernelGGL(epic_fm_loss_backward_kernel, dim3(B), dim3(NT), (int)lds, (hipStream_t)stream, blob,
-                       d->blob_floats, cond, mask, saved, inv_mask_total, grad_scale, grad_blob);
+                       d->blob_floats, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, crit, jet_w);
     return check_hip(hipGetLastError(), "epic_fm_loss_backward_kernel launch");
+}
+
+extern "C" int pfm_epic_fm_loss_backward(const pfm_epic_desc* d, const float* blob, const float* t, const float* cond,
+                                         const float* mask, const float* saved, const float* inv_mask_total,
+                                         const float* grad_scale, float* grad_blob, int32_t B, void* stream) {
+    (void)t;  // the time embedding is part of `saved`
+    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, 0, nullptr, B, stream);
+}
+
+extern "C" int pfm_epic_diffusion_loss_backward(const pfm_epic_desc* d, const float* blob, int32_t criterion, const float* jet_weight,
+                                                const float* cond, const float* mask, const float* saved,
+                                                const float* inv_mask_total, const float* grad_scale, float* grad_blob,
+                                                int32_t B, void* stream) {
+    if (criterion < 0 || criterion > 1) return set_err(PFM_E_BADARG, "criterion must be 0 (mse) or 1 (huber)");
+    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, criterion, jet_weight, B, stream);
 }

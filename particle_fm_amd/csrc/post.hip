@@ -40,3 +40,39 @@ extern "C" int pfm_sample_epilogue(float* x, const float* mask, const float* sca
                        shift, (int)log_pt_col, n, (int)features);
     return check_hip(hipGetLastError(), "sample_epilogue_kernel launch");
 }
+
+// ------------------------------------------------------------------------------------------------
+// One state update of the reference's diffusion samplers (particle_fm/models/components/solver.py), op for op:
+//   mode 0 = ddim_sampler :81-93   data = (x - nr * pred) / sr;  x <- nsr * data + nnr * pred     c = (nr, sr, nsr, nnr)
+//   mode 1 = euler_maruyama :126-132   s = -pred / nr;  x <- x + 0.5 * beta * (x + 2 s) * dt;  x <- x + sqrt(beta dt) * noise
+//                                                                                                c = (nr, beta, dt, sqrt(beta dt))
+// ------------------------------------------------------------------------------------------------
+namespace pfm {
+__global__ __launch_bounds__(256) void diffusion_update_kernel(int mode, float* __restrict__ x, const float* __restrict__ pred,
+                                                               const float* __restrict__ noise, float c0, float c1, float c2,
+                                                               float c3, float* __restrict__ data_out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float xv = x[i], p = pred[i];
+    if (mode == 0) {
+        const float data = __fdiv_rn(__fsub_rn(xv, __fmul_rn(c0, p)), c1);
+        if (data_out) data_out[i] = data;
+        x[i] = __fadd_rn(__fmul_rn(c2, data), __fmul_rn(c3, p));
+    } else {
+        const float s = __fdiv_rn(-p, c0);
+        const float drift = __fmul_rn(__fmul_rn(__fmul_rn(0.5f, c1), __fadd_rn(xv, __fmul_rn(2.0f, s))), c2);
+        x[i] = __fadd_rn(__fadd_rn(xv, drift), __fmul_rn(c3, noise[i]));
+    }
+}
+}  // namespace pfm
+
+extern "C" int pfm_diffusion_update(int32_t mode, float* x, const float* pred, const float* noise, float c0, float c1, float c2,
+                                    float c3, float* data_out, int64_t n, void* stream) {
+    using namespace pfm;
+    if (n <= 0) return 0;
+    if (mode < 0 || mode > 1) return set_err(PFM_E_BADARG, "mode must be 0 (ddim) or 1 (euler-maruyama)");
+    if (!x || !pred || (mode == 1 && !noise)) return set_err(PFM_E_BADARG, "NULL device pointer");
+    hipLaunchKernelGGL(diffusion_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)mode, x, pred,
+                       noise, c0, c1, c2, c3, data_out, n);
+    return check_hip(hipGetLastError(), "diffusion_update_kernel launch");
+}

@@ -88,3 +88,53 @@ def epic_fm_loss(layout: EpicLayout, src: torch.Tensor, x: torch.Tensor, t: torc
                  kind: str = "FM-OT", eps: Optional[torch.Tensor] = None) -> torch.Tensor:
     """loss = sum((v - u)^2) / sum(mask) with v = EPiC(t, y); differentiable w.r.t. ``src``."""
     return EpicFMLossFn.apply(src, layout, x, t, z, eps, cond, mask, float(sigma), kind)
+
+
+class EpicDiffusionLossFn(torch.autograd.Function):
+    """DiffusionLoss (losses.py:207-290) with the draws given: loss = sum_b w_b * sum_n,f criterion(v - z) / sum(mask),
+    w_b = 1 + mle_weight * beta(t_b) / noise_rate(t_b)."""
+
+    @staticmethod
+    def forward(ctx, src, layout, x, t, z, rates, jet_w, cond, mask, criterion):
+        blob = pack_blob_from_source(layout, src)
+        parts, count, saved = hip_ops.epic_diffusion_loss_forward(layout, blob, x, t, z, rates, cond, mask, criterion)
+        total = count.sum()
+        ctx.layout, ctx.mask, ctx.cond, ctx.criterion = layout, mask, cond, criterion
+        ctx.save_for_backward(blob, saved, total, jet_w)
+        ctx.n_source = src.numel()
+        return (parts * jet_w).sum() / total
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        layout = ctx.layout
+        blob, saved, total, jet_w = ctx.saved_tensors
+        dev = blob.device
+        lib = _lib.load()
+        B = saved.shape[0]
+        gblob = torch.zeros_like(blob)
+        inv_total = (1.0 / total).reshape(1).contiguous()
+        gscale = grad_loss.to(torch.float32).reshape(1).contiguous()
+        cond = None if (ctx.cond is None or layout.cfg.global_cond_dim == 0) else ctx.cond.to(torch.float32).contiguous()
+        maskf = None if ctx.mask is None else ctx.mask.reshape(B, -1).to(torch.float32).contiguous()
+        P = hip_ops._ptr
+        rc = lib.pfm_epic_diffusion_loss_backward(ctypes.byref(layout.desc), P(blob), {"mse": 0, "huber": 1}[ctx.criterion],
+                                                  P(jet_w.contiguous()), P(cond), P(maskf), P(saved), P(inv_total), P(gscale),
+                                                  P(gblob), B, hip_ops._stream_ptr(dev))
+        _lib.check(rc, "pfm_epic_diffusion_loss_backward")
+        _, gpos, _ = _Maps.get(layout, dev)
+        d_src = torch.zeros(ctx.n_source, device=dev, dtype=torch.float32)
+        d_src[: gpos.numel()] = gblob[gpos]
+        return (d_src,) + (None,) * 9
+
+
+MLE_LOSS_WEIGHT = 0.001  # losses.py:226
+
+
+def epic_diffusion_loss(layout: EpicLayout, src, x, t, z, cond=None, mask=None, criterion: str = "huber",
+                        diff_config=None) -> torch.Tensor:
+    """z must already be multiplied by the mask (losses.py:244).  diff_config: {"max_sr", "min_sr"} of VPDiffusionSchedule."""
+    dc = dict(diff_config or {"max_sr": 1, "min_sr": 1e-8})
+    sr, nr, beta = hip_ops.diffusion_schedule(t.to(torch.float32), **dc)
+    rates = torch.stack([sr, nr], dim=1).contiguous()
+    jet_w = (1.0 + MLE_LOSS_WEIGHT * (beta / nr)).contiguous()
+    return EpicDiffusionLossFn.apply(src, layout, x, t, z, rates, jet_w, cond, mask, criterion)

@@ -151,9 +151,10 @@ def rk_grid(ode_steps: int, solver: str, t0: float = 1.0, t1: float = 0.0):
 
 def epic_sample_rk(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor, cond: Optional[torch.Tensor] = None,
                    mask: Optional[torch.Tensor] = None, ode_steps: int = 100, solver: str = "rk4", t0: float = 1.0,
-                   t1: float = 0.0) -> torch.Tensor:
+                   t1: float = 0.0, diff_config=None) -> torch.Tensor:
     """x(t1) from x(t0) = z*mask with the fixed-step explicit Runge-Kutta scheme ``solver`` over linspace(t0, t1, ode_steps),
-    one persistent launch."""
+    one persistent launch.  ``diff_config`` (loss_type="diffusion"): integrate the probability-flow ODE
+    -0.5 beta (x - f / noise_rate) of a noise-predicting network instead (ode_wrapper.forward, flow_matching_module.py:62-69)."""
     lib = _lib.load()
     dev, B, blob, z, cond, mask = _prep_common(layout, blob, z, cond, mask)
     if ode_steps < 2:
@@ -163,8 +164,12 @@ def epic_sample_rk(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor, cond
     ts, dts = ts.to(dev), dts.to(dev)
     out = torch.empty_like(z)
     kbuf = torch.empty(tab.stages * z.numel(), device=dev, dtype=torch.float32)
+    rhs = None
+    if diff_config is not None:
+        _, nr, beta = diffusion_schedule(ts, **diff_config)
+        rhs = torch.stack([-0.5 * beta, nr], dim=1).contiguous()
     rc = lib.pfm_epic_sample_rk(ctypes.byref(layout.desc), _ptr(blob), ctypes.byref(tab), _ptr(ts), _ptr(dts), ode_steps - 1,
-                                _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, _ptr(kbuf), _stream_ptr(dev))
+                                _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, _ptr(kbuf), _ptr(rhs), _stream_ptr(dev))
     _lib.check(rc, "pfm_epic_sample_rk")
     return out
 
@@ -215,3 +220,45 @@ def epic_fm_loss_forward(layout: EpicLayout, blob: torch.Tensor, x: torch.Tensor
                                       _ptr(count), B, _stream_ptr(dev))
     _lib.check(rc, "pfm_epic_fm_loss_forward")
     return parts, count, saved
+
+
+# ---- loss_type="diffusion" (models/components/diffusion.py, losses.py:207-290, solver.py) ------------------------------
+def diffusion_schedule(t: torch.Tensor, max_sr: float = 1.0, min_sr: float = 1e-2):
+    """(signal_rate, noise_rate, beta) of the cosine VP schedule at the diffusion times ``t`` (diffusion.py:21-62); O(len(t))
+    scalars computed where ``t`` lives, in the reference's fp32 op order."""
+    import math
+    start, end = math.acos(max_sr), math.acos(min_sr)
+    ang = start + t * (end - start)
+    return torch.cos(ang), torch.sin(ang), 2 * (end - start) * torch.tan(ang)
+
+
+def epic_diffusion_loss_forward(layout: EpicLayout, blob, x, t, z, rates, cond=None, mask=None, criterion: str = "huber"):
+    """DiffusionLoss forward with the draws given: rates (B,2) = (signal, noise) rate per jet, z already masked.
+    Returns (loss_parts (B,) = sum criterion(v - z) per jet, mask_count (B,), saved)."""
+    lib = _lib.load()
+    dev, B, blob, x, cond, mask = _prep_common(layout, blob, x, cond, mask)
+    t = _dev_f32("t", t, dev, (B,))
+    z = _dev_f32("z", z, dev, tuple(x.shape))
+    rates = _dev_f32("rates", rates, dev, (B, 2))
+    crit = {"mse": 0, "huber": 1}[criterion]
+    per_jet = lib.pfm_epic_saved_floats_per_jet(ctypes.byref(layout.desc))
+    saved = torch.empty(B, per_jet, device=dev, dtype=torch.float32)
+    parts = torch.empty(B, device=dev, dtype=torch.float32)
+    count = torch.empty(B, device=dev, dtype=torch.float32)
+    rc = lib.pfm_epic_diffusion_loss_forward(ctypes.byref(layout.desc), _ptr(blob), crit, _ptr(rates), _ptr(t), _ptr(x), _ptr(z),
+                                             _ptr(cond), _ptr(mask), _ptr(saved), _ptr(parts), _ptr(count), B, _stream_ptr(dev))
+    _lib.check(rc, "pfm_epic_diffusion_loss_forward")
+    return parts, count, saved
+
+
+def diffusion_update_(mode: str, x: torch.Tensor, pred: torch.Tensor, coefs, noise: Optional[torch.Tensor] = None,
+                      data_out: Optional[torch.Tensor] = None) -> None:
+    """One step of the reference's diffusion samplers, in place on ``x`` (solver.py:81-93, 126-132).
+    "ddim": data = (x - c0 pred) / c1; x <- c2 data + c3 pred  (c = noise rate, signal rate, next signal rate, next noise rate)
+    "em":   x <- x + 0.5 c1 (x + 2 (-pred / c0)) c2;  x <- x + c3 noise  (c = noise rate, beta, delta_t, sqrt(beta delta_t))"""
+    lib = _lib.load()
+    dev = x.device
+    c = [float(v) for v in coefs]
+    rc = lib.pfm_diffusion_update({"ddim": 0, "em": 1}[mode], _ptr(x), _ptr(pred), _ptr(noise), c[0], c[1], c[2], c[3],
+                                  _ptr(data_out), ctypes.c_int64(x.numel()), _stream_ptr(dev))
+    _lib.check(rc, "pfm_diffusion_update")

@@ -86,3 +86,31 @@ class DroidLoss(nn.Module):
             raise TypeError("DroidLoss needs a mask (losses.py:339 multiplies by it)")
         t, z = self.draw(x)
         return _single_flow(self.flows).fm_loss(x, t, z, mask=mask, cond=cond, sigma=self.sigma, kind="droid")
+
+
+class DiffusionLoss(nn.Module):
+    """losses.py:207-290 (PC-JeDi style noise prediction): noisy = signal_rate(t) x + noise_rate(t) z with z = randn * mask,
+    loss = sum criterion(z, net(t, noisy)) * mask * (1 + 0.001 beta(t) / noise_rate(t)) / sum(mask)."""
+
+    def __init__(self, flows: nn.ModuleList, sigma: float = 1e-4, criterion: str = "huber",
+                 diff_config={"max_sr": 1, "min_sr": 1e-8}):
+        super().__init__()
+        self.flows = flows
+        self.sigma = sigma
+        self.mle_loss_weight = 0.001
+        self.diff_config = dict(diff_config)
+        if criterion not in ("mse", "huber"):
+            raise NotImplementedError(f"criterion {criterion} not supported")
+        self.criterion = criterion
+
+    def draw(self, x: torch.Tensor, mask: torch.Tensor):
+        t = torch.rand_like(torch.ones(x.shape[0])).type_as(x)  # :241-243
+        z = torch.randn_like(x) * mask                           # :247
+        return t, z
+
+    def forward(self, x: torch.Tensor, mask: torch.Tensor = None, cond: torch.Tensor = None) -> torch.Tensor:
+        if mask is None:
+            raise TypeError("DiffusionLoss needs a mask (losses.py:247 multiplies the noise by it)")
+        t, z = self.draw(x, mask)
+        return _single_flow(self.flows).diffusion_loss(x, t, z, mask=mask, cond=cond, criterion=self.criterion,
+                                                       diff_config=self.diff_config)

@@ -24,7 +24,7 @@ from .. import fm_loss_wide as _fm_loss_wide
 from .. import hip_ops, hip_ops_ca, hip_ops_tf, hip_ops_wide
 from .components.droid_transformer import FullCrossAttentionEncoder, FullTransformerEncoder
 from .components.epic import EPiC_encoder
-from .components.losses import ConditionalFlowMatchingLoss, DroidLoss, FlowMatchingLoss
+from .components.losses import ConditionalFlowMatchingLoss, DiffusionLoss, DroidLoss, FlowMatchingLoss
 from .components.time_emb import CosineEncoding
 
 try:  # Lightning is optional: present in the reference's environment, absent in the build container
@@ -84,14 +84,17 @@ class ode_wrapper(torch.nn.Module):
     def __init__(self, model: nn.Module, mask: torch.Tensor = None, cond: torch.Tensor = None,
                  loss_type: str = "FM-OT", diff_config: Mapping = {"max_sr": 0.999, "min_sr": 0.02}):
         super().__init__()
-        if loss_type == "diffusion":
-            raise NotImplementedError("loss_type='diffusion' has no HIP path")
         self.model = model
         self.mask = mask
         self.cond = cond
         self.loss_type = loss_type
+        self.diff_config = dict(diff_config)
 
     def forward(self, t, x, *args, **kwargs):
+        if self.loss_type == "diffusion":
+            # :62-69.  The probability-flow right-hand side -0.5 beta (x - net / noise_rate) is applied inside the sampler
+            # kernel (CNF.decode -> pfm_epic_sample_rk with `rhs`); there is no per-call PyTorch version of it here.
+            raise NotImplementedError("ode_wrapper(loss_type='diffusion') is evaluated inside CNF.decode on the HIP path")
         return self.model(t, x, mask=self.mask, cond=self.cond)
 
 
@@ -196,6 +199,8 @@ class CNF(nn.Module):
                ode_steps: int = 100, weights: Tensor = None) -> Tensor:
         """flow_matching_module.py:245-328.  "midpoint" = t_span linspace(1, 0, ode_steps), ode_steps-1
         explicit-midpoint intervals (torchdyn), here one persistent kernel launch."""
+        if self.loss_type == "diffusion":
+            return self._decode_diffusion(z, cond, mask, ode_solver, ode_steps, weights)
         if ode_solver == "midpoint":
             # mask is applied to the ODE right-hand side by the network itself; z arrives already masked
             # `weights` (extension): an already packed kernel blob, e.g. a snapshot taken on another stream
@@ -219,6 +224,47 @@ class CNF(nn.Module):
         if ode_solver in ("dopri5_zuko", "dopri5", "tsit5", "ieuler", "alf"):
             raise NotImplementedError(f"Solver {ode_solver} has no HIP path in this build (fixed-step 'midpoint', 'euler', 'rk4' do).")
         raise NotImplementedError(f"Solver {ode_solver} not implemented")  # :328
+
+    def _decode_diffusion(self, z, cond, mask, ode_solver, ode_steps, weights):
+        """loss_type="diffusion" (:62-69, 301-325): the fixed-step ODE solvers integrate -0.5 beta (x - net / noise_rate);
+        "ddim" / "em" are the samplers of models/components/solver.py (n_steps = ode_steps)."""
+        if self.is_transformer or self.is_cross_attention or self.net.wide:
+            raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' at hidden_dim 128 "
+                                      "(configs/model/diffusion.yaml) only")
+        lay = self.net.layout(z.shape[1])
+        blob = weights if weights is not None else self.net.packed_weights(z.shape[1])
+        dc = dict(self.diff_config)
+        if ode_solver in ("midpoint", "euler", "rk4"):
+            return hip_ops.epic_sample_rk(lay, blob, z, cond, mask, ode_steps=ode_steps, solver=ode_solver, diff_config=dc)
+        if ode_solver not in ("ddim", "em"):
+            raise NotImplementedError(f"Solver {ode_solver} has no HIP path in this build for loss_type='diffusion' "
+                                      "(midpoint, euler, rk4, ddim, em do).")
+        # solver.py:55-96 / 113-141: times 1, 1 - 1/n, ...; the schedule values are host scalars (known before any launch)
+        n = int(ode_steps)
+        times = [torch.ones(1)]
+        for _ in range(n):
+            times.append(times[-1] - 1 / n)
+        sr, nr, beta = hip_ops.diffusion_schedule(torch.cat(times), **dc)
+        x = z.to(torch.float32).clone()
+        data = torch.empty_like(x)
+        for k in range(n):
+            pred = hip_ops.epic_forward(lay, blob, times[k].expand(x.shape[0]).to(x.device), x, cond, mask)
+            if ode_solver == "ddim":
+                hip_ops.diffusion_update_("ddim", x, pred, (nr[k], sr[k], sr[k + 1], nr[k + 1]), data_out=data)
+            else:
+                delta = 1 / n
+                hip_ops.diffusion_update_("em", x, pred, (nr[k], beta[k], delta, (beta[k] * delta).sqrt()),
+                                          noise=torch.randn_like(x))  # solver.py:131
+        return data if ode_solver == "ddim" else x
+
+    def diffusion_loss(self, x, t, z, mask=None, cond=None, criterion: str = "huber", diff_config=None) -> Tensor:
+        """DiffusionLoss body (losses.py:250-288) with the draws given; z is already multiplied by the mask."""
+        if self.is_transformer or self.is_cross_attention or self.net.wide:
+            raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' at hidden_dim 128 "
+                                      "(configs/model/diffusion.yaml) only")
+        lay = self.net.layout(x.shape[1])
+        return _fm_loss.epic_diffusion_loss(lay, self.net.source_vector(lay), x, t, z, cond=cond, mask=mask,
+                                            criterion=criterion, diff_config=diff_config)
 
     def _sample_rk(self, blob, z, cond, mask, ode_steps, solver, t0, t1):
         lay = self.net.layout(z.shape[1])
@@ -275,8 +321,10 @@ class SetFlowMatchingLitModule(_LitBase):
             self.loss = ConditionalFlowMatchingLoss(flows=self.flows, sigma=sigma, criterion=criterion)
         elif loss_type == "droid":
             self.loss = DroidLoss(flows=self.flows, sigma=sigma, criterion=criterion)
-        elif loss_type in ("CFM-OT", "diffusion"):
-            raise NotImplementedError(f"Loss type {loss_type} has no HIP path in this build (FM-OT, CFM and droid do).")
+        elif loss_type == "diffusion":  # flow_matching_module.py:452-458
+            self.loss = DiffusionLoss(flows=self.flows, sigma=sigma, criterion=criterion, diff_config=diff_config)
+        elif loss_type == "CFM-OT":
+            raise NotImplementedError(f"Loss type {loss_type} has no HIP path in this build (FM-OT, CFM, droid and diffusion do).")
         else:
             raise NotImplementedError(f"Loss type {loss_type} not implemented.")  # :465
         if use_normaliser:

@@ -1,0 +1,89 @@
+"""loss_type="diffusion" (configs/model/diffusion.yaml) on the jet-resident EPiC path: DiffusionLoss forward + every parameter
+gradient, the probability-flow ODE samplers, DDIM and Euler-Maruyama, against the reference's recorded vectors."""
+import copy
+
+import pytest
+import torch
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("crit", ["huber", "mse"])
+def test_loss_and_all_parameter_gradients(crit):
+    from particle_fm_amd.fm_loss import epic_diffusion_loss
+    from particle_fm_amd.layout import EpicLayout
+    from tests.test_layout_cpu import cfg_of
+    g = load_golden("diffusion")
+    lay = EpicLayout(cfg_of(g.hp))
+    state = {k: v.clone().cuda().requires_grad_(k != "flows.0.frequencies") for k, v in g.state.items()}
+    src = lay.source_vector(state, "flows.0.net.", freqs=g.freqs.cuda())
+    tag = f"loss_{crit}/"
+    x, t, z, mask, cond = (g.get(tag + k).cuda() for k in ("x", "t", "z", "mask", "cond"))
+    loss = epic_diffusion_loss(lay, src, x, t, z, cond=cond, mask=mask, criterion=crit, diff_config=g.hp["diff_config"])
+    torch.testing.assert_close(loss.detach().cpu(), g.get(tag + "loss"), rtol=2e-5, atol=1e-6)
+    loss.backward()
+    ref = g.grads(tag)
+    for k, want in ref.items():
+        got = state[k].grad.cpu()
+        assert float((got - want).norm()) <= 5e-4 * float(want.norm()) + 1e-6, k
+
+
+def test_samplers_match_reference_vectors():
+    from particle_fm_amd import hip_ops
+    from particle_fm_amd.layout import EpicLayout
+    from tests.test_layout_cpu import cfg_of
+    g = load_golden("diffusion")
+    lay = EpicLayout(cfg_of(g.hp))
+    blob = lay.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    dc = g.hp["diff_config"]
+    for steps in (3, 10):
+        tag = f"midpoint_{steps}/"
+        z, mask, cond = (g.get(tag + k).cuda() for k in ("z", "mask", "cond"))
+        xe = hip_ops.epic_sample_rk(lay, blob, z, cond, mask, ode_steps=steps, solver="midpoint", diff_config=dc).cpu()
+        torch.testing.assert_close(xe, g.get(tag + "x_end"), rtol=1e-3, atol=2e-4)
+
+
+def test_module_surface_ddim_em_and_training_step():
+    from oracle import diffusion_ref as dr
+    from oracle.fm_ref import EpicVectorField
+    from particle_fm_amd.layout import EpicLayout
+    from tests.test_layout_cpu import cfg_of
+    g = load_golden("diffusion")
+    from particle_fm_amd.models import SetFlowMatchingLitModule
+    m = SetFlowMatchingLitModule(optimizer=None, criterion="huber", **copy.deepcopy(g.hp))
+    full = dict(g.state)
+    full.update({"loss." + k: v for k, v in g.state.items()})
+    m.load_state_dict(full)
+    m = m.cuda()
+    freqs = EpicLayout(cfg_of(g.hp)).default_freqs()  # the product's table; the oracle gets the same one
+    vf = EpicVectorField(g.state, "flows.0.net", g.hp, freqs=freqs)
+    dc, n = g.hp["diff_config"], int(g.z["n_steps"])
+    z, mask, cond = (g.get("ddim/" + k) for k in ("z", "mask", "cond"))
+    zc = (z * mask).cuda()
+    out = m(zc, cond=cond.cuda(), mask=mask.cuda(), reverse=True, ode_solver="ddim", ode_steps=n).cpu()
+    torch.testing.assert_close(out, dr.ddim_sample(vf, z * mask, cond, mask, n, dc), rtol=1e-3, atol=2e-4)
+    # Euler-Maruyama: same device generator state -> same per-step draws as the module made
+    torch.manual_seed(31)
+    out = m(zc, cond=cond.cuda(), mask=mask.cuda(), reverse=True, ode_solver="em", ode_steps=n).cpu()
+    torch.manual_seed(31)
+    noises = [torch.randn_like(zc).cpu() for _ in range(n)]
+    torch.testing.assert_close(out, dr.em_sample(vf, z * mask, cond, mask, n, dc, noises), rtol=1e-3, atol=2e-4)
+    # probability-flow ODE with the tuned names
+    out = m(zc, cond=cond.cuda(), mask=mask.cuda(), reverse=True, ode_solver="midpoint", ode_steps=8).cpu()
+    from oracle.fm_ref import midpoint_trajectory_end
+    with torch.no_grad():
+        ref = midpoint_trajectory_end(lambda tt, xx: dr.diffusion_rhs(vf, tt, xx, cond, mask, dc), z * mask, torch.linspace(1.0, 0.0, 8))
+    torch.testing.assert_close(out, ref, rtol=1e-3, atol=2e-4)
+    # training_step: the reference's draws replayed (t from the CPU generator, z on x's device)
+    x = g.get("loss_huber/x").cuda()
+    torch.manual_seed(77)
+    loss = m.training_step((x, mask.cuda(), cond.cuda()), 0)["loss"]
+    torch.manual_seed(77)
+    t = torch.rand_like(torch.ones(x.shape[0]))
+    zz = (torch.randn_like(x) * mask.cuda()).cpu()
+    ref_loss, *_ = dr.diffusion_loss(vf, x.cpu(), mask, cond, t, zz, "huber", dc)
+    torch.testing.assert_close(loss.detach().cpu(), ref_loss, rtol=2e-5, atol=1e-6)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.flows[0].net.parameters())

@@ -1,0 +1,53 @@
+"""oracle/diffusion_ref.py against vectors recorded from the reference's DiffusionLoss, ode_wrapper (diffusion branch),
+ddim_sampler and euler_maruyama_sampler (tests/golden/epic_diffusion.npz)."""
+import pytest
+import torch
+
+from oracle import diffusion_ref as dr
+from oracle.fm_ref import EpicVectorField, midpoint_trajectory_end
+from tests.conftest import load_golden
+
+
+def _vf(g, state=None):
+    return EpicVectorField(state or g.state, "flows.0.net", g.hp, freqs=g.freqs)
+
+
+@pytest.mark.parametrize("crit", ["huber", "mse"])
+def test_loss_and_gradients(crit):
+    g = load_golden("diffusion")
+    state = {k: v.clone().requires_grad_(True) for k, v in g.state.items() if k != "flows.0.frequencies"}
+    tag = f"loss_{crit}/"
+    x, t, z, mask, cond = (g.get(tag + k) for k in ("x", "t", "z", "mask", "cond"))
+    loss, noisy, pred = dr.diffusion_loss(_vf(g, state), x, mask, cond, t, z, crit, g.hp["diff_config"])
+    if crit == "huber":
+        assert float(((z - pred).abs() * mask > 1).float().mean()) > 0.01  # both branches of the huber criterion are exercised
+    torch.testing.assert_close(loss.detach(), g.get(tag + "loss"), rtol=1e-5, atol=1e-6)
+    loss.backward()
+    ref = g.grads(tag)
+    assert len(ref) == len(state)
+    for k, want in ref.items():
+        assert float((state[k].grad - want).norm()) <= 2e-4 * float(want.norm()) + 1e-7, k
+
+
+def test_ode_rhs_and_midpoint():
+    g = load_golden("diffusion")
+    vf, dc = _vf(g), g.hp["diff_config"]
+    t, x, mask, cond = (g.get("rhs/" + k) for k in ("t", "x", "mask", "cond"))
+    with torch.no_grad():
+        f = dr.diffusion_rhs(vf, t, x, cond, mask, dc)
+    torch.testing.assert_close(f, g.get("rhs/f"), rtol=1e-5, atol=1e-5)
+    for steps in (3, 10):
+        tag = f"midpoint_{steps}/"
+        z, mask, cond = (g.get(tag + k) for k in ("z", "mask", "cond"))
+        with torch.no_grad():
+            xe = midpoint_trajectory_end(lambda tt, xx: dr.diffusion_rhs(vf, tt, xx, cond, mask, dc), z * mask, torch.linspace(1.0, 0.0, steps))
+        torch.testing.assert_close(xe, g.get(tag + "x_end"), rtol=1e-4, atol=5e-5)
+
+
+def test_ddim_and_euler_maruyama():
+    g = load_golden("diffusion")
+    vf, dc, n = _vf(g), g.hp["diff_config"], int(g.z["n_steps"])
+    z, mask, cond = (g.get("ddim/" + k) for k in ("z", "mask", "cond"))
+    torch.testing.assert_close(dr.ddim_sample(vf, z * mask, cond, mask, n, dc), g.get("ddim/x_end"), rtol=1e-4, atol=5e-5)
+    z, mask, cond, noise = (g.get("em/" + k) for k in ("z", "mask", "cond", "noise"))
+    torch.testing.assert_close(dr.em_sample(vf, z * mask, cond, mask, n, dc, noise), g.get("em/x_end"), rtol=1e-4, atol=5e-5)
