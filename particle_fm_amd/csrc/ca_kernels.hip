@@ -94,31 +94,9 @@ int linear(const Plan& p, int rows, int per_jet, const float* A, int lda, int K,
     a.jb_stride = (int64_t)(2 * p.d->layers + 2) * p.d->hidden;
     a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.M = rows; a.K = K; a.NO = NO; a.N = per_jet; a.act = act;
     a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
-    const int chunks = NO / BN;
-    const int64_t slots = 2 * (int64_t)num_cus();
-    const int64_t w64 = (int64_t)((rows + 63) / 64) * chunks, w32 = (int64_t)((rows + 31) / 32) * chunks;
-    const bool half = ((w32 + slots - 1) / slots) < 2 * ((w64 + slots - 1) / slots);
-    const int rb = half ? 32 : 64;
-    a.row_tiles = (rows + rb - 1) / rb;
-    const int grid = ((a.row_tiles + 7) / 8) * 8 * chunks;
-    const bool x3 = (p.d->flags & PFM_CA_F_F16X3) != 0;
-    const size_t lds = x3 ? (size_t)rb * X3ROW * 2 * 2 * 2 + 2 * rb * sizeof(float) : (rb * 128 + 2 * rb) * sizeof(float);
     const int ni = (ln && ln->gamma >= 0) ? K / 64 : 0;
-#define PFM_LAUNCH_LIN(NI)                                                                                        \
-    if (x3) {                                                                                                     \
-        if (half) hipLaunchKernelGGL((tf_linear_kernel<NI, 2, true>), dim3(grid), dim3(LT), lds, p.s, a);         \
-        else hipLaunchKernelGGL((tf_linear_kernel<NI, 4, true>), dim3(grid), dim3(LT), lds, p.s, a);              \
-    } else if (half) hipLaunchKernelGGL((tf_linear_kernel<NI, 2>), dim3(grid), dim3(LT), lds, p.s, a);            \
-    else hipLaunchKernelGGL((tf_linear_kernel<NI, 4>), dim3(grid), dim3(LT), lds, p.s, a);
-    switch (ni) {
-        case 0: PFM_LAUNCH_LIN(0) break;
-        case 2: PFM_LAUNCH_LIN(2) break;
-        case 4: PFM_LAUNCH_LIN(4) break;
-        case 6: PFM_LAUNCH_LIN(6) break;
-        case 8: PFM_LAUNCH_LIN(8) break;
-        default: return set_err(PFM_E_BADARG, "LayerNorm width must be 128, 256, 384 or 512");
-    }
-#undef PFM_LAUNCH_LIN
+    if (launch_linear_kernel(a, ni, (p.d->flags & PFM_CA_F_F16X3) != 0, num_cus(), p.s))
+        return set_err(PFM_E_BADARG, "LayerNorm width must be 128, 256, 384 or 512");
     return check_hip(hipGetLastError(), "tf_linear_kernel launch (ca)");
 }
 

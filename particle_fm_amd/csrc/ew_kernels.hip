@@ -274,7 +274,6 @@ int linear(const Plan& p, int Mrows, const float* A, int lda, int K1, const floa
     a.rowjet = (jb && p.rowjet) ? p.rowjet : nullptr; a.m_dev = (jb && p.m_dev) ? p.m_dev : nullptr;  // particle-row GEMMs are the ones with a jet bias
     a.blob_floats = p.d->blob_floats; a.W = lin.W; a.b = lin.b; a.gamma = -1; a.beta = -1; a.jb_stride = jb_stride;
     a.ldr = ldr; a.ldo = ldo; a.M = Mrows; a.K = K; a.NO = NO; a.N = jbN; a.act = act;
-    a.row_tiles = (Mrows + BM - 1) / BM;
     a.slope = p.d->neg_slope; a.eps = 0.f;
     // per-jet GEMMs (a few hundred rows) are latency chains over K: split K over workgroups, reduce in a second launch
     a.part = nullptr; a.ksplit = 1;
@@ -284,12 +283,7 @@ int linear(const Plan& p, int Mrows, const float* A, int lda, int K1, const floa
         while (nstep % ks) --ks;
         if (ks > 1 && (int64_t)ks * Mrows * NO <= p.part_floats) { a.part = p.part; a.ksplit = ks; }
     }
-    const int grid = ((a.row_tiles + 7) / 8) * 8 * ((NO + BN - 1) / BN) * a.ksplit;
-    if (p.d->flags & PFM_EW_F_F16X3)
-        hipLaunchKernelGGL((tf_linear_kernel<0, 4, true>), dim3(grid), dim3(LT), (size_t)BM * X3ROW * 2 * 2 * 2 + 2 * BM * sizeof(float),
-                           p.s, a);
-    else
-        hipLaunchKernelGGL(tf_linear_kernel<0>, dim3(grid), dim3(LT), (BM * 128 + 2 * BM) * sizeof(float), p.s, a);
+    launch_linear_kernel(a, 0, (p.d->flags & PFM_EW_F_F16X3) != 0, num_cus(), p.s);
     int rc = check_hip(hipGetLastError(), "tf_linear_kernel launch (epicw)");
     if (rc || a.ksplit == 1) return rc;
     const int64_t n4 = (int64_t)Mrows * (NO / 4);

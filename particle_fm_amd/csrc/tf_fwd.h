@@ -19,6 +19,8 @@
 //   tf_head_kernel    outp_embd output block (F <= 16 outputs): LayerNorm + F dot products per row, 16 lanes per
 //                     row, fused with the midpoint state update when sampling.
 #pragma once
+#include <stdlib.h>
+
 #include "tf_common.h"
 
 namespace pfm {
@@ -452,6 +454,64 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
             }
         }
     }
+}
+
+// Row tile of a Linear launch: 32, 64 or 128 rows per workgroup, whichever gives the shortest schedule on this GPU's
+// 2 x CU workgroup slots.  Work per round ~ rows x cost-per-row of the tile: a 128-row tile reads every weight block
+// from L2 once per 128 rows instead of once per 64 (the L2 -> register weight stream is what limits the 64-row kernel),
+// a 32-row tile fills the tail of launches that are only a little over a whole number of rounds.
+inline int pick_row_tile(int64_t M, int chunks, int cus, bool allow128) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("PFM_TF_ROWTILE");  // diagnostics only (tests/diag): 32, 64 or 128
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 32 || forced == 64 || (forced == 128 && allow128)) return forced;
+    const int64_t slots = 2 * (int64_t)cus;
+    auto rounds = [&](int rb) { return ((M + rb - 1) / rb * chunks + slots - 1) / slots; };
+    static double f128 = 0.0;
+    if (f128 == 0.0) {
+        const char* e = getenv("PFM_TF_F128");
+        f128 = e ? atof(e) : 0.85;
+    }
+    const double t32 = 32.0 * rounds(32), t64 = 64.0 * rounds(64), t128 = 128.0 * f128 * rounds(128);
+    int rb = t32 < t64 ? 32 : 64;
+    if (allow128 && t128 < (rb == 32 ? t32 : t64)) rb = 128;
+    return rb;
+}
+
+// launches tf_linear_kernel for `a` (everything but row_tiles filled in); ni = K / 64 of the LayerNorm prologue or 0
+inline int launch_linear_kernel(LinArgs& a, int ni, bool x3, int cus, hipStream_t s) {
+    const int chunks = (a.NO + BN - 1) / BN;
+    const int rb = pick_row_tile(a.M, chunks * a.ksplit, cus, !x3);
+    a.row_tiles = (a.M + rb - 1) / rb;
+    const int grid = ((a.row_tiles + 7) / 8) * 8 * chunks * a.ksplit;
+    const size_t lds = x3 ? (size_t)rb * X3ROW * 2 * 2 * 2 + 2 * rb * sizeof(float) : (size_t)(rb * 128 + 2 * rb) * sizeof(float);
+#define PFM_LAUNCH_LIN(NI)                                                                                  \
+    if (x3) {                                                                                               \
+        if (rb == 32) hipLaunchKernelGGL((tf_linear_kernel<NI, 2, true>), dim3(grid), dim3(LT), lds, s, a); \
+        else hipLaunchKernelGGL((tf_linear_kernel<NI, 4, true>), dim3(grid), dim3(LT), lds, s, a);          \
+    } else if (rb == 32) hipLaunchKernelGGL((tf_linear_kernel<NI, 2>), dim3(grid), dim3(LT), lds, s, a);    \
+    else if (rb == 64) hipLaunchKernelGGL((tf_linear_kernel<NI, 4>), dim3(grid), dim3(LT), lds, s, a);      \
+    else {                                                                                                  \
+        static bool big = false; /* 65 KB of dynamic LDS: opt in once per instantiation */                  \
+        if (!big) {                                                                                         \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(tf_linear_kernel<NI, 8>),                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 * 128 + 256) * 4));  \
+            big = true;                                                                                     \
+        }                                                                                                   \
+        hipLaunchKernelGGL((tf_linear_kernel<NI, 8>), dim3(grid), dim3(LT), lds, s, a);                     \
+    }
+    switch (ni) {
+        case 0: PFM_LAUNCH_LIN(0) break;
+        case 2: PFM_LAUNCH_LIN(2) break;
+        case 4: PFM_LAUNCH_LIN(4) break;
+        case 6: PFM_LAUNCH_LIN(6) break;
+        case 8: PFM_LAUNCH_LIN(8) break;
+        default: return -1;
+    }
+#undef PFM_LAUNCH_LIN
+    return 0;
 }
 
 // split-K epilogue: out = epi( sum_ks part[ks] + b ) with the same activation / residual modes as the Linear kernel

@@ -50,33 +50,9 @@ int launch_linear(const Plan& p, const float* A, int lda, int K, const pfm_tf_li
     a.jb_stride = (int64_t)(p.d->layers + 2) * p.d->hidden;
     a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.M = p.M; a.K = K; a.NO = NO; a.N = p.d->n_points; a.act = act ? 1 : 0;
     a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
-    // Row tile: 64 rows, or 32 when that shortens the schedule on this GPU's 2 x CU workgroup slots (a launch of
-    // 1120 64-row workgroups needs 3 rounds of 512 for 2.2 rounds of work; 2240 half-size ones need 2.5 round-times)
-    const int chunks = NO / BN;
-    const int64_t slots = 2 * (int64_t)num_cus();
-    const int64_t w64 = (int64_t)((p.M + 63) / 64) * chunks, w32 = (int64_t)((p.M + 31) / 32) * chunks;
-    const bool half = ((w32 + slots - 1) / slots) < 2 * ((w64 + slots - 1) / slots);
-    const int rb = half ? 32 : 64;
-    a.row_tiles = (p.M + rb - 1) / rb;
-    const int grid = ((a.row_tiles + 7) / 8) * 8 * chunks;
-    const bool x3 = (p.d->flags & PFM_TF_F_F16X3) != 0;
-    const size_t lds = x3 ? (size_t)rb * X3ROW * 2 * 2 * 2 + 2 * rb * sizeof(float) : (rb * 128 + 2 * rb) * sizeof(float);
     const int ni = (ln && ln->gamma >= 0) ? K / 64 : 0;
-#define PFM_LAUNCH_LIN(NI)                                                                                        \
-    if (x3) {                                                                                                     \
-        if (half) hipLaunchKernelGGL((tf_linear_kernel<NI, 2, true>), dim3(grid), dim3(LT), lds, p.s, a);         \
-        else hipLaunchKernelGGL((tf_linear_kernel<NI, 4, true>), dim3(grid), dim3(LT), lds, p.s, a);              \
-    } else if (half) hipLaunchKernelGGL((tf_linear_kernel<NI, 2>), dim3(grid), dim3(LT), lds, p.s, a);            \
-    else hipLaunchKernelGGL((tf_linear_kernel<NI, 4>), dim3(grid), dim3(LT), lds, p.s, a);
-    switch (ni) {
-        case 0: PFM_LAUNCH_LIN(0) break;
-        case 2: PFM_LAUNCH_LIN(2) break;
-        case 4: PFM_LAUNCH_LIN(4) break;
-        case 6: PFM_LAUNCH_LIN(6) break;
-        case 8: PFM_LAUNCH_LIN(8) break;
-        default: return set_err(PFM_E_BADARG, "LayerNorm width must be 128, 256, 384 or 512");
-    }
-#undef PFM_LAUNCH_LIN
+    if (launch_linear_kernel(a, ni, (p.d->flags & PFM_TF_F_F16X3) != 0, num_cus(), p.s))
+        return set_err(PFM_E_BADARG, "LayerNorm width must be 128, 256, 384 or 512");
     return check_hip(hipGetLastError(), "tf_linear_kernel launch");
 }
 

@@ -211,26 +211,42 @@ class FusedFMTrainer:
         lib = _lib.load()
         P, S = hip_ops._ptr, hip_ops._stream_ptr(self.fp.flat.device)
         loss_mod = self.module.loss
-        kind = {"ConditionalFlowMatchingLoss": "CFM", "DroidLoss": "droid"}.get(type(loss_mod).__name__, "FM-OT")
-        if kind == "CFM":
-            if mask is None:
-                raise TypeError("ConditionalFlowMatchingLoss needs a mask (losses.py:119)")
-            t, z, eps = loss_mod.draw(x)
-        else:
-            (t, z), eps = loss_mod.draw(x), None
+        kind = {"ConditionalFlowMatchingLoss": "CFM", "DroidLoss": "droid", "DiffusionLoss": "diffusion"}.get(
+            type(loss_mod).__name__, "FM-OT")
+        if kind in ("CFM", "diffusion") and mask is None:
+            raise TypeError(f"{type(loss_mod).__name__} needs a mask (losses.py:119, 247)")
         st = self._fused_state(x.shape[1])
         lay, tb, gblob = st["layout"], st["tables"], st["gblob"]
         blob = self._pack(st)
-        parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x, t, z, cond, mask, loss_mod.sigma, kind, eps)
-        total = count.sum()
-        loss = parts.sum() / total
-        inv_total = (1.0 / total).reshape(1)
-        gblob.zero_()
         B = x.shape[0]
         condf = None if lay.cfg.global_cond_dim == 0 else cond.to(torch.float32).contiguous()
         maskf = None if mask is None else mask.reshape(B, -1).to(torch.float32).contiguous()
-        _lib.check(lib.pfm_epic_fm_loss_backward(ctypes.byref(lay.desc), P(blob), P(None), P(condf), P(maskf), P(saved),
-                                                 P(inv_total), P(st["one"]), P(gblob), B, S), "pfm_epic_fm_loss_backward")
+        if kind == "diffusion":
+            from .fm_loss import MLE_LOSS_WEIGHT
+            t, z = loss_mod.draw(x, mask)
+            sr, nr, beta = hip_ops.diffusion_schedule(t.to(torch.float32), **loss_mod.diff_config)
+            jet_w = (1.0 + MLE_LOSS_WEIGHT * (beta / nr)).contiguous()
+            parts, count, saved = hip_ops.epic_diffusion_loss_forward(lay, blob, x, t, z, torch.stack([sr, nr], dim=1), cond, mask,
+                                                                      loss_mod.criterion)
+            total = count.sum()
+            loss = (parts * jet_w).sum() / total
+            inv_total = (1.0 / total).reshape(1)
+            gblob.zero_()
+            _lib.check(lib.pfm_epic_diffusion_loss_backward(ctypes.byref(lay.desc), P(blob), {"mse": 0, "huber": 1}[loss_mod.criterion],
+                                                            P(jet_w), P(condf), P(maskf), P(saved), P(inv_total), P(st["one"]),
+                                                            P(gblob), B, S), "pfm_epic_diffusion_loss_backward")
+        else:
+            if kind == "CFM":
+                t, z, eps = loss_mod.draw(x)
+            else:
+                (t, z), eps = loss_mod.draw(x), None
+            parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x, t, z, cond, mask, loss_mod.sigma, kind, eps)
+            total = count.sum()
+            loss = parts.sum() / total
+            inv_total = (1.0 / total).reshape(1)
+            gblob.zero_()
+            _lib.check(lib.pfm_epic_fm_loss_backward(ctypes.byref(lay.desc), P(blob), P(None), P(condf), P(maskf), P(saved),
+                                                     P(inv_total), P(st["one"]), P(gblob), B, S), "pfm_epic_fm_loss_backward")
         _lib.check(lib.pfm_wn_unpack_grad(P(self.fp.flat), P(gblob), P(tb.rows), tb.n_rows, P(tb.gsrc), P(tb.bias_gblob),
                                           P(tb.bias_param), tb.n_bias, P(self.fp.grad), S), "pfm_wn_unpack_grad")
         return loss

@@ -87,3 +87,23 @@ def test_module_surface_ddim_em_and_training_step():
     torch.testing.assert_close(loss.detach().cpu(), ref_loss, rtol=2e-5, atol=1e-6)
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.flows[0].net.parameters())
+
+
+def test_fused_trainer_step_equals_autograd_path():
+    """FusedFMTrainer's graph-free diffusion step (pack, loss, backward, weight-norm unpack) against the autograd path."""
+    from particle_fm_amd.engine import FusedFMTrainer
+    from particle_fm_amd.models import SetFlowMatchingLitModule
+    g = load_golden("diffusion")
+    x, mask, cond = (g.get("loss_huber/" + k).cuda() for k in ("x", "mask", "cond"))
+    grads = []
+    for fused in (True, False):
+        m = SetFlowMatchingLitModule(optimizer=None, criterion="huber", **copy.deepcopy(g.hp))
+        full = dict(g.state)
+        full.update({"loss." + k: v for k, v in g.state.items()})
+        m.load_state_dict(full)
+        tr = FusedFMTrainer(m.cuda(), lr=1e-3, weight_decay=0.0, max_grad_norm=None, ema_decay=None)
+        torch.manual_seed(5)
+        loss = tr.step((x, mask, cond), fused=fused)
+        grads.append((loss.cpu(), tr.fp.grad.clone().cpu()))
+    torch.testing.assert_close(grads[0][0], grads[1][0], rtol=1e-6, atol=1e-7)
+    assert float((grads[0][1] - grads[1][1]).norm()) <= 1e-4 * float(grads[1][1].norm())
