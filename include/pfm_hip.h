@@ -21,6 +21,7 @@
  *   pfm_epic_fm_loss_backward   models/components/losses.py:38-77, 101-136 and their autograd
  *   pfm_epic_diffusion_loss_*   DiffusionLoss.forward and its autograd   models/components/losses.py:207-290
  *   pfm_diffusion_update        the state update of ddim_sampler / euler_maruyama_sampler   models/components/solver.py:81-93, 126-132
+ *   pfm_norm_update / _apply    IterativeNormLayer.update / fit / forward / reverse   models/components/norm_layer.py:98-152
  *   pfm_sample_epilogue         the per-batch post-processing of generate_data   utils/data_generation.py:94-123
  *   pfm_optim_step              clip_grad_norm_(gradient_clip_val) + AdamW + EMA
  *                               configs/experiment/jetnet/fm_tops150.yaml:24, configs/model/flow_matching.yaml:3-7,
@@ -209,6 +210,16 @@ int pfm_epic_diffusion_loss_backward(const pfm_epic_desc *desc, const float *blo
  * mode 1 = euler_maruyama_sampler :126-132 (c = noise rate, beta, delta_t, sqrt(beta delta_t); noise = the step's normal draw). */
 int pfm_diffusion_update(int32_t mode, float *x, const float *pred, const float *noise, float c0, float c1, float c2, float c3,
                          float *data_out, int64_t n, void *stream);
+
+/* IterativeNormLayer (models/components/norm_layer.py:17-155; SetFlowMatchingLitModule with use_normaliser=True,
+ * flow_matching_module.py:467-473, 514-518, 666-677) on rows x[rows][features] (features <= 16), row mask fp32 {0,1} or NULL.
+ * pfm_norm_update: one running-statistics step with the valid rows (fit() on the first batch, the batched Welford update()
+ * afterwards, nothing once *n >= max_n); n (int64), means / vars / m2 [features] are the module's buffers, on the device.
+ * pfm_norm_apply: out = (x - means) / (sqrt(vars) + 1e-8) on the valid rows (reverse != 0: x sqrt(vars) + means), others copied. */
+int pfm_norm_update(const float *x, const float *mask, int64_t rows, int32_t features, int64_t *n, float *means, float *vars,
+                    float *m2, int64_t max_n, void *stream);
+int pfm_norm_apply(float *out, const float *x, const float *mask, int64_t rows, int32_t features, const float *means,
+                   const float *vars, int32_t reverse, void *stream);
 
 /* Optimiser tail on flat fp32 buffers of n elements:
  *   gnorm = ||grad * grad_mul||_2 ; c = min(1, max_norm/(gnorm+1e-6)) (clip_grad_norm_) ; g = grad*grad_mul*c

@@ -43,6 +43,8 @@ SYMBOLS = {
         c_int, [POINTER(EpicDesc), _fp, c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
     "pfm_epic_diffusion_loss_backward": (
         c_int, [POINTER(EpicDesc), _fp, c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
+    "pfm_norm_update": (c_int, [_fp, _fp, c_int64, c_int32, _fp, _fp, _fp, _fp, c_int64, c_void_p]),
+    "pfm_norm_apply": (c_int, [_fp, _fp, _fp, c_int64, c_int32, _fp, _fp, c_int32, c_void_p]),
     "pfm_diffusion_update": (c_int, [c_int32, _fp, _fp, _fp, c_float, c_float, c_float, c_float, _fp, c_int64, c_void_p]),
     "pfm_tf_sample_rk": (
         c_int, [POINTER(TfDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),

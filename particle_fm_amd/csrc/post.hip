@@ -76,3 +76,112 @@ extern "C" int pfm_diffusion_update(int32_t mode, float* x, const float* pred, c
                        noise, c0, c1, c2, c3, data_out, n);
     return check_hip(hipGetLastError(), "diffusion_update_kernel launch");
 }
+
+// ------------------------------------------------------------------------------------------------
+// IterativeNormLayer (particle_fm/models/components/norm_layer.py:84-155): running per-feature standardisation of the
+// valid particles.  One workgroup: the batch is a few 1e5 numbers and the update is two dependent reductions.
+//   first batch (n == 0), fit():  vars, means = var_mean (unbiased);  n = len;  m2 = vars * n              :98-104
+//   later batches, update():      n += len;  delta = x - means;  means += sum(delta) / n;  delta2 = x - means;
+//                                 m2 += sum(delta * delta2);  vars = m2 / n                                 :137-152
+// Nothing happens once n >= max_n (frozen, :154).
+// ------------------------------------------------------------------------------------------------
+namespace pfm {
+__global__ __launch_bounds__(1024) void norm_update_kernel(const float* __restrict__ x, const float* __restrict__ mask, int64_t M,
+                                                           int F, int64_t* __restrict__ n, float* __restrict__ means,
+                                                           float* __restrict__ vars, float* __restrict__ m2, int64_t max_n) {
+    __shared__ float red[64][17];
+    __shared__ float mean_new[16];
+    __shared__ float len_s;
+    const int tid = threadIdx.x, f = tid & 15, g = tid >> 4;
+    const int64_t n_old = *n;
+    if (n_old >= max_n) return;  // frozen
+    const bool first = n_old == 0;
+    const float m_old = (f < F && !first) ? means[f] : 0.f;
+    float s = 0.f, cnt = 0.f;
+    for (int64_t r = g; r < M; r += 64) {
+        if (mask && mask[r] == 0.f) continue;
+        cnt += 1.f;
+        if (f < F) s += x[r * F + f] - m_old;
+    }
+    red[g][f] = s;
+    if (f == 0) red[g][16] = cnt;
+    __syncthreads();
+    if (tid < 17) {
+        float t = 0.f;
+        for (int i = 0; i < 64; ++i) t += red[i][tid];
+        if (tid == 16) len_s = t;
+        else mean_new[tid] = t;  // sum of (x - m_old) for now
+    }
+    __syncthreads();
+    const float len = len_s;
+    if (len == 0.f) return;
+    const float n_new = (float)n_old + len;
+    const float mean = m_old + mean_new[f] / n_new;  // first batch: m_old = 0, n_new = len
+    __syncthreads();
+    const float ref = first ? mean : m_old;  // first batch: sum (x - mean)^2; later: sum (x - old mean) (x - new mean)
+    float q = 0.f;
+    for (int64_t r = g; r < M; r += 64) {
+        if (mask && mask[r] == 0.f) continue;
+        if (f < F) {
+            const float xv = x[r * F + f];
+            q += (xv - ref) * (xv - mean);
+        }
+    }
+    red[g][f] = q;
+    __syncthreads();
+    if (tid < F) {
+        float t = 0.f;
+        for (int i = 0; i < 64; ++i) t += red[i][tid];
+        means[tid] = mean;  // tid == f here
+        if (first) {
+            const float v = t / (len - 1.f);
+            vars[tid] = v;
+            m2[tid] = v * len;
+        } else {
+            const float mm = m2[tid] + t;
+            m2[tid] = mm;
+            vars[tid] = mm / n_new;
+        }
+    }
+    if (tid == 0) *n = n_old + (int64_t)len;
+}
+
+// forward (:116-126): (x - means) / (sqrt(vars) + 1e-8) on the valid rows, the rest untouched;  reverse (:128-139): x sqrt(vars) + means
+__global__ __launch_bounds__(256) void norm_apply_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ mask,
+                                                         int64_t n, int F, const float* __restrict__ means, const float* __restrict__ vars,
+                                                         int reverse) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t row = i / F;
+    const int f = (int)(i - row * F);
+    float v = x[i];
+    if (!mask || mask[row] != 0.f) {
+        const float sd = sqrtf(vars[f]);
+        v = reverse ? __fadd_rn(__fmul_rn(v, sd), means[f]) : __fdiv_rn(__fsub_rn(v, means[f]), __fadd_rn(sd, 1e-8f));
+    }
+    out[i] = v;
+}
+}  // namespace pfm
+
+extern "C" int pfm_norm_update(const float* x, const float* mask, int64_t rows, int32_t features, int64_t* n, float* means, float* vars,
+                               float* m2, int64_t max_n, void* stream) {
+    using namespace pfm;
+    if (rows <= 0) return 0;
+    if (!x || !n || !means || !vars || !m2) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (features < 1 || features > 16) return set_err(PFM_E_BADARG, "features must be in 1..16");
+    hipLaunchKernelGGL(norm_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, mask, rows, (int)features, n, means, vars, m2,
+                       max_n);
+    return check_hip(hipGetLastError(), "norm_update_kernel launch");
+}
+
+extern "C" int pfm_norm_apply(float* out, const float* x, const float* mask, int64_t rows, int32_t features, const float* means,
+                              const float* vars, int32_t reverse, void* stream) {
+    using namespace pfm;
+    if (rows <= 0) return 0;
+    if (!out || !x || !means || !vars) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (features < 1 || features > 16) return set_err(PFM_E_BADARG, "features must be in 1..16");
+    const int64_t n = rows * features;
+    hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, x, mask, n,
+                       (int)features, means, vars, (int)reverse);
+    return check_hip(hipGetLastError(), "norm_apply_kernel launch");
+}
