@@ -619,10 +619,41 @@ def gen_diffusion(ref, out_dir, B=4, seed=2468):
     print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
 
 
+# ----------------------------------------------------------------------------------------------
+# IterativeNormLayer (norm_layer.py): three training batches, then eval-mode forward / reverse
+# ----------------------------------------------------------------------------------------------
+def gen_norm_layer(ref, out_dir, seed=97531):
+    gen = torch.Generator().manual_seed(seed)
+    B, N, Fe = 8, 12, 3
+    layer = ref.norm_layer.IterativeNormLayer((Fe,), max_n=150)
+    layer.train()
+    out = {"max_n": np.array(150)}
+    for k in range(4):
+        mask = make_mask(B, N, "f32", gen).squeeze(-1) == 1
+        x = (torch.randn(B, N, Fe, generator=gen) * torch.tensor([1.0, 2.5, 0.3]) + torch.tensor([0.5, -1.0, 3.0])) * mask.unsqueeze(-1)
+        y = layer(x, mask)
+        tag = f"step{k}/"
+        out[tag + "x"], out[tag + "mask"], out[tag + "y"] = x.numpy(), mask.numpy(), y.numpy()
+        for b in ("means", "vars", "n", "m2"):
+            out[tag + b] = getattr(layer, b).detach().clone().numpy()
+        out[tag + "frozen"] = np.array(bool(layer.frozen))
+    layer.eval()
+    out["rev/y"] = layer.reverse(y, mask).numpy()  # of the last batch
+    c = torch.randn(B, 2, generator=gen) * 3 + 1
+    cl = ref.norm_layer.IterativeNormLayer((2,), max_n=250)
+    cl.train()
+    out["cond/x"], out["cond/y"] = c.numpy(), cl(c).numpy()
+    for b in ("means", "vars", "n", "m2"):
+        out["cond/" + b] = getattr(cl, b).detach().clone().numpy()
+    path = os.path.join(out_dir, "norm_layer.npz")
+    np.savez(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path)/1e3:.1f} kB, {len(out)} arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,diffusion}; default all")
+    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,diffusion,norm}; default all")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
@@ -635,6 +666,8 @@ def main():
         gen_no_sets(ref, args.out)
     if ap2 is None or "diffusion" in ap2:
         gen_diffusion(ref, args.out)
+    if ap2 is None or "norm" in ap2:
+        gen_norm_layer(ref, args.out)
     for name, (hp, B) in WIDE_CONFIGS.items():
         if ap2 is None or "wide" in ap2:
             gen_epic_wide(ref, name, hp, B, args.out)

@@ -258,6 +258,8 @@ class FusedFMTrainer:
             if self._fused is not None:
                 self._fused = {}
         self.fp.grad.zero_()
+        if getattr(getattr(self.module, "hparams", None), "use_normaliser", False):  # training_step's pre-processing (:514-518)
+            x, cond = self.module._normalise(x, mask, cond)
         if fused and self._fused is not None:
             loss = self.fused_loss_and_grad(x, mask, cond)
         else:

@@ -7,7 +7,7 @@ pipeline (Lightning Trainer, EMA callback, evaluation callbacks -> ``sample``) k
 of the hot path -- EPiC, Full-Transformer or cross-attention vector field, FM / CFM / droid loss forward+backward,
 fixed-step midpoint sampling -- runs in libpfm_hip.so.  What the native path does not cover raises NotImplementedError at construction or call time
 (never a silent PyTorch fallback): model "mdma", losses other than FM-OT / CFM / droid, solvers other than "midpoint",
-t_emb="gaussian", use_normaliser=True.
+t_emb="gaussian".
 """
 from __future__ import annotations
 
@@ -24,6 +24,7 @@ from .. import fm_loss_wide as _fm_loss_wide
 from .. import hip_ops, hip_ops_ca, hip_ops_tf, hip_ops_wide
 from .components.droid_transformer import FullCrossAttentionEncoder, FullTransformerEncoder
 from .components.epic import EPiC_encoder
+from .components.norm_layer import IterativeNormLayer
 from .components.losses import ConditionalFlowMatchingLoss, DiffusionLoss, DroidLoss, FlowMatchingLoss
 from .components.time_emb import CosineEncoding
 
@@ -327,9 +328,10 @@ class SetFlowMatchingLitModule(_LitBase):
             raise NotImplementedError(f"Loss type {loss_type} has no HIP path in this build (FM-OT, CFM, droid and diffusion do).")
         else:
             raise NotImplementedError(f"Loss type {loss_type} not implemented.")  # :465
-        if use_normaliser:
-            raise NotImplementedError("use_normaliser=True (IterativeNormLayer) is not implemented; every model yaml "
-                                      "of the reference sets use_normaliser: False")
+        if use_normaliser:  # flow_matching_module.py:467-473
+            self.normaliser = IterativeNormLayer((features,), **normaliser_config)
+            if self.conditioned:
+                self.ctxt_normaliser = IterativeNormLayer((global_cond_dim,), **normaliser_config)
 
     # -- sampling ------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, cond: torch.Tensor = None, mask: torch.Tensor = None, reverse: bool = False,
@@ -355,10 +357,17 @@ class SetFlowMatchingLitModule(_LitBase):
                         self.hparams.features).to(self.device)
         if cond is not None:
             cond = cond.to(self.device)
+            if self.hparams.use_normaliser:
+                cond = self.ctxt_normaliser(cond)  # :666-667
         if mask is not None:
             mask = mask[:n_samples].to(self.device)
             z = z * mask
-        return self.forward(z, cond=cond, mask=mask, reverse=True, ode_solver=ode_solver, ode_steps=ode_steps)
+        samples = self.forward(z, cond=cond, mask=mask, reverse=True, ode_solver=ode_solver, ode_steps=ode_steps)
+        if self.hparams.use_normaliser:
+            # :675-676 passes the (B,N,1) float mask straight into boolean indexing, which torch rejects; the intent
+            # (un-normalise the valid particles) is what runs here
+            samples = self.normaliser.reverse(samples, None if mask is None else mask.reshape(samples.shape[:-1]) != 0)
+        return samples
 
     # -- training ------------------------------------------------------------------------------------
     def _variable_jet_sizes(self) -> bool:
@@ -367,8 +376,17 @@ class SetFlowMatchingLitModule(_LitBase):
             return True
         return bool(dm.hparams.variable_jet_sizes)
 
+    def _normalise(self, x, mask, cond):
+        if self.hparams.use_normaliser:
+            bool_mask = (mask.detach() == 1).reshape(x.shape[:-1])
+            x = self.normaliser(x, bool_mask)
+            if self.conditioned:
+                cond = self.ctxt_normaliser(cond)
+        return x, cond
+
     def training_step(self, batch, batch_idx):
         x, mask, cond = batch
+        x, cond = self._normalise(x, mask, cond)  # :514-518
         if not self._variable_jet_sizes():  # flow_matching_module.py:519-520
             mask = None
         loss = self.loss(x, mask=mask, cond=cond)
@@ -383,6 +401,7 @@ class SetFlowMatchingLitModule(_LitBase):
 
     def validation_step(self, batch: Any, batch_idx: int):
         x, mask, cond = batch
+        x, cond = self._normalise(x, mask, cond)  # :564-568
         if not self._variable_jet_sizes():
             mask = None
         with torch.no_grad():

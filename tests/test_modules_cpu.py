@@ -58,7 +58,8 @@ def test_lit_module_surface():
     (dict(loss_type="nope"), NotImplementedError),              # :465
     (dict(t_emb="nope"), NotImplementedError),                  # :231
     (dict(criterion="l1"), NotImplementedError),                # losses.py:36
-    (dict(use_normaliser=True), NotImplementedError),
+    (dict(use_normaliser=True, normaliser_config={"extra_dims": (0,)}), NotImplementedError),
+    (dict(loss_type="CFM-OT"), NotImplementedError),
     (dict(model="mdma"), NotImplementedError),
     (dict(model="droid_fulltransformer", net_config={"te_config": {"model_dim": 64, "mha_config": {"num_heads": 4}}}),
      NotImplementedError),
@@ -174,3 +175,21 @@ def test_flat_params_alias_and_survive_load_state_dict():
     assert torch.equal(fp.flat[: p0.numel()].view_as(p0), p0.data)
     fp.grad.fill_(2.0)
     assert float(p0.grad.sum()) == 2.0 * p0.numel()
+
+
+def test_normaliser_buffers_and_errors():
+    """use_normaliser=True: IterativeNormLayer buffers appear under the reference's names; unsupported shapes / CPU inputs raise."""
+    from particle_fm_amd.models.components.norm_layer import IterativeNormLayer
+    m = SetFlowMatchingLitModule(optimizer=None, features=3, hidden_dim=128, num_particles=30, frequencies=16, layers=1, latent=10,
+                                 t_local_cat=True, t_global_cat=True, add_time_to_input=False, t_emb="cosine", global_cond_dim=2,
+                                 use_normaliser=True, normaliser_config={"max_n": 2000})
+    keys = list(m.state_dict().keys())
+    assert keys[-8:] == ["normaliser.means", "normaliser.vars", "normaliser.n", "normaliser.m2",
+                         "ctxt_normaliser.means", "ctxt_normaliser.vars", "ctxt_normaliser.n", "ctxt_normaliser.m2"]
+    assert m.normaliser.means.shape == (1, 3) and m.normaliser.n.dtype == torch.int64 and m.normaliser.max_n == 2000
+    with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
+        m.normaliser(torch.randn(2, 30, 3), torch.ones(2, 30, dtype=torch.bool))
+    with pytest.raises(NotImplementedError):
+        IterativeNormLayer((30, 3), extra_dims=(0,))
+    with pytest.raises(ValueError):
+        IterativeNormLayer((3,), means=torch.zeros(1, 3))
