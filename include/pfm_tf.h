@@ -47,6 +47,12 @@ extern "C" {
 
 #define PFM_TF_ABI_VERSION 1
 #define PFM_TF_MAX_LAYERS 12
+#define PFM_TF_F_VALID_ROWS 4 /* inference entry points (forward, samplers) with a mask: evaluate the VALID particles only --
+                                 rows are compacted to the valid particles in (jet, particle) order, attention runs over each
+                                 jet's own keys, padded rows of the state are left as they are (z * mask) and padded rows of a raw
+                                 field are 0.  Valid rows see the same arithmetic as without the flag (padded keys never
+                                 contribute); the reference's (unmasked, meaningless) values at padded rows are not produced.
+                                 The loss entry points ignore the flag: the reference's loss includes the padded rows. */
 #define PFM_TF_F_TEMB_SINCOS 2 /* t_emb="sincos": temb = [cos(f t) ; sin(f t)], freqs table = [f ; f] (flow_matching_module.py:208-211) */
 #define PFM_TF_F_F16X3 1 /* desc.flags: every Linear (forward and dX) as three fp16 MFMAs on (hi, lo) splits of both operands,
                             fp32 accumulate: fp32-grade products (see PFM_F_F16X3_MFMA in pfm_hip.h); needs |x| < 65504 */

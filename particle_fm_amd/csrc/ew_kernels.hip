@@ -70,54 +70,6 @@ __global__ __launch_bounds__(256) void ew_pool_kernel(const float* __restrict__ 
     }
 }
 
-// ---- row compaction (inference): rows = valid particles only, in (jet, particle) order -----------------------
-__global__ __launch_bounds__(256) void ew_count_kernel(const float* __restrict__ mask, int* __restrict__ cnt, int N) {
-    __shared__ int red[4];
-    const int jet = blockIdx.x;
-    int c = 0;
-    for (int r = threadIdx.x; r < N; r += 256) c += mask[(int64_t)jet * N + r] != 0.f;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) cnt[jet] = red[0] + red[1] + red[2] + red[3];
-}
-// off[0..B] = exclusive scan of cnt; m_valid = off[B]   (one workgroup; B is a batch size)
-__global__ __launch_bounds__(1024) void ew_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ m_valid, int B) {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
-    const int per = (B + 1023) / 1024;
-    int s = 0;
-    for (int i = 0; i < per; ++i) { const int j = tid * per + i; if (j < B) s += cnt[j]; }
-    part[tid] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int run = tid ? part[tid - 1] : 0;
-    for (int i = 0; i < per; ++i) { const int j = tid * per + i; if (j < B) { off[j] = run; run += cnt[j]; } }
-    if (tid == 1023) { off[B] = part[1023]; *m_valid = part[1023]; }
-}
-// rowsrc / rowjet of every valid particle (wave 0 of the jet's workgroup walks the mask in order)
-__global__ __launch_bounds__(64) void ew_rowmap_kernel(const float* __restrict__ mask, const int* __restrict__ off,
-                                                       int* __restrict__ rowsrc, int* __restrict__ rowjet, int N) {
-    const int jet = blockIdx.x, lane = threadIdx.x;
-    int base = off[jet];
-    for (int r0 = 0; r0 < N; r0 += 64) {
-        const int r = r0 + lane;
-        const bool ok = r < N && mask[(int64_t)jet * N + r] != 0.f;
-        const unsigned long long bal = __ballot(ok);
-        if (ok) {
-            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            rowsrc[pos] = jet * N + r;
-            rowjet[pos] = jet;
-        }
-        base += __popcll(bal);
-    }
-}
 // compact pooling: the jet's rows are [off[jet], off[jet+1]), all valid
 __global__ __launch_bounds__(256) void ew_pool_compact_kernel(const float* __restrict__ X, const int* __restrict__ off,
                                                               float* __restrict__ Q, int Hp, float scale) {
@@ -584,13 +536,8 @@ int make_plan(Plan& p, const pfm_ew_desc* d, const float* blob, float* ws, int n
 // Inference with a mask: evaluate only the valid particles (they are the only rows that can influence an output the
 // reference does not multiply by zero).  Row maps are built once per call; the mask is constant over an ODE solve.
 int setup_compaction(Plan& p, const float* mask) {
-    int* im = reinterpret_cast<int*>(p.ws + p.w.imaps);
-    const int B = p.n_jets, N = p.d->n_points;
-    int *cnt = im, *off = im + B, *mv = im + 2 * B + 1, *rowsrc = im + 2 * B + 64, *rowjet = rowsrc + p.M;
-    hipLaunchKernelGGL(ew_count_kernel, dim3(B), dim3(256), 0, p.s, mask, cnt, N);
-    hipLaunchKernelGGL(ew_scan_kernel, dim3(1), dim3(1024), 0, p.s, (const int*)cnt, off, mv, B);
-    hipLaunchKernelGGL(ew_rowmap_kernel, dim3(B), dim3(64), 0, p.s, mask, (const int*)off, rowsrc, rowjet, N);
-    p.rowsrc = rowsrc; p.rowjet = rowjet; p.off = off; p.m_dev = mv;
+    const RowMaps m = build_row_maps(reinterpret_cast<int*>(p.ws + p.w.imaps), mask, p.n_jets, p.d->n_points, p.s);
+    p.rowsrc = m.rowsrc; p.rowjet = m.rowjet; p.off = m.off; p.m_dev = m.m_dev;
     return check_hip(hipGetLastError(), "row compaction launch");
 }
 

@@ -22,6 +22,7 @@ struct Ws {
     int64_t layer0, lstride;       // per layer: qkv | att | xmid | dh | xout
     int64_t o_qkv, o_att, o_xmid, o_dh, o_xout;
     int64_t oh;                    // rows x hidden: outp_embd hidden
+    int64_t imaps;                 // int32 row maps of the valid-rows-only evaluation (tf_fwd.h: row_maps_ints)
     int64_t total;
 };
 
@@ -64,6 +65,7 @@ __host__ inline Ws make_ws(const pfm_tf_desc& d, int n_jets, bool train) {
         o += w.o_dh + round64(M * Hd);
     }
     w.oh = o; o += round64(M * Hd);
+    w.imaps = o; o += round64(2 * (int64_t)n_jets + 64 + 2 * M);
     w.total = o;
     return w;
 }

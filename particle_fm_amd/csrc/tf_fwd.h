@@ -180,6 +180,80 @@ static __global__ __launch_bounds__(256) void tf_embed_kernel(const float* __res
     }
 }
 
+// ---- row compaction (inference): rows = valid particles only, in (jet, particle) order -----------------------
+static __global__ __launch_bounds__(256) void rows_count_kernel(const float* __restrict__ mask, int* __restrict__ cnt, int N) {
+    __shared__ int red[4];
+    const int jet = blockIdx.x;
+    int c = 0;
+    for (int r = threadIdx.x; r < N; r += 256) c += mask[(int64_t)jet * N + r] != 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[jet] = red[0] + red[1] + red[2] + red[3];
+}
+// off[0..B] = exclusive scan of cnt; m_valid = off[B]   (one workgroup; B is a batch size)
+static __global__ __launch_bounds__(1024) void rows_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ m_valid, int B) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    int s = 0;
+    for (int i = 0; i < per; ++i) { const int j = tid * per + i; if (j < B) s += cnt[j]; }
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (int i = 0; i < per; ++i) { const int j = tid * per + i; if (j < B) { off[j] = run; run += cnt[j]; } }
+    if (tid == 1023) { off[B] = part[1023]; *m_valid = part[1023]; }
+}
+// rowsrc / rowjet of every valid particle (wave 0 of the jet's workgroup walks the mask in order)
+static __global__ __launch_bounds__(64) void rows_map_kernel(const float* __restrict__ mask, const int* __restrict__ off,
+                                                       int* __restrict__ rowsrc, int* __restrict__ rowjet, int N) {
+    const int jet = blockIdx.x, lane = threadIdx.x;
+    int base = off[jet];
+    for (int r0 = 0; r0 < N; r0 += 64) {
+        const int r = r0 + lane;
+        const bool ok = r < N && mask[(int64_t)jet * N + r] != 0.f;
+        const unsigned long long bal = __ballot(ok);
+        if (ok) {
+            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            rowsrc[pos] = jet * N + r;
+            rowjet[pos] = jet;
+        }
+        base += __popcll(bal);
+    }
+}
+// int32 scratch for the maps of n_jets x N rows: cnt[B] | off[B+1] | m_valid (padded to 64) | rowsrc[M] | rowjet[M]
+__host__ __device__ inline int64_t row_maps_ints(int64_t n_jets, int64_t M) { return 2 * n_jets + 64 + 2 * M; }
+struct RowMaps {
+    int *cnt, *off, *m_dev, *rowsrc, *rowjet;
+};
+inline RowMaps build_row_maps(int* im, const float* mask, int B, int N, hipStream_t s) {
+    RowMaps m;
+    m.cnt = im; m.off = im + B; m.m_dev = im + 2 * B + 1; m.rowsrc = im + 2 * B + 64; m.rowjet = m.rowsrc + (int64_t)B * N;
+    hipLaunchKernelGGL(rows_count_kernel, dim3(B), dim3(256), 0, s, mask, m.cnt, N);
+    hipLaunchKernelGGL(rows_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)m.cnt, m.off, m.m_dev, B);
+    hipLaunchKernelGGL(rows_map_kernel, dim3(B), dim3(64), 0, s, mask, (const int*)m.off, m.rowsrc, m.rowjet, N);
+    return m;
+}
+
+// raw field of a compacted evaluation: the rows it never touches are 0 (NaN for a jet without any valid particle when
+// `nan_empty`: EPiC's 0 / 0 mean poisons the whole jet, epic.py:331-339)
+static __global__ __launch_bounds__(256) void rows_fill_masked_kernel(const float* __restrict__ mask, const int* __restrict__ cnt,
+                                                               const float* __restrict__ base, float* __restrict__ dst, int64_t M,
+                                                               int N, int F, int nan_empty) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * F) return;
+    const int64_t row = i / F;
+    if (mask[row] != 0.f) return;
+    dst[i] = (nan_empty && cnt[row / N] == 0) ? __builtin_nanf("") : (base ? base[i] : 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Linear
 // ------------------------------------------------------------------------------------------------
@@ -565,17 +639,26 @@ __host__ __device__ inline int attn_lds_floats(int N) {
 
 template <int MAXKT>
 __global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
-                                                         float* __restrict__ out, int N, int D, int heads) {
+                                                         float* __restrict__ out, int N, int D, int heads,
+                                                         const int* __restrict__ off = nullptr) {
     static_assert(MAXKT % 2 == 0, "key tiles are processed in pairs");
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int jet = blockIdx.x / heads, h = blockIdx.x - jet * heads;
+    // compacted rows (off != nullptr): the jet owns rows [off[jet], off[jet + 1]), all valid, and N becomes its multiplicity
+    int64_t row_base = (int64_t)jet * N;
+    if (off) {
+        row_base = off[jet];
+        N = off[jet + 1] - off[jet];
+        mask = nullptr;
+        if (N == 0) return;
+    }
     const int np = attn_np32(N), nkt = np >> 4, npv = np + 4, nqt = attn_np16(N) >> 4;
     float* const Ks = lds;              // [np][KROW]
     float* const Vt = Ks + np * KROW;   // [HD][npv]
     float* const mb = Vt + HD * npv;    // [np]: 0 for a valid key, -inf for a padded one
-    const int jet = blockIdx.x / heads, h = blockIdx.x - jet * heads;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
     const int ld = 3 * D;
-    const float* base = qkv + (int64_t)jet * N * ld + h * HD;
+    const float* base = qkv + row_base * ld + h * HD;
 
     for (int idx = tid; idx < np * 4; idx += 256) {
         const int key = idx >> 2, part = idx & 3;
@@ -591,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict
         Vt[(4 * part + 3) * npv + key] = vv.w;
     }
     for (int key = tid; key < np; key += 256) {
-        const bool ok = key < N && (mask == nullptr || mask[(int64_t)jet * N + key] != 0.f);
+        const bool ok = key < N && (mask == nullptr || mask[row_base + key] != 0.f);
         mb[key] = ok ? 0.f : -__builtin_inff();
     }
     __syncthreads();
@@ -650,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict
         }
         const int orow = qt * 16 + pl;
         if (orow < N)
-            *reinterpret_cast<f32x4*>(out + ((int64_t)jet * N + orow) * D + h * HD + 4 * q) = o0 + o1;
+            *reinterpret_cast<f32x4*>(out + (row_base + orow) * D + h * HD + 4 * q) = o0 + o1;
     }
 }
 
@@ -664,6 +747,8 @@ struct HeadArgs {
     const float* dt;    // device scalar (with base)
     float* dst;
     float* v_out;  // optional raw field
+    const int* rowsrc;  // compacted rows: row -> row of base / dst / v_out (nullptr: identity)
+    const int* m_dev;   // device-side row count overriding M, or nullptr
     int64_t gamma, beta, W, b;
     int M, Hd, F;
     float eps, coef;
@@ -674,6 +759,8 @@ __global__ __launch_bounds__(256) void tf_head_kernel(HeadArgs a) {
     constexpr int Hd = 64 * NI;
     const int tid = threadIdx.x, pl = tid & 15;
     const int row = blockIdx.x * 16 + (tid >> 4);
+    if (a.m_dev) a.M = *a.m_dev;
+    if (blockIdx.x * 16 >= a.M) return;
     const int rowc = min(row, a.M - 1);
     const float* ap = a.A + (int64_t)rowc * Hd + 4 * pl;
     f32x4 v[NI];
@@ -707,7 +794,7 @@ __global__ __launch_bounds__(256) void tf_head_kernel(HeadArgs a) {
         }
         d = row_sum16(d) + a.blob[a.b + f];
         if (pl == (f & 15) && row < a.M) {
-            const int64_t e = (int64_t)row * a.F + f;
+            const int64_t e = (int64_t)(a.rowsrc ? a.rowsrc[row] : row) * a.F + f;
             if (a.v_out) a.v_out[e] = d;
             if (a.base) a.dst[e] = __fadd_rn(a.base[e], __fmul_rn(__fmul_rn(a.coef, a.dt[0]), d));
             else if (a.dst) a.dst[e] = d;

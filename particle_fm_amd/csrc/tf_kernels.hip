@@ -39,12 +39,14 @@ struct Plan {
     Ws w;
     int n_jets, M;
     hipStream_t s;
+    // valid-rows-only evaluation (PFM_TF_F_VALID_ROWS, inference): rows are the valid particles in (jet, particle) order
+    const int *rowsrc = nullptr, *rowjet = nullptr, *off = nullptr, *m_dev = nullptr, *cnt = nullptr;
 };
 
 int launch_linear(const Plan& p, const float* A, int lda, int K, const pfm_tf_lin& lin, const pfm_tf_norm* ln, int NO,
                   const float* jb, const float* R, int ldr, float* out, int ldo, bool act) {
     LinArgs a;
-    a.A = A; a.A2 = nullptr; a.lda2 = 0; a.K1 = K; a.blob = p.blob; a.jb = jb; a.R = R; a.Y = nullptr; a.ldy = 0; a.rowjet = nullptr; a.m_dev = nullptr; a.part = nullptr; a.ksplit = 1; a.out = out;
+    a.A = A; a.A2 = nullptr; a.lda2 = 0; a.K1 = K; a.blob = p.blob; a.jb = jb; a.R = R; a.Y = nullptr; a.ldy = 0; a.rowjet = jb ? p.rowjet : nullptr; a.m_dev = p.m_dev; a.part = nullptr; a.ksplit = 1; a.out = out;
     a.blob_floats = p.d->blob_floats; a.W = lin.W; a.b = lin.b;
     a.gamma = ln ? ln->gamma : -1; a.beta = ln ? ln->beta : -1;
     a.jb_stride = (int64_t)(p.d->layers + 2) * p.d->hidden;
@@ -62,11 +64,11 @@ int launch_attn(const Plan& p, const float* qkv, const float* mask, float* out) 
     const int nkt = attn_np32(N) / 16;
     const dim3 grid(p.n_jets * heads), block(256);
     if (nkt <= 12)
-        hipLaunchKernelGGL(tf_attn_kernel<12>, grid, block, lds, p.s, qkv, mask, out, N, D, heads);
+        hipLaunchKernelGGL(tf_attn_kernel<12>, grid, block, lds, p.s, qkv, mask, out, N, D, heads, p.off);
     else if (nkt <= 18)
-        hipLaunchKernelGGL(tf_attn_kernel<18>, grid, block, lds, p.s, qkv, mask, out, N, D, heads);
+        hipLaunchKernelGGL(tf_attn_kernel<18>, grid, block, lds, p.s, qkv, mask, out, N, D, heads, p.off);
     else
-        hipLaunchKernelGGL(tf_attn_kernel<32>, grid, block, lds, p.s, qkv, mask, out, N, D, heads);
+        hipLaunchKernelGGL(tf_attn_kernel<32>, grid, block, lds, p.s, qkv, mask, out, N, D, heads, p.off);
     return check_hip(hipGetLastError(), "tf_attn_kernel launch");
 }
 
@@ -108,7 +110,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
     }
     const float* jb = ws + w.jb;
     hipLaunchKernelGGL(tf_embed_kernel, dim3((p.M + 31) / 32), dim3(256), 0, p.s, p.blob, d.n1.W, x, jb, (int64_t)nb * Hd,
-                       ws + w.h1, p.M, d.n_points, d.features, Hd, d.neg_slope);
+                       ws + w.h1, p.M, d.n_points, d.features, Hd, d.neg_slope, p.rowsrc, p.rowjet, p.m_dev);
     if ((rc = check_hip(hipGetLastError(), "tf_embed_kernel launch"))) return rc;
     if ((rc = launch_linear(p, ws + w.h1, Hd, Hd, d.n2, &d.n_norm, D, nullptr, nullptr, 0, ws + w.x0, D, false))) return rc;
     const float* xin = ws + w.x0;
@@ -129,6 +131,14 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
     h.A = ws + w.oh; h.blob = p.blob;
     h.gamma = d.o_norm.gamma; h.beta = d.o_norm.beta; h.W = d.o2.W; h.b = d.o2.b;
     h.M = p.M; h.Hd = Hd; h.F = d.features; h.eps = d.ln_eps;
+    h.rowsrc = p.rowsrc; h.m_dev = p.m_dev;
+    if (p.rowsrc && !h.base) {  // raw field: the rows the compacted evaluation never touches are 0
+        const int64_t n = (int64_t)p.M * d.features;
+        for (float* dst : {h.dst, h.v_out})
+            if (dst)
+                hipLaunchKernelGGL(rows_fill_masked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, mask, p.cnt,
+                                   (const float*)nullptr, dst, (int64_t)p.M, d.n_points, d.features, 0);
+    }
     const dim3 hg((p.M + 15) / 16), hb(256);
     switch (Hd / 64) {
         case 2: hipLaunchKernelGGL(tf_head_kernel<2>, hg, hb, 0, p.s, h); break;
@@ -146,6 +156,14 @@ int make_plan(Plan& p, const pfm_tf_desc* d, const float* blob, float* ws, int n
     p.d = d; p.blob = blob; p.ws = ws; p.n_jets = n_jets; p.M = n_jets * d->n_points; p.s = (hipStream_t)stream;
     p.w = make_ws(*d, n_jets, train);
     return 0;
+}
+
+// PFM_TF_F_VALID_ROWS: evaluate the valid particles only (the mask is constant over an ODE solve: built once per call)
+int setup_valid_rows(Plan& p, const float* mask) {
+    if (!(p.d->flags & PFM_TF_F_VALID_ROWS) || !mask) return 0;
+    const RowMaps m = build_row_maps(reinterpret_cast<int*>(p.ws + p.w.imaps), mask, p.n_jets, p.d->n_points, p.s);
+    p.rowsrc = m.rowsrc; p.rowjet = m.rowjet; p.off = m.off; p.m_dev = m.m_dev; p.cnt = m.cnt;
+    return check_hip(hipGetLastError(), "row compaction launch");
 }
 
 
@@ -384,6 +402,7 @@ int pfm_tf_forward(const pfm_tf_desc* d, const float* blob, const float* t, int3
     if (n_jets <= 0) return 0;
     if (!blob || !t || !x || !v || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
+    if ((rc = setup_valid_rows(p, mask))) return rc;
     HeadArgs h{};
     h.dst = v;
     return run_nfe(p, t, t_stride ? 1 : 0, x, cond, mask, h);
@@ -405,6 +424,9 @@ int pfm_tf_sample_midpoint(const pfm_tf_desc* d, const float* blob, const float*
     hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, xs, n,
                        d->features);
     if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+    if ((rc = setup_valid_rows(p, mask))) return rc;
+    if (p.rowsrc)  // x_mid's padded rows are never read; give them defined values once
+        if ((rc = check_hip(hipMemcpyAsync(xm, xs, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_mid"))) return rc;
     for (int k = 0; k < n_steps; ++k) {
         // k1 = f(t_k, x); x_mid = x + 0.5 dt k1; x <- x + dt f(t_k + dt/2, x_mid)
         HeadArgs h{};
@@ -431,6 +453,7 @@ int pfm_tf_sample_rk(const pfm_tf_desc* d, const float* blob, const pfm_rk_table
     hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, state, n,
                        d->features);
     if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+    if ((rc = setup_valid_rows(p, mask))) return rc;
     rc = sample_rk_rows(*tab, t_eval, dt, n_steps, state, n, p.s, [&](const float* t, const float* x, float* v) {
         HeadArgs h{};
         h.dst = v;

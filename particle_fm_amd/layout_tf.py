@@ -22,6 +22,7 @@ PFM_TF_MAX_LAYERS = 12
 HEAD_DIM = 16
 PFM_TF_F_F16X3 = 1
 PFM_TF_F_TEMB_SINCOS = 2
+PFM_TF_F_VALID_ROWS = 4
 
 
 class TfNorm(ctypes.Structure):

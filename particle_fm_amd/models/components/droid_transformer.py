@@ -187,16 +187,25 @@ class _FusedEncoder(nn.Module):
         self.num_points, self.frequencies, self.add_time_to_input, self.t_emb = num_points, frequencies, add_time_to_input, t_emb
         self._layouts = {}
         self.mfma_dtype = "fp32"  # "f16x3": every Linear on split-fp16 operands, fp32-grade accuracy
+        # inference evaluates the valid particles only (PFM_*_F_VALID_ROWS): same numbers at valid particles, the reference's
+        # unmasked values at padded positions (which every consumer multiplies by the mask) are not produced
+        self.valid_rows_only = False
         self.cfg = self.config(num_points or 1)
         self._LAYOUT(self.cfg)  # rejects unsupported sizes at construction
 
     def layout(self, num_points: Optional[int] = None):
         n = num_points or self.num_points
-        flags = 1 if self.mfma_dtype == "f16x3" else 0
+        flags = (1 if self.mfma_dtype == "f16x3" else 0) | (4 if self.valid_rows_only else 0)
         lay = self._layouts.get((n, flags))
         if lay is None:
             lay = self._layouts[(n, flags)] = self._LAYOUT(self.config(n), flags=flags)
         return lay
+
+    def set_valid_rows_only(self, on: bool = True) -> None:
+        """Sampling / forward skip padded particles (training is unaffected: the reference's loss includes padded rows)."""
+        if on and self._LAYOUT is not TfLayout:
+            raise NotImplementedError("valid-rows-only evaluation is built for the Full-Transformer path")
+        self.valid_rows_only = bool(on)
 
     def set_precision(self, precision) -> None:
         """"f16x3" -> split-fp16 Linears; anything else (incl. Lightning's "bf16-mixed": no bf16 kernels on this path) fp32."""
