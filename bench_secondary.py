@@ -115,6 +115,9 @@ def run(name, args):
     net = model.flows[0].net
     if args.precision != "fp32":
         net.set_precision(args.precision)
+    valid_rows = hasattr(net, "set_valid_rows_only") and not args.dense_rows
+    if valid_rows:  # what generate_data does with variable_set_sizes: the sampler skips padded particles (EPiC always does)
+        net.set_valid_rows_only(True)
     trainer = FusedFMTrainer(model, lr=1e-3, weight_decay=5e-5, max_grad_norm=0.5, ema_decay=0.999)
     N, F = hp["num_particles"], hp["features"]
     x, mask, cond = (a.to(dev) for a in make_batch(B, N, F, C, n_min, 12345))
@@ -153,7 +156,8 @@ def run(name, args):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else f"f32 ({args.precision} matrix operands)",
         "data": "synthetic",
         "config": {"workload": what, "jets_per_gpu": B, "parallelism": "dp1", "ode_steps": args.ode_steps,
-                   "multiplicity": f"U{{{n_min}..{N}}} per jet"},
+                   "multiplicity": f"U{{{n_min}..{N}}} per jet",
+                   "sampler_rows": "valid particles only" if (valid_rows or hp["model"] == "epic") else "all N rows (padded included)"},
         "train_ms": train_ms, "sample_ms": sample_ms, "train_jets_per_s": B / (train_ms * 1e-3),
         "sample_jets_per_s": B / (sample_ms * 1e-3),
         "roofline": {"bound": "mfma", "kernel": "sampling launches (tf_linear_kernel dominates)" if name != "jetnet30" else "epic_sample_midpoint_kernel",
@@ -176,6 +180,7 @@ def main():
     ap.add_argument("--ode-steps", type=int, default=100)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-rows", action="store_true", help="transformer paths: sample all N rows like the reference (padded included)")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_secondary.py needs an MI355X (the HIP path has no CPU fallback)")

@@ -30,6 +30,7 @@ extern "C" {
 #define PFM_CA_MAX_TOKENS 8
 #define PFM_CA_F_F16X3 1        /* split-fp16 Linears, see PFM_TF_F_F16X3 */
 #define PFM_CA_F_TEMB_SINCOS 2  /* see PFM_TF_F_TEMB_SINCOS */
+#define PFM_CA_F_VALID_ROWS 4    /* see PFM_TF_F_VALID_ROWS: inference over the valid particles only */
 
 typedef struct {
     pfm_tf_norm norm0, norm1, norm2, attn_norm, d_norm; /* norm0: keys/values input, norm1: query input, norm2: dense input */

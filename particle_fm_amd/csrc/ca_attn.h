@@ -76,17 +76,24 @@ __device__ __forceinline__ void load_queries(float (&qr)[TK][HD], const float* _
 template <int HD, int TK>
 __global__ __launch_bounds__(256) void ca_attn_from_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                            const float* __restrict__ mask, float* __restrict__ out, int N,
-                                                           int D, int heads, int Tk) {
+                                                           int D, int heads, int Tk, const int* __restrict__ off = nullptr) {
     const int jet = blockIdx.x, lane = threadIdx.x & 63, h = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (h >= heads) return;
+    // compacted particle rows (off != nullptr): the jet's keys are rows [off[jet], off[jet + 1]), all valid
+    int64_t row_base = (int64_t)jet * N;
+    if (off) {
+        row_base = off[jet];
+        N = off[jet + 1] - off[jet];
+        mask = nullptr;
+    }
     float qr[TK][HD];  // pre-scaled by 1 / sqrt(HD)
     load_queries<HD, TK>(qr, q + (int64_t)jet * Tk * D + h * HD, Tk, D, 1.0f / sqrtf((float)HD));
     Running<HD, TK> st;
     st.init();
-    const float* base = kv + (int64_t)jet * N * 2 * D + h * HD;
+    const float* base = kv + row_base * 2 * D + h * HD;
 #pragma unroll 2
     for (int n = lane; n < N; n += 64) {
-        if (mask && mask[(int64_t)jet * N + n] == 0.f) continue;
+        if (mask && mask[row_base + n] == 0.f) continue;
         float kr[HD], vr[HD];
         load_row<HD>(kr, base + (int64_t)n * 2 * D);
         load_row<HD>(vr, base + (int64_t)n * 2 * D + D);
@@ -218,15 +225,23 @@ __global__ __launch_bounds__(256) void ca_attn_from_bwd_kernel(const float* __re
 // q [n_jets*N][D]; kv [n_jets*Tk][2D]; out [n_jets*N][D]; no key mask (droid_transformer.py:470)
 template <int HD, int TK>
 __global__ __launch_bounds__(256) void ca_attn_to_kernel(const float* __restrict__ q, const float* __restrict__ kv,
-                                                         float* __restrict__ out, int N, int D, int heads, int Tk) {
+                                                         float* __restrict__ out, int N, int D, int heads, int Tk,
+                                                         const int* __restrict__ off = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [Tk][2D]
-    const int jet = blockIdx.x, r0 = blockIdx.y * TO_ROWS, nr = min(TO_ROWS, N - r0);
+    const int jet = blockIdx.x, r0 = blockIdx.y * TO_ROWS;
+    int64_t row_base = (int64_t)jet * N;
+    if (off) {  // compacted particle rows
+        row_base = off[jet];
+        N = off[jet + 1] - off[jet];
+    }
+    if (r0 >= N) return;
+    const int nr = min(TO_ROWS, N - r0);
     for (int i = threadIdx.x; i < Tk * 2 * D; i += 256) lds[i] = kv[(int64_t)jet * Tk * 2 * D + i];
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)HD);
     for (int idx = threadIdx.x; idx < nr * heads; idx += 256) {
         const int r = r0 + idx / heads, h = idx % heads;
-        const int64_t e = ((int64_t)jet * N + r) * D + h * HD;
+        const int64_t e = (row_base + r) * D + h * HD;
         float qr[HD];
         load_row<HD>(qr, q + e);
         float s[TK], mx = -__builtin_inff();

@@ -39,7 +39,7 @@ struct Ws {
     int64_t temb, chid, ctxt, jb, h1, seq0, tok0, layer0, lstride;
     int64_t f_kv, f_q, f_att, f_mid, f_dh, f_out;  // from-layer: kv [M][2D], q / att / mid / out [Mt][D], dh [Mt][Hd]
     int64_t t_q, t_kv, t_att, t_mid, t_dh, t_out;  // to-layer:   q / att / mid / out [M][D], kv [Mt][2D], dh [M][Hd]
-    int64_t oh, total;
+    int64_t oh, imaps, total;  // imaps: int32 row maps of the valid-rows-only evaluation
 };
 
 Ws make_ws(const pfm_ca_desc& d, int n_jets, bool train) {
@@ -70,6 +70,7 @@ Ws make_ws(const pfm_ca_desc& d, int n_jets, bool train) {
         o += p;
     }
     w.oh = take(M * Hd);
+    w.imaps = take(row_maps_ints(n_jets, M));
     w.total = o;
     return w;
 }
@@ -81,6 +82,8 @@ struct Plan {
     Ws w;
     int n_jets, M, Mt;
     hipStream_t s;
+    // valid-rows-only evaluation (PFM_CA_F_VALID_ROWS, inference): the particle rows are the valid particles
+    const int *rowsrc = nullptr, *rowjet = nullptr, *off = nullptr, *m_dev = nullptr, *cnt = nullptr;
 };
 
 // out[rows][ldo] = epi(LN?(A) W^T + b / jet bias) (+R); per_jet = rows per jet of this row matrix (jet-bias lookup)
@@ -88,7 +91,8 @@ int linear(const Plan& p, int rows, int per_jet, const float* A, int lda, int K,
            const float* jb, const float* R, int ldr, float* out, int ldo, int act) {
     LinArgs a;
     a.A = A; a.A2 = nullptr; a.lda2 = 0; a.K1 = K; a.blob = p.blob; a.jb = jb; a.R = R; a.Y = nullptr; a.ldy = 0;
-    a.rowjet = nullptr; a.m_dev = nullptr; a.part = nullptr; a.ksplit = 1; a.out = out;
+    const bool prow = p.rowsrc && rows == p.M && per_jet == p.d->n_points;  // a particle-row GEMM of a compacted evaluation
+    a.rowjet = (prow && jb) ? p.rowjet : nullptr; a.m_dev = prow ? p.m_dev : nullptr; a.part = nullptr; a.ksplit = 1; a.out = out;
     a.blob_floats = p.d->blob_floats; a.W = lin.W; a.b = lin.b;
     a.gamma = ln ? ln->gamma : -1; a.beta = ln ? ln->beta : -1;
     a.jb_stride = (int64_t)(2 * p.d->layers + 2) * p.d->hidden;
@@ -133,7 +137,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
     }
     const float* jb = ws + w.jb;
     hipLaunchKernelGGL(tf_embed_kernel, dim3((p.M + 31) / 32), dim3(256), 0, p.s, p.blob, d.n1.W, x, jb, (int64_t)nb * Hd, ws + w.h1, p.M,
-                       N, d.features, Hd, d.neg_slope);
+                       N, d.features, Hd, d.neg_slope, p.rowsrc, p.rowjet, p.m_dev);
     PFM_TRY(check_hip(hipGetLastError(), "tf_embed_kernel launch (ca)"));
     PFM_TRY(linear(p, p.M, N, ws + w.h1, Hd, Hd, d.n2, &d.n_norm, D, nullptr, nullptr, 0, ws + w.seq0, D, 0));
     {
@@ -151,7 +155,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         PFM_TRY(linear(p, p.M, N, seq, D, D, Fl.kv, &Fl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.f_kv, 2 * D, 0));
         PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Fl.q, &Fl.norm1, D, nullptr, nullptr, 0, lb + w.f_q, D, 0));
         PFM_ATTN(ca_attn_from_kernel, dim3(p.n_jets, (heads + 3) / 4), 0, (const float*)(lb + w.f_q), (const float*)(lb + w.f_kv), mask, lb + w.f_att, N, D,
-                 heads, Tk);
+                 heads, Tk, p.off);
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_from_kernel launch"));
         PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_att, D, D, Fl.out, &Fl.attn_norm, D, nullptr, tok, D, lb + w.f_mid, D, 0));
         PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_mid, D, D, Fl.d1, &Fl.norm2, Hd, jb + (int64_t)(1 + 2 * l) * Hd, nullptr, 0, lb + w.f_dh, Hd, 1));
@@ -161,7 +165,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         PFM_TRY(linear(p, p.M, N, seq, D, D, Tl.q, &Tl.norm1, D, nullptr, nullptr, 0, lb + w.t_q, D, 0));
         PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Tl.kv, &Tl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.t_kv, 2 * D, 0));
         PFM_ATTN(ca_attn_to_kernel, dim3(p.n_jets, (N + TO_ROWS - 1) / TO_ROWS), (size_t)Tk * 2 * D * sizeof(float), (const float*)(lb + w.t_q),
-                 (const float*)(lb + w.t_kv), lb + w.t_att, N, D, heads, Tk);
+                 (const float*)(lb + w.t_kv), lb + w.t_att, N, D, heads, Tk, p.off);
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_to_kernel launch"));
         PFM_TRY(linear(p, p.M, N, lb + w.t_att, D, D, Tl.out, &Tl.attn_norm, D, nullptr, seq, D, lb + w.t_mid, D, 0));
         PFM_TRY(linear(p, p.M, N, lb + w.t_mid, D, D, Tl.d1, &Tl.norm2, Hd, jb + (int64_t)(2 + 2 * l) * Hd, nullptr, 0, lb + w.t_dh, Hd, 1));
@@ -174,6 +178,14 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
     h.A = ws + w.oh; h.blob = p.blob;
     h.gamma = d.o_norm.gamma; h.beta = d.o_norm.beta; h.W = d.o2.W; h.b = d.o2.b;
     h.M = p.M; h.Hd = Hd; h.F = d.features; h.eps = d.ln_eps;
+    h.rowsrc = p.rowsrc; h.m_dev = p.m_dev;
+    if (p.rowsrc && !h.base) {  // raw field: the rows the compacted evaluation never touches are 0
+        const int64_t n = (int64_t)p.M * d.features;
+        for (float* dst : {h.dst, h.v_out})
+            if (dst)
+                hipLaunchKernelGGL(rows_fill_masked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, mask, p.cnt,
+                                   (const float*)nullptr, dst, (int64_t)p.M, N, d.features, 0);
+    }
     const dim3 hg((p.M + 15) / 16), hb(256);
     switch (Hd / 64) {
         case 2: hipLaunchKernelGGL(tf_head_kernel<2>, hg, hb, 0, p.s, h); break;
@@ -191,6 +203,14 @@ int make_plan(Plan& p, const pfm_ca_desc* d, const float* blob, float* ws, int n
     p.s = (hipStream_t)stream;
     p.w = make_ws(*d, n_jets, train);
     return 0;
+}
+
+int setup_valid_rows(Plan& p, const float* mask) {
+    if (!(p.d->flags & PFM_CA_F_VALID_ROWS) || !mask) return 0;
+    if (p.d->n_points <= p.d->tokens) return 0;  // linear() tells particle rows from token rows by their count per jet
+    const RowMaps m = build_row_maps(reinterpret_cast<int*>(p.ws + p.w.imaps), mask, p.n_jets, p.d->n_points, p.s);
+    p.rowsrc = m.rowsrc; p.rowjet = m.rowjet; p.off = m.off; p.m_dev = m.m_dev; p.cnt = m.cnt;
+    return check_hip(hipGetLastError(), "row compaction launch");
 }
 
 // ---- backward ------------------------------------------------------------------------------------------
@@ -448,6 +468,7 @@ int pfm_ca_forward(const pfm_ca_desc* d, const float* blob, const float* t, int3
     if (n_jets <= 0) return 0;
     if (!blob || !t || !x || !v || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
+    if ((rc = ca::setup_valid_rows(p, mask))) return rc;
     tf::HeadArgs h{};
     h.dst = v;
     return ca::run_nfe(p, t, t_stride ? 1 : 0, x, cond, mask, h);
@@ -469,6 +490,9 @@ int pfm_ca_sample_midpoint(const pfm_ca_desc* d, const float* blob, const float*
     hipLaunchKernelGGL(tf::tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, xs, n,
                        d->features);
     if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+    if ((rc = ca::setup_valid_rows(p, mask))) return rc;
+    if (p.rowsrc)  // x_mid's padded rows are never read; give them defined values once
+        if ((rc = check_hip(hipMemcpyAsync(xm, xs, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_mid"))) return rc;
     for (int k = 0; k < n_steps; ++k) {
         tf::HeadArgs h{};
         h.base = xs; h.dt = dt + k; h.coef = 0.5f; h.dst = xm;
@@ -494,6 +518,7 @@ int pfm_ca_sample_rk(const pfm_ca_desc* d, const float* blob, const pfm_rk_table
     hipLaunchKernelGGL(tf::tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, state, n,
                        d->features);
     if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+    if ((rc = ca::setup_valid_rows(p, mask))) return rc;
     rc = tf::sample_rk_rows(*tab, t_eval, dt, n_steps, state, n, p.s, [&](const float* t, const float* x, float* v) {
         tf::HeadArgs h{};
         h.dst = v;

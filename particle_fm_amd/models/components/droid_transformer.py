@@ -203,8 +203,6 @@ class _FusedEncoder(nn.Module):
 
     def set_valid_rows_only(self, on: bool = True) -> None:
         """Sampling / forward skip padded particles (training is unaffected: the reference's loss includes padded rows)."""
-        if on and self._LAYOUT is not TfLayout:
-            raise NotImplementedError("valid-rows-only evaluation is built for the Full-Transformer path")
         self.valid_rows_only = bool(on)
 
     def set_precision(self, precision) -> None:

@@ -23,7 +23,7 @@ def flop_per_jet(c):
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 cfg = CaConfig(num_particles=279, global_cond_dim=5)
-lay = CaLayout(cfg, flags=1 if "x3" in sys.argv else 0)
+lay = CaLayout(cfg, flags=(1 if "x3" in sys.argv else 0) | (4 if "valid" in sys.argv else 0))
 st = {k: torch.from_numpy(v) for k, v in seeded_state(dict(cfg.param_shapes()), 1).items()}
 blob = lay.pack_blob(st).cuda()
 gen = torch.Generator().manual_seed(0)
