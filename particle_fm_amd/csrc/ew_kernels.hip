@@ -551,7 +551,11 @@ extern "C" {
 
 int64_t pfm_ew_workspace_floats(const pfm_ew_desc* d, int32_t n_jets, int32_t train) {
     if (ew::validate(d)) return -1;
-    return ew::make_ws(*d, n_jets < 1 ? 1 : n_jets, train != 0).total;
+    const int n = n_jets < 1 ? 1 : n_jets;
+    const int64_t whole = ew::make_ws(*d, n, train != 0).total;
+    if (train || n < 2) return whole;
+    const int64_t halves = ew::make_ws(*d, n / 2, false).total + ew::make_ws(*d, n - n / 2, false).total;  // two-stream samplers
+    return whole > halves ? whole : halves;
 }
 
 int pfm_ew_forward(const pfm_ew_desc* d, const float* blob, const float* t, int32_t t_stride, const float* x,
@@ -571,28 +575,53 @@ int pfm_ew_forward(const pfm_ew_desc* d, const float* blob, const float* t, int3
 int pfm_ew_sample_midpoint(const pfm_ew_desc* d, const float* blob, const float* t_eval, const float* dt,
                            int32_t n_steps, const float* z, const float* cond, const float* mask, float* x_out,
                            int32_t n_jets, int32_t premask, float* state, float* workspace, void* stream) {
-    ew::Plan p;
-    int rc = ew::make_plan(p, d, blob, workspace, n_jets, false, stream);
+    int rc = ew::validate(d);
     if (rc) return rc;
     if (n_jets <= 0) return 0;
     if (!blob || !t_eval || !dt || !z || !x_out || !state || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (n_steps < 0) return set_err(PFM_E_BADARG, "n_steps < 0");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
-    const int64_t n = (int64_t)p.M * d->features;
-    float* xs = state;
-    float* xm = state + n;
-    hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, xs, n,
-                       d->features);
-    if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
-    if (mask && (rc = ew::setup_compaction(p, mask))) return rc;
-    for (int k = 0; k < n_steps; ++k) {
-        ew::HeadArgs h{};
-        h.base = xs; h.dt = dt + k; h.coef = 0.5f; h.dst = xm;
-        if ((rc = ew::run_nfe(p, t_eval + 2 * k, 0, xs, cond, mask, h))) return rc;
-        h.coef = 1.0f; h.dst = xs;
-        if ((rc = ew::run_nfe(p, t_eval + 2 * k + 1, 0, xm, cond, mask, h))) return rc;
+    // Two half-batches on two streams, their launches interleaved evaluation by evaluation (tf_common.h: side_stream)
+    const int n_a = split_point(n_jets, 32);
+    SideStream* ss = n_a ? side_stream() : nullptr;
+    const int parts = ss ? 2 : 1;
+    ew::Plan p[2];
+    float *xs[2], *xm[2];
+    const float *cnd[2], *msk[2];
+    int64_t n[2], r0[2];
+    if (ss && (hipEventRecord(ss->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess))
+        return set_err(PFM_E_BADARG, "side stream fork failed");
+    for (int i = 0; i < parts; ++i) {
+        const int j0 = i ? n_a : 0, nj = parts == 1 ? n_jets : (i ? n_jets - n_a : n_a);
+        float* ws = workspace + (i ? ew::make_ws(*d, n_a, false).total : 0);
+        if ((rc = ew::make_plan(p[i], d, blob, ws, nj, false, i ? (void*)ss->s : stream))) return rc;
+        r0[i] = (int64_t)j0 * d->n_points;
+        n[i] = (int64_t)p[i].M * d->features;
+        xs[i] = state + 2 * r0[i] * d->features;
+        xm[i] = xs[i] + n[i];
+        cnd[i] = cond ? cond + (int64_t)j0 * d->cond_global : nullptr;
+        msk[i] = mask ? mask + r0[i] : nullptr;
+        hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n[i] + 255) / 256)), dim3(256), 0, p[i].s, z + r0[i] * d->features,
+                           premask ? msk[i] : nullptr, xs[i], n[i], d->features);
+        if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+        if (mask && (rc = ew::setup_compaction(p[i], msk[i]))) return rc;
     }
-    return check_hip(hipMemcpyAsync(x_out, xs, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_out");
+    for (int k = 0; k < n_steps; ++k)
+        for (int stage = 0; stage < 2; ++stage)
+            for (int i = 0; i < parts; ++i) {
+                ew::HeadArgs h{};
+                h.base = xs[i]; h.dt = dt + k; h.coef = stage ? 1.0f : 0.5f; h.dst = stage ? xs[i] : xm[i];
+                if ((rc = ew::run_nfe(p[i], t_eval + 2 * k + stage, 0, stage ? xm[i] : xs[i], cnd[i], msk[i], h))) return rc;
+            }
+    for (int i = 0; i < parts; ++i)
+        if ((rc = check_hip(hipMemcpyAsync(x_out + r0[i] * d->features, xs[i], n[i] * sizeof(float), hipMemcpyDeviceToDevice, p[i].s),
+                            "copy x_out")))
+            return rc;
+    if (ss) {
+        hipEventRecord(ss->join, ss->s);
+        hipStreamWaitEvent((hipStream_t)stream, ss->join, 0);
+    }
+    return 0;
 }
 
 int pfm_ew_sample_rk(const pfm_ew_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,

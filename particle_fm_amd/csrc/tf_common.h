@@ -1,5 +1,7 @@
 // Shared pieces of the Full-Transformer kernels (gfx950): workspace layout, launch geometry, small device helpers.
 #pragma once
+#include <stdlib.h>
+
 #include "pfm_common.h"
 #include "pfm_tf.h"
 
@@ -36,6 +38,48 @@ inline int num_cus() {
         if (n <= 0) n = 256;
     }
     return n;
+}
+
+// Two half-batches on two streams: the jets of a sampling call are independent, so the latency-bound stretches of one half
+// (per-jet GEMMs, context path, global tokens: a few workgroups each) run under the particle-row GEMMs of the other.
+// One side stream + fork / join events per device, created on first use and kept for the life of the process.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+inline SideStream* side_stream() {
+    static SideStream st[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream& e = st[dev];
+    if (!e.s) {
+        if (hipStreamCreateWithFlags(&e.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess)
+            return nullptr;
+    }
+    return &e;
+}
+// jets of the first half (0: do not split).  PFM_SPLIT_STREAMS=0 turns the split off (diagnostics).
+inline int split_point(int n_jets, int min_half) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("PFM_SPLIT_STREAMS");
+        on = e ? atoi(e) : 1;
+    }
+    return (on && n_jets >= 2 * min_half) ? n_jets / 2 : 0;
+}
+// f(part, jet0, n, stream) queues one half; the caller's stream waits for the side stream at the end
+template <class F>
+int run_halves(int n_jets, int n_a, hipStream_t s, F f) {
+    SideStream* ss = n_a ? side_stream() : nullptr;
+    if (!ss) return f(0, 0, n_jets, s);
+    if (hipEventRecord(ss->fork, s) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return f(0, 0, n_jets, s);
+    int rc = f(0, 0, n_a, s);
+    const int rc2 = f(1, n_a, n_jets - n_a, ss->s);
+    hipEventRecord(ss->join, ss->s);
+    hipStreamWaitEvent(s, ss->join, 0);
+    return rc ? rc : rc2;
 }
 
 __host__ __device__ inline int64_t round64(int64_t x) { return (x + 63) & ~(int64_t)63; }
