@@ -185,7 +185,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ode-steps", type=int, default=100)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3", "bf16"],
+                    help="matrix operands: f16x3 = split fp16, fp32-grade accuracy (jet-resident EPiC: the sampler; row-matrix paths: "
+                         "every Linear, training included); bf16 = the jet-resident EPiC sampler only (BASELINE cfg 2 is quoted in bf16; "
+                         "training stays fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dense-rows", action="store_true", help="transformer paths: sample all N rows like the reference (padded included)")
     args = ap.parse_args()
