@@ -146,10 +146,14 @@ int pfm_epic_forward_temb(const pfm_epic_desc *desc, const float *blob, const fl
 
 /* Fixed-step explicit midpoint over n_intervals steps, all inside one launch:
  *   x <- z*mask;  for k: k1 = f(t_eval[2k], x); xm = x + 0.5*dt[k]*k1; x <- x + dt[k]*f(t_eval[2k+1], xm)
- * t_eval[2*n_intervals], dt[n_intervals] are the fp32 values the reference's driver visits. */
+ * t_eval[2*n_intervals], dt[n_intervals] are the fp32 values the reference's driver visits.
+ * scratch (pfm_epic_sample_scratch_floats(desc, n_intervals) floats, or NULL): every jet is evaluated at the same times, so
+ * the time columns of the per-jet Linears give jet-independent vectors; with scratch they are tabulated once per call (a
+ * second, tiny launch) and the per-jet phase of the kernel skips those weight rows. */
+int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc *desc, int32_t n_intervals);
 int pfm_epic_sample_midpoint(const pfm_epic_desc *desc, const float *blob, const float *t_eval,
                              const float *dt, int32_t n_intervals, const float *z, const float *cond,
-                             const float *mask, float *x_out, int32_t B, void *stream);
+                             const float *mask, float *x_out, int32_t B, float *scratch, void *stream);
 
 /* Explicit Runge-Kutta scheme with up to 4 stages (a strictly lower triangular; row s of `a` feeds stage s):
  *   k_s = f(t + c[s] dt, x + dt * (a[s][0] k_0 + ... + a[s][s-1] k_{s-1}));   x <- x + dt * (b[0] k_0 + ... + b[S-1] k_{S-1})

@@ -92,9 +92,9 @@ __global__ __launch_bounds__(NT, 2) void epic_forward_kernel(const float* __rest
 // One evaluation of the vector field inside the persistent sampler + the integrator update.  (Tried as a real,
 // non-inlined function to isolate its register allocation: the call ABI's callee-saved spills made it 25 % slower.)
 //   stage 0: x_mid = x + 0.5*dt*k1 -> next input;   stage 1: x = x + dt*f(t+dt/2, x_mid)
-template <int MODE>
+template <int MODE, bool TB>
 static __device__ __forceinline__ void sampler_eval(const float* __restrict__ blob, int64_t desc_off, int n_rows,
-                                                      float t, float hs, int stage) {
+                                                      float t, float hs, int stage, const float* __restrict__ tb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
@@ -105,7 +105,7 @@ static __device__ __forceinline__ void sampler_eval(const float* __restrict__ bl
     const int F = j.F;
     epic_time_embedding(d, j, blob, lds, c, t);
     __syncthreads();
-    epic_body<false, MODE>(d, j, blob, lds, c, n_rows, nullptr, sl);
+    epic_body<false, MODE, TB>(d, j, blob, lds, c, n_rows, nullptr, sl, tb);
     epic_head<MODE>(d, j, blob, lds, c, n_rows, [=](int p, int f, float val) {
         const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
         yin[p * F + f] = xn;
@@ -118,11 +118,11 @@ static __device__ __forceinline__ void sampler_eval(const float* __restrict__ bl
 // Persistent fixed-step midpoint integrator: all 2*n_intervals evaluations of a jet in one launch,
 // state and activations never leave the CU.  (torchdyn Midpoint.step restated in oracle/fm_ref.py)
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool TB>
 __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
     const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ t_eval,
     const float* __restrict__ dt, int n_intervals, const float* __restrict__ z, const float* __restrict__ cond,
-    const float* __restrict__ mask, float* __restrict__ x_out) {
+    const float* __restrict__ mask, float* __restrict__ x_out, const float* __restrict__ table) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d0);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
         const int stage = e & 1;
         const float h = dt[e >> 1];
         const float hs = stage ? h : __fmul_rn(0.5f, h);
-        sampler_eval<MODE>(blob, desc_off, n_rows, t_eval[e], hs, stage);
+        sampler_eval<MODE, TB>(blob, desc_off, n_rows, t_eval[e], hs, stage, TB ? table + (size_t)e * j.layers * TB_SLOT : nullptr);
         PFM_STAMP(30);
     }
     float* oj = x_out + (size_t)jet * j.N * j.F;
@@ -208,6 +208,44 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_rk_kernel(
     }
     float* oj = x_out + (size_t)jet * NF;
     for (int i = tid; i < NF; i += NT) oj[i] = xs[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Time-term table of a sampling call (epic_nfe.h: TB): table[e][layer][TB_SLOT] = W_t^T temb(t_eval[e]) for the four per-jet
+// Linears of every EPiC layer (fc_global1, local-1 extras, local-2 extras: KM16 blocks; fc_global2: KP16), time rows = the
+// first T rows of each block.  grid (n_evals, layers), 512 threads.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void epic_time_table_kernel(const float* __restrict__ blob, int64_t desc_off,
+                                                              const float* __restrict__ t_eval, float* __restrict__ table) {
+    __shared__ float temb[MAXT];
+    const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
+    const JetDims j = dims_of(d);
+    const int e = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+    if (tid < j.T) {  // the op order of epic_time_embedding
+        const float t = t_eval[e], f = blob[d.freqs + tid];
+        float v;
+        if (d.flags & PFM_F_TEMB_SINCOS) {
+            const float arg = __fmul_rn(f, t);
+            v = 2 * tid < j.T ? cosf(arg) : sinf(arg);
+        } else {
+            v = cosf(__fdiv_rn(__fmul_rn(__fmul_rn(__fadd_rn(t, 0.0f), f), 3.14159274101257324f), 1.0f));
+        }
+        temb[tid] = v;
+    }
+    __syncthreads();
+    const pfm_epic_layer& ly = d.layer[k];
+    float* out = table + ((size_t)e * j.layers + k) * TB_SLOT;
+    const int which = tid >> 7, o = tid & 127;  // 0: fc_global1, 1: local-1 extras, 2: local-2 extras, 3: fc_global2
+    if (which < 3) {
+        const int64_t W = which == 0 ? ly.gl1.W : (which == 1 ? ly.lc1.We : ly.lc2.We);
+        float s = 0.f;
+        for (int r = 0; r < j.T; ++r) s = fmaf(blob[W + km16(r, o)], temb[r], s);
+        out[which * 128 + o] = s;
+    } else if (o < 16) {
+        float s = 0.f;
+        for (int r = 0; r < j.T; ++r) s = fmaf(blob[ly.gl2.W + (r >> 4) * 256 + (r & 15) * 16 + o], temb[r], s);
+        out[TB_G2 + o] = s;
+    }
 }
 
 // which matrix-pipe flavour the inference kernels use (descriptor flags): 0 fp32, 1 bf16 operands, 2 split fp16
@@ -282,22 +320,38 @@ int pfm_epic_forward_temb(const pfm_epic_desc* d, const float* blob, const float
     return check_hip(hipGetLastError(), "epic_forward_kernel launch");
 }
 
+int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc* d, int32_t n_intervals) {
+    if (!d || n_intervals < 0) return -1;
+    return (int64_t)2 * n_intervals * d->layers * TB_SLOT;
+}
+
 int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const float* t_eval, const float* dt,
                              int32_t n_intervals, const float* z, const float* cond, const float* mask,
-                             float* x_out, int32_t B, void* stream) {
+                             float* x_out, int32_t B, float* scratch, void* stream) {
     int lds = 0;
     const int mode = mfma_mode(d);
-    int rc = mode == 2 ? prepare(epic_sample_midpoint_kernel<2>, d, &lds)
-                       : (mode == 1 ? prepare(epic_sample_midpoint_kernel<1>, d, &lds) : prepare(epic_sample_midpoint_kernel<0>, d, &lds));
+    // the time-term table needs whole 16-row time panels and at least one EPiC layer
+    const bool tb = scratch && d && d->layers > 0 && d->t_dim % 16 == 0 && d->t_dim > 0;
+    int rc;
+#define PFM_PREP(M, T) prepare(epic_sample_midpoint_kernel<M, T>, d, &lds)
+    if (tb) rc = mode == 2 ? PFM_PREP(2, true) : (mode == 1 ? PFM_PREP(1, true) : PFM_PREP(0, true));
+    else rc = mode == 2 ? PFM_PREP(2, false) : (mode == 1 ? PFM_PREP(1, false) : PFM_PREP(0, false));
+#undef PFM_PREP
     if (rc) return rc;
     if (B <= 0) return 0;
     if (!blob || !t_eval || !dt || !z || !x_out) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (n_intervals < 0) return set_err(PFM_E_BADARG, "n_intervals < 0");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
-#define PFM_LAUNCH_SMP(M)                                                                                                  \
-    hipLaunchKernelGGL(epic_sample_midpoint_kernel<M>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, \
-                       t_eval, dt, n_intervals, z, cond, mask, x_out)
-    if (mode == 2) PFM_LAUNCH_SMP(2); else if (mode == 1) PFM_LAUNCH_SMP(1); else PFM_LAUNCH_SMP(0);
+    if (tb && n_intervals > 0) {
+        hipLaunchKernelGGL(epic_time_table_kernel, dim3(2 * n_intervals, d->layers), dim3(NT), 0, (hipStream_t)stream, blob,
+                           d->blob_floats, t_eval, scratch);
+        if ((rc = check_hip(hipGetLastError(), "epic_time_table_kernel launch"))) return rc;
+    }
+#define PFM_LAUNCH_SMP(M, T)                                                                                                  \
+    hipLaunchKernelGGL((epic_sample_midpoint_kernel<M, T>), dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, \
+                       t_eval, dt, n_intervals, z, cond, mask, x_out, (const float*)scratch)
+    if (tb) { if (mode == 2) PFM_LAUNCH_SMP(2, true); else if (mode == 1) PFM_LAUNCH_SMP(1, true); else PFM_LAUNCH_SMP(0, true); }
+    else { if (mode == 2) PFM_LAUNCH_SMP(2, false); else if (mode == 1) PFM_LAUNCH_SMP(1, false); else PFM_LAUNCH_SMP(0, false); }
 #undef PFM_LAUNCH_SMP
     return check_hip(hipGetLastError(), "epic_sample_midpoint_kernel launch");
 }

@@ -429,9 +429,16 @@ constexpr int GW2 = 8;   // further panels issued at the start of the per-jet ph
 // issue the loads of this thread's fc_global1 rows: they do not depend on data, so the caller issues them BEFORE
 // the particle phase whose pooled output the GEMV consumes; the 152 KB stream from L2 (64 B/clk/CU = 2.4k cycles)
 // then hides behind that phase's MFMAs instead of sitting on the serial path.
-__device__ __forceinline__ void prefetch_gl1(f32x4 (&gw)[GW], blob_rsrc rs, const pfm_dense_lin& gl1, int K1) {
-    gemv4_load<GW>(gw, rs, gl1.W, K1, 0, launder(threadIdx.x));
+__device__ __forceinline__ void prefetch_gl1(f32x4 (&gw)[GW], blob_rsrc rs, const pfm_dense_lin& gl1, int K1, int tp = 0) {
+    gemv4_load<GW>(gw, rs, gl1.W, K1, tp, launder(threadIdx.x));
 }
+
+// Sampling evaluates every jet at the same time t, so the time columns of the per-jet Linears (the first T rows of every
+// extras / fc_global block: inputs are ordered [temb ; ...]) give jet-independent vectors.  epic_time_table_kernel
+// computes them once per evaluation for all layers; with TB the per-jet phase skips the tp = T / 16 time panels of every
+// block (a quarter of its weight fetches, which is what bounds it) and adds the table entry to the bias instead.
+constexpr int TB_SLOT = 512;  // floats per (evaluation, layer): fc_global1 | local-1 extras | local-2 extras | fc_global2 (16)
+constexpr int TB_G1 = 0, TB_L1 = 128, TB_L2 = 256, TB_G2 = 384;
 
 // The per-jet phase between two particle phases:
 //   g1 = lrelu(Wg1.[temb;cond;mean;sum;g] + b)            epic.py:180-182 / :375-377
@@ -443,12 +450,15 @@ __device__ __forceinline__ void prefetch_gl1(f32x4 (&gw)[GW], blob_rsrc rs, cons
 // redundantly and finishes the bias slice [16w,16w+16) that its own MFMA phase reads, so the next particle phase
 // starts without another barrier.  Out: vin.g = g_new (written by wave 0), bj1/bj2 ready.
 // STEM: fc_g1/fc_g2 (no g input, no residual, no local biases) and a trailing barrier (vin.g is read next).
-template <bool STEM, bool SAVE>
+template <bool STEM, bool SAVE, bool TB = false>
 __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __restrict__ blob, blob_rsrc rs,
                                               const pfm_dense_lin& gl1, const pfm_dense_lin& gl2,
                                               const LocalBiasSrc& lb, float* __restrict__ lds, const Carve& c,
                                               float* __restrict__ save_g1, float* __restrict__ save_g,
-                                              const f32x4 (&gw)[GW], f32x4 (&a_next)[8], int64_t a_next_off) {
+                                              const f32x4 (&gw)[GW], f32x4 (&a_next)[8], int64_t a_next_off,
+                                              const float* __restrict__ tb = nullptr) {
+    static_assert(!(STEM && TB), "the stem keeps its time rows");
+    const int tp = TB ? (j.T >> 4) : 0;  // time panels skipped in every block
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int og = tid >> 4, pt = tid & 15;   // fc_global1 / bias GEMVs
     const int o4 = lane >> 4, part = lane & 15;  // fc_global2: DPP row o4 owns outputs 4*o4.., lanes = rows 16 i + part
@@ -459,31 +469,35 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
     const int K2 = TC + H;
     if (!STEM) PFM_MARK(0);
     // ---- loads whose address does not depend on data, all issued up front (gw already holds 80 VGPRs) ----
-    constexpr int KA = 3, KBp = 2;  // panels kept in registers: local-1 extras (T+Cl+L <= 48), local-2 extras (<= 32)
+    // panels kept in registers: local-1 extras (T+Cl+L <= 48), local-2 extras (<= 32); with TB only what follows the time rows
+    constexpr int KA = TB ? 1 : 3, KBp = TB ? 1 : 2;
     const int Ka = Ke + j.L;        // rows of local linear 1's extras: [temb ; cond_l ; g]
     f32x4 wbA[KA], wbB[KBp];
+    const bool has_b = !TB || 16 * tp < Ke;  // local-2 extras beyond the time rows (cond_l): none for unconditioned jets
     if (!STEM) {
-        gemv4_load<KA>(wbA, rs, lb.We1, Ka, 0, tid);
-        gemv4_load<KBp>(wbB, rs, lb.We2, Ke, 0, tid);
+        gemv4_load<KA>(wbA, rs, lb.We1, Ka, tp, tid);
+        if (has_b) gemv4_load<KBp>(wbB, rs, lb.We2, Ke, tp, tid);
     }
-    constexpr int K2P = 11;  // fc_global2 panels kept in registers (K2 <= 176); wider ones the slow way
+    constexpr int K2P = TB ? 9 : 11;  // fc_global2 panels kept in registers (K2 <= 176); wider ones the slow way
     f32x4 w2[K2P];  // KP16 [k][16]: row k = 16 i + part, outputs 4*o4..4*o4+3
 #pragma unroll
-    for (int i = 0; i < K2P; ++i) w2[i] = bload4(rs, gl2.W + i * 256, (part * 16 + 4 * o4) * 4);  // unconditional, see gemv4_load
-    const f32x4 bg1 = bload4(rs, gl1.b, og * 16);
+    for (int i = 0; i < K2P; ++i) w2[i] = bload4(rs, gl2.W + (i + tp) * 256, (part * 16 + 4 * o4) * 4);  // unconditional, see gemv4_load
+    f32x4 bg1 = bload4(rs, gl1.b, og * 16);
+    if (TB) bg1 += *reinterpret_cast<const f32x4*>(tb + TB_G1 + 4 * og);
     f32x4 gold = {0.f, 0.f, 0.f, 0.f};
     if (!STEM) gold = *reinterpret_cast<const f32x4*>(vin + TC + 2 * H + 4 * o4);  // g_old, before anyone overwrites it
-    f32x4 gw2[GW2];  // the panels of fc_global1 beyond the prefetch window: land behind the first GW panels' FMAs
-    gemv4_load<GW2>(gw2, rs, gl1.W, K1, GW, tid);
+    constexpr int GW2w = TB ? GW2 - 2 : GW2;
+    f32x4 gw2[GW2w];  // the panels of fc_global1 beyond the prefetch window: land behind the first GW panels' FMAs
+    gemv4_load<GW2w>(gw2, rs, gl1.W, K1, GW + tp, tid);
     if (!STEM) PFM_MARK(1);
     // ---- fc_global1 ----
     f32x4 p = {0.f, 0.f, 0.f, 0.f};
-    gemv4_fma<GW>(p, gw, vin, K1, 0, pt);
-    gemv4_fma<GW2>(p, gw2, vin, K1, GW, pt);
-    if (K1 > 16 * (GW + GW2)) {  // wider models: the rest the slow way
+    gemv4_fma<GW>(p, gw, vin, K1, tp, pt);
+    gemv4_fma<GW2w>(p, gw2, vin, K1, GW + tp, pt);
+    for (int base = GW + GW2w + tp; 16 * base < K1; base += 4) {  // wider models: the rest the slow way
         f32x4 wa[4];
-        gemv4_load<4>(wa, rs, gl1.W, K1, GW + GW2, tid);
-        gemv4_fma<4>(p, wa, vin, K1, GW + GW2, pt);
+        gemv4_load<4>(wa, rs, gl1.W, K1, base, tid);
+        gemv4_fma<4>(p, wa, vin, K1, base, pt);
     }
     if (!STEM) PFM_MARK(2);
     (void)a_next; (void)a_next_off;  // the next phase's A fragments were issued before the previous particle phase
@@ -496,17 +510,25 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
     }
     if (!STEM) {
         f32x4 p2 = {0.f, 0.f, 0.f, 0.f};
-        gemv4_fma<KBp>(p2, wbB, vin, Ke, 0, pt);
-        for (int base = KBp; 16 * base < Ke; base += KBp) {
-            gemv4_load<KBp>(wbB, rs, lb.We2, Ke, base, tid);
-            gemv4_fma<KBp>(p2, wbB, vin, Ke, base, pt);
+        if (has_b) {
+            gemv4_fma<KBp>(p2, wbB, vin, Ke, tp, pt);
+            for (int base = KBp + tp; 16 * base < Ke; base += KBp) {
+                gemv4_load<KBp>(wbB, rs, lb.We2, Ke, base, tid);
+                gemv4_fma<KBp>(p2, wbB, vin, Ke, base, pt);
+            }
+            p2 = reduce_pt(p2);
         }
-        p2 = reduce_pt(p2);
-        if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.bj2 + 4 * og) = p2 + bload4(rs, lb.b2, og * 16);
+        if (pt == 0) {
+            f32x4 b2 = p2 + bload4(rs, lb.b2, og * 16);
+            if (TB) b2 += *reinterpret_cast<const f32x4*>(tb + TB_L2 + 4 * og);
+            *reinterpret_cast<f32x4*>(lds + c.bj2 + 4 * og) = b2;
+        }
     }
-    const f32x4 bg2 = bload4(rs, gl2.b, o4 * 16);  // padded to 16 entries
+    f32x4 bg2 = bload4(rs, gl2.b, o4 * 16);  // padded to 16 entries
+    if (TB) bg2 += *reinterpret_cast<const f32x4*>(tb + TB_G2 + 4 * o4);
     f32x4 bl1 = {0.f, 0.f, 0.f, 0.f};
     if (!STEM) bl1 = bload4(rs, lb.b1, og * 16);
+    if (TB) bl1 += *reinterpret_cast<const f32x4*>(tb + TB_L1 + 4 * og);
     if (!STEM) PFM_MARK(3);
     __syncthreads();
     if (!STEM) PFM_MARK(4);
@@ -514,10 +536,10 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
     f32x4 gn = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < K2P; ++i) {
-        const int k = 16 * i + part;
+        const int k = 16 * (i + tp) + part;
         gn += w2[i] * (k < K2 ? vin2[k] : 0.f);
     }
-    for (int i = K2P; 16 * i < K2; ++i) {
+    for (int i = K2P + tp; 16 * i < K2; ++i) {
         const int k = 16 * i + part;
         gn += bload4(rs, gl2.W + i * 256, (part * 16 + 4 * o4) * 4) * (k < K2 ? vin2[k] : 0.f);
     }
@@ -539,11 +561,11 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
         f32x4 p1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < KA; ++i) {
-            const int k = 16 * i + pt;
+            const int k = 16 * (i + tp) + pt;
             const float x = k < Ke ? vin[k] : (k < Ka ? gcopy[k - Ke] : 0.f);
             p1 += wbA[i] * x;
         }
-        for (int base = KA; 16 * base < Ka; ++base) {  // wider extras than the register window
+        for (int base = KA + tp; 16 * base < Ka; ++base) {  // wider extras than the register window
             f32x4 wx[1];
             gemv4_load<1>(wx, rs, lb.We1, Ka, base, tid);
             const int k = 16 * base + pt;
@@ -604,11 +626,12 @@ __device__ __forceinline__ void stem_l1(const pfm_epic_desc& d, const JetDims& j
 
 // Full network body up to (excluding) the fc_l3 head.  Preconditions (in LDS): yin (N x F input),
 // maskf, misc[0] = sum(mask), vin.temb, vin.cond.  Postcondition: bufB holds the last hidden state.
-template <bool SAVE, int MODE = 0>
+template <bool SAVE, int MODE = 0, bool TB = false>
 __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims& j,
                                           const float* __restrict__ blob, float* __restrict__ lds,
                                           const Carve& c, int n_rows, float* __restrict__ saved,
-                                          const SavedLayout& sl) {
+                                          const SavedLayout& sl, const float* __restrict__ tb = nullptr) {
+    const int tp = TB ? (j.T >> 4) : 0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float* bufA = lds + c.bufA;
     float* bufB = lds + c.bufB;
@@ -648,7 +671,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     {
         LocalBiasSrc none; none.We1 = none.b1 = none.We2 = none.b2 = 0;
         per_jet_phase<true, SAVE>(j, blob, rs, d.g1, d.g2, none, lds, c, saved + sl.gstem1, saved + sl.gstem, gw, a1, -1);
-        if (j.layers > 0) prefetch_gl1(gw, rs, d.layer[0].gl1, K1l);  // no particle phase in between: exposed once
+        if (j.layers > 0) prefetch_gl1(gw, rs, d.layer[0].gl1, K1l, tp);  // no particle phase in between: exposed once
     }
     // ---- EPiC layers (epic.py:382-385 -> :159-203) -----------------------------------------------
     for (int k = 0; k < j.layers; ++k) {
@@ -656,8 +679,8 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
         PFM_STAMP(10);
         // vin still holds mean / sum of the current hidden state (bufB) and g
         LocalBiasSrc lb; lb.We1 = ly.lc1.We; lb.b1 = ly.lc1.b; lb.We2 = ly.lc2.We; lb.b2 = ly.lc2.b;
-        per_jet_phase<false, SAVE>(j, blob, rs, ly.gl1, ly.gl2, lb, lds, c, saved + sl.glayer + k * sl.gstride,
-                                   saved + sl.glayer + k * sl.gstride + H, gw, a1, ly.lc1.A);
+        per_jet_phase<false, SAVE, TB>(j, blob, rs, ly.gl1, ly.gl2, lb, lds, c, saved + sl.glayer + k * sl.gstride,
+                                       saved + sl.glayer + k * sl.gstride + H, gw, a1, ly.lc1.A, TB ? tb + k * TB_SLOT : nullptr);
         PFM_STAMP(12);
         load_afrag_m<MODE>(a2, rs, ly.lc2.A, w, lane);  // lands behind phase 1's MFMAs
         // phase 1: bufA = lrelu(W1 . bufB + bj1)                       epic.py:194-196
@@ -667,7 +690,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
         __syncthreads();
         PFM_STAMP(13);
         if (k + 1 < j.layers) {
-            prefetch_gl1(gw, rs, d.layer[k + 1].gl1, K1l);
+            prefetch_gl1(gw, rs, d.layer[k + 1].gl1, K1l, tp);
             load_afrag_m<MODE>(a1, rs, d.layer[k + 1].lc1.A, w, lane);  // next layer's phase-1 weights, in flight across phase 2
         }
         // phase 2: bufB = lrelu(W2 . bufA + bj2 + bufB), pooled -> vin    epic.py:198-200, :160-162

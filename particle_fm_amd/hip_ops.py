@@ -176,7 +176,7 @@ def epic_sample_rk(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor, cond
 
 def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor,
                          cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-                         ode_steps: int = 100, premask: bool = True) -> torch.Tensor:
+                         ode_steps: int = 100, premask: bool = True, time_table: bool = True) -> torch.Tensor:
     """x(0) from x(1) = z*mask by ode_steps-1 explicit-midpoint intervals, one persistent launch.
     The kernel multiplies the start state by the mask (SetFlowMatchingLitModule.sample does, :668-671);
     ``premask`` is informational: masking twice is idempotent for a 0/1 mask."""
@@ -187,8 +187,16 @@ def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor
     ts, dts = midpoint_grid(ode_steps)
     ts, dts = ts.to(dev), dts.to(dev)
     out = torch.empty_like(z)
+    # time-term table of the call (every jet is evaluated at the same times): cached per (layout, steps, device)
+    cache = layout.__dict__.setdefault("_sample_scratch", {})
+    key = (ode_steps, str(dev))
+    if key not in cache:
+        cache.clear()
+        cache[key] = torch.empty(max(1, lib.pfm_epic_sample_scratch_floats(ctypes.byref(layout.desc), ode_steps - 1)), device=dev,
+                                 dtype=torch.float32)
     rc = lib.pfm_epic_sample_midpoint(ctypes.byref(layout.desc), _ptr(blob), _ptr(ts), _ptr(dts), ode_steps - 1,
-                                      _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, _stream_ptr(dev))
+                                      _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B,
+                                      _ptr(cache[key] if time_table else None), _stream_ptr(dev))
     _lib.check(rc, "pfm_epic_sample_midpoint")
     return out
 

@@ -29,10 +29,10 @@ ts, dts = midpoint_grid(6)
 ts, dts = ts.cuda(), dts.cuda()
 for it in range(3):
     if MODE == "forward":
-        rc = lib.pfm_epic_forward(ctypes.byref(lay.desc), P(blob.data_ptr()), P(t.data_ptr()), P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, P(0))
+        rc = lib.pfm_epic_forward(ctypes.byref(lay.desc), P(blob.data_ptr()), P(t.data_ptr()), P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, P(0), P(0))
     else:  # stamps of the LAST of 10 evaluations inside the persistent sampler (warm scalar cache, steady state)
         rc = lib.pfm_epic_sample_midpoint(ctypes.byref(lay.desc), P(blob.data_ptr()), P(ts.data_ptr()), P(dts.data_ptr()), 5,
-                                          P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, P(0))
+                                          P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, P(0), P(0))
     assert rc == 0, rc
     buf = (ctypes.c_ulonglong * 512)(); n = ctypes.c_int(0)
     lib.pfm_diag_read_stamps(buf, ctypes.byref(n))

@@ -76,3 +76,15 @@ def test_forward_vs_oracle_bench_shape(hip):
     xp = torch.gather(x, 1, perm[..., None].expand(-1, -1, 3))
     vp = hip.epic_forward(lay, blob, t.cuda(), xp.cuda(), None, mask.cuda()).cpu()
     torch.testing.assert_close(vp, torch.gather(v, 1, perm[..., None].expand(-1, -1, 3)), atol=2e-6, rtol=1e-5)
+
+
+def test_time_term_table_is_a_pure_optimisation(hip, golden):
+    """The sampler tabulates the time columns of the per-jet Linears once per call (all jets share the evaluation times) and
+    skips those weight rows in the kernel: same trajectory as the kernel that fetches them (sum order differs: ~1e-7)."""
+    lay, blob = _setup(golden)
+    tag = "midpoint_10/"
+    z, mask, cond = golden.get(tag + "z"), golden.get(tag + "mask"), golden.get(tag + "cond")
+    a = hip.epic_sample_midpoint(lay, blob, _dev(z), _dev(cond), _dev(mask), ode_steps=10, time_table=True).cpu()
+    b = hip.epic_sample_midpoint(lay, blob, _dev(z), _dev(cond), _dev(mask), ode_steps=10, time_table=False).cpu()
+    torch.testing.assert_close(a, b, atol=5e-6, rtol=1e-5)
+    torch.testing.assert_close(a, golden.get(tag + "x_end"), atol=5e-5, rtol=1e-4)
