@@ -60,8 +60,11 @@ def test_euler_rk4_and_midpoint_tableau(family):
         torch.testing.assert_close(got, ref, atol=1e-4, rtol=1e-3)
     # the generic scheme with the midpoint tableau reproduces the tuned midpoint sampler bit for bit
     a = sample_rk(lay, blob, _dev(z), _dev(cond), _dev(mask), ode_steps=10, solver="midpoint").cpu()
-    b = sample_mid(lay, blob, _dev(z), _dev(cond), _dev(mask), ode_steps=10).cpu()
+    kw = dict(time_table=False) if family == "epic" else {}  # the tuned EPiC sampler's time-term table changes the sum order
+    b = sample_mid(lay, blob, _dev(z), _dev(cond), _dev(mask), ode_steps=10, **kw).cpu()
     assert torch.equal(a, b)
+    if kw:
+        torch.testing.assert_close(sample_mid(lay, blob, _dev(z), _dev(cond), _dev(mask), ode_steps=10).cpu(), a, atol=5e-6, rtol=1e-5)
     torch.testing.assert_close(a, g.get(tag + "x_end"), atol=2e-4, rtol=1e-3)
 
 
