@@ -226,7 +226,7 @@ def main():
         executed = rows * 13 * 2 * 128 * 128 * n_nfe / (sample_ms * 1e-3)
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")))["pfm::epic_sample_midpoint_kernel"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_hbm_summary.json")))["pfm::epic_sample_midpoint_kernel<0, true>"]
             traffic = (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         except Exception:
             pass
@@ -247,13 +247,13 @@ def main():
             "train_ms": train_ms, "sample_ms": sample_ms,
             "train_jets_per_s": B * world / (train_ms * 1e-3), "sample_jets_per_s": B * world / (sample_ms * 1e-3),
             "roofline": {
-                "bound": "mfma", "kernel": "epic_sample_midpoint_kernel", "achieved": achieved / 1e12,
+                "bound": "mfma", "kernel": "epic_sample_midpoint_kernel<0, true>", "achieved": achieved / 1e12,
                 "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK, "traffic": traffic,
                 "executed_on_mfma": executed / 1e12,
                 "note": f"algorithmic {NFE_FLOP_PER_JET/1e6:.2f} MFLOP/jet/NFE x {n_nfe} NFE x {B} jets per launch "
                         "(dense over padded N, concatenated t/cond columns counted) / HIP-event launch time; executed_on_mfma = "
                         "TFLOP/s the matrix cores really ran (tile pairs up to each jet's last valid particle); traffic = "
-                        "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/round1_pmc_summary.json",
+                        "HBM-side bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/round1_pmc_hbm_summary.json (it counts each of the 8 XCD L2s fetching the weights and the time-term table once, Infinity-Cache hits included)",
             },
         }
         if world == 1:
