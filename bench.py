@@ -122,15 +122,16 @@ def cpu_baseline(state, freqs, ode_steps, jets=64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="jets per GPU (BASELINE config: 256)")
     ap.add_argument("--ode-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", type=int, default=1,
+    ap.add_argument("--overlap", type=int, default=2,
                     help="sampling launches in flight: step i's sample runs on its own HIP stream with a weight snapshot "
-                         "while step i+1 trains (1 = strictly sequential, the default: per-launch times then match rocprof; "
-                         "2 measured +9 % jets/s on one MI355X)")
+                         "while step i+1 trains and the next sample starts (default 2: +13 % jets/s on one MI355X -- a launch lasts "
+                         "as long as its largest jet, the CUs that finish early pick up the next launch's jets; 1 = strictly "
+                         "sequential, one launch at a time)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,9 +172,9 @@ def main():
 
     def step(i, ev=None):
         s = i % D
+        main.wait_event(done[s])          # snapshot slot s is free again (sample i-D has finished)
         if ev:
             ev[0].record(main)
-        main.wait_event(done[s])          # snapshot slot s is free again (sample i-D has finished)
         trainer.step((x, mask, cond))
         trainer.snapshot_blob(N, out=snaps[s])
         if ev:
@@ -216,6 +217,20 @@ def main():
     sample_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / args.steps  # on the stream the sampler was launched on
     assert torch.isfinite(out).all()
 
+    # the dominant kernel alone on the GPU (outside the timed region): with --overlap > 1 the launches of the timed region
+    # share the machine, so their individual durations say little about the kernel itself
+    excl_ms = sample_ms
+    if D > 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            e0.record(main)
+            for _ in range(3):
+                model(z, cond=None, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps, weights=snaps[0])
+            e1.record(main)
+        torch.cuda.synchronize(dev)
+        excl_ms = e0.elapsed_time(e1) / 3
+
     if rank == 0:
         jets_per_step = B * world
         value = jets_per_step * args.steps / elapsed
@@ -223,7 +238,7 @@ def main():
         # what the matrix cores actually execute: 13 Linears of 128x128 per evaluation on 32-row tile pairs up to the
         # last valid particle of each jet (folded t/cond/g columns and fully masked tiles are not computed)
         rows = ((mask.sum((1, 2)).cpu() + 31) // 32 * 32).sum().item()
-        executed = rows * 13 * 2 * 128 * 128 * n_nfe / (sample_ms * 1e-3)
+        executed = rows * 13 * 2 * 128 * 128 * n_nfe * args.steps / elapsed  # whole timed region (launches may overlap)
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_hbm_summary.json")))["pfm::epic_sample_midpoint_kernel<0, true>"]
@@ -250,9 +265,17 @@ def main():
                 "bound": "mfma", "kernel": "epic_sample_midpoint_kernel<0, true>", "achieved": achieved / 1e12,
                 "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK, "traffic": traffic,
                 "executed_on_mfma": executed / 1e12,
+                "concurrent_launches": D,
+                "aggregate_achieved": B * n_nfe * NFE_FLOP_PER_JET * args.steps / elapsed / 1e12,
+                "frac_aggregate": B * n_nfe * NFE_FLOP_PER_JET * args.steps / elapsed / FP32_MFMA_PEAK,
+                "frac_exclusive": B * n_nfe * NFE_FLOP_PER_JET / (excl_ms * 1e-3) / FP32_MFMA_PEAK,
                 "note": f"algorithmic {NFE_FLOP_PER_JET/1e6:.2f} MFLOP/jet/NFE x {n_nfe} NFE x {B} jets per launch "
-                        "(dense over padded N, concatenated t/cond columns counted) / HIP-event launch time; executed_on_mfma = "
-                        "TFLOP/s the matrix cores really ran (tile pairs up to each jet's last valid particle); traffic = "
+                        "(dense over padded N, concatenated t/cond columns counted) / HIP-event launch time in the timed region; with "
+                        "concurrent_launches = 2 two sampler launches share the GPU (a launch lasts as long as its largest jet, the CUs "
+                        "that finish early pick up the next launch's jets), so a launch takes ~1.5x longer while the GPU completes one "
+                        "every ms_per_step: frac_aggregate = all launches' algorithmic FLOP / timed wall time / peak, frac_exclusive = "
+                        "the same kernel alone on the GPU (3 launches after the timed region); executed_on_mfma = "
+                        "TFLOP/s the matrix cores really ran over the timed region (tile pairs up to each jet's last valid particle); traffic = "
                         "HBM-side bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/round1_pmc_hbm_summary.json (it counts each of the 8 XCD L2s fetching the weights and the time-term table once, Infinity-Cache hits included)",
             },
         }

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/bench_prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 5 --warmup 2 > $O/bench_line.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py > $O/bench_line.json 2> $O/stats.err
 rm -f $O/stats/*trace.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o bench -- python3 $R/bench.py --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o bench -- python3 $R/bench.py --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.err
