@@ -189,9 +189,10 @@ def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor
     out = torch.empty_like(z)
     # time-term table of the call (every jet is evaluated at the same times): cached per (layout, steps, device)
     cache = layout.__dict__.setdefault("_sample_scratch", {})
-    key = (ode_steps, str(dev))
+    key = (ode_steps, str(dev), torch.cuda.current_stream(dev).cuda_stream)  # per stream: launches on two streams may overlap
     if key not in cache:
-        cache.clear()
+        for k in [k for k in cache if k[:2] != key[:2]]:
+            del cache[k]
         cache[key] = torch.empty(max(1, lib.pfm_epic_sample_scratch_floats(ctypes.byref(layout.desc), ode_steps - 1)), device=dev,
                                  dtype=torch.float32)
     rc = lib.pfm_epic_sample_midpoint(ctypes.byref(layout.desc), _ptr(blob), _ptr(ts), _ptr(dts), ode_steps - 1,
