@@ -147,10 +147,13 @@ int pfm_epic_forward_temb(const pfm_epic_desc *desc, const float *blob, const fl
 /* Fixed-step explicit midpoint over n_intervals steps, all inside one launch:
  *   x <- z*mask;  for k: k1 = f(t_eval[2k], x); xm = x + 0.5*dt[k]*k1; x <- x + dt[k]*f(t_eval[2k+1], xm)
  * t_eval[2*n_intervals], dt[n_intervals] are the fp32 values the reference's driver visits.
- * scratch (pfm_epic_sample_scratch_floats(desc, n_intervals) floats, or NULL): every jet is evaluated at the same times, so
- * the time columns of the per-jet Linears give jet-independent vectors; with scratch they are tabulated once per call (a
- * second, tiny launch) and the per-jet phase of the kernel skips those weight rows. */
-int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc *desc, int32_t n_intervals);
+ * scratch (pfm_epic_sample_scratch_floats(desc, n_intervals, B) floats, or NULL) enables two things that do not change results
+ * beyond fp32 rounding: (1) every jet is evaluated at the same times, so the time columns of the per-jet Linears give
+ * jet-independent vectors: they are tabulated once per call (a tiny launch) and the kernel's per-jet phase skips those weight rows;
+ * (2) with a mask, workgroups take the jets in descending multiplicity (a one-workgroup ranking launch): a jet's run time grows
+ * with its valid particles and workgroups are dispatched in order, so the short jets fill the tail of a launch -- and, when
+ * several launches are in flight, the gaps of the previous one -- instead of a long jet starting last. */
+int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc *desc, int32_t n_intervals, int32_t B);
 int pfm_epic_sample_midpoint(const pfm_epic_desc *desc, const float *blob, const float *t_eval,
                              const float *dt, int32_t n_intervals, const float *z, const float *cond,
                              const float *mask, float *x_out, int32_t B, float *scratch, void *stream);
@@ -170,7 +173,8 @@ typedef struct {
 
 /* Fixed-step explicit Runge-Kutta over n_intervals steps, all inside one launch: x <- z*mask, then the scheme above per
  * interval.  t_eval[n_intervals * stages] = the stage times t_k + c[s] dt_k, dt[n_intervals]: the fp32 values the reference's
- * driver visits.  kbuf: B * stages * N * F floats of scratch (the stage slopes of every jet).
+ * driver visits.  kbuf: B * stages * N * F floats of scratch (the stage slopes of every jet) + B more (rounded up to 64) for the
+ * jet launch order (see pfm_epic_sample_midpoint).
  * rhs (NULL for flow matching): [n_intervals * stages][2] = (-0.5 beta(t), noise_rate(t)) at every stage time: the ODE
  * right-hand side becomes rhs0 * (x - f(t, x) / rhs1), the probability-flow ODE of a noise-predicting network
  * (ode_wrapper.forward for loss_type="diffusion", flow_matching_module.py:62-69). */

@@ -122,12 +122,12 @@ template <int MODE, bool TB>
 __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
     const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ t_eval,
     const float* __restrict__ dt, int n_intervals, const float* __restrict__ z, const float* __restrict__ cond,
-    const float* __restrict__ mask, float* __restrict__ x_out, const float* __restrict__ table) {
+    const float* __restrict__ mask, float* __restrict__ x_out, const float* __restrict__ table, const int* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d0);
     const Carve c = make_carve(j.N, j.F);
-    const int jet = blockIdx.x, tid = threadIdx.x;
+    const int jet = order ? order[blockIdx.x] : blockIdx.x, tid = threadIdx.x;  // longest jets first (epic_jet_order_kernel)
     const int n_rows = epic_jet_setup(d0, j, blob, lds, c, cond ? cond + (size_t)jet * j.C : nullptr,
                                       mask ? mask + (size_t)jet * j.N : nullptr);
     const float* zj = z + (size_t)jet * j.N * j.F;
@@ -165,12 +165,13 @@ template <int MODE>
 __global__ __launch_bounds__(NT, 2) void epic_sample_rk_kernel(
     const float* __restrict__ blob, int64_t desc_off, pfm_rk_tableau tab, const float* __restrict__ t_eval,
     const float* __restrict__ dt, int n_intervals, const float* __restrict__ z, const float* __restrict__ cond,
-    const float* __restrict__ mask, float* __restrict__ x_out, float* __restrict__ kbuf, const float* __restrict__ rhs) {
+    const float* __restrict__ mask, float* __restrict__ x_out, float* __restrict__ kbuf, const float* __restrict__ rhs,
+    const int* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d0);
     const Carve c = make_carve(j.N, j.F);
-    const int jet = blockIdx.x, tid = threadIdx.x;
+    const int jet = order ? order[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
     const int n_rows = epic_jet_setup(d0, j, blob, lds, c, cond ? cond + (size_t)jet * j.C : nullptr,
                                       mask ? mask + (size_t)jet * j.N : nullptr);
     const int NF = j.N * j.F, F = j.F, S = tab.stages;
@@ -248,6 +249,31 @@ __global__ __launch_bounds__(NT) void epic_time_table_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Launch order of the jets of a sampling call: descending multiplicity (ties by index).  A jet's run time grows with its
+// number of valid particles (masked tail tiles are skipped) and workgroups are dispatched in blockIdx order as CUs free up, so
+// "longest first" is the classic LPT schedule: with more jets than CUs, or several launches in flight, the short jets fill the
+// tail instead of a long jet starting last.  order[rank] = jet; every jet still writes its own rows: results do not change.
+// One workgroup; B <= ORDER_MAX_JETS (larger batches keep the identity order).
+// ------------------------------------------------------------------------------------------------
+constexpr int ORDER_MAX_JETS = 8192;
+__global__ __launch_bounds__(1024) void epic_jet_order_kernel(const float* __restrict__ mask, int B, int N, int* __restrict__ order) {
+    __shared__ int cnt[ORDER_MAX_JETS];
+    const int tid = threadIdx.x;
+    for (int jet = tid; jet < B; jet += 1024) {
+        int c = 0;
+        for (int r = 0; r < N; ++r) c += mask[(int64_t)jet * N + r] != 0.f;
+        cnt[jet] = c;
+    }
+    __syncthreads();
+    for (int jet = tid; jet < B; jet += 1024) {
+        const int c = cnt[jet];
+        int rank = 0;
+        for (int k = 0; k < B; ++k) rank += (cnt[k] > c) || (cnt[k] == c && k < jet);
+        order[rank] = jet;
+    }
+}
+
 // which matrix-pipe flavour the inference kernels use (descriptor flags): 0 fp32, 1 bf16 operands, 2 split fp16
 int mfma_mode(const pfm_epic_desc* d) {
     if (!d) return 0;
@@ -320,9 +346,18 @@ int pfm_epic_forward_temb(const pfm_epic_desc* d, const float* blob, const float
     return check_hip(hipGetLastError(), "epic_forward_kernel launch");
 }
 
-int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc* d, int32_t n_intervals) {
-    if (!d || n_intervals < 0) return -1;
-    return (int64_t)2 * n_intervals * d->layers * TB_SLOT;
+// scratch of a sampling call: time-term table [2 n_intervals][layers][TB_SLOT] | jet order [B] (int32)
+int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc* d, int32_t n_intervals, int32_t B) {
+    if (!d || n_intervals < 0 || B < 0) return -1;
+    return (int64_t)2 * n_intervals * d->layers * TB_SLOT + ((B + 63) & ~63);
+}
+
+// device pointer of the jet order inside `scratch`, after queueing its computation; nullptr: identity order
+static const int* queue_jet_order(const pfm_epic_desc* d, float* scratch, int64_t table_floats, const float* mask, int B, hipStream_t s) {
+    if (!scratch || !mask || B < 2 || B > ORDER_MAX_JETS) return nullptr;
+    int* order = reinterpret_cast<int*>(scratch + table_floats);
+    hipLaunchKernelGGL(epic_jet_order_kernel, dim3(1), dim3(1024), 0, s, mask, B, d->n_points, order);
+    return order;
 }
 
 int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const float* t_eval, const float* dt,
@@ -349,7 +384,8 @@ int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const fl
     }
 #define PFM_LAUNCH_SMP(M, T)                                                                                                  \
     hipLaunchKernelGGL((epic_sample_midpoint_kernel<M, T>), dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, \
-                       t_eval, dt, n_intervals, z, cond, mask, x_out, (const float*)scratch)
+                       t_eval, dt, n_intervals, z, cond, mask, x_out, (const float*)scratch, order)
+    const int* order = queue_jet_order(d, scratch, (int64_t)2 * n_intervals * d->layers * TB_SLOT, mask, B, (hipStream_t)stream);
     if (tb) { if (mode == 2) PFM_LAUNCH_SMP(2, true); else if (mode == 1) PFM_LAUNCH_SMP(1, true); else PFM_LAUNCH_SMP(0, true); }
     else { if (mode == 2) PFM_LAUNCH_SMP(2, false); else if (mode == 1) PFM_LAUNCH_SMP(1, false); else PFM_LAUNCH_SMP(0, false); }
 #undef PFM_LAUNCH_SMP
@@ -371,7 +407,8 @@ int pfm_epic_sample_rk(const pfm_epic_desc* d, const float* blob, const pfm_rk_t
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
 #define PFM_LAUNCH_RK(M)                                                                                                    \
     hipLaunchKernelGGL(epic_sample_rk_kernel<M>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, *tab, \
-                       t_eval, dt, n_intervals, z, cond, mask, x_out, kbuf, rhs)
+                       t_eval, dt, n_intervals, z, cond, mask, x_out, kbuf, rhs, order)
+    const int* order = queue_jet_order(d, kbuf, (int64_t)B * tab->stages * d->n_points * d->features, mask, B, (hipStream_t)stream);
     if (mode == 2) PFM_LAUNCH_RK(2); else if (mode == 1) PFM_LAUNCH_RK(1); else PFM_LAUNCH_RK(0);
 #undef PFM_LAUNCH_RK
     return check_hip(hipGetLastError(), "epic_sample_rk_kernel launch");

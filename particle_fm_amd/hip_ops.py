@@ -163,7 +163,7 @@ def epic_sample_rk(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor, cond
     ts, dts = rk_grid(ode_steps, solver, t0, t1)
     ts, dts = ts.to(dev), dts.to(dev)
     out = torch.empty_like(z)
-    kbuf = torch.empty(tab.stages * z.numel(), device=dev, dtype=torch.float32)
+    kbuf = torch.empty(tab.stages * z.numel() + ((B + 63) // 64) * 64, device=dev, dtype=torch.float32)  # stage slopes | jet order
     rhs = None
     if diff_config is not None:
         _, nr, beta = diffusion_schedule(ts, **diff_config)
@@ -189,11 +189,11 @@ def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor
     out = torch.empty_like(z)
     # time-term table of the call (every jet is evaluated at the same times): cached per (layout, steps, device)
     cache = layout.__dict__.setdefault("_sample_scratch", {})
-    key = (ode_steps, str(dev), torch.cuda.current_stream(dev).cuda_stream)  # per stream: launches on two streams may overlap
+    key = (ode_steps, str(dev), torch.cuda.current_stream(dev).cuda_stream, B)  # per stream: launches on two streams may overlap
     if key not in cache:
         for k in [k for k in cache if k[:2] != key[:2]]:
             del cache[k]
-        cache[key] = torch.empty(max(1, lib.pfm_epic_sample_scratch_floats(ctypes.byref(layout.desc), ode_steps - 1)), device=dev,
+        cache[key] = torch.empty(max(1, lib.pfm_epic_sample_scratch_floats(ctypes.byref(layout.desc), ode_steps - 1, B)), device=dev,
                                  dtype=torch.float32)
     rc = lib.pfm_epic_sample_midpoint(ctypes.byref(layout.desc), _ptr(blob), _ptr(ts), _ptr(dts), ode_steps - 1,
                                       _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B,
