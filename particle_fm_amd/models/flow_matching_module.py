@@ -346,8 +346,10 @@ class SetFlowMatchingLitModule(_LitBase):
 
     @torch.no_grad()
     def sample(self, n_samples: int, cond: torch.Tensor = None, mask: torch.Tensor = None,
-               ode_solver: str = "midpoint", ode_steps: int = 100, num_points: int = None):
-        """flow_matching_module.py:637-677: z ~ N(0,1) drawn on the CPU generator, masked, integrated 1 -> 0."""
+               ode_solver: str = "midpoint", ode_steps: int = 100, num_points: int = None, weights: torch.Tensor = None):
+        """flow_matching_module.py:637-677: z ~ N(0,1) drawn on the CPU generator, masked, integrated 1 -> 0.
+        `weights` (extension): an already packed kernel blob (``flows[0].net.packed_weights()``), so that a loop over batches
+        packs the parameters once."""
         prec = getattr(getattr(self, "trainer", None), "precision", None)
         if prec is not None:  # trainer.precision = "bf16-mixed" -> bf16 MFMA in the sampler (EPiC jet-resident path)
             for f in self.flows:
@@ -362,7 +364,7 @@ class SetFlowMatchingLitModule(_LitBase):
         if mask is not None:
             mask = mask[:n_samples].to(self.device)
             z = z * mask
-        samples = self.forward(z, cond=cond, mask=mask, reverse=True, ode_solver=ode_solver, ode_steps=ode_steps)
+        samples = self.forward(z, cond=cond, mask=mask, reverse=True, ode_solver=ode_solver, ode_steps=ode_steps, weights=weights)
         if self.hparams.use_normaliser:
             # :675-676 passes the (B,N,1) float mask straight into boolean indexing, which torch rejects; the intent
             # (un-normalise the valid particles) is what runs here

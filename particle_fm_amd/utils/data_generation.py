@@ -9,6 +9,7 @@ measures the generation, not the enqueue.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import time
 from typing import Optional
@@ -55,7 +56,7 @@ def generate_data(model, num_jet_samples: int, batch_size: int = 256, cond: torc
                   variable_set_sizes: bool = False, mask: torch.Tensor = None, normalized_data: bool = False,
                   normalize_sigma: int = 5, means=None, stds=None, log_pt: bool = False, pt_standardization: bool = False,
                   shuffle_mask: bool = False, verbose: bool = True, ode_solver: str = "midpoint", ode_steps: int = 100,
-                  valid_rows_only: bool = True):
+                  valid_rows_only: bool = True, pipeline: bool = True):
     if variable_set_sizes and mask is None:
         raise ValueError("Please use mask when using variable_set_sizes=True")  # data_generation.py:62-63
     if mask is not None and len(mask) != num_jet_samples:
@@ -75,29 +76,85 @@ def generate_data(model, num_jet_samples: int, batch_size: int = 256, cond: torc
                 switched.append(net)
     try:
         return _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes, mask, normalized_data, normalize_sigma,
-                         means, stds, log_pt, pt_standardization, shuffle_mask, ode_solver, ode_steps)
+                         means, stds, log_pt, pt_standardization, shuffle_mask, ode_solver, ode_steps, pipeline)
     finally:
         for net in switched:
             net.set_valid_rows_only(False)
 
 
+_PIPE_STREAMS = {}
+
+
+def _pipeline_streams(dev):
+    """the two side streams of the batch pipeline, created once per device (stream -> hardware-queue mapping is fixed at
+    creation; a fresh pair per call occasionally lands both on one queue and the overlap is lost)"""
+    key = str(dev)
+    if key not in _PIPE_STREAMS:
+        _PIPE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    return _PIPE_STREAMS[key]
+
+
+def _jet_resident(model) -> bool:
+    """a single flow on the jet-resident EPiC kernel: launches share no activation workspace"""
+    flows = list(getattr(model, "flows", []))
+    return len(flows) == 1 and hasattr(flows[0].net, "source_vector") and not getattr(flows[0].net, "wide", False)
+
+
 def _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes, mask, normalized_data, normalize_sigma, means, stds,
-              log_pt, pt_standardization, shuffle_mask, ode_solver, ode_steps):
+              log_pt, pt_standardization, shuffle_mask, ode_solver, ode_steps, pipeline):
     n_full = num_jet_samples // batch_size
     rem = num_jet_samples - n_full * batch_size
     scale = shift = None
     outs = []
     start_time = 0.0
+    # Jet-resident EPiC (extension `pipeline`): the parameters are packed once for all batches, and consecutive batches alternate
+    # between two streams -- a sampler launch lasts as long as its largest jet, and with the jets taken longest-first the next
+    # batch starts in the gaps of the current one.  Same draws in the same order (CPU generator), same results.
+    blob, streams = None, None
+    if pipeline and dev.type == "cuda" and _jet_resident(model) and ode_solver == "midpoint":
+        with torch.no_grad():
+            blob = model.flows[0].net.packed_weights(getattr(model.hparams, "num_particles", None))
+        streams = _pipeline_streams(dev)
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream(dev))
+
+    pinned, staged = None, [None, None]
+    if streams and not getattr(model.hparams, "use_normaliser", False):
+        # sample() inlined (flow_matching_module.py:656-674) so that nothing in the loop blocks the host: z is drawn by the same
+        # torch.randn call into a pinned buffer (one per stream, reused once its copy has been consumed) and copied asynchronously
+        N_, F_ = model.hparams.num_particles, model.hparams.features
+        pinned = [torch.empty(batch_size, N_, F_, pin_memory=True) for _ in range(2)]
 
     def one_batch(n, cond_b, mask_b):
         nonlocal scale, shift
-        with torch.no_grad():
-            x = model.sample(n_samples=n, cond=cond_b, mask=mask_b, ode_solver=ode_solver, ode_steps=ode_steps)
-        x = x.contiguous()
-        if normalized_data and scale is None:
-            scale, shift = (t.to(dev) for t in _affine(means, stds, x.shape[-1], normalize_sigma, pt_standardization))
-        sample_epilogue_(x, mask_b if variable_set_sizes else None, scale if normalized_data else None,
-                         shift if normalized_data else None, 2 if (normalized_data and log_pt) else -1)
+        k = len(outs) % 2
+        ctx = torch.cuda.stream(streams[k]) if streams else contextlib.nullcontext()
+        with ctx, torch.no_grad():
+            if pinned is not None:
+                if staged[k] is not None:
+                    staged[k].synchronize()  # the H2D copy that last read this pinned buffer
+                zh = pinned[k][:n]
+                torch.randn(n, zh.shape[1], zh.shape[2], out=zh)
+                z = zh.to(dev, non_blocking=True)
+                staged[k] = torch.cuda.Event()
+                staged[k].record()
+                cd = None if cond_b is None else cond_b.to(dev, non_blocking=True)
+                md = None if mask_b is None else mask_b[:n].to(dev, non_blocking=True)
+                if md is not None:
+                    z = z * md
+                x = model.forward(z, cond=cd, mask=md, reverse=True, ode_solver=ode_solver, ode_steps=ode_steps, weights=blob)
+                mask_b = md  # the epilogue below must not copy the host mask again: a pageable copy behind the sampler would
+                             # park the host until the sampler is done
+            else:
+                kw = {"weights": blob} if blob is not None else {}
+                x = model.sample(n_samples=n, cond=cond_b, mask=mask_b, ode_solver=ode_solver, ode_steps=ode_steps, **kw)
+            x = x.contiguous()
+            if normalized_data and scale is None:
+                scale, shift = (t.to(dev) for t in _affine(means, stds, x.shape[-1], normalize_sigma, pt_standardization))
+                if streams:  # made on this stream, read by the other one from the next batch on
+                    torch.cuda.current_stream(dev).synchronize()
+            sample_epilogue_(x, mask_b if variable_set_sizes else None, scale if normalized_data else None,
+                             shift if normalized_data else None, 2 if (normalized_data and log_pt) else -1)
         outs.append(x)
 
     for i in range(n_full):
@@ -125,5 +182,7 @@ def _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes,
         else:
             mask_b = None
         one_batch(rem, cond_b, mask_b)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)  # the remainder batch may have run on a side stream
     data = torch.cat(outs).cpu().numpy() if outs else np.zeros((0,), dtype=np.float32)
     return data, end_time - start_time

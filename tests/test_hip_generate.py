@@ -39,6 +39,13 @@ def test_generate_data_matches_reference_pipeline(pt_std, log_pt):
         xs = sample_midpoint(vf, z, None, mb, ode_steps=steps)
         ref.append(generate_epilogue(xs, mb, True, 5, means, stds, log_pt, pt_std, True))
     torch.testing.assert_close(torch.from_numpy(data), torch.cat(ref), atol=5e-5, rtol=1e-4)
+    # batches alternating between two streams with the weights packed once (the default for this model) give exactly what
+    # one stream and a pack per batch give
+    torch.manual_seed(9999)
+    data1, _ = generate_data(m, n_jets, batch_size=bs, cond=None, device="cuda", variable_set_sizes=True, mask=mask,
+                             normalized_data=True, normalize_sigma=5, means=means, stds=stds, log_pt=log_pt,
+                             pt_standardization=pt_std, verbose=False, ode_solver="midpoint", ode_steps=steps, pipeline=False)
+    assert np.array_equal(data, data1)
 
 
 def test_generate_data_argument_errors():
