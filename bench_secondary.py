@@ -124,30 +124,47 @@ def run(name, args):
     z = (torch.randn(B, N, F, generator=torch.Generator().manual_seed(9999)) * mask.cpu()).to(dev)
     cnd = cond if C else None
 
-    def step(ev=None):
-        if ev:
-            ev[0].record()
-        trainer.step((x, mask, cond))
-        if ev:
-            ev[1].record()
-        with torch.no_grad():
-            out = model(z, cond=cnd, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps)
-        if ev:
-            ev[2].record()
-        return out
+    # step i = train step i (default stream) + sample i with the weights of step i, on stream i % D; D = 2: the sample runs
+    # while step i+1 trains and the next sample is queued (bench.py does the same; all launches are inside the timed region)
+    D = max(1, args.overlap)
+    main = torch.cuda.current_stream(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(D)] if D > 1 else [main]
+    done = [torch.cuda.Event() for _ in range(D)]
+    outs = [None] * D
 
-    for _ in range(args.warmup):
-        step()
+    def step(i, ev=None):
+        s = i % D
+        main.wait_event(done[s])
+        if ev:
+            ev[0].record(main)
+        trainer.step((x, mask, cond))
+        with torch.no_grad():
+            blob = net.packed_weights(N)  # this step's weights, packed on the training stream
+        if ev:
+            ev[1].record(main)
+        streams[s].wait_stream(main)
+        with torch.cuda.stream(streams[s]), torch.no_grad():
+            blob.record_stream(streams[s])
+            if ev:
+                ev[2].record(streams[s])
+            outs[s] = model(z, cond=cnd, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps, weights=blob)
+            if ev:
+                ev[3].record(streams[s])
+            done[s].record(streams[s])
+
+    for i in range(args.warmup):
+        step(i)
     torch.cuda.synchronize(dev)
-    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for e in evs:
-        out = step(e)
+    for i, e in enumerate(evs):
+        step(i, e)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    out = outs[(args.steps - 1) % D]
     assert torch.isfinite(out[mask.squeeze(-1) > 0]).all()
     train_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
-    sample_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
+    sample_ms = sum(e[2].elapsed_time(e[3]) for e in evs) / args.steps  # per sample, on its own stream (samples may overlap)
     n_nfe = 2 * (args.ode_steps - 1)
     achieved = B * n_nfe * flop / (sample_ms * 1e-3)
     # what the matrix cores really ran: the samplers skip padded particles (row work ~ n, self-attention ~ n^2)
@@ -160,14 +177,15 @@ def run(name, args):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else f"f32 ({args.precision} matrix operands)",
         "data": "synthetic",
-        "config": {"workload": what, "jets_per_gpu": B, "parallelism": "dp1", "ode_steps": args.ode_steps,
+        "config": {"workload": what, "jets_per_gpu": B, "parallelism": "dp1", "ode_steps": args.ode_steps, "overlap": D,
                    "multiplicity": f"U{{{n_min}..{N}}} per jet",
                    "sampler_rows": "valid particles only" if (valid_rows or hp["model"] == "epic") else "all N rows (padded included)"},
         "train_ms": train_ms, "sample_ms": sample_ms, "train_jets_per_s": B / (train_ms * 1e-3),
         "sample_jets_per_s": B / (sample_ms * 1e-3),
         "roofline": {"bound": "mfma", "kernel": "sampling launches (tf_linear_kernel dominates)" if name != "jetnet30" else "epic_sample_midpoint_kernel",
                      "achieved": achieved / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK,
-                     "traffic": None, "executed_on_mfma": executed / 1e12,
+                     "traffic": None, "executed_on_mfma": executed / 1e12, "concurrent_launches": D,
+                     "frac_aggregate": B * n_nfe * flop * args.steps / elapsed / FP32_MFMA_PEAK,
                      "note": f"algorithmic {flop/1e6:.1f} MFLOP/jet/NFE (dense over the padded N, SURVEY 8d) x {n_nfe} NFE x {B} jets / HIP-event "
                              "time of the sampling launches; executed_on_mfma = estimate of the TFLOP/s really run (padded particles are "
                              "skipped: row work scaled by mean(n)/N, self-attention by mean(n^2)/N^2)"},
@@ -182,14 +200,15 @@ def run(name, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="all", choices=list(WORKLOADS) + ["all"])
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ode-steps", type=int, default=100)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3", "bf16"],
                     help="matrix operands: f16x3 = split fp16, fp32-grade accuracy (jet-resident EPiC: the sampler; row-matrix paths: "
                          "every Linear, training included); bf16 = the jet-resident EPiC sampler only (BASELINE cfg 2 is quoted in bf16; "
                          "training stays fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", type=int, default=2, help="sampling launches in flight (1 = strictly sequential)")
     ap.add_argument("--dense-rows", action="store_true", help="transformer paths: sample all N rows like the reference (padded included)")
     args = ap.parse_args()
     if not torch.cuda.is_available():

@@ -13,12 +13,13 @@ from .layout_wide import EpicWideLayout
 def workspace(layout: EpicWideLayout, n_jets: int, device, train: bool = False) -> torch.Tensor:
     lib = _lib.load()
     cache = layout.__dict__.setdefault("_ws", {})
-    key = (n_jets, bool(train), str(device))
+    # one workspace per stream: samples queued on two streams may run at the same time
+    key = (n_jets, bool(train), str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in cache:
         n = lib.pfm_ew_workspace_floats(ctypes.byref(layout.desc), n_jets, int(train))
         if n < 0:
             _lib.check(1, "pfm_ew_workspace_floats")
-        for k in [k for k in cache if k[1] == key[1]]:
+        for k in [k for k in cache if k[1] == key[1] and k[0] != key[0]]:
             del cache[k]
         cache[key] = torch.empty(n, device=device, dtype=torch.float32)
     return cache[key]
