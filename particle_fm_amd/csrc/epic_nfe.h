@@ -185,6 +185,14 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
             PFM_MFMA_PAIR(acc0, acc1, a[2 * (qq) + kk], B0[kk], B1[kk]);                                        \
         }                                                                                                      \
     }
+    // the last pair of a jet whose tile count is odd holds one real tile: only that tile's MFMAs are issued
+#define PFM_MFMAQ1(B0, B1, qq)                                                                                 \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                         \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].x, B0[kk].x, acc0, 0, 0, 0);              \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].y, B0[kk].y, acc0, 0, 0, 0);              \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].z, B0[kk].z, acc0, 0, 0, 0);              \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].w, B0[kk].w, acc0, 0, 0, 0);              \
+    }
     PFM_LOADQ(X0, X1, src, 0);
     if (RESID) {
         r0 = *reinterpret_cast<const f32x4*>(resid + ooff);
@@ -229,34 +237,41 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
             psum += v1 ? e1 * m1 : z;
         }
     };
-    for (int pair = 0; pair < npairs; ++pair) {
-        const float* s0 = src + pair * 2 * TILE * H;
-        // hipcc sinks every ds_read down to its first use (read -> wait -> MFMA); the sched_barriers pin each
-        // quarter's reads BEFORE the MFMA block of the previous quarter so their latency hides behind 16 MFMAs.
-        PFM_LOADQ(Y0, Y1, s0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (pair > 0) epilogue_full(pacc0, pacc1, pair - 1);  // pair - 1 <= npairs - 2: every row valid
-        f32x4 acc0 = bias, acc1 = bias;
-        if (RESID) { acc0 += r0; acc1 += r1; }
-        PFM_MFMAQ(X0, X1, 0);
-        PFM_LOADQ(X0, X1, s0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        PFM_MFMAQ(Y0, Y1, 1);
-        PFM_LOADQ(Y0, Y1, s0, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        PFM_MFMAQ(X0, X1, 2);
-        // first quarter of the NEXT pair (one pair past the end on the last iteration: inside the LDS window)
-        PFM_LOADQ(X0, X1, s0 + 2 * TILE * H, 0);
-        if (RESID) {
-            const float* rn = resid + (pair + 1) * 2 * TILE * H;
-            r0 = *reinterpret_cast<const f32x4*>(rn + ooff);
-            r1 = *reinterpret_cast<const f32x4*>(rn + TILE * H + ooff);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        PFM_MFMAQ(Y0, Y1, 3);
-        pacc0 = acc0;
-        pacc1 = acc1;
+    // one pair: hipcc sinks every ds_read down to its first use (read -> wait -> MFMA); the sched_barriers pin each
+    // quarter's reads BEFORE the MFMA block of the previous quarter so their latency hides behind 16 MFMAs.
+#define PFM_PAIR_BODY(MF)                                                                                       \
+    {                                                                                                           \
+        const float* s0 = src + pair * 2 * TILE * H;                                                            \
+        PFM_LOADQ(Y0, Y1, s0, 1);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        if (pair > 0) epilogue_full(pacc0, pacc1, pair - 1); /* pair - 1 <= npairs - 2: every row valid */     \
+        f32x4 acc0 = bias, acc1 = bias;                                                                         \
+        if (RESID) { acc0 += r0; acc1 += r1; }                                                                  \
+        MF(X0, X1, 0);                                                                                          \
+        PFM_LOADQ(X0, X1, s0, 2);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        MF(Y0, Y1, 1);                                                                                          \
+        PFM_LOADQ(Y0, Y1, s0, 3);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        MF(X0, X1, 2);                                                                                          \
+        /* first quarter of the NEXT pair (one pair past the end on the last iteration: inside the LDS window) */ \
+        PFM_LOADQ(X0, X1, s0 + 2 * TILE * H, 0);                                                                \
+        if (RESID) {                                                                                            \
+            const float* rn = resid + (pair + 1) * 2 * TILE * H;                                                \
+            r0 = *reinterpret_cast<const f32x4*>(rn + ooff);                                                    \
+            r1 = *reinterpret_cast<const f32x4*>(rn + TILE * H + ooff);                                         \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        MF(Y0, Y1, 3);                                                                                          \
+        pacc0 = acc0;                                                                                           \
+        pacc1 = acc1;                                                                                           \
     }
+    int pair = 0;
+    for (; pair < npairs - 1; ++pair) PFM_PAIR_BODY(PFM_MFMAQ)
+    if (!BF16 && (2 * pair + 1) * TILE >= n_rows) PFM_PAIR_BODY(PFM_MFMAQ1)  // odd tile count: one real tile in the last pair
+    else PFM_PAIR_BODY(PFM_MFMAQ)
+#undef PFM_PAIR_BODY
+#undef PFM_MFMAQ1
 #undef PFM_LOADQ
 #undef PFM_MFMAQ
     epilogue(pacc0, pacc1, npairs - 1);
