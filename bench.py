@@ -235,9 +235,9 @@ def main():
         jets_per_step = B * world
         value = jets_per_step * args.steps / elapsed
         achieved = B * n_nfe * NFE_FLOP_PER_JET / (sample_ms * 1e-3)
-        # what the matrix cores actually execute: 13 Linears of 128x128 per evaluation on 32-row tile pairs up to the
+        # what the matrix cores actually execute: 13 Linears of 128x128 per evaluation on the 16-row tiles up to the
         # last valid particle of each jet (folded t/cond/g columns and fully masked tiles are not computed)
-        rows = ((mask.sum((1, 2)).cpu() + 31) // 32 * 32).sum().item()
+        rows = ((mask.sum((1, 2)).cpu() + 15) // 16 * 16).sum().item()
         executed = rows * 13 * 2 * 128 * 128 * n_nfe * args.steps / elapsed  # whole timed region (launches may overlap)
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
@@ -275,7 +275,7 @@ def main():
                         "that finish early pick up the next launch's jets), so a launch takes ~1.5x longer while the GPU completes one "
                         "every ms_per_step: frac_aggregate = all launches' algorithmic FLOP / timed wall time / peak, frac_exclusive = "
                         "the same kernel alone on the GPU (3 launches after the timed region); executed_on_mfma = "
-                        "TFLOP/s the matrix cores really ran over the timed region (tile pairs up to each jet's last valid particle); traffic = "
+                        "TFLOP/s the matrix cores really ran over the timed region (16-row tiles up to each jet's last valid particle); traffic = "
                         "HBM-side bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/round1_pmc_hbm_summary.json (it counts each of the 8 XCD L2s fetching the weights and the time-term table once, Infinity-Cache hits included)",
             },
         }
