@@ -589,12 +589,14 @@ int pfm_ew_sample_midpoint(const pfm_ew_desc* d, const float* blob, const float*
     float *xs[2], *xm[2];
     const float *cnd[2], *msk[2];
     int64_t n[2], r0[2];
-    if (ss && (hipEventRecord(ss->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess))
+    // both halves run on the device's two side streams (never on one hardware queue together); the caller's stream forks and joins
+    if (ss && (hipEventRecord(ss->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess ||
+               hipStreamWaitEvent(ss->s2, ss->fork, 0) != hipSuccess))
         return set_err(PFM_E_BADARG, "side stream fork failed");
     for (int i = 0; i < parts; ++i) {
         const int j0 = i ? n_a : 0, nj = parts == 1 ? n_jets : (i ? n_jets - n_a : n_a);
         float* ws = workspace + (i ? ew::make_ws(*d, n_a, false).total : 0);
-        if ((rc = ew::make_plan(p[i], d, blob, ws, nj, false, i ? (void*)ss->s : stream))) return rc;
+        if ((rc = ew::make_plan(p[i], d, blob, ws, nj, false, ss ? (void*)(i ? ss->s2 : ss->s) : stream))) return rc;
         r0[i] = (int64_t)j0 * d->n_points;
         n[i] = (int64_t)p[i].M * d->features;
         xs[i] = state + 2 * r0[i] * d->features;
@@ -619,7 +621,9 @@ int pfm_ew_sample_midpoint(const pfm_ew_desc* d, const float* blob, const float*
             return rc;
     if (ss) {
         hipEventRecord(ss->join, ss->s);
+        hipEventRecord(ss->join2, ss->s2);
         hipStreamWaitEvent((hipStream_t)stream, ss->join, 0);
+        hipStreamWaitEvent((hipStream_t)stream, ss->join2, 0);
     }
     return 0;
 }

@@ -44,8 +44,9 @@ inline int num_cus() {
 // (per-jet GEMMs, context path, global tokens: a few workgroups each) run under the particle-row GEMMs of the other.
 // One side stream + fork / join events per device, created on first use and kept for the life of the process.
 struct SideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t s = nullptr, s2 = nullptr;  // two streams created back to back: the runtime deals hardware queues round-robin
+                                            // at creation, so these two never share one (the caller's stream may share with either)
+    hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
 };
 inline SideStream* side_stream() {
     static SideStream st[16];
@@ -54,9 +55,13 @@ inline SideStream* side_stream() {
     SideStream& e = st[dev];
     if (!e.s) {
         if (hipStreamCreateWithFlags(&e.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess)
+        if (hipStreamCreateWithFlags(&e.s2, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e.join2, hipEventDisableTiming) != hipSuccess) {
+            e.s = nullptr;
             return nullptr;
+        }
     }
     return &e;
 }
@@ -69,19 +74,6 @@ inline int split_point(int n_jets, int min_half) {
     }
     return (on && n_jets >= 2 * min_half) ? n_jets / 2 : 0;
 }
-// f(part, jet0, n, stream) queues one half; the caller's stream waits for the side stream at the end
-template <class F>
-int run_halves(int n_jets, int n_a, hipStream_t s, F f) {
-    SideStream* ss = n_a ? side_stream() : nullptr;
-    if (!ss) return f(0, 0, n_jets, s);
-    if (hipEventRecord(ss->fork, s) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return f(0, 0, n_jets, s);
-    int rc = f(0, 0, n_a, s);
-    const int rc2 = f(1, n_a, n_jets - n_a, ss->s);
-    hipEventRecord(ss->join, ss->s);
-    hipStreamWaitEvent(s, ss->join, 0);
-    return rc ? rc : rc2;
-}
-
 __host__ __device__ inline int64_t round64(int64_t x) { return (x + 63) & ~(int64_t)63; }
 
 __host__ inline Ws make_ws(const pfm_tf_desc& d, int n_jets, bool train) {
