@@ -164,21 +164,28 @@ def main():
     # the next train step may update the parameters meanwhile).  All launches of all K steps are inside the timed
     # region; the fence at the end waits for every stream.  With D = 1 everything is on one stream.
     D = max(1, args.overlap)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(D)] if D > 1 else [torch.cuda.current_stream(dev)]
-    snaps = [trainer.snapshot_blob(N) for _ in range(D)]
+    # D + 1 streams created back to back (the runtime deals hardware queues round-robin at creation: no two of them share one);
+    # with D > 1 the train step runs on the last of them rather than on the default stream, whose queue may coincide with a sampler's
+    pool = [torch.cuda.Stream(device=dev) for _ in range(D + 1)] if D > 1 else []
+    streams = pool[:D] if D > 1 else [torch.cuda.current_stream(dev)]
+    main = pool[D] if D > 1 else torch.cuda.current_stream(dev)
+    if D > 1:
+        main.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(main):
+        snaps = [trainer.snapshot_blob(N) for _ in range(D)]
     outs = [None] * D
     done = [torch.cuda.Event() for _ in range(D)]
-    main = torch.cuda.current_stream(dev)
 
     def step(i, ev=None):
         s = i % D
         main.wait_event(done[s])          # snapshot slot s is free again (sample i-D has finished)
-        if ev:
-            ev[0].record(main)
-        trainer.step((x, mask, cond))
-        trainer.snapshot_blob(N, out=snaps[s])
-        if ev:
-            ev[1].record(main)
+        with torch.cuda.stream(main):
+            if ev:
+                ev[0].record(main)
+            trainer.step((x, mask, cond))
+            trainer.snapshot_blob(N, out=snaps[s])
+            if ev:
+                ev[1].record(main)
         streams[s].wait_stream(main)
         with torch.cuda.stream(streams[s]), torch.no_grad():
             if ev:
@@ -223,7 +230,7 @@ def main():
     if D > 1:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
-        with torch.no_grad():
+        with torch.cuda.stream(main), torch.no_grad():
             e0.record(main)
             for _ in range(3):
                 model(z, cond=None, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps, weights=snaps[0])
