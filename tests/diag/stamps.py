@@ -10,7 +10,7 @@ from particle_fm_amd import build as B
 
 out = "/tmp/libpfm_diag.so"
 os.makedirs("gpurun_out", exist_ok=True)
-cmd = [B._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPFM_DIAG", "-fgpu-rdc",
+cmd = [B._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPFM_DIAG", *os.environ.get("PFM_DEFS", "").split(), "-fgpu-rdc",
        "-Iinclude", "-Iparticle_fm_amd/csrc", *B.sources(), "-o", out]
 subprocess.check_call(cmd)
 lib = ctypes.CDLL(out)
