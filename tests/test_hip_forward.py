@@ -88,3 +88,33 @@ def test_time_term_table_is_a_pure_optimisation(hip, golden):
     b = hip.epic_sample_midpoint(lay, blob, _dev(z), _dev(cond), _dev(mask), ode_steps=10, time_table=False).cpu()
     torch.testing.assert_close(a, b, atol=5e-6, rtol=1e-5)
     torch.testing.assert_close(a, golden.get(tag + "x_end"), atol=5e-5, rtol=1e-4)
+
+
+def test_jet_launch_order_is_longest_first(hip, golden):
+    """The sampler's scratch ends with the launch order of the jets: a permutation, descending multiplicity, ties by index."""
+    import ctypes
+    from particle_fm_amd import _lib
+    if golden.get("midpoint_10/mask") is None:
+        pytest.skip("no mask in this fixture")
+    lay, blob = _setup(golden)
+    gen = torch.Generator().manual_seed(21)
+    B, N, F = 300, golden.hp["num_particles"], golden.hp["features"]   # more jets than CUs
+    n = torch.randint(1, N + 1, (B,), generator=gen)
+    mask = (torch.arange(N)[None] < n[:, None]).float().unsqueeze(-1)
+    z = torch.randn(B, N, F, generator=gen)
+    cond = None if golden.get("midpoint_10/cond") is None else torch.randn(B, golden.get("midpoint_10/cond").shape[1], generator=gen)
+    out = hip.epic_sample_midpoint(lay, blob, _dev(z), _dev(cond), _dev(mask), ode_steps=4)
+    torch.cuda.synchronize()
+    scratch = [v for k, v in lay.__dict__["_sample_scratch"].items() if k[0] == 4 and k[3] == B][0]
+    total = _lib.load().pfm_epic_sample_scratch_floats(ctypes.byref(lay.desc), 3, B)
+    order = scratch[total - ((B + 63) // 64) * 64: total - ((B + 63) // 64) * 64 + B].view(torch.int32).cpu().long()
+    assert sorted(order.tolist()) == list(range(B))
+    key = n[order]
+    assert torch.all(key[:-1] >= key[1:])
+    same = key[:-1] == key[1:]
+    assert torch.all(order[:-1][same] < order[1:][same])
+    # and the order is scheduling only: every jet equals the jet sampled on its own
+    for jj in (int(order[0]), int(order[-1]), 7):
+        one = hip.epic_sample_midpoint(lay, blob, _dev(z[jj:jj + 1]), _dev(None if cond is None else cond[jj:jj + 1]), _dev(mask[jj:jj + 1]),
+                                       ode_steps=4)
+        torch.testing.assert_close(out[jj].cpu(), one[0].cpu(), atol=0, rtol=0)
