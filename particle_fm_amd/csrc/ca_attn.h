@@ -76,8 +76,10 @@ __device__ __forceinline__ void load_queries(float (&qr)[TK][HD], const float* _
 template <int HD, int TK>
 __global__ __launch_bounds__(256) void ca_attn_from_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                            const float* __restrict__ mask, float* __restrict__ out, int N,
-                                                           int D, int heads, int Tk, const int* __restrict__ off = nullptr) {
-    const int jet = blockIdx.x, lane = threadIdx.x & 63, h = blockIdx.y * 4 + (threadIdx.x >> 6);
+                                                           int D, int heads, int Tk, const int* __restrict__ off = nullptr,
+                                                           const int* __restrict__ order = nullptr) {
+    const int jet = order ? order[blockIdx.x] : blockIdx.x;  // longest jets first (tf_fwd.h: rows_rank_kernel)
+    const int lane = threadIdx.x & 63, h = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (h >= heads) return;
     // compacted particle rows (off != nullptr): the jet's keys are rows [off[jet], off[jet + 1]), all valid
     int64_t row_base = (int64_t)jet * N;

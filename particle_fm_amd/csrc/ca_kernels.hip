@@ -83,7 +83,7 @@ struct Plan {
     int n_jets, M, Mt;
     hipStream_t s;
     // valid-rows-only evaluation (PFM_CA_F_VALID_ROWS, inference): the particle rows are the valid particles
-    const int *rowsrc = nullptr, *rowjet = nullptr, *off = nullptr, *m_dev = nullptr, *cnt = nullptr;
+    const int *rowsrc = nullptr, *rowjet = nullptr, *off = nullptr, *m_dev = nullptr, *cnt = nullptr, *order = nullptr;
 };
 
 // out[rows][ldo] = epi(LN?(A) W^T + b / jet bias) (+R); per_jet = rows per jet of this row matrix (jet-bias lookup)
@@ -155,7 +155,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         PFM_TRY(linear(p, p.M, N, seq, D, D, Fl.kv, &Fl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.f_kv, 2 * D, 0));
         PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Fl.q, &Fl.norm1, D, nullptr, nullptr, 0, lb + w.f_q, D, 0));
         PFM_ATTN(ca_attn_from_kernel, dim3(p.n_jets, (heads + 3) / 4), 0, (const float*)(lb + w.f_q), (const float*)(lb + w.f_kv), mask, lb + w.f_att, N, D,
-                 heads, Tk, p.off);
+                 heads, Tk, p.off, p.order);
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_from_kernel launch"));
         PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_att, D, D, Fl.out, &Fl.attn_norm, D, nullptr, tok, D, lb + w.f_mid, D, 0));
         PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_mid, D, D, Fl.d1, &Fl.norm2, Hd, jb + (int64_t)(1 + 2 * l) * Hd, nullptr, 0, lb + w.f_dh, Hd, 1));
@@ -209,7 +209,7 @@ int setup_valid_rows(Plan& p, const float* mask) {
     if (!(p.d->flags & PFM_CA_F_VALID_ROWS) || !mask) return 0;
     if (p.d->n_points <= p.d->tokens) return 0;  // linear() tells particle rows from token rows by their count per jet
     const RowMaps m = build_row_maps(reinterpret_cast<int*>(p.ws + p.w.imaps), mask, p.n_jets, p.d->n_points, p.s);
-    p.rowsrc = m.rowsrc; p.rowjet = m.rowjet; p.off = m.off; p.m_dev = m.m_dev; p.cnt = m.cnt;
+    p.rowsrc = m.rowsrc; p.rowjet = m.rowjet; p.off = m.off; p.m_dev = m.m_dev; p.cnt = m.cnt; p.order = m.order;
     return check_hip(hipGetLastError(), "row compaction launch");
 }
 

@@ -182,7 +182,7 @@ __host__ inline Ws make_ws(const pfm_ew_desc& d, int n_jets, bool train) {
     w.X = take(M * Hp); o += w.xstride * (stages - 1);
     w.lstride = train ? round64(M * Hp) : 0;
     w.L1 = take(M * Hp); o += w.lstride * (stages > 2 ? stages - 2 : 0);
-    w.imaps = take(2 * (int64_t)n_jets + 64 + 2 * M);
+    w.imaps = take(row_maps_ints(n_jets, M));
     w.part_floats = n_jets <= 1024 ? 8 * (int64_t)n_jets * (2 * Hp + 128) : 0;
     w.part = take(w.part_floats);
     w.total = o;

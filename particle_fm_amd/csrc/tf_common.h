@@ -101,7 +101,7 @@ __host__ inline Ws make_ws(const pfm_tf_desc& d, int n_jets, bool train) {
         o += w.o_dh + round64(M * Hd);
     }
     w.oh = o; o += round64(M * Hd);
-    w.imaps = o; o += round64(2 * (int64_t)n_jets + 64 + 2 * M);
+    w.imaps = o; o += round64(3 * (int64_t)n_jets + 64 + 2 * M);
     w.total = o;
     return w;
 }

@@ -228,10 +228,24 @@ static __global__ __launch_bounds__(64) void rows_map_kernel(const float* __rest
         base += __popcll(bal);
     }
 }
-// int32 scratch for the maps of n_jets x N rows: cnt[B] | off[B+1] | m_valid (padded to 64) | rowsrc[M] | rowjet[M]
-__host__ __device__ inline int64_t row_maps_ints(int64_t n_jets, int64_t M) { return 2 * n_jets + 64 + 2 * M; }
+// order[rank] = jet, descending multiplicity (ties by index): kernels with one workgroup per jet whose cost grows with the
+// jet's size (attention ~ n^2) dispatch the long jets first and fill the tail with the short ones.  One workgroup, B <= 8192.
+constexpr int RANK_MAX_JETS = 8192;
+static __global__ __launch_bounds__(1024) void rows_rank_kernel(const int* __restrict__ cnt, int B, int* __restrict__ order) {
+    __shared__ int c[RANK_MAX_JETS];
+    for (int j = threadIdx.x; j < B; j += 1024) c[j] = cnt[j];
+    __syncthreads();
+    for (int j = threadIdx.x; j < B; j += 1024) {
+        const int cj = c[j];
+        int rank = 0;
+        for (int k = 0; k < B; ++k) rank += (c[k] > cj) || (c[k] == cj && k < j);
+        order[rank] = j;
+    }
+}
+// int32 scratch for the maps of n_jets x N rows: cnt[B] | off[B+1] | m_valid (padded to 64) | rowsrc[M] | rowjet[M] | order[B]
+__host__ __device__ inline int64_t row_maps_ints(int64_t n_jets, int64_t M) { return 3 * n_jets + 64 + 2 * M; }
 struct RowMaps {
-    int *cnt, *off, *m_dev, *rowsrc, *rowjet;
+    int *cnt, *off, *m_dev, *rowsrc, *rowjet, *order;  // order: nullptr for batches beyond RANK_MAX_JETS
 };
 inline RowMaps build_row_maps(int* im, const float* mask, int B, int N, hipStream_t s) {
     RowMaps m;
@@ -239,6 +253,11 @@ inline RowMaps build_row_maps(int* im, const float* mask, int B, int N, hipStrea
     hipLaunchKernelGGL(rows_count_kernel, dim3(B), dim3(256), 0, s, mask, m.cnt, N);
     hipLaunchKernelGGL(rows_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)m.cnt, m.off, m.m_dev, B);
     hipLaunchKernelGGL(rows_map_kernel, dim3(B), dim3(64), 0, s, mask, (const int*)m.off, m.rowsrc, m.rowjet, N);
+    m.order = nullptr;
+    if (B >= 2 && B <= RANK_MAX_JETS) {
+        m.order = m.rowjet + (int64_t)B * N;
+        hipLaunchKernelGGL(rows_rank_kernel, dim3(1), dim3(1024), 0, s, (const int*)m.cnt, B, m.order);
+    }
     return m;
 }
 
@@ -640,10 +659,11 @@ __host__ __device__ inline int attn_lds_floats(int N) {
 template <int MAXKT>
 __global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
                                                          float* __restrict__ out, int N, int D, int heads,
-                                                         const int* __restrict__ off = nullptr) {
+                                                         const int* __restrict__ off = nullptr, const int* __restrict__ order = nullptr) {
     static_assert(MAXKT % 2 == 0, "key tiles are processed in pairs");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int jet = blockIdx.x / heads, h = blockIdx.x - jet * heads;
+    const int slot = blockIdx.x / heads, h = blockIdx.x - slot * heads;
+    const int jet = order ? order[slot] : slot;  // longest jets first (rows_rank_kernel)
     // compacted rows (off != nullptr): the jet owns rows [off[jet], off[jet + 1]), all valid, and N becomes its multiplicity
     int64_t row_base = (int64_t)jet * N;
     if (off) {

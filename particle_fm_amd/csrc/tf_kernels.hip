@@ -40,7 +40,7 @@ struct Plan {
     int n_jets, M;
     hipStream_t s;
     // valid-rows-only evaluation (PFM_TF_F_VALID_ROWS, inference): rows are the valid particles in (jet, particle) order
-    const int *rowsrc = nullptr, *rowjet = nullptr, *off = nullptr, *m_dev = nullptr, *cnt = nullptr;
+    const int *rowsrc = nullptr, *rowjet = nullptr, *off = nullptr, *m_dev = nullptr, *cnt = nullptr, *order = nullptr;
 };
 
 int launch_linear(const Plan& p, const float* A, int lda, int K, const pfm_tf_lin& lin, const pfm_tf_norm* ln, int NO,
@@ -64,11 +64,11 @@ int launch_attn(const Plan& p, const float* qkv, const float* mask, float* out) 
     const int nkt = attn_np32(N) / 16;
     const dim3 grid(p.n_jets * heads), block(256);
     if (nkt <= 12)
-        hipLaunchKernelGGL(tf_attn_kernel<12>, grid, block, lds, p.s, qkv, mask, out, N, D, heads, p.off);
+        hipLaunchKernelGGL(tf_attn_kernel<12>, grid, block, lds, p.s, qkv, mask, out, N, D, heads, p.off, p.order);
     else if (nkt <= 18)
-        hipLaunchKernelGGL(tf_attn_kernel<18>, grid, block, lds, p.s, qkv, mask, out, N, D, heads, p.off);
+        hipLaunchKernelGGL(tf_attn_kernel<18>, grid, block, lds, p.s, qkv, mask, out, N, D, heads, p.off, p.order);
     else
-        hipLaunchKernelGGL(tf_attn_kernel<32>, grid, block, lds, p.s, qkv, mask, out, N, D, heads, p.off);
+        hipLaunchKernelGGL(tf_attn_kernel<32>, grid, block, lds, p.s, qkv, mask, out, N, D, heads, p.off, p.order);
     return check_hip(hipGetLastError(), "tf_attn_kernel launch");
 }
 
@@ -162,7 +162,7 @@ int make_plan(Plan& p, const pfm_tf_desc* d, const float* blob, float* ws, int n
 int setup_valid_rows(Plan& p, const float* mask) {
     if (!(p.d->flags & PFM_TF_F_VALID_ROWS) || !mask) return 0;
     const RowMaps m = build_row_maps(reinterpret_cast<int*>(p.ws + p.w.imaps), mask, p.n_jets, p.d->n_points, p.s);
-    p.rowsrc = m.rowsrc; p.rowjet = m.rowjet; p.off = m.off; p.m_dev = m.m_dev; p.cnt = m.cnt;
+    p.rowsrc = m.rowsrc; p.rowjet = m.rowjet; p.off = m.off; p.m_dev = m.m_dev; p.cnt = m.cnt; p.order = m.order;
     return check_hip(hipGetLastError(), "row compaction launch");
 }
 
