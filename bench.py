@@ -141,10 +141,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs (the HIP path has no CPU fallback)")
+    # PFM_BENCH_REHEARSAL=gloo: rehearse the N > 1 control flow on a box with fewer GPUs than ranks (ranks share the cards, the
+    # gradient all-reduce goes through gloo); never set by the driver, and the line it prints says so in `config`
+    rehearsal = os.environ.get("PFM_BENCH_REHEARSAL", "")
+    if rehearsal not in ("", "gloo"):
+        raise SystemExit(f"PFM_BENCH_REHEARSAL={rehearsal!r}: only 'gloo' is known")
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     from particle_fm_amd.engine import FusedFMTrainer
     from particle_fm_amd.models import SetFlowMatchingLitModule
@@ -220,6 +230,13 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    if rehearsal and world > 1:  # data-parallel invariant: identical replicas after K synchronised steps (bitwise)
+        flat = trainer.fp.flat.detach()
+        lo, hi = flat.clone(), flat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit(f"rank {rank}: parameter replicas diverged (max spread {float((hi - lo).abs().max()):.3e})")
     train_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     sample_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / args.steps  # on the stream the sampler was launched on
     assert torch.isfinite(out).all()
@@ -261,7 +278,8 @@ def main():
                 "workload": "EPiC-FM JetNet150 (N=150, F=3, H=128, L=10, 6 EPiC layers, 561330 params): per step "
                             "1 train step (FM-OT fwd+bwd, grad all-reduce, clip 0.5, AdamW, EMA) + 1 midpoint "
                             f"ODE sample (ode_steps={args.ode_steps}, {n_nfe} NFE) on the same number of jets",
-                "jets_per_gpu": B, "global_batch": jets_per_step, "parallelism": f"dp{world}",
+                "jets_per_gpu": B, "global_batch": jets_per_step,
+                "parallelism": f"dp{world}" + (f" (REHEARSAL: {rehearsal} collectives, ranks share {torch.cuda.device_count()} GPU(s))" if rehearsal else ""),
                 "overlap": f"{D} sampling launches in flight (sample of step i on its own HIP stream with a weight "
                            "snapshot while step i+1 trains); every launch of the K steps is inside the timed region",
                 "multiplicity": "U{30..150} per jet (masked tail tiles are skipped; results identical)",

@@ -30,3 +30,20 @@ def test_bench_line_schema():
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert 0.3 < r["frac"] < 1.0 and r["traffic"] is None or r["traffic"] > 1e6
+
+
+def test_two_rank_launch_rehearsal():
+    """The driver's N > 1 launch line on the one-GPU box: two ranks share the card and the gradient all-reduce goes through gloo
+    (PFM_BENCH_REHEARSAL; RCCL refuses two ranks on one device).  Checks the rendezvous, the per-rank control flow with the
+    collective on the train stream, the max-over-ranks timing and that only rank 0 prints."""
+    env = dict(os.environ, PFM_BENCH_REHEARSAL="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and "REHEARSAL" in d["config"]["parallelism"]
+    assert abs(d["value"] - 512 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
