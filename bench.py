@@ -158,6 +158,7 @@ def main():
 
     from particle_fm_amd.engine import FusedFMTrainer
     from particle_fm_amd.models import SetFlowMatchingLitModule
+    from particle_fm_amd.utils.streams import concurrent_streams
 
     torch.manual_seed(12345)  # fm_tops150.yaml:19 -- identical replicas on every rank
     model = SetFlowMatchingLitModule(optimizer=None, **HP).to(dev)
@@ -174,9 +175,9 @@ def main():
     # the next train step may update the parameters meanwhile).  All launches of all K steps are inside the timed
     # region; the fence at the end waits for every stream.  With D = 1 everything is on one stream.
     D = max(1, args.overlap)
-    # D + 1 streams created back to back (the runtime deals hardware queues round-robin at creation: no two of them share one);
-    # with D > 1 the train step runs on the last of them rather than on the default stream, whose queue may coincide with a sampler's
-    pool = [torch.cuda.Stream(device=dev) for _ in range(D + 1)] if D > 1 else []
+    # D + 1 streams on hardware queues of their own (a stream is bound to a queue at creation and two streams on one queue
+    # serialise); with D > 1 the train step runs on the last of them rather than on the default stream
+    pool = concurrent_streams(D + 1, dev) if D > 1 else []  # verified by measurement to run side by side (utils/streams.py)
     streams = pool[:D] if D > 1 else [torch.cuda.current_stream(dev)]
     main = pool[D] if D > 1 else torch.cuda.current_stream(dev)
     if D > 1:

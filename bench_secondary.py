@@ -100,6 +100,7 @@ def cpu_baseline(name, hp, state, jets, C, n_min):
 
 def run(name, args):
     from particle_fm_amd.engine import FusedFMTrainer
+    from particle_fm_amd.utils.streams import concurrent_streams
     from particle_fm_amd.models import SetFlowMatchingLitModule
     hp, B, n_min, C, flop, what = WORKLOADS[name]
     dev = torch.device("cuda", 0)
@@ -128,7 +129,8 @@ def run(name, args):
     # while step i+1 trains and the next sample is queued (bench.py does the same; all launches are inside the timed region)
     D = max(1, args.overlap)
     main = torch.cuda.current_stream(dev)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(D)] if D > 1 else [main]
+    # the sampling streams must sit on hardware queues of their own (checked by measurement, utils/streams.py)
+    streams = concurrent_streams(D, dev, also=[main]) if D > 1 else [main]
     done = [torch.cuda.Event() for _ in range(D)]
     outs = [None] * D
 

@@ -232,7 +232,8 @@ int pfm_norm_apply(float *out, const float *x, const float *mask, int64_t rows, 
 /* Optimiser tail on flat fp32 buffers of n elements:
  *   gnorm = ||grad * grad_mul||_2 ; c = min(1, max_norm/(gnorm+1e-6)) (clip_grad_norm_) ; g = grad*grad_mul*c
  *   AdamW (decoupled weight decay, torch.optim.AdamW defaults eps/betas passed in) ; ema = decay*ema + (1-decay)*p
- * `scratch` needs >= 1024 floats and must be zeroed by pfm_optim_step itself (it does).  step is 1-based. */
+ * `scratch` needs >= 1024 floats; on return (stream order) scratch[0] = gnorm^2 (0 without clipping).  The norm is reduced in a
+ * fixed order, without atomics: ranks that hold the same all-reduced gradient apply bit-identical updates.  step is 1-based. */
 int pfm_optim_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *ema,
                    float *scratch, int64_t n, float grad_mul, float max_norm, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float ema_decay, int32_t step,

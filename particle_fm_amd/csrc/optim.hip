@@ -13,8 +13,21 @@ namespace pfm {
 int set_err(int code, const char* what);
 int check_hip(hipError_t e, const char* where);
 
+// ||g * mul||^2 in two deterministic stages (no atomics: every rank of a data-parallel job must derive the SAME clip factor
+// from the same all-reduced gradient, or the replicas drift apart by an ulp per step): block b writes its partial sum to
+// part[b]; the optimiser kernel adds the partials in a fixed order.
+constexpr int SUMSQ_MAX_BLOCKS = 1023;  // partials live in scratch[1 .. 1024), scratch[0] receives the total
+
+__device__ __forceinline__ float block_sum256(float acc) {
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float mul,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ part) {
     float acc = 0.f;
     const int64_t n4 = n >> 2;
     const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
@@ -26,11 +39,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
         const float v = g[(n4 << 2) + threadIdx.x] * mul;
         acc += v * v;
     }
-    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
-    __shared__ float red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+    const float tot = block_sum256(acc);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
 struct AdamArgs {
@@ -50,12 +60,16 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
-                                                        float* __restrict__ ema, const float* __restrict__ sumsq,
-                                                        int64_t n, AdamArgs a) {
+                                                        float* __restrict__ ema, float* __restrict__ scratch,
+                                                        int nparts, int64_t n, AdamArgs a) {
     float clip = 1.0f;
     if (a.max_norm > 0.f) {
-        const float gnorm = sqrtf(*sumsq);
-        clip = fminf(1.0f, a.max_norm / (gnorm + 1e-6f));  // clip_grad_norm_: clamp(max_norm/(norm+1e-6), max=1)
+        // every block adds the same partials in the same order: one value for the whole grid, bit-identical on every rank
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += 256) acc += scratch[1 + i];
+        const float sumsq = block_sum256(acc);
+        if (blockIdx.x == 0 && threadIdx.x == 0) scratch[0] = sumsq;  // read back by the host side (grad_norm)
+        clip = fminf(1.0f, a.max_norm / (sqrtf(sumsq) + 1e-6f));  // clip_grad_norm_: clamp(max_norm/(norm+1e-6), max=1)
     }
     const bool has_ema = ema != nullptr;
     const int64_t n4 = n >> 2;
@@ -105,13 +119,14 @@ extern "C" int pfm_optim_step(float* param, const float* grad, float* exp_avg, f
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    if (max_norm > 0.f) hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, grad, n, grad_mul, scratch);
+    const int nparts = blocks < SUMSQ_MAX_BLOCKS ? blocks : SUMSQ_MAX_BLOCKS;
+    if (max_norm > 0.f) hipLaunchKernelGGL(sumsq_kernel, dim3(nparts), dim3(256), 0, s, grad, n, grad_mul, scratch + 1);
     AdamArgs a;
     a.grad_mul = grad_mul; a.max_norm = max_norm; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.weight_decay = weight_decay; a.ema_decay = ema_decay;
     a.bc1 = 1.0f - powf(beta1, (float)step);
     a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_ema_kernel, dim3(blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, ema,
-                       scratch, n, a);
+                       scratch, nparts, n, a);
     return check_hip(hipGetLastError(), "pfm_optim_step launch");
 }

@@ -343,23 +343,18 @@ __device__ __forceinline__ bool tile_of_block(int bid, int row_tiles, int nchunk
 // the weights are split per wave from the same fp32 MFMA_AK block read in k8 order, three v_mfma_f32_16x16x32_f16
 // per (output tile, row tile, 32 k) accumulate into a main and a correction accumulator.
 constexpr int X3ROW = 72;  // halfs per LDS row of an X3 slice (64 + 8 pad)
-template <int NI, int TPW = 4, bool X3 = false>
-__global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
+// NS = 16-row A operands (output tiles) per wave: 2 in a full 128-output column chunk.  A last chunk of <= 64 outputs (NO = 320:
+// 128 + 128 + 64) runs the NS = 1 body, every wave one operand, so that workgroup costs half a full one instead of idling two
+// of its waves; the two bodies are separate code paths behind one workgroup-uniform branch (separate register allocations).
+template <int NI, int TPW, bool X3, int NS>
+__device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ lds, int rt, int ch, int ks) {
     constexpr bool LN = NI > 0;
     constexpr int RB = 16 * TPW, SI = RB / 16;  // SI: float4 staged per thread and 64-wide step
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const tile = lds;             // two RB x 64 slices, 16-byte slots XOR-swizzled with (row & 15)
     float* const stat = lds + (X3 ? RB * X3ROW * 2 : RB * 128);  // RB x (mean, rstd), behind the slices
-    int rt, ch;
-    const int ks = a.ksplit > 1 ? blockIdx.x % a.ksplit : 0;
-    if (!tile_of_block(a.ksplit > 1 ? blockIdx.x / a.ksplit : blockIdx.x, a.row_tiles, (a.NO + BN - 1) / BN, rt, ch)) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
     const int row0 = rt * RB;
-    if (a.m_dev) {
-        a.M = *a.m_dev;
-        if (row0 >= a.M) return;
-    }
-    const int ob = ch * BN + 32 * w;  // this wave: outputs [ob, ob + 32) as two 16-row A operands
+    const int ob = ch * BN + 16 * NS * w;  // this wave: outputs [ob, ob + 16 NS) as NS 16-row A operands
     const blob_rsrc rs = make_blob_rsrc(a.blob, a.blob_floats);
     // NO is a multiple of 32: in a partial last column chunk the waves past NO only help staging
     const bool active = ob < a.NO;
@@ -370,16 +365,16 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     }
 
     // accumulators start from the bias (+ the jet-bias row of the particle's jet)
-    f32x4 acc[2][TPW];
-    f32x4 cor[2][X3 ? TPW : 1];  // X3: correction accumulators (hi.wlo + lo.whi), scaled by 2^-11 at the end
+    f32x4 acc[NS][TPW];
+    f32x4 cor[NS][X3 ? TPW : 1];  // X3: correction accumulators (hi.wlo + lo.whi), scaled by 2^-11 at the end
     if (X3) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int t = 0; t < (X3 ? TPW : 1); ++t) cor[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const int o = ob + 16 * s + 4 * q;
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
@@ -405,10 +400,10 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     const int nst_all = a.K >> 6;
     const int st0 = a.ksplit > 1 ? ks * (nst_all / a.ksplit) : 0;       // K / 64 is a multiple of ksplit (host)
     const int nst = a.ksplit > 1 ? st0 + nst_all / a.ksplit : nst_all;  // one past this workgroup's last step
-    auto request = [&](f32x4 (&af)[2][4], f32x4 (&st)[SI], int step) {
+    auto request = [&](f32x4 (&af)[NS][4], f32x4 (&st)[SI], int step) {
         if (active) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < NS; ++s) {
                 const int64_t base = a.W + ((int64_t)((ob >> 4) + s) * nst_all + step) * 1024;
                 if (X3) {  // k8 order: af[2 kp + h] = k-tile 2 kp + (q >> 1), lane (pl, 2 (q & 1) + h)  (see load_afrag_k8)
 #pragma unroll
@@ -432,7 +427,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
             st[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)row * ld);
         }
     };
-    auto step_fn = [&](f32x4 (&af)[2][4], f32x4 (&st)[SI], f32x4 (&afn)[2][4], f32x4 (&stn)[SI], int step) {
+    auto step_fn = [&](f32x4 (&af)[NS][4], f32x4 (&st)[SI], f32x4 (&afn)[NS][4], f32x4 (&stn)[SI], int step) {
         float* const buf = tile + (step & 1) * (X3 ? RB * X3ROW : RB * 64);  // X3: hi plane, lo plane RB * X3ROW halfs later
         if (LN) {
             const int col = 64 * step + 4 * sc4;
@@ -467,9 +462,9 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         if (!active) return;
         if (X3) {
             const _Float16* hb = reinterpret_cast<const _Float16*>(buf);
-            h8 wh[2][2], wl[2][2];
+            h8 wh[NS][2], wl[NS][2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < NS; ++s)
 #pragma unroll
                 for (int kp = 0; kp < 2; ++kp) x3_split8(af[s][2 * kp], af[s][2 * kp + 1], wh[s][kp], wl[s][kp]);
 #pragma unroll
@@ -480,7 +475,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
                     const h8 bh = *reinterpret_cast<const h8*>(bp);
                     const h8 bl = *reinterpret_cast<const h8*>(bp + RB * X3ROW);
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
+                    for (int s = 0; s < NS; ++s) {
                         acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][kp], bh, acc[s][t], 0, 0, 0);
                         cor[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][kp], bl, cor[s][t], 0, 0, 0);
                         cor[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s][kp], bh, cor[s][t], 0, 0, 0);
@@ -498,18 +493,20 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
                 const int so = ((4 * kt + q) ^ pl) << 2;
                 const f32x4 B0 = *reinterpret_cast<const f32x4*>(b0p + so);
                 const f32x4 B1 = *reinterpret_cast<const f32x4*>(b1p + so);
-#define PFM_TF_STEP(c)                                                                                         \
-    acc[0][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B0.c, acc[0][2 * tp], 0, 0, 0);         \
-    acc[1][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][kt].c, B0.c, acc[1][2 * tp], 0, 0, 0);         \
-    acc[0][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B1.c, acc[0][2 * tp + 1], 0, 0, 0); \
-    acc[1][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][kt].c, B1.c, acc[1][2 * tp + 1], 0, 0, 0);
+#define PFM_TF_STEP(c)                                                                                                    \
+    acc[0][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B0.c, acc[0][2 * tp], 0, 0, 0);                    \
+    if constexpr (NS == 2)                                                                                                \
+        acc[NS - 1][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[NS - 1][kt].c, B0.c, acc[NS - 1][2 * tp], 0, 0, 0); \
+    acc[0][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B1.c, acc[0][2 * tp + 1], 0, 0, 0);            \
+    if constexpr (NS == 2)                                                                                                \
+        acc[NS - 1][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[NS - 1][kt].c, B1.c, acc[NS - 1][2 * tp + 1], 0, 0, 0);
                 PFM_TF_STEP(x) PFM_TF_STEP(y) PFM_TF_STEP(z) PFM_TF_STEP(w)
 #undef PFM_TF_STEP
             }
         }
     };
     {
-        f32x4 afA[2][4], afB[2][4], stA[SI], stB[SI];
+        f32x4 afA[NS][4], afB[NS][4], stA[SI], stB[SI];
         request(afA, stA, st0);
         int step = st0;
 #pragma unroll 1
@@ -522,7 +519,7 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
 
     // epilogue: lane (particle pl of tile t, q) holds 4 consecutive outputs
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const int o = ob + 16 * s + 4 * q;
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
@@ -547,6 +544,20 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
             }
         }
     }
+}
+
+template <int NI, int TPW = 4, bool X3 = false>
+__global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int rt, ch;
+    const int ks = a.ksplit > 1 ? blockIdx.x % a.ksplit : 0;
+    if (!tile_of_block(a.ksplit > 1 ? blockIdx.x / a.ksplit : blockIdx.x, a.row_tiles, (a.NO + BN - 1) / BN, rt, ch)) return;
+    if (a.m_dev) {
+        a.M = *a.m_dev;
+        if (rt * 16 * TPW >= a.M) return;
+    }
+    if (a.NO - ch * BN <= 64) tf_linear_body<NI, TPW, X3, 1>(a, lds, rt, ch, ks);
+    else tf_linear_body<NI, TPW, X3, 2>(a, lds, rt, ch, ks);
 }
 
 // Row tile of a Linear launch: 32, 64 or 128 rows per workgroup, whichever gives the shortest schedule on this GPU's

@@ -19,6 +19,7 @@ import torch
 
 from .. import _lib
 from ..hip_ops import _ptr, _stream_ptr
+from .streams import concurrent_streams
 
 
 def sample_epilogue_(x: torch.Tensor, mask: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
@@ -86,11 +87,11 @@ _PIPE_STREAMS = {}
 
 
 def _pipeline_streams(dev):
-    """the two side streams of the batch pipeline, created once per device (stream -> hardware-queue mapping is fixed at
-    creation; a fresh pair per call occasionally lands both on one queue and the overlap is lost)"""
+    """the two side streams of the batch pipeline, created once per device and checked to run side by side (the stream ->
+    hardware-queue mapping is fixed at creation; a pair that lands on one queue loses the overlap: utils/streams.py)"""
     key = str(dev)
     if key not in _PIPE_STREAMS:
-        _PIPE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        _PIPE_STREAMS[key] = concurrent_streams(2, dev)
     return _PIPE_STREAMS[key]
 
 
