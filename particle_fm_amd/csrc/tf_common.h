@@ -43,9 +43,43 @@ inline int num_cus() {
 // Two half-batches on two streams: the jets of a sampling call are independent, so the latency-bound stretches of one half
 // (per-jet GEMMs, context path, global tokens: a few workgroups each) run under the particle-row GEMMs of the other.
 // One side stream + fork / join events per device, created on first use and kept for the life of the process.
+// A HIP stream is bound to one of a few hardware queues when it is created (least-referenced queue, first one on a tie) and two
+// streams on one queue run strictly one after the other, so "two new streams" are not automatically two queues: which queue a
+// stream gets depends on every stream the process made before.  streams_overlap() measures it with a one-thread spin kernel.
+static __global__ void spin_kernel(long long ticks) {  // ticks of the 100 MHz constant clock
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+inline bool streams_overlap(hipStream_t a, hipStream_t b) {
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) return false;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, a, 100LL);  // the hardware queue is set up at the first launch
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, b, 100LL);
+    hipStreamSynchronize(a);
+    hipStreamSynchronize(b);
+    bool ok = false;
+    // serial streams can never look concurrent (b's kernel starts after a's has ended); concurrent ones may look serial once in a
+    // while (another process on the card): best of three
+    for (int attempt = 0; attempt < 3 && !ok; ++attempt) {
+        hipEventRecord(e0, a);
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, a, 30000LL);  // 0.3 ms
+        hipEventRecord(e1, a);
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, b, 30000LL);
+        hipEventRecord(e2, b);
+        float ta = 0.f, tab = 0.f;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventSynchronize(e2) != hipSuccess) break;
+        if (hipEventElapsedTime(&ta, e0, e1) != hipSuccess || hipEventElapsedTime(&tab, e0, e2) != hipSuccess) break;
+        ok = tab < 1.5f * ta;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipEventDestroy(e2);
+    (void)hipGetLastError();
+    return ok;
+}
+
 struct SideStream {
-    hipStream_t s = nullptr, s2 = nullptr;  // two streams created back to back: the runtime deals hardware queues round-robin
-                                            // at creation, so these two never share one (the caller's stream may share with either)
+    hipStream_t s = nullptr, s2 = nullptr;  // two streams measured to run side by side (the caller's stream only forks / joins)
     hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
 };
 inline SideStream* side_stream() {
@@ -55,8 +89,17 @@ inline SideStream* side_stream() {
     SideStream& e = st[dev];
     if (!e.s) {
         if (hipStreamCreateWithFlags(&e.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipStreamCreateWithFlags(&e.s2, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
+        hipStream_t cand[6] = {};
+        int n = 0, pick = -1;
+        for (; n < 6 && pick < 0; ++n) {  // rejected candidates stay alive until the choice is made (else their queue is dealt again)
+            if (hipStreamCreateWithFlags(&cand[n], hipStreamNonBlocking) != hipSuccess) { cand[n] = nullptr; break; }
+            if (streams_overlap(e.s, cand[n])) pick = n;
+        }
+        if (pick < 0 && n > 0 && cand[0]) pick = 0;  // fewer independent queues than hoped for: still correct, just not concurrent
+        for (int i = 0; i < 6; ++i)
+            if (cand[i] && i != pick) hipStreamDestroy(cand[i]);
+        e.s2 = pick >= 0 ? cand[pick] : nullptr;
+        if (!e.s2 || hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e.join2, hipEventDisableTiming) != hipSuccess) {
             e.s = nullptr;
