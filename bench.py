@@ -182,14 +182,18 @@ def main():
     main = pool[D] if D > 1 else torch.cuda.current_stream(dev)
     if D > 1:
         main.wait_stream(torch.cuda.current_stream(dev))
+    # D + 1 snapshot slots: train step i may run while samples i-1 .. i-D are still in flight (it only has to wait for sample
+    # i-(D+1), the last reader of its slot), so the train chain -- which includes the gradient all-reduce when N > 1 -- has a
+    # whole step of slack and a late collective delays nothing
+    S = D + 1
     with torch.cuda.stream(main):
-        snaps = [trainer.snapshot_blob(N) for _ in range(D)]
-    outs = [None] * D
-    done = [torch.cuda.Event() for _ in range(D)]
+        snaps = [trainer.snapshot_blob(N) for _ in range(S)]
+    outs = [None] * S
+    done = [torch.cuda.Event() for _ in range(S)]
 
     def step(i, ev=None):
-        s = i % D
-        main.wait_event(done[s])          # snapshot slot s is free again (sample i-D has finished)
+        s, q = i % S, streams[i % D]
+        main.wait_event(done[s])          # snapshot slot s is free again (sample i-S has finished)
         with torch.cuda.stream(main):
             if ev:
                 ev[0].record(main)
@@ -197,15 +201,15 @@ def main():
             trainer.snapshot_blob(N, out=snaps[s])
             if ev:
                 ev[1].record(main)
-        streams[s].wait_stream(main)
-        with torch.cuda.stream(streams[s]), torch.no_grad():
+        q.wait_stream(main)
+        with torch.cuda.stream(q), torch.no_grad():
             if ev:
-                ev[2].record(streams[s])
+                ev[2].record(q)
             outs[s] = model(z, cond=None, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps,
                             weights=snaps[s])
             if ev:
-                ev[3].record(streams[s])
-            done[s].record(streams[s])
+                ev[3].record(q)
+            done[s].record(q)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -226,7 +230,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     log(f"timed {args.steps} steps in {elapsed:.3f}s")
-    out = outs[(args.steps - 1) % D]
+    out = outs[(args.steps - 1) % S]
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
