@@ -119,6 +119,9 @@ def run(name, args):
     valid_rows = hasattr(net, "set_valid_rows_only") and not args.dense_rows
     if valid_rows:  # what generate_data does with variable_set_sizes: the sampler skips padded particles (EPiC always does)
         net.set_valid_rows_only(True)
+    graph = args.overlap > 1 and getattr(net, "_GRAPH_FLAG", 0) != 0 and not args.no_graph
+    if graph:  # two sampler calls in flight from one thread: ~200 launches per step make the host the limiter without it
+        net.set_graph_replay(True)
     trainer = FusedFMTrainer(model, lr=1e-3, weight_decay=5e-5, max_grad_norm=0.5, ema_decay=0.999)
     N, F = hp["num_particles"], hp["features"]
     x, mask, cond = (a.to(dev) for a in make_batch(B, N, F, C, n_min, 12345))
@@ -181,7 +184,8 @@ def run(name, args):
         "data": "synthetic",
         "config": {"workload": what, "jets_per_gpu": B, "parallelism": "dp1", "ode_steps": args.ode_steps, "overlap": D,
                    "multiplicity": f"U{{{n_min}..{N}}} per jet",
-                   "sampler_rows": "valid particles only" if (valid_rows or hp["model"] == "epic") else "all N rows (padded included)"},
+                   "sampler_rows": "valid particles only" if (valid_rows or hp["model"] == "epic") else "all N rows (padded included)",
+                   "sampler_launches": "step body captured once per call, replayed as a hipGraph" if graph else "every launch enqueued by the host"},
         "train_ms": train_ms, "sample_ms": sample_ms, "train_jets_per_s": B / (train_ms * 1e-3),
         "sample_jets_per_s": B / (sample_ms * 1e-3),
         "roofline": {"bound": "mfma", "kernel": "sampling launches (tf_linear_kernel dominates)" if name != "jetnet30" else "epic_sample_midpoint_kernel",
@@ -211,6 +215,8 @@ def main():
                          "training stays fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=2, help="sampling launches in flight (1 = strictly sequential)")
+    ap.add_argument("--no-graph", action="store_true", help="cross-attention path: enqueue every launch of the sampler from the host "
+                    "instead of replaying the captured step body (hipGraph)")
     ap.add_argument("--dense-rows", action="store_true", help="transformer paths: sample all N rows like the reference (padded included)")
     args = ap.parse_args()
     if not torch.cuda.is_available():

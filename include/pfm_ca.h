@@ -31,6 +31,11 @@ extern "C" {
 #define PFM_CA_F_F16X3 1        /* split-fp16 Linears, see PFM_TF_F_F16X3 */
 #define PFM_CA_F_TEMB_SINCOS 2  /* see PFM_TF_F_TEMB_SINCOS */
 #define PFM_CA_F_VALID_ROWS 4    /* see PFM_TF_F_VALID_ROWS: inference over the valid particles only */
+#define PFM_CA_F_GRAPH_STEPS 8   /* pfm_ca_sample_midpoint on a non-null stream: step 0 is launched directly, the step body is captured
+                                  * once (t / dt behind a device-side step counter) and replayed as a hipGraph for the other steps --
+                                  * same kernels, same results; the graph is kept in a per-stream slot and released by the next such call
+                                  * on that stream.  For callers that keep several sampler calls in flight from one thread and are
+                                  * bound by the ~11 us the host needs per launch (~200 launches per step) */
 
 typedef struct {
     pfm_tf_norm norm0, norm1, norm2, attn_norm, d_norm; /* norm0: keys/values input, norm1: query input, norm2: dense input */

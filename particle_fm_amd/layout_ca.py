@@ -21,6 +21,7 @@ PFM_CA_MAX_TOKENS = 8
 PFM_CA_F_F16X3 = 1
 PFM_CA_F_TEMB_SINCOS = 2
 PFM_CA_F_VALID_ROWS = 4
+PFM_CA_F_GRAPH_STEPS = 8
 
 
 class CaLayer(ctypes.Structure):

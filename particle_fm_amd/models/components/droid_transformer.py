@@ -181,6 +181,7 @@ class _FusedEncoder(nn.Module):
 
     _LAYOUT = None
     _forward_op = None
+    _GRAPH_FLAG = 0  # descriptor flag of the hipGraph replay of the sampler's step body (0: the path has none)
 
     def _init_fused(self, num_points, frequencies, add_time_to_input, t_emb):
         # what the kernels need to know beyond the reference's own arguments
@@ -190,12 +191,15 @@ class _FusedEncoder(nn.Module):
         # inference evaluates the valid particles only (PFM_*_F_VALID_ROWS): same numbers at valid particles, the reference's
         # unmasked values at padded positions (which every consumer multiplies by the mask) are not produced
         self.valid_rows_only = False
+        # the midpoint sampler replays its step body as a hipGraph (PFM_CA_F_GRAPH_STEPS): for callers that keep several sampler
+        # calls in flight from one thread and are bound by the host's launch rate; same kernels, same results
+        self.graph_replay = False
         self.cfg = self.config(num_points or 1)
         self._LAYOUT(self.cfg)  # rejects unsupported sizes at construction
 
     def layout(self, num_points: Optional[int] = None):
         n = num_points or self.num_points
-        flags = (1 if self.mfma_dtype == "f16x3" else 0) | (4 if self.valid_rows_only else 0)
+        flags = (1 if self.mfma_dtype == "f16x3" else 0) | (4 if self.valid_rows_only else 0) | (self._GRAPH_FLAG if self.graph_replay else 0)
         lay = self._layouts.get((n, flags))
         if lay is None:
             lay = self._layouts[(n, flags)] = self._LAYOUT(self.config(n), flags=flags)
@@ -204,6 +208,10 @@ class _FusedEncoder(nn.Module):
     def set_valid_rows_only(self, on: bool = True) -> None:
         """Sampling / forward skip padded particles (training is unaffected: the reference's loss includes padded rows)."""
         self.valid_rows_only = bool(on)
+
+    def set_graph_replay(self, on: bool = True) -> None:
+        """The midpoint sampler captures its step body once per call and replays it (paths that have it: cross-attention)."""
+        self.graph_replay = bool(on)
 
     def set_precision(self, precision) -> None:
         """"f16x3" -> split-fp16 Linears; anything else (incl. Lightning's "bf16-mixed": no bf16 kernels on this path) fp32."""
@@ -292,6 +300,8 @@ class FullTransformerEncoder(_FusedEncoder):
 
 class FullCrossAttentionEncoder(_FusedEncoder):
     """droid_transformer.py:620-711; evaluation as FullTransformerEncoder (``vector_field``)."""
+
+    _GRAPH_FLAG = 8  # PFM_CA_F_GRAPH_STEPS
 
     def __init__(self, inpt_dim: int, outp_dim: int, ctxt_dim: int = 0, cae_config: Mapping | None = None,
                  node_embd_config: Mapping | None = None, outp_embd_config: Mapping | None = None,

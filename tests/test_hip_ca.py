@@ -167,3 +167,27 @@ def test_loss_and_all_parameter_gradients(ca_golden, kind):
     torch.testing.assert_close(loss.detach().cpu(), g.get(tag + "loss"), rtol=2e-5, atol=1e-6)
     loss.backward()
     _check_grads(g, lay, flat.grad.cpu(), tag)
+
+
+def test_graph_replay_of_the_step_body_gives_the_same_sample(ops, ca_golden):
+    """PFM_CA_F_GRAPH_STEPS: step 0 direct, the captured body replayed for the rest -- bit-identical to plain launches, on a
+    side stream (graph mode), twice in a row (the parked graph of the first call is retired by the second), and on the null
+    stream (falls back to plain launches); dense rows and valid rows only."""
+    from particle_fm_amd.layout_ca import PFM_CA_F_GRAPH_STEPS, PFM_CA_F_VALID_ROWS, CaConfig, CaLayout
+    g = ca_golden
+    tag = "midpoint_10/"
+    z, mask, cond = (_dev(g.get(tag + k)) for k in ("z", "mask", "cond"))
+    cfg = CaConfig.from_hparams(g.hp)
+    for extra in (0, PFM_CA_F_VALID_ROWS):
+        lay_ref, lay_g = CaLayout(cfg, flags=extra), CaLayout(cfg, flags=extra | PFM_CA_F_GRAPH_STEPS)
+        blob = lay_ref.pack_blob(g.state, "flows.0.", freqs=g.freqs).cuda()
+        want = ops.ca_sample_midpoint(lay_ref, blob, z, cond, mask, ode_steps=10)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            got1 = ops.ca_sample_midpoint(lay_g, blob, z, cond, mask, ode_steps=10)
+            got2 = ops.ca_sample_midpoint(lay_g, blob, z, cond, mask, ode_steps=10)
+        side.synchronize()
+        got0 = ops.ca_sample_midpoint(lay_g, blob, z, cond, mask, ode_steps=10)  # null stream: no capture
+        torch.cuda.synchronize()
+        assert torch.equal(got1, want) and torch.equal(got2, want) and torch.equal(got0, want)
