@@ -119,8 +119,9 @@ def run(name, args):
     valid_rows = hasattr(net, "set_valid_rows_only") and not args.dense_rows
     if valid_rows:  # what generate_data does with variable_set_sizes: the sampler skips padded particles (EPiC always does)
         net.set_valid_rows_only(True)
+    # cross-attention (~200 launches per midpoint step): with two calls in flight the host's launch rate, not the GPU, sets the pace
     graph = args.overlap > 1 and getattr(net, "_GRAPH_FLAG", 0) != 0 and not args.no_graph
-    if graph:  # two sampler calls in flight from one thread: ~200 launches per step make the host the limiter without it
+    if graph:
         net.set_graph_replay(True)
     trainer = FusedFMTrainer(model, lr=1e-3, weight_decay=5e-5, max_grad_norm=0.5, ema_decay=0.999)
     N, F = hp["num_particles"], hp["features"]

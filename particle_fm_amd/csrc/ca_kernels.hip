@@ -4,8 +4,6 @@
 // shapes are in ca_attn.h.
 #include <hip/hip_runtime.h>
 
-#include <mutex>
-
 #include "pfm_ca.h"
 #include "tf_fwd.h"
 #include "tf_bwd.h"
@@ -73,7 +71,7 @@ Ws make_ws(const pfm_ca_desc& d, int n_jets, bool train) {
     }
     w.oh = take(M * Hd);
     w.imaps = take(row_maps_ints(n_jets, M));
-    w.step = take(64);
+    w.step = take(tf::STEP_SLOT_FLOATS);
     w.total = o;
     return w;
 }
@@ -477,62 +475,6 @@ int pfm_ca_forward(const pfm_ca_desc* d, const float* blob, const float* t, int3
     return ca::run_nfe(p, t, t_stride ? 1 : 0, x, cond, mask, h);
 }
 
-namespace pfm { namespace ca {
-// Graph replay of the midpoint step (PFM_CA_F_GRAPH_STEPS).  One step is ~200 launches of 5-20 us; the host needs ~11 us to enqueue
-// each, so with two sampler calls in flight on two streams (bench_secondary.py --overlap 2) the enqueueing thread, not the GPU,
-// sets the pace.  The step body is the same for every k except for three scalars, so it is captured once per call with those
-// scalars behind fixed addresses: slot = {t_eval[2k], t_eval[2k+1], dt[k]}, refreshed by this one-thread kernel at the head of
-// the body from a device-side step counter; the captured graph is then replayed for the remaining steps.
-static __global__ void ca_step_args_kernel(const float* __restrict__ t_eval, const float* __restrict__ dt, float* __restrict__ slot) {
-    int* counter = reinterpret_cast<int*>(slot + 4);
-    const int k = *counter;
-    slot[0] = t_eval[2 * k];
-    slot[1] = t_eval[2 * k + 1];
-    slot[2] = dt[k];
-    *counter = k + 1;
-}
-// The executable graph of a call must outlive its launches, and the call must not wait for them (the caller wants to go on
-// enqueueing other streams): the graph is parked in a per-stream slot together with an event recorded behind its last launch,
-// and retired by the next graph-mode call on that stream (which finds the event complete unless the caller reuses the stream
-// without waiting for the previous sample, in which case it waits here).
-struct GraphSlot {
-    hipStream_t s = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipEvent_t done = nullptr;
-};
-constexpr int GRAPH_SLOTS = 16;
-static GraphSlot g_graph_slots[GRAPH_SLOTS];
-static std::mutex g_graph_mutex;
-
-static void retire(GraphSlot& g) {
-    if (g.exec) {
-        (void)hipEventSynchronize(g.done);
-        (void)hipGraphExecDestroy(g.exec);
-        g.exec = nullptr;
-    }
-    if (g.graph) {
-        (void)hipGraphDestroy(g.graph);
-        g.graph = nullptr;
-    }
-}
-// the slot of stream s with its previous graph retired, or nullptr (every slot taken by another stream: no graph this call)
-static GraphSlot* graph_slot(hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_graph_mutex);
-    GraphSlot* g = nullptr;
-    for (auto& e : g_graph_slots)
-        if (e.s == s) g = &e;
-    if (!g)
-        for (auto& e : g_graph_slots)
-            if (!e.s && !g) g = &e;
-    if (!g) return nullptr;
-    if (!g->done && hipEventCreateWithFlags(&g->done, hipEventDisableTiming) != hipSuccess) return nullptr;
-    g->s = s;
-    retire(*g);
-    return g;
-}
-}}  // namespace pfm::ca
-
 int pfm_ca_sample_midpoint(const pfm_ca_desc* d, const float* blob, const float* t_eval, const float* dt, int32_t n_steps,
                            const float* z, const float* cond, const float* mask, float* x_out, int32_t n_jets, int32_t premask,
                            float* state, float* workspace, void* stream) {
@@ -561,7 +503,7 @@ int pfm_ca_sample_midpoint(const pfm_ca_desc* d, const float* blob, const float*
     };
     int k = 0;
     // the legacy null stream cannot be captured; two steps or fewer are not worth a graph
-    ca::GraphSlot* gs = ((d->flags & PFM_CA_F_GRAPH_STEPS) && p.s != nullptr && n_steps > 2) ? ca::graph_slot(p.s) : nullptr;
+    tf::ParkedGraph* gs = ((d->flags & PFM_CA_F_GRAPH_STEPS) && p.s != nullptr && n_steps > 2) ? tf::park_graph(p.s) : nullptr;
     if (gs) {
         // step 0 runs directly: whatever the first launch of a kernel does lazily (module load, the 128-row Linear's LDS opt-in)
         // happens outside the capture
@@ -569,7 +511,7 @@ int pfm_ca_sample_midpoint(const pfm_ca_desc* d, const float* blob, const float*
         float* slot = p.ws + p.w.step;
         if ((rc = check_hip(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(slot + 4), 1, 1, p.s), "step counter"))) return rc;
         if ((rc = check_hip(hipStreamBeginCapture(p.s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture"))) return rc;
-        hipLaunchKernelGGL(ca::ca_step_args_kernel, dim3(1), dim3(1), 0, p.s, t_eval, dt, slot);
+        hipLaunchKernelGGL(tf::step_args_kernel, dim3(1), dim3(1), 0, p.s, t_eval, dt, slot);
         rc = one_step(slot, slot + 1, slot + 2);
         const hipError_t ce = hipStreamEndCapture(p.s, &gs->graph);  // always end the capture, also after a failed launch
         if (rc == 0) rc = check_hip(ce, "hipStreamEndCapture");

@@ -2,6 +2,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "pfm_common.h"
 #include "pfm_tf.h"
 
@@ -108,6 +110,69 @@ inline SideStream* side_stream() {
     }
     return &e;
 }
+// ---- graph replay of a sampler's step body (PFM_CA_F_GRAPH_STEPS) ------------------------------------------------------------
+// One midpoint step of the row-matrix models is hundreds of launches of 5-20 us and the host needs ~10 us to enqueue each, so
+// the enqueueing thread, not the GPU, sets the pace once two calls are in flight (cross-attention: 225 of 276 ms per call).  The
+// step body is the same for every k except for three scalars, so it is captured once per call with those scalars behind fixed
+// addresses -- slot = {t_eval[2k], t_eval[2k+1], dt[k]}, refreshed by this one-thread kernel at the head of the body from a
+// device-side step counter (slot[4], as int) -- and the captured graph is replayed for the remaining steps.
+static __global__ void step_args_kernel(const float* __restrict__ t_eval, const float* __restrict__ dt, float* __restrict__ slot) {
+    int* counter = reinterpret_cast<int*>(slot + 4);
+    const int k = *counter;
+    slot[0] = t_eval[2 * k];
+    slot[1] = t_eval[2 * k + 1];
+    slot[2] = dt[k];
+    *counter = k + 1;
+}
+constexpr int STEP_SLOT_FLOATS = 64;
+// The executable graph of a call must outlive its launches, and the call must not wait for them (the caller goes on enqueueing
+// other streams): the graph is parked in a small per-stream ring together with an event recorded behind its last launch; a later
+// call on that stream retires the oldest entry (complete long ago unless the caller runs more than two calls ahead).
+struct ParkedGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipEvent_t done = nullptr;
+};
+struct GraphRing {
+    hipStream_t s = nullptr;
+    ParkedGraph ring[2];
+    int next = 0;
+};
+struct GraphRings {
+    std::mutex m;
+    GraphRing r[16];
+};
+inline GraphRings& graph_rings() {
+    static GraphRings g;
+    return g;
+}
+// a free entry for a graph launched on stream s (its previous occupant retired), or nullptr: no graph this call
+inline ParkedGraph* park_graph(hipStream_t s) {
+    GraphRings& G = graph_rings();
+    std::lock_guard<std::mutex> lock(G.m);
+    GraphRing* g = nullptr;
+    for (auto& e : G.r)
+        if (e.s == s) g = &e;
+    if (!g)
+        for (auto& e : G.r)
+            if (!e.s && !g) g = &e;
+    if (!g) return nullptr;
+    g->s = s;
+    ParkedGraph& pg = g->ring[g->next];
+    g->next ^= 1;
+    if (!pg.done && hipEventCreateWithFlags(&pg.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (pg.exec) {
+        (void)hipEventSynchronize(pg.done);
+        (void)hipGraphExecDestroy(pg.exec);
+        pg.exec = nullptr;
+    }
+    if (pg.graph) {
+        (void)hipGraphDestroy(pg.graph);
+        pg.graph = nullptr;
+    }
+    return &pg;
+}
+
 // jets of the first half (0: do not split).  PFM_SPLIT_STREAMS=0 turns the split off (diagnostics).
 inline int split_point(int n_jets, int min_half) {
     static int on = -1;

@@ -39,9 +39,10 @@ if steps > 1:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     xs = ops.ew_sample_midpoint(lay, blob, x, cond, mask, ode_steps=steps)
+    t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"sample {steps} steps: {dt*1e3:.1f} ms  {B/dt:.1f} jets/s  {fl*2*(steps-1)/dt/1e12:.1f} TFLOP/s")
+    print(f"sample {steps} steps: {dt*1e3:.1f} ms  {B/dt:.1f} jets/s  {fl*2*(steps-1)/dt/1e12:.1f} TFLOP/s  (host enqueue {t_host*1e3:.1f} ms)")
 if len(sys.argv) > 3 and sys.argv[3] == "train":
     from particle_fm_amd.fm_loss_wide import epic_wide_fm_loss
     layb = EpicWideLayout(cfg)
