@@ -75,12 +75,22 @@ def generate_data(model, num_jet_samples: int, batch_size: int = 256, cond: torc
             if hasattr(net, "set_valid_rows_only") and not net.valid_rows_only:
                 net.set_valid_rows_only(True)
                 switched.append(net)
+    # Two batches in flight from this one thread: the cross-attention sampler (~200 launches per step) is then bound by the host's
+    # launch rate unless it replays its captured step body (PFM_CA_F_GRAPH_STEPS); same kernels, same results.
+    replay = []
+    if pipeline and dev.type == "cuda" and _pipelined(model) and ode_solver == "midpoint":
+        net = model.flows[0].net
+        if getattr(net, "_GRAPH_FLAG", 0) and hasattr(net, "set_graph_replay") and not net.graph_replay:
+            net.set_graph_replay(True)
+            replay.append(net)
     try:
         return _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes, mask, normalized_data, normalize_sigma,
                          means, stds, log_pt, pt_standardization, shuffle_mask, ode_solver, ode_steps, pipeline)
     finally:
         for net in switched:
             net.set_valid_rows_only(False)
+        for net in replay:
+            net.set_graph_replay(False)
 
 
 _PIPE_STREAMS = {}
@@ -95,10 +105,11 @@ def _pipeline_streams(dev):
     return _PIPE_STREAMS[key]
 
 
-def _jet_resident(model) -> bool:
-    """a single flow on the jet-resident EPiC kernel: launches share no activation workspace"""
+def _pipelined(model) -> bool:
+    """a single flow on a HIP network: the weights can be packed once for all batches, and launches on different streams share no
+    activation workspace (the jet-resident EPiC kernel has none, the row-matrix paths keep one per stream)"""
     flows = list(getattr(model, "flows", []))
-    return len(flows) == 1 and hasattr(flows[0].net, "source_vector") and not getattr(flows[0].net, "wide", False)
+    return len(flows) == 1 and hasattr(flows[0].net, "packed_weights")
 
 
 def _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes, mask, normalized_data, normalize_sigma, means, stds,
@@ -108,11 +119,12 @@ def _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes,
     scale = shift = None
     outs = []
     start_time = 0.0
-    # Jet-resident EPiC (extension `pipeline`): the parameters are packed once for all batches, and consecutive batches alternate
-    # between two streams -- a sampler launch lasts as long as its largest jet, and with the jets taken longest-first the next
-    # batch starts in the gaps of the current one.  Same draws in the same order (CPU generator), same results.
+    # Extension `pipeline`: the parameters are packed once for all batches, and consecutive batches alternate between two streams.
+    # Jet-resident EPiC: a sampler launch lasts as long as its largest jet, and with the jets taken longest-first the next batch
+    # starts in the gaps of the current one; row-matrix models (transformer, cross-attention, wide EPiC): the short dependent
+    # launches of one batch run in the gaps of the other's.  Same draws in the same order (CPU generator), same results.
     blob, streams = None, None
-    if pipeline and dev.type == "cuda" and _jet_resident(model) and ode_solver == "midpoint":
+    if pipeline and dev.type == "cuda" and _pipelined(model) and ode_solver == "midpoint":
         with torch.no_grad():
             blob = model.flows[0].net.packed_weights(getattr(model.hparams, "num_particles", None))
         streams = _pipeline_streams(dev)

@@ -100,3 +100,32 @@ def test_generate_data_uses_valid_rows_and_matches_dense():
         assert m.flows[0].net.valid_rows_only is False  # restored
     torch.testing.assert_close(outs[0], outs[1], atol=1e-4, rtol=1e-3)
     assert torch.all(outs[0][mask.squeeze(-1) == 0] == 0)
+
+
+@pytest.mark.parametrize("which", ["tf", "ca"])
+def test_generate_data_two_stream_pipeline_changes_nothing(which):
+    """generate_data's batch pipeline (weights packed once, batches alternating between two streams, graph replay of the
+    cross-attention step) for the row-matrix models: the same array as one batch after the other."""
+    import copy
+    from particle_fm_amd.models import SetFlowMatchingLitModule
+    from particle_fm_amd.utils.data_generation import generate_data
+    from tests.conftest import load_ca_golden
+    g = load_tf_golden("small") if which == "tf" else load_ca_golden("small")
+    m = SetFlowMatchingLitModule(optimizer=None, **copy.deepcopy(g.hp))
+    full = dict(g.state)
+    full.update({"loss." + k: v for k, v in g.state.items()})
+    m.load_state_dict(full)
+    N, C = g.hp["num_particles"], g.hp["global_cond_dim"]
+    gen = torch.Generator().manual_seed(5)
+    n = torch.randint(1, N + 1, (20,), generator=gen)
+    mask = (torch.arange(N)[None] < n[:, None]).float().unsqueeze(-1)
+    cond = torch.randn(20, C, generator=gen)
+    outs = []
+    for pipe in (True, False):
+        torch.manual_seed(321)
+        data, _ = generate_data(m, 20, cond=cond, batch_size=6, device="cuda", variable_set_sizes=True, mask=mask, verbose=False,
+                                ode_steps=6, pipeline=pipe)
+        outs.append(torch.from_numpy(data))
+        assert getattr(m.flows[0].net, "graph_replay", False) is False  # restored
+    assert torch.equal(outs[0], outs[1])
+    assert torch.all(outs[0][mask.squeeze(-1) == 0] == 0)
