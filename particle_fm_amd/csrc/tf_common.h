@@ -90,18 +90,26 @@ inline SideStream* side_stream() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     SideStream& e = st[dev];
     if (!e.s) {
-        if (hipStreamCreateWithFlags(&e.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        hipStream_t cand[6] = {};
-        int n = 0, pick = -1;
-        for (; n < 6 && pick < 0; ++n) {  // rejected candidates stay alive until the choice is made (else their queue is dealt again)
+        // candidates are kept alive until both choices are made (a destroyed stream's queue would be dealt to the next one again);
+        // s must overlap with the null stream (where callers without a stream of their own run their other work), s2 with both
+        hipStream_t cand[8] = {};
+        int n = 0, a = -1, b = -1;
+        for (; n < 8 && b < 0; ++n) {
             if (hipStreamCreateWithFlags(&cand[n], hipStreamNonBlocking) != hipSuccess) { cand[n] = nullptr; break; }
-            if (streams_overlap(e.s, cand[n])) pick = n;
+            if (!streams_overlap(nullptr, cand[n])) continue;
+            if (a < 0) a = n;
+            else if (streams_overlap(cand[a], cand[n])) b = n;
         }
-        if (pick < 0 && n > 0 && cand[0]) pick = 0;  // fewer independent queues than hoped for: still correct, just not concurrent
-        for (int i = 0; i < 6; ++i)
-            if (cand[i] && i != pick) hipStreamDestroy(cand[i]);
-        e.s2 = pick >= 0 ? cand[pick] : nullptr;
-        if (!e.s2 || hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
+        // fewer independent queues than hoped for: still correct, just not concurrent
+        if (a < 0 && cand[0]) a = 0;
+        if (b < 0)
+            for (int i = 0; i < 8 && b < 0; ++i)
+                if (cand[i] && i != a) b = i;
+        for (int i = 0; i < 8; ++i)
+            if (cand[i] && i != a && i != b) hipStreamDestroy(cand[i]);
+        e.s = a >= 0 ? cand[a] : nullptr;
+        e.s2 = b >= 0 ? cand[b] : nullptr;
+        if (!e.s || !e.s2 || hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e.join2, hipEventDisableTiming) != hipSuccess) {
             e.s = nullptr;
