@@ -119,8 +119,11 @@ def run(name, args):
     valid_rows = hasattr(net, "set_valid_rows_only") and not args.dense_rows
     if valid_rows:  # what generate_data does with variable_set_sizes: the sampler skips padded particles (EPiC always does)
         net.set_valid_rows_only(True)
-    # cross-attention (~200 launches per midpoint step): with two calls in flight the host's launch rate, not the GPU, sets the pace
-    graph = args.overlap > 1 and getattr(net, "_GRAPH_FLAG", 0) != 0 and not args.no_graph
+    # sampler calls in flight: 2 everywhere, 3 for the cross-attention path (its ~200 short launches per step leave most CUs idle,
+    # a third call still finds room: 443 jets/s one call at a time, 621 with two, 708 with three in flight).  From two calls on the
+    # host's launch rate, not the GPU, would set the pace (485 with two): the sampler then replays its captured step body
+    overlap = args.overlap if args.overlap is not None else (3 if hp["model"] == "droid_fullcrossattention" else 2)
+    graph = overlap > 1 and getattr(net, "_GRAPH_FLAG", 0) != 0 and not args.no_graph
     if graph:
         net.set_graph_replay(True)
     trainer = FusedFMTrainer(model, lr=1e-3, weight_decay=5e-5, max_grad_norm=0.5, ema_decay=0.999)
@@ -131,7 +134,7 @@ def run(name, args):
 
     # step i = train step i (default stream) + sample i with the weights of step i, on stream i % D; D = 2: the sample runs
     # while step i+1 trains and the next sample is queued (bench.py does the same; all launches are inside the timed region)
-    D = max(1, args.overlap)
+    D = max(1, overlap)
     main = torch.cuda.current_stream(dev)
     # the sampling streams must sit on hardware queues of their own (checked by measurement, utils/streams.py)
     streams = concurrent_streams(D, dev, also=[main]) if D > 1 else [main]
@@ -215,7 +218,8 @@ def main():
                          "every Linear, training included); bf16 = the jet-resident EPiC sampler only (BASELINE cfg 2 is quoted in bf16; "
                          "training stays fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", type=int, default=2, help="sampling launches in flight (1 = strictly sequential)")
+    ap.add_argument("--overlap", type=int, default=None, help="sampler calls in flight (1 = strictly sequential; default 2, "
+                    "cross-attention 3)")
     ap.add_argument("--no-graph", action="store_true", help="cross-attention path: enqueue every launch of the sampler from the host "
                     "instead of replaying the captured step body (hipGraph)")
     ap.add_argument("--dense-rows", action="store_true", help="transformer paths: sample all N rows like the reference (padded included)")
