@@ -96,12 +96,12 @@ def generate_data(model, num_jet_samples: int, batch_size: int = 256, cond: torc
 _PIPE_STREAMS = {}
 
 
-def _pipeline_streams(dev):
-    """the two side streams of the batch pipeline, created once per device and checked to run side by side (the stream ->
-    hardware-queue mapping is fixed at creation; a pair that lands on one queue loses the overlap: utils/streams.py)"""
-    key = str(dev)
+def _pipeline_streams(dev, n=2):
+    """the side streams of the batch pipeline, created once per device and checked to run side by side (the stream ->
+    hardware-queue mapping is fixed at creation; streams that land on one queue lose the overlap: utils/streams.py)"""
+    key = (str(dev), n)
     if key not in _PIPE_STREAMS:
-        _PIPE_STREAMS[key] = concurrent_streams(2, dev)
+        _PIPE_STREAMS[key] = concurrent_streams(n, dev)
     return _PIPE_STREAMS[key]
 
 
@@ -127,20 +127,22 @@ def _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes,
     if pipeline and dev.type == "cuda" and _pipelined(model) and ode_solver == "midpoint":
         with torch.no_grad():
             blob = model.flows[0].net.packed_weights(getattr(model.hparams, "num_particles", None))
-        streams = _pipeline_streams(dev)
+        # batches in flight: 2; 3 for the cross-attention model, whose short launches leave room for a third (bench_secondary.py)
+        streams = _pipeline_streams(dev, 3 if getattr(model.flows[0].net, "_GRAPH_FLAG", 0) else 2)
         for st in streams:
             st.wait_stream(torch.cuda.current_stream(dev))
 
-    pinned, staged = None, [None, None]
+    P = len(streams) if streams else 1
+    pinned, staged = None, [None] * P
     if streams and not getattr(model.hparams, "use_normaliser", False):
         # sample() inlined (flow_matching_module.py:656-674) so that nothing in the loop blocks the host: z is drawn by the same
         # torch.randn call into a pinned buffer (one per stream, reused once its copy has been consumed) and copied asynchronously
         N_, F_ = model.hparams.num_particles, model.hparams.features
-        pinned = [torch.empty(batch_size, N_, F_, pin_memory=True) for _ in range(2)]
+        pinned = [torch.empty(batch_size, N_, F_, pin_memory=True) for _ in range(P)]
 
     def one_batch(n, cond_b, mask_b):
         nonlocal scale, shift
-        k = len(outs) % 2
+        k = len(outs) % P
         ctx = torch.cuda.stream(streams[k]) if streams else contextlib.nullcontext()
         with ctx, torch.no_grad():
             if pinned is not None:
