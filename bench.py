@@ -122,7 +122,7 @@ def cpu_baseline(state, freqs, ode_steps, jets=64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="jets per GPU (BASELINE config: 256)")
     ap.add_argument("--ode-steps", type=int, default=100)
