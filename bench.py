@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 NFE_FLOP_PER_JET = 84.22e6     # algorithmic fwd FLOP / jet, dense over the padded N=150
 FP32_MFMA_PEAK = 157.3e12      # MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
+PMC_SUMMARIES = ("round2_pmc_hbm_summary.json", "round1_pmc_hbm_summary.json")  # profiles/: rocprofv3 --pmc passes of this command (tests/diag/collect_bench_profiles.sh), newest first
 HP = dict(model="epic", features=3, hidden_dim=128, num_particles=150, frequencies=16, layers=6, latent=10,
           activation="leaky_relu", wrapper_func="weight_norm", t_local_cat=True, t_global_cat=True,
           add_time_to_input=False, t_emb="cosine", loss_type="FM-OT", sigma=1e-4, global_cond_dim=0,
@@ -74,9 +75,14 @@ def usable_cores() -> int:
     return max(1, min(n, int(os.environ.get("PFM_BENCH_CPU_THREADS", "32"))))
 
 
-def cpu_baseline(state, freqs, ode_steps, jets=64):
-    """The oracle (eager PyTorch restatement of the reference graph) on the host cores, bounded sample."""
-    from oracle.fm_ref import EpicVectorField, fm_ot_loss, sample_midpoint
+def cpu_baseline(state, freqs, ode_steps, jets=256, sample_nfe=20, warmup=3, reps=5):
+    """The oracle (eager PyTorch restatement of the reference graph) on the host cores, SURVEY.md §8d protocol:
+    the bench batch (256 jets), `warmup` untimed + `reps` timed iterations of each leg, median.  The train leg is the
+    full (T) step.  The sample leg integrates `sample_nfe` network evaluations (sample_nfe / 2 midpoint intervals of the
+    same t-grid spacing) and is scaled to the 2 (ode_steps - 1) evaluations of the GPU's sample: the cost of an evaluation
+    does not depend on t, and the scaling is stated in `sample`."""
+    import statistics
+    from oracle.fm_ref import EpicVectorField, fm_ot_loss, midpoint_trajectory_end
     cores = usable_cores()
     torch.set_num_threads(cores)
     log(f"  cpu: {cores} threads (os.cpu_count()={os.cpu_count()})")
@@ -84,7 +90,7 @@ def cpu_baseline(state, freqs, ode_steps, jets=64):
     st = {k: v.clone().requires_grad_(v.is_floating_point() and "frequencies" not in k) for k, v in state.items()}
     params = [v for v in st.values() if v.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=5e-5)
-    x, mask, _ = synthetic_batch(jets, HP["num_particles"], HP["features"], 4242)
+    x, mask, _ = synthetic_batch(jets, HP["num_particles"], HP["features"], 12345)  # the GPU leg's batch of rank 0
     maskf = mask.float()
     vf = EpicVectorField(st, "flows.0.net", ohp, freqs=freqs)
 
@@ -97,26 +103,92 @@ def cpu_baseline(state, freqs, ode_steps, jets=64):
         torch.nn.utils.clip_grad_norm_(params, 0.5)
         opt.step()
 
-    train_step()  # warm-up
-    log("  cpu: train warm-up done")
-    t0 = time.perf_counter()
-    reps = 2
-    for _ in range(reps):
-        train_step()
-    t_train = (time.perf_counter() - t0) / reps
-    log(f"  cpu: train step {t_train*1e3:.1f} ms")
-    z = torch.randn(jets, HP["num_particles"], HP["features"])
-    with torch.no_grad():
-        vf_ng = EpicVectorField({k: v.detach() for k, v in st.items()}, "flows.0.net", ohp, freqs=freqs)
-        t0 = time.perf_counter()
-        sample_midpoint(vf_ng, z, None, maskf, ode_steps=ode_steps)
-        t_sample = time.perf_counter() - t0
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), ts
+
+    t_train, tr_all = timed(train_step)
+    log(f"  cpu: train step median {t_train*1e3:.1f} ms over {reps} (after {warmup} warm-up)")
+    n_nfe = 2 * (ode_steps - 1)
+    n_int = max(1, min(ode_steps - 1, sample_nfe // 2))
+    t_span = torch.linspace(1.0, 0.0, ode_steps)[: n_int + 1]  # the first n_int intervals of the reference's grid
+    z = torch.randn(jets, HP["num_particles"], HP["features"], generator=torch.Generator().manual_seed(9999)) * maskf
+    vf_ng = EpicVectorField({k: v.detach() for k, v in st.items()}, "flows.0.net", ohp, freqs=freqs)
+
+    def sample_leg():
+        with torch.no_grad():
+            midpoint_trajectory_end(lambda t, xx: vf_ng(t, xx, mask=maskf, cond=None), z, t_span)
+
+    t_part, sm_all = timed(sample_leg)
+    scale = n_nfe / (2 * n_int)
+    t_sample = t_part * scale
+    log(f"  cpu: {2 * n_int} NFE median {t_part*1e3:.1f} ms -> x{scale:.2f} = {t_sample:.2f} s per {n_nfe}-NFE sample")
     return {
         "value": jets / (t_train + t_sample), "unit": "jets/s", "cores": cores, "kind": "port",
-        "sample": f"{jets} jets: {reps} train steps (fwd+bwd+clip+AdamW) averaged + 1 full {ode_steps}-step midpoint "
-                  f"sample ({2 * (ode_steps - 1)} NFE); eager-PyTorch oracle, fp32, torch threads = {cores}",
+        "sample": f"{jets} jets (the bench batch), {warmup} warm-up + {reps} timed iterations per leg, median: (T) full train step "
+                  f"(FM-OT fwd+bwd, clip 0.5, AdamW); (S) {2 * n_int} of the {n_nfe} network evaluations of the midpoint sample "
+                  f"(first {n_int} intervals of linspace(1,0,{ode_steps})), time SCALED x{scale:.2f} to {n_nfe} NFE; eager-PyTorch "
+                  f"oracle, fp32, torch threads = {cores}",
         "train_jets_per_s": jets / t_train, "sample_jets_per_s": jets / t_sample,
+        "train_ms_median": 1e3 * t_train, "sample_s_scaled": t_sample, "sample_nfe_timed": 2 * n_int, "sample_scale": scale,
+        "train_ms_all": [1e3 * v for v in tr_all], "sample_part_ms_all": [1e3 * v for v in sm_all],
     }
+
+
+class StepLoop:
+    """The bench's step pipeline.  Step i = train step i + sample i with the weights of step i (a snapshot blob, so the next train
+    step may update the parameters meanwhile).  With D = overlap > 1 the sample of step i runs on stream i % D while step i+1 trains
+    on a stream of its own and the next sample is queued; with D = 1 everything is on the caller's stream.  The results do not
+    depend on D (tests/test_hip_bench_pipeline.py compares the parameters and the samples bit for bit)."""
+
+    def __init__(self, model, trainer, batch, z, ode_steps, overlap, dev):
+        from particle_fm_amd.utils.streams import concurrent_streams
+        self.model, self.trainer, self.batch, self.z, self.ode_steps, self.dev = model, trainer, batch, z, ode_steps, dev
+        N = batch[0].shape[1]
+        D = self.D = max(1, overlap)
+        # D + 1 streams on hardware queues of their own (a stream is bound to a queue at creation and two streams on one queue
+        # serialise); with D > 1 the train step runs on the last of them rather than on the default stream
+        pool = concurrent_streams(D + 1, dev) if D > 1 else []  # verified by measurement to run side by side (utils/streams.py)
+        self.streams = pool[:D] if D > 1 else [torch.cuda.current_stream(dev)]
+        self.main = pool[D] if D > 1 else torch.cuda.current_stream(dev)
+        if D > 1:
+            self.main.wait_stream(torch.cuda.current_stream(dev))
+        # D + 1 snapshot slots: train step i may run while samples i-1 .. i-D are still in flight (it only has to wait for sample
+        # i-(D+1), the last reader of its slot), so the train chain -- which includes the gradient all-reduce when N > 1 -- has a
+        # whole step of slack and a late collective delays nothing
+        S = self.S = D + 1
+        with torch.cuda.stream(self.main):
+            self.snaps = [trainer.snapshot_blob(N) for _ in range(S)]
+        self.outs = [None] * S
+        self.done = [torch.cuda.Event() for _ in range(S)]
+        self.N = N
+
+    def step(self, i, ev=None):
+        s, q, main = i % self.S, self.streams[i % self.D], self.main
+        x, mask, cond = self.batch
+        main.wait_event(self.done[s])          # snapshot slot s is free again (sample i-S has finished)
+        with torch.cuda.stream(main):
+            if ev:
+                ev[0].record(main)
+            self.trainer.step((x, mask, cond))
+            self.trainer.snapshot_blob(self.N, out=self.snaps[s])
+            if ev:
+                ev[1].record(main)
+        q.wait_stream(main)
+        with torch.cuda.stream(q), torch.no_grad():
+            if ev:
+                ev[2].record(q)
+            self.outs[s] = self.model(self.z, cond=None, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=self.ode_steps,
+                                      weights=self.snaps[s])
+            if ev:
+                ev[3].record(q)
+            self.done[s].record(q)
 
 
 def main():
@@ -158,7 +230,6 @@ def main():
 
     from particle_fm_amd.engine import FusedFMTrainer
     from particle_fm_amd.models import SetFlowMatchingLitModule
-    from particle_fm_amd.utils.streams import concurrent_streams
 
     torch.manual_seed(12345)  # fm_tops150.yaml:19 -- identical replicas on every rank
     model = SetFlowMatchingLitModule(optimizer=None, **HP).to(dev)
@@ -171,45 +242,8 @@ def main():
     z = (torch.randn(B, N, F, generator=gz) * mask.cpu()).to(dev)  # sample(): CPU draw, masked (:659-671)
     n_nfe = 2 * (args.ode_steps - 1)
 
-    # Step i = train step i (default stream) + sample i (stream i % D) with the weights of step i (a snapshot blob, so
-    # the next train step may update the parameters meanwhile).  All launches of all K steps are inside the timed
-    # region; the fence at the end waits for every stream.  With D = 1 everything is on one stream.
-    D = max(1, args.overlap)
-    # D + 1 streams on hardware queues of their own (a stream is bound to a queue at creation and two streams on one queue
-    # serialise); with D > 1 the train step runs on the last of them rather than on the default stream
-    pool = concurrent_streams(D + 1, dev) if D > 1 else []  # verified by measurement to run side by side (utils/streams.py)
-    streams = pool[:D] if D > 1 else [torch.cuda.current_stream(dev)]
-    main = pool[D] if D > 1 else torch.cuda.current_stream(dev)
-    if D > 1:
-        main.wait_stream(torch.cuda.current_stream(dev))
-    # D + 1 snapshot slots: train step i may run while samples i-1 .. i-D are still in flight (it only has to wait for sample
-    # i-(D+1), the last reader of its slot), so the train chain -- which includes the gradient all-reduce when N > 1 -- has a
-    # whole step of slack and a late collective delays nothing
-    S = D + 1
-    with torch.cuda.stream(main):
-        snaps = [trainer.snapshot_blob(N) for _ in range(S)]
-    outs = [None] * S
-    done = [torch.cuda.Event() for _ in range(S)]
-
-    def step(i, ev=None):
-        s, q = i % S, streams[i % D]
-        main.wait_event(done[s])          # snapshot slot s is free again (sample i-S has finished)
-        with torch.cuda.stream(main):
-            if ev:
-                ev[0].record(main)
-            trainer.step((x, mask, cond))
-            trainer.snapshot_blob(N, out=snaps[s])
-            if ev:
-                ev[1].record(main)
-        q.wait_stream(main)
-        with torch.cuda.stream(q), torch.no_grad():
-            if ev:
-                ev[2].record(q)
-            outs[s] = model(z, cond=None, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps,
-                            weights=snaps[s])
-            if ev:
-                ev[3].record(q)
-            done[s].record(q)
+    loop = StepLoop(model, trainer, (x, mask, cond), z, args.ode_steps, args.overlap, dev)
+    D, S, main, snaps, outs, step = loop.D, loop.S, loop.main, loop.snaps, loop.outs, loop.step
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -275,17 +309,28 @@ def main():
     if rank == 0:
         jets_per_step = B * world
         value = jets_per_step * args.steps / elapsed
-        achieved = B * n_nfe * NFE_FLOP_PER_JET / (sample_ms * 1e-3)
-        # what the matrix cores actually execute: 13 Linears of 128x128 per evaluation on the 16-row tiles up to the
-        # last valid particle of each jet (folded t/cond/g columns and fully masked tiles are not computed)
-        rows = ((mask.sum((1, 2)).cpu() + 15) // 16 * 16).sum().item()
-        executed = rows * 13 * 2 * 128 * 128 * n_nfe * args.steps / elapsed  # whole timed region (launches may overlap)
+        # What the matrix cores execute (rank 0's batch; every rank has the same shape of work): the 13 128x128 Linears of an
+        # evaluation on the 16-row tiles up to the last valid particle of each jet.  The t / cond / g columns of the reference's
+        # concatenated inputs are folded into per-jet biases (GEMVs on the VALU) and fully masked tiles are skipped, so this is
+        # LESS than SURVEY 8d's dense count (84.22 MFLOP/jet/NFE); the train step executes 3x the forward (fwd, dX, dW).
+        n_valid = mask.sum((1, 2)).cpu()
+        rows_exec = int(((n_valid + 15) // 16 * 16).sum().item())
+        lin_flop_per_row = 13 * 2 * 128 * 128
+        exec_sample = rows_exec * lin_flop_per_row * n_nfe            # per sampler launch
+        exec_train = rows_exec * lin_flop_per_row * 3                 # per train step
+        dense_sample = B * n_nfe * NFE_FLOP_PER_JET                   # SURVEY 8d algorithmic count per launch
+        executed = (exec_sample + exec_train) * args.steps / elapsed  # FLOP/s on the MFMA pipe over the timed wall time
+        n_pad = (N + 15) // 16 * 16
         traffic = None
-        try:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_hbm_summary.json")))["pfm::epic_sample_midpoint_kernel<0, true>"]
-            traffic = (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-        except Exception:
-            pass
+        pmc_file = None
+        for cand in PMC_SUMMARIES:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                pmc = next(v for k, v in pmc.items() if k.startswith("pfm::epic_sample_midpoint_kernel<0"))
+                traffic, pmc_file = (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0, cand
+                break
+            except Exception:
+                continue
         res = {
             "metric": "jets/sec (train step + 100-step ODE sample), EPiC-FM JetNet N=150",
             "value": value, "unit": "jets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -305,24 +350,28 @@ def main():
             "train_jets_per_s": B * world / (train_alone_ms * 1e-3), "sample_jets_per_s": B * world / (sample_ms * 1e-3),
             "timing_note": "train_ms / sample_ms: HIP events around the train step / one sampler launch INSIDE the timed region, where "
                            "they share the GPU (the train step's kernels wait for CUs held by sampler workgroups); train_ms_alone and "
-                           "roofline.frac_exclusive: the same work alone on the GPU after the timed region; train_jets_per_s uses "
+                           "roofline.kernel_alone_ms: the same work alone on the GPU after the timed region; train_jets_per_s uses "
                            "train_ms_alone",
             "roofline": {
-                "bound": "mfma", "kernel": "epic_sample_midpoint_kernel<0, true>", "achieved": achieved / 1e12,
-                "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK, "traffic": traffic,
-                "executed_on_mfma": executed / 1e12,
-                "concurrent_launches": D,
-                "aggregate_achieved": B * n_nfe * NFE_FLOP_PER_JET * args.steps / elapsed / 1e12,
-                "frac_aggregate": B * n_nfe * NFE_FLOP_PER_JET * args.steps / elapsed / FP32_MFMA_PEAK,
-                "frac_exclusive": B * n_nfe * NFE_FLOP_PER_JET / (excl_ms * 1e-3) / FP32_MFMA_PEAK,
-                "note": f"algorithmic {NFE_FLOP_PER_JET/1e6:.2f} MFLOP/jet/NFE x {n_nfe} NFE x {B} jets per launch "
-                        "(dense over padded N, concatenated t/cond columns counted) / HIP-event launch time in the timed region; with "
-                        "concurrent_launches = 2 two sampler launches share the GPU (a launch lasts as long as its largest jet, the CUs "
-                        "that finish early pick up the next launch's jets), so a launch takes ~1.5x longer while the GPU completes one "
-                        "every ms_per_step: frac_aggregate = all launches' algorithmic FLOP / timed wall time / peak, frac_exclusive = "
-                        "the same kernel alone on the GPU (3 launches after the timed region); executed_on_mfma = "
-                        "TFLOP/s the matrix cores really ran over the timed region (16-row tiles up to each jet's last valid particle); traffic = "
-                        "HBM-side bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/round1_pmc_hbm_summary.json (it counts each of the 8 XCD L2s fetching the weights and the time-term table once, Infinity-Cache hits included)",
+                "bound": "mfma", "kernel": "epic_sample_midpoint_kernel<0, true>",
+                "achieved": executed / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": executed / FP32_MFMA_PEAK, "traffic": traffic,
+                "executed_flop_per_launch": exec_sample, "executed_flop_per_train_step": exec_train,
+                "valid_row_fraction": float(n_valid.sum().item()) / (B * N),
+                "executed_row_fraction": rows_exec / float(B * n_pad),
+                "kernel_ms_in_timed_region": sample_ms, "kernel_alone_ms": excl_ms, "concurrent_launches": D,
+                "algorithmic_dense_flop_per_launch": dense_sample,
+                "frac_algorithmic_dense": dense_sample / (excl_ms * 1e-3) / FP32_MFMA_PEAK,
+                "dense_flop_not_executed_share": 1.0 - exec_sample / dense_sample,
+                "note": "frac = achieved / peak with achieved = FLOP the matrix cores EXECUTE (13 Linears of 128x128 per evaluation on "
+                        "the 16-row tiles up to each jet's last valid particle; sampler launches + train steps, train = 3x forward) "
+                        "over the timed wall time: it cannot exceed 1.  frac_algorithmic_dense = SURVEY 8d's dense count "
+                        f"({NFE_FLOP_PER_JET/1e6:.2f} MFLOP/jet/NFE x {n_nfe} NFE x {B} jets: padded N, concatenated t/cond/g columns "
+                        "counted) / duration of ONE launch alone on the GPU (kernel_alone_ms) / peak; dense_flop_not_executed_share of "
+                        "that count is never executed (masked tail tiles skipped, t/cond/g columns folded into per-jet bias GEMVs on "
+                        "the VALU), so the dense figure is a throughput-equivalent, not MFMA utilisation.  traffic = HBM-side bytes per "
+                        f"launch, (2*FETCH_SIZE + WRITE_SIZE) KiB of profiles/{pmc_file} (each of the 8 XCD L2s fetches the "
+                        "weights and the time-term table once, Infinity-Cache hits included)",
             },
         }
         if world == 1:

@@ -17,7 +17,9 @@ is latency-bound on the 7 xGMI links; one flat call lets RCCL pick its low-laten
 from __future__ import annotations
 
 import ctypes
-from typing import Iterable, List, Optional
+import contextlib
+import math
+from typing import Callable, Dict, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -127,8 +129,11 @@ class FusedFMTrainer:
 
     def __init__(self, module: nn.Module, lr: float = 1e-3, weight_decay: float = 5e-5, betas=(0.9, 0.999),
                  eps: float = 1e-8, max_grad_norm: float = 0.5, ema_decay: Optional[float] = 0.999,
-                 process_group=None):
+                 process_group=None, lr_schedule: Optional[Callable[[int], float]] = None):
+        """``lr_schedule(k)`` -> factor on ``lr`` for the k-th optimiser step (k = 0 for the first one), e.g.
+        :func:`cosine_warmup`; None keeps the rate constant."""
         self.module = module
+        self.lr_schedule = lr_schedule
         self.fp = FlatParams(module.parameters())
         dev = self.fp.flat.device
         if dev.type != "cuda":
@@ -151,13 +156,18 @@ class FusedFMTrainer:
             self._fused = {}
             flows[0].net._fast_pack = self.packed_blob  # sampling re-packs with one HIP launch instead of ~100 torch ops
 
+    def current_lr(self) -> float:
+        """learning rate of the NEXT optimiser step"""
+        return self.lr * (float(self.lr_schedule(self.step_count)) if self.lr_schedule is not None else 1.0)
+
     def optimizer_step(self, grad_mul: float = 1.0):
+        lr = self.current_lr()
         self.step_count += 1
         fp = self.fp
         P = hip_ops._ptr
         rc = _lib.load().pfm_optim_step(
             P(fp.flat), P(fp.grad), P(self.exp_avg), P(self.exp_avg_sq), P(self.ema), P(self.scratch),
-            ctypes.c_int64(fp.numel), grad_mul, self.max_grad_norm if self.max_grad_norm else 0.0, self.lr,
+            ctypes.c_int64(fp.numel), grad_mul, self.max_grad_norm if self.max_grad_norm else 0.0, lr,
             self.betas[0], self.betas[1], self.eps, self.weight_decay,
             self.ema_decay if self.ema_decay is not None else 0.0, self.step_count,
             hip_ops._stream_ptr(fp.flat.device))
@@ -254,9 +264,7 @@ class FusedFMTrainer:
     def step(self, batch, fused: bool = True) -> torch.Tensor:
         x, mask, cond = batch
         if not self.fp.is_intact():
-            self.fp.rebuild()
-            if self._fused is not None:
-                self._fused = {}
+            self._rebuild()
         self.fp.grad.zero_()
         if getattr(getattr(self.module, "hparams", None), "use_normaliser", False):  # training_step's pre-processing (:514-518)
             x, cond = self.module._normalise(x, mask, cond)
@@ -270,6 +278,93 @@ class FusedFMTrainer:
         self.optimizer_step(mul)
         return loss.detach()
 
+    def _rebuild(self):
+        """The parameters no longer alias the flat buffer (module.to(device), a parameter replaced): re-home them, and move the
+        optimiser / EMA state along (same element order: FlatParams keeps the parameter list and the offsets)."""
+        self.fp.rebuild()
+        dev = self.fp.flat.device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedFMTrainer needs the module on a ROCm device (no CPU fallback)")
+        self.exp_avg, self.exp_avg_sq, self.scratch = self.exp_avg.to(dev), self.exp_avg_sq.to(dev), self.scratch.to(dev)
+        if self.ema is not None:
+            self.ema = self.ema.to(dev)
+        if self._fused is not None:
+            self._fused = {}
+
+    # ---- checkpoint / resume (what Lightning saves for the reference: optimizer state + the EMA callback's weights) ----
+    def _names(self) -> List[str]:
+        by_id = {id(p): n for n, p in self.module.named_parameters()}
+        return [by_id[id(p)] for p in self.fp.params]
+
+    def state_dict(self) -> Dict[str, object]:
+        """Everything a resume needs besides ``module.state_dict()``: Adam moments, step count (bias correction, schedule),
+        EMA weights, hyper-parameters; flat tensors in the order of ``param_names`` (CPU copies)."""
+        if not self.fp.is_intact():
+            self._rebuild()
+        return {
+            "step_count": self.step_count, "param_names": self._names(), "offsets": list(self.fp.offsets), "numel": self.fp.numel,
+            "exp_avg": self.exp_avg.detach().cpu().clone(), "exp_avg_sq": self.exp_avg_sq.detach().cpu().clone(),
+            "ema": None if self.ema is None else self.ema.detach().cpu().clone(),
+            "hparams": {"lr": self.lr, "weight_decay": self.weight_decay, "betas": tuple(self.betas), "eps": self.eps,
+                        "max_grad_norm": self.max_grad_norm, "ema_decay": self.ema_decay},
+        }
+
+    def load_state_dict(self, sd: Dict[str, object], load_hparams: bool = True) -> None:
+        if not self.fp.is_intact():
+            self._rebuild()
+        if list(sd["param_names"]) != self._names() or int(sd["numel"]) != self.fp.numel:
+            raise ValueError("trainer state was saved for a different parameter list")
+        dev = self.fp.flat.device
+        self.exp_avg.copy_(sd["exp_avg"].to(dev))
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"].to(dev))
+        if sd.get("ema") is not None and self.ema is not None:
+            self.ema.copy_(sd["ema"].to(dev))
+        self.step_count = int(sd["step_count"])
+        if load_hparams:
+            hp = sd["hparams"]
+            self.lr, self.weight_decay, self.betas, self.eps = hp["lr"], hp["weight_decay"], tuple(hp["betas"]), hp["eps"]
+            self.max_grad_norm = hp["max_grad_norm"]
+            if self.ema is not None:
+                self.ema_decay = hp["ema_decay"]
+
+    def ema_state_dict(self) -> Dict[str, torch.Tensor]:
+        """``module.state_dict()`` with every trainable parameter replaced by its EMA value: what the reference's
+        ``-EMA.ckpt`` holds under "state_dict" (callbacks/ema.py:145-157, EMAModelCheckpoint)."""
+        if self.ema is None:
+            raise RuntimeError("EMA is off (ema_decay=None)")
+        out = {k: v.detach().clone() for k, v in self.module.state_dict().items()}
+        names = self._names()
+        for name, p, off in zip(names, self.fp.params, self.fp.offsets):
+            out[name] = self.ema[off:off + p.numel()].view_as(p).detach().clone()
+        return out
+
+    @contextlib.contextmanager
+    def swap_ema(self):
+        """``with trainer.swap_ema(): validate / sample`` -- the EMA callback's replace_model_weights / restore_original_weights
+        (callbacks/ema.py:145-176): inside the block the module's parameters ARE the EMA weights (one device copy each way)."""
+        if self.ema is None:
+            raise RuntimeError("EMA is off (ema_decay=None)")
+        if not self.fp.is_intact():
+            self._rebuild()
+        keep = self.fp.flat.detach().clone()
+        self.fp.flat.copy_(self.ema)
+        try:
+            yield self.module
+        finally:
+            self.fp.flat.copy_(keep)
+
     def grad_norm(self) -> torch.Tensor:
         """global L2 norm of the last (scaled) gradient, as clip_grad_norm_ saw it"""
         return self.scratch[0].sqrt()
+
+
+def cosine_warmup(warmup: int, max_iters: int) -> Callable[[int], float]:
+    """The reference's CosineWarmupScheduler.get_lr_factor (schedulers/lr_scheduler.py:17-21) as an ``lr_schedule`` for
+    :class:`FusedFMTrainer`: 0.5 (1 + cos(pi k / max_iters)), times k / warmup while k <= warmup.  The reference steps it once per
+    EPOCH (flow_matching_module.py:626-633, ``interval: "epoch"``): pass ``lambda k: f(k // steps_per_epoch)`` for that."""
+    def factor(k: int) -> float:
+        f = 0.5 * (1.0 + math.cos(math.pi * k / max_iters))
+        if k <= warmup:
+            f *= k * 1.0 / warmup
+        return f
+    return factor

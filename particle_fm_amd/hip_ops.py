@@ -84,9 +84,7 @@ def epic_forward_temb(layout: EpicLayout, blob: torch.Tensor, temb: torch.Tensor
     return v
 
 
-def midpoint_grid(ode_steps: int):
-    """Times and step sizes the fixed-step driver visits for t_span = linspace(1, 0, ode_steps)
-    (flow_matching_module.py:285; torchdyn driver: t += dt; dt = t_span[k+1] - t), in fp32 on the host."""
+def _midpoint_grid_host(ode_steps: int):
     t_span = torch.linspace(1.0, 0.0, ode_steps)
     t = t_span[0]
     dt = t_span[1] - t
@@ -98,6 +96,27 @@ def midpoint_grid(ode_steps: int):
         if k < ode_steps - 1:
             dt = t_span[k + 1] - t
     return torch.stack(ts), torch.stack(dts)
+
+
+_GRID_CACHE: dict = {}
+
+
+def midpoint_grid(ode_steps: int, device=None):
+    """Times and step sizes the fixed-step driver visits for t_span = linspace(1, 0, ode_steps)
+    (flow_matching_module.py:285; torchdyn driver: t += dt; dt = t_span[k+1] - t), in fp32 on the host.  The grid is a
+    pure function of ``ode_steps``: it is built once (198 scalar tensor ops) and, with ``device``, copied there once --
+    a sampler call then costs no host arithmetic and no pageable H2D copy.  Callers must not write to the result."""
+    key = (int(ode_steps), None if device is None else str(device))
+    hit = _GRID_CACHE.get(key)
+    if hit is None:
+        host = _GRID_CACHE.get((int(ode_steps), None))
+        if host is None:
+            host = _GRID_CACHE[(int(ode_steps), None)] = _midpoint_grid_host(int(ode_steps))
+        hit = host if device is None else tuple(a.to(device) for a in host)
+        if len(_GRID_CACHE) > 64:
+            _GRID_CACHE.clear()
+        _GRID_CACHE[key] = hit
+    return hit
 
 
 class RkTableau(ctypes.Structure):
@@ -134,7 +153,14 @@ def rk_tableau(solver: str) -> RkTableau:
 
 def rk_grid(ode_steps: int, solver: str, t0: float = 1.0, t1: float = 0.0):
     """Stage times and step sizes the fixed-step driver visits for t_span = linspace(t0, t1, ode_steps) (torchdyn driver:
-    t += dt; dt = t_span[k+1] - t; stage s is evaluated at t + c[s] * dt), in fp32 on the host."""
+    t += dt; dt = t_span[k+1] - t; stage s is evaluated at t + c[s] * dt), in fp32 on the host (built once per argument set)."""
+    key = ("rk", int(ode_steps), solver, float(t0), float(t1))
+    if key not in _GRID_CACHE:
+        _GRID_CACHE[key] = _rk_grid_host(ode_steps, solver, t0, t1)
+    return _GRID_CACHE[key]
+
+
+def _rk_grid_host(ode_steps: int, solver: str, t0: float = 1.0, t1: float = 0.0):
     c = torch.tensor(RK_TABLEAUS[solver][0], dtype=torch.float32)
     t_span = torch.linspace(t0, t1, ode_steps)
     t = t_span[0]
@@ -184,8 +210,7 @@ def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor
     dev, B, blob, z, cond, mask = _prep_common(layout, blob, z, cond, mask)
     if ode_steps < 2:
         raise ValueError("ode_steps must be >= 2")
-    ts, dts = midpoint_grid(ode_steps)
-    ts, dts = ts.to(dev), dts.to(dev)
+    ts, dts = midpoint_grid(ode_steps, dev)
     out = torch.empty_like(z)
     # time-term table of the call (every jet is evaluated at the same times): cached per (layout, steps, device)
     cache = layout.__dict__.setdefault("_sample_scratch", {})

@@ -12,6 +12,15 @@ from .layout_wide import EpicWideLayout
 
 def workspace(layout: EpicWideLayout, n_jets: int, device, train: bool = False) -> torch.Tensor:
     lib = _lib.load()
+    if train:
+        # The loss forward hands this tensor to its autograd node as the saved activations: it must be private to the call.  (A
+        # cached one would be overwritten by a second forward of the same batch size before the first backward -- two
+        # micro-batches summed before .backward(), a no_grad validation loss between a forward and its backward -- and the
+        # backward would silently return wrong gradients.)  torch's caching allocator hands the block back in steady state.
+        n = lib.pfm_ew_workspace_floats(ctypes.byref(layout.desc), n_jets, 1)
+        if n < 0:
+            _lib.check(1, "pfm_ew_workspace_floats")
+        return torch.empty(n, device=device, dtype=torch.float32)
     cache = layout.__dict__.setdefault("_ws", {})
     # one workspace per stream: samples queued on two streams may run at the same time
     key = (n_jets, bool(train), str(device), torch.cuda.current_stream(device).cuda_stream)
@@ -44,8 +53,7 @@ def ew_sample_midpoint(layout: EpicWideLayout, blob, z, cond=None, mask=None, od
     dev, B, blob, z, cond, mask = _prep_common(layout, blob, z, cond, mask)
     if ode_steps < 2:
         raise ValueError("ode_steps must be >= 2")
-    ts, dts = midpoint_grid(ode_steps)
-    ts, dts = ts.to(dev), dts.to(dev)
+    ts, dts = midpoint_grid(ode_steps, dev)
     out = torch.empty_like(z)
     state = torch.empty(2 * z.numel(), device=dev, dtype=torch.float32)
     rc = lib.pfm_ew_sample_midpoint(ctypes.byref(layout.desc), _ptr(blob), _ptr(ts), _ptr(dts), ode_steps - 1, _ptr(z),

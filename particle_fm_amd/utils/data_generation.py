@@ -57,7 +57,7 @@ def generate_data(model, num_jet_samples: int, batch_size: int = 256, cond: torc
                   variable_set_sizes: bool = False, mask: torch.Tensor = None, normalized_data: bool = False,
                   normalize_sigma: int = 5, means=None, stds=None, log_pt: bool = False, pt_standardization: bool = False,
                   shuffle_mask: bool = False, verbose: bool = True, ode_solver: str = "midpoint", ode_steps: int = 100,
-                  valid_rows_only: bool = True, pipeline: bool = True):
+                  valid_rows_only: bool = True, pipeline: bool = True, _shard=(0, 1)):
     if variable_set_sizes and mask is None:
         raise ValueError("Please use mask when using variable_set_sizes=True")  # data_generation.py:62-63
     if mask is not None and len(mask) != num_jet_samples:
@@ -85,7 +85,7 @@ def generate_data(model, num_jet_samples: int, batch_size: int = 256, cond: torc
             replay.append(net)
     try:
         return _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes, mask, normalized_data, normalize_sigma,
-                         means, stds, log_pt, pt_standardization, shuffle_mask, ode_solver, ode_steps, pipeline)
+                         means, stds, log_pt, pt_standardization, shuffle_mask, ode_solver, ode_steps, pipeline, _shard)
     finally:
         for net in switched:
             net.set_valid_rows_only(False)
@@ -113,7 +113,9 @@ def _pipelined(model) -> bool:
 
 
 def _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes, mask, normalized_data, normalize_sigma, means, stds,
-              log_pt, pt_standardization, shuffle_mask, ode_solver, ode_steps, pipeline):
+              log_pt, pt_standardization, shuffle_mask, ode_solver, ode_steps, pipeline, shard=(0, 1)):
+    rank, world = shard
+    dev_sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)  # (the sampler itself refuses CPU tensors)
     n_full = num_jet_samples // batch_size
     rem = num_jet_samples - n_full * batch_size
     scale = shift = None
@@ -140,8 +142,16 @@ def _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes,
         N_, F_ = model.hparams.num_particles, model.hparams.features
         pinned = [torch.empty(batch_size, N_, F_, pin_memory=True) for _ in range(P)]
 
+    n_seen = 0
+
     def one_batch(n, cond_b, mask_b):
-        nonlocal scale, shift
+        nonlocal scale, shift, n_seen
+        n_seen += 1
+        if (n_seen - 1) % world != rank:
+            # another rank's batch (generate_data_sharded): consume the same numbers of the CPU generator as sample() would
+            # (flow_matching_module.py:659-663), so that every rank's z is the slice the single-process run would have drawn
+            torch.randn(n, getattr(model.hparams, "num_particles"), getattr(model.hparams, "features"))
+            return
         k = len(outs) % P
         ctx = torch.cuda.stream(streams[k]) if streams else contextlib.nullcontext()
         with ctx, torch.no_grad():
@@ -175,7 +185,7 @@ def _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes,
     for i in range(n_full):
         cond_b = None if cond is None else cond[i * batch_size:(i + 1) * batch_size]
         if i == 1:  # the reference's convention: the first (warm-up) batch is not timed (data_generation.py:82-83)
-            torch.cuda.synchronize(dev)
+            dev_sync()
             start_time = time.time()
         if variable_set_sizes:
             if shuffle_mask:
@@ -186,7 +196,7 @@ def _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes,
         else:
             mask_b = None
         one_batch(batch_size, cond_b, mask_b)
-    torch.cuda.synchronize(dev)
+    dev_sync()
     end_time = time.time()
     if rem:
         cond_b = None if cond is None else cond[-rem:]
@@ -199,5 +209,67 @@ def _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes,
         one_batch(rem, cond_b, mask_b)
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)  # the remainder batch may have run on a side stream
+    if world > 1:
+        return outs, end_time - start_time  # this rank's batches (round-robin), still on the device
     data = torch.cat(outs).cpu().numpy() if outs else np.zeros((0,), dtype=np.float32)
     return data, end_time - start_time
+
+
+def shard_plan(num_jet_samples: int, batch_size: int, world: int):
+    """Row ranges (start, stop) of the batches generate_data forms -- full batches in order, then the remainder -- and the rank
+    that takes each (round-robin over batches: consecutive batches go to different GPUs, every rank sees the same mix of the
+    caller's jet order)."""
+    n_full = num_jet_samples // batch_size
+    spans = [(i * batch_size, (i + 1) * batch_size) for i in range(n_full)]
+    if num_jet_samples - n_full * batch_size:
+        spans.append((n_full * batch_size, num_jet_samples))
+    return [(a, b, i % world) for i, (a, b) in enumerate(spans)]
+
+
+def generate_data_sharded(model, num_jet_samples: int, batch_size: int = 256, process_group=None, gather: bool = True,
+                          rank: Optional[int] = None, world: Optional[int] = None, **kw):
+    """``generate_data`` with the jet list split across the ranks of ``process_group`` (sampling is embarrassingly
+    parallel; one process per GPU, no data-path collective).  The reference's helper is single-process
+    (utils/data_generation.py:17-176); this one returns the SAME array bit for bit:
+
+    * every rank walks the same batch list (:func:`shard_plan`) and runs batch i iff ``i % world == rank``;
+    * z is drawn from the CPU generator exactly as the single process draws it -- every rank draws every batch's z (cheap next to
+      198 network evaluations) and drops the ones it does not run -- so all ranks must enter with the same CPU RNG state
+      (``seed_everything`` / ``torch.manual_seed``, as the reference's evaluation callbacks do) and leave with the state the
+      single-process run leaves; ``shuffle_mask`` likewise relies on identical numpy RNG state;
+    * ``cond`` / ``mask`` are the FULL arrays on every rank (a rank slices its rows itself).
+
+    ``gather=True``: the shards are exchanged with one all_gather of equal-sized (padded) device tensors (RCCL for backend
+    "nccl", gloo in the CPU tests) and every rank returns the full (num_jet_samples, N, F) array; ``gather=False``: returns this
+    rank's rows and their indices ``(rows, index)``.  The time returned is this rank's (same convention as generate_data:
+    from its second batch to the end of its full batches)."""
+    import torch.distributed as dist
+
+    if world is None:
+        world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(process_group) if dist.is_available() and dist.is_initialized() else 0
+    if world == 1:
+        return generate_data(model, num_jet_samples, batch_size=batch_size, **kw)
+    outs, seconds = generate_data(model, num_jet_samples, batch_size=batch_size, _shard=(rank, world), **kw)
+    plan = shard_plan(num_jet_samples, batch_size, world)
+    mine = [(a, b) for a, b, r in plan if r == rank]
+    assert len(mine) == len(outs) and all(o.shape[0] == b - a for o, (a, b) in zip(outs, mine))
+    index = np.concatenate([np.arange(a, b) for a, b in mine]) if mine else np.zeros((0,), dtype=np.int64)
+    if not gather:
+        rows = torch.cat(outs).cpu().numpy() if outs else np.zeros((0,), dtype=np.float32)
+        return (rows, index), seconds
+    N, F = model.hparams.num_particles, model.hparams.features
+    dev = outs[0].device if outs else torch.device(kw.get("device", "cuda"))
+    counts = [sum(b - a for a, b, r in plan if r == q) for q in range(world)]
+    pad = max(counts)
+    buf = torch.zeros(pad, N, F, device=dev, dtype=torch.float32)
+    if outs:
+        buf[:counts[rank]] = torch.cat(outs)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=process_group)
+    full = torch.empty(num_jet_samples, N, F, dtype=torch.float32)
+    for q in range(world):
+        rows_q = np.concatenate([np.arange(a, b) for a, b, r in plan if r == q]) if counts[q] else np.zeros((0,), dtype=np.int64)
+        full[torch.from_numpy(rows_q)] = parts[q][:counts[q]].cpu()
+    return full.numpy(), seconds

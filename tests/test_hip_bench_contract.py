@@ -29,7 +29,13 @@ def test_bench_line_schema():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert 0.3 < r["frac"] < 1.0 and r["traffic"] is None or r["traffic"] > 1e6
+    assert 0.3 < r["frac"] < 1.0 and (r["traffic"] is None or r["traffic"] > 1e6)
+    # self-consistency: the FLOP the line says were executed per step, over the step time, cannot exceed the peak
+    per_step = r["executed_flop_per_launch"] + r["executed_flop_per_train_step"]
+    assert abs(per_step / (d["ms_per_step"] * 1e-3) / 1e12 - r["achieved"]) < 1e-6 * r["achieved"]
+    assert per_step / (d["ms_per_step"] * 1e-3) <= r["peak"] * 1e12
+    assert 0.0 < r["valid_row_fraction"] <= r["executed_row_fraction"] <= 1.0
+    assert "frac_algorithmic_dense" in r and 0.0 < r["dense_flop_not_executed_share"] < 1.0
 
 
 def test_two_rank_launch_rehearsal():

@@ -54,3 +54,34 @@ def test_generate_data_argument_errors():
         generate_data(None, 4, variable_set_sizes=True, mask=None)
     with pytest.raises(ValueError):
         generate_data(None, 4, variable_set_sizes=True, mask=torch.ones(3, 5, 1))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_sharded_generation_is_the_single_process_array(world):
+    """generate_data_sharded, rank by rank in this one process (the exchange itself is covered on CPU by
+    tests/test_generate_sharded_gloo.py, world 2): the union of the ranks' rows is the single-process array, bit for bit."""
+    from particle_fm_amd.models import SetFlowMatchingLitModule
+    from particle_fm_amd.utils.data_generation import generate_data, generate_data_sharded
+    from tests.conftest import load_golden
+    g = load_golden("jetnet30")
+    m = SetFlowMatchingLitModule(optimizer=None, sigma=1e-4, **_yaml_kwargs(g.hp))
+    full = dict(g.state)
+    full.update({"loss." + k: v for k, v in g.state.items()})
+    m.load_state_dict(full)
+    gen = torch.Generator().manual_seed(12)
+    n_jets, bs, N, F, steps = 45, 8, 30, 3, 4  # five full batches + a remainder of 5
+    nv = torch.randint(5, N + 1, (n_jets,), generator=gen)
+    mask = (torch.arange(N)[None] < nv[:, None]).float().unsqueeze(-1)
+    kw = dict(cond=None, device="cuda", variable_set_sizes=True, mask=mask, normalized_data=True, normalize_sigma=5,
+              means=np.array([0.01, -0.02, 0.05]), stds=np.array([0.11, 0.12, 0.9]), log_pt=True, verbose=False, ode_steps=steps)
+    torch.manual_seed(9999)
+    want, _ = generate_data(m, n_jets, batch_size=bs, **kw)
+    end_state = torch.get_rng_state()
+    got = np.full_like(want, np.nan)
+    for rank in range(world):
+        torch.manual_seed(9999)
+        (rows, index), _ = generate_data_sharded(m, n_jets, batch_size=bs, gather=False, rank=rank, world=world, **kw)
+        assert torch.equal(torch.get_rng_state(), end_state)
+        assert np.isnan(got[index]).all()
+        got[index] = rows
+    assert got.tobytes() == want.tobytes()

@@ -46,3 +46,22 @@ def test_loss_and_all_parameter_gradients(tf_golden, kind):
     torch.testing.assert_close(loss.detach().cpu(), g.get(tag + "loss"), rtol=2e-5, atol=1e-6)
     loss.backward()
     _check_grads(g, lay, flat.grad.cpu(), tag)
+
+
+def test_second_forward_before_the_first_backward_keeps_the_first_gradients(tf_golden):
+    """The saved activations belong to the call: a second loss forward of the same batch size (another micro-batch, a no_grad
+    validation loss) between a forward and its backward must not change that backward's gradients."""
+    from particle_fm_amd.fm_loss_tf import tf_fm_loss
+    g = tf_golden
+    lay, flat = _setup(g)
+    tag = "loss_f32/"
+    x, t, mask, cond, z = (g.get(tag + k).cuda() for k in ("x", "t", "mask", "cond", "z"))
+    loss = tf_fm_loss(lay, flat, x, t, z, cond, mask, 1e-4, "FM-OT", None, freqs=g.freqs)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    with torch.no_grad():  # same shapes, different numbers
+        tf_fm_loss(lay, flat, torch.randn(x.shape, device="cuda", generator=gen), 1.0 - t, torch.randn(z.shape, device="cuda", generator=gen),
+                   cond, mask, 1e-4, "FM-OT", None, freqs=g.freqs)
+    other = tf_fm_loss(lay, flat, x.flip(0), t.flip(0), z, cond.flip(0), mask.flip(0), 1e-4, "FM-OT", None, freqs=g.freqs)
+    loss.backward()
+    _check_grads(g, lay, flat.grad.cpu(), tag)
+    del other
