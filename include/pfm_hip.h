@@ -40,7 +40,7 @@
  *   MFMA_A           the H x H block that multiplies the per-particle activations, pre-arranged as the
  *                    A operand of v_mfma_f32_16x16x4_f32: float4 at ((w*8 + kt)*64 + lane) holds
  *                    W[16*w + (lane&15)][16*kt + 4*(lane>>4) + r], r = 0..3   (w = output slice 0..7).
- *   GRAD_D           (gradient blob only) a 128x128 block in accumulator order: float ((w*8 + it)*4 + r)*64 + lane
+ *   GRAD_D           (gradient blob only) a 128x128 block in the order of a 16-row-panel accumulator: float ((w*8 + it)*4 + r)*64 + lane
  *                    holds dW[16*w + 4*(lane>>4) + r][8*(lane&15) + it].
  *   MFMA_AT          the same block transposed (used by the backward dX products):
  *                    float4 at ((w*8 + kt)*64 + lane) holds W[16*kt + 4*(lane>>4) + r][16*w + (lane&15)].
@@ -191,14 +191,24 @@ int pfm_epic_fm_loss_forward(const pfm_epic_desc *desc, const float *blob, int32
                              const float *cond, const float *mask, float *saved, float *loss_parts,
                              float *mask_count, int32_t B, void *stream);
 
-/* Backward of the above w.r.t. the blob: grad_blob += d(loss)/d(blob) with loss = sum(loss_parts)/sum(mask_count)
+/* Backward of the above w.r.t. the blob: grad_blob = d(loss)/d(blob) with loss = sum(loss_parts)/sum(mask_count)
  * scaled by grad_scale (the incoming dL).  inv_mask_total = 1/sum(mask_count) is passed as a device scalar.
- * grad_blob has the offsets (and length) of the blob and must be zeroed by the caller; MFMA_A blocks come back in
- * GRAD_D order, MFMA_AT blocks are not written, everything else is in blob order.  `t` is unused (may be NULL). */
+ * grad_blob has the offsets (and length) of the blob; every position that carries a parameter's gradient is WRITTEN (not
+ * accumulated; the rest is left alone): MFMA_A blocks come back in GRAD_D order, MFMA_AT blocks are not written, everything
+ * else is in blob order.  `t` is unused (may be NULL).  scratch: pfm_epic_backward_scratch_floats(desc, B) floats (the
+ * gradient rows of every 128x128 Linear, the per-jet rank-1 operands, the partial dW tiles).  Three launches -- the per-jet
+ * chain, one GEMM launch for all dW over the rows of all jets, one fixed-order reduction -- and no atomics: the result is a
+ * pure function of the inputs, bit for bit, run to run.  B <= 8192 per call. */
+int64_t pfm_epic_backward_scratch_floats(const pfm_epic_desc *desc, int32_t B);
 int pfm_epic_fm_loss_backward(const pfm_epic_desc *desc, const float *blob, const float *t,
                               const float *cond, const float *mask, const float *saved,
                               const float *inv_mask_total, const float *grad_scale, float *grad_blob,
-                              int32_t B, void *stream);
+                              int32_t B, float *scratch, void *stream);
+
+/* The scalar tail of the losses above (losses.py:75-76: sum / mask.sum()) in one launch: out2[0] = sum_b w_b loss_parts[b] /
+ * sum_b mask_count[b] (w = jet_weight, or 1 if NULL), out2[1] = 1 / sum_b mask_count[b] (the inv_mask_total of the backward).
+ * Sums in a fixed order. */
+int pfm_loss_finish(const float *loss_parts, const float *mask_count, const float *jet_weight, int32_t B, float *out2, void *stream);
 
 /* DiffusionLoss (models/components/losses.py:207-290, configs/model/diffusion.yaml): noisy = rates[b][0] * x + rates[b][1] * z
  * (signal / noise rate of the jet's diffusion time, models/components/diffusion.py:21-52; z arrives multiplied by the mask),
@@ -211,7 +221,7 @@ int pfm_epic_diffusion_loss_forward(const pfm_epic_desc *desc, const float *blob
 /* Backward of loss = sum_b jet_weight[b] * loss_parts[b] / sum(mask_count), as pfm_epic_fm_loss_backward. */
 int pfm_epic_diffusion_loss_backward(const pfm_epic_desc *desc, const float *blob, int32_t criterion, const float *jet_weight,
                                      const float *cond, const float *mask, const float *saved, const float *inv_mask_total,
-                                     const float *grad_scale, float *grad_blob, int32_t B, void *stream);
+                                     const float *grad_scale, float *grad_blob, int32_t B, float *scratch, void *stream);
 
 /* One in-place state update of the diffusion samplers (models/components/solver.py): mode 0 = ddim_sampler :81-93
  * (c = noise rate, signal rate, next signal rate, next noise rate; data_out, optional, receives the predicted data),

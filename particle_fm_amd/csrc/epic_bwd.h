@@ -8,11 +8,14 @@
 // the whole backward; Hb holds the gradient at the inner activation of the current layer.
 //   dX products   dl1 = W2^T da2,  dh = W1^T da1 + da2        -> same MFMA scheme as the forward with the
 //                 transposed weight fragments (MFMA_AT) in registers and the gradient rows from LDS
-//   dW products   dW[o][i] = sum_p da[p][o] * act[p][i]       -> A = da^T from LDS (one ds_read_b32 per
-//                 k-step of 4 particles), B = saved activation rows straight from global/L2
-//                 (lane j reads act[p][8j..8j+7], i.e. output tile `it` holds input feature 8j+it),
-//                 accumulators 32 VGPRs per wave, then one coalesced 256-byte atomic per register
-//   per-jet GEMV parts (global MLP, folded t/cond/g columns): rank-1 updates, atomics over K-major rows
+//   dW products   dW[o][i] = sum_jets sum_p da[p][o] * act[p][i]  are NOT formed here: a sum over all jets needs a
+//                 reduction across workgroups, and with one jet per CU nothing can be accumulated on chip.  (Round 1 added every
+//                 jet's full dW with fp32 atomics: 2.2 MB of atomics per jet, 258x the gradient's size, atomic-rate bound and
+//                 run-to-run non-deterministic.)  The chain kernel stores the gradient rows da (valid rows only, plain 16-byte
+//                 stores) and epic_dw_kernel (epic_dw.h) forms each 128x128 dW as ONE GEMM over the rows of all jets, split over
+//                 workgroups by row ranges, partial tiles summed in a fixed order: no atomics, bit-reproducible.
+//   per-jet GEMV parts (global MLP, folded t/cond/g columns): the operands of every rank-1 update (x, dy) go to a per-jet
+//                 record; epic_bwd_reduce_kernel sums x (x) dy over the jets in a fixed order.
 // The weight gradient goes to `gblob`, which has the offsets of the weight blob; the 128x128 blocks
 // are stored in the accumulator-native order documented in pfm_hip.h (GRAD_D format).
 #pragma once
@@ -34,6 +37,7 @@ struct BCarve {
     int dag2;          // MAXL
     int dg1;           // H
     int misc;          // 16
+    int tg;            // VIN_FLOATS: result of km16_tgemv (aliases da3 | w3, both dead after the head; padded where they are too small)
     int total;
 };
 
@@ -43,8 +47,10 @@ __host__ __device__ inline BCarve make_bcarve(int N, int F) {
     c.G = o; o += N * H;
     c.Hb = o; o += N * H;
     c.da3 = o; o += round4(N * F);
-    c.maskf = o; o += round4(N);
     c.w3 = o; o += F * H;
+    c.tg = c.da3;
+    if (o - c.tg < VIN_FLOATS) o = c.tg + VIN_FLOATS;
+    c.maskf = o; o += round4(N);
     c.vin = o; o += VIN_FLOATS;
     c.vin2 = o; o += 208;
     c.dbj1 = o; o += H;
@@ -68,10 +74,12 @@ __device__ __forceinline__ f32x4 dlrelu4(f32x4 y, float s) {
 
 __device__ __forceinline__ f32x4 colsum16(f32x4 v) { return row_sum16(v); }
 
-// dX product: for every row p < n_rows, epi(p, oslot, acc) with
+// dX product: for every row p < n_rows, epi(p, oslot, acc, pre(p, oslot)) with
 //   acc[r] = sum_k AT-block[16w + 4q + r][k] * src[p][k]        (a = MFMA_AT fragments of this wave)
-template <typename Epi>
-__device__ __forceinline__ void gemm_dx(const f32x4 (&a)[8], const float* __restrict__ src, int n_rows, Epi epi) {
+// pre(p, oslot) fetches what the epilogue needs from global memory (the saved activation whose sign gates the gradient): it is
+// called BEFORE the pair's 64 MFMAs so that the load flies behind them (in the epilogue it would be a bare L2 round trip per pair).
+template <typename Pre, typename Epi>
+__device__ __forceinline__ void gemm_dx(const f32x4 (&a)[8], const float* __restrict__ src, int n_rows, Pre pre, Epi epi) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int pl = lane & 15, q = lane >> 4, oslot = 4 * w + q;
     const int npairs = (n_rows + 2 * TILE - 1) / (2 * TILE);
@@ -84,74 +92,87 @@ __device__ __forceinline__ void gemm_dx(const f32x4 (&a)[8], const float* __rest
             b0[kt] = *reinterpret_cast<const f32x4*>(src + lds_off(pc0, 4 * kt + q));
             b1[kt] = *reinterpret_cast<const f32x4*>(src + lds_off(pc1, 4 * kt + q));
         }
+        const f32x4 x0 = pre(pc0, oslot), x1 = pre(pc1, oslot);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) { PFM_MFMA_PAIR(acc0, acc1, a[kt], b0[kt], b1[kt]); }
-        if (p0 < n_rows) epi(p0, oslot, acc0);
-        if (p1 < n_rows) epi(p1, oslot, acc1);
+        if (p0 < n_rows) epi(p0, oslot, acc0, x0);
+        if (p1 < n_rows) epi(p1, oslot, acc1, x1);
     }
 }
 
-// dW product: gblock (GRAD_D order) += da^T . act, K = particles.
-//   da  : LDS buffer (N x 128, swizzled rows), only rows < n_rows are meaningful
-//   act : global (N x 128 row-major) saved activation
-__device__ __forceinline__ void gemm_dw(const float* __restrict__ da, const float* __restrict__ act, int n_rows,
-                                        float* __restrict__ gblock) {
+// ---- per-jet record of the reductions over jets (floats) ------------------------------------------------------------
+// stage s = 0 (stem: fc_g1 / fc_g2, fc_l1 / fc_l2 extras) and s = 1 + k (EPiC layer k): the operands of the rank-1 updates
+//   dW_gl1 += vin (x) dag1, dW_gl2 += vin2 (x) dag2, dWe_lc1 += [vin[0..Ke) ; gout] (x) dbj1, dWe_lc2 += vin[0..Ke) (x) dbj2
+// head: this jet's partial sums of dW3 (fc_l3 particle block) and dWx (fc_l1 particle block), db3.
+struct BwdRec {
+    static constexpr int VIN = 0, VIN2 = VIN_FLOATS, DAG1 = VIN2 + VIN2_FLOATS, DAG2 = DAG1 + H, DBJ1 = DAG2 + MAXL,
+                         DBJ2 = DBJ1 + H, GOUT = DBJ2 + H, STAGE = GOUT + MAXL;
+    int head;             // (layers + 1) * STAGE
+    int dW3, dWx, db3;    // MAXF*H, MAXF*H, 16
+    int total;
+};
+__host__ __device__ inline BwdRec make_bwd_rec(int layers) {
+    BwdRec r;
+    r.head = (layers + 1) * BwdRec::STAGE;
+    r.dW3 = r.head;
+    r.dWx = r.dW3 + MAXF * H;
+    r.db3 = r.dWx + MAXF * H;
+    r.total = r.db3 + 16;
+    return r;
+}
+
+// ---- scratch of one backward call (floats) -----------------------------------------------------------------------------
+//   nrows [B] (int32)            rows the chain kernel computed per jet (skip-masked-tail: last valid particle + 1)
+//   rec   [B][BwdRec.total]
+//   da    [B][nblk][N][H]        gradient rows; block 0: da2 of the stem (pairs with x1 -> dW of fc_l2),
+//                                1 + 2k: da2 of layer k (pairs with l1_k -> fc_local2), 2 + 2k: da1 of layer k (pairs with h_k -> fc_local1)
+//   part  [nblk][nsplit][H*H]    partial dW tiles of epic_dw_kernel
+struct BwdWork {
+    int64_t nrows, rec, da, part, total;
+    int nblk, nsplit, rec_floats;
+};
+__host__ __device__ inline BwdWork make_bwd_work(int N, int layers, int B) {
+    BwdWork w;
+    w.nblk = 2 * layers + 1;
+    // ~2 workgroups per CU of a 256-CU part over all blocks, at least ~8 16-row pieces per split (a fixed function of the
+    // shapes, never of the device: the summation order, hence the result, is the same everywhere)
+    int ns = 512 / w.nblk;
+    const int cap = (B * ((N + 15) / 16) + 7) / 8;
+    if (ns > cap) ns = cap;
+    if (ns < 1) ns = 1;
+    w.nsplit = ns;
+    w.rec_floats = make_bwd_rec(layers).total;
+    int64_t o = 0;
+    w.nrows = o; o += (B + 63) & ~63;
+    w.rec = o; o += (int64_t)B * w.rec_floats;
+    w.da = o; o += (int64_t)B * w.nblk * N * H;
+    w.part = o; o += (int64_t)w.nblk * ns * H * H;
+    w.total = o;
+    return w;
+}
+
+// Transposed GEMV on a KM16 block: out[k - 16 p_lo] = sum_o W[k][o] * v[o] for every row k of the panels p_lo .. p_hi (16 rows
+// each), v a 128-vector in LDS, out in LDS.  Wave w takes the panels p_lo + w, + 8, ...: a panel is 512 float4 = 8 coalesced
+// 1-KiB loads per wave (lane l, step s: row l & 15, outputs 4 (4 s + (l >> 4)) ..+3); the 4 DPP rows of a wave are summed with two
+// shuffles, so no cross-wave reduction and no barrier inside.  The caller puts a barrier before reading `out`.
+__device__ __forceinline__ void km16_tgemv(const float* __restrict__ W, int p_lo, int p_hi, const float* __restrict__ v,
+                                           float* __restrict__ out) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int jl = lane & 15, q = lane >> 4;
-    f32x4 acc[8];
+    const f32x4* Wp = reinterpret_cast<const f32x4*>(W);
+    for (int p = p_lo + w; p <= p_hi; p += NW) {
+        f32x4 wv[8];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) acc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nsteps = (n_rows + 3) >> 2;
-    // A: lane (o_local = jl, k = q) reads da[4s + q][16w + jl]
-    const int acol_slot = 4 * w + (jl >> 2), acol_r = jl & 3;
-#pragma unroll 2
-    for (int s = 0; s < nsteps; ++s) {
-        const int p = 4 * s + q;
-        const int pc = min(p, n_rows - 1);
-        float av = da[lds_off(pc, acol_slot) + acol_r];
-        if (p >= n_rows) av = 0.f;
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(act + pc * H + 8 * jl);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(act + pc * H + 8 * jl + 4);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.w, acc[3], 0, 0, 0);
-        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.x, acc[4], 0, 0, 0);
-        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.y, acc[5], 0, 0, 0);
-        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.z, acc[6], 0, 0, 0);
-        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.w, acc[7], 0, 0, 0);
-    }
-    // GRAD_D: float ((w*8 + it)*4 + r)*64 + lane  holds dW[16w + 4(lane>>4) + r][8(lane&15) + it]
+        for (int s8 = 0; s8 < 8; ++s8) wv[s8] = Wp[(size_t)p * 512 + s8 * 64 + lane];
+        float a = 0.f;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        float* g = gblock + ((w * 8 + it) * 4) * 64 + lane;
-        atomicAdd(g, acc[it].x);
-        atomicAdd(g + 64, acc[it].y);
-        atomicAdd(g + 128, acc[it].z);
-        atomicAdd(g + 192, acc[it].w);
-    }
-}
-
-// Rank-1 gradient of a per-jet GEMV block: gW[(k,o)] += x[k] * dy[o] for k < K, gb[o] += dy[o]  (x, dy in LDS).
-// OUT = 128: KM16 block, walked in storage order (coalesced atomics); OUT <= 16: KP16 block.
-__device__ __forceinline__ void rank1_atomic(float* __restrict__ gW, float* __restrict__ gb, int K, int OUT,
-                                             const float* __restrict__ x, const float* __restrict__ dy) {
-    const int tid = threadIdx.x;
-    if (OUT == H) {
-        const int K16 = (K + 15) & ~15;
-        for (int lin = tid; lin < K16 * H; lin += NT) {
-            const int k = ((lin >> 11) << 4) + ((lin >> 2) & 15);
-            const int o = (((lin >> 6) & 31) << 2) + (lin & 3);
-            if (k < K) atomicAdd(gW + lin, x[k] * dy[o]);
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(v + 4 * (4 * s8 + (lane >> 4)));
+            a += (wv[s8].x * dv.x + wv[s8].y * dv.y) + (wv[s8].z * dv.z + wv[s8].w * dv.w);
         }
-        if (tid < H && gb) atomicAdd(gb + tid, dy[tid]);
-    } else {
-        for (int i = tid; i < K * 16; i += NT) {
-            const int o = i & 15;
-            if (o < OUT) atomicAdd(gW + i, x[i >> 4] * dy[o]);
-        }
-        if (tid < OUT && gb) atomicAdd(gb + tid, dy[tid]);
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        if (lane < 16) out[(p - p_lo) * 16 + lane] = a;
     }
 }
 
@@ -170,39 +191,48 @@ __device__ __forceinline__ float km16_rowdot(const float* __restrict__ W, int k,
 
 // Backward of the global MLP of one stage (epic.py:180-186 / :375-380).
 // In : c.dg = dL/dg_out (L), c.vin = [temb;cond;mean;sum;g_in], g1 / g_out (saved).
-// Out: c.dP (gradient w.r.t. the raw pooled sum), c.dg = dL/dg_in (STEM: unused), weight grads.
+// Out: c.dP (gradient w.r.t. the raw pooled sum), c.dg = dL/dg_in (STEM: unused), c.dag1 / c.dag2 / c.vin2 for the record.
 template <bool STEM>
 __device__ __forceinline__ void global_backward(const JetDims& j, const float* __restrict__ blob,
-                                                float* __restrict__ gblob, const pfm_dense_lin& gl1,
+                                                const pfm_dense_lin& gl1,
                                                 const pfm_dense_lin& gl2, float* __restrict__ lds, const BCarve& c,
                                                 const float* __restrict__ sv_g1, const float* __restrict__ sv_gout) {
     const int tid = threadIdx.x;
     const int TC = j.T + j.C;
-    const int K1 = TC + 2 * H + (STEM ? 0 : j.L), K2 = TC + H;
     const float nvalid = lds[c.misc];
     // dag2 = dg_out * phi'(g_out);  vin2 = [temb ; cond ; g1]
     if (tid < j.L) lds[c.dag2 + tid] = lds[c.dg + tid] * dlrelu(sv_gout[tid], j.slope);
     if (tid >= 64 && tid < 64 + TC) lds[c.vin2 + (tid - 64)] = lds[c.vin + (tid - 64)];
     if (tid >= 256 && tid < 256 + H) lds[c.vin2 + TC + (tid - 256)] = sv_g1[tid - 256];
     __syncthreads();
-    // dW_gl2 += vin2 (x) dag2 ; db_gl2 += dag2 ; dg1 = W_gl2[g1 rows] . dag2
-    rank1_atomic(gblob + gl2.W, gblob + gl2.b, K2, j.L, lds + c.vin2, lds + c.dag2);
+    // (dW_gl2 = sum_jets vin2 (x) dag2, db_gl2 = sum dag2: epic_bwd_reduce_kernel)   dg1 = W_gl2[g1 rows] . dag2
     if (tid < H) {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(blob + gl2.W + (TC + tid) * 16);  // KP16 row: 16 floats
+        const f32x4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+        const float* dq = lds + c.dag2;
         float a = 0.f;
-        for (int jj = 0; jj < j.L; ++jj) a = fmaf(blob[gl2.W + (TC + tid) * 16 + jj], lds[c.dag2 + jj], a);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (jj < j.L) a = fmaf(w0[jj], dq[jj], a);
+            if (4 + jj < j.L) a = fmaf(w1[jj], dq[4 + jj], a);
+            if (8 + jj < j.L) a = fmaf(w2[jj], dq[8 + jj], a);
+            if (12 + jj < j.L) a = fmaf(w3[jj], dq[12 + jj], a);
+        }
         lds[c.dag1 + tid] = a * dlrelu(sv_g1[tid], j.slope);  // dag1 = dg1 * phi'(g1)
     }
     __syncthreads();
-    // dW_gl1 += vin (x) dag1 ; db_gl1 += dag1
-    rank1_atomic(gblob + gl1.W, gblob + gl1.b, K1, H, lds + c.vin, lds + c.dag1);
+    // (dW_gl1 = sum_jets vin (x) dag1, db_gl1 = sum dag1: epic_bwd_reduce_kernel)
     // dvin[k] = W_gl1[k][:] . dag1 for k >= TC  -> dmean, dsum (-> dP), dg_in
-    auto rowdot = [&](int k) { return km16_rowdot(blob + gl1.W, k, lds + c.dag1); };
+    const int p_lo = TC >> 4, k_hi = TC + 2 * H + (STEM ? 0 : j.L) - 1;
+    km16_tgemv(blob + gl1.W, p_lo, k_hi >> 4, lds + c.dag1, lds + c.tg);
+    __syncthreads();
+    const float* dv = lds + c.tg - 16 * p_lo;  // dv[k] = dvin[k]
     if (tid < H) {
         // pooled mean = sum / n (epic.py:161), pooled sum * scale (:162)
-        lds[c.dP + tid] = rowdot(TC + tid) / nvalid + rowdot(TC + H + tid) * j.sscale;
+        lds[c.dP + tid] = dv[TC + tid] / nvalid + dv[TC + H + tid] * j.sscale;
     } else if (!STEM && tid < H + j.L) {
         const int jj = tid - H;
-        lds[c.dg + jj] = lds[c.dag2 + jj] + rowdot(TC + 2 * H + jj);  // residual path + vin path
+        lds[c.dg + jj] = lds[c.dag2 + jj] + dv[TC + 2 * H + jj];  // residual path + vin path
     }
     __syncthreads();
 }

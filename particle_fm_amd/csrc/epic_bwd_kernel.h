@@ -19,11 +19,20 @@ __device__ __forceinline__ void build_vin(const JetDims& j, float* __restrict__ 
     }
 }
 
-// gblob += d(loss)/d(blob), loss = sum(loss_parts) / sum(mask_count), times *grad_scale
+// copy n floats (n % 4 == 0, 16-byte aligned both sides) from LDS to the jet's record: threads [t0, t0 + n/4)
+__device__ __forceinline__ void rec_put(float* __restrict__ dst, const float* __restrict__ src, int n, int t0) {
+    const int i = (int)threadIdx.x - t0;
+    if (i >= 0 && 4 * i < n) *reinterpret_cast<f32x4*>(dst + 4 * i) = *reinterpret_cast<const f32x4*>(src + 4 * i);
+}
+
+// The per-jet chain of d(loss)/d(blob), loss = sum(loss_parts) / sum(mask_count), times *grad_scale: the gradient w.r.t. the
+// hidden state walks back through the layers inside LDS; what has to be summed over jets leaves the CU as plain stores --
+// the gradient rows `da` of every 128x128 Linear (epic_dw_kernel forms dW from them), the rank-1 operands and the small
+// per-jet partial sums in `rec` (epic_bwd_reduce_kernel).  No atomics.
 __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ cond,
     const float* __restrict__ mask, const float* __restrict__ saved, const float* __restrict__ inv_mask_total,
-    const float* __restrict__ grad_scale, float* __restrict__ gblob, int crit, const float* __restrict__ jet_w) {
+    const float* __restrict__ grad_scale, float* __restrict__ work, BwdWork bw, int crit, const float* __restrict__ jet_w) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
@@ -32,6 +41,9 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     const int jet = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int pl = lane & 15, q = lane >> 4, oslot = 4 * w + q;
     const float* sv = saved + (size_t)jet * sl.total;
+    const BwdRec br = make_bwd_rec(j.layers);
+    float* rec = work + bw.rec + (size_t)jet * br.total;
+    float* daj = work + bw.da + (size_t)jet * bw.nblk * j.N * H;  // this jet's gradient rows, [nblk][N][H]
     const float slope = j.slope;
     const int Ke = j.T + j.Cl;
     float* G = lds + c.G;
@@ -70,6 +82,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     // a jet without any valid particle is NaN in the reference (epic.py:370 divides by 0): compute all rows then too
     if ((d.flags & PFM_F_SKIP_MASKED_TAIL) && lds[c.misc + 1] >= 0.f) n_rows = (int)lds[c.misc + 1] + 1;
     const int ntiles = (n_rows + TILE - 1) / TILE;
+    if (tid == 0) reinterpret_cast<int*>(work + bw.nrows)[jet] = n_rows;
     // d/dv of  w_jet * sum crit(v - u) / M:  mse (crit 0) 2 (v - u);  huber (crit 1, delta 1) clamp(v - u, -1, 1)
     const float gscale = (crit ? 1.0f : 2.0f) * inv_mask_total[0] * grad_scale[0] * (jet_w ? jet_w[jet] : 1.0f);
     const float* maskf = lds + c.maskf;
@@ -89,7 +102,8 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     __syncthreads();
     {
         const float* hL = sv + (j.layers > 0 ? sl.xo + (j.layers - 1) * sl.lstride : sl.x2);
-        // dW3[f][k] += sum_p da3[p][f] * hL[p][k]: k = tid & 127, particles split 4 ways
+        // this jet's part of dW3[f][k] = sum_p da3[p][f] * hL[p][k]: k = tid & 127, particles split 4 ways, the 4 partial sums
+        // joined through LDS (Hb is free here) in a fixed order -> rec.dW3
         for (int f0 = 0; f0 < j.F; f0 += 4) {
             const int k = tid & (H - 1), pt = tid >> 7;
             float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -100,16 +114,24 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
                     if (f0 + jf < j.F) a[jf] = fmaf(lds[c.da3 + p * j.F + f0 + jf], hv, a[jf]);
             }
 #pragma unroll
-            for (int jf = 0; jf < 4; ++jf)
-                if (f0 + jf < j.F) atomicAdd(gblob + d.l3_W + (f0 + jf) * H + k, a[jf]);
+            for (int jf = 0; jf < 4; ++jf) Hb[(jf * 4 + pt) * H + k] = a[jf];
+            __syncthreads();
+            {
+                const int jf = tid >> 7;  // 4 features x 128 k = 512 threads
+                if (f0 + jf < j.F) {
+                    const float* q4 = Hb + (jf * 4) * H + k;
+                    rec[br.dW3 + (f0 + jf) * H + k] = (q4[0] + q4[H]) + (q4[2 * H] + q4[3 * H]);
+                }
+            }
+            __syncthreads();
         }
-        // db3j[f] = sum_p da3[p][f]; dWe3[k][f] += e[k] * db3j[f]   (wave f)
-        for (int f = w; f < j.F; f += NW) {
+        // db3j[f] = sum_p da3[p][f]   (wave f); dWe3 = sum_jets e (x) db3j: epic_bwd_reduce_kernel
+        for (int f = w; f < MAXF; f += NW) {
             float a = 0.f;
-            for (int p = lane; p < n_rows; p += 64) a += lds[c.da3 + p * j.F + f];
+            if (f < j.F)
+                for (int p = lane; p < n_rows; p += 64) a += lds[c.da3 + p * j.F + f];
             for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
-            if (lane == 0) atomicAdd(gblob + d.l3_b + f, a);
-            for (int k = lane; k < Ke; k += 64) atomicAdd(gblob + d.l3_We + k * j.F + f, evec[k] * a);
+            if (lane == 0) rec[br.db3 + f] = a;
         }
         // G[p][4slot..] = sum_f W3[f][4slot..] * da3[p][f]
         const int slot = tid & 31;
@@ -135,9 +157,14 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         const float* gin = (k > 0) ? sv + sl.glayer + (k - 1) * sl.gstride + H : sv + sl.gstem;
         load_afrag(a2, rs, ly.lc2.AT, w, lane);
         load_afrag(a1, rs, ly.lc1.AT, w, lane);
-        // (1) da2 = G * phi'(h_{k+1}) in place; db2j = column sums
-        {
+        float* rstage = rec + (1 + k) * BwdRec::STAGE;
+        float* da2 = daj + (size_t)(1 + 2 * k) * j.N * H;  // pairs with l1_k: dW of fc_local2 (epic.py:198-200)
+        float* da1 = daj + (size_t)(2 + 2 * k) * j.N * H;  // pairs with h_k : dW of fc_local1 (epic.py:194-196)
+        // (1) da2 = G * phi'(h_{k+1}) in place (and to `da`); db2j = column sums.  Only for the last layer: for the others
+        //     step (7) of the layer above has already done it in its epilogue.
+        if (k == j.layers - 1) {
             f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
             for (int tile = 0; tile < ntiles; ++tile) {
                 const int p = tile * TILE + pl;
                 if (p < n_rows) {
@@ -145,57 +172,76 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
                     f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, oslot));
                     gv *= dlrelu4(hv, slope);
                     *reinterpret_cast<f32x4*>(G + lds_off(p, oslot)) = gv;
+                    *reinterpret_cast<f32x4*>(da2 + p * H + 4 * oslot) = gv;
                     ps += gv;
                 }
             }
             ps = colsum16(ps);
             if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj2 + 4 * oslot) = ps;
+            __syncthreads();
         }
-        __syncthreads();
-        // (2) dW_lc2 += da2^T . l1   (epic.py:198-200)
-        gemm_dw(G, l1, n_rows, gblob + ly.lc2.A);
-        // (3) da1 = (W_lc2^T da2) * phi'(l1) -> Hb; db1j = column sums
+        // (3) da1 = (W_lc2^T da2) * phi'(l1) -> Hb (and to `da`); db1j = column sums
         {
             f32x4 ps = {0.f, 0.f, 0.f, 0.f};
-            gemm_dx(a2, G, n_rows, [&](int p, int os, f32x4 acc) {
-                const f32x4 lv = *reinterpret_cast<const f32x4*>(l1 + p * H + 4 * os);
-                acc *= dlrelu4(lv, slope);
-                *reinterpret_cast<f32x4*>(Hb + lds_off(p, os)) = acc;
-                ps += acc;
-            });
+            gemm_dx(a2, G, n_rows,
+                    [&](int p, int os) { return *reinterpret_cast<const f32x4*>(l1 + p * H + 4 * os); },
+                    [&](int p, int os, f32x4 acc, f32x4 lv) {
+                        acc *= dlrelu4(lv, slope);
+                        *reinterpret_cast<f32x4*>(Hb + lds_off(p, os)) = acc;
+                        *reinterpret_cast<f32x4*>(da1 + p * H + 4 * os) = acc;
+                        ps += acc;
+                    });
             ps = colsum16(ps);
             if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj1 + 4 * oslot) = ps;
         }
         // vin of this stage (for the global backward): [temb;cond;mean_k;sum_k;g_k]
         build_vin(j, lds, c, sv + sl.pool + k * sl.pstride, gin, true);
         __syncthreads();
-        // (4) per-jet pieces: bias / extras gradients of both local linears; dg_{k+1} += We_lc1[g rows] . db1j
-        {
-            float* e1 = lds + c.vin2;  // [temb ; cond_l ; g_{k+1}] (scratch until global_backward rebuilds vin2)
-            if (tid < Ke) e1[tid] = evec[tid];
-            else if (tid < Ke + j.L) e1[tid] = gout[tid - Ke];
-            if (tid >= 128 && tid < 128 + j.L) {
-                const int jj = tid - 128;
-                const float a = km16_rowdot(blob + ly.lc1.We, Ke + jj, lds + c.dbj1);
-                lds[c.dg + jj] += a;
-            }
-            __syncthreads();
-            rank1_atomic(gblob + ly.lc1.We, gblob + ly.lc1.b, Ke + j.L, H, e1, lds + c.dbj1);
-            rank1_atomic(gblob + ly.lc2.We, gblob + ly.lc2.b, Ke, H, e1, lds + c.dbj2);
-            __syncthreads();
+        // (4) per-jet pieces: dg_{k+1} += We_lc1[g rows] . db1j  (the extras / bias gradients of both local linears are the
+        //     rank-1 sums  [temb ; cond_l ; g_{k+1}] (x) db1j,  [temb ; cond_l] (x) db2j  over jets: operands -> rec)
+        km16_tgemv(blob + ly.lc1.We, Ke >> 4, (Ke + j.L - 1) >> 4, lds + c.dbj1, lds + c.tg);
+        __syncthreads();
+        if (tid >= 128 && tid < 128 + j.L) {
+            const int jj = tid - 128;
+            lds[c.dg + jj] += lds[c.tg + (Ke + jj) - 16 * (Ke >> 4)];
         }
-        // (5) global MLP backward -> dP_k, dg_k
-        global_backward<false>(j, blob, gblob, ly.gl1, ly.gl2, lds, c, g1, gout);
-        // (6) dW_lc1 += da1^T . h_k   (epic.py:194-196)
-        gemm_dw(Hb, hin, n_rows, gblob + ly.lc1.A);
-        // (7) dh_k = W_lc1^T da1 + da2 (residual) + mask * dP_k (pooling) -> G in place
+        rec_put(rstage + BwdRec::DBJ1, lds + c.dbj1, H, 0);
+        rec_put(rstage + BwdRec::DBJ2, lds + c.dbj2, H, 32);
+        if (tid >= 64 && tid < 64 + MAXL) rstage[BwdRec::GOUT + tid - 64] = (tid - 64 < j.L) ? gout[tid - 64] : 0.f;
+        __syncthreads();
+        // (5) global MLP backward -> dP_k, dg_k; its rank-1 operands -> rec
+        global_backward<false>(j, blob, ly.gl1, ly.gl2, lds, c, g1, gout);
+        rec_put(rstage + BwdRec::VIN, lds + c.vin, VIN_FLOATS, 0);
+        rec_put(rstage + BwdRec::VIN2, lds + c.vin2, VIN2_FLOATS, 128);
+        rec_put(rstage + BwdRec::DAG1, lds + c.dag1, H, 192);
+        rec_put(rstage + BwdRec::DAG2, lds + c.dag2, MAXL, 224);
+        // (7) dh_k = W_lc1^T da1 + da2 (residual) + mask * dP_k (pooling) -> G in place; for k > 0 times phi'(h_k) right away:
+        //     that is da2 of layer k - 1 (step (1) of the next iteration, fused here: one pass over G and one L2 round trip less)
         {
             const f32x4 dP4 = *reinterpret_cast<const f32x4*>(lds + c.dP + 4 * oslot);
-            gemm_dx(a1, Hb, n_rows, [&](int p, int os, f32x4 acc) {
-                f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, os));
-                gv += acc + dP4 * maskf[p];
-                *reinterpret_cast<f32x4*>(G + lds_off(p, os)) = gv;
-            });
+            if (k > 0) {
+                float* da2n = daj + (size_t)(1 + 2 * (k - 1)) * j.N * H;
+                f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+                gemm_dx(a1, Hb, n_rows,
+                        [&](int p, int os) { return *reinterpret_cast<const f32x4*>(hin + p * H + 4 * os); },
+                        [&](int p, int os, f32x4 acc, f32x4 hv) {
+                            f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, os));
+                            gv = (gv + acc + dP4 * maskf[p]) * dlrelu4(hv, slope);
+                            *reinterpret_cast<f32x4*>(G + lds_off(p, os)) = gv;
+                            *reinterpret_cast<f32x4*>(da2n + p * H + 4 * os) = gv;
+                            ps += gv;
+                        });
+                ps = colsum16(ps);
+                if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj2 + 4 * oslot) = ps;  // db2j of layer k - 1
+            } else {
+                gemm_dx(a1, Hb, n_rows,
+                        [&](int, int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
+                        [&](int p, int os, f32x4 acc, f32x4) {
+                            f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, os));
+                            gv += acc + dP4 * maskf[p];
+                            *reinterpret_cast<f32x4*>(G + lds_off(p, os)) = gv;
+                        });
+            }
         }
         __syncthreads();
     }
@@ -204,7 +250,11 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     // global stem backward (fc_g1 / fc_g2): dg_0 -> dP (the pool of x2 as seen by the stem MLP)
     build_vin(j, lds, c, sv + sl.pool, nullptr, false);
     __syncthreads();
-    global_backward<true>(j, blob, gblob, d.g1, d.g2, lds, c, sv + sl.gstem1, sv + sl.gstem);
+    global_backward<true>(j, blob, d.g1, d.g2, lds, c, sv + sl.gstem1, sv + sl.gstem);
+    rec_put(rec + BwdRec::VIN, lds + c.vin, VIN_FLOATS, 0);
+    rec_put(rec + BwdRec::VIN2, lds + c.vin2, VIN2_FLOATS, 128);
+    rec_put(rec + BwdRec::DAG1, lds + c.dag1, H, 192);
+    rec_put(rec + BwdRec::DAG2, lds + c.dag2, MAXL, 224);
     load_afrag(a2, rs, d.l2.AT, w, lane);
     // da2s = (G + mask * dP) * phi'(x2) in place; db2j
     {
@@ -218,6 +268,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
                 f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, oslot));
                 gv = (gv + dP4 * maskf[p]) * dlrelu4(hv, slope);
                 *reinterpret_cast<f32x4*>(G + lds_off(p, oslot)) = gv;
+                *reinterpret_cast<f32x4*>(daj + p * H + 4 * oslot) = gv;  // block 0: pairs with x1 -> dW of fc_l2
                 ps += gv;
             }
         }
@@ -225,25 +276,25 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj2 + 4 * oslot) = ps;
     }
     __syncthreads();
-    // dW_l2 += da2s^T . x1 ; da1s = (W_l2^T da2s + da2s) * phi'(x1) -> Hb   (epic.py:364-366, 360-362)
-    gemm_dw(G, sv + sl.x1, n_rows, gblob + d.l2.A);
+    // da1s = (W_l2^T da2s + da2s) * phi'(x1) -> Hb   (epic.py:364-366, 360-362)
     {
         const float* x1 = sv + sl.x1;
         f32x4 ps = {0.f, 0.f, 0.f, 0.f};
-        gemm_dx(a2, G, n_rows, [&](int p, int os, f32x4 acc) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x1 + p * H + 4 * os);
-            acc += *reinterpret_cast<const f32x4*>(G + lds_off(p, os));
-            acc *= dlrelu4(xv, slope);
-            *reinterpret_cast<f32x4*>(Hb + lds_off(p, os)) = acc;
-            ps += acc;
-        });
+        gemm_dx(a2, G, n_rows,
+                [&](int p, int os) { return *reinterpret_cast<const f32x4*>(x1 + p * H + 4 * os); },
+                [&](int p, int os, f32x4 acc, f32x4 xv) {
+                    acc += *reinterpret_cast<const f32x4*>(G + lds_off(p, os));
+                    acc *= dlrelu4(xv, slope);
+                    *reinterpret_cast<f32x4*>(Hb + lds_off(p, os)) = acc;
+                    ps += acc;
+                });
         ps = colsum16(ps);
         if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj1 + 4 * oslot) = ps;
     }
     __syncthreads();
-    rank1_atomic(gblob + d.l1_We, gblob + d.l1_b, Ke, H, evec, lds + c.dbj1);
-    rank1_atomic(gblob + d.l2.We, gblob + d.l2.b, Ke, H, evec, lds + c.dbj2);
-    // dWx_l1[f][o] += sum_p y[p][f] * da1s[p][o]   (K-major [F][H])
+    rec_put(rec + BwdRec::DBJ1, lds + c.dbj1, H, 0);   // dWe of fc_l1 / fc_l2 = sum_jets [temb ; cond_l] (x) db1j / db2j
+    rec_put(rec + BwdRec::DBJ2, lds + c.dbj2, H, 32);
+    // this jet's part of dWx_l1[f][o] = sum_p y[p][f] * da1s[p][o]   (K-major [F][H]) -> rec.dWx
     for (int f0 = 0; f0 < j.F; f0 += 4) {
         f32x4 acc[4];
 #pragma unroll
@@ -261,13 +312,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         for (int jf = 0; jf < 4; ++jf) {
             if (f0 + jf < j.F) {
                 const f32x4 s4 = colsum16(acc[jf]);
-                if (pl == 0) {
-                    float* g = gblob + d.l1x.W + (f0 + jf) * H + 4 * oslot;
-                    atomicAdd(g, s4.x);
-                    atomicAdd(g + 1, s4.y);
-                    atomicAdd(g + 2, s4.z);
-                    atomicAdd(g + 3, s4.w);
-                }
+                if (pl == 0) *reinterpret_cast<f32x4*>(rec + br.dWx + (f0 + jf) * H + 4 * oslot) = s4;
             }
         }
     }

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "epic_bwd_kernel.h"
+#include "epic_dw.h"
 
 namespace pfm {
 int set_err(int code, const char* what);
@@ -130,35 +131,94 @@ extern "C" int pfm_epic_diffusion_loss_forward(const pfm_epic_desc* d, const flo
 
 static int loss_backward(const pfm_epic_desc* d, const float* blob, const float* cond, const float* mask, const float* saved,
                          const float* inv_mask_total, const float* grad_scale, float* grad_blob, int crit, const float* jet_w,
-                         int B, void* stream) {
+                         int B, float* scratch, void* stream) {
     int rc = validate(d);
     if (rc) return rc;
     const int64_t lds = (int64_t)make_bcarve(d->n_points, d->features).total * 4;
     if (lds > 163840) return set_err(PFM_E_LDS, "set does not fit the 160 KiB LDS tile of the backward kernel");
     if (d->l2.AT < 0) return set_err(PFM_E_BADARG, "blob was packed without the transposed (backward) weight copies");
+    if (B > DW_MAXB) return set_err(PFM_E_BADARG, "at most 8192 jets per backward call (split the batch)");
     rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(epic_fm_loss_backward_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                    "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
+    const int dw_lds = (128 * DW_S + (B > 0 ? B : 0) + 1) * 4;
+    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(epic_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds),
+                   "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc) return rc;
     if (B <= 0) return 0;
-    if (!blob || !saved || !inv_mask_total || !grad_scale || !grad_blob) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (!blob || !saved || !inv_mask_total || !grad_scale || !grad_blob || !scratch) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
-    hipLaunchKernelGGL(epic_fm_loss_backward_kernel, dim3(B), dim3(NT), (int)lds, (hipStream_t)stream, blob,
-                       d->blob_floats, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, crit, jet_w);
-    return check_hip(hipGetLastError(), "epic_fm_loss_backward_kernel launch");
+    const BwdWork bw = make_bwd_work(d->n_points, d->layers, B);
+    hipStream_t s = (hipStream_t)stream;
+    // 1. per-jet chain: gradient rows + rank-1 operands -> scratch
+    hipLaunchKernelGGL(epic_fm_loss_backward_kernel, dim3(B), dim3(NT), (int)lds, s, blob, d->blob_floats, cond, mask, saved,
+                       inv_mask_total, grad_scale, scratch, bw, crit, jet_w);
+    if ((rc = check_hip(hipGetLastError(), "epic_fm_loss_backward_kernel launch"))) return rc;
+    // 2. the 2 * layers + 1 dW GEMMs over the rows of all jets, split by row ranges
+    hipLaunchKernelGGL(epic_dw_kernel, dim3(bw.nsplit, bw.nblk), dim3(DW_T), dw_lds, s, blob, d->blob_floats, saved, scratch, bw, B);
+    if ((rc = check_hip(hipGetLastError(), "epic_dw_kernel launch"))) return rc;
+    // 3. fixed-order sums: partial tiles, rank-1 sums over jets, the F-wide particle blocks
+    RedArgs ra;
+    ra.n_tile = bw.nblk * 16;
+    ra.panels_per_job = (VIN_FLOATS + 15) / 16 + 1;
+    ra.n_r1 = (d->layers + 2) * 4 * ra.panels_per_job;
+    ra.n_small = (2 * MAXF * H + RED_T - 1) / RED_T;
+    hipLaunchKernelGGL(epic_bwd_reduce_kernel, dim3(ra.n_tile + ra.n_r1 + ra.n_small), dim3(RED_T), 0, s, blob, d->blob_floats,
+                       (const float*)scratch, bw, B, ra, grad_blob);
+    return check_hip(hipGetLastError(), "epic_bwd_reduce_kernel launch");
+}
+
+// loss = sum_b w_b parts_b / sum_b count_b and 1 / sum count from the per-jet outputs of the loss forward: one workgroup, sums in a
+// fixed order (a pure function of its inputs)
+namespace pfm {
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ parts, const float* __restrict__ count,
+                                                          const float* __restrict__ jet_w, int B, float* __restrict__ out) {
+    __shared__ float red[2 * 256];
+    const int tid = threadIdx.x;
+    float sp = 0.f, sc = 0.f;
+    for (int i = tid; i < B; i += 256) {
+        sp += parts[i] * (jet_w ? jet_w[i] : 1.0f);
+        sc += count[i];
+    }
+    red[tid] = sp;
+    red[256 + tid] = sc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (tid < s) { red[tid] += red[tid + s]; red[256 + tid] += red[256 + tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[0] = red[0] / red[256];
+        out[1] = 1.0f / red[256];
+    }
+}
+}  // namespace pfm
+
+extern "C" int pfm_loss_finish(const float* loss_parts, const float* mask_count, const float* jet_weight, int32_t B, float* out2,
+                               void* stream) {
+    if (B <= 0) return set_err(PFM_E_BADARG, "B must be positive");
+    if (!loss_parts || !mask_count || !out2) return set_err(PFM_E_BADARG, "NULL device pointer");
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_parts, mask_count, jet_weight, B, out2);
+    return check_hip(hipGetLastError(), "loss_finish_kernel launch");
+}
+
+extern "C" int64_t pfm_epic_backward_scratch_floats(const pfm_epic_desc* d, int32_t B) {
+    if (!d || B < 0) return -1;
+    return make_bwd_work(d->n_points, d->layers, B).total;
 }
 
 extern "C" int pfm_epic_fm_loss_backward(const pfm_epic_desc* d, const float* blob, const float* t, const float* cond,
                                          const float* mask, const float* saved, const float* inv_mask_total,
-                                         const float* grad_scale, float* grad_blob, int32_t B, void* stream) {
+                                         const float* grad_scale, float* grad_blob, int32_t B, float* scratch, void* stream) {
     (void)t;  // the time embedding is part of `saved`
-    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, 0, nullptr, B, stream);
+    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, 0, nullptr, B, scratch, stream);
 }
 
 extern "C" int pfm_epic_diffusion_loss_backward(const pfm_epic_desc* d, const float* blob, int32_t criterion, const float* jet_weight,
                                                 const float* cond, const float* mask, const float* saved,
                                                 const float* inv_mask_total, const float* grad_scale, float* grad_blob,
-                                                int32_t B, void* stream) {
+                                                int32_t B, float* scratch, void* stream) {
     if (criterion < 0 || criterion > 1) return set_err(PFM_E_BADARG, "criterion must be 0 (mse) or 1 (huber)");
-    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, criterion, jet_weight, B, stream);
+    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, criterion, jet_weight, B, scratch, stream);
 }

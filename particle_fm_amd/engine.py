@@ -183,7 +183,7 @@ class FusedFMTrainer:
                   # initial blob the slow (torch) way: fixes freqs + descriptor tail; the pack kernel rewrites the rest
                   "blob": fm_loss.pack_blob_from_source(lay, net.source_vector(lay).detach()).contiguous(),
                   "one": torch.ones(1, device=self.fp.flat.device)}
-            st["gblob"] = torch.zeros_like(st["blob"])
+            st["gblob"] = torch.zeros_like(st["blob"])  # the backward WRITES every gradient slot (no atomics): zeroed once
             self._fused[n_points] = st
         return st
 
@@ -230,33 +230,32 @@ class FusedFMTrainer:
         blob = self._pack(st)
         B = x.shape[0]
         condf = None if lay.cfg.global_cond_dim == 0 else cond.to(torch.float32).contiguous()
-        maskf = None if mask is None else mask.reshape(B, -1).to(torch.float32).contiguous()
+        maskf = None if mask is None else mask.reshape(B, -1).to(torch.float32).contiguous()  # converted once, used by both kernels
+        fin = st.get("fin")
+        if fin is None:
+            fin = st["fin"] = torch.empty(2, device=x.device, dtype=torch.float32)  # [loss, 1 / sum(mask)]
+        scratch = hip_ops.epic_backward_scratch(lay, B, x.device)
         if kind == "diffusion":
             from .fm_loss import MLE_LOSS_WEIGHT
             t, z = loss_mod.draw(x, mask)
             sr, nr, beta = hip_ops.diffusion_schedule(t.to(torch.float32), **loss_mod.diff_config)
             jet_w = (1.0 + MLE_LOSS_WEIGHT * (beta / nr)).contiguous()
-            parts, count, saved = hip_ops.epic_diffusion_loss_forward(lay, blob, x, t, z, torch.stack([sr, nr], dim=1), cond, mask,
+            parts, count, saved = hip_ops.epic_diffusion_loss_forward(lay, blob, x, t, z, torch.stack([sr, nr], dim=1), cond, maskf,
                                                                       loss_mod.criterion)
-            total = count.sum()
-            loss = (parts * jet_w).sum() / total
-            inv_total = (1.0 / total).reshape(1)
-            gblob.zero_()
+            _lib.check(lib.pfm_loss_finish(P(parts), P(count), P(jet_w), B, P(fin), S), "pfm_loss_finish")
             _lib.check(lib.pfm_epic_diffusion_loss_backward(ctypes.byref(lay.desc), P(blob), {"mse": 0, "huber": 1}[loss_mod.criterion],
-                                                            P(jet_w), P(condf), P(maskf), P(saved), P(inv_total), P(st["one"]),
-                                                            P(gblob), B, S), "pfm_epic_diffusion_loss_backward")
+                                                            P(jet_w), P(condf), P(maskf), P(saved), P(fin[1:]), P(st["one"]),
+                                                            P(gblob), B, P(scratch), S), "pfm_epic_diffusion_loss_backward")
         else:
             if kind == "CFM":
                 t, z, eps = loss_mod.draw(x)
             else:
                 (t, z), eps = loss_mod.draw(x), None
-            parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x, t, z, cond, mask, loss_mod.sigma, kind, eps)
-            total = count.sum()
-            loss = parts.sum() / total
-            inv_total = (1.0 / total).reshape(1)
-            gblob.zero_()
+            parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x, t, z, cond, maskf, loss_mod.sigma, kind, eps)
+            _lib.check(lib.pfm_loss_finish(P(parts), P(count), P(None), B, P(fin), S), "pfm_loss_finish")
             _lib.check(lib.pfm_epic_fm_loss_backward(ctypes.byref(lay.desc), P(blob), P(None), P(condf), P(maskf), P(saved),
-                                                     P(inv_total), P(st["one"]), P(gblob), B, S), "pfm_epic_fm_loss_backward")
+                                                     P(fin[1:]), P(st["one"]), P(gblob), B, P(scratch), S), "pfm_epic_fm_loss_backward")
+        loss = fin[0].clone()  # `fin` is rewritten by the next step
         _lib.check(lib.pfm_wn_unpack_grad(P(self.fp.flat), P(gblob), P(tb.rows), tb.n_rows, P(tb.gsrc), P(tb.bias_gblob),
                                           P(tb.bias_param), tb.n_bias, P(self.fp.grad), S), "pfm_wn_unpack_grad")
         return loss

@@ -73,7 +73,8 @@ class EpicFMLossFn(torch.autograd.Function):
         maskf = None if mask is None else mask.reshape(B, -1).to(torch.float32).contiguous()
         P = hip_ops._ptr
         rc = lib.pfm_epic_fm_loss_backward(ctypes.byref(layout.desc), P(blob), P(None), P(cond), P(maskf), P(saved),
-                                           P(inv_total), P(gscale), P(gblob), B, hip_ops._stream_ptr(dev))
+                                           P(inv_total), P(gscale), P(gblob), B, P(hip_ops.epic_backward_scratch(layout, B, dev)),
+                                           hip_ops._stream_ptr(dev))
         _lib.check(rc, "pfm_epic_fm_loss_backward")
         _, gpos, _ = _Maps.get(layout, dev)
         # every weight / bias has exactly one gradient slot in the blob (layout.src_gpos): a plain gather;
@@ -119,7 +120,8 @@ class EpicDiffusionLossFn(torch.autograd.Function):
         P = hip_ops._ptr
         rc = lib.pfm_epic_diffusion_loss_backward(ctypes.byref(layout.desc), P(blob), {"mse": 0, "huber": 1}[ctx.criterion],
                                                   P(jet_w.contiguous()), P(cond), P(maskf), P(saved), P(inv_total), P(gscale),
-                                                  P(gblob), B, hip_ops._stream_ptr(dev))
+                                                  P(gblob), B, P(hip_ops.epic_backward_scratch(layout, B, dev)),
+                                                  hip_ops._stream_ptr(dev))
         _lib.check(rc, "pfm_epic_diffusion_loss_backward")
         _, gpos, _ = _Maps.get(layout, dev)
         d_src = torch.zeros(ctx.n_source, device=dev, dtype=torch.float32)

@@ -256,6 +256,22 @@ def epic_fm_loss_forward(layout: EpicLayout, blob: torch.Tensor, x: torch.Tensor
     return parts, count, saved
 
 
+def epic_backward_scratch(layout: EpicLayout, B: int, device) -> torch.Tensor:
+    """Scratch of one pfm_epic_*_loss_backward call (gradient rows, per-jet rank-1 operands, partial dW tiles), cached on the
+    layout per (B, device, stream): the backward fully writes what it reads, and two backwards on one stream run in order."""
+    lib = _lib.load()
+    cache = layout.__dict__.setdefault("_bwd_scratch", {})
+    key = (int(B), str(device), torch.cuda.current_stream(device).cuda_stream)
+    if key not in cache:
+        n = lib.pfm_epic_backward_scratch_floats(ctypes.byref(layout.desc), int(B))
+        if n < 0:
+            _lib.check(1, "pfm_epic_backward_scratch_floats")
+        for k in [k for k in cache if k[1:] == key[1:]]:  # one batch size per (device, stream) at a time
+            del cache[k]
+        cache[key] = torch.empty(max(1, n), device=device, dtype=torch.float32)
+    return cache[key]
+
+
 # ---- loss_type="diffusion" (models/components/diffusion.py, losses.py:207-290, solver.py) ------------------------------
 def diffusion_schedule(t: torch.Tensor, max_sr: float = 1.0, min_sr: float = 1e-2):
     """(signal_rate, noise_rate, beta) of the cosine VP schedule at the diffusion times ``t`` (diffusion.py:21-62); O(len(t))
