@@ -48,6 +48,7 @@ int validate(const pfm_epic_desc* d) {
     if (d->cond_local != 0 && d->cond_local != d->cond_global)
         return set_err(PFM_E_BADARG, "cond_local must be 0 or cond_global");
     if (d->n_points < 13) return set_err(PFM_E_BADARG, "n_points must be >= 13");
+    if (d->n_points > 2 * TILE * MAXPAIRS) return set_err(PFM_E_LDS, "set does not fit the LDS tile (n_points > 160: the particle phases are unrolled for at most 5 tile pairs)");
     if ((int64_t)make_carve(d->n_points, d->features).total * 4 > 163840)
         return set_err(PFM_E_LDS, "set does not fit the 160 KiB LDS tile (n_points too large for fp32, hidden 128)");
     return 0;

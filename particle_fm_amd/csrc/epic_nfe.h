@@ -132,6 +132,47 @@ template <bool SAVE>
 __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float* __restrict__ lds, const Carve& c,
                                             int oslot, int pl, float* __restrict__ save_pool);
 
+// ---- prefetch lists -----------------------------------------------------------------------------------------------
+// A particle phase keeps the matrix pipe busy for thousands of cycles while the CU's vector-memory path idles, so the weights the
+// NEXT phases need (A fragments, per-jet GEMV panels) are requested during it.  A wave issues in order: 20 loads in a row at the
+// head of a phase hold EVERY wave back ~2.5k cycles (8 waves x 20 KiB through the 64 B/clk path) before its first MFMA -- measured
+// as the 2.9k + 3.5k cycles of load issue per layer in tests/diag/stamps.py.  gemm_phase therefore unrolls its pair loop (at most
+// MAXPAIRS pairs: the LDS tile holds <= 160 rows) and issues ONE load of the list behind every K-quarter of every pair: register
+// indices are compile-time constants and no wave ever queues more than one load at a time.  What a short jet cannot spread over its
+// few pairs is issued after the loop, as before.
+constexpr int MAXPAIRS = 5;
+struct PfSeg {  // load i of a segment: bload4(rs, off + i * stride, lane_bytes)
+    int64_t off;
+    int stride, lane_bytes;
+};
+template <int N0, int N1 = 0, int N2 = 0, int N3 = 0>
+struct Prefetch {
+    static constexpr int COUNT = N0 + N1 + N2 + N3;
+    blob_rsrc rs;
+    f32x4 *r0, *r1, *r2, *r3;
+    PfSeg s0, s1, s2, s3;
+    template <int I>
+    __device__ __forceinline__ void issue() const {
+        if constexpr (I < N0) r0[I] = bload4(rs, s0.off + (int64_t)I * s0.stride, s0.lane_bytes);
+        else if constexpr (I < N0 + N1) r1[I - N0] = bload4(rs, s1.off + (int64_t)(I - N0) * s1.stride, s1.lane_bytes);
+        else if constexpr (I < N0 + N1 + N2) r2[I - N0 - N1] = bload4(rs, s2.off + (int64_t)(I - N0 - N1) * s2.stride, s2.lane_bytes);
+        else if constexpr (I < COUNT) r3[I - N0 - N1 - N2] = bload4(rs, s3.off + (int64_t)(I - N0 - N1 - N2) * s3.stride, s3.lane_bytes);
+    }
+    template <int I0, int I1>
+    __device__ __forceinline__ void issue_range() const {
+        if constexpr (I0 < I1) {
+            issue<I0>();
+            issue_range<I0 + 1, I1>();
+        }
+    }
+};
+using PfNone = Prefetch<0>;
+// segment of an A-fragment load (load_afrag) / of a run of KM16 GEMV panels (gemv4_load) / of this thread's fc_global2 rows
+__device__ __forceinline__ PfSeg seg_afrag(int64_t A_off, int w, int lane) { return PfSeg{A_off, 256, ((w * 8) * 64 + lane) * 16}; }
+__device__ __forceinline__ PfSeg seg_panels(int64_t W_off, int first_panel, int tid) {
+    return PfSeg{W_off + (int64_t)first_panel * (NT * 4), NT * 4, tid * 16};
+}
+
 // One particle phase: for every row p < n_rows
 //   dst[p][16w..16w+16) = lrelu( W[16w.., :] . src[p][:] + bj[16w..] (+ resid[p][16w..] if RESID) )
 // Each wave walks the particle tiles two at a time (two accumulator chains).  Software pipeline, one
@@ -142,12 +183,13 @@ __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float*
 // Rows are NOT clamped: tiles may run up to 31 rows past n_rows / N (the carve keeps that window inside LDS);
 // such rows only produce garbage in their own output columns, which are never stored or pooled.
 // POOL: masked column sums -> vin (mean | sum*scale).  SAVE: rows also go to `save` (global).
-template <bool RESID, bool POOL, bool SAVE, bool BF16 = false>
+template <bool RESID, bool POOL, bool SAVE, bool BF16 = false, typename PF = PfNone>
 __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __restrict__ src,
                                            float* __restrict__ dst, const float* __restrict__ resid,
                                            const float* __restrict__ bj, const float* __restrict__ maskf,
                                            const JetDims& j, float* __restrict__ lds, const Carve& c,
-                                           float* __restrict__ save, float* __restrict__ save_pool, int n_rows) {
+                                           float* __restrict__ save, float* __restrict__ save_pool, int n_rows,
+                                           const PF& pf = PF{}) {
     const int tid_ = launder(threadIdx.x);
     const int lane = tid_ & 63, w = tid_ >> 6;
     const int pl = lane & 15, q = lane >> 4;
@@ -239,7 +281,8 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
     };
     // one pair: hipcc sinks every ds_read down to its first use (read -> wait -> MFMA); the sched_barriers pin each
     // quarter's reads BEFORE the MFMA block of the previous quarter so their latency hides behind 16 MFMAs.
-#define PFM_PAIR_BODY(MF)                                                                                       \
+    // PFM_PAIR_BODY(MF, PFI): `pair` in scope; PFI(q) issues the prefetch load that rides behind quarter q.
+#define PFM_PAIR_BODY(MF, PFI)                                                                                  \
     {                                                                                                           \
         const float* s0 = src + pair * 2 * TILE * H;                                                            \
         PFM_LOADQ(Y0, Y1, s0, 1);                                                                               \
@@ -248,12 +291,15 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
         f32x4 acc0 = bias, acc1 = bias;                                                                         \
         if (RESID) { acc0 += r0; acc1 += r1; }                                                                  \
         MF(X0, X1, 0);                                                                                          \
+        PFI(0);                                                                                                 \
         PFM_LOADQ(X0, X1, s0, 2);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         MF(Y0, Y1, 1);                                                                                          \
+        PFI(1);                                                                                                 \
         PFM_LOADQ(Y0, Y1, s0, 3);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         MF(X0, X1, 2);                                                                                          \
+        PFI(2);                                                                                                 \
         /* first quarter of the NEXT pair (one pair past the end on the last iteration: inside the LDS window) */ \
         PFM_LOADQ(X0, X1, s0 + 2 * TILE * H, 0);                                                                \
         if (RESID) {                                                                                            \
@@ -263,18 +309,50 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         MF(Y0, Y1, 3);                                                                                          \
+        PFI(3);                                                                                                 \
         pacc0 = acc0;                                                                                           \
         pacc1 = acc1;                                                                                           \
     }
-    int pair = 0;
-    for (; pair < npairs - 1; ++pair) PFM_PAIR_BODY(PFM_MFMAQ)
-    if (!BF16 && (2 * pair + 1) * TILE >= n_rows) PFM_PAIR_BODY(PFM_MFMAQ1)  // odd tile count: one real tile in the last pair
-    else PFM_PAIR_BODY(PFM_MFMAQ)
+    // The pairs whose two tiles are both real run as straight-line bodies with a compile-time pair index P (the loop is unrolled
+    // so that the prefetch list's loads get static registers: one load behind every K-quarter); a jet with an odd tile count
+    // ends with one more body that issues the real tile's MFMAs only (runtime pair index, no prefetch slot).
+    const int nfull = BF16 ? npairs : (n_rows / TILE + (n_rows % TILE >= 1 ? 1 : 0)) / 2;  // = ntiles / 2
+#define PFM_NOPF(q)
+#define PFM_PAIR_AT(P)                                                                                          \
+    if ((P) < nfull) {                                                                                          \
+        constexpr int pair = (P);                                                                               \
+        PFM_PAIR_BODY(PFM_MFMAQ, PFM_PFI_##P)                                                                   \
+    }
+#define PFM_PFI_0(q) pf.template issue<0 + (q)>()
+#define PFM_PFI_1(q) pf.template issue<4 + (q)>()
+#define PFM_PFI_2(q) pf.template issue<8 + (q)>()
+#define PFM_PFI_3(q) pf.template issue<12 + (q)>()
+#define PFM_PFI_4(q) pf.template issue<16 + (q)>()
+    static_assert(MAXPAIRS == 5, "unroll PFM_PAIR_AT to MAXPAIRS");
+    PFM_PAIR_AT(0) PFM_PAIR_AT(1) PFM_PAIR_AT(2) PFM_PAIR_AT(3) PFM_PAIR_AT(4)
+    if (nfull < npairs) {  // odd tile count: one real tile in the last pair
+        const int pair = nfull;
+        PFM_PAIR_BODY(PFM_MFMAQ1, PFM_NOPF)
+    }
+#undef PFM_PFI_0
+#undef PFM_PFI_1
+#undef PFM_PFI_2
+#undef PFM_PFI_3
+#undef PFM_PFI_4
+#undef PFM_PAIR_AT
+#undef PFM_NOPF
 #undef PFM_PAIR_BODY
 #undef PFM_MFMAQ1
 #undef PFM_LOADQ
 #undef PFM_MFMAQ
     epilogue(pacc0, pacc1, npairs - 1);
+    // the part of the prefetch list a short jet had no pairs for (and anything beyond 4 loads per pair)
+    if (nfull <= 0) pf.template issue_range<0, 4>();
+    if (nfull <= 1) pf.template issue_range<4, 8>();
+    if (nfull <= 2) pf.template issue_range<8, 12>();
+    if (nfull <= 3) pf.template issue_range<12, 16>();
+    if (nfull <= 4) pf.template issue_range<16, 20>();
+    pf.template issue_range<20, (PF::COUNT > 20 ? PF::COUNT : 20)>();
     if (POOL) pool_finish<SAVE>(psum, j, lds, c, oslot, pl, save_pool);
 }
 
@@ -438,15 +516,11 @@ __device__ __forceinline__ void stem_bias(const float* __restrict__ blob, blob_r
     __syncthreads();
 }
 
-constexpr int GW = 12;   // panels of fc_global1 prefetched into registers across the particle phase (48 VGPRs)
-constexpr int GW2 = 8;   // further panels issued at the start of the per-jet phase (K1 <= 16*(GW+GW2) = 320)
-
-// issue the loads of this thread's fc_global1 rows: they do not depend on data, so the caller issues them BEFORE
-// the particle phase whose pooled output the GEMV consumes; the 152 KB stream from L2 (64 B/clk/CU = 2.4k cycles)
-// then hides behind that phase's MFMAs instead of sitting on the serial path.
-__device__ __forceinline__ void prefetch_gl1(f32x4 (&gw)[GW], blob_rsrc rs, const pfm_dense_lin& gl1, int K1, int tp = 0) {
-    gemv4_load<GW>(gw, rs, gl1.W, K1, tp, launder(threadIdx.x));
-}
+// Register windows of the per-jet phase (all requested during the particle phases before it, see Prefetch):
+constexpr int NGL = 20;   // panels of fc_global1 (K1 <= 16 * (tp + NGL); wider inputs: the rest the slow way)
+constexpr int NGL1 = 12;  // ... of which the first NGL1 ride on particle phase 1, the rest on phase 2
+constexpr int NWA = 3;    // panels of local linear 1's extras [temb ; cond_l ; g] (T + Cl + L <= 48; with TB what follows the time rows)
+constexpr int NWB = 2;    // panels of local linear 2's extras [temb ; cond_l]
 
 // Sampling evaluates every jet at the same time t, so the time columns of the per-jet Linears (the first T rows of every
 // extras / fc_global block: inputs are ordered [temb ; ...]) give jet-independent vectors.  epic_time_table_kernel
@@ -455,67 +529,83 @@ __device__ __forceinline__ void prefetch_gl1(f32x4 (&gw)[GW], blob_rsrc rs, cons
 constexpr int TB_SLOT = 512;  // floats per (evaluation, layer): fc_global1 | local-1 extras | local-2 extras | fc_global2 (16)
 constexpr int TB_G1 = 0, TB_L1 = 128, TB_L2 = 256, TB_G2 = 384;
 
+// row_ror:4 / row_ror:8 sums: every lane ends with the sum over the 4 lanes of its DPP row that share (lane & 3)
+__device__ __forceinline__ float row_sum_stride4(float v) {
+    v += dpp_move<0x124>(v);  // row_ror:4
+    v += dpp_move<0x128>(v);  // row_ror:8
+    return v;
+}
+
 // The per-jet phase between two particle phases:
 //   g1 = lrelu(Wg1.[temb;cond;mean;sum;g] + b)            epic.py:180-182 / :375-377
 //   g  = lrelu(Wg2.[temb;cond;g1] + b (+ g))              epic.py:184-186 / :378-380
 //   bj1 = b1 + We1.[temb;cond_l;g],  bj2 = b2 + We2.[temb;cond_l]     (folded t/cond/global columns)
 // In : vin = [temb;cond;mean;sum;g_old] complete (pooled part written by the previous particle phase, barrier
-//      passed), vin2[0..T+C) = [temb;cond], gw = this thread's fc_global1 rows (prefetched).
-// One workgroup barrier (after g1); everything after it is wave-local: every wave evaluates the small fc_global2
-// redundantly and finishes the bias slice [16w,16w+16) that its own MFMA phase reads, so the next particle phase
-// starts without another barrier.  Out: vin.g = g_new (written by wave 0), bj1/bj2 ready.
+//      passed), vin2[0..T+C) = [temb;cond]; gl / wbA / wbB = this thread's rows of fc_global1 / the two extras blocks, requested
+//      during the particle phases before (epic_body).
+// fc_global1 and the bias GEMVs: thread (og = t >> 4, pt = t & 15) owns outputs 4 og.. of rows 16 i + pt; the 16 partial sums of
+// an output group sit in one DPP row.  fc_global2 (L <= 16 outputs, K2 <= 208 rows): thread (kq = t >> 2, o4 = t & 3) takes rows
+// kq and kq + 128 -- ONE or two 16-byte loads per thread instead of every wave fetching the whole block --, a wave sums its 16 rows
+// with two DPP rotations and two cross-row shuffles, the 8 wave partials meet in LDS (second barrier) and every wave adds them up
+// in the same fixed order.  From there on everything is wave-local: each wave finishes the bias slice [16w,16w+16) that its own
+// MFMA phase reads, so the next particle phase starts without another barrier.  Out: vin.g = g_new (written by wave 0), bj1/bj2.
 // STEM: fc_g1/fc_g2 (no g input, no residual, no local biases) and a trailing barrier (vin.g is read next).
 template <bool STEM, bool SAVE, bool TB = false>
 __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __restrict__ blob, blob_rsrc rs,
                                               const pfm_dense_lin& gl1, const pfm_dense_lin& gl2,
                                               const LocalBiasSrc& lb, float* __restrict__ lds, const Carve& c,
                                               float* __restrict__ save_g1, float* __restrict__ save_g,
-                                              const f32x4 (&gw)[GW], f32x4 (&a_next)[8], int64_t a_next_off,
+                                              const f32x4 (&gl)[NGL], const f32x4 (&wbA)[NWA], const f32x4 (&wbB)[NWB],
                                               const float* __restrict__ tb = nullptr) {
     static_assert(!(STEM && TB), "the stem keeps its time rows");
     const int tp = TB ? (j.T >> 4) : 0;  // time panels skipped in every block
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int og = tid >> 4, pt = tid & 15;   // fc_global1 / bias GEMVs
-    const int o4 = lane >> 4, part = lane & 15;  // fc_global2: DPP row o4 owns outputs 4*o4.., lanes = rows 16 i + part
+    const int o4r = lane >> 4, part = lane & 15;  // after the second barrier: DPP row o4r owns outputs 4*o4r..
     float* vin = lds + c.vin;
     float* vin2 = lds + c.vin2;
     const int TC = j.T + j.C, Ke = j.T + j.Cl;
     const int K1 = TC + 2 * H + (STEM ? 0 : j.L);
     const int K2 = TC + H;
-    if (!STEM) PFM_MARK(0);
-    // ---- loads whose address does not depend on data, all issued up front (gw already holds 80 VGPRs) ----
-    // panels kept in registers: local-1 extras (T+Cl+L <= 48), local-2 extras (<= 32); with TB only what follows the time rows
-    constexpr int KA = TB ? 1 : 3, KBp = TB ? 1 : 2;
-    const int Ka = Ke + j.L;        // rows of local linear 1's extras: [temb ; cond_l ; g]
-    f32x4 wbA[KA], wbB[KBp];
+    const int Ka = Ke + j.L;  // rows of local linear 1's extras: [temb ; cond_l ; g]
+    constexpr int NGLu = TB ? NGL - 2 : NGL, KA = TB ? 1 : NWA, KBp = TB ? 1 : NWB;  // the part of each window a TB call uses
     const bool has_b = !TB || 16 * tp < Ke;  // local-2 extras beyond the time rows (cond_l): none for unconditioned jets
-    if (!STEM) {
-        gemv4_load<KA>(wbA, rs, lb.We1, Ka, tp, tid);
-        if (has_b) gemv4_load<KBp>(wbB, rs, lb.We2, Ke, tp, tid);
-    }
-    constexpr int K2P = TB ? 9 : 11;  // fc_global2 panels kept in registers (K2 <= 176); wider ones the slow way
-    f32x4 w2[K2P];  // KP16 [k][16]: row k = 16 i + part, outputs 4*o4..4*o4+3
-#pragma unroll
-    for (int i = 0; i < K2P; ++i) w2[i] = bload4(rs, gl2.W + (i + tp) * 256, (part * 16 + 4 * o4) * 4);  // unconditional, see gemv4_load
+    if (!STEM) PFM_MARK(0);
+    // ---- the few loads left to this phase: this thread's rows of fc_global2 and the bias vectors ----
+    const int kq = tid >> 2, o4 = tid & 3;
+    const int r0 = 16 * tp + kq, r1 = r0 + 128;  // rows of fc_global2 (KP16 [k][16]) this thread multiplies
+    const f32x4 w2a = bload4(rs, gl2.W + (int64_t)16 * tp * 16, (kq * 16 + 4 * o4) * 4);
+    f32x4 w2b = {0.f, 0.f, 0.f, 0.f};
+    if (K2 > 16 * tp + 128) w2b = bload4(rs, gl2.W + (int64_t)(16 * tp + 128) * 16, (kq * 16 + 4 * o4) * 4);  // wave-uniform
     f32x4 bg1 = bload4(rs, gl1.b, og * 16);
-    if (TB) bg1 += *reinterpret_cast<const f32x4*>(tb + TB_G1 + 4 * og);
+    f32x4 bg2 = bload4(rs, gl2.b, o4r * 16);  // padded to 16 entries
+    f32x4 bl1 = {0.f, 0.f, 0.f, 0.f}, bl2 = bl1;
+    if (!STEM) {
+        bl1 = bload4(rs, lb.b1, og * 16);
+        bl2 = bload4(rs, lb.b2, og * 16);
+    }
+    if (TB) {  // the time terms of the four per-jet Linears, tabulated once per evaluation (epic_time_table_kernel)
+        bg1 += *reinterpret_cast<const f32x4*>(tb + TB_G1 + 4 * og);
+        bg2 += *reinterpret_cast<const f32x4*>(tb + TB_G2 + 4 * o4r);
+        bl1 += *reinterpret_cast<const f32x4*>(tb + TB_L1 + 4 * og);
+        bl2 += *reinterpret_cast<const f32x4*>(tb + TB_L2 + 4 * og);
+    }
     f32x4 gold = {0.f, 0.f, 0.f, 0.f};
-    if (!STEM) gold = *reinterpret_cast<const f32x4*>(vin + TC + 2 * H + 4 * o4);  // g_old, before anyone overwrites it
-    constexpr int GW2w = TB ? GW2 - 2 : GW2;
-    f32x4 gw2[GW2w];  // the panels of fc_global1 beyond the prefetch window: land behind the first GW panels' FMAs
-    gemv4_load<GW2w>(gw2, rs, gl1.W, K1, GW + tp, tid);
+    if (!STEM) gold = *reinterpret_cast<const f32x4*>(vin + TC + 2 * H + 4 * o4r);  // g_old, before anyone overwrites it
     if (!STEM) PFM_MARK(1);
     // ---- fc_global1 ----
     f32x4 p = {0.f, 0.f, 0.f, 0.f};
-    gemv4_fma<GW>(p, gw, vin, K1, tp, pt);
-    gemv4_fma<GW2w>(p, gw2, vin, K1, GW + tp, pt);
-    for (int base = GW + GW2w + tp; 16 * base < K1; base += 4) {  // wider models: the rest the slow way
+#pragma unroll
+    for (int u = 0; u < NGLu; ++u) {
+        const int k = 16 * (tp + u) + pt;
+        p += gl[u] * (k < K1 ? vin[k] : 0.f);
+    }
+    for (int base = NGLu + tp; 16 * base < K1; base += 4) {  // wider models: the rest the slow way
         f32x4 wa[4];
         gemv4_load<4>(wa, rs, gl1.W, K1, base, tid);
         gemv4_fma<4>(p, wa, vin, K1, base, pt);
     }
     if (!STEM) PFM_MARK(2);
-    (void)a_next; (void)a_next_off;  // the next phase's A fragments were issued before the previous particle phase
     // 16-lane reductions; g1 -> vin2; local bias 2 (t / cond only) for this wave's own output slice
     p = reduce_pt(p);
     if (pt == 0) {
@@ -526,39 +616,39 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
     if (!STEM) {
         f32x4 p2 = {0.f, 0.f, 0.f, 0.f};
         if (has_b) {
-            gemv4_fma<KBp>(p2, wbB, vin, Ke, tp, pt);
-            for (int base = KBp + tp; 16 * base < Ke; base += KBp) {
-                gemv4_load<KBp>(wbB, rs, lb.We2, Ke, base, tid);
-                gemv4_fma<KBp>(p2, wbB, vin, Ke, base, pt);
+#pragma unroll
+            for (int u = 0; u < KBp; ++u) {
+                const int k = 16 * (tp + u) + pt;
+                p2 += wbB[u] * (k < Ke ? vin[k] : 0.f);
+            }
+            for (int base = KBp + tp; 16 * base < Ke; base += 1) {
+                f32x4 wx[1];
+                gemv4_load<1>(wx, rs, lb.We2, Ke, base, tid);
+                gemv4_fma<1>(p2, wx, vin, Ke, base, pt);
             }
             p2 = reduce_pt(p2);
         }
-        if (pt == 0) {
-            f32x4 b2 = p2 + bload4(rs, lb.b2, og * 16);
-            if (TB) b2 += *reinterpret_cast<const f32x4*>(tb + TB_L2 + 4 * og);
-            *reinterpret_cast<f32x4*>(lds + c.bj2 + 4 * og) = b2;
-        }
+        if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.bj2 + 4 * og) = p2 + bl2;
     }
-    f32x4 bg2 = bload4(rs, gl2.b, o4 * 16);  // padded to 16 entries
-    if (TB) bg2 += *reinterpret_cast<const f32x4*>(tb + TB_G2 + 4 * o4);
-    f32x4 bl1 = {0.f, 0.f, 0.f, 0.f};
-    if (!STEM) bl1 = bload4(rs, lb.b1, og * 16);
-    if (TB) bl1 += *reinterpret_cast<const f32x4*>(tb + TB_L1 + 4 * og);
     if (!STEM) PFM_MARK(3);
     __syncthreads();
     if (!STEM) PFM_MARK(4);
-    // ---- fc_global2, redundantly in every wave (wave-local from here on) ----
-    f32x4 gn = {0.f, 0.f, 0.f, 0.f};
+    // ---- fc_global2: rows split over all 512 threads, wave partials through LDS ----
+    {
+        f32x4 gp = w2a * (r0 < K2 ? vin2[r0] : 0.f);
+        gp += w2b * (r1 < K2 ? vin2[r1] : 0.f);
+        gp.x = row_sum_stride4(gp.x); gp.y = row_sum_stride4(gp.y); gp.z = row_sum_stride4(gp.z); gp.w = row_sum_stride4(gp.w);
 #pragma unroll
-    for (int i = 0; i < K2P; ++i) {
-        const int k = 16 * (i + tp) + part;
-        gn += w2[i] * (k < K2 ? vin2[k] : 0.f);
+        for (int e = 0; e < 4; ++e) {
+            gp[e] += __shfl_xor(gp[e], 16);
+            gp[e] += __shfl_xor(gp[e], 32);
+        }
+        if (lane < 4) *reinterpret_cast<f32x4*>(lds + c.g2p + MAXL * w + 4 * o4) = gp;  // lane = o4 here (kq & 15 == 0)
     }
-    for (int i = K2P + tp; 16 * i < K2; ++i) {
-        const int k = 16 * i + part;
-        gn += bload4(rs, gl2.W + i * 256, (part * 16 + 4 * o4) * 4) * (k < K2 ? vin2[k] : 0.f);
-    }
-    gn = row_sum16(gn);  // every lane of DPP row o4 now holds outputs 4*o4..4*o4+3
+    __syncthreads();
+    f32x4 gn = *reinterpret_cast<const f32x4*>(lds + c.g2p + 4 * o4r);
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) gn += *reinterpret_cast<const f32x4*>(lds + c.g2p + MAXL * ww + 4 * o4r);
     if (!STEM) PFM_MARK(5);
     gn += bg2;
     if (!STEM) gn += gold;  // residual before the activation, epic.py:184-186
@@ -567,8 +657,8 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
     // copy is vin.g itself, the input of the next stage
     float* gcopy = (w == 0) ? vin + TC + 2 * H : lds + c.gcopy + MAXL * w;
     if (part == 0) {
-        *reinterpret_cast<f32x4*>(gcopy + 4 * o4) = gn;
-        if (SAVE && w == 0) *reinterpret_cast<f32x4*>(save_g + 4 * o4) = gn;
+        *reinterpret_cast<f32x4*>(gcopy + 4 * o4r) = gn;
+        if (SAVE && w == 0) *reinterpret_cast<f32x4*>(save_g + 4 * o4r) = gn;
     }
     if (!STEM) {
         // local bias 1 = b1 + We1 . [temb ; cond_l ; g_new] for this wave's slice: row k = 16 i + pt of the extras
@@ -641,6 +731,11 @@ __device__ __forceinline__ void stem_l1(const pfm_epic_desc& d, const JetDims& j
 
 // Full network body up to (excluding) the fc_l3 head.  Preconditions (in LDS): yin (N x F input),
 // maskf, misc[0] = sum(mask), vin.temb, vin.cond.  Postcondition: bufB holds the last hidden state.
+// Weight traffic (per layer ~330 KB through the CU's 64 B/clk path) is spread over the particle phases (Prefetch):
+//   fc_l2 phase     : the stem's fc_g1 panels
+//   per-jet phase k : A fragments of fc_local1[k] (issued at its head, consumed by phase 1 right behind it)
+//   phase 1 of k    : A fragments of fc_local2[k], first NGL1 panels of fc_global1[k+1]
+//   phase 2 of k    : the other panels of fc_global1[k+1], the extras panels of fc_local1/2[k+1]
 template <bool SAVE, int MODE = 0, bool TB = false>
 __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims& j,
                                           const float* __restrict__ blob, float* __restrict__ lds,
@@ -652,15 +747,12 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     float* bufB = lds + c.bufB;
     float* bj1 = lds + c.bj1;
     float* bj2 = lds + c.bj2;
-    const float* vin = lds + c.vin;
     const float* maskf = lds + c.maskf;
     const int Ke = j.T + j.Cl;
-    const int TC = j.T + j.C;
-    if (TC > j.T + j.Cl) { /* cond_local == 0 while cond_global > 0: local extras use only temb */ }
+    constexpr int NGLu = TB ? NGL - 2 : NGL, KA = TB ? 1 : NWA, KBp = TB ? 1 : NWB;  // as in per_jet_phase
 
     f32x4 a1[8], a2[8];
-    f32x4 gw[GW];  // fc_global1 rows of the NEXT per-jet phase, in flight during the particle phase before it
-    const int K1s = TC + 2 * H, K1l = TC + 2 * H + j.L;
+    f32x4 gl[NGL], wbA[NWA], wbB[NWB];  // per-jet GEMV windows of the NEXT per-jet phase (see per_jet_phase)
     PFM_STAMP(1);
     // ---- stem: per-jet biases of fc_l1 / fc_l2 (t / cond columns) ------------------------------
     const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
@@ -676,42 +768,64 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     __syncthreads();
     PFM_STAMP(3);
     // ---- fc_l2: bufB = lrelu(W.bufA + bj2 + bufA)  epic.py:364-366 (residual from the source buffer)
-    prefetch_gl1(gw, rs, d.g1, K1s);
-    if (j.layers > 0) load_afrag_m<MODE>(a1, rs, d.layer[0].lc1.A, w, lane);  // first layer's phase-1 weights: in flight across fc_l2
-    if (MODE == 2) gemm_phase_x3<true, true>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, n_rows);
-    else gemm_phase<true, true, SAVE, MODE == 1>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, saved + sl.x2, saved + sl.pool, n_rows);
+    {
+        Prefetch<NGL> pf{rs, gl, nullptr, nullptr, nullptr, seg_panels(d.g1.W, 0, tid), {}, {}, {}};
+        if (MODE == 2) {
+            pf.template issue_range<0, NGL>();
+            gemm_phase_x3<true, true>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, n_rows);
+        } else {
+            gemm_phase<true, true, SAVE, MODE == 1>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, saved + sl.x2, saved + sl.pool, n_rows, pf);
+        }
+    }
     __syncthreads();
     PFM_STAMP(4);
     // ---- fc_g1 / fc_g2 (epic.py:369-380) ---------------------------------------------------------
     {
         LocalBiasSrc none; none.We1 = none.b1 = none.We2 = none.b2 = 0;
-        per_jet_phase<true, SAVE>(j, blob, rs, d.g1, d.g2, none, lds, c, saved + sl.gstem1, saved + sl.gstem, gw, a1, -1);
-        if (j.layers > 0) prefetch_gl1(gw, rs, d.layer[0].gl1, K1l, tp);  // no particle phase in between: exposed once
+        per_jet_phase<true, SAVE>(j, blob, rs, d.g1, d.g2, none, lds, c, saved + sl.gstem1, saved + sl.gstem, gl, wbA, wbB);
+        if (j.layers > 0) {  // the first layer's windows: no particle phase in between, exposed once per evaluation
+            const pfm_epic_layer& l0 = d.layer[0];
+            Prefetch<NGLu, KA, KBp> pf{rs, gl, wbA, wbB, nullptr, seg_panels(l0.gl1.W, tp, tid), seg_panels(l0.lc1.We, tp, tid),
+                                       seg_panels(l0.lc2.We, tp, tid), {}};
+            pf.template issue_range<0, NGLu + KA + KBp>();
+        }
     }
     // ---- EPiC layers (epic.py:382-385 -> :159-203) -----------------------------------------------
     for (int k = 0; k < j.layers; ++k) {
         const pfm_epic_layer ly = d.layer[k];  // by value: all 24 offset dwords in one batch of scalar loads
+        const pfm_epic_layer& nx = d.layer[k + 1 < j.layers ? k + 1 : k];  // last layer: its own blocks again (harmless, hidden)
         PFM_STAMP(10);
         // vin still holds mean / sum of the current hidden state (bufB) and g
+        load_afrag_m<MODE>(a1, rs, ly.lc1.A, w, lane);  // phase-1 weights: land behind the per-jet phase
         LocalBiasSrc lb; lb.We1 = ly.lc1.We; lb.b1 = ly.lc1.b; lb.We2 = ly.lc2.We; lb.b2 = ly.lc2.b;
         per_jet_phase<false, SAVE, TB>(j, blob, rs, ly.gl1, ly.gl2, lb, lds, c, saved + sl.glayer + k * sl.gstride,
-                                       saved + sl.glayer + k * sl.gstride + H, gw, a1, ly.lc1.A, TB ? tb + k * TB_SLOT : nullptr);
+                                       saved + sl.glayer + k * sl.gstride + H, gl, wbA, wbB, TB ? tb + k * TB_SLOT : nullptr);
         PFM_STAMP(12);
-        load_afrag_m<MODE>(a2, rs, ly.lc2.A, w, lane);  // lands behind phase 1's MFMAs
         // phase 1: bufA = lrelu(W1 . bufB + bj1)                       epic.py:194-196
-        if (MODE == 2) gemm_phase_x3<false, false>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, n_rows);
-        else gemm_phase<false, false, SAVE, MODE == 1>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, saved + sl.l1 + k * sl.lstride,
-                                                       nullptr, n_rows);
+        if (MODE == 2) {
+            load_afrag_m<MODE>(a2, rs, ly.lc2.A, w, lane);
+            Prefetch<NGL1> pf{rs, gl, nullptr, nullptr, nullptr, seg_panels(nx.gl1.W, tp, tid), {}, {}, {}};
+            pf.template issue_range<0, NGL1>();
+            gemm_phase_x3<false, false>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, n_rows);
+        } else {
+            Prefetch<8, NGL1> pf{rs, a2, gl, nullptr, nullptr, seg_afrag(ly.lc2.A, w, lane), seg_panels(nx.gl1.W, tp, tid), {}, {}};
+            gemm_phase<false, false, SAVE, MODE == 1>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, saved + sl.l1 + k * sl.lstride,
+                                                      nullptr, n_rows, pf);
+        }
         __syncthreads();
         PFM_STAMP(13);
-        if (k + 1 < j.layers) {
-            prefetch_gl1(gw, rs, d.layer[k + 1].gl1, K1l, tp);
-            load_afrag_m<MODE>(a1, rs, d.layer[k + 1].lc1.A, w, lane);  // next layer's phase-1 weights, in flight across phase 2
-        }
         // phase 2: bufB = lrelu(W2 . bufA + bj2 + bufB), pooled -> vin    epic.py:198-200, :160-162
-        if (MODE == 2) gemm_phase_x3<true, true>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, n_rows);
-        else gemm_phase<true, true, SAVE, MODE == 1>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, saved + sl.xo + k * sl.lstride,
-                                                     saved + sl.pool + (k + 1) * sl.pstride, n_rows);
+        {
+            Prefetch<NGLu - NGL1, KA, KBp> pf{rs, gl + NGL1, wbA, wbB, nullptr, seg_panels(nx.gl1.W, tp + NGL1, tid),
+                                              seg_panels(nx.lc1.We, tp, tid), seg_panels(nx.lc2.We, tp, tid), {}};
+            if (MODE == 2) {
+                pf.template issue_range<0, NGLu - NGL1 + KA + KBp>();
+                gemm_phase_x3<true, true>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, n_rows);
+            } else {
+                gemm_phase<true, true, SAVE, MODE == 1>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, saved + sl.xo + k * sl.lstride,
+                                                        saved + sl.pool + (k + 1) * sl.pstride, n_rows, pf);
+            }
+        }
         __syncthreads();
     }
     PFM_STAMP(20);
@@ -797,7 +911,6 @@ __device__ __forceinline__ int epic_jet_setup(const pfm_epic_desc& d, const JetD
         cnt += m;
         if (m != 0.f) last = p;
     }
-    for (int i = tid; i < j.F * H; i += NT) lds[c.w3 + i] = blob[d.l3_W + i];
     if (tid < j.C) {
         lds[c.vin + j.T + tid] = cond_jet[tid];
         lds[c.vin2 + j.T + tid] = cond_jet[tid];

@@ -53,7 +53,7 @@ struct Carve {
     int bufA, bufB;  // N*H each
     int xs, yin;     // N*F : ODE state, network input
     int maskf;       // N (rounded to 4)
-    int w3;          // F*H  head weights
+    int g2p;         // NW*MAXL: per-wave partial sums of fc_global2 (the k range is split over the waves)
     int bj1, bj2;    // H each: per-jet bias of the two local linears of the current layer
     int vin;         // 352: [temb(T) ; cond(C) ; mean(H) ; sum*scale(H) ; g(L)]  input of fc_global1
     int vin2;        // 208: [temb ; cond ; g1]  input of fc_global2
@@ -76,7 +76,7 @@ __host__ __device__ inline Carve make_carve(int N, int F) {
     c.xs = o; o += round4(N * F);
     c.yin = o; o += round4(N * F);
     c.maskf = o; o += round4(N);
-    c.w3 = o; o += F * H;
+    c.g2p = o; o += NW * MAXL;
     c.bj1 = o; o += H;
     c.bj2 = o; o += H;
     c.vin = o; o += VIN_FLOATS;

@@ -23,16 +23,19 @@ Bn = 256
 gen = torch.Generator().manual_seed(0)
 x = torch.randn(Bn, NP, 3, generator=gen).cuda(); t = torch.rand(Bn, generator=gen).cuda(); v = torch.empty_like(x)
 P = ctypes.c_void_p
-MODE = os.environ.get("PFM_MODE", "sample")
+MODE = os.environ.get("PFM_MODE", "sample")  # "forward": one evaluation launch
 from particle_fm_amd.hip_ops import midpoint_grid
 ts, dts = midpoint_grid(6)
 ts, dts = ts.cuda(), dts.cuda()
+lib.pfm_epic_sample_scratch_floats.restype = ctypes.c_int64
+scratch = torch.empty(lib.pfm_epic_sample_scratch_floats(ctypes.byref(lay.desc), 5, Bn), device="cuda")  # time-term table (the bench's variant)
+SCR = P(0) if os.environ.get("PFM_NO_TB") else P(scratch.data_ptr())
 for it in range(3):
     if MODE == "forward":
         rc = lib.pfm_epic_forward(ctypes.byref(lay.desc), P(blob.data_ptr()), P(t.data_ptr()), P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, P(0), P(0))
     else:  # stamps of the LAST of 10 evaluations inside the persistent sampler (warm scalar cache, steady state)
         rc = lib.pfm_epic_sample_midpoint(ctypes.byref(lay.desc), P(blob.data_ptr()), P(ts.data_ptr()), P(dts.data_ptr()), 5,
-                                          P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, P(0), P(0))
+                                          P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, SCR, P(0))
     assert rc == 0, rc
     buf = (ctypes.c_ulonglong * 512)(); n = ctypes.c_int(0)
     lib.pfm_diag_read_stamps(buf, ctypes.byref(n))
