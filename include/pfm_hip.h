@@ -130,8 +130,10 @@ typedef struct pfm_epic_desc {
 int pfm_abi_version(void);
 const char *pfm_last_error(void);
 
-/* bytes of LDS one workgroup (= one jet) needs; > 163840 means PFM_E_LDS */
+/* bytes of LDS one workgroup (= one jet) needs in the inference / loss-forward kernels and in the backward kernel; > 163840
+ * (or n_points > 160) means PFM_E_LDS: such sets run on the row-matrix path of pfm_epicw.h (the host side picks it by these) */
 int64_t pfm_epic_lds_bytes(const pfm_epic_desc *desc);
+int64_t pfm_epic_backward_lds_bytes(const pfm_epic_desc *desc);
 /* floats of activation workspace per jet that pfm_epic_fm_loss_forward writes for the backward */
 int64_t pfm_epic_saved_floats_per_jet(const pfm_epic_desc *desc);
 

@@ -430,6 +430,9 @@ WIDE_CONFIGS = {
     "jetclass": (dict(WIDE_BASE, num_particles=128, layers=20), 2),
     # the class default t_emb="sincos" (flow_matching_module.py:104, 208-211) at hidden 128: both EPiC kernels
     "sincos": (dict(BASE, num_particles=24, layers=2, global_cond_dim=2, local_cond_dim=2, t_emb="sincos", frequencies=6), 4),
+    # configs/experiment/lhco/x_jet.yaml:26-29 (y_jet.yaml the same): flow_matching.yaml at its default width with 279 particles and
+    # 4 + 4 conditioning values -- hidden 128, but the set no longer fits the jet-resident kernel's LDS tile: row-matrix path
+    "lhco128": (dict(BASE, num_particles=279, global_cond_dim=4, local_cond_dim=4), 2),
 }
 
 

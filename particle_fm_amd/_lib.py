@@ -23,6 +23,7 @@ SYMBOLS = {
     "pfm_abi_version": (c_int, []),
     "pfm_last_error": (c_char_p, []),
     "pfm_epic_lds_bytes": (c_int64, [POINTER(EpicDesc)]),
+    "pfm_epic_backward_lds_bytes": (c_int64, [POINTER(EpicDesc)]),
     "pfm_epic_saved_floats_per_jet": (c_int64, [POINTER(EpicDesc)]),
     "pfm_epic_forward": (c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
     "pfm_epic_forward_temb": (c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),

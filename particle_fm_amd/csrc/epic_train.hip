@@ -203,6 +203,11 @@ extern "C" int pfm_loss_finish(const float* loss_parts, const float* mask_count,
     return check_hip(hipGetLastError(), "loss_finish_kernel launch");
 }
 
+extern "C" int64_t pfm_epic_backward_lds_bytes(const pfm_epic_desc* d) {
+    if (!d) return -1;
+    return (int64_t)make_bcarve(d->n_points, d->features).total * 4;
+}
+
 extern "C" int64_t pfm_epic_backward_scratch_floats(const pfm_epic_desc* d, int32_t B) {
     if (!d || B < 0) return -1;
     return make_bwd_work(d->n_points, d->layers, B).total;

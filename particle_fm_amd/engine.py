@@ -174,17 +174,18 @@ class FusedFMTrainer:
         _lib.check(rc, "pfm_optim_step")
 
     def _fused_state(self, n_points: int):
-        st = self._fused.get(n_points)
+        net = self.module.flows[0].net
+        key = (n_points, getattr(net, "_freq_version", 0))  # a new frequency table (set_freq_table) means a new blob
+        st = self._fused.get(key)
         if st is None:
             from . import fm_loss
-            net = self.module.flows[0].net
             lay = net.layout(n_points)
             st = {"layout": lay, "tables": FusedEpicTables(net, lay, self.fp),
                   # initial blob the slow (torch) way: fixes freqs + descriptor tail; the pack kernel rewrites the rest
                   "blob": fm_loss.pack_blob_from_source(lay, net.source_vector(lay).detach()).contiguous(),
                   "one": torch.ones(1, device=self.fp.flat.device)}
             st["gblob"] = torch.zeros_like(st["blob"])  # the backward WRITES every gradient slot (no atomics): zeroed once
-            self._fused[n_points] = st
+            self._fused[key] = st
         return st
 
     def _pack(self, st):
@@ -267,7 +268,7 @@ class FusedFMTrainer:
         self.fp.grad.zero_()
         if getattr(getattr(self.module, "hparams", None), "use_normaliser", False):  # training_step's pre-processing (:514-518)
             x, cond = self.module._normalise(x, mask, cond)
-        if fused and self._fused is not None:
+        if fused and self._fused is not None and not self.module.flows[0].net.is_wide(x.shape[1]):
             loss = self.fused_loss_and_grad(x, mask, cond)
         else:
             self.fp.zero_grad()

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from ... import hip_ops_ca, hip_ops_tf
 from ...layout_ca import CaConfig, CaLayout
+from ...freq_table import FreqTableMixin
 from ...layout_tf import TfConfig, TfLayout, default_freqs
 
 
@@ -175,7 +176,7 @@ class CrossAttentionEncoder(nn.Module):
     forward = _container_only("CrossAttentionEncoder")
 
 
-class _FusedEncoder(nn.Module):
+class _FusedEncoder(FreqTableMixin, nn.Module):
     """What the two full encoders share: the kernel layout per (num_points, precision), the flat parameter vector and
     the packed weight blob.  Subclasses provide ``config()``, ``_LAYOUT`` and ``_forward_op``."""
 
@@ -229,7 +230,10 @@ class _FusedEncoder(nn.Module):
         lay = self.layout(num_points)
         with torch.no_grad():
             flat = self.flat_parameters(lay)
-            src = torch.cat([flat.float(), default_freqs(lay.cfg.t_dim, lay.cfg.t_emb).to(flat.device), torch.zeros(1, device=flat.device)])
+            f = self.freq_tensor()
+            if f is None:
+                f = default_freqs(lay.cfg.t_dim, lay.cfg.t_emb)
+            src = torch.cat([flat.float(), f.to(flat.device), torch.zeros(1, device=flat.device)])
             return src[lay.index_map_on(flat.device)]
 
     def vector_field(self, t: torch.Tensor, x: torch.Tensor, cond: torch.Tensor = None, mask: torch.Tensor = None,

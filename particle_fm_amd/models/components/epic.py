@@ -13,9 +13,26 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
-from ... import fm_loss, fm_loss_wide, hip_ops, hip_ops_wide
-from ...layout import PFM_HIDDEN, EpicConfig, EpicLayout
+import ctypes
+
+from ... import _lib, fm_loss, fm_loss_wide, hip_ops, hip_ops_wide
+from ...layout import PFM_HIDDEN, EpicConfig, EpicDesc, EpicLayout
+from ...freq_table import FreqTableMixin
 from ...layout_wide import EpicWideLayout
+
+LDS_BYTES = 160 * 1024   # per CU on gfx950
+MAX_RESIDENT_POINTS = 160  # the particle phases of the jet-resident kernel are unrolled for 5 pairs of 16-row tiles
+
+
+def jet_resident_fits(num_points: int, features: int) -> bool:
+    """Does one jet's (N x 128) activation tile pair fit the 160 KiB LDS of a CU, in the inference / loss-forward kernels AND in the
+    backward kernel (asked of the library: the carve is defined there, csrc/pfm_common.h, epic_bwd.h)?  N <= 150 at 3 features."""
+    if num_points > MAX_RESIDENT_POINTS:
+        return False
+    d = EpicDesc()
+    d.n_points, d.features = int(num_points), int(features)
+    lib = _lib.load()
+    return max(lib.pfm_epic_lds_bytes(ctypes.byref(d)), lib.pfm_epic_backward_lds_bytes(ctypes.byref(d))) <= LDS_BYTES
 
 
 class WNLinear(nn.Module):
@@ -65,7 +82,7 @@ class EPiC_layer(nn.Module):
         raise RuntimeError("EPiC_layer is evaluated by the fused EPiC_encoder kernel, not on its own")
 
 
-class EPiC_encoder(nn.Module):
+class EPiC_encoder(FreqTableMixin, nn.Module):
     """epic.py:206-391.  ``forward(t_in, x_local, global_cond_in, mask)`` with t_in the (B,N,T) time
     embedding, like the reference; ``vector_field(t, x, cond, mask)`` takes the time itself (B,) and lets
     the kernel embed it (what CNF.forward uses)."""
@@ -100,15 +117,28 @@ class EPiC_encoder(nn.Module):
                                            frequencies=frequencies, dropout=dropout, sum_scale=sum_scale))
         self.fc_l3 = WNLinear(hid_d + tl + local_cond_dim, feats)
         self._layouts: Dict[int, EpicLayout] = {}
-        # hidden 128: one workgroup per jet, activations resident in LDS (pfm_hip.h).  Any other width (JetClass: 300):
-        # the multi-kernel GEMM path over all particles (pfm_epicw.h).
-        self.wide = hid_d != PFM_HIDDEN
+        # hidden 128 and a set that fits the LDS tile (N <= 150 at 3 features): one workgroup per jet, activations resident in
+        # LDS (pfm_hip.h).  Any other width (JetClass: 300) or a larger set (LHCO x_jet / y_jet: N = 279, whole_event: 560, all on
+        # flow_matching.yaml's hidden 128): the multi-kernel GEMM path over all particles (pfm_epicw.h).  Decided per set size:
+        # is_wide(n); `wide` is the answer for the module's own num_points.
+        self._wide_cache: Dict[int, bool] = {}
         self.skip_masked_tail = True
         # "bf16": the inference kernels of the jet-resident path (forward, midpoint sampler) run the particle Linears on
         # bf16 MFMA with fp32 accumulate and fp32 activations (PFM_F_BF16_MFMA) -- what trainer.precision="bf16-mixed"
         # means for this model in the reference.  Training kernels and the wide path stay fp32.
         self.mfma_dtype = "fp32"
         self._fast_pack = None  # set by engine.FusedFMTrainer: one-launch weight-norm pack from the flat buffer
+
+    def is_wide(self, num_points: Optional[int] = None) -> bool:
+        n = int(num_points or self.num_points)
+        w = self._wide_cache.get(n)
+        if w is None:
+            w = self._wide_cache[n] = self.hid_d != PFM_HIDDEN or not jet_resident_fits(n, self.feats)
+        return w
+
+    @property
+    def wide(self) -> bool:
+        return self.is_wide(self.num_points)
 
     # -- layout / weights ------------------------------------------------------------------------
     def config(self, num_points: Optional[int] = None) -> EpicConfig:
@@ -120,13 +150,14 @@ class EPiC_encoder(nn.Module):
 
     def layout(self, num_points: Optional[int] = None) -> EpicLayout:
         n = num_points or self.num_points
-        if self.wide:  # row-matrix GEMM path: only the split-fp16 flavour exists besides fp32
+        wide = self.is_wide(n)
+        if wide:  # row-matrix GEMM path: only the split-fp16 flavour exists besides fp32
             mode = 1 if self.mfma_dtype == "f16x3" else 0
         else:
             mode = {"fp32": 0, "bf16": 2, "f16x3": 4}[self.mfma_dtype]
         lay = self._layouts.get((n, mode))
         if lay is None:
-            if self.wide:
+            if wide:
                 lay = EpicWideLayout(self.config(n), flags=mode)
             else:
                 lay = EpicLayout(self.config(n), flags=(1 if self.skip_masked_tail else 0) | mode)
@@ -143,19 +174,20 @@ class EPiC_encoder(nn.Module):
     def source_vector(self, layout: Optional[EpicLayout] = None) -> torch.Tensor:
         """effective weights | biases | freqs | 0 from the live parameters (differentiable)."""
         lay = layout or self.layout()
-        return lay.source_vector(dict(self.named_parameters()), "")
+        return lay.source_vector(dict(self.named_parameters()), "", freqs=self.freq_tensor())
 
     def packed_weights(self, num_points: Optional[int] = None) -> torch.Tensor:
         """The kernel blob for the current parameter values (no autograd).  Cheap (a few small launches);
         rebuilt on every call, so it can never go stale after an optimizer step, load_state_dict or an EMA
         swap (callbacks/ema.py:145-157), and nothing extra ever appears in state_dict()."""
-        if self._fast_pack is not None:
+        wide = self.is_wide(num_points)
+        if self._fast_pack is not None and not wide:
             blob = self._fast_pack(num_points or self.num_points)
             if blob is not None:
                 return blob
         lay = self.layout(num_points)
         with torch.no_grad():
-            pack = fm_loss_wide.pack_blob_from_source if self.wide else fm_loss.pack_blob_from_source
+            pack = fm_loss_wide.pack_blob_from_source if wide else fm_loss.pack_blob_from_source
             return pack(lay, self.source_vector(lay))
 
     # -- evaluation --------------------------------------------------------------------------------
@@ -172,9 +204,9 @@ class EPiC_encoder(nn.Module):
     def forward(self, t_in: torch.Tensor = None, x_local: torch.Tensor = None,
                 global_cond_in: torch.Tensor = None, mask: torch.Tensor = None) -> torch.Tensor:
         self._check_inputs(t_in, x_local, global_cond_in)
-        if self.wide:
-            raise NotImplementedError("EPiC_encoder.forward(t_emb, ...) with hid_d != 128: the wide HIP path embeds the time "
-                                      "in-kernel; call vector_field(t, x, cond, mask) (CNF.forward does)")
+        if self.is_wide(x_local.shape[1]):
+            raise NotImplementedError("EPiC_encoder.forward(t_emb, ...) on the row-matrix path (hid_d != 128 or a set beyond the LDS "
+                                      "tile): that path embeds the time in-kernel; call vector_field(t, x, cond, mask) (CNF.forward does)")
         lay = self.layout(x_local.shape[1])
         B = x_local.shape[0]
         if t_in is None:
@@ -190,6 +222,6 @@ class EPiC_encoder(nn.Module):
         lay = self.layout(x_local.shape[1])
         if blob is None:
             blob = self.packed_weights(x_local.shape[1])
-        if self.wide:
+        if self.is_wide(x_local.shape[1]):
             return hip_ops_wide.ew_forward(lay, blob, t, x_local, global_cond_in, mask)
         return hip_ops.epic_forward(lay, blob, t, x_local, global_cond_in, mask)

@@ -187,12 +187,12 @@ class CNF(nn.Module):
         lay = self.net.layout(x.shape[1])
         if self.is_transformer:
             return _fm_loss_tf.tf_fm_loss(lay, self.net.flat_parameters(lay), x, t, z, cond=cond, mask=mask, sigma=sigma,
-                                          kind=kind, eps=eps)
+                                          kind=kind, eps=eps, freqs=self.net.freq_tensor())
         if self.is_cross_attention:
             return _fm_loss_ca.ca_fm_loss(lay, self.net.flat_parameters(lay), x, t, z, cond=cond, mask=mask, sigma=sigma,
-                                          kind=kind, eps=eps)
+                                          kind=kind, eps=eps, freqs=self.net.freq_tensor())
         src = self.net.source_vector(lay)
-        if self.net.wide:
+        if self.net.is_wide(x.shape[1]):
             return _fm_loss_wide.epic_wide_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps)
         return _fm_loss.epic_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps)
 
@@ -212,7 +212,7 @@ class CNF(nn.Module):
             if self.is_cross_attention:
                 return hip_ops_ca.ca_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
                                                      ode_steps=ode_steps, premask=False)
-            if self.net.wide:
+            if self.net.is_wide(z.shape[1]):
                 return hip_ops_wide.ew_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
                                                        ode_steps=ode_steps, premask=False)
             return hip_ops.epic_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
@@ -229,9 +229,9 @@ class CNF(nn.Module):
     def _decode_diffusion(self, z, cond, mask, ode_solver, ode_steps, weights):
         """loss_type="diffusion" (:62-69, 301-325): the fixed-step ODE solvers integrate -0.5 beta (x - net / noise_rate);
         "ddim" / "em" are the samplers of models/components/solver.py (n_steps = ode_steps)."""
-        if self.is_transformer or self.is_cross_attention or self.net.wide:
-            raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' at hidden_dim 128 "
-                                      "(configs/model/diffusion.yaml) only")
+        if self.is_transformer or self.is_cross_attention or self.net.is_wide(z.shape[1]):
+            raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' at hidden_dim 128 with sets that fit "
+                                      "the LDS tile (configs/model/diffusion.yaml, N <= 150) only")
         lay = self.net.layout(z.shape[1])
         blob = weights if weights is not None else self.net.packed_weights(z.shape[1])
         dc = dict(self.diff_config)
@@ -260,9 +260,9 @@ class CNF(nn.Module):
 
     def diffusion_loss(self, x, t, z, mask=None, cond=None, criterion: str = "huber", diff_config=None) -> Tensor:
         """DiffusionLoss body (losses.py:250-288) with the draws given; z is already multiplied by the mask."""
-        if self.is_transformer or self.is_cross_attention or self.net.wide:
-            raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' at hidden_dim 128 "
-                                      "(configs/model/diffusion.yaml) only")
+        if self.is_transformer or self.is_cross_attention or self.net.is_wide(x.shape[1]):
+            raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' at hidden_dim 128 with sets that fit "
+                                      "the LDS tile (configs/model/diffusion.yaml, N <= 150) only")
         lay = self.net.layout(x.shape[1])
         return _fm_loss.epic_diffusion_loss(lay, self.net.source_vector(lay), x, t, z, cond=cond, mask=mask,
                                             criterion=criterion, diff_config=diff_config)
@@ -274,7 +274,7 @@ class CNF(nn.Module):
             return hip_ops_tf.tf_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
         if self.is_cross_attention:
             return hip_ops_ca.ca_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
-        if self.net.wide:
+        if self.net.is_wide(z.shape[1]):
             return hip_ops_wide.ew_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
         return hip_ops.epic_sample_rk(lay, blob, z, cond, mask, **kw)
 
@@ -332,6 +332,13 @@ class SetFlowMatchingLitModule(_LitBase):
             self.normaliser = IterativeNormLayer((features,), **normaliser_config)
             if self.conditioned:
                 self.ctxt_normaliser = IterativeNormLayer((global_cond_dim,), **normaliser_config)
+
+    def set_freq_table(self, spec="float64-rounded") -> None:
+        """Frequency table of the cosine time embedding for every flow (extension; particle_fm_amd/freq_table.py):
+        "float64-rounded" (default, host-independent), "torch" (this host's fp32 ``torch.arange(T).exp()``, what the reference
+        computes here) or the tensor a checkpoint was trained with.  The reference's constructor signature is untouched."""
+        for f in self.flows:
+            f.net.set_freq_table(spec)
 
     # -- sampling ------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, cond: torch.Tensor = None, mask: torch.Tensor = None, reverse: bool = False,

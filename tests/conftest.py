@@ -100,7 +100,7 @@ def load_wide_golden(name):
     return _cache[key]
 
 
-@pytest.fixture(params=["small", "jetclass", "sincos"])
+@pytest.fixture(params=["small", "jetclass", "sincos", "lhco128"])
 def wide_golden(request):
     return load_wide_golden(request.param)
 

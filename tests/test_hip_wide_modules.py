@@ -24,7 +24,8 @@ def _oracle(g, m, state=None):
 def test_forward_and_sample(wide_golden):
     g = wide_golden
     m = _module(g)
-    assert m.flows[0].net.wide == (g.hp["hidden_dim"] != 128)  # the sincos fixture is hidden 128: jet-resident kernel
+    # sincos fixture: hidden 128, N = 24 -> jet-resident kernel; lhco128: hidden 128 but N = 279 does not fit the LDS tile
+    assert m.flows[0].net.wide == (g.hp["hidden_dim"] != 128 or g.hp["num_particles"] > 150)
     tag = "nfe_f32/"
     x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))
     N = x.shape[1]

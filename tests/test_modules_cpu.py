@@ -193,3 +193,55 @@ def test_normaliser_buffers_and_errors():
         IterativeNormLayer((30, 3), extra_dims=(0,))
     with pytest.raises(ValueError):
         IterativeNormLayer((3,), means=torch.zeros(1, 3))
+
+
+def test_epic_path_is_chosen_by_set_size_and_width():
+    """configs/experiment/lhco/{x_jet,y_jet}.yaml (N = 279) and whole_event.yaml (N = 560) run flow_matching.yaml at hidden 128: the
+    set does not fit the jet-resident kernel's LDS tile, the module must take the row-matrix path instead of raising."""
+    from particle_fm_amd.layout import EpicLayout
+    from particle_fm_amd.layout_wide import EpicWideLayout
+    from particle_fm_amd.models import SetFlowMatchingLitModule
+    from particle_fm_amd.models.components.epic import jet_resident_fits
+    assert jet_resident_fits(150, 3) and not jet_resident_fits(152, 3) and not jet_resident_fits(279, 3)
+    kw = dict(optimizer=None, model="epic", features=3, hidden_dim=128, frequencies=16, layers=2, latent=10, t_local_cat=True,
+              t_global_cat=True, add_time_to_input=False, t_emb="cosine", loss_type="FM-OT")
+    for n, gc in ((279, 4), (560, 4)):
+        m = SetFlowMatchingLitModule(num_particles=n, global_cond_dim=gc, local_cond_dim=gc, **kw)
+        net = m.flows[0].net
+        assert net.wide and net.is_wide(n) and isinstance(net.layout(), EpicWideLayout)
+        assert not net.is_wide(150) and isinstance(net.layout(150), EpicLayout)  # sample(num_points=150) would stay jet-resident
+    m = SetFlowMatchingLitModule(num_particles=150, **kw)
+    assert not m.flows[0].net.wide and isinstance(m.flows[0].net.layout(), EpicLayout)
+    assert m.flows[0].net.is_wide(279)
+    m = SetFlowMatchingLitModule(num_particles=30, **dict(kw, hidden_dim=300, latent=16))
+    assert m.flows[0].net.wide
+
+
+def test_freq_table_override():
+    """The cosine embedding's frequency table is part of what a checkpoint means (freq_table.py): default = host-independent,
+    "torch" = this host's fp32 exp, or the recorded table."""
+    import numpy as np
+
+    from particle_fm_amd.models import SetFlowMatchingLitModule
+    kw = dict(optimizer=None, model="epic", features=3, hidden_dim=128, num_particles=30, frequencies=16, layers=1, latent=10,
+              t_local_cat=True, t_global_cat=True, add_time_to_input=False, t_emb="cosine", loss_type="FM-OT")
+    m = SetFlowMatchingLitModule(**kw)
+    net = m.flows[0].net
+    lay = net.layout()
+    d = lay.desc
+    f0 = net.packed_weights()[d.freqs:d.freqs + 32]
+    assert torch.equal(f0, torch.arange(32, dtype=torch.float64).exp().float())
+    m.set_freq_table("torch")
+    assert torch.equal(net.packed_weights()[d.freqs:d.freqs + 32], torch.arange(32).exp())
+    rec = torch.arange(32).exp()
+    rec[15] = torch.from_numpy(np.nextafter(rec[15:16].numpy(), np.float32(np.inf)))[0]  # the 1-ulp difference measured between hosts
+    m.set_freq_table(rec)
+    got = net.packed_weights()[d.freqs:d.freqs + 32]
+    assert torch.equal(got, rec) and not torch.equal(got, f0)
+    m.set_freq_table("float64-rounded")
+    assert torch.equal(net.packed_weights()[d.freqs:d.freqs + 32], f0)
+    with pytest.raises(ValueError):
+        m.set_freq_table(torch.ones(5))
+    with pytest.raises(ValueError):
+        m.set_freq_table("nope")
+    assert "freq" not in " ".join(k for k in m.state_dict() if "frequencies" not in k)  # nothing new in state_dict
