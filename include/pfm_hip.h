@@ -74,7 +74,7 @@ extern "C" {
                                both operands -- fp32-grade products (error 2^-22) at 2.7x less matrix-pipe time; needs |x| < 65504 */
 #define PFM_F_TEMB_SINCOS 8u /* t_emb="sincos" (flow_matching_module.py:208-211): temb = [cos(f t) ; sin(f t)], freqs table = [f ; f],
                                f = 2^k pi; default: t_emb="cosine" (time_emb.py:79-96) */
-#define PFM_F_BF16_MFMA 2u /* inference kernels only: the 128x128 particle Linears run on v_mfma_f32_16x16x16_bf16 (operands
+#define PFM_F_BF16_MFMA 2u /* inference kernels, loss forward and the dX products of the backward: the 128x128 particle Linears run on v_mfma_f32_16x16x16_bf16 (operands
                               rounded to bf16 on the fly, fp32 accumulate, fp32 activations); everything else stays fp32 */
 
 typedef struct pfm_local_lin {

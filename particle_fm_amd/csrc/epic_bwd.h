@@ -78,7 +78,9 @@ __device__ __forceinline__ f32x4 colsum16(f32x4 v) { return row_sum16(v); }
 //   acc[r] = sum_k AT-block[16w + 4q + r][k] * src[p][k]        (a = MFMA_AT fragments of this wave)
 // pre(p, oslot) fetches what the epilogue needs from global memory (the saved activation whose sign gates the gradient): it is
 // called BEFORE the pair's 64 MFMAs so that the load flies behind them (in the epilogue it would be a bare L2 round trip per pair).
-template <typename Pre, typename Epi>
+// BF16: both operands rounded to bf16 on the fly (v_mfma_f32_16x16x16_bf16, fp32 accumulate), as the forward does under
+// PFM_F_BF16_MFMA -- what Lightning's precision="bf16-mixed" (autocast around the same modules) means for these products.
+template <bool BF16 = false, typename Pre, typename Epi>
 __device__ __forceinline__ void gemm_dx(const f32x4 (&a)[8], const float* __restrict__ src, int n_rows, Pre pre, Epi epi) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int pl = lane & 15, q = lane >> 4, oslot = 4 * w + q;
@@ -95,7 +97,15 @@ __device__ __forceinline__ void gemm_dx(const f32x4 (&a)[8], const float* __rest
         const f32x4 x0 = pre(pc0, oslot), x1 = pre(pc1, oslot);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) { PFM_MFMA_PAIR(acc0, acc1, a[kt], b0[kt], b1[kt]); }
+        for (int kt = 0; kt < 8; ++kt) {
+            if (BF16) {
+                const s16x4 ab = pack_bf16(a[kt]);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, pack_bf16(b0[kt]), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, pack_bf16(b1[kt]), acc1, 0, 0, 0);
+            } else {
+                PFM_MFMA_PAIR(acc0, acc1, a[kt], b0[kt], b1[kt]);
+            }
+        }
         if (p0 < n_rows) epi(p0, oslot, acc0, x0);
         if (p1 < n_rows) epi(p1, oslot, acc1, x1);
     }

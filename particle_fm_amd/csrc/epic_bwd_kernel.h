@@ -29,6 +29,7 @@ __device__ __forceinline__ void rec_put(float* __restrict__ dst, const float* __
 // hidden state walks back through the layers inside LDS; what has to be summed over jets leaves the CU as plain stores --
 // the gradient rows `da` of every 128x128 Linear (epic_dw_kernel forms dW from them), the rank-1 operands and the small
 // per-jet partial sums in `rec` (epic_bwd_reduce_kernel).  No atomics.
+template <bool BF16>
 __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ cond,
     const float* __restrict__ mask, const float* __restrict__ saved, const float* __restrict__ inv_mask_total,
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         // (3) da1 = (W_lc2^T da2) * phi'(l1) -> Hb (and to `da`); db1j = column sums
         {
             f32x4 ps = {0.f, 0.f, 0.f, 0.f};
-            gemm_dx(a2, G, n_rows,
+            gemm_dx<BF16>(a2, G, n_rows,
                     [&](int p, int os) { return *reinterpret_cast<const f32x4*>(l1 + p * H + 4 * os); },
                     [&](int p, int os, f32x4 acc, f32x4 lv) {
                         acc *= dlrelu4(lv, slope);
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
             if (k > 0) {
                 float* da2n = daj + (size_t)(1 + 2 * (k - 1)) * j.N * H;
                 f32x4 ps = {0.f, 0.f, 0.f, 0.f};
-                gemm_dx(a1, Hb, n_rows,
+                gemm_dx<BF16>(a1, Hb, n_rows,
                         [&](int p, int os) { return *reinterpret_cast<const f32x4*>(hin + p * H + 4 * os); },
                         [&](int p, int os, f32x4 acc, f32x4 hv) {
                             f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, os));
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
                 ps = colsum16(ps);
                 if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj2 + 4 * oslot) = ps;  // db2j of layer k - 1
             } else {
-                gemm_dx(a1, Hb, n_rows,
+                gemm_dx<BF16>(a1, Hb, n_rows,
                         [&](int, int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
                         [&](int p, int os, f32x4 acc, f32x4) {
                             f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, os));
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     {
         const float* x1 = sv + sl.x1;
         f32x4 ps = {0.f, 0.f, 0.f, 0.f};
-        gemm_dx(a2, G, n_rows,
+        gemm_dx<BF16>(a2, G, n_rows,
                 [&](int p, int os) { return *reinterpret_cast<const f32x4*>(x1 + p * H + 4 * os); },
                 [&](int p, int os, f32x4 acc, f32x4 xv) {
                     acc += *reinterpret_cast<const f32x4*>(G + lds_off(p, os));

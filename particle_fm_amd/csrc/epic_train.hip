@@ -13,10 +13,13 @@ namespace pfm {
 int set_err(int code, const char* what);
 int check_hip(hipError_t e, const char* where);
 int validate(const pfm_epic_desc* d);
+int mfma_mode(const pfm_epic_desc* d);
 
 // ------------------------------------------------------------------------------------------------
 // forward: y, u from (x, z, t); v = f(t, y); loss_parts[jet] = sum (v-u)^2; activations -> saved
 // ------------------------------------------------------------------------------------------------
+// MODE 0: fp32 MFMA; 1: bf16 MFMA operands in the particle Linears (PFM_F_BF16_MFMA; fp32 accumulate, fp32 activations and saves)
+template <int MODE>
 __global__ __launch_bounds__(NT, 2) void epic_fm_loss_forward_kernel(
     const float* __restrict__ blob, int64_t desc_off, int kind, float sigma, const float* __restrict__ t,
     const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ eps,
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_forward_kernel(
     epic_time_embedding(d, j, blob, lds, c, tj);
     __syncthreads();
     if (tid < j.T) sv[sl.temb + tid] = lds[c.vin + tid];
-    epic_body<true>(d, j, blob, lds, c, n_rows, sv, sl);
+    epic_body<true, MODE>(d, j, blob, lds, c, n_rows, sv, sl);
     float sq = 0.f;
     const int F = j.F;
     float* svv = sv + sl.v;
@@ -98,7 +101,9 @@ static int loss_forward(const pfm_epic_desc* d, const float* blob, int kind, flo
     int rc = validate(d);
     if (rc) return rc;
     const int lds = make_carve(d->n_points, d->features).total * 4;
-    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(epic_fm_loss_forward_kernel),
+    const bool bf16 = mfma_mode(d) == 1;  // the split-fp16 flavour is for the inference kernels only: training stays fp32 there
+    rc = check_hip(hipFuncSetAttribute(bf16 ? reinterpret_cast<const void*>(epic_fm_loss_forward_kernel<1>)
+                                            : reinterpret_cast<const void*>(epic_fm_loss_forward_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                    "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -108,8 +113,12 @@ static int loss_forward(const pfm_epic_desc* d, const float* blob, int kind, flo
     if (kind == 1 && !eps) return set_err(PFM_E_BADARG, "CFM needs eps");
     if (kind == 3 && !rates) return set_err(PFM_E_BADARG, "the diffusion loss needs the signal / noise rates");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
-    hipLaunchKernelGGL(epic_fm_loss_forward_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, kind,
-                       sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, crit, rates);
+    if (bf16)
+        hipLaunchKernelGGL(epic_fm_loss_forward_kernel<1>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, kind,
+                           sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, crit, rates);
+    else
+        hipLaunchKernelGGL(epic_fm_loss_forward_kernel<0>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, kind,
+                           sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, crit, rates);
     return check_hip(hipGetLastError(), "epic_fm_loss_forward_kernel launch");
 }
 
@@ -138,7 +147,9 @@ static int loss_backward(const pfm_epic_desc* d, const float* blob, const float*
     if (lds > 163840) return set_err(PFM_E_LDS, "set does not fit the 160 KiB LDS tile of the backward kernel");
     if (d->l2.AT < 0) return set_err(PFM_E_BADARG, "blob was packed without the transposed (backward) weight copies");
     if (B > DW_MAXB) return set_err(PFM_E_BADARG, "at most 8192 jets per backward call (split the batch)");
-    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(epic_fm_loss_backward_kernel),
+    const bool bf16 = mfma_mode(d) == 1;  // dX products on bf16 operands like the forward; the dW GEMM keeps fp32 operands
+    rc = check_hip(hipFuncSetAttribute(bf16 ? reinterpret_cast<const void*>(epic_fm_loss_backward_kernel<true>)
+                                            : reinterpret_cast<const void*>(epic_fm_loss_backward_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                    "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -152,8 +163,12 @@ static int loss_backward(const pfm_epic_desc* d, const float* blob, const float*
     const BwdWork bw = make_bwd_work(d->n_points, d->layers, B);
     hipStream_t s = (hipStream_t)stream;
     // 1. per-jet chain: gradient rows + rank-1 operands -> scratch
-    hipLaunchKernelGGL(epic_fm_loss_backward_kernel, dim3(B), dim3(NT), (int)lds, s, blob, d->blob_floats, cond, mask, saved,
-                       inv_mask_total, grad_scale, scratch, bw, crit, jet_w);
+    if (bf16)
+        hipLaunchKernelGGL(epic_fm_loss_backward_kernel<true>, dim3(B), dim3(NT), (int)lds, s, blob, d->blob_floats, cond, mask, saved,
+                           inv_mask_total, grad_scale, scratch, bw, crit, jet_w);
+    else
+        hipLaunchKernelGGL(epic_fm_loss_backward_kernel<false>, dim3(B), dim3(NT), (int)lds, s, blob, d->blob_floats, cond, mask, saved,
+                           inv_mask_total, grad_scale, scratch, bw, crit, jet_w);
     if ((rc = check_hip(hipGetLastError(), "epic_fm_loss_backward_kernel launch"))) return rc;
     // 2. the 2 * layers + 1 dW GEMMs over the rows of all jets, split by row ranges
     hipLaunchKernelGGL(epic_dw_kernel, dim3(bw.nsplit, bw.nblk), dim3(DW_T), dw_lds, s, blob, d->blob_floats, saved, scratch, bw, B);

@@ -175,7 +175,8 @@ class FusedFMTrainer:
 
     def _fused_state(self, n_points: int):
         net = self.module.flows[0].net
-        key = (n_points, getattr(net, "_freq_version", 0))  # a new frequency table (set_freq_table) means a new blob
+        # a new frequency table (set_freq_table) means a new blob; the precision switch (set_precision) another descriptor
+        key = (n_points, getattr(net, "_freq_version", 0), getattr(net, "mfma_dtype", "fp32"))
         st = self._fused.get(key)
         if st is None:
             from . import fm_loss

@@ -123,9 +123,9 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
         # is_wide(n); `wide` is the answer for the module's own num_points.
         self._wide_cache: Dict[int, bool] = {}
         self.skip_masked_tail = True
-        # "bf16": the inference kernels of the jet-resident path (forward, midpoint sampler) run the particle Linears on
-        # bf16 MFMA with fp32 accumulate and fp32 activations (PFM_F_BF16_MFMA) -- what trainer.precision="bf16-mixed"
-        # means for this model in the reference.  Training kernels and the wide path stay fp32.
+        # "bf16": the kernels of the jet-resident path (forward, samplers, loss forward, the backward's dX products) run the
+        # particle Linears on bf16 MFMA with fp32 accumulate and fp32 activations (PFM_F_BF16_MFMA) -- what
+        # trainer.precision="bf16-mixed" means for this model in the reference.  The dW GEMM and the wide path stay fp32.
         self.mfma_dtype = "fp32"
         self._fast_pack = None  # set by engine.FusedFMTrainer: one-launch weight-norm pack from the flat buffer
 
@@ -165,7 +165,7 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
         return lay
 
     def set_precision(self, precision) -> None:
-        """Accepts Lightning's spellings: "bf16", "bf16-mixed", "bf16-true" -> bf16 MFMA operands for inference;
+        """Accepts Lightning's spellings: "bf16", "bf16-mixed", "bf16-true" -> bf16 MFMA operands (inference and training);
         "f16x3" -> split-fp16 operands (three fp16 MFMAs per product block, fp32-grade accuracy, PFM_F_F16X3_MFMA);
         anything else fp32 MFMA."""
         p = str(precision)

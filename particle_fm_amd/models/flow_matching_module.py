@@ -357,11 +357,7 @@ class SetFlowMatchingLitModule(_LitBase):
         """flow_matching_module.py:637-677: z ~ N(0,1) drawn on the CPU generator, masked, integrated 1 -> 0.
         `weights` (extension): an already packed kernel blob (``flows[0].net.packed_weights()``), so that a loop over batches
         packs the parameters once."""
-        prec = getattr(getattr(self, "trainer", None), "precision", None)
-        if prec is not None:  # trainer.precision = "bf16-mixed" -> bf16 MFMA in the sampler (EPiC jet-resident path)
-            for f in self.flows:
-                if hasattr(f.net, "set_precision"):
-                    f.net.set_precision(prec)
+        self._apply_trainer_precision()
         z = torch.randn(n_samples, num_points if num_points else self.hparams.num_particles,
                         self.hparams.features).to(self.device)
         if cond is not None:
@@ -377,6 +373,15 @@ class SetFlowMatchingLitModule(_LitBase):
             # (un-normalise the valid particles) is what runs here
             samples = self.normaliser.reverse(samples, None if mask is None else mask.reshape(samples.shape[:-1]) != 0)
         return samples
+
+    def _apply_trainer_precision(self) -> None:
+        """trainer.precision = "bf16-mixed" (configs/trainer/default.yaml:11-12; Lightning wraps the steps in autocast) -> bf16 MFMA
+        operands in the kernels that have them (EPiC jet-resident path: sampler, loss forward, dX products)."""
+        prec = getattr(getattr(self, "trainer", None), "precision", None)
+        if prec is not None:
+            for f in self.flows:
+                if hasattr(f.net, "set_precision"):
+                    f.net.set_precision(prec)
 
     # -- training ------------------------------------------------------------------------------------
     def _variable_jet_sizes(self) -> bool:
@@ -394,6 +399,7 @@ class SetFlowMatchingLitModule(_LitBase):
         return x, cond
 
     def training_step(self, batch, batch_idx):
+        self._apply_trainer_precision()
         x, mask, cond = batch
         x, cond = self._normalise(x, mask, cond)  # :514-518
         if not self._variable_jet_sizes():  # flow_matching_module.py:519-520
@@ -409,6 +415,7 @@ class SetFlowMatchingLitModule(_LitBase):
         torch.manual_seed(torch.seed())
 
     def validation_step(self, batch: Any, batch_idx: int):
+        self._apply_trainer_precision()
         x, mask, cond = batch
         x, cond = self._normalise(x, mask, cond)  # :564-568
         if not self._variable_jet_sizes():

@@ -72,6 +72,63 @@ def test_bf16_sampler_and_module_switch():
     e16, eac = (x16 - ref).abs(), (rac - ref).abs()
     assert 1e-5 < e16.max() <= 1.5 * eac.max() + 2e-3, (e16.max(), eac.max())
     assert torch.all(x16[mask.squeeze(-1) == 0] == 0)
-    # training is untouched by the switch (fp32 kernels)
+    # training follows the switch too (bf16 operands in the loss forward and the dX products: next test)
     loss = m.training_step((g.get("loss_f32/x").cuda(), g.get("loss_f32/mask").cuda(), torch.zeros(B).cuda()), 0)["loss"]
     assert torch.isfinite(loss)
+
+
+@pytest.mark.parametrize("name", ["jetnet30", "cond_gl"])
+def test_bf16_training_within_the_reference_bf16_error(name):
+    """BASELINE cfg 2 trains under Lightning's precision="bf16-mixed" (configs/trainer/default.yaml:11-12): autocast around the same
+    modules.  Here the flag selects the bf16-operand instantiations of the loss forward and of the backward's dX products (fp32
+    accumulate, fp32 activations and saved tensors; the dW GEMM keeps fp32 operands).  Bar: loss and every parameter gradient are no
+    further from the reference's fp32 vectors than the oracle under torch.autocast(bfloat16) is."""
+    from oracle.fm_ref import fm_ot_loss
+    from particle_fm_amd.fm_loss import epic_fm_loss
+    from particle_fm_amd.layout import EpicLayout
+    from tests.conftest import load_golden
+    g = load_golden(name)
+    tag = "loss_f32/"
+    x, t, z, mask, cond = (g.get(tag + k) for k in ("x", "t", "z", "mask", "cond"))
+    ref_loss, ref = g.get(tag + "loss"), g.grads(tag)
+    dev = lambda a: None if a is None else a.cuda()
+
+    def hip(flags):
+        lay = EpicLayout(cfg_of(g.hp), flags=flags)
+        state = {k: v.clone().cuda().requires_grad_(v.is_floating_point() and "frequencies" not in k) for k, v in g.state.items()}
+        src = lay.source_vector(state, "flows.0.net.", freqs=g.freqs)
+        loss = epic_fm_loss(lay, src, dev(x), dev(t), dev(z), dev(cond), dev(mask), sigma=1e-4)
+        loss.backward()
+        return loss.detach().cpu(), {k: v.grad.cpu() for k, v in state.items() if v.grad is not None}
+
+    l32, g32 = hip(1)
+    l16, g16 = hip(1 | 2)
+    st = {k: v.clone().requires_grad_(v.is_floating_point() and "frequencies" not in k) for k, v in g.state.items()}
+    vf = EpicVectorField(st, "flows.0.net", g.hp, freqs=g.freqs)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lac, *_ = fm_ot_loss(vf, x, mask, cond, t, z, sigma=1e-4)
+    lac.float().backward()
+    assert abs(l32 - ref_loss) < 2e-5 * max(1.0, abs(ref_loss))
+    e16, eac = abs(float(l16 - ref_loss)), abs(float(lac.float().detach() - ref_loss))
+    assert e16 > 1e-7, "the flag must select the bf16-operand kernels"
+    assert e16 <= 1.5 * eac + 2e-3 * abs(float(ref_loss)), (e16, eac)
+    # Rounding noise: a single tensor's max error fluctuates (a weight_g gradient is a projection <dW, v> / |v| of a noisy dW), so the
+    # bar is on the whole gradient -- relative L2 error and the sum of the per-tensor max errors no larger than the reference's own
+    # bf16 path --, with a loose per-tensor sanity bound that still catches a broken tensor.
+    worse = []
+    tot16 = totac = 0.0
+    n16 = nac = nref = 0.0
+    for k, gref in ref.items():
+        scale = max(gref.abs().max().item(), 1e-8)
+        d16 = (g16[k] - gref).abs().max().item() / scale
+        dac = (st[k].grad.float() - gref).abs().max().item() / scale
+        tot16, totac = tot16 + d16, totac + dac
+        n16 += float((g16[k] - gref).double().pow(2).sum())
+        nac += float((st[k].grad.float() - gref).double().pow(2).sum())
+        nref += float(gref.double().pow(2).sum())
+        if not d16 <= 5.0 * dac + 2e-2:
+            worse.append((k, d16, dac))
+        assert (g32[k] - gref).abs().max().item() / scale <= 2e-4
+    assert not worse, worse[:6]
+    assert tot16 <= 1.1 * totac, (tot16, totac)
+    assert (n16 / nref) ** 0.5 <= 1.05 * (nac / nref) ** 0.5, ((n16 / nref) ** 0.5, (nac / nref) ** 0.5)
