@@ -199,10 +199,15 @@ def run(name, args):
     skips = valid_rows or hp["model"] == "epic"
     exec_share = ((1 - att_share) * float(nv.mean()) / N + att_share * float((nv ** 2).mean()) / N ** 2) if skips else 1.0
     executed = dense_aggregate * exec_share  # over the timed wall time: cannot exceed the peak
+    # the dense MFMA peak of the operand type (MI355X_MICROARCH.md): bf16 / fp16 ~2.5 PFLOP/s; f16x3 runs 3 fp16 MFMAs per product
+    # block, so its useful-FLOP peak is a third of that
+    peak = {"fp32": FP32_MFMA_PEAK, "bf16": 2500e12, "f16x3": 2500e12 / 3}[args.precision]
     res = {
         "metric": "jets/sec (train step + 100-step ODE sample)", "value": B * args.steps / elapsed, "unit": "jets/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else f"f32 ({args.precision} matrix operands)",
+        # dtype = the arithmetic type of the matrix products: "bf16" = bf16 MFMA operands with fp32 accumulate (the reference's
+        # bf16-mixed); "f16x3" = split-fp16 operands (22-bit products, NOT fp32: never reported as f32)
+        "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "f16x3": "f16x3"}[args.precision],
         "data": "synthetic",
         "config": {"workload": what, "jets_per_gpu": B, "parallelism": "dp1", "ode_steps": args.ode_steps, "overlap": D,
                    "multiplicity": f"U{{{n_min}..{N}}} per jet",
@@ -211,11 +216,11 @@ def run(name, args):
         "train_ms": train_ms, "sample_ms": sample_ms, "train_jets_per_s": B / (train_ms * 1e-3),
         "sample_jets_per_s": B / (sample_ms * 1e-3),
         "roofline": {"bound": "mfma", "kernel": "sampling launches (tf_linear_kernel dominates)" if name != "jetnet30" else "epic_sample_midpoint_kernel",
-                     "achieved": executed / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": executed / FP32_MFMA_PEAK,
+                     "achieved": executed / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": executed / peak,
                      "traffic": None, "concurrent_launches": D, "valid_row_fraction": float(nv.mean()) / N,
                      "executed_share_of_dense": exec_share,
-                     "frac_algorithmic_dense": dense_launch / FP32_MFMA_PEAK,
-                     "frac_algorithmic_dense_aggregate": dense_aggregate / FP32_MFMA_PEAK,
+                     "frac_algorithmic_dense": dense_launch / peak,
+                     "frac_algorithmic_dense_aggregate": dense_aggregate / peak,
                      "note": "frac = achieved / peak, achieved = estimate of the FLOP the matrix cores executed in the sampling launches over "
                              f"the timed wall time: SURVEY 8d's dense count ({flop/1e6:.1f} MFLOP/jet/NFE over the padded N x {n_nfe} NFE x {B} "
                              "jets) scaled by executed_share_of_dense (padded particles are skipped: row work ~ mean(n)/N, self-attention ~ "

@@ -70,6 +70,10 @@ extern "C" {
 
 /* flags */
 #define PFM_F_SKIP_MASKED_TAIL 1u /* do not compute particle tiles that lie wholly behind the last valid particle */
+#define PFM_F_PACK_JETS 16u /* pfm_epic_sample_midpoint (fp32 / bf16 kernels, with SKIP_MASKED_TAIL and a mask): two short jets may share a
+                               workgroup -- rows one behind the other in the LDS tile, ONE weight stream and ONE set of phases for both
+                               (the k-th longest jet takes the shortest remaining one if pad16(rows A) + rows B fit).  Same results
+                               bit for bit; pays off for large batches of short jets, see DESIGN.md */
 #define PFM_F_F16X3_MFMA 4u /* inference kernels only: the particle Linears as three v_mfma_f32_16x16x16_f16 on (hi, lo) fp16 splits of
                                both operands -- fp32-grade products (error 2^-22) at 2.7x less matrix-pipe time; needs |x| < 65504 */
 #define PFM_F_TEMB_SINCOS 8u /* t_emb="sincos" (flow_matching_module.py:208-211): temb = [cos(f t) ; sin(f t)], freqs table = [f ; f],

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "epic_nfe.h"
@@ -93,9 +94,10 @@ __global__ __launch_bounds__(NT, 2) void epic_forward_kernel(const float* __rest
 // One evaluation of the vector field inside the persistent sampler + the integrator update.  (Tried as a real,
 // non-inlined function to isolate its register allocation: the call ABI's callee-saved spills made it 25 % slower.)
 //   stage 0: x_mid = x + 0.5*dt*k1 -> next input;   stage 1: x = x + dt*f(t+dt/2, x_mid)
-template <int MODE, bool TB>
+template <int MODE, bool TB, int NSEG = 1>
 static __device__ __forceinline__ void sampler_eval(const float* __restrict__ blob, int64_t desc_off, int n_rows,
-                                                      float t, float hs, int stage, const float* __restrict__ tb) {
+                                                      float t, float hs, int stage, const float* __restrict__ tb,
+                                                      const Segs* sg = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
@@ -104,15 +106,97 @@ static __device__ __forceinline__ void sampler_eval(const float* __restrict__ bl
     float* xs = lds + c.xs;
     float* yin = lds + c.yin;
     const int F = j.F;
-    epic_time_embedding(d, j, blob, lds, c, t);
+    epic_time_embedding(d, j, blob, lds, c, t, NSEG == 2);
     __syncthreads();
-    epic_body<false, MODE, TB>(d, j, blob, lds, c, n_rows, nullptr, sl, tb);
-    epic_head<MODE>(d, j, blob, lds, c, n_rows, [=](int p, int f, float val) {
+    epic_body<false, MODE, TB, NSEG>(d, j, blob, lds, c, n_rows, nullptr, sl, tb, sg);
+    epic_head<MODE, NSEG>(d, j, blob, lds, c, n_rows, [=](int p, int f, float val) {
         const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
         yin[p * F + f] = xn;
         if (stage) xs[p * F + f] = xn;
-    });
+    }, sg);
     __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two jets in one workgroup (packed sampler).  A jet's evaluation costs a fixed ~100k cycles (per-jet GEMV phases, stem, head,
+// phase fill / drain: ~330 KB of weights through the CU's 64 B/clk path per layer) plus ~30k per 16-row tile; for a 2-tile jet the
+// fixed part is two thirds of the time.  Two short jets whose rows fit the LDS tile together share ONE weight stream and ONE set of
+// phases: rows [0, n0) = jet A, [r1, r1 + n1) = jet B with r1 = n0 rounded up to a tile; rows in between are holes (zero input,
+// zero mask: finite, never pooled).  Results are those of the one-jet kernel (same arithmetic per row and per jet).
+// epic_pair_setup: masks, valid counts, conditioning, start state of both jets; returns the segment description.
+// ------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ Segs epic_pair_setup(const pfm_epic_desc& d, const JetDims& j, float* __restrict__ lds, const Carve& c,
+                                                         int jetA, int jetB, const float* __restrict__ z, const float* __restrict__ cond,
+                                                         const float* __restrict__ mask) {
+    const int tid = threadIdx.x;
+    const SegView v0 = seg_view(c, j.N, 0), v1 = seg_view(c, j.N, 1);
+    const float* mA = mask + (size_t)jetA * j.N;
+    const float* mB = mask + (size_t)jetB * j.N;
+    // last valid particle and valid count of both jets (wave 0..3: jet A, 4..7: jet B would do; simpler: everyone scans both)
+    int lastA = -1, lastB = -1;
+    float cntA = 0.f, cntB = 0.f;
+    for (int p = tid; p < j.N; p += NT) {
+        const float a = mA[p], b = mB[p];
+        cntA += a; cntB += b;
+        if (a != 0.f) lastA = p;
+        if (b != 0.f) lastB = p;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        cntA += __shfl_xor(cntA, m); cntB += __shfl_xor(cntB, m);
+        lastA = max(lastA, __shfl_xor(lastA, m)); lastB = max(lastB, __shfl_xor(lastB, m));
+    }
+    float* red = lds + c.misc + 8;  // 16 floats of scratch + 8 more in the second view
+    float* red2 = lds + v1.misc;
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = cntA; red[8 + (tid >> 6)] = (float)lastA;
+        red2[tid >> 6] = cntB;
+    }
+    __syncthreads();
+    float sA = 0.f, sB = 0.f, lA = -1.f;
+    for (int i = 0; i < NW; ++i) { sA += red[i]; lA = fmaxf(lA, red[8 + i]); sB += red2[i]; }
+    __syncthreads();
+    // lastB through a second round (red2 holds 8 floats only)
+    if ((tid & 63) == 0) red2[tid >> 6] = (float)lastB;
+    __syncthreads();
+    float lB = -1.f;
+    for (int i = 0; i < NW; ++i) lB = fmaxf(lB, red2[i]);
+    __syncthreads();
+    Segs sg;
+    sg.nseg = 2;
+    sg.n0 = (int)lA + 1;
+    sg.n1 = (int)lB + 1;
+    sg.r1 = (sg.n0 + TILE - 1) / TILE * TILE;
+    sg.rows = sg.r1 + sg.n1;
+    if (tid == 0) { lds[v0.misc] = sA; lds[v0.misc + 1] = lA; lds[v1.misc] = sB; }
+    const int F = j.F;
+    const float* zA = z + (size_t)jetA * j.N * F;
+    const float* zB = z + (size_t)jetB * j.N * F;
+    for (int p = tid; p < j.N; p += NT) {  // true mask of every row; second jet's mask on its own rows
+        float m = 0.f, m1 = 0.f;
+        if (p < sg.n0) m = mA[p];
+        else if (p >= sg.r1 && p < sg.rows) m = m1 = mB[p - sg.r1];
+        lds[v0.maskf + p] = m;
+        lds[v1.maskf + p] = m1;
+    }
+    for (int i = tid; i < j.N * F; i += NT) {
+        const int p = i / F, f = i - p * F;
+        float z0 = 0.f;
+        if (p < sg.n0) z0 = zA[i] * mA[p];                                               // flow_matching_module.py:668-671
+        else if (p >= sg.r1 && p < sg.rows) z0 = zB[(p - sg.r1) * F + f] * mB[p - sg.r1];
+        lds[c.xs + i] = z0;
+        lds[c.yin + i] = z0;
+    }
+    if (tid < j.C) {
+        const float a = cond[(size_t)jetA * j.C + tid], b = cond[(size_t)jetB * j.C + tid];
+        lds[v0.vin + j.T + tid] = a; lds[v0.vin2 + j.T + tid] = a;
+        lds[v1.vin + j.T + tid] = b; lds[v1.vin2 + j.T + tid] = b;
+    }
+    if (tid >= 64 && tid < 64 + MAXL) {
+        lds[v0.vin + j.T + j.C + 2 * H + (tid - 64)] = 0.f;
+        lds[v1.vin + j.T + j.C + 2 * H + (tid - 64)] = 0.f;
+    }
+    __syncthreads();
+    return sg;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -123,12 +207,45 @@ template <int MODE, bool TB>
 __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
     const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ t_eval,
     const float* __restrict__ dt, int n_intervals, const float* __restrict__ z, const float* __restrict__ cond,
-    const float* __restrict__ mask, float* __restrict__ x_out, const float* __restrict__ table, const int* __restrict__ order) {
+    const float* __restrict__ mask, float* __restrict__ x_out, const float* __restrict__ table, const int* __restrict__ pack) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d0);
     const Carve c = make_carve(j.N, j.F);
-    const int jet = order ? order[blockIdx.x] : blockIdx.x, tid = threadIdx.x;  // longest jets first (epic_jet_order_kernel)
+    const int tid = threadIdx.x;
+    // pack (epic_jet_pack_kernel): [0] = workgroups in use, then (jet A, jet B or -1) per workgroup, longest first
+    int jetA = blockIdx.x, jetB = -1;
+    if (pack) {
+        if ((int)blockIdx.x >= pack[0]) return;
+        jetA = pack[1 + 2 * blockIdx.x];
+        jetB = pack[2 + 2 * blockIdx.x];
+    }
+    float* xs = lds + c.xs;
+    const int F = j.F;
+    if constexpr (MODE != 2) if (jetB >= 0) {
+        // ---- two jets ----
+        const Segs sg = epic_pair_setup(d0, j, lds, c, jetA, jetB, z, cond, mask);
+        for (int e = 0; e < 2 * n_intervals; ++e) {
+#ifdef PFM_DIAG
+            if (e == 2 * n_intervals - 1 && blockIdx.x == 0 && threadIdx.x == 0) g_pfm_nstamp = 0;  // keep the last NFE
+            PFM_STAMP(0);
+#endif
+            const int stage = e & 1;
+            const float h = dt[e >> 1];
+            const float hs = stage ? h : __fmul_rn(0.5f, h);
+            sampler_eval<MODE, TB, 2>(blob, desc_off, sg.rows, t_eval[e], hs, stage, TB ? table + (size_t)e * j.layers * TB_SLOT : nullptr, &sg);
+            PFM_STAMP(30);
+        }
+        float* oA = x_out + (size_t)jetA * j.N * F;
+        float* oB = x_out + (size_t)jetB * j.N * F;
+        for (int i = tid; i < j.N * F; i += NT) {
+            const int p = i / F;
+            oA[i] = p < sg.n0 ? xs[i] : 0.f;                      // rows behind a jet's last valid particle are masked: 0
+            oB[i] = p < sg.n1 ? xs[sg.r1 * F + i] : 0.f;
+        }
+        return;
+    }
+    const int jet = jetA;
     const int n_rows = epic_jet_setup(d0, j, blob, lds, c, cond ? cond + (size_t)jet * j.C : nullptr,
                                       mask ? mask + (size_t)jet * j.N : nullptr);
     const float* zj = z + (size_t)jet * j.N * j.F;
@@ -137,10 +254,6 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
         lds[c.xs + i] = z0;
         lds[c.yin + i] = z0;
     }
-    const SavedLayout sl = make_saved(j.N, j.F, j.layers);
-    float* xs = lds + c.xs;
-    float* yin = lds + c.yin;
-    const int F = j.F;
     // 2*n_intervals evaluations; even = k1 at t_k, odd = slope at the midpoint (one inlined body)
     for (int e = 0; e < 2 * n_intervals; ++e) {
 #ifdef PFM_DIAG
@@ -275,6 +388,49 @@ __global__ __launch_bounds__(1024) void epic_jet_order_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Workgroup list of a packed sampling call: jets in descending row count (rows = last valid particle + 1, what the kernel
+// computes), the k-th longest paired with the shortest remaining jet if both fit the LDS tile together
+// (pad16(rows A) + rows B <= seg2_rows(N)), else alone.  pack[0] = number of workgroups, pack[1 + 2k], pack[2 + 2k] = jets of
+// workgroup k (second = -1: alone).  One workgroup; the pairing walk is sequential (B steps of one thread: ~50 us at B = 1024).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void epic_jet_pack_kernel(const float* __restrict__ mask, int B, int N, int pair_ok,
+                                                             int* __restrict__ pack) {
+    __shared__ int cnt[ORDER_MAX_JETS];
+    __shared__ int sorted[ORDER_MAX_JETS];
+    const int tid = threadIdx.x;
+    for (int jet = tid; jet < B; jet += 1024) {
+        int last = -1;
+        for (int r = 0; r < N; ++r)
+            if (mask[(int64_t)jet * N + r] != 0.f) last = r;
+        cnt[jet] = last >= 0 ? last + 1 : N;  // no valid particle: every row is computed (NaN like the reference)
+    }
+    __syncthreads();
+    for (int jet = tid; jet < B; jet += 1024) {
+        const int c = cnt[jet];
+        int rank = 0;
+        for (int k = 0; k < B; ++k) rank += (cnt[k] > c) || (cnt[k] == c && k < jet);
+        sorted[rank] = jet;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int cap = seg2_rows(N);
+        int i = 0, jj = B - 1, nwg = 0;
+        while (i <= jj) {
+            const int a = sorted[i++];
+            int b = -1;
+            if (pair_ok && i <= jj) {
+                const int cand = sorted[jj];
+                if ((cnt[a] + TILE - 1) / TILE * TILE + cnt[cand] <= cap) { b = cand; --jj; }
+            }
+            pack[1 + 2 * nwg] = a;
+            pack[2 + 2 * nwg] = b;
+            ++nwg;
+        }
+        pack[0] = nwg;
+    }
+}
+
 // which matrix-pipe flavour the inference kernels use (descriptor flags): 0 fp32, 1 bf16 operands, 2 split fp16
 int mfma_mode(const pfm_epic_desc* d) {
     if (!d) return 0;
@@ -347,10 +503,27 @@ int pfm_epic_forward_temb(const pfm_epic_desc* d, const float* blob, const float
     return check_hip(hipGetLastError(), "epic_forward_kernel launch");
 }
 
-// scratch of a sampling call: time-term table [2 n_intervals][layers][TB_SLOT] | jet order [B] (int32)
+// scratch of a sampling call: time-term table [2 n_intervals][layers][TB_SLOT] | workgroup list [1 + 2 B] (int32)
 int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc* d, int32_t n_intervals, int32_t B) {
     if (!d || n_intervals < 0 || B < 0) return -1;
-    return (int64_t)2 * n_intervals * d->layers * TB_SLOT + ((B + 63) & ~63);
+    return (int64_t)2 * n_intervals * d->layers * TB_SLOT + ((2 * (int64_t)B + 1 + 63) & ~63);
+}
+
+// device pointer of the workgroup list inside `scratch`, after queueing its computation; nullptr: one jet per workgroup, in order
+static const int* queue_jet_pack(const pfm_epic_desc* d, float* scratch, int64_t table_floats, const float* mask, int B, int mode,
+                                 hipStream_t s) {
+    if (!scratch || !mask || B < 2 || B > ORDER_MAX_JETS) return nullptr;
+    int* pack = reinterpret_cast<int*>(scratch + table_floats);
+    // two jets per workgroup: fp32 / bf16 kernels, tail-skipping on (a jet then occupies rows up to its last valid particle only)
+    // two jets per workgroup: opt-in (PFM_F_PACK_JETS; the diagnostic tests/diag/pack_time.py also switches it with the environment
+    // variable PFM_PACK=1 / 0).  Measured on MI355X: a pair saves one jet's fixed cost (7.05 ms per 100-step sample) but
+    // pays 3.2 ms for the doubled per-jet work, and the workgroups of a launch become few and uniformly long -- +1 % at 1024 jets,
+    // +-0 at 256 with two launches in flight, -4 % at 512: not on by default.
+    static const char* env = getenv("PFM_PACK");
+    const bool want = env ? env[0] == '1' : (d->flags & PFM_F_PACK_JETS) != 0;
+    const int pair_ok = want && (mode != 2) && (d->flags & PFM_F_SKIP_MASKED_TAIL) && seg2_rows(d->n_points) >= 2 * TILE;
+    hipLaunchKernelGGL(epic_jet_pack_kernel, dim3(1), dim3(1024), 0, s, mask, B, d->n_points, pair_ok, pack);
+    return pack;
 }
 
 // device pointer of the jet order inside `scratch`, after queueing its computation; nullptr: identity order
@@ -386,7 +559,7 @@ int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const fl
 #define PFM_LAUNCH_SMP(M, T)                                                                                                  \
     hipLaunchKernelGGL((epic_sample_midpoint_kernel<M, T>), dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, \
                        t_eval, dt, n_intervals, z, cond, mask, x_out, (const float*)scratch, order)
-    const int* order = queue_jet_order(d, scratch, (int64_t)2 * n_intervals * d->layers * TB_SLOT, mask, B, (hipStream_t)stream);
+    const int* order = queue_jet_pack(d, scratch, (int64_t)2 * n_intervals * d->layers * TB_SLOT, mask, B, mode, (hipStream_t)stream);
     if (tb) { if (mode == 2) PFM_LAUNCH_SMP(2, true); else if (mode == 1) PFM_LAUNCH_SMP(1, true); else PFM_LAUNCH_SMP(0, true); }
     else { if (mode == 2) PFM_LAUNCH_SMP(2, false); else if (mode == 1) PFM_LAUNCH_SMP(1, false); else PFM_LAUNCH_SMP(0, false); }
 #undef PFM_LAUNCH_SMP

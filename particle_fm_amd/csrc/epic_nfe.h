@@ -129,8 +129,16 @@ __device__ __forceinline__ void load_afrag_m(f32x4 (&a)[8], blob_rsrc rs, int64_
 
 
 template <bool SAVE>
-__device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float* __restrict__ lds, const Carve& c,
+__device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float* __restrict__ lds, int vin_off, int misc_off,
                                             int oslot, int pl, float* __restrict__ save_pool);
+
+// The second jet of a two-jet workgroup as a particle phase sees it (NSEG == 2; see Segs / SegView in pfm_common.h)
+struct Seg2Phase {
+    const float* bj = nullptr;     // its per-jet bias vector for this Linear
+    const float* mask1 = nullptr;  // mask of its rows, 0 on the first jet's rows
+    int t1 = 1 << 20;              // its first 16-row tile
+    int vin1 = 0, misc1 = 0;       // where its pooled mean / sum go, where its valid count is
+};
 
 // ---- prefetch lists -----------------------------------------------------------------------------------------------
 // A particle phase keeps the matrix pipe busy for thousands of cycles while the CU's vector-memory path idles, so the weights the
@@ -183,19 +191,24 @@ __device__ __forceinline__ PfSeg seg_panels(int64_t W_off, int first_panel, int 
 // Rows are NOT clamped: tiles may run up to 31 rows past n_rows / N (the carve keeps that window inside LDS);
 // such rows only produce garbage in their own output columns, which are never stored or pooled.
 // POOL: masked column sums -> vin (mean | sum*scale).  SAVE: rows also go to `save` (global).
-template <bool RESID, bool POOL, bool SAVE, bool BF16 = false, typename PF = PfNone>
+// NSEG == 2: the rows hold two jets (the second from tile s2.t1 on): each tile takes its own jet's bias, the pool keeps two sums.
+template <bool RESID, bool POOL, bool SAVE, bool BF16 = false, typename PF = PfNone, int NSEG = 1>
 __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __restrict__ src,
                                            float* __restrict__ dst, const float* __restrict__ resid,
                                            const float* __restrict__ bj, const float* __restrict__ maskf,
                                            const JetDims& j, float* __restrict__ lds, const Carve& c,
                                            float* __restrict__ save, float* __restrict__ save_pool, int n_rows,
-                                           const PF& pf = PF{}) {
+                                           const PF& pf = PF{}, const Seg2Phase& s2 = Seg2Phase{}) {
     const int tid_ = launder(threadIdx.x);
     const int lane = tid_ & 63, w = tid_ >> 6;
     const int pl = lane & 15, q = lane >> 4;
     const int oslot = 4 * w + q;  // 16-byte slot of this lane's 4 output features
     const float slope = j.slope;
     const f32x4 bias = *reinterpret_cast<const f32x4*>(bj + 4 * oslot);
+    f32x4 biasB = bias, psumB = {0.f, 0.f, 0.f, 0.f};
+    if (NSEG == 2) biasB = *reinterpret_cast<const f32x4*>(s2.bj + 4 * oslot);
+    const int t1 = s2.t1;
+    const float* const mask1 = s2.mask1;
     f32x4 psum = {0.f, 0.f, 0.f, 0.f};
     const int npairs = (n_rows + 2 * TILE - 1) / (2 * TILE);
     // (row & 15) == pl for every tile, so the swizzled slot offsets are per-lane constants
@@ -254,8 +267,17 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
         }
         if (POOL) {
             const float* mp = maskf + pair * 2 * TILE + pl;
-            psum += e0 * mp[0];
-            psum += e1 * mp[TILE];
+            if (NSEG == 2) {  // mask1 = the mask on the second jet's rows, 0 on the first's
+                const float* mq = mask1 + pair * 2 * TILE + pl;
+                const float q0 = mq[0], q1 = mq[TILE];
+                psumB += e0 * q0;
+                psumB += e1 * q1;
+                psum += e0 * (mp[0] - q0);
+                psum += e1 * (mp[TILE] - q1);
+            } else {
+                psum += e0 * mp[0];
+                psum += e1 * mp[TILE];
+            }
         }
     };
     // epilogue of the LAST pair (straight-line too: rows >= n_rows store to a sink and add 0 to the pool)
@@ -275,8 +297,16 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
         if (POOL) {
             const float m0 = maskf[v0 ? p0 : 0], m1 = maskf[v1 ? p1 : 0];
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            psum += v0 ? e0 * m0 : z;
-            psum += v1 ? e1 * m1 : z;
+            if (NSEG == 2) {
+                const float q0 = mask1[v0 ? p0 : 0], q1 = mask1[v1 ? p1 : 0];
+                psumB += v0 ? e0 * q0 : z;
+                psumB += v1 ? e1 * q1 : z;
+                psum += v0 ? e0 * (m0 - q0) : z;
+                psum += v1 ? e1 * (m1 - q1) : z;
+            } else {
+                psum += v0 ? e0 * m0 : z;
+                psum += v1 ? e1 * m1 : z;
+            }
         }
     };
     // one pair: hipcc sinks every ds_read down to its first use (read -> wait -> MFMA); the sched_barriers pin each
@@ -289,6 +319,10 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         if (pair > 0) epilogue_full(pacc0, pacc1, pair - 1); /* pair - 1 <= npairs - 2: every row valid */     \
         f32x4 acc0 = bias, acc1 = bias;                                                                         \
+        if (NSEG == 2) { /* wave-uniform: which jet each of the two tiles belongs to */                         \
+            if (2 * pair >= t1) acc0 = biasB;                                                                   \
+            if (2 * pair + 1 >= t1) acc1 = biasB;                                                               \
+        }                                                                                                       \
         if (RESID) { acc0 += r0; acc1 += r1; }                                                                  \
         MF(X0, X1, 0);                                                                                          \
         PFI(0);                                                                                                 \
@@ -353,7 +387,10 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
     if (nfull <= 3) pf.template issue_range<12, 16>();
     if (nfull <= 4) pf.template issue_range<16, 20>();
     pf.template issue_range<20, (PF::COUNT > 20 ? PF::COUNT : 20)>();
-    if (POOL) pool_finish<SAVE>(psum, j, lds, c, oslot, pl, save_pool);
+    if (POOL) {
+        pool_finish<SAVE>(psum, j, lds, c.vin, c.misc, oslot, pl, save_pool);
+        if (NSEG == 2) pool_finish<false>(psumB, j, lds, s2.vin1, s2.misc1, oslot, pl, nullptr);
+    }
 }
 
 // The same particle phase on split-fp16 operands.  src / dst / resid are (hi, lo) fp16 plane pairs (the lo plane
@@ -459,7 +496,7 @@ __device__ __forceinline__ void gemm_phase_x3(const f32x4 (&a)[8], const float* 
         pe1 = m1 + c1 * X3_DN;
     }
     epilogue(pe0, pe1, npairs - 1);
-    if (POOL) pool_finish<false>(psum, j, lds, c, oslot, pl, nullptr);
+    if (POOL) pool_finish<false>(psum, j, lds, c.vin, c.misc, oslot, pl, nullptr);
 }
 
 // ---- per-jet GEMVs (global MLP, per-jet biases) ------------------------------------------------
@@ -493,25 +530,32 @@ struct LocalBiasSrc {  // the two local linears whose per-jet bias a stage prepa
 };
 
 // Stem: bj1 / bj2 = b + We^T [temb ; cond_l] for fc_l1 / fc_l2 (K = T + Cl <= 96).  Ends with a barrier.
+template <int NSEG = 1>
 __device__ __forceinline__ void stem_bias(const float* __restrict__ blob, blob_rsrc rs, const LocalBiasSrc& lb, int Ke,
-                                          float* __restrict__ lds, const Carve& c) {
+                                          float* __restrict__ lds, const SegView (&sv)[2]) {
     const int tid = launder(threadIdx.x), og = tid >> 4, pt = tid & 15;
-    const float* vin = lds + c.vin;
     f32x4 w1[2], w2[2];
     const f32x4 b1 = bload4(rs, lb.b1, og * 16);
     const f32x4 b2 = bload4(rs, lb.b2, og * 16);
-    f32x4 p1 = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 p1[NSEG], p2[NSEG];
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) p1[s] = p2[s] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int base = 0; 16 * base < Ke; base += 2) {
         gemv4_load<2>(w1, rs, lb.We1, Ke, base, tid);
         gemv4_load<2>(w2, rs, lb.We2, Ke, base, tid);
-        gemv4_fma<2>(p1, w1, vin, Ke, base, pt);
-        gemv4_fma<2>(p2, w2, vin, Ke, base, pt);
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) {
+            gemv4_fma<2>(p1[s], w1, lds + sv[s].vin, Ke, base, pt);
+            gemv4_fma<2>(p2[s], w2, lds + sv[s].vin, Ke, base, pt);
+        }
     }
-    p1 = reduce_pt(p1);
-    p2 = reduce_pt(p2);
-    if (pt == 0) {
-        *reinterpret_cast<f32x4*>(lds + c.bj1 + 4 * og) = p1 + b1;
-        *reinterpret_cast<f32x4*>(lds + c.bj2 + 4 * og) = p2 + b2;
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        const f32x4 q1 = reduce_pt(p1[s]), q2 = reduce_pt(p2[s]);
+        if (pt == 0) {
+            *reinterpret_cast<f32x4*>(lds + sv[s].bj1 + 4 * og) = q1 + b1;
+            *reinterpret_cast<f32x4*>(lds + sv[s].bj2 + 4 * og) = q2 + b2;
+        }
     }
     __syncthreads();
 }
@@ -550,20 +594,20 @@ __device__ __forceinline__ float row_sum_stride4(float v) {
 // in the same fixed order.  From there on everything is wave-local: each wave finishes the bias slice [16w,16w+16) that its own
 // MFMA phase reads, so the next particle phase starts without another barrier.  Out: vin.g = g_new (written by wave 0), bj1/bj2.
 // STEM: fc_g1/fc_g2 (no g input, no residual, no local biases) and a trailing barrier (vin.g is read next).
-template <bool STEM, bool SAVE, bool TB = false>
+// NSEG == 2: two jets in the workgroup -- the weights are in registers once, every per-jet step runs for both (views sv[0], sv[1]).
+template <bool STEM, bool SAVE, bool TB = false, int NSEG = 1>
 __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __restrict__ blob, blob_rsrc rs,
                                               const pfm_dense_lin& gl1, const pfm_dense_lin& gl2,
-                                              const LocalBiasSrc& lb, float* __restrict__ lds, const Carve& c,
+                                              const LocalBiasSrc& lb, float* __restrict__ lds, const SegView (&sv)[2],
                                               float* __restrict__ save_g1, float* __restrict__ save_g,
                                               const f32x4 (&gl)[NGL], const f32x4 (&wbA)[NWA], const f32x4 (&wbB)[NWB],
                                               const float* __restrict__ tb = nullptr) {
     static_assert(!(STEM && TB), "the stem keeps its time rows");
+    static_assert(!(SAVE && NSEG != 1), "training keeps one jet per workgroup");
     const int tp = TB ? (j.T >> 4) : 0;  // time panels skipped in every block
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int og = tid >> 4, pt = tid & 15;   // fc_global1 / bias GEMVs
     const int o4r = lane >> 4, part = lane & 15;  // after the second barrier: DPP row o4r owns outputs 4*o4r..
-    float* vin = lds + c.vin;
-    float* vin2 = lds + c.vin2;
     const int TC = j.T + j.C, Ke = j.T + j.Cl;
     const int K1 = TC + 2 * H + (STEM ? 0 : j.L);
     const int K2 = TC + H;
@@ -590,51 +634,62 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
         bl1 += *reinterpret_cast<const f32x4*>(tb + TB_L1 + 4 * og);
         bl2 += *reinterpret_cast<const f32x4*>(tb + TB_L2 + 4 * og);
     }
-    f32x4 gold = {0.f, 0.f, 0.f, 0.f};
-    if (!STEM) gold = *reinterpret_cast<const f32x4*>(vin + TC + 2 * H + 4 * o4r);  // g_old, before anyone overwrites it
+    f32x4 gold[NSEG];
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        gold[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!STEM) gold[s] = *reinterpret_cast<const f32x4*>(lds + sv[s].vin + TC + 2 * H + 4 * o4r);  // g_old, before anyone overwrites it
+    }
     if (!STEM) PFM_MARK(1);
-    // ---- fc_global1 ----
-    f32x4 p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < NGLu; ++u) {
-        const int k = 16 * (tp + u) + pt;
-        p += gl[u] * (k < K1 ? vin[k] : 0.f);
-    }
-    for (int base = NGLu + tp; 16 * base < K1; base += 4) {  // wider models: the rest the slow way
-        f32x4 wa[4];
-        gemv4_load<4>(wa, rs, gl1.W, K1, base, tid);
-        gemv4_fma<4>(p, wa, vin, K1, base, pt);
-    }
-    if (!STEM) PFM_MARK(2);
-    // 16-lane reductions; g1 -> vin2; local bias 2 (t / cond only) for this wave's own output slice
-    p = reduce_pt(p);
-    if (pt == 0) {
-        const f32x4 g1 = lrelu4(p + bg1, j.slope);
-        *reinterpret_cast<f32x4*>(vin2 + TC + 4 * og) = g1;
-        if (SAVE) *reinterpret_cast<f32x4*>(save_g1 + 4 * og) = g1;
-    }
-    if (!STEM) {
-        f32x4 p2 = {0.f, 0.f, 0.f, 0.f};
-        if (has_b) {
+    for (int s = 0; s < NSEG; ++s) {
+        const float* vin = lds + sv[s].vin;
+        float* vin2 = lds + sv[s].vin2;
+        // ---- fc_global1 ----
+        f32x4 p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < KBp; ++u) {
-                const int k = 16 * (tp + u) + pt;
-                p2 += wbB[u] * (k < Ke ? vin[k] : 0.f);
-            }
-            for (int base = KBp + tp; 16 * base < Ke; base += 1) {
-                f32x4 wx[1];
-                gemv4_load<1>(wx, rs, lb.We2, Ke, base, tid);
-                gemv4_fma<1>(p2, wx, vin, Ke, base, pt);
-            }
-            p2 = reduce_pt(p2);
+        for (int u = 0; u < NGLu; ++u) {
+            const int k = 16 * (tp + u) + pt;
+            p += gl[u] * (k < K1 ? vin[k] : 0.f);
         }
-        if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.bj2 + 4 * og) = p2 + bl2;
+        for (int base = NGLu + tp; 16 * base < K1; base += 4) {  // wider models: the rest the slow way
+            f32x4 wa[4];
+            gemv4_load<4>(wa, rs, gl1.W, K1, base, tid);
+            gemv4_fma<4>(p, wa, vin, K1, base, pt);
+        }
+        if (!STEM && s == 0) PFM_MARK(2);
+        // 16-lane reductions; g1 -> vin2; local bias 2 (t / cond only) for this wave's own output slice
+        p = reduce_pt(p);
+        if (pt == 0) {
+            const f32x4 g1 = lrelu4(p + bg1, j.slope);
+            *reinterpret_cast<f32x4*>(vin2 + TC + 4 * og) = g1;
+            if (SAVE) *reinterpret_cast<f32x4*>(save_g1 + 4 * og) = g1;
+        }
+        if (!STEM) {
+            f32x4 p2 = {0.f, 0.f, 0.f, 0.f};
+            if (has_b) {
+#pragma unroll
+                for (int u = 0; u < KBp; ++u) {
+                    const int k = 16 * (tp + u) + pt;
+                    p2 += wbB[u] * (k < Ke ? vin[k] : 0.f);
+                }
+                for (int base = KBp + tp; 16 * base < Ke; base += 1) {
+                    f32x4 wx[1];
+                    gemv4_load<1>(wx, rs, lb.We2, Ke, base, tid);
+                    gemv4_fma<1>(p2, wx, vin, Ke, base, pt);
+                }
+                p2 = reduce_pt(p2);
+            }
+            if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].bj2 + 4 * og) = p2 + bl2;
+        }
     }
     if (!STEM) PFM_MARK(3);
     __syncthreads();
     if (!STEM) PFM_MARK(4);
     // ---- fc_global2: rows split over all 512 threads, wave partials through LDS ----
-    {
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        const float* vin2 = lds + sv[s].vin2;
         f32x4 gp = w2a * (r0 < K2 ? vin2[r0] : 0.f);
         gp += w2b * (r1 < K2 ? vin2[r1] : 0.f);
         gp.x = row_sum_stride4(gp.x); gp.y = row_sum_stride4(gp.y); gp.z = row_sum_stride4(gp.z); gp.w = row_sum_stride4(gp.w);
@@ -643,75 +698,80 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
             gp[e] += __shfl_xor(gp[e], 16);
             gp[e] += __shfl_xor(gp[e], 32);
         }
-        if (lane < 4) *reinterpret_cast<f32x4*>(lds + c.g2p + MAXL * w + 4 * o4) = gp;  // lane = o4 here (kq & 15 == 0)
+        if (lane < 4) *reinterpret_cast<f32x4*>(lds + sv[s].g2p + MAXL * w + 4 * o4) = gp;  // lane = o4 here (kq & 15 == 0)
     }
     __syncthreads();
-    f32x4 gn = *reinterpret_cast<const f32x4*>(lds + c.g2p + 4 * o4r);
 #pragma unroll
-    for (int ww = 1; ww < NW; ++ww) gn += *reinterpret_cast<const f32x4*>(lds + c.g2p + MAXL * ww + 4 * o4r);
-    if (!STEM) PFM_MARK(5);
-    gn += bg2;
-    if (!STEM) gn += gold;  // residual before the activation, epic.py:184-186
-    gn = lrelu4(gn, j.slope);
-    // each wave keeps its own copy of g_new in LDS (read back below as the tail of the extras vector); wave 0's
-    // copy is vin.g itself, the input of the next stage
-    float* gcopy = (w == 0) ? vin + TC + 2 * H : lds + c.gcopy + MAXL * w;
-    if (part == 0) {
-        *reinterpret_cast<f32x4*>(gcopy + 4 * o4r) = gn;
-        if (SAVE && w == 0) *reinterpret_cast<f32x4*>(save_g + 4 * o4r) = gn;
-    }
-    if (!STEM) {
-        // local bias 1 = b1 + We1 . [temb ; cond_l ; g_new] for this wave's slice: row k = 16 i + pt of the extras
-        // takes temb/cond from vin (k < Ke) or g_new[k - Ke] from the wave's copy (same wave wrote it: LDS is in order)
-        f32x4 p1 = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NSEG; ++s) {
+        const float* vin = lds + sv[s].vin;
+        f32x4 gn = *reinterpret_cast<const f32x4*>(lds + sv[s].g2p + 4 * o4r);
 #pragma unroll
-        for (int i = 0; i < KA; ++i) {
-            const int k = 16 * (i + tp) + pt;
-            const float x = k < Ke ? vin[k] : (k < Ka ? gcopy[k - Ke] : 0.f);
-            p1 += wbA[i] * x;
+        for (int ww = 1; ww < NW; ++ww) gn += *reinterpret_cast<const f32x4*>(lds + sv[s].g2p + MAXL * ww + 4 * o4r);
+        if (!STEM && s == 0) PFM_MARK(5);
+        gn += bg2;
+        if (!STEM) gn += gold[s];  // residual before the activation, epic.py:184-186
+        gn = lrelu4(gn, j.slope);
+        // each wave keeps its own copy of g_new in LDS (read back below as the tail of the extras vector); wave 0's
+        // copy is vin.g itself, the input of the next stage
+        float* gcopy = (w == 0) ? lds + sv[s].vin + TC + 2 * H : lds + sv[s].gcopy + MAXL * w;
+        if (part == 0) {
+            *reinterpret_cast<f32x4*>(gcopy + 4 * o4r) = gn;
+            if (SAVE && w == 0) *reinterpret_cast<f32x4*>(save_g + 4 * o4r) = gn;
         }
-        for (int base = KA + tp; 16 * base < Ka; ++base) {  // wider extras than the register window
-            f32x4 wx[1];
-            gemv4_load<1>(wx, rs, lb.We1, Ka, base, tid);
-            const int k = 16 * base + pt;
-            p1 += wx[0] * (k < Ke ? vin[k] : (k < Ka ? gcopy[k - Ke] : 0.f));
+        if (!STEM) {
+            // local bias 1 = b1 + We1 . [temb ; cond_l ; g_new] for this wave's slice: row k = 16 i + pt of the extras
+            // takes temb/cond from vin (k < Ke) or g_new[k - Ke] from the wave's copy (same wave wrote it: LDS is in order)
+            f32x4 p1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KA; ++i) {
+                const int k = 16 * (i + tp) + pt;
+                const float x = k < Ke ? vin[k] : (k < Ka ? gcopy[k - Ke] : 0.f);
+                p1 += wbA[i] * x;
+            }
+            for (int base = KA + tp; 16 * base < Ka; ++base) {  // wider extras than the register window
+                f32x4 wx[1];
+                gemv4_load<1>(wx, rs, lb.We1, Ka, base, tid);
+                const int k = 16 * base + pt;
+                p1 += wx[0] * (k < Ke ? vin[k] : (k < Ka ? gcopy[k - Ke] : 0.f));
+            }
+            p1 = reduce_pt(p1);
+            if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].bj1 + 4 * og) = p1 + bl1;
         }
-        p1 = reduce_pt(p1);
-        if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.bj1 + 4 * og) = p1 + bl1;
-        PFM_MARK(6);
-    } else {
-        __syncthreads();
     }
+    if (!STEM) PFM_MARK(6);
+    if (STEM) __syncthreads();
 }
 
 // masked pooling tail of a particle phase: 16-lane tree, then mean / scaled sum straight into vin
 template <bool SAVE>
-__device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float* __restrict__ lds, const Carve& c,
+__device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float* __restrict__ lds, int vin_off, int misc_off,
                                             int oslot, int pl, float* __restrict__ save_pool) {
     psum = row_sum16(psum);
     if (pl == 0) {
-        const float nvalid = lds[c.misc];
+        const float nvalid = lds[misc_off];
         const int TC = j.T + j.C;
         f32x4 mean;
         mean.x = psum.x / nvalid; mean.y = psum.y / nvalid; mean.z = psum.z / nvalid; mean.w = psum.w / nvalid;  // epic.py:161/:370
-        *reinterpret_cast<f32x4*>(lds + c.vin + TC + 4 * oslot) = mean;
-        *reinterpret_cast<f32x4*>(lds + c.vin + TC + H + 4 * oslot) = psum * j.sscale;  // epic.py:162/:371
+        *reinterpret_cast<f32x4*>(lds + vin_off + TC + 4 * oslot) = mean;
+        *reinterpret_cast<f32x4*>(lds + vin_off + TC + H + 4 * oslot) = psum * j.sscale;  // epic.py:162/:371
         if (SAVE) *reinterpret_cast<f32x4*>(save_pool + 4 * oslot) = psum;
     }
 }
 
-template <int FM, bool SAVE, int MODE = 0>
+template <int FM, bool SAVE, int MODE = 0, int NSEG = 1>
 __device__ __forceinline__ void stem_l1(const pfm_epic_desc& d, const JetDims& j, const float* __restrict__ blob,
                                         float* __restrict__ lds, const Carve& c, int n_rows,
-                                        float* __restrict__ save_x1) {
+                                        float* __restrict__ save_x1, int bj1_seg1 = 0, int r1 = 1 << 20) {
     const int tid = launder(threadIdx.x), slot = tid & 31;
     const float* Wx = blob + d.l1x.W;
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds + c.bj1 + 4 * slot);
+    f32x4 b4B = b4;
+    if (NSEG == 2) b4B = *reinterpret_cast<const f32x4*>(lds + bj1_seg1 + 4 * slot);
     f32x4 wv[FM];
 #pragma unroll
     for (int f = 0; f < FM; ++f) wv[f] = *reinterpret_cast<const f32x4*>(Wx + min(f, j.F - 1) * H + 4 * slot);
     for (int p = tid >> 5; p < n_rows; p += NT / 32) {
-        f32x4 acc = b4;
+        f32x4 acc = (NSEG == 2 && p >= r1) ? b4B : b4;
 #pragma unroll
         for (int f = 0; f < FM; ++f)
             if (f < j.F) acc += wv[f] * lds[c.yin + p * j.F + f];
@@ -736,11 +796,24 @@ __device__ __forceinline__ void stem_l1(const pfm_epic_desc& d, const JetDims& j
 //   per-jet phase k : A fragments of fc_local1[k] (issued at its head, consumed by phase 1 right behind it)
 //   phase 1 of k    : A fragments of fc_local2[k], first NGL1 panels of fc_global1[k+1]
 //   phase 2 of k    : the other panels of fc_global1[k+1], the extras panels of fc_local1/2[k+1]
-template <bool SAVE, int MODE = 0, bool TB = false>
+// NSEG == 2 (the packed sampler): the rows [0, n_rows) hold two jets, `sg` says where the second starts; everything per-particle
+// sees one set of n_rows rows with holes, everything per-jet runs for both (SegView).
+template <bool SAVE, int MODE = 0, bool TB = false, int NSEG = 1>
 __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims& j,
                                           const float* __restrict__ blob, float* __restrict__ lds,
                                           const Carve& c, int n_rows, float* __restrict__ saved,
-                                          const SavedLayout& sl, const float* __restrict__ tb = nullptr) {
+                                          const SavedLayout& sl, const float* __restrict__ tb = nullptr,
+                                          const Segs* sg = nullptr) {
+    static_assert(NSEG == 1 || (MODE != 2 && !SAVE), "two jets per workgroup: fp32 / bf16 inference kernels only");
+    const SegView sv[2] = {seg_view(c, j.N, 0), seg_view(c, j.N, NSEG == 2 ? 1 : 0)};
+    Seg2Phase s2l1, s2l2;  // the second jet as the two local Linears of a stage see it
+    if (NSEG == 2) {
+        s2l1.bj = lds + sv[1].bj1; s2l2.bj = lds + sv[1].bj2;
+        s2l1.mask1 = s2l2.mask1 = lds + sv[1].maskf;
+        s2l1.t1 = s2l2.t1 = sg->r1 / TILE;
+        s2l1.vin1 = s2l2.vin1 = sv[1].vin;
+        s2l1.misc1 = s2l2.misc1 = sv[1].misc;
+    }
     const int tp = TB ? (j.T >> 4) : 0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float* bufA = lds + c.bufA;
@@ -759,12 +832,12 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     load_afrag_m<MODE>(a2, rs, d.l2.A, w, lane);
     {
         LocalBiasSrc lb; lb.We1 = d.l1_We; lb.b1 = d.l1_b; lb.We2 = d.l2.We; lb.b2 = d.l2.b;
-        stem_bias(blob, rs, lb, Ke, lds, c);
+        stem_bias<NSEG>(blob, rs, lb, Ke, lds, sv);
     }
     PFM_STAMP(2);
     // ---- fc_l1 (K = F, VALU): bufA[p][o] = lrelu(bj1[o] + sum_f Wx[f][o] * y[p][f])  epic.py:360-362
-    if (j.F <= 4) stem_l1<4, SAVE, MODE>(d, j, blob, lds, c, n_rows, saved + sl.x1);
-    else stem_l1<MAXF, SAVE, MODE>(d, j, blob, lds, c, n_rows, saved + sl.x1);
+    if (j.F <= 4) stem_l1<4, SAVE, MODE, NSEG>(d, j, blob, lds, c, n_rows, saved + sl.x1, sv[1].bj1, NSEG == 2 ? sg->r1 : 0);
+    else stem_l1<MAXF, SAVE, MODE, NSEG>(d, j, blob, lds, c, n_rows, saved + sl.x1, sv[1].bj1, NSEG == 2 ? sg->r1 : 0);
     __syncthreads();
     PFM_STAMP(3);
     // ---- fc_l2: bufB = lrelu(W.bufA + bj2 + bufA)  epic.py:364-366 (residual from the source buffer)
@@ -774,7 +847,8 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
             pf.template issue_range<0, NGL>();
             gemm_phase_x3<true, true>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, n_rows);
         } else {
-            gemm_phase<true, true, SAVE, MODE == 1>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, saved + sl.x2, saved + sl.pool, n_rows, pf);
+            gemm_phase<true, true, SAVE, MODE == 1, decltype(pf), NSEG>(a2, bufA, bufB, bufA, bj2, maskf, j, lds, c, saved + sl.x2,
+                                                                         saved + sl.pool, n_rows, pf, s2l2);
         }
     }
     __syncthreads();
@@ -782,7 +856,7 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
     // ---- fc_g1 / fc_g2 (epic.py:369-380) ---------------------------------------------------------
     {
         LocalBiasSrc none; none.We1 = none.b1 = none.We2 = none.b2 = 0;
-        per_jet_phase<true, SAVE>(j, blob, rs, d.g1, d.g2, none, lds, c, saved + sl.gstem1, saved + sl.gstem, gl, wbA, wbB);
+        per_jet_phase<true, SAVE, false, NSEG>(j, blob, rs, d.g1, d.g2, none, lds, sv, saved + sl.gstem1, saved + sl.gstem, gl, wbA, wbB);
         if (j.layers > 0) {  // the first layer's windows: no particle phase in between, exposed once per evaluation
             const pfm_epic_layer& l0 = d.layer[0];
             Prefetch<NGLu, KA, KBp> pf{rs, gl, wbA, wbB, nullptr, seg_panels(l0.gl1.W, tp, tid), seg_panels(l0.lc1.We, tp, tid),
@@ -798,8 +872,8 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
         // vin still holds mean / sum of the current hidden state (bufB) and g
         load_afrag_m<MODE>(a1, rs, ly.lc1.A, w, lane);  // phase-1 weights: land behind the per-jet phase
         LocalBiasSrc lb; lb.We1 = ly.lc1.We; lb.b1 = ly.lc1.b; lb.We2 = ly.lc2.We; lb.b2 = ly.lc2.b;
-        per_jet_phase<false, SAVE, TB>(j, blob, rs, ly.gl1, ly.gl2, lb, lds, c, saved + sl.glayer + k * sl.gstride,
-                                       saved + sl.glayer + k * sl.gstride + H, gl, wbA, wbB, TB ? tb + k * TB_SLOT : nullptr);
+        per_jet_phase<false, SAVE, TB, NSEG>(j, blob, rs, ly.gl1, ly.gl2, lb, lds, sv, saved + sl.glayer + k * sl.gstride,
+                                             saved + sl.glayer + k * sl.gstride + H, gl, wbA, wbB, TB ? tb + k * TB_SLOT : nullptr);
         PFM_STAMP(12);
         // phase 1: bufA = lrelu(W1 . bufB + bj1)                       epic.py:194-196
         if (MODE == 2) {
@@ -809,8 +883,8 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
             gemm_phase_x3<false, false>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, n_rows);
         } else {
             Prefetch<8, NGL1> pf{rs, a2, gl, nullptr, nullptr, seg_afrag(ly.lc2.A, w, lane), seg_panels(nx.gl1.W, tp, tid), {}, {}};
-            gemm_phase<false, false, SAVE, MODE == 1>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c, saved + sl.l1 + k * sl.lstride,
-                                                      nullptr, n_rows, pf);
+            gemm_phase<false, false, SAVE, MODE == 1, decltype(pf), NSEG>(a1, bufB, bufA, nullptr, bj1, maskf, j, lds, c,
+                                                                           saved + sl.l1 + k * sl.lstride, nullptr, n_rows, pf, s2l1);
         }
         __syncthreads();
         PFM_STAMP(13);
@@ -822,8 +896,9 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
                 pf.template issue_range<0, NGLu - NGL1 + KA + KBp>();
                 gemm_phase_x3<true, true>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, n_rows);
             } else {
-                gemm_phase<true, true, SAVE, MODE == 1>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c, saved + sl.xo + k * sl.lstride,
-                                                        saved + sl.pool + (k + 1) * sl.pstride, n_rows, pf);
+                gemm_phase<true, true, SAVE, MODE == 1, decltype(pf), NSEG>(a2, bufA, bufB, bufB, bj2, maskf, j, lds, c,
+                                                                             saved + sl.xo + k * sl.lstride,
+                                                                             saved + sl.pool + (k + 1) * sl.pstride, n_rows, pf, s2l2);
             }
         }
         __syncthreads();
@@ -835,10 +910,10 @@ __device__ __forceinline__ void epic_body(const pfm_epic_desc& d, const JetDims&
 // (rows >= n_rows are emitted as 0: they are masked).  epic.py:387-391
 // The F <= 16 outputs are one 16-row MFMA panel: wave w takes the particle tiles w, w+8, ...; lane (particle, q)
 // ends up with features 4q..4q+3 of its particle.
-template <int MODE = 0, typename Emit>
+template <int MODE = 0, int NSEG = 1, typename Emit>
 __device__ __forceinline__ void epic_head(const pfm_epic_desc& d, const JetDims& j,
                                           const float* __restrict__ blob, float* __restrict__ lds,
-                                          const Carve& c, int n_rows, Emit emit) {
+                                          const Carve& c, int n_rows, Emit emit, const Segs* sg = nullptr) {
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int pl = lane & 15, q = lane >> 4;
     const float* bufB = lds + c.bufB;
@@ -850,24 +925,40 @@ __device__ __forceinline__ void epic_head(const pfm_epic_desc& d, const JetDims&
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) a[kt] = bload4(rs, d.l3_A + kt * 256, lane * 16);
     // bj3[f] = b3[f] + sum_k We3[k][f] * e[k]: wave w takes features w, w+8; lanes split k
+    const SegView sv1 = seg_view(c, j.N, NSEG == 2 ? 1 : 0);
+    float* bj3B = lds + sv1.bj1;  // second jet: in its own bj1
     for (int f = w; f < j.F; f += NW) {
-        float s = 0.f;
-        for (int k = lane; k < Ke; k += 64) s = fmaf(blob[d.l3_We + k * j.F + f], vin[k], s);
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-        if (lane == 0) bj3[f] = s + blob[d.l3_b + f];
+        float s = 0.f, sB = 0.f;
+        for (int k = lane; k < Ke; k += 64) {
+            const float wv = blob[d.l3_We + k * j.F + f];
+            s = fmaf(wv, vin[k], s);
+            if (NSEG == 2) sB = fmaf(wv, lds[sv1.vin + k], sB);
+        }
+        for (int m = 32; m >= 1; m >>= 1) {
+            s += __shfl_xor(s, m);
+            if (NSEG == 2) sB += __shfl_xor(sB, m);
+        }
+        if (lane == 0) {
+            bj3[f] = s + blob[d.l3_b + f];
+            if (NSEG == 2) bj3B[f] = sB + blob[d.l3_b + f];
+        }
     }
     __syncthreads();
     int koff[8];
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) koff[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
     const int ntiles = (n_rows + TILE - 1) / TILE;
-    f32x4 b3 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 b3 = {0.f, 0.f, 0.f, 0.f}, b3B = b3;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b3[r] = (4 * q + r < j.F) ? bj3[4 * q + r] : 0.f;
+    for (int r = 0; r < 4; ++r) {
+        b3[r] = (4 * q + r < j.F) ? bj3[4 * q + r] : 0.f;
+        if (NSEG == 2) b3B[r] = (4 * q + r < j.F) ? bj3B[4 * q + r] : 0.f;
+    }
+    const int t1 = NSEG == 2 ? sg->r1 / TILE : (1 << 20);
     for (int tile = w; tile < ntiles; tile += NW) {
         const int p = tile * TILE + pl;
         const float* s0 = bufB + tile * TILE * H;
-        f32x4 acc = b3;
+        f32x4 acc = (NSEG == 2 && tile >= t1) ? b3B : b3;
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
             f32x4 b;
@@ -939,7 +1030,7 @@ __device__ __forceinline__ int epic_jet_setup(const pfm_epic_desc& d, const JetD
 // vin.temb[k] = cos(((t + 0) * freqs[k]) * pi / 1)  -- exact fp32 op order of time_emb.py:96
 __device__ __forceinline__ void epic_time_embedding(const pfm_epic_desc& d, const JetDims& j,
                                                     const float* __restrict__ blob, float* __restrict__ lds,
-                                                    const Carve& c, float t) {
+                                                    const Carve& c, float t, bool second_jet = false) {
     const int tid = threadIdx.x;
     if (tid < j.T) {
         const float f = blob[d.freqs + tid];
@@ -953,6 +1044,11 @@ __device__ __forceinline__ void epic_time_embedding(const pfm_epic_desc& d, cons
         }
         lds[c.vin + tid] = e;
         lds[c.vin2 + tid] = e;
+        if (second_jet) {  // the packed sampler: both jets of the workgroup are at the same time
+            const SegView v1 = seg_view(c, j.N, 1);
+            lds[v1.vin + tid] = e;
+            lds[v1.vin2 + tid] = e;
+        }
     }
 }
 

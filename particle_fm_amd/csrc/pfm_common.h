@@ -95,6 +95,32 @@ __host__ __device__ inline Carve make_carve(int N, int F) {
     return c;
 }
 
+// ---- a SECOND jet in the workgroup (the packed sampler of epic_kernels.hip) ---------------------------------------------
+// Two short jets may share a workgroup: their rows sit one behind the other in bufA / bufB (the second jet starts on a 16-row
+// tile boundary), the weight streams are fetched once for both.  The second jet's per-jet vectors live in the tail of bufB, which
+// such a workgroup never fills: it is formed only if  pad16(rows of jet 0) + rows of jet 1 <= seg2_rows(N).
+constexpr int X2_VIN = 0, X2_VIN2 = X2_VIN + VIN_FLOATS, X2_BJ1 = X2_VIN2 + VIN2_FLOATS, X2_BJ2 = X2_BJ1 + H,
+              X2_GCOPY = X2_BJ2 + H, X2_G2P = X2_GCOPY + NW * MAXL, X2_MISC = X2_G2P + NW * MAXL, X2_MASK = X2_MISC + 8;
+__host__ __device__ inline int x2_floats(int N) { return X2_MASK + round4(N); }
+__host__ __device__ inline int seg2_rows(int N) { return N - (x2_floats(N) + H - 1) / H; }
+// LDS offsets (floats) of one jet's per-jet vectors: segment 0 = the carve's own, segment 1 = the tail of bufB.
+// maskf: segment 0 -> the TRUE mask of every row of the workgroup; segment 1 -> the mask of segment 1's rows, 0 elsewhere.
+struct SegView {
+    int vin, vin2, bj1, bj2, gcopy, g2p, misc, maskf;
+};
+__host__ __device__ inline SegView seg_view(const Carve& c, int N, int s) {
+    if (s == 0) return SegView{c.vin, c.vin2, c.bj1, c.bj2, c.gcopy, c.g2p, c.misc, c.maskf};
+    const int b = c.bufB + N * H - x2_floats(N);
+    return SegView{b + X2_VIN, b + X2_VIN2, b + X2_BJ1, b + X2_BJ2, b + X2_GCOPY, b + X2_G2P, b + X2_MISC, b + X2_MASK};
+}
+// The jets of a workgroup (wave-uniform).  One jet: nseg = 1, rows = its computed rows.
+struct Segs {
+    int nseg;    // 1 or 2
+    int r1;      // first LDS row of segment 1 (a multiple of 16; segment 0 starts at row 0); 1 << 20 if there is none
+    int n0, n1;  // rows computed for each segment (last valid particle + 1)
+    int rows;    // r1 + n1, or n0
+};
+
 // index of element (k, o) of a KM16 block (K-major, OUT = 128, rows in blocks of 16; see pfm_hip.h)
 __host__ __device__ inline int km16(int k, int o) { return ((k >> 4) * 32 + (o >> 2)) * 64 + (k & 15) * 4 + (o & 3); }
 

@@ -30,6 +30,7 @@ PFM_F_SKIP_MASKED_TAIL = 1
 PFM_F_BF16_MFMA = 2
 PFM_F_F16X3_MFMA = 4
 PFM_F_TEMB_SINCOS = 8
+PFM_F_PACK_JETS = 16
 
 
 class LocalLin(ctypes.Structure):

@@ -127,6 +127,9 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
         # particle Linears on bf16 MFMA with fp32 accumulate and fp32 activations (PFM_F_BF16_MFMA) -- what
         # trainer.precision="bf16-mixed" means for this model in the reference.  The dW GEMM and the wide path stay fp32.
         self.mfma_dtype = "fp32"
+        # the midpoint sampler may put two short jets into one workgroup (PFM_F_PACK_JETS, include/pfm_hip.h): same results; worth
+        # it for large batches of short jets only, hence opt-in
+        self.pack_jets = False
         self._fast_pack = None  # set by engine.FusedFMTrainer: one-launch weight-norm pack from the flat buffer
 
     def is_wide(self, num_points: Optional[int] = None) -> bool:
@@ -154,7 +157,7 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
         if wide:  # row-matrix GEMM path: only the split-fp16 flavour exists besides fp32
             mode = 1 if self.mfma_dtype == "f16x3" else 0
         else:
-            mode = {"fp32": 0, "bf16": 2, "f16x3": 4}[self.mfma_dtype]
+            mode = {"fp32": 0, "bf16": 2, "f16x3": 4}[self.mfma_dtype] | (16 if self.pack_jets else 0)
         lay = self._layouts.get((n, mode))
         if lay is None:
             if wide:
@@ -163,6 +166,10 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
                 lay = EpicLayout(self.config(n), flags=(1 if self.skip_masked_tail else 0) | mode)
             self._layouts[(n, mode)] = lay
         return lay
+
+    def set_jet_packing(self, on: bool = True) -> None:
+        """Two short jets per workgroup in the midpoint sampler (jet-resident path, fp32 / bf16 operands); results unchanged."""
+        self.pack_jets = bool(on)
 
     def set_precision(self, precision) -> None:
         """Accepts Lightning's spellings: "bf16", "bf16-mixed", "bf16-true" -> bf16 MFMA operands (inference and training);

@@ -17,7 +17,7 @@ lib = ctypes.CDLL(out)
 g = load_golden("jetnet150")
 NP = int(os.environ.get("PFM_N", "150"))
 hp = dict(g.hp); hp["num_particles"] = NP
-lay = EpicLayout(cfg_of(hp), flags=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+lay = EpicLayout(cfg_of(hp), flags=int(sys.argv[1]) if len(sys.argv) > 1 else (1 if os.environ.get("PFM_MASKN") else 0))
 blob = lay.pack_blob(g.state, "flows.0.net.").cuda()
 Bn = 256
 gen = torch.Generator().manual_seed(0)
@@ -30,12 +30,17 @@ ts, dts = ts.cuda(), dts.cuda()
 lib.pfm_epic_sample_scratch_floats.restype = ctypes.c_int64
 scratch = torch.empty(lib.pfm_epic_sample_scratch_floats(ctypes.byref(lay.desc), 5, Bn), device="cuda")  # time-term table (the bench's variant)
 SCR = P(0) if os.environ.get("PFM_NO_TB") else P(scratch.data_ptr())
+MASKN = int(os.environ.get("PFM_MASKN", "0"))  # > 0: every jet has MASKN valid particles (masked tail skipped; short jets pair up)
+maskt = None
+if MASKN:
+    maskt = (torch.arange(NP)[None] < torch.full((Bn, 1), MASKN)).float().cuda().contiguous()
+MSK = P(maskt.data_ptr()) if MASKN else P(0)
 for it in range(3):
     if MODE == "forward":
         rc = lib.pfm_epic_forward(ctypes.byref(lay.desc), P(blob.data_ptr()), P(t.data_ptr()), P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, P(0), P(0))
     else:  # stamps of the LAST of 10 evaluations inside the persistent sampler (warm scalar cache, steady state)
         rc = lib.pfm_epic_sample_midpoint(ctypes.byref(lay.desc), P(blob.data_ptr()), P(ts.data_ptr()), P(dts.data_ptr()), 5,
-                                          P(x.data_ptr()), P(0), P(0), P(v.data_ptr()), Bn, SCR, P(0))
+                                          P(x.data_ptr()), P(0), MSK, P(v.data_ptr()), Bn, SCR, P(0))
     assert rc == 0, rc
     buf = (ctypes.c_ulonglong * 512)(); n = ctypes.c_int(0)
     lib.pfm_diag_read_stamps(buf, ctypes.byref(n))

@@ -91,7 +91,8 @@ def test_time_term_table_is_a_pure_optimisation(hip, golden):
 
 
 def test_jet_launch_order_is_longest_first(hip, golden):
-    """The sampler's scratch ends with the launch order of the jets: a permutation, descending multiplicity, ties by index."""
+    """The sampler's scratch ends with the workgroup list of the call, [n_workgroups, (jet, partner or -1) ...]: without
+    PFM_F_PACK_JETS one jet per workgroup -- a permutation, descending multiplicity, ties by index."""
     import ctypes
     from particle_fm_amd import _lib
     if golden.get("midpoint_10/mask") is None:
@@ -107,7 +108,11 @@ def test_jet_launch_order_is_longest_first(hip, golden):
     torch.cuda.synchronize()
     scratch = [v for k, v in lay.__dict__["_sample_scratch"].items() if k[0] == 4 and k[3] == B][0]
     total = _lib.load().pfm_epic_sample_scratch_floats(ctypes.byref(lay.desc), 3, B)
-    order = scratch[total - ((B + 63) // 64) * 64: total - ((B + 63) // 64) * 64 + B].view(torch.int32).cpu().long()
+    ints = scratch.view(torch.int32)[total - ((2 * B + 1 + 63) // 64) * 64:].cpu().long()
+    assert int(ints[0]) == B
+    wl = ints[1:1 + 2 * B].reshape(B, 2)
+    assert torch.all(wl[:, 1] == -1)  # no pairing unless asked for
+    order = wl[:, 0]
     assert sorted(order.tolist()) == list(range(B))
     key = n[order]
     assert torch.all(key[:-1] >= key[1:])
