@@ -164,6 +164,12 @@ int pfm_epic_sample_midpoint(const pfm_epic_desc *desc, const float *blob, const
                              const float *dt, int32_t n_intervals, const float *z, const float *cond,
                              const float *mask, float *x_out, int32_t B, float *scratch, void *stream);
 
+/* The same with the time embedding of every evaluation supplied by the caller: temb_tab[2 * n_intervals][T], row e = the embedding
+ * of the e-th evaluation time (t_emb="gaussian": the caller's trainable embedding network, flow_matching_module.py:213-221). */
+int pfm_epic_sample_midpoint_temb(const pfm_epic_desc *desc, const float *blob, const float *temb_tab, const float *dt,
+                                  int32_t n_intervals, const float *z, const float *cond, const float *mask, float *x_out,
+                                  int32_t B, float *scratch, void *stream);
+
 /* Explicit Runge-Kutta scheme with up to 4 stages (a strictly lower triangular; row s of `a` feeds stage s):
  *   k_s = f(t + c[s] dt, x + dt * (a[s][0] k_0 + ... + a[s][s-1] k_{s-1}));   x <- x + dt * (b[0] k_0 + ... + b[S-1] k_{S-1})
  * with the sums formed left to right in fp32 before the multiplication by dt (the op order of torchdyn's solver steps).
@@ -188,6 +194,11 @@ int pfm_epic_sample_rk(const pfm_epic_desc *desc, const float *blob, const pfm_r
                        const float *dt, int32_t n_intervals, const float *z, const float *cond, const float *mask,
                        float *x_out, int32_t B, float *kbuf, const float *rhs, void *stream);
 
+/* pfm_epic_sample_rk with caller-supplied embeddings: temb_tab[n_intervals * stages][T] (flow matching only: rhs = NULL). */
+int pfm_epic_sample_rk_temb(const pfm_epic_desc *desc, const float *blob, const pfm_rk_tableau *tab, const float *temb_tab,
+                            const float *dt, int32_t n_intervals, const float *z, const float *cond, const float *mask,
+                            float *x_out, int32_t B, float *kbuf, void *stream);
+
 /* Flow-matching loss, forward.  kind 0 = "FM-OT" (losses.py:56-62: y=(1-t)x+(sigma+(1-sigma)t)z, u=((1-sigma)z-x)*mask),
  * kind 1 = "CFM" (losses.py:115-119: y=(1-t)x+t*z+sigma*eps, u=(z-x)*mask; eps required).
  * Writes loss_parts[B] = sum_n,f (v-u)^2 of each jet, mask_count[B] = sum_n mask, and the activations the
@@ -210,6 +221,16 @@ int pfm_epic_fm_loss_backward(const pfm_epic_desc *desc, const float *blob, cons
                               const float *cond, const float *mask, const float *saved,
                               const float *inv_mask_total, const float *grad_scale, float *grad_blob,
                               int32_t B, float *scratch, void *stream);
+
+/* The same two with the time embedding supplied by the caller, temb[B][T] (t_emb="gaussian": a small trainable network in front of
+ * the field, flow_matching_module.py:178-181, 213-221; t is still needed for the interpolation y, u): the backward also returns
+ * grad_temb[B][T] = d(loss)/d(temb) * grad_scale, from which the caller's autograd continues into that network. */
+int pfm_epic_fm_loss_forward_temb(const pfm_epic_desc *desc, const float *blob, int32_t kind, float sigma, const float *t,
+                                  const float *temb, const float *x, const float *z, const float *eps, const float *cond,
+                                  const float *mask, float *saved, float *loss_parts, float *mask_count, int32_t B, void *stream);
+int pfm_epic_fm_loss_backward_temb(const pfm_epic_desc *desc, const float *blob, const float *cond, const float *mask,
+                                   const float *saved, const float *inv_mask_total, const float *grad_scale, float *grad_blob,
+                                   float *grad_temb, int32_t B, float *scratch, void *stream);
 
 /* The scalar tail of the losses above (losses.py:75-76: sum / mask.sum()) in one launch: out2[0] = sum_b w_b loss_parts[b] /
  * sum_b mask_count[b] (w = jet_weight, or 1 if NULL), out2[1] = 1 / sum_b mask_count[b] (the inv_mask_total of the backward).

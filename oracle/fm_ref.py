@@ -49,6 +49,22 @@ def time_embedding_cosine(t: torch.Tensor, x: torch.Tensor, t_dim: int, freqs=No
     return emb.expand(*x.shape[:-1], -1)
 
 
+def gaussian_time_embedding(t: torch.Tensor, x: torch.Tensor, state: Mapping[str, torch.Tensor], cnf_prefix: str,
+                            activation: str = "leaky_relu") -> torch.Tensor:
+    """t_emb="gaussian" (flow_matching_module.py:178-181, 213-221): GaussianFourierProjection (time_emb.py:9-22: frozen W,
+    x_proj = t W 2 pi, cat(sin, cos)) -> Linear -> activation -> Linear(2 * frequencies), one row per jet, expanded over particles.
+    The four Linear tensors are trainable parameters of the CNF (``embed.1.*``, ``linear.*``), W is ``embed.0.W``."""
+    if t.dim() == 2:
+        t = t[:, 0]  # :217-218 "different shape for training"
+    W = state[cnf_prefix + "embed.0.W"]
+    x_proj = t[..., None] * W[None, ...] * 2 * math.pi
+    e = torch.cat([torch.sin(x_proj), torch.cos(x_proj)], dim=-1)
+    e = torch.nn.functional.linear(e, state[cnf_prefix + "embed.1.weight"], state[cnf_prefix + "embed.1.bias"])
+    e = getattr(torch.nn.functional, activation, lambda v: v)(e)
+    e = torch.nn.functional.linear(e, state[cnf_prefix + "linear.weight"], state[cnf_prefix + "linear.bias"]).unsqueeze(1)
+    return e.expand(*x.shape[:-1], -1)
+
+
 def time_embedding(t: torch.Tensor, x: torch.Tensor, hp: Mapping, freqs=None) -> torch.Tensor:
     """CNF.time_embedding (flow_matching_module.py:206-233) for t_emb in {"cosine", "sincos"}.
     sincos (:208-211): t = frequencies * t[..., None]; cat(cos, sin); frequencies = 2**arange(F) * pi (:172) -- pass the
@@ -75,7 +91,11 @@ class EpicVectorField:
     def __call__(self, t, x, cond=None, mask=None):
         hp = self.hp
         t_dim = 2 * hp["frequencies"]
-        temb = time_embedding(t, x, hp, self.freqs)
+        if hp.get("t_emb", "cosine") == "gaussian":
+            cnf_prefix = self.prefix[: -len("net")] if self.prefix.endswith("net") else self.prefix + "."
+            temb = gaussian_time_embedding(t, x, self.state, cnf_prefix, hp.get("activation", "leaky_relu"))
+        else:
+            temb = time_embedding(t, x, hp, self.freqs)
         if hp.get("add_time_to_input", False):
             x = torch.cat((temb, x), dim=-1)  # :199-200
         return epic_encoder(

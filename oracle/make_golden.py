@@ -101,6 +101,9 @@ CONFIGS = {
     # fm_tops150_cond.yaml style (global 2 / local 2) and jetclass_cond.yaml style (global 12 / local 0, F=13, L=16)
     "cond_gl": dict(BASE, num_particles=40, layers=2, global_cond_dim=2, local_cond_dim=2),
     "cond_jetclass": dict(BASE, num_particles=48, layers=2, features=13, latent=16, global_cond_dim=12),
+    # t_emb="gaussian" (flow_matching_module.py:178-181, 213-221; time_emb.py:9-22): a learned time embedding -- random Fourier
+    # features -> Linear -> activation -> Linear(2 * frequencies) -- whose parameters train with the network
+    "gauss": dict(BASE, num_particles=24, layers=2, t_emb="gaussian", global_cond_dim=2, local_cond_dim=2),
 }
 
 
@@ -186,7 +189,8 @@ def gen_config(ref, name, hp, out_dir, B=4, seed=12345):
             out[tag + "cond"] = cond.numpy()
         out[tag + "loss"] = loss.detach().numpy()
         for k, p in cnf.named_parameters():
-            out[tag + "grad/flows.0." + k] = p.grad.detach().clone().numpy()
+            if p.grad is not None:  # (GaussianFourierProjection.W is a frozen parameter)
+                out[tag + "grad/flows.0." + k] = p.grad.detach().clone().numpy()
 
     # ---- CFM loss (losses.py:101-136), mask required ----
     mask = make_mask(B, N, "f32", gen)

@@ -30,6 +30,13 @@ SYMBOLS = {
     "pfm_epic_sample_midpoint": (
         c_int, [POINTER(EpicDesc), _fp, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_epic_sample_scratch_floats": (c_int64, [POINTER(EpicDesc), c_int32, c_int32]),
+    "pfm_epic_sample_midpoint_temb": (
+        c_int, [POINTER(EpicDesc), _fp, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_epic_sample_rk_temb": (c_int, [POINTER(EpicDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_epic_fm_loss_forward_temb": (
+        c_int, [POINTER(EpicDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
+    "pfm_epic_fm_loss_backward_temb": (
+        c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_epic_fm_loss_forward": (
         c_int, [POINTER(EpicDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
     "pfm_epic_backward_scratch_floats": (c_int64, [POINTER(EpicDesc), c_int32]),

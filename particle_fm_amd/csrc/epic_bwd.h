@@ -37,6 +37,7 @@ struct BCarve {
     int dag2;          // MAXL
     int dg1;           // H
     int misc;          // 16
+    int dte;           // MAXT: gradient w.r.t. the time embedding (only when the caller supplies it: t_emb="gaussian")
     int tg;            // VIN_FLOATS: result of km16_tgemv (aliases da3 | w3, both dead after the head; padded where they are too small)
     int total;
 };
@@ -61,6 +62,7 @@ __host__ __device__ inline BCarve make_bcarve(int N, int F) {
     c.dag2 = o; o += MAXL;
     c.dg1 = o; o += H;
     c.misc = o; o += 16;
+    c.dte = o; o += MAXT;
     c.total = o;
     return c;
 }
@@ -186,6 +188,16 @@ __device__ __forceinline__ void km16_tgemv(const float* __restrict__ W, int p_lo
     }
 }
 
+// dte[k] += We[k][:] . dy for the time rows k < T of a KM16 extras block (the gradient a caller-supplied time embedding receives
+// through the per-jet bias of a local Linear).  Two barriers.
+__device__ __forceinline__ void dtemb_from_extras(const float* __restrict__ We, const float* __restrict__ dy, int T,
+                                                  float* __restrict__ tg, float* __restrict__ dte) {
+    km16_tgemv(We, 0, (T - 1) >> 4, dy, tg);
+    __syncthreads();
+    if ((int)threadIdx.x < T) dte[threadIdx.x] += tg[threadIdx.x];
+    __syncthreads();
+}
+
 // dot of row k of a KM16 block with a 128-vector in LDS
 __device__ __forceinline__ float km16_rowdot(const float* __restrict__ W, int k, const float* __restrict__ v) {
     const f32x4* row = reinterpret_cast<const f32x4*>(W) + (k >> 4) * 512 + (k & 15);
@@ -206,7 +218,8 @@ template <bool STEM>
 __device__ __forceinline__ void global_backward(const JetDims& j, const float* __restrict__ blob,
                                                 const pfm_dense_lin& gl1,
                                                 const pfm_dense_lin& gl2, float* __restrict__ lds, const BCarve& c,
-                                                const float* __restrict__ sv_g1, const float* __restrict__ sv_gout) {
+                                                const float* __restrict__ sv_g1, const float* __restrict__ sv_gout,
+                                                bool want_dt = false) {
     const int tid = threadIdx.x;
     const int TC = j.T + j.C;
     const float nvalid = lds[c.misc];
@@ -233,10 +246,17 @@ __device__ __forceinline__ void global_backward(const JetDims& j, const float* _
     __syncthreads();
     // (dW_gl1 = sum_jets vin (x) dag1, db_gl1 = sum dag1: epic_bwd_reduce_kernel)
     // dvin[k] = W_gl1[k][:] . dag1 for k >= TC  -> dmean, dsum (-> dP), dg_in
-    const int p_lo = TC >> 4, k_hi = TC + 2 * H + (STEM ? 0 : j.L) - 1;
+    // (with want_dt also the time rows k < T: d loss / d temb of a caller-supplied embedding gets W_gl1[k] . dag1 + W_gl2[k] . dag2)
+    const int p_lo = want_dt ? 0 : TC >> 4, k_hi = TC + 2 * H + (STEM ? 0 : j.L) - 1;
     km16_tgemv(blob + gl1.W, p_lo, k_hi >> 4, lds + c.dag1, lds + c.tg);
     __syncthreads();
     const float* dv = lds + c.tg - 16 * p_lo;  // dv[k] = dvin[k]
+    if (want_dt && tid >= 256 && tid < 256 + j.T) {
+        const int k = tid - 256;
+        float a = dv[k];
+        for (int o = 0; o < j.L; ++o) a = fmaf(blob[gl2.W + k * 16 + o], lds[c.dag2 + o], a);
+        lds[c.dte + k] += a;
+    }
     if (tid < H) {
         // pooled mean = sum / n (epic.py:161), pooled sum * scale (:162)
         lds[c.dP + tid] = dv[TC + tid] / nvalid + dv[TC + H + tid] * j.sscale;

@@ -33,7 +33,8 @@ template <bool BF16>
 __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ cond,
     const float* __restrict__ mask, const float* __restrict__ saved, const float* __restrict__ inv_mask_total,
-    const float* __restrict__ grad_scale, float* __restrict__ work, BwdWork bw, int crit, const float* __restrict__ jet_w) {
+    const float* __restrict__ grad_scale, float* __restrict__ work, BwdWork bw, int crit, const float* __restrict__ jet_w,
+    float* __restrict__ dtemb) {  // dtemb (or NULL): [B][T] gradient w.r.t. a caller-supplied time embedding
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         if (tid < j.T) lds[c.vin + tid] = sv[sl.temb + tid];
         if (tid >= 64 && tid < 64 + j.C) lds[c.vin + j.T + (tid - 64)] = cond[(size_t)jet * j.C + (tid - 64)];
         if (tid >= 128 && tid < 128 + MAXL) lds[c.dg + (tid - 128)] = 0.f;
+        if (tid >= 192 && tid < 192 + MAXT) lds[c.dte + (tid - 192)] = 0.f;
         for (int m = 32; m >= 1; m >>= 1) {
             cnt += __shfl_xor(cnt, m);
             last = max(last, __shfl_xor(last, m));
@@ -132,7 +134,10 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
             if (f < j.F)
                 for (int p = lane; p < n_rows; p += 64) a += lds[c.da3 + p * j.F + f];
             for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
-            if (lane == 0) rec[br.db3 + f] = a;
+            if (lane == 0) {
+                rec[br.db3 + f] = a;
+                lds[c.dag2 + f] = a;  // (scratch until the first global_backward) for the time rows of fc_l3's extras below
+            }
         }
         // G[p][4slot..] = sum_f W3[f][4slot..] * da3[p][f]
         const int slot = tid & 31;
@@ -145,6 +150,13 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     }
     __syncthreads();
 
+    const bool want_dt = dtemb != nullptr;
+    if (want_dt && tid < j.T) {  // fc_l3 extras, KMAJOR [Ke][F]: d temb[k] = sum_f We3[k][f] db3j[f]   (db3j written before the barrier above)
+        float a = 0.f;
+        for (int f = 0; f < j.F; ++f) a = fmaf(blob[d.l3_We + tid * j.F + f], lds[c.dag2 + f], a);
+        lds[c.dte + tid] += a;
+    }
+    if (want_dt) __syncthreads();
     f32x4 a1[8], a2[8];
     const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
     // ---- EPiC layers, last to first ----
@@ -210,8 +222,12 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         rec_put(rstage + BwdRec::DBJ2, lds + c.dbj2, H, 32);
         if (tid >= 64 && tid < 64 + MAXL) rstage[BwdRec::GOUT + tid - 64] = (tid - 64 < j.L) ? gout[tid - 64] : 0.f;
         __syncthreads();
+        if (want_dt) {  // time rows of the two extras blocks
+            dtemb_from_extras(blob + ly.lc1.We, lds + c.dbj1, j.T, lds + c.tg, lds + c.dte);
+            dtemb_from_extras(blob + ly.lc2.We, lds + c.dbj2, j.T, lds + c.tg, lds + c.dte);
+        }
         // (5) global MLP backward -> dP_k, dg_k; its rank-1 operands -> rec
-        global_backward<false>(j, blob, ly.gl1, ly.gl2, lds, c, g1, gout);
+        global_backward<false>(j, blob, ly.gl1, ly.gl2, lds, c, g1, gout, want_dt);
         rec_put(rstage + BwdRec::VIN, lds + c.vin, VIN_FLOATS, 0);
         rec_put(rstage + BwdRec::VIN2, lds + c.vin2, VIN2_FLOATS, 128);
         rec_put(rstage + BwdRec::DAG1, lds + c.dag1, H, 192);
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     // global stem backward (fc_g1 / fc_g2): dg_0 -> dP (the pool of x2 as seen by the stem MLP)
     build_vin(j, lds, c, sv + sl.pool, nullptr, false);
     __syncthreads();
-    global_backward<true>(j, blob, d.g1, d.g2, lds, c, sv + sl.gstem1, sv + sl.gstem);
+    global_backward<true>(j, blob, d.g1, d.g2, lds, c, sv + sl.gstem1, sv + sl.gstem, want_dt);
     rec_put(rec + BwdRec::VIN, lds + c.vin, VIN_FLOATS, 0);
     rec_put(rec + BwdRec::VIN2, lds + c.vin2, VIN2_FLOATS, 128);
     rec_put(rec + BwdRec::DAG1, lds + c.dag1, H, 192);
@@ -295,6 +311,11 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     __syncthreads();
     rec_put(rec + BwdRec::DBJ1, lds + c.dbj1, H, 0);   // dWe of fc_l1 / fc_l2 = sum_jets [temb ; cond_l] (x) db1j / db2j
     rec_put(rec + BwdRec::DBJ2, lds + c.dbj2, H, 32);
+    if (want_dt) {
+        dtemb_from_extras(blob + d.l1_We, lds + c.dbj1, j.T, lds + c.tg, lds + c.dte);
+        dtemb_from_extras(blob + d.l2.We, lds + c.dbj2, j.T, lds + c.tg, lds + c.dte);
+        if (tid < j.T) dtemb[(size_t)jet * j.T + tid] = lds[c.dte + tid];
+    }
     // this jet's part of dWx_l1[f][o] = sum_p y[p][f] * da1s[p][o]   (K-major [F][H]) -> rec.dWx
     for (int f0 = 0; f0 < j.F; f0 += 4) {
         f32x4 acc[4];

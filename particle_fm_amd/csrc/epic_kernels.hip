@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NT, 2) void epic_forward_kernel(const float* __rest
 template <int MODE, bool TB, int NSEG = 1>
 static __device__ __forceinline__ void sampler_eval(const float* __restrict__ blob, int64_t desc_off, int n_rows,
                                                       float t, float hs, int stage, const float* __restrict__ tb,
-                                                      const Segs* sg = nullptr) {
+                                                      const Segs* sg = nullptr, const float* __restrict__ temb_row = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
@@ -106,7 +106,8 @@ static __device__ __forceinline__ void sampler_eval(const float* __restrict__ bl
     float* xs = lds + c.xs;
     float* yin = lds + c.yin;
     const int F = j.F;
-    epic_time_embedding(d, j, blob, lds, c, t, NSEG == 2);
+    if (temb_row) epic_time_embedding_from(j, lds, c, temb_row, NSEG == 2);
+    else epic_time_embedding(d, j, blob, lds, c, t, NSEG == 2);
     __syncthreads();
     epic_body<false, MODE, TB, NSEG>(d, j, blob, lds, c, n_rows, nullptr, sl, tb, sg);
     epic_head<MODE, NSEG>(d, j, blob, lds, c, n_rows, [=](int p, int f, float val) {
@@ -207,7 +208,8 @@ template <int MODE, bool TB>
 __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
     const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ t_eval,
     const float* __restrict__ dt, int n_intervals, const float* __restrict__ z, const float* __restrict__ cond,
-    const float* __restrict__ mask, float* __restrict__ x_out, const float* __restrict__ table, const int* __restrict__ pack) {
+    const float* __restrict__ mask, float* __restrict__ x_out, const float* __restrict__ table, const int* __restrict__ pack,
+    const float* __restrict__ temb_tab) {  // temb_tab (or NULL): [2 n_intervals][T] embedding of every evaluation time, from the caller
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d0);
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
             const int stage = e & 1;
             const float h = dt[e >> 1];
             const float hs = stage ? h : __fmul_rn(0.5f, h);
-            sampler_eval<MODE, TB, 2>(blob, desc_off, sg.rows, t_eval[e], hs, stage, TB ? table + (size_t)e * j.layers * TB_SLOT : nullptr, &sg);
+            sampler_eval<MODE, TB, 2>(blob, desc_off, sg.rows, t_eval[e], hs, stage, TB ? table + (size_t)e * j.layers * TB_SLOT : nullptr, &sg,
+                                      temb_tab ? temb_tab + (size_t)e * j.T : nullptr);
             PFM_STAMP(30);
         }
         float* oA = x_out + (size_t)jetA * j.N * F;
@@ -263,7 +266,8 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
         const int stage = e & 1;
         const float h = dt[e >> 1];
         const float hs = stage ? h : __fmul_rn(0.5f, h);
-        sampler_eval<MODE, TB>(blob, desc_off, n_rows, t_eval[e], hs, stage, TB ? table + (size_t)e * j.layers * TB_SLOT : nullptr);
+        sampler_eval<MODE, TB>(blob, desc_off, n_rows, t_eval[e], hs, stage, TB ? table + (size_t)e * j.layers * TB_SLOT : nullptr, nullptr,
+                               temb_tab ? temb_tab + (size_t)e * j.T : nullptr);
         PFM_STAMP(30);
     }
     float* oj = x_out + (size_t)jet * j.N * j.F;
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_rk_kernel(
     const float* __restrict__ blob, int64_t desc_off, pfm_rk_tableau tab, const float* __restrict__ t_eval,
     const float* __restrict__ dt, int n_intervals, const float* __restrict__ z, const float* __restrict__ cond,
     const float* __restrict__ mask, float* __restrict__ x_out, float* __restrict__ kbuf, const float* __restrict__ rhs,
-    const int* __restrict__ order) {
+    const int* __restrict__ order, const float* __restrict__ temb_tab) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d0);
@@ -304,7 +308,8 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_rk_kernel(
         const float h = dt[e / S];
         const bool last = st == S - 1;
         const float* coef = last ? tab.b : tab.a[st + 1 < PFM_RK_MAX_STAGES ? st + 1 : 0];
-        epic_time_embedding(d0, j, blob, lds, c, t_eval[e]);
+        if (temb_tab) epic_time_embedding_from(j, lds, c, temb_tab + (size_t)e * j.T);
+        else epic_time_embedding(d0, j, blob, lds, c, t_eval[e]);
         __syncthreads();
         epic_body<false, MODE>(d0, j, blob, lds, c, n_rows, nullptr, sl);
         const float r0 = rhs ? rhs[2 * e] : 0.f, r1 = rhs ? rhs[2 * e + 1] : 1.f;
@@ -331,12 +336,15 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_rk_kernel(
 // first T rows of each block.  grid (n_evals, layers), 512 threads.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void epic_time_table_kernel(const float* __restrict__ blob, int64_t desc_off,
-                                                              const float* __restrict__ t_eval, float* __restrict__ table) {
+                                                              const float* __restrict__ t_eval, float* __restrict__ table,
+                                                              const float* __restrict__ temb_tab) {
     __shared__ float temb[MAXT];
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
     const int e = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
-    if (tid < j.T) {  // the op order of epic_time_embedding
+    if (temb_tab) {
+        if (tid < j.T) temb[tid] = temb_tab[(size_t)e * j.T + tid];
+    } else if (tid < j.T) {  // the op order of epic_time_embedding
         const float t = t_eval[e], f = blob[d.freqs + tid];
         float v;
         if (d.flags & PFM_F_TEMB_SINCOS) {
@@ -534,9 +542,9 @@ static const int* queue_jet_order(const pfm_epic_desc* d, float* scratch, int64_
     return order;
 }
 
-int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const float* t_eval, const float* dt,
-                             int32_t n_intervals, const float* z, const float* cond, const float* mask,
-                             float* x_out, int32_t B, float* scratch, void* stream) {
+static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const float* t_eval, const float* dt,
+                           int32_t n_intervals, const float* z, const float* cond, const float* mask,
+                           float* x_out, int32_t B, float* scratch, void* stream, const float* temb_tab) {
     int lds = 0;
     const int mode = mfma_mode(d);
     // the time-term table needs whole 16-row time panels and at least one EPiC layer
@@ -553,12 +561,12 @@ int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const fl
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
     if (tb && n_intervals > 0) {
         hipLaunchKernelGGL(epic_time_table_kernel, dim3(2 * n_intervals, d->layers), dim3(NT), 0, (hipStream_t)stream, blob,
-                           d->blob_floats, t_eval, scratch);
+                           d->blob_floats, t_eval, scratch, temb_tab);
         if ((rc = check_hip(hipGetLastError(), "epic_time_table_kernel launch"))) return rc;
     }
 #define PFM_LAUNCH_SMP(M, T)                                                                                                  \
     hipLaunchKernelGGL((epic_sample_midpoint_kernel<M, T>), dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, \
-                       t_eval, dt, n_intervals, z, cond, mask, x_out, (const float*)scratch, order)
+                       t_eval, dt, n_intervals, z, cond, mask, x_out, (const float*)scratch, order, temb_tab)
     const int* order = queue_jet_pack(d, scratch, (int64_t)2 * n_intervals * d->layers * TB_SLOT, mask, B, mode, (hipStream_t)stream);
     if (tb) { if (mode == 2) PFM_LAUNCH_SMP(2, true); else if (mode == 1) PFM_LAUNCH_SMP(1, true); else PFM_LAUNCH_SMP(0, true); }
     else { if (mode == 2) PFM_LAUNCH_SMP(2, false); else if (mode == 1) PFM_LAUNCH_SMP(1, false); else PFM_LAUNCH_SMP(0, false); }
@@ -566,9 +574,23 @@ int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const fl
     return check_hip(hipGetLastError(), "epic_sample_midpoint_kernel launch");
 }
 
-int pfm_epic_sample_rk(const pfm_epic_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
-                       int32_t n_intervals, const float* z, const float* cond, const float* mask, float* x_out, int32_t B,
-                       float* kbuf, const float* rhs, void* stream) {
+int pfm_epic_sample_midpoint(const pfm_epic_desc* d, const float* blob, const float* t_eval, const float* dt,
+                             int32_t n_intervals, const float* z, const float* cond, const float* mask,
+                             float* x_out, int32_t B, float* scratch, void* stream) {
+    return sample_midpoint(d, blob, t_eval, dt, n_intervals, z, cond, mask, x_out, B, scratch, stream, nullptr);
+}
+
+int pfm_epic_sample_midpoint_temb(const pfm_epic_desc* d, const float* blob, const float* temb_tab, const float* dt,
+                                  int32_t n_intervals, const float* z, const float* cond, const float* mask,
+                                  float* x_out, int32_t B, float* scratch, void* stream) {
+    if (!temb_tab) return set_err(PFM_E_BADARG, "temb_tab is NULL");
+    return sample_midpoint(d, blob, temb_tab /* stands in for t_eval: never read */, dt, n_intervals, z, cond, mask, x_out, B, scratch,
+                           stream, temb_tab);
+}
+
+static int sample_rk(const pfm_epic_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
+                     int32_t n_intervals, const float* z, const float* cond, const float* mask, float* x_out, int32_t B,
+                     float* kbuf, const float* rhs, void* stream, const float* temb_tab) {
     int lds = 0;
     const int mode = mfma_mode(d);
     int rc = mode == 2 ? prepare(epic_sample_rk_kernel<2>, d, &lds)
@@ -581,11 +603,24 @@ int pfm_epic_sample_rk(const pfm_epic_desc* d, const float* blob, const pfm_rk_t
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
 #define PFM_LAUNCH_RK(M)                                                                                                    \
     hipLaunchKernelGGL(epic_sample_rk_kernel<M>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, *tab, \
-                       t_eval, dt, n_intervals, z, cond, mask, x_out, kbuf, rhs, order)
+                       t_eval, dt, n_intervals, z, cond, mask, x_out, kbuf, rhs, order, temb_tab)
     const int* order = queue_jet_order(d, kbuf, (int64_t)B * tab->stages * d->n_points * d->features, mask, B, (hipStream_t)stream);
     if (mode == 2) PFM_LAUNCH_RK(2); else if (mode == 1) PFM_LAUNCH_RK(1); else PFM_LAUNCH_RK(0);
 #undef PFM_LAUNCH_RK
     return check_hip(hipGetLastError(), "epic_sample_rk_kernel launch");
+}
+
+int pfm_epic_sample_rk(const pfm_epic_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
+                       int32_t n_intervals, const float* z, const float* cond, const float* mask, float* x_out, int32_t B,
+                       float* kbuf, const float* rhs, void* stream) {
+    return sample_rk(d, blob, tab, t_eval, dt, n_intervals, z, cond, mask, x_out, B, kbuf, rhs, stream, nullptr);
+}
+
+int pfm_epic_sample_rk_temb(const pfm_epic_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* temb_tab, const float* dt,
+                            int32_t n_intervals, const float* z, const float* cond, const float* mask, float* x_out, int32_t B,
+                            float* kbuf, void* stream) {
+    if (!temb_tab) return set_err(PFM_E_BADARG, "temb_tab is NULL");
+    return sample_rk(d, blob, tab, temb_tab, dt, n_intervals, z, cond, mask, x_out, B, kbuf, nullptr, stream, temb_tab);
 }
 
 }  // extern "C"

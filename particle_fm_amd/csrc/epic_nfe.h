@@ -1027,6 +1027,22 @@ __device__ __forceinline__ int epic_jet_setup(const pfm_epic_desc& d, const JetD
     return n_rows;
 }
 
+// vin.temb = a row of a caller-supplied embedding (t_emb="gaussian": computed by the caller's trainable embedding network)
+__device__ __forceinline__ void epic_time_embedding_from(const JetDims& j, float* __restrict__ lds, const Carve& c,
+                                                         const float* __restrict__ row, bool second_jet = false) {
+    const int tid = threadIdx.x;
+    if (tid < j.T) {
+        const float e = row[tid];
+        lds[c.vin + tid] = e;
+        lds[c.vin2 + tid] = e;
+        if (second_jet) {
+            const SegView v1 = seg_view(c, j.N, 1);
+            lds[v1.vin + tid] = e;
+            lds[v1.vin2 + tid] = e;
+        }
+    }
+}
+
 // vin.temb[k] = cos(((t + 0) * freqs[k]) * pi / 1)  -- exact fp32 op order of time_emb.py:96
 __device__ __forceinline__ void epic_time_embedding(const pfm_epic_desc& d, const JetDims& j,
                                                     const float* __restrict__ blob, float* __restrict__ lds,

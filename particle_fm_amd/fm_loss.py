@@ -44,9 +44,10 @@ def pack_blob_from_source(layout: EpicLayout, src: torch.Tensor) -> torch.Tensor
 
 class EpicFMLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, layout, x, t, z, eps, cond, mask, sigma, kind):
+    def forward(ctx, src, layout, x, t, z, eps, cond, mask, sigma, kind, temb=None):
         blob = pack_blob_from_source(layout, src)
-        parts, count, saved = hip_ops.epic_fm_loss_forward(layout, blob, x, t, z, cond, mask, sigma, kind, eps)
+        parts, count, saved = hip_ops.epic_fm_loss_forward(layout, blob, x, t, z, cond, mask, sigma, kind, eps, temb=temb)
+        ctx.has_temb = temb is not None
         total = count.sum()
         loss = parts.sum() / total  # losses.py:75-76 / :130
         ctx.layout = layout
@@ -72,23 +73,32 @@ class EpicFMLossFn(torch.autograd.Function):
         cond = None if cond is None else cond.to(torch.float32).contiguous()
         maskf = None if mask is None else mask.reshape(B, -1).to(torch.float32).contiguous()
         P = hip_ops._ptr
-        rc = lib.pfm_epic_fm_loss_backward(ctypes.byref(layout.desc), P(blob), P(None), P(cond), P(maskf), P(saved),
-                                           P(inv_total), P(gscale), P(gblob), B, P(hip_ops.epic_backward_scratch(layout, B, dev)),
-                                           hip_ops._stream_ptr(dev))
-        _lib.check(rc, "pfm_epic_fm_loss_backward")
+        d_temb = None
+        if ctx.has_temb:  # the caller's embedding network trains too: d loss / d temb comes back with the weight gradient
+            d_temb = torch.empty(B, layout.cfg.t_dim, device=dev, dtype=torch.float32)
+            rc = lib.pfm_epic_fm_loss_backward_temb(ctypes.byref(layout.desc), P(blob), P(cond), P(maskf), P(saved), P(inv_total),
+                                                    P(gscale), P(gblob), P(d_temb), B,
+                                                    P(hip_ops.epic_backward_scratch(layout, B, dev)), hip_ops._stream_ptr(dev))
+            _lib.check(rc, "pfm_epic_fm_loss_backward_temb")
+        else:
+            rc = lib.pfm_epic_fm_loss_backward(ctypes.byref(layout.desc), P(blob), P(None), P(cond), P(maskf), P(saved),
+                                               P(inv_total), P(gscale), P(gblob), B, P(hip_ops.epic_backward_scratch(layout, B, dev)),
+                                               hip_ops._stream_ptr(dev))
+            _lib.check(rc, "pfm_epic_fm_loss_backward")
         _, gpos, _ = _Maps.get(layout, dev)
         # every weight / bias has exactly one gradient slot in the blob (layout.src_gpos): a plain gather;
         # freqs and the zero pad get no gradient
         d_src = torch.zeros(ctx.n_source, device=dev, dtype=torch.float32)
         d_src[: gpos.numel()] = gblob[gpos]
-        return d_src, None, None, None, None, None, None, None, None, None
+        return d_src, None, None, None, None, None, None, None, None, None, d_temb
 
 
 def epic_fm_loss(layout: EpicLayout, src: torch.Tensor, x: torch.Tensor, t: torch.Tensor, z: torch.Tensor,
                  cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None, sigma: float = 1e-4,
-                 kind: str = "FM-OT", eps: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """loss = sum((v - u)^2) / sum(mask) with v = EPiC(t, y); differentiable w.r.t. ``src``."""
-    return EpicFMLossFn.apply(src, layout, x, t, z, eps, cond, mask, float(sigma), kind)
+                 kind: str = "FM-OT", eps: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """loss = sum((v - u)^2) / sum(mask) with v = EPiC(t, y); differentiable w.r.t. ``src`` and, if given, the caller-supplied
+    time embedding ``temb`` (B,T)."""
+    return EpicFMLossFn.apply(src, layout, x, t, z, eps, cond, mask, float(sigma), kind, temb)
 
 
 class EpicDiffusionLossFn(torch.autograd.Function):

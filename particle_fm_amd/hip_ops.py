@@ -177,7 +177,7 @@ def _rk_grid_host(ode_steps: int, solver: str, t0: float = 1.0, t1: float = 0.0)
 
 def epic_sample_rk(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor, cond: Optional[torch.Tensor] = None,
                    mask: Optional[torch.Tensor] = None, ode_steps: int = 100, solver: str = "rk4", t0: float = 1.0,
-                   t1: float = 0.0, diff_config=None) -> torch.Tensor:
+                   t1: float = 0.0, diff_config=None, temb_fn=None) -> torch.Tensor:
     """x(t1) from x(t0) = z*mask with the fixed-step explicit Runge-Kutta scheme ``solver`` over linspace(t0, t1, ode_steps),
     one persistent launch.  ``diff_config`` (loss_type="diffusion"): integrate the probability-flow ODE
     -0.5 beta (x - f / noise_rate) of a noise-predicting network instead (ode_wrapper.forward, flow_matching_module.py:62-69)."""
@@ -194,6 +194,14 @@ def epic_sample_rk(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor, cond
     if diff_config is not None:
         _, nr, beta = diffusion_schedule(ts, **diff_config)
         rhs = torch.stack([-0.5 * beta, nr], dim=1).contiguous()
+    if temb_fn is not None:  # caller-supplied embedding of the stage times (t_emb="gaussian")
+        if rhs is not None:
+            raise NotImplementedError("a caller-supplied time embedding with the diffusion right-hand side")
+        tt = _dev_f32("temb_tab", temb_fn(ts), dev, (ts.numel(), layout.cfg.t_dim))
+        rc = lib.pfm_epic_sample_rk_temb(ctypes.byref(layout.desc), _ptr(blob), ctypes.byref(tab), _ptr(tt), _ptr(dts), ode_steps - 1,
+                                         _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, _ptr(kbuf), _stream_ptr(dev))
+        _lib.check(rc, "pfm_epic_sample_rk_temb")
+        return out
     rc = lib.pfm_epic_sample_rk(ctypes.byref(layout.desc), _ptr(blob), ctypes.byref(tab), _ptr(ts), _ptr(dts), ode_steps - 1,
                                 _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, _ptr(kbuf), _ptr(rhs), _stream_ptr(dev))
     _lib.check(rc, "pfm_epic_sample_rk")
@@ -202,7 +210,8 @@ def epic_sample_rk(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor, cond
 
 def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor,
                          cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-                         ode_steps: int = 100, premask: bool = True, time_table: bool = True) -> torch.Tensor:
+                         ode_steps: int = 100, premask: bool = True, time_table: bool = True,
+                         temb_tab: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x(0) from x(1) = z*mask by ode_steps-1 explicit-midpoint intervals, one persistent launch.
     The kernel multiplies the start state by the mask (SetFlowMatchingLitModule.sample does, :668-671);
     ``premask`` is informational: masking twice is idempotent for a 0/1 mask."""
@@ -220,6 +229,13 @@ def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor
             del cache[k]
         cache[key] = torch.empty(max(1, lib.pfm_epic_sample_scratch_floats(ctypes.byref(layout.desc), ode_steps - 1, B)), device=dev,
                                  dtype=torch.float32)
+    if temb_tab is not None:  # (2 (ode_steps - 1), T): the caller's embedding of every evaluation time of midpoint_grid
+        temb_tab = _dev_f32("temb_tab", temb_tab, dev, (2 * (ode_steps - 1), layout.cfg.t_dim))
+        rc = lib.pfm_epic_sample_midpoint_temb(ctypes.byref(layout.desc), _ptr(blob), _ptr(temb_tab), _ptr(dts), ode_steps - 1,
+                                               _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B,
+                                               _ptr(cache[key] if time_table else None), _stream_ptr(dev))
+        _lib.check(rc, "pfm_epic_sample_midpoint_temb")
+        return out
     rc = lib.pfm_epic_sample_midpoint(ctypes.byref(layout.desc), _ptr(blob), _ptr(ts), _ptr(dts), ode_steps - 1,
                                       _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B,
                                       _ptr(cache[key] if time_table else None), _stream_ptr(dev))
@@ -229,8 +245,10 @@ def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor
 
 def epic_fm_loss_forward(layout: EpicLayout, blob: torch.Tensor, x: torch.Tensor, t: torch.Tensor, z: torch.Tensor,
                          cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-                         sigma: float = 1e-4, kind: str = "FM-OT", eps: Optional[torch.Tensor] = None):
-    """Flow-matching loss forward with the draws (t, z[, eps]) given.
+                         sigma: float = 1e-4, kind: str = "FM-OT", eps: Optional[torch.Tensor] = None,
+                         temb: Optional[torch.Tensor] = None):
+    """Flow-matching loss forward with the draws (t, z[, eps]) given; ``temb`` (B,T): the time embedding supplied by the caller
+    (t_emb="gaussian") instead of the in-kernel cosine / sincos one.
     Returns (loss_parts (B,), mask_count (B,), saved (B, floats_per_jet))."""
     lib = _lib.load()
     dev, B, blob, x, cond, mask = _prep_common(layout, blob, x, cond, mask)
@@ -249,6 +267,13 @@ def epic_fm_loss_forward(layout: EpicLayout, blob: torch.Tensor, x: torch.Tensor
     saved = torch.empty(B, per_jet, device=dev, dtype=torch.float32)
     parts = torch.empty(B, device=dev, dtype=torch.float32)
     count = torch.empty(B, device=dev, dtype=torch.float32)
+    if temb is not None:
+        temb = _dev_f32("temb", temb, dev, (B, layout.cfg.t_dim))
+        rc = lib.pfm_epic_fm_loss_forward_temb(ctypes.byref(layout.desc), _ptr(blob), kinds[kind], float(sigma), _ptr(t), _ptr(temb),
+                                               _ptr(x), _ptr(z), _ptr(eps), _ptr(cond), _ptr(mask), _ptr(saved), _ptr(parts),
+                                               _ptr(count), B, _stream_ptr(dev))
+        _lib.check(rc, "pfm_epic_fm_loss_forward_temb")
+        return parts, count, saved
     rc = lib.pfm_epic_fm_loss_forward(ctypes.byref(layout.desc), _ptr(blob), kinds[kind], float(sigma), _ptr(t),
                                       _ptr(x), _ptr(z), _ptr(eps), _ptr(cond), _ptr(mask), _ptr(saved), _ptr(parts),
                                       _ptr(count), B, _stream_ptr(dev))

@@ -9,6 +9,21 @@ from __future__ import annotations
 import math
 
 import torch
+import torch.nn as nn
+
+
+class GaussianFourierProjection(nn.Module):
+    """time_emb.py:9-22: Gaussian random features of the time, [sin(2 pi W t) ; cos(2 pi W t)], W a frozen parameter drawn
+    N(0, scale^2) (in state_dict as ``W``).  Front of the t_emb="gaussian" embedding network of CNF (flow_matching_module.py:178-181):
+    a per-jet vector of hidden_dim numbers, O(B * hidden) work -- host-side torch ops on the device, not a kernel."""
+
+    def __init__(self, embed_dim, scale=30.0):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(embed_dim // 2) * scale, requires_grad=False)
+
+    def forward(self, x):
+        x_proj = x[..., None] * self.W[None, ...] * 2 * math.pi
+        return torch.cat([torch.sin(x_proj), torch.cos(x_proj)], dim=-1)
 
 
 def exp_frequencies(outp_dim: int) -> torch.Tensor:

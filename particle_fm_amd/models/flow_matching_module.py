@@ -26,7 +26,7 @@ from .components.droid_transformer import FullCrossAttentionEncoder, FullTransfo
 from .components.epic import EPiC_encoder
 from .components.norm_layer import IterativeNormLayer
 from .components.losses import ConditionalFlowMatchingLoss, DiffusionLoss, DroidLoss, FlowMatchingLoss
-from .components.time_emb import CosineEncoding
+from .components.time_emb import CosineEncoding, GaussianFourierProjection
 
 try:  # Lightning is optional: present in the reference's environment, absent in the build container
     import pytorch_lightning as pl
@@ -150,7 +150,13 @@ class CNF(nn.Module):
         elif t_emb == "sincos":
             self.embed = None  # frequencies * t -> cat(cos, sin), in-kernel (flow_matching_module.py:208-211)
         elif t_emb == "gaussian":
-            raise NotImplementedError("t_emb=gaussian has no HIP path in this build ('cosine' and 'sincos' do).")
+            # flow_matching_module.py:178-181: random Fourier features -> Linear -> activation -> Linear(2 frequencies), trainable.
+            # O(B * hidden) per call: host-side torch ops on the device; its output (B, T) goes to the kernels as the time
+            # embedding (pfm_epic_*_temb) and the loss backward returns d loss / d temb, so the four tensors train exactly.
+            if model != "epic":
+                raise NotImplementedError("t_emb='gaussian' has a HIP path for model='epic' only")
+            self.embed = nn.Sequential(GaussianFourierProjection(embed_dim=hidden_dim), nn.Linear(hidden_dim, hidden_dim))
+            self.linear = nn.Linear(hidden_dim, 2 * frequencies)
         else:
             raise NotImplementedError(f"t_emb={t_emb} not implemented")  # :231
 
@@ -167,7 +173,23 @@ class CNF(nn.Module):
             raise ValueError(f"t has shape {tuple(t.shape)}; expected (), (B,) or (B,N) with B={x.shape[0]}")
         return t.to(x.device, torch.float32)
 
+    def _gaussian_temb(self, t: Tensor) -> Tensor:
+        """(..., ) times -> (..., T) embedding rows (flow_matching_module.py:213-221 without the expand over particles)."""
+        e = self.embed(t)
+        e = getattr(torch.nn.functional, self.activation, lambda v: v)(e)
+        return self.linear(e)
+
+    def _check_gaussian_path(self, n_points: int):
+        if self.net.is_wide(n_points):
+            raise NotImplementedError("t_emb='gaussian' has a HIP path for model='epic' at hidden_dim 128 with sets that fit the "
+                                      "LDS tile only (the row-matrix path embeds the time in-kernel)")
+
     def time_embedding(self, t: Tensor, x: Tensor, t_emb: str = "cosine") -> Tensor:
+        if t_emb == "gaussian":  # :213-221
+            if t.dim() == 2:
+                t = t[:, 0]
+            e = self._gaussian_temb(t if t.dim() else t.unsqueeze(0))
+            return e.unsqueeze(1).expand(*x.shape[:-1], -1)
         if t_emb == "sincos":  # :208-211
             a = self.frequencies * t[..., None]
             return torch.cat((a.cos(), a.sin()), dim=-1).expand(*x.shape[:-1], -1)
@@ -180,6 +202,10 @@ class CNF(nn.Module):
     # -- reference surface -------------------------------------------------------------------------
     def forward(self, t: Tensor, x: Tensor, cond: Tensor = None, mask: Tensor = None) -> Tensor:
         """v = f(t, x) (flow_matching_module.py:191-204); one HIP launch, embedding included."""
+        if self.t_emb == "gaussian":
+            self._check_gaussian_path(x.shape[1])
+            temb = self._gaussian_temb(self._per_jet_time(t, x))  # (B, T)
+            return self.net.forward(temb, x, cond, mask)
         return self.net.vector_field(self._per_jet_time(t, x), x, cond, mask)
 
     def fm_loss(self, x, t, z, mask=None, cond=None, sigma: float = 1e-4, kind: str = "FM-OT", eps=None) -> Tensor:
@@ -192,6 +218,10 @@ class CNF(nn.Module):
             return _fm_loss_ca.ca_fm_loss(lay, self.net.flat_parameters(lay), x, t, z, cond=cond, mask=mask, sigma=sigma,
                                           kind=kind, eps=eps, freqs=self.net.freq_tensor())
         src = self.net.source_vector(lay)
+        if self.t_emb == "gaussian":
+            self._check_gaussian_path(x.shape[1])
+            return _fm_loss.epic_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps,
+                                         temb=self._gaussian_temb(t.to(x.device, torch.float32)))
         if self.net.is_wide(x.shape[1]):
             return _fm_loss_wide.epic_wide_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps)
         return _fm_loss.epic_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps)
@@ -212,6 +242,13 @@ class CNF(nn.Module):
             if self.is_cross_attention:
                 return hip_ops_ca.ca_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
                                                      ode_steps=ode_steps, premask=False)
+            if self.t_emb == "gaussian":
+                self._check_gaussian_path(z.shape[1])
+                ts, _ = hip_ops.midpoint_grid(ode_steps, z.device)
+                with torch.no_grad():
+                    tab = self._gaussian_temb(ts)  # (2 (ode_steps - 1), T): every jet is evaluated at the same times
+                return hip_ops.epic_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask, ode_steps=ode_steps,
+                                                    premask=False, temb_tab=tab)
             if self.net.is_wide(z.shape[1]):
                 return hip_ops_wide.ew_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
                                                        ode_steps=ode_steps, premask=False)
@@ -276,6 +313,11 @@ class CNF(nn.Module):
             return hip_ops_ca.ca_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
         if self.net.is_wide(z.shape[1]):
             return hip_ops_wide.ew_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
+        if self.t_emb == "gaussian":
+            def temb_fn(ts):
+                with torch.no_grad():
+                    return self._gaussian_temb(ts.to(z.device))
+            return hip_ops.epic_sample_rk(lay, blob, z, cond, mask, temb_fn=temb_fn, **kw)
         return hip_ops.epic_sample_rk(lay, blob, z, cond, mask, **kw)
 
     def encode(self, x: Tensor, mask: Tensor = None, ode_solver: str = "dopri5_zuko", ode_steps: int = 100) -> Tensor:
