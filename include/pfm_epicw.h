@@ -80,6 +80,22 @@ int pfm_ew_fm_loss_backward(const pfm_ew_desc *desc, const float *blob, const fl
                             const float *u, const float *v, const float *gscale, float *gblob, int32_t n_jets,
                             float *workspace, float *scratch, void *stream);
 
+/* loss_type="diffusion" on this path (DiffusionLoss, models/components/losses.py:207-290; see pfm_epic_diffusion_loss_* in pfm_hip.h):
+ * noisy = rates[b][0] x + rates[b][1] z, the field predicts z; loss_sums[0] = sum_b jet_weight[b] sum_n,f criterion(v - z),
+ * loss_sums[1] = sum mask; criterion 0 = mse, 1 = huber (delta 1).  The backward is that of loss_sums[0] * gscale. */
+int pfm_ew_diffusion_loss_forward(const pfm_ew_desc *desc, const float *blob, int32_t criterion, const float *rates,
+                                  const float *jet_weight, const float *t, const float *x, const float *z, const float *cond,
+                                  const float *mask, float *y_out, float *u_out, float *v_out, float *loss_sums,
+                                  int32_t n_jets, float *workspace, void *stream);
+int pfm_ew_diffusion_loss_backward(const pfm_ew_desc *desc, const float *blob, int32_t criterion, const float *jet_weight,
+                                   const float *mask, const float *y, const float *u, const float *v, const float *gscale,
+                                   float *gblob, int32_t n_jets, float *workspace, float *scratch, void *stream);
+/* pfm_ew_sample_rk on the probability-flow ODE of a noise-predicting network: rhs[n_steps * stages][2] = (-0.5 beta, noise_rate) at
+ * every stage time, the right-hand side is rhs0 (x - f(t, x) / rhs1) (ode_wrapper.forward, flow_matching_module.py:62-69). */
+int pfm_ew_sample_rk_rhs(const pfm_ew_desc *desc, const float *blob, const pfm_rk_tableau *tab, const float *t_eval,
+                         const float *dt, int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
+                         int32_t n_jets, int32_t premask, float *state, float *workspace, const float *rhs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

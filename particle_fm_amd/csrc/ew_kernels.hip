@@ -327,20 +327,31 @@ __global__ __launch_bounds__(256) void ew_actbwd_kernel(const float* __restrict_
     out[r * ldo + c] = v;
 }
 
-// dpre[row][0..16) = 2 (v - u) gscale * mask * lrelu'(v)   (v = lrelu(pre) * mask: same sign as pre on valid rows)
+// dpre[row][0..16) = crit'(v - u) w_jet gscale * mask * lrelu'(v)   (v = lrelu(pre) * mask: same sign as pre on valid rows)
+// crit 0: 2 (v - u); 1 (huber, delta 1): clamp(v - u, -1, 1); jet_w (or NULL = 1): per-jet loss weight, N = rows per jet
 __global__ __launch_bounds__(256) void ew_head_bwd_kernel(const float* __restrict__ v, const float* __restrict__ u,
                                                           const float* __restrict__ mask, const float* __restrict__ gscale,
-                                                          float* __restrict__ dpre, int64_t M, int F, float slope) {
+                                                          float* __restrict__ dpre, int64_t M, int F, float slope, int crit,
+                                                          const float* __restrict__ jet_w, int N) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M * 16) return;
     const int64_t row = i >> 4;
     const int f = (int)(i & 15);
     float d = 0.f;
     if (f < F) {
-        const float vv = v[row * F + f];
-        d = 2.0f * (vv - u[row * F + f]) * gscale[0] * (mask ? mask[row] : 1.0f) * (vv > 0.f ? 1.f : slope);
+        const float vv = v[row * F + f], df = vv - u[row * F + f];
+        const float dl = crit ? fminf(fmaxf(df, -1.0f), 1.0f) : 2.0f * df;
+        d = dl * (jet_w ? jet_w[row / N] : 1.0f) * gscale[0] * (mask ? mask[row] : 1.0f) * (vv > 0.f ? 1.f : slope);
     }
     dpre[i] = d;
+}
+
+// K <- r0 * (x - K / r1): the probability-flow right-hand side of a noise-predicting network, -0.5 beta (x - eps_theta / noise_rate)
+// (ode_wrapper.forward for loss_type="diffusion", flow_matching_module.py:62-69); rhs = (-0.5 beta, noise_rate) of this stage time
+__global__ __launch_bounds__(256) void ew_diffusion_rhs_kernel(float* __restrict__ K, const float* __restrict__ x,
+                                                               const float* __restrict__ rhs, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) K[i] = __fmul_rn(rhs[0], __fsub_rn(x[i], __fdiv_rn(K[i], rhs[1])));
 }
 
 // dX[row][c] += mask[row] * ( dmean[jet][c] / n_jet + dsum[jet][c] * scale )
@@ -430,7 +441,8 @@ struct Bwd {
     }
 };
 
-int run_backward(const Bwd& W, const float* mask, const float* y, const float* u, const float* v, const float* gscale) {
+int run_backward(const Bwd& W, const float* mask, const float* y, const float* u, const float* v, const float* gscale,
+                 int crit = 0, const float* jet_w = nullptr) {
     const Plan& p = W.p;
     const pfm_ew_desc& d = *p.d;
     const Ws& w = p.w;
@@ -451,7 +463,7 @@ int run_backward(const Bwd& W, const float* mask, const float* y, const float* u
     PFM_TRY(check_hip(hipMemsetAsync(dG, 0, (size_t)B * 128 * sizeof(float), p.s), "memset dG"));
     // ---- head: v = lrelu(W3 X_L + jb3) mask ----
     hipLaunchKernelGGL(ew_head_bwd_kernel, dim3((unsigned)(((int64_t)M * 16 + 255) / 256)), dim3(256), 0, p.s, v, u, mask, gscale, dpre,
-                       (int64_t)M, F, d.neg_slope);
+                       (int64_t)M, F, d.neg_slope, crit, jet_w, N);
     PFM_TRY(check_hip(hipGetLastError(), "ew_head_bwd_kernel launch"));
     const float* XL = Xst(d.layers);
     PFM_TRY(W.colsum(XL, Hp, Hp, M, N, dpre, F, nullptr, 0, d.l3));                       // d W3[f][k]
@@ -628,9 +640,9 @@ int pfm_ew_sample_midpoint(const pfm_ew_desc* d, const float* blob, const float*
     return 0;
 }
 
-int pfm_ew_sample_rk(const pfm_ew_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
-                     int32_t n_steps, const float* z, const float* cond, const float* mask, float* x_out, int32_t n_jets,
-                     int32_t premask, float* state, float* workspace, void* stream) {
+static int ew_sample_rk(const pfm_ew_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
+                        int32_t n_steps, const float* z, const float* cond, const float* mask, float* x_out, int32_t n_jets,
+                        int32_t premask, float* state, float* workspace, void* stream, const float* rhs) {
     ew::Plan p;
     int rc = ew::make_plan(p, d, blob, workspace, n_jets, false, stream);
     if (rc) return rc;
@@ -647,25 +659,42 @@ int pfm_ew_sample_rk(const pfm_ew_desc* d, const float* blob, const pfm_rk_table
     rc = sample_rk_rows(*tab, t_eval, dt, n_steps, state, n, p.s, [&](const float* t, const float* x, float* v) {
         ew::HeadArgs h{};
         h.dst = v;
-        return ew::run_nfe(p, t, 0, x, cond, mask, h);
+        int r = ew::run_nfe(p, t, 0, x, cond, mask, h);
+        if (r || !rhs) return r;
+        hipLaunchKernelGGL(ew::ew_diffusion_rhs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, v, x,
+                           rhs + 2 * (t - t_eval), n);
+        return check_hip(hipGetLastError(), "ew_diffusion_rhs_kernel launch");
     });
     if (rc) return rc;
     if ((rc = check_hip(hipGetLastError(), "tf_rk_combine_kernel launch"))) return rc;
     return check_hip(hipMemcpyAsync(x_out, state, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_out");
 }
 
-int pfm_ew_fm_loss_forward(const pfm_ew_desc* d, const float* blob, int32_t kind, float sigma, const float* t,
+int pfm_ew_sample_rk(const pfm_ew_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
+                     int32_t n_steps, const float* z, const float* cond, const float* mask, float* x_out, int32_t n_jets,
+                     int32_t premask, float* state, float* workspace, void* stream) {
+    return ew_sample_rk(d, blob, tab, t_eval, dt, n_steps, z, cond, mask, x_out, n_jets, premask, state, workspace, stream, nullptr);
+}
+
+int pfm_ew_sample_rk_rhs(const pfm_ew_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
+                         int32_t n_steps, const float* z, const float* cond, const float* mask, float* x_out, int32_t n_jets,
+                         int32_t premask, float* state, float* workspace, const float* rhs, void* stream) {
+    if (!rhs) return set_err(PFM_E_BADARG, "rhs is NULL");
+    return ew_sample_rk(d, blob, tab, t_eval, dt, n_steps, z, cond, mask, x_out, n_jets, premask, state, workspace, stream, rhs);
+}
+
+static int ew_loss_forward(const pfm_ew_desc* d, const float* blob, int32_t kind, float sigma, const float* t,
                            const float* x, const float* a, const float* b, const float* cond, const float* mask,
                            float* y_out, float* u_out, float* v_out, float* loss_sums, int32_t n_jets,
-                           float* workspace, void* stream) {
+                           float* workspace, void* stream, int crit, const float* jet_w) {
     ew::Plan p;
     int rc = ew::make_plan(p, d, blob, workspace, n_jets, true, stream);
     if (rc) return rc;
     if (n_jets <= 0) return 0;
-    if (kind < 0 || kind > 2) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT), 1 (CFM) or 2 (droid)");
+    if (kind < 0 || kind > 3) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT), 1 (CFM), 2 (droid) or 3 (diffusion)");
     if (!blob || !t || !x || !a || !y_out || !u_out || !v_out || !loss_sums || !workspace)
         return set_err(PFM_E_BADARG, "NULL device pointer");
-    if (kind == 1 && !b) return set_err(PFM_E_BADARG, "CFM needs eps");
+    if ((kind == 1 || kind == 3) && !b) return set_err(PFM_E_BADARG, "CFM needs eps (diffusion: the rates)");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
     const int64_t n = (int64_t)p.M * d->features;
     hipLaunchKernelGGL(tf_yu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, kind, sigma, t, x, a, b, mask, y_out,
@@ -675,8 +704,27 @@ int pfm_ew_fm_loss_forward(const pfm_ew_desc* d, const float* blob, int32_t kind
     h.dst = v_out;
     if ((rc = ew::run_nfe(p, t, 1, y_out, cond, mask, h))) return rc;
     hipLaunchKernelGGL(tf_loss_kernel, dim3(256), dim3(256), 0, p.s, (const float*)v_out, (const float*)u_out, mask, loss_sums, n,
-                       (int64_t)p.M);
+                       (int64_t)p.M, crit, jet_w, d->n_points * d->features);
     return check_hip(hipGetLastError(), "tf_loss_kernel launch");
+}
+
+int pfm_ew_fm_loss_forward(const pfm_ew_desc* d, const float* blob, int32_t kind, float sigma, const float* t,
+                           const float* x, const float* a, const float* b, const float* cond, const float* mask,
+                           float* y_out, float* u_out, float* v_out, float* loss_sums, int32_t n_jets,
+                           float* workspace, void* stream) {
+    if (kind < 0 || kind > 2) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT), 1 (CFM) or 2 (droid)");
+    return ew_loss_forward(d, blob, kind, sigma, t, x, a, b, cond, mask, y_out, u_out, v_out, loss_sums, n_jets, workspace, stream, 0,
+                           nullptr);
+}
+
+int pfm_ew_diffusion_loss_forward(const pfm_ew_desc* d, const float* blob, int32_t criterion, const float* rates,
+                                  const float* jet_weight, const float* t, const float* x, const float* z, const float* cond,
+                                  const float* mask, float* y_out, float* u_out, float* v_out, float* loss_sums,
+                                  int32_t n_jets, float* workspace, void* stream) {
+    if (criterion < 0 || criterion > 1) return set_err(PFM_E_BADARG, "criterion must be 0 (mse) or 1 (huber)");
+    if (!rates || !jet_weight) return set_err(PFM_E_BADARG, "the diffusion loss needs the signal / noise rates and the jet weights");
+    return ew_loss_forward(d, blob, 3, 0.f, t, x, z, rates, cond, mask, y_out, u_out, v_out, loss_sums, n_jets, workspace, stream,
+                           criterion, jet_weight);
 }
 
 int64_t pfm_ew_backward_scratch_floats(const pfm_ew_desc* d, int32_t n_jets) {
@@ -684,9 +732,9 @@ int64_t pfm_ew_backward_scratch_floats(const pfm_ew_desc* d, int32_t n_jets) {
     return ew::make_bs(*d, n_jets < 1 ? 1 : n_jets).total;
 }
 
-int pfm_ew_fm_loss_backward(const pfm_ew_desc* d, const float* blob, const float* mask, const float* y, const float* u,
+static int ew_loss_backward(const pfm_ew_desc* d, const float* blob, const float* mask, const float* y, const float* u,
                             const float* v, const float* gscale, float* gblob, int32_t n_jets, float* workspace,
-                            float* scratch, void* stream) {
+                            float* scratch, void* stream, int crit, const float* jet_w) {
     ew::Bwd W;
     int rc = ew::make_plan(W.p, d, blob, workspace, n_jets, true, stream);
     if (rc) return rc;
@@ -699,7 +747,21 @@ int pfm_ew_fm_loss_backward(const pfm_ew_desc* d, const float* blob, const float
     if ((rc = check_hip(hipMemsetAsync(scratch + W.b.DSJB, 0, (size_t)n_jets * (2 * d->hidden_pad + 128) * sizeof(float),
                                        (hipStream_t)stream), "memset DSJB")))
         return rc;
-    return ew::run_backward(W, mask, y, u, v, gscale);
+    return ew::run_backward(W, mask, y, u, v, gscale, crit, jet_w);
+}
+
+int pfm_ew_fm_loss_backward(const pfm_ew_desc* d, const float* blob, const float* mask, const float* y, const float* u,
+                            const float* v, const float* gscale, float* gblob, int32_t n_jets, float* workspace,
+                            float* scratch, void* stream) {
+    return ew_loss_backward(d, blob, mask, y, u, v, gscale, gblob, n_jets, workspace, scratch, stream, 0, nullptr);
+}
+
+int pfm_ew_diffusion_loss_backward(const pfm_ew_desc* d, const float* blob, int32_t criterion, const float* jet_weight,
+                                   const float* mask, const float* y, const float* u, const float* v, const float* gscale,
+                                   float* gblob, int32_t n_jets, float* workspace, float* scratch, void* stream) {
+    if (criterion < 0 || criterion > 1) return set_err(PFM_E_BADARG, "criterion must be 0 (mse) or 1 (huber)");
+    if (!jet_weight) return set_err(PFM_E_BADARG, "jet_weight is NULL");
+    return ew_loss_backward(d, blob, mask, y, u, v, gscale, gblob, n_jets, workspace, scratch, stream, criterion, jet_weight);
 }
 
 }  // extern "C"

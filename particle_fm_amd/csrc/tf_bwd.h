@@ -40,6 +40,10 @@ static __global__ void tf_yu_kernel(int kind, float sigma, const float* __restri
     } else if (kind == 2) {  // DroidLoss, losses.py:332-336: y = x + t z, u = z mask
         y[i] = __fadd_rn(xv, __fmul_rn(tj, zv));
         u[i] = __fmul_rn(zv, m);
+    } else if (kind == 3) {  // DiffusionLoss, losses.py:260, 272: noisy = signal_rate x + noise_rate z, target = z (z arrives masked);
+        const int64_t jet = i / NF;  // b = rates[n_jets][2]
+        y[i] = __fadd_rn(__fmul_rn(b[2 * jet], xv), __fmul_rn(b[2 * jet + 1], zv));
+        u[i] = zv;
     } else {
         const float mu = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, tj), xv), __fmul_rn(tj, zv));
         y[i] = __fadd_rn(mu, __fmul_rn(sigma, b[i]));
@@ -47,15 +51,22 @@ static __global__ void tf_yu_kernel(int kind, float sigma, const float* __restri
     }
 }
 
-// sums[0] += sum (v-u)^2 ; sums[1] += sum mask
+// sums[0] += sum w_jet crit(v-u) ; sums[1] += sum mask.  crit 0: d^2, 1: huber (delta 1); jet_w (or NULL = 1): per-jet weight,
+// NF = floats per jet (DiffusionLoss, losses.py:275-288)
 static __global__ __launch_bounds__(256) void tf_loss_kernel(const float* __restrict__ v, const float* __restrict__ u,
                                                       const float* __restrict__ mask, float* __restrict__ sums,
-                                                      int64_t n, int64_t rows) {
+                                                      int64_t n, int64_t rows, int crit = 0, const float* __restrict__ jet_w = nullptr,
+                                                      int NF = 1) {
     __shared__ float red[8];
     float sq = 0.f, mc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float d = v[i] - u[i];
-        sq = fmaf(d, d, sq);
+        if (crit || jet_w) {
+            const float c = crit ? (fabsf(d) < 1.0f ? 0.5f * d * d : fabsf(d) - 0.5f) : d * d;
+            sq = fmaf(c, jet_w ? jet_w[i / NF] : 1.0f, sq);
+        } else {
+            sq = fmaf(d, d, sq);
+        }
         if (i < rows) mc += mask ? mask[i] : 1.0f;
     }
     sq = wave_sum(sq);

@@ -63,7 +63,7 @@ def ew_sample_midpoint(layout: EpicWideLayout, blob, z, cond=None, mask=None, od
     return out
 
 
-def ew_sample_rk(layout: EpicWideLayout, blob, z, cond=None, mask=None, ode_steps: int = 100, solver: str = "rk4",
+def ew_sample_rk(layout: EpicWideLayout, blob, z, cond=None, mask=None, ode_steps: int = 100, solver: str = "rk4", diff_config=None,
                  premask: bool = True, t0: float = 1.0, t1: float = 0.0) -> torch.Tensor:
     """x(t1) from x(t0) = z (*mask) with the fixed-step explicit Runge-Kutta scheme ``solver`` ("euler", "midpoint", "rk4" =
     torchdyn's 3/8 rule) over linspace(t0, t1, ode_steps); all launches queued on the current stream."""
@@ -76,6 +76,15 @@ def ew_sample_rk(layout: EpicWideLayout, blob, z, cond=None, mask=None, ode_step
     ts, dts = ts.to(dev), dts.to(dev)
     out = torch.empty_like(z)
     state = torch.empty((2 + tab.stages) * z.numel(), device=dev, dtype=torch.float32)
+    if diff_config is not None:  # loss_type="diffusion": the probability-flow ODE of a noise-predicting network
+        from .hip_ops import diffusion_schedule
+        _, nr, beta = diffusion_schedule(ts, **diff_config)
+        rhs = torch.stack([-0.5 * beta, nr], dim=1).contiguous()
+        rc = lib.pfm_ew_sample_rk_rhs(ctypes.byref(layout.desc), _ptr(blob), ctypes.byref(tab), _ptr(ts), _ptr(dts), ode_steps - 1,
+                                      _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, int(bool(premask and mask is not None)),
+                                      _ptr(state), _ptr(workspace(layout, B, dev)), _ptr(rhs), _stream_ptr(dev))
+        _lib.check(rc, "pfm_ew_sample_rk_rhs")
+        return out
     rc = lib.pfm_ew_sample_rk(ctypes.byref(layout.desc), _ptr(blob), ctypes.byref(tab), _ptr(ts), _ptr(dts), ode_steps - 1,
                               _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, int(bool(premask and mask is not None)),
                               _ptr(state), _ptr(workspace(layout, B, dev)), _stream_ptr(dev))
@@ -111,8 +120,28 @@ def ew_fm_loss_forward(layout: EpicWideLayout, blob, x, t, a, cond=None, mask=No
     return sums, (y, u, v, ws, mask)
 
 
-def ew_fm_loss_backward(layout: EpicWideLayout, blob, saved, gscale: torch.Tensor) -> torch.Tensor:
-    """Gradient blob (layout.blob_total floats); gscale: 0-dim device tensor grad_output / sum(mask)."""
+def ew_diffusion_loss_forward(layout: EpicWideLayout, blob, x, t, z, rates, jet_w, cond=None, mask=None, criterion: str = "huber"):
+    """DiffusionLoss forward with the draws given (see hip_ops.epic_diffusion_loss_forward): rates (B,2), jet_w (B,).
+    Returns (sums (2,) = [sum_b w_b sum criterion(v - z), sum mask], saved)."""
+    lib = _lib.load()
+    dev, B, blob, x, cond, mask = _prep_common(layout, blob, x, cond, mask)
+    t = _dev_f32("t", t, dev, (B,))
+    z = _dev_f32("z", z, dev, tuple(x.shape))
+    rates = _dev_f32("rates", rates, dev, (B, 2))
+    jet_w = _dev_f32("jet_w", jet_w, dev, (B,))
+    y, u, v = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    sums = torch.zeros(2, device=dev, dtype=torch.float32)
+    ws = workspace(layout, B, dev, train=True)
+    rc = lib.pfm_ew_diffusion_loss_forward(ctypes.byref(layout.desc), _ptr(blob), {"mse": 0, "huber": 1}[criterion], _ptr(rates),
+                                           _ptr(jet_w), _ptr(t), _ptr(x), _ptr(z), _ptr(cond), _ptr(mask), _ptr(y), _ptr(u),
+                                           _ptr(v), _ptr(sums), B, _ptr(ws), _stream_ptr(dev))
+    _lib.check(rc, "pfm_ew_diffusion_loss_forward")
+    return sums, (y, u, v, ws, mask)
+
+
+def ew_fm_loss_backward(layout: EpicWideLayout, blob, saved, gscale: torch.Tensor, criterion=None, jet_w=None) -> torch.Tensor:
+    """Gradient blob (layout.blob_total floats); gscale: 0-dim device tensor grad_output / sum(mask).
+    criterion / jet_w: the diffusion loss's (None: the flow-matching losses)."""
     lib = _lib.load()
     y, u, v, ws, mask = saved
     dev, B = y.device, y.shape[0]
@@ -124,6 +153,13 @@ def ew_fm_loss_backward(layout: EpicWideLayout, blob, saved, gscale: torch.Tenso
         cache[key] = torch.empty(n, device=dev, dtype=torch.float32)
     gblob = torch.zeros(layout.blob_total, device=dev, dtype=torch.float32)
     gs = gscale.to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+    if criterion is not None:
+        jw = _dev_f32("jet_w", jet_w, dev, (B,))
+        rc = lib.pfm_ew_diffusion_loss_backward(ctypes.byref(layout.desc), _ptr(blob), {"mse": 0, "huber": 1}[criterion], _ptr(jw),
+                                                _ptr(mask), _ptr(y), _ptr(u), _ptr(v), _ptr(gs), _ptr(gblob), B, _ptr(ws),
+                                                _ptr(cache[key]), _stream_ptr(dev))
+        _lib.check(rc, "pfm_ew_diffusion_loss_backward")
+        return gblob
     rc = lib.pfm_ew_fm_loss_backward(ctypes.byref(layout.desc), _ptr(blob), _ptr(mask), _ptr(y), _ptr(u), _ptr(v), _ptr(gs),
                                      _ptr(gblob), B, _ptr(ws), _ptr(cache[key]), _stream_ptr(dev))
     _lib.check(rc, "pfm_ew_fm_loss_backward")

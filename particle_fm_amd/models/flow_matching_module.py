@@ -266,13 +266,17 @@ class CNF(nn.Module):
     def _decode_diffusion(self, z, cond, mask, ode_solver, ode_steps, weights):
         """loss_type="diffusion" (:62-69, 301-325): the fixed-step ODE solvers integrate -0.5 beta (x - net / noise_rate);
         "ddim" / "em" are the samplers of models/components/solver.py (n_steps = ode_steps)."""
-        if self.is_transformer or self.is_cross_attention or self.net.is_wide(z.shape[1]):
-            raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' at hidden_dim 128 with sets that fit "
-                                      "the LDS tile (configs/model/diffusion.yaml, N <= 150) only")
+        if self.is_transformer or self.is_cross_attention or self.t_emb == "gaussian":
+            raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' (configs/model/diffusion.yaml) with the "
+                                      "cosine / sincos time embeddings only")
+        wide = self.net.is_wide(z.shape[1])
         lay = self.net.layout(z.shape[1])
         blob = weights if weights is not None else self.net.packed_weights(z.shape[1])
         dc = dict(self.diff_config)
         if ode_solver in ("midpoint", "euler", "rk4"):
+            if wide:
+                return hip_ops_wide.ew_sample_rk(lay, blob, z, cond, mask, ode_steps=ode_steps, solver=ode_solver, diff_config=dc,
+                                                 premask=False)
             return hip_ops.epic_sample_rk(lay, blob, z, cond, mask, ode_steps=ode_steps, solver=ode_solver, diff_config=dc)
         if ode_solver not in ("ddim", "em"):
             raise NotImplementedError(f"Solver {ode_solver} has no HIP path in this build for loss_type='diffusion' "
@@ -286,7 +290,7 @@ class CNF(nn.Module):
         x = z.to(torch.float32).clone()
         data = torch.empty_like(x)
         for k in range(n):
-            pred = hip_ops.epic_forward(lay, blob, times[k].expand(x.shape[0]).to(x.device), x, cond, mask)
+            pred = self.net.vector_field(times[k].expand(x.shape[0]).to(x.device), x, cond, mask, blob=blob)  # either EPiC path
             if ode_solver == "ddim":
                 hip_ops.diffusion_update_("ddim", x, pred, (nr[k], sr[k], sr[k + 1], nr[k + 1]), data_out=data)
             else:
@@ -297,10 +301,13 @@ class CNF(nn.Module):
 
     def diffusion_loss(self, x, t, z, mask=None, cond=None, criterion: str = "huber", diff_config=None) -> Tensor:
         """DiffusionLoss body (losses.py:250-288) with the draws given; z is already multiplied by the mask."""
-        if self.is_transformer or self.is_cross_attention or self.net.is_wide(x.shape[1]):
-            raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' at hidden_dim 128 with sets that fit "
-                                      "the LDS tile (configs/model/diffusion.yaml, N <= 150) only")
+        if self.is_transformer or self.is_cross_attention or self.t_emb == "gaussian":
+            raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' (configs/model/diffusion.yaml) with the "
+                                      "cosine / sincos time embeddings only")
         lay = self.net.layout(x.shape[1])
+        if self.net.is_wide(x.shape[1]):
+            return _fm_loss_wide.epic_wide_diffusion_loss(lay, self.net.source_vector(lay), x, t, z, cond=cond, mask=mask,
+                                                          criterion=criterion, diff_config=diff_config)
         return _fm_loss.epic_diffusion_loss(lay, self.net.source_vector(lay), x, t, z, cond=cond, mask=mask,
                                             criterion=criterion, diff_config=diff_config)
 
