@@ -355,6 +355,8 @@ def gen_transformer(ref, name, hp, B, store_all, out_dir, seed=2024, file_prefix
 
     def put_grads(tag):
         for k, p in cnf.named_parameters():
+            if p.grad is None:  # MDMA: Block.cond_cls is constructed but never used (mdma.py:30, 36)
+                continue
             g = p.grad.detach().clone().numpy()
             out[tag + "grad/flows.0." + k] = g if store_all else subsample(g)
 
@@ -418,7 +420,7 @@ def gen_transformer(ref, name, hp, B, store_all, out_dir, seed=2024, file_prefix
     tag = "droid/"
     out[tag + "x"], out[tag + "t"], out[tag + "z"] = x.numpy(), t.numpy(), z.numpy()
     out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
-    for k, p in list(cnf.named_parameters())[:6]:
+    for k, p in [kp for kp in cnf.named_parameters() if kp[1].grad is not None][:6]:
         out[tag + "grad/flows.0." + k] = subsample(p.grad.detach().clone().numpy())
     path = os.path.join(out_dir, f"{file_prefix}_{name}.npz")
     np.savez(path, **out)
@@ -552,6 +554,25 @@ CA_CONFIGS = {
 
 
 # ----------------------------------------------------------------------------------------------
+# model="mdma" (configs/model/flow_matching_mdma.yaml:15-36; experiment/jetnet/fm_mdma.yaml, calo_challenge/fm_mdma.yaml).
+# CNF passes input_dim and **net_config to MDMA (flow_matching_module.py:163-167): its own global_cond_dim is net_config's (0).
+# ----------------------------------------------------------------------------------------------
+def mdma_net_config(layers, hidden=128, latent=16):
+    return dict(feats=3, latent=latent, layers=layers, hidden_dim=hidden, activation="leaky_relu", wrapper_func="weight_norm",
+                frequencies=6, num_points=150, t_local_cat=False, t_global_cat=False, global_cond_dim=0, local_cond_dim=0,
+                dropout=0.0, sum_scale=1e-2)
+
+
+MDMA_BASE = dict(model="mdma", features=3, frequencies=16, add_time_to_input=True, t_emb="cosine", loss_type="FM-OT",
+                 global_cond_dim=0)
+MDMA_CONFIGS = {
+    "small": (dict(MDMA_BASE, num_particles=40, net_config=mdma_net_config(2)), 4, False),
+    # the yaml's own sizes with experiment/jetnet/fm_mdma.yaml:27 (150 particles) and calo_challenge/fm_mdma.yaml:26 (4 features)
+    "yaml": (dict(MDMA_BASE, num_particles=150, features=4, net_config=mdma_net_config(4)), 2, False),
+}
+
+
+# ----------------------------------------------------------------------------------------------
 # loss_type="diffusion" (configs/model/diffusion.yaml: EPiC, hidden 128, cosine embedding, huber criterion)
 # ----------------------------------------------------------------------------------------------
 DIFF_HP = dict(BASE, num_particles=30, layers=2, global_cond_dim=2, loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02})
@@ -660,7 +681,7 @@ def gen_norm_layer(ref, out_dir, seed=97531):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,diffusion,norm}; default all")
+    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,norm}; default all")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
@@ -684,6 +705,9 @@ def main():
     for name, (hp, B, store_all) in CA_CONFIGS.items():
         if ap2 is None or "ca" in ap2:
             gen_transformer(ref, name, hp, B, store_all, args.out, seed=4048, file_prefix="ca")
+    for name, (hp, B, store_all) in MDMA_CONFIGS.items():
+        if ap2 is None or "mdma" in ap2:
+            gen_transformer(ref, name, hp, B, store_all, args.out, seed=6061, file_prefix="mdma")
 
 
 if __name__ == "__main__":

@@ -1,4 +1,4 @@
-"""ctypes binding of libpfm_hip.so (C ABI in include/pfm_hip.h, pfm_tf.h, pfm_epicw.h and pfm_ca.h).
+"""ctypes binding of libpfm_hip.so (C ABI in include/pfm_hip.h, pfm_tf.h, pfm_epicw.h, pfm_ca.h and pfm_mdma.h).
 
 There is no CPU fallback: if the library is missing or a call fails this raises."""
 from __future__ import annotations
@@ -9,6 +9,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 from .layout import EpicDesc
 from .layout_ca import CaDesc
+from .layout_mdma import MdmaDesc
 from .layout_tf import TfDesc
 from .layout_wide import EwDesc
 
@@ -92,6 +93,15 @@ SYMBOLS = {
         c_int, [POINTER(CaDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_ca_backward_scratch_floats": (c_int64, [POINTER(CaDesc), c_int32]),
     "pfm_ca_fm_loss_backward": (c_int, [POINTER(CaDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
+    # include/pfm_mdma.h
+    "pfm_mdma_workspace_floats": (c_int64, [POINTER(MdmaDesc), c_int32, c_int32]),
+    "pfm_mdma_backward_scratch_floats": (c_int64, [POINTER(MdmaDesc), c_int32]),
+    "pfm_mdma_forward": (c_int, [POINTER(MdmaDesc), _fp, _fp, c_int32, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_mdma_sample_rk": (
+        c_int, [POINTER(MdmaDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),
+    "pfm_mdma_fm_loss_forward": (
+        c_int, [POINTER(MdmaDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_mdma_fm_loss_backward": (c_int, [POINTER(MdmaDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
     "pfm_tf_fm_loss_forward": (
         c_int, [POINTER(TfDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_tf_backward_scratch_floats": (c_int64, [POINTER(TfDesc), c_int32]),

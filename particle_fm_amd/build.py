@@ -11,7 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libpfm_hip.so")
-SOURCES = ["epic_kernels.hip", "epic_train.hip", "optim.hip", "wn.hip", "post.hip", "tf_kernels.hip", "ew_kernels.hip", "ca_kernels.hip"]  # missing files are skipped until they exist
+SOURCES = ["epic_kernels.hip", "epic_train.hip", "optim.hip", "wn.hip", "post.hip", "tf_kernels.hip", "ew_kernels.hip", "ca_kernels.hip", "mdma_kernels.hip"]  # missing files are skipped until they exist
 ARCH = "gfx950"
 
 
@@ -31,7 +31,7 @@ def is_stale() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    deps += [os.path.join(ROOT, "include", h) for h in ("pfm_hip.h", "pfm_tf.h", "pfm_epicw.h", "pfm_ca.h")]
+    deps += [os.path.join(ROOT, "include", h) for h in ("pfm_hip.h", "pfm_tf.h", "pfm_epicw.h", "pfm_ca.h", "pfm_mdma.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

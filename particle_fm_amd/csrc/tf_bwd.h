@@ -307,6 +307,8 @@ struct DwArgs {
     float* part;         // [tiles][nsplit][128*128] partial tiles
     int64_t gamma, beta;
     int ldz, lda, lda2, K1, M, NO, K, nsplit, row_tiles;
+    int pre_act = 0;     // 1: the Linear's input was LeakyReLU(A) (see LinArgs::pre_act)
+    float slope = 0.f;
 };
 
 constexpr int DWS = 132;  // LDS row stride (floats)
@@ -350,7 +352,7 @@ static __global__ __launch_bounds__(LT, 2) void tf_dw_kernel(DwArgs a) {
                 const float mean = a.stats[2 * (int64_t)rc], rstd = a.stats[2 * (int64_t)rc + 1];
                 as[i] = (av - mean) * rstd * g4 + b4;
             } else {
-                as[i] = av;
+                as[i] = a.pre_act ? lrelu4(av, a.slope) : av;
             }
         }
         __syncthreads();  // the previous tile has been consumed
@@ -734,7 +736,7 @@ struct OuterJob {
     int64_t ldu, ldv;
     int K, NO;
 };
-constexpr int OUTER_MAX_JOBS = 12;
+constexpr int OUTER_MAX_JOBS = 16;
 struct OuterJobs {
     OuterJob job[OUTER_MAX_JOBS];
     int n_jets;

@@ -289,8 +289,9 @@ struct LinArgs {
     int ksplit;         // 1: the whole K in one workgroup
     float* out;         // [M][ldo]
     int64_t blob_floats, W, b, gamma, beta, jb_stride;
-    int lda, lda2, K1, ldr, ldy, ldo, M, K, NO, N, act, row_tiles;  // act: 0 none (+R), 1 lrelu(acc) (+R after), 2 lrelu(acc + R), 3 (acc + R) * lrelu'(Y)
+    int lda, lda2, K1, ldr, ldy, ldo, M, K, NO, N, act, row_tiles;  // act: 0 none (+R), 1 lrelu(acc) (+R after), 2 lrelu(acc + R), 3 (acc + R) * lrelu'(Y), 4 acc * lrelu'(Y) + R
     float slope, eps;
+    int pre_act = 0;    // 1: the input rows pass through LeakyReLU(slope) on their way into LDS (MDMA: fc0(act(x)), mdma.py:65)
 };
 
 // row statistics of a BM-row tile: 16 lanes per row, two-pass (mean, then centred sum of squares)
@@ -440,6 +441,10 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
                 st[i] = (st[i] - mean) * rstd * g4 + b4;
             }
         }
+        if (a.pre_act) {
+#pragma unroll
+            for (int i = 0; i < SI; ++i) st[i] = lrelu4(st[i], a.slope);
+        }
         if (X3) {
             _Float16* hb = reinterpret_cast<_Float16*>(buf);
 #pragma unroll
@@ -530,11 +535,12 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
                 *reinterpret_cast<f32x4*>(a.part + ((int64_t)ks * a.M + row) * a.NO + o) = acc[s][t];
             } else if (row < a.M) {
                 f32x4 v = acc[s][t];
-                if (a.act == 3) {
-                    if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+                if (a.act >= 3) {
+                    if (a.act == 3 && a.R) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
                     const f32x4 y = *reinterpret_cast<const f32x4*>(a.Y + (int64_t)row * a.ldy + o);
                     v.x *= y.x > 0.f ? 1.f : a.slope; v.y *= y.y > 0.f ? 1.f : a.slope;
                     v.z *= y.z > 0.f ? 1.f : a.slope; v.w *= y.w > 0.f ? 1.f : a.slope;
+                    if (a.act == 4 && a.R) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
                 } else {
                     if (a.act == 2) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
                     if (a.act) v = lrelu4(v, a.slope);

@@ -123,6 +123,24 @@ def ca_golden(request):
     return load_ca_golden(request.param)
 
 
+class MdmaGolden(TfGolden):
+    """tests/golden/mdma_<name>.npz: the MDMA model (model "mdma"), seed-derived weights."""
+
+    FILE = "mdma_{}.npz"
+
+
+def load_mdma_golden(name):
+    key = "mdma_" + name
+    if key not in _cache:
+        _cache[key] = MdmaGolden(name)
+    return _cache[key]
+
+
+@pytest.fixture(params=["small", "yaml"])
+def mdma_golden(request):
+    return load_mdma_golden(request.param)
+
+
 def load_tf_golden(name):
     key = "tf_" + name
     if key not in _cache:

@@ -1,0 +1,47 @@
+"""layout_mdma.py: descriptor, gather maps and blob formats, checked on the CPU against the reference vectors."""
+import numpy as np
+import pytest
+import torch
+
+from particle_fm_amd.layout_mdma import MdmaConfig, MdmaLayout
+from tests import mdma_blob_interp
+
+
+def _layout(g):
+    return MdmaLayout(MdmaConfig.from_hparams(g.hp))
+
+
+def test_state_dict_order_and_count(mdma_golden):
+    lay = _layout(mdma_golden)
+    assert lay.keys("flows.0.") == [k for k in mdma_golden.keys if not k.endswith("frequencies")]
+    assert lay.n_params == sum(v.numel() for k, v in mdma_golden.state.items() if not k.endswith("frequencies"))
+
+
+def test_blob_evaluates_to_reference(mdma_golden):
+    g = mdma_golden
+    lay = _layout(g)
+    blob = lay.pack_blob(g.state, "flows.0.", g.freqs)
+    assert blob.numel() == lay.blob_total
+    for mk in ("f32", "ones"):
+        tag = f"nfe_{mk}/"
+        x, t, mask = (g.get(tag + k) for k in ("x", "t", "mask"))
+        v = mdma_blob_interp.forward(lay.desc, blob, t, x, mask.reshape(x.shape[0], -1).float())
+        torch.testing.assert_close(v.unsqueeze(-1), g.get(tag + "v_vec_t"), rtol=2e-4, atol=2e-5)
+
+
+def test_grad_pos_is_a_bijection_onto_primary_slots(mdma_golden):
+    lay = _layout(mdma_golden)
+    gp = lay.grad_pos
+    assert gp.shape == (lay.n_params,) and len(np.unique(gp)) == lay.n_params
+    assert np.array_equal(lay.index_map[gp], np.arange(lay.n_params))
+
+
+def test_unsupported_configs_are_rejected():
+    hp = dict(num_particles=30, features=3, frequencies=16, net_config=dict(hidden_dim=128, layers=2, t_local_cat=False, t_global_cat=False))
+    MdmaLayout(MdmaConfig.from_hparams(hp))
+    for bad in (dict(t_local_cat=True), dict(t_global_cat=True), dict(global_cond_dim=1), dict(local_cat_cond=True), dict(hidden_dim=64),
+                dict(num_heads=2), dict(latent=10)):
+        with pytest.raises(NotImplementedError):
+            MdmaLayout(MdmaConfig.from_hparams(dict(hp, net_config=dict(hp["net_config"], **bad))))
+    with pytest.raises(NotImplementedError):  # MDMA's own defaults concatenate the time embedding (mdma.py:103-104)
+        MdmaConfig.from_hparams(dict(hp, net_config=dict(hidden_dim=128)))
