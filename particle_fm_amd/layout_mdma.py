@@ -69,6 +69,8 @@ class MdmaConfig:
     def head_dim(self) -> int:
         return self.hidden // self.num_heads
 
+    global_cond_dim = 0  # MDMA never reads the condition with the switches this build supports
+
     @property
     def input_dim(self) -> int:
         return self.features + (self.t_dim if self.add_time_to_input else 0)

@@ -6,8 +6,8 @@ Same class names, constructor keywords, ``state_dict`` keys and call signatures 
 pipeline (Lightning Trainer, EMA callback, evaluation callbacks -> ``sample``) keeps working.  The compute
 of the hot path -- EPiC, Full-Transformer or cross-attention vector field, FM / CFM / droid loss forward+backward,
 fixed-step midpoint sampling -- runs in libpfm_hip.so.  What the native path does not cover raises NotImplementedError at construction or call time
-(never a silent PyTorch fallback): model "mdma", losses other than FM-OT / CFM / droid, solvers other than "midpoint",
-t_emb="gaussian".
+(never a silent PyTorch fallback): losses other than FM-OT / CFM / droid / diffusion, the adaptive solvers, and the
+combinations listed in DESIGN.md section 7.
 """
 from __future__ import annotations
 
@@ -19,11 +19,13 @@ from torch import Tensor
 
 from .. import fm_loss as _fm_loss
 from .. import fm_loss_ca as _fm_loss_ca
+from .. import fm_loss_mdma as _fm_loss_mdma
 from .. import fm_loss_tf as _fm_loss_tf
 from .. import fm_loss_wide as _fm_loss_wide
-from .. import hip_ops, hip_ops_ca, hip_ops_tf, hip_ops_wide
+from .. import hip_ops, hip_ops_ca, hip_ops_mdma, hip_ops_tf, hip_ops_wide
 from .components.droid_transformer import FullCrossAttentionEncoder, FullTransformerEncoder
 from .components.epic import EPiC_encoder
+from .components.mdma import MDMA
 from .components.norm_layer import IterativeNormLayer
 from .components.losses import ConditionalFlowMatchingLoss, DiffusionLoss, DroidLoss, FlowMatchingLoss
 from .components.time_emb import CosineEncoding, GaussianFourierProjection
@@ -132,13 +134,17 @@ class CNF(nn.Module):
                                                  num_points=num_particles, frequencies=frequencies,
                                                  add_time_to_input=add_time_to_input,
                                                  t_emb=t_emb if t_emb in ("cosine", "sincos") else "cosine")
-        elif model == "mdma":
-            raise NotImplementedError(f"Model {model} has no HIP path in this build ('epic', 'droid_fulltransformer' and "
-                                      "'droid_fullcrossattention' do).")
+        elif model == "mdma":  # flow_matching_module.py:163-167
+            if t_emb not in ("cosine", "sincos"):
+                raise NotImplementedError("model='mdma' has a HIP path for the cosine / sincos time embeddings only")
+            self.net = MDMA(input_dim=input_dim, **net_config,
+                            _cnf=dict(features=features, num_particles=num_particles, frequencies=frequencies,
+                                      add_time_to_input=add_time_to_input, t_emb=t_emb))
         else:
             raise NotImplementedError(f"Model {model} not implemented.")  # flow_matching_module.py:170
         self.is_transformer = model == "droid_fulltransformer"
         self.is_cross_attention = model == "droid_fullcrossattention"
+        self.is_mdma = model == "mdma"
         self.register_buffer("frequencies", 2 ** torch.arange(frequencies) * torch.pi)  # :172
         self.activation = activation
         self.t_emb = t_emb
@@ -217,6 +223,10 @@ class CNF(nn.Module):
         if self.is_cross_attention:
             return _fm_loss_ca.ca_fm_loss(lay, self.net.flat_parameters(lay), x, t, z, cond=cond, mask=mask, sigma=sigma,
                                           kind=kind, eps=eps, freqs=self.net.freq_tensor())
+        if self.is_mdma:  # the (B, N, 1) field broadcast over the features, as losses.py:74 does implicitly; cond is not read
+            m = torch.ones(*x.shape[:2], 1, device=x.device) if mask is None else mask  # losses.py:42-43
+            return _fm_loss_mdma.mdma_fm_loss(lay, self.net.flat_parameters(lay), x, t, z, m, sigma=sigma, kind=kind, eps=eps,
+                                              freqs=self.net.freq_tensor())
         src = self.net.source_vector(lay)
         if self.t_emb == "gaussian":
             self._check_gaussian_path(x.shape[1])
@@ -236,6 +246,8 @@ class CNF(nn.Module):
             # mask is applied to the ODE right-hand side by the network itself; z arrives already masked
             # `weights` (extension): an already packed kernel blob, e.g. a snapshot taken on another stream
             blob = weights if weights is not None else self.net.packed_weights(z.shape[1])
+            if self.is_mdma:
+                return self._sample_rk(blob, z, cond, mask, ode_steps, "midpoint", 1.0, 0.0)
             if self.is_transformer:
                 return hip_ops_tf.tf_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
                                                      ode_steps=ode_steps, premask=False)
@@ -266,7 +278,7 @@ class CNF(nn.Module):
     def _decode_diffusion(self, z, cond, mask, ode_solver, ode_steps, weights):
         """loss_type="diffusion" (:62-69, 301-325): the fixed-step ODE solvers integrate -0.5 beta (x - net / noise_rate);
         "ddim" / "em" are the samplers of models/components/solver.py (n_steps = ode_steps)."""
-        if self.is_transformer or self.is_cross_attention or self.t_emb == "gaussian":
+        if self.is_transformer or self.is_cross_attention or self.is_mdma or self.t_emb == "gaussian":
             raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' (configs/model/diffusion.yaml) with the "
                                       "cosine / sincos time embeddings only")
         wide = self.net.is_wide(z.shape[1])
@@ -301,7 +313,7 @@ class CNF(nn.Module):
 
     def diffusion_loss(self, x, t, z, mask=None, cond=None, criterion: str = "huber", diff_config=None) -> Tensor:
         """DiffusionLoss body (losses.py:250-288) with the draws given; z is already multiplied by the mask."""
-        if self.is_transformer or self.is_cross_attention or self.t_emb == "gaussian":
+        if self.is_transformer or self.is_cross_attention or self.is_mdma or self.t_emb == "gaussian":
             raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' (configs/model/diffusion.yaml) with the "
                                       "cosine / sincos time embeddings only")
         lay = self.net.layout(x.shape[1])
@@ -314,6 +326,9 @@ class CNF(nn.Module):
     def _sample_rk(self, blob, z, cond, mask, ode_steps, solver, t0, t1):
         lay = self.net.layout(z.shape[1])
         kw = dict(ode_steps=ode_steps, solver=solver, t0=t0, t1=t1)
+        if self.is_mdma:
+            m = torch.ones(*z.shape[:2], 1, device=z.device) if mask is None else mask
+            return hip_ops_mdma.mdma_sample_rk(lay, blob, z, m, premask=False, **kw)
         if self.is_transformer:
             return hip_ops_tf.tf_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
         if self.is_cross_attention:

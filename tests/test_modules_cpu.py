@@ -160,6 +160,30 @@ def test_ca_desc_mirror_matches_the_c_struct(tmp_path):
     assert rc == 10001 and b"tokens" in lib.pfm_last_error()
 
 
+def test_mdma_desc_mirror_matches_the_c_struct(tmp_path):
+    """pfm_mdma_desc as gcc lays it out vs the ctypes mirror; host-side validation of the MDMA entry points."""
+    import subprocess
+    from particle_fm_amd.layout_mdma import MdmaBlock, MdmaConfig, MdmaDesc, MdmaLayout
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pfm_mdma.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(pfm_mdma_desc), offsetof(pfm_mdma_desc, block), sizeof(pfm_mdma_block), offsetof(pfm_mdma_desc, avg_n),'
+                   'offsetof(pfm_mdma_desc, out_b), offsetof(pfm_mdma_block, fc2c_b));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", f"{ROOT}/include", str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [ctypes.sizeof(MdmaDesc), MdmaDesc.block.offset, ctypes.sizeof(MdmaBlock), MdmaDesc.avg_n.offset,
+                   MdmaDesc.out_b.offset, MdmaBlock.fc2c_b.offset]
+    lib = _lib.load()
+    lay = MdmaLayout(MdmaConfig(num_particles=150, hidden=128, num_layers=4, frequencies=16))
+    n0, n1 = (lib.pfm_mdma_workspace_floats(ctypes.byref(lay.desc), 128, tr) for tr in (0, 1))
+    assert 0 < n0 < n1
+    assert lib.pfm_mdma_backward_scratch_floats(ctypes.byref(lay.desc), 128) > 0
+    lay.desc.latent = 10
+    assert lib.pfm_mdma_workspace_floats(ctypes.byref(lay.desc), 1, 0) == -1
+    rc = lib.pfm_mdma_forward(ctypes.byref(lay.desc), None, None, 0, None, None, None, 1, None, None)
+    assert rc == 10001 and b"latent" in lib.pfm_last_error()
+
+
 def test_flat_params_alias_and_survive_load_state_dict():
     m = SetFlowMatchingLitModule(optimizer=None, features=3, hidden_dim=128, num_particles=30, frequencies=16,
                                  layers=1, latent=10, t_local_cat=True, t_global_cat=True, add_time_to_input=False,
