@@ -35,22 +35,51 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIB
-    cmd = [
-        _hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+def _flags():
+    return [
+        f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
         # fp32 atomicAdd as the hardware instruction instead of a CAS loop: every buffer the kernels add into is
         # ordinary (coarse-grained) device memory owned by the caller
         "-munsafe-fp-atomics",
         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-        *sources(), "-o", LIB + ".tmp",
     ]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """One hipcc -c per translation unit (in parallel, objects cached under build/obj by source + header mtimes),
+    then one link.  A full rebuild takes about a minute on 8 cores instead of three."""
+    if not force and not is_stale():
+        return LIB
+    from concurrent.futures import ThreadPoolExecutor
+
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs += [os.path.join(ROOT, "include", h) for h in os.listdir(os.path.join(ROOT, "include")) if h.endswith(".h")]
+    hdr_t = max(os.path.getmtime(h) for h in hdrs)
+    hipcc = _hipcc()
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(src)):
+            return obj
+        cmd = [hipcc, *_flags(), "-c", src, "-o", obj + ".tmp"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 
