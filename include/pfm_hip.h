@@ -78,6 +78,8 @@ extern "C" {
                                both operands -- fp32-grade products (error 2^-22) at 2.7x less matrix-pipe time; needs |x| < 65504 */
 #define PFM_F_TEMB_SINCOS 8u /* t_emb="sincos" (flow_matching_module.py:208-211): temb = [cos(f t) ; sin(f t)], freqs table = [f ; f],
                                f = 2^k pi; default: t_emb="cosine" (time_emb.py:79-96) */
+#define PFM_F_GENERIC_SAMPLER 32u /* pfm_epic_sample_midpoint: keep the generic kernel where the lean evaluation (csrc/epic_fast.h: unconditioned
+                                     jets, T = 32, F <= 4) would run; results differ by fp32 re-association only */
 #define PFM_F_BF16_MFMA 2u /* inference kernels, loss forward and the dX products of the backward: the 128x128 particle Linears run on v_mfma_f32_16x16x16_bf16 (operands
                               rounded to bf16 on the fly, fp32 accumulate, fp32 activations); everything else stays fp32 */
 
@@ -160,6 +162,9 @@ int pfm_epic_forward_temb(const pfm_epic_desc *desc, const float *blob, const fl
  * with its valid particles and workgroups are dispatched in order, so the short jets fill the tail of a launch -- and, when
  * several launches are in flight, the gaps of the previous one -- instead of a long jet starting last. */
 int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc *desc, int32_t n_intervals, int32_t B);
+/* 1 if pfm_epic_sample_midpoint(desc, ..., scratch != NULL, ...) runs the lean evaluation of csrc/epic_fast.h (unconditioned jets,
+ * t_dim = 32, features <= 4, fp32 / bf16 operands, no PFM_F_PACK_JETS / PFM_F_GENERIC_SAMPLER), 0 if the generic kernel. */
+int pfm_epic_sample_is_fast(const pfm_epic_desc *desc);
 int pfm_epic_sample_midpoint(const pfm_epic_desc *desc, const float *blob, const float *t_eval,
                              const float *dt, int32_t n_intervals, const float *z, const float *cond,
                              const float *mask, float *x_out, int32_t B, float *scratch, void *stream);

@@ -31,6 +31,7 @@ SYMBOLS = {
     "pfm_epic_sample_midpoint": (
         c_int, [POINTER(EpicDesc), _fp, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_epic_sample_scratch_floats": (c_int64, [POINTER(EpicDesc), c_int32, c_int32]),
+    "pfm_epic_sample_is_fast": (c_int, [POINTER(EpicDesc)]),
     "pfm_epic_sample_midpoint_temb": (
         c_int, [POINTER(EpicDesc), _fp, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_epic_sample_rk_temb": (c_int, [POINTER(EpicDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),

@@ -1,0 +1,291 @@
+// The midpoint sampler's lean evaluation ("fast path") for the headline configuration of the EPiC network: unconditioned jets
+// (cond_global = cond_local = 0), time embedding of width 32, F <= 4 features, fp32 or bf16 matrix operands.
+//
+// Reference graph: the same as epic_nfe.h (particle_fm/models/components/epic.py:304-391, :85-203).
+//
+// Why a second body.  Ablations on MI355X (tests/diag/ab_time.py on builds with pieces removed) showed where a 2-tile jet's
+// 128k cycles per evaluation go: 53k matrix-pipe issue, 32k the six per-jet chains (pool -> fc_global1 -> fc_global2 -> local
+// biases), 20k weight loads that stall wave issue, the rest stem / head / phase boundaries.  The fp32 MFMA does not co-issue
+// with VALU work, so every VALU instruction is paid in full -- and the generic chain (any T / C / Cl / L, two jets per
+// workgroup, SAVE for training) compiles to ~1000 instructions per thread: guards for rows past K, loops for wider models,
+// exec-mask branches around every conditional store, serialized LDS round trips, SGPR spills.  Overlapping it with the MFMA
+// phase changes nothing (measured: the chain issued behind the K-quarters of phase 1 took the same time as ahead of it).
+// With everything per-jet that depends on time alone tabulated per evaluation, this configuration needs ~170:
+//   * the table (epic_time_table_kernel, fast format) holds for every evaluation and layer the COMPLETE bias of each per-jet
+//     Linear's time columns (b + W_t^T temb), and a stem slot with the per-jet biases of fc_l1 / fc_l2 / fc_l3 and the time terms
+//     of fc_g1 / fc_g2: no time embedding (a Payne-Hanek cosf on arguments up to 1e13), no stem GEMVs, no head GEMV, and two
+//     barriers fewer per evaluation;
+//   * no guards: every input vector is zero-padded in LDS to the 16-row panels the weights are padded to;
+//   * fc_global2's rows sit along the DPP row (16 k of one output group per row): its reduction is row_sum16, no bpermute;
+//   * bias vectors that are constant per (evaluation, layer) are read by the MFMA phases straight from the table;
+//   * fc_l1 (K = F <= 4) is ONE v_mfma_f32_16x16x4_f32 per tile and wave instead of a VALU layer;
+//   * the head's weights and the next evaluation's fc_l2 weights are requested before they are needed.
+// The layer chain keeps the generic chain's arithmetic order (same panels, same reduction trees, same wave-partial order), so
+// a layer gives the same bits as the generic time-table path; the stem's tabulated terms and the MFMA fc_l1 differ from the
+// generic kernels by fp32 re-association (~1e-7), inside every parity bar (tests/test_hip_forward.py, test_hip_fast.py).
+#pragma once
+#include "epic_nfe.h"
+
+namespace pfm {
+
+constexpr int FT = 32;        // time-embedding width the fast path is built for
+constexpr int FTP = FT / 16;  // time panels of every per-jet block (tabulated, skipped)
+constexpr int FNG = 17;       // fc_global1 panels behind the time rows: [mean(128) ; sum(128) ; g(16)]
+constexpr int FNGS = 16;      // fc_g1 (stem): [mean ; sum]
+constexpr int FNG1 = 12;      // ... of the FNG panels, how many ride on particle phase 1 (the rest on phase 2)
+// stem slot of the fast table (slot index = layers): per-jet biases of fc_l1 / fc_l2, time terms (+ bias) of fc_g1 / fc_g2, fc_l3 bias
+constexpr int TB_SJ1 = 0, TB_SJ2 = 128, TB_SG1 = 256, TB_SG2 = 384, TB_SB3 = 400;
+
+__host__ __device__ inline bool fast_path_ok(const pfm_epic_desc& d) {
+    return d.t_dim == FT && d.cond_global == 0 && d.cond_local == 0 && d.features <= 4 && d.layers > 0 &&
+           !(d.flags & (PFM_F_F16X3_MFMA | PFM_F_PACK_JETS | PFM_F_GENERIC_SAMPLER));
+}
+
+// fc_l1: bufA[p][o] = lrelu(bj1[o] + sum_f Wx[f][o] * y[p][f])   epic.py:360-362, on the matrix pipe (K = F padded to 4).
+// aw = this lane's element of the A operand (fast_l1_weight: constant over the call), bias = its slice of the per-jet bias (table).
+__device__ __forceinline__ float fast_l1_weight(const pfm_epic_desc& d, const JetDims& j, const float* __restrict__ blob) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pl = lane & 15, q = lane >> 4;
+    return q < j.F ? blob[d.l1x.W + q * H + 16 * w + pl] : 0.f;  // A[i = pl][k = q] = Wx[k][16 w + i]
+}
+__device__ __forceinline__ void fast_stem_l1(const JetDims& j, float* __restrict__ lds, const Carve& c, int n_rows, float aw, f32x4 bias) {
+    const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
+    const int pl = lane & 15, q = lane >> 4;
+    const int oslot = 4 * w + q;
+    const bool kf = q < j.F;
+    const float* yin = lds + c.yin;
+    const int ntiles = (n_rows + TILE - 1) / TILE;
+    for (int t = 0; t < ntiles; ++t) {
+        const int p = t * TILE + pl;
+        const float bv = (kf && p < n_rows) ? yin[p * j.F + q] : 0.f;  // B[k = q][j = pl]
+        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv, bias, 0, 0, 0);
+        acc = lrelu4(acc, j.slope);
+        if (p < n_rows) *reinterpret_cast<f32x4*>(lds + c.bufA + lds_off(p, oslot)) = acc;
+    }
+}
+
+// The few loads of a per-jet chain that are not weight panels: this thread's row of fc_global2 and its slices of the tabulated
+// bias + time terms.  Requested a whole particle phase ahead (a load waited for right behind its request costs an L2 round trip
+// with the matrix pipe idle -- and a vmcnt wait also waits for every weight load queued before it).
+struct ChainLoads {
+    f32x4 w2, bg1, bg2, bl1;
+};
+__device__ __forceinline__ ChainLoads fast_chain_loads(blob_rsrc rs, int64_t gl2_W, const float* __restrict__ tg1,
+                                                       const float* __restrict__ tg2, const float* __restrict__ tl1) {
+    const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
+    const int og = tid >> 4, pt = tid & 15, o4 = lane >> 4;
+    ChainLoads L;
+    L.w2 = bload4(rs, gl2_W + (int64_t)FT * 16, ((16 * w + pt) * 16 + 4 * o4) * 4);  // row FT + 16 w + pt, outputs 4 o4..
+    L.bg1 = *reinterpret_cast<const f32x4*>(tg1 + 4 * og);
+    L.bg2 = *reinterpret_cast<const f32x4*>(tg2 + 4 * o4);
+    L.bl1 = *reinterpret_cast<const f32x4*>(tl1 + 4 * og);
+    return L;
+}
+
+// sum of the eight wave partials of fc_global2 in wave order; all eight reads in flight before the first add
+__device__ __forceinline__ f32x4 fast_sum_partials(const float* __restrict__ g2p_o4) {
+    f32x4 part[NW];
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) part[ww] = *reinterpret_cast<const f32x4*>(g2p_o4 + MAXL * ww);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 gn = part[0];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) gn += part[ww];
+    return gn;
+}
+
+// Stem chain: g = lrelu(Wg2 . lrelu(Wg1 . [mean ; sum] + tg1) + tg2), tg* = bias + time term (table).  epic.py:369-380
+// In: vin.mean / vin.sum (written by the fc_l2 phase, barrier passed), gl = this thread's rows of fc_g1 behind the time rows.
+// after_fc1(): called once gl has been consumed (the caller requests the first layer's windows there).  Out: vin.g.  Ends with a barrier.
+template <typename After>
+__device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restrict__ lds, const Carve& c, const f32x4 (&gl)[FNG],
+                                                const ChainLoads& L, After after_fc1) {
+    const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
+    const int og = tid >> 4, pt = tid & 15, o4 = lane >> 4;
+    const float* vp = lds + c.vin + FT + pt;
+    float* vin2 = lds + c.vin2;
+    f32x4 p = gl[0] * vp[0];
+#pragma unroll
+    for (int u = 1; u < FNGS; ++u) p += gl[u] * vp[16 * u];
+    after_fc1();
+    p = reduce_pt(p);
+    if (pt == 0) *reinterpret_cast<f32x4*>(vin2 + FT + 4 * og) = lrelu4(p + L.bg1, j.slope);
+    __syncthreads();
+    f32x4 gp = L.w2 * vin2[FT + 16 * w + pt];
+    gp = row_sum16(gp);
+    if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.g2p + MAXL * w + 4 * o4) = gp;
+    __syncthreads();
+    if (w == 0) {
+        f32x4 gn = fast_sum_partials(lds + c.g2p + 4 * o4);
+        gn = lrelu4(gn + L.bg2, j.slope);
+        if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.vin + FT + 2 * H + 4 * o4) = gn;
+    }
+    __syncthreads();
+}
+
+// Layer chain (epic.py:159-190): g1 = lrelu(Wg1.[mean;sum;g] + tg1); g = lrelu(Wg2.g1 + tg2 + g); bj1 = tl1 + We1.g
+// (t* = bias + time term of the table slot).  Same panels, reduction trees and wave-partial order as PerJet phase of epic_nfe.h.
+// In: vin = [.. ; mean ; sum ; g_old], gl = rows of fc_global1 behind the time rows, wbA = row FT + pt of local linear 1's extras.
+// Out: vin.g = g_new, bj1 (each wave its own slice: the particle phase that follows needs no barrier).
+__device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __restrict__ lds, const Carve& c, const f32x4 (&gl)[FNG],
+                                                 const f32x4& wbA, const ChainLoads& L) {
+    const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
+    const int og = tid >> 4, pt = tid & 15, o4 = lane >> 4;
+    const float* vin = lds + c.vin;
+    float* vin2 = lds + c.vin2;
+    const f32x4 gold = *reinterpret_cast<const f32x4*>(vin + FT + 2 * H + 4 * o4);  // before anyone overwrites it
+    const float* vp = vin + FT + pt;
+    f32x4 p = gl[0] * vp[0];
+#pragma unroll
+    for (int u = 1; u < FNG; ++u) p += gl[u] * vp[16 * u];
+    p = reduce_pt(p);
+    if (pt == 0) *reinterpret_cast<f32x4*>(vin2 + FT + 4 * og) = lrelu4(p + L.bg1, j.slope);
+    __syncthreads();
+    f32x4 gp = L.w2 * vin2[FT + 16 * w + pt];
+    gp = row_sum16(gp);
+    if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.g2p + MAXL * w + 4 * o4) = gp;
+    __syncthreads();
+    f32x4 gn = fast_sum_partials(lds + c.g2p + 4 * o4);
+    gn += L.bg2;
+    gn += gold;  // residual before the activation, epic.py:184-186
+    gn = lrelu4(gn, j.slope);
+    // each wave keeps its own copy of g_new (read back as the input of the bias GEMV: same wave, LDS is in order); wave 0's copy
+    // is vin.g itself, the input of the next stage
+    float* gcopy = (w == 0) ? lds + c.vin + FT + 2 * H : lds + c.gcopy + MAXL * w;
+    if (pt == 0) *reinterpret_cast<f32x4*>(gcopy + 4 * o4) = gn;
+    f32x4 p1 = wbA * gcopy[pt];  // entries >= L are lrelu(0) = 0 (zero-padded weights and biases)
+    p1 = reduce_pt(p1);
+    if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.bj1 + 4 * og) = p1 + L.bl1;
+}
+
+// fc_l3 head with its per-jet bias from the table and its weights already in registers (requested during the last particle
+// phase).  emit(p, f, lrelu(b3[f] + W3[f].x[p]) * mask[p]) for the rows p < n_rows ONLY: the sampler's state rows behind a jet's
+// last valid particle start as z * mask = 0 and an update by 0 would leave them there.  epic.py:387-391
+template <typename Emit>
+__device__ __forceinline__ void fast_head(const JetDims& j, float* __restrict__ lds, const Carve& c, int n_rows,
+                                          const f32x4 (&a)[8], f32x4 b3, Emit emit) {
+    const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
+    const int pl = lane & 15, q = lane >> 4;
+    const float* bufB = lds + c.bufB;
+    int koff[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) koff[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
+    const int ntiles = (n_rows + TILE - 1) / TILE;
+    for (int tile = w; tile < ntiles; tile += NW) {
+        const int p = tile * TILE + pl;
+        const float* s0 = bufB + tile * TILE * H;
+        f32x4 b[8];
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) b[kt] = *reinterpret_cast<const f32x4*>(s0 + koff[kt]);
+        // two accumulator chains over the K halves (a dependent fp32 MFMA waits 40 cycles, the pipe issues one every 32)
+        f32x4 acc0 = b3, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].x, b[kt].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 4].x, b[kt + 4].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].y, b[kt].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 4].y, b[kt + 4].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].z, b[kt].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 4].z, b[kt + 4].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].w, b[kt].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 4].w, b[kt + 4].w, acc1, 0, 0, 0);
+        }
+        acc0 += acc1;
+        if (p < n_rows) {
+            const float m = lds[c.maskf + p];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 4 * q + r;
+                if (f < j.F) emit(p, f, lrelu(acc0[r], j.slope) * m);
+            }
+        }
+    }
+}
+
+// What an evaluation carries over from the one before it (requested behind that one's last particle phase / during its head):
+struct FastCarry {
+    f32x4 a1[8], a2[8];  // a2: fc_l2's weights on entry; a1: scratch (phase-1 weights, then the head's)
+    f32x4 sj1;           // this lane's slice of fc_l1's per-jet bias for the coming evaluation
+    float aw;            // this lane's element of fc_l1's A operand (constant over the call)
+};
+__device__ __forceinline__ void fast_carry_request(FastCarry& cy, const pfm_epic_desc& d, blob_rsrc rs, const float* __restrict__ tbS_next) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    load_afrag(cy.a2, rs, d.l2.A, w, lane);
+    cy.sj1 = *reinterpret_cast<const f32x4*>(tbS_next + TB_SJ1 + 4 * (4 * w + (lane >> 4)));
+}
+
+// One evaluation: yin -> emit(...).  tbE / tbE_next: the table rows of this and of the next evaluation (the last evaluation
+// passes its own again).
+template <bool BF16, typename Emit>
+__device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims& j, const float* __restrict__ blob,
+                                          float* __restrict__ lds, const Carve& c, int n_rows, const float* __restrict__ tbE,
+                                          const float* __restrict__ tbE_next, FastCarry& cy, Emit emit) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float* bufA = lds + c.bufA;
+    float* bufB = lds + c.bufB;
+    const float* maskf = lds + c.maskf;
+    const float* tbS = tbE + (size_t)j.layers * TB_SLOT;
+    const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
+    f32x4 gl[FNG], wbA[1];
+    PFM_STAMP(1);
+    // the stem chain's own loads, two phases ahead of their use
+    ChainLoads L = fast_chain_loads(rs, d.g2.W, tbS + TB_SG1, tbS + TB_SG2, tbS + TB_SG1);
+    const f32x4 b3 = *reinterpret_cast<const f32x4*>(tbS + TB_SB3 + 4 * (lane >> 4));  // head bias, zero for f >= F
+    fast_stem_l1(j, lds, c, n_rows, cy.aw, cy.sj1);
+    __syncthreads();
+    PFM_STAMP(3);
+    // ---- fc_l2: bufB = lrelu(W.bufA + bj2 + bufA), pooled -> vin   epic.py:364-371; carries the stem chain's fc_g1 rows
+    {
+        Prefetch<FNGS> pf{rs, gl, nullptr, nullptr, nullptr, seg_panels(d.g1.W, FTP, tid), {}, {}, {}};
+        gemm_phase<true, true, false, BF16, decltype(pf)>(cy.a2, bufA, bufB, bufA, tbS + TB_SJ2, maskf, j, lds, c, nullptr, nullptr,
+                                                           n_rows, pf);
+    }
+    __syncthreads();
+    PFM_STAMP(4);
+    {
+        const pfm_epic_layer& l0 = d.layer[0];
+        fast_chain_stem(j, lds, c, gl, L, [&]() {
+            // the first layer's windows and phase-1 weights: no particle phase to ride on; they land behind the rest of the stem chain
+            Prefetch<FNG, 1> pf{rs, gl, wbA, nullptr, nullptr, seg_panels(l0.gl1.W, FTP, tid), seg_panels(l0.lc1.We, FTP, tid), {}, {}};
+            pf.template issue_range<0, FNG + 1>();
+            load_afrag(cy.a1, rs, l0.lc1.A, w, lane);
+        });
+        L = fast_chain_loads(rs, l0.gl2.W, tbE + TB_G1, tbE + TB_G2, tbE + TB_L1);
+    }
+    for (int k = 0; k < j.layers; ++k) {
+        const pfm_epic_layer ly = d.layer[k];  // by value: the offset dwords in one batch of scalar loads
+        const bool last = k + 1 == j.layers;
+        const pfm_epic_layer& nx = d.layer[last ? k : k + 1];  // last layer: its own blocks again (harmless, hidden)
+        const float* tbK = tbE + (size_t)k * TB_SLOT;
+        const float* tbN = tbE + (size_t)(last ? k : k + 1) * TB_SLOT;
+        PFM_STAMP(10);
+        fast_chain_layer(j, lds, c, gl, wbA[0], L);
+        PFM_STAMP(12);
+        // phase 1: bufA = lrelu(W1 . bufB + bj1)   epic.py:194-196.  Riders: phase 2's weights and ALL per-jet windows of the next
+        // layer (gl / wbA were consumed by the chain above), so that nothing the next chain waits for is requested late
+        {
+            Prefetch<8, FNG, 1> pf{rs, cy.a2, gl, wbA, nullptr, seg_afrag(ly.lc2.A, w, lane), seg_panels(nx.gl1.W, FTP, tid),
+                                   seg_panels(nx.lc1.We, FTP, tid), {}};
+            gemm_phase<false, false, false, BF16, decltype(pf)>(cy.a1, bufB, bufA, nullptr, lds + c.bj1, maskf, j, lds, c, nullptr, nullptr,
+                                                                 n_rows, pf);
+        }
+        __syncthreads();
+        PFM_STAMP(13);
+        L = fast_chain_loads(rs, nx.gl2.W, tbN + TB_G1, tbN + TB_G2, tbN + TB_L1);  // the next chain's loads, a phase ahead
+        // phase 2: bufB = lrelu(W2 . bufA + bj2 + bufB), pooled -> vin    epic.py:198-200, :160-162
+        // (bj2 = bias + time term: constant per evaluation and layer, read from the table).  Riders: the next layer's phase-1
+        // weights, or the head's one 16-row panel behind the last layer, into a1 (free since phase 1)
+        {
+            const PfSeg sa = last ? PfSeg{d.l3_A, 256, lane * 16} : seg_afrag(nx.lc1.A, w, lane);
+            Prefetch<8> pf{rs, cy.a1, nullptr, nullptr, nullptr, sa, {}, {}, {}};
+            gemm_phase<true, true, false, BF16, decltype(pf)>(cy.a2, bufA, bufB, bufB, tbK + TB_L2, maskf, j, lds, c, nullptr, nullptr,
+                                                               n_rows, pf);
+        }
+        __syncthreads();
+    }
+    PFM_STAMP(20);
+    fast_carry_request(cy, d, rs, tbE_next + (size_t)j.layers * TB_SLOT);  // lands behind the head
+    fast_head(j, lds, c, n_rows, cy.a1, b3, emit);
+}
+
+}  // namespace pfm

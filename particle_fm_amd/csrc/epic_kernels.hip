@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "epic_nfe.h"
+#include "epic_fast.h"
 
 #ifdef PFM_DIAG
 namespace pfm {
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
             const int stage = e & 1;
             const float h = dt[e >> 1];
             const float hs = stage ? h : __fmul_rn(0.5f, h);
-            sampler_eval<MODE, TB, 2>(blob, desc_off, sg.rows, t_eval[e], hs, stage, TB ? table + (size_t)e * j.layers * TB_SLOT : nullptr, &sg,
+            sampler_eval<MODE, TB, 2>(blob, desc_off, sg.rows, t_eval[e], hs, stage, TB ? table + (size_t)e * (j.layers + 1) * TB_SLOT : nullptr, &sg,
                                       temb_tab ? temb_tab + (size_t)e * j.T : nullptr);
             PFM_STAMP(30);
         }
@@ -266,8 +267,60 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
         const int stage = e & 1;
         const float h = dt[e >> 1];
         const float hs = stage ? h : __fmul_rn(0.5f, h);
-        sampler_eval<MODE, TB>(blob, desc_off, n_rows, t_eval[e], hs, stage, TB ? table + (size_t)e * j.layers * TB_SLOT : nullptr, nullptr,
+        sampler_eval<MODE, TB>(blob, desc_off, n_rows, t_eval[e], hs, stage, TB ? table + (size_t)e * (j.layers + 1) * TB_SLOT : nullptr, nullptr,
                                temb_tab ? temb_tab + (size_t)e * j.T : nullptr);
+        PFM_STAMP(30);
+    }
+    float* oj = x_out + (size_t)jet * j.N * j.F;
+    for (int i = tid; i < j.N * j.F; i += NT) oj[i] = xs[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same integrator on the lean evaluation of epic_fast.h (unconditioned jets, T = 32, F <= 4; fp32 or bf16 operands): one jet per
+// workgroup, jets in descending multiplicity (`pack`), every time-only term from the fast-format table.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
+    const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ dt, int n_intervals, const float* __restrict__ z,
+    const float* __restrict__ mask, float* __restrict__ x_out, const float* __restrict__ table, const int* __restrict__ pack) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
+    const JetDims j = dims_of(d0);
+    const Carve c = make_carve(j.N, j.F);
+    const int tid = threadIdx.x;
+    const int jet = pack ? pack[1 + 2 * blockIdx.x] : blockIdx.x;  // epic_jet_pack_kernel's list without pairs: (jet, -1), longest first
+    const int n_rows = epic_jet_setup(d0, j, blob, lds, c, nullptr, mask ? mask + (size_t)jet * j.N : nullptr);
+    const float* zj = z + (size_t)jet * j.N * j.F;
+    for (int i = tid; i < j.N * j.F; i += NT) {
+        const float z0 = zj[i] * lds[c.maskf + i / j.F];  // flow_matching_module.py:668-671
+        lds[c.xs + i] = z0;
+        lds[c.yin + i] = z0;
+    }
+    __syncthreads();
+    float* xs = lds + c.xs;
+    float* yin = lds + c.yin;
+    const int F = j.F;
+    const size_t estride = (size_t)(j.layers + 1) * TB_SLOT;
+    FastCarry cy;
+    cy.aw = fast_l1_weight(d0, j, blob);
+    fast_carry_request(cy, d0, make_blob_rsrc(blob, d0.blob_floats + PFM_DESC_FLOATS), table + (size_t)j.layers * TB_SLOT);
+    const int n_evals = 2 * n_intervals;
+    for (int e = 0; e < n_evals; ++e) {
+#ifdef PFM_DIAG
+        if (e == n_evals - 1 && blockIdx.x == 0 && threadIdx.x == 0) g_pfm_nstamp = 0;  // keep the last NFE
+        PFM_STAMP(0);
+#endif
+        const int stage = e & 1;
+        const float h = dt[e >> 1];
+        const float hs = stage ? h : __fmul_rn(0.5f, h);
+        // stage 0: x_mid = x + 0.5*dt*k1 -> next input;   stage 1: x = x + dt*f(t+dt/2, x_mid)
+        fast_eval<MODE == 1>(d0, j, blob, lds, c, n_rows, table + e * estride, table + (e + 1 < n_evals ? e + 1 : e) * estride, cy,
+                             [=](int p, int f, float val) {
+                                 const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
+                                 yin[p * F + f] = xn;
+                                 if (stage) xs[p * F + f] = xn;
+                             });
+        __syncthreads();
         PFM_STAMP(30);
     }
     float* oj = x_out + (size_t)jet * j.N * j.F;
@@ -333,11 +386,12 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_rk_kernel(
 // ------------------------------------------------------------------------------------------------
 // Time-term table of a sampling call (epic_nfe.h: TB): table[e][layer][TB_SLOT] = W_t^T temb(t_eval[e]) for the four per-jet
 // Linears of every EPiC layer (fc_global1, local-1 extras, local-2 extras: KM16 blocks; fc_global2: KP16), time rows = the
-// first T rows of each block.  grid (n_evals, layers), 512 threads.
+// first T rows of each block; slot `layers` of an evaluation is the stem slot of the fast format (epic_fast.h).
+// grid (n_evals, layers + 1), 512 threads.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void epic_time_table_kernel(const float* __restrict__ blob, int64_t desc_off,
                                                               const float* __restrict__ t_eval, float* __restrict__ table,
-                                                              const float* __restrict__ temb_tab) {
+                                                              const float* __restrict__ temb_tab, int fast) {
     __shared__ float temb[MAXT];
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
@@ -356,18 +410,45 @@ __global__ __launch_bounds__(NT) void epic_time_table_kernel(const float* __rest
         temb[tid] = v;
     }
     __syncthreads();
+    float* out = table + ((size_t)e * (j.layers + 1) + k) * TB_SLOT;
+    const int which = tid >> 7, o = tid & 127;
+    if (k == j.layers) {
+        // stem slot (fast format only; epic_fast.h): complete per-jet biases of fc_l1 / fc_l2 / fc_l3, bias + time term of fc_g1 / fc_g2
+        if (!fast) return;
+        if (which < 3) {  // 0: fc_l1 extras, 1: fc_l2 extras, 2: fc_g1 time rows
+            const int64_t W = which == 0 ? d.l1_We : (which == 1 ? d.l2.We : d.g1.W);
+            const int64_t b = which == 0 ? d.l1_b : (which == 1 ? d.l2.b : d.g1.b);
+            float s = 0.f;
+            for (int r = 0; r < j.T; ++r) s = fmaf(blob[W + km16(r, o)], temb[r], s);
+            out[which * 128 + o] = s + blob[b + o];
+        } else if (o < 16) {  // fc_g2 time rows (KP16)
+            float s = 0.f;
+            for (int r = 0; r < j.T; ++r) s = fmaf(blob[d.g2.W + (r >> 4) * 256 + (r & 15) * 16 + o], temb[r], s);
+            out[TB_SG2 + o] = s + blob[d.g2.b + o];  // bias padded to 16 entries
+        } else if (o < 32) {  // fc_l3: b3[f] + We3[:, f] . temb, zero for f >= F
+            const int f = o - 16;
+            float s = 0.f;
+            if (f < j.F) {
+                for (int r = 0; r < j.T; ++r) s = fmaf(blob[d.l3_We + r * j.F + f], temb[r], s);
+                s += blob[d.l3_b + f];
+            }
+            out[TB_SB3 + f] = s;
+        }
+        return;
+    }
+    // layer slot: the time terms of fc_global1 | local-1 extras | local-2 extras (KM16 blocks) | fc_global2 (KP16);
+    // fast format: with the Linear's bias added (b + t, the sum the generic chain forms in registers)
     const pfm_epic_layer& ly = d.layer[k];
-    float* out = table + ((size_t)e * j.layers + k) * TB_SLOT;
-    const int which = tid >> 7, o = tid & 127;  // 0: fc_global1, 1: local-1 extras, 2: local-2 extras, 3: fc_global2
     if (which < 3) {
         const int64_t W = which == 0 ? ly.gl1.W : (which == 1 ? ly.lc1.We : ly.lc2.We);
+        const int64_t b = which == 0 ? ly.gl1.b : (which == 1 ? ly.lc1.b : ly.lc2.b);
         float s = 0.f;
         for (int r = 0; r < j.T; ++r) s = fmaf(blob[W + km16(r, o)], temb[r], s);
-        out[which * 128 + o] = s;
+        out[which * 128 + o] = fast ? blob[b + o] + s : s;
     } else if (o < 16) {
         float s = 0.f;
         for (int r = 0; r < j.T; ++r) s = fmaf(blob[ly.gl2.W + (r >> 4) * 256 + (r & 15) * 16 + o], temb[r], s);
-        out[TB_G2 + o] = s;
+        out[TB_G2 + o] = fast ? blob[ly.gl2.b + o] + s : s;
     }
 }
 
@@ -511,11 +592,17 @@ int pfm_epic_forward_temb(const pfm_epic_desc* d, const float* blob, const float
     return check_hip(hipGetLastError(), "epic_forward_kernel launch");
 }
 
-// scratch of a sampling call: time-term table [2 n_intervals][layers][TB_SLOT] | workgroup list [1 + 2 B] (int32)
+// scratch of a sampling call: time-term table [2 n_intervals][layers + 1][TB_SLOT] | workgroup list [1 + 2 B] (int32)
 int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc* d, int32_t n_intervals, int32_t B) {
     if (!d || n_intervals < 0 || B < 0) return -1;
-    return (int64_t)2 * n_intervals * d->layers * TB_SLOT + ((2 * (int64_t)B + 1 + 63) & ~63);
+    return (int64_t)2 * n_intervals * (d->layers + 1) * TB_SLOT + ((2 * (int64_t)B + 1 + 63) & ~63);
 }
+
+static bool sample_fast(const pfm_epic_desc* d, int mode) {
+    static const char* env_pack = getenv("PFM_PACK");  // diagnostic switch of tests/diag/pack_time.py: packing implies the generic kernel
+    return d && d->layers > 0 && fast_path_ok(*d) && mode != 2 && !(env_pack && env_pack[0] == '1');
+}
+int pfm_epic_sample_is_fast(const pfm_epic_desc* d) { return validate(d) == 0 && sample_fast(d, mfma_mode(d)) ? 1 : 0; }
 
 // device pointer of the workgroup list inside `scratch`, after queueing its computation; nullptr: one jet per workgroup, in order
 static const int* queue_jet_pack(const pfm_epic_desc* d, float* scratch, int64_t table_floats, const float* mask, int B, int mode,
@@ -559,15 +646,32 @@ static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const floa
     if (!blob || !t_eval || !dt || !z || !x_out) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (n_intervals < 0) return set_err(PFM_E_BADARG, "n_intervals < 0");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
+    const int64_t table_floats = (int64_t)2 * n_intervals * (d->layers + 1) * TB_SLOT;
+    // the lean evaluation of epic_fast.h: unconditioned jets, T = 32, F <= 4, fp32 / bf16 operands, one jet per workgroup
+    const bool fast = tb && sample_fast(d, mode);
+    if (fast) {
+        rc = mode == 1 ? prepare(epic_sample_midpoint_fast_kernel<1>, d, &lds) : prepare(epic_sample_midpoint_fast_kernel<0>, d, &lds);
+        if (rc) return rc;
+    }
     if (tb && n_intervals > 0) {
-        hipLaunchKernelGGL(epic_time_table_kernel, dim3(2 * n_intervals, d->layers), dim3(NT), 0, (hipStream_t)stream, blob,
-                           d->blob_floats, t_eval, scratch, temb_tab);
+        hipLaunchKernelGGL(epic_time_table_kernel, dim3(2 * n_intervals, d->layers + 1), dim3(NT), 0, (hipStream_t)stream, blob,
+                           d->blob_floats, t_eval, scratch, temb_tab, fast ? 1 : 0);
         if ((rc = check_hip(hipGetLastError(), "epic_time_table_kernel launch"))) return rc;
+    }
+    if (fast) {
+        const int* jet_order = queue_jet_pack(d, scratch, table_floats, mask, B, mode, (hipStream_t)stream);  // never pairs here
+        if (mode == 1)
+            hipLaunchKernelGGL(epic_sample_midpoint_fast_kernel<1>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, dt,
+                               n_intervals, z, mask, x_out, (const float*)scratch, jet_order);
+        else
+            hipLaunchKernelGGL(epic_sample_midpoint_fast_kernel<0>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, dt,
+                               n_intervals, z, mask, x_out, (const float*)scratch, jet_order);
+        return check_hip(hipGetLastError(), "epic_sample_midpoint_fast_kernel launch");
     }
 #define PFM_LAUNCH_SMP(M, T)                                                                                                  \
     hipLaunchKernelGGL((epic_sample_midpoint_kernel<M, T>), dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, \
                        t_eval, dt, n_intervals, z, cond, mask, x_out, (const float*)scratch, order, temb_tab)
-    const int* order = queue_jet_pack(d, scratch, (int64_t)2 * n_intervals * d->layers * TB_SLOT, mask, B, mode, (hipStream_t)stream);
+    const int* order = queue_jet_pack(d, scratch, table_floats, mask, B, mode, (hipStream_t)stream);
     if (tb) { if (mode == 2) PFM_LAUNCH_SMP(2, true); else if (mode == 1) PFM_LAUNCH_SMP(1, true); else PFM_LAUNCH_SMP(0, true); }
     else { if (mode == 2) PFM_LAUNCH_SMP(2, false); else if (mode == 1) PFM_LAUNCH_SMP(1, false); else PFM_LAUNCH_SMP(0, false); }
 #undef PFM_LAUNCH_SMP

@@ -145,9 +145,9 @@ struct Seg2Phase {
 // NEXT phases need (A fragments, per-jet GEMV panels) are requested during it.  A wave issues in order: 20 loads in a row at the
 // head of a phase hold EVERY wave back ~2.5k cycles (8 waves x 20 KiB through the 64 B/clk path) before its first MFMA -- measured
 // as the 2.9k + 3.5k cycles of load issue per layer in tests/diag/stamps.py.  gemm_phase therefore unrolls its pair loop (at most
-// MAXPAIRS pairs: the LDS tile holds <= 160 rows) and issues ONE load of the list behind every K-quarter of every pair: register
-// indices are compile-time constants and no wave ever queues more than one load at a time.  What a short jet cannot spread over its
-// few pairs is issued after the loop, as before.
+// MAXPAIRS pairs: the LDS tile holds <= 160 rows) and issues ONE load of the list (two for lists longer than 20) behind every
+// K-quarter of every pair: register indices are compile-time constants and a wave never queues more than that at a time.  What a
+// short jet cannot spread over its few pairs is issued after the loop, as before.
 constexpr int MAXPAIRS = 5;
 struct PfSeg {  // load i of a segment: bload4(rs, off + i * stride, lane_bytes)
     int64_t off;
@@ -172,6 +172,18 @@ struct Prefetch {
             issue<I0>();
             issue_range<I0 + 1, I1>();
         }
+    }
+    // Slot S (= 4 * pair + K-quarter) of a particle phase carries LPS loads of the list: one while the list fits the 4 * MAXPAIRS slots
+    // of a full-length jet, two for the longer lists (static: a runtime choice inside the pair bodies would cut their straight-line
+    // blocks apart -- measured: +4 % on a 10-tile jet).  The pairs a shorter jet does not have issue theirs behind the loop.
+    static constexpr int LPS = (COUNT + 19) / 20 > 0 ? (COUNT + 19) / 20 : 1;
+    template <int S>
+    __device__ __forceinline__ void issue_slot() const {
+        issue_range<(S * LPS < COUNT ? S * LPS : COUNT), ((S + 1) * LPS < COUNT ? (S + 1) * LPS : COUNT)>();
+    }
+    template <int P>
+    __device__ __forceinline__ void issue_pair() const {  // everything pair P would have carried
+        issue_range<(4 * P * LPS < COUNT ? 4 * P * LPS : COUNT), (4 * (P + 1) * LPS < COUNT ? 4 * (P + 1) * LPS : COUNT)>();
     }
 };
 using PfNone = Prefetch<0>;
@@ -357,11 +369,11 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
         constexpr int pair = (P);                                                                               \
         PFM_PAIR_BODY(PFM_MFMAQ, PFM_PFI_##P)                                                                   \
     }
-#define PFM_PFI_0(q) pf.template issue<0 + (q)>()
-#define PFM_PFI_1(q) pf.template issue<4 + (q)>()
-#define PFM_PFI_2(q) pf.template issue<8 + (q)>()
-#define PFM_PFI_3(q) pf.template issue<12 + (q)>()
-#define PFM_PFI_4(q) pf.template issue<16 + (q)>()
+#define PFM_PFI_0(q) pf.template issue_slot<0 + (q)>()
+#define PFM_PFI_1(q) pf.template issue_slot<4 + (q)>()
+#define PFM_PFI_2(q) pf.template issue_slot<8 + (q)>()
+#define PFM_PFI_3(q) pf.template issue_slot<12 + (q)>()
+#define PFM_PFI_4(q) pf.template issue_slot<16 + (q)>()
     static_assert(MAXPAIRS == 5, "unroll PFM_PAIR_AT to MAXPAIRS");
     PFM_PAIR_AT(0) PFM_PAIR_AT(1) PFM_PAIR_AT(2) PFM_PAIR_AT(3) PFM_PAIR_AT(4)
     if (nfull < npairs) {  // odd tile count: one real tile in the last pair
@@ -380,13 +392,12 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
 #undef PFM_LOADQ
 #undef PFM_MFMAQ
     epilogue(pacc0, pacc1, npairs - 1);
-    // the part of the prefetch list a short jet had no pairs for (and anything beyond 4 loads per pair)
-    if (nfull <= 0) pf.template issue_range<0, 4>();
-    if (nfull <= 1) pf.template issue_range<4, 8>();
-    if (nfull <= 2) pf.template issue_range<8, 12>();
-    if (nfull <= 3) pf.template issue_range<12, 16>();
-    if (nfull <= 4) pf.template issue_range<16, 20>();
-    pf.template issue_range<20, (PF::COUNT > 20 ? PF::COUNT : 20)>();
+    // the part of the prefetch list a short jet had no pairs for
+    if (nfull <= 0) pf.template issue_pair<0>();
+    if (nfull <= 1) pf.template issue_pair<1>();
+    if (nfull <= 2) pf.template issue_pair<2>();
+    if (nfull <= 3) pf.template issue_pair<3>();
+    if (nfull <= 4) pf.template issue_pair<4>();
     if (POOL) {
         pool_finish<SAVE>(psum, j, lds, c.vin, c.misc, oslot, pl, save_pool);
         if (NSEG == 2) pool_finish<false>(psumB, j, lds, s2.vin1, s2.misc1, oslot, pl, nullptr);

@@ -31,6 +31,7 @@ PFM_F_BF16_MFMA = 2
 PFM_F_F16X3_MFMA = 4
 PFM_F_TEMB_SINCOS = 8
 PFM_F_PACK_JETS = 16
+PFM_F_GENERIC_SAMPLER = 32  # keep the generic sampler kernel where the lean evaluation (csrc/epic_fast.h) would run
 
 
 class LocalLin(ctypes.Structure):
