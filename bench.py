@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 NFE_FLOP_PER_JET = 84.22e6     # algorithmic fwd FLOP / jet, dense over the padded N=150
 FP32_MFMA_PEAK = 157.3e12      # MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
-PMC_SUMMARIES = ("round2_pmc_hbm_summary.json", "round1_pmc_hbm_summary.json")  # profiles/: rocprofv3 --pmc passes of this command (tests/diag/collect_bench_profiles.sh), newest first
+PMC_SUMMARIES = ("round2_fast_pmc_hbm_summary.json", "round2_pmc_hbm_summary.json", "round1_pmc_hbm_summary.json")  # profiles/: rocprofv3 --pmc passes of this command (tests/diag/collect_bench_profiles.sh), newest first
 HP = dict(model="epic", features=3, hidden_dim=128, num_particles=150, frequencies=16, layers=6, latent=10,
           activation="leaky_relu", wrapper_func="weight_norm", t_local_cat=True, t_global_cat=True,
           add_time_to_input=False, t_emb="cosine", loss_type="FM-OT", sigma=1e-4, global_cond_dim=0,
@@ -323,10 +323,16 @@ def main():
         n_pad = (N + 15) // 16 * 16
         traffic = None
         pmc_file = None
+        # which kernel the sampler launches for this descriptor (csrc/epic_fast.h: the lean evaluation of unconditioned jets)
+        import ctypes
+        from particle_fm_amd import _lib
+        lay = model.flows[0].net.layout()
+        sampler_kernel = ("epic_sample_midpoint_fast_kernel<0>" if _lib.load().pfm_epic_sample_is_fast(ctypes.byref(lay.desc))
+                          else "epic_sample_midpoint_kernel<0, true>")
         for cand in PMC_SUMMARIES:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                pmc = next(v for k, v in pmc.items() if k.startswith("pfm::epic_sample_midpoint_kernel<0"))
+                pmc = next(v for k, v in pmc.items() if k.startswith("pfm::" + sampler_kernel.split("<")[0] + "<0"))
                 traffic, pmc_file = (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0, cand
                 break
             except Exception:
@@ -353,7 +359,7 @@ def main():
                            "roofline.kernel_alone_ms: the same work alone on the GPU after the timed region; train_jets_per_s uses "
                            "train_ms_alone",
             "roofline": {
-                "bound": "mfma", "kernel": "epic_sample_midpoint_kernel<0, true>",
+                "bound": "mfma", "kernel": sampler_kernel,
                 "achieved": executed / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": executed / FP32_MFMA_PEAK, "traffic": traffic,
                 "executed_flop_per_launch": exec_sample, "executed_flop_per_train_step": exec_train,

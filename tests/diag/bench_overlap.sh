@@ -1,8 +1,2 @@
-#!/bin/bash
-# bench.py at several overlap depths (sampling launches in flight), one summary line each.  Run on the GPU box.
-for d in 1 2 3 2 1; do
-  python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --overlap $d --no-cpu-baseline 2>/dev/null | python3 -c "
-import sys, json
-d = json.loads(sys.stdin.read())
-print('overlap $d', round(d['value'], 1), 'jets/s', round(d['ms_per_step'], 2), 'ms/step  sample_ms', round(d['sample_ms'], 2), 'train_ms', round(d['train_ms'], 2), 'frac', round(d['roofline']['frac'], 3))"
-done
+for o in 2 3 4; do python bench.py --steps 30 --warmup 5 --overlap $o 2>/dev/null > gpurun_out/ovl_$o.json; python -c "
+import json,sys;d=json.loads(open('gpurun_out/ovl_$o.json').read().strip().splitlines()[-1]);print('overlap $o',d['ms_per_step'],d['value'],d['sample_ms'],d['roofline']['frac'])"; done
