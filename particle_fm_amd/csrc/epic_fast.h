@@ -1,5 +1,5 @@
 // The midpoint sampler's lean evaluation ("fast path") for the headline configuration of the EPiC network: unconditioned jets
-// (cond_global = cond_local = 0), time embedding of width 32, F <= 4 features, fp32 or bf16 matrix operands.
+// (cond_global = cond_local = 0), time embedding of width 32, F <= 4 features, fp32 matrix operands.
 //
 // Reference graph: the same as epic_nfe.h (particle_fm/models/components/epic.py:304-391, :85-203).
 //

@@ -106,6 +106,208 @@ __global__ __launch_bounds__(256) void ew_pool_compact_kernel(const float* __res
         Q[(int64_t)jet * 2 * Hp + Hp + c] = s * scale;
     }
 }
+// ------------------------------------------------------------------------------------------------
+// The per-jet chain of a stage in ONE launch (inference): pool -> fc_global1 -> fc_global2 -> jet-bias rows, one workgroup per jet.
+//   Q  = [masked mean | masked sum * scale] of the jet's rows of X                      epic.py:108-117 / :331-339
+//   g1 = lrelu(Wg1 . [P256 | Q] + b)                                                    epic.py:180-182 / :375-377
+//   g  = lrelu(Wg2 . [P256 | g1] + b (+ g))  -> P[128 ..)                               epic.py:184-186 / :378-380
+//   JB = Wjb . P256 + b   (the time / conditioning / broadcast-g columns of fc_local1 | fc_local2 for this jet)
+// As row GEMMs over the B per-jet rows these were 6-7 launches per layer (three split-K GEMMs with their epilogues and the
+// pooling), each a few workgroups and ~5 us of launch + ramp latency: 126 of the 191 launches of a JetClass evaluation and 23 % of
+// its time (profiles/round1_cfg5_nfe_kernel_stats.csv).  Here every jet walks the chain on its own CU as GEMVs straight on the
+// MFMA_AK blocks (pfm_tf.h): a wave takes a 16-output block, lane (i, q) multiplies the float4 it would feed the matrix pipe with
+// (row 16 ob + i, k = 64 st + 16 kt + 4 q ..) by the matching float4 of the input vector in LDS -- coalesced 1 KB loads, no second
+// weight copy -- and the four q-partials meet by two wave shuffles.  Floor: the ~1.9 MB of weights per jet and layer crossing the
+// CU's 64 B/clk path (~13 us); measured 25 us per launch at 256 jets (every jet on its own CU), the same with 16 waves or deeper
+// load batches, 38 us with two jets per workgroup: the LDS operand reads and FMAs of a jet do not hide behind its loads.
+// STEM: the stem's chain (fc_g1 / fc_g2: no g input, no residual) runs first and the first layer's chain right behind it on the same
+// pooled vector (epic.py:369-385: the first layer pools the same x).
+// ------------------------------------------------------------------------------------------------
+struct ChainArgs {
+    const float *blob, *X, *mask;
+    const int* off;  // compacted rows: the jet's rows are [off[jet], off[jet+1]); nullptr: dense rows with `mask` (or all valid)
+    float *P, *JB;
+    pfm_ew_lin sg1, sg2, g1, g2, jb;
+    int Hp, N, ldp, nob_latent, B;  // nob_latent: 16-output blocks of fc_global2 that hold real outputs; B: jets of the launch
+    float scale, slope;
+};
+
+constexpr int CT = 512;       // threads of a chain workgroup (1024 measured the same 25 us)
+constexpr int CW = CT / 64;   // waves
+constexpr int JPW = 1;        // jets per workgroup (2: every weight float4 serves two jets -- measured 38 us against 25 us: the chain is
+                              // bound by the latency of each wave's dependent load -> FMA batches, not by L2 or the 64 B/clk path)
+constexpr int KQ = 4;         // K splits of fc_global1 (work items = output blocks x KQ)
+constexpr int VIN = 256 + 1024, VIN2 = 256 + 512;
+
+// NS k-steps of one output block for JPW input vectors: all 4 NS weight loads (1 KB per wave each) in flight before the first FMA
+template <int NS>
+__device__ __forceinline__ void chain_steps(f32x4 (&acc)[JPW][2], const float* __restrict__ wp, const float* __restrict__ xp, int xs) {
+    f32x4 wv[4 * NS];
+#pragma unroll
+    for (int i = 0; i < 4 * NS; ++i) wv[i] = *reinterpret_cast<const f32x4*>(wp + 256 * i);
+#pragma unroll
+    for (int i = 0; i < 4 * NS; ++i)
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj) acc[jj][i & 1] += wv[i] * *reinterpret_cast<const f32x4*>(xp + jj * xs + 16 * i);
+}
+
+// partial dot products of output block ob over the k-steps [st0, st1) of an MFMA_AK matrix with K = 64 * ksteps, for the JPW
+// input vectors vin + jj * xs: out[jj] = in every lane, the sum for output row 16 ob + (lane & 15)
+__device__ __forceinline__ void chain_block(float (&out)[JPW], const float* __restrict__ blob, int64_t W, int ksteps, int ob, int st0,
+                                            int st1, const float* __restrict__ vin, int xs, int lane) {
+    const int q = lane >> 4;
+    const float* wp = blob + W + ((int64_t)ob * ksteps + st0) * 1024 + lane * 4;
+    const float* xp = vin + 64 * st0 + 4 * q;
+    f32x4 acc[JPW][2];
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) acc[jj][0] = acc[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int n = st1 - st0;
+    for (; n >= 4; n -= 4, wp += 4096, xp += 256) chain_steps<4>(acc, wp, xp, xs);
+    if (n & 2) { chain_steps<2>(acc, wp, xp, xs); wp += 2048; xp += 128; }
+    if (n & 1) chain_steps<1>(acc, wp, xp, xs);
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        const f32x4 t = acc[jj][0] + acc[jj][1];
+        float v = (t.x + t.y) + (t.z + t.w);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        out[jj] = v;
+    }
+}
+
+// masked mean | masked sum * scale of one jet's rows of X into q[0 .. 2 Hp); ends behind a barrier
+__device__ __forceinline__ void chain_pool(const ChainArgs& a, int jet, float* __restrict__ q, float* __restrict__ red,
+                                           float* __restrict__ cnt) {
+    const int tid = threadIdx.x, cg = tid & 63, rg = tid >> 6;
+    const int Hp = a.Hp, nc4 = Hp >> 2;
+    const bool c0 = cg < nc4, c1 = cg + 64 < nc4;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float n = 0.f;
+    if (a.off) {
+        const int r0 = a.off[jet], r1 = a.off[jet + 1];
+        int r = r0 + rg;
+        for (; r + 3 * CW < r1; r += 4 * CW) {  // four rows in flight per thread
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            f32x4 u[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* xr = a.X + (int64_t)(r + CW * i) * Hp + 4 * cg;
+                u[i][0] = c0 ? *reinterpret_cast<const f32x4*>(xr) : z;
+                u[i][1] = c1 ? *reinterpret_cast<const f32x4*>(xr + 256) : z;
+            }
+            acc[0] += (u[0][0] + u[1][0]) + (u[2][0] + u[3][0]);
+            acc[1] += (u[0][1] + u[1][1]) + (u[2][1] + u[3][1]);
+        }
+        for (; r < r1; r += CW) {
+            const float* x0 = a.X + (int64_t)r * Hp + 4 * cg;
+            if (c0) acc[0] += *reinterpret_cast<const f32x4*>(x0);
+            if (c1) acc[1] += *reinterpret_cast<const f32x4*>(x0 + 256);
+        }
+        n = (float)(r1 - r0);  // every group knows the count
+    } else {
+        for (int r = rg; r < a.N; r += CW) {
+            const int64_t row = (int64_t)jet * a.N + r;
+            const float wgt = a.mask ? a.mask[row] : 1.0f;
+            n += wgt;
+            if (c0) acc[0] += wgt * *reinterpret_cast<const f32x4*>(a.X + row * Hp + 4 * cg);
+            if (c1) acc[1] += wgt * *reinterpret_cast<const f32x4*>(a.X + row * Hp + 4 * (cg + 64));
+        }
+    }
+    if (c0) *reinterpret_cast<f32x4*>(red + rg * 512 + 4 * cg) = acc[0];
+    if (c1) *reinterpret_cast<f32x4*>(red + rg * 512 + 4 * (cg + 64)) = acc[1];
+    if (cg == 0) cnt[rg] = n;
+    __syncthreads();
+    float nv = cnt[0];
+    if (!a.off)
+        for (int g = 1; g < CW; ++g) nv += cnt[g];
+    for (int c = tid; c < Hp; c += CT) {
+        float s = red[c];
+        for (int g = 1; g < CW; ++g) s += red[g * 512 + c];
+        q[c] = s / nv;
+        q[Hp + c] = s * a.scale;
+    }
+    __syncthreads();
+}
+
+template <bool STEM>
+__global__ __launch_bounds__(CT) void ew_chain_kernel(ChainArgs a) {
+    __shared__ __attribute__((aligned(16))) float vin[JPW * VIN];     // per jet [P256 | Q]
+    __shared__ __attribute__((aligned(16))) float vin2[JPW * VIN2];   // per jet [P256 | g1]
+    __shared__ __attribute__((aligned(16))) float red[CW * 512];      // pooling partials; then GEMV partials
+    __shared__ float cnt[CW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int Hp = a.Hp, nob = Hp >> 4;
+    // the workgroup's jets; an odd batch ends with a workgroup whose second jet repeats the first (same values stored twice)
+    int jets[JPW];
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) jets[jj] = min((int)blockIdx.x * JPW + jj, a.B - 1);
+    // ---- P256 = [temb | cond | 0 ; g | 0], pooled vector ----
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        if (tid < 256) {
+            const float v = a.P[(int64_t)jets[jj] * a.ldp + tid];
+            vin[jj * VIN + tid] = v;
+            vin2[jj * VIN2 + tid] = v;
+        }
+        chain_pool(a, jets[jj], vin + jj * VIN + 256, red, cnt);
+    }
+    const int ks1 = (256 + 2 * Hp) >> 6, ks2 = a.ldp >> 6;
+    for (int pass = STEM ? 0 : 1; pass < 2; ++pass) {
+        const bool stem = pass == 0;
+        const pfm_ew_lin& L1 = stem ? a.sg1 : a.g1;
+        const pfm_ew_lin& L2 = stem ? a.sg2 : a.g2;
+        // ---- fc_global1: items (output block, K quarter), partials red[jj][quarter][Hp] ----
+        for (int item = w; item < KQ * nob; item += CW) {
+            const int ob = item / KQ, h = item - ob * KQ;
+            float v[JPW];
+            chain_block(v, a.blob, L1.W, ks1, ob, ks1 * h / KQ, ks1 * (h + 1) / KQ, vin, VIN, lane);
+#pragma unroll
+            for (int jj = 0; jj < JPW; ++jj)
+                if (lane < 16) red[(jj * KQ + h) * 512 + 16 * ob + lane] = v[jj];
+        }
+        __syncthreads();
+        for (int c = tid; c < JPW * Hp; c += CT) {
+            const int jj = c / Hp, o = c - jj * Hp;
+            const float* r = red + (jj * KQ) * 512 + o;
+            vin2[jj * VIN2 + 256 + o] = lrelu(((r[0] + r[512]) + (r[1024] + r[1536])) + a.blob[L1.b + o], a.slope);
+        }
+        __syncthreads();
+        // ---- fc_global2: the blocks that hold real outputs, K split over the waves by k-step; partials red[jj][st][128] ----
+        for (int item = w; item < a.nob_latent * ks2; item += CW) {
+            const int ob = item / ks2, st = item - ob * ks2;
+            float v[JPW];
+            chain_block(v, a.blob, L2.W, ks2, ob, st, st + 1, vin2, VIN2, lane);
+#pragma unroll
+            for (int jj = 0; jj < JPW; ++jj)
+                if (lane < 16) red[(jj * 16 + st) * 128 + 16 * ob + lane] = v[jj];
+        }
+        __syncthreads();
+        if (tid < JPW * 128) {
+            const int jj = tid >> 7, o = tid & 127;
+            if (o < 16 * a.nob_latent) {
+                float v = red[(jj * 16) * 128 + o];
+                for (int st = 1; st < ks2; ++st) v += red[(jj * 16 + st) * 128 + o];
+                v += a.blob[L2.b + o];
+                if (!stem) v += vin[jj * VIN + 128 + o];  // residual before the activation, epic.py:184-186
+                v = lrelu(v, a.slope);
+                vin[jj * VIN + 128 + o] = v;   // the g the next Linear sees (and the next pass's g_old)
+                vin2[jj * VIN2 + 128 + o] = v;
+                if (!STEM || !stem) a.P[(int64_t)jets[jj] * a.ldp + 128 + o] = v;  // the next layer's chain reads it back
+            }
+        }
+        __syncthreads();
+    }
+    // ---- jet-bias rows: JB[jet] = Wjb . P256 + b, 2 Hp outputs, K = 256 ----
+    for (int ob = w; ob < 2 * nob; ob += CW) {
+        float v[JPW];
+        chain_block(v, a.blob, a.jb.W, 4, ob, 0, 4, vin, VIN, lane);
+        const float b = a.blob[a.jb.b + 16 * ob + (lane & 15)];
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj)
+            if (lane < 16) a.JB[(int64_t)jets[jj] * 2 * Hp + 16 * ob + lane] = v[jj] + b;
+    }
+}
+
 // masked rows of the output: 0 (or the state they start from), NaN for a jet without any valid particle (the
 // reference's 0/0 mean poisons the whole jet, epic.py:331-339)
 __global__ __launch_bounds__(256) void ew_fill_masked_kernel(const float* __restrict__ mask, const int* __restrict__ cnt,
@@ -273,16 +475,36 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
             hipLaunchKernelGGL(ew_pool_kernel, dim3(B), dim3(256), 0, p.s, (const float*)Xst(s), mask, Qst(s), N, Hp, d.sum_scale);
         return check_hip(hipGetLastError(), "ew_pool_kernel launch");
     };
-    PFM_TRY(pool(0));
-    PFM_TRY(linear(p, B, Pst(0), ldp, 256, Qst(0), 2 * Hp, 256 + 2 * Hp, d.sg1, Hp, nullptr, 0, 1, nullptr, 0, Pst(0) + 256, ldp, 1));
-    PFM_TRY(linear(p, B, Pst(0), ldp, ldp, nullptr, 0, ldp, d.sg2, 128, nullptr, 0, 1, nullptr, 0, Pst(0) + 128, ldp, 1));
+    // inference: the per-jet chain of a stage is ONE launch (ew_chain_kernel); training keeps the row GEMMs, whose per-stage P / Q the
+    // backward re-reads
+    const bool fused_chain = !w.pstride && B <= 65535;
+    auto chain = [&](int l) {
+        const pfm_ew_layer& L = d.layer[l];
+        ChainArgs a;
+        a.blob = p.blob; a.X = Xst(0); a.mask = p.off ? nullptr : mask; a.off = p.off; a.P = Pst(0); a.JB = JB;
+        a.sg1 = d.sg1; a.sg2 = d.sg2; a.g1 = L.g1; a.g2 = L.g2; a.jb = L.jb;
+        a.Hp = Hp; a.N = N; a.ldp = ldp; a.nob_latent = (d.latent + 15) / 16; a.B = B; a.scale = d.sum_scale; a.slope = d.neg_slope;
+        const dim3 grid((B + JPW - 1) / JPW);
+        if (l == 0) hipLaunchKernelGGL(ew_chain_kernel<true>, grid, dim3(CT), 0, p.s, a);
+        else hipLaunchKernelGGL(ew_chain_kernel<false>, grid, dim3(CT), 0, p.s, a);
+        return check_hip(hipGetLastError(), "ew_chain_kernel launch");
+    };
+    if (!fused_chain || d.layers == 0) {
+        PFM_TRY(pool(0));
+        PFM_TRY(linear(p, B, Pst(0), ldp, 256, Qst(0), 2 * Hp, 256 + 2 * Hp, d.sg1, Hp, nullptr, 0, 1, nullptr, 0, Pst(0) + 256, ldp, 1));
+        PFM_TRY(linear(p, B, Pst(0), ldp, ldp, nullptr, 0, ldp, d.sg2, 128, nullptr, 0, 1, nullptr, 0, Pst(0) + 128, ldp, 1));
+    }
     for (int l = 0; l < d.layers; ++l) {
         const pfm_ew_layer& L = d.layer[l];
         float *Pin = Pst(l), *Pout = Pst(l + 1);  // the same row set at inference
-        if (l) PFM_TRY(pool(l));
-        PFM_TRY(linear(p, B, Pin, ldp, 256, Qst(l), 2 * Hp, 256 + 2 * Hp, L.g1, Hp, nullptr, 0, 1, nullptr, 0, Pout + 256, ldp, 1));
-        PFM_TRY(linear(p, B, Pout, ldp, ldp, nullptr, 0, ldp, L.g2, 128, nullptr, 0, 1, Pin + 128, ldp, Pout + 128, ldp, 2));
-        PFM_TRY(linear(p, B, Pout, ldp, 256, nullptr, 0, 256, L.jb, 2 * Hp, nullptr, 0, 1, nullptr, 0, JB, 2 * Hp, 0));
+        if (fused_chain) {
+            PFM_TRY(chain(l));
+        } else {
+            if (l) PFM_TRY(pool(l));
+            PFM_TRY(linear(p, B, Pin, ldp, 256, Qst(l), 2 * Hp, 256 + 2 * Hp, L.g1, Hp, nullptr, 0, 1, nullptr, 0, Pout + 256, ldp, 1));
+            PFM_TRY(linear(p, B, Pout, ldp, ldp, nullptr, 0, ldp, L.g2, 128, nullptr, 0, 1, Pin + 128, ldp, Pout + 128, ldp, 2));
+            PFM_TRY(linear(p, B, Pout, ldp, 256, nullptr, 0, 256, L.jb, 2 * Hp, nullptr, 0, 1, nullptr, 0, JB, 2 * Hp, 0));
+        }
         float* L1 = ws + w.L1 + w.lstride * l;
         PFM_TRY(linear(p, p.M, Xst(l), Hp, Hp, nullptr, 0, Hp, L.l1, Hp, JB, 2 * Hp, N, nullptr, 0, L1, Hp, 1));
         PFM_TRY(linear(p, p.M, L1, Hp, Hp, nullptr, 0, Hp, L.l2, Hp, JB + Hp, 2 * Hp, N, Xst(l), Hp, Xst(l + 1), Hp, 2));

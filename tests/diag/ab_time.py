@@ -15,7 +15,8 @@ from particle_fm_amd.hip_ops import midpoint_grid
 P = ctypes.c_void_p
 g = load_golden("jetnet150")
 hp = dict(g.hp); hp["num_particles"] = 150
-lay = EpicLayout(cfg_of(hp), flags=1)  # PFM_F_SKIP_MASKED_TAIL
+FLAGS = int(os.environ.get("PFM_FLAGS", "1"))  # 1 SKIP_MASKED_TAIL | 2 BF16 | 32 GENERIC_SAMPLER ...
+lay = EpicLayout(cfg_of(hp), flags=FLAGS)
 blob = lay.pack_blob(g.state, "flows.0.net.").cuda()
 ts, dts = midpoint_grid(100)
 ts, dts = ts.cuda(), dts.cuda()
