@@ -67,4 +67,8 @@ for k, v_ in tot.items():
     print(f"{k:50s} n={len(v_):2d} mean {sum(v_)/len(v_):8.1f} ticks  sum {sum(v_):7d}  ({100*sum(v_)/total:.1f}%)")
 
 marks = [buf[384 + i] for i in range(8)]
-print("per-jet marks (last layer), deltas:", [marks[i + 1] - marks[i] for i in range(6)])
+deltas = [marks[i + 1] - marks[i] for i in range(6)]
+if all(0 <= d_ < 1 << 24 for d_ in deltas):  # the generic chain's PFM_MARKs; the lean chain (epic_fast.h) sets none
+    print("per-jet marks (last layer), deltas:", deltas)
+print("NOTE: the -DPFM_DIAG build runs ~25 % slower than the shipped one (its stamp stores cut the scheduling regions): use these numbers "
+      "for proportions; absolute per-piece costs come from ablation builds (tests/diag/ab_time.py)")
