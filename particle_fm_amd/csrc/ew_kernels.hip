@@ -817,49 +817,49 @@ int pfm_ew_sample_midpoint(const pfm_ew_desc* d, const float* blob, const float*
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
     // Two half-batches on two streams, their launches interleaved evaluation by evaluation (tf_common.h: side_stream)
     const int n_a = split_point(n_jets, 32);
-    SideStream* ss = n_a ? side_stream() : nullptr;
+    SideStream* ss = n_a ? side_stream((hipStream_t)stream) : nullptr;
     const int parts = ss ? 2 : 1;
     ew::Plan p[2];
     float *xs[2], *xm[2];
     const float *cnd[2], *msk[2];
     int64_t n[2], r0[2];
-    // both halves run on the device's two side streams (never on one hardware queue together); the caller's stream forks and joins
+    // both halves run on the two side streams of this caller stream (never on one hardware queue together); the caller's stream forks and joins
     if (ss && (hipEventRecord(ss->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess ||
                hipStreamWaitEvent(ss->s2, ss->fork, 0) != hipSuccess))
         return set_err(PFM_E_BADARG, "side stream fork failed");
-    for (int i = 0; i < parts; ++i) {
-        const int j0 = i ? n_a : 0, nj = parts == 1 ? n_jets : (i ? n_jets - n_a : n_a);
-        float* ws = workspace + (i ? ew::make_ws(*d, n_a, false).total : 0);
-        if ((rc = ew::make_plan(p[i], d, blob, ws, nj, false, ss ? (void*)(i ? ss->s2 : ss->s) : stream))) return rc;
-        r0[i] = (int64_t)j0 * d->n_points;
-        n[i] = (int64_t)p[i].M * d->features;
-        xs[i] = state + 2 * r0[i] * d->features;
-        xm[i] = xs[i] + n[i];
-        cnd[i] = cond ? cond + (int64_t)j0 * d->cond_global : nullptr;
-        msk[i] = mask ? mask + r0[i] : nullptr;
-        hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n[i] + 255) / 256)), dim3(256), 0, p[i].s, z + r0[i] * d->features,
-                           premask ? msk[i] : nullptr, xs[i], n[i], d->features);
-        if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
-        if (mask && (rc = ew::setup_compaction(p[i], msk[i]))) return rc;
-    }
-    for (int k = 0; k < n_steps; ++k)
-        for (int stage = 0; stage < 2; ++stage)
-            for (int i = 0; i < parts; ++i) {
-                ew::HeadArgs h{};
-                h.base = xs[i]; h.dt = dt + k; h.coef = stage ? 1.0f : 0.5f; h.dst = stage ? xs[i] : xm[i];
-                if ((rc = ew::run_nfe(p[i], t_eval + 2 * k + stage, 0, stage ? xm[i] : xs[i], cnd[i], msk[i], h))) return rc;
-            }
-    for (int i = 0; i < parts; ++i)
-        if ((rc = check_hip(hipMemcpyAsync(x_out + r0[i] * d->features, xs[i], n[i] * sizeof(float), hipMemcpyDeviceToDevice, p[i].s),
-                            "copy x_out")))
-            return rc;
-    if (ss) {
-        hipEventRecord(ss->join, ss->s);
-        hipEventRecord(ss->join2, ss->s2);
-        hipStreamWaitEvent((hipStream_t)stream, ss->join, 0);
-        hipStreamWaitEvent((hipStream_t)stream, ss->join2, 0);
-    }
-    return 0;
+    // everything between fork and join: an error return still joins (the caller stream must not overtake the side streams' work)
+    rc = [&]() -> int {
+        int rc = 0;
+        for (int i = 0; i < parts; ++i) {
+            const int j0 = i ? n_a : 0, nj = parts == 1 ? n_jets : (i ? n_jets - n_a : n_a);
+            float* ws = workspace + (i ? ew::make_ws(*d, n_a, false).total : 0);
+            if ((rc = ew::make_plan(p[i], d, blob, ws, nj, false, ss ? (void*)(i ? ss->s2 : ss->s) : stream))) return rc;
+            r0[i] = (int64_t)j0 * d->n_points;
+            n[i] = (int64_t)p[i].M * d->features;
+            xs[i] = state + 2 * r0[i] * d->features;
+            xm[i] = xs[i] + n[i];
+            cnd[i] = cond ? cond + (int64_t)j0 * d->cond_global : nullptr;
+            msk[i] = mask ? mask + r0[i] : nullptr;
+            hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n[i] + 255) / 256)), dim3(256), 0, p[i].s, z + r0[i] * d->features,
+                               premask ? msk[i] : nullptr, xs[i], n[i], d->features);
+            if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+            if (mask && (rc = ew::setup_compaction(p[i], msk[i]))) return rc;
+        }
+        for (int k = 0; k < n_steps; ++k)
+            for (int stage = 0; stage < 2; ++stage)
+                for (int i = 0; i < parts; ++i) {
+                    ew::HeadArgs h{};
+                    h.base = xs[i]; h.dt = dt + k; h.coef = stage ? 1.0f : 0.5f; h.dst = stage ? xs[i] : xm[i];
+                    if ((rc = ew::run_nfe(p[i], t_eval + 2 * k + stage, 0, stage ? xm[i] : xs[i], cnd[i], msk[i], h))) return rc;
+                }
+        for (int i = 0; i < parts; ++i)
+            if ((rc = check_hip(hipMemcpyAsync(x_out + r0[i] * d->features, xs[i], n[i] * sizeof(float), hipMemcpyDeviceToDevice, p[i].s),
+                                "copy x_out")))
+                return rc;
+        return 0;
+    }();
+    side_join(ss, (hipStream_t)stream);
+    return rc;
 }
 
 static int ew_sample_rk(const pfm_ew_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,

@@ -84,12 +84,27 @@ struct SideStream {
     hipStream_t s = nullptr, s2 = nullptr;  // two streams measured to run side by side (the caller's stream only forks / joins)
     hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
 };
-inline SideStream* side_stream() {
-    static SideStream st[16];
+// One pair of side streams per CALLER stream (up to SIDE_PAIRS per device; later caller streams share the last pair): two sampler calls
+// in flight from different caller streams (generate_data's batch pipeline, bench_secondary --overlap) then run side by side
+// instead of queueing on one pair.  Creation is serialised by a mutex (two host threads may enter a sampler at once).
+constexpr int SIDE_PAIRS = 4;
+inline SideStream* side_stream(hipStream_t caller) {
+    struct PerDev {
+        SideStream pair[SIDE_PAIRS];
+        hipStream_t owner[SIDE_PAIRS] = {};
+        int n = 0;
+    };
+    static PerDev st[16];
+    static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SideStream& e = st[dev];
-    if (!e.s) {
+    std::lock_guard<std::mutex> lock(mu);
+    PerDev& pd = st[dev];
+    for (int i = 0; i < pd.n; ++i)
+        if (pd.owner[i] == caller) return &pd.pair[i];
+    if (pd.n == SIDE_PAIRS) return &pd.pair[SIDE_PAIRS - 1];
+    SideStream e;
+    {
         // candidates are kept alive until both choices are made (a destroyed stream's queue would be dealt to the next one again);
         // s must overlap with the null stream (where callers without a stream of their own run their other work), s2 with both
         hipStream_t cand[8] = {};
@@ -111,12 +126,21 @@ inline SideStream* side_stream() {
         e.s2 = b >= 0 ? cand[b] : nullptr;
         if (!e.s || !e.s2 || hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e.join2, hipEventDisableTiming) != hipSuccess) {
-            e.s = nullptr;
+            hipEventCreateWithFlags(&e.join2, hipEventDisableTiming) != hipSuccess)
             return nullptr;
-        }
     }
-    return &e;
+    pd.pair[pd.n] = e;
+    pd.owner[pd.n] = caller;
+    return &pd.pair[pd.n++];
+}
+// the caller's stream waits for whatever the two side streams have queued so far (the normal end of a call, and every error return
+// after the fork: the caller stream must never run ahead of half-finished side work)
+inline void side_join(SideStream* ss, hipStream_t caller) {
+    if (!ss) return;
+    hipEventRecord(ss->join, ss->s);
+    hipEventRecord(ss->join2, ss->s2);
+    hipStreamWaitEvent(caller, ss->join, 0);
+    hipStreamWaitEvent(caller, ss->join2, 0);
 }
 // ---- graph replay of a sampler's step body (PFM_CA_F_GRAPH_STEPS) ------------------------------------------------------------
 // One midpoint step of the row-matrix models is hundreds of launches of 5-20 us and the host needs ~10 us to enqueue each, so
