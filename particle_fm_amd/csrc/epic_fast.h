@@ -1,5 +1,5 @@
 // The midpoint sampler's lean evaluation ("fast path") for the headline configuration of the EPiC network: unconditioned jets
-// (cond_global = cond_local = 0), time embedding of width 32, F <= 4 features, fp32 matrix operands.
+// (cond_global = cond_local = 0), time embedding of width 32, F <= 4 features, fp32 or bf16 matrix operands.
 //
 // Reference graph: the same as epic_nfe.h (particle_fm/models/components/epic.py:304-391, :85-203).
 //
@@ -38,7 +38,8 @@ constexpr int TB_SJ1 = 0, TB_SJ2 = 128, TB_SG1 = 256, TB_SG2 = 384, TB_SB3 = 400
 
 __host__ __device__ inline bool fast_path_ok(const pfm_epic_desc& d) {
     return d.t_dim == FT && d.cond_global == 0 && d.cond_local == 0 && d.features <= 4 && d.layers > 0 &&
-           !(d.flags & (PFM_F_F16X3_MFMA | PFM_F_PACK_JETS | PFM_F_GENERIC_SAMPLER));
+           !(d.flags & (PFM_F_F16X3_MFMA | PFM_F_PACK_JETS | PFM_F_GENERIC_SAMPLER)) &&
+           ((int64_t)make_carve(d.n_points, d.features).total + 288) * 4 <= 163840;  // + TBL_FLOATS behind the carve
 }
 
 // fc_l1: bufA[p][o] = lrelu(bj1[o] + sum_f Wx[f][o] * y[p][f])   epic.py:360-362, on the matrix pipe (K = F padded to 4).
@@ -64,22 +65,34 @@ __device__ __forceinline__ void fast_stem_l1(const JetDims& j, float* __restrict
     }
 }
 
-// The few loads of a per-jet chain that are not weight panels: this thread's row of fc_global2 and its slices of the tabulated
-// bias + time terms.  Requested a whole particle phase ahead (a load waited for right behind its request costs an L2 round trip
-// with the matrix pipe idle -- and a vmcnt wait also waits for every weight load queued before it).
+// The few loads of a per-jet chain that are not weight panels: this thread's row of fc_global2, and the tabulated bias + time terms
+// of the chain's three Linears.  Requested a whole particle phase ahead (a load waited for right behind its request costs an L2 round
+// trip with the matrix pipe idle -- and a vmcnt wait also waits for every weight load queued before it).  The table rows (272 floats
+// per chain) do not stay in registers for that phase: 68 threads fetch one float4 each (`stg`) and publish it to a small LDS area
+// behind the carve (`tbl`) right before the barrier that precedes the chain, which reads its slices with ds_read (no vmcnt at all).
+constexpr int TBL_G1 = 0, TBL_L1 = 128, TBL_G2 = 256, TBL_FLOATS = 288;  // LDS floats behind Carve::total
 struct ChainLoads {
-    f32x4 w2, bg1, bg2, bl1;
+    f32x4 w2;   // row FT + 16 w + pt of fc_global2 (KP16), outputs 4 o4..
+    f32x4 stg;  // threads 0..67: one float4 of [G1 (128) | L1 (128) | G2 (16)]
 };
-__device__ __forceinline__ ChainLoads fast_chain_loads(blob_rsrc rs, int64_t gl2_W, const float* __restrict__ tg1,
-                                                       const float* __restrict__ tg2, const float* __restrict__ tl1) {
+// slot: the table slot of the chain; o_g1 / o_l1 / o_g2: where its three rows start inside the slot (layer slot: TB_G1 / TB_L1 /
+// TB_G2; stem slot: TB_SG1 / (none: pass o_g1) / TB_SG2)
+__device__ __forceinline__ ChainLoads fast_chain_loads(blob_rsrc rs, int64_t gl2_W, const float* __restrict__ slot, int o_g1, int o_l1, int o_g2) {
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
-    const int og = tid >> 4, pt = tid & 15, o4 = lane >> 4;
+    const int pt = tid & 15, o4 = lane >> 4;
     ChainLoads L;
-    L.w2 = bload4(rs, gl2_W + (int64_t)FT * 16, ((16 * w + pt) * 16 + 4 * o4) * 4);  // row FT + 16 w + pt, outputs 4 o4..
-    L.bg1 = *reinterpret_cast<const f32x4*>(tg1 + 4 * og);
-    L.bg2 = *reinterpret_cast<const f32x4*>(tg2 + 4 * o4);
-    L.bl1 = *reinterpret_cast<const f32x4*>(tl1 + 4 * og);
+    L.w2 = bload4(rs, gl2_W + (int64_t)FT * 16, ((16 * w + pt) * 16 + 4 * o4) * 4);
+    L.stg = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 68) {
+        const int off = tid < 32 ? o_g1 + 4 * tid : (tid < 64 ? o_l1 + 4 * (tid - 32) : o_g2 + 4 * (tid - 64));
+        L.stg = *reinterpret_cast<const f32x4*>(slot + off);
+    }
     return L;
+}
+// a barrier must separate this from the previous chain's last read of tbl, and another one from the next chain's reads
+__device__ __forceinline__ void fast_chain_publish(const ChainLoads& L, float* __restrict__ tbl) {
+    const int tid = launder(threadIdx.x);
+    if (tid < 68) *reinterpret_cast<f32x4*>(tbl + (tid < 64 ? 4 * tid : TBL_G2 + 4 * (tid - 64))) = L.stg;
 }
 
 // sum of the eight wave partials of fc_global2 in wave order; all eight reads in flight before the first add
@@ -97,9 +110,9 @@ __device__ __forceinline__ f32x4 fast_sum_partials(const float* __restrict__ g2p
 // Stem chain: g = lrelu(Wg2 . lrelu(Wg1 . [mean ; sum] + tg1) + tg2), tg* = bias + time term (table).  epic.py:369-380
 // In: vin.mean / vin.sum (written by the fc_l2 phase, barrier passed), gl = this thread's rows of fc_g1 behind the time rows.
 // after_fc1(): called once gl has been consumed (the caller requests the first layer's windows there).  Out: vin.g.  Ends with a barrier.
-template <typename After>
+template <typename After, typename Publish>
 __device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restrict__ lds, const Carve& c, const f32x4 (&gl)[FNG],
-                                                const ChainLoads& L, After after_fc1) {
+                                                const ChainLoads& L, const float* __restrict__ tbl, After after_fc1, Publish publish_next) {
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int og = tid >> 4, pt = tid & 15, o4 = lane >> 4;
     const float* vp = lds + c.vin + FT + pt;
@@ -109,15 +122,17 @@ __device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restr
     for (int u = 1; u < FNGS; ++u) p += gl[u] * vp[16 * u];
     after_fc1();
     p = reduce_pt(p);
-    if (pt == 0) *reinterpret_cast<f32x4*>(vin2 + FT + 4 * og) = lrelu4(p + L.bg1, j.slope);
+    if (pt == 0) *reinterpret_cast<f32x4*>(vin2 + FT + 4 * og) = lrelu4(p + *reinterpret_cast<const f32x4*>(tbl + TBL_G1 + 4 * og), j.slope);
     __syncthreads();
+    const f32x4 bg2 = *reinterpret_cast<const f32x4*>(tbl + TBL_G2 + 4 * o4);  // before the next chain's rows replace these
     f32x4 gp = L.w2 * vin2[FT + 16 * w + pt];
     gp = row_sum16(gp);
     if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.g2p + MAXL * w + 4 * o4) = gp;
     __syncthreads();
+    publish_next();  // every read of this chain's table rows lies before the barrier above
     if (w == 0) {
         f32x4 gn = fast_sum_partials(lds + c.g2p + 4 * o4);
-        gn = lrelu4(gn + L.bg2, j.slope);
+        gn = lrelu4(gn + bg2, j.slope);
         if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.vin + FT + 2 * H + 4 * o4) = gn;
     }
     __syncthreads();
@@ -128,7 +143,7 @@ __device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restr
 // In: vin = [.. ; mean ; sum ; g_old], gl = rows of fc_global1 behind the time rows, wbA = row FT + pt of local linear 1's extras.
 // Out: vin.g = g_new, bj1 (each wave its own slice: the particle phase that follows needs no barrier).
 __device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __restrict__ lds, const Carve& c, const f32x4 (&gl)[FNG],
-                                                 const f32x4& wbA, const ChainLoads& L) {
+                                                 const f32x4& wbA, const f32x4& w2, const float* __restrict__ tbl) {
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int og = tid >> 4, pt = tid & 15, o4 = lane >> 4;
     const float* vin = lds + c.vin;
@@ -139,14 +154,14 @@ __device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __rest
 #pragma unroll
     for (int u = 1; u < FNG; ++u) p += gl[u] * vp[16 * u];
     p = reduce_pt(p);
-    if (pt == 0) *reinterpret_cast<f32x4*>(vin2 + FT + 4 * og) = lrelu4(p + L.bg1, j.slope);
+    if (pt == 0) *reinterpret_cast<f32x4*>(vin2 + FT + 4 * og) = lrelu4(p + *reinterpret_cast<const f32x4*>(tbl + TBL_G1 + 4 * og), j.slope);
     __syncthreads();
-    f32x4 gp = L.w2 * vin2[FT + 16 * w + pt];
+    f32x4 gp = w2 * vin2[FT + 16 * w + pt];
     gp = row_sum16(gp);
     if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.g2p + MAXL * w + 4 * o4) = gp;
     __syncthreads();
     f32x4 gn = fast_sum_partials(lds + c.g2p + 4 * o4);
-    gn += L.bg2;
+    gn += *reinterpret_cast<const f32x4*>(tbl + TBL_G2 + 4 * o4);
     gn += gold;  // residual before the activation, epic.py:184-186
     gn = lrelu4(gn, j.slope);
     // each wave keeps its own copy of g_new (read back as the input of the bias GEMV: same wave, LDS is in order); wave 0's copy
@@ -155,7 +170,7 @@ __device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __rest
     if (pt == 0) *reinterpret_cast<f32x4*>(gcopy + 4 * o4) = gn;
     f32x4 p1 = wbA * gcopy[pt];  // entries >= L are lrelu(0) = 0 (zero-padded weights and biases)
     p1 = reduce_pt(p1);
-    if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.bj1 + 4 * og) = p1 + L.bl1;
+    if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.bj1 + 4 * og) = p1 + *reinterpret_cast<const f32x4*>(tbl + TBL_L1 + 4 * og);
 }
 
 // fc_l3 head with its per-jet bias from the table and its weights already in registers (requested during the last particle
@@ -228,8 +243,9 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
     f32x4 gl[FNG], wbA[1];
     PFM_STAMP(1);
+    float* tbl = lds + c.total;  // TBL_FLOATS behind the carve (fast_path_ok: it fits)
     // the stem chain's own loads, two phases ahead of their use
-    ChainLoads L = fast_chain_loads(rs, d.g2.W, tbS + TB_SG1, tbS + TB_SG2, tbS + TB_SG1);
+    ChainLoads L = fast_chain_loads(rs, d.g2.W, tbS, TB_SG1, TB_SG1, TB_SG2);
     const f32x4 b3 = *reinterpret_cast<const f32x4*>(tbS + TB_SB3 + 4 * (lane >> 4));  // head bias, zero for f >= F
     fast_stem_l1(j, lds, c, n_rows, cy.aw, cy.sj1);
     __syncthreads();
@@ -240,17 +256,20 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         gemm_phase<true, true, false, BF16, decltype(pf)>(cy.a2, bufA, bufB, bufA, tbS + TB_SJ2, maskf, j, lds, c, nullptr, nullptr,
                                                            n_rows, pf);
     }
+    fast_chain_publish(L, tbl);  // (the previous evaluation's last chain read tbl many barriers ago)
     __syncthreads();
     PFM_STAMP(4);
     {
         const pfm_epic_layer& l0 = d.layer[0];
-        fast_chain_stem(j, lds, c, gl, L, [&]() {
-            // the first layer's windows and phase-1 weights: no particle phase to ride on; they land behind the rest of the stem chain
+        ChainLoads L0;
+        fast_chain_stem(j, lds, c, gl, L, tbl, [&]() {
+            // the first layer's windows, phase-1 weights and chain loads: no particle phase to ride on; they land behind the rest of the stem chain
             Prefetch<FNG, 1> pf{rs, gl, wbA, nullptr, nullptr, seg_panels(l0.gl1.W, FTP, tid), seg_panels(l0.lc1.We, FTP, tid), {}, {}};
             pf.template issue_range<0, FNG + 1>();
             load_afrag(cy.a1, rs, l0.lc1.A, w, lane);
-        });
-        L = fast_chain_loads(rs, l0.gl2.W, tbE + TB_G1, tbE + TB_G2, tbE + TB_L1);
+            L0 = fast_chain_loads(rs, l0.gl2.W, tbE, TB_G1, TB_L1, TB_G2);
+        }, [&]() { fast_chain_publish(L0, tbl); });
+        L.w2 = L0.w2;
     }
     for (int k = 0; k < j.layers; ++k) {
         const pfm_epic_layer ly = d.layer[k];  // by value: the offset dwords in one batch of scalar loads
@@ -259,7 +278,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         const float* tbK = tbE + (size_t)k * TB_SLOT;
         const float* tbN = tbE + (size_t)(last ? k : k + 1) * TB_SLOT;
         PFM_STAMP(10);
-        fast_chain_layer(j, lds, c, gl, wbA[0], L);
+        fast_chain_layer(j, lds, c, gl, wbA[0], L.w2, tbl);
         PFM_STAMP(12);
         // phase 1: bufA = lrelu(W1 . bufB + bj1)   epic.py:194-196.  Riders: phase 2's weights and ALL per-jet windows of the next
         // layer (gl / wbA were consumed by the chain above), so that nothing the next chain waits for is requested late
@@ -271,7 +290,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         }
         __syncthreads();
         PFM_STAMP(13);
-        L = fast_chain_loads(rs, nx.gl2.W, tbN + TB_G1, tbN + TB_G2, tbN + TB_L1);  // the next chain's loads, a phase ahead
+        L = fast_chain_loads(rs, nx.gl2.W, tbN, TB_G1, TB_L1, TB_G2);  // the next chain's loads, a phase ahead
         // phase 2: bufB = lrelu(W2 . bufA + bj2 + bufB), pooled -> vin    epic.py:198-200, :160-162
         // (bj2 = bias + time term: constant per evaluation and layer, read from the table).  Riders: the next layer's phase-1
         // weights, or the head's one 16-row panel behind the last layer, into a1 (free since phase 1)
@@ -281,6 +300,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
             gemm_phase<true, true, false, BF16, decltype(pf)>(cy.a2, bufA, bufB, bufB, tbK + TB_L2, maskf, j, lds, c, nullptr, nullptr,
                                                                n_rows, pf);
         }
+        fast_chain_publish(L, tbl);  // this layer's chain read tbl two barriers ago; the next one reads it behind the barrier below
         __syncthreads();
     }
     PFM_STAMP(20);

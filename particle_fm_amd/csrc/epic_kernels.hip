@@ -276,8 +276,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same integrator on the lean evaluation of epic_fast.h (unconditioned jets, T = 32, F <= 4; fp32 operands; MODE 1 = bf16
-// operands compiles and passes parity but is not dispatched, see sample_fast): one jet per
+// The same integrator on the lean evaluation of epic_fast.h (unconditioned jets, T = 32, F <= 4; fp32 or bf16 operands): one jet per
 // workgroup, jets in descending multiplicity (`pack`), every time-only term from the fast-format table.
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
@@ -601,9 +600,7 @@ int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc* d, int32_t n_interva
 
 static bool sample_fast(const pfm_epic_desc* d, int mode) {
     static const char* env_pack = getenv("PFM_PACK");  // diagnostic switch of tests/diag/pack_time.py: packing implies the generic kernel
-    // fp32 operands only: with bf16 operands the lean body measured slower on short jets (8.1 vs 7.9 ms per 100-step sample at 32
-    // particles; 12.0 vs 12.3 at 150): its register budget has no room for the packed operand copies and it spills
-    return d && d->layers > 0 && fast_path_ok(*d) && mode == 0 && !(env_pack && env_pack[0] == '1');
+    return d && d->layers > 0 && fast_path_ok(*d) && mode != 2 && !(env_pack && env_pack[0] == '1');
 }
 int pfm_epic_sample_is_fast(const pfm_epic_desc* d) { return validate(d) == 0 && sample_fast(d, mfma_mode(d)) ? 1 : 0; }
 
@@ -653,7 +650,11 @@ static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const floa
     // the lean evaluation of epic_fast.h: unconditioned jets, T = 32, F <= 4, fp32 / bf16 operands, one jet per workgroup
     const bool fast = tb && sample_fast(d, mode);
     if (fast) {
-        if ((rc = prepare(epic_sample_midpoint_fast_kernel<0>, d, &lds))) return rc;
+        if ((rc = mode == 1 ? prepare(epic_sample_midpoint_fast_kernel<1>, d, &lds) : prepare(epic_sample_midpoint_fast_kernel<0>, d, &lds))) return rc;
+        lds += TBL_FLOATS * 4;  // the chain's table rows behind the carve (fast_path_ok checked that it fits)
+        const hipError_t e1 = mode == 1 ? hipFuncSetAttribute(reinterpret_cast<const void*>(epic_sample_midpoint_fast_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+                                        : hipFuncSetAttribute(reinterpret_cast<const void*>(epic_sample_midpoint_fast_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if ((rc = check_hip(e1, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))) return rc;
     }
     if (tb && n_intervals > 0) {
         hipLaunchKernelGGL(epic_time_table_kernel, dim3(2 * n_intervals, d->layers + 1), dim3(NT), 0, (hipStream_t)stream, blob,
@@ -662,8 +663,12 @@ static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const floa
     }
     if (fast) {
         const int* jet_order = queue_jet_pack(d, scratch, table_floats, mask, B, mode, (hipStream_t)stream);  // never pairs here
-        hipLaunchKernelGGL(epic_sample_midpoint_fast_kernel<0>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, dt,
-                           n_intervals, z, mask, x_out, (const float*)scratch, jet_order);
+        if (mode == 1)
+            hipLaunchKernelGGL(epic_sample_midpoint_fast_kernel<1>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, dt,
+                               n_intervals, z, mask, x_out, (const float*)scratch, jet_order);
+        else
+            hipLaunchKernelGGL(epic_sample_midpoint_fast_kernel<0>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, dt,
+                               n_intervals, z, mask, x_out, (const float*)scratch, jet_order);
         return check_hip(hipGetLastError(), "epic_sample_midpoint_fast_kernel launch");
     }
 #define PFM_LAUNCH_SMP(M, T)                                                                                                  \

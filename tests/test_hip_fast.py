@@ -44,7 +44,7 @@ def test_path_selection():
     g = load_golden("jetnet150")
     assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL)) == 1
     assert q(EpicLayout(cfg_of(g.hp), flags=0)) == 1
-    assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL | BF16)) == 0  # bf16 operands: the generic kernel is the faster one on short jets
+    assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL | BF16)) == 1
     assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL | GENERIC)) == 0
     assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL | PACK)) == 0
     assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL | 4)) == 0  # split fp16
@@ -113,3 +113,31 @@ def test_fast_sampler_all_masked_jet_is_nan_like_the_reference():
     keep = [0, 1, 3, 4, 5]
     torch.testing.assert_close(a[keep], b[keep], atol=5e-6, rtol=1e-5)
     assert torch.equal(torch.isnan(a[2]), torch.isnan(b[2]))
+
+
+def test_fast_bf16_sampler_tracks_the_generic_bf16_kernel():
+    from particle_fm_amd import hip_ops
+    g, fast, blob_f, gen, blob_g = _layouts("jetnet150", extra=BF16)
+    N, F = g.hp["num_particles"], g.hp["features"]
+    _, mask, z = _ragged(24, N, F, seed=19, lo=4)
+    a = hip_ops.epic_sample_midpoint(fast, blob_f, z.cuda(), None, mask.cuda(), ode_steps=8).cpu()
+    b = hip_ops.epic_sample_midpoint(gen, blob_g, z.cuda(), None, mask.cuda(), ode_steps=8).cpu()
+    # both round the same operands to bf16; inputs that differ by 1e-7 may round to neighbouring bf16 values
+    torch.testing.assert_close(a, b, atol=3e-3, rtol=3e-3)
+    vf = EpicVectorField(g.state, "flows.0.net", g.hp, freqs=g.freqs)
+    ref = sample_midpoint(vf, z, None, mask, ode_steps=8)
+    assert (a - ref).abs().max() < 1.5 * (b - ref).abs().max() + 1e-3
+
+
+def test_lds_boundary_of_the_fast_path():
+    """The chain's table rows live in 1152 bytes of LDS behind the activation tile: at F = 3 that fits up to 150 particles;
+    a 151-particle set (which the generic kernel still holds) stays on the generic kernel."""
+    from particle_fm_amd import _lib
+    from particle_fm_amd.layout import EpicLayout
+    from tests.conftest import load_golden
+    lib = _lib.load()
+    g = load_golden("jetnet150")
+    for n, want in ((150, 1), (151, 0), (128, 1)):
+        hp = dict(g.hp); hp["num_particles"] = n
+        lay = EpicLayout(cfg_of(hp), flags=SKIP_TAIL)
+        assert lib.pfm_epic_sample_is_fast(ctypes.byref(lay.desc)) == want, n
