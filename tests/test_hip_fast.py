@@ -141,3 +141,32 @@ def test_lds_boundary_of_the_fast_path():
         hp = dict(g.hp); hp["num_particles"] = n
         lay = EpicLayout(cfg_of(hp), flags=SKIP_TAIL)
         assert lib.pfm_epic_sample_is_fast(ctypes.byref(lay.desc)) == want, n
+
+
+def test_fast_sampler_properties_at_the_bench_size():
+    """Size-independent properties at the bench's full size (256 jets, N = 150, 100 midpoint steps, multiplicities U{30..150}), where
+    the oracle would take minutes: a jet's result does not depend on its batch (bitwise), the field is permutation equivariant
+    (epic.py pools with a masked mean / sum), masked rows are exactly 0, everything is finite."""
+    from particle_fm_amd import hip_ops
+    g, fast, blob_f, _, _ = _layouts("jetnet150")
+    N, F, B = 150, 3, 256
+    gen = torch.Generator().manual_seed(2024)
+    n = torch.randint(30, N + 1, (B,), generator=gen)
+    mask = (torch.arange(N)[None] < n[:, None]).float().unsqueeze(-1)
+    z = torch.randn(B, N, F, generator=gen)
+    out = hip_ops.epic_sample_midpoint(fast, blob_f, z.cuda(), None, mask.cuda(), ode_steps=100).cpu()
+    assert torch.isfinite(out).all()
+    assert torch.all(out[mask.squeeze(-1) == 0] == 0)
+    # batch independence: 40 jets picked out of the batch, in another order
+    pick = torch.randperm(B, generator=gen)[:40]
+    sub = hip_ops.epic_sample_midpoint(fast, blob_f, z[pick].cuda(), None, mask[pick].cuda(), ode_steps=100).cpu()
+    assert torch.equal(sub, out[pick])
+    # permutation equivariance over the valid particles (the sums re-associate: fp32 noise amplified over 198 evaluations)
+    zp, perm = z.clone(), []
+    for b in range(B):
+        p = torch.randperm(int(n[b]), generator=gen)
+        perm.append(p)
+        zp[b, : int(n[b])] = z[b, p]
+    outp = hip_ops.epic_sample_midpoint(fast, blob_f, zp.cuda(), None, mask.cuda(), ode_steps=100).cpu()
+    for b in range(0, B, 7):
+        torch.testing.assert_close(outp[b, : int(n[b])], out[b, perm[b]], atol=5e-5, rtol=1e-4)
