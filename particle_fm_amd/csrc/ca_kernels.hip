@@ -105,6 +105,172 @@ int linear(const Plan& p, int rows, int per_jet, const float* A, int lda, int K,
     return check_hip(hipGetLastError(), "tf_linear_kernel launch (ca)");
 }
 
+// ------------------------------------------------------------------------------------------------
+// The token side of a layer pair behind its attention, in ONE launch (inference): one workgroup per jet walks
+//   mid = tok + out(LN_attn(att))                        droid_transformer.py:380-397 (TransformerCrossAttentionLayer)
+//   dh  = lrelu(d1(LN_2(mid)) + ctxt bias)               :793-813 (DenseNetwork / MLPBlock)
+//   tok = mid + d2(LN_d(dh))
+//   kv  = kv_linear(LN_0(tok))      of the particles <- tokens layer that follows
+//   q   = q_linear(LN_1(tok))       of the NEXT pair's tokens <- particles layer (if any)
+// As row GEMMs over the 4 n_jets token rows these were five launches of a few workgroups each, ~7 us of launch + ramp latency
+// apiece (40 of the ~100 launches of an evaluation).  Here the jet's Tk <= 8 token rows live in LDS and every Linear is a GEMV
+// group straight on the MFMA_AK blocks (as ew_chain_kernel of ew_kernels.hip): a wave takes a 16-output block, lane (i, q)
+// multiplies the weight float4 it would feed the matrix pipe with by the matching float4 of each token row.
+// ------------------------------------------------------------------------------------------------
+constexpr int TKLD = MAXK + 8;          // floats per LDS row
+
+struct TokArgs {
+    const float *blob, *att, *jb;  // att [Mt][D]; jb: this layer's context-bias row of jet j at jb + j * jb_stride (Hd floats)
+    float *tok, *kv_out, *q_out;   // tok [Mt][D] in / out; kv_out [Mt][2D]; q_out [Mt][D] or nullptr
+    pfm_tf_norm attn_norm, norm2, d_norm, kv_norm, q_norm;
+    pfm_tf_lin out, d1, d2, kv, q;
+    int64_t jb_stride;
+    int D, Hd, Tk;
+    float slope, eps;
+};
+
+// LayerNorm of the workgroup's Tk rows src[Tk][TKLD] (width K) into dst; a norm with gamma < 0 copies.  One wave per row,
+// the two-pass statistics of tf_fwd.h::ln_stats_tile.  Ends behind a barrier.
+__device__ __forceinline__ void tok_layernorm(const float* __restrict__ blob, const pfm_tf_norm& nm, const float* __restrict__ src,
+                                              float* __restrict__ dst, int K, int Tk, float eps) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = w; r < Tk; r += (int)(blockDim.x >> 6)) {
+        const float* x = src + r * TKLD;
+        float s = 0.f;
+        for (int c = lane; c < K; c += 64) s += x[c];
+        const float mean = wsum(s) / (float)K;
+        float ss = 0.f;
+        for (int c = lane; c < K; c += 64) { const float dl = x[c] - mean; ss += dl * dl; }
+        const float rstd = 1.0f / sqrtf(wsum(ss) / (float)K + eps);
+        for (int c = lane; c < K; c += 64)
+            dst[r * TKLD + c] = nm.gamma >= 0 ? (x[c] - mean) * rstd * blob[nm.gamma + c] + blob[nm.beta + c] : x[c];
+    }
+    __syncthreads();
+}
+
+constexpr int TKT = 512;       // threads of a token-chain workgroup
+constexpr int TKW = TKT / 64;  // waves: each takes the output blocks w, w + TKW, ...
+
+// One Linear on the workgroup's token rows: out(ob, i, v[r]) is called by lanes i < 16 with v[r] = W[16 ob + i] . vin[r] (K = 64 ksteps,
+// ksteps even: widths are multiples of 128).  The wave walks its (output block, 128-wide K chunk) pairs as one flat sequence with the
+// NEXT pair's eight weight loads in flight behind the current pair's FMAs: one exposed L2 round trip per Linear instead of one per block.
+template <int TK, typename Out>
+__device__ __forceinline__ void tok_linear(const float* __restrict__ blob, int64_t W, int ksteps, int nob, const float* __restrict__ vin, Out out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4;
+    const int nch = ksteps >> 1;
+    const int mine = w < nob ? (nob - w + TKW - 1) / TKW : 0, total = mine * nch;
+    if (total == 0) return;
+    auto wptr = [&](int f) { return blob + W + ((int64_t)(w + TKW * (f / nch)) * ksteps + 2 * (f % nch)) * 1024 + lane * 4; };
+    f32x4 wa[8], wb[8];
+    f32x4 acc[TK];
+    auto load = [&](f32x4 (&wv)[8], int f) {
+        const float* wp = wptr(f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wv[i] = *reinterpret_cast<const f32x4*>(wp + 256 * i);
+    };
+    auto compute = [&](const f32x4 (&wv)[8], int f) {
+        const int ch = f % nch;
+        if (ch == 0) {
+#pragma unroll
+            for (int r = 0; r < TK; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float* xp = vin + 128 * ch + 4 * q;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < TK; ++r) acc[r] += wv[i] * *reinterpret_cast<const f32x4*>(xp + r * TKLD + 16 * i);
+        if (ch == nch - 1) {
+            float v[TK];
+#pragma unroll
+            for (int r = 0; r < TK; ++r) {
+                float t = hsum4(acc[r]);
+                t += __shfl_xor(t, 16);
+                t += __shfl_xor(t, 32);
+                v[r] = t;
+            }
+            if (lane < 16) out(w + TKW * (f / nch), lane, v);
+        }
+    };
+    load(wa, 0);
+    int f = 0;
+    for (; f + 1 < total; f += 2) {
+        load(wb, f + 1);
+        compute(wa, f);
+        if (f + 2 < total) load(wa, f + 2);
+        compute(wb, f + 1);
+    }
+    if (f < total) compute(wa, f);
+}
+
+template <int TK>
+__global__ __launch_bounds__(TKT) void ca_token_chain_kernel(TokArgs a) {
+    __shared__ __attribute__((aligned(16))) float xa[TK * TKLD];  // LayerNorm output = GEMV input
+    __shared__ __attribute__((aligned(16))) float xb[TK * TKLD];  // raw rows: att, then dh
+    __shared__ __attribute__((aligned(16))) float mid[TK * TKLD]; // the token stream: tok, mid, new tok
+    const int tid = threadIdx.x, jet = blockIdx.x;
+    const int D = a.D, Hd = a.Hd, Tk = a.Tk;
+    const int64_t row0 = (int64_t)jet * Tk;
+    // rows beyond Tk stay zero (they are multiplied along and never stored)
+    for (int i = tid; i < TK * TKLD; i += TKT) { xa[i] = 0.f; xb[i] = 0.f; mid[i] = 0.f; }
+    __syncthreads();
+    for (int i = tid; i < Tk * D; i += TKT) {
+        const int r = i / D, c = i - r * D;
+        xb[r * TKLD + c] = a.att[(row0 + r) * D + c];
+        mid[r * TKLD + c] = a.tok[(row0 + r) * D + c];
+    }
+    __syncthreads();
+    // ---- mid = tok + out(LN_attn(att)) ----
+    tok_layernorm(a.blob, a.attn_norm, xb, xa, D, Tk, a.eps);
+    tok_linear<TK>(a.blob, a.out.W, D / 64, D / 16, xa, [&](int ob, int i, const float (&v)[TK]) {
+        const float b = a.blob[a.out.b + 16 * ob + i];
+#pragma unroll
+        for (int r = 0; r < TK; ++r)
+            if (r < Tk) mid[r * TKLD + 16 * ob + i] += v[r] + b;  // each element has one owner: no race
+    });
+    __syncthreads();
+    // ---- dh = lrelu(d1(LN_2(mid)) + ctxt bias) ----
+    tok_layernorm(a.blob, a.norm2, mid, xa, D, Tk, a.eps);
+    const float* jb = a.jb + (int64_t)jet * a.jb_stride;
+    tok_linear<TK>(a.blob, a.d1.W, D / 64, Hd / 16, xa, [&](int ob, int i, const float (&v)[TK]) {
+        const float b = jb[16 * ob + i];  // includes the Linear's bias (tf_ctxt_kernel)
+#pragma unroll
+        for (int r = 0; r < TK; ++r)
+            if (r < Tk) xb[r * TKLD + 16 * ob + i] = lrelu(v[r] + b, a.slope);
+    });
+    __syncthreads();
+    // ---- tok = mid + d2(LN_d(dh)) ----
+    tok_layernorm(a.blob, a.d_norm, xb, xa, Hd, Tk, a.eps);
+    tok_linear<TK>(a.blob, a.d2.W, Hd / 64, D / 16, xa, [&](int ob, int i, const float (&v)[TK]) {
+        const float b = a.blob[a.d2.b + 16 * ob + i];
+#pragma unroll
+        for (int r = 0; r < TK; ++r)
+            if (r < Tk) {
+                const float t = mid[r * TKLD + 16 * ob + i] + (v[r] + b);
+                mid[r * TKLD + 16 * ob + i] = t;
+                a.tok[(row0 + r) * D + 16 * ob + i] = t;
+            }
+    });
+    __syncthreads();
+    // ---- kv = kv_linear(LN_0(tok)) of the particles <- tokens layer ----
+    tok_layernorm(a.blob, a.kv_norm, mid, xa, D, Tk, a.eps);
+    tok_linear<TK>(a.blob, a.kv.W, D / 64, 2 * D / 16, xa, [&](int ob, int i, const float (&v)[TK]) {
+        const float b = a.blob[a.kv.b + 16 * ob + i];
+#pragma unroll
+        for (int r = 0; r < TK; ++r)
+            if (r < Tk) a.kv_out[(row0 + r) * 2 * D + 16 * ob + i] = v[r] + b;
+    });
+    if (!a.q_out) return;
+    __syncthreads();
+    // ---- q = q_linear(LN_1(tok)) of the next pair ----
+    tok_layernorm(a.blob, a.q_norm, mid, xa, D, Tk, a.eps);
+    tok_linear<TK>(a.blob, a.q.W, D / 64, D / 16, xa, [&](int ob, int i, const float (&v)[TK]) {
+        const float b = a.blob[a.q.b + 16 * ob + i];
+#pragma unroll
+        for (int r = 0; r < TK; ++r)
+            if (r < Tk) a.q_out[(row0 + r) * D + 16 * ob + i] = v[r] + b;
+    });
+}
+
 #define PFM_TRY(x) do { if ((rc = (x))) return rc; } while (0)
 #define PFM_ATTN(KERNEL, grid, lds, ...)                                                                   \
     do {                                                                                                   \
@@ -148,23 +314,41 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         PFM_TRY(check_hip(hipGetLastError(), "ca_tokens_init_kernel launch"));
     }
     const float *seq = ws + w.seq0, *tok = ws + w.tok0;
+    // inference (one in-place buffer set): the token side of a layer pair behind its attention is one launch (ca_token_chain_kernel)
+    const bool fused_tokens = w.lstride == 0 && !(d.flags & PFM_CA_F_F16X3);
     for (int l = 0; l < d.layers; ++l) {
         float* lb = ws + w.layer0 + w.lstride * l;
         const pfm_ca_layer& Fl = d.from_layer[l];
         const pfm_ca_layer& Tl = d.to_layer[l];
         // tokens <- particles
         PFM_TRY(linear(p, p.M, N, seq, D, D, Fl.kv, &Fl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.f_kv, 2 * D, 0));
-        PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Fl.q, &Fl.norm1, D, nullptr, nullptr, 0, lb + w.f_q, D, 0));
+        if (!fused_tokens || l == 0)  // (fused: the previous pair's token chain already wrote this pair's queries)
+            PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Fl.q, &Fl.norm1, D, nullptr, nullptr, 0, lb + w.f_q, D, 0));
         PFM_ATTN(ca_attn_from_kernel, dim3(p.n_jets, (heads + 3) / 4), 0, (const float*)(lb + w.f_q), (const float*)(lb + w.f_kv), mask, lb + w.f_att, N, D,
                  heads, Tk, p.off, p.order);
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_from_kernel launch"));
-        PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_att, D, D, Fl.out, &Fl.attn_norm, D, nullptr, tok, D, lb + w.f_mid, D, 0));
-        PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_mid, D, D, Fl.d1, &Fl.norm2, Hd, jb + (int64_t)(1 + 2 * l) * Hd, nullptr, 0, lb + w.f_dh, Hd, 1));
-        PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_dh, Hd, Hd, Fl.d2, &Fl.d_norm, D, nullptr, lb + w.f_mid, D, lb + w.f_out, D, 0));
-        tok = lb + w.f_out;
+        if (fused_tokens) {
+            TokArgs a;
+            a.blob = p.blob; a.att = lb + w.f_att; a.jb = jb + (int64_t)(1 + 2 * l) * Hd; a.jb_stride = (int64_t)nb * Hd;
+            a.tok = ws + w.tok0; a.kv_out = lb + w.t_kv; a.q_out = l + 1 < d.layers ? lb + w.f_q : nullptr;
+            a.attn_norm = Fl.attn_norm; a.norm2 = Fl.norm2; a.d_norm = Fl.d_norm; a.kv_norm = Tl.norm0;
+            a.out = Fl.out; a.d1 = Fl.d1; a.d2 = Fl.d2; a.kv = Tl.kv;
+            if (l + 1 < d.layers) { a.q_norm = d.from_layer[l + 1].norm1; a.q = d.from_layer[l + 1].q; }
+            else { a.q_norm = Fl.norm1; a.q = Fl.q; }
+            a.D = D; a.Hd = Hd; a.Tk = Tk; a.slope = d.neg_slope; a.eps = d.ln_eps;
+            if (Tk <= 4) hipLaunchKernelGGL(ca_token_chain_kernel<4>, dim3(p.n_jets), dim3(TKT), 0, p.s, a);
+            else hipLaunchKernelGGL(ca_token_chain_kernel<PFM_CA_MAX_TOKENS>, dim3(p.n_jets), dim3(TKT), 0, p.s, a);
+            PFM_TRY(check_hip(hipGetLastError(), "ca_token_chain_kernel launch"));
+            tok = ws + w.tok0;
+        } else {
+            PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_att, D, D, Fl.out, &Fl.attn_norm, D, nullptr, tok, D, lb + w.f_mid, D, 0));
+            PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_mid, D, D, Fl.d1, &Fl.norm2, Hd, jb + (int64_t)(1 + 2 * l) * Hd, nullptr, 0, lb + w.f_dh, Hd, 1));
+            PFM_TRY(linear(p, p.Mt, Tk, lb + w.f_dh, Hd, Hd, Fl.d2, &Fl.d_norm, D, nullptr, lb + w.f_mid, D, lb + w.f_out, D, 0));
+            tok = lb + w.f_out;
+        }
         // particles <- tokens
         PFM_TRY(linear(p, p.M, N, seq, D, D, Tl.q, &Tl.norm1, D, nullptr, nullptr, 0, lb + w.t_q, D, 0));
-        PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Tl.kv, &Tl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.t_kv, 2 * D, 0));
+        if (!fused_tokens) PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Tl.kv, &Tl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.t_kv, 2 * D, 0));
         PFM_ATTN(ca_attn_to_kernel, dim3(p.n_jets, (N + TO_ROWS - 1) / TO_ROWS), (size_t)Tk * 2 * D * sizeof(float), (const float*)(lb + w.t_q),
                  (const float*)(lb + w.t_kv), lb + w.t_att, N, D, heads, Tk, p.off);
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_to_kernel launch"));
