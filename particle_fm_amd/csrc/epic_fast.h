@@ -23,6 +23,8 @@
 // The layer chain keeps the generic chain's arithmetic order (same panels, same reduction trees, same wave-partial order), so
 // a layer gives the same bits as the generic time-table path; the stem's tabulated terms and the MFMA fc_l1 differ from the
 // generic kernels by fp32 re-association (~1e-7), inside every parity bar (tests/test_hip_forward.py, test_hip_fast.py).
+// Two jets per workgroup (PFM_F_PACK_JETS): fast_eval<.., NSEG = 2> -- every tabulated bias is the same for both jets (no
+// conditioning), only the chains run per jet; same bits as one jet per workgroup (tests/test_hip_packed.py).
 #pragma once
 #include "epic_nfe.h"
 
@@ -38,7 +40,7 @@ constexpr int TB_SJ1 = 0, TB_SJ2 = 128, TB_SG1 = 256, TB_SG2 = 384, TB_SB3 = 400
 
 __host__ __device__ inline bool fast_path_ok(const pfm_epic_desc& d) {
     return d.t_dim == FT && d.cond_global == 0 && d.cond_local == 0 && d.features <= 4 && d.layers > 0 &&
-           !(d.flags & (PFM_F_F16X3_MFMA | PFM_F_PACK_JETS | PFM_F_GENERIC_SAMPLER)) &&
+           !(d.flags & (PFM_F_F16X3_MFMA | PFM_F_GENERIC_SAMPLER)) &&
            ((int64_t)make_carve(d.n_points, d.features).total + 288) * 4 <= 163840;  // + TBL_FLOATS behind the carve
 }
 
@@ -110,30 +112,43 @@ __device__ __forceinline__ f32x4 fast_sum_partials(const float* __restrict__ g2p
 // Stem chain: g = lrelu(Wg2 . lrelu(Wg1 . [mean ; sum] + tg1) + tg2), tg* = bias + time term (table).  epic.py:369-380
 // In: vin.mean / vin.sum (written by the fc_l2 phase, barrier passed), gl = this thread's rows of fc_g1 behind the time rows.
 // after_fc1(): called once gl has been consumed (the caller requests the first layer's windows there).  Out: vin.g.  Ends with a barrier.
-template <typename After, typename Publish>
-__device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restrict__ lds, const Carve& c, const f32x4 (&gl)[FNG],
+template <int NSEG, typename After, typename Publish>
+__device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restrict__ lds, const SegView (&sv)[2], const f32x4 (&gl)[FNG],
                                                 const ChainLoads& L, const float* __restrict__ tbl, After after_fc1, Publish publish_next) {
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int og = tid >> 4, pt = tid & 15, o4 = lane >> 4;
-    const float* vp = lds + c.vin + FT + pt;
-    float* vin2 = lds + c.vin2;
-    f32x4 p = gl[0] * vp[0];
+    f32x4 p[NSEG];
 #pragma unroll
-    for (int u = 1; u < FNGS; ++u) p += gl[u] * vp[16 * u];
+    for (int s = 0; s < NSEG; ++s) {
+        const float* vp = lds + sv[s].vin + FT + pt;
+        p[s] = gl[0] * vp[0];
+#pragma unroll
+        for (int u = 1; u < FNGS; ++u) p[s] += gl[u] * vp[16 * u];
+    }
     after_fc1();
-    p = reduce_pt(p);
-    if (pt == 0) *reinterpret_cast<f32x4*>(vin2 + FT + 4 * og) = lrelu4(p + *reinterpret_cast<const f32x4*>(tbl + TBL_G1 + 4 * og), j.slope);
+    const f32x4 bg1 = *reinterpret_cast<const f32x4*>(tbl + TBL_G1 + 4 * og);
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        p[s] = reduce_pt(p[s]);
+        if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].vin2 + FT + 4 * og) = lrelu4(p[s] + bg1, j.slope);
+    }
     __syncthreads();
     const f32x4 bg2 = *reinterpret_cast<const f32x4*>(tbl + TBL_G2 + 4 * o4);  // before the next chain's rows replace these
-    f32x4 gp = L.w2 * vin2[FT + 16 * w + pt];
-    gp = row_sum16(gp);
-    if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.g2p + MAXL * w + 4 * o4) = gp;
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        f32x4 gp = L.w2 * lds[sv[s].vin2 + FT + 16 * w + pt];
+        gp = row_sum16(gp);
+        if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].g2p + MAXL * w + 4 * o4) = gp;
+    }
     __syncthreads();
     publish_next();  // every read of this chain's table rows lies before the barrier above
     if (w == 0) {
-        f32x4 gn = fast_sum_partials(lds + c.g2p + 4 * o4);
-        gn = lrelu4(gn + bg2, j.slope);
-        if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.vin + FT + 2 * H + 4 * o4) = gn;
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) {
+            f32x4 gn = fast_sum_partials(lds + sv[s].g2p + 4 * o4);
+            gn = lrelu4(gn + bg2, j.slope);
+            if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].vin + FT + 2 * H + 4 * o4) = gn;
+        }
     }
     __syncthreads();
 }
@@ -142,35 +157,52 @@ __device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restr
 // (t* = bias + time term of the table slot).  Same panels, reduction trees and wave-partial order as PerJet phase of epic_nfe.h.
 // In: vin = [.. ; mean ; sum ; g_old], gl = rows of fc_global1 behind the time rows, wbA = row FT + pt of local linear 1's extras.
 // Out: vin.g = g_new, bj1 (each wave its own slice: the particle phase that follows needs no barrier).
-__device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __restrict__ lds, const Carve& c, const f32x4 (&gl)[FNG],
+// NSEG == 2 (two jets in the workgroup, the packed sampler): the weights are in registers once, every step runs for both jets.
+template <int NSEG>
+__device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __restrict__ lds, const SegView (&sv)[2], const f32x4 (&gl)[FNG],
                                                  const f32x4& wbA, const f32x4& w2, const float* __restrict__ tbl) {
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int og = tid >> 4, pt = tid & 15, o4 = lane >> 4;
-    const float* vin = lds + c.vin;
-    float* vin2 = lds + c.vin2;
-    const f32x4 gold = *reinterpret_cast<const f32x4*>(vin + FT + 2 * H + 4 * o4);  // before anyone overwrites it
-    const float* vp = vin + FT + pt;
-    f32x4 p = gl[0] * vp[0];
+    f32x4 gold[NSEG], p[NSEG];
 #pragma unroll
-    for (int u = 1; u < FNG; ++u) p += gl[u] * vp[16 * u];
-    p = reduce_pt(p);
-    if (pt == 0) *reinterpret_cast<f32x4*>(vin2 + FT + 4 * og) = lrelu4(p + *reinterpret_cast<const f32x4*>(tbl + TBL_G1 + 4 * og), j.slope);
+    for (int s = 0; s < NSEG; ++s) {
+        const float* vin = lds + sv[s].vin;
+        gold[s] = *reinterpret_cast<const f32x4*>(vin + FT + 2 * H + 4 * o4);  // before anyone overwrites it
+        const float* vp = vin + FT + pt;
+        p[s] = gl[0] * vp[0];
+#pragma unroll
+        for (int u = 1; u < FNG; ++u) p[s] += gl[u] * vp[16 * u];
+    }
+    const f32x4 bg1 = *reinterpret_cast<const f32x4*>(tbl + TBL_G1 + 4 * og);
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        p[s] = reduce_pt(p[s]);
+        if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].vin2 + FT + 4 * og) = lrelu4(p[s] + bg1, j.slope);
+    }
     __syncthreads();
-    f32x4 gp = w2 * vin2[FT + 16 * w + pt];
-    gp = row_sum16(gp);
-    if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.g2p + MAXL * w + 4 * o4) = gp;
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        f32x4 gp = w2 * lds[sv[s].vin2 + FT + 16 * w + pt];
+        gp = row_sum16(gp);
+        if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].g2p + MAXL * w + 4 * o4) = gp;
+    }
     __syncthreads();
-    f32x4 gn = fast_sum_partials(lds + c.g2p + 4 * o4);
-    gn += *reinterpret_cast<const f32x4*>(tbl + TBL_G2 + 4 * o4);
-    gn += gold;  // residual before the activation, epic.py:184-186
-    gn = lrelu4(gn, j.slope);
-    // each wave keeps its own copy of g_new (read back as the input of the bias GEMV: same wave, LDS is in order); wave 0's copy
-    // is vin.g itself, the input of the next stage
-    float* gcopy = (w == 0) ? lds + c.vin + FT + 2 * H : lds + c.gcopy + MAXL * w;
-    if (pt == 0) *reinterpret_cast<f32x4*>(gcopy + 4 * o4) = gn;
-    f32x4 p1 = wbA * gcopy[pt];  // entries >= L are lrelu(0) = 0 (zero-padded weights and biases)
-    p1 = reduce_pt(p1);
-    if (pt == 0) *reinterpret_cast<f32x4*>(lds + c.bj1 + 4 * og) = p1 + *reinterpret_cast<const f32x4*>(tbl + TBL_L1 + 4 * og);
+    const f32x4 bg2 = *reinterpret_cast<const f32x4*>(tbl + TBL_G2 + 4 * o4);
+    const f32x4 bl1 = *reinterpret_cast<const f32x4*>(tbl + TBL_L1 + 4 * og);
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        f32x4 gn = fast_sum_partials(lds + sv[s].g2p + 4 * o4);
+        gn += bg2;
+        gn += gold[s];  // residual before the activation, epic.py:184-186
+        gn = lrelu4(gn, j.slope);
+        // each wave keeps its own copy of g_new (read back as the input of the bias GEMV: same wave, LDS is in order); wave 0's copy
+        // is vin.g itself, the input of the next stage
+        float* gcopy = (w == 0) ? lds + sv[s].vin + FT + 2 * H : lds + sv[s].gcopy + MAXL * w;
+        if (pt == 0) *reinterpret_cast<f32x4*>(gcopy + 4 * o4) = gn;
+        f32x4 p1 = wbA * gcopy[pt];  // entries >= L are lrelu(0) = 0 (zero-padded weights and biases)
+        p1 = reduce_pt(p1);
+        if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].bj1 + 4 * og) = p1 + bl1;
+    }
 }
 
 // fc_l3 head with its per-jet bias from the table and its weights already in registers (requested during the last particle
@@ -231,11 +263,22 @@ __device__ __forceinline__ void fast_carry_request(FastCarry& cy, const pfm_epic
 
 // One evaluation: yin -> emit(...).  tbE / tbE_next: the table rows of this and of the next evaluation (the last evaluation
 // passes its own again).
-template <bool BF16, typename Emit>
+// NSEG == 2: the rows [0, n_rows) hold two jets (sg: where the second starts); without conditioning every tabulated bias is the same
+// for both, so only the chains (pooled vectors, g, bj1) run per jet.
+template <bool BF16, int NSEG, typename Emit>
 __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims& j, const float* __restrict__ blob,
                                           float* __restrict__ lds, const Carve& c, int n_rows, const float* __restrict__ tbE,
-                                          const float* __restrict__ tbE_next, FastCarry& cy, Emit emit) {
+                                          const float* __restrict__ tbE_next, FastCarry& cy, Emit emit, const Segs* sg = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const SegView sv[2] = {seg_view(c, j.N, 0), seg_view(c, j.N, NSEG == 2 ? 1 : 0)};
+    Seg2Phase s2p, s2t;  // the second jet as a phase with an LDS bias (bj1) / with a table bias sees it
+    if (NSEG == 2) {
+        s2p.bj = lds + sv[1].bj1;
+        s2p.mask1 = s2t.mask1 = lds + sv[1].maskf;
+        s2p.t1 = s2t.t1 = sg->r1 / TILE;
+        s2p.vin1 = s2t.vin1 = sv[1].vin;
+        s2p.misc1 = s2t.misc1 = sv[1].misc;
+    }
     float* bufA = lds + c.bufA;
     float* bufB = lds + c.bufB;
     const float* maskf = lds + c.maskf;
@@ -253,8 +296,9 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     // ---- fc_l2: bufB = lrelu(W.bufA + bj2 + bufA), pooled -> vin   epic.py:364-371; carries the stem chain's fc_g1 rows
     {
         Prefetch<FNGS> pf{rs, gl, nullptr, nullptr, nullptr, seg_panels(d.g1.W, FTP, tid), {}, {}, {}};
-        gemm_phase<true, true, false, BF16, decltype(pf)>(cy.a2, bufA, bufB, bufA, tbS + TB_SJ2, maskf, j, lds, c, nullptr, nullptr,
-                                                           n_rows, pf);
+        s2t.bj = tbS + TB_SJ2;
+        gemm_phase<true, true, false, BF16, decltype(pf), NSEG>(cy.a2, bufA, bufB, bufA, tbS + TB_SJ2, maskf, j, lds, c, nullptr, nullptr,
+                                                                 n_rows, pf, s2t);
     }
     fast_chain_publish(L, tbl);  // (the previous evaluation's last chain read tbl many barriers ago)
     __syncthreads();
@@ -262,7 +306,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     {
         const pfm_epic_layer& l0 = d.layer[0];
         ChainLoads L0;
-        fast_chain_stem(j, lds, c, gl, L, tbl, [&]() {
+        fast_chain_stem<NSEG>(j, lds, sv, gl, L, tbl, [&]() {
             // the first layer's windows, phase-1 weights and chain loads: no particle phase to ride on; they land behind the rest of the stem chain
             Prefetch<FNG, 1> pf{rs, gl, wbA, nullptr, nullptr, seg_panels(l0.gl1.W, FTP, tid), seg_panels(l0.lc1.We, FTP, tid), {}, {}};
             pf.template issue_range<0, FNG + 1>();
@@ -278,15 +322,15 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         const float* tbK = tbE + (size_t)k * TB_SLOT;
         const float* tbN = tbE + (size_t)(last ? k : k + 1) * TB_SLOT;
         PFM_STAMP(10);
-        fast_chain_layer(j, lds, c, gl, wbA[0], L.w2, tbl);
+        fast_chain_layer<NSEG>(j, lds, sv, gl, wbA[0], L.w2, tbl);
         PFM_STAMP(12);
         // phase 1: bufA = lrelu(W1 . bufB + bj1)   epic.py:194-196.  Riders: phase 2's weights and ALL per-jet windows of the next
         // layer (gl / wbA were consumed by the chain above), so that nothing the next chain waits for is requested late
         {
             Prefetch<8, FNG, 1> pf{rs, cy.a2, gl, wbA, nullptr, seg_afrag(ly.lc2.A, w, lane), seg_panels(nx.gl1.W, FTP, tid),
                                    seg_panels(nx.lc1.We, FTP, tid), {}};
-            gemm_phase<false, false, false, BF16, decltype(pf)>(cy.a1, bufB, bufA, nullptr, lds + c.bj1, maskf, j, lds, c, nullptr, nullptr,
-                                                                 n_rows, pf);
+            gemm_phase<false, false, false, BF16, decltype(pf), NSEG>(cy.a1, bufB, bufA, nullptr, lds + c.bj1, maskf, j, lds, c, nullptr,
+                                                                       nullptr, n_rows, pf, s2p);
         }
         __syncthreads();
         PFM_STAMP(13);
@@ -297,8 +341,9 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         {
             const PfSeg sa = last ? PfSeg{d.l3_A, 256, lane * 16} : seg_afrag(nx.lc1.A, w, lane);
             Prefetch<8> pf{rs, cy.a1, nullptr, nullptr, nullptr, sa, {}, {}, {}};
-            gemm_phase<true, true, false, BF16, decltype(pf)>(cy.a2, bufA, bufB, bufB, tbK + TB_L2, maskf, j, lds, c, nullptr, nullptr,
-                                                               n_rows, pf);
+            s2t.bj = tbK + TB_L2;
+            gemm_phase<true, true, false, BF16, decltype(pf), NSEG>(cy.a2, bufA, bufB, bufB, tbK + TB_L2, maskf, j, lds, c, nullptr, nullptr,
+                                                                     n_rows, pf, s2t);
         }
         fast_chain_publish(L, tbl);  // this layer's chain read tbl two barriers ago; the next one reads it behind the barrier below
         __syncthreads();

@@ -288,7 +288,46 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
     const JetDims j = dims_of(d0);
     const Carve c = make_carve(j.N, j.F);
     const int tid = threadIdx.x;
-    const int jet = pack ? pack[1 + 2 * blockIdx.x] : blockIdx.x;  // epic_jet_pack_kernel's list without pairs: (jet, -1), longest first
+    // pack (epic_jet_pack_kernel): [0] = workgroups in use, then (jet A, jet B or -1) per workgroup, longest first
+    int jetA = blockIdx.x, jetB = -1;
+    if (pack) {
+        if ((int)blockIdx.x >= pack[0]) return;
+        jetA = pack[1 + 2 * blockIdx.x];
+        jetB = pack[2 + 2 * blockIdx.x];
+    }
+    float* xs = lds + c.xs;
+    float* yin = lds + c.yin;
+    const int F = j.F;
+    const size_t estride = (size_t)(j.layers + 1) * TB_SLOT;
+    const int n_evals = 2 * n_intervals;
+    FastCarry cy;
+    cy.aw = fast_l1_weight(d0, j, blob);
+    if (jetB >= 0) {
+        // ---- two jets: rows [0, n0) = jet A, [r1, r1 + n1) = jet B (epic_pair_setup), one weight stream and one set of phases ----
+        const Segs sg = epic_pair_setup(d0, j, lds, c, jetA, jetB, z, nullptr, mask);
+        fast_carry_request(cy, d0, make_blob_rsrc(blob, d0.blob_floats + PFM_DESC_FLOATS), table + (size_t)j.layers * TB_SLOT);
+        for (int e = 0; e < n_evals; ++e) {
+            const int stage = e & 1;
+            const float h = dt[e >> 1];
+            const float hs = stage ? h : __fmul_rn(0.5f, h);
+            fast_eval<MODE == 1, 2>(d0, j, blob, lds, c, sg.rows, table + e * estride, table + (e + 1 < n_evals ? e + 1 : e) * estride, cy,
+                                    [=](int p, int f, float val) {
+                                        const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
+                                        yin[p * F + f] = xn;
+                                        if (stage) xs[p * F + f] = xn;
+                                    }, &sg);
+            __syncthreads();
+        }
+        float* oA = x_out + (size_t)jetA * j.N * F;
+        float* oB = x_out + (size_t)jetB * j.N * F;
+        for (int i = tid; i < j.N * F; i += NT) {
+            const int p = i / F;
+            oA[i] = p < sg.n0 ? xs[i] : 0.f;  // rows behind a jet's last valid particle are masked: 0
+            oB[i] = p < sg.n1 ? xs[sg.r1 * F + i] : 0.f;
+        }
+        return;
+    }
+    const int jet = jetA;
     const int n_rows = epic_jet_setup(d0, j, blob, lds, c, nullptr, mask ? mask + (size_t)jet * j.N : nullptr);
     const float* zj = z + (size_t)jet * j.N * j.F;
     for (int i = tid; i < j.N * j.F; i += NT) {
@@ -297,14 +336,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
         lds[c.yin + i] = z0;
     }
     __syncthreads();
-    float* xs = lds + c.xs;
-    float* yin = lds + c.yin;
-    const int F = j.F;
-    const size_t estride = (size_t)(j.layers + 1) * TB_SLOT;
-    FastCarry cy;
-    cy.aw = fast_l1_weight(d0, j, blob);
     fast_carry_request(cy, d0, make_blob_rsrc(blob, d0.blob_floats + PFM_DESC_FLOATS), table + (size_t)j.layers * TB_SLOT);
-    const int n_evals = 2 * n_intervals;
     for (int e = 0; e < n_evals; ++e) {
 #ifdef PFM_DIAG
         if (e == n_evals - 1 && blockIdx.x == 0 && threadIdx.x == 0) g_pfm_nstamp = 0;  // keep the last NFE
@@ -314,12 +346,12 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
         const float h = dt[e >> 1];
         const float hs = stage ? h : __fmul_rn(0.5f, h);
         // stage 0: x_mid = x + 0.5*dt*k1 -> next input;   stage 1: x = x + dt*f(t+dt/2, x_mid)
-        fast_eval<MODE == 1>(d0, j, blob, lds, c, n_rows, table + e * estride, table + (e + 1 < n_evals ? e + 1 : e) * estride, cy,
-                             [=](int p, int f, float val) {
-                                 const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
-                                 yin[p * F + f] = xn;
-                                 if (stage) xs[p * F + f] = xn;
-                             });
+        fast_eval<MODE == 1, 1>(d0, j, blob, lds, c, n_rows, table + e * estride, table + (e + 1 < n_evals ? e + 1 : e) * estride, cy,
+                                [=](int p, int f, float val) {
+                                    const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
+                                    yin[p * F + f] = xn;
+                                    if (stage) xs[p * F + f] = xn;
+                                });
         __syncthreads();
         PFM_STAMP(30);
     }
@@ -598,10 +630,7 @@ int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc* d, int32_t n_interva
     return (int64_t)2 * n_intervals * (d->layers + 1) * TB_SLOT + ((2 * (int64_t)B + 1 + 63) & ~63);
 }
 
-static bool sample_fast(const pfm_epic_desc* d, int mode) {
-    static const char* env_pack = getenv("PFM_PACK");  // diagnostic switch of tests/diag/pack_time.py: packing implies the generic kernel
-    return d && d->layers > 0 && fast_path_ok(*d) && mode != 2 && !(env_pack && env_pack[0] == '1');
-}
+static bool sample_fast(const pfm_epic_desc* d, int mode) { return d && d->layers > 0 && fast_path_ok(*d) && mode != 2; }
 int pfm_epic_sample_is_fast(const pfm_epic_desc* d) { return validate(d) == 0 && sample_fast(d, mfma_mode(d)) ? 1 : 0; }
 
 // device pointer of the workgroup list inside `scratch`, after queueing its computation; nullptr: one jet per workgroup, in order

@@ -46,7 +46,7 @@ def test_path_selection():
     assert q(EpicLayout(cfg_of(g.hp), flags=0)) == 1
     assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL | BF16)) == 1
     assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL | GENERIC)) == 0
-    assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL | PACK)) == 0
+    assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL | PACK)) == 1  # two jets per workgroup run on the lean evaluation too
     assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL | 4)) == 0  # split fp16
     assert q(EpicLayout(cfg_of(load_golden("jetnet30").hp), flags=SKIP_TAIL)) == 1
     assert q(EpicLayout(cfg_of(load_golden("cond_gl").hp), flags=SKIP_TAIL)) == 0  # conditioned: per-jet stem terms

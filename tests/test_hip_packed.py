@@ -83,7 +83,7 @@ def test_packed_sampler_is_deterministic_and_order_independent():
     a = hip_ops.epic_sample_midpoint(lay, blob, z.cuda(), None, mask.cuda(), ode_steps=5).cpu()
     a2 = hip_ops.epic_sample_midpoint(lay, blob, z.cuda(), None, mask.cuda(), ode_steps=5).cpu()
     assert torch.equal(a, a2)
-    lay1 = EpicLayout(cfg_of(g.hp), flags=1 | 32)  # one jet per workgroup on the same (generic) kernel: the same bits
+    lay1 = EpicLayout(cfg_of(g.hp), flags=1)  # one jet per workgroup (same kernel, the lean evaluation of epic_fast.h): the same bits
     blob1 = lay1.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
     assert torch.equal(a, hip_ops.epic_sample_midpoint(lay1, blob1, z.cuda(), None, mask.cuda(), ode_steps=5).cpu())
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))
