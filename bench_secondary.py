@@ -132,6 +132,11 @@ def run(name, args):
     net = model.flows[0].net
     if args.precision != "fp32":
         net.set_precision(args.precision)
+    # cfg 2: 1024 jets of <= 30 particles -- two jets per workgroup on an 80-row LDS tile (hip_ops.packed_tile_rows; same numbers bit for
+    # bit): a jet this short is all fixed cost, which a pair shares
+    packed = name == "jetnet30" and not args.no_pack
+    if packed:
+        net.set_jet_packing(True)
     valid_rows = hasattr(net, "set_valid_rows_only") and not args.dense_rows
     if valid_rows:  # what generate_data does with variable_set_sizes: the sampler skips padded particles (EPiC always does)
         net.set_valid_rows_only(True)
@@ -212,10 +217,11 @@ def run(name, args):
         "config": {"workload": what, "jets_per_gpu": B, "parallelism": "dp1", "ode_steps": args.ode_steps, "overlap": D,
                    "multiplicity": f"U{{{n_min}..{N}}} per jet",
                    "sampler_rows": "valid particles only" if (valid_rows or hp["model"] == "epic") else "all N rows (padded included)",
-                   "sampler_launches": "step body captured once per call, replayed as a hipGraph" if graph else "every launch enqueued by the host"},
+                   "sampler_launches": "step body captured once per call, replayed as a hipGraph" if graph else "every launch enqueued by the host",
+                   "jets_per_workgroup": 2 if packed else 1},
         "train_ms": train_ms, "sample_ms": sample_ms, "train_jets_per_s": B / (train_ms * 1e-3),
         "sample_jets_per_s": B / (sample_ms * 1e-3),
-        "roofline": {"bound": "mfma", "kernel": "sampling launches (tf_linear_kernel dominates)" if name != "jetnet30" else "epic_sample_midpoint_kernel",
+        "roofline": {"bound": "mfma", "kernel": "sampling launches (tf_linear_kernel dominates)" if name != "jetnet30" else "epic_sample_midpoint_fast_kernel",
                      "achieved": executed / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": executed / peak,
                      "traffic": None, "concurrent_launches": D, "valid_row_fraction": float(nv.mean()) / N,
                      "executed_share_of_dense": exec_share,
@@ -240,6 +246,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ode-steps", type=int, default=100)
+    ap.add_argument("--no-pack", action="store_true", help="jetnet30: one jet per workgroup (default: two, PFM_F_PACK_JETS)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3", "bf16"],
                     help="matrix operands: f16x3 = split fp16, fp32-grade accuracy (jet-resident EPiC: the sampler; row-matrix paths: "
                          "every Linear, training included); bf16 = the jet-resident EPiC sampler only (BASELINE cfg 2 is quoted in bf16; "

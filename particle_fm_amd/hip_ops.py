@@ -208,6 +208,36 @@ def epic_sample_rk(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor, cond
     return out
 
 
+# ---- two jets per workgroup for sets SHORTER than what the LDS tile could hold (PFM_F_PACK_JETS) --------------------------------
+# The kernels size their LDS tile by desc.n_points, so two 30-particle jets never fit the tile of a 30-particle model although the
+# CU's LDS would hold ten of them.  With packing asked for, such a call runs on a descriptor of a LARGER set size -- the smallest
+# multiple of 16 whose tile takes two full-length jets -- with the inputs zero-padded to it (mask 0 on the padding: those rows are
+# never computed); the weights are the same blob with the other descriptor in its tail.  Same numbers, bit for bit: packing never
+# mixes rows or per-jet vectors (tests/test_hip_packed.py).
+_X2_MASK = 352 + 208 + 128 + 128 + 128 + 128 + 8  # csrc/pfm_common.h: X2_MASK (per-jet vectors of the second jet, in the tail of bufB)
+
+
+def _seg2_rows(n: int) -> int:
+    return n - (_X2_MASK + (n + 3) // 4 * 4 + 127) // 128
+
+
+def packed_tile_rows(layout: EpicLayout, n: int) -> int:
+    """Set size to run an n-particle batch on so that two full-length jets share a workgroup, or 0 if packing is off, the tile
+    already takes them, or no tile that fits the LDS would."""
+    from .layout import PFM_F_PACK_JETS, PFM_F_SKIP_MASKED_TAIL
+    fl = int(layout.desc.flags)
+    if not (fl & PFM_F_PACK_JETS) or not (fl & PFM_F_SKIP_MASKED_TAIL):
+        return 0
+    need = (n + 15) // 16 * 16 + n
+    if _seg2_rows(n) >= need:
+        return 0
+    for cand in range((n + 15) // 16 * 16, 161, 16):
+        if _seg2_rows(cand) >= need:
+            probe = layout.padded(cand)
+            return cand if _lib.load().pfm_epic_lds_bytes(ctypes.byref(probe.desc)) <= 163840 - 1152 else 0
+    return 0
+
+
 def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor,
                          cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
                          ode_steps: int = 100, premask: bool = True, time_table: bool = True,
@@ -216,6 +246,17 @@ def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor
     The kernel multiplies the start state by the mask (SetFlowMatchingLitModule.sample does, :668-671);
     ``premask`` is informational: masking twice is idempotent for a 0/1 mask."""
     lib = _lib.load()
+    n_in = z.shape[1]
+    n_tile = packed_tile_rows(layout, n_in) if time_table else 0
+    if n_tile:  # run on the larger tile (see packed_tile_rows): padded inputs, the same weights behind the other descriptor
+        big = layout.padded(n_tile)
+        pad = n_tile - n_in
+        m2 = mask if mask is not None else torch.ones(z.shape[0], n_in, device=z.device, dtype=torch.float32)
+        m2 = m2.reshape(z.shape[0], n_in).to(torch.float32)
+        blob_big = torch.cat([blob.reshape(-1)[: int(layout.desc.blob_floats)], big.desc_tail().to(blob.device)])
+        out = epic_sample_midpoint(big, blob_big, torch.nn.functional.pad(z, (0, 0, 0, pad)), cond, torch.nn.functional.pad(m2, (0, pad)),
+                                   ode_steps=ode_steps, premask=premask, time_table=True, temb_tab=temb_tab)
+        return out[:, :n_in].contiguous()
     dev, B, blob, z, cond, mask = _prep_common(layout, blob, z, cond, mask)
     if ode_steps < 2:
         raise ValueError("ode_steps must be >= 2")

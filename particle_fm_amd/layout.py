@@ -424,6 +424,18 @@ class EpicLayout:
     def blob_total(self) -> int:
         return int(self.desc.blob_floats) + self.desc_floats
 
+    def padded(self, num_particles: int) -> "EpicLayout":
+        """The same network on a larger set size (same blob offsets: only desc.n_points differs); cached."""
+        cache = self.__dict__.setdefault("_padded", {})
+        lay = cache.get(num_particles)
+        if lay is None:
+            import dataclasses
+            lay = cache[num_particles] = EpicLayout(dataclasses.replace(self.cfg, num_particles=int(num_particles)),
+                                                    with_backward=self.with_backward,
+                                                    flags=int(self.desc.flags) & ~PFM_F_TEMB_SINCOS)
+            assert int(lay.desc.blob_floats) == int(self.desc.blob_floats)
+        return lay
+
     def desc_tail(self) -> torch.Tensor:
         """The descriptor's bytes as fp32 words: the tail of every blob (read by the kernels)."""
         raw = bytes(self.desc)

@@ -48,17 +48,19 @@ def test_packed_sampler_matches_unpacked_and_oracle(name, B):
     dev = lambda a: None if a is None else a.cuda()
     steps = 6
     packed = hip_ops.epic_sample_midpoint(lay, blob, dev(z), dev(cond), dev(mask), ode_steps=steps).cpu()
-    nwg, wl = _pack_list(lay, B, steps)
+    tile = hip_ops.packed_tile_rows(lay, N)  # short sets run on a larger LDS tile (zero-padded inputs, same weights)
+    nwg, wl = _pack_list(lay.padded(tile) if tile else lay, B, steps)
+    N_tile = tile or N
     assert sorted(int(v) for v in wl.reshape(-1) if v >= 0) == list(range(B))  # every jet exactly once
     pairs = int((wl[:, 1] >= 0).sum())
     assert nwg == B - pairs
-    if N >= 100:
+    if N_tile >= 64:
         assert pairs >= B // 6, f"only {pairs} pairs formed out of {B} ragged jets"
     for a, b in wl.tolist():  # capacity rule
         if b >= 0:
             ra = int(mask[a].nonzero()[:, 0].max()) + 1
             rb = int(mask[b].nonzero()[:, 0].max()) + 1
-            assert (ra + 15) // 16 * 16 + rb <= N - 9
+            assert (ra + 15) // 16 * 16 + rb <= hip_ops._seg2_rows(N_tile)
     single = hip_ops.epic_sample_midpoint(lay, blob, dev(z), dev(cond), dev(mask), ode_steps=steps, time_table=False).cpu()
     # same arithmetic per row and per jet; the only difference is the tabulated time term (fp32 re-association, ~1e-7)
     torch.testing.assert_close(packed, single, atol=2e-6, rtol=1e-5)
@@ -90,3 +92,36 @@ def test_packed_sampler_is_deterministic_and_order_independent():
     keep = perm[: B // 2]  # drop half of the jets: partners change
     b = hip_ops.epic_sample_midpoint(lay, blob, z[keep].cuda(), None, mask[keep].cuda(), ode_steps=5).cpu()
     assert torch.equal(a[keep], b)
+
+
+def test_short_sets_pack_on_a_larger_tile():
+    """A 30-particle model's own LDS tile never takes two jets; with packing on, the call runs on the smallest tile that does (80 rows,
+    hip_ops.packed_tile_rows) with zero-padded inputs and the same weights: every jet keeps its bits."""
+    from particle_fm_amd import hip_ops
+    from particle_fm_amd.layout import EpicLayout
+    from tests.conftest import load_golden
+    g = load_golden("jetnet30")
+    N, F = g.hp["num_particles"], g.hp["features"]
+    assert N == 30
+    lay = EpicLayout(cfg_of(g.hp), flags=1 | 16)
+    assert hip_ops.packed_tile_rows(lay, N) == 80
+    blob = lay.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    B = 96
+    n, mask, z, _ = _ragged(B, N, F, 0, seed=77, lo=1)
+    packed = hip_ops.epic_sample_midpoint(lay, blob, z.cuda(), None, mask.cuda(), ode_steps=7).cpu()
+    lay1 = EpicLayout(cfg_of(g.hp), flags=1)
+    blob1 = lay1.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    single = hip_ops.epic_sample_midpoint(lay1, blob1, z.cuda(), None, mask.cuda(), ode_steps=7).cpu()
+    assert torch.equal(packed, single)
+    # and the workgroup list of the padded call really holds pairs
+    big = lay.padded(80)
+    scr = [v for k, v in big.__dict__["_sample_scratch"].items() if k[0] == 7 and k[3] == B][0]
+    from particle_fm_amd import _lib
+    total = _lib.load().pfm_epic_sample_scratch_floats(ctypes.byref(big.desc), 6, B)
+    ints = scr.view(torch.int32)[total - ((2 * B + 1 + 63) // 64) * 64:].cpu()
+    nwg = int(ints[0])
+    assert nwg == B // 2, f"{nwg} workgroups for {B} jets of <= 30 particles"
+    # no mask at all: every jet is full length
+    full = hip_ops.epic_sample_midpoint(lay, blob, z.cuda(), None, None, ode_steps=4).cpu()
+    full1 = hip_ops.epic_sample_midpoint(lay1, blob1, z.cuda(), None, None, ode_steps=4).cpu()
+    assert torch.equal(full, full1)
