@@ -279,7 +279,9 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
 // The same integrator on the lean evaluation of epic_fast.h (unconditioned jets, T = 32, F <= 4; fp32 or bf16 operands): one jet per
 // workgroup, jets in descending multiplicity (`pack`), every time-only term from the fast-format table.
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+// PAIRS: the launch may hold two-jet workgroups (PFM_F_PACK_JETS); the one-jet instantiation does not carry that path (its register
+// allocation and code size are the single jet's own).
+template <int MODE, bool PAIRS>
 __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
     const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ dt, int n_intervals, const float* __restrict__ z,
     const float* __restrict__ mask, float* __restrict__ x_out, const float* __restrict__ table, const int* __restrict__ pack) {
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
     const int n_evals = 2 * n_intervals;
     FastCarry cy;
     cy.aw = fast_l1_weight(d0, j, blob);
-    if (jetB >= 0) {
+    if constexpr (PAIRS) if (jetB >= 0) {
         // ---- two jets: rows [0, n0) = jet A, [r1, r1 + n1) = jet B (epic_pair_setup), one weight stream and one set of phases ----
         const Segs sg = epic_pair_setup(d0, j, lds, c, jetA, jetB, z, nullptr, mask);
         fast_carry_request(cy, d0, make_blob_rsrc(blob, d0.blob_floats + PFM_DESC_FLOATS), table + (size_t)j.layers * TB_SLOT);
@@ -679,11 +681,14 @@ static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const floa
     // the lean evaluation of epic_fast.h: unconditioned jets, T = 32, F <= 4, fp32 / bf16 operands, one jet per workgroup
     const bool fast = tb && sample_fast(d, mode);
     if (fast) {
-        if ((rc = mode == 1 ? prepare(epic_sample_midpoint_fast_kernel<1>, d, &lds) : prepare(epic_sample_midpoint_fast_kernel<0>, d, &lds))) return rc;
-        lds += TBL_FLOATS * 4;  // the chain's table rows behind the carve (fast_path_ok checked that it fits)
-        const hipError_t e1 = mode == 1 ? hipFuncSetAttribute(reinterpret_cast<const void*>(epic_sample_midpoint_fast_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-                                        : hipFuncSetAttribute(reinterpret_cast<const void*>(epic_sample_midpoint_fast_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if ((rc = check_hip(e1, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)"))) return rc;
+        static const char* env_pack = getenv("PFM_PACK");  // as queue_jet_pack
+        const bool pairs = env_pack ? env_pack[0] == '1' : (d->flags & PFM_F_PACK_JETS) != 0;
+        const void* fk = pairs ? (mode == 1 ? (const void*)epic_sample_midpoint_fast_kernel<1, true> : (const void*)epic_sample_midpoint_fast_kernel<0, true>)
+                               : (mode == 1 ? (const void*)epic_sample_midpoint_fast_kernel<1, false> : (const void*)epic_sample_midpoint_fast_kernel<0, false>);
+        if ((rc = validate(d))) return rc;
+        lds = (make_carve(d->n_points, d->features).total + TBL_FLOATS) * 4;  // + the chain's table rows behind the carve (fast_path_ok: it fits)
+        if ((rc = check_hip(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(MaxDynamicSharedMemorySize)")))
+            return rc;
     }
     if (tb && n_intervals > 0) {
         hipLaunchKernelGGL(epic_time_table_kernel, dim3(2 * n_intervals, d->layers + 1), dim3(NT), 0, (hipStream_t)stream, blob,
@@ -691,13 +696,15 @@ static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const floa
         if ((rc = check_hip(hipGetLastError(), "epic_time_table_kernel launch"))) return rc;
     }
     if (fast) {
-        const int* jet_order = queue_jet_pack(d, scratch, table_floats, mask, B, mode, (hipStream_t)stream);  // never pairs here
-        if (mode == 1)
-            hipLaunchKernelGGL(epic_sample_midpoint_fast_kernel<1>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, dt,
-                               n_intervals, z, mask, x_out, (const float*)scratch, jet_order);
-        else
-            hipLaunchKernelGGL(epic_sample_midpoint_fast_kernel<0>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, dt,
-                               n_intervals, z, mask, x_out, (const float*)scratch, jet_order);
+        static const char* env_pack = getenv("PFM_PACK");
+        const bool pairs = env_pack ? env_pack[0] == '1' : (d->flags & PFM_F_PACK_JETS) != 0;
+        const int* jet_order = queue_jet_pack(d, scratch, table_floats, mask, B, mode, (hipStream_t)stream);  // singles unless `pairs`
+#define PFM_LAUNCH_FAST(M, P)                                                                                                          \
+    hipLaunchKernelGGL((epic_sample_midpoint_fast_kernel<M, P>), dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, dt, \
+                       n_intervals, z, mask, x_out, (const float*)scratch, jet_order)
+        if (pairs) { if (mode == 1) PFM_LAUNCH_FAST(1, true); else PFM_LAUNCH_FAST(0, true); }
+        else { if (mode == 1) PFM_LAUNCH_FAST(1, false); else PFM_LAUNCH_FAST(0, false); }
+#undef PFM_LAUNCH_FAST
         return check_hip(hipGetLastError(), "epic_sample_midpoint_fast_kernel launch");
     }
 #define PFM_LAUNCH_SMP(M, T)                                                                                                  \
