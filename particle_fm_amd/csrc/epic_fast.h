@@ -289,7 +289,6 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     float* tbl = lds + c.total;  // TBL_FLOATS behind the carve (fast_path_ok: it fits)
     // the stem chain's own loads, two phases ahead of their use
     ChainLoads L = fast_chain_loads(rs, d.g2.W, tbS, TB_SG1, TB_SG1, TB_SG2);
-    const f32x4 b3 = *reinterpret_cast<const f32x4*>(tbS + TB_SB3 + 4 * (lane >> 4));  // head bias, zero for f >= F
     fast_stem_l1(j, lds, c, n_rows, cy.aw, cy.sj1);
     __syncthreads();
     PFM_STAMP(3);
@@ -315,6 +314,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         }, [&]() { fast_chain_publish(L0, tbl); });
         L.w2 = L0.w2;
     }
+    f32x4 b3 = {0.f, 0.f, 0.f, 0.f};  // head bias (zero for f >= F): requested in front of the last particle phase
     for (int k = 0; k < j.layers; ++k) {
         const pfm_epic_layer ly = d.layer[k];  // by value: the offset dwords in one batch of scalar loads
         const bool last = k + 1 == j.layers;
@@ -335,6 +335,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         __syncthreads();
         PFM_STAMP(13);
         L = fast_chain_loads(rs, nx.gl2.W, tbN, TB_G1, TB_L1, TB_G2);  // the next chain's loads, a phase ahead
+        if (last) b3 = *reinterpret_cast<const f32x4*>(tbS + TB_SB3 + 4 * (lane >> 4));
         // phase 2: bufB = lrelu(W2 . bufA + bj2 + bufB), pooled -> vin    epic.py:198-200, :160-162
         // (bj2 = bias + time term: constant per evaluation and layer, read from the table).  Riders: the next layer's phase-1
         // weights, or the head's one 16-row panel behind the last layer, into a1 (free since phase 1)
