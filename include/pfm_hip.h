@@ -200,6 +200,14 @@ int pfm_epic_sample_rk(const pfm_epic_desc *desc, const float *blob, const pfm_r
                        const float *dt, int32_t n_intervals, const float *z, const float *cond, const float *mask,
                        float *x_out, int32_t B, float *kbuf, const float *rhs, void *stream);
 
+/* The same with the size of kbuf stated: with pfm_epic_sample_rk_scratch_floats(desc, stages, n_intervals, B) floats (stage slopes |
+ * jet order | time-term table of every stage time) unconditioned jets (see pfm_epic_sample_is_fast) run the lean evaluation of
+ * csrc/epic_fast.h; with less (at least the kbuf of pfm_epic_sample_rk) the generic kernel.  Results differ by fp32 re-association. */
+int64_t pfm_epic_sample_rk_scratch_floats(const pfm_epic_desc *desc, int32_t stages, int32_t n_intervals, int32_t B);
+int pfm_epic_sample_rk_sized(const pfm_epic_desc *desc, const float *blob, const pfm_rk_tableau *tab, const float *t_eval,
+                             const float *dt, int32_t n_intervals, const float *z, const float *cond, const float *mask,
+                             float *x_out, int32_t B, float *kbuf, int64_t kbuf_floats, const float *rhs, void *stream);
+
 /* pfm_epic_sample_rk with caller-supplied embeddings: temb_tab[n_intervals * stages][T] (flow matching only: rhs = NULL). */
 int pfm_epic_sample_rk_temb(const pfm_epic_desc *desc, const float *blob, const pfm_rk_tableau *tab, const float *temb_tab,
                             const float *dt, int32_t n_intervals, const float *z, const float *cond, const float *mask,

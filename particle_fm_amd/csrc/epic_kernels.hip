@@ -418,6 +418,62 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_rk_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// The Runge-Kutta integrator on the lean evaluation of epic_fast.h (unconditioned jets, T = 32, F <= 4): euler / rk4 / any tableau,
+// and the probability-flow ODE of a diffusion model (`rhs`).  table: fast-format time table of all stages * n_intervals evaluation
+// times.  Rows behind a jet's last valid particle are never evaluated: their state is z * mask = 0 and stays 0.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(NT, 2) void epic_sample_rk_fast_kernel(
+    const float* __restrict__ blob, int64_t desc_off, pfm_rk_tableau tab, const float* __restrict__ dt, int n_intervals,
+    const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x_out, float* __restrict__ kbuf,
+    const float* __restrict__ rhs, const int* __restrict__ order, const float* __restrict__ table) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
+    const JetDims j = dims_of(d0);
+    const Carve c = make_carve(j.N, j.F);
+    const int jet = order ? order[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
+    const int n_rows = epic_jet_setup(d0, j, blob, lds, c, nullptr, mask ? mask + (size_t)jet * j.N : nullptr);
+    const int NF = j.N * j.F, F = j.F, S = tab.stages;
+    const float* zj = z + (size_t)jet * NF;
+    for (int i = tid; i < NF; i += NT) {
+        const float z0 = zj[i] * lds[c.maskf + i / F];
+        lds[c.xs + i] = z0;
+        lds[c.yin + i] = z0;
+    }
+    __syncthreads();
+    float* xs = lds + c.xs;
+    float* yin = lds + c.yin;
+    float* kj = kbuf + (size_t)jet * S * NF;
+    const size_t estride = (size_t)(j.layers + 1) * TB_SLOT;
+    const int n_evals = S * n_intervals;
+    FastCarry cy;
+    cy.aw = fast_l1_weight(d0, j, blob);
+    fast_carry_request(cy, d0, make_blob_rsrc(blob, d0.blob_floats + PFM_DESC_FLOATS), table + (size_t)j.layers * TB_SLOT);
+    int st = 0;
+    for (int e = 0; e < n_evals; ++e) {
+        const float h = dt[e / S];
+        const bool last = st == S - 1;
+        const float* coef = last ? tab.b : tab.a[st + 1 < PFM_RK_MAX_STAGES ? st + 1 : 0];
+        const float r0 = rhs ? rhs[2 * e] : 0.f, r1 = rhs ? rhs[2 * e + 1] : 1.f;
+        fast_eval<MODE == 1, 1>(d0, j, blob, lds, c, n_rows, table + e * estride, table + (e + 1 < n_evals ? e + 1 : e) * estride, cy,
+                                [=](int p, int f, float val) {
+                                    const int i = p * F + f;
+                                    if (rhs) val = __fmul_rn(r0, __fsub_rn(yin[i], __fdiv_rn(val, r1)));  // -0.5 beta (x - eps_theta / noise_rate)
+                                    if (!last) kj[st * NF + i] = val;
+                                    float acc = __fmul_rn(coef[0], st == 0 ? val : kj[i]);
+                                    for (int q = 1; q <= st; ++q) acc = __fadd_rn(acc, __fmul_rn(coef[q], q == st ? val : kj[q * NF + i]));
+                                    const float xn = __fadd_rn(xs[i], __fmul_rn(h, acc));
+                                    yin[i] = xn;
+                                    if (last) xs[i] = xn;
+                                });
+        __syncthreads();
+        st = last ? 0 : st + 1;
+    }
+    float* oj = x_out + (size_t)jet * NF;
+    for (int i = tid; i < NF; i += NT) oj[i] = xs[i];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Time-term table of a sampling call (epic_nfe.h: TB): table[e][layer][TB_SLOT] = W_t^T temb(t_eval[e]) for the four per-jet
 // Linears of every EPiC layer (fc_global1, local-1 extras, local-2 extras: KM16 blocks; fc_global2: KP16), time rows = the
 // first T rows of each block; slot `layers` of an evaluation is the stem slot of the fast format (epic_fast.h).
@@ -731,9 +787,13 @@ int pfm_epic_sample_midpoint_temb(const pfm_epic_desc* d, const float* blob, con
                            stream, temb_tab);
 }
 
+// kbuf: [stage slopes B * stages * N * F | jet order, B rounded up to 64 | fast-format time table of all stage times]
+static int64_t rk_order_off(const pfm_epic_desc* d, int stages, int B) { return (int64_t)B * stages * d->n_points * d->features; }
+static int64_t rk_table_off(const pfm_epic_desc* d, int stages, int B) { return rk_order_off(d, stages, B) + (((int64_t)B + 63) & ~(int64_t)63); }
+
 static int sample_rk(const pfm_epic_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
                      int32_t n_intervals, const float* z, const float* cond, const float* mask, float* x_out, int32_t B,
-                     float* kbuf, const float* rhs, void* stream, const float* temb_tab) {
+                     float* kbuf, int64_t kbuf_floats, const float* rhs, void* stream, const float* temb_tab) {
     int lds = 0;
     const int mode = mfma_mode(d);
     int rc = mode == 2 ? prepare(epic_sample_rk_kernel<2>, d, &lds)
@@ -744,26 +804,58 @@ static int sample_rk(const pfm_epic_desc* d, const float* blob, const pfm_rk_tab
     if (!blob || !t_eval || !dt || !z || !x_out || !kbuf) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (n_intervals < 0) return set_err(PFM_E_BADARG, "n_intervals < 0");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
+    const int64_t order_off = rk_order_off(d, tab->stages, B);
+    const int* order = queue_jet_order(d, kbuf, order_off, mask, B, (hipStream_t)stream);
+    // the lean evaluation (epic_fast.h) when the caller's scratch has room for the time table of every stage time
+    const int n_evals = tab->stages * n_intervals;
+    const int64_t table_off = rk_table_off(d, tab->stages, B), table_floats = (int64_t)n_evals * (d->layers + 1) * TB_SLOT;
+    if (sample_fast(d, mode) && !(d->flags & PFM_F_PACK_JETS) && kbuf_floats >= table_off + table_floats && n_evals > 0) {
+        float* table = kbuf + table_off;
+        hipLaunchKernelGGL(epic_time_table_kernel, dim3(n_evals, d->layers + 1), dim3(NT), 0, (hipStream_t)stream, blob, d->blob_floats,
+                           t_eval, table, temb_tab, 1);
+        if ((rc = check_hip(hipGetLastError(), "epic_time_table_kernel launch"))) return rc;
+        const void* fk = mode == 1 ? (const void*)epic_sample_rk_fast_kernel<1> : (const void*)epic_sample_rk_fast_kernel<0>;
+        lds = (make_carve(d->n_points, d->features).total + TBL_FLOATS) * 4;
+        if ((rc = check_hip(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(MaxDynamicSharedMemorySize)")))
+            return rc;
+        if (mode == 1)
+            hipLaunchKernelGGL(epic_sample_rk_fast_kernel<1>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, *tab, dt,
+                               n_intervals, z, mask, x_out, kbuf, rhs, order, (const float*)table);
+        else
+            hipLaunchKernelGGL(epic_sample_rk_fast_kernel<0>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, *tab, dt,
+                               n_intervals, z, mask, x_out, kbuf, rhs, order, (const float*)table);
+        return check_hip(hipGetLastError(), "epic_sample_rk_fast_kernel launch");
+    }
 #define PFM_LAUNCH_RK(M)                                                                                                    \
     hipLaunchKernelGGL(epic_sample_rk_kernel<M>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, *tab, \
                        t_eval, dt, n_intervals, z, cond, mask, x_out, kbuf, rhs, order, temb_tab)
-    const int* order = queue_jet_order(d, kbuf, (int64_t)B * tab->stages * d->n_points * d->features, mask, B, (hipStream_t)stream);
     if (mode == 2) PFM_LAUNCH_RK(2); else if (mode == 1) PFM_LAUNCH_RK(1); else PFM_LAUNCH_RK(0);
 #undef PFM_LAUNCH_RK
     return check_hip(hipGetLastError(), "epic_sample_rk_kernel launch");
 }
 
+int64_t pfm_epic_sample_rk_scratch_floats(const pfm_epic_desc* d, int32_t stages, int32_t n_intervals, int32_t B) {
+    if (!d || stages < 1 || stages > PFM_RK_MAX_STAGES || n_intervals < 0 || B < 0) return -1;
+    return rk_table_off(d, stages, B) + (int64_t)stages * n_intervals * (d->layers + 1) * TB_SLOT;
+}
+
+int pfm_epic_sample_rk_sized(const pfm_epic_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
+                             int32_t n_intervals, const float* z, const float* cond, const float* mask, float* x_out, int32_t B,
+                             float* kbuf, int64_t kbuf_floats, const float* rhs, void* stream) {
+    return sample_rk(d, blob, tab, t_eval, dt, n_intervals, z, cond, mask, x_out, B, kbuf, kbuf_floats, rhs, stream, nullptr);
+}
+
 int pfm_epic_sample_rk(const pfm_epic_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
                        int32_t n_intervals, const float* z, const float* cond, const float* mask, float* x_out, int32_t B,
                        float* kbuf, const float* rhs, void* stream) {
-    return sample_rk(d, blob, tab, t_eval, dt, n_intervals, z, cond, mask, x_out, B, kbuf, rhs, stream, nullptr);
+    return sample_rk(d, blob, tab, t_eval, dt, n_intervals, z, cond, mask, x_out, B, kbuf, 0, rhs, stream, nullptr);
 }
 
 int pfm_epic_sample_rk_temb(const pfm_epic_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* temb_tab, const float* dt,
                             int32_t n_intervals, const float* z, const float* cond, const float* mask, float* x_out, int32_t B,
                             float* kbuf, void* stream) {
     if (!temb_tab) return set_err(PFM_E_BADARG, "temb_tab is NULL");
-    return sample_rk(d, blob, tab, temb_tab, dt, n_intervals, z, cond, mask, x_out, B, kbuf, nullptr, stream, temb_tab);
+    return sample_rk(d, blob, tab, temb_tab, dt, n_intervals, z, cond, mask, x_out, B, kbuf, 0, nullptr, stream, temb_tab);
 }
 
 }  // extern "C"

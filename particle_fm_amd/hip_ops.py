@@ -189,7 +189,9 @@ def epic_sample_rk(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor, cond
     ts, dts = rk_grid(ode_steps, solver, t0, t1)
     ts, dts = ts.to(dev), dts.to(dev)
     out = torch.empty_like(z)
-    kbuf = torch.empty(tab.stages * z.numel() + ((B + 63) // 64) * 64, device=dev, dtype=torch.float32)  # stage slopes | jet order
+    # stage slopes | jet order | time-term table of every stage time (the lean evaluation of csrc/epic_fast.h needs the last part)
+    kbuf = torch.empty(lib.pfm_epic_sample_rk_scratch_floats(ctypes.byref(layout.desc), tab.stages, ode_steps - 1, B), device=dev,
+                       dtype=torch.float32)
     rhs = None
     if diff_config is not None:
         _, nr, beta = diffusion_schedule(ts, **diff_config)
@@ -202,9 +204,9 @@ def epic_sample_rk(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor, cond
                                          _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, _ptr(kbuf), _stream_ptr(dev))
         _lib.check(rc, "pfm_epic_sample_rk_temb")
         return out
-    rc = lib.pfm_epic_sample_rk(ctypes.byref(layout.desc), _ptr(blob), ctypes.byref(tab), _ptr(ts), _ptr(dts), ode_steps - 1,
-                                _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, _ptr(kbuf), _ptr(rhs), _stream_ptr(dev))
-    _lib.check(rc, "pfm_epic_sample_rk")
+    rc = lib.pfm_epic_sample_rk_sized(ctypes.byref(layout.desc), _ptr(blob), ctypes.byref(tab), _ptr(ts), _ptr(dts), ode_steps - 1,
+                                      _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, _ptr(kbuf), kbuf.numel(), _ptr(rhs), _stream_ptr(dev))
+    _lib.check(rc, "pfm_epic_sample_rk_sized")
     return out
 
 
