@@ -1,5 +1,6 @@
-// The midpoint sampler's lean evaluation ("fast path") for the headline configuration of the EPiC network: unconditioned jets
-// (cond_global = cond_local = 0), time embedding of width 32, F <= 4 features, fp32 or bf16 matrix operands.
+// The samplers' lean evaluation ("fast path": the persistent midpoint and Runge-Kutta integrators of epic_kernels.hip) for the
+// headline configuration of the EPiC network: unconditioned jets (cond_global = cond_local = 0), time embedding of width 32,
+// F <= 4 features, fp32 or bf16 matrix operands.
 //
 // Reference graph: the same as epic_nfe.h (particle_fm/models/components/epic.py:304-391, :85-203).
 //
@@ -17,7 +18,8 @@
 //     barriers fewer per evaluation;
 //   * no guards: every input vector is zero-padded in LDS to the 16-row panels the weights are padded to;
 //   * fc_global2's rows sit along the DPP row (16 k of one output group per row): its reduction is row_sum16, no bpermute;
-//   * bias vectors that are constant per (evaluation, layer) are read by the MFMA phases straight from the table;
+//   * bias vectors that are constant per (evaluation, layer) are read by the MFMA phases straight from the table; the chain's own
+//     three table rows are fetched a phase ahead by 68 threads and published to a 288-float LDS area behind the carve;
 //   * fc_l1 (K = F <= 4) is ONE v_mfma_f32_16x16x4_f32 per tile and wave instead of a VALU layer;
 //   * the head's weights and the next evaluation's fc_l2 weights are requested before they are needed.
 // The layer chain keeps the generic chain's arithmetic order (same panels, same reduction trees, same wave-partial order), so
@@ -34,7 +36,6 @@ constexpr int FT = 32;        // time-embedding width the fast path is built for
 constexpr int FTP = FT / 16;  // time panels of every per-jet block (tabulated, skipped)
 constexpr int FNG = 17;       // fc_global1 panels behind the time rows: [mean(128) ; sum(128) ; g(16)]
 constexpr int FNGS = 16;      // fc_g1 (stem): [mean ; sum]
-constexpr int FNG1 = 12;      // ... of the FNG panels, how many ride on particle phase 1 (the rest on phase 2)
 // stem slot of the fast table (slot index = layers): per-jet biases of fc_l1 / fc_l2, time terms (+ bias) of fc_g1 / fc_g2, fc_l3 bias
 constexpr int TB_SJ1 = 0, TB_SJ2 = 128, TB_SG1 = 256, TB_SG2 = 384, TB_SB3 = 400;
 
