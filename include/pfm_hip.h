@@ -163,6 +163,7 @@ int pfm_epic_forward_temb(const pfm_epic_desc *desc, const float *blob, const fl
  * several launches are in flight, the gaps of the previous one -- instead of a long jet starting last. */
 int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc *desc, int32_t n_intervals, int32_t B);
 /* 1 if pfm_epic_sample_midpoint(desc, ..., scratch != NULL, ...) runs the lean evaluation of csrc/epic_fast.h (unconditioned jets,
+ * or conditioned ones with cond_local + latent <= 16 and no PFM_F_PACK_JETS: their conditioning terms come from a per-jet table;
  * t_dim = 32, features <= 4, fp32 / bf16 operands, no PFM_F_GENERIC_SAMPLER, the set leaves 1152 bytes of LDS
  * behind the activation tile: n_points <= 150 at features = 3), 0 if the generic kernel. */
 int pfm_epic_sample_is_fast(const pfm_epic_desc *desc);

@@ -35,12 +35,18 @@ namespace pfm {
 constexpr int FT = 32;        // time-embedding width the fast path is built for
 constexpr int FTP = FT / 16;  // time panels of every per-jet block (tabulated, skipped)
 constexpr int FNG = 17;       // fc_global1 panels behind the time rows: [mean(128) ; sum(128) ; g(16)]
+constexpr int FNGC = 18;      // ... of a conditioned model: [cond(C <= 16, multiplied by zeros) ; mean ; sum ; g(16)] = up to 288 rows
 constexpr int FNGS = 16;      // fc_g1 (stem): [mean ; sum]
 // stem slot of the fast table (slot index = layers): per-jet biases of fc_l1 / fc_l2, time terms (+ bias) of fc_g1 / fc_g2, fc_l3 bias
 constexpr int TB_SJ1 = 0, TB_SJ2 = 128, TB_SG1 = 256, TB_SG2 = 384, TB_SB3 = 400;
 
+// Conditioned jets (cond_global = C > 0): every conditioning column multiplies a per-jet constant, so its contribution to each per-jet
+// Linear is one more table, per JET instead of per evaluation (epic_cond_table_kernel: W_c^T cond, same slot layout), added to the
+// time table's row wherever that is read; the conditioning slots of the input vectors hold zeros (the weight panels run over them).
+// One jet per workgroup, and cond_local + latent <= 16 (local linear 1's [cond_l ; g] rows fit one panel).
 __host__ __device__ inline bool fast_path_ok(const pfm_epic_desc& d) {
-    return d.t_dim == FT && d.cond_global == 0 && d.cond_local == 0 && d.features <= 4 && d.layers > 0 &&
+    const bool cond_ok = d.cond_global == 0 || (d.cond_local + d.latent <= 16 && !(d.flags & PFM_F_PACK_JETS));
+    return d.t_dim == FT && cond_ok && d.features <= 4 && d.layers > 0 &&
            !(d.flags & (PFM_F_F16X3_MFMA | PFM_F_GENERIC_SAMPLER)) &&
            ((int64_t)make_carve(d.n_points, d.features).total + 288) * 4 <= 163840;  // + TBL_FLOATS behind the carve
 }
@@ -80,15 +86,19 @@ struct ChainLoads {
 };
 // slot: the table slot of the chain; o_g1 / o_l1 / o_g2: where its three rows start inside the slot (layer slot: TB_G1 / TB_L1 /
 // TB_G2; stem slot: TB_SG1 / (none: pass o_g1) / TB_SG2)
-__device__ __forceinline__ ChainLoads fast_chain_loads(blob_rsrc rs, int64_t gl2_W, const float* __restrict__ slot, int o_g1, int o_l1, int o_g2) {
+// ct (conditioned jets, or nullptr): the jet's cond-table slot with the same row offsets; then threads 68..99 also fetch the local
+// linear 2 row (o_l2), which the particle phase reads from LDS (c.bj2) instead of the time table
+__device__ __forceinline__ ChainLoads fast_chain_loads(blob_rsrc rs, int64_t gl2_W, int w2_row0, const float* __restrict__ slot, int o_g1,
+                                                       int o_l1, int o_g2, const float* __restrict__ ct = nullptr, int o_l2 = 0) {
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int pt = tid & 15, o4 = lane >> 4;
     ChainLoads L;
-    L.w2 = bload4(rs, gl2_W + (int64_t)FT * 16, ((16 * w + pt) * 16 + 4 * o4) * 4);
+    L.w2 = bload4(rs, gl2_W + (int64_t)w2_row0 * 16, ((16 * w + pt) * 16 + 4 * o4) * 4);  // row w2_row0 + 16 w + pt (KP16), outputs 4 o4..
     L.stg = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < 68) {
-        const int off = tid < 32 ? o_g1 + 4 * tid : (tid < 64 ? o_l1 + 4 * (tid - 32) : o_g2 + 4 * (tid - 64));
+    if (tid < (ct ? 100 : 68)) {
+        const int off = tid < 32 ? o_g1 + 4 * tid : (tid < 64 ? o_l1 + 4 * (tid - 32) : (tid < 68 ? o_g2 + 4 * (tid - 64) : o_l2 + 4 * (tid - 68)));
         L.stg = *reinterpret_cast<const f32x4*>(slot + off);
+        if (ct) L.stg += *reinterpret_cast<const f32x4*>(ct + off);
     }
     return L;
 }
@@ -96,6 +106,12 @@ __device__ __forceinline__ ChainLoads fast_chain_loads(blob_rsrc rs, int64_t gl2
 __device__ __forceinline__ void fast_chain_publish(const ChainLoads& L, float* __restrict__ tbl) {
     const int tid = launder(threadIdx.x);
     if (tid < 68) *reinterpret_cast<f32x4*>(tbl + (tid < 64 ? 4 * tid : TBL_G2 + 4 * (tid - 64))) = L.stg;
+}
+// conditioned jets: the local-linear-2 bias row of threads 68..99 -> bj2.  Readers (the particle phase) must lie behind a later barrier,
+// the previous phase's reads of bj2 behind an earlier one.
+__device__ __forceinline__ void fast_chain_publish_l2(const ChainLoads& L, float* __restrict__ bj2) {
+    const int tid = launder(threadIdx.x);
+    if (tid >= 68 && tid < 100) *reinterpret_cast<f32x4*>(bj2 + 4 * (tid - 68)) = L.stg;
 }
 
 // sum of the eight wave partials of fc_global2 in wave order; all eight reads in flight before the first add
@@ -113,31 +129,35 @@ __device__ __forceinline__ f32x4 fast_sum_partials(const float* __restrict__ g2p
 // Stem chain: g = lrelu(Wg2 . lrelu(Wg1 . [mean ; sum] + tg1) + tg2), tg* = bias + time term (table).  epic.py:369-380
 // In: vin.mean / vin.sum (written by the fc_l2 phase, barrier passed), gl = this thread's rows of fc_g1 behind the time rows.
 // after_fc1(): called once gl has been consumed (the caller requests the first layer's windows there).  Out: vin.g.  Ends with a barrier.
-template <int NSEG, typename After, typename Publish>
-__device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restrict__ lds, const SegView (&sv)[2], const f32x4 (&gl)[FNG],
-                                                const ChainLoads& L, const float* __restrict__ tbl, After after_fc1, Publish publish_next) {
+template <int NSEG, bool COND, typename After, typename Publish>
+__device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restrict__ lds, const SegView (&sv)[2],
+                                                const f32x4 (&gl)[COND ? FNGC : FNG], const ChainLoads& L, const float* __restrict__ tbl,
+                                                After after_fc1, Publish publish_next) {
+    static_assert(!(COND && NSEG != 1), "conditioned jets: one jet per workgroup");
+    constexpr int NP = COND ? FNGS + 1 : FNGS;  // [cond (zeros in vin) ;] mean ; sum
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int og = tid >> 4, pt = tid & 15, o4 = lane >> 4;
+    const int TC = COND ? FT + j.C : FT;
     f32x4 p[NSEG];
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         const float* vp = lds + sv[s].vin + FT + pt;
         p[s] = gl[0] * vp[0];
 #pragma unroll
-        for (int u = 1; u < FNGS; ++u) p[s] += gl[u] * vp[16 * u];
+        for (int u = 1; u < NP; ++u) p[s] += gl[u] * vp[16 * u];
     }
     after_fc1();
     const f32x4 bg1 = *reinterpret_cast<const f32x4*>(tbl + TBL_G1 + 4 * og);
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         p[s] = reduce_pt(p[s]);
-        if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].vin2 + FT + 4 * og) = lrelu4(p[s] + bg1, j.slope);
+        if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].vin2 + TC + 4 * og) = lrelu4(p[s] + bg1, j.slope);
     }
     __syncthreads();
     const f32x4 bg2 = *reinterpret_cast<const f32x4*>(tbl + TBL_G2 + 4 * o4);  // before the next chain's rows replace these
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
-        f32x4 gp = L.w2 * lds[sv[s].vin2 + FT + 16 * w + pt];
+        f32x4 gp = L.w2 * lds[sv[s].vin2 + TC + 16 * w + pt];
         gp = row_sum16(gp);
         if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].g2p + MAXL * w + 4 * o4) = gp;
     }
@@ -148,7 +168,7 @@ __device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restr
         for (int s = 0; s < NSEG; ++s) {
             f32x4 gn = fast_sum_partials(lds + sv[s].g2p + 4 * o4);
             gn = lrelu4(gn + bg2, j.slope);
-            if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].vin + FT + 2 * H + 4 * o4) = gn;
+            if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].vin + TC + 2 * H + 4 * o4) = gn;
         }
     }
     __syncthreads();
@@ -159,31 +179,38 @@ __device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restr
 // In: vin = [.. ; mean ; sum ; g_old], gl = rows of fc_global1 behind the time rows, wbA = row FT + pt of local linear 1's extras.
 // Out: vin.g = g_new, bj1 (each wave its own slice: the particle phase that follows needs no barrier).
 // NSEG == 2 (two jets in the workgroup, the packed sampler): the weights are in registers once, every step runs for both jets.
-template <int NSEG>
-__device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __restrict__ lds, const SegView (&sv)[2], const f32x4 (&gl)[FNG],
-                                                 const f32x4& wbA, const f32x4& w2, const float* __restrict__ tbl) {
+// COND: the input vectors carry C zeroed conditioning slots behind the time slots (the pooled part starts at TC = FT + C), L holds
+// this layer's local-linear-2 bias row for c.bj2 (published behind the first barrier: the previous particle phase has read the old one).
+template <int NSEG, bool COND>
+__device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __restrict__ lds, const Carve& c, const SegView (&sv)[2],
+                                                 const f32x4 (&gl)[COND ? FNGC : FNG], const f32x4& wbA, const ChainLoads& L,
+                                                 const float* __restrict__ tbl) {
+    static_assert(!(COND && NSEG != 1), "conditioned jets: one jet per workgroup");
+    constexpr int NP = COND ? FNGC : FNG;
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int og = tid >> 4, pt = tid & 15, o4 = lane >> 4;
+    const int TC = COND ? FT + j.C : FT;
     f32x4 gold[NSEG], p[NSEG];
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         const float* vin = lds + sv[s].vin;
-        gold[s] = *reinterpret_cast<const f32x4*>(vin + FT + 2 * H + 4 * o4);  // before anyone overwrites it
+        gold[s] = *reinterpret_cast<const f32x4*>(vin + TC + 2 * H + 4 * o4);  // before anyone overwrites it
         const float* vp = vin + FT + pt;
         p[s] = gl[0] * vp[0];
 #pragma unroll
-        for (int u = 1; u < FNG; ++u) p[s] += gl[u] * vp[16 * u];
+        for (int u = 1; u < NP; ++u) p[s] += gl[u] * vp[16 * u];
     }
     const f32x4 bg1 = *reinterpret_cast<const f32x4*>(tbl + TBL_G1 + 4 * og);
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         p[s] = reduce_pt(p[s]);
-        if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].vin2 + FT + 4 * og) = lrelu4(p[s] + bg1, j.slope);
+        if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].vin2 + TC + 4 * og) = lrelu4(p[s] + bg1, j.slope);
     }
     __syncthreads();
+    if (COND) fast_chain_publish_l2(L, lds + c.bj2);
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
-        f32x4 gp = w2 * lds[sv[s].vin2 + FT + 16 * w + pt];
+        f32x4 gp = L.w2 * lds[sv[s].vin2 + TC + 16 * w + pt];
         gp = row_sum16(gp);
         if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].g2p + MAXL * w + 4 * o4) = gp;
     }
@@ -198,9 +225,18 @@ __device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __rest
         gn = lrelu4(gn, j.slope);
         // each wave keeps its own copy of g_new (read back as the input of the bias GEMV: same wave, LDS is in order); wave 0's copy
         // is vin.g itself, the input of the next stage
-        float* gcopy = (w == 0) ? lds + sv[s].vin + FT + 2 * H : lds + sv[s].gcopy + MAXL * w;
+        float* gcopy = (w == 0) ? lds + sv[s].vin + TC + 2 * H : lds + sv[s].gcopy + MAXL * w;
         if (pt == 0) *reinterpret_cast<f32x4*>(gcopy + 4 * o4) = gn;
-        f32x4 p1 = wbA * gcopy[pt];  // entries >= L are lrelu(0) = 0 (zero-padded weights and biases)
+        // local linear 1's extras behind the time rows: [cond_l (Cl, tabulated: multiplied by 0 here) ; g]; entries >= L of g are
+        // lrelu(0) = 0 (zero-padded weights and biases)
+        float x;
+        if (COND) {
+            const int gx = pt - j.Cl;
+            x = gx >= 0 ? gcopy[gx] : 0.f;
+        } else {
+            x = gcopy[pt];
+        }
+        f32x4 p1 = wbA * x;
         p1 = reduce_pt(p1);
         if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].bj1 + 4 * og) = p1 + bl1;
     }
@@ -250,26 +286,42 @@ __device__ __forceinline__ void fast_head(const JetDims& j, float* __restrict__ 
     }
 }
 
+// Conditioned jets: the conditioning slots of the per-jet input vector and what the 18th panel reads behind g hold zeros for the whole
+// call (the conditioning terms come from the cond table).  Call once behind epic_jet_setup(cond = nullptr); a barrier must follow.
+__device__ __forceinline__ void fast_cond_zero(const JetDims& j, float* __restrict__ lds, const Carve& c) {
+    const int tid = threadIdx.x;
+    if (tid < j.C) lds[c.vin + FT + tid] = 0.f;
+    const int tail0 = FT + j.C + 2 * H + MAXL;  // behind g's 16 slots
+    if (tid < VIN_FLOATS - tail0) lds[c.vin + tail0 + tid] = 0.f;
+}
+
 // What an evaluation carries over from the one before it (requested behind that one's last particle phase / during its head):
 struct FastCarry {
     f32x4 a1[8], a2[8];  // a2: fc_l2's weights on entry; a1: scratch (phase-1 weights, then the head's)
     f32x4 sj1;           // this lane's slice of fc_l1's per-jet bias for the coming evaluation
     float aw;            // this lane's element of fc_l1's A operand (constant over the call)
 };
-__device__ __forceinline__ void fast_carry_request(FastCarry& cy, const pfm_epic_desc& d, blob_rsrc rs, const float* __restrict__ tbS_next) {
+// ctS (conditioned jets): the stem slot of the jet's cond table, or nullptr
+__device__ __forceinline__ void fast_carry_request(FastCarry& cy, const pfm_epic_desc& d, blob_rsrc rs, const float* __restrict__ tbS_next,
+                                                   const float* __restrict__ ctS = nullptr) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     load_afrag(cy.a2, rs, d.l2.A, w, lane);
     cy.sj1 = *reinterpret_cast<const f32x4*>(tbS_next + TB_SJ1 + 4 * (4 * w + (lane >> 4)));
+    if (ctS) cy.sj1 += *reinterpret_cast<const f32x4*>(ctS + TB_SJ1 + 4 * (4 * w + (lane >> 4)));
 }
 
 // One evaluation: yin -> emit(...).  tbE / tbE_next: the table rows of this and of the next evaluation (the last evaluation
 // passes its own again).
 // NSEG == 2: the rows [0, n_rows) hold two jets (sg: where the second starts); without conditioning every tabulated bias is the same
 // for both, so only the chains (pooled vectors, g, bj1) run per jet.
-template <bool BF16, int NSEG, typename Emit>
+// COND: ct = the jet's cond table ((layers + 1) slots, stem slot last); see fast_path_ok.
+template <bool BF16, int NSEG, bool COND, typename Emit>
 __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims& j, const float* __restrict__ blob,
                                           float* __restrict__ lds, const Carve& c, int n_rows, const float* __restrict__ tbE,
-                                          const float* __restrict__ tbE_next, FastCarry& cy, Emit emit, const Segs* sg = nullptr) {
+                                          const float* __restrict__ tbE_next, FastCarry& cy, Emit emit, const Segs* sg = nullptr,
+                                          const float* __restrict__ ct = nullptr) {
+    static_assert(!(COND && NSEG != 1), "conditioned jets: one jet per workgroup");
+    constexpr int NGL = COND ? FNGC : FNG, NGLS = COND ? FNGS + 1 : FNGS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const SegView sv[2] = {seg_view(c, j.N, 0), seg_view(c, j.N, NSEG == 2 ? 1 : 0)};
     Seg2Phase s2p, s2t;  // the second jet as a phase with an LDS bias (bj1) / with a table bias sees it
@@ -284,36 +336,43 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     float* bufB = lds + c.bufB;
     const float* maskf = lds + c.maskf;
     const float* tbS = tbE + (size_t)j.layers * TB_SLOT;
+    const float* ctS = COND ? ct + (size_t)j.layers * TB_SLOT : nullptr;
+    const int w2r0 = COND ? FT + j.C : FT;  // fc_global2's 128-row window starts behind the (zeroed) conditioning rows
     const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
-    f32x4 gl[FNG], wbA[1];
+    f32x4 gl[NGL], wbA[1];
     PFM_STAMP(1);
     float* tbl = lds + c.total;  // TBL_FLOATS behind the carve (fast_path_ok: it fits)
-    // the stem chain's own loads, two phases ahead of their use
-    ChainLoads L = fast_chain_loads(rs, d.g2.W, tbS, TB_SG1, TB_SG1, TB_SG2);
+    // the stem chain's own loads, two phases ahead of their use (conditioned jets: with fc_l2's bias row for c.bj2)
+    ChainLoads L = fast_chain_loads(rs, d.g2.W, w2r0, tbS, TB_SG1, TB_SG1, TB_SG2, ctS, TB_SJ2);
     fast_stem_l1(j, lds, c, n_rows, cy.aw, cy.sj1);
+    if (COND) {  // fc_l2 reads its per-jet bias (time + conditioning term) from LDS: in place before the barrier in front of it
+        fast_chain_publish(L, tbl);
+        fast_chain_publish_l2(L, lds + c.bj2);
+    }
     __syncthreads();
     PFM_STAMP(3);
     // ---- fc_l2: bufB = lrelu(W.bufA + bj2 + bufA), pooled -> vin   epic.py:364-371; carries the stem chain's fc_g1 rows
     {
-        Prefetch<FNGS> pf{rs, gl, nullptr, nullptr, nullptr, seg_panels(d.g1.W, FTP, tid), {}, {}, {}};
-        s2t.bj = tbS + TB_SJ2;
-        gemm_phase<true, true, false, BF16, decltype(pf), NSEG>(cy.a2, bufA, bufB, bufA, tbS + TB_SJ2, maskf, j, lds, c, nullptr, nullptr,
-                                                                 n_rows, pf, s2t);
+        Prefetch<NGLS> pf{rs, gl, nullptr, nullptr, nullptr, seg_panels(d.g1.W, FTP, tid), {}, {}, {}};
+        const float* bj = COND ? lds + c.bj2 : tbS + TB_SJ2;
+        s2t.bj = bj;
+        gemm_phase<true, true, false, BF16, decltype(pf), NSEG>(cy.a2, bufA, bufB, bufA, bj, maskf, j, lds, c, nullptr, nullptr, n_rows, pf,
+                                                                 s2t);
     }
-    fast_chain_publish(L, tbl);  // (the previous evaluation's last chain read tbl many barriers ago)
+    if (!COND) fast_chain_publish(L, tbl);  // (the previous evaluation's last chain read tbl many barriers ago)
     __syncthreads();
     PFM_STAMP(4);
     {
         const pfm_epic_layer& l0 = d.layer[0];
         ChainLoads L0;
-        fast_chain_stem<NSEG>(j, lds, sv, gl, L, tbl, [&]() {
+        fast_chain_stem<NSEG, COND>(j, lds, sv, gl, L, tbl, [&]() {
             // the first layer's windows, phase-1 weights and chain loads: no particle phase to ride on; they land behind the rest of the stem chain
-            Prefetch<FNG, 1> pf{rs, gl, wbA, nullptr, nullptr, seg_panels(l0.gl1.W, FTP, tid), seg_panels(l0.lc1.We, FTP, tid), {}, {}};
-            pf.template issue_range<0, FNG + 1>();
+            Prefetch<NGL, 1> pf{rs, gl, wbA, nullptr, nullptr, seg_panels(l0.gl1.W, FTP, tid), seg_panels(l0.lc1.We, FTP, tid), {}, {}};
+            pf.template issue_range<0, NGL + 1>();
             load_afrag(cy.a1, rs, l0.lc1.A, w, lane);
-            L0 = fast_chain_loads(rs, l0.gl2.W, tbE, TB_G1, TB_L1, TB_G2);
+            L0 = fast_chain_loads(rs, l0.gl2.W, w2r0, tbE, TB_G1, TB_L1, TB_G2, COND ? ct : nullptr, TB_L2);
         }, [&]() { fast_chain_publish(L0, tbl); });
-        L.w2 = L0.w2;
+        L = L0;
     }
     f32x4 b3 = {0.f, 0.f, 0.f, 0.f};  // head bias (zero for f >= F): requested in front of the last particle phase
     for (int k = 0; k < j.layers; ++k) {
@@ -323,35 +382,40 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         const float* tbK = tbE + (size_t)k * TB_SLOT;
         const float* tbN = tbE + (size_t)(last ? k : k + 1) * TB_SLOT;
         PFM_STAMP(10);
-        fast_chain_layer<NSEG>(j, lds, sv, gl, wbA[0], L.w2, tbl);
+        fast_chain_layer<NSEG, COND>(j, lds, c, sv, gl, wbA[0], L, tbl);
         PFM_STAMP(12);
         // phase 1: bufA = lrelu(W1 . bufB + bj1)   epic.py:194-196.  Riders: phase 2's weights and ALL per-jet windows of the next
         // layer (gl / wbA were consumed by the chain above), so that nothing the next chain waits for is requested late
         {
-            Prefetch<8, FNG, 1> pf{rs, cy.a2, gl, wbA, nullptr, seg_afrag(ly.lc2.A, w, lane), seg_panels(nx.gl1.W, FTP, tid),
+            Prefetch<8, NGL, 1> pf{rs, cy.a2, gl, wbA, nullptr, seg_afrag(ly.lc2.A, w, lane), seg_panels(nx.gl1.W, FTP, tid),
                                    seg_panels(nx.lc1.We, FTP, tid), {}};
             gemm_phase<false, false, false, BF16, decltype(pf), NSEG>(cy.a1, bufB, bufA, nullptr, lds + c.bj1, maskf, j, lds, c, nullptr,
                                                                        nullptr, n_rows, pf, s2p);
         }
         __syncthreads();
         PFM_STAMP(13);
-        L = fast_chain_loads(rs, nx.gl2.W, tbN, TB_G1, TB_L1, TB_G2);  // the next chain's loads, a phase ahead
-        if (last) b3 = *reinterpret_cast<const f32x4*>(tbS + TB_SB3 + 4 * (lane >> 4));
+        // the next chain's loads, a phase ahead
+        L = fast_chain_loads(rs, nx.gl2.W, w2r0, tbN, TB_G1, TB_L1, TB_G2, COND ? ct + (size_t)(last ? k : k + 1) * TB_SLOT : nullptr, TB_L2);
+        if (last) {
+            b3 = *reinterpret_cast<const f32x4*>(tbS + TB_SB3 + 4 * (lane >> 4));
+            if (COND) b3 += *reinterpret_cast<const f32x4*>(ctS + TB_SB3 + 4 * (lane >> 4));
+        }
         // phase 2: bufB = lrelu(W2 . bufA + bj2 + bufB), pooled -> vin    epic.py:198-200, :160-162
-        // (bj2 = bias + time term: constant per evaluation and layer, read from the table).  Riders: the next layer's phase-1
-        // weights, or the head's one 16-row panel behind the last layer, into a1 (free since phase 1)
+        // (bj2 = bias + time term: constant per evaluation and layer, read from the table; conditioned jets: + the jet's term, from
+        // c.bj2).  Riders: the next layer's phase-1 weights, or the head's one 16-row panel behind the last layer, into a1 (free since phase 1)
         {
             const PfSeg sa = last ? PfSeg{d.l3_A, 256, lane * 16} : seg_afrag(nx.lc1.A, w, lane);
             Prefetch<8> pf{rs, cy.a1, nullptr, nullptr, nullptr, sa, {}, {}, {}};
-            s2t.bj = tbK + TB_L2;
-            gemm_phase<true, true, false, BF16, decltype(pf), NSEG>(cy.a2, bufA, bufB, bufB, tbK + TB_L2, maskf, j, lds, c, nullptr, nullptr,
-                                                                     n_rows, pf, s2t);
+            const float* bj = COND ? lds + c.bj2 : tbK + TB_L2;
+            s2t.bj = bj;
+            gemm_phase<true, true, false, BF16, decltype(pf), NSEG>(cy.a2, bufA, bufB, bufB, bj, maskf, j, lds, c, nullptr, nullptr, n_rows, pf,
+                                                                     s2t);
         }
         fast_chain_publish(L, tbl);  // this layer's chain read tbl two barriers ago; the next one reads it behind the barrier below
         __syncthreads();
     }
     PFM_STAMP(20);
-    fast_carry_request(cy, d, rs, tbE_next + (size_t)j.layers * TB_SLOT);  // lands behind the head
+    fast_carry_request(cy, d, rs, tbE_next + (size_t)j.layers * TB_SLOT, ctS);  // lands behind the head
     fast_head(j, lds, c, n_rows, cy.a1, b3, emit);
 }
 

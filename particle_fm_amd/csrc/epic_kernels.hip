@@ -281,10 +281,13 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_kernel(
 // ------------------------------------------------------------------------------------------------
 // PAIRS: the launch may hold two-jet workgroups (PFM_F_PACK_JETS); the one-jet instantiation does not carry that path (its register
 // allocation and code size are the single jet's own).
-template <int MODE, bool PAIRS>
+// COND: conditioned jets (one per workgroup); ctab = the call's cond table [n_jets][layers + 1][TB_SLOT] (epic_cond_table_kernel).
+template <int MODE, bool PAIRS, bool COND = false>
 __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
     const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ dt, int n_intervals, const float* __restrict__ z,
-    const float* __restrict__ mask, float* __restrict__ x_out, const float* __restrict__ table, const int* __restrict__ pack) {
+    const float* __restrict__ mask, float* __restrict__ x_out, const float* __restrict__ table, const int* __restrict__ pack,
+    const float* __restrict__ ctab) {
+    static_assert(!(PAIRS && COND), "conditioned jets: one jet per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d0);
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
             const int stage = e & 1;
             const float h = dt[e >> 1];
             const float hs = stage ? h : __fmul_rn(0.5f, h);
-            fast_eval<MODE == 1, 2>(d0, j, blob, lds, c, sg.rows, table + e * estride, table + (e + 1 < n_evals ? e + 1 : e) * estride, cy,
+            fast_eval<MODE == 1, 2, false>(d0, j, blob, lds, c, sg.rows, table + e * estride, table + (e + 1 < n_evals ? e + 1 : e) * estride, cy,
                                     [=](int p, int f, float val) {
                                         const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
                                         yin[p * F + f] = xn;
@@ -337,8 +340,11 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
         lds[c.xs + i] = z0;
         lds[c.yin + i] = z0;
     }
+    const float* ct = COND ? ctab + (size_t)jet * estride : nullptr;
+    if (COND) fast_cond_zero(j, lds, c);
     __syncthreads();
-    fast_carry_request(cy, d0, make_blob_rsrc(blob, d0.blob_floats + PFM_DESC_FLOATS), table + (size_t)j.layers * TB_SLOT);
+    fast_carry_request(cy, d0, make_blob_rsrc(blob, d0.blob_floats + PFM_DESC_FLOATS), table + (size_t)j.layers * TB_SLOT,
+                       COND ? ct + (size_t)j.layers * TB_SLOT : nullptr);
     for (int e = 0; e < n_evals; ++e) {
 #ifdef PFM_DIAG
         if (e == n_evals - 1 && blockIdx.x == 0 && threadIdx.x == 0) g_pfm_nstamp = 0;  // keep the last NFE
@@ -348,12 +354,12 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
         const float h = dt[e >> 1];
         const float hs = stage ? h : __fmul_rn(0.5f, h);
         // stage 0: x_mid = x + 0.5*dt*k1 -> next input;   stage 1: x = x + dt*f(t+dt/2, x_mid)
-        fast_eval<MODE == 1, 1>(d0, j, blob, lds, c, n_rows, table + e * estride, table + (e + 1 < n_evals ? e + 1 : e) * estride, cy,
-                                [=](int p, int f, float val) {
-                                    const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
-                                    yin[p * F + f] = xn;
-                                    if (stage) xs[p * F + f] = xn;
-                                });
+        fast_eval<MODE == 1, 1, COND>(d0, j, blob, lds, c, n_rows, table + e * estride, table + (e + 1 < n_evals ? e + 1 : e) * estride, cy,
+                                      [=](int p, int f, float val) {
+                                          const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
+                                          yin[p * F + f] = xn;
+                                          if (stage) xs[p * F + f] = xn;
+                                      }, nullptr, ct);
         __syncthreads();
         PFM_STAMP(30);
     }
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_rk_fast_kernel(
         const bool last = st == S - 1;
         const float* coef = last ? tab.b : tab.a[st + 1 < PFM_RK_MAX_STAGES ? st + 1 : 0];
         const float r0 = rhs ? rhs[2 * e] : 0.f, r1 = rhs ? rhs[2 * e + 1] : 1.f;
-        fast_eval<MODE == 1, 1>(d0, j, blob, lds, c, n_rows, table + e * estride, table + (e + 1 < n_evals ? e + 1 : e) * estride, cy,
+        fast_eval<MODE == 1, 1, false>(d0, j, blob, lds, c, n_rows, table + e * estride, table + (e + 1 < n_evals ? e + 1 : e) * estride, cy,
                                 [=](int p, int f, float val) {
                                     const int i = p * F + f;
                                     if (rhs) val = __fmul_rn(r0, __fsub_rn(yin[i], __fdiv_rn(val, r1)));  // -0.5 beta (x - eps_theta / noise_rate)
@@ -539,6 +545,49 @@ __global__ __launch_bounds__(NT) void epic_time_table_kernel(const float* __rest
         float s = 0.f;
         for (int r = 0; r < j.T; ++r) s = fmaf(blob[ly.gl2.W + (r >> 4) * 256 + (r & 15) * 16 + o], temb[r], s);
         out[TB_G2 + o] = fast ? blob[ly.gl2.b + o] + s : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cond table of a sampling call (conditioned jets on the lean evaluation, epic_fast.h): ctab[jet][slot][TB_SLOT] = W_c^T cond[jet] for
+// the conditioning rows (rows T .. T + C of every global block, T .. T + Cl of every extras block) of the Linears the time table covers,
+// same slot layout (layer slots, stem slot last), no bias.  grid (n_jets, layers + 1), 512 threads.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void epic_cond_table_kernel(const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ cond,
+                                                              float* __restrict__ ctab) {
+    __shared__ float cj[MAXC];
+    const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
+    const JetDims j = dims_of(d);
+    const int jet = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+    if (tid < j.C) cj[tid] = cond[(size_t)jet * j.C + tid];
+    __syncthreads();
+    float* out = ctab + ((size_t)jet * (j.layers + 1) + k) * TB_SLOT;
+    const int which = tid >> 7, o = tid & 127;
+    const bool stem = k == j.layers;
+    if (which < 3) {
+        // layer slot: 0 fc_global1 (C rows) | 1 local-1 extras (Cl) | 2 local-2 extras (Cl); stem slot: 0 fc_l1 extras (Cl) | 1 fc_l2
+        // extras (Cl) | 2 fc_g1 (C)
+        int64_t W;
+        int rows;
+        if (stem) { W = which == 0 ? d.l1_We : (which == 1 ? d.l2.We : d.g1.W); rows = which == 2 ? j.C : j.Cl; }
+        else { const pfm_epic_layer& ly = d.layer[k]; W = which == 0 ? ly.gl1.W : (which == 1 ? ly.lc1.We : ly.lc2.We); rows = which == 0 ? j.C : j.Cl; }
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s = fmaf(blob[W + km16(j.T + r, o)], cj[r], s);
+        out[which * 128 + o] = s;
+    } else if (o < 16) {  // fc_global2 / fc_g2 (KP16), C rows
+        const int64_t W = stem ? d.g2.W : d.layer[k].gl2.W;
+        float s = 0.f;
+        for (int r = 0; r < j.C; ++r) {
+            const int kr = j.T + r;
+            s = fmaf(blob[W + (kr >> 4) * 256 + (kr & 15) * 16 + o], cj[r], s);
+        }
+        out[(stem ? TB_SG2 : TB_G2) + o] = s;
+    } else if (o < 32 && stem) {  // fc_l3 extras (KMAJOR [T + Cl][F]), Cl rows
+        const int f = o - 16;
+        float s = 0.f;
+        if (f < j.F)
+            for (int r = 0; r < j.Cl; ++r) s = fmaf(blob[d.l3_We + (j.T + r) * j.F + f], cj[r], s);
+        out[TB_SB3 + f] = s;
     }
 }
 
@@ -682,10 +731,12 @@ int pfm_epic_forward_temb(const pfm_epic_desc* d, const float* blob, const float
     return check_hip(hipGetLastError(), "epic_forward_kernel launch");
 }
 
-// scratch of a sampling call: time-term table [2 n_intervals][layers + 1][TB_SLOT] | workgroup list [1 + 2 B] (int32)
+// scratch of a sampling call: time-term table [2 n_intervals][layers + 1][TB_SLOT] | cond table [B][layers + 1][TB_SLOT] (conditioned
+// models) | workgroup list [1 + 2 B] (int32)
+static int64_t cond_table_floats(const pfm_epic_desc* d, int B) { return d->cond_global > 0 ? (int64_t)B * (d->layers + 1) * TB_SLOT : 0; }
 int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc* d, int32_t n_intervals, int32_t B) {
     if (!d || n_intervals < 0 || B < 0) return -1;
-    return (int64_t)2 * n_intervals * (d->layers + 1) * TB_SLOT + ((2 * (int64_t)B + 1 + 63) & ~63);
+    return (int64_t)2 * n_intervals * (d->layers + 1) * TB_SLOT + cond_table_floats(d, B) + ((2 * (int64_t)B + 1 + 63) & ~63);
 }
 
 static bool sample_fast(const pfm_epic_desc* d, int mode) { return d && d->layers > 0 && fast_path_ok(*d) && mode != 2; }
@@ -734,12 +785,15 @@ static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const floa
     if (n_intervals < 0) return set_err(PFM_E_BADARG, "n_intervals < 0");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
     const int64_t table_floats = (int64_t)2 * n_intervals * (d->layers + 1) * TB_SLOT;
+    const int64_t list_off = table_floats + cond_table_floats(d, B);  // the workgroup list sits behind both tables
     // the lean evaluation of epic_fast.h: unconditioned jets, T = 32, F <= 4, fp32 / bf16 operands, one jet per workgroup
     const bool fast = tb && sample_fast(d, mode);
     if (fast) {
         static const char* env_pack = getenv("PFM_PACK");  // as queue_jet_pack
         const bool pairs = env_pack ? env_pack[0] == '1' : (d->flags & PFM_F_PACK_JETS) != 0;
-        const void* fk = pairs ? (mode == 1 ? (const void*)epic_sample_midpoint_fast_kernel<1, true> : (const void*)epic_sample_midpoint_fast_kernel<0, true>)
+        const bool cnd = d->cond_global > 0;  // (fast_path_ok: never together with pairs)
+        const void* fk = cnd ? (mode == 1 ? (const void*)epic_sample_midpoint_fast_kernel<1, false, true> : (const void*)epic_sample_midpoint_fast_kernel<0, false, true>)
+                       : pairs ? (mode == 1 ? (const void*)epic_sample_midpoint_fast_kernel<1, true> : (const void*)epic_sample_midpoint_fast_kernel<0, true>)
                                : (mode == 1 ? (const void*)epic_sample_midpoint_fast_kernel<1, false> : (const void*)epic_sample_midpoint_fast_kernel<0, false>);
         if ((rc = validate(d))) return rc;
         lds = (make_carve(d->n_points, d->features).total + TBL_FLOATS) * 4;  // + the chain's table rows behind the carve (fast_path_ok: it fits)
@@ -754,19 +808,27 @@ static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const floa
     if (fast) {
         static const char* env_pack = getenv("PFM_PACK");
         const bool pairs = env_pack ? env_pack[0] == '1' : (d->flags & PFM_F_PACK_JETS) != 0;
-        const int* jet_order = queue_jet_pack(d, scratch, table_floats, mask, B, mode, (hipStream_t)stream);  // singles unless `pairs`
-#define PFM_LAUNCH_FAST(M, P)                                                                                                          \
-    hipLaunchKernelGGL((epic_sample_midpoint_fast_kernel<M, P>), dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, dt, \
-                       n_intervals, z, mask, x_out, (const float*)scratch, jet_order)
-        if (pairs) { if (mode == 1) PFM_LAUNCH_FAST(1, true); else PFM_LAUNCH_FAST(0, true); }
-        else { if (mode == 1) PFM_LAUNCH_FAST(1, false); else PFM_LAUNCH_FAST(0, false); }
+        const int* jet_order = queue_jet_pack(d, scratch, list_off, mask, B, mode, (hipStream_t)stream);  // singles unless `pairs`
+        const bool cnd = d->cond_global > 0;
+        float* ctab = nullptr;
+        if (cnd) {  // the jets' conditioning terms, once per call
+            ctab = scratch + table_floats;
+            hipLaunchKernelGGL(epic_cond_table_kernel, dim3(B, d->layers + 1), dim3(NT), 0, (hipStream_t)stream, blob, d->blob_floats, cond, ctab);
+            if ((rc = check_hip(hipGetLastError(), "epic_cond_table_kernel launch"))) return rc;
+        }
+#define PFM_LAUNCH_FAST(M, P, C)                                                                                                          \
+    hipLaunchKernelGGL((epic_sample_midpoint_fast_kernel<M, P, C>), dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, dt, \
+                       n_intervals, z, mask, x_out, (const float*)scratch, jet_order, (const float*)ctab)
+        if (cnd) { if (mode == 1) PFM_LAUNCH_FAST(1, false, true); else PFM_LAUNCH_FAST(0, false, true); }
+        else if (pairs) { if (mode == 1) PFM_LAUNCH_FAST(1, true, false); else PFM_LAUNCH_FAST(0, true, false); }
+        else { if (mode == 1) PFM_LAUNCH_FAST(1, false, false); else PFM_LAUNCH_FAST(0, false, false); }
 #undef PFM_LAUNCH_FAST
         return check_hip(hipGetLastError(), "epic_sample_midpoint_fast_kernel launch");
     }
 #define PFM_LAUNCH_SMP(M, T)                                                                                                  \
     hipLaunchKernelGGL((epic_sample_midpoint_kernel<M, T>), dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, \
                        t_eval, dt, n_intervals, z, cond, mask, x_out, (const float*)scratch, order, temb_tab)
-    const int* order = queue_jet_pack(d, scratch, table_floats, mask, B, mode, (hipStream_t)stream);
+    const int* order = queue_jet_pack(d, scratch, list_off, mask, B, mode, (hipStream_t)stream);
     if (tb) { if (mode == 2) PFM_LAUNCH_SMP(2, true); else if (mode == 1) PFM_LAUNCH_SMP(1, true); else PFM_LAUNCH_SMP(0, true); }
     else { if (mode == 2) PFM_LAUNCH_SMP(2, false); else if (mode == 1) PFM_LAUNCH_SMP(1, false); else PFM_LAUNCH_SMP(0, false); }
 #undef PFM_LAUNCH_SMP
@@ -809,7 +871,7 @@ static int sample_rk(const pfm_epic_desc* d, const float* blob, const pfm_rk_tab
     // the lean evaluation (epic_fast.h) when the caller's scratch has room for the time table of every stage time
     const int n_evals = tab->stages * n_intervals;
     const int64_t table_off = rk_table_off(d, tab->stages, B), table_floats = (int64_t)n_evals * (d->layers + 1) * TB_SLOT;
-    if (sample_fast(d, mode) && !(d->flags & PFM_F_PACK_JETS) && kbuf_floats >= table_off + table_floats && n_evals > 0) {
+    if (sample_fast(d, mode) && d->cond_global == 0 && !(d->flags & PFM_F_PACK_JETS) && kbuf_floats >= table_off + table_floats && n_evals > 0) {
         float* table = kbuf + table_off;
         hipLaunchKernelGGL(epic_time_table_kernel, dim3(n_evals, d->layers + 1), dim3(NT), 0, (hipStream_t)stream, blob, d->blob_floats,
                            t_eval, table, temb_tab, 1);

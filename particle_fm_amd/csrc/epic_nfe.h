@@ -1013,9 +1013,10 @@ __device__ __forceinline__ int epic_jet_setup(const pfm_epic_desc& d, const JetD
         cnt += m;
         if (m != 0.f) last = p;
     }
-    if (tid < j.C) {
-        lds[c.vin + j.T + tid] = cond_jet[tid];
-        lds[c.vin2 + j.T + tid] = cond_jet[tid];
+    if (tid < j.C) {  // (cond_jet == nullptr: the lean evaluation of conditioned jets keeps zeros there, epic_fast.h)
+        const float cv = cond_jet ? cond_jet[tid] : 0.f;
+        lds[c.vin + j.T + tid] = cv;
+        lds[c.vin2 + j.T + tid] = cv;
     }
     if (tid >= 64 && tid < 64 + MAXL) lds[c.vin + j.T + j.C + 2 * H + (tid - 64)] = 0.f;
     for (int m = 32; m >= 1; m >>= 1) {

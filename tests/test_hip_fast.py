@@ -49,7 +49,9 @@ def test_path_selection():
     assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL | PACK)) == 1  # two jets per workgroup run on the lean evaluation too
     assert q(EpicLayout(cfg_of(g.hp), flags=SKIP_TAIL | 4)) == 0  # split fp16
     assert q(EpicLayout(cfg_of(load_golden("jetnet30").hp), flags=SKIP_TAIL)) == 1
-    assert q(EpicLayout(cfg_of(load_golden("cond_gl").hp), flags=SKIP_TAIL)) == 0  # conditioned: per-jet stem terms
+    assert q(EpicLayout(cfg_of(load_golden("cond_gl").hp), flags=SKIP_TAIL)) == 1  # conditioned (2 + 2): the jet's terms from the cond table
+    assert q(EpicLayout(cfg_of(load_golden("cond_gl").hp), flags=SKIP_TAIL | PACK)) == 0  # ... one jet per workgroup only
+    assert q(EpicLayout(cfg_of(load_golden("cond_jetclass").hp), flags=SKIP_TAIL)) == 0  # 13 features: fc_l1 is not one MFMA
 
 
 @pytest.mark.parametrize("name,B,steps", [("jetnet150", 40, 6), ("jetnet30", 48, 11), ("jetnet150", 7, 100)])
@@ -191,3 +193,32 @@ def test_fast_rk_sampler_matches_generic_and_oracle(solver, steps):
     torch.testing.assert_close(a, ref, atol=2e-5, rtol=1e-4)
     assert torch.all(a[mask.squeeze(-1) == 0] == 0)
     assert torch.equal(a, hip_ops.epic_sample_rk(fast, blob_f, z.cuda(), None, mask.cuda(), ode_steps=steps, solver=solver).cpu())
+
+
+@pytest.mark.parametrize("B,steps", [(24, 6), (5, 100)])
+def test_fast_sampler_conditioned_jets(B, steps):
+    """global + local conditioning (fm_tops*_cond.yaml: 2 + 2): the conditioning columns of every per-jet Linear come from the
+    per-jet cond table (epic_cond_table_kernel); against the generic kernel, the oracle and the reference's midpoint vectors."""
+    from particle_fm_amd import hip_ops
+    g, fast, blob_f, gen, blob_g = _layouts("cond_gl")
+    N, F, C = g.hp["num_particles"], g.hp["features"], g.hp["global_cond_dim"]
+    n, mask, z = _ragged(B, N, F, seed=3 + B)
+    n[0], n[1] = N, 1
+    mask = (torch.arange(N)[None] < n[:, None]).float().unsqueeze(-1)
+    cond = torch.randn(B, C, generator=torch.Generator().manual_seed(B))
+    a = hip_ops.epic_sample_midpoint(fast, blob_f, z.cuda(), cond.cuda(), mask.cuda(), ode_steps=steps).cpu()
+    b = hip_ops.epic_sample_midpoint(gen, blob_g, z.cuda(), cond.cuda(), mask.cuda(), ode_steps=steps).cpu()
+    torch.testing.assert_close(a, b, atol=5e-6, rtol=1e-5)
+    vf = EpicVectorField(g.state, "flows.0.net", g.hp, freqs=g.freqs)
+    ref = sample_midpoint(vf, z, cond, mask, ode_steps=steps)
+    torch.testing.assert_close(a, ref, atol=5e-5 if steps > 20 else 2e-5, rtol=1e-4)
+    assert torch.all(a[mask.squeeze(-1) == 0] == 0)
+    # a jet's result depends on its own conditioning only
+    cond2 = cond.clone(); cond2[3:] += 1.0
+    a2 = hip_ops.epic_sample_midpoint(fast, blob_f, z.cuda(), cond2.cuda(), mask.cuda(), ode_steps=steps).cpu()
+    assert torch.equal(a2[:3], a[:3]) and not torch.equal(a2[3:], a[3:])
+    for st in (3, 10):
+        tag = f"midpoint_{st}/"
+        out = hip_ops.epic_sample_midpoint(fast, blob_f, g.get(tag + "z").cuda(), g.get(tag + "cond").cuda(),
+                                           None if g.get(tag + "mask") is None else g.get(tag + "mask").float().cuda(), ode_steps=st).cpu()
+        torch.testing.assert_close(out, g.get(tag + "x_end"), atol=5e-5, rtol=1e-4)

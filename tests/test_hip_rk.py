@@ -66,7 +66,8 @@ def test_euler_rk4_and_midpoint_tableau(family):
         from particle_fm_amd import _lib
         # unconditioned jets run both samplers on the lean evaluation with the time-term table (csrc/epic_fast.h); otherwise the Runge-
         # Kutta kernel has no table and the tuned midpoint sampler's table changes the sum order
-        if not _lib.load().pfm_epic_sample_is_fast(ctypes.byref(lay.desc)):
+        # (conditioned jets: only the midpoint sampler has the lean path, the Runge-Kutta kernel stays generic)
+        if not _lib.load().pfm_epic_sample_is_fast(ctypes.byref(lay.desc)) or g.hp["global_cond_dim"] > 0:
             kw = dict(time_table=False)
     b = sample_mid(lay, blob, _dev(z), _dev(cond), _dev(mask), ode_steps=10, **kw).cpu()
     assert torch.equal(a, b)
