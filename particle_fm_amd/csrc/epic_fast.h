@@ -181,8 +181,8 @@ __device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restr
 // In: vin = [.. ; mean ; sum ; g_old], gl = rows of fc_global1 behind the time rows, wbA = row FT + pt of local linear 1's extras.
 // Out: vin.g = g_new, bj1 (each wave its own slice: the particle phase that follows needs no barrier).
 // NSEG == 2 (two jets in the workgroup, the packed sampler): the weights are in registers once, every step runs for both jets.
-// COND: the input vectors carry C zeroed conditioning slots behind the time slots (the pooled part starts at TC = FT + C), L holds
-// this layer's local-linear-2 bias row for c.bj2 (published behind the first barrier: the previous particle phase has read the old one).
+// COND: the input vectors carry C zeroed conditioning slots behind the time slots (the pooled part starts at TC = FT + C).  L holds
+// this layer's local-linear-2 bias row for c.bj2 (published at the end of the chain).
 template <int NSEG, bool COND>
 __device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __restrict__ lds, const Carve& c, const SegView (&sv)[2],
                                                  const f32x4 (&gl)[COND ? FNGC : FNG], const f32x4& wbA, const ChainLoads& L,
@@ -209,7 +209,6 @@ __device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __rest
         if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].vin2 + TC + 4 * og) = lrelu4(p[s] + bg1, j.slope);
     }
     __syncthreads();
-    if (COND || L2LDS) fast_chain_publish_l2(L, lds + c.bj2);
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         f32x4 gp = L.w2 * lds[sv[s].vin2 + TC + 16 * w + pt];
@@ -242,6 +241,9 @@ __device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __rest
         p1 = reduce_pt(p1);
         if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].bj1 + 4 * og) = p1 + bl1;
     }
+    // local linear 2's bias row -> c.bj2, last: its vmcnt wait covers the phase-1 weights requested behind the row, which the particle
+    // phase right behind this chain waits for anyway (the previous particle phase read the old row two barriers ago)
+    if (COND || L2LDS) fast_chain_publish_l2(L, lds + c.bj2);
 }
 
 // fc_l3 head with its per-jet bias from the table and its weights already in registers (requested during the last particle
@@ -410,10 +412,13 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
             Prefetch<8> pf{rs, cy.a1, nullptr, nullptr, nullptr, sa, {}, {}, {}};
             const float* bj = (COND || L2LDS) ? lds + c.bj2 : tbK + TB_L2;
             s2t.bj = bj;
-            gemm_phase<true, true, false, BF16, decltype(pf), NSEG>(cy.a2, bufA, bufB, bufB, bj, maskf, j, lds, c, nullptr, nullptr, n_rows, pf,
-                                                                     s2t);
+            gemm_phase<true, true, false, BF16, decltype(pf), NSEG, false>(cy.a2, bufA, bufB, bufB, bj, maskf, j, lds, c, nullptr, nullptr, n_rows,
+                                                                            pf, s2t);
+            // this layer's chain read tbl two barriers ago; the next one reads it behind the barrier below.  The publish waits for the
+            // staged row with a vmcnt that covers every load issued before it: the riders a short jet had no K-quarter for go behind it
+            fast_chain_publish(L, tbl);
+            pf.issue_tail(phase_full_pairs<BF16>(n_rows));
         }
-        fast_chain_publish(L, tbl);  // this layer's chain read tbl two barriers ago; the next one reads it behind the barrier below
         __syncthreads();
     }
     PFM_STAMP(20);

@@ -185,6 +185,14 @@ struct Prefetch {
     __device__ __forceinline__ void issue_pair() const {  // everything pair P would have carried
         issue_range<(4 * P * LPS < COUNT ? 4 * P * LPS : COUNT), (4 * (P + 1) * LPS < COUNT ? 4 * (P + 1) * LPS : COUNT)>();
     }
+    // the part of the list a jet with `nfull` full tile pairs had no pairs for (behind the pair loop)
+    __device__ __forceinline__ void issue_tail(int nfull) const {
+        if (nfull <= 0) issue_pair<0>();
+        if (nfull <= 1) issue_pair<1>();
+        if (nfull <= 2) issue_pair<2>();
+        if (nfull <= 3) issue_pair<3>();
+        if (nfull <= 4) issue_pair<4>();
+    }
 };
 using PfNone = Prefetch<0>;
 // segment of an A-fragment load (load_afrag) / of a run of KM16 GEMV panels (gemv4_load) / of this thread's fc_global2 rows
@@ -204,7 +212,14 @@ __device__ __forceinline__ PfSeg seg_panels(int64_t W_off, int first_panel, int 
 // such rows only produce garbage in their own output columns, which are never stored or pooled.
 // POOL: masked column sums -> vin (mean | sum*scale).  SAVE: rows also go to `save` (global).
 // NSEG == 2: the rows hold two jets (the second from tile s2.t1 on): each tile takes its own jet's bias, the pool keeps two sums.
-template <bool RESID, bool POOL, bool SAVE, bool BF16 = false, typename PF = PfNone, int NSEG = 1>
+// the number of full tile pairs the pair loop of gemm_phase runs for n_rows rows
+template <bool BF16>
+__device__ __forceinline__ int phase_full_pairs(int n_rows) {
+    return BF16 ? (n_rows + 2 * TILE - 1) / (2 * TILE) : (n_rows / TILE + (n_rows % TILE >= 1 ? 1 : 0)) / 2;  // bf16: no half pair
+}
+// TAIL = false: the caller issues pf.issue_tail(phase_full_pairs<BF16>(n_rows)) itself (behind work of its own that must not wait for
+// those loads: a vmcnt wait covers every load issued before it)
+template <bool RESID, bool POOL, bool SAVE, bool BF16 = false, typename PF = PfNone, int NSEG = 1, bool TAIL = true>
 __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __restrict__ src,
                                            float* __restrict__ dst, const float* __restrict__ resid,
                                            const float* __restrict__ bj, const float* __restrict__ maskf,
@@ -362,7 +377,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
     // The pairs whose two tiles are both real run as straight-line bodies with a compile-time pair index P (the loop is unrolled
     // so that the prefetch list's loads get static registers: one load behind every K-quarter); a jet with an odd tile count
     // ends with one more body that issues the real tile's MFMAs only (runtime pair index, no prefetch slot).
-    const int nfull = BF16 ? npairs : (n_rows / TILE + (n_rows % TILE >= 1 ? 1 : 0)) / 2;  // = ntiles / 2
+    const int nfull = phase_full_pairs<BF16>(n_rows);  // = ntiles / 2
 #define PFM_NOPF(q)
 #define PFM_PAIR_AT(P)                                                                                          \
     if ((P) < nfull) {                                                                                          \
@@ -393,11 +408,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
 #undef PFM_MFMAQ
     epilogue(pacc0, pacc1, npairs - 1);
     // the part of the prefetch list a short jet had no pairs for
-    if (nfull <= 0) pf.template issue_pair<0>();
-    if (nfull <= 1) pf.template issue_pair<1>();
-    if (nfull <= 2) pf.template issue_pair<2>();
-    if (nfull <= 3) pf.template issue_pair<3>();
-    if (nfull <= 4) pf.template issue_pair<4>();
+    if (TAIL) pf.issue_tail(nfull);
     if (POOL) {
         pool_finish<SAVE>(psum, j, lds, c.vin, c.misc, oslot, pl, save_pool);
         if (NSEG == 2) pool_finish<false>(psumB, j, lds, s2.vin1, s2.misc1, oslot, pl, nullptr);
