@@ -291,6 +291,7 @@ struct LinArgs {
     int64_t blob_floats, W, b, gamma, beta, jb_stride;
     int lda, lda2, K1, ldr, ldy, ldo, M, K, NO, N, act, row_tiles;  // act: 0 none (+R), 1 lrelu(acc) (+R after), 2 lrelu(acc + R), 3 (acc + R) * lrelu'(Y), 4 acc * lrelu'(Y) + R
     float slope, eps;
+    int cpw = 1;        // panel kernel: column chunks (of BN outputs) per workgroup
     int pre_act = 0;    // 1: the input rows pass through LeakyReLU(slope) on their way into LDS (MDMA: fc0(act(x)), mdma.py:65)
 };
 
@@ -353,7 +354,8 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
     constexpr int RB = 16 * TPW, SI = RB / 16;  // SI: float4 staged per thread and 64-wide step
     float* const tile = lds;             // two RB x 64 slices, 16-byte slots XOR-swizzled with (row & 15)
     float* const stat = lds + (X3 ? RB * X3ROW * 2 : RB * 128);  // RB x (mean, rstd), behind the slices
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pl = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, pl = lane & 15, q = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the weight-block offsets below become SGPR offsets of the buffer loads
     const int row0 = rt * RB;
     const int ob = ch * BN + 16 * NS * w;  // this wave: outputs [ob, ob + 16 NS) as NS 16-row A operands
     const blob_rsrc rs = make_blob_rsrc(a.blob, a.blob_floats);
@@ -401,7 +403,9 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
     const int nst_all = a.K >> 6;
     const int st0 = a.ksplit > 1 ? ks * (nst_all / a.ksplit) : 0;       // K / 64 is a multiple of ksplit (host)
     const int nst = a.ksplit > 1 ? st0 + nst_all / a.ksplit : nst_all;  // one past this workgroup's last step
-    auto request = [&](f32x4 (&af)[NS][4], f32x4 (&st)[SI], int step) {
+    // gb: the LayerNorm gamma / beta columns of the step (requested with its operands, one step ahead like them: read at the head of
+    // the step they exposed an L2 round trip per step)
+    auto request = [&](f32x4 (&af)[NS][4], f32x4 (&st)[SI], f32x4 (&gb)[2], int step) {
         if (active) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -427,13 +431,15 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
             const int row = min(row0 + sr + 16 * i, a.M - 1);
             st[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)row * ld);
         }
+        if (LN) {
+            gb[0] = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + col);
+            gb[1] = *reinterpret_cast<const f32x4*>(a.blob + a.beta + col);
+        }
     };
-    auto step_fn = [&](f32x4 (&af)[NS][4], f32x4 (&st)[SI], f32x4 (&afn)[NS][4], f32x4 (&stn)[SI], int step) {
+    auto step_fn = [&](f32x4 (&af)[NS][4], f32x4 (&st)[SI], f32x4 (&gb)[2], f32x4 (&afn)[NS][4], f32x4 (&stn)[SI], f32x4 (&gbn)[2], int step) {
         float* const buf = tile + (step & 1) * (X3 ? RB * X3ROW : RB * 64);  // X3: hi plane, lo plane RB * X3ROW halfs later
         if (LN) {
-            const int col = 64 * step + 4 * sc4;
-            const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + col);
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + col);
+            const f32x4 g4 = gb[0], b4 = gb[1];
 #pragma unroll
             for (int i = 0; i < SI; ++i) {
                 const int r = sr + 16 * i;
@@ -463,7 +469,7 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
             }
         }
         __syncthreads();  // also orders this write after every wave's reads of the same slice two steps ago
-        if (step + 1 < nst) request(afn, stn, step + 1);
+        if (step + 1 < nst) request(afn, stn, gbn, step + 1);
         if (!active) return;
         if (X3) {
             const _Float16* hb = reinterpret_cast<const _Float16*>(buf);
@@ -489,15 +495,21 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
             }
             return;
         }
+        // B fragments (two 16-row tiles x 16 k per ds_read_b128 pair) are read one item ahead of the 16 MFMAs that use them
+        constexpr int NIT = (TPW / 2) * 4;
+        auto bfrag = [&](f32x4 (&B)[2], int it) {
+            const int tp = it >> 2, kt = it & 3;
+            const float* b0p = buf + (32 * tp + pl) * 64 + (((4 * kt + q) ^ pl) << 2);
+            B[0] = *reinterpret_cast<const f32x4*>(b0p);
+            B[1] = *reinterpret_cast<const f32x4*>(b0p + 16 * 64);
+        };
+        f32x4 Bq[2][2];
+        bfrag(Bq[0], 0);
 #pragma unroll
-        for (int tp = 0; tp < TPW / 2; ++tp) {
-            const float* b0p = buf + (32 * tp + pl) * 64;
-            const float* b1p = b0p + 16 * 64;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const int so = ((4 * kt + q) ^ pl) << 2;
-                const f32x4 B0 = *reinterpret_cast<const f32x4*>(b0p + so);
-                const f32x4 B1 = *reinterpret_cast<const f32x4*>(b1p + so);
+        for (int it = 0; it < NIT; ++it) {
+            if (it + 1 < NIT) bfrag(Bq[(it + 1) & 1], it + 1);
+            const int tp = it >> 2, kt = it & 3;
+            const f32x4 B0 = Bq[it & 1][0], B1 = Bq[it & 1][1];
 #define PFM_TF_STEP(c)                                                                                                    \
     acc[0][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B0.c, acc[0][2 * tp], 0, 0, 0);                    \
     if constexpr (NS == 2)                                                                                                \
@@ -505,21 +517,20 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
     acc[0][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B1.c, acc[0][2 * tp + 1], 0, 0, 0);            \
     if constexpr (NS == 2)                                                                                                \
         acc[NS - 1][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[NS - 1][kt].c, B1.c, acc[NS - 1][2 * tp + 1], 0, 0, 0);
-                PFM_TF_STEP(x) PFM_TF_STEP(y) PFM_TF_STEP(z) PFM_TF_STEP(w)
+            PFM_TF_STEP(x) PFM_TF_STEP(y) PFM_TF_STEP(z) PFM_TF_STEP(w)
 #undef PFM_TF_STEP
-            }
         }
     };
     {
-        f32x4 afA[NS][4], afB[NS][4], stA[SI], stB[SI];
-        request(afA, stA, st0);
+        f32x4 afA[NS][4], afB[NS][4], stA[SI], stB[SI], gbA[2], gbB[2];
+        request(afA, stA, gbA, st0);
         int step = st0;
 #pragma unroll 1
         for (; step + 1 < nst; step += 2) {
-            step_fn(afA, stA, afB, stB, step);
-            step_fn(afB, stB, afA, stA, step + 1);
+            step_fn(afA, stA, gbA, afB, stB, gbB, step);
+            step_fn(afB, stB, gbB, afA, stA, gbA, step + 1);
         }
-        if (step < nst) step_fn(afA, stA, afB, stB, step);  // odd number of 64-wide steps
+        if (step < nst) step_fn(afA, stA, gbA, afB, stB, gbB, step);  // odd number of 64-wide steps
     }
 
     // epilogue: lane (particle pl of tile t, q) holds 4 consecutive outputs
@@ -566,6 +577,173 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     else tf_linear_body<NI, TPW, X3, 2>(a, lds, rt, ch, ks);
 }
 
+// ------------------------------------------------------------------------------------------------
+// tf_linear_panel_kernel: the LayerNorm-Linear of launches with many rows (no split-K, no second input segment, NO a multiple of 128).
+// The fp32 MFMA shares its issue port with the VALU (tests/diag/mfma_coissue.hip: the two add up, they do not overlap), so what the
+// kernel above spends per column chunk on row statistics, the LayerNorm transform of every 64-wide step, staging addresses and barriers
+// is matrix-pipe time.  Here a workgroup owns RB rows for ALL outputs: the rows are read once, normalised once (statistics from the
+// registers that hold the row) and kept in LDS as the B operand of every step -- K / 64 slices of RB x 64, the swizzle of the kernel
+// above -- and the loop over (chunk, step) is weight requests (buffer loads at scalar offsets, one step ahead), ds_read_b128 and MFMAs:
+// no barrier after the staging one.  Same products in the same order as tf_linear_kernel: the results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <int NI, int TPW>
+__global__ __launch_bounds__(LT, TPW == 2 && NI <= 4 ? 3 : 2) void tf_linear_panel_kernel(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int RB = 16 * TPW, K = 64 * NI, NS = 2;
+    const int tid = threadIdx.x, lane = tid & 63, pl = lane & 15, q = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.m_dev) a.M = *a.m_dev;
+    // a.cpw chunks per workgroup: blockIdx -> (row tile, chunk group), the groups of a row tile on consecutive ids
+    const int nchunk_all = a.NO / BN, ngrp = (nchunk_all + a.cpw - 1) / a.cpw;
+    const int row0 = (blockIdx.x / ngrp) * RB, c0 = (blockIdx.x % ngrp) * a.cpw;
+    if (row0 >= a.M) return;
+    const blob_rsrc rs = make_blob_rsrc(a.blob, a.blob_floats);
+
+    // weights of (chunk c, step): this wave's two 16-output operands, four k-tiles of 16 each
+    auto request = [&](f32x4 (&af)[NS][4], int c, int step) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t base = a.W + ((int64_t)(((c * BN + 32 * w) >> 4) + s) * NI + step) * 1024;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) af[s][kt] = bload4(rs, base + kt * 256, lane * 16);
+        }
+    };
+    f32x4 afA[NS][4], afB[NS][4];
+    request(afA, c0, 0);  // in flight during the staging
+
+    // staging: 16 lanes per row (lane pl: columns 4 pl + 64 i), four rows per wave and pass; two-pass statistics as ln_stats_tile
+    constexpr int RPW = RB / (LT / 64);
+#pragma unroll 1
+    for (int pass = 0; pass < RPW / 4; ++pass) {
+        const int r = RPW * w + 4 * pass + q;
+        const int row = min(row0 + r, a.M - 1);
+        const float* ap = a.A + (int64_t)row * a.lda + 4 * pl;
+        f32x4 v[NI];
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            v[i] = *reinterpret_cast<const f32x4*>(ap + 64 * i);
+            sm += hsum4(v[i]);
+        }
+        const float mean = row_sum16(sm) / (float)K;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const f32x4 dl = v[i] - mean;
+            ss += hsum4(dl * dl);
+        }
+        const float rstd = 1.0f / sqrtf(row_sum16(ss) / (float)K + a.eps);
+        float* const dst = lds + r * 64 + ((pl ^ (r & 15)) << 2);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + 64 * i + 4 * pl);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 64 * i + 4 * pl);
+            f32x4 x = (v[i] - mean) * rstd * g4 + b4;
+            if (a.pre_act) x = lrelu4(x, a.slope);
+            *reinterpret_cast<f32x4*>(dst + i * (RB * 64)) = x;
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[NS][TPW];
+    auto mma = [&](f32x4 (&af)[NS][4], int step) {
+        const float* const buf = lds + step * (RB * 64);
+        constexpr int NIT = (TPW / 2) * 4;
+        auto bfrag = [&](f32x4 (&B)[2], int it) {
+            const int tp = it >> 2, kt = it & 3;
+            const float* b0p = buf + (32 * tp + pl) * 64 + (((4 * kt + q) ^ pl) << 2);
+            B[0] = *reinterpret_cast<const f32x4*>(b0p);
+            B[1] = *reinterpret_cast<const f32x4*>(b0p + 16 * 64);
+        };
+        f32x4 Bq[2][2];
+        bfrag(Bq[0], 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (it + 1 < NIT) bfrag(Bq[(it + 1) & 1], it + 1);
+            const int tp = it >> 2, kt = it & 3;
+            const f32x4 B0 = Bq[it & 1][0], B1 = Bq[it & 1][1];
+#define PFM_TF_STEP(c)                                                                                         \
+    acc[0][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B0.c, acc[0][2 * tp], 0, 0, 0);         \
+    acc[1][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][kt].c, B0.c, acc[1][2 * tp], 0, 0, 0);         \
+    acc[0][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B1.c, acc[0][2 * tp + 1], 0, 0, 0); \
+    acc[1][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][kt].c, B1.c, acc[1][2 * tp + 1], 0, 0, 0);
+            PFM_TF_STEP(x) PFM_TF_STEP(y) PFM_TF_STEP(z) PFM_TF_STEP(w)
+#undef PFM_TF_STEP
+        }
+    };
+
+    const int nchunk = min(nchunk_all, c0 + a.cpw);
+    int nsteps = NI;
+    if constexpr (NI == 2) asm volatile("" : "+s"(nsteps));  // opaque: the step loop stays a loop (unrolled into the chunk loop it spilled)
+#pragma unroll 1
+    for (int c = c0; c < nchunk; ++c) {
+        const int ob = c * BN + 32 * w;
+        // accumulators start from the bias (+ the jet-bias row of the particle's jet)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int o = ob + 16 * s + 4 * q;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                if (a.jb) {
+                    const int row = min(row0 + 16 * t + pl, a.M - 1);
+                    const int jet = a.rowjet ? a.rowjet[row] : row / a.N;
+                    acc[s][t] = *reinterpret_cast<const f32x4*>(a.jb + (int64_t)jet * a.jb_stride + o);
+                } else if (a.b >= 0) {
+                    acc[s][t] = *reinterpret_cast<const f32x4*>(a.blob + a.b + o);
+                } else {
+                    acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+#pragma unroll 1
+        for (int step = 0; step < nsteps; step += 2) {
+            request(afB, c, step + 1);
+            mma(afA, step);
+            if (step + 2 < nsteps) request(afA, c, step + 2);
+            else if (c + 1 < nchunk) request(afA, c + 1, 0);
+            mma(afB, step + 1);
+        }
+        // epilogue: lane (particle pl of tile t, q) holds 4 consecutive outputs.  (Requesting the residual rows and the next chunk's start
+        // values under the last steps was measured: no gain, the 32 registers cost the third wave per SIMD.)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int o = ob + 16 * s + 4 * q;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int row = row0 + 16 * t + pl;
+                if (row >= a.M) continue;
+                f32x4 v = acc[s][t];
+                if (a.act >= 3) {
+                    if (a.act == 3 && a.R) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(a.Y + (int64_t)row * a.ldy + o);
+                    v.x *= y.x > 0.f ? 1.f : a.slope; v.y *= y.y > 0.f ? 1.f : a.slope;
+                    v.z *= y.z > 0.f ? 1.f : a.slope; v.w *= y.w > 0.f ? 1.f : a.slope;
+                    if (a.act == 4 && a.R) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+                } else {
+                    if (a.act == 2) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+                    if (a.act) v = lrelu4(v, a.slope);
+                    if (a.R && a.act != 2) v += *reinterpret_cast<const f32x4*>(a.R + (int64_t)row * a.ldr + o);
+                }
+                *reinterpret_cast<f32x4*>(a.out + (int64_t)row * a.ldo + o) = v;
+            }
+        }
+    }
+}
+
+template <int NI, int TPW>
+inline void launch_panel(const LinArgs& a, hipStream_t s) {
+    constexpr int lds = NI * 16 * TPW * 64 * 4;
+    if (lds > 64 * 1024) {
+        static bool big = false;
+        if (!big) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(tf_linear_panel_kernel<NI, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            big = true;
+        }
+    }
+    const int ngrp = (a.NO / BN + a.cpw - 1) / a.cpw;
+    hipLaunchKernelGGL((tf_linear_panel_kernel<NI, TPW>), dim3((a.M + 16 * TPW - 1) / (16 * TPW) * ngrp), dim3(LT), lds, s, a);
+}
+
 // Row tile of a Linear launch: 32, 64 or 128 rows per workgroup, whichever gives the shortest schedule on this GPU's
 // 2 x CU workgroup slots.  Work per round ~ rows x cost-per-row of the tile: a 128-row tile reads every weight block
 // from L2 once per 128 rows instead of once per 64 (the L2 -> register weight stream is what limits the 64-row kernel),
@@ -593,6 +771,31 @@ inline int pick_row_tile(int64_t M, int chunks, int cus, bool allow128) {
 // launches tf_linear_kernel for `a` (everything but row_tiles filled in); ni = K / 64 of the LayerNorm prologue or 0
 inline int launch_linear_kernel(LinArgs& a, int ni, bool x3, int cus, hipStream_t s) {
     const int chunks = (a.NO + BN - 1) / BN;
+    {   // the row-panel kernel where a launch has the rows to fill the GPU with 32-row workgroups
+        static int panel = -1;
+        if (panel < 0) {
+            const char* e = getenv("PFM_TF_PANEL");  // diagnostics only (tests/diag): 0 off, 32 / 64 force the row tile
+            panel = e ? atoi(e) : 1;
+        }
+        if (panel && ni >= 2 && ni <= 6 && (ni & 1) == 0 && !x3 && a.ksplit == 1 && !a.A2 && a.NO % BN == 0 &&
+            (int64_t)(a.M + 31) / 32 >= 2 * (int64_t)cus) {
+            const bool r64 = panel == 64;
+            // chunk groups per row tile: the fewest (dividing the chunk count) that give the launch two rounds of 3 workgroups per CU --
+            // fewer, longer workgroups all stage their rows at once and leave the matrix pipes idle meanwhile
+            const int64_t tiles = (a.M + (r64 ? 63 : 31)) / (r64 ? 64 : 32);
+            int grp = 1;
+            while (grp < chunks && (chunks % grp != 0 || tiles * grp < 6 * (int64_t)cus)) ++grp;
+            static int cpw = -1;
+            if (cpw < 0) { const char* e = getenv("PFM_TF_CPW"); cpw = e ? atoi(e) : 0; }
+            a.cpw = cpw > 0 ? cpw : chunks / grp;
+            switch (ni) {
+                case 2: r64 ? launch_panel<2, 4>(a, s) : launch_panel<2, 2>(a, s); break;
+                case 4: r64 ? launch_panel<4, 4>(a, s) : launch_panel<4, 2>(a, s); break;
+                default: r64 ? launch_panel<6, 4>(a, s) : launch_panel<6, 2>(a, s); break;
+            }
+            return 0;
+        }
+    }
     const int rb = pick_row_tile(a.M, chunks * a.ksplit, cus, !x3);
     a.row_tiles = (a.M + rb - 1) / rb;
     const int grid = ((a.row_tiles + 7) / 8) * 8 * chunks * a.ksplit;
