@@ -327,7 +327,7 @@ def main():
         import ctypes
         from particle_fm_amd import _lib
         lay = model.flows[0].net.layout()
-        sampler_kernel = ("epic_sample_midpoint_fast_kernel<0, false>" if _lib.load().pfm_epic_sample_is_fast(ctypes.byref(lay.desc))
+        sampler_kernel = ("epic_sample_midpoint_fast_kernel<0, false, false>" if _lib.load().pfm_epic_sample_is_fast(ctypes.byref(lay.desc))
                           else "epic_sample_midpoint_kernel<0, true>")
         for cand in PMC_SUMMARIES:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
             try:

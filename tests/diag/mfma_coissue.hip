@@ -120,7 +120,7 @@ int main() {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned long long h; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
         const double flop = 256.0 * 8 * 8.0 * iters * 2048.0;
-        printf("fp32 MFMA on toggling operands, %d iterations: %.2f ms, %.1f TFLOP/s, %.3f GHz, %.1f clocks per 8 MFMAs\n", iters, ms, flop / ms * 1e-9, h / (ms * 1e6), (double)h / iters);
+        printf("fp32 MFMA on toggling operands, %d iterations: %.2f ms, %.1f TFLOP/s, %.3f GHz, %.1f clocks per 8 MFMAs of each of the two waves of a SIMD\n", iters, ms, flop / ms * 1e-9, h / (ms * 1e6), (double)h / iters);
     }
     return 0;
 }
