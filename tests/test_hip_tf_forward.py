@@ -76,3 +76,45 @@ def test_forward_vs_oracle_ragged_batch(ops):
     v2 = ops.tf_forward(lay, blob, t.cuda(), x2.cuda(), cond.cuda(), mask.cuda()).cpu()
     keep = mask.squeeze(-1) == 1
     torch.testing.assert_close(v2[keep], v[keep], atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("family", ["tf", "ca"])
+def test_row_panel_linear_is_bit_identical_to_the_chunk_kernel(family):
+    """Launches with >= 2 x CUs 32-row tiles run the LayerNorm-Linears on tf_linear_panel_kernel (csrc/tf_fwd.h: rows normalised once into
+    LDS, barrier-free walk over the output chunks), smaller ones on tf_linear_kernel.  Same products in the same order: a jet evaluated
+    inside a 72-jet batch (20 088 rows: panel kernel) must equal, bit for bit, the same jet evaluated in a batch of three (chunk kernel);
+    and the big batch must match the oracle."""
+    if family == "tf":
+        from particle_fm_amd import hip_ops_tf as ops
+        from tests.conftest import load_tf_golden
+        g = load_tf_golden("lhco")
+        lay, blob = _setup(g)
+        fwd = ops.tf_forward
+        vf = TransformerVectorField(g.state, "flows.0.", g.hp, freqs=g.freqs)
+    else:
+        from oracle.ca_ref import CrossAttentionVectorField
+        from particle_fm_amd import hip_ops_ca as ops
+        from particle_fm_amd.layout_ca import CaConfig, CaLayout
+        from tests.conftest import load_ca_golden
+        g = load_ca_golden("lhco")
+        lay = CaLayout(CaConfig.from_hparams(g.hp))
+        blob = lay.pack_blob(g.state, "flows.0.", freqs=g.freqs).cuda()
+        fwd = ops.ca_forward
+        vf = CrossAttentionVectorField(g.state, "flows.0.", g.hp, freqs=g.freqs)
+    gen = torch.Generator().manual_seed(11)
+    B, N, C, F = 72, g.hp["num_particles"], g.hp["global_cond_dim"], g.hp["features"]
+    n = torch.randint(1, N + 1, (B,), generator=gen)
+    n[0], n[1] = N, 1
+    mask = (torch.arange(N)[None] < n[:, None]).float().unsqueeze(-1)
+    x = torch.randn(B, N, F, generator=gen) * mask
+    t = torch.rand(B, generator=gen)
+    cond = torch.randn(B, C, generator=gen) if C else None
+    big = fwd(lay, blob, _dev(t), _dev(x), _dev(cond), _dev(mask)).cpu()
+    for lo in (0, 35, 69):
+        sl = slice(lo, lo + 3)
+        small = fwd(lay, blob, _dev(t[sl]), _dev(x[sl]), _dev(None if cond is None else cond[sl]), _dev(mask[sl])).cpu()
+        assert torch.equal(big[sl], small), f"jets {lo}..{lo + 2} differ between the panel and the chunk kernel"
+    sub = slice(0, 4)  # the oracle on a few jets of the big batch (CPU seconds)
+    with torch.no_grad():
+        ref = vf(t[sub, None].expand(4, N), x[sub], cond=None if cond is None else cond[sub], mask=mask[sub])
+    torch.testing.assert_close(big[sub], ref, atol=ATOL, rtol=RTOL)
