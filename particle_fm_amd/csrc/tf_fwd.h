@@ -922,7 +922,9 @@ __global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict
     for (int qt = w; qt < nqt; qt += 4) {
         const int qrow = min(qt * 16 + pl, N - 1);
         f32x4 Qf = *reinterpret_cast<const f32x4*>(base + (int64_t)qrow * ld + 4 * q);
-        Qf *= 0.25f;  // 1/sqrt(16), exact
+        // 1/sqrt(16) and log2(e) folded into Q: the scores come out of the MFMAs in base-2 units and the softmax is exp2 of differences
+        // (one v_exp_f32 per score, no multiply; the fp32 MFMA shares its issue port with the VALU, so softmax instructions are pipe time)
+        Qf *= 0.25f * 1.44269504088896340736f;
         f32x4 s[MAXKT];
         // S^T tiles kt, kt+1: rows = keys 16kt + 4q + r, column = query pl
 #pragma unroll
@@ -952,8 +954,8 @@ __global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict
             if (kt < nkt) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    s[kt + e].x = __expf(s[kt + e].x - m); s[kt + e].y = __expf(s[kt + e].y - m);
-                    s[kt + e].z = __expf(s[kt + e].z - m); s[kt + e].w = __expf(s[kt + e].w - m);
+                    s[kt + e].x = __builtin_amdgcn_exp2f(s[kt + e].x - m); s[kt + e].y = __builtin_amdgcn_exp2f(s[kt + e].y - m);
+                    s[kt + e].z = __builtin_amdgcn_exp2f(s[kt + e].z - m); s[kt + e].w = __builtin_amdgcn_exp2f(s[kt + e].w - m);
                     l += hsum4(s[kt + e]);
                 }
             }
@@ -967,13 +969,12 @@ __global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict
             if (kt < nkt) {
                 const f32x4 V0 = *reinterpret_cast<const f32x4*>(Vt + pl * npv + 16 * kt + 4 * q);
                 const f32x4 V1 = *reinterpret_cast<const f32x4*>(Vt + pl * npv + 16 * kt + 16 + 4 * q);
-                const f32x4 p0 = s[kt] * inv, p1 = s[kt + 1] * inv;
-                PFM_MFMA4x2(o0, V0, p0, o1, V1, p1)
+                PFM_MFMA4x2(o0, V0, s[kt], o1, V1, s[kt + 1])  // unnormalised weights: 1 / l scales the 4 outputs instead of the 72 weights
             }
         }
         const int orow = qt * 16 + pl;
         if (orow < N)
-            *reinterpret_cast<f32x4*>(out + (row_base + orow) * D + h * HD + 4 * q) = o0 + o1;
+            *reinterpret_cast<f32x4*>(out + (row_base + orow) * D + h * HD + 4 * q) = (o0 + o1) * inv;
     }
 }
 
