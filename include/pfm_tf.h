@@ -111,7 +111,8 @@ typedef struct {
 } pfm_tf_desc;
 
 /* Workspace size in floats for n_jets jets.  `train` != 0: every layer keeps its own activations (what
- * pfm_tf_fm_loss_backward re-reads); 0: layers share one set. */
+ * pfm_tf_fm_loss_backward re-reads); 0: layers share one set (and the size covers the two half-batch workspaces of
+ * pfm_tf_sample_midpoint). */
 int64_t pfm_tf_workspace_floats(const pfm_tf_desc *desc, int32_t n_jets, int32_t train);
 
 /* v[n_jets][N][F] = f(t, x).  t: one time per jet (t_stride 1) or a single time for all jets (t_stride 0, the
@@ -121,7 +122,9 @@ int pfm_tf_forward(const pfm_tf_desc *desc, const float *blob, const float *t, i
                    const float *cond, const float *mask, float *v, int32_t n_jets, float *workspace, void *stream);
 
 /* Fixed-step midpoint over the 2*(ode_steps-1) times t_eval / ode_steps-1 steps dt (see pfm_epic_sample_midpoint).
- * x_out may alias z.  premask != 0 multiplies z by the mask first.  state: 2 * n_jets*N*F floats of scratch. */
+ * x_out may alias z.  premask != 0 multiplies z by the mask first.  state: 2 * n_jets*N*F floats of scratch.
+ * Calls on >= 64 jets run as two half-batches on two internal streams that fork from and join `stream` (same bits:
+ * every kernel is row- or jet-local). */
 int pfm_tf_sample_midpoint(const pfm_tf_desc *desc, const float *blob, const float *t_eval, const float *dt,
                            int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
                            int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);

@@ -391,7 +391,11 @@ extern "C" {
 
 int64_t pfm_tf_workspace_floats(const pfm_tf_desc* d, int32_t n_jets, int32_t train) {
     if (validate(d)) return -1;
-    return make_ws(*d, n_jets < 1 ? 1 : n_jets, train != 0).total;
+    const int n = n_jets < 1 ? 1 : n_jets;
+    const int64_t whole = make_ws(*d, n, train != 0).total;
+    if (train || n < 2) return whole;
+    const int64_t halves = make_ws(*d, n / 2, false).total + make_ws(*d, n - n / 2, false).total;  // two-stream midpoint sampler
+    return whole > halves ? whole : halves;
 }
 
 int pfm_tf_forward(const pfm_tf_desc* d, const float* blob, const float* t, int32_t t_stride, const float* x,
@@ -411,31 +415,61 @@ int pfm_tf_forward(const pfm_tf_desc* d, const float* blob, const float* t, int3
 int pfm_tf_sample_midpoint(const pfm_tf_desc* d, const float* blob, const float* t_eval, const float* dt,
                            int32_t n_steps, const float* z, const float* cond, const float* mask, float* x_out,
                            int32_t n_jets, int32_t premask, float* state, float* workspace, void* stream) {
-    Plan p;
-    int rc = make_plan(p, d, blob, workspace, n_jets, false, stream);
+    int rc = validate(d);
     if (rc) return rc;
     if (n_jets <= 0) return 0;
     if (!blob || !t_eval || !dt || !z || !x_out || !state || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (n_steps < 0) return set_err(PFM_E_BADARG, "n_steps < 0");
     if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
-    const int64_t n = (int64_t)p.M * d->features;
-    float* xs = state;
-    float* xm = state + n;
-    hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, xs, n,
-                       d->features);
-    if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
-    if ((rc = setup_valid_rows(p, mask))) return rc;
-    if (p.rowsrc)  // x_mid's padded rows are never read; give them defined values once
-        if ((rc = check_hip(hipMemcpyAsync(xm, xs, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_mid"))) return rc;
-    for (int k = 0; k < n_steps; ++k) {
-        // k1 = f(t_k, x); x_mid = x + 0.5 dt k1; x <- x + dt f(t_k + dt/2, x_mid)
-        HeadArgs h{};
-        h.base = xs; h.dt = dt + k; h.coef = 0.5f; h.dst = xm;
-        if ((rc = run_nfe(p, t_eval + 2 * k, 0, xs, cond, mask, h))) return rc;
-        h.coef = 1.0f; h.dst = xs;
-        if ((rc = run_nfe(p, t_eval + 2 * k + 1, 0, xm, cond, mask, h))) return rc;
-    }
-    return check_hip(hipMemcpyAsync(x_out, xs, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_out");
+    // Two half-batches on two streams, their launches interleaved evaluation by evaluation (tf_common.h: side_stream): every kernel of an
+    // evaluation is row- or jet-local, so the halves never meet, and one half's Linear workgroups stage their rows while the other half's
+    // multiply (the workgroups of ONE launch start, stage and multiply together: DESIGN 4b)
+    const int n_a = split_point(n_jets, 32);
+    SideStream* ss = n_a ? side_stream((hipStream_t)stream) : nullptr;
+    const int parts = ss ? 2 : 1;
+    Plan p[2];
+    float *xs[2], *xm[2];
+    const float *cnd[2], *msk[2];
+    int64_t n[2], r0[2];
+    if (ss && (hipEventRecord(ss->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess ||
+               hipStreamWaitEvent(ss->s2, ss->fork, 0) != hipSuccess))
+        return set_err(PFM_E_BADARG, "side stream fork failed");
+    // everything between fork and join: an error return still joins (the caller stream must not overtake the side streams' work)
+    rc = [&]() -> int {
+        int rc = 0;
+        for (int i = 0; i < parts; ++i) {
+            const int j0 = i ? n_a : 0, nj = parts == 1 ? n_jets : (i ? n_jets - n_a : n_a);
+            float* ws = workspace + (i ? make_ws(*d, n_a, false).total : 0);
+            if ((rc = make_plan(p[i], d, blob, ws, nj, false, ss ? (void*)(i ? ss->s2 : ss->s) : stream))) return rc;
+            r0[i] = (int64_t)j0 * d->n_points;
+            n[i] = (int64_t)p[i].M * d->features;
+            xs[i] = state + 2 * r0[i] * d->features;
+            xm[i] = xs[i] + n[i];
+            cnd[i] = cond ? cond + (int64_t)j0 * d->cond_dim : nullptr;
+            msk[i] = mask ? mask + r0[i] : nullptr;
+            hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n[i] + 255) / 256)), dim3(256), 0, p[i].s, z + r0[i] * d->features,
+                               premask ? msk[i] : nullptr, xs[i], n[i], d->features);
+            if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+            if ((rc = setup_valid_rows(p[i], msk[i]))) return rc;
+            if (p[i].rowsrc)  // x_mid's padded rows are never read; give them defined values once
+                if ((rc = check_hip(hipMemcpyAsync(xm[i], xs[i], n[i] * sizeof(float), hipMemcpyDeviceToDevice, p[i].s), "copy x_mid"))) return rc;
+        }
+        for (int k = 0; k < n_steps; ++k)
+            for (int stage = 0; stage < 2; ++stage)
+                for (int i = 0; i < parts; ++i) {
+                    // k1 = f(t_k, x); x_mid = x + 0.5 dt k1; x <- x + dt f(t_k + dt/2, x_mid)
+                    HeadArgs h{};
+                    h.base = xs[i]; h.dt = dt + k; h.coef = stage ? 1.0f : 0.5f; h.dst = stage ? xs[i] : xm[i];
+                    if ((rc = run_nfe(p[i], t_eval + 2 * k + stage, 0, stage ? xm[i] : xs[i], cnd[i], msk[i], h))) return rc;
+                }
+        for (int i = 0; i < parts; ++i)
+            if ((rc = check_hip(hipMemcpyAsync(x_out + r0[i] * d->features, xs[i], n[i] * sizeof(float), hipMemcpyDeviceToDevice, p[i].s),
+                                "copy x_out")))
+                return rc;
+        return 0;
+    }();
+    side_join(ss, (hipStream_t)stream);
+    return rc;
 }
 
 int pfm_tf_sample_rk(const pfm_tf_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,

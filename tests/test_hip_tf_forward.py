@@ -118,3 +118,31 @@ def test_row_panel_linear_is_bit_identical_to_the_chunk_kernel(family):
     with torch.no_grad():
         ref = vf(t[sub, None].expand(4, N), x[sub], cond=None if cond is None else cond[sub], mask=mask[sub])
     torch.testing.assert_close(big[sub], ref, atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("valid_rows", [False, True])
+def test_two_stream_halves_of_the_midpoint_sampler_change_nothing(ops, valid_rows):
+    """A midpoint call on >= 64 jets runs as two half-batches on two side streams (pfm_tf_sample_midpoint; every kernel is row- or
+    jet-local): the result must be, bit for bit, what each half gives when sampled on its own (31 / 33 jets: below the split size)."""
+    from particle_fm_amd.layout_tf import TfConfig, TfLayout
+    from tests.conftest import load_tf_golden
+    g = load_tf_golden("small")
+    lay = TfLayout(TfConfig.from_hparams(g.hp), flags=4 if valid_rows else 0)  # PFM_TF_F_VALID_ROWS
+    blob = lay.pack_blob(g.state, "flows.0.", freqs=g.freqs).cuda()
+    gen = torch.Generator().manual_seed(23)
+    B, N, C, F = 65, g.hp["num_particles"], g.hp["global_cond_dim"], g.hp["features"]
+    n = torch.randint(1, N + 1, (B,), generator=gen)
+    mask = (torch.arange(N)[None] < n[:, None]).float().unsqueeze(-1)
+    z = torch.randn(B, N, F, generator=gen)
+    cond = torch.randn(B, C, generator=gen) if C else None
+    sub = lambda a, sl: None if a is None else a[sl].cuda()
+    whole = ops.tf_sample_midpoint(lay, blob, z.cuda(), _dev(cond), mask.cuda(), ode_steps=4).cpu()
+    h = B // 2  # the split point of the C entry
+    for sl in (slice(0, h), slice(h, B)):
+        part = ops.tf_sample_midpoint(lay, blob, sub(z, sl), sub(cond, sl), sub(mask, sl), ode_steps=4).cpu()
+        assert torch.equal(whole[sl], part)
+    vf = TransformerVectorField(g.state, "flows.0.", g.hp, freqs=g.freqs)
+    from oracle.fm_ref import sample_midpoint
+    ref = sample_midpoint(vf, z[:3], None if cond is None else cond[:3], mask[:3], ode_steps=4)
+    keep = mask[:3].squeeze(-1) == 1  # padded rows: the valid-rows path never computes them
+    torch.testing.assert_close(whole[:3][keep], ref[keep], atol=2e-4, rtol=1e-3)
