@@ -147,6 +147,8 @@ def run(name, args):
     graph = overlap > 1 and getattr(net, "_GRAPH_FLAG", 0) != 0 and not args.no_graph
     if graph:
         net.set_graph_replay(True)
+    if overlap > 1 and getattr(net, "_ONE_STREAM_FLAG", 0):
+        net.set_stream_split(False)  # whole calls overlap here; a call that splits itself over two more streams only adds launches
     trainer = FusedFMTrainer(model, lr=1e-3, weight_decay=5e-5, max_grad_norm=0.5, ema_decay=0.999)
     N, F = hp["num_particles"], hp["features"]
     x, mask, cond = (a.to(dev) for a in make_batch(B, N, F, C, n_min, 12345))

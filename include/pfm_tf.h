@@ -53,6 +53,8 @@ extern "C" {
                                  field are 0.  Valid rows see the same arithmetic as without the flag (padded keys never
                                  contribute); the reference's (unmasked, meaningless) values at padded rows are not produced.
                                  The loss entry points ignore the flag: the reference's loss includes the padded rows. */
+#define PFM_TF_F_ONE_STREAM 16 /* pfm_tf_sample_midpoint stays on the caller's stream (no half-batch split): for callers that keep several
+                                * sampler calls in flight themselves (generate_data's batch pipeline, bench_secondary --overlap) */
 #define PFM_TF_F_TEMB_SINCOS 2 /* t_emb="sincos": temb = [cos(f t) ; sin(f t)], freqs table = [f ; f] (flow_matching_module.py:208-211) */
 #define PFM_TF_F_F16X3 1 /* desc.flags: every Linear (forward and dX) as three fp16 MFMAs on (hi, lo) splits of both operands,
                             fp32 accumulate: fp32-grade products (see PFM_F_F16X3_MFMA in pfm_hip.h); needs |x| < 65504 */
@@ -124,7 +126,7 @@ int pfm_tf_forward(const pfm_tf_desc *desc, const float *blob, const float *t, i
 /* Fixed-step midpoint over the 2*(ode_steps-1) times t_eval / ode_steps-1 steps dt (see pfm_epic_sample_midpoint).
  * x_out may alias z.  premask != 0 multiplies z by the mask first.  state: 2 * n_jets*N*F floats of scratch.
  * Calls on >= 64 jets run as two half-batches on two internal streams that fork from and join `stream` (same bits:
- * every kernel is row- or jet-local). */
+ * every kernel is row- or jet-local) unless desc.flags has PFM_TF_F_ONE_STREAM. */
 int pfm_tf_sample_midpoint(const pfm_tf_desc *desc, const float *blob, const float *t_eval, const float *dt,
                            int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
                            int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);

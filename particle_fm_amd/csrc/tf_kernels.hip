@@ -424,7 +424,7 @@ int pfm_tf_sample_midpoint(const pfm_tf_desc* d, const float* blob, const float*
     // Two half-batches on two streams, their launches interleaved evaluation by evaluation (tf_common.h: side_stream): every kernel of an
     // evaluation is row- or jet-local, so the halves never meet, and one half's Linear workgroups stage their rows while the other half's
     // multiply (the workgroups of ONE launch start, stage and multiply together: DESIGN 4b)
-    const int n_a = split_point(n_jets, 32);
+    const int n_a = (d->flags & PFM_TF_F_ONE_STREAM) ? 0 : split_point(n_jets, 32);
     SideStream* ss = n_a ? side_stream((hipStream_t)stream) : nullptr;
     const int parts = ss ? 2 : 1;
     Plan p[2];

@@ -23,6 +23,7 @@ HEAD_DIM = 16
 PFM_TF_F_F16X3 = 1
 PFM_TF_F_TEMB_SINCOS = 2
 PFM_TF_F_VALID_ROWS = 4
+PFM_TF_F_ONE_STREAM = 16  # the midpoint sampler stays on the caller's stream (callers with several calls in flight)
 
 
 class TfNorm(ctypes.Structure):

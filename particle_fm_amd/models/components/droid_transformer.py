@@ -183,6 +183,7 @@ class _FusedEncoder(FreqTableMixin, nn.Module):
     _LAYOUT = None
     _forward_op = None
     _GRAPH_FLAG = 0  # descriptor flag of the hipGraph replay of the sampler's step body (0: the path has none)
+    _ONE_STREAM_FLAG = 0  # descriptor flag that keeps the midpoint sampler on the caller's stream (0: the path never splits a call)
 
     def _init_fused(self, num_points, frequencies, add_time_to_input, t_emb):
         # what the kernels need to know beyond the reference's own arguments
@@ -195,12 +196,15 @@ class _FusedEncoder(FreqTableMixin, nn.Module):
         # the midpoint sampler replays its step body as a hipGraph (PFM_CA_F_GRAPH_STEPS): for callers that keep several sampler
         # calls in flight from one thread and are bound by the host's launch rate; same kernels, same results
         self.graph_replay = False
+        # a midpoint call on >= 64 jets runs as two half-batches on two internal streams (Full-Transformer: PFM_TF_F_ONE_STREAM switches
+        # it off); callers that keep several calls in flight themselves (generate_data's pipeline) turn it off: same results either way
+        self.stream_split = True
         self.cfg = self.config(num_points or 1)
         self._LAYOUT(self.cfg)  # rejects unsupported sizes at construction
 
     def layout(self, num_points: Optional[int] = None):
         n = num_points or self.num_points
-        flags = (1 if self.mfma_dtype == "f16x3" else 0) | (4 if self.valid_rows_only else 0) | (self._GRAPH_FLAG if self.graph_replay else 0)
+        flags = (1 if self.mfma_dtype == "f16x3" else 0) | (4 if self.valid_rows_only else 0) | (self._GRAPH_FLAG if self.graph_replay else 0) | (0 if self.stream_split else self._ONE_STREAM_FLAG)
         lay = self._layouts.get((n, flags))
         if lay is None:
             lay = self._layouts[(n, flags)] = self._LAYOUT(self.config(n), flags=flags)
@@ -209,6 +213,10 @@ class _FusedEncoder(FreqTableMixin, nn.Module):
     def set_valid_rows_only(self, on: bool = True) -> None:
         """Sampling / forward skip padded particles (training is unaffected: the reference's loss includes padded rows)."""
         self.valid_rows_only = bool(on)
+
+    def set_stream_split(self, on: bool = True) -> None:
+        """A single midpoint call may fan out over two internal streams (paths that have it: Full-Transformer)."""
+        self.stream_split = bool(on)
 
     def set_graph_replay(self, on: bool = True) -> None:
         """The midpoint sampler captures its step body once per call and replays it (paths that have it: cross-attention)."""
@@ -254,6 +262,8 @@ class FullTransformerEncoder(_FusedEncoder):
     """droid_transformer.py:440-548.  ``forward(t, x, ctxt, mask)`` keeps the reference's call (t = the (B,N,T)
     time embedding, x already time-concatenated); ``vector_field(t, x, cond, mask)`` takes the time itself (B,)
     and the bare particle features and lets the kernels embed (what CNF.forward uses)."""
+
+    _ONE_STREAM_FLAG = 16  # PFM_TF_F_ONE_STREAM
 
     def __init__(self, inpt_dim: int, outp_dim: int, edge_dim: int = 0, ctxt_dim: int = 0,
                  te_config: Mapping | None = None, node_embd_config: Mapping | None = None,

@@ -77,12 +77,15 @@ def generate_data(model, num_jet_samples: int, batch_size: int = 256, cond: torc
                 switched.append(net)
     # Two batches in flight from this one thread: the cross-attention sampler (~200 launches per step) is then bound by the host's
     # launch rate unless it replays its captured step body (PFM_CA_F_GRAPH_STEPS); same kernels, same results.
-    replay = []
+    replay, unsplit = [], []
     if pipeline and dev.type == "cuda" and _pipelined(model) and ode_solver == "midpoint":
         net = model.flows[0].net
         if getattr(net, "_GRAPH_FLAG", 0) and hasattr(net, "set_graph_replay") and not net.graph_replay:
             net.set_graph_replay(True)
             replay.append(net)
+        if getattr(net, "_ONE_STREAM_FLAG", 0) and getattr(net, "stream_split", False):
+            net.set_stream_split(False)  # the pipeline overlaps whole calls; a call splitting itself as well only adds launches
+            unsplit.append(net)
     try:
         return _generate(model, num_jet_samples, cond, batch_size, dev, variable_set_sizes, mask, normalized_data, normalize_sigma,
                          means, stds, log_pt, pt_standardization, shuffle_mask, ode_solver, ode_steps, pipeline, _shard)
@@ -91,6 +94,8 @@ def generate_data(model, num_jet_samples: int, batch_size: int = 256, cond: torc
             net.set_valid_rows_only(False)
         for net in replay:
             net.set_graph_replay(False)
+        for net in unsplit:
+            net.set_stream_split(True)
 
 
 _PIPE_STREAMS = {}

@@ -141,6 +141,10 @@ def test_two_stream_halves_of_the_midpoint_sampler_change_nothing(ops, valid_row
     for sl in (slice(0, h), slice(h, B)):
         part = ops.tf_sample_midpoint(lay, blob, sub(z, sl), sub(cond, sl), sub(mask, sl), ode_steps=4).cpu()
         assert torch.equal(whole[sl], part)
+    # PFM_TF_F_ONE_STREAM (callers with several calls in flight): the same call on the caller's stream alone
+    lay1 = TfLayout(TfConfig.from_hparams(g.hp), flags=(4 if valid_rows else 0) | 16)
+    blob1 = lay1.pack_blob(g.state, "flows.0.", freqs=g.freqs).cuda()
+    assert torch.equal(ops.tf_sample_midpoint(lay1, blob1, z.cuda(), _dev(cond), mask.cuda(), ode_steps=4).cpu(), whole)
     vf = TransformerVectorField(g.state, "flows.0.", g.hp, freqs=g.freqs)
     from oracle.fm_ref import sample_midpoint
     ref = sample_midpoint(vf, z[:3], None if cond is None else cond[:3], mask[:3], ode_steps=4)
