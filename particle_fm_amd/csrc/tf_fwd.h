@@ -292,6 +292,9 @@ struct LinArgs {
     int lda, lda2, K1, ldr, ldy, ldo, M, K, NO, N, act, row_tiles;  // act: 0 none (+R), 1 lrelu(acc) (+R after), 2 lrelu(acc + R), 3 (acc + R) * lrelu'(Y), 4 acc * lrelu'(Y) + R
     float slope, eps;
     int cpw = 1;        // panel kernel: column chunks (of BN outputs) per workgroup
+#ifdef PFM_TF_DIAG
+    int diag = 0;       // tests/diag/tf_panel_stamps.py: this launch records s_memtime stamps of wave 0 of every 8th workgroup
+#endif
     int pre_act = 0;    // 1: the input rows pass through LeakyReLU(slope) on their way into LDS (MDMA: fc0(act(x)), mdma.py:65)
 };
 
@@ -577,6 +580,15 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     else tf_linear_body<NI, TPW, X3, 2>(a, lds, rt, ch, ks);
 }
 
+#ifdef PFM_TF_DIAG
+// diagnostics build only (tests/diag/tf_panel_stamps.py): [workgroup / 8][8] s_memtime stamps of wave 0
+__device__ unsigned long long g_tf_stamps[512 * 8];
+#define PFM_TF_STAMP(k)                                                                              \
+    if (a.diag && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 512 && tid == 0)                      \
+        g_tf_stamps[(blockIdx.x >> 3) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define PFM_TF_STAMP(k)
+#endif
 // ------------------------------------------------------------------------------------------------
 // tf_linear_panel_kernel: the LayerNorm-Linear of launches with many rows (no split-K, no second input segment, NO a multiple of 128).
 // The fp32 MFMA shares its issue port with the VALU (tests/diag/mfma_coissue.hip: the two add up, they do not overlap), so what the
@@ -597,6 +609,7 @@ __global__ __launch_bounds__(LT, TPW == 2 && NI <= 4 ? 3 : 2) void tf_linear_pan
     const int nchunk_all = a.NO / BN, ngrp = (nchunk_all + a.cpw - 1) / a.cpw;
     const int row0 = (blockIdx.x / ngrp) * RB, c0 = (blockIdx.x % ngrp) * a.cpw;
     if (row0 >= a.M) return;
+    PFM_TF_STAMP(0)
     const blob_rsrc rs = make_blob_rsrc(a.blob, a.blob_floats);
 
     // weights of (chunk c, step): this wave's two 16-output operands, four k-tiles of 16 each
@@ -643,7 +656,9 @@ __global__ __launch_bounds__(LT, TPW == 2 && NI <= 4 ? 3 : 2) void tf_linear_pan
             *reinterpret_cast<f32x4*>(dst + i * (RB * 64)) = x;
         }
     }
+    PFM_TF_STAMP(1)
     __syncthreads();
+    PFM_TF_STAMP(2)
 
     f32x4 acc[NS][TPW];
     auto mma = [&](f32x4 (&af)[NS][4], int step) {
@@ -695,6 +710,12 @@ __global__ __launch_bounds__(LT, TPW == 2 && NI <= 4 ? 3 : 2) void tf_linear_pan
                 }
             }
         }
+#ifdef PFM_TF_DIAG
+        if (c == c0) {
+            __builtin_amdgcn_s_waitcnt(0);  // start values and first weights have arrived
+            PFM_TF_STAMP(3)
+        }
+#endif
 #pragma unroll 1
         for (int step = 0; step < nsteps; step += 2) {
             request(afB, c, step + 1);
@@ -703,6 +724,9 @@ __global__ __launch_bounds__(LT, TPW == 2 && NI <= 4 ? 3 : 2) void tf_linear_pan
             else if (c + 1 < nchunk) request(afA, c + 1, 0);
             mma(afB, step + 1);
         }
+#ifdef PFM_TF_DIAG
+        if (c == c0) { PFM_TF_STAMP(4) }
+#endif
         // epilogue: lane (particle pl of tile t, q) holds 4 consecutive outputs.  (Requesting the residual rows and the next chunk's start
         // values under the last steps was measured: no gain, the 32 registers cost the third wave per SIMD.)
 #pragma unroll
@@ -727,7 +751,11 @@ __global__ __launch_bounds__(LT, TPW == 2 && NI <= 4 ? 3 : 2) void tf_linear_pan
                 *reinterpret_cast<f32x4*>(a.out + (int64_t)row * a.ldo + o) = v;
             }
         }
+#ifdef PFM_TF_DIAG
+        if (c == c0) { PFM_TF_STAMP(5) }
+#endif
     }
+    PFM_TF_STAMP(6)
 }
 
 template <int NI, int TPW>
@@ -788,6 +816,9 @@ inline int launch_linear_kernel(LinArgs& a, int ni, bool x3, int cus, hipStream_
             static int cpw = -1;
             if (cpw < 0) { const char* e = getenv("PFM_TF_CPW"); cpw = e ? atoi(e) : 0; }
             a.cpw = cpw > 0 ? cpw : chunks / grp;
+#ifdef PFM_TF_DIAG
+            { const char* e = getenv("PFM_TF_DIAG_NO"); a.diag = e && atoi(e) == a.NO; }
+#endif
             switch (ni) {
                 case 2: r64 ? launch_panel<2, 4>(a, s) : launch_panel<2, 2>(a, s); break;
                 case 4: r64 ? launch_panel<4, 4>(a, s) : launch_panel<4, 2>(a, s); break;

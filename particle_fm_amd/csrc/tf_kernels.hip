@@ -389,6 +389,14 @@ using namespace pfm::tf;
 
 extern "C" {
 
+#ifdef PFM_TF_DIAG
+// diagnostics build only: copies the stamps of the last stamped panel launch to the host (synchronises the device)
+int pfm_tf_diag_stamps(unsigned long long* host, int n) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tf_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int64_t pfm_tf_workspace_floats(const pfm_tf_desc* d, int32_t n_jets, int32_t train) {
     if (validate(d)) return -1;
     const int n = n_jets < 1 ? 1 : n_jets;
