@@ -114,6 +114,13 @@ def test_row_panel_linear_is_bit_identical_to_the_chunk_kernel(family):
         sl = slice(lo, lo + 3)
         small = fwd(lay, blob, _dev(t[sl]), _dev(x[sl]), _dev(None if cond is None else cond[sl]), _dev(mask[sl])).cpu()
         assert torch.equal(big[sl], small), f"jets {lo}..{lo + 2} differ between the panel and the chunk kernel"
+    # valid-rows evaluation of the same large batch (compacted rows, device-side row count, row -> jet map: the panel kernel exits past the
+    # valid rows and looks the jet bias up through the map): the dense numbers at the valid particles
+    lay_v = type(lay)(lay.cfg, flags=4)
+    blob_v = lay_v.pack_blob(g.state, "flows.0.", freqs=g.freqs).cuda()
+    valid = fwd(lay_v, blob_v, _dev(t), _dev(x), _dev(cond), _dev(mask)).cpu()
+    keep = mask.squeeze(-1) == 1
+    torch.testing.assert_close(valid[keep], big[keep], atol=1e-5, rtol=1e-4)
     sub = slice(0, 4)  # the oracle on a few jets of the big batch (CPU seconds)
     with torch.no_grad():
         ref = vf(t[sub, None].expand(4, N), x[sub], cond=None if cond is None else cond[sub], mask=mask[sub])
