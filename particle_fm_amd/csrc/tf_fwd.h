@@ -907,6 +907,12 @@ __host__ __device__ inline int attn_lds_floats(int N) {
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0.w, B0.w, acc0, 0, 0, 0); \
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1.w, B1.w, acc1, 0, 0, 0);
 
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int MAXKT>
 __global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
                                                          float* __restrict__ out, int N, int D, int heads,
@@ -963,19 +969,19 @@ __global__ __launch_bounds__(256, 2) void tf_attn_kernel(const float* __restrict
             if (kt < nkt) {
                 const f32x4 K0 = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + pl) * KROW + 4 * q);
                 const f32x4 K1 = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + 16 + pl) * KROW + 4 * q);
-                f32x4 c0 = *reinterpret_cast<const f32x4*>(mb + 16 * kt + 4 * q);
-                f32x4 c1 = *reinterpret_cast<const f32x4*>(mb + 16 * kt + 16 + 4 * q);
-                PFM_MFMA4x2(c0, K0, Qf, c1, K1, Qf)
-                s[kt] = c0;
-                s[kt + 1] = c1;
+                s[kt] = *reinterpret_cast<const f32x4*>(mb + 16 * kt + 4 * q);  // accumulate in place (no copies out of temporaries)
+                s[kt + 1] = *reinterpret_cast<const f32x4*>(mb + 16 * kt + 16 + 4 * q);
+                PFM_MFMA4x2(s[kt], K0, Qf, s[kt + 1], K1, Qf)
             }
         }
         float m = -__builtin_inff();
 #pragma unroll
         for (int kt = 0; kt < MAXKT; kt += 2)
-            if (kt < nkt) {
-                m = fmaxf(fmaxf(fmaxf(s[kt].x, s[kt].y), fmaxf(s[kt].z, s[kt].w)), m);
-                m = fmaxf(fmaxf(fmaxf(s[kt + 1].x, s[kt + 1].y), fmaxf(s[kt + 1].z, s[kt + 1].w)), m);
+            if (kt < nkt) {  // v_max3_f32 written out: fmaxf() also emits a canonicalising v_max_f32 x, x, x per operand (113 + 18 instructions per query tile, now 36)
+                m = max3f(m, s[kt].x, s[kt].y);
+                m = max3f(m, s[kt].z, s[kt].w);
+                m = max3f(m, s[kt + 1].x, s[kt + 1].y);
+                m = max3f(m, s[kt + 1].z, s[kt + 1].w);
             }
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
