@@ -105,6 +105,29 @@ int linear(const Plan& p, int rows, int per_jet, const float* A, int lda, int K,
     return check_hip(hipGetLastError(), "tf_linear_kernel launch (ca)");
 }
 
+// the dense block of a particle row matrix  out = mid + d2(LN(lrelu(d1(LN(mid)) + jet bias)))  (droid_transformer.py:793-813 / 958-981): one launch
+// (tf_mlp_panel_kernel) where the shapes and the row count allow it, else the two Linears through the hidden buffer `dh`
+int dense_block(const Plan& p, int rows, int per_jet, const float* mid, int D, int Hd, const pfm_tf_lin& d1, const pfm_tf_norm* n1, const float* jb,
+                const pfm_tf_lin& d2, const pfm_tf_norm* n2, float* dh, float* out) {
+    if (!(p.d->flags & PFM_CA_F_F16X3) && n1 && n2 && n1->gamma >= 0 && n2->gamma >= 0) {
+        LinArgs a, b;
+        a.A = mid; a.A2 = nullptr; a.lda2 = 0; a.K1 = D; a.blob = p.blob; a.jb = jb; a.R = nullptr; a.Y = nullptr; a.ldy = 0;
+        const bool prow = p.rowsrc && rows == p.M && per_jet == p.d->n_points;
+        a.rowjet = (prow && jb) ? p.rowjet : nullptr; a.m_dev = prow ? p.m_dev : nullptr; a.part = nullptr; a.ksplit = 1; a.out = nullptr;
+        a.blob_floats = p.d->blob_floats; a.W = d1.W; a.b = d1.b; a.gamma = n1->gamma; a.beta = n1->beta;
+        a.jb_stride = (int64_t)(2 * p.d->layers + 2) * p.d->hidden;
+        a.lda = D; a.ldr = 0; a.ldo = Hd; a.M = rows; a.K = D; a.NO = Hd; a.N = per_jet; a.act = 1;
+        a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
+        b = a;
+        b.A = nullptr; b.jb = nullptr; b.rowjet = nullptr; b.W = d2.W; b.b = d2.b; b.gamma = n2->gamma; b.beta = n2->beta;
+        b.R = mid; b.ldr = D; b.out = out; b.ldo = D; b.K = Hd; b.NO = D; b.act = 0;
+        if (launch_mlp_panel(a, b, num_cus(), p.s)) return check_hip(hipGetLastError(), "tf_mlp_panel_kernel launch (ca)");
+    }
+    int rc = linear(p, rows, per_jet, mid, D, D, d1, n1, Hd, jb, nullptr, 0, dh, Hd, 1);
+    if (rc) return rc;
+    return linear(p, rows, per_jet, dh, Hd, Hd, d2, n2, D, nullptr, mid, D, out, D, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // The token side of a layer pair behind its attention, in ONE launch (inference): one workgroup per jet walks
 //   mid = tok + out(LN_attn(att))                        droid_transformer.py:380-397 (TransformerCrossAttentionLayer)
@@ -353,8 +376,12 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
                  (const float*)(lb + w.t_kv), lb + w.t_att, N, D, heads, Tk, p.off);
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_to_kernel launch"));
         PFM_TRY(linear(p, p.M, N, lb + w.t_att, D, D, Tl.out, &Tl.attn_norm, D, nullptr, seq, D, lb + w.t_mid, D, 0));
-        PFM_TRY(linear(p, p.M, N, lb + w.t_mid, D, D, Tl.d1, &Tl.norm2, Hd, jb + (int64_t)(2 + 2 * l) * Hd, nullptr, 0, lb + w.t_dh, Hd, 1));
-        PFM_TRY(linear(p, p.M, N, lb + w.t_dh, Hd, Hd, Tl.d2, &Tl.d_norm, D, nullptr, lb + w.t_mid, D, lb + w.t_out, D, 0));
+        if (fused_tokens) {  // inference: nothing reads the hidden rows again
+            PFM_TRY(dense_block(p, p.M, N, lb + w.t_mid, D, Hd, Tl.d1, &Tl.norm2, jb + (int64_t)(2 + 2 * l) * Hd, Tl.d2, &Tl.d_norm, lb + w.t_dh, lb + w.t_out));
+        } else {
+            PFM_TRY(linear(p, p.M, N, lb + w.t_mid, D, D, Tl.d1, &Tl.norm2, Hd, jb + (int64_t)(2 + 2 * l) * Hd, nullptr, 0, lb + w.t_dh, Hd, 1));
+            PFM_TRY(linear(p, p.M, N, lb + w.t_dh, Hd, Hd, Tl.d2, &Tl.d_norm, D, nullptr, lb + w.t_mid, D, lb + w.t_out, D, 0));
+        }
         seq = lb + w.t_out;
     }
     // outp_embd: Linear on cat(seq, ctxt) without a LayerNorm in front (FullCrossAttentionEncoder has no final norm)

@@ -21,6 +21,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "tf_common.h"
 
 namespace pfm {
@@ -770,6 +772,204 @@ inline void launch_panel(const LinArgs& a, hipStream_t s) {
     }
     const int ngrp = (a.NO / BN + a.cpw - 1) / a.cpw;
     hipLaunchKernelGGL((tf_linear_panel_kernel<NI, TPW>), dim3((a.M + 16 * TPW - 1) / (16 * TPW) * ngrp), dim3(LT), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tf_mlp_panel_kernel: the dense block  out = R + W2 LN2( lrelu( W1 LN1(A) + jet bias ) )  of a row tile in ONE workgroup (inference; K1 = 128,
+// hidden 256: the cross-attention layers).  The two Linears of the block are row-local, so the hidden rows never leave the CU: stage 1 is the panel
+// kernel above with its epilogue writing the activated hidden values into a second LDS panel (same slice / swizzle layout), the rows are normalised
+// there in place (statistics with the staging's own reduction order, from the same floats the two-launch path reads back from memory), and stage 2
+// multiplies from that panel.  Same products and sums in the same order as two tf_linear(_panel)_kernel launches: bit-identical, minus the hidden
+// tensor's trip through HBM (2 x M x 256 floats per block) and one launch.
+// ------------------------------------------------------------------------------------------------
+struct MlpArgs {
+    LinArgs l1, l2;  // l1: A, lda, M, m_dev, W, gamma, beta, jb / b, rowjet, N, jb_stride, slope, eps, K, NO (= hidden);  l2: W, b, gamma, beta, R, ldr, out, ldo, NO
+};
+
+template <int NI1, int NI2>
+__global__ __launch_bounds__(LT, 3) void tf_mlp_panel_kernel(MlpArgs m) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TPW = 2, RB = 32, NS = 2, RPW = RB / (LT / 64), NP = RPW / 4;
+    LinArgs& a = m.l1;
+    LinArgs& b = m.l2;
+    float* const X = lds;                   // NI1 slices of RB x 64: LN1(A)
+    float* const H = lds + NI1 * RB * 64;   // NI2 slices: the hidden rows
+    const int tid = threadIdx.x, lane = tid & 63, pl = lane & 15, q = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.m_dev) a.M = *a.m_dev;
+    const int row0 = blockIdx.x * RB;
+    if (row0 >= a.M) return;
+    const blob_rsrc rs = make_blob_rsrc(a.blob, a.blob_floats);
+    auto request = [&](f32x4 (&af)[NS][4], int64_t W, int nst, int c, int step) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t base = W + ((int64_t)(((c * BN + 32 * w) >> 4) + s) * nst + step) * 1024;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) af[s][kt] = bload4(rs, base + kt * 256, lane * 16);
+        }
+    };
+    f32x4 afA[NS][4], afB[NS][4];
+    request(afA, a.W, NI1, 0, 0);
+
+    // rows -> LN -> panel (global rows into X; later the hidden rows in place in H): 16 lanes per row, two-pass statistics as ln_stats_tile
+    auto normalise = [&](auto load, float* dstp, auto NIc, int64_t gamma, int64_t beta, float eps) {
+        constexpr int NI = decltype(NIc)::value;
+#pragma unroll 1
+        for (int pass = 0; pass < NP; ++pass) {
+            const int r = RPW * w + 4 * pass + q;
+            f32x4 v[NI];
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                v[i] = load(r, i);
+                sm += hsum4(v[i]);
+            }
+            const float mean = row_sum16(sm) / (float)(64 * NI);
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const f32x4 dl = v[i] - mean;
+                ss += hsum4(dl * dl);
+            }
+            const float rstd = 1.0f / sqrtf(row_sum16(ss) / (float)(64 * NI) + eps);
+            float* const dst = dstp + r * 64 + ((pl ^ (r & 15)) << 2);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.blob + gamma + 64 * i + 4 * pl);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.blob + beta + 64 * i + 4 * pl);
+                *reinterpret_cast<f32x4*>(dst + i * (RB * 64)) = (v[i] - mean) * rstd * g4 + b4;
+            }
+        }
+    };
+    normalise([&](int r, int i) { return *reinterpret_cast<const f32x4*>(a.A + (int64_t)min(row0 + r, a.M - 1) * a.lda + 4 * pl + 64 * i); }, X,
+              std::integral_constant<int, NI1>{}, a.gamma, a.beta, a.eps);
+    __syncthreads();
+
+    f32x4 acc[NS][TPW];
+    auto mma = [&](f32x4 (&af)[NS][4], const float* buf) {
+        constexpr int NIT = (TPW / 2) * 4;
+        auto bfrag = [&](f32x4 (&B)[2], int it) {
+            const int tp = it >> 2, kt = it & 3;
+            const float* b0p = buf + (32 * tp + pl) * 64 + (((4 * kt + q) ^ pl) << 2);
+            B[0] = *reinterpret_cast<const f32x4*>(b0p);
+            B[1] = *reinterpret_cast<const f32x4*>(b0p + 16 * 64);
+        };
+        f32x4 Bq[2][2];
+        bfrag(Bq[0], 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (it + 1 < NIT) bfrag(Bq[(it + 1) & 1], it + 1);
+            const int tp = it >> 2, kt = it & 3;
+            const f32x4 B0 = Bq[it & 1][0], B1 = Bq[it & 1][1];
+#define PFM_TF_STEP(c)                                                                                         \
+    acc[0][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B0.c, acc[0][2 * tp], 0, 0, 0);         \
+    acc[1][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][kt].c, B0.c, acc[1][2 * tp], 0, 0, 0);         \
+    acc[0][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B1.c, acc[0][2 * tp + 1], 0, 0, 0); \
+    acc[1][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][kt].c, B1.c, acc[1][2 * tp + 1], 0, 0, 0);
+            PFM_TF_STEP(x) PFM_TF_STEP(y) PFM_TF_STEP(z) PFM_TF_STEP(w)
+#undef PFM_TF_STEP
+        }
+    };
+
+    // ---- stage 1: hidden = lrelu(W1 LN1(A) + jet bias), into H --------------------------------------------------------------------------
+    const int nc1 = a.NO / BN;
+    int n1 = NI1, n2 = NI2;
+    asm volatile("" : "+s"(n1), "+s"(n2));  // the step loops stay loops
+#pragma unroll 1
+    for (int c = 0; c < nc1; ++c) {
+        const int ob = c * BN + 32 * w;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int o = ob + 16 * s + 4 * q;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                if (a.jb) {
+                    const int row = min(row0 + 16 * t + pl, a.M - 1);
+                    const int jet = a.rowjet ? a.rowjet[row] : row / a.N;
+                    acc[s][t] = *reinterpret_cast<const f32x4*>(a.jb + (int64_t)jet * a.jb_stride + o);
+                } else if (a.b >= 0) {
+                    acc[s][t] = *reinterpret_cast<const f32x4*>(a.blob + a.b + o);
+                } else {
+                    acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+#pragma unroll 1
+        for (int step = 0; step < n1; step += 2) {
+            request(afB, a.W, NI1, c, step + 1);
+            mma(afA, X + step * (RB * 64));
+            if (step + 2 < n1) request(afA, a.W, NI1, c, step + 2);
+            else if (c + 1 < nc1) request(afA, a.W, NI1, c + 1, 0);
+            else request(afA, b.W, NI2, 0, 0);  // first weights of stage 2
+            mma(afB, X + (step + 1) * (RB * 64));
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int o = ob + 16 * s + 4 * q;  // 4 consecutive hidden columns: slice o / 64, 16-byte slot (o % 64) / 4
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int r = 16 * t + pl;
+                f32x4 v = acc[s][t];
+                if (a.act) v = lrelu4(v, a.slope);
+                *reinterpret_cast<f32x4*>(H + (o >> 6) * (RB * 64) + r * 64 + ((((o & 63) >> 2) ^ (r & 15)) << 2)) = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- LN2 over the hidden rows, in place ---------------------------------------------------------------------------------------------
+    normalise([&](int r, int i) { return *reinterpret_cast<const f32x4*>(H + i * (RB * 64) + r * 64 + ((pl ^ (r & 15)) << 2)); }, H,
+              std::integral_constant<int, NI2>{}, b.gamma, b.beta, a.eps);
+    __syncthreads();
+    // ---- stage 2: out = R + W2 LN2(hidden) + b2 -----------------------------------------------------------------------------------------
+    const int nc2 = b.NO / BN;
+#pragma unroll 1
+    for (int c = 0; c < nc2; ++c) {
+        const int ob = c * BN + 32 * w;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int o = ob + 16 * s + 4 * q;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                acc[s][t] = b.b >= 0 ? *reinterpret_cast<const f32x4*>(a.blob + b.b + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int step = 0; step < n2; step += 2) {
+            request(afB, b.W, NI2, c, step + 1);
+            mma(afA, H + step * (RB * 64));
+            if (step + 2 < n2) request(afA, b.W, NI2, c, step + 2);
+            else if (c + 1 < nc2) request(afA, b.W, NI2, c + 1, 0);
+            mma(afB, H + (step + 1) * (RB * 64));
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int o = ob + 16 * s + 4 * q;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int row = row0 + 16 * t + pl;
+                if (row >= a.M) continue;
+                f32x4 v = acc[s][t];
+                if (b.R) v += *reinterpret_cast<const f32x4*>(b.R + (int64_t)row * b.ldr + o);
+                *reinterpret_cast<f32x4*>(b.out + (int64_t)row * b.ldo + o) = v;
+            }
+        }
+    }
+}
+
+// the dense block in one launch where the panel conditions hold (launch_linear_kernel) and the shapes are the cross-attention ones; false: the caller
+// launches the two Linears
+inline bool launch_mlp_panel(const LinArgs& l1, const LinArgs& l2, int cus, hipStream_t s) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("PFM_TF_MLP");  // diagnostics only (tests/diag): 0 = two launches
+        const char* p = getenv("PFM_TF_PANEL");
+        on = (e ? atoi(e) : 1) && (p ? atoi(p) : 1);
+    }
+    if (!on || l1.K != 128 || l1.NO != 256 || l2.K != 256 || l2.NO % BN != 0 || l1.gamma < 0 || l2.gamma < 0 || l1.A2 || l1.pre_act || l2.pre_act ||
+        l1.act != 1 || l1.R || l2.act != 0 || l2.jb || (int64_t)(l1.M + 31) / 32 < 2 * (int64_t)cus)
+        return false;
+    MlpArgs m{l1, l2};
+    hipLaunchKernelGGL((tf_mlp_panel_kernel<2, 4>), dim3((l1.M + 31) / 32), dim3(LT), (2 + 4) * 32 * 64 * 4, s, m);
+    return true;
 }
 
 // Row tile of a Linear launch: 32, 64 or 128 rows per workgroup, whichever gives the shortest schedule on this GPU's
