@@ -107,8 +107,11 @@ int linear(const Plan& p, int rows, int per_jet, const float* A, int lda, int K,
 
 // the dense block of a particle row matrix  out = mid + d2(LN(lrelu(d1(LN(mid)) + jet bias)))  (droid_transformer.py:793-813 / 958-981): one launch
 // (tf_mlp_panel_kernel) where the shapes and the row count allow it, else the two Linears through the hidden buffer `dh`
-int dense_block(const Plan& p, int rows, int per_jet, const float* mid, int D, int Hd, const pfm_tf_lin& d1, const pfm_tf_norm* n1, const float* jb,
-                const pfm_tf_lin& d2, const pfm_tf_norm* n2, float* dh, float* out) {
+// (att != nullptr: with the Linear in front of it, mid = res + lo(LN(att)), as stage 0 of the same launch)
+int dense_block(const Plan& p, int rows, int per_jet, float* mid, int D, int Hd, const pfm_tf_lin& d1, const pfm_tf_norm* n1, const float* jb,
+                const pfm_tf_lin& d2, const pfm_tf_norm* n2, float* dh, float* out, const float* att = nullptr, const pfm_tf_lin* lo = nullptr,
+                const pfm_tf_norm* no = nullptr, const float* res = nullptr) {
+    bool pre_done = false;
     if (!(p.d->flags & PFM_CA_F_F16X3) && n1 && n2 && n1->gamma >= 0 && n2->gamma >= 0) {
         LinArgs a, b;
         a.A = mid; a.A2 = nullptr; a.lda2 = 0; a.K1 = D; a.blob = p.blob; a.jb = jb; a.R = nullptr; a.Y = nullptr; a.ldy = 0;
@@ -121,7 +124,22 @@ int dense_block(const Plan& p, int rows, int per_jet, const float* mid, int D, i
         b = a;
         b.A = nullptr; b.jb = nullptr; b.rowjet = nullptr; b.W = d2.W; b.b = d2.b; b.gamma = n2->gamma; b.beta = n2->beta;
         b.R = mid; b.ldr = D; b.out = out; b.ldo = D; b.K = Hd; b.NO = D; b.act = 0;
+        if (att && no && no->gamma >= 0) {
+            LinArgs z = a;
+            z.A = att; z.jb = nullptr; z.rowjet = nullptr; z.W = lo->W; z.b = lo->b; z.gamma = no->gamma; z.beta = no->beta;
+            z.R = res; z.ldr = D; z.out = mid; z.ldo = D; z.NO = D; z.act = 0;
+            if (launch_mlp_panel(a, b, num_cus(), p.s, &z)) return check_hip(hipGetLastError(), "tf_mlp_panel_kernel launch (ca)");
+        }
+        if (att) {
+            int rc = linear(p, rows, per_jet, att, D, D, *lo, no, D, nullptr, res, D, mid, D, 0);
+            if (rc) return rc;
+            pre_done = true;
+        }
         if (launch_mlp_panel(a, b, num_cus(), p.s)) return check_hip(hipGetLastError(), "tf_mlp_panel_kernel launch (ca)");
+    }
+    if (att && !pre_done) {
+        int rc = linear(p, rows, per_jet, att, D, D, *lo, no, D, nullptr, res, D, mid, D, 0);
+        if (rc) return rc;
     }
     int rc = linear(p, rows, per_jet, mid, D, D, d1, n1, Hd, jb, nullptr, 0, dh, Hd, 1);
     if (rc) return rc;
@@ -375,10 +393,11 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         PFM_ATTN(ca_attn_to_kernel, dim3(p.n_jets, (N + TO_ROWS - 1) / TO_ROWS), (size_t)Tk * 2 * D * sizeof(float), (const float*)(lb + w.t_q),
                  (const float*)(lb + w.t_kv), lb + w.t_att, N, D, heads, Tk, p.off);
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_to_kernel launch"));
-        PFM_TRY(linear(p, p.M, N, lb + w.t_att, D, D, Tl.out, &Tl.attn_norm, D, nullptr, seq, D, lb + w.t_mid, D, 0));
-        if (fused_tokens) {  // inference: nothing reads the hidden rows again
-            PFM_TRY(dense_block(p, p.M, N, lb + w.t_mid, D, Hd, Tl.d1, &Tl.norm2, jb + (int64_t)(2 + 2 * l) * Hd, Tl.d2, &Tl.d_norm, lb + w.t_dh, lb + w.t_out));
+        if (fused_tokens) {  // inference: nothing reads the hidden rows again; to.out rides in front of the block (stage 0 of the same launch)
+            PFM_TRY(dense_block(p, p.M, N, lb + w.t_mid, D, Hd, Tl.d1, &Tl.norm2, jb + (int64_t)(2 + 2 * l) * Hd, Tl.d2, &Tl.d_norm, lb + w.t_dh, lb + w.t_out,
+                                lb + w.t_att, &Tl.out, &Tl.attn_norm, seq));
         } else {
+            PFM_TRY(linear(p, p.M, N, lb + w.t_att, D, D, Tl.out, &Tl.attn_norm, D, nullptr, seq, D, lb + w.t_mid, D, 0));
             PFM_TRY(linear(p, p.M, N, lb + w.t_mid, D, D, Tl.d1, &Tl.norm2, Hd, jb + (int64_t)(2 + 2 * l) * Hd, nullptr, 0, lb + w.t_dh, Hd, 1));
             PFM_TRY(linear(p, p.M, N, lb + w.t_dh, Hd, Hd, Tl.d2, &Tl.d_norm, D, nullptr, lb + w.t_mid, D, lb + w.t_out, D, 0));
         }

@@ -783,10 +783,13 @@ inline void launch_panel(const LinArgs& a, hipStream_t s) {
 // tensor's trip through HBM (2 x M x 256 floats per block) and one launch.
 // ------------------------------------------------------------------------------------------------
 struct MlpArgs {
+    LinArgs l0;      // PRE: the Linear in front of the block, mid = R0 + W0 LN0(A0) + b0 (one 128-output chunk; also stored to l0.out: stage 2's residual)
     LinArgs l1, l2;  // l1: A, lda, M, m_dev, W, gamma, beta, jb / b, rowjet, N, jb_stride, slope, eps, K, NO (= hidden);  l2: W, b, gamma, beta, R, ldr, out, ldo, NO
 };
 
-template <int NI1, int NI2>
+// PRE (cross-attention: to.out in front of the block): stage 0 multiplies LN0(A0) from the X panel, its epilogue adds the residual, stores the rows
+// (the block's own residual reads them back, same thread) and parks them raw in the H region; they are normalised from there into X for stage 1.
+template <int NI1, int NI2, bool PRE>
 __global__ __launch_bounds__(LT, 3) void tf_mlp_panel_kernel(MlpArgs m) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TPW = 2, RB = 32, NS = 2, RPW = RB / (LT / 64), NP = RPW / 4;
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(LT, 3) void tf_mlp_panel_kernel(MlpArgs m) {
         }
     };
     f32x4 afA[NS][4], afB[NS][4];
-    request(afA, a.W, NI1, 0, 0);
+    request(afA, PRE ? m.l0.W : a.W, NI1, 0, 0);
 
     // rows -> LN -> panel (global rows into X; later the hidden rows in place in H): 16 lanes per row, two-pass statistics as ln_stats_tile
     auto normalise = [&](auto load, float* dstp, auto NIc, int64_t gamma, int64_t beta, float eps) {
@@ -841,8 +844,11 @@ __global__ __launch_bounds__(LT, 3) void tf_mlp_panel_kernel(MlpArgs m) {
             }
         }
     };
-    normalise([&](int r, int i) { return *reinterpret_cast<const f32x4*>(a.A + (int64_t)min(row0 + r, a.M - 1) * a.lda + 4 * pl + 64 * i); }, X,
-              std::integral_constant<int, NI1>{}, a.gamma, a.beta, a.eps);
+    {
+        const LinArgs& f = PRE ? m.l0 : a;  // the Linear that reads the global rows
+        normalise([&](int r, int i) { return *reinterpret_cast<const f32x4*>(f.A + (int64_t)min(row0 + r, a.M - 1) * f.lda + 4 * pl + 64 * i); }, X,
+                  std::integral_constant<int, NI1>{}, f.gamma, f.beta, a.eps);
+    }
     __syncthreads();
 
     f32x4 acc[NS][TPW];
@@ -871,10 +877,44 @@ __global__ __launch_bounds__(LT, 3) void tf_mlp_panel_kernel(MlpArgs m) {
         }
     };
 
-    // ---- stage 1: hidden = lrelu(W1 LN1(A) + jet bias), into H --------------------------------------------------------------------------
-    const int nc1 = a.NO / BN;
     int n1 = NI1, n2 = NI2;
     asm volatile("" : "+s"(n1), "+s"(n2));  // the step loops stay loops
+    if constexpr (PRE) {
+        // ---- stage 0: mid = R0 + W0 LN0(A0) + b0 (NI1 columns = one chunk), to l0.out and, raw, into the H region ----------------------------
+        const LinArgs& z = m.l0;
+        const int ob = 32 * w;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                acc[s][t] = z.b >= 0 ? *reinterpret_cast<const f32x4*>(a.blob + z.b + ob + 16 * s + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int step = 0; step < n1; step += 2) {
+            request(afB, z.W, NI1, 0, step + 1);
+            mma(afA, X + step * (RB * 64));
+            if (step + 2 < n1) request(afA, z.W, NI1, 0, step + 2);
+            else request(afA, a.W, NI1, 0, 0);  // first weights of stage 1
+            mma(afB, X + (step + 1) * (RB * 64));
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int o = ob + 16 * s + 4 * q;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int r = 16 * t + pl, row = min(row0 + r, a.M - 1);
+                f32x4 v = acc[s][t];
+                if (z.R) v += *reinterpret_cast<const f32x4*>(z.R + (int64_t)row * z.ldr + o);
+                if (row0 + r < a.M) *reinterpret_cast<f32x4*>(z.out + (int64_t)row * z.ldo + o) = v;
+                *reinterpret_cast<f32x4*>(H + (o >> 6) * (RB * 64) + r * 64 + ((((o & 63) >> 2) ^ (r & 15)) << 2)) = v;
+            }
+        }
+        __syncthreads();  // every wave is done with LN0(A0) in X and has parked its mid columns
+        normalise([&](int r, int i) { return *reinterpret_cast<const f32x4*>(H + i * (RB * 64) + r * 64 + ((pl ^ (r & 15)) << 2)); }, X,
+                  std::integral_constant<int, NI1>{}, a.gamma, a.beta, a.eps);
+        __syncthreads();
+    }
+    // ---- stage 1: hidden = lrelu(W1 LN1(mid) + jet bias), into H ------------------------------------------------------------------------
+    const int nc1 = a.NO / BN;
 #pragma unroll 1
     for (int c = 0; c < nc1; ++c) {
         const int ob = c * BN + 32 * w;
@@ -957,18 +997,21 @@ __global__ __launch_bounds__(LT, 3) void tf_mlp_panel_kernel(MlpArgs m) {
 
 // the dense block in one launch where the panel conditions hold (launch_linear_kernel) and the shapes are the cross-attention ones; false: the caller
 // launches the two Linears
-inline bool launch_mlp_panel(const LinArgs& l1, const LinArgs& l2, int cus, hipStream_t s) {
+inline bool launch_mlp_panel(const LinArgs& l1, const LinArgs& l2, int cus, hipStream_t s, const LinArgs* l0 = nullptr) {
     static int on = -1;
     if (on < 0) {
-        const char* e = getenv("PFM_TF_MLP");  // diagnostics only (tests/diag): 0 = two launches
+        const char* e = getenv("PFM_TF_MLP");  // diagnostics only (tests/diag): 0 = separate launches, 1 = the block alone, 2 (default) = with the Linear in front
         const char* p = getenv("PFM_TF_PANEL");
-        on = (e ? atoi(e) : 1) && (p ? atoi(p) : 1);
+        on = (p && !atoi(p)) ? 0 : (e ? atoi(e) : 2);
     }
-    if (!on || l1.K != 128 || l1.NO != 256 || l2.K != 256 || l2.NO % BN != 0 || l1.gamma < 0 || l2.gamma < 0 || l1.A2 || l1.pre_act || l2.pre_act ||
-        l1.act != 1 || l1.R || l2.act != 0 || l2.jb || (int64_t)(l1.M + 31) / 32 < 2 * (int64_t)cus)
+    if (!on || (l0 && on < 2) || l1.K != 128 || l1.NO != 256 || l2.K != 256 || l2.NO % BN != 0 || l1.gamma < 0 || l2.gamma < 0 || l1.A2 || l1.pre_act ||
+        l2.pre_act || l1.act != 1 || l1.R || l2.act != 0 || l2.jb || (int64_t)(l1.M + 31) / 32 < 2 * (int64_t)cus)
         return false;
-    MlpArgs m{l1, l2};
-    hipLaunchKernelGGL((tf_mlp_panel_kernel<2, 4>), dim3((l1.M + 31) / 32), dim3(LT), (2 + 4) * 32 * 64 * 4, s, m);
+    if (l0 && (l0->K != 128 || l0->NO != 128 || l0->gamma < 0 || l0->act != 0 || l0->jb || l0->A2 || l0->pre_act || l0->out != l1.A || l0->ldo != l1.lda))
+        return false;
+    MlpArgs m{l0 ? *l0 : l1, l1, l2};
+    if (l0) hipLaunchKernelGGL((tf_mlp_panel_kernel<2, 4, true>), dim3((l1.M + 31) / 32), dim3(LT), (2 + 4) * 32 * 64 * 4, s, m);
+    else hipLaunchKernelGGL((tf_mlp_panel_kernel<2, 4, false>), dim3((l1.M + 31) / 32), dim3(LT), (2 + 4) * 32 * 64 * 4, s, m);
     return true;
 }
 
