@@ -105,6 +105,22 @@ int linear(const Plan& p, int rows, int per_jet, const float* A, int lda, int K,
     return check_hip(hipGetLastError(), "tf_linear_kernel launch (ca)");
 }
 
+// two plain LayerNorm-Linears of the same particle rows (from.kv and to.q of a layer pair) in one launch (tf_linear_panel2_kernel); false: not launched
+bool linear_pair(const Plan& p, int rows, int per_jet, const float* A, int D, const pfm_tf_lin& w1, const pfm_tf_norm* n1, int NO1, float* out1,
+                 const pfm_tf_lin& w2, const pfm_tf_norm* n2, int NO2, float* out2) {
+    if ((p.d->flags & PFM_CA_F_F16X3) || !n1 || !n2 || n1->gamma < 0 || n2->gamma < 0) return false;
+    LinArgs a;
+    a.A = A; a.A2 = nullptr; a.lda2 = 0; a.K1 = D; a.blob = p.blob; a.jb = nullptr; a.R = nullptr; a.Y = nullptr; a.ldy = 0; a.rowjet = nullptr;
+    const bool prow = p.rowsrc && rows == p.M && per_jet == p.d->n_points;
+    a.m_dev = prow ? p.m_dev : nullptr; a.part = nullptr; a.ksplit = 1;
+    a.blob_floats = p.d->blob_floats; a.jb_stride = 0; a.lda = D; a.ldr = 0; a.M = rows; a.K = D; a.N = per_jet; a.act = 0;
+    a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
+    LinArgs b = a;
+    a.W = w1.W; a.b = w1.b; a.gamma = n1->gamma; a.beta = n1->beta; a.NO = NO1; a.out = out1; a.ldo = NO1;
+    b.W = w2.W; b.b = w2.b; b.gamma = n2->gamma; b.beta = n2->beta; b.NO = NO2; b.out = out2; b.ldo = NO2;
+    return launch_panel2(a, b, num_cus(), p.s);
+}
+
 // the dense block of a particle row matrix  out = mid + d2(LN(lrelu(d1(LN(mid)) + jet bias)))  (droid_transformer.py:793-813 / 958-981): one launch
 // (tf_mlp_panel_kernel) where the shapes and the row count allow it, else the two Linears through the hidden buffer `dh`
 // (att != nullptr: with the Linear in front of it, mid = res + lo(LN(att)), as stage 0 of the same launch)
@@ -362,7 +378,10 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         const pfm_ca_layer& Fl = d.from_layer[l];
         const pfm_ca_layer& Tl = d.to_layer[l];
         // tokens <- particles
-        PFM_TRY(linear(p, p.M, N, seq, D, D, Fl.kv, &Fl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.f_kv, 2 * D, 0));
+        // from.kv and to.q both read the particle rows of the pair's input (the tokens <- particles half does not change them): one launch at inference
+        const bool kvq = fused_tokens && linear_pair(p, p.M, N, seq, D, Fl.kv, &Fl.norm0, 2 * D, lb + w.f_kv, Tl.q, &Tl.norm1, D, lb + w.t_q);
+        if (kvq) PFM_TRY(check_hip(hipGetLastError(), "tf_linear_panel2_kernel launch (ca)"));
+        if (!kvq) PFM_TRY(linear(p, p.M, N, seq, D, D, Fl.kv, &Fl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.f_kv, 2 * D, 0));
         if (!fused_tokens || l == 0)  // (fused: the previous pair's token chain already wrote this pair's queries)
             PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Fl.q, &Fl.norm1, D, nullptr, nullptr, 0, lb + w.f_q, D, 0));
         PFM_ATTN(ca_attn_from_kernel, dim3(p.n_jets, (heads + 3) / 4), 0, (const float*)(lb + w.f_q), (const float*)(lb + w.f_kv), mask, lb + w.f_att, N, D,
@@ -388,7 +407,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
             tok = lb + w.f_out;
         }
         // particles <- tokens
-        PFM_TRY(linear(p, p.M, N, seq, D, D, Tl.q, &Tl.norm1, D, nullptr, nullptr, 0, lb + w.t_q, D, 0));
+        if (!kvq) PFM_TRY(linear(p, p.M, N, seq, D, D, Tl.q, &Tl.norm1, D, nullptr, nullptr, 0, lb + w.t_q, D, 0));
         if (!fused_tokens) PFM_TRY(linear(p, p.Mt, Tk, tok, D, D, Tl.kv, &Tl.norm0, 2 * D, nullptr, nullptr, 0, lb + w.t_kv, 2 * D, 0));
         PFM_ATTN(ca_attn_to_kernel, dim3(p.n_jets, (N + TO_ROWS - 1) / TO_ROWS), (size_t)Tk * 2 * D * sizeof(float), (const float*)(lb + w.t_q),
                  (const float*)(lb + w.t_kv), lb + w.t_att, N, D, heads, Tk, p.off);

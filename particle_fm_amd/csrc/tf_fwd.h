@@ -1015,6 +1015,146 @@ inline bool launch_mlp_panel(const LinArgs& l1, const LinArgs& l2, int cus, hipS
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// tf_linear_panel2_kernel: TWO plain LayerNorm-Linears of the same rows (own LayerNorm, weights, bias and output each; no jet bias, residual or
+// activation) in one launch: the rows are read and their statistics taken once, the two affine transforms fill two LDS panels, and the workgroup walks
+// the chunks of the first Linear, then of the second.  Cross-attention: `from.kv` and `to.q` of a layer pair both read the particle rows.  Same
+// arithmetic per output as two tf_linear_panel_kernel launches (bit-identical).
+// ------------------------------------------------------------------------------------------------
+template <int NI>
+__global__ __launch_bounds__(LT, 3) void tf_linear_panel2_kernel(MlpArgs m) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TPW = 2, RB = 32, K = 64 * NI, NS = 2, RPW = RB / (LT / 64), NP = RPW / 4;
+    LinArgs& a = m.l1;
+    LinArgs& b = m.l2;
+    float* const X1 = lds;
+    float* const X2 = lds + NI * RB * 64;
+    const int tid = threadIdx.x, lane = tid & 63, pl = lane & 15, q = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.m_dev) a.M = *a.m_dev;
+    const int row0 = blockIdx.x * RB;
+    if (row0 >= a.M) return;
+    const blob_rsrc rs = make_blob_rsrc(a.blob, a.blob_floats);
+    auto request = [&](f32x4 (&af)[NS][4], int64_t W, int c, int step) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t base = W + ((int64_t)(((c * BN + 32 * w) >> 4) + s) * NI + step) * 1024;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) af[s][kt] = bload4(rs, base + kt * 256, lane * 16);
+        }
+    };
+    f32x4 afA[NS][4], afB[NS][4];
+    request(afA, a.W, 0, 0);
+#pragma unroll 1
+    for (int pass = 0; pass < NP; ++pass) {
+        const int r = RPW * w + 4 * pass + q;
+        const int row = min(row0 + r, a.M - 1);
+        const float* ap = a.A + (int64_t)row * a.lda + 4 * pl;
+        f32x4 v[NI];
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            v[i] = *reinterpret_cast<const f32x4*>(ap + 64 * i);
+            sm += hsum4(v[i]);
+        }
+        const float mean = row_sum16(sm) / (float)K;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const f32x4 dl = v[i] - mean;
+            ss += hsum4(dl * dl);
+        }
+        const float rstd = 1.0f / sqrtf(row_sum16(ss) / (float)K + a.eps);
+        const int so = r * 64 + ((pl ^ (r & 15)) << 2);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.blob + a.gamma + 64 * i + 4 * pl);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.blob + a.beta + 64 * i + 4 * pl);
+            const f32x4 g2 = *reinterpret_cast<const f32x4*>(a.blob + b.gamma + 64 * i + 4 * pl);
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.blob + b.beta + 64 * i + 4 * pl);
+            *reinterpret_cast<f32x4*>(X1 + so + i * (RB * 64)) = (v[i] - mean) * rstd * g1 + b1;
+            *reinterpret_cast<f32x4*>(X2 + so + i * (RB * 64)) = (v[i] - mean) * rstd * g2 + b2;
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[NS][TPW];
+    auto mma = [&](f32x4 (&af)[NS][4], const float* buf) {
+        constexpr int NIT = (TPW / 2) * 4;
+        auto bfrag = [&](f32x4 (&B)[2], int it) {
+            const int tp = it >> 2, kt = it & 3;
+            const float* b0p = buf + (32 * tp + pl) * 64 + (((4 * kt + q) ^ pl) << 2);
+            B[0] = *reinterpret_cast<const f32x4*>(b0p);
+            B[1] = *reinterpret_cast<const f32x4*>(b0p + 16 * 64);
+        };
+        f32x4 Bq[2][2];
+        bfrag(Bq[0], 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (it + 1 < NIT) bfrag(Bq[(it + 1) & 1], it + 1);
+            const int tp = it >> 2, kt = it & 3;
+            const f32x4 B0 = Bq[it & 1][0], B1 = Bq[it & 1][1];
+#define PFM_TF_STEP(c)                                                                                         \
+    acc[0][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B0.c, acc[0][2 * tp], 0, 0, 0);         \
+    acc[1][2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][kt].c, B0.c, acc[1][2 * tp], 0, 0, 0);         \
+    acc[0][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][kt].c, B1.c, acc[0][2 * tp + 1], 0, 0, 0); \
+    acc[1][2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][kt].c, B1.c, acc[1][2 * tp + 1], 0, 0, 0);
+            PFM_TF_STEP(x) PFM_TF_STEP(y) PFM_TF_STEP(z) PFM_TF_STEP(w)
+#undef PFM_TF_STEP
+        }
+    };
+    const int nc1 = a.NO / BN, nc = nc1 + b.NO / BN;
+    int nsteps = NI;
+    asm volatile("" : "+s"(nsteps));  // the step loop stays a loop
+#pragma unroll 1
+    for (int cc = 0; cc < nc; ++cc) {
+        const bool second = cc >= nc1;  // workgroup-uniform
+        const LinArgs& L = second ? b : a;
+        const float* const X = second ? X2 : X1;
+        const int c = second ? cc - nc1 : cc;
+        const int ob = c * BN + 32 * w;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                acc[s][t] = L.b >= 0 ? *reinterpret_cast<const f32x4*>(a.blob + L.b + ob + 16 * s + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int step = 0; step < nsteps; step += 2) {
+            request(afB, L.W, c, step + 1);
+            mma(afA, X + step * (RB * 64));
+            if (step + 2 < nsteps) request(afA, L.W, c, step + 2);
+            else if (cc + 1 < nc) request(afA, cc + 1 >= nc1 ? b.W : a.W, cc + 1 >= nc1 ? cc + 1 - nc1 : cc + 1, 0);
+            mma(afB, X + (step + 1) * (RB * 64));
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int o = ob + 16 * s + 4 * q;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int row = row0 + 16 * t + pl;
+                if (row < a.M) *reinterpret_cast<f32x4*>(L.out + (int64_t)row * L.ldo + o) = acc[s][t];
+            }
+        }
+    }
+}
+
+// two plain LayerNorm-Linears of the same rows in one launch where the panel conditions hold; false: the caller launches them one by one
+inline bool launch_panel2(const LinArgs& l1, const LinArgs& l2, int cus, hipStream_t s) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("PFM_TF_PANEL2");  // diagnostics only (tests/diag): 0 = two launches
+        const char* p = getenv("PFM_TF_PANEL");
+        on = (p && !atoi(p)) ? 0 : (e ? atoi(e) : 1);
+    }
+    auto plain = [](const LinArgs& l) { return l.gamma >= 0 && !l.jb && !l.R && !l.act && !l.pre_act && !l.A2 && l.ksplit == 1 && l.NO % BN == 0; };
+    if (!on || !plain(l1) || !plain(l2) || l1.K != 128 || l2.K != 128 || l1.A != l2.A || l1.lda != l2.lda || l1.M != l2.M || l1.m_dev != l2.m_dev ||
+        (int64_t)(l1.M + 31) / 32 < 2 * (int64_t)cus)
+        return false;
+    MlpArgs m{l1, l1, l2};
+    hipLaunchKernelGGL((tf_linear_panel2_kernel<2>), dim3((l1.M + 31) / 32), dim3(LT), 2 * 2 * 32 * 64 * 4, s, m);
+    return true;
+}
+
 // Row tile of a Linear launch: 32, 64 or 128 rows per workgroup, whichever gives the shortest schedule on this GPU's
 // 2 x CU workgroup slots.  Work per round ~ rows x cost-per-row of the tile: a 128-row tile reads every weight block
 // from L2 once per 128 rows instead of once per 64 (the L2 -> register weight stream is what limits the 64-row kernel),
