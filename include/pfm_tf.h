@@ -133,7 +133,7 @@ int pfm_tf_sample_midpoint(const pfm_tf_desc *desc, const float *blob, const flo
 
 /* Fixed-step explicit Runge-Kutta (pfm_rk_tableau, pfm_hip.h): t_eval[n_steps * stages], dt[n_steps];
  * state: (2 + stages) * n_jets*N*F floats of scratch.  ode_solver "euler" / "rk4" of CNF.decode and the rk4 of CNF.encode
- * (flow_matching_module.py:235-243, 261-282). */
+ * (flow_matching_module.py:235-243, 261-282).  Splits into two half-batches on two internal streams like pfm_tf_sample_midpoint. */
 int pfm_tf_sample_rk(const pfm_tf_desc *desc, const float *blob, const pfm_rk_tableau *tab, const float *t_eval,
                      const float *dt, int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
                      int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);

@@ -480,30 +480,55 @@ int pfm_tf_sample_midpoint(const pfm_tf_desc* d, const float* blob, const float*
     return rc;
 }
 
+// one fixed-step Runge-Kutta call on the jets [j0, j0 + nj) of the caller's arrays, everything on `stream` (state: this part's (2 + stages) x rows x F floats)
+static int tf_sample_rk_part(const pfm_tf_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt, int32_t n_steps,
+                             const float* z, const float* cond, const float* mask, float* x_out, int j0, int nj, int32_t premask, float* state,
+                             float* workspace, void* stream) {
+    Plan p;
+    int rc = make_plan(p, d, blob, workspace, nj, false, stream);
+    if (rc) return rc;
+    const int64_t r0 = (int64_t)j0 * d->n_points, n = (int64_t)p.M * d->features;
+    const float* cnd = cond ? cond + (int64_t)j0 * d->cond_dim : nullptr;
+    const float* msk = mask ? mask + r0 : nullptr;
+    hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z + r0 * d->features, premask ? msk : nullptr, state, n,
+                       d->features);
+    if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+    if ((rc = setup_valid_rows(p, msk))) return rc;
+    rc = sample_rk_rows(*tab, t_eval, dt, n_steps, state, n, p.s, [&](const float* t, const float* x, float* v) {
+        HeadArgs h{};
+        h.dst = v;
+        return run_nfe(p, t, 0, x, cnd, msk, h);
+    });
+    if (rc) return rc;
+    if ((rc = check_hip(hipGetLastError(), "tf_rk_combine_kernel launch"))) return rc;
+    return check_hip(hipMemcpyAsync(x_out + r0 * d->features, state, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_out");
+}
+
 int pfm_tf_sample_rk(const pfm_tf_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
                      int32_t n_steps, const float* z, const float* cond, const float* mask, float* x_out, int32_t n_jets,
                      int32_t premask, float* state, float* workspace, void* stream) {
-    Plan p;
-    int rc = make_plan(p, d, blob, workspace, n_jets, false, stream);
+    int rc = validate(d);
     if (rc) return rc;
     if (const char* e = rk_tableau_error(tab)) return set_err(PFM_E_BADARG, e);
     if (n_jets <= 0) return 0;
     if (!blob || !t_eval || !dt || !z || !x_out || !state || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (n_steps < 0) return set_err(PFM_E_BADARG, "n_steps < 0");
     if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
-    const int64_t n = (int64_t)p.M * d->features;
-    hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, state, n,
-                       d->features);
-    if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
-    if ((rc = setup_valid_rows(p, mask))) return rc;
-    rc = sample_rk_rows(*tab, t_eval, dt, n_steps, state, n, p.s, [&](const float* t, const float* x, float* v) {
-        HeadArgs h{};
-        h.dst = v;
-        return run_nfe(p, t, 0, x, cond, mask, h);
-    });
-    if (rc) return rc;
-    if ((rc = check_hip(hipGetLastError(), "tf_rk_combine_kernel launch"))) return rc;
-    return check_hip(hipMemcpyAsync(x_out, state, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_out");
+    // two half-batches on two side streams like the midpoint sampler (here one half is queued after the other: the host enqueues a call several
+    // times faster than the GPU runs it, so the halves still run side by side)
+    const int n_a = (d->flags & PFM_TF_F_ONE_STREAM) ? 0 : split_point(n_jets, 32);
+    SideStream* ss = n_a ? side_stream((hipStream_t)stream) : nullptr;
+    if (!ss) return tf_sample_rk_part(d, blob, tab, t_eval, dt, n_steps, z, cond, mask, x_out, 0, n_jets, premask, state, workspace, stream);
+    if (hipEventRecord(ss->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess ||
+        hipStreamWaitEvent(ss->s2, ss->fork, 0) != hipSuccess)
+        return set_err(PFM_E_BADARG, "side stream fork failed");
+    const int64_t per_row = (int64_t)(2 + tab->stages) * d->features;
+    rc = tf_sample_rk_part(d, blob, tab, t_eval, dt, n_steps, z, cond, mask, x_out, 0, n_a, premask, state, workspace, ss->s);
+    if (!rc)
+        rc = tf_sample_rk_part(d, blob, tab, t_eval, dt, n_steps, z, cond, mask, x_out, n_a, n_jets - n_a, premask,
+                               state + per_row * n_a * d->n_points, workspace + make_ws(*d, n_a, false).total, ss->s2);
+    side_join(ss, (hipStream_t)stream);  // also on an error return: the caller's stream must not overtake the side streams' work
+    return rc;
 }
 
 int pfm_tf_fm_loss_forward(const pfm_tf_desc* d, const float* blob, int32_t kind, float sigma, const float* t,

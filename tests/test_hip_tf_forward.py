@@ -148,6 +148,10 @@ def test_two_stream_halves_of_the_midpoint_sampler_change_nothing(ops, valid_row
     for sl in (slice(0, h), slice(h, B)):
         part = ops.tf_sample_midpoint(lay, blob, sub(z, sl), sub(cond, sl), sub(mask, sl), ode_steps=4).cpu()
         assert torch.equal(whole[sl], part)
+    # the Runge-Kutta sampler splits the same way (pfm_tf_sample_rk)
+    whole_rk = ops.tf_sample_rk(lay, blob, z.cuda(), _dev(cond), mask.cuda(), ode_steps=3, solver="rk4").cpu()
+    for sl in (slice(0, h), slice(h, B)):
+        assert torch.equal(whole_rk[sl], ops.tf_sample_rk(lay, blob, sub(z, sl), sub(cond, sl), sub(mask, sl), ode_steps=3, solver="rk4").cpu())
     # PFM_TF_F_ONE_STREAM (callers with several calls in flight): the same call on the caller's stream alone
     lay1 = TfLayout(TfConfig.from_hparams(g.hp), flags=(4 if valid_rows else 0) | 16)
     blob1 = lay1.pack_blob(g.state, "flows.0.", freqs=g.freqs).cuda()
