@@ -32,7 +32,9 @@ sys.path.insert(0, ROOT)
 
 NFE_FLOP_PER_JET = 84.22e6     # algorithmic fwd FLOP / jet, dense over the padded N=150
 FP32_MFMA_PEAK = 157.3e12      # MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
-PMC_SUMMARIES = ("round2_fast_pmc_hbm_summary.json", "round2_pmc_hbm_summary.json", "round1_pmc_hbm_summary.json")  # profiles/: rocprofv3 --pmc passes of this command (tests/diag/collect_bench_profiles.sh), newest first
+# profiles/: rocprofv3 --pmc passes of this command, newest first (tests/diag/collect_pmc_sq.sh: SQ / GRBM / TCC counters per launch;
+# tests/diag/collect_bench_profiles.sh: FETCH_SIZE / WRITE_SIZE only)
+PMC_SUMMARIES = ("round3_pmc_summary.json", "round2_fast_pmc_hbm_summary.json", "round2_pmc_hbm_summary.json", "round1_pmc_hbm_summary.json")
 HP = dict(model="epic", features=3, hidden_dim=128, num_particles=150, frequencies=16, layers=6, latent=10,
           activation="leaky_relu", wrapper_func="weight_norm", t_local_cat=True, t_global_cat=True,
           add_time_to_input=False, t_emb="cosine", loss_type="FM-OT", sigma=1e-4, global_cond_dim=0,
@@ -44,6 +46,36 @@ def log(msg):
 
 
 T_START = time.perf_counter()
+
+
+class stage:
+    """`with stage("rendezvous", 180): ...` -- logs entry / exit per rank and, if the block has not finished after `limit` seconds
+    (a rank that never arrives, a collective that hangs), prints what it was waiting in and ends the PROCESS with a non-zero code:
+    torch.distributed.run then tears the other ranks down, and the driver's record shows the stage instead of a silent time-out."""
+
+    def __init__(self, what, limit):
+        self.what, self.limit = what, float(os.environ.get("PFM_BENCH_STAGE_TIMEOUT", limit))
+
+    def _expired(self):
+        rank = os.environ.get("RANK", "0")
+        print(f"[bench +{time.perf_counter() - T_START:7.1f}s] rank {rank}: stage '{self.what}' did not finish within {self.limit:.0f} s "
+              "-- giving up (exit 124)", file=sys.stderr, flush=True)
+        os._exit(124)
+
+    def __enter__(self):
+        import threading
+        self.t0 = time.perf_counter()
+        self.timer = threading.Timer(self.limit, self._expired)
+        self.timer.daemon = True
+        self.timer.start()
+        log(f"rank {os.environ.get('RANK', '0')}: {self.what} ...")
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        if exc[0] is None:
+            log(f"rank {os.environ.get('RANK', '0')}: {self.what} done in {time.perf_counter() - self.t0:.2f} s")
+        return False
 
 
 def synthetic_batch(B, N, F, seed):
@@ -223,10 +255,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        import datetime
+        with stage(f"rendezvous ({'gloo rehearsal' if rehearsal else 'RCCL'}, world {world}, MASTER {os.environ.get('MASTER_ADDR')}:"
+                   f"{os.environ.get('MASTER_PORT')})", 300):
+            if rehearsal:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+            else:
+                dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))  # RCCL over xGMI
+        with stage("first all-reduce (communicator set-up)", 300):
+            probe = torch.ones(4, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize(dev)
+            if float(probe[0].item()) != float(world):
+                raise SystemExit(f"rank {rank}: all-reduce of ones gave {float(probe[0].item())}, expected {world}")
 
     from particle_fm_amd.engine import FusedFMTrainer
     from particle_fm_amd.models import SetFlowMatchingLitModule
@@ -252,18 +293,23 @@ def main():
         torch.cuda.synchronize(dev)
 
     log(f"rank {rank}/{world}: model + data ready, {args.warmup} warm-up steps, overlap depth {D}")
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize(dev)
-    log("warm-up done, timing")
+    with stage(f"warm-up ({args.warmup} steps; the first one loads the kernels and, N > 1, runs the first gradient all-reduce on the "
+               "train stream)", 600):
+        for i in range(args.warmup):
+            step(i)
+            if i == 0:
+                torch.cuda.synchronize(dev)
+                log(f"rank {rank}: first step done")
+        torch.cuda.synchronize(dev)
     ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, ev[i])
-    fence()
-    elapsed = time.perf_counter() - t0
-    log(f"timed {args.steps} steps in {elapsed:.3f}s")
+    with stage(f"timed region ({args.steps} steps)", 1200):
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, ev[i])
+        fence()
+        elapsed = time.perf_counter() - t0
+    log(f"rank {rank}: timed {args.steps} steps in {elapsed:.3f}s")
     out = outs[(args.steps - 1) % S]
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -305,6 +351,25 @@ def main():
         t1e.record(main)
     torch.cuda.synchronize(dev)
     train_alone_ms = t0e.elapsed_time(t1e) / 3
+    # the gradient exchange alone (N > 1): the flat 2.2 MB all-reduce on the train stream, 10 in a row
+    allreduce_alone_ms = 0.0
+    if world > 1:
+        with stage("all-reduce timing", 300):
+            with torch.cuda.stream(main):
+                trainer.sync.sync(trainer.fp.grad)
+                t0e.record(main)
+                for _ in range(10):
+                    trainer.sync.sync(trainer.fp.grad)
+                t1e.record(main)
+            torch.cuda.synchronize(dev)
+            allreduce_alone_ms = t0e.elapsed_time(t1e) / 10
+    per_rank = torch.tensor([train_alone_ms, allreduce_alone_ms, train_ms, sample_ms, excl_ms], device=dev, dtype=torch.float64)
+    if world > 1:
+        gathered = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(gathered, per_rank)
+        per_rank = torch.stack(gathered).cpu()
+    else:
+        per_rank = per_rank[None].cpu()
 
     if rank == 0:
         jets_per_step = B * world
@@ -329,12 +394,15 @@ def main():
         lay = model.flows[0].net.layout()
         sampler_kernel = ("epic_sample_midpoint_fast_kernel<0, false, false>" if _lib.load().pfm_epic_sample_is_fast(ctypes.byref(lay.desc))
                           else "epic_sample_midpoint_kernel<0, true>")
+        mfma_busy, sq_file = None, None
         for cand in PMC_SUMMARIES:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 pmc = next(v for k, v in pmc.items() if k.startswith("pfm::" + sampler_kernel.split("<")[0] + "<0"))
-                traffic, pmc_file = (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0, cand
-                break
+                if traffic is None and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                    traffic, pmc_file = (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0, cand
+                if mfma_busy is None and "mfma_busy" in pmc:
+                    mfma_busy, sq_file = pmc["mfma_busy"], cand
             except Exception:
                 continue
         res = {
@@ -345,14 +413,24 @@ def main():
             "config": {
                 "workload": "EPiC-FM JetNet150 (N=150, F=3, H=128, L=10, 6 EPiC layers, 561330 params): per step "
                             "1 train step (FM-OT fwd+bwd, grad all-reduce, clip 0.5, AdamW, EMA) + 1 midpoint "
-                            f"ODE sample (ode_steps={args.ode_steps}, {n_nfe} NFE) on the same number of jets",
+                            f"ODE sample (ode_steps={args.ode_steps}, {n_nfe} NFE) on the same number of jets; the sample starts from a "
+                            "z that is already resident in HBM (drawn once on the CPU generator and copied before the timed region: "
+                            "sample()'s own per-call CPU randn + H2D copy, flow_matching_module.py:659-663, is NOT in the timed "
+                            "region -- generate_data, which performs it, reaches the same rate, DESIGN.md section 5)",
                 "jets_per_gpu": B, "global_batch": jets_per_step,
                 "parallelism": f"dp{world}" + (f" (REHEARSAL: {rehearsal} collectives, ranks share {torch.cuda.device_count()} GPU(s))" if rehearsal else ""),
                 "overlap": f"{D} sampling launches in flight (sample of step i on its own HIP stream with a weight "
                            "snapshot while step i+1 trains); every launch of the K steps is inside the timed region",
                 "multiplicity": "U{30..150} per jet (masked tail tiles are skipped; results identical)",
             },
-            "train_ms": train_ms, "sample_ms": sample_ms, "train_ms_alone": train_alone_ms,
+            "train_ms": train_ms, "sample_ms": sample_ms, "train_ms_alone": train_alone_ms, "allreduce_ms_alone": allreduce_alone_ms,
+            "per_rank": {"train_ms_alone": [float(v) for v in per_rank[:, 0]], "allreduce_ms_alone": [float(v) for v in per_rank[:, 1]],
+                         "train_ms_in_timed_region": [float(v) for v in per_rank[:, 2]],
+                         "sample_ms_in_timed_region": [float(v) for v in per_rank[:, 3]],
+                         "sample_ms_alone": [float(v) for v in per_rank[:, 4]],
+                         "note": "one entry per rank; train_ms_alone includes the gradient all-reduce when N > 1, allreduce_ms_alone is "
+                                 "that collective by itself (flat 2.245 MB fp32 buffer, 10 in a row on the train stream): a SCALE record "
+                                 "separates collective cost from compute with these"},
             "train_jets_per_s": B * world / (train_alone_ms * 1e-3), "sample_jets_per_s": B * world / (sample_ms * 1e-3),
             "timing_note": "train_ms / sample_ms: HIP events around the train step / one sampler launch INSIDE the timed region, where "
                            "they share the GPU (the train step's kernels wait for CUs held by sampler workgroups); train_ms_alone and "
@@ -367,11 +445,15 @@ def main():
                 "executed_row_fraction": rows_exec / float(B * n_pad),
                 "kernel_ms_in_timed_region": sample_ms, "kernel_alone_ms": excl_ms, "concurrent_launches": D,
                 "algorithmic_dense_flop_per_launch": dense_sample,
-                "frac_algorithmic_dense": dense_sample / (excl_ms * 1e-3) / FP32_MFMA_PEAK,
+                "dense_equiv_over_peak": dense_sample / (excl_ms * 1e-3) / FP32_MFMA_PEAK,
+                "mfma_busy": mfma_busy,
                 "dense_flop_not_executed_share": 1.0 - exec_sample / dense_sample,
                 "note": "frac = achieved / peak with achieved = FLOP the matrix cores EXECUTE (13 Linears of 128x128 per evaluation on "
                         "the 16-row tiles up to each jet's last valid particle; sampler launches + train steps, train = 3x forward) "
-                        "over the timed wall time: it cannot exceed 1.  frac_algorithmic_dense = SURVEY 8d's dense count "
+                        "over the timed wall time: it cannot exceed 1.  mfma_busy = the hardware's own count for ONE sampler launch alone on "
+                        f"the GPU: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of profiles/{sq_file} (rocprofv3 --pmc, "
+                        "tests/diag/collect_pmc_sq.sh; null if that file has no SQ pass for this kernel).  dense_equiv_over_peak (NOT a "
+                        "utilisation: it may exceed 1) = SURVEY 8d's dense count "
                         f"({NFE_FLOP_PER_JET/1e6:.2f} MFLOP/jet/NFE x {n_nfe} NFE x {B} jets: padded N, concatenated t/cond/g columns "
                         "counted) / duration of ONE launch alone on the GPU (kernel_alone_ms) / peak; dense_flop_not_executed_share of "
                         "that count is never executed (masked tail tiles skipped, t/cond/g columns folded into per-jet bias GEMVs on "

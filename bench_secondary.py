@@ -7,7 +7,7 @@ metric is quoted on).  One JSON line per workload, same schema as bench.py, sing
 step = 1 train step (loss forward + backward through the HIP kernels, clip 0.5 + AdamW + EMA) + 1 midpoint sample
 (ode_steps = 100, 198 NFE) on the configuration's batch; inputs synthetic and resident in HBM.  `roofline.achieved` is
 the FLOP rate the matrix cores executed in the sampling launches over the timed wall time (padded particles skipped), against
-the fp32 MFMA peak; `frac_algorithmic_dense` keeps SURVEY.md section 8's dense count for comparison.
+the fp32 MFMA peak; `dense_equiv_over_peak` keeps SURVEY.md section 8's dense count for comparison.
 `cpu_baseline` = the oracle on the host cores on a bounded sample (a few jets, 3-step sample scaled to 100 steps: stated).
 """
 from __future__ import annotations
@@ -227,12 +227,12 @@ def run(name, args):
                      "achieved": executed / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": executed / peak,
                      "traffic": None, "concurrent_launches": D, "valid_row_fraction": float(nv.mean()) / N,
                      "executed_share_of_dense": exec_share,
-                     "frac_algorithmic_dense": dense_launch / peak,
-                     "frac_algorithmic_dense_aggregate": dense_aggregate / peak,
+                     "dense_equiv_over_peak": dense_launch / peak,
+                     "dense_equiv_over_peak_aggregate": dense_aggregate / peak,
                      "note": "frac = achieved / peak, achieved = estimate of the FLOP the matrix cores executed in the sampling launches over "
                              f"the timed wall time: SURVEY 8d's dense count ({flop/1e6:.1f} MFLOP/jet/NFE over the padded N x {n_nfe} NFE x {B} "
                              "jets) scaled by executed_share_of_dense (padded particles are skipped: row work ~ mean(n)/N, self-attention ~ "
-                             "mean(n^2)/N^2); frac_algorithmic_dense = the dense count / HIP-event time of ONE sampler call (calls overlap: "
+                             "mean(n^2)/N^2); dense_equiv_over_peak = the dense count / HIP-event time of ONE sampler call (calls overlap: "
                              "a throughput-equivalent, not MFMA utilisation)"},
     }
     if not args.no_cpu_baseline:

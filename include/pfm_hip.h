@@ -61,7 +61,9 @@
 extern "C" {
 #endif
 
-#define PFM_ABI_VERSION 1
+/* 2 (round 3): pfm_epic_fm_loss_backward / pfm_epic_diffusion_loss_backward take a `scratch` pointer in front of `stream` and WRITE
+ * grad_blob (round 2 changed both under version 1: a caller or a stale library built against that header must be refused) */
+#define PFM_ABI_VERSION 2
 #define PFM_MAX_LAYERS 24
 #define PFM_HIDDEN 128
 

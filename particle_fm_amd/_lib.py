@@ -128,8 +128,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.pfm_abi_version() != 1:
-        raise RuntimeError("libpfm_hip.so ABI version mismatch")
+    from .layout import PFM_ABI_VERSION
+    if lib.pfm_abi_version() != PFM_ABI_VERSION:
+        raise RuntimeError(f"libpfm_hip.so ABI version {lib.pfm_abi_version()} != {PFM_ABI_VERSION} (include/pfm_hip.h): stale library, rebuild with "
+                           "`python -m particle_fm_amd.build --force`")
     _lib = lib
     return lib
 

@@ -742,19 +742,23 @@ int64_t pfm_epic_sample_scratch_floats(const pfm_epic_desc* d, int32_t n_interva
 static bool sample_fast(const pfm_epic_desc* d, int mode) { return d && d->layers > 0 && fast_path_ok(*d) && mode != 2; }
 int pfm_epic_sample_is_fast(const pfm_epic_desc* d) { return validate(d) == 0 && sample_fast(d, mfma_mode(d)) ? 1 : 0; }
 
-// device pointer of the workgroup list inside `scratch`, after queueing its computation; nullptr: one jet per workgroup, in order
+// Two jets per workgroup: opt-in (PFM_F_PACK_JETS; the diagnostic tests/diag/pack_time.py also switches it with the environment
+// variable PFM_PACK=1 / 0).  Measured on MI355X: a pair saves one jet's fixed cost but pays for the doubled per-jet work,
+// and the workgroups of a launch become few and uniformly long -- +1 % at 1024 jets, +-0 at 256 with two launches in flight, -4 % at
+// 512: not on by default.  ONE place decides it, so that the workgroup list and the kernel instantiation can never disagree.
+static bool pairs_wanted(const pfm_epic_desc* d) {
+    static const char* env = getenv("PFM_PACK");
+    return env ? env[0] == '1' : (d->flags & PFM_F_PACK_JETS) != 0;
+}
+
+// device pointer of the workgroup list inside `scratch`, after queueing its computation; nullptr: one jet per workgroup, in order.
+// allow_pairs: the kernel that will read the list has a two-jet path (fp32 / bf16 kernels with tail-skipping on: a jet then occupies
+// rows up to its last valid particle only); false: singles in descending multiplicity, whatever the flag / environment says.
 static const int* queue_jet_pack(const pfm_epic_desc* d, float* scratch, int64_t table_floats, const float* mask, int B, int mode,
-                                 hipStream_t s) {
+                                 hipStream_t s, bool allow_pairs) {
     if (!scratch || !mask || B < 2 || B > ORDER_MAX_JETS) return nullptr;
     int* pack = reinterpret_cast<int*>(scratch + table_floats);
-    // two jets per workgroup: fp32 / bf16 kernels, tail-skipping on (a jet then occupies rows up to its last valid particle only)
-    // two jets per workgroup: opt-in (PFM_F_PACK_JETS; the diagnostic tests/diag/pack_time.py also switches it with the environment
-    // variable PFM_PACK=1 / 0).  Measured on MI355X: a pair saves one jet's fixed cost (7.05 ms per 100-step sample) but
-    // pays 3.2 ms for the doubled per-jet work, and the workgroups of a launch become few and uniformly long -- +1 % at 1024 jets,
-    // +-0 at 256 with two launches in flight, -4 % at 512: not on by default.
-    static const char* env = getenv("PFM_PACK");
-    const bool want = env ? env[0] == '1' : (d->flags & PFM_F_PACK_JETS) != 0;
-    const int pair_ok = want && (mode != 2) && (d->flags & PFM_F_SKIP_MASKED_TAIL) && seg2_rows(d->n_points) >= 2 * TILE;
+    const int pair_ok = allow_pairs && pairs_wanted(d) && (mode != 2) && (d->flags & PFM_F_SKIP_MASKED_TAIL) && seg2_rows(d->n_points) >= 2 * TILE;
     hipLaunchKernelGGL(epic_jet_pack_kernel, dim3(1), dim3(1024), 0, s, mask, B, d->n_points, pair_ok, pack);
     return pack;
 }
@@ -789,9 +793,8 @@ static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const floa
     // the lean evaluation of epic_fast.h: unconditioned jets, T = 32, F <= 4, fp32 / bf16 operands, one jet per workgroup
     const bool fast = tb && sample_fast(d, mode);
     if (fast) {
-        static const char* env_pack = getenv("PFM_PACK");  // as queue_jet_pack
-        const bool pairs = env_pack ? env_pack[0] == '1' : (d->flags & PFM_F_PACK_JETS) != 0;
-        const bool cnd = d->cond_global > 0;  // (fast_path_ok: never together with pairs)
+        const bool cnd = d->cond_global > 0;  // conditioned jets: one per workgroup (the PFM_PACK override must not pair them either)
+        const bool pairs = !cnd && pairs_wanted(d);
         const void* fk = cnd ? (mode == 1 ? (const void*)epic_sample_midpoint_fast_kernel<1, false, true> : (const void*)epic_sample_midpoint_fast_kernel<0, false, true>)
                        : pairs ? (mode == 1 ? (const void*)epic_sample_midpoint_fast_kernel<1, true> : (const void*)epic_sample_midpoint_fast_kernel<0, true>)
                                : (mode == 1 ? (const void*)epic_sample_midpoint_fast_kernel<1, false> : (const void*)epic_sample_midpoint_fast_kernel<0, false>);
@@ -806,10 +809,9 @@ static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const floa
         if ((rc = check_hip(hipGetLastError(), "epic_time_table_kernel launch"))) return rc;
     }
     if (fast) {
-        static const char* env_pack = getenv("PFM_PACK");
-        const bool pairs = env_pack ? env_pack[0] == '1' : (d->flags & PFM_F_PACK_JETS) != 0;
-        const int* jet_order = queue_jet_pack(d, scratch, list_off, mask, B, mode, (hipStream_t)stream);  // singles unless `pairs`
         const bool cnd = d->cond_global > 0;
+        const bool pairs = !cnd && pairs_wanted(d);
+        const int* jet_order = queue_jet_pack(d, scratch, list_off, mask, B, mode, (hipStream_t)stream, pairs);  // singles unless `pairs`
         float* ctab = nullptr;
         if (cnd) {  // the jets' conditioning terms, once per call
             ctab = scratch + table_floats;
@@ -828,7 +830,7 @@ static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const floa
 #define PFM_LAUNCH_SMP(M, T)                                                                                                  \
     hipLaunchKernelGGL((epic_sample_midpoint_kernel<M, T>), dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, \
                        t_eval, dt, n_intervals, z, cond, mask, x_out, (const float*)scratch, order, temb_tab)
-    const int* order = queue_jet_pack(d, scratch, list_off, mask, B, mode, (hipStream_t)stream);
+    const int* order = queue_jet_pack(d, scratch, list_off, mask, B, mode, (hipStream_t)stream, true);  // the generic kernel pairs conditioned jets too
     if (tb) { if (mode == 2) PFM_LAUNCH_SMP(2, true); else if (mode == 1) PFM_LAUNCH_SMP(1, true); else PFM_LAUNCH_SMP(0, true); }
     else { if (mode == 2) PFM_LAUNCH_SMP(2, false); else if (mode == 1) PFM_LAUNCH_SMP(1, false); else PFM_LAUNCH_SMP(0, false); }
 #undef PFM_LAUNCH_SMP

@@ -84,9 +84,12 @@ struct SideStream {
     hipStream_t s = nullptr, s2 = nullptr;  // two streams measured to run side by side (the caller's stream only forks / joins)
     hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
 };
-// One pair of side streams per CALLER stream (up to SIDE_PAIRS per device; later caller streams share the last pair): two sampler calls
-// in flight from different caller streams (generate_data's batch pipeline, bench_secondary --overlap) then run side by side
-// instead of queueing on one pair.  Creation is serialised by a mutex (two host threads may enter a sampler at once).
+// One PRIVATE pair of side streams per CALLER stream (up to SIDE_PAIRS per device): two sampler calls in flight from different caller
+// streams (generate_data's batch pipeline, bench_secondary --overlap) then run side by side instead of queueing on one pair.  A pair and
+// its fork / join events are never shared between caller streams: with a shared pair, one call's side streams could wait on the OTHER
+// caller's fork record and start before their own caller stream's earlier work (z H2D copy, blob pack) has finished.  A caller stream
+// beyond SIDE_PAIRS gets nullptr: its call runs unsplit on its own stream.  Creation is serialised by a mutex (two host threads may enter
+// a sampler at once; two threads on the SAME caller stream are the caller's race, as with any stream).
 constexpr int SIDE_PAIRS = 4;
 inline SideStream* side_stream(hipStream_t caller) {
     struct PerDev {
@@ -102,7 +105,7 @@ inline SideStream* side_stream(hipStream_t caller) {
     PerDev& pd = st[dev];
     for (int i = 0; i < pd.n; ++i)
         if (pd.owner[i] == caller) return &pd.pair[i];
-    if (pd.n == SIDE_PAIRS) return &pd.pair[SIDE_PAIRS - 1];
+    if (pd.n == SIDE_PAIRS) return nullptr;  // no private pair left: single-stream path
     SideStream e;
     {
         // candidates are kept alive until both choices are made (a destroyed stream's queue would be dealt to the next one again);
@@ -126,8 +129,15 @@ inline SideStream* side_stream(hipStream_t caller) {
         e.s2 = b >= 0 ? cand[b] : nullptr;
         if (!e.s || !e.s2 || hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e.join2, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&e.join2, hipEventDisableTiming) != hipSuccess) {
+            if (e.s) hipStreamDestroy(e.s);  // nothing half-made is kept (or leaked)
+            if (e.s2) hipStreamDestroy(e.s2);
+            if (e.fork) hipEventDestroy(e.fork);
+            if (e.join) hipEventDestroy(e.join);
+            if (e.join2) hipEventDestroy(e.join2);
+            (void)hipGetLastError();
             return nullptr;
+        }
     }
     pd.pair[pd.n] = e;
     pd.owner[pd.n] = caller;

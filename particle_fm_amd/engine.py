@@ -185,7 +185,9 @@ class FusedFMTrainer:
                   # initial blob the slow (torch) way: fixes freqs + descriptor tail; the pack kernel rewrites the rest
                   "blob": fm_loss.pack_blob_from_source(lay, net.source_vector(lay).detach()).contiguous(),
                   "one": torch.ones(1, device=self.fp.flat.device)}
-            st["gblob"] = torch.zeros_like(st["blob"])  # the backward WRITES every gradient slot (no atomics): zeroed once
+            # the backward WRITES every gradient slot the unpack kernel reads (no atomics; tests/test_hip_train.py fills it with NaN
+            # first and checks): allocated once, never zeroed again
+            st["gblob"] = torch.zeros_like(st["blob"])
             self._fused[key] = st
         return st
 
@@ -236,7 +238,6 @@ class FusedFMTrainer:
         fin = st.get("fin")
         if fin is None:
             fin = st["fin"] = torch.empty(2, device=x.device, dtype=torch.float32)  # [loss, 1 / sum(mask)]
-        scratch = hip_ops.epic_backward_scratch(lay, B, x.device)
         if kind == "diffusion":
             from .fm_loss import MLE_LOSS_WEIGHT
             t, z = loss_mod.draw(x, mask)
@@ -245,9 +246,7 @@ class FusedFMTrainer:
             parts, count, saved = hip_ops.epic_diffusion_loss_forward(lay, blob, x, t, z, torch.stack([sr, nr], dim=1), cond, maskf,
                                                                       loss_mod.criterion)
             _lib.check(lib.pfm_loss_finish(P(parts), P(count), P(jet_w), B, P(fin), S), "pfm_loss_finish")
-            _lib.check(lib.pfm_epic_diffusion_loss_backward(ctypes.byref(lay.desc), P(blob), {"mse": 0, "huber": 1}[loss_mod.criterion],
-                                                            P(jet_w), P(condf), P(maskf), P(saved), P(fin[1:]), P(st["one"]),
-                                                            P(gblob), B, P(scratch), S), "pfm_epic_diffusion_loss_backward")
+            hip_ops.epic_loss_backward(lay, blob, condf, maskf, saved, fin[1:], st["one"], gblob, criterion=loss_mod.criterion, jet_w=jet_w)
         else:
             if kind == "CFM":
                 t, z, eps = loss_mod.draw(x)
@@ -255,8 +254,7 @@ class FusedFMTrainer:
                 (t, z), eps = loss_mod.draw(x), None
             parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x, t, z, cond, maskf, loss_mod.sigma, kind, eps)
             _lib.check(lib.pfm_loss_finish(P(parts), P(count), P(None), B, P(fin), S), "pfm_loss_finish")
-            _lib.check(lib.pfm_epic_fm_loss_backward(ctypes.byref(lay.desc), P(blob), P(None), P(condf), P(maskf), P(saved),
-                                                     P(fin[1:]), P(st["one"]), P(gblob), B, P(scratch), S), "pfm_epic_fm_loss_backward")
+            hip_ops.epic_loss_backward(lay, blob, condf, maskf, saved, fin[1:], st["one"], gblob)
         loss = fin[0].clone()  # `fin` is rewritten by the next step
         _lib.check(lib.pfm_wn_unpack_grad(P(self.fp.flat), P(gblob), P(tb.rows), tb.n_rows, P(tb.gsrc), P(tb.bias_gblob),
                                           P(tb.bias_param), tb.n_bias, P(self.fp.grad), S), "pfm_wn_unpack_grad")

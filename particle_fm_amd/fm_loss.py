@@ -72,19 +72,9 @@ class EpicFMLossFn(torch.autograd.Function):
             cond = None
         cond = None if cond is None else cond.to(torch.float32).contiguous()
         maskf = None if mask is None else mask.reshape(B, -1).to(torch.float32).contiguous()
-        P = hip_ops._ptr
-        d_temb = None
-        if ctx.has_temb:  # the caller's embedding network trains too: d loss / d temb comes back with the weight gradient
-            d_temb = torch.empty(B, layout.cfg.t_dim, device=dev, dtype=torch.float32)
-            rc = lib.pfm_epic_fm_loss_backward_temb(ctypes.byref(layout.desc), P(blob), P(cond), P(maskf), P(saved), P(inv_total),
-                                                    P(gscale), P(gblob), P(d_temb), B,
-                                                    P(hip_ops.epic_backward_scratch(layout, B, dev)), hip_ops._stream_ptr(dev))
-            _lib.check(rc, "pfm_epic_fm_loss_backward_temb")
-        else:
-            rc = lib.pfm_epic_fm_loss_backward(ctypes.byref(layout.desc), P(blob), P(None), P(cond), P(maskf), P(saved),
-                                               P(inv_total), P(gscale), P(gblob), B, P(hip_ops.epic_backward_scratch(layout, B, dev)),
-                                               hip_ops._stream_ptr(dev))
-            _lib.check(rc, "pfm_epic_fm_loss_backward")
+        d_temb = torch.empty(B, layout.cfg.t_dim, device=dev, dtype=torch.float32) if ctx.has_temb else None
+        # (the caller's embedding network trains too: d loss / d temb comes back with the weight gradient)
+        hip_ops.epic_loss_backward(layout, blob, cond, maskf, saved, inv_total, gscale, gblob, d_temb=d_temb)
         _, gpos, _ = _Maps.get(layout, dev)
         # every weight / bias has exactly one gradient slot in the blob (layout.src_gpos): a plain gather;
         # freqs and the zero pad get no gradient
@@ -127,12 +117,8 @@ class EpicDiffusionLossFn(torch.autograd.Function):
         gscale = grad_loss.to(torch.float32).reshape(1).contiguous()
         cond = None if (ctx.cond is None or layout.cfg.global_cond_dim == 0) else ctx.cond.to(torch.float32).contiguous()
         maskf = None if ctx.mask is None else ctx.mask.reshape(B, -1).to(torch.float32).contiguous()
-        P = hip_ops._ptr
-        rc = lib.pfm_epic_diffusion_loss_backward(ctypes.byref(layout.desc), P(blob), {"mse": 0, "huber": 1}[ctx.criterion],
-                                                  P(jet_w.contiguous()), P(cond), P(maskf), P(saved), P(inv_total), P(gscale),
-                                                  P(gblob), B, P(hip_ops.epic_backward_scratch(layout, B, dev)),
-                                                  hip_ops._stream_ptr(dev))
-        _lib.check(rc, "pfm_epic_diffusion_loss_backward")
+        hip_ops.epic_loss_backward(layout, blob, cond, maskf, saved, inv_total, gscale, gblob, criterion=ctx.criterion,
+                                   jet_w=jet_w.contiguous())
         _, gpos, _ = _Maps.get(layout, dev)
         d_src = torch.zeros(ctx.n_source, device=dev, dtype=torch.float32)
         d_src[: gpos.numel()] = gblob[gpos]

@@ -324,20 +324,70 @@ def epic_fm_loss_forward(layout: EpicLayout, blob: torch.Tensor, x: torch.Tensor
     return parts, count, saved
 
 
+BWD_CHUNK_JETS = 2048   # jets per pfm_epic_*_loss_backward call: its scratch is B * (2 layers + 1) * N * 128 floats (1 GiB at 1024 jets
+                        # of 150 particles, 6 layers) and the C ABI takes at most 8192 jets per call (DW_MAXB, csrc/epic_dw.h)
+_BWD_SCRATCH_SLOTS = 4  # cached scratch buffers per layout (least recently used goes first)
+
+
 def epic_backward_scratch(layout: EpicLayout, B: int, device) -> torch.Tensor:
     """Scratch of one pfm_epic_*_loss_backward call (gradient rows, per-jet rank-1 operands, partial dW tiles), cached on the
-    layout per (B, device, stream): the backward fully writes what it reads, and two backwards on one stream run in order."""
+    layout per (B, device, stream): the backward fully writes what it reads, and two backwards on one stream run in order.
+    At most _BWD_SCRATCH_SLOTS buffers are kept per layout (LRU), one batch size per (device, stream)."""
     lib = _lib.load()
     cache = layout.__dict__.setdefault("_bwd_scratch", {})
     key = (int(B), str(device), torch.cuda.current_stream(device).cuda_stream)
-    if key not in cache:
-        n = lib.pfm_epic_backward_scratch_floats(ctypes.byref(layout.desc), int(B))
-        if n < 0:
-            _lib.check(1, "pfm_epic_backward_scratch_floats")
-        for k in [k for k in cache if k[1:] == key[1:]]:  # one batch size per (device, stream) at a time
-            del cache[k]
-        cache[key] = torch.empty(max(1, n), device=device, dtype=torch.float32)
+    if key in cache:
+        cache[key] = cache.pop(key)  # most recently used last
+        return cache[key]
+    n = lib.pfm_epic_backward_scratch_floats(ctypes.byref(layout.desc), int(B))
+    if n < 0:
+        _lib.check(1, "pfm_epic_backward_scratch_floats")
+    for k in [k for k in cache if k[1:] == key[1:]]:  # one batch size per (device, stream) at a time
+        del cache[k]
+    while len(cache) >= _BWD_SCRATCH_SLOTS:  # streams that are gone (or idle) must not pin their GiB forever
+        del cache[next(iter(cache))]
+    cache[key] = torch.empty(max(1, n), device=device, dtype=torch.float32)
     return cache[key]
+
+
+def epic_loss_backward(layout: EpicLayout, blob, cond, maskf, saved, inv_total, gscale, gblob, *, criterion: Optional[str] = None,
+                       jet_w=None, d_temb=None) -> None:
+    """The atomics-free backward of the jet-resident EPiC loss (pfm_epic_fm_loss_backward / _temb / pfm_epic_diffusion_loss_backward):
+    WRITES every gradient slot of ``gblob`` (layout.src_gpos) -- nothing has to be zeroed by the caller.  Batches beyond
+    BWD_CHUNK_JETS run in chunks (each chunk's gradient is written to a second blob and added in chunk order: still a pure function
+    of the inputs), so neither the 8192-jet limit of one call nor its B-proportional scratch bounds the batch size.
+    cond / maskf: float32 (B,C) / (B,N) or None; inv_total, gscale: 1-element device tensors; criterion: None (FM-OT / CFM / droid)
+    or "mse" / "huber" (diffusion, with jet_w (B,)); d_temb: (B,T) out, or None."""
+    lib = _lib.load()
+    dev = blob.device
+    B = saved.shape[0]
+    S = _stream_ptr(dev)
+    P = _ptr
+    tmp = None
+    for c0 in range(0, B, BWD_CHUNK_JETS):
+        c1 = min(B, c0 + BWD_CHUNK_JETS)
+        n = c1 - c0
+        out = gblob if c0 == 0 else (tmp if tmp is not None else torch.empty_like(gblob))
+        if c0 > 0:
+            tmp = out
+        cc = None if cond is None else cond[c0:c1]
+        mm = None if maskf is None else maskf[c0:c1]
+        sv = saved[c0:c1]
+        scr = epic_backward_scratch(layout, n, dev)
+        if criterion is not None:
+            rc = lib.pfm_epic_diffusion_loss_backward(ctypes.byref(layout.desc), P(blob), {"mse": 0, "huber": 1}[criterion],
+                                                      P(jet_w[c0:c1]), P(cc), P(mm), P(sv), P(inv_total), P(gscale), P(out), n, P(scr), S)
+            _lib.check(rc, "pfm_epic_diffusion_loss_backward")
+        elif d_temb is not None:
+            rc = lib.pfm_epic_fm_loss_backward_temb(ctypes.byref(layout.desc), P(blob), P(cc), P(mm), P(sv), P(inv_total), P(gscale),
+                                                    P(out), P(d_temb[c0:c1]), n, P(scr), S)
+            _lib.check(rc, "pfm_epic_fm_loss_backward_temb")
+        else:
+            rc = lib.pfm_epic_fm_loss_backward(ctypes.byref(layout.desc), P(blob), P(None), P(cc), P(mm), P(sv), P(inv_total),
+                                               P(gscale), P(out), n, P(scr), S)
+            _lib.check(rc, "pfm_epic_fm_loss_backward")
+        if c0 > 0:
+            gblob.add_(tmp)
 
 
 # ---- loss_type="diffusion" (models/components/diffusion.py, losses.py:207-290, solver.py) ------------------------------

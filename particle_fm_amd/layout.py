@@ -23,7 +23,7 @@ from typing import Dict, List, Mapping, Sequence, Tuple
 import numpy as np
 import torch
 
-PFM_ABI_VERSION = 1
+PFM_ABI_VERSION = 2
 PFM_MAX_LAYERS = 24
 PFM_HIDDEN = 128
 PFM_F_SKIP_MASKED_TAIL = 1

@@ -35,7 +35,10 @@ def test_bench_line_schema():
     assert abs(per_step / (d["ms_per_step"] * 1e-3) / 1e12 - r["achieved"]) < 1e-6 * r["achieved"]
     assert per_step / (d["ms_per_step"] * 1e-3) <= r["peak"] * 1e12
     assert 0.0 < r["valid_row_fraction"] <= r["executed_row_fraction"] <= 1.0
-    assert "frac_algorithmic_dense" in r and 0.0 < r["dense_flop_not_executed_share"] < 1.0
+    assert "dense_equiv_over_peak" in r and "frac_algorithmic_dense" not in r and 0.0 < r["dense_flop_not_executed_share"] < 1.0
+    assert "mfma_busy" in r and (r["mfma_busy"] is None or 0.2 < r["mfma_busy"] < 1.0)
+    assert "resident in HBM" in d["config"]["workload"]
+    assert len(d["per_rank"]["train_ms_alone"]) == 1 and d["allreduce_ms_alone"] == 0.0
 
 
 def test_two_rank_launch_rehearsal():
@@ -53,3 +56,15 @@ def test_two_rank_launch_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and "REHEARSAL" in d["config"]["parallelism"]
     assert abs(d["value"] - 512 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    pr = d["per_rank"]
+    assert len(pr["train_ms_alone"]) == 2 and len(pr["allreduce_ms_alone"]) == 2 and all(v > 0 for v in pr["allreduce_ms_alone"])
+    assert "rendezvous" in res.stderr and "first all-reduce" in res.stderr and "first step done" in res.stderr
+
+
+def test_a_stage_that_hangs_ends_the_process_with_a_non_zero_code():
+    """bench.py's per-rank watchdog (`stage`): a rank stuck in a stage exits 124 and says which one, instead of hanging the launcher."""
+    code = ("import sys, time; sys.argv=['bench.py']; sys.path.insert(0, %r); import bench\n"
+            "with bench.stage('sleeping', 0.5):\n    time.sleep(30)\n") % ROOT
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, cwd=ROOT)
+    assert res.returncode == 124, (res.returncode, res.stderr[-500:])
+    assert "stage 'sleeping' did not finish" in res.stderr

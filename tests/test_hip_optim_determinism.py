@@ -80,3 +80,43 @@ def test_epic_backward_is_bitwise_repeatable_and_matches_the_oracle_on_a_ragged_
         scale = max(v.grad.abs().max().item(), 1e-8)
         err = (grads[0][k].cpu() - v.grad).abs().max().item() / scale
         assert err <= 2e-4, (k, err)
+
+
+def test_backward_writes_every_gradient_slot_and_chunked_batches_agree():
+    """(i) the atomics-free backward WRITES the gradient blob -- FusedFMTrainer allocates it once and never zeroes it again,
+    which is only right if every slot the unpack reads (layout.src_gpos) is written on every call: fill it with NaN first and look;
+    (ii) batches beyond hip_ops.BWD_CHUNK_JETS run in chunks whose gradients are added in chunk order: same numbers as one call up to
+    fp32 re-association, and bitwise repeatable."""
+    import ctypes
+    from particle_fm_amd import hip_ops
+    from particle_fm_amd.layout import EpicLayout
+    from tests.test_layout_cpu import cfg_of
+    B = 20
+    g, x, mask, t, z = _ragged_loss_inputs(B, seed=11)
+    lay = EpicLayout(cfg_of(dict(g.hp)), flags=1)
+    blob = lay.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    maskf = mask.reshape(B, -1).float().cuda().contiguous()
+    parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x.cuda(), t.cuda(), z.cuda(), None, maskf, 1e-4, "FM-OT", None)
+    inv_total = (1.0 / count.sum()).reshape(1).contiguous()
+    one = torch.ones(1, device="cuda")
+    gpos = torch.from_numpy(lay.src_gpos.astype("int64")).cuda()
+
+    def run():
+        gblob = torch.full_like(blob, float("nan"))
+        hip_ops.epic_loss_backward(lay, blob, None, maskf, saved, inv_total, one, gblob)
+        return gblob[gpos]
+
+    whole = run()
+    assert torch.isfinite(whole).all(), f"{int((~torch.isfinite(whole)).sum())} gradient slots were not written"
+    assert float(whole.abs().max()) > 0
+    keep = hip_ops.BWD_CHUNK_JETS
+    try:
+        hip_ops.BWD_CHUNK_JETS = 8  # 8 + 8 + 4 jets
+        a, b = run(), run()
+    finally:
+        hip_ops.BWD_CHUNK_JETS = keep
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    scale = float(whole.abs().max())
+    assert float((a - whole).abs().max()) <= 2e-6 * scale + 1e-9, float((a - whole).abs().max()) / scale
+    # the scratch cache stays bounded
+    assert len(lay.__dict__["_bwd_scratch"]) <= hip_ops._BWD_SCRATCH_SLOTS

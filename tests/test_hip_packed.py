@@ -125,3 +125,128 @@ def test_short_sets_pack_on_a_larger_tile():
     full = hip_ops.epic_sample_midpoint(lay, blob, z.cuda(), None, None, ode_steps=4).cpu()
     full1 = hip_ops.epic_sample_midpoint(lay1, blob1, z.cuda(), None, None, ode_steps=4).cpu()
     assert torch.equal(full, full1)
+
+
+# ---- the instantiations behind the published cfg-2 numbers (bench_secondary.py --workload jetnet30 [--precision bf16]) -----------------
+# epic_sample_midpoint_fast_kernel<1, true, false> (bf16 operands, two jets per workgroup on the 80-row tile), <1, false, true>
+# (bf16, conditioned jets), and the full-size cfg-2 call (1024 jets of <= 30 particles, 100 steps).
+def _autocast_bar(vf, z, cond, mask, steps):
+    ref = sample_midpoint(vf, z, cond, mask, ode_steps=steps)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        rac = sample_midpoint(vf, z, cond, mask, ode_steps=steps).float()
+    return ref, (rac - ref).abs()
+
+
+def test_bf16_packed_sampler_equals_unpacked_bf16_bitwise_and_meets_the_autocast_bar():
+    """flags = SKIP_MASKED_TAIL | BF16_MFMA | PACK_JETS on the 30-particle model (the kernel behind the cfg-2 bf16 line): the same bits
+    as one jet per workgroup with bf16 operands (rows and per-jet vectors never mix; the operand rounding is per element), and no
+    further from the fp32 reference than the oracle under torch.autocast(bfloat16) (the bar of tests/test_hip_bf16.py)."""
+    from particle_fm_amd import hip_ops
+    from particle_fm_amd.layout import EpicLayout
+    from tests.conftest import load_golden
+    g = load_golden("jetnet30")
+    N, F = g.hp["num_particles"], g.hp["features"]
+    lay_p = EpicLayout(cfg_of(g.hp), flags=1 | 2 | 16)
+    lay_1 = EpicLayout(cfg_of(g.hp), flags=1 | 2)
+    assert hip_ops.packed_tile_rows(lay_p, N) == 80
+    blob_p = lay_p.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    blob_1 = lay_1.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    B, steps = 96, 12
+    n, mask, z, _ = _ragged(B, N, F, 0, seed=123, lo=1)
+    packed = hip_ops.epic_sample_midpoint(lay_p, blob_p, z.cuda(), None, mask.cuda(), ode_steps=steps).cpu()
+    single = hip_ops.epic_sample_midpoint(lay_1, blob_1, z.cuda(), None, mask.cuda(), ode_steps=steps).cpu()
+    assert torch.equal(packed, single)
+    nwg, wl = _pack_list(lay_p.padded(80), B, steps)
+    assert nwg == B // 2 and int((wl[:, 1] >= 0).sum()) == B // 2  # the call really ran two jets per workgroup
+    vf = EpicVectorField(g.state, "flows.0.net", g.hp, freqs=g.freqs)
+    ref, eac = _autocast_bar(vf, z, None, mask, steps)
+    e16 = (packed - ref).abs()
+    assert 1e-5 < e16.max() <= 1.5 * eac.max() + 2e-3, (e16.max(), eac.max())
+    assert e16.mean() <= 1.5 * eac.mean() + 1e-4, (e16.mean(), eac.mean())
+    assert torch.all(packed[mask.squeeze(-1) == 0] == 0)
+    # the fixture's own 100-step vector (reference vector field + restated integrator), through the packed bf16 kernel
+    tag = "midpoint_100/"
+    zz, mm, want = g.get(tag + "z"), g.get(tag + "mask"), g.get(tag + "x_end")
+    out = hip_ops.epic_sample_midpoint(lay_p, blob_p, zz.cuda(), None, None if mm is None else mm.float().cuda(), ode_steps=100).cpu()
+    out1 = hip_ops.epic_sample_midpoint(lay_1, blob_1, zz.cuda(), None, None if mm is None else mm.float().cuda(), ode_steps=100).cpu()
+    assert torch.equal(out, out1)
+    assert (out - want).abs().max() < 5e-2
+
+
+@pytest.mark.parametrize("B,steps", [(24, 8), (6, 40)])
+def test_bf16_conditioned_lean_sampler_tracks_the_generic_bf16_kernel(B, steps):
+    """epic_sample_midpoint_fast_kernel<1, false, true> (bf16 operands, conditioned jets: fm_tops*_cond.yaml, 2 + 2 values) against the
+    generic bf16 kernel (PFM_F_GENERIC_SAMPLER), the autocast bar, and the reference's cond_gl midpoint vectors."""
+    from particle_fm_amd import hip_ops
+    from particle_fm_amd.layout import EpicLayout
+    from tests.conftest import load_golden
+    g = load_golden("cond_gl")
+    N, F, C = g.hp["num_particles"], g.hp["features"], g.hp["global_cond_dim"]
+    fast = EpicLayout(cfg_of(g.hp), flags=1 | 2)
+    gen = EpicLayout(cfg_of(g.hp), flags=1 | 2 | 32)
+    from particle_fm_amd import _lib
+    assert _lib.load().pfm_epic_sample_is_fast(ctypes.byref(fast.desc)) == 1
+    assert _lib.load().pfm_epic_sample_is_fast(ctypes.byref(gen.desc)) == 0
+    blob_f = fast.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    blob_g = gen.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    n, mask, z, cond = _ragged(B, N, F, C, seed=41 + B, lo=1)
+    a = hip_ops.epic_sample_midpoint(fast, blob_f, z.cuda(), cond.cuda(), mask.cuda(), ode_steps=steps).cpu()
+    b = hip_ops.epic_sample_midpoint(gen, blob_g, z.cuda(), cond.cuda(), mask.cuda(), ode_steps=steps).cpu()
+    # both round the same operands to bf16; inputs that differ by 1e-7 (tabulated terms) may round to neighbouring bf16 values
+    torch.testing.assert_close(a, b, atol=3e-3, rtol=3e-3)
+    vf = EpicVectorField(g.state, "flows.0.net", g.hp, freqs=g.freqs)
+    ref, eac = _autocast_bar(vf, z, cond, mask, steps)
+    e16 = (a - ref).abs()
+    assert 1e-5 < e16.max() <= 1.5 * eac.max() + 2e-3, (e16.max(), eac.max())
+    assert e16.max() <= 1.5 * (b - ref).abs().max() + 1e-3
+    assert torch.all(a[mask.squeeze(-1) == 0] == 0)
+    assert torch.equal(a, hip_ops.epic_sample_midpoint(fast, blob_f, z.cuda(), cond.cuda(), mask.cuda(), ode_steps=steps).cpu())
+    # a jet's result depends on its own conditioning only
+    cond2 = cond.clone(); cond2[3:] += 1.0
+    a2 = hip_ops.epic_sample_midpoint(fast, blob_f, z.cuda(), cond2.cuda(), mask.cuda(), ode_steps=steps).cpu()
+    assert torch.equal(a2[:3], a[:3]) and not torch.equal(a2[3:], a[3:])
+    for st in (3, 10):
+        tag = f"midpoint_{st}/"
+        out = hip_ops.epic_sample_midpoint(fast, blob_f, g.get(tag + "z").cuda(), g.get(tag + "cond").cuda(),
+                                           None if g.get(tag + "mask") is None else g.get(tag + "mask").float().cuda(), ode_steps=st).cpu()
+        assert (out - g.get(tag + "x_end")).abs().max() < 5e-2
+
+
+@pytest.mark.parametrize("flags", [1 | 16, 1 | 2 | 16], ids=["fp32-packed", "bf16-packed"])
+def test_cfg2_full_size_properties(flags):
+    """BASELINE cfg 2 at its own size -- 1024 jets of the 30-particle model, multiplicities U{10..30}, ode_steps = 100, two jets per
+    workgroup on the 80-row tile (512 paired workgroups = two rounds on 256 CUs; what bench_secondary.py --workload jetnet30 times) --
+    through size-independent properties: a jet's result does not depend on its batch or partner (bitwise, 40 picked jets), masked rows
+    are exactly 0, everything is finite, and the fp32 call agrees with the oracle on a handful of jets."""
+    from particle_fm_amd import hip_ops
+    from particle_fm_amd.layout import EpicLayout
+    from tests.conftest import load_golden
+    g = load_golden("jetnet30")
+    N, F, B = g.hp["num_particles"], g.hp["features"], 1024
+    lay = EpicLayout(cfg_of(g.hp), flags=flags)
+    blob = lay.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    gen = torch.Generator().manual_seed(30 + flags)
+    n = torch.randint(10, N + 1, (B,), generator=gen)
+    mask = (torch.arange(N)[None] < n[:, None]).float().unsqueeze(-1)
+    z = torch.randn(B, N, F, generator=gen)
+    out = hip_ops.epic_sample_midpoint(lay, blob, z.cuda(), None, mask.cuda(), ode_steps=100).cpu()
+    nwg, wl = _pack_list(lay.padded(80), B, 100)
+    assert nwg == B // 2 and sorted(int(v) for v in wl.reshape(-1)) == list(range(B))
+    assert torch.isfinite(out).all()
+    assert torch.all(out[mask.squeeze(-1) == 0] == 0)
+    pick = torch.randperm(B, generator=gen)[:40]
+    sub = hip_ops.epic_sample_midpoint(lay, blob, z[pick].cuda(), None, mask[pick].cuda(), ode_steps=100).cpu()
+    assert torch.equal(sub, out[pick])
+    assert torch.equal(out, hip_ops.epic_sample_midpoint(lay, blob, z.cuda(), None, mask.cuda(), ode_steps=100).cpu())
+    # one jet per workgroup, same operands: the same bits
+    lay1 = EpicLayout(cfg_of(g.hp), flags=flags & ~16)
+    blob1 = lay1.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    few = pick[:8]
+    one = hip_ops.epic_sample_midpoint(lay1, blob1, z[few].cuda(), None, mask[few].cuda(), ode_steps=100).cpu()
+    assert torch.equal(one, out[few])
+    vf = EpicVectorField(g.state, "flows.0.net", g.hp, freqs=g.freqs)
+    ref = sample_midpoint(vf, z[few], None, mask[few], ode_steps=100)
+    if flags & 2:
+        assert (out[few] - ref).abs().max() < 5e-2
+    else:
+        torch.testing.assert_close(out[few], ref, atol=5e-5, rtol=1e-4)
