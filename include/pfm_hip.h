@@ -42,6 +42,11 @@
  *                    W[16*w + (lane&15)][16*kt + 4*(lane>>4) + r], r = 0..3   (w = output slice 0..7).
  *   GRAD_D           (gradient blob only) a 128x128 block in the order of a 16-row-panel accumulator: float ((w*8 + it)*4 + r)*64 + lane
  *                    holds dW[16*w + 4*(lane>>4) + r][8*(lane&15) + it].
+ *   MFMA_A16         the same block rounded to bf16 (round-to-nearest-even), the A operand of v_mfma_f32_16x16x32_bf16 in the kernels'
+ *                    k order: the 16-byte unit ((w*4 + kt2)*64 + lane) holds the MFMA_A float4s of k-tiles 2*kt2 and 2*kt2 + 1 of that
+ *                    (w, lane) as 8 bf16, i.e. W[16*w + (lane&15)][32*kt2 + 16*h + 4*(lane>>4) + r] at bf16 index 4*h + r.  H*H/2 floats.
+ *                    Not gathered from the state_dict: pfm_epic_pack_a16 (device blobs) / layout.finish_blob (host blobs) derive it
+ *                    from MFMA_A; only blobs of PFM_F_BF16_MFMA descriptors carry it (zeros otherwise).  Read by the lean bf16 sampler.
  *   MFMA_AT          the same block transposed (used by the backward dX products):
  *                    float4 at ((w*8 + kt)*64 + lane) holds W[16*kt + 4*(lane>>4) + r][16*w + (lane&15)].
  * The blob carries a copy of the descriptor in its tail: element blob[desc.blob_floats] starts
@@ -61,7 +66,7 @@
 extern "C" {
 #endif
 
-/* 2 (round 3): pfm_epic_fm_loss_backward / pfm_epic_diffusion_loss_backward take a `scratch` pointer in front of `stream` and WRITE
+/* 2 (round 3): pfm_local_lin.A16 / pfm_epic_desc.l3_A16 (bf16 copies of the particle blocks in the blob); pfm_epic_fm_loss_backward / pfm_epic_diffusion_loss_backward take a `scratch` pointer in front of `stream` and WRITE
  * grad_blob (round 2 changed both under version 1: a caller or a stale library built against that header must be refused) */
 #define PFM_ABI_VERSION 2
 #define PFM_MAX_LAYERS 24
@@ -90,6 +95,7 @@ typedef struct pfm_local_lin {
     int64_t AT; /* MFMA_AT block, H*H floats (or -1 if the blob carries no backward copies) */
     int64_t We; /* KM16 [Ke][H] extras block */
     int64_t b;  /* [H] bias */
+    int64_t A16; /* MFMA_A16 block, H*H/2 floats */
 } pfm_local_lin;
 
 typedef struct pfm_dense_lin {
@@ -131,12 +137,17 @@ typedef struct pfm_epic_desc {
     int64_t l3_b;        /* [F] */
     int64_t l3_A;        /* fc_l3 particle block as ONE 16-row MFMA_A panel: float4 at (kt*64 + lane) holds
                             W3[lane&15][16*kt + 4*(lane>>4) + r] (rows >= F are zero), 2048 floats */
+    int64_t l3_A16;      /* the same panel as MFMA_A16 (one output slice), 1024 floats */
 } pfm_epic_desc;
 
 #define PFM_DESC_FLOATS ((int64_t)((sizeof(pfm_epic_desc) + 15) / 16 * 4))
 
 int pfm_abi_version(void);
 const char *pfm_last_error(void);
+
+/* Fills the MFMA_A16 blocks of a DEVICE blob from its MFMA_A blocks (one launch on `stream`); a no-op for descriptors without
+ * PFM_F_BF16_MFMA.  Whoever writes the fp32 blocks of a bf16 model's blob (the gather of layout.py, pfm_wn_pack) calls it afterwards. */
+int pfm_epic_pack_a16(const pfm_epic_desc *desc, float *blob, void *stream);
 
 /* bytes of LDS one workgroup (= one jet) needs in the inference / loss-forward kernels and in the backward kernel; > 163840
  * (or n_points > 160) means PFM_E_LDS: such sets run on the row-matrix path of pfm_epicw.h (the host side picks it by these) */

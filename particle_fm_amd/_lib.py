@@ -22,6 +22,7 @@ _lib = None
 _fp = c_void_p  # device pointers travel as integers (tensor.data_ptr())
 SYMBOLS = {
     "pfm_abi_version": (c_int, []),
+    "pfm_epic_pack_a16": (c_int, [POINTER(EpicDesc), c_void_p, c_void_p]),
     "pfm_last_error": (c_char_p, []),
     "pfm_epic_lds_bytes": (c_int64, [POINTER(EpicDesc)]),
     "pfm_epic_backward_lds_bytes": (c_int64, [POINTER(EpicDesc)]),

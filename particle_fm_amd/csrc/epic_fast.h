@@ -249,9 +249,10 @@ __device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __rest
 // fc_l3 head with its per-jet bias from the table and its weights already in registers (requested during the last particle
 // phase).  emit(p, f, lrelu(b3[f] + W3[f].x[p]) * mask[p]) for the rows p < n_rows ONLY: the sampler's state rows behind a jet's
 // last valid particle start as z * mask = 0 and an update by 0 would leave them there.  epic.py:387-391
-template <typename Emit>
+// AF == 4: the panel's MFMA_A16 copy on the bf16 pipe (four v_mfma_f32_16x16x32_bf16 per tile)
+template <int AF, typename Emit>
 __device__ __forceinline__ void fast_head(const JetDims& j, float* __restrict__ lds, const Carve& c, int n_rows,
-                                          const f32x4 (&a)[8], f32x4 b3, Emit emit) {
+                                          const f32x4 (&a)[AF], f32x4 b3, Emit emit) {
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int pl = lane & 15, q = lane >> 4;
     const float* bufB = lds + c.bufB;
@@ -267,16 +268,24 @@ __device__ __forceinline__ void fast_head(const JetDims& j, float* __restrict__ 
         for (int kt = 0; kt < 8; ++kt) b[kt] = *reinterpret_cast<const f32x4*>(s0 + koff[kt]);
         // two accumulator chains over the K halves (a dependent fp32 MFMA waits 40 cycles, the pipe issues one every 32)
         f32x4 acc0 = b3, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (AF == 4) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].x, b[kt].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 4].x, b[kt + 4].x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].y, b[kt].y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 4].y, b[kt + 4].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].z, b[kt].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 4].z, b[kt + 4].z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].w, b[kt].w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 4].w, b[kt + 4].w, acc1, 0, 0, 0);
+            for (int kt2 = 0; kt2 < 2; ++kt2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[kt2]), pack_bf16x8(b[2 * kt2], b[2 * kt2 + 1]), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[kt2 + 2]), pack_bf16x8(b[2 * kt2 + 4], b[2 * kt2 + 5]), acc1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].x, b[kt].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 4].x, b[kt + 4].x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].y, b[kt].y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 4].y, b[kt + 4].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].z, b[kt].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 4].z, b[kt + 4].z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].w, b[kt].w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt + 4].w, b[kt + 4].w, acc1, 0, 0, 0);
+            }
         }
         acc0 += acc1;
         if (p < n_rows) {
@@ -300,16 +309,30 @@ __device__ __forceinline__ void fast_cond_zero(const JetDims& j, float* __restri
 }
 
 // What an evaluation carries over from the one before it (requested behind that one's last particle phase / during its head):
+// BF16: the A operands are MFMA_A16 fragments (4 float4 registers of bf16 instead of 8 of fp32: half the weight stream of the particle
+// Linears and 32 VGPRs fewer -- with fp32 fragments rounded in the kernel the bf16 instantiations spilled 52-84 bytes per lane)
+template <bool BF16>
 struct FastCarry {
-    f32x4 a1[8], a2[8];  // a2: fc_l2's weights on entry; a1: scratch (phase-1 weights, then the head's)
-    f32x4 sj1;           // this lane's slice of fc_l1's per-jet bias for the coming evaluation
-    float aw;            // this lane's element of fc_l1's A operand (constant over the call)
+    static constexpr int AF = BF16 ? 4 : 8;
+    f32x4 a1[AF], a2[AF];  // a2: fc_l2's weights on entry; a1: scratch (phase-1 weights, then the head's)
+    f32x4 sj1;             // this lane's slice of fc_l1's per-jet bias for the coming evaluation
+    float aw;              // this lane's element of fc_l1's A operand (constant over the call)
 };
+template <bool BF16>
+__device__ __forceinline__ void load_afrag_lin(f32x4 (&a)[BF16 ? 4 : 8], blob_rsrc rs, const pfm_local_lin& l, int w, int lane) {
+    if constexpr (BF16) load_afrag16(a, rs, l.A16, w, lane);
+    else load_afrag(a, rs, l.A, w, lane);
+}
+template <bool BF16>
+__device__ __forceinline__ PfSeg seg_afrag_lin(const pfm_local_lin& l, int w, int lane) {
+    return BF16 ? seg_afrag16(l.A16, w, lane) : seg_afrag(l.A, w, lane);
+}
 // ctS (conditioned jets): the stem slot of the jet's cond table, or nullptr
-__device__ __forceinline__ void fast_carry_request(FastCarry& cy, const pfm_epic_desc& d, blob_rsrc rs, const float* __restrict__ tbS_next,
+template <bool BF16>
+__device__ __forceinline__ void fast_carry_request(FastCarry<BF16>& cy, const pfm_epic_desc& d, blob_rsrc rs, const float* __restrict__ tbS_next,
                                                    const float* __restrict__ ctS = nullptr) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    load_afrag(cy.a2, rs, d.l2.A, w, lane);
+    load_afrag_lin<BF16>(cy.a2, rs, d.l2, w, lane);
     cy.sj1 = *reinterpret_cast<const f32x4*>(tbS_next + TB_SJ1 + 4 * (4 * w + (lane >> 4)));
     if (ctS) cy.sj1 += *reinterpret_cast<const f32x4*>(ctS + TB_SJ1 + 4 * (4 * w + (lane >> 4)));
 }
@@ -322,10 +345,11 @@ __device__ __forceinline__ void fast_carry_request(FastCarry& cy, const pfm_epic
 template <bool BF16, int NSEG, bool COND, typename Emit>
 __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims& j, const float* __restrict__ blob,
                                           float* __restrict__ lds, const Carve& c, int n_rows, const float* __restrict__ tbE,
-                                          const float* __restrict__ tbE_next, FastCarry& cy, Emit emit, const Segs* sg = nullptr,
+                                          const float* __restrict__ tbE_next, FastCarry<BF16>& cy, Emit emit, const Segs* sg = nullptr,
                                           const float* __restrict__ ct = nullptr) {
     static_assert(!(COND && NSEG != 1), "conditioned jets: one jet per workgroup");
     constexpr int NGL = COND ? FNGC : FNG, NGLS = COND ? FNGS + 1 : FNGS;
+    constexpr int AF = FastCarry<BF16>::AF;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const SegView sv[2] = {seg_view(c, j.N, 0), seg_view(c, j.N, NSEG == 2 ? 1 : 0)};
     Seg2Phase s2p, s2t;  // the second jet as a phase with an LDS bias (bj1) / with a table bias sees it
@@ -373,7 +397,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
             // the first layer's windows, phase-1 weights and chain loads: no particle phase to ride on; they land behind the rest of the stem chain
             Prefetch<NGL, 1> pf{rs, gl, wbA, nullptr, nullptr, seg_panels(l0.gl1.W, FTP, tid), seg_panels(l0.lc1.We, FTP, tid), {}, {}};
             pf.template issue_range<0, NGL + 1>();
-            load_afrag(cy.a1, rs, l0.lc1.A, w, lane);
+            load_afrag_lin<BF16>(cy.a1, rs, l0.lc1, w, lane);
             L0 = fast_chain_loads(rs, l0.gl2.W, w2r0, tbE, TB_G1, TB_L1, TB_G2, COND ? ct : nullptr, TB_L2);
         }, [&]() { fast_chain_publish(L0, tbl); });
         L = L0;
@@ -391,7 +415,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         // phase 1: bufA = lrelu(W1 . bufB + bj1)   epic.py:194-196.  Riders: phase 2's weights and ALL per-jet windows of the next
         // layer (gl / wbA were consumed by the chain above), so that nothing the next chain waits for is requested late
         {
-            Prefetch<8, NGL, 1> pf{rs, cy.a2, gl, wbA, nullptr, seg_afrag(ly.lc2.A, w, lane), seg_panels(nx.gl1.W, FTP, tid),
+            Prefetch<AF, NGL, 1> pf{rs, cy.a2, gl, wbA, nullptr, seg_afrag_lin<BF16>(ly.lc2, w, lane), seg_panels(nx.gl1.W, FTP, tid),
                                    seg_panels(nx.lc1.We, FTP, tid), {}};
             gemm_phase<false, false, false, BF16, decltype(pf), NSEG>(cy.a1, bufB, bufA, nullptr, lds + c.bj1, maskf, j, lds, c, nullptr,
                                                                        nullptr, n_rows, pf, s2p);
@@ -408,8 +432,8 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         // (bj2 = bias + time term: constant per evaluation and layer, read from the table; conditioned jets: + the jet's term, from
         // c.bj2).  Riders: the next layer's phase-1 weights, or the head's one 16-row panel behind the last layer, into a1 (free since phase 1)
         {
-            const PfSeg sa = last ? PfSeg{d.l3_A, 256, lane * 16} : seg_afrag(nx.lc1.A, w, lane);
-            Prefetch<8> pf{rs, cy.a1, nullptr, nullptr, nullptr, sa, {}, {}, {}};
+            const PfSeg sa = last ? PfSeg{BF16 ? d.l3_A16 : d.l3_A, 256, lane * 16} : seg_afrag_lin<BF16>(nx.lc1, w, lane);
+            Prefetch<AF> pf{rs, cy.a1, nullptr, nullptr, nullptr, sa, {}, {}, {}};
             const float* bj = (COND || L2LDS) ? lds + c.bj2 : tbK + TB_L2;
             s2t.bj = bj;
             gemm_phase<true, true, false, BF16, decltype(pf), NSEG, false>(cy.a2, bufA, bufB, bufB, bj, maskf, j, lds, c, nullptr, nullptr, n_rows,
@@ -423,7 +447,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     }
     PFM_STAMP(20);
     fast_carry_request(cy, d, rs, tbE_next + (size_t)j.layers * TB_SLOT, ctS);  // lands behind the head
-    fast_head(j, lds, c, n_rows, cy.a1, b3, emit);
+    fast_head<AF>(j, lds, c, n_rows, cy.a1, b3, emit);
 }
 
 }  // namespace pfm

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
     const int F = j.F;
     const size_t estride = (size_t)(j.layers + 1) * TB_SLOT;
     const int n_evals = 2 * n_intervals;
-    FastCarry cy;
+    FastCarry<MODE == 1> cy;
     cy.aw = fast_l1_weight(d0, j, blob);
     if constexpr (PAIRS) if (jetB >= 0) {
         // ---- two jets: rows [0, n0) = jet A, [r1, r1 + n1) = jet B (epic_pair_setup), one weight stream and one set of phases ----
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_rk_fast_kernel(
     float* kj = kbuf + (size_t)jet * S * NF;
     const size_t estride = (size_t)(j.layers + 1) * TB_SLOT;
     const int n_evals = S * n_intervals;
-    FastCarry cy;
+    FastCarry<MODE == 1> cy;
     cy.aw = fast_l1_weight(d0, j, blob);
     fast_carry_request(cy, d0, make_blob_rsrc(blob, d0.blob_floats + PFM_DESC_FLOATS), table + (size_t)j.layers * TB_SLOT);
     int st = 0;
@@ -659,6 +659,27 @@ __global__ __launch_bounds__(1024) void epic_jet_pack_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA_A16 blocks of a blob from its MFMA_A blocks (pfm_hip.h): thread (block b, w, kt2, lane) rounds the two float4s of k-tiles
+// 2 kt2, 2 kt2 + 1 to bf16 (round-to-nearest-even) and stores them as one 16-byte unit.  grid (2 layers + 2): the particle blocks of
+// fc_l2, of every layer's two local Linears, and the head's one-slice panel; 512 threads.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void epic_a16_pack_kernel(float* __restrict__ blob, int64_t desc_off) {
+    const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
+    const int b = blockIdx.x, nl = 2 * d.layers + 1;
+    int64_t A, A16;
+    int nw = 8;
+    if (b == 0) { A = d.l2.A; A16 = d.l2.A16; }
+    else if (b < nl) { const pfm_epic_layer& ly = d.layer[(b - 1) >> 1]; A = (b & 1) ? ly.lc1.A : ly.lc2.A; A16 = (b & 1) ? ly.lc1.A16 : ly.lc2.A16; }
+    else { A = d.l3_A; A16 = d.l3_A16; nw = 1; }
+    for (int u = threadIdx.x; u < nw * 4 * 64; u += NT) {  // u = (w * 4 + kt2) * 64 + lane
+        const int lane = u & 63, wk = u >> 6, w = wk >> 2, kt2 = wk & 3;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(blob + A + ((int64_t)((w * 8 + 2 * kt2) * 64 + lane)) * 4);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(blob + A + ((int64_t)((w * 8 + 2 * kt2 + 1) * 64 + lane)) * 4);
+        *reinterpret_cast<bf16x8*>(blob + A16 + (int64_t)u * 4) = pack_bf16x8(lo, hi);
+    }
+}
+
 // which matrix-pipe flavour the inference kernels use (descriptor flags): 0 fp32, 1 bf16 operands, 2 split fp16
 int mfma_mode(const pfm_epic_desc* d) {
     if (!d) return 0;
@@ -684,6 +705,16 @@ extern "C" {
 
 int pfm_abi_version(void) { return PFM_ABI_VERSION; }
 const char* pfm_last_error(void) { return g_err; }
+
+int pfm_epic_pack_a16(const pfm_epic_desc* d, float* blob, void* stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    if (!(d->flags & PFM_F_BF16_MFMA)) return 0;
+    if (!blob) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (d->l2.A16 <= 0 || d->l3_A16 <= 0) return set_err(PFM_E_BADARG, "descriptor without MFMA_A16 offsets");
+    hipLaunchKernelGGL(epic_a16_pack_kernel, dim3(2 * d->layers + 2), dim3(NT), 0, (hipStream_t)stream, blob, d->blob_floats);
+    return check_hip(hipGetLastError(), "epic_a16_pack_kernel launch");
+}
 
 int64_t pfm_epic_lds_bytes(const pfm_epic_desc* d) {
     if (!d) return -1;

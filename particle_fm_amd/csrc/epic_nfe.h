@@ -98,6 +98,22 @@ __device__ __forceinline__ s16x4 pack_bf16(f32x4 v) {
     return __builtin_bit_cast(s16x4, u);
 }
 
+// gfx950's v_mfma_f32_16x16x32_bf16 contracts 32 k per instruction (lane (i, q) holds 8 of them) in 16 cycles.  The two float4
+// a lane holds for k-tiles 2 kt2 and 2 kt2 + 1 -- k = 32 kt2 + 16 h + 4 q + r -- are, rounded and concatenated, a valid operand: the
+// instruction sums over its 32 k slots whatever their order, as long as A and B use the same one.  One MFMA replaces eight fp32 ones.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 pack_bf16x8(f32x4 lo, f32x4 hi) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x4 a = pack_bf16(lo), b = pack_bf16(hi);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// A operand of one 128x128 block for this wave from its MFMA_A16 copy (pfm_hip.h): 4 x 16 bytes = 16 VGPRs, already bf16
+__device__ __forceinline__ void load_afrag16(f32x4 (&a)[4], blob_rsrc rs, int64_t A16_off, int w, int lane) {
+    const int lb = ((w * 4) * 64 + lane) * 16;
+#pragma unroll
+    for (int kt2 = 0; kt2 < 4; ++kt2) a[kt2] = bload4(rs, A16_off + kt2 * 256, lb);
+}
+
 // ---- split-fp16 operands (PFM_F_F16X3_MFMA): fp32-accurate products on the fp16 matrix pipe -----------------------
 // x = hi + lo * 2^-11 with hi = fp16(x), lo = fp16((x - hi) * 2^11)  (22 significant bits); then
 //   x . w  =  hi.whi  +  2^-11 (hi.wlo + lo.whi)  +  O(2^-22),
@@ -197,6 +213,7 @@ struct Prefetch {
 using PfNone = Prefetch<0>;
 // segment of an A-fragment load (load_afrag) / of a run of KM16 GEMV panels (gemv4_load) / of this thread's fc_global2 rows
 __device__ __forceinline__ PfSeg seg_afrag(int64_t A_off, int w, int lane) { return PfSeg{A_off, 256, ((w * 8) * 64 + lane) * 16}; }
+__device__ __forceinline__ PfSeg seg_afrag16(int64_t A16_off, int w, int lane) { return PfSeg{A16_off, 256, ((w * 4) * 64 + lane) * 16}; }
 __device__ __forceinline__ PfSeg seg_panels(int64_t W_off, int first_panel, int tid) {
     return PfSeg{W_off + (int64_t)first_panel * (NT * 4), NT * 4, tid * 16};
 }
@@ -219,13 +236,15 @@ __device__ __forceinline__ int phase_full_pairs(int n_rows) {
 }
 // TAIL = false: the caller issues pf.issue_tail(phase_full_pairs<BF16>(n_rows)) itself (behind work of its own that must not wait for
 // those loads: a vmcnt wait covers every load issued before it)
-template <bool RESID, bool POOL, bool SAVE, bool BF16 = false, typename PF = PfNone, int NSEG = 1, bool TAIL = true>
-__device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __restrict__ src,
+// AF: float4 registers of the A operand: 8 (fp32 MFMA_A fragment; BF16: rounded here) or, BF16 only, 4 (an MFMA_A16 fragment)
+template <bool RESID, bool POOL, bool SAVE, bool BF16 = false, typename PF = PfNone, int NSEG = 1, bool TAIL = true, int AF = 8>
+__device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __restrict__ src,
                                            float* __restrict__ dst, const float* __restrict__ resid,
                                            const float* __restrict__ bj, const float* __restrict__ maskf,
                                            const JetDims& j, float* __restrict__ lds, const Carve& c,
                                            float* __restrict__ save, float* __restrict__ save_pool, int n_rows,
                                            const PF& pf = PF{}, const Seg2Phase& s2 = Seg2Phase{}) {
+    static_assert(AF == 8 || (BF16 && AF == 4), "A operand: 8 fp32 float4s, or 4 pre-packed bf16 ones for the bf16 pipe");
     const int tid_ = launder(threadIdx.x);
     const int lane = tid_ & 63, w = tid_ >> 6;
     const int pl = lane & 15, q = lane >> 4;
@@ -253,27 +272,33 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[8], const float* __r
         B0[kk] = *reinterpret_cast<const f32x4*>((base) + koff[2 * (qq) + kk]);            \
         B1[kk] = *reinterpret_cast<const f32x4*>((base) + TILE * H + koff[2 * (qq) + kk]); \
     }
-    s16x4 ab[8];
-    if (BF16) {
+    // bf16 pipe: one v_mfma_f32_16x16x32_bf16 per tile and K-quarter (32 k: the two float4s of the quarter, see pack_bf16x8)
+    bf16x8 ab[4];
+    if constexpr (BF16) {
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) ab[kt] = pack_bf16(a[kt]);
+        for (int kt2 = 0; kt2 < 4; ++kt2) {
+            if constexpr (AF == 4) ab[kt2] = __builtin_bit_cast(bf16x8, a[kt2]);
+            else ab[kt2] = pack_bf16x8(a[2 * kt2], a[2 * kt2 + 1]);
+        }
     }
 #define PFM_MFMAQ(B0, B1, qq)                                                                                  \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                        \
-        if (BF16) {                                                                                            \
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[2 * (qq) + kk], pack_bf16(B0[kk]), acc0, 0, 0, 0); \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[2 * (qq) + kk], pack_bf16(B1[kk]), acc1, 0, 0, 0); \
-        } else {                                                                                               \
+    if constexpr (BF16) {                                                                                      \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[(qq)], pack_bf16x8(B0[0], B0[1]), acc0, 0, 0, 0);    \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[(qq)], pack_bf16x8(B1[0], B1[1]), acc1, 0, 0, 0);    \
+    } else {                                                                                                   \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                    \
             PFM_MFMA_PAIR(acc0, acc1, a[2 * (qq) + kk], B0[kk], B1[kk]);                                        \
         }                                                                                                      \
     }
-    // the last pair of a jet whose tile count is odd holds one real tile: only that tile's MFMAs are issued
+    // the last pair of a jet whose tile count is odd holds one real tile: only that tile's MFMAs are issued (fp32 pipe only)
 #define PFM_MFMAQ1(B0, B1, qq)                                                                                 \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                         \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].x, B0[kk].x, acc0, 0, 0, 0);              \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].y, B0[kk].y, acc0, 0, 0, 0);              \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].z, B0[kk].z, acc0, 0, 0, 0);              \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].w, B0[kk].w, acc0, 0, 0, 0);              \
+    if constexpr (!BF16) {                                                                                     \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                     \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].x, B0[kk].x, acc0, 0, 0, 0);          \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].y, B0[kk].y, acc0, 0, 0, 0);          \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].z, B0[kk].z, acc0, 0, 0, 0);          \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].w, B0[kk].w, acc0, 0, 0, 0);          \
+        }                                                                                                      \
     }
     PFM_LOADQ(X0, X1, src, 0);
     if (RESID) {

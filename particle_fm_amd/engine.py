@@ -197,7 +197,7 @@ class FusedFMTrainer:
         _lib.check(_lib.load().pfm_wn_pack(P(self.fp.flat), P(tb.rows), tb.n_rows, P(tb.dst1), P(tb.dst2),
                                            P(tb.bias_param), P(tb.bias_blob), tb.n_bias, P(st["blob"]),
                                            hip_ops._stream_ptr(self.fp.flat.device)), "pfm_wn_pack")
-        return st["blob"]
+        return st["layout"].finish_blob(st["blob"])  # bf16 layouts: + the MFMA_A16 copies (one more launch)
 
     def packed_blob(self, n_points: int):
         """The kernel blob for the CURRENT flat parameters (weight-norm pack kernel); None if the parameters no
@@ -217,7 +217,7 @@ class FusedFMTrainer:
         _lib.check(_lib.load().pfm_wn_pack(P(self.fp.flat), P(tb.rows), tb.n_rows, P(tb.dst1), P(tb.dst2),
                                            P(tb.bias_param), P(tb.bias_blob), tb.n_bias, P(out),
                                            hip_ops._stream_ptr(self.fp.flat.device)), "pfm_wn_pack")
-        return out
+        return st["layout"].finish_blob(out)
 
     def fused_loss_and_grad(self, x, mask, cond) -> torch.Tensor:
         """pack -> loss forward -> backward -> d(weight_g, weight_v, bias) accumulated into the flat gradient;

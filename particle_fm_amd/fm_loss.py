@@ -39,7 +39,7 @@ class _Maps:
 
 def pack_blob_from_source(layout: EpicLayout, src: torch.Tensor) -> torch.Tensor:
     imap, _, tail = _Maps.get(layout, src.device)
-    return torch.cat([src.detach()[imap], tail])
+    return layout.finish_blob(torch.cat([src.detach()[imap], tail]))  # + the bf16 copies of the particle blocks, if the layout wants them
 
 
 class EpicFMLossFn(torch.autograd.Function):

@@ -35,7 +35,7 @@ PFM_F_GENERIC_SAMPLER = 32  # keep the generic sampler kernel where the lean eva
 
 
 class LocalLin(ctypes.Structure):
-    _fields_ = [("A", ctypes.c_int64), ("AT", ctypes.c_int64), ("We", ctypes.c_int64), ("b", ctypes.c_int64)]
+    _fields_ = [("A", ctypes.c_int64), ("AT", ctypes.c_int64), ("We", ctypes.c_int64), ("b", ctypes.c_int64), ("A16", ctypes.c_int64)]
 
 
 class DenseLin(ctypes.Structure):
@@ -75,6 +75,7 @@ class EpicDesc(ctypes.Structure):
         ("l3_We", ctypes.c_int64),
         ("l3_b", ctypes.c_int64),
         ("l3_A", ctypes.c_int64),
+        ("l3_A16", ctypes.c_int64),
     ]
 
 
@@ -269,7 +270,11 @@ class EpicLayout:
         ll = LocalLin()
         ll.A = self._mfma_a(name, xc0, False)
         ll.AT = self._mfma_a(name, xc0, True) if self.with_backward else -1
+        # bf16 copy of the A block (MFMA_A16, include/pfm_hip.h): not part of the gather map -- filled from the fp32 block by
+        # finish_blob() / pfm_epic_pack_a16 when the descriptor asks for bf16 operands
+        ll.A16 = self._alloc(PFM_HIDDEN * PFM_HIDDEN // 2)
         self._local_blocks.append((name, xc0, int(ll.A), int(ll.AT)))
+        self._a16_blocks.append((int(ll.A), int(ll.A16), 8))
         ll.We = self._kmajor(name, list(tcols) + list(ccols) + list(gcols))
         ll.b = self._bias(name)
         return ll
@@ -282,6 +287,7 @@ class EpicLayout:
         self._cursor = 0
         self._segments: List[Tuple[int, np.ndarray]] = []
         self._local_blocks: List[Tuple[str, int, int, int]] = []
+        self._a16_blocks: List[Tuple[int, int, int]] = []  # (fp32 MFMA_A offset, MFMA_A16 offset, output slices w)
         d = EpicDesc()
         d.abi_version = PFM_ABI_VERSION
         d.n_points, d.features, d.hidden, d.latent, d.layers = cfg.num_particles, F, H, L, cfg.layers
@@ -343,6 +349,8 @@ class EpicLayout:
         idx = np.where(f < F, idx, self.zero_off)
         d.l3_A = self._alloc(2048)
         self._put(d.l3_A, idx)
+        d.l3_A16 = self._alloc(1024)
+        self._a16_blocks.append((int(d.l3_A), int(d.l3_A16), 1))
         d.blob_floats = self._cursor
         index_map = np.full(self._cursor, self.zero_off, dtype=np.int64)
         for off, flat in self._segments:
@@ -447,4 +455,24 @@ class EpicLayout:
         src = self.source_vector(state, prefix, freqs)
         if index_map is None:
             index_map = torch.from_numpy(self.index_map).to(src.device)
-        return torch.cat([src[index_map], self.desc_tail().to(src.device)])
+        return self.finish_blob(torch.cat([src[index_map], self.desc_tail().to(src.device)]))
+
+    def finish_blob(self, blob: torch.Tensor) -> torch.Tensor:
+        """What a freshly gathered blob still lacks: the bf16 copies of the 128x128 particle blocks (MFMA_A16) that the lean bf16
+        sampler streams instead of the fp32 ones.  Only blobs of bf16 descriptors (PFM_F_BF16_MFMA) carry them -- the region is zero
+        otherwise.  In place; a device blob is converted by one launch (pfm_epic_pack_a16 on the current stream), a host blob here.
+        Rounding: round-to-nearest-even, what v_cvt_pk_bf16_f32 does to the same value in the kernels that convert on the fly."""
+        if not (int(self.desc.flags) & PFM_F_BF16_MFMA):
+            return blob
+        if blob.is_cuda:
+            from . import _lib
+            rc = _lib.load().pfm_epic_pack_a16(ctypes.byref(self.desc), ctypes.c_void_p(blob.data_ptr()),
+                                               ctypes.c_void_p(torch.cuda.current_stream(blob.device).cuda_stream))
+            _lib.check(rc, "pfm_epic_pack_a16")
+            return blob
+        with torch.no_grad():
+            for offA, off16, nw in self._a16_blocks:
+                a = blob[offA: offA + nw * 2048].detach().reshape(nw, 4, 2, 64, 4)   # [w][kt2][h][lane][r]
+                a16 = a.permute(0, 1, 3, 2, 4).contiguous().to(torch.bfloat16)      # [w][kt2][lane][h][r]: 8 bf16 = one 16-byte unit
+                blob[off16: off16 + nw * 1024] = a16.reshape(-1, 2).view(torch.float32).reshape(-1)
+        return blob
