@@ -81,13 +81,18 @@ extern "C" {
                                workgroup -- rows one behind the other in the LDS tile, ONE weight stream and ONE set of phases for both
                                (the k-th longest jet takes the shortest remaining one if pad16(rows A) + rows B fit).  Same results
                                bit for bit; pays off for large batches of short jets, see DESIGN.md */
+#define PFM_F_QUAD_JETS 64u /* pfm_epic_sample_midpoint with PFM_F_PACK_JETS on a descriptor of n_points = 128 (unconditioned jets, a mask, fp32 / bf16
+                                operands): FOUR jets per workgroup in fixed 32-row slots.  The caller states that every jet's valid particles lie
+                                in its first 32 rows -- particles behind row 32 are IGNORED (treated as masked) and come back as 0.  The host
+                                side sets it when it pads a batch of sets of <= 32 particles to the 128-row tile (hip_ops.packed_tile_rows).
+                                Same results bit for bit as one jet per workgroup */
 #define PFM_F_F16X3_MFMA 4u /* inference kernels only: the particle Linears as three v_mfma_f32_16x16x16_f16 on (hi, lo) fp16 splits of
                                both operands -- fp32-grade products (error 2^-22) at 2.7x less matrix-pipe time; needs |x| < 65504 */
 #define PFM_F_TEMB_SINCOS 8u /* t_emb="sincos" (flow_matching_module.py:208-211): temb = [cos(f t) ; sin(f t)], freqs table = [f ; f],
                                f = 2^k pi; default: t_emb="cosine" (time_emb.py:79-96) */
 #define PFM_F_GENERIC_SAMPLER 32u /* pfm_epic_sample_midpoint: keep the generic kernel where the lean evaluation (csrc/epic_fast.h: unconditioned
                                      jets, T = 32, F <= 4) would run; results differ by fp32 re-association only */
-#define PFM_F_BF16_MFMA 2u /* inference kernels, loss forward and the dX products of the backward: the 128x128 particle Linears run on v_mfma_f32_16x16x16_bf16 (operands
+#define PFM_F_BF16_MFMA 2u /* inference kernels, loss forward and the dX products of the backward: the 128x128 particle Linears run on v_mfma_f32_16x16x32_bf16 (operands
                               rounded to bf16 on the fly, fp32 accumulate, fp32 activations); everything else stays fp32 */
 
 typedef struct pfm_local_lin {

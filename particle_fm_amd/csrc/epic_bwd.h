@@ -80,7 +80,7 @@ __device__ __forceinline__ f32x4 colsum16(f32x4 v) { return row_sum16(v); }
 //   acc[r] = sum_k AT-block[16w + 4q + r][k] * src[p][k]        (a = MFMA_AT fragments of this wave)
 // pre(p, oslot) fetches what the epilogue needs from global memory (the saved activation whose sign gates the gradient): it is
 // called BEFORE the pair's 64 MFMAs so that the load flies behind them (in the epilogue it would be a bare L2 round trip per pair).
-// BF16: both operands rounded to bf16 on the fly (v_mfma_f32_16x16x16_bf16, fp32 accumulate), as the forward does under
+// BF16: both operands rounded to bf16 on the fly (v_mfma_f32_16x16x32_bf16, fp32 accumulate), as the forward does under
 // PFM_F_BF16_MFMA -- what Lightning's precision="bf16-mixed" (autocast around the same modules) means for these products.
 template <bool BF16 = false, typename Pre, typename Epi>
 __device__ __forceinline__ void gemm_dx(const f32x4 (&a)[8], const float* __restrict__ src, int n_rows, Pre pre, Epi epi) {
@@ -98,13 +98,16 @@ __device__ __forceinline__ void gemm_dx(const f32x4 (&a)[8], const float* __rest
         }
         const f32x4 x0 = pre(pc0, oslot), x1 = pre(pc1, oslot);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF16) {  // v_mfma_f32_16x16x32_bf16: 32 k in the cycles the 16x16x16 form takes for 16 (measured on gfx950)
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-            if (BF16) {
-                const s16x4 ab = pack_bf16(a[kt]);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, pack_bf16(b0[kt]), acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, pack_bf16(b1[kt]), acc1, 0, 0, 0);
-            } else {
+            for (int kt2 = 0; kt2 < 4; ++kt2) {
+                const bf16x8 ab = pack_bf16x8(a[2 * kt2], a[2 * kt2 + 1]);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, pack_bf16x8(b0[2 * kt2], b0[2 * kt2 + 1]), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, pack_bf16x8(b1[2 * kt2], b1[2 * kt2 + 1]), acc1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
                 PFM_MFMA_PAIR(acc0, acc1, a[kt], b0[kt], b1[kt]);
             }
         }

@@ -51,6 +51,28 @@ __host__ __device__ inline bool fast_path_ok(const pfm_epic_desc& d) {
            ((int64_t)make_carve(d.n_points, d.features).total + 288) * 4 <= 163840;  // + TBL_FLOATS behind the carve
 }
 
+// ---- FOUR short jets per workgroup (quad mode; PFM_F_QUAD_JETS on a 128-row descriptor, unconditioned jets) -------------------------
+// A jet of <= 32 particles is all fixed cost (two 16-row tiles against ~2 MB of weights per evaluation and seven serial per-jet chains),
+// and even the packed pair leaves a 1024-jet batch at two rounds of 512 workgroups.  Quad mode gives every jet a fixed 32-row slot --
+// jet s owns rows [32 s, 32 s + 32) = tile pair s of every particle phase -- so the pair bodies know their jet at compile time (bias,
+// pool sum: gemm_phase<.., NSEG = 4>, epic_nfe.h), nothing is predicated (rows behind a jet's last particle are holes: zero input,
+// zero mask, finite, never pooled) and the chains run for the four jets from ONE set of weight registers.  The per-jet vectors of jets
+// 1..3 live behind the carve and the chain's table rows.  Same arithmetic per row and per jet as one jet per workgroup: same bits.
+constexpr int QROWS = 32, QJETS = 4;
+constexpr int QV_VIN = 0, QV_VIN2 = QV_VIN + VIN_FLOATS, QV_BJ1 = QV_VIN2 + VIN2_FLOATS, QV_GCOPY = QV_BJ1 + H, QV_G2P = QV_GCOPY + NW * MAXL,
+              QV_MISC = QV_G2P + NW * MAXL, QV_FLOATS = QV_MISC + 8;
+constexpr int QUAD_TILE_ROWS = QROWS * QJETS;  // desc.n_points of a quad call
+__host__ __device__ inline int quad_lds_floats(int F) { return make_carve(QUAD_TILE_ROWS, F).total + 288 + (QJETS - 1) * QV_FLOATS; }
+__host__ __device__ inline SegView quad_view(const Carve& c, int s) {
+    if (s == 0) return SegView{c.vin, c.vin2, c.bj1, c.bj2, c.gcopy, c.g2p, c.misc, c.maskf};
+    const int b = c.total + 288 + (s - 1) * QV_FLOATS;  // behind TBL_FLOATS
+    return SegView{b + QV_VIN, b + QV_VIN2, b + QV_BJ1, c.bj2, b + QV_GCOPY, b + QV_G2P, b + QV_MISC, c.maskf};
+}
+__host__ __device__ inline bool quad_path_ok(const pfm_epic_desc& d) {
+    return (d.flags & PFM_F_QUAD_JETS) && d.n_points == QUAD_TILE_ROWS && d.cond_global == 0 && fast_path_ok(d) &&
+           (int64_t)quad_lds_floats(d.features) * 4 <= 163840;
+}
+
 // fc_l1: bufA[p][o] = lrelu(bj1[o] + sum_f Wx[f][o] * y[p][f])   epic.py:360-362, on the matrix pipe (K = F padded to 4).
 // aw = this lane's element of the A operand (fast_l1_weight: constant over the call), bias = its slice of the per-jet bias (table).
 __device__ __forceinline__ float fast_l1_weight(const pfm_epic_desc& d, const JetDims& j, const float* __restrict__ blob) {
@@ -80,6 +102,7 @@ __device__ __forceinline__ void fast_stem_l1(const JetDims& j, float* __restrict
 // per chain) do not stay in registers for that phase: 68 threads fetch one float4 each (`stg`) and publish it to a small LDS area
 // behind the carve (`tbl`) right before the barrier that precedes the chain, which reads its slices with ds_read (no vmcnt at all).
 constexpr int TBL_G1 = 0, TBL_L1 = 128, TBL_G2 = 256, TBL_FLOATS = 288;  // LDS floats behind Carve::total
+static_assert(TBL_FLOATS == 288, "quad_view / quad_lds_floats place the extra jets' vectors behind it");
 constexpr bool L2LDS = true;  // measured: 0.3-1 % faster than the table read, same bits
 struct ChainLoads {
     f32x4 w2;   // row FT + 16 w + pt of fc_global2 (KP16), outputs 4 o4..
@@ -131,11 +154,12 @@ __device__ __forceinline__ f32x4 fast_sum_partials(const float* __restrict__ g2p
 // Stem chain: g = lrelu(Wg2 . lrelu(Wg1 . [mean ; sum] + tg1) + tg2), tg* = bias + time term (table).  epic.py:369-380
 // In: vin.mean / vin.sum (written by the fc_l2 phase, barrier passed), gl = this thread's rows of fc_g1 behind the time rows.
 // after_fc1(): called once gl has been consumed (the caller requests the first layer's windows there).  Out: vin.g.  Ends with a barrier.
-template <int NSEG, bool COND, typename After, typename Publish>
-__device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restrict__ lds, const SegView (&sv)[2],
+template <int NSEG, bool COND, int NSV, typename After, typename Publish>
+__device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restrict__ lds, const SegView (&sv)[NSV],
                                                 const f32x4 (&gl)[COND ? FNGC : FNG], const ChainLoads& L, const float* __restrict__ tbl,
                                                 After after_fc1, Publish publish_next) {
     static_assert(!(COND && NSEG != 1), "conditioned jets: one jet per workgroup");
+    static_assert(NSEG <= NSV, "a view per jet");
     constexpr int NP = COND ? FNGS + 1 : FNGS;  // [cond (zeros in vin) ;] mean ; sum
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int og = tid >> 4, pt = tid & 15, o4 = lane >> 4;
@@ -183,8 +207,8 @@ __device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restr
 // NSEG == 2 (two jets in the workgroup, the packed sampler): the weights are in registers once, every step runs for both jets.
 // COND: the input vectors carry C zeroed conditioning slots behind the time slots (the pooled part starts at TC = FT + C).  L holds
 // this layer's local-linear-2 bias row for c.bj2 (published at the end of the chain).
-template <int NSEG, bool COND>
-__device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __restrict__ lds, const Carve& c, const SegView (&sv)[2],
+template <int NSEG, bool COND, int NSV>
+__device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __restrict__ lds, const Carve& c, const SegView (&sv)[NSV],
                                                  const f32x4 (&gl)[COND ? FNGC : FNG], const f32x4& wbA, const ChainLoads& L,
                                                  const float* __restrict__ tbl) {
     static_assert(!(COND && NSEG != 1), "conditioned jets: one jet per workgroup");
@@ -348,10 +372,25 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
                                           const float* __restrict__ tbE_next, FastCarry<BF16>& cy, Emit emit, const Segs* sg = nullptr,
                                           const float* __restrict__ ct = nullptr) {
     static_assert(!(COND && NSEG != 1), "conditioned jets: one jet per workgroup");
+    static_assert(NSEG != 4 || L2LDS, "quad mode reads the shared biases from c.bj2");
     constexpr int NGL = COND ? FNGC : FNG, NGLS = COND ? FNGS + 1 : FNGS;
     constexpr int AF = FastCarry<BF16>::AF;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const SegView sv[2] = {seg_view(c, j.N, 0), seg_view(c, j.N, NSEG == 2 ? 1 : 0)};
+    constexpr int NSV = NSEG == 4 ? 4 : 2;
+    SegView sv[NSV];
+    QuadPhase qp1, qpt;  // quad mode: the four jets as a phase with a per-jet LDS bias (bj1) / with a shared bias (c.bj2) sees them
+    if constexpr (NSEG == 4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sv[s] = quad_view(c, s);
+            qp1.bj[s] = sv[s].bj1; qpt.bj[s] = c.bj2;
+            qp1.vin[s] = qpt.vin[s] = sv[s].vin;
+            qp1.misc[s] = qpt.misc[s] = sv[s].misc;
+        }
+    } else {
+        sv[0] = seg_view(c, j.N, 0);
+        sv[1] = seg_view(c, j.N, NSEG == 2 ? 1 : 0);
+    }
     Seg2Phase s2p, s2t;  // the second jet as a phase with an LDS bias (bj1) / with a table bias sees it
     if (NSEG == 2) {
         s2p.bj = lds + sv[1].bj1;
@@ -385,7 +424,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         const float* bj = (COND || L2LDS) ? lds + c.bj2 : tbS + TB_SJ2;
         s2t.bj = bj;
         gemm_phase<true, true, false, BF16, decltype(pf), NSEG>(cy.a2, bufA, bufB, bufA, bj, maskf, j, lds, c, nullptr, nullptr, n_rows, pf,
-                                                                 s2t);
+                                                                 s2t, &qpt);
     }
     if (!(COND || L2LDS)) fast_chain_publish(L, tbl);  // (the previous evaluation's last chain read tbl many barriers ago)
     __syncthreads();
@@ -418,7 +457,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
             Prefetch<AF, NGL, 1> pf{rs, cy.a2, gl, wbA, nullptr, seg_afrag_lin<BF16>(ly.lc2, w, lane), seg_panels(nx.gl1.W, FTP, tid),
                                    seg_panels(nx.lc1.We, FTP, tid), {}};
             gemm_phase<false, false, false, BF16, decltype(pf), NSEG>(cy.a1, bufB, bufA, nullptr, lds + c.bj1, maskf, j, lds, c, nullptr,
-                                                                       nullptr, n_rows, pf, s2p);
+                                                                       nullptr, n_rows, pf, s2p, &qp1);
         }
         __syncthreads();
         PFM_STAMP(13);
@@ -437,11 +476,11 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
             const float* bj = (COND || L2LDS) ? lds + c.bj2 : tbK + TB_L2;
             s2t.bj = bj;
             gemm_phase<true, true, false, BF16, decltype(pf), NSEG, false>(cy.a2, bufA, bufB, bufB, bj, maskf, j, lds, c, nullptr, nullptr, n_rows,
-                                                                            pf, s2t);
+                                                                            pf, s2t, &qpt);
             // this layer's chain read tbl two barriers ago; the next one reads it behind the barrier below.  The publish waits for the
             // staged row with a vmcnt that covers every load issued before it: the riders a short jet had no K-quarter for go behind it
             fast_chain_publish(L, tbl);
-            pf.issue_tail(phase_full_pairs<BF16>(n_rows));
+            pf.issue_tail(NSEG == 4 ? n_rows / (2 * TILE) : phase_full_pairs<BF16>(n_rows));
         }
         __syncthreads();
     }

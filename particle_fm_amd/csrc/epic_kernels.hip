@@ -368,6 +368,69 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// The midpoint integrator on the lean evaluation with FOUR jets per workgroup (quad mode, epic_fast.h): workgroup k takes the jets
+// 4 k .. 4 k + 3 (the last one possibly fewer), jet s in the fixed 32-row slot [32 s, 32 s + 32).  Only the first QROWS rows of a jet
+// are read (PFM_F_QUAD_JETS: the caller pads sets of <= 32 particles to the 128-row tile); rows behind them come back as 0.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_quad_kernel(
+    const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ dt, int n_intervals, const float* __restrict__ z,
+    const float* __restrict__ mask, float* __restrict__ x_out, const float* __restrict__ table, int B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const pfm_epic_desc& d0 = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
+    const JetDims j = dims_of(d0);
+    const Carve c = make_carve(j.N, j.F);
+    const int tid = threadIdx.x, F = j.F;
+    const int jet0 = QJETS * blockIdx.x;
+    const int nseg = min(QJETS, B - jet0);  // jets in this workgroup (wave-uniform)
+    float* xs = lds + c.xs;
+    float* yin = lds + c.yin;
+    // ---- setup: masks, valid counts, start state of the (up to) four jets ----
+    if (tid < QUAD_TILE_ROWS) {  // one thread per row: waves 0, 1 hold two jets each (32 lanes per jet)
+        const int s = tid >> 5, p = tid & 31;
+        const float m = s < nseg ? mask[(size_t)(jet0 + s) * j.N + p] : 0.f;
+        lds[c.maskf + tid] = m;
+        float cnt = m;
+        for (int sh = 16; sh >= 1; sh >>= 1) cnt += __shfl_xor(cnt, sh);  // over the jet's 32 lanes
+        if (p == 0) lds[quad_view(c, s).misc] = cnt;
+    }
+    for (int i = tid; i < QUAD_TILE_ROWS * F; i += NT) {
+        const int r = i / F, f = i - r * F, s = r >> 5, p = r & 31;
+        float z0 = 0.f;
+        if (s < nseg) z0 = z[((size_t)(jet0 + s) * j.N + p) * F + f] * mask[(size_t)(jet0 + s) * j.N + p];  // flow_matching_module.py:668-671
+        xs[i] = z0;
+        yin[i] = z0;
+    }
+    if (tid < QJETS * MAXL) {  // every jet's g starts at 0 (the stem chain overwrites it; the padding entries must be 0)
+        const SegView v = quad_view(c, tid / MAXL);
+        lds[v.vin + FT + 2 * H + (tid % MAXL)] = 0.f;
+    }
+    __syncthreads();
+    const int n_rows = QROWS * nseg;
+    const size_t estride = (size_t)(j.layers + 1) * TB_SLOT;
+    const int n_evals = 2 * n_intervals;
+    FastCarry<MODE == 1> cy;
+    cy.aw = fast_l1_weight(d0, j, blob);
+    fast_carry_request(cy, d0, make_blob_rsrc(blob, d0.blob_floats + PFM_DESC_FLOATS), table + (size_t)j.layers * TB_SLOT);
+    for (int e = 0; e < n_evals; ++e) {
+        const int stage = e & 1;
+        const float h = dt[e >> 1];
+        const float hs = stage ? h : __fmul_rn(0.5f, h);
+        fast_eval<MODE == 1, 4, false>(d0, j, blob, lds, c, n_rows, table + e * estride, table + (e + 1 < n_evals ? e + 1 : e) * estride, cy,
+                                       [=](int p, int f, float val) {
+                                           const float xn = __fadd_rn(xs[p * F + f], __fmul_rn(hs, val));
+                                           yin[p * F + f] = xn;
+                                           if (stage) xs[p * F + f] = xn;
+                                       });
+        __syncthreads();
+    }
+    for (int i = tid; i < nseg * j.N * F; i += NT) {  // rows behind the slot are masked: 0
+        const int s = i / (j.N * F), r = i - s * j.N * F, p = r / F;
+        x_out[(size_t)(jet0 + s) * j.N * F + r] = p < QROWS ? xs[s * QROWS * F + r] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent fixed-step explicit Runge-Kutta integrator (pfm_rk_tableau: euler, midpoint, torchdyn's rk4 = 3/8 rule):
 // as above, with the stage slopes of the jet parked in global scratch (every element is written and read back by the
 // same lane; the LDS carve has no room for four more N x F tiles at N = 150).
@@ -823,7 +886,14 @@ static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const floa
     const int64_t list_off = table_floats + cond_table_floats(d, B);  // the workgroup list sits behind both tables
     // the lean evaluation of epic_fast.h: unconditioned jets, T = 32, F <= 4, fp32 / bf16 operands, one jet per workgroup
     const bool fast = tb && sample_fast(d, mode);
-    if (fast) {
+    // four jets per workgroup in fixed 32-row slots (epic_fast.h, quad mode): the caller's descriptor says the sets fit them
+    const bool quad = fast && mask && quad_path_ok(*d) && pairs_wanted(d);
+    if (quad) {
+        const void* qk = mode == 1 ? (const void*)epic_sample_midpoint_quad_kernel<1> : (const void*)epic_sample_midpoint_quad_kernel<0>;
+        lds = quad_lds_floats(d->features) * 4;
+        if ((rc = check_hip(hipFuncSetAttribute(qk, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "hipFuncSetAttribute(MaxDynamicSharedMemorySize)")))
+            return rc;
+    } else if (fast) {
         const bool cnd = d->cond_global > 0;  // conditioned jets: one per workgroup (the PFM_PACK override must not pair them either)
         const bool pairs = !cnd && pairs_wanted(d);
         const void* fk = cnd ? (mode == 1 ? (const void*)epic_sample_midpoint_fast_kernel<1, false, true> : (const void*)epic_sample_midpoint_fast_kernel<0, false, true>)
@@ -838,6 +908,15 @@ static int sample_midpoint(const pfm_epic_desc* d, const float* blob, const floa
         hipLaunchKernelGGL(epic_time_table_kernel, dim3(2 * n_intervals, d->layers + 1), dim3(NT), 0, (hipStream_t)stream, blob,
                            d->blob_floats, t_eval, scratch, temb_tab, fast ? 1 : 0);
         if ((rc = check_hip(hipGetLastError(), "epic_time_table_kernel launch"))) return rc;
+    }
+    if (quad) {
+        if (mode == 1)
+            hipLaunchKernelGGL(epic_sample_midpoint_quad_kernel<1>, dim3((B + QJETS - 1) / QJETS), dim3(NT), lds, (hipStream_t)stream, blob,
+                               d->blob_floats, dt, n_intervals, z, mask, x_out, (const float*)scratch, B);
+        else
+            hipLaunchKernelGGL(epic_sample_midpoint_quad_kernel<0>, dim3((B + QJETS - 1) / QJETS), dim3(NT), lds, (hipStream_t)stream, blob,
+                               d->blob_floats, dt, n_intervals, z, mask, x_out, (const float*)scratch, B);
+        return check_hip(hipGetLastError(), "epic_sample_midpoint_quad_kernel launch");
     }
     if (fast) {
         const bool cnd = d->cond_global > 0;

@@ -84,7 +84,7 @@ __device__ __forceinline__ void load_afrag(f32x4 (&a)[8], blob_rsrc rs, int64_t 
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).w, (bv0).w, acc0, 0, 0, 0);      \
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).w, (bv1).w, acc1, 0, 0, 0);
 
-// bf16 operands for v_mfma_f32_16x16x16_bf16 (PFM_F_BF16_MFMA): the fp32 float4 a lane already holds -- four
+// bf16 operands (PFM_F_BF16_MFMA; the kernels issue v_mfma_f32_16x16x32_bf16, see pack_bf16x8): the fp32 float4 a lane already holds -- four
 // consecutive k of one row / column -- is exactly that instruction's operand after rounding, so one MFMA replaces four.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 // (plain vector conversion, not inline asm: the compiler must see the VALU write to insert the MFMA read hazard nop)
@@ -154,6 +154,15 @@ struct Seg2Phase {
     const float* mask1 = nullptr;  // mask of its rows, 0 on the first jet's rows
     int t1 = 1 << 20;              // its first 16-row tile
     int vin1 = 0, misc1 = 0;       // where its pooled mean / sum go, where its valid count is
+};
+
+// FOUR short jets in a workgroup (NSEG == 4, the quad mode of the lean sampler, epic_fast.h): fixed geometry -- jet s owns the 32-row
+// slot [32 s, 32 s + 32) of the activation tiles = tile pair s of every particle phase, so a pair body knows its jet at compile time:
+// its bias vector, and where its pooled mean / sum go.  LDS float offsets.
+struct QuadPhase {
+    int bj[4];    // per-jet bias of this Linear (all four the same offset if the bias does not depend on the jet)
+    int vin[4];   // where the jet's pooled mean / sum go (POOL)
+    int misc[4];  // where its valid count is (POOL)
 };
 
 // ---- prefetch lists -----------------------------------------------------------------------------------------------
@@ -243,7 +252,9 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
                                            const float* __restrict__ bj, const float* __restrict__ maskf,
                                            const JetDims& j, float* __restrict__ lds, const Carve& c,
                                            float* __restrict__ save, float* __restrict__ save_pool, int n_rows,
-                                           const PF& pf = PF{}, const Seg2Phase& s2 = Seg2Phase{}) {
+                                           const PF& pf = PF{}, const Seg2Phase& s2 = Seg2Phase{}, const QuadPhase* qp = nullptr) {
+    static_assert(NSEG == 1 || NSEG == 2 || NSEG == 4, "one jet, a packed pair, or four 32-row slots");
+    static_assert(!(NSEG == 4 && SAVE), "quad mode: inference only");
     static_assert(AF == 8 || (BF16 && AF == 4), "A operand: 8 fp32 float4s, or 4 pre-packed bf16 ones for the bf16 pipe");
     const int tid_ = launder(threadIdx.x);
     const int lane = tid_ & 63, w = tid_ >> 6;
@@ -256,6 +267,11 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
     const int t1 = s2.t1;
     const float* const mask1 = s2.mask1;
     f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 psq[NSEG == 4 ? 4 : 1];  // quad mode: one pool sum per tile pair = per jet (static indices only)
+    if (NSEG == 4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) psq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int npairs = (n_rows + 2 * TILE - 1) / (2 * TILE);
     // (row & 15) == pl for every tile, so the swizzled slot offsets are per-lane constants
     int koff[8];
@@ -306,7 +322,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
         r1 = *reinterpret_cast<const f32x4*>(resid + TILE * H + ooff);
     }
     // epilogue of an INTERIOR pair: all 32 rows are < n_rows, no predication at all
-    auto epilogue_full = [&](f32x4 e0, f32x4 e1, int pair) {
+    auto epilogue_full = [&](f32x4 e0, f32x4 e1, int pair, f32x4& ps) {  // ps: the pool sum this pair adds to
         e0 = lrelu4(e0, slope);
         e1 = lrelu4(e1, slope);
         float* d0 = dst + pair * 2 * TILE * H + ooff;
@@ -324,11 +340,11 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
                 const float q0 = mq[0], q1 = mq[TILE];
                 psumB += e0 * q0;
                 psumB += e1 * q1;
-                psum += e0 * (mp[0] - q0);
-                psum += e1 * (mp[TILE] - q1);
+                ps += e0 * (mp[0] - q0);
+                ps += e1 * (mp[TILE] - q1);
             } else {
-                psum += e0 * mp[0];
-                psum += e1 * mp[TILE];
+                ps += e0 * mp[0];
+                ps += e1 * mp[TILE];
             }
         }
     };
@@ -369,11 +385,14 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
         const float* s0 = src + pair * 2 * TILE * H;                                                            \
         PFM_LOADQ(Y0, Y1, s0, 1);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        if (pair > 0) epilogue_full(pacc0, pacc1, pair - 1); /* pair - 1 <= npairs - 2: every row valid */     \
+        if (pair > 0) epilogue_full(pacc0, pacc1, pair - 1, PFM_PSUM_OF(pair - 1)); /* pair - 1 <= npairs - 2: every row valid */ \
         f32x4 acc0 = bias, acc1 = bias;                                                                         \
         if (NSEG == 2) { /* wave-uniform: which jet each of the two tiles belongs to */                         \
             if (2 * pair >= t1) acc0 = biasB;                                                                   \
             if (2 * pair + 1 >= t1) acc1 = biasB;                                                               \
+        }                                                                                                       \
+        if constexpr (NSEG == 4) { /* this pair IS jet `pair` */                                                \
+            acc0 = acc1 = *reinterpret_cast<const f32x4*>(lds + qp->bj[pair] + 4 * oslot);                      \
         }                                                                                                       \
         if (RESID) { acc0 += r0; acc1 += r1; }                                                                  \
         MF(X0, X1, 0);                                                                                          \
@@ -402,7 +421,9 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
     // The pairs whose two tiles are both real run as straight-line bodies with a compile-time pair index P (the loop is unrolled
     // so that the prefetch list's loads get static registers: one load behind every K-quarter); a jet with an odd tile count
     // ends with one more body that issues the real tile's MFMAs only (runtime pair index, no prefetch slot).
-    const int nfull = phase_full_pairs<BF16>(n_rows);  // = ntiles / 2
+    const int nfull = NSEG == 4 ? npairs : phase_full_pairs<BF16>(n_rows);  // = ntiles / 2 (quad mode: whole 32-row slots)
+    // the pool sum pair P adds to: the jet's own in quad mode (P is a constant expression at every use)
+#define PFM_PSUM_OF(P) (NSEG == 4 ? psq[NSEG == 4 ? ((P) > 0 ? (P) : 0) : 0] : psum)
 #define PFM_NOPF(q)
 #define PFM_PAIR_AT(P)                                                                                          \
     if ((P) < nfull) {                                                                                          \
@@ -416,9 +437,11 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
 #define PFM_PFI_4(q) pf.template issue_slot<16 + (q)>()
     static_assert(MAXPAIRS == 5, "unroll PFM_PAIR_AT to MAXPAIRS");
     PFM_PAIR_AT(0) PFM_PAIR_AT(1) PFM_PAIR_AT(2) PFM_PAIR_AT(3) PFM_PAIR_AT(4)
-    if (nfull < npairs) {  // odd tile count: one real tile in the last pair
-        const int pair = nfull;
-        PFM_PAIR_BODY(PFM_MFMAQ1, PFM_NOPF)
+    if constexpr (NSEG != 4) {
+        if (nfull < npairs) {  // odd tile count: one real tile in the last pair
+            const int pair = nfull;
+            PFM_PAIR_BODY(PFM_MFMAQ1, PFM_NOPF)
+        }
     }
 #undef PFM_PFI_0
 #undef PFM_PFI_1
@@ -426,17 +449,33 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
 #undef PFM_PFI_3
 #undef PFM_PFI_4
 #undef PFM_PAIR_AT
+#undef PFM_PSUM_OF
 #undef PFM_NOPF
 #undef PFM_PAIR_BODY
 #undef PFM_MFMAQ1
 #undef PFM_LOADQ
 #undef PFM_MFMAQ
-    epilogue(pacc0, pacc1, npairs - 1);
+    if constexpr (NSEG == 4) {
+        // the last jet's slot: every row of a slot is computed (holes carry zero input and zero mask), so no predication; the
+        // branch is wave-uniform and the pool sum's index static in each arm
+        if (npairs == 1) epilogue_full(pacc0, pacc1, 0, psq[0]);
+        else if (npairs == 2) epilogue_full(pacc0, pacc1, 1, psq[1]);
+        else if (npairs == 3) epilogue_full(pacc0, pacc1, 2, psq[2]);
+        else epilogue_full(pacc0, pacc1, 3, psq[3]);
+    } else {
+        epilogue(pacc0, pacc1, npairs - 1);
+    }
     // the part of the prefetch list a short jet had no pairs for
     if (TAIL) pf.issue_tail(nfull);
     if (POOL) {
-        pool_finish<SAVE>(psum, j, lds, c.vin, c.misc, oslot, pl, save_pool);
-        if (NSEG == 2) pool_finish<false>(psumB, j, lds, s2.vin1, s2.misc1, oslot, pl, nullptr);
+        if constexpr (NSEG == 4) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s < npairs) pool_finish<false>(psq[s], j, lds, qp->vin[s], qp->misc[s], oslot, pl, nullptr);
+        } else {
+            pool_finish<SAVE>(psum, j, lds, c.vin, c.misc, oslot, pl, save_pool);
+            if (NSEG == 2) pool_finish<false>(psumB, j, lds, s2.vin1, s2.misc1, oslot, pl, nullptr);
+        }
     }
 }
 

@@ -223,6 +223,27 @@ def _seg2_rows(n: int) -> int:
     return n - (_X2_MASK + (n + 3) // 4 * 4 + 127) // 128
 
 
+QUAD_TILE_ROWS, QUAD_SLOT_ROWS = 128, 32  # csrc/epic_fast.h: four jets per workgroup, each in a fixed 32-row slot of a 128-row tile
+QUAD_PRECISIONS = (2,)  # matrix-operand flags whose quad kernel is built without register spills: PFM_F_BF16_MFMA (fp32: 48 dwords)
+
+
+def packed_layout(layout: EpicLayout, n: int) -> Optional[EpicLayout]:
+    """The descriptor to run an n-particle batch on when jet packing is asked for (PFM_F_PACK_JETS), or None (packing off, the tile
+    already takes two full-length jets, or nothing fits).  Sets of <= 32 particles without conditioning go FOUR to a workgroup on the
+    128-row tile (PFM_F_QUAD_JETS, bf16 operands); otherwise the smallest tile that takes two full-length jets."""
+    from .layout import PFM_F_BF16_MFMA, PFM_F_F16X3_MFMA, PFM_F_GENERIC_SAMPLER, PFM_F_PACK_JETS, PFM_F_QUAD_JETS, PFM_F_SKIP_MASKED_TAIL
+    fl = int(layout.desc.flags)
+    if not (fl & PFM_F_PACK_JETS) or not (fl & PFM_F_SKIP_MASKED_TAIL):
+        return None
+    cfg = layout.cfg
+    mode = fl & (PFM_F_BF16_MFMA | PFM_F_F16X3_MFMA)
+    if (n <= QUAD_SLOT_ROWS and mode in QUAD_PRECISIONS and cfg.global_cond_dim == 0 and cfg.t_dim == 32 and cfg.features <= 4
+            and not (fl & PFM_F_GENERIC_SAMPLER)):
+        return layout.padded(QUAD_TILE_ROWS, PFM_F_QUAD_JETS)
+    tile = packed_tile_rows(layout, n)
+    return layout.padded(tile) if tile else None
+
+
 def packed_tile_rows(layout: EpicLayout, n: int) -> int:
     """Set size to run an n-particle batch on so that two full-length jets share a workgroup, or 0 if packing is off, the tile
     already takes them, or no tile that fits the LDS would."""
@@ -249,9 +270,9 @@ def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor
     ``premask`` is informational: masking twice is idempotent for a 0/1 mask."""
     lib = _lib.load()
     n_in = z.shape[1]
-    n_tile = packed_tile_rows(layout, n_in) if time_table else 0
-    if n_tile:  # run on the larger tile (see packed_tile_rows): padded inputs, the same weights behind the other descriptor
-        big = layout.padded(n_tile)
+    big = packed_layout(layout, n_in) if time_table else None
+    if big is not None:  # run on the larger tile (see packed_layout): padded inputs, the same weights behind the other descriptor
+        n_tile = big.cfg.num_particles
         pad = n_tile - n_in
         m2 = mask if mask is not None else torch.ones(z.shape[0], n_in, device=z.device, dtype=torch.float32)
         m2 = m2.reshape(z.shape[0], n_in).to(torch.float32)

@@ -32,6 +32,7 @@ PFM_F_F16X3_MFMA = 4
 PFM_F_TEMB_SINCOS = 8
 PFM_F_PACK_JETS = 16
 PFM_F_GENERIC_SAMPLER = 32  # keep the generic sampler kernel where the lean evaluation (csrc/epic_fast.h) would run
+PFM_F_QUAD_JETS = 64  # four jets per workgroup in fixed 32-row slots on a 128-row descriptor (set by hip_ops for padded short sets)
 
 
 class LocalLin(ctypes.Structure):
@@ -432,15 +433,16 @@ class EpicLayout:
     def blob_total(self) -> int:
         return int(self.desc.blob_floats) + self.desc_floats
 
-    def padded(self, num_particles: int) -> "EpicLayout":
-        """The same network on a larger set size (same blob offsets: only desc.n_points differs); cached."""
+    def padded(self, num_particles: int, extra_flags: int = 0) -> "EpicLayout":
+        """The same network on a larger set size (same blob offsets: only desc.n_points -- and ``extra_flags`` -- differ); cached."""
         cache = self.__dict__.setdefault("_padded", {})
-        lay = cache.get(num_particles)
+        key = (int(num_particles), int(extra_flags))
+        lay = cache.get(key)
         if lay is None:
             import dataclasses
-            lay = cache[num_particles] = EpicLayout(dataclasses.replace(self.cfg, num_particles=int(num_particles)),
-                                                    with_backward=self.with_backward,
-                                                    flags=int(self.desc.flags) & ~PFM_F_TEMB_SINCOS)
+            lay = cache[key] = EpicLayout(dataclasses.replace(self.cfg, num_particles=int(num_particles)),
+                                          with_backward=self.with_backward,
+                                          flags=(int(self.desc.flags) & ~PFM_F_TEMB_SINCOS) | int(extra_flags))
             assert int(lay.desc.blob_floats) == int(self.desc.blob_floats)
         return lay
 

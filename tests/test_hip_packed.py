@@ -138,39 +138,72 @@ def _autocast_bar(vf, z, cond, mask, steps):
 
 
 def test_bf16_packed_sampler_equals_unpacked_bf16_bitwise_and_meets_the_autocast_bar():
-    """flags = SKIP_MASKED_TAIL | BF16_MFMA | PACK_JETS on the 30-particle model (the kernel behind the cfg-2 bf16 line): the same bits
-    as one jet per workgroup with bf16 operands (rows and per-jet vectors never mix; the operand rounding is per element), and no
-    further from the fp32 reference than the oracle under torch.autocast(bfloat16) (the bar of tests/test_hip_bf16.py)."""
+    """flags = SKIP_MASKED_TAIL | BF16_MFMA | PACK_JETS on the 30-particle model (the kernel behind the cfg-2 bf16 line; round 3: FOUR
+    jets per workgroup in fixed 32-row slots of a 128-row tile, epic_sample_midpoint_quad_kernel<1>): the same bits as one jet per
+    workgroup with bf16 operands (rows and per-jet vectors never mix; the operand rounding is per element), and no further from the
+    fp32 reference than the oracle under torch.autocast(bfloat16) (the bar of tests/test_hip_bf16.py)."""
     from particle_fm_amd import hip_ops
-    from particle_fm_amd.layout import EpicLayout
+    from particle_fm_amd.layout import EpicLayout, PFM_F_QUAD_JETS
     from tests.conftest import load_golden
     g = load_golden("jetnet30")
     N, F = g.hp["num_particles"], g.hp["features"]
     lay_p = EpicLayout(cfg_of(g.hp), flags=1 | 2 | 16)
     lay_1 = EpicLayout(cfg_of(g.hp), flags=1 | 2)
-    assert hip_ops.packed_tile_rows(lay_p, N) == 80
+    big = hip_ops.packed_layout(lay_p, N)
+    assert big.cfg.num_particles == 128 and int(big.desc.flags) & PFM_F_QUAD_JETS  # the call really runs four jets per workgroup
+    assert hip_ops.packed_layout(lay_1, N) is None
     blob_p = lay_p.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
     blob_1 = lay_1.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
-    B, steps = 96, 12
-    n, mask, z, _ = _ragged(B, N, F, 0, seed=123, lo=1)
-    packed = hip_ops.epic_sample_midpoint(lay_p, blob_p, z.cuda(), None, mask.cuda(), ode_steps=steps).cpu()
-    single = hip_ops.epic_sample_midpoint(lay_1, blob_1, z.cuda(), None, mask.cuda(), ode_steps=steps).cpu()
-    assert torch.equal(packed, single)
-    nwg, wl = _pack_list(lay_p.padded(80), B, steps)
-    assert nwg == B // 2 and int((wl[:, 1] >= 0).sum()) == B // 2  # the call really ran two jets per workgroup
+    steps = 12
     vf = EpicVectorField(g.state, "flows.0.net", g.hp, freqs=g.freqs)
-    ref, eac = _autocast_bar(vf, z, None, mask, steps)
-    e16 = (packed - ref).abs()
-    assert 1e-5 < e16.max() <= 1.5 * eac.max() + 2e-3, (e16.max(), eac.max())
-    assert e16.mean() <= 1.5 * eac.mean() + 1e-4, (e16.mean(), eac.mean())
-    assert torch.all(packed[mask.squeeze(-1) == 0] == 0)
-    # the fixture's own 100-step vector (reference vector field + restated integrator), through the packed bf16 kernel
+    for B in (96, 7, 1):  # whole quads; a last workgroup with 3 jets; a single jet
+        n, mask, z, _ = _ragged(max(B, 4), N, F, 0, seed=123 + B, lo=1)
+        mask, z = mask[:B], z[:B]
+        packed = hip_ops.epic_sample_midpoint(lay_p, blob_p, z.cuda(), None, mask.cuda(), ode_steps=steps).cpu()
+        single = hip_ops.epic_sample_midpoint(lay_1, blob_1, z.cuda(), None, mask.cuda(), ode_steps=steps).cpu()
+        assert torch.equal(packed, single), B
+        assert torch.all(packed[mask.squeeze(-1) == 0] == 0)
+        if B == 96:
+            ref, eac = _autocast_bar(vf, z, None, mask, steps)
+            e16 = (packed - ref).abs()
+            assert 1e-5 < e16.max() <= 1.5 * eac.max() + 2e-3, (e16.max(), eac.max())
+            assert e16.mean() <= 1.5 * eac.mean() + 1e-4, (e16.mean(), eac.mean())
+    # no mask at all: every jet is full length
+    full = hip_ops.epic_sample_midpoint(lay_p, blob_p, z.cuda(), None, None, ode_steps=4).cpu()
+    full1 = hip_ops.epic_sample_midpoint(lay_1, blob_1, z.cuda(), None, None, ode_steps=4).cpu()
+    assert torch.equal(full, full1)
+    # the fixture's own 100-step vector (reference vector field + restated integrator), through the quad bf16 kernel
     tag = "midpoint_100/"
     zz, mm, want = g.get(tag + "z"), g.get(tag + "mask"), g.get(tag + "x_end")
     out = hip_ops.epic_sample_midpoint(lay_p, blob_p, zz.cuda(), None, None if mm is None else mm.float().cuda(), ode_steps=100).cpu()
     out1 = hip_ops.epic_sample_midpoint(lay_1, blob_1, zz.cuda(), None, None if mm is None else mm.float().cuda(), ode_steps=100).cpu()
     assert torch.equal(out, out1)
     assert (out - want).abs().max() < 5e-2
+
+
+def test_bf16_pair_packing_on_long_sets_equals_unpacked_bf16_bitwise():
+    """epic_sample_midpoint_fast_kernel<1, true, false> (bf16 operands, two jets of arbitrary length per workgroup): what a bf16 model
+    with sets beyond 32 particles runs under PFM_F_PACK_JETS.  Same bits as one jet per workgroup; pairs really form."""
+    from particle_fm_amd import hip_ops
+    from particle_fm_amd.layout import EpicLayout
+    from tests.conftest import load_golden
+    g = load_golden("jetnet150")
+    N, F = g.hp["num_particles"], g.hp["features"]
+    lay_p = EpicLayout(cfg_of(g.hp), flags=1 | 2 | 16)
+    lay_1 = EpicLayout(cfg_of(g.hp), flags=1 | 2)
+    assert hip_ops.packed_layout(lay_p, N) is None  # the 150-row tile takes the pairs itself
+    blob_p = lay_p.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    blob_1 = lay_1.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    B, steps = 48, 6
+    n, mask, z, _ = _ragged(B, N, F, 0, seed=77, lo=1)
+    packed = hip_ops.epic_sample_midpoint(lay_p, blob_p, z.cuda(), None, mask.cuda(), ode_steps=steps).cpu()
+    single = hip_ops.epic_sample_midpoint(lay_1, blob_1, z.cuda(), None, mask.cuda(), ode_steps=steps).cpu()
+    assert torch.equal(packed, single)
+    nwg, wl = _pack_list(lay_p, B, steps)
+    assert int((wl[:, 1] >= 0).sum()) >= B // 6 and nwg == B - int((wl[:, 1] >= 0).sum())
+    vf = EpicVectorField(g.state, "flows.0.net", g.hp, freqs=g.freqs)
+    ref, eac = _autocast_bar(vf, z, None, mask, steps)
+    assert (packed - ref).abs().max() <= 1.5 * eac.max() + 2e-3
 
 
 @pytest.mark.parametrize("B,steps", [(24, 8), (6, 40)])
@@ -215,7 +248,8 @@ def test_bf16_conditioned_lean_sampler_tracks_the_generic_bf16_kernel(B, steps):
 @pytest.mark.parametrize("flags", [1 | 16, 1 | 2 | 16], ids=["fp32-packed", "bf16-packed"])
 def test_cfg2_full_size_properties(flags):
     """BASELINE cfg 2 at its own size -- 1024 jets of the 30-particle model, multiplicities U{10..30}, ode_steps = 100, two jets per
-    workgroup on the 80-row tile (512 paired workgroups = two rounds on 256 CUs; what bench_secondary.py --workload jetnet30 times) --
+    workgroup on the 80-row tile (fp32: 512 paired workgroups = two rounds on 256 CUs) or four per workgroup in 32-row slots (bf16: 256
+    workgroups = one round; what bench_secondary.py --workload jetnet30 [--precision bf16] times) --
     through size-independent properties: a jet's result does not depend on its batch or partner (bitwise, 40 picked jets), masked rows
     are exactly 0, everything is finite, and the fp32 call agrees with the oracle on a handful of jets."""
     from particle_fm_amd import hip_ops
@@ -230,8 +264,13 @@ def test_cfg2_full_size_properties(flags):
     mask = (torch.arange(N)[None] < n[:, None]).float().unsqueeze(-1)
     z = torch.randn(B, N, F, generator=gen)
     out = hip_ops.epic_sample_midpoint(lay, blob, z.cuda(), None, mask.cuda(), ode_steps=100).cpu()
-    nwg, wl = _pack_list(lay.padded(80), B, 100)
-    assert nwg == B // 2 and sorted(int(v) for v in wl.reshape(-1)) == list(range(B))
+    if flags & 2:  # bf16: four jets per workgroup (256 workgroups = one round on 256 CUs), no workgroup list
+        from particle_fm_amd.layout import PFM_F_QUAD_JETS
+        big = hip_ops.packed_layout(lay, N)
+        assert big.cfg.num_particles == 128 and int(big.desc.flags) & PFM_F_QUAD_JETS
+    else:
+        nwg, wl = _pack_list(lay.padded(80), B, 100)
+        assert nwg == B // 2 and sorted(int(v) for v in wl.reshape(-1)) == list(range(B))
     assert torch.isfinite(out).all()
     assert torch.all(out[mask.squeeze(-1) == 0] == 0)
     pick = torch.randperm(B, generator=gen)[:40]
