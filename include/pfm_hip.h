@@ -327,6 +327,11 @@ int pfm_wn_pack(const float *params, const int32_t *rows, int32_t n_rows, const 
 int pfm_wn_unpack_grad(const float *params, const float *gblob, const int32_t *rows, int32_t n_rows,
                        const int32_t *gsrc, const int32_t *bias_from, const int32_t *bias_to, int32_t n_bias,
                        float *grad, void *stream);
+/* The same with `=` in place of `+=`: every g / v / bias element the tables name is WRITTEN (a caller whose tables cover the whole
+ * flat buffer needs no zeroing launch in front). */
+int pfm_wn_unpack_grad_set(const float *params, const float *gblob, const int32_t *rows, int32_t n_rows,
+                           const int32_t *gsrc, const int32_t *bias_from, const int32_t *bias_to, int32_t n_bias,
+                           float *grad, void *stream);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,7 @@ SYMBOLS = {
                 c_float, c_float, c_int32, c_void_p]),
     "pfm_wn_pack": (c_int, [_fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_wn_unpack_grad": (c_int, [_fp, _fp, _fp, c_int32, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_wn_unpack_grad_set": (c_int, [_fp, _fp, _fp, c_int32, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_sample_epilogue": (c_int, [_fp, _fp, _fp, _fp, c_int32, c_int64, c_int32, c_void_p]),
     "pfm_epic_sample_rk": (c_int, [POINTER(EpicDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
     "pfm_epic_sample_rk_scratch_floats": (c_int64, [POINTER(EpicDesc), c_int32, c_int32, c_int32]),

@@ -212,13 +212,18 @@ struct RedArgs {
     int n_tile, n_r1, n_small, panels_per_job;  // panels_per_job: max 16-row panels of any job (ceil(VIN_FLOATS / 16))
 };
 
-__global__ __launch_bounds__(RED_T) void epic_bwd_reduce_kernel(const float* __restrict__ blob, int64_t desc_off,
-                                                                const float* __restrict__ work, BwdWork bw, int B, RedArgs ra,
-                                                                float* __restrict__ gblob) {
+// RED_G groups of RED_T threads per workgroup: the rank-1 sums over jets (part (b)) are cut into RED_G contiguous jet ranges, one per
+// group -- a chain of dependent L2 round trips a quarter as long -- and joined through LDS in group order; parts (a) and (c) run on
+// the first group alone (the other waves end at once: ended waves do not take part in a barrier).
+constexpr int RED_G = 4;
+__global__ __launch_bounds__(RED_T * RED_G) void epic_bwd_reduce_kernel(const float* __restrict__ blob, int64_t desc_off,
+                                                                        const float* __restrict__ work, BwdWork bw, int B, RedArgs ra,
+                                                                        float* __restrict__ gblob) {
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
-    const int tid = threadIdx.x;
+    const int grp = threadIdx.x / RED_T, tid = threadIdx.x % RED_T;
     int item = blockIdx.x;
     if (item < ra.n_tile) {
+        if (grp != 0) return;
         // ---- (a) dW tile b = sum over splits, to GRAD_D order ----
         const int b = item >> 4, slice = item & 15;
         const int p4 = slice * 1024 + tid * 4;  // float index inside the tile (accumulator order), 4 consecutive = e 0..3
@@ -254,6 +259,8 @@ __global__ __launch_bounds__(RED_T) void epic_bwd_reduce_kernel(const float* __r
     const float* rec = work + bw.rec;
     if (item < ra.n_r1) {
         // ---- (b) one 16-row panel of a rank-1 job: thread (kk = tid >> 5, o4 = tid & 31) -> rows 16 panel + kk, + kk + 8; 4 outputs ----
+        // (every exit up to the join is uniform over the workgroup; per-thread conditions only mask the work)
+        __shared__ f32x4 comb[(RED_G - 1) * RED_T * 2];  // partial sums of groups 1 .. RED_G - 1 (two float4 per thread)
         const int panel = item % ra.panels_per_job, ji = item / ra.panels_per_job;
         R1Job jb;
         if (!r1_job(d, ji >> 2, ji & 3, jb)) return;
@@ -261,22 +268,22 @@ __global__ __launch_bounds__(RED_T) void epic_bwd_reduce_kernel(const float* __r
         if (16 * panel >= K16 + 16) return;  // one extra "panel" carries the bias row
         const bool bias_panel = 16 * panel >= K16;
         const int kk = tid >> 5, o4 = tid & 31;
-        if (4 * o4 >= ((jb.OUT + 3) & ~3)) return;
+        const bool idle = 4 * o4 >= ((jb.OUT + 3) & ~3) || (bias_panel && kk != 0);
         const int ka = 16 * panel + kk, kb = ka + 8;
         const bool va = !bias_panel && ka < jb.K, vb = !bias_panel && kb < jb.K;
-        if (bias_panel && kk != 0) return;
         // record offsets of this thread's two x entries (rows past K: any valid float, multiplied by 0)
         const int xa = va ? (ka < jb.x0n ? jb.x0 + ka : jb.x1 + (ka - jb.x0n)) : jb.x0;
         const int xb = vb ? (kb < jb.x0n ? jb.x0 + kb : jb.x1 + (kb - jb.x0n)) : jb.x0;
         const float ma = va ? 1.f : 0.f, mb = vb ? 1.f : 0.f;
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
-        // jets in order, 8 per step: all 24 loads of a step are issued before its FMAs (the loop is latency-bound otherwise);
-        // even jets accumulate in (a0, b0), odd ones in (a1, b1): a fixed order
+        // this group's jets in order, 8 per step: all 24 loads of a step are issued before its FMAs (the loop is latency-bound
+        // otherwise); even jets accumulate in (a0, b0), odd ones in (a1, b1): a fixed order
         constexpr int U = 8;
         const int64_t rt = br.total;
-        const float* rbase = rec + jb.dy + 4 * o4;
-        int jet = 0;
-        for (; jet + U <= B; jet += U) {
+        const float* rbase = rec + jb.dy + 4 * (idle ? 0 : o4);
+        int jet = (int)((int64_t)B * grp / RED_G);
+        const int jend = idle ? jet : (int)((int64_t)B * (grp + 1) / RED_G);
+        for (; jet + U <= jend; jet += U) {
             f32x4 dy[U];
             float xav[U], xbv[U];
 #pragma unroll
@@ -295,14 +302,22 @@ __global__ __launch_bounds__(RED_T) void epic_bwd_reduce_kernel(const float* __r
                 b1 += dy[u + 1] * (xbv[u + 1] * mb);
             }
         }
-        for (; jet < B; ++jet) {
+        for (; jet < jend; ++jet) {
             const float* r = rec + (int64_t)jet * rt;
             const f32x4 dy0 = *reinterpret_cast<const f32x4*>(rbase + (int64_t)jet * rt);
             if (bias_panel) { a0 += dy0; continue; }
             a0 += dy0 * (r[xa] * ma);
             b0 += dy0 * (r[xb] * mb);
         }
-        const f32x4 sa = a0 + a1, sb = b0 + b1;
+        if (grp > 0) {
+            comb[((grp - 1) * RED_T + tid) * 2 + 0] = a0 + a1;
+            comb[((grp - 1) * RED_T + tid) * 2 + 1] = b0 + b1;
+        }
+        __syncthreads();
+        if (grp != 0 || idle) return;
+        static_assert(RED_G == 4, "four partials are joined below");
+        const f32x4 sa = ((a0 + a1) + comb[(0 * RED_T + tid) * 2]) + (comb[(1 * RED_T + tid) * 2] + comb[(2 * RED_T + tid) * 2]);
+        const f32x4 sb = ((b0 + b1) + comb[(0 * RED_T + tid) * 2 + 1]) + (comb[(1 * RED_T + tid) * 2 + 1] + comb[(2 * RED_T + tid) * 2 + 1]);
         if (bias_panel) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -328,21 +343,28 @@ __global__ __launch_bounds__(RED_T) void epic_bwd_reduce_kernel(const float* __r
     }
     item -= ra.n_r1;
     if (item < ra.n_small) {
-        // ---- (c) dW3 (row-major [F][H]) and dWx (K-major [F][H]): sums of the per-jet partials ----
-        const int e = item * RED_T + tid;  // 0 .. 2 * MAXF * H
+        // ---- (c) dW3 (row-major [F][H]) and dWx (K-major [F][H]): sums of the per-jet partials.  A workgroup takes 64 outputs; wave g
+        //      sums the jets of its quarter [B g / 4, B (g + 1) / 4) with 8 loads in flight (the loop is a chain of dependent L2 round
+        //      trips: one thread walking all B jets took 130 us at 1024 jets), the four partials meet in LDS in wave order ----
+        if (grp != 0) return;
+        __shared__ float combc[3 * 64];
+        const int g = tid >> 6, l = tid & 63;
+        const int e = item * 64 + l;  // 0 .. 2 * MAXF * H
         const int which = e / (MAXF * H), fe = e - which * (MAXF * H);
-        if (which > 1 || fe >= d.features * H) return;
-        const int off = (which == 0 ? br.dW3 : br.dWx) + fe;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int jet = 0;
-        for (; jet + 4 <= B; jet += 4) {
-            s0 += rec[(int64_t)jet * br.total + off];
-            s1 += rec[(int64_t)(jet + 1) * br.total + off];
-            s2 += rec[(int64_t)(jet + 2) * br.total + off];
-            s3 += rec[(int64_t)(jet + 3) * br.total + off];
+        const bool live = which <= 1 && fe < d.features * H;
+        const int off = (which == 0 ? br.dW3 : br.dWx) + (live ? fe : 0);
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int jet = (int)((int64_t)B * g / 4);
+        const int jend = live ? (int)((int64_t)B * (g + 1) / 4) : jet;
+        for (; jet + 8 <= jend; jet += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += rec[(int64_t)(jet + u) * br.total + off];
         }
-        for (; jet < B; ++jet) s0 += rec[(int64_t)jet * br.total + off];
-        gblob[(which == 0 ? d.l3_W : d.l1x.W) + fe] = (s0 + s1) + (s2 + s3);
+        for (; jet < jend; ++jet) s[0] += rec[(int64_t)jet * br.total + off];
+        const float part = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        if (g > 0) combc[(g - 1) * 64 + l] = part;
+        __syncthreads();
+        if (g == 0 && live) gblob[(which == 0 ? d.l3_W : d.l1x.W) + fe] = (part + combc[l]) + (combc[64 + l] + combc[128 + l]);
     }
 }
 

@@ -392,7 +392,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
             if (2 * pair + 1 >= t1) acc1 = biasB;                                                               \
         }                                                                                                       \
         if constexpr (NSEG == 4) { /* this pair IS jet `pair` */                                                \
-            acc0 = acc1 = *reinterpret_cast<const f32x4*>(lds + qp->bj[pair] + 4 * oslot);                      \
+            acc0 = acc1 = *reinterpret_cast<const f32x4*>(lds + qp->bj[pair < 4 ? pair : 3] + 4 * oslot);       \
         }                                                                                                       \
         if (RESID) { acc0 += r0; acc1 += r1; }                                                                  \
         MF(X0, X1, 0);                                                                                          \

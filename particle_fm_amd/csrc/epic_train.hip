@@ -193,8 +193,8 @@ static int loss_backward(const pfm_epic_desc* d, const float* blob, const float*
     ra.n_tile = bw.nblk * 16;
     ra.panels_per_job = (VIN_FLOATS + 15) / 16 + 1;
     ra.n_r1 = (d->layers + 2) * 4 * ra.panels_per_job;
-    ra.n_small = (2 * MAXF * H + RED_T - 1) / RED_T;
-    hipLaunchKernelGGL(epic_bwd_reduce_kernel, dim3(ra.n_tile + ra.n_r1 + ra.n_small), dim3(RED_T), 0, s, blob, d->blob_floats,
+    ra.n_small = (2 * MAXF * H + 63) / 64;  // 64 outputs per workgroup (epic_bwd_reduce_kernel, part (c))
+    hipLaunchKernelGGL(epic_bwd_reduce_kernel, dim3(ra.n_tile + ra.n_r1 + ra.n_small), dim3(RED_T * RED_G), 0, s, blob, d->blob_floats,
                        (const float*)scratch, bw, B, ra, grad_blob);
     return check_hip(hipGetLastError(), "epic_bwd_reduce_kernel launch");
 }

@@ -113,8 +113,10 @@ extern "C" int pfm_optim_step(float* param, const float* grad, float* exp_avg, f
          reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(ema)) & 15)
         return set_err(PFM_E_BADARG, "flat buffers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    int rc = check_hip(hipMemsetAsync(scratch, 0, sizeof(float), s), "hipMemsetAsync(scratch)");
-    if (rc) return rc;
+    if (!(max_norm > 0.f)) {  // with clipping the optimiser kernel itself writes scratch[0] = ||g||^2; without, it reads as 0
+        int rc = check_hip(hipMemsetAsync(scratch, 0, sizeof(float), s), "hipMemsetAsync(scratch)");
+        if (rc) return rc;
+    }
     const int64_t n4 = (n + 3) / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;

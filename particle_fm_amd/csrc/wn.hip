@@ -52,6 +52,8 @@ __global__ __launch_bounds__(256) void wn_pack_kernel(const float* __restrict__ 
 }
 
 // dW -> dg = <dW, v>/||v||,  dv = (g/||v||) (dW - v <dW, v>/||v||^2);  grad += (accumulates like autograd)
+// ACC: grad += (autograd's accumulate semantics); !ACC: grad = (the fused trainer, whose tables cover every parameter: no zeroing launch)
+template <bool ACC>
 __global__ __launch_bounds__(256) void wn_unpack_grad_kernel(const float* __restrict__ params,
                                                              const float* __restrict__ gblob,
                                                              const WnRow* __restrict__ rows, int n_rows,
@@ -74,13 +76,13 @@ __global__ __launch_bounds__(256) void wn_unpack_grad_kernel(const float* __rest
         dot = wave_sum(dot);
         const float inv_n = 1.0f / sqrtf(ss);
         const float g = params[r.g_off];
-        if (lane == 0) grad[r.g_off] += dot * inv_n;
+        if (lane == 0) grad[r.g_off] = (ACC ? grad[r.g_off] : 0.f) + dot * inv_n;
         const float k1 = g * inv_n, k2 = dot / ss;
         for (int c = lane; c < r.in_dim; c += 64)
-            grad[r.v_off + c] += k1 * (gblob[gsrc[r.src_off + c]] - v[c] * k2);
+            grad[r.v_off + c] = (ACC ? grad[r.v_off + c] : 0.f) + k1 * (gblob[gsrc[r.src_off + c]] - v[c] * k2);
     }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int i = gid; i < n_bias; i += gridDim.x * blockDim.x) grad[bias_to[i]] += gblob[bias_from[i]];
+    for (int i = gid; i < n_bias; i += gridDim.x * blockDim.x) grad[bias_to[i]] = (ACC ? grad[bias_to[i]] : 0.f) + gblob[bias_from[i]];
 }
 }  // namespace pfm
 
@@ -103,7 +105,18 @@ extern "C" int pfm_wn_unpack_grad(const float* params, const float* gblob, const
     if (!params || !gblob || !rows || !gsrc || !grad || (n_bias > 0 && (!bias_from || !bias_to)))
         return set_err(PFM_E_BADARG, "NULL device pointer");
     if (n_rows <= 0) return 0;
-    hipLaunchKernelGGL(wn_unpack_grad_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, gblob,
+    hipLaunchKernelGGL(wn_unpack_grad_kernel<true>, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, gblob,
+                       reinterpret_cast<const WnRow*>(rows), n_rows, gsrc, bias_from, bias_to, n_bias, grad);
+    return check_hip(hipGetLastError(), "wn_unpack_grad_kernel launch");
+}
+
+extern "C" int pfm_wn_unpack_grad_set(const float* params, const float* gblob, const int32_t* rows, int32_t n_rows,
+                                      const int32_t* gsrc, const int32_t* bias_from, const int32_t* bias_to,
+                                      int32_t n_bias, float* grad, void* stream) {
+    if (!params || !gblob || !rows || !gsrc || !grad || (n_bias > 0 && (!bias_from || !bias_to)))
+        return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(wn_unpack_grad_kernel<false>, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, gblob,
                        reinterpret_cast<const WnRow*>(rows), n_rows, gsrc, bias_from, bias_to, n_bias, grad);
     return check_hip(hipGetLastError(), "wn_unpack_grad_kernel launch");
 }

@@ -119,6 +119,11 @@ class FusedEpicTables:
         self.bias_blob = t(layout.src_dst1[bsrc].astype(np.int32))  # their place in the blob
         self.bias_gblob = t(layout.src_gpos[bsrc].astype(np.int32))  # and in the gradient blob
         self.n_bias = len(bfrom)
+        # do the tables name EVERY element of the flat buffer that belongs to a parameter?  Then the unpack kernel may write (=)
+        # instead of accumulating and the step needs no zeroing launch (padding between parameters is never read as a gradient:
+        # the optimiser multiplies it by nothing that matters -- it stays at its initial 0).
+        self.covers_all = (int(sum(i * o for _, i, o in layout.linears)) + int(sum(o for _, _, o in layout.linears)) + self.n_bias
+                           == sum(p.numel() for p in fp.params))
 
 
 class FusedFMTrainer:
@@ -147,6 +152,12 @@ class FusedFMTrainer:
         self.scratch = torch.zeros(1024, device=dev, dtype=torch.float32)
         self.sync = GradSync(process_group)
         self.step_count = 0
+        # the reference draws t on the CPU generator (losses.py:46); a pageable host tensor lands on the device through a copy that
+        # SYNCHRONISES the stream -- every step would drain the GPU before its first kernel is even queued.  A small ring of pinned
+        # staging buffers + asynchronous copies keeps the host a few steps ahead (same numbers: the draw itself is unchanged).
+        self._t_ring = []
+        self._t_next = 0
+        self._fin_next = 0
         # fully fused path (no autograd): single EPiC flow with an FM-OT / CFM loss.  The transformer's parameters are
         # plain (no weight norm): its autograd node already is two launches + two gathers, so it takes the generic path
         self._fused = None
@@ -155,6 +166,22 @@ class FusedFMTrainer:
                 and not getattr(flows[0].net, "wide", False) and getattr(flows[0], "t_emb", None) != "gaussian":
             self._fused = {}
             flows[0].net._fast_pack = self.packed_blob  # sampling re-packs with one HIP launch instead of ~100 torch ops
+
+    def _land(self, t_cpu: torch.Tensor) -> torch.Tensor:
+        """A small host tensor (the per-jet times) -> device, without a stream synchronisation: through one of 8 pinned slots, each
+        guarded by an event recorded behind its last copy."""
+        dev = self.fp.flat.device
+        n = t_cpu.numel()
+        if not self._t_ring or self._t_ring[0][0].numel() < n:
+            self._t_ring = [(torch.empty(max(n, 1024), dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+        buf, ev = self._t_ring[self._t_next % 8]
+        self._t_next += 1
+        ev.synchronize()  # the copy that last read this slot (8 steps ago) has finished
+        view = buf[:n].view(t_cpu.shape)
+        view.copy_(t_cpu.to(torch.float32))
+        out = view.to(dev, non_blocking=True)
+        ev.record(torch.cuda.current_stream(dev))
+        return out
 
     def current_lr(self) -> float:
         """learning rate of the NEXT optimiser step"""
@@ -235,12 +262,14 @@ class FusedFMTrainer:
         B = x.shape[0]
         condf = None if lay.cfg.global_cond_dim == 0 else cond.to(torch.float32).contiguous()
         maskf = None if mask is None else mask.reshape(B, -1).to(torch.float32).contiguous()  # converted once, used by both kernels
-        fin = st.get("fin")
-        if fin is None:
-            fin = st["fin"] = torch.empty(2, device=x.device, dtype=torch.float32)  # [loss, 1 / sum(mask)]
+        ring = st.get("fin")
+        if ring is None:
+            ring = st["fin"] = torch.empty(16, 2, device=x.device, dtype=torch.float32)  # [loss, 1 / sum(mask)] of the last 16 steps
+        fin = ring[self._fin_next % 16]  # the returned loss is a view into the ring: valid until 16 more steps have been queued
+        self._fin_next += 1
         if kind == "diffusion":
             from .fm_loss import MLE_LOSS_WEIGHT
-            t, z = loss_mod.draw(x, mask)
+            t, z = loss_mod.draw(x, mask, land=self._land)
             sr, nr, beta = hip_ops.diffusion_schedule(t.to(torch.float32), **loss_mod.diff_config)
             jet_w = (1.0 + MLE_LOSS_WEIGHT * (beta / nr)).contiguous()
             parts, count, saved = hip_ops.epic_diffusion_loss_forward(lay, blob, x, t, z, torch.stack([sr, nr], dim=1), cond, maskf,
@@ -249,25 +278,27 @@ class FusedFMTrainer:
             hip_ops.epic_loss_backward(lay, blob, condf, maskf, saved, fin[1:], st["one"], gblob, criterion=loss_mod.criterion, jet_w=jet_w)
         else:
             if kind == "CFM":
-                t, z, eps = loss_mod.draw(x)
+                t, z, eps = loss_mod.draw(x, land=self._land)
             else:
-                (t, z), eps = loss_mod.draw(x), None
+                (t, z), eps = loss_mod.draw(x, land=self._land), None
             parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x, t, z, cond, maskf, loss_mod.sigma, kind, eps)
             _lib.check(lib.pfm_loss_finish(P(parts), P(count), P(None), B, P(fin), S), "pfm_loss_finish")
             hip_ops.epic_loss_backward(lay, blob, condf, maskf, saved, fin[1:], st["one"], gblob)
-        loss = fin[0].clone()  # `fin` is rewritten by the next step
-        _lib.check(lib.pfm_wn_unpack_grad(P(self.fp.flat), P(gblob), P(tb.rows), tb.n_rows, P(tb.gsrc), P(tb.bias_gblob),
-                                          P(tb.bias_param), tb.n_bias, P(self.fp.grad), S), "pfm_wn_unpack_grad")
+        loss = fin[0]
+        unpack = lib.pfm_wn_unpack_grad_set if tb.covers_all else lib.pfm_wn_unpack_grad
+        _lib.check(unpack(P(self.fp.flat), P(gblob), P(tb.rows), tb.n_rows, P(tb.gsrc), P(tb.bias_gblob),
+                          P(tb.bias_param), tb.n_bias, P(self.fp.grad), S), "pfm_wn_unpack_grad")
         return loss
 
     def step(self, batch, fused: bool = True) -> torch.Tensor:
         x, mask, cond = batch
         if not self.fp.is_intact():
             self._rebuild()
-        self.fp.grad.zero_()
         if getattr(getattr(self.module, "hparams", None), "use_normaliser", False):  # training_step's pre-processing (:514-518)
             x, cond = self.module._normalise(x, mask, cond)
         if fused and self._fused is not None and not self.module.flows[0].net.is_wide(x.shape[1]):
+            if not self._fused_state(x.shape[1])["tables"].covers_all:
+                self.fp.grad.zero_()  # (never for the EPiC network: its unpack kernel writes every gradient element)
             loss = self.fused_loss_and_grad(x, mask, cond)
         else:
             self.fp.zero_grad()

@@ -13,6 +13,12 @@ import torch
 import torch.nn as nn
 
 
+def _to_device(t_cpu: torch.Tensor, x: torch.Tensor, land=None) -> torch.Tensor:
+    if land is not None and x.is_cuda and x.dtype == torch.float32:
+        return land(t_cpu)
+    return t_cpu.type_as(x)
+
+
 def _single_flow(flows):
     if len(flows) != 1:
         raise NotImplementedError("n_transforms > 1 is not implemented on the HIP path (every shipped config uses 1)")
@@ -30,9 +36,11 @@ class FlowMatchingLoss(nn.Module):
             raise NotImplementedError(f"criterion {criterion} not supported")
         self.criterion = criterion
 
-    def draw(self, x: torch.Tensor):
-        """losses.py:46-53: t ~ U(0,1) per jet from the CPU generator, z ~ N(0,1) like x."""
-        t = torch.rand_like(torch.ones(x.shape[0])).type_as(x)
+    def draw(self, x: torch.Tensor, land=None):
+        """losses.py:46-53: t ~ U(0,1) per jet from the CPU generator, z ~ N(0,1) like x.  ``land`` (optional): how the host tensor
+        reaches x's device (the fused trainer passes an asynchronous pinned-memory copy; default: ``.type_as(x)`` like the reference,
+        which synchronises the stream)."""
+        t = _to_device(torch.rand_like(torch.ones(x.shape[0])), x, land)
         z = torch.randn_like(x)
         return t, z
 
@@ -51,9 +59,9 @@ class ConditionalFlowMatchingLoss(nn.Module):
         if criterion not in ("mse",):
             raise NotImplementedError(f"criterion {criterion} not supported on the HIP path")
 
-    def draw(self, x: torch.Tensor):
+    def draw(self, x: torch.Tensor, land=None):
         """losses.py:104, 108, 116: t, x_0, then the noise added to mu_t."""
-        t = torch.rand_like(torch.ones(x.shape[0])).type_as(x)
+        t = _to_device(torch.rand_like(torch.ones(x.shape[0])), x, land)
         x0 = torch.randn_like(x)
         eps = torch.randn_like(x)
         return t, x0, eps
@@ -76,9 +84,9 @@ class DroidLoss(nn.Module):
         if criterion not in ("mse", "huber"):
             raise NotImplementedError(f"criterion {criterion} not supported")
 
-    def draw(self, x: torch.Tensor):
-        t = torch.rand_like(torch.ones(x.shape[0])).type_as(x)  # :330
-        z = torch.randn_like(x)                                  # :335
+    def draw(self, x: torch.Tensor, land=None):
+        t = _to_device(torch.rand_like(torch.ones(x.shape[0])), x, land)  # :330
+        z = torch.randn_like(x)                                            # :335
         return t, z
 
     def forward(self, x: torch.Tensor, mask: torch.Tensor = None, cond: torch.Tensor = None) -> torch.Tensor:
@@ -103,9 +111,9 @@ class DiffusionLoss(nn.Module):
             raise NotImplementedError(f"criterion {criterion} not supported")
         self.criterion = criterion
 
-    def draw(self, x: torch.Tensor, mask: torch.Tensor):
-        t = torch.rand_like(torch.ones(x.shape[0])).type_as(x)  # :241-243
-        z = torch.randn_like(x) * mask                           # :247
+    def draw(self, x: torch.Tensor, mask: torch.Tensor, land=None):
+        t = _to_device(torch.rand_like(torch.ones(x.shape[0])), x, land)  # :241-243
+        z = torch.randn_like(x) * mask                                     # :247
         return t, z
 
     def forward(self, x: torch.Tensor, mask: torch.Tensor = None, cond: torch.Tensor = None) -> torch.Tensor:
