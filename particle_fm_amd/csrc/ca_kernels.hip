@@ -511,7 +511,10 @@ struct Bwd {
         a.Z = Z; a.X = X; a.jet_out = jet_out; a.gblob = gblob; a.gb = gb;
         a.jet_stride = (int64_t)(2 * p.d->layers + 2) * p.d->hidden;
         a.ldz = ldz; a.NO = NO; a.N = group; a.F = F; a.rows = rows;
-        hipLaunchKernelGGL(tf_colsum_kernel, dim3((unsigned)((rows + group - 1) / group), X ? F : 1, (NO + 767) / 768), dim3(256), 0, p.s, a);
+        const int ny = X ? F : 1, ngrp = (int)((rows + group - 1) / group);
+        a.part = gb >= 0 ? sc + b.dwpart : nullptr;  // (free between two dW launches; every launch on p.s: stream order)
+        hipLaunchKernelGGL(tf_colsum_kernel, dim3((unsigned)ngrp, ny, (NO + 767) / 768), dim3(256), 0, p.s, a);
+        if (gb >= 0) launch_ordered_sum(p.s, a.part, ngrp, (int64_t)ny * NO, ny * NO, gblob + gb, ny * NO, nullptr);
         return check_hip(hipGetLastError(), "tf_colsum_kernel launch (ca)");
     }
     // dW += Z^T LN(A) over `rows` rows (ln == nullptr: no LayerNorm prologue)
@@ -551,6 +554,7 @@ struct Bwd {
         a.A = A; a.G = G; a.add = add; a.out = out; a.blob = p.blob; a.gblob = gblob;
         a.gamma = ln.gamma; a.beta = ln.beta; a.M = rows; a.K = K; a.act = act ? 1 : 0;
         a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
+        a.part = sc + b.dwpart;  // d gamma | d beta: per-workgroup partials, summed in block order (no atomics)
         const dim3 g((rows + 63) / 64), bl(256);
         switch (K / 64) {
             case 2: hipLaunchKernelGGL(tf_ln_bwd_kernel<2>, g, bl, 0, p.s, a); break;
@@ -558,6 +562,7 @@ struct Bwd {
             case 6: hipLaunchKernelGGL(tf_ln_bwd_kernel<6>, g, bl, 0, p.s, a); break;
             default: hipLaunchKernelGGL(tf_ln_bwd_kernel<8>, g, bl, 0, p.s, a); break;
         }
+        launch_ordered_sum(p.s, a.part, (int)g.x, 2 * (int64_t)K, 2 * K, gblob + ln.gamma, K, gblob + ln.beta);
         return check_hip(hipGetLastError(), "tf_ln_bwd_kernel launch (ca)");
     }
     // the block  q <- q + out(LN_a(att));  q <- q + d2(LN_d(lrelu(d1(LN2(q)) + jet bias)))  of one cross-attention layer,
@@ -616,6 +621,7 @@ int run_backward(const Bwd& B, const float* cond, const float* mask, const float
         a.blob = p.blob; a.gblob = B.gblob;
         a.gamma = d.o_norm.gamma; a.beta = d.o_norm.beta; a.W3 = d.o2.W; a.b3 = d.o2.b;
         a.M = p.M; a.K = Hd; a.F = F; a.eps = d.ln_eps;
+        a.part = sc + b.dwpart;
         const dim3 g((p.M + 15) / 16), bl(256);
         switch (Hd / 64) {
             case 2: hipLaunchKernelGGL(tf_head_bwd_kernel<2>, g, bl, 0, p.s, a); break;
@@ -623,6 +629,7 @@ int run_backward(const Bwd& B, const float* cond, const float* mask, const float
             case 6: hipLaunchKernelGGL(tf_head_bwd_kernel<6>, g, bl, 0, p.s, a); break;
             default: hipLaunchKernelGGL(tf_head_bwd_kernel<8>, g, bl, 0, p.s, a); break;
         }
+        launch_ordered_sum(p.s, a.part, (int)g.x, 16, F, B.gblob + d.o2.b, F, nullptr);
         PFM_TRY(check_hip(hipGetLastError(), "tf_head_bwd_kernel launch (ca)"));
         PFM_TRY(B.colsum(gh2, Hd, Hd, p.M, N, sc + b.dv, F, nullptr, d.o2.W));
         PFM_TRY(B.lnbwd(p.M, ws + w.oh, Hd, gkv, nullptr, gh, d.o_norm, true));
@@ -819,7 +826,7 @@ int pfm_ca_fm_loss_forward(const pfm_ca_desc* d, const float* blob, int32_t kind
     tf::HeadArgs h{};
     h.dst = v_out;
     if ((rc = ca::run_nfe(p, t, 1, y_out, cond, mask, h))) return rc;
-    hipLaunchKernelGGL(tf::tf_loss_kernel, dim3(256), dim3(256), 0, p.s, (const float*)v_out, (const float*)u_out, mask, loss_sums, n,
+    hipLaunchKernelGGL(tf::tf_loss_kernel, dim3(1), dim3(tf::LOSS_T), 0, p.s, (const float*)v_out, (const float*)u_out, mask, loss_sums, n,
                        (int64_t)p.M);
     return check_hip(hipGetLastError(), "tf_loss_kernel launch");
 }

@@ -629,7 +629,10 @@ struct Bwd {
         ColsumArgs a;
         a.Z = Z; a.X = X; a.jet_out = jet_out; a.gblob = gblob; a.gb = gb; a.jet_stride = jet_stride;
         a.ldz = ldz; a.NO = NO; a.N = group; a.F = X ? 16 : 1; a.rows = rows;
-        hipLaunchKernelGGL(tf_colsum_kernel, dim3((unsigned)((rows + group - 1) / group), X ? F : 1, (NO + 767) / 768), dim3(256), 0, p.s, a);
+        const int ny = X ? F : 1, ngrp = (int)((rows + group - 1) / group);
+        a.part = gb >= 0 ? sc + b.dwpart : nullptr;  // (free between two dW launches; every launch on p.s: stream order)
+        hipLaunchKernelGGL(tf_colsum_kernel, dim3((unsigned)ngrp, ny, (NO + 767) / 768), dim3(256), 0, p.s, a);
+        if (gb >= 0) launch_ordered_sum(p.s, a.part, ngrp, (int64_t)ny * NO, ny * NO, gblob + gb, ny * NO, nullptr);
         return check_hip(hipGetLastError(), "tf_colsum_kernel launch (epicw)");
     }
     // gblob[W] += Z^T [A | A2]
@@ -748,7 +751,9 @@ int run_backward(const Bwd& W, const float* mask, const float* y, const float* u
     {
         ColsumArgs a;  // d fc_l1 particle columns [F][Hp] = sum_rows y[row][f] dZ1[row][:]
         a.Z = dT; a.X = y; a.jet_out = nullptr; a.gblob = W.gblob; a.gb = d.l1x; a.jet_stride = 0; a.ldz = Hp; a.NO = Hp; a.N = N; a.F = F; a.rows = 0;
+        a.part = W.sc + W.b.dwpart;  // per-jet sums, added over the jets in jet order (no atomics)
         hipLaunchKernelGGL(tf_colsum_kernel, dim3(B, F, 1), dim3(256), 0, p.s, a);
+        launch_ordered_sum(p.s, a.part, B, (int64_t)F * Hp, F * Hp, W.gblob + d.l1x, F * Hp, nullptr);
         PFM_TRY(check_hip(hipGetLastError(), "tf_colsum_kernel launch (fc_l1)"));
     }
     // static jet-bias GEMM (the 112 padding columns of the fc_l3 block of DSJB were never written: clear them first)
@@ -925,7 +930,7 @@ static int ew_loss_forward(const pfm_ew_desc* d, const float* blob, int32_t kind
     ew::HeadArgs h{};
     h.dst = v_out;
     if ((rc = ew::run_nfe(p, t, 1, y_out, cond, mask, h))) return rc;
-    hipLaunchKernelGGL(tf_loss_kernel, dim3(256), dim3(256), 0, p.s, (const float*)v_out, (const float*)u_out, mask, loss_sums, n,
+    hipLaunchKernelGGL(tf_loss_kernel, dim3(1), dim3(LOSS_T), 0, p.s, (const float*)v_out, (const float*)u_out, mask, loss_sums, n,
                        (int64_t)p.M, crit, jet_w, d->n_points * d->features);
     return check_hip(hipGetLastError(), "tf_loss_kernel launch");
 }

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void mdma_head_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mask, const float* __restrict__ gscale,
                                                             const float* __restrict__ blob, int64_t W, float* __restrict__ gblob, int64_t gb,
                                                             float* __restrict__ dvrow, float* __restrict__ zact, float* __restrict__ gX,
-                                                            int M, int F, float slope) {
+                                                            int M, int F, float slope, float* __restrict__ part) {  // part[gridDim.x]: the
+    // workgroups' partial sums of the head's bias gradient (added in block order by launch_ordered_sum: no atomics)
     constexpr int H = 64 * NI;
     __shared__ float red[16];
     const int tid = threadIdx.x, pl = tid & 15;
@@ -310,7 +311,8 @@ __global__ __launch_bounds__(256) void mdma_head_bwd_kernel(const float* __restr
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += red[i];
-        atomicAdd(gblob + gb, t);
+        if (part) part[blockIdx.x] = t;
+        else atomicAdd(gblob + gb, t);
     }
 }
 
@@ -602,7 +604,10 @@ struct Bwd {
         ColsumArgs a;
         a.Z = Z; a.X = X; a.jet_out = jet_out; a.gblob = gblob; a.gb = gb; a.jet_stride = NO;
         a.ldz = NO; a.NO = NO; a.N = p.d->n_points; a.F = F; a.rows = p.M;
-        hipLaunchKernelGGL(tf_colsum_kernel, dim3(p.n_jets, X ? F : 1, (NO + 767) / 768), dim3(256), 0, p.s, a);
+        const int ny = X ? F : 1;
+        a.part = gb >= 0 ? sc + b.dwpart : nullptr;  // (free between two dW launches; every launch on p.s: stream order)
+        hipLaunchKernelGGL(tf_colsum_kernel, dim3(p.n_jets, ny, (NO + 767) / 768), dim3(256), 0, p.s, a);
+        if (gb >= 0) launch_ordered_sum(p.s, a.part, p.n_jets, (int64_t)ny * NO, ny * NO, gblob + gb, ny * NO, nullptr);
         return check_hip(hipGetLastError(), "tf_colsum_kernel launch (mdma)");
     }
     int dw(const float* Z, int NO, const float* A, int K, int64_t gW, bool pre_act) const {
@@ -649,7 +654,8 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
     float* gxc[2] = {sc + b.gxc, sc + b.gxc + round64((int64_t)B * L)};
     int rc;
     PFM_MDMA_NI(mdma_head_bwd_kernel, dim3((p.M + 15) / 16), (const float*)p.X(d.layers), v, u, mask, gscale, p.blob, d.out_W, Bw.gblob,
-                d.out_b, sc + b.dvrow, sc + b.zact, gX, p.M, F, d.neg_slope);
+                d.out_b, sc + b.dvrow, sc + b.zact, gX, p.M, F, d.neg_slope, sc + b.dwpart);
+    launch_ordered_sum(p.s, sc + b.dwpart, (p.M + 15) / 16, 1, 1, Bw.gblob + d.out_b, 1, nullptr);
     PFM_TRY(check_hip(hipGetLastError(), "mdma_head_bwd_kernel launch"));
     PFM_TRY(Bw.colsum(sc + b.zact, H, sc + b.dvrow, 1, nullptr, d.out_W));
     int cur = 0;  // gxc[cur]: d loss / d x_cls_out of the block being processed (none for the last block)
@@ -807,7 +813,7 @@ int pfm_mdma_fm_loss_forward(const pfm_mdma_desc* d, const float* blob, int32_t 
                        d->n_points * d->features, d->features);
     if ((rc = check_hip(hipGetLastError(), "tf_yu_kernel launch (mdma)"))) return rc;
     if ((rc = run_nfe(p, t, 1, y_out, mask, v_out))) return rc;
-    hipLaunchKernelGGL(tf_loss_kernel, dim3(256), dim3(256), 0, p.s, (const float*)v_out, (const float*)u_out, mask, loss_sums, n,
+    hipLaunchKernelGGL(tf_loss_kernel, dim3(1), dim3(LOSS_T), 0, p.s, (const float*)v_out, (const float*)u_out, mask, loss_sums, n,
                        (int64_t)p.M, 0, (const float*)nullptr, 1);
     return check_hip(hipGetLastError(), "tf_loss_kernel launch (mdma)");
 }

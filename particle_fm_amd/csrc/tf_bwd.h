@@ -52,31 +52,78 @@ static __global__ void tf_yu_kernel(int kind, float sigma, const float* __restri
 }
 
 // sums[0] += sum w_jet crit(v-u) ; sums[1] += sum mask.  crit 0: d^2, 1: huber (delta 1); jet_w (or NULL = 1): per-jet weight,
-// NF = floats per jet (DiffusionLoss, losses.py:275-288)
-static __global__ __launch_bounds__(256) void tf_loss_kernel(const float* __restrict__ v, const float* __restrict__ u,
-                                                      const float* __restrict__ mask, float* __restrict__ sums,
-                                                      int64_t n, int64_t rows, int crit = 0, const float* __restrict__ jet_w = nullptr,
-                                                      int NF = 1) {
-    __shared__ float red[8];
-    float sq = 0.f, mc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+// NF = floats per jet (DiffusionLoss, losses.py:275-288).  ONE workgroup of 1024 threads, sums in a fixed order (thread-strided
+// partial sums, wave tree, the 16 wave sums in wave order): the loss is a pure function of v, u, mask -- bit for bit, run to run.
+// (Launch with grid 1: LOSS_T threads.)
+constexpr int LOSS_T = 1024;
+static __global__ __launch_bounds__(LOSS_T) void tf_loss_kernel(const float* __restrict__ v, const float* __restrict__ u,
+                                                         const float* __restrict__ mask, float* __restrict__ sums,
+                                                         int64_t n, int64_t rows, int crit = 0, const float* __restrict__ jet_w = nullptr,
+                                                         int NF = 1) {
+    __shared__ float red[2 * (LOSS_T / 64)];
+    float sq[4] = {0.f, 0.f, 0.f, 0.f}, mc = 0.f;
+    auto term = [&](int64_t i) {
         const float d = v[i] - u[i];
         if (crit || jet_w) {
             const float c = crit ? (fabsf(d) < 1.0f ? 0.5f * d * d : fabsf(d) - 0.5f) : d * d;
-            sq = fmaf(c, jet_w ? jet_w[i / NF] : 1.0f, sq);
-        } else {
-            sq = fmaf(d, d, sq);
+            return c * (jet_w ? jet_w[i / NF] : 1.0f);
         }
-        if (i < rows) mc += mask ? mask[i] : 1.0f;
+        return d * d;
+    };
+    int64_t i = threadIdx.x;
+    for (; i + 3 * LOSS_T < n; i += 4 * LOSS_T) {  // four independent chains: the loads of a round are in flight together
+        sq[0] += term(i); sq[1] += term(i + LOSS_T); sq[2] += term(i + 2 * LOSS_T); sq[3] += term(i + 3 * LOSS_T);
     }
-    sq = wave_sum(sq);
+    for (; i < n; i += LOSS_T) sq[0] += term(i);
+    for (int64_t r = threadIdx.x; r < rows; r += LOSS_T) mc += mask ? mask[r] : 1.0f;
+    float s = wave_sum((sq[0] + sq[1]) + (sq[2] + sq[3]));
     mc = wave_sum(mc);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sq; red[4 + (threadIdx.x >> 6)] = mc; }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[LOSS_T / 64 + (threadIdx.x >> 6)] = mc; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(sums, red[0] + red[1] + red[2] + red[3]);
-        atomicAdd(sums + 1, red[4] + red[5] + red[6] + red[7]);
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < LOSS_T / 64; ++w) { a += red[w]; b += red[LOSS_T / 64 + w]; }
+        sums[0] += a;
+        sums[1] += b;
     }
+}
+
+// out[c] += sum_{p < P} part[p * stride + c] for c < n, the partials added in a fixed order (P cut into `R` contiguous ranges, one
+// per thread row; a range summed with 8 loads in flight; the R range sums joined through LDS in range order): what replaces the
+// fp32 atomicAdd of per-workgroup partial sums -- LayerNorm gamma / beta, bias and column sums -- so that every parameter gradient
+// is a pure function of the inputs.  Columns c < n0 go to out0[c], the others to out1[c - n0].  256 threads: C columns x R ranges.
+template <int C>
+static __global__ __launch_bounds__(256) void tf_ordered_sum_kernel(const float* __restrict__ part, int P, int64_t stride, int n,
+                                                                    float* __restrict__ out0, int n0, float* __restrict__ out1) {
+    constexpr int R = 256 / C;
+    __shared__ float comb[256];
+    const int cl = threadIdx.x % C, r = threadIdx.x / C;
+    const int c = blockIdx.x * C + cl;
+    const bool live = c < n;
+    int p = (int)((int64_t)P * r / R);
+    const int pend = live ? (int)((int64_t)P * (r + 1) / R) : p;
+    const float* pp = part + (live ? c : 0);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (; p + 8 <= pend; p += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += pp[(int64_t)(p + k) * stride];
+    }
+    for (; p < pend; ++p) s[0] += pp[(int64_t)p * stride];
+    comb[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (r == 0 && live) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < R; ++k) t += comb[k * C + cl];
+        if (c < n0) out0[c] += t;
+        else out1[c - n0] += t;
+    }
+}
+// (the caller checks hipGetLastError)
+static inline void launch_ordered_sum(hipStream_t s, const float* part, int P, int64_t stride, int n, float* out0, int n0, float* out1) {
+    if (n <= 0 || P <= 0) return;
+    if (n <= 16) hipLaunchKernelGGL(tf_ordered_sum_kernel<16>, dim3((n + 15) / 16), dim3(256), 0, s, part, P, stride, n, out0, n0, out1);
+    else hipLaunchKernelGGL(tf_ordered_sum_kernel<64>, dim3((n + 63) / 64), dim3(256), 0, s, part, P, stride, n, out0, n0, out1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -114,6 +161,8 @@ struct LnBwdArgs {
     int64_t gamma, beta;
     int M, K, act;
     float slope, eps;
+    float* part;         // [gridDim.x][2 K] per-workgroup partial sums of d gamma | d beta (summed in block order by
+                         // launch_ordered_sum), or nullptr: fp32 atomics on gblob (order, hence the last bits, vary run to run)
 };
 
 template <int NI>
@@ -184,7 +233,8 @@ __global__ __launch_bounds__(256) void tf_ln_bwd_kernel(LnBwdArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += red[r * a.K + c];
-            atomicAdd(a.gblob + (which ? a.beta : a.gamma) + c, s);
+            if (a.part) a.part[(int64_t)blockIdx.x * 2 * a.K + which * a.K + c] = s;
+            else atomicAdd(a.gblob + (which ? a.beta : a.gamma) + c, s);
         }
     }
 }
@@ -200,14 +250,14 @@ struct HeadBwdArgs {
     int64_t gamma, beta, W3, b3;
     int M, K, F;
     float eps;
+    float* part;      // [gridDim.x][16] per-workgroup partial sums of d b3 (launch_ordered_sum), or nullptr: atomics
 };
 
 template <int NI>
 __global__ __launch_bounds__(256) void tf_head_bwd_kernel(HeadBwdArgs a) {
     __shared__ float db3[16];
+    __shared__ float drow[16][16];  // [row of the workgroup][f]: summed over the rows in row order (no LDS atomics)
     const int tid = threadIdx.x, pl = tid & 15;
-    if (tid < 16) db3[tid] = 0.f;
-    __syncthreads();
     const int row = blockIdx.x * 16 + (tid >> 4);
     const bool ok = row < a.M;
     const int64_t ro = (int64_t)min(row, a.M - 1) * a.K + 4 * pl;
@@ -239,7 +289,7 @@ __global__ __launch_bounds__(256) void tf_head_bwd_kernel(HeadBwdArgs a) {
     for (int f = 0; f < a.F; ++f) {
         const int64_t e = (int64_t)min(row, a.M - 1) * a.F + f;
         const float d = ok ? 2.0f * (a.v[e] - a.u[e]) * gs : 0.f;
-        if (pl == 0 && ok) { a.dv[e] = d; atomicAdd(db3 + f, d); }
+        if (pl == 0) { if (ok) a.dv[e] = d; drow[tid >> 4][f] = d; }
 #pragma unroll
         for (int i = 0; i < NI; ++i)
                 dn[i] += d * *reinterpret_cast<const f32x4*>(a.blob + a.W3 + (int64_t)f * a.K + 4 * pl + 64 * i);
@@ -250,7 +300,14 @@ __global__ __launch_bounds__(256) void tf_head_bwd_kernel(HeadBwdArgs a) {
             *reinterpret_cast<f32x4*>(a.dn + ro + 64 * i) = dn[i];
     }
     __syncthreads();
-    if (tid < a.F) atomicAdd(a.gblob + a.b3 + tid, db3[tid]);
+    if (tid < a.F) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += drow[r][tid];
+        if (a.part) a.part[(int64_t)blockIdx.x * 16 + tid] = t;
+        else atomicAdd(a.gblob + a.b3 + tid, t);
+    }
+    (void)db3;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -265,6 +322,7 @@ struct ColsumArgs {
     int64_t jet_stride;
     int ldz, NO, N, F;
     int64_t rows;       // total rows of Z (the last group may be short); 0: every group has N rows
+    float* part;        // [jets][gridDim.y][NO] per-jet sums for the sum over all jets (launch_ordered_sum), or nullptr: atomics
 };
 
 static __global__ __launch_bounds__(256) void tf_colsum_kernel(ColsumArgs a) {
@@ -291,7 +349,10 @@ static __global__ __launch_bounds__(256) void tf_colsum_kernel(ColsumArgs a) {
     for (int c = tid; c < ncol; c += 256) {
         const float s = (red[c] + red[768 + c]) + (red[2 * 768 + c] + red[3 * 768 + c]);
         if (a.jet_out) a.jet_out[(int64_t)jet * a.jet_stride + col0 + c] = s;
-        if (a.gb >= 0) atomicAdd(a.gblob + a.gb + (int64_t)f * a.NO + col0 + c, s);
+        if (a.gb >= 0) {
+            if (a.part) a.part[((int64_t)jet * gridDim.y + f) * a.NO + col0 + c] = s;
+            else atomicAdd(a.gblob + a.gb + (int64_t)f * a.NO + col0 + c, s);
+        }
     }
 }
 

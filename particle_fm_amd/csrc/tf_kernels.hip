@@ -209,7 +209,10 @@ struct Bwd {
         a.Z = Z; a.X = X; a.jet_out = jet_out; a.gblob = gblob; a.gb = gb;
         a.jet_stride = (int64_t)(p.d->layers + 2) * p.d->hidden;
         a.ldz = ldz; a.NO = NO; a.N = p.d->n_points; a.F = F; a.rows = 0;
-        hipLaunchKernelGGL(tf_colsum_kernel, dim3(p.n_jets, X ? F : 1, (NO + 767) / 768), dim3(256), 0, p.s, a);
+        const int ny = X ? F : 1;
+        a.part = gb >= 0 ? sc + b.dwpart : nullptr;  // (free between two dW launches; every launch on p.s: stream order)
+        hipLaunchKernelGGL(tf_colsum_kernel, dim3(p.n_jets, ny, (NO + 767) / 768), dim3(256), 0, p.s, a);
+        if (gb >= 0) launch_ordered_sum(p.s, a.part, p.n_jets, (int64_t)ny * NO, ny * NO, gblob + gb, ny * NO, nullptr);
         return check_hip(hipGetLastError(), "tf_colsum_kernel launch");
     }
     int rowstats(const float* A, int K) const {
@@ -252,6 +255,7 @@ struct Bwd {
         a.A = A; a.G = G; a.add = add; a.out = out; a.blob = p.blob; a.gblob = gblob;
         a.gamma = ln.gamma; a.beta = ln.beta; a.M = p.M; a.K = K; a.act = act ? 1 : 0;
         a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
+        a.part = sc + b.dwpart;  // d gamma | d beta: per-workgroup partials, summed in block order (no atomics)
         const dim3 g((p.M + 63) / 64), bl(256);
         switch (K / 64) {
             case 2: hipLaunchKernelGGL(tf_ln_bwd_kernel<2>, g, bl, 0, p.s, a); break;
@@ -259,6 +263,7 @@ struct Bwd {
             case 6: hipLaunchKernelGGL(tf_ln_bwd_kernel<6>, g, bl, 0, p.s, a); break;
             default: hipLaunchKernelGGL(tf_ln_bwd_kernel<8>, g, bl, 0, p.s, a); break;
         }
+        launch_ordered_sum(p.s, a.part, (int)g.x, 2 * (int64_t)K, 2 * K, gblob + ln.gamma, K, gblob + ln.beta);
         return check_hip(hipGetLastError(), "tf_ln_bwd_kernel launch");
     }
 };
@@ -284,6 +289,7 @@ int run_backward(const Bwd& B, const float* cond, const float* mask, const float
         a.blob = p.blob; a.gblob = B.gblob;
         a.gamma = d.o_norm.gamma; a.beta = d.o_norm.beta; a.W3 = d.o2.W; a.b3 = d.o2.b;
         a.M = p.M; a.K = Hd; a.F = F; a.eps = d.ln_eps;
+        a.part = sc + b.dwpart;
         const dim3 g((p.M + 15) / 16), bl(256);
         switch (Hd / 64) {
             case 2: hipLaunchKernelGGL(tf_head_bwd_kernel<2>, g, bl, 0, p.s, a); break;
@@ -291,6 +297,7 @@ int run_backward(const Bwd& B, const float* cond, const float* mask, const float
             case 6: hipLaunchKernelGGL(tf_head_bwd_kernel<6>, g, bl, 0, p.s, a); break;
             default: hipLaunchKernelGGL(tf_head_bwd_kernel<8>, g, bl, 0, p.s, a); break;
         }
+        launch_ordered_sum(p.s, a.part, (int)g.x, 16, F, B.gblob + d.o2.b, F, nullptr);
         PFM_TRY(check_hip(hipGetLastError(), "tf_head_bwd_kernel launch"));
         PFM_TRY(B.colsum(gh2, Hd, Hd, sc + b.dv, F, nullptr, d.o2.W));
         PFM_TRY(B.lnbwd(ws + w.oh, Hd, gqkv, nullptr, gh, d.o_norm, true));
@@ -551,7 +558,7 @@ int pfm_tf_fm_loss_forward(const pfm_tf_desc* d, const float* blob, int32_t kind
     HeadArgs h{};
     h.dst = v_out;
     if ((rc = run_nfe(p, t, 1, y_out, cond, mask, h))) return rc;
-    hipLaunchKernelGGL(tf_loss_kernel, dim3(256), dim3(256), 0, p.s, (const float*)v_out, (const float*)u_out, mask, loss_sums, n,
+    hipLaunchKernelGGL(tf_loss_kernel, dim3(1), dim3(LOSS_T), 0, p.s, (const float*)v_out, (const float*)u_out, mask, loss_sums, n,
                        (int64_t)p.M);
     return check_hip(hipGetLastError(), "tf_loss_kernel launch");
 }
