@@ -344,13 +344,16 @@ def main():
     # its kernels queue behind sampler workgroups for a free CU, so `train_ms` there is mostly waiting
     t0e, t1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
+    TRAIN_ALONE_REPS = 20  # (3 were too few: the first step's host-side enqueue time sat in the average, 0.80 instead of 0.65 ms)
     with torch.cuda.stream(main):
-        t0e.record(main)
         for _ in range(3):
+            trainer.step((x, mask, cond))
+        t0e.record(main)
+        for _ in range(TRAIN_ALONE_REPS):
             trainer.step((x, mask, cond))
         t1e.record(main)
     torch.cuda.synchronize(dev)
-    train_alone_ms = t0e.elapsed_time(t1e) / 3
+    train_alone_ms = t0e.elapsed_time(t1e) / TRAIN_ALONE_REPS
     # the gradient exchange alone (N > 1): the flat 2.2 MB all-reduce on the train stream, 10 in a row
     allreduce_alone_ms = 0.0
     if world > 1:
