@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-/* 2 (round 3): pfm_local_lin.A16 / pfm_epic_desc.l3_A16 (bf16 copies of the particle blocks in the blob); pfm_epic_fm_loss_backward / pfm_epic_diffusion_loss_backward take a `scratch` pointer in front of `stream` and WRITE
+/* 2 (round 3): the loss forward / backward entry points take a jet launch order; pfm_local_lin.A16 / pfm_epic_desc.l3_A16 (bf16 copies of the particle blocks in the blob); pfm_epic_fm_loss_backward / pfm_epic_diffusion_loss_backward take a `scratch` pointer in front of `stream` and WRITE
  * grad_blob (round 2 changed both under version 1: a caller or a stale library built against that header must be refused) */
 #define PFM_ABI_VERSION 2
 #define PFM_MAX_LAYERS 24
@@ -239,7 +239,13 @@ int pfm_epic_sample_rk_temb(const pfm_epic_desc *desc, const float *blob, const 
 int pfm_epic_fm_loss_forward(const pfm_epic_desc *desc, const float *blob, int32_t kind, float sigma,
                              const float *t, const float *x, const float *z, const float *eps,
                              const float *cond, const float *mask, float *saved, float *loss_parts,
-                             float *mask_count, int32_t B, void *stream);
+                             float *mask_count, int32_t B, const int32_t *order, void *stream);
+
+/* Launch order of the jets of a training call: order[rank] = jet, descending multiplicity (ties by index; one small launch).
+ * Every loss forward / backward entry point of this header takes `order` (device, B int32, or NULL = batch order): a jet's run
+ * time grows with its valid particles and workgroups are dispatched in order, so with more jets than CUs the short jets fill the
+ * tail of the launch instead of a long jet starting last.  Scheduling only: every jet writes its own records, results unchanged. */
+int pfm_epic_jet_order(const float *mask, int32_t B, int32_t n_points, int32_t *order, void *stream);
 
 /* Backward of the above w.r.t. the blob: grad_blob = d(loss)/d(blob) with loss = sum(loss_parts)/sum(mask_count)
  * scaled by grad_scale (the incoming dL).  inv_mask_total = 1/sum(mask_count) is passed as a device scalar.
@@ -253,17 +259,18 @@ int64_t pfm_epic_backward_scratch_floats(const pfm_epic_desc *desc, int32_t B);
 int pfm_epic_fm_loss_backward(const pfm_epic_desc *desc, const float *blob, const float *t,
                               const float *cond, const float *mask, const float *saved,
                               const float *inv_mask_total, const float *grad_scale, float *grad_blob,
-                              int32_t B, float *scratch, void *stream);
+                              int32_t B, float *scratch, const int32_t *order, void *stream);
 
 /* The same two with the time embedding supplied by the caller, temb[B][T] (t_emb="gaussian": a small trainable network in front of
  * the field, flow_matching_module.py:178-181, 213-221; t is still needed for the interpolation y, u): the backward also returns
  * grad_temb[B][T] = d(loss)/d(temb) * grad_scale, from which the caller's autograd continues into that network. */
 int pfm_epic_fm_loss_forward_temb(const pfm_epic_desc *desc, const float *blob, int32_t kind, float sigma, const float *t,
                                   const float *temb, const float *x, const float *z, const float *eps, const float *cond,
-                                  const float *mask, float *saved, float *loss_parts, float *mask_count, int32_t B, void *stream);
+                                  const float *mask, float *saved, float *loss_parts, float *mask_count, int32_t B,
+                                  const int32_t *order, void *stream);
 int pfm_epic_fm_loss_backward_temb(const pfm_epic_desc *desc, const float *blob, const float *cond, const float *mask,
                                    const float *saved, const float *inv_mask_total, const float *grad_scale, float *grad_blob,
-                                   float *grad_temb, int32_t B, float *scratch, void *stream);
+                                   float *grad_temb, int32_t B, float *scratch, const int32_t *order, void *stream);
 
 /* The scalar tail of the losses above (losses.py:75-76: sum / mask.sum()) in one launch: out2[0] = sum_b w_b loss_parts[b] /
  * sum_b mask_count[b] (w = jet_weight, or 1 if NULL), out2[1] = 1 / sum_b mask_count[b] (the inv_mask_total of the backward).
@@ -276,12 +283,13 @@ int pfm_loss_finish(const float *loss_parts, const float *mask_count, const floa
  * (the caller applies the per-jet weight 1 + 0.001 beta / noise_rate, losses.py:275-281); the rest as pfm_epic_fm_loss_forward. */
 int pfm_epic_diffusion_loss_forward(const pfm_epic_desc *desc, const float *blob, int32_t criterion, const float *rates,
                                     const float *t, const float *x, const float *z, const float *cond, const float *mask,
-                                    float *saved, float *loss_parts, float *mask_count, int32_t B, void *stream);
+                                    float *saved, float *loss_parts, float *mask_count, int32_t B, const int32_t *order, void *stream);
 
 /* Backward of loss = sum_b jet_weight[b] * loss_parts[b] / sum(mask_count), as pfm_epic_fm_loss_backward. */
 int pfm_epic_diffusion_loss_backward(const pfm_epic_desc *desc, const float *blob, int32_t criterion, const float *jet_weight,
                                      const float *cond, const float *mask, const float *saved, const float *inv_mask_total,
-                                     const float *grad_scale, float *grad_blob, int32_t B, float *scratch, void *stream);
+                                     const float *grad_scale, float *grad_blob, int32_t B, float *scratch, const int32_t *order,
+                                     void *stream);
 
 /* One in-place state update of the diffusion samplers (models/components/solver.py): mode 0 = ddim_sampler :81-93
  * (c = noise rate, signal rate, next signal rate, next noise rate; data_out, optional, receives the predicted data),

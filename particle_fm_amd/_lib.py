@@ -37,15 +37,16 @@ SYMBOLS = {
         c_int, [POINTER(EpicDesc), _fp, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_epic_sample_rk_temb": (c_int, [POINTER(EpicDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_epic_fm_loss_forward_temb": (
-        c_int, [POINTER(EpicDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
+        c_int, [POINTER(EpicDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_epic_fm_loss_backward_temb": (
-        c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+        c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
+    "pfm_epic_jet_order": (c_int, [_fp, c_int32, c_int32, _fp, c_void_p]),
     "pfm_epic_fm_loss_forward": (
-        c_int, [POINTER(EpicDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
+        c_int, [POINTER(EpicDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_epic_backward_scratch_floats": (c_int64, [POINTER(EpicDesc), c_int32]),
     "pfm_loss_finish": (c_int, [_fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_epic_fm_loss_backward": (
-        c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+        c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
     "pfm_optim_step": (
         c_int, [_fp, _fp, _fp, _fp, _fp, _fp, c_int64, c_float, c_float, c_float, c_float, c_float, c_float,
                 c_float, c_float, c_int32, c_void_p]),
@@ -57,9 +58,9 @@ SYMBOLS = {
     "pfm_epic_sample_rk_scratch_floats": (c_int64, [POINTER(EpicDesc), c_int32, c_int32, c_int32]),
     "pfm_epic_sample_rk_sized": (c_int, [POINTER(EpicDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_int64, _fp, c_void_p]),
     "pfm_epic_diffusion_loss_forward": (
-        c_int, [POINTER(EpicDesc), _fp, c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, c_void_p]),
+        c_int, [POINTER(EpicDesc), _fp, c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_epic_diffusion_loss_backward": (
-        c_int, [POINTER(EpicDesc), _fp, c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+        c_int, [POINTER(EpicDesc), _fp, c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
     "pfm_norm_update": (c_int, [_fp, _fp, c_int64, c_int32, _fp, _fp, _fp, _fp, c_int64, c_void_p]),
     "pfm_norm_apply": (c_int, [_fp, _fp, _fp, c_int64, c_int32, _fp, _fp, c_int32, c_void_p]),
     "pfm_diffusion_update": (c_int, [c_int32, _fp, _fp, _fp, c_float, c_float, c_float, c_float, _fp, c_int64, c_void_p]),

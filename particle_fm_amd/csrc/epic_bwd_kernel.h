@@ -34,13 +34,14 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     const float* __restrict__ blob, int64_t desc_off, const float* __restrict__ cond,
     const float* __restrict__ mask, const float* __restrict__ saved, const float* __restrict__ inv_mask_total,
     const float* __restrict__ grad_scale, float* __restrict__ work, BwdWork bw, int crit, const float* __restrict__ jet_w,
-    float* __restrict__ dtemb) {  // dtemb (or NULL): [B][T] gradient w.r.t. a caller-supplied time embedding
+    float* __restrict__ dtemb,        // dtemb (or NULL): [B][T] gradient w.r.t. a caller-supplied time embedding
+    const int* __restrict__ order) {  // order (or NULL): launch order of the jets, longest first (pfm_epic_jet_order)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
     const BCarve c = make_bcarve(j.N, j.F);
     const SavedLayout sl = make_saved(j.N, j.F, j.layers);
-    const int jet = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int jet = order ? order[blockIdx.x] : blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int pl = lane & 15, q = lane >> 4, oslot = 4 * w + q;
     const float* sv = saved + (size_t)jet * sl.total;
     const BwdRec br = make_bwd_rec(j.layers);

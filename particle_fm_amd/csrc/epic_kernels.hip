@@ -779,6 +779,13 @@ int pfm_epic_pack_a16(const pfm_epic_desc* d, float* blob, void* stream) {
     return check_hip(hipGetLastError(), "epic_a16_pack_kernel launch");
 }
 
+int pfm_epic_jet_order(const float* mask, int32_t B, int32_t n_points, int32_t* order, void* stream) {
+    if (!mask || !order) return set_err(PFM_E_BADARG, "NULL device pointer");
+    if (B < 1 || B > ORDER_MAX_JETS) return set_err(PFM_E_BADARG, "1 <= B <= 8192 jets");
+    hipLaunchKernelGGL(epic_jet_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, n_points, order);
+    return check_hip(hipGetLastError(), "epic_jet_order_kernel launch");
+}
+
 int64_t pfm_epic_lds_bytes(const pfm_epic_desc* d) {
     if (!d) return -1;
     return (int64_t)make_carve(d->n_points, d->features).total * 4;

@@ -25,13 +25,14 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_forward_kernel(
     const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ eps,
     const float* __restrict__ cond, const float* __restrict__ mask, float* __restrict__ saved,
     float* __restrict__ loss_parts, float* __restrict__ mask_count, int crit, const float* __restrict__ rates,
-    const float* __restrict__ temb) {  // temb (or NULL): [B][T] time embedding supplied by the caller (t_emb="gaussian")
+    const float* __restrict__ temb,   // temb (or NULL): [B][T] time embedding supplied by the caller (t_emb="gaussian")
+    const int* __restrict__ order) {  // order (or NULL): launch order of the jets, longest first (pfm_epic_jet_order)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
     const Carve c = make_carve(j.N, j.F);
     const SavedLayout sl = make_saved(j.N, j.F, j.layers);
-    const int jet = blockIdx.x, tid = threadIdx.x;
+    const int jet = order ? order[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
     const int n_rows = epic_jet_setup(d, j, blob, lds, c, cond ? cond + (size_t)jet * j.C : nullptr,
                                       mask ? mask + (size_t)jet * j.N : nullptr);
     float* sv = saved + (size_t)jet * sl.total;
@@ -102,7 +103,7 @@ using namespace pfm;
 
 static int loss_forward(const pfm_epic_desc* d, const float* blob, int kind, float sigma, const float* t, const float* x,
                         const float* z, const float* eps, const float* cond, const float* mask, float* saved,
-                        float* loss_parts, float* mask_count, int crit, const float* rates, int B, void* stream,
+                        float* loss_parts, float* mask_count, int crit, const float* rates, int B, const int32_t* order, void* stream,
                         const float* temb = nullptr) {
     int rc = validate(d);
     if (rc) return rc;
@@ -121,41 +122,41 @@ static int loss_forward(const pfm_epic_desc* d, const float* blob, int kind, flo
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
     if (bf16)
         hipLaunchKernelGGL(epic_fm_loss_forward_kernel<1>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, kind,
-                           sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, crit, rates, temb);
+                           sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, crit, rates, temb, order);
     else
         hipLaunchKernelGGL(epic_fm_loss_forward_kernel<0>, dim3(B), dim3(NT), lds, (hipStream_t)stream, blob, d->blob_floats, kind,
-                           sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, crit, rates, temb);
+                           sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, crit, rates, temb, order);
     return check_hip(hipGetLastError(), "epic_fm_loss_forward_kernel launch");
 }
 
 extern "C" int pfm_epic_fm_loss_forward(const pfm_epic_desc* d, const float* blob, int32_t kind, float sigma,
                                         const float* t, const float* x, const float* z, const float* eps,
                                         const float* cond, const float* mask, float* saved, float* loss_parts,
-                                        float* mask_count, int32_t B, void* stream) {
+                                        float* mask_count, int32_t B, const int32_t* order, void* stream) {
     if (kind < 0 || kind > 2) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT), 1 (CFM) or 2 (droid)");
-    return loss_forward(d, blob, kind, sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, 0, nullptr, B, stream);
+    return loss_forward(d, blob, kind, sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, 0, nullptr, B, order, stream);
 }
 
 extern "C" int pfm_epic_fm_loss_forward_temb(const pfm_epic_desc* d, const float* blob, int32_t kind, float sigma, const float* t,
                                              const float* temb, const float* x, const float* z, const float* eps,
                                              const float* cond, const float* mask, float* saved, float* loss_parts,
-                                             float* mask_count, int32_t B, void* stream) {
+                                             float* mask_count, int32_t B, const int32_t* order, void* stream) {
     if (kind < 0 || kind > 2) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT), 1 (CFM) or 2 (droid)");
     if (!temb) return set_err(PFM_E_BADARG, "temb is NULL");
-    return loss_forward(d, blob, kind, sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, 0, nullptr, B, stream, temb);
+    return loss_forward(d, blob, kind, sigma, t, x, z, eps, cond, mask, saved, loss_parts, mask_count, 0, nullptr, B, order, stream, temb);
 }
 
 extern "C" int pfm_epic_diffusion_loss_forward(const pfm_epic_desc* d, const float* blob, int32_t criterion, const float* rates,
                                                const float* t, const float* x, const float* z, const float* cond,
                                                const float* mask, float* saved, float* loss_parts, float* mask_count,
-                                               int32_t B, void* stream) {
+                                               int32_t B, const int32_t* order, void* stream) {
     if (criterion < 0 || criterion > 1) return set_err(PFM_E_BADARG, "criterion must be 0 (mse) or 1 (huber)");
-    return loss_forward(d, blob, 3, 0.f, t, x, z, nullptr, cond, mask, saved, loss_parts, mask_count, criterion, rates, B, stream);
+    return loss_forward(d, blob, 3, 0.f, t, x, z, nullptr, cond, mask, saved, loss_parts, mask_count, criterion, rates, B, order, stream);
 }
 
 static int loss_backward(const pfm_epic_desc* d, const float* blob, const float* cond, const float* mask, const float* saved,
                          const float* inv_mask_total, const float* grad_scale, float* grad_blob, int crit, const float* jet_w,
-                         int B, float* scratch, void* stream, float* dtemb = nullptr) {
+                         int B, float* scratch, const int32_t* order, void* stream, float* dtemb = nullptr) {
     int rc = validate(d);
     if (rc) return rc;
     const int64_t lds = (int64_t)make_bcarve(d->n_points, d->features).total * 4;
@@ -180,10 +181,10 @@ static int loss_backward(const pfm_epic_desc* d, const float* blob, const float*
     // 1. per-jet chain: gradient rows + rank-1 operands -> scratch
     if (bf16)
         hipLaunchKernelGGL(epic_fm_loss_backward_kernel<true>, dim3(B), dim3(NT), (int)lds, s, blob, d->blob_floats, cond, mask, saved,
-                           inv_mask_total, grad_scale, scratch, bw, crit, jet_w, dtemb);
+                           inv_mask_total, grad_scale, scratch, bw, crit, jet_w, dtemb, order);
     else
         hipLaunchKernelGGL(epic_fm_loss_backward_kernel<false>, dim3(B), dim3(NT), (int)lds, s, blob, d->blob_floats, cond, mask, saved,
-                           inv_mask_total, grad_scale, scratch, bw, crit, jet_w, dtemb);
+                           inv_mask_total, grad_scale, scratch, bw, crit, jet_w, dtemb, order);
     if ((rc = check_hip(hipGetLastError(), "epic_fm_loss_backward_kernel launch"))) return rc;
     // 2. the 2 * layers + 1 dW GEMMs over the rows of all jets, split by row ranges
     hipLaunchKernelGGL(epic_dw_kernel, dim3(bw.nsplit, bw.nblk), dim3(DW_T), dw_lds, s, blob, d->blob_floats, saved, scratch, bw, B);
@@ -245,22 +246,24 @@ extern "C" int64_t pfm_epic_backward_scratch_floats(const pfm_epic_desc* d, int3
 
 extern "C" int pfm_epic_fm_loss_backward(const pfm_epic_desc* d, const float* blob, const float* t, const float* cond,
                                          const float* mask, const float* saved, const float* inv_mask_total,
-                                         const float* grad_scale, float* grad_blob, int32_t B, float* scratch, void* stream) {
+                                         const float* grad_scale, float* grad_blob, int32_t B, float* scratch, const int32_t* order,
+                                         void* stream) {
     (void)t;  // the time embedding is part of `saved`
-    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, 0, nullptr, B, scratch, stream);
+    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, 0, nullptr, B, scratch, order, stream);
 }
 
 extern "C" int pfm_epic_fm_loss_backward_temb(const pfm_epic_desc* d, const float* blob, const float* cond, const float* mask,
                                               const float* saved, const float* inv_mask_total, const float* grad_scale,
-                                              float* grad_blob, float* grad_temb, int32_t B, float* scratch, void* stream) {
+                                              float* grad_blob, float* grad_temb, int32_t B, float* scratch, const int32_t* order,
+                                              void* stream) {
     if (!grad_temb) return set_err(PFM_E_BADARG, "grad_temb is NULL");
-    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, 0, nullptr, B, scratch, stream, grad_temb);
+    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, 0, nullptr, B, scratch, order, stream, grad_temb);
 }
 
 extern "C" int pfm_epic_diffusion_loss_backward(const pfm_epic_desc* d, const float* blob, int32_t criterion, const float* jet_weight,
                                                 const float* cond, const float* mask, const float* saved,
                                                 const float* inv_mask_total, const float* grad_scale, float* grad_blob,
-                                                int32_t B, float* scratch, void* stream) {
+                                                int32_t B, float* scratch, const int32_t* order, void* stream) {
     if (criterion < 0 || criterion > 1) return set_err(PFM_E_BADARG, "criterion must be 0 (mse) or 1 (huber)");
-    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, criterion, jet_weight, B, scratch, stream);
+    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, criterion, jet_weight, B, scratch, order, stream);
 }

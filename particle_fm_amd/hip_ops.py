@@ -224,7 +224,10 @@ def _seg2_rows(n: int) -> int:
 
 
 QUAD_TILE_ROWS, QUAD_SLOT_ROWS = 128, 32  # csrc/epic_fast.h: four jets per workgroup, each in a fixed 32-row slot of a 128-row tile
-QUAD_PRECISIONS = (2,)  # matrix-operand flags whose quad kernel is built without register spills: PFM_F_BF16_MFMA (fp32: 48 dwords)
+import os as _os
+# matrix-operand flags that take the quad kernel: PFM_F_BF16_MFMA (11 spilled dwords); the fp32 instantiation spills 48 dwords per
+# lane and is opt-in (PFM_QUAD_FP32=1) until measured to pay
+QUAD_PRECISIONS = (0, 2) if _os.environ.get("PFM_QUAD_FP32") == "1" else (2,)
 
 
 def packed_layout(layout: EpicLayout, n: int) -> Optional[EpicLayout]:
@@ -307,6 +310,20 @@ def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor
     return out
 
 
+JET_ORDER_MIN_JETS = 384  # longest-first launch order of the training kernels from this batch size on (1.5 jets per CU of a 256-CU part)
+
+
+def jet_order(maskf: Optional[torch.Tensor], B: int, n_points: int):
+    """order[rank] = jet in descending multiplicity for the loss forward / backward launches (one workgroup per jet, dispatched in
+    order: with several jets per CU the short ones should fill the tail).  None for small batches, no mask, or more than 8192 jets."""
+    if maskf is None or B < JET_ORDER_MIN_JETS or B > 8192:
+        return None
+    order = torch.empty(B, device=maskf.device, dtype=torch.int32)
+    rc = _lib.load().pfm_epic_jet_order(_ptr(maskf), B, int(n_points), _ptr(order), _stream_ptr(maskf.device))
+    _lib.check(rc, "pfm_epic_jet_order")
+    return order
+
+
 def epic_fm_loss_forward(layout: EpicLayout, blob: torch.Tensor, x: torch.Tensor, t: torch.Tensor, z: torch.Tensor,
                          cond: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
                          sigma: float = 1e-4, kind: str = "FM-OT", eps: Optional[torch.Tensor] = None,
@@ -331,16 +348,17 @@ def epic_fm_loss_forward(layout: EpicLayout, blob: torch.Tensor, x: torch.Tensor
     saved = torch.empty(B, per_jet, device=dev, dtype=torch.float32)
     parts = torch.empty(B, device=dev, dtype=torch.float32)
     count = torch.empty(B, device=dev, dtype=torch.float32)
+    order = jet_order(mask, B, layout.cfg.num_particles)
     if temb is not None:
         temb = _dev_f32("temb", temb, dev, (B, layout.cfg.t_dim))
         rc = lib.pfm_epic_fm_loss_forward_temb(ctypes.byref(layout.desc), _ptr(blob), kinds[kind], float(sigma), _ptr(t), _ptr(temb),
                                                _ptr(x), _ptr(z), _ptr(eps), _ptr(cond), _ptr(mask), _ptr(saved), _ptr(parts),
-                                               _ptr(count), B, _stream_ptr(dev))
+                                               _ptr(count), B, _ptr(order), _stream_ptr(dev))
         _lib.check(rc, "pfm_epic_fm_loss_forward_temb")
         return parts, count, saved
     rc = lib.pfm_epic_fm_loss_forward(ctypes.byref(layout.desc), _ptr(blob), kinds[kind], float(sigma), _ptr(t),
                                       _ptr(x), _ptr(z), _ptr(eps), _ptr(cond), _ptr(mask), _ptr(saved), _ptr(parts),
-                                      _ptr(count), B, _stream_ptr(dev))
+                                      _ptr(count), B, _ptr(order), _stream_ptr(dev))
     _lib.check(rc, "pfm_epic_fm_loss_forward")
     return parts, count, saved
 
@@ -395,17 +413,19 @@ def epic_loss_backward(layout: EpicLayout, blob, cond, maskf, saved, inv_total, 
         mm = None if maskf is None else maskf[c0:c1]
         sv = saved[c0:c1]
         scr = epic_backward_scratch(layout, n, dev)
+        order = jet_order(mm, n, layout.cfg.num_particles)
         if criterion is not None:
             rc = lib.pfm_epic_diffusion_loss_backward(ctypes.byref(layout.desc), P(blob), {"mse": 0, "huber": 1}[criterion],
-                                                      P(jet_w[c0:c1]), P(cc), P(mm), P(sv), P(inv_total), P(gscale), P(out), n, P(scr), S)
+                                                      P(jet_w[c0:c1]), P(cc), P(mm), P(sv), P(inv_total), P(gscale), P(out), n, P(scr),
+                                                      P(order), S)
             _lib.check(rc, "pfm_epic_diffusion_loss_backward")
         elif d_temb is not None:
             rc = lib.pfm_epic_fm_loss_backward_temb(ctypes.byref(layout.desc), P(blob), P(cc), P(mm), P(sv), P(inv_total), P(gscale),
-                                                    P(out), P(d_temb[c0:c1]), n, P(scr), S)
+                                                    P(out), P(d_temb[c0:c1]), n, P(scr), P(order), S)
             _lib.check(rc, "pfm_epic_fm_loss_backward_temb")
         else:
             rc = lib.pfm_epic_fm_loss_backward(ctypes.byref(layout.desc), P(blob), P(None), P(cc), P(mm), P(sv), P(inv_total),
-                                               P(gscale), P(out), n, P(scr), S)
+                                               P(gscale), P(out), n, P(scr), P(order), S)
             _lib.check(rc, "pfm_epic_fm_loss_backward")
         if c0 > 0:
             gblob.add_(tmp)
@@ -435,7 +455,8 @@ def epic_diffusion_loss_forward(layout: EpicLayout, blob, x, t, z, rates, cond=N
     parts = torch.empty(B, device=dev, dtype=torch.float32)
     count = torch.empty(B, device=dev, dtype=torch.float32)
     rc = lib.pfm_epic_diffusion_loss_forward(ctypes.byref(layout.desc), _ptr(blob), crit, _ptr(rates), _ptr(t), _ptr(x), _ptr(z),
-                                             _ptr(cond), _ptr(mask), _ptr(saved), _ptr(parts), _ptr(count), B, _stream_ptr(dev))
+                                             _ptr(cond), _ptr(mask), _ptr(saved), _ptr(parts), _ptr(count), B,
+                                             _ptr(jet_order(mask, B, layout.cfg.num_particles)), _stream_ptr(dev))
     _lib.check(rc, "pfm_epic_diffusion_loss_forward")
     return parts, count, saved
 

@@ -120,3 +120,44 @@ def test_backward_writes_every_gradient_slot_and_chunked_batches_agree():
     assert float((a - whole).abs().max()) <= 2e-6 * scale + 1e-9, float((a - whole).abs().max()) / scale
     # the scratch cache stays bounded
     assert len(lay.__dict__["_bwd_scratch"]) <= hip_ops._BWD_SCRATCH_SLOTS
+
+
+def test_longest_first_launch_order_of_the_training_kernels_changes_nothing():
+    """From hip_ops.JET_ORDER_MIN_JETS jets on the loss forward / backward take their jets longest first (pfm_epic_jet_order: scheduling
+    only, every jet writes its own records): loss parts, saved activations and every gradient slot keep their bits."""
+    from particle_fm_amd import hip_ops
+    from particle_fm_amd.layout import EpicLayout
+    from tests.conftest import load_golden
+    from tests.test_layout_cpu import cfg_of
+    g = load_golden("jetnet30")
+    N, F, B = g.hp["num_particles"], g.hp["features"], 448
+    lay = EpicLayout(cfg_of(dict(g.hp)), flags=1)
+    blob = lay.pack_blob(g.state, "flows.0.net.", freqs=g.freqs).cuda()
+    gen = torch.Generator().manual_seed(3)
+    n = torch.randint(1, N + 1, (B,), generator=gen)
+    maskf = (torch.arange(N)[None] < n[:, None]).float().cuda().contiguous()
+    x = (torch.randn(B, N, F, generator=gen)).cuda() * maskf[..., None]
+    t, z = torch.rand(B, generator=gen).cuda(), torch.randn(B, N, F, generator=gen).cuda()
+    gpos = torch.from_numpy(lay.src_gpos.astype("int64")).cuda()
+    one = torch.ones(1, device="cuda")
+
+    def run():
+        parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x, t, z, None, maskf, 1e-4, "FM-OT", None)
+        gblob = torch.full_like(blob, float("nan"))
+        hip_ops.epic_loss_backward(lay, blob, None, maskf, saved, (1.0 / count.sum()).reshape(1), one, gblob)
+        return parts.clone(), saved.clone(), gblob[gpos].clone()
+
+    assert hip_ops.jet_order(maskf, B, N) is not None
+    order = hip_ops.jet_order(maskf, B, N).cpu().long()
+    cnt = maskf.sum(1).cpu()
+    assert sorted(order.tolist()) == list(range(B)) and bool((cnt[order][:-1] >= cnt[order][1:]).all())
+    a = run()
+    keep = hip_ops.JET_ORDER_MIN_JETS
+    try:
+        hip_ops.JET_ORDER_MIN_JETS = 1 << 30  # batch order
+        b = run()
+    finally:
+        hip_ops.JET_ORDER_MIN_JETS = keep
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert torch.isfinite(a[2]).all()
