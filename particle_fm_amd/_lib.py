@@ -14,7 +14,8 @@ from .layout_tf import TfDesc
 from .layout_wide import EwDesc
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libpfm_hip.so")
+# PFM_LIB_PATH: diagnostics only (tests/diag A/B timing of library variants); the product loads the in-tree build
+LIB_PATH = os.environ.get("PFM_LIB_PATH") or os.path.join(_PKG, "libpfm_hip.so")
 
 _lib = None
 

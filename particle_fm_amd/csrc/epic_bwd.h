@@ -84,36 +84,70 @@ __device__ __forceinline__ f32x4 colsum16(f32x4 v) { return row_sum16(v); }
 // PFM_F_BF16_MFMA -- what Lightning's precision="bf16-mixed" (autocast around the same modules) means for these products.
 template <bool BF16 = false, typename Pre, typename Epi>
 __device__ __forceinline__ void gemm_dx(const f32x4 (&a)[8], const float* __restrict__ src, int n_rows, Pre pre, Epi epi) {
+    // Software pipeline over pairs of 16-row tiles, the scheme of the forward's gemm_phase (round 3; before, a pair read its 16
+    // operand fragments, waited, multiplied, and ran its epilogue with the matrix pipe idle: 47 % of the kernel's dX time was MFMA):
+    //   * the B operands are staged through two register sets of one K-quarter each: the ds_reads of a quarter are in flight while
+    //     the 16 MFMAs of the previous one issue, the first quarter of the NEXT pair behind the current pair's last MFMAs;
+    //   * pre() -- a global load of the saved activation whose sign gates the gradient -- is issued at the head of its pair and
+    //     consumed one pair LATER, in the epilogue that runs next to the following pair's MFMAs.
+    // Tiles are clamped to the last computed one (rows read stay inside [0, 16 ntiles): the carve has that room behind G / Hb);
+    // a clamped tile's results are never handed to epi.
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int pl = lane & 15, q = lane >> 4, oslot = 4 * w + q;
-    const int npairs = (n_rows + 2 * TILE - 1) / (2 * TILE);
+    const int ntiles = (n_rows + TILE - 1) / TILE, npairs = (ntiles + 1) >> 1;
+    if (npairs <= 0) return;
+    int koff[8];  // (row & 15) == pl for every tile: the swizzled slot offsets are per-lane constants
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) koff[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
+    f32x4 X0[2], X1[2], Y0[2], Y1[2];
+#define PFM_DX_LOADQ(B0, B1, t0p, t1p, qq)                                              \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                 \
+        B0[kk] = *reinterpret_cast<const f32x4*>((t0p) + koff[2 * (qq) + kk]);          \
+        B1[kk] = *reinterpret_cast<const f32x4*>((t1p) + koff[2 * (qq) + kk]);          \
+    }
+#define PFM_DX_MFMAQ(B0, B1, qq)                                                                                   \
+    if constexpr (BF16) {                                                                                          \
+        const bf16x8 ab = pack_bf16x8(a[2 * (qq)], a[2 * (qq) + 1]);                                               \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, pack_bf16x8(B0[0], B0[1]), acc0, 0, 0, 0);              \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, pack_bf16x8(B1[0], B1[1]), acc1, 0, 0, 0);              \
+    } else {                                                                                                       \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) { PFM_MFMA_PAIR(acc0, acc1, a[2 * (qq) + kk], B0[kk], B1[kk]); } \
+    }
+    const float* t0p = src;
+    const float* t1p = src + (ntiles > 1 ? TILE * H : 0);
+    PFM_DX_LOADQ(X0, X1, t0p, t1p, 0);
+    f32x4 pacc0 = {0.f, 0.f, 0.f, 0.f}, pacc1 = pacc0, px0 = pacc0, px1 = pacc0;
+    int pp0 = n_rows, pp1 = n_rows;  // rows of the pair whose epilogue is pending (>= n_rows: none)
     for (int pair = 0; pair < npairs; ++pair) {
         const int p0 = pair * 2 * TILE + pl, p1 = p0 + TILE;
-        const int pc0 = min(p0, n_rows - 1), pc1 = min(p1, n_rows - 1);
-        f32x4 b0[8], b1[8];
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-            b0[kt] = *reinterpret_cast<const f32x4*>(src + lds_off(pc0, 4 * kt + q));
-            b1[kt] = *reinterpret_cast<const f32x4*>(src + lds_off(pc1, 4 * kt + q));
-        }
-        const f32x4 x0 = pre(pc0, oslot), x1 = pre(pc1, oslot);
+        const f32x4 x0 = pre(min(p0, n_rows - 1), oslot), x1 = pre(min(p1, n_rows - 1), oslot);  // land during this pair's MFMAs
+        PFM_DX_LOADQ(Y0, Y1, t0p, t1p, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pp0 < n_rows) epi(pp0, oslot, pacc0, px0);  // the previous pair's epilogue, next to this pair's MFMAs
+        if (pp1 < n_rows) epi(pp1, oslot, pacc1, px1);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (BF16) {  // v_mfma_f32_16x16x32_bf16: 32 k in the cycles the 16x16x16 form takes for 16 (measured on gfx950)
-#pragma unroll
-            for (int kt2 = 0; kt2 < 4; ++kt2) {
-                const bf16x8 ab = pack_bf16x8(a[2 * kt2], a[2 * kt2 + 1]);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, pack_bf16x8(b0[2 * kt2], b0[2 * kt2 + 1]), acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, pack_bf16x8(b1[2 * kt2], b1[2 * kt2 + 1]), acc1, 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int kt = 0; kt < 8; ++kt) {
-                PFM_MFMA_PAIR(acc0, acc1, a[kt], b0[kt], b1[kt]);
-            }
-        }
-        if (p0 < n_rows) epi(p0, oslot, acc0, x0);
-        if (p1 < n_rows) epi(p1, oslot, acc1, x1);
+        PFM_DX_MFMAQ(X0, X1, 0);
+        PFM_DX_LOADQ(X0, X1, t0p, t1p, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        PFM_DX_MFMAQ(Y0, Y1, 1);
+        PFM_DX_LOADQ(Y0, Y1, t0p, t1p, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        PFM_DX_MFMAQ(X0, X1, 2);
+        // first quarter of the next pair (the last pair re-reads its own: harmless)
+        const int tn0 = min(2 * pair + 2, ntiles - 1), tn1 = min(2 * pair + 3, ntiles - 1);
+        const float* n0p = src + tn0 * TILE * H;
+        const float* n1p = src + tn1 * TILE * H;
+        PFM_DX_LOADQ(X0, X1, n0p, n1p, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        PFM_DX_MFMAQ(Y0, Y1, 3);
+        t0p = n0p; t1p = n1p;
+        pacc0 = acc0; pacc1 = acc1; px0 = x0; px1 = x1;
+        pp0 = p0; pp1 = p1;
     }
+    if (pp0 < n_rows) epi(pp0, oslot, pacc0, px0);
+    if (pp1 < n_rows) epi(pp1, oslot, pacc1, px1);
+#undef PFM_DX_LOADQ
+#undef PFM_DX_MFMAQ
 }
 
 // ---- per-jet record of the reductions over jets (floats) ------------------------------------------------------------
@@ -226,6 +260,15 @@ __device__ __forceinline__ void global_backward(const JetDims& j, const float* _
     const int tid = threadIdx.x;
     const int TC = j.T + j.C;
     const float nvalid = lds[c.misc];
+    // this thread's row of W_gl2 and its saved g1 entry: requested first, consumed behind the barrier below (the loads used to sit
+    // right in front of their use: an exposed L2 / HBM round trip per layer)
+    f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0, w2 = w0, w3 = w0;
+    float g1v = 0.f;
+    if (tid < H) {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(blob + gl2.W + (TC + tid) * 16);  // KP16 row: 16 floats
+        w0 = wr[0]; w1 = wr[1]; w2 = wr[2]; w3 = wr[3];
+        g1v = sv_g1[tid];
+    }
     // dag2 = dg_out * phi'(g_out);  vin2 = [temb ; cond ; g1]
     if (tid < j.L) lds[c.dag2 + tid] = lds[c.dg + tid] * dlrelu(sv_gout[tid], j.slope);
     if (tid >= 64 && tid < 64 + TC) lds[c.vin2 + (tid - 64)] = lds[c.vin + (tid - 64)];
@@ -233,8 +276,6 @@ __device__ __forceinline__ void global_backward(const JetDims& j, const float* _
     __syncthreads();
     // (dW_gl2 = sum_jets vin2 (x) dag2, db_gl2 = sum dag2: epic_bwd_reduce_kernel)   dg1 = W_gl2[g1 rows] . dag2
     if (tid < H) {
-        const f32x4* wr = reinterpret_cast<const f32x4*>(blob + gl2.W + (TC + tid) * 16);  // KP16 row: 16 floats
-        const f32x4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
         const float* dq = lds + c.dag2;
         float a = 0.f;
 #pragma unroll
@@ -244,7 +285,7 @@ __device__ __forceinline__ void global_backward(const JetDims& j, const float* _
             if (8 + jj < j.L) a = fmaf(w2[jj], dq[8 + jj], a);
             if (12 + jj < j.L) a = fmaf(w3[jj], dq[12 + jj], a);
         }
-        lds[c.dag1 + tid] = a * dlrelu(sv_g1[tid], j.slope);  // dag1 = dg1 * phi'(g1)
+        lds[c.dag1 + tid] = a * dlrelu(g1v, j.slope);  // dag1 = dg1 * phi'(g1)
     }
     __syncthreads();
     // (dW_gl1 = sum_jets vin (x) dag1, db_gl1 = sum dag1: epic_bwd_reduce_kernel)

@@ -111,7 +111,19 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         for (int f0 = 0; f0 < j.F; f0 += 4) {
             const int k = tid & (H - 1), pt = tid >> 7;
             float a[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int p = pt; p < n_rows; p += 4) {
+            // (eight rows' loads in flight per step: one row at a time this loop was a chain of ~40 exposed L2 round trips per jet)
+            int p = pt;
+            for (; p + 28 < n_rows; p += 32) {
+                float hv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) hv[u] = hL[(p + 4 * u) * H + k];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int jf = 0; jf < 4; ++jf)
+                        if (f0 + jf < j.F) a[jf] = fmaf(lds[c.da3 + (p + 4 * u) * j.F + f0 + jf], hv[u], a[jf]);
+            }
+            for (; p < n_rows; p += 4) {
                 const float hv = hL[p * H + k];
 #pragma unroll
                 for (int jf = 0; jf < 4; ++jf)
@@ -170,7 +182,6 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         const float* gout = g1 + H;
         const float* gin = (k > 0) ? sv + sl.glayer + (k - 1) * sl.gstride + H : sv + sl.gstem;
         load_afrag(a2, rs, ly.lc2.AT, w, lane);
-        load_afrag(a1, rs, ly.lc1.AT, w, lane);
         float* rstage = rec + (1 + k) * BwdRec::STAGE;
         float* da2 = daj + (size_t)(1 + 2 * k) * j.N * H;  // pairs with l1_k: dW of fc_local2 (epic.py:198-200)
         float* da1 = daj + (size_t)(2 + 2 * k) * j.N * H;  // pairs with h_k : dW of fc_local1 (epic.py:194-196)
@@ -178,16 +189,21 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         //     step (7) of the layer above has already done it in its epilogue.
         if (k == j.layers - 1) {
             f32x4 ps = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-            for (int tile = 0; tile < ntiles; ++tile) {
-                const int p = tile * TILE + pl;
-                if (p < n_rows) {
-                    const f32x4 hv = *reinterpret_cast<const f32x4*>(xo + p * H + 4 * oslot);
-                    f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, oslot));
-                    gv *= dlrelu4(hv, slope);
-                    *reinterpret_cast<f32x4*>(G + lds_off(p, oslot)) = gv;
-                    *reinterpret_cast<f32x4*>(da2 + p * H + 4 * oslot) = gv;
-                    ps += gv;
+            for (int t0 = 0; t0 < ntiles; t0 += 10) {  // every tile's global load in flight at once (the saved activations come from
+                                                       // HBM: tile by tile, or five at a time, the pass was a chain of DRAM round trips)
+                f32x4 hv[10];
+#pragma unroll
+                for (int u = 0; u < 10; ++u) hv[u] = *reinterpret_cast<const f32x4*>(xo + min((t0 + u) * TILE + pl, n_rows - 1) * H + 4 * oslot);
+#pragma unroll
+                for (int u = 0; u < 10; ++u) {
+                    const int p = (t0 + u) * TILE + pl;
+                    if (t0 + u < ntiles && p < n_rows) {
+                        f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, oslot));
+                        gv *= dlrelu4(hv[u], slope);
+                        *reinterpret_cast<f32x4*>(G + lds_off(p, oslot)) = gv;
+                        *reinterpret_cast<f32x4*>(da2 + p * H + 4 * oslot) = gv;
+                        ps += gv;
+                    }
                 }
             }
             ps = colsum16(ps);
@@ -208,6 +224,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
             ps = colsum16(ps);
             if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj1 + 4 * oslot) = ps;
         }
+        load_afrag(a1, rs, ly.lc1.AT, w, lane);  // step (7)'s weights: land behind the per-jet steps below (32 VGPRs less across (3))
         // vin of this stage (for the global backward): [temb;cond;mean_k;sum_k;g_k]
         build_vin(j, lds, c, sv + sl.pool + k * sl.pstride, gin, true);
         __syncthreads();
@@ -279,15 +296,20 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         const float* x2 = sv + sl.x2;
         const f32x4 dP4 = *reinterpret_cast<const f32x4*>(lds + c.dP + 4 * oslot);
         f32x4 ps = {0.f, 0.f, 0.f, 0.f};
-        for (int tile = 0; tile < ntiles; ++tile) {
-            const int p = tile * TILE + pl;
-            if (p < n_rows) {
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(x2 + p * H + 4 * oslot);
-                f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, oslot));
-                gv = (gv + dP4 * maskf[p]) * dlrelu4(hv, slope);
-                *reinterpret_cast<f32x4*>(G + lds_off(p, oslot)) = gv;
-                *reinterpret_cast<f32x4*>(daj + p * H + 4 * oslot) = gv;  // block 0: pairs with x1 -> dW of fc_l2
-                ps += gv;
+        for (int t0 = 0; t0 < ntiles; t0 += 10) {  // every tile's global load in flight at once
+            f32x4 hv[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) hv[u] = *reinterpret_cast<const f32x4*>(x2 + min((t0 + u) * TILE + pl, n_rows - 1) * H + 4 * oslot);
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int p = (t0 + u) * TILE + pl;
+                if (t0 + u < ntiles && p < n_rows) {
+                    f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, oslot));
+                    gv = (gv + dP4 * maskf[p]) * dlrelu4(hv[u], slope);
+                    *reinterpret_cast<f32x4*>(G + lds_off(p, oslot)) = gv;
+                    *reinterpret_cast<f32x4*>(daj + p * H + 4 * oslot) = gv;  // block 0: pairs with x1 -> dW of fc_l2
+                    ps += gv;
+                }
             }
         }
         ps = colsum16(ps);
@@ -318,6 +340,11 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         if (tid < j.T) dtemb[(size_t)jet * j.T + tid] = lds[c.dte + tid];
     }
     // this jet's part of dWx_l1[f][o] = sum_p y[p][f] * da1s[p][o]   (K-major [F][H]) -> rec.dWx
+    // (y through LDS -- da3 is dead since the head, its alias tg since the last tgemv: scalar global loads inside the tile loop
+    //  were an exposed L2 round trip per tile)
+    __syncthreads();
+    for (int i = tid; i < n_rows * j.F; i += NT) lds[c.da3 + i] = sv[sl.y + i];
+    __syncthreads();
     for (int f0 = 0; f0 < j.F; f0 += 4) {
         f32x4 acc[4];
 #pragma unroll
@@ -328,7 +355,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
                 const f32x4 dv = *reinterpret_cast<const f32x4*>(Hb + lds_off(p, oslot));
 #pragma unroll
                 for (int jf = 0; jf < 4; ++jf)
-                    if (f0 + jf < j.F) acc[jf] += dv * sv[sl.y + p * j.F + f0 + jf];
+                    if (f0 + jf < j.F) acc[jf] += dv * lds[c.da3 + p * j.F + f0 + jf];
             }
         }
 #pragma unroll
