@@ -273,10 +273,12 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
         for (int s = 0; s < 4; ++s) psq[s] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int npairs = (n_rows + 2 * TILE - 1) / (2 * TILE);
-    // (row & 15) == pl for every tile, so the swizzled slot offsets are per-lane constants
-    int koff[8];
+    // (row & 15) == pl for every tile, so the swizzled slot offsets are per-lane constants -- four of them: slot 4 kt + q of k-tile
+    // kt >= 4 is slot 4 (kt - 4) + q plus 16 (pl < 16 never touches bit 4), i.e. 64 floats further: an immediate in the ds_read
+    int koff4[4];
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt) koff[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
+    for (int kt = 0; kt < 4; ++kt) koff4[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
+#define PFM_KOFF(kt) (koff4[(kt) & 3] + 64 * ((kt) >> 2))
     const int ooff = pl * H + ((oslot ^ pl) << 2);
     float* const sink = lds + c.dummy;
     // operand staging: two register sets X / Y of one K-quarter (2 kt x 2 tiles = 16 VGPRs each)
@@ -285,8 +287,8 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
     f32x4 pacc0 = {0.f, 0.f, 0.f, 0.f}, pacc1 = {0.f, 0.f, 0.f, 0.f};
 #define PFM_LOADQ(B0, B1, base, qq)                                                        \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                    \
-        B0[kk] = *reinterpret_cast<const f32x4*>((base) + koff[2 * (qq) + kk]);            \
-        B1[kk] = *reinterpret_cast<const f32x4*>((base) + TILE * H + koff[2 * (qq) + kk]); \
+        B0[kk] = *reinterpret_cast<const f32x4*>((base) + PFM_KOFF(2 * (qq) + kk));            \
+        B1[kk] = *reinterpret_cast<const f32x4*>((base) + TILE * H + PFM_KOFF(2 * (qq) + kk)); \
     }
     // bf16 pipe: one v_mfma_f32_16x16x32_bf16 per tile and K-quarter (32 k: the two float4s of the quarter, see pack_bf16x8)
     bf16x8 ab[4];
@@ -455,6 +457,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
 #undef PFM_MFMAQ1
 #undef PFM_LOADQ
 #undef PFM_MFMAQ
+#undef PFM_KOFF
     if constexpr (NSEG == 4) {
         // the last jet's slot: every row of a slot is computed (holes carry zero input and zero mask), so no predication; the
         // branch is wave-uniform and the pool sum's index static in each arm
