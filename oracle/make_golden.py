@@ -104,6 +104,10 @@ CONFIGS = {
     # t_emb="gaussian" (flow_matching_module.py:178-181, 213-221; time_emb.py:9-22): a learned time embedding -- random Fourier
     # features -> Linear -> activation -> Linear(2 * frequencies) -- whose parameters train with the network
     "gauss": dict(BASE, num_particles=24, layers=2, t_emb="gaussian", global_cond_dim=2, local_cond_dim=2),
+    # add_time_to_input=True for model "epic" (flow_matching_module.py:126, 199-200: the network sees cat(time embedding, x); the class
+    # default, off in configs/model/flow_matching.yaml): with t_local_cat (fc_l1 then has TWO time blocks) and without
+    "addtime": dict(BASE, num_particles=24, layers=2, add_time_to_input=True, global_cond_dim=2, local_cond_dim=2),
+    "addtime_notl": dict(BASE, num_particles=20, layers=2, add_time_to_input=True, t_local_cat=False),
 }
 
 
@@ -682,13 +686,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
     ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,norm}; default all")
+    ap.add_argument("--names", default="", help="with --only epic: comma list of configuration names (default all)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
     ap2 = args.only.split(",") if args.only else None
+    names = args.names.split(",") if args.names else None
     for name, hp in CONFIGS.items():
-        if ap2 is None or "epic" in ap2:
+        if (ap2 is None or "epic" in ap2) and (names is None or name in names):
             gen_config(ref, name, hp, args.out)
     if ap2 is None or "no_sets" in ap2:
         gen_no_sets(ref, args.out)

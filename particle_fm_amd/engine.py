@@ -163,7 +163,8 @@ class FusedFMTrainer:
         self._fused = None
         flows = getattr(module, "flows", None)
         if flows is not None and len(flows) == 1 and hasattr(flows[0], "net") and hasattr(flows[0].net, "source_vector") \
-                and not getattr(flows[0].net, "wide", False) and getattr(flows[0], "t_emb", None) != "gaussian":
+                and not getattr(flows[0].net, "wide", False) and getattr(flows[0], "t_emb", None) != "gaussian" \
+                and not getattr(flows[0].net, "add_time_to_input", False):  # (its fc_l1 is a folded matrix: autograd path)
             self._fused = {}
             flows[0].net._fast_pack = self.packed_blob  # sampling re-packs with one HIP launch instead of ~100 torch ops
 

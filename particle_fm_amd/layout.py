@@ -122,10 +122,24 @@ class EpicConfig:
     sum_scale: float = 1e-2
     neg_slope: float = 0.01  # F.leaky_relu default (epic.py:180)
     t_emb: str = "cosine"   # or "sincos" (flow_matching_module.py:208-211)
+    # CNF.forward concatenates the time embedding to the particle features (flow_matching_module.py:199-200: x = cat(t, x)), so the
+    # reference's fc_l1 has 2 * frequencies more input columns: [t_l ; temb ; x ; c_l].  Both time blocks multiply the SAME per-jet
+    # vector, so the kernels see ONE time block whose weights are the sum of the two (source_vector folds them; the gradient of the
+    # folded block flows back to both): no kernel knows about the switch.
+    add_time_to_input: bool = False
 
     @property
     def t_local(self) -> int:
         return 2 * self.frequencies if self.t_local_cat else 0
+
+    @property
+    def t_l1(self) -> int:
+        """time columns of fc_l1 as the kernels see it (after the folding of add_time_to_input)"""
+        return 2 * self.frequencies if (self.t_local_cat or self.add_time_to_input) else 0
+
+    @property
+    def t_input(self) -> int:
+        return 2 * self.frequencies if self.add_time_to_input else 0
 
     @property
     def t_global(self) -> int:
@@ -133,14 +147,15 @@ class EpicConfig:
 
     @property
     def t_dim(self) -> int:
-        return 2 * self.frequencies if (self.t_local_cat or self.t_global_cat) else 0
+        return 2 * self.frequencies if (self.t_local_cat or self.t_global_cat or self.add_time_to_input) else 0
 
     def linear_shapes(self) -> List[Tuple[str, int, int]]:
-        """(name, in, out) of every Linear in the reference's registration order."""
+        """(name, in, out) of every Linear in the reference's registration order, as the kernels see them (fc_l1 with its two
+        time blocks folded into one under add_time_to_input; the stored parameter has ``t_input`` more columns)."""
         H, L, F = self.hidden_dim, self.latent, self.features
         Tl, Tg, Cg, Cl = self.t_local, self.t_global, self.global_cond_dim, self.local_cond_dim
         out = [
-            ("fc_l1", F + Tl + Cl, H),
+            ("fc_l1", F + self.t_l1 + Cl, H),
             ("fc_l2", H + Tl + Cl, H),
             ("fc_g1", 2 * H + Tg + Cg, H),
             ("fc_g2", H + Tg + Cg, L),
@@ -156,7 +171,7 @@ class EpicConfig:
         return out
 
     def param_count(self) -> int:
-        return sum(o * i + 2 * o for _, i, o in self.linear_shapes())
+        return sum(o * i + 2 * o for _, i, o in self.linear_shapes()) + (self.t_local + self.t_input - self.t_l1) * self.hidden_dim
 
 
 class EpicLayout:
@@ -300,10 +315,11 @@ class EpicLayout:
 
         d.freqs = self._alloc(T)
         self._put(d.freqs, self.freq_off + np.arange(T))
-        # fc_l1: [t_l ; x(F) ; c_l]
-        d.l1x.W = self._plain_kmajor("fc_l1", range(Tl, Tl + F))
+        # fc_l1: [t_l ; x(F) ; c_l]  (T1 = its time columns after the folding of add_time_to_input, EpicConfig.t_l1)
+        T1 = cfg.t_l1
+        d.l1x.W = self._plain_kmajor("fc_l1", range(T1, T1 + F))
         d.l1x.b = -1
-        d.l1_We = self._kmajor("fc_l1", tcols(Tl) + list(range(Tl + F, Tl + F + Cl)))
+        d.l1_We = self._kmajor("fc_l1", tcols(T1) + list(range(T1 + F, T1 + F + Cl)))
         d.l1_b = self._bias("fc_l1")
         # fc_l2: [t_l ; x(H) ; c_l]
         d.l2 = self._local("fc_l2", tcols(Tl), Tl, range(Tl + H, Tl + H + Cl))
@@ -413,7 +429,13 @@ class EpicLayout:
         for name, _, _ in self.linears:
             v = state[prefix + name + ".weight_v"]
             g = state[prefix + name + ".weight_g"]
-            ws.append((v * (g / v.norm(dim=1, keepdim=True))).reshape(-1))
+            w = v * (g / v.norm(dim=1, keepdim=True))
+            if name == "fc_l1" and self.cfg.add_time_to_input:
+                # reference columns [t_l (Tl) ; temb (T) ; x ; c_l] -> kernel columns [t ; x ; c_l]: the two time blocks multiply the
+                # same embedding, their weights add (autograd sends the folded block's gradient to both)
+                T, Tl = self.cfg.t_input, self.cfg.t_local
+                w = torch.cat([w[:, :T] + w[:, T:2 * T], w[:, 2 * T:]], dim=1) if Tl else w
+            ws.append(w.reshape(-1))
             bs.append(state[prefix + name + ".bias"].reshape(-1))
             any_t = v
         if freqs is None:

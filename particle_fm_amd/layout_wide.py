@@ -50,6 +50,9 @@ class EpicWideLayout(EpicLayout):
 
     def __init__(self, cfg: EpicConfig, with_backward: bool = True, flags: int = 0):
         self.flags = flags
+        if getattr(cfg, "add_time_to_input", False):
+            raise NotImplementedError("add_time_to_input=True on the row-matrix EPiC path: only the jet-resident kernels (hidden_dim 128, "
+                                      "sets that fit the LDS tile) fold the extra time columns of fc_l1")
         if cfg.hidden_dim > 512:
             raise NotImplementedError("hidden_dim > 512 is beyond this build's Linear kernel (K <= 512 per segment)")
         if cfg.layers > PFM_EW_MAX_LAYERS:

@@ -95,10 +95,12 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
         super().__init__()
         _check_supported(activation, wrapper_func, dropout)
         self.t_emb = t_emb  # what CNF embeds the time with: the kernels embed in place of CNF.time_embedding
-        if input_dim != feats:
-            raise NotImplementedError(
-                "add_time_to_input=True (input_dim != feats) is not implemented for the EPiC HIP kernels; "
-                "configs/model/flow_matching.yaml uses add_time_to_input: False")
+        # add_time_to_input (flow_matching_module.py:126, 199-200): CNF hands the network cat(time embedding, x), so fc_l1 has
+        # 2 * frequencies more input columns.  The kernels fold them into fc_l1's time block (layout.EpicConfig.add_time_to_input).
+        if input_dim not in (feats, feats + 2 * frequencies):
+            raise NotImplementedError(f"input_dim={input_dim}: the EPiC HIP kernels take the particle features ({feats}) or, with "
+                                      f"add_time_to_input, the time embedding in front of them ({feats + 2 * frequencies})")
+        self.add_time_to_input = input_dim != feats
         self.latent, self.input_dim, self.hid_d, self.feats = latent, input_dim, hid_d, feats
         self.equiv_layers, self.global_cond_dim, self.local_cond_dim = equiv_layers, global_cond_dim, local_cond_dim
         self.num_points, self.sum_scale = num_points, sum_scale
@@ -137,6 +139,9 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
         w = self._wide_cache.get(n)
         if w is None:
             w = self._wide_cache[n] = self.hid_d != PFM_HIDDEN or not jet_resident_fits(n, self.feats)
+        if w and self.add_time_to_input:
+            raise NotImplementedError("add_time_to_input=True on the row-matrix EPiC path (hid_d != 128 or a set beyond the LDS tile): "
+                                      "only the jet-resident kernels fold the extra time columns")
         return w
 
     @property
@@ -149,7 +154,7 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
                           latent=self.latent, layers=self.equiv_layers, frequencies=self.frequencies,
                           t_local_cat=self.t_local_cat, t_global_cat=self.t_global_cat,
                           global_cond_dim=self.global_cond_dim, local_cond_dim=self.local_cond_dim,
-                          sum_scale=self.sum_scale, t_emb=self.t_emb)
+                          sum_scale=self.sum_scale, t_emb=self.t_emb, add_time_to_input=self.add_time_to_input)
 
     def layout(self, num_points: Optional[int] = None) -> EpicLayout:
         n = num_points or self.num_points
@@ -216,6 +221,13 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
                                       "tile): that path embeds the time in-kernel; call vector_field(t, x, cond, mask) (CNF.forward does)")
         lay = self.layout(x_local.shape[1])
         B = x_local.shape[0]
+        if self.add_time_to_input and x_local.shape[-1] == self.input_dim:
+            # the reference's caller passes cat(time embedding, x) (flow_matching_module.py:199-200); the kernels take the particle
+            # features and fold the embedding's columns into fc_l1's time block, so the embedding in front of x must be the one in
+            # t_in (it is, in CNF.forward); without t_in it is taken from there
+            if t_in is None:
+                t_in = x_local[:, 0, : 2 * self.frequencies]
+            x_local = x_local[..., 2 * self.frequencies:].contiguous()
         if t_in is None:
             temb = torch.zeros(B, lay.cfg.t_dim, device=x_local.device)
         else:

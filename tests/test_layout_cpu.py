@@ -17,7 +17,7 @@ def cfg_of(hp):
         latent=hp["latent"], layers=hp["layers"], frequencies=hp["frequencies"],
         t_local_cat=hp["t_local_cat"], t_global_cat=hp["t_global_cat"],
         global_cond_dim=hp["global_cond_dim"], local_cond_dim=hp["local_cond_dim"], sum_scale=hp["sum_scale"],
-        t_emb=hp.get("t_emb", "cosine"),
+        t_emb=hp.get("t_emb", "cosine"), add_time_to_input=bool(hp.get("add_time_to_input", False)),
     )
 
 

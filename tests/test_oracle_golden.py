@@ -26,8 +26,8 @@ def test_state_dict_keys_and_shapes(golden):
     hp = golden.hp
     T = 2 * hp["frequencies"]
     expect = epic_param_shapes(
-        features=hp["features"], input_dim=hp["features"], hidden=hp["hidden_dim"], latent=hp["latent"],
-        layers=hp["layers"], t_dim_local=T, t_dim_global=T,
+        features=hp["features"], input_dim=hp["features"] + (T if hp.get("add_time_to_input") else 0), hidden=hp["hidden_dim"],
+        latent=hp["latent"], layers=hp["layers"], t_dim_local=T if hp["t_local_cat"] else 0, t_dim_global=T if hp["t_global_cat"] else 0,
         global_cond_dim=hp["global_cond_dim"], local_cond_dim=hp["local_cond_dim"],
     )
     keys = ["flows.0.frequencies"] + ["flows.0.net." + k for k, _ in expect]
