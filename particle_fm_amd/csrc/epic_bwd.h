@@ -23,6 +23,26 @@
 
 namespace pfm {
 
+// Diagnostic build only (-DPFM_BDIAG, tests/diag/bwd_stamps.py; never the shipped library): workgroup 0 of the backward chain kernel
+// records (id, s_memtime) pairs at its step boundaries.  Expands to nothing otherwise.
+#ifdef PFM_BDIAG
+extern __device__ unsigned long long g_pfm_bstamps[1024];
+extern __device__ int g_pfm_nbstamp;
+#define PFM_BSTAMP(id)                                                      \
+    do {                                                                    \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                          \
+            const int i_ = g_pfm_nbstamp;                                   \
+            if (i_ < 512) {                                                 \
+                g_pfm_bstamps[2 * i_] = (unsigned long long)(id);           \
+                g_pfm_bstamps[2 * i_ + 1] = __builtin_amdgcn_s_memtime();   \
+                g_pfm_nbstamp = i_ + 1;                                     \
+            }                                                               \
+        }                                                                   \
+    } while (0)
+#else
+#define PFM_BSTAMP(id) do { } while (0)
+#endif
+
 struct BCarve {
     int G, Hb;         // N*H each
     int da3;           // N*F  gradient at the head pre-activation

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     const int Ke = j.T + j.Cl;
     float* G = lds + c.G;
     float* Hb = lds + c.Hb;
+    PFM_BSTAMP(0);
     // ---- setup: mask, n_valid, n_rows, temb, cond, head weights ----
     {
         const float* mj = mask ? mask + (size_t)jet * j.N : nullptr;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     const float gscale = (crit ? 1.0f : 2.0f) * inv_mask_total[0] * grad_scale[0] * (jet_w ? jet_w[jet] : 1.0f);
     const float* maskf = lds + c.maskf;
     const float* evec = lds + c.vin;  // [temb ; cond_l] is a prefix of vin (Cl in {0, C})
+    PFM_BSTAMP(1);
 
     // ---- head backward (epic.py:387-391): da3 = dv * mask * phi'(v);  G = W3^T da3 ----
     for (int i = tid; i < j.N * j.F; i += NT) {
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     }
     __syncthreads();
 
+    PFM_BSTAMP(2);
     const bool want_dt = dtemb != nullptr;
     if (want_dt && tid < j.T) {  // fc_l3 extras, KMAJOR [Ke][F]: d temb[k] = sum_f We3[k][f] db3j[f]   (db3j written before the barrier above)
         float a = 0.f;
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         const float* g1 = sv + sl.glayer + k * sl.gstride;
         const float* gout = g1 + H;
         const float* gin = (k > 0) ? sv + sl.glayer + (k - 1) * sl.gstride + H : sv + sl.gstem;
+        PFM_BSTAMP(10);
         load_afrag(a2, rs, ly.lc2.AT, w, lane);
         float* rstage = rec + (1 + k) * BwdRec::STAGE;
         float* da2 = daj + (size_t)(1 + 2 * k) * j.N * H;  // pairs with l1_k: dW of fc_local2 (epic.py:198-200)
@@ -210,6 +214,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
             if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj2 + 4 * oslot) = ps;
             __syncthreads();
         }
+        PFM_BSTAMP(11);
         // (3) da1 = (W_lc2^T da2) * phi'(l1) -> Hb (and to `da`); db1j = column sums
         {
             f32x4 ps = {0.f, 0.f, 0.f, 0.f};
@@ -224,6 +229,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
             ps = colsum16(ps);
             if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj1 + 4 * oslot) = ps;
         }
+        PFM_BSTAMP(12);
         load_afrag(a1, rs, ly.lc1.AT, w, lane);  // step (7)'s weights: land behind the per-jet steps below (32 VGPRs less across (3))
         // vin of this stage (for the global backward): [temb;cond;mean_k;sum_k;g_k]
         build_vin(j, lds, c, sv + sl.pool + k * sl.pstride, gin, true);
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         rec_put(rstage + BwdRec::DBJ2, lds + c.dbj2, H, 32);
         if (tid >= 64 && tid < 64 + MAXL) rstage[BwdRec::GOUT + tid - 64] = (tid - 64 < j.L) ? gout[tid - 64] : 0.f;
         __syncthreads();
+        PFM_BSTAMP(13);
         if (want_dt) {  // time rows of the two extras blocks
             dtemb_from_extras(blob + ly.lc1.We, lds + c.dbj1, j.T, lds + c.tg, lds + c.dte);
             dtemb_from_extras(blob + ly.lc2.We, lds + c.dbj2, j.T, lds + c.tg, lds + c.dte);
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         rec_put(rstage + BwdRec::VIN2, lds + c.vin2, VIN2_FLOATS, 128);
         rec_put(rstage + BwdRec::DAG1, lds + c.dag1, H, 192);
         rec_put(rstage + BwdRec::DAG2, lds + c.dag2, MAXL, 224);
+        PFM_BSTAMP(14);
         // (7) dh_k = W_lc1^T da1 + da2 (residual) + mask * dP_k (pooling) -> G in place; for k > 0 times phi'(h_k) right away:
         //     that is da2 of layer k - 1 (step (1) of the next iteration, fused here: one pass over G and one L2 round trip less)
         {
@@ -281,6 +289,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         __syncthreads();
     }
 
+    PFM_BSTAMP(20);
     // ---- stem ----
     // global stem backward (fc_g1 / fc_g2): dg_0 -> dP (the pool of x2 as seen by the stem MLP)
     build_vin(j, lds, c, sv + sl.pool, nullptr, false);
@@ -316,6 +325,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj2 + 4 * oslot) = ps;
     }
     __syncthreads();
+    PFM_BSTAMP(21);
     // da1s = (W_l2^T da2s + da2s) * phi'(x1) -> Hb   (epic.py:364-366, 360-362)
     {
         const float* x1 = sv + sl.x1;
@@ -332,6 +342,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj1 + 4 * oslot) = ps;
     }
     __syncthreads();
+    PFM_BSTAMP(22);
     rec_put(rec + BwdRec::DBJ1, lds + c.dbj1, H, 0);   // dWe of fc_l1 / fc_l2 = sum_jets [temb ; cond_l] (x) db1j / db2j
     rec_put(rec + BwdRec::DBJ2, lds + c.dbj2, H, 32);
     if (want_dt) {
@@ -366,6 +377,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
             }
         }
     }
+    PFM_BSTAMP(30);
 }
 
 }  // namespace pfm

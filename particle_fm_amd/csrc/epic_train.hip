@@ -9,6 +9,21 @@
 #include "epic_bwd_kernel.h"
 #include "epic_dw.h"
 
+#ifdef PFM_BDIAG
+namespace pfm {
+__device__ unsigned long long g_pfm_bstamps[1024];
+__device__ int g_pfm_nbstamp;
+}
+extern "C" int pfm_diag_read_bwd_stamps(unsigned long long* out, int* n) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(n, HIP_SYMBOL(pfm::g_pfm_nbstamp), sizeof(int));
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pfm::g_pfm_bstamps), sizeof(unsigned long long) * 1024);
+    int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(pfm::g_pfm_nbstamp), &zero, sizeof(int));
+    return 0;
+}
+#endif
+
 namespace pfm {
 int set_err(int code, const char* what);
 int check_hip(hipError_t e, const char* where);

@@ -50,9 +50,6 @@ class EpicWideLayout(EpicLayout):
 
     def __init__(self, cfg: EpicConfig, with_backward: bool = True, flags: int = 0):
         self.flags = flags
-        if getattr(cfg, "add_time_to_input", False):
-            raise NotImplementedError("add_time_to_input=True on the row-matrix EPiC path: only the jet-resident kernels (hidden_dim 128, "
-                                      "sets that fit the LDS tile) fold the extra time columns of fc_l1")
         if cfg.hidden_dim > 512:
             raise NotImplementedError("hidden_dim > 512 is beyond this build's Linear kernel (K <= 512 per segment)")
         if cfg.layers > PFM_EW_MAX_LAYERS:
@@ -169,12 +166,14 @@ class EpicWideLayout(EpicLayout):
         def t(n):  # the time columns of a Linear that takes them first, or "absent"
             return list(range(n)) if n else []
 
-        # fc_l1 [t_l ; x(F) ; c_l]: particle columns K-major [F][Hp]
-        d.l1x = self._put(self._src("fc_l1", ar(Hp)[None, :], (Tl + ar(F))[:, None]))
+        # fc_l1 [t_l ; x(F) ; c_l]: particle columns K-major [F][Hp].  T1 = its time columns as source_vector hands them over: under
+        # add_time_to_input the reference's two time blocks [t_l ; temb] folded into one (layout.EpicConfig.t_l1), so T1 may be T with Tl = 0
+        T1 = cfg.t_l1
+        d.l1x = self._put(self._src("fc_l1", ar(Hp)[None, :], (T1 + ar(F))[:, None]))
         # fc_l3 [t_l ; x(H) ; c_l]: particle block row-major [F][Hp]
         kk = ar(Hp)[None, :]
         d.l3 = self._put(self._src("fc_l3", ar(16)[:, None], np.where(kk < H, Tl + kk, -1)))  # [16][Hp], rows >= F zero
-        ext_l1 = self._pcols(t(Tl), list(range(Tl + F, Tl + F + Cl)))
+        ext_l1 = self._pcols(t(T1), list(range(T1 + F, T1 + F + Cl)))
         ext_h = self._pcols(t(Tl), list(range(Tl + H, Tl + H + Cl)))  # fc_l2 / fc_local2 / fc_l3 share [t ; x(H) ; c]
         d.sjb = self._lin([("fc_l1", 0, Hp, ext_l1), ("fc_l2", Hp, Hp, ext_h), ("fc_l3", 2 * Hp, 128, ext_h)],
                           2 * Hp + 128, 256, [("fc_l1", 0), ("fc_l2", Hp), ("fc_l3", 2 * Hp)])

@@ -139,9 +139,6 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
         w = self._wide_cache.get(n)
         if w is None:
             w = self._wide_cache[n] = self.hid_d != PFM_HIDDEN or not jet_resident_fits(n, self.feats)
-        if w and self.add_time_to_input:
-            raise NotImplementedError("add_time_to_input=True on the row-matrix EPiC path (hid_d != 128 or a set beyond the LDS tile): "
-                                      "only the jet-resident kernels fold the extra time columns")
         return w
 
     @property

@@ -1,5 +1,5 @@
-"""Diagnostic: where workgroup 0 of the backward chain kernel spends its cycles (s_memtime stamps; library built by the recipe in
-tests/diag/README.md with PFM_BSTAMP markers).   PFM_LIB_PATH=tests/diag/libtr_stamps.so python tests/diag/bwd_stamps.py [n_particles]"""
+"""Diagnostic: where workgroup 0 of the backward chain kernel spends its cycles (s_memtime stamps; library built in the CPU container by
+tests/diag/build_bwd_stamps.sh: epic_train.hip under -DPFM_BDIAG).   PFM_LIB_PATH=tests/diag/libtr_stamps.so python tests/diag/bwd_stamps.py [n_particles]"""
 import ctypes
 import os
 import sys
@@ -26,7 +26,7 @@ inv = (1.0 / count.sum()).reshape(1)
 one = torch.ones(1, device=dev)
 gblob = torch.zeros_like(blob)
 lib = _lib.load()
-buf = (ctypes.c_ulonglong * 512)()
+buf = (ctypes.c_ulonglong * 1024)()
 cnt = ctypes.c_int(0)
 for it in range(3):
     hip_ops.epic_loss_backward(lay, blob, None, maskf, saved, inv, one, gblob)

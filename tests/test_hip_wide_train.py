@@ -31,3 +31,35 @@ def test_loss_and_all_parameter_gradients(wide_golden):
         if not (err < 1e-2 and l2 < 2e-3):
             bad.append((k, err, l2, scale))
     assert not bad, "gradient mismatch (key, max err / max |ref|, rel L2, max |ref|): " + str(bad[:10])
+
+
+@pytest.mark.parametrize("name", ["addtime", "addtime_notl"])
+def test_add_time_to_input_loss_and_gradients_on_the_row_matrix_path(name):
+    """add_time_to_input=True (flow_matching_module.py:126, 199-200: fc_l1 sees [t_l ; temb ; x ; c_l]) through the row-matrix kernels:
+    source_vector folds the two time blocks into one, the fold is differentiable, so the reference's recorded loss and the gradient of
+    EVERY parameter (fc_l1.weight_v with its 2 * frequencies extra columns included) must come back."""
+    from particle_fm_amd.fm_loss_wide import epic_wide_fm_loss
+    from particle_fm_amd.layout_wide import EpicWideLayout
+    from tests.conftest import load_golden
+    g = load_golden(name)
+    assert g.hp["add_time_to_input"]
+    lay = EpicWideLayout(cfg_of(g.hp))
+    state = {k[len("flows.0.net."):]: v.cuda().requires_grad_(True) for k, v in g.state.items() if k.startswith("flows.0.net.")}
+    assert state["fc_l1.weight_v"].shape[1] == g.hp["features"] + lay.cfg.t_local + lay.cfg.t_input + lay.cfg.local_cond_dim
+    src = lay.source_vector(state, "", freqs=g.freqs)
+    tag = "loss_f32/"
+    x, t, z, mask = (g.get(tag + k).cuda() for k in ("x", "t", "z", "mask"))
+    cond = g.get(tag + "cond")
+    loss = epic_wide_fm_loss(lay, src, x, t, z, None if cond is None else cond.cuda(), mask, 1e-4, "FM-OT")
+    torch.testing.assert_close(loss.detach().cpu(), g.get(tag + "loss"), rtol=2e-5, atol=1e-6)
+    loss.backward()
+    ref = g.grads(tag)
+    bad = []
+    for k, p in state.items():
+        want = ref["flows.0.net." + k]
+        got = p.grad.cpu()
+        scale = max(float(want.abs().max()), 1e-6)
+        err = float((got - want).abs().max()) / scale
+        if not err < 2e-3:
+            bad.append((k, err, scale))
+    assert not bad, "gradient mismatch (key, max err / max |ref|, max |ref|): " + str(bad[:10])

@@ -85,10 +85,6 @@ def test_grad_pos_covers_every_weight_once():
 
 def test_also_packs_the_narrow_configs(golden):
     """hidden 128 goes through the same layout (Hp = 128): the wide path is a superset of the jet-resident one."""
-    if golden.hp.get("add_time_to_input"):  # ... except for the folded time block of add_time_to_input: refused, not mis-evaluated
-        with pytest.raises(NotImplementedError, match="add_time_to_input"):
-            _layout(golden)
-        return
     lay = _layout(golden)
     blob = lay.pack_blob(golden.state, "flows.0.net.", freqs=golden.freqs)
     tag = "nfe_f32/"
