@@ -96,78 +96,165 @@ __device__ __forceinline__ f32x4 dlrelu4(f32x4 y, float s) {
 
 __device__ __forceinline__ f32x4 colsum16(f32x4 v) { return row_sum16(v); }
 
-// dX product: for every row p < n_rows, epi(p, oslot, acc, pre(p, oslot)) with
+// dX product: for every row p < n_rows, epi(rowbase, valid, acc, pre(rowbase)) with p = rowbase + (lane & 15) and
 //   acc[r] = sum_k AT-block[16w + 4q + r][k] * src[p][k]        (a = MFMA_AT fragments of this wave)
-// pre(p, oslot) fetches what the epilogue needs from global memory (the saved activation whose sign gates the gradient): it is
-// called BEFORE the pair's 64 MFMAs so that the load flies behind them (in the epilogue it would be a bare L2 round trip per pair).
-// BF16: both operands rounded to bf16 on the fly (v_mfma_f32_16x16x32_bf16, fp32 accumulate), as the forward does under
-// PFM_F_BF16_MFMA -- what Lightning's precision="bf16-mixed" (autocast around the same modules) means for these products.
+// pre(rowbase) fetches what the epilogue needs from global memory (the saved activation whose sign gates the gradient): it is
+// called at the head of the tile pair and consumed one pair LATER, in the epilogue that runs next to the following pair's MFMAs.
+// `valid` is the literal true for every pair but the last (its rows all lie below n_rows): the functors' predication folds away.
+//
+// fp32 pipe: the scheme of the forward's gemm_phase (epic_nfe.h) -- the pairs whose two tiles are real run as straight-line bodies
+// with a COMPILE-TIME pair index (at most MAXPAIRS: the LDS tile holds <= 160 rows), so every LDS address is a per-lane constant
+// plus an immediate and the callers' loads are buffer offsets (scalar base + lane constant): the rolled loop this replaces spent
+// ~100 VALU instructions per pair and wave on addresses, register rotation and clamps next to its 64 MFMAs (the fp32 MFMA does not
+// co-issue with VALU work) and recomputed a whole tile for every jet with an odd tile count; such a jet now ends with a body that
+// issues the real tile's MFMAs only.  B operands are staged through two register sets of one K-quarter each (the ds_reads of a
+// quarter fly behind the 16 MFMAs of the previous one, the first quarter of the NEXT pair behind the current pair's last MFMAs).
+// Rows read stay inside [0, 16 ntiles).
+// BF16 (v_mfma_f32_16x16x32_bf16 on operands rounded on the fly, fp32 accumulate -- what Lightning's precision="bf16-mixed" means for
+// these products): the rolled loop (no half pair on that pipe), tiles clamped to the last computed one.
 template <bool BF16 = false, typename Pre, typename Epi>
 __device__ __forceinline__ void gemm_dx(const f32x4 (&a)[8], const float* __restrict__ src, int n_rows, Pre pre, Epi epi) {
-    // Software pipeline over pairs of 16-row tiles, the scheme of the forward's gemm_phase (round 3; before, a pair read its 16
-    // operand fragments, waited, multiplied, and ran its epilogue with the matrix pipe idle: 47 % of the kernel's dX time was MFMA):
-    //   * the B operands are staged through two register sets of one K-quarter each: the ds_reads of a quarter are in flight while
-    //     the 16 MFMAs of the previous one issue, the first quarter of the NEXT pair behind the current pair's last MFMAs;
-    //   * pre() -- a global load of the saved activation whose sign gates the gradient -- is issued at the head of its pair and
-    //     consumed one pair LATER, in the epilogue that runs next to the following pair's MFMAs.
-    // Tiles are clamped to the last computed one (rows read stay inside [0, 16 ntiles): the carve has that room behind G / Hb);
-    // a clamped tile's results are never handed to epi.
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int pl = lane & 15, q = lane >> 4, oslot = 4 * w + q;
+    const int tid_ = launder(threadIdx.x);
+    const int lane = tid_ & 63;
+    const int pl = lane & 15, q = lane >> 4;
     const int ntiles = (n_rows + TILE - 1) / TILE, npairs = (ntiles + 1) >> 1;
     if (npairs <= 0) return;
-    int koff[8];  // (row & 15) == pl for every tile: the swizzled slot offsets are per-lane constants
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt) koff[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
     f32x4 X0[2], X1[2], Y0[2], Y1[2];
+    f32x4 pacc0 = {0.f, 0.f, 0.f, 0.f}, pacc1 = pacc0, px0 = pacc0, px1 = pacc0;
+    if constexpr (BF16) {
+        int koff[8];  // (row & 15) == pl for every tile: the swizzled slot offsets are per-lane constants
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) koff[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
 #define PFM_DX_LOADQ(B0, B1, t0p, t1p, qq)                                              \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                 \
         B0[kk] = *reinterpret_cast<const f32x4*>((t0p) + koff[2 * (qq) + kk]);          \
         B1[kk] = *reinterpret_cast<const f32x4*>((t1p) + koff[2 * (qq) + kk]);          \
     }
 #define PFM_DX_MFMAQ(B0, B1, qq)                                                                                   \
-    if constexpr (BF16) {                                                                                          \
+    {                                                                                                              \
         const bf16x8 ab = pack_bf16x8(a[2 * (qq)], a[2 * (qq) + 1]);                                               \
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, pack_bf16x8(B0[0], B0[1]), acc0, 0, 0, 0);              \
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, pack_bf16x8(B1[0], B1[1]), acc1, 0, 0, 0);              \
-    } else {                                                                                                       \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) { PFM_MFMA_PAIR(acc0, acc1, a[2 * (qq) + kk], B0[kk], B1[kk]); } \
     }
-    const float* t0p = src;
-    const float* t1p = src + (ntiles > 1 ? TILE * H : 0);
-    PFM_DX_LOADQ(X0, X1, t0p, t1p, 0);
-    f32x4 pacc0 = {0.f, 0.f, 0.f, 0.f}, pacc1 = pacc0, px0 = pacc0, px1 = pacc0;
-    int pp0 = n_rows, pp1 = n_rows;  // rows of the pair whose epilogue is pending (>= n_rows: none)
-    for (int pair = 0; pair < npairs; ++pair) {
-        const int p0 = pair * 2 * TILE + pl, p1 = p0 + TILE;
-        const f32x4 x0 = pre(min(p0, n_rows - 1), oslot), x1 = pre(min(p1, n_rows - 1), oslot);  // land during this pair's MFMAs
-        PFM_DX_LOADQ(Y0, Y1, t0p, t1p, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (pp0 < n_rows) epi(pp0, oslot, pacc0, px0);  // the previous pair's epilogue, next to this pair's MFMAs
-        if (pp1 < n_rows) epi(pp1, oslot, pacc1, px1);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        PFM_DX_MFMAQ(X0, X1, 0);
-        PFM_DX_LOADQ(X0, X1, t0p, t1p, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        PFM_DX_MFMAQ(Y0, Y1, 1);
-        PFM_DX_LOADQ(Y0, Y1, t0p, t1p, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        PFM_DX_MFMAQ(X0, X1, 2);
-        // first quarter of the next pair (the last pair re-reads its own: harmless)
-        const int tn0 = min(2 * pair + 2, ntiles - 1), tn1 = min(2 * pair + 3, ntiles - 1);
-        const float* n0p = src + tn0 * TILE * H;
-        const float* n1p = src + tn1 * TILE * H;
-        PFM_DX_LOADQ(X0, X1, n0p, n1p, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        PFM_DX_MFMAQ(Y0, Y1, 3);
-        t0p = n0p; t1p = n1p;
-        pacc0 = acc0; pacc1 = acc1; px0 = x0; px1 = x1;
-        pp0 = p0; pp1 = p1;
-    }
-    if (pp0 < n_rows) epi(pp0, oslot, pacc0, px0);
-    if (pp1 < n_rows) epi(pp1, oslot, pacc1, px1);
+        const float* t0p = src;
+        const float* t1p = src + (ntiles > 1 ? TILE * H : 0);
+        PFM_DX_LOADQ(X0, X1, t0p, t1p, 0);
+        int prb = -1;  // row base of the pair whose epilogue is pending
+        for (int pair = 0; pair < npairs; ++pair) {
+            const int rb = pair * 2 * TILE;
+            const f32x4 x0 = pre(rb), x1 = pre(rb + TILE);  // land during this pair's MFMAs
+            PFM_DX_LOADQ(Y0, Y1, t0p, t1p, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (prb >= 0) {  // the previous pair's epilogue, next to this pair's MFMAs
+                epi(prb, true, pacc0, px0);
+                epi(prb + TILE, true, pacc1, px1);
+            }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            PFM_DX_MFMAQ(X0, X1, 0);
+            PFM_DX_LOADQ(X0, X1, t0p, t1p, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            PFM_DX_MFMAQ(Y0, Y1, 1);
+            PFM_DX_LOADQ(Y0, Y1, t0p, t1p, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            PFM_DX_MFMAQ(X0, X1, 2);
+            // first quarter of the next pair (the last pair re-reads its own: harmless)
+            const int tn0 = min(2 * pair + 2, ntiles - 1), tn1 = min(2 * pair + 3, ntiles - 1);
+            const float* n0p = src + tn0 * TILE * H;
+            const float* n1p = src + tn1 * TILE * H;
+            PFM_DX_LOADQ(X0, X1, n0p, n1p, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            PFM_DX_MFMAQ(Y0, Y1, 3);
+            t0p = n0p; t1p = n1p;
+            pacc0 = acc0; pacc1 = acc1; px0 = x0; px1 = x1;
+            prb = rb;
+        }
+        epi(prb, prb + pl < n_rows, pacc0, px0);
+        epi(prb + TILE, prb + TILE + pl < n_rows, pacc1, px1);
 #undef PFM_DX_LOADQ
 #undef PFM_DX_MFMAQ
+    } else {
+        // four per-lane slot offsets: slot 4 kt + q of k-tile kt >= 4 is slot 4 (kt - 4) + q plus 16 (pl < 16 never touches bit 4), i.e. 64
+        // floats further -- an immediate in the ds_read
+        const float* kb[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) kb[kt] = src + pl * H + (((4 * kt + q) ^ pl) << 2);
+#define PFM_DX_K(kt, fo) (kb[(kt) & 3] + 64 * ((kt) >> 2) + (fo))
+        // both tiles of a pair / the pair's first tile only (the last tile of a jet with an odd tile count)
+#define PFM_DX_LOADQ(B0, B1, fo, qq)                                                            \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                         \
+        B0[kk] = *reinterpret_cast<const f32x4*>(PFM_DX_K(2 * (qq) + kk, (fo)));                \
+        B1[kk] = *reinterpret_cast<const f32x4*>(PFM_DX_K(2 * (qq) + kk, (fo) + TILE * H));     \
+    }
+#define PFM_DX_LOADQ1(B0, B1, fo, qq)                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) B0[kk] = *reinterpret_cast<const f32x4*>(PFM_DX_K(2 * (qq) + kk, (fo)));
+#define PFM_DX_MFMAQ(B0, B1, qq)                                                                \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) { PFM_MFMA_PAIR(acc0, acc1, a[2 * (qq) + kk], B0[kk], B1[kk]); }
+#define PFM_DX_MFMAQ1(B0, B1, qq)                                                               \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                         \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].x, B0[kk].x, acc0, 0, 0, 0); \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].y, B0[kk].y, acc0, 0, 0, 0); \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].z, B0[kk].z, acc0, 0, 0, 0); \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * (qq) + kk].w, B0[kk].w, acc0, 0, 0, 0); \
+    }
+        const int nfull = ntiles >> 1;  // pairs whose two tiles are real
+        // the next pair's first quarter rides behind the current pair's last MFMAs (nothing behind the jet's last body)
+#define PFM_DX_BODY(LQ, MF, NEXT_FO)                                                            \
+    {                                                                                           \
+        constexpr int rb = pair * 2 * TILE, fo = rb * H;                                        \
+        const f32x4 x0 = pre(rb), x1 = pre(rb + TILE); /* land during this pair's MFMAs */     \
+        LQ(Y0, Y1, fo, 1);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if constexpr (pair > 0) { /* the previous pair's epilogue (every row valid), next to this pair's MFMAs */ \
+            epi(rb - 2 * TILE, true, pacc0, px0);                                               \
+            epi(rb - TILE, true, pacc1, px1);                                                   \
+        }                                                                                       \
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};                         \
+        MF(X0, X1, 0);                                                                          \
+        LQ(X0, X1, fo, 2);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        MF(Y0, Y1, 1);                                                                          \
+        LQ(Y0, Y1, fo, 3);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        MF(X0, X1, 2);                                                                          \
+        NEXT_FO                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        MF(Y0, Y1, 3);                                                                          \
+        pacc0 = acc0; pacc1 = acc1; px0 = x0; px1 = x1;                                         \
+    }
+#define PFM_DX_NEXT                                                                             \
+        if (pair + 1 < nfull) { PFM_DX_LOADQ(X0, X1, fo + 2 * TILE * H, 0); }                   \
+        else if (pair + 1 < npairs) { PFM_DX_LOADQ1(X0, X1, fo + 2 * TILE * H, 0); }
+#define PFM_DX_NONE
+#define PFM_DX_PAIR_AT(P)                                                                       \
+    if ((P) < nfull) {                                                                          \
+        constexpr int pair = (P);                                                               \
+        PFM_DX_BODY(PFM_DX_LOADQ, PFM_DX_MFMAQ, PFM_DX_NEXT)                                    \
+    }
+#define PFM_DX_TAIL_AT(P)                                                                       \
+    if ((P) == nfull) {                                                                         \
+        constexpr int pair = (P);                                                               \
+        PFM_DX_BODY(PFM_DX_LOADQ1, PFM_DX_MFMAQ1, PFM_DX_NONE)                                  \
+    }
+        if (nfull > 0) { PFM_DX_LOADQ(X0, X1, 0, 0); } else { PFM_DX_LOADQ1(X0, X1, 0, 0); }
+        static_assert(MAXPAIRS == 5, "unroll PFM_DX_PAIR_AT to MAXPAIRS");
+        PFM_DX_PAIR_AT(0) PFM_DX_PAIR_AT(1) PFM_DX_PAIR_AT(2) PFM_DX_PAIR_AT(3) PFM_DX_PAIR_AT(4)
+        if (nfull < npairs) {  // odd tile count: one real tile in the last pair
+            PFM_DX_TAIL_AT(0) PFM_DX_TAIL_AT(1) PFM_DX_TAIL_AT(2) PFM_DX_TAIL_AT(3) PFM_DX_TAIL_AT(4)
+        }
+        const int rbl = (npairs - 1) * 2 * TILE;
+        epi(rbl, rbl + pl < n_rows, pacc0, px0);
+        if (nfull == npairs) epi(rbl + TILE, rbl + TILE + pl < n_rows, pacc1, px1);
+#undef PFM_DX_TAIL_AT
+#undef PFM_DX_PAIR_AT
+#undef PFM_DX_NONE
+#undef PFM_DX_NEXT
+#undef PFM_DX_BODY
+#undef PFM_DX_MFMAQ1
+#undef PFM_DX_MFMAQ
+#undef PFM_DX_LOADQ1
+#undef PFM_DX_LOADQ
+#undef PFM_DX_K
+    }
 }
 
 // ---- per-jet record of the reductions over jets (floats) ------------------------------------------------------------

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     const float* evec = lds + c.vin;  // [temb ; cond_l] is a prefix of vin (Cl in {0, C})
     PFM_BSTAMP(1);
 
+#ifndef PFM_AB_NOHEAD  // (timing-only ablation: head skipped, G left as it is)
     // ---- head backward (epic.py:387-391): da3 = dv * mask * phi'(v);  G = W3^T da3 ----
     for (int i = tid; i < j.N * j.F; i += NT) {
         const int p = i / j.F;
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     }
     __syncthreads();
 
+#endif
     PFM_BSTAMP(2);
     const bool want_dt = dtemb != nullptr;
     if (want_dt && tid < j.T) {  // fc_l3 extras, KMAJOR [Ke][F]: d temb[k] = sum_f We3[k][f] db3j[f]   (db3j written before the barrier above)
@@ -175,12 +177,31 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     if (want_dt) __syncthreads();
     f32x4 a1[8], a2[8];
     const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
+    // the dX products address this jet's saved record and gradient rows as buffers: wave-uniform block / row-base offset + a per-lane
+    // constant (row pl of a tile, the lane's four output features), LDS rows as a per-lane constant + an immediate
+    const blob_rsrc rs_sv = make_blob_rsrc(sv, sl.total);
+    const blob_rsrc rs_da = make_blob_rsrc(daj, (int64_t)bw.nblk * j.N * H);
+    const int gofs = (pl * H + 4 * oslot) * 4;          // bytes: [row pl][features 4 oslot ..] of a row-major (rows, H) block
+    const int ooff = pl * H + ((oslot ^ pl) << 2);      // floats: the same element in a swizzled LDS tile (lds_off(pl, oslot))
+    const float* const mrow = maskf + pl;
+#if defined(PFM_AB_NOSTORE)
+#define PFM_DA_STORE(off, v) ((void)(v))
+#elif defined(PFM_BWD_PLAIN_ST)
+#define PFM_DA_STORE(off, v) (*reinterpret_cast<f32x4*>(daj + (off) + (gofs >> 2)) = (v))
+#else
+#define PFM_DA_STORE(off, v) bstore4(rs_da, (off), gofs, (v))  // (WRONG results on gfx950: see below)
+#endif
+#if defined(PFM_AB_NOLOAD)
+#define PFM_SV_LOAD(off) (f32x4{1.f, 1.f, 1.f, 1.f})
+#elif defined(PFM_BWD_PLAIN_LD)
+#define PFM_SV_LOAD(off) (*reinterpret_cast<const f32x4*>(sv + (off) + (gofs >> 2)))
+#else
+#define PFM_SV_LOAD(off) bload4(rs_sv, (off), gofs)
+#endif
     // ---- EPiC layers, last to first ----
     for (int k = j.layers - 1; k >= 0; --k) {
         const pfm_epic_layer& ly = d.layer[k];
         const float* xo = sv + sl.xo + k * sl.lstride;                           // h_{k+1}
-        const float* l1 = sv + sl.l1 + k * sl.lstride;                           // inner activation
-        const float* hin = sv + (k > 0 ? sl.xo + (k - 1) * sl.lstride : sl.x2);  // h_k
         const float* g1 = sv + sl.glayer + k * sl.gstride;
         const float* gout = g1 + H;
         const float* gin = (k > 0) ? sv + sl.glayer + (k - 1) * sl.gstride + H : sv + sl.gstem;
@@ -188,7 +209,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         load_afrag(a2, rs, ly.lc2.AT, w, lane);
         float* rstage = rec + (1 + k) * BwdRec::STAGE;
         float* da2 = daj + (size_t)(1 + 2 * k) * j.N * H;  // pairs with l1_k: dW of fc_local2 (epic.py:198-200)
-        float* da1 = daj + (size_t)(2 + 2 * k) * j.N * H;  // pairs with h_k : dW of fc_local1 (epic.py:194-196)
+        // da block 2 + 2k: da1, pairs with h_k: dW of fc_local1 (epic.py:194-196)
         // (1) da2 = G * phi'(h_{k+1}) in place (and to `da`); db2j = column sums.  Only for the last layer: for the others
         //     step (7) of the layer above has already done it in its epilogue.
         if (k == j.layers - 1) {
@@ -218,19 +239,23 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         // (3) da1 = (W_lc2^T da2) * phi'(l1) -> Hb (and to `da`); db1j = column sums
         {
             f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+            const int64_t l1_off = sl.l1 + (int64_t)k * sl.lstride, da1_off = (int64_t)(2 + 2 * k) * j.N * H;
             gemm_dx<BF16>(a2, G, n_rows,
-                    [&](int p, int os) { return *reinterpret_cast<const f32x4*>(l1 + p * H + 4 * os); },
-                    [&](int p, int os, f32x4 acc, f32x4 lv) {
+                    [&](int rb) { return PFM_SV_LOAD(l1_off + rb * H); },
+                    [&](int rb, bool valid, f32x4 acc, f32x4 lv) {
                         acc *= dlrelu4(lv, slope);
-                        *reinterpret_cast<f32x4*>(Hb + lds_off(p, os)) = acc;
-                        *reinterpret_cast<f32x4*>(da1 + p * H + 4 * os) = acc;
-                        ps += acc;
+                        if (valid) {
+                            *reinterpret_cast<f32x4*>(Hb + rb * H + ooff) = acc;
+                            PFM_DA_STORE(da1_off + rb * H, acc);
+                            ps += acc;
+                        }
                     });
             ps = colsum16(ps);
             if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj1 + 4 * oslot) = ps;
         }
         PFM_BSTAMP(12);
         load_afrag(a1, rs, ly.lc1.AT, w, lane);  // step (7)'s weights: land behind the per-jet steps below (32 VGPRs less across (3))
+#ifndef PFM_AB_NOCHAIN  // (timing-only ablation: the per-jet steps between the two dX products skipped)
         // vin of this stage (for the global backward): [temb;cond;mean_k;sum_k;g_k]
         build_vin(j, lds, c, sv + sl.pool + k * sl.pstride, gin, true);
         __syncthreads();
@@ -257,32 +282,39 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         rec_put(rstage + BwdRec::VIN2, lds + c.vin2, VIN2_FLOATS, 128);
         rec_put(rstage + BwdRec::DAG1, lds + c.dag1, H, 192);
         rec_put(rstage + BwdRec::DAG2, lds + c.dag2, MAXL, 224);
+#else
+        __syncthreads();
+#endif
         PFM_BSTAMP(14);
         // (7) dh_k = W_lc1^T da1 + da2 (residual) + mask * dP_k (pooling) -> G in place; for k > 0 times phi'(h_k) right away:
         //     that is da2 of layer k - 1 (step (1) of the next iteration, fused here: one pass over G and one L2 round trip less)
         {
             const f32x4 dP4 = *reinterpret_cast<const f32x4*>(lds + c.dP + 4 * oslot);
             if (k > 0) {
-                float* da2n = daj + (size_t)(1 + 2 * (k - 1)) * j.N * H;
                 f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+                const int64_t hin_off = sl.xo + (int64_t)(k - 1) * sl.lstride, da2n_off = (int64_t)(1 + 2 * (k - 1)) * j.N * H;
                 gemm_dx<BF16>(a1, Hb, n_rows,
-                        [&](int p, int os) { return *reinterpret_cast<const f32x4*>(hin + p * H + 4 * os); },
-                        [&](int p, int os, f32x4 acc, f32x4 hv) {
-                            f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, os));
-                            gv = (gv + acc + dP4 * maskf[p]) * dlrelu4(hv, slope);
-                            *reinterpret_cast<f32x4*>(G + lds_off(p, os)) = gv;
-                            *reinterpret_cast<f32x4*>(da2n + p * H + 4 * os) = gv;
-                            ps += gv;
+                        [&](int rb) { return PFM_SV_LOAD(hin_off + rb * H); },
+                        [&](int rb, bool valid, f32x4 acc, f32x4 hv) {
+                            if (valid) {
+                                f32x4 gv = *reinterpret_cast<f32x4*>(G + rb * H + ooff);
+                                gv = (gv + acc + dP4 * mrow[rb]) * dlrelu4(hv, slope);
+                                *reinterpret_cast<f32x4*>(G + rb * H + ooff) = gv;
+                                PFM_DA_STORE(da2n_off + rb * H, gv);
+                                ps += gv;
+                            }
                         });
                 ps = colsum16(ps);
                 if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj2 + 4 * oslot) = ps;  // db2j of layer k - 1
             } else {
                 gemm_dx<BF16>(a1, Hb, n_rows,
-                        [&](int, int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
-                        [&](int p, int os, f32x4 acc, f32x4) {
-                            f32x4 gv = *reinterpret_cast<f32x4*>(G + lds_off(p, os));
-                            gv += acc + dP4 * maskf[p];
-                            *reinterpret_cast<f32x4*>(G + lds_off(p, os)) = gv;
+                        [&](int) { return f32x4{0.f, 0.f, 0.f, 0.f}; },
+                        [&](int rb, bool valid, f32x4 acc, f32x4) {
+                            if (valid) {
+                                f32x4 gv = *reinterpret_cast<f32x4*>(G + rb * H + ooff);
+                                gv += acc + dP4 * mrow[rb];
+                                *reinterpret_cast<f32x4*>(G + rb * H + ooff) = gv;
+                            }
                         });
             }
         }
@@ -328,15 +360,16 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     PFM_BSTAMP(21);
     // da1s = (W_l2^T da2s + da2s) * phi'(x1) -> Hb   (epic.py:364-366, 360-362)
     {
-        const float* x1 = sv + sl.x1;
         f32x4 ps = {0.f, 0.f, 0.f, 0.f};
         gemm_dx<BF16>(a2, G, n_rows,
-                [&](int p, int os) { return *reinterpret_cast<const f32x4*>(x1 + p * H + 4 * os); },
-                [&](int p, int os, f32x4 acc, f32x4 xv) {
-                    acc += *reinterpret_cast<const f32x4*>(G + lds_off(p, os));
-                    acc *= dlrelu4(xv, slope);
-                    *reinterpret_cast<f32x4*>(Hb + lds_off(p, os)) = acc;
-                    ps += acc;
+                [&](int rb) { return PFM_SV_LOAD(sl.x1 + rb * H); },
+                [&](int rb, bool valid, f32x4 acc, f32x4 xv) {
+                    if (valid) {
+                        acc += *reinterpret_cast<const f32x4*>(G + rb * H + ooff);
+                        acc *= dlrelu4(xv, slope);
+                        *reinterpret_cast<f32x4*>(Hb + rb * H + ooff) = acc;
+                        ps += acc;
+                    }
                 });
         ps = colsum16(ps);
         if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj1 + 4 * oslot) = ps;

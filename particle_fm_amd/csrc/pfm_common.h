@@ -183,6 +183,11 @@ __device__ __forceinline__ blob_rsrc make_blob_rsrc(const float* blob, int64_t t
 __device__ __forceinline__ f32x4 bload4(blob_rsrc rs, int64_t elem_off, int lane_bytes) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes, (int)(elem_off << 2), 0));
 }
+// 16 bytes to  base + 4*elem_off (wave-uniform) + lane_bytes (per lane); a lane whose offset lies outside the resource stores nothing
+__device__ __forceinline__ void bstore4(blob_rsrc rs, int64_t elem_off, int lane_bytes, f32x4 v) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rs, lane_bytes, (int)(elem_off << 2), 0);
+}
 
 // split-fp16 operand helpers (PFM_F_F16X3_MFMA; see epic_nfe.h): x = hi + lo * 2^-11, hi = fp16(x), lo = fp16((x - hi) * 2^11)
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
