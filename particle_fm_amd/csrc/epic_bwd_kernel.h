@@ -94,6 +94,10 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     const float* evec = lds + c.vin;  // [temb ; cond_l] is a prefix of vin (Cl in {0, C})
     PFM_BSTAMP(1);
 
+    // the first dX product's weights (step (3) of the last layer, or the stem's): in flight across the head
+    f32x4 a2[8];
+    const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
+    load_afrag(a2, rs, j.layers > 0 ? d.layer[j.layers - 1].lc2.AT : d.l2.AT, w, lane);
 #ifndef PFM_AB_NOHEAD  // (timing-only ablation: head skipped, G left as it is)
     // ---- head backward (epic.py:387-391): da3 = dv * mask * phi'(v);  G = W3^T da3 ----
     for (int i = tid; i < j.N * j.F; i += NT) {
@@ -175,21 +179,26 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         lds[c.dte + tid] += a;
     }
     if (want_dt) __syncthreads();
-    f32x4 a1[8], a2[8];
-    const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
+    f32x4 a1[8];
     // the dX products address this jet's saved record and gradient rows as buffers: wave-uniform block / row-base offset + a per-lane
     // constant (row pl of a tile, the lane's four output features), LDS rows as a per-lane constant + an immediate
     const blob_rsrc rs_sv = make_blob_rsrc(sv, sl.total);
+#ifdef PFM_BWD_BUF_ST
     const blob_rsrc rs_da = make_blob_rsrc(daj, (int64_t)bw.nblk * j.N * H);
+#endif
     const int gofs = (pl * H + 4 * oslot) * 4;          // bytes: [row pl][features 4 oslot ..] of a row-major (rows, H) block
     const int ooff = pl * H + ((oslot ^ pl) << 2);      // floats: the same element in a swizzled LDS tile (lds_off(pl, oslot))
     const float* const mrow = maskf + pl;
+    // Gradient rows leave through ordinary global stores.  buffer_store_dwordx4 with an SGPR soffset gave WRONG rows on gfx950 (lanes
+    // 12..15 of a tile, dwords 1 and 3, in the bodies of jets with an odd tile count: tests/diag/ab_bwd.py against the previous build):
+    // hipcc assumes that form has no store-data hazard and reuses the data registers at once; the global_store form gets the hazard's
+    // wait states.  (-DPFM_BWD_BUF_ST keeps the buffer form for that diagnosis; PFM_AB_*: timing-only ablations, tests/diag.)
 #if defined(PFM_AB_NOSTORE)
 #define PFM_DA_STORE(off, v) ((void)(v))
-#elif defined(PFM_BWD_PLAIN_ST)
-#define PFM_DA_STORE(off, v) (*reinterpret_cast<f32x4*>(daj + (off) + (gofs >> 2)) = (v))
+#elif defined(PFM_BWD_BUF_ST)
+#define PFM_DA_STORE(off, v) bstore4(rs_da, (off), gofs, (v))
 #else
-#define PFM_DA_STORE(off, v) bstore4(rs_da, (off), gofs, (v))  // (WRONG results on gfx950: see below)
+#define PFM_DA_STORE(off, v) (*reinterpret_cast<f32x4*>(daj + (off) + (gofs >> 2)) = (v))
 #endif
 #if defined(PFM_AB_NOLOAD)
 #define PFM_SV_LOAD(off) (f32x4{1.f, 1.f, 1.f, 1.f})
@@ -206,7 +215,6 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         const float* gout = g1 + H;
         const float* gin = (k > 0) ? sv + sl.glayer + (k - 1) * sl.gstride + H : sv + sl.gstem;
         PFM_BSTAMP(10);
-        load_afrag(a2, rs, ly.lc2.AT, w, lane);
         float* rstage = rec + (1 + k) * BwdRec::STAGE;
         float* da2 = daj + (size_t)(1 + 2 * k) * j.N * H;  // pairs with l1_k: dW of fc_local2 (epic.py:198-200)
         // da block 2 + 2k: da1, pairs with h_k: dW of fc_local1 (epic.py:194-196)
@@ -254,7 +262,10 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
             if (pl == 0) *reinterpret_cast<f32x4*>(lds + c.dbj1 + 4 * oslot) = ps;
         }
         PFM_BSTAMP(12);
-        load_afrag(a1, rs, ly.lc1.AT, w, lane);  // step (7)'s weights: land behind the per-jet steps below (32 VGPRs less across (3))
+        // step (7)'s weights and the NEXT dX product's (step (3) of layer k - 1, or the stem's): they land behind
+        // the per-jet steps below
+        load_afrag(a1, rs, ly.lc1.AT, w, lane);
+        load_afrag(a2, rs, k > 0 ? d.layer[k - 1].lc2.AT : d.l2.AT, w, lane);
 #ifndef PFM_AB_NOCHAIN  // (timing-only ablation: the per-jet steps between the two dX products skipped)
         // vin of this stage (for the global backward): [temb;cond;mean_k;sum_k;g_k]
         build_vin(j, lds, c, sv + sl.pool + k * sl.pstride, gin, true);
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     rec_put(rec + BwdRec::VIN2, lds + c.vin2, VIN2_FLOATS, 128);
     rec_put(rec + BwdRec::DAG1, lds + c.dag1, H, 192);
     rec_put(rec + BwdRec::DAG2, lds + c.dag2, MAXL, 224);
-    load_afrag(a2, rs, d.l2.AT, w, lane);
+    // (a2 = fc_l2's transposed block: requested behind step (3) of layer 0, or ahead of the head when there is no layer)
     // da2s = (G + mask * dP) * phi'(x2) in place; db2j
     {
         const float* x2 = sv + sl.x2;
