@@ -251,7 +251,7 @@ def main():
     ap.add_argument("--no-pack", action="store_true", help="jetnet30: one jet per workgroup (default: two, PFM_F_PACK_JETS)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3", "bf16"],
                     help="matrix operands: f16x3 = split fp16, fp32-grade accuracy (jet-resident EPiC: the sampler; row-matrix paths: "
-                         "every Linear, training included); bf16 = the jet-resident EPiC sampler only (BASELINE cfg 2 is quoted in bf16; "
+                         "every Linear, training included); bf16 = bf16 operands in every Linear of the model, training included (BASELINE cfg 2 is quoted in bf16; "
                          "training stays fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=None, help="sampler calls in flight (1 = strictly sequential; default 2, "

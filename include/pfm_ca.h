@@ -29,6 +29,7 @@ extern "C" {
 #define PFM_CA_MAX_LAYERS 16 /* from/to layer pairs */
 #define PFM_CA_MAX_TOKENS 8
 #define PFM_CA_F_F16X3 1        /* split-fp16 Linears, see PFM_TF_F_F16X3 */
+#define PFM_CA_F_BF16 32        /* bf16 operands in the particle-side Linears (forward and dX), see PFM_TF_F_BF16; tokens, attention, dW: fp32 */
 #define PFM_CA_F_TEMB_SINCOS 2  /* see PFM_TF_F_TEMB_SINCOS */
 #define PFM_CA_F_VALID_ROWS 4    /* see PFM_TF_F_VALID_ROWS: inference over the valid particles only */
 #define PFM_CA_F_GRAPH_STEPS 8   /* pfm_ca_sample_midpoint on a non-null stream: step 0 is launched directly, the step body is captured

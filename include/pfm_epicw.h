@@ -35,6 +35,8 @@ extern "C" {
 #define PFM_EW_MAX_LAYERS 24
 #define PFM_EW_F_TEMB_SINCOS 2 /* as PFM_TF_F_TEMB_SINCOS */
 #define PFM_EW_F_F16X3 1 /* desc.flags: as PFM_TF_F_F16X3 (pfm_tf.h) */
+#define PFM_EW_F_BF16 32 /* desc.flags: as PFM_TF_F_BF16 (pfm_tf.h): the particle Linears (forward and dX) on bf16 operands; the per-jet chain,
+                          * the pooling and the dW GEMMs stay fp32 */
 
 typedef struct { int64_t W, b, WT; } pfm_ew_lin; /* MFMA_AK weights, bias (-1: none), MFMA_AKT copy (-1: none) */
 

@@ -33,6 +33,7 @@ extern "C" {
 
 #define PFM_MDMA_ABI_VERSION 1
 #define PFM_MDMA_MAX_LAYERS 16
+#define PFM_MDMA_F_BF16 32u /* bf16 operands in the particle-stream Linears (forward and dX), see PFM_TF_F_BF16 (pfm_tf.h) */
 #define PFM_MDMA_F_TEMB_SINCOS 2u /* t_emb = "sincos" (flow_matching_module.py:208-211) instead of "cosine" */
 
 typedef struct {

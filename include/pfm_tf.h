@@ -56,6 +56,10 @@ extern "C" {
 #define PFM_TF_F_ONE_STREAM 16 /* pfm_tf_sample_midpoint stays on the caller's stream (no half-batch split): for callers that keep several
                                 * sampler calls in flight themselves (generate_data's batch pipeline, bench_secondary --overlap) */
 #define PFM_TF_F_TEMB_SINCOS 2 /* t_emb="sincos": temb = [cos(f t) ; sin(f t)], freqs table = [f ; f] (flow_matching_module.py:208-211) */
+#define PFM_TF_F_BF16 32 /* desc.flags: every Linear (forward and dX; the dW GEMMs, LayerNorm, softmax and attention products stay fp32) on
+                          * v_mfma_f32_16x16x32_bf16 with both operands rounded to bf16, fp32 accumulate, fp32 activations: what
+                          * trainer.precision="bf16-mixed" (configs/trainer/default.yaml:11-12: autocast around the same modules) asks of
+                          * the nn.Linear layers.  Bar: no further from the fp32 vectors than the oracle under torch.autocast(bfloat16) */
 #define PFM_TF_F_F16X3 1 /* desc.flags: every Linear (forward and dX) as three fp16 MFMAs on (hi, lo) splits of both operands,
                             fp32 accumulate: fp32-grade products (see PFM_F_F16X3_MFMA in pfm_hip.h); needs |x| < 65504 */
 

@@ -100,7 +100,7 @@ int linear(const Plan& p, int rows, int per_jet, const float* A, int lda, int K,
     a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.M = rows; a.K = K; a.NO = NO; a.N = per_jet; a.act = act;
     a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
     const int ni = (ln && ln->gamma >= 0) ? K / 64 : 0;
-    if (launch_linear_kernel(a, ni, (p.d->flags & PFM_CA_F_F16X3) != 0, num_cus(), p.s))
+    if (launch_linear_kernel(a, ni, (p.d->flags & PFM_CA_F_F16X3) ? 1 : ((p.d->flags & PFM_CA_F_BF16) ? 2 : 0), num_cus(), p.s))
         return set_err(PFM_E_BADARG, "LayerNorm width must be 128, 256, 384 or 512");
     return check_hip(hipGetLastError(), "tf_linear_kernel launch (ca)");
 }
@@ -108,7 +108,7 @@ int linear(const Plan& p, int rows, int per_jet, const float* A, int lda, int K,
 // two plain LayerNorm-Linears of the same particle rows (from.kv and to.q of a layer pair) in one launch (tf_linear_panel2_kernel); false: not launched
 bool linear_pair(const Plan& p, int rows, int per_jet, const float* A, int D, const pfm_tf_lin& w1, const pfm_tf_norm* n1, int NO1, float* out1,
                  const pfm_tf_lin& w2, const pfm_tf_norm* n2, int NO2, float* out2) {
-    if ((p.d->flags & PFM_CA_F_F16X3) || !n1 || !n2 || n1->gamma < 0 || n2->gamma < 0) return false;
+    if ((p.d->flags & (PFM_CA_F_F16X3 | PFM_CA_F_BF16)) || !n1 || !n2 || n1->gamma < 0 || n2->gamma < 0) return false;
     LinArgs a;
     a.A = A; a.A2 = nullptr; a.lda2 = 0; a.K1 = D; a.blob = p.blob; a.jb = nullptr; a.R = nullptr; a.Y = nullptr; a.ldy = 0; a.rowjet = nullptr;
     const bool prow = p.rowsrc && rows == p.M && per_jet == p.d->n_points;
@@ -128,7 +128,7 @@ int dense_block(const Plan& p, int rows, int per_jet, float* mid, int D, int Hd,
                 const pfm_tf_lin& d2, const pfm_tf_norm* n2, float* dh, float* out, const float* att = nullptr, const pfm_tf_lin* lo = nullptr,
                 const pfm_tf_norm* no = nullptr, const float* res = nullptr) {
     bool pre_done = false;
-    if (!(p.d->flags & PFM_CA_F_F16X3) && n1 && n2 && n1->gamma >= 0 && n2->gamma >= 0) {
+    if (!(p.d->flags & (PFM_CA_F_F16X3 | PFM_CA_F_BF16)) && n1 && n2 && n1->gamma >= 0 && n2->gamma >= 0) {
         LinArgs a, b;
         a.A = mid; a.A2 = nullptr; a.lda2 = 0; a.K1 = D; a.blob = p.blob; a.jb = jb; a.R = nullptr; a.Y = nullptr; a.ldy = 0;
         const bool prow = p.rowsrc && rows == p.M && per_jet == p.d->n_points;

@@ -84,29 +84,6 @@ __device__ __forceinline__ void load_afrag(f32x4 (&a)[8], blob_rsrc rs, int64_t 
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).w, (bv0).w, acc0, 0, 0, 0);      \
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((av).w, (bv1).w, acc1, 0, 0, 0);
 
-// bf16 operands (PFM_F_BF16_MFMA; the kernels issue v_mfma_f32_16x16x32_bf16, see pack_bf16x8): the fp32 float4 a lane already holds -- four
-// consecutive k of one row / column -- is exactly that instruction's operand after rounding, so one MFMA replaces four.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-// (plain vector conversion, not inline asm: the compiler must see the VALU write to insert the MFMA read hazard nop)
-__device__ __forceinline__ s16x4 pack_bf16(f32x4 v) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};  // one v_cvt_pk_bf16_f32 each (round-to-nearest-even, gfx950)
-    const u32x2 u = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)),
-                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2))};
-    return __builtin_bit_cast(s16x4, u);
-}
-
-// gfx950's v_mfma_f32_16x16x32_bf16 contracts 32 k per instruction (lane (i, q) holds 8 of them) in 16 cycles.  The two float4
-// a lane holds for k-tiles 2 kt2 and 2 kt2 + 1 -- k = 32 kt2 + 16 h + 4 q + r -- are, rounded and concatenated, a valid operand: the
-// instruction sums over its 32 k slots whatever their order, as long as A and B use the same one.  One MFMA replaces eight fp32 ones.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ bf16x8 pack_bf16x8(f32x4 lo, f32x4 hi) {
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x4 a = pack_bf16(lo), b = pack_bf16(hi);
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
-}
 // A operand of one 128x128 block for this wave from its MFMA_A16 copy (pfm_hip.h): 4 x 16 bytes = 16 VGPRs, already bf16
 __device__ __forceinline__ void load_afrag16(f32x4 (&a)[4], blob_rsrc rs, int64_t A16_off, int w, int lane) {
     const int lb = ((w * 4) * 64 + lane) * 16;

@@ -437,7 +437,7 @@ int linear(const Plan& p, int Mrows, const float* A, int lda, int K1, const floa
         while (nstep % ks) --ks;
         if (ks > 1 && (int64_t)ks * Mrows * NO <= p.part_floats) { a.part = p.part; a.ksplit = ks; }
     }
-    launch_linear_kernel(a, 0, (p.d->flags & PFM_EW_F_F16X3) != 0, num_cus(), p.s);
+    launch_linear_kernel(a, 0, (p.d->flags & PFM_EW_F_F16X3) ? 1 : ((p.d->flags & PFM_EW_F_BF16) ? 2 : 0), num_cus(), p.s);
     int rc = check_hip(hipGetLastError(), "tf_linear_kernel launch (epicw)");
     if (rc || a.ksplit == 1) return rc;
     const int64_t n4 = (int64_t)Mrows * (NO / 4);

@@ -498,7 +498,7 @@ int linear(const Plan& p, const float* A, int K, int64_t W, int64_t b, int NO, c
     a.blob_floats = p.d->blob_floats; a.W = W; a.b = b; a.gamma = -1; a.beta = -1; a.jb_stride = p.d->hidden;
     a.lda = K; a.ldr = NO; a.ldo = NO; a.M = p.M; a.K = K; a.NO = NO; a.N = p.d->n_points; a.act = act;
     a.slope = p.d->neg_slope; a.eps = p.d->ln_eps; a.pre_act = pre_act ? 1 : 0;
-    if (launch_linear_kernel(a, 0, false, num_cus(), p.s)) return set_err(PFM_E_BADARG, "tf_linear_kernel: unsupported shape");
+    if (launch_linear_kernel(a, 0, (p.d->flags & PFM_MDMA_F_BF16) ? 2 : 0, num_cus(), p.s)) return set_err(PFM_E_BADARG, "tf_linear_kernel: unsupported shape");
     return check_hip(hipGetLastError(), "tf_linear_kernel launch (mdma)");
 }
 

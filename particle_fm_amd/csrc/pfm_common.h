@@ -207,6 +207,29 @@ __device__ __forceinline__ void x3_split8(f32x4 x0, f32x4 x1, h8& hi, h8& lo) {
     hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
     lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// bf16 operands (PFM_F_BF16_MFMA; the kernels issue v_mfma_f32_16x16x32_bf16, see pack_bf16x8): the fp32 float4 a lane already holds -- four
+// consecutive k of one row / column -- is exactly that instruction's operand after rounding, so one MFMA replaces four.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// (plain vector conversion, not inline asm: the compiler must see the VALU write to insert the MFMA read hazard nop)
+__device__ __forceinline__ s16x4 pack_bf16(f32x4 v) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};  // one v_cvt_pk_bf16_f32 each (round-to-nearest-even, gfx950)
+    const u32x2 u = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2)),
+                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2))};
+    return __builtin_bit_cast(s16x4, u);
+}
+
+// gfx950's v_mfma_f32_16x16x32_bf16 contracts 32 k per instruction (lane (i, q) holds 8 of them) in 16 cycles.  The two float4
+// a lane holds for k-tiles 2 kt2 and 2 kt2 + 1 -- k = 32 kt2 + 16 h + 4 q + r -- are, rounded and concatenated, a valid operand: the
+// instruction sums over its 32 k slots whatever their order, as long as A and B use the same one.  One MFMA replaces eight fp32 ones.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 pack_bf16x8(f32x4 lo, f32x4 hi) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x4 a = pack_bf16(lo), b = pack_bf16(hi);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 __device__ __forceinline__ int lds_off(int p, int slot) { return p * H + ((slot ^ (p & 15)) << 2); }
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return fmaxf(x, x * slope); }

@@ -353,12 +353,16 @@ constexpr int X3ROW = 72;  // halfs per LDS row of an X3 slice (64 + 8 pad)
 // NS = 16-row A operands (output tiles) per wave: 2 in a full 128-output column chunk.  A last chunk of <= 64 outputs (NO = 320:
 // 128 + 128 + 64) runs the NS = 1 body, every wave one operand, so that workgroup costs half a full one instead of idling two
 // of its waves; the two bodies are separate code paths behind one workgroup-uniform branch (separate register allocations).
-template <int NI, int TPW, bool X3, int NS>
+// MODE 2 (BF16; PFM_*_F_BF16: what trainer.precision = "bf16-mixed" means for the Linears of these models in the reference -- autocast
+// around nn.Linear): operands rounded to bf16 (round-to-nearest-even), ONE v_mfma_f32_16x16x32_bf16 per (output tile, row tile, 32 k),
+// fp32 accumulate, fp32 activations in HBM.  Same staging as X3 with the hi plane only.
+template <int NI, int TPW, int MODE, int NS>
 __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ lds, int rt, int ch, int ks) {
+    constexpr bool X3 = MODE == 1, BF = MODE == 2, HALF = MODE != 0;  // HALF: 16-bit operand planes in LDS, weights read in k8 order
     constexpr bool LN = NI > 0;
     constexpr int RB = 16 * TPW, SI = RB / 16;  // SI: float4 staged per thread and 64-wide step
     float* const tile = lds;             // two RB x 64 slices, 16-byte slots XOR-swizzled with (row & 15)
-    float* const stat = lds + (X3 ? RB * X3ROW * 2 : RB * 128);  // RB x (mean, rstd), behind the slices
+    float* const stat = lds + (HALF ? RB * X3ROW * 2 : RB * 128);  // RB x (mean, rstd), behind the slices
     const int tid = threadIdx.x, lane = tid & 63, pl = lane & 15, q = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the weight-block offsets below become SGPR offsets of the buffer loads
     const int row0 = rt * RB;
@@ -415,7 +419,7 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int64_t base = a.W + ((int64_t)((ob >> 4) + s) * nst_all + step) * 1024;
-                if (X3) {  // k8 order: af[2 kp + h] = k-tile 2 kp + (q >> 1), lane (pl, 2 (q & 1) + h)  (see load_afrag_k8)
+                if (HALF) {  // k8 order: af[2 kp + h] = k-tile 2 kp + (q >> 1), lane (pl, 2 (q & 1) + h)  (see load_afrag_k8)
 #pragma unroll
                     for (int kp = 0; kp < 2; ++kp)
 #pragma unroll
@@ -442,7 +446,7 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
         }
     };
     auto step_fn = [&](f32x4 (&af)[NS][4], f32x4 (&st)[SI], f32x4 (&gb)[2], f32x4 (&afn)[NS][4], f32x4 (&stn)[SI], f32x4 (&gbn)[2], int step) {
-        float* const buf = tile + (step & 1) * (X3 ? RB * X3ROW : RB * 64);  // X3: hi plane, lo plane RB * X3ROW halfs later
+        float* const buf = tile + (step & 1) * (HALF ? RB * X3ROW : RB * 64);  // X3: hi plane, lo plane RB * X3ROW halfs later (BF16: unused)
         if (LN) {
             const f32x4 g4 = gb[0], b4 = gb[1];
 #pragma unroll
@@ -466,6 +470,10 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
                 *reinterpret_cast<h4*>(dp) = hi;
                 *reinterpret_cast<h4*>(dp + RB * X3ROW) = lo;
             }
+        } else if (BF) {
+            short* hb = reinterpret_cast<short*>(buf);
+#pragma unroll
+            for (int i = 0; i < SI; ++i) *reinterpret_cast<s16x4*>(hb + (sr + 16 * i) * X3ROW + 4 * sc4) = pack_bf16(st[i]);
         } else {
 #pragma unroll
             for (int i = 0; i < SI; ++i) {
@@ -496,6 +504,24 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
                         cor[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][kp], bl, cor[s][t], 0, 0, 0);
                         cor[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s][kp], bh, cor[s][t], 0, 0, 0);
                     }
+                }
+            }
+            return;
+        }
+        if (BF) {
+            const short* hb = reinterpret_cast<const short*>(buf);
+            bf16x8 wb[NS][2];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp) wb[s][kp] = pack_bf16x8(af[s][2 * kp], af[s][2 * kp + 1]);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hb + (16 * t + pl) * X3ROW + 32 * kp + 8 * q);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s][kp], bh, acc[s][t], 0, 0, 0);
                 }
             }
             return;
@@ -568,7 +594,7 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
     }
 }
 
-template <int NI, int TPW = 4, bool X3 = false>
+template <int NI, int TPW = 4, int MODE = 0>  // MODE: 0 fp32 MFMA, 1 split-fp16 (X3), 2 bf16 operands
 __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int rt, ch;
@@ -578,8 +604,8 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         a.M = *a.m_dev;
         if (rt * 16 * TPW >= a.M) return;
     }
-    if (a.NO - ch * BN <= 64) tf_linear_body<NI, TPW, X3, 1>(a, lds, rt, ch, ks);
-    else tf_linear_body<NI, TPW, X3, 2>(a, lds, rt, ch, ks);
+    if (a.NO - ch * BN <= 64) tf_linear_body<NI, TPW, MODE, 1>(a, lds, rt, ch, ks);
+    else tf_linear_body<NI, TPW, MODE, 2>(a, lds, rt, ch, ks);
 }
 
 #ifdef PFM_TF_DIAG
@@ -1180,7 +1206,9 @@ inline int pick_row_tile(int64_t M, int chunks, int cus, bool allow128) {
 }
 
 // launches tf_linear_kernel for `a` (everything but row_tiles filled in); ni = K / 64 of the LayerNorm prologue or 0
-inline int launch_linear_kernel(LinArgs& a, int ni, bool x3, int cus, hipStream_t s) {
+// mode: 0 fp32 MFMA, 1 split-fp16 operands (X3), 2 bf16 operands (lin_mode() of the descriptor flags)
+inline int launch_linear_kernel(LinArgs& a, int ni, int mode, int cus, hipStream_t s) {
+    const bool x3 = mode != 0;  // 16-bit operand planes: no row-panel kernel, no 128-row tile, the X3 LDS layout
     const int chunks = (a.NO + BN - 1) / BN;
     {   // the row-panel kernel where a launch has the rows to fill the GPU with 32-row workgroups
         static int panel = -1;
@@ -1215,9 +1243,12 @@ inline int launch_linear_kernel(LinArgs& a, int ni, bool x3, int cus, hipStream_
     const int grid = ((a.row_tiles + 7) / 8) * 8 * chunks * a.ksplit;
     const size_t lds = x3 ? (size_t)rb * X3ROW * 2 * 2 * 2 + 2 * rb * sizeof(float) : (size_t)(rb * 128 + 2 * rb) * sizeof(float);
 #define PFM_LAUNCH_LIN(NI)                                                                                  \
-    if (x3) {                                                                                               \
-        if (rb == 32) hipLaunchKernelGGL((tf_linear_kernel<NI, 2, true>), dim3(grid), dim3(LT), lds, s, a); \
-        else hipLaunchKernelGGL((tf_linear_kernel<NI, 4, true>), dim3(grid), dim3(LT), lds, s, a);          \
+    if (mode == 2) {                                                                                        \
+        if (rb == 32) hipLaunchKernelGGL((tf_linear_kernel<NI, 2, 2>), dim3(grid), dim3(LT), lds, s, a);    \
+        else hipLaunchKernelGGL((tf_linear_kernel<NI, 4, 2>), dim3(grid), dim3(LT), lds, s, a);             \
+    } else if (x3) {                                                                                        \
+        if (rb == 32) hipLaunchKernelGGL((tf_linear_kernel<NI, 2, 1>), dim3(grid), dim3(LT), lds, s, a);    \
+        else hipLaunchKernelGGL((tf_linear_kernel<NI, 4, 1>), dim3(grid), dim3(LT), lds, s, a);             \
     } else if (rb == 32) hipLaunchKernelGGL((tf_linear_kernel<NI, 2>), dim3(grid), dim3(LT), lds, s, a);    \
     else if (rb == 64) hipLaunchKernelGGL((tf_linear_kernel<NI, 4>), dim3(grid), dim3(LT), lds, s, a);      \
     else {                                                                                                  \

@@ -53,7 +53,7 @@ int launch_linear(const Plan& p, const float* A, int lda, int K, const pfm_tf_li
     a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.M = p.M; a.K = K; a.NO = NO; a.N = p.d->n_points; a.act = act ? 1 : 0;
     a.slope = p.d->neg_slope; a.eps = p.d->ln_eps;
     const int ni = (ln && ln->gamma >= 0) ? K / 64 : 0;
-    if (launch_linear_kernel(a, ni, (p.d->flags & PFM_TF_F_F16X3) != 0, num_cus(), p.s))
+    if (launch_linear_kernel(a, ni, (p.d->flags & PFM_TF_F_F16X3) ? 1 : ((p.d->flags & PFM_TF_F_BF16) ? 2 : 0), num_cus(), p.s))
         return set_err(PFM_E_BADARG, "LayerNorm width must be 128, 256, 384 or 512");
     return check_hip(hipGetLastError(), "tf_linear_kernel launch");
 }

@@ -189,7 +189,7 @@ class _FusedEncoder(FreqTableMixin, nn.Module):
         # what the kernels need to know beyond the reference's own arguments
         self.num_points, self.frequencies, self.add_time_to_input, self.t_emb = num_points, frequencies, add_time_to_input, t_emb
         self._layouts = {}
-        self.mfma_dtype = "fp32"  # "f16x3": every Linear on split-fp16 operands, fp32-grade accuracy
+        self.mfma_dtype = "fp32"  # "f16x3": every Linear on split-fp16 operands, fp32-grade accuracy; "bf16": bf16 operands (PFM_TF_F_BF16)
         # inference evaluates the valid particles only (PFM_*_F_VALID_ROWS): same numbers at valid particles, the reference's
         # unmasked values at padded positions (which every consumer multiplies by the mask) are not produced
         self.valid_rows_only = False
@@ -204,7 +204,7 @@ class _FusedEncoder(FreqTableMixin, nn.Module):
 
     def layout(self, num_points: Optional[int] = None):
         n = num_points or self.num_points
-        flags = (1 if self.mfma_dtype == "f16x3" else 0) | (4 if self.valid_rows_only else 0) | (self._GRAPH_FLAG if self.graph_replay else 0) | (0 if self.stream_split else self._ONE_STREAM_FLAG)
+        flags = {"fp32": 0, "f16x3": 1, "bf16": 32}[self.mfma_dtype] | (4 if self.valid_rows_only else 0) | (self._GRAPH_FLAG if self.graph_replay else 0) | (0 if self.stream_split else self._ONE_STREAM_FLAG)
         lay = self._layouts.get((n, flags))
         if lay is None:
             lay = self._layouts[(n, flags)] = self._LAYOUT(self.config(n), flags=flags)
@@ -223,8 +223,11 @@ class _FusedEncoder(FreqTableMixin, nn.Module):
         self.graph_replay = bool(on)
 
     def set_precision(self, precision) -> None:
-        """"f16x3" -> split-fp16 Linears; anything else (incl. Lightning's "bf16-mixed": no bf16 kernels on this path) fp32."""
-        self.mfma_dtype = "f16x3" if str(precision) == "f16x3" else "fp32"
+        """Accepts Lightning's spellings: "bf16", "bf16-mixed", "bf16-true" -> the Linears (forward and dX, inference and training) on bf16
+        operands with fp32 accumulate (PFM_TF_F_BF16 / PFM_CA_F_BF16; LayerNorm, softmax, attention products and the dW GEMMs stay fp32);
+        "f16x3" -> split-fp16 Linears (fp32-grade); anything else fp32."""
+        p = str(precision)
+        self.mfma_dtype = "bf16" if p.startswith("bf16") else ("f16x3" if p == "f16x3" else "fp32")
 
     def flat_parameters(self, layout=None) -> torch.Tensor:
         """All parameters in the layout's (= state_dict) order as one differentiable vector."""

@@ -127,7 +127,8 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
         self.skip_masked_tail = True
         # "bf16": the kernels of the jet-resident path (forward, samplers, loss forward, the backward's dX products) run the
         # particle Linears on bf16 MFMA with fp32 accumulate and fp32 activations (PFM_F_BF16_MFMA) -- what
-        # trainer.precision="bf16-mixed" means for this model in the reference.  The dW GEMM and the wide path stay fp32.
+        # trainer.precision="bf16-mixed" means for this model in the reference.  The dW GEMM stays fp32; the row-matrix
+        # path has the same switch for its particle Linears (PFM_EW_F_BF16).
         self.mfma_dtype = "fp32"
         # the midpoint sampler may put two short jets into one workgroup (PFM_F_PACK_JETS, include/pfm_hip.h): same results; worth
         # it for large batches of short jets only, hence opt-in
@@ -156,8 +157,8 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
     def layout(self, num_points: Optional[int] = None) -> EpicLayout:
         n = num_points or self.num_points
         wide = self.is_wide(n)
-        if wide:  # row-matrix GEMM path: only the split-fp16 flavour exists besides fp32
-            mode = 1 if self.mfma_dtype == "f16x3" else 0
+        if wide:  # row-matrix GEMM path: PFM_EW_F_F16X3 / PFM_EW_F_BF16
+            mode = {"fp32": 0, "f16x3": 1, "bf16": 32}[self.mfma_dtype]
         else:
             mode = {"fp32": 0, "bf16": 2, "f16x3": 4}[self.mfma_dtype] | (16 if self.pack_jets else 0)
         lay = self._layouts.get((n, mode))

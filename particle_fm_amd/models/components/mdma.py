@@ -92,14 +92,16 @@ class MDMA(_FusedEncoder):
 
     def layout(self, num_points: Optional[int] = None):
         n = num_points or self.num_points
-        lay = self._layouts.get(n)
+        flags = 32 if getattr(self, "mfma_dtype", "fp32") == "bf16" else 0  # PFM_MDMA_F_BF16
+        lay = self._layouts.get((n, flags))
         if lay is None:
-            lay = self._layouts[n] = MdmaLayout(self.config(n))
+            lay = self._layouts[(n, flags)] = MdmaLayout(self.config(n), flags=flags)
         return lay
 
     def set_precision(self, precision) -> None:
-        """fp32 kernels only on this path (Lightning's "bf16-mixed" and "f16x3" fall back to fp32 operands, not to PyTorch)."""
-        self.mfma_dtype = "fp32"
+        """Lightning's "bf16", "bf16-mixed", "bf16-true" -> the particle-stream Linears (forward and dX) on bf16 operands with fp32
+        accumulate (PFM_MDMA_F_BF16); the class token, the one-query attention and the dW GEMMs stay fp32.  Anything else: fp32."""
+        self.mfma_dtype = "bf16" if str(precision).startswith("bf16") else "fp32"
 
     _LAYOUT = MdmaLayout
 
