@@ -261,6 +261,21 @@ int pfm_epic_fm_loss_backward(const pfm_epic_desc *desc, const float *blob, cons
                               const float *inv_mask_total, const float *grad_scale, float *grad_blob,
                               int32_t B, float *scratch, const int32_t *order, void *stream);
 
+/* The same backward in two halves, for a data-parallel caller that starts exchanging gradients before the backward has finished
+ * (torch DDP's bucketed, overlapped all-reduce under configs/trainer/ddp.yaml:4-9):
+ *   PFM_BWD_PHASE_CHAIN  the per-jet chain + the sums that need its records only: afterwards every gradient slot of grad_blob is final
+ *                        EXCEPT the 128x128 particle blocks of fc_l2 / fc_local1 / fc_local2, i.e. the gradients of fc_l1, fc_l3, fc_g1,
+ *                        fc_g2 and every fc_global1 / fc_global2 (51 % of the parameters at the JetNet shapes) can be unpacked and reduced
+ *   PFM_BWD_PHASE_DW     the dW GEMM + its tile sums (needs the chain phase of the same scratch first)
+ * Both bits = pfm_epic_fm_loss_backward, bit for bit.  criterion / jet_weight: 0 / NULL for FM-OT, CFM, droid; as
+ * pfm_epic_diffusion_loss_backward otherwise. */
+#define PFM_BWD_PHASE_CHAIN 1
+#define PFM_BWD_PHASE_DW 2
+int pfm_epic_fm_loss_backward_phases(const pfm_epic_desc *desc, const float *blob, const float *cond, const float *mask,
+                                     const float *saved, const float *inv_mask_total, const float *grad_scale, float *grad_blob,
+                                     int32_t criterion, const float *jet_weight, int32_t B, float *scratch, const int32_t *order,
+                                     int32_t phases, void *stream);
+
 /* The same two with the time embedding supplied by the caller, temb[B][T] (t_emb="gaussian": a small trainable network in front of
  * the field, flow_matching_module.py:178-181, 213-221; t is still needed for the interpolation y, u): the backward also returns
  * grad_temb[B][T] = d(loss)/d(temb) * grad_scale, from which the caller's autograd continues into that network. */

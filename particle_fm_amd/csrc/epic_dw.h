@@ -210,6 +210,7 @@ constexpr int RED_T = 256;
 //   rest                       the F-wide particle blocks (dW3, dWx): item = 256 floats of the 2 x MAXF*H sums
 struct RedArgs {
     int n_tile, n_r1, n_small, panels_per_job;  // panels_per_job: max 16-row panels of any job (ceil(VIN_FLOATS / 16))
+    int item0;                                  // first work item of this launch (a launch may cover parts (b) + (c) or part (a) alone)
 };
 
 // RED_G groups of RED_T threads per workgroup: the rank-1 sums over jets (part (b)) are cut into RED_G contiguous jet ranges, one per
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(RED_T * RED_G) void epic_bwd_reduce_kernel(const fl
                                                                         float* __restrict__ gblob) {
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const int grp = threadIdx.x / RED_T, tid = threadIdx.x % RED_T;
-    int item = blockIdx.x;
+    int item = blockIdx.x + ra.item0;
     if (item < ra.n_tile) {
         if (grp != 0) return;
         // ---- (a) dW tile b = sum over splits, to GRAD_D order ----

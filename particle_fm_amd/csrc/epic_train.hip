@@ -169,9 +169,12 @@ extern "C" int pfm_epic_diffusion_loss_forward(const pfm_epic_desc* d, const flo
     return loss_forward(d, blob, 3, 0.f, t, x, z, nullptr, cond, mask, saved, loss_parts, mask_count, criterion, rates, B, order, stream);
 }
 
+// phases: PFM_BWD_PHASE_CHAIN (the per-jet chain kernel + the rank-1 / F-wide parts of the reduction: afterwards every gradient slot of
+// the blob is final except the 128x128 particle blocks) | PFM_BWD_PHASE_DW (the dW GEMM + the tile part of the reduction)
 static int loss_backward(const pfm_epic_desc* d, const float* blob, const float* cond, const float* mask, const float* saved,
                          const float* inv_mask_total, const float* grad_scale, float* grad_blob, int crit, const float* jet_w,
-                         int B, float* scratch, const int32_t* order, void* stream, float* dtemb = nullptr) {
+                         int B, float* scratch, const int32_t* order, void* stream, float* dtemb = nullptr,
+                         int phases = PFM_BWD_PHASE_CHAIN | PFM_BWD_PHASE_DW) {
     int rc = validate(d);
     if (rc) return rc;
     const int64_t lds = (int64_t)make_bcarve(d->n_points, d->features).total * 4;
@@ -193,26 +196,39 @@ static int loss_backward(const pfm_epic_desc* d, const float* blob, const float*
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
     const BwdWork bw = make_bwd_work(d->n_points, d->layers, B);
     hipStream_t s = (hipStream_t)stream;
-    // 1. per-jet chain: gradient rows + rank-1 operands -> scratch
-    if (bf16)
-        hipLaunchKernelGGL(epic_fm_loss_backward_kernel<true>, dim3(B), dim3(NT), (int)lds, s, blob, d->blob_floats, cond, mask, saved,
-                           inv_mask_total, grad_scale, scratch, bw, crit, jet_w, dtemb, order);
-    else
-        hipLaunchKernelGGL(epic_fm_loss_backward_kernel<false>, dim3(B), dim3(NT), (int)lds, s, blob, d->blob_floats, cond, mask, saved,
-                           inv_mask_total, grad_scale, scratch, bw, crit, jet_w, dtemb, order);
-    if ((rc = check_hip(hipGetLastError(), "epic_fm_loss_backward_kernel launch"))) return rc;
-    // 2. the 2 * layers + 1 dW GEMMs over the rows of all jets, split by row ranges
-    hipLaunchKernelGGL(epic_dw_kernel, dim3(bw.nsplit, bw.nblk), dim3(DW_T), dw_lds, s, blob, d->blob_floats, saved, scratch, bw, B);
-    if ((rc = check_hip(hipGetLastError(), "epic_dw_kernel launch"))) return rc;
-    // 3. fixed-order sums: partial tiles, rank-1 sums over jets, the F-wide particle blocks
     RedArgs ra;
     ra.n_tile = bw.nblk * 16;
     ra.panels_per_job = (VIN_FLOATS + 15) / 16 + 1;
     ra.n_r1 = (d->layers + 2) * 4 * ra.panels_per_job;
     ra.n_small = (2 * MAXF * H + 63) / 64;  // 64 outputs per workgroup (epic_bwd_reduce_kernel, part (c))
-    hipLaunchKernelGGL(epic_bwd_reduce_kernel, dim3(ra.n_tile + ra.n_r1 + ra.n_small), dim3(RED_T * RED_G), 0, s, blob, d->blob_floats,
-                       (const float*)scratch, bw, B, ra, grad_blob);
-    return check_hip(hipGetLastError(), "epic_bwd_reduce_kernel launch");
+    const bool whole = (phases & PFM_BWD_PHASE_CHAIN) && (phases & PFM_BWD_PHASE_DW);
+    if (phases & PFM_BWD_PHASE_CHAIN) {
+        // 1. per-jet chain: gradient rows + rank-1 operands -> scratch
+        if (bf16)
+            hipLaunchKernelGGL(epic_fm_loss_backward_kernel<true>, dim3(B), dim3(NT), (int)lds, s, blob, d->blob_floats, cond, mask, saved,
+                               inv_mask_total, grad_scale, scratch, bw, crit, jet_w, dtemb, order);
+        else
+            hipLaunchKernelGGL(epic_fm_loss_backward_kernel<false>, dim3(B), dim3(NT), (int)lds, s, blob, d->blob_floats, cond, mask, saved,
+                               inv_mask_total, grad_scale, scratch, bw, crit, jet_w, dtemb, order);
+        if ((rc = check_hip(hipGetLastError(), "epic_fm_loss_backward_kernel launch"))) return rc;
+        if (!whole) {  // the sums that need the chain's records only: rank-1 sums over jets, the F-wide particle blocks
+            ra.item0 = ra.n_tile;
+            hipLaunchKernelGGL(epic_bwd_reduce_kernel, dim3(ra.n_r1 + ra.n_small), dim3(RED_T * RED_G), 0, s, blob, d->blob_floats,
+                               (const float*)scratch, bw, B, ra, grad_blob);
+            if ((rc = check_hip(hipGetLastError(), "epic_bwd_reduce_kernel launch (records)"))) return rc;
+        }
+    }
+    if (phases & PFM_BWD_PHASE_DW) {
+        // 2. the 2 * layers + 1 dW GEMMs over the rows of all jets, split by row ranges
+        hipLaunchKernelGGL(epic_dw_kernel, dim3(bw.nsplit, bw.nblk), dim3(DW_T), dw_lds, s, blob, d->blob_floats, saved, scratch, bw, B);
+        if ((rc = check_hip(hipGetLastError(), "epic_dw_kernel launch"))) return rc;
+        // 3. fixed-order sums: partial tiles (whole call: + the rank-1 sums and the F-wide blocks, one launch)
+        ra.item0 = 0;
+        hipLaunchKernelGGL(epic_bwd_reduce_kernel, dim3(whole ? ra.n_tile + ra.n_r1 + ra.n_small : ra.n_tile), dim3(RED_T * RED_G), 0, s,
+                           blob, d->blob_floats, (const float*)scratch, bw, B, ra, grad_blob);
+        if ((rc = check_hip(hipGetLastError(), "epic_bwd_reduce_kernel launch"))) return rc;
+    }
+    return 0;
 }
 
 // loss = sum_b w_b parts_b / sum_b count_b and 1 / sum count from the per-jet outputs of the loss forward: one workgroup, sums in a
@@ -265,6 +281,17 @@ extern "C" int pfm_epic_fm_loss_backward(const pfm_epic_desc* d, const float* bl
                                          void* stream) {
     (void)t;  // the time embedding is part of `saved`
     return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, 0, nullptr, B, scratch, order, stream);
+}
+
+extern "C" int pfm_epic_fm_loss_backward_phases(const pfm_epic_desc* d, const float* blob, const float* cond, const float* mask,
+                                                const float* saved, const float* inv_mask_total, const float* grad_scale,
+                                                float* grad_blob, int32_t criterion, const float* jet_weight, int32_t B, float* scratch,
+                                                const int32_t* order, int32_t phases, void* stream) {
+    if (criterion < 0 || criterion > 1) return set_err(PFM_E_BADARG, "criterion must be 0 (mse) or 1 (huber)");
+    if (!(phases & (PFM_BWD_PHASE_CHAIN | PFM_BWD_PHASE_DW)) || (phases & ~(PFM_BWD_PHASE_CHAIN | PFM_BWD_PHASE_DW)))
+        return set_err(PFM_E_BADARG, "phases must be PFM_BWD_PHASE_CHAIN, PFM_BWD_PHASE_DW or both");
+    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, criterion, jet_weight, B, scratch, order, stream,
+                         nullptr, phases);
 }
 
 extern "C" int pfm_epic_fm_loss_backward_temb(const pfm_epic_desc* d, const float* blob, const float* cond, const float* mask,

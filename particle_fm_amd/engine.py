@@ -33,8 +33,15 @@ class FlatParams:
     one).  ``state_dict`` / ``load_state_dict`` keep working (they copy in place); after ``module.to(device)``
     call :meth:`rebuild`."""
 
-    def __init__(self, params: Iterable[nn.Parameter]):
-        self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
+    def __init__(self, params: Iterable[nn.Parameter], first: Optional[set] = None):
+        """``first``: ids of the parameters whose gradients are final EARLY in the backward; they are laid out in front of the others
+        (``n_first`` floats) so that their share of the gradient is one contiguous range that can be reduced while the rest is still
+        being computed.  The order inside each group stays the registration order."""
+        ps = [p for p in params if p.requires_grad]
+        if first:
+            ps = [p for p in ps if id(p) in first] + [p for p in ps if id(p) not in first]
+        self.params: List[nn.Parameter] = ps
+        self._first = set(first or ())
         self.rebuild()
 
     def rebuild(self):
@@ -48,6 +55,8 @@ class FlatParams:
             o += (n + 3) & ~3
         self.numel = o
         self.offsets = offs
+        nf = sum(1 for p in ps if id(p) in self._first)
+        self.n_first = (offs[nf] if nf < len(ps) else o) if nf else 0  # floats of the early group (a multiple of 4)
         flat = torch.zeros(o, device=dev, dtype=torch.float32)
         grad = torch.zeros(o, device=dev, dtype=torch.float32)
         for p, off in zip(ps, offs):
@@ -83,6 +92,17 @@ class GradSync:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         return 1.0 / self.world
 
+    def start(self, part: torch.Tensor):
+        """Begins the sum of one contiguous part of the flat gradient (ordered behind what the current stream has queued so far) and
+        returns at once: kernels queued afterwards run next to the collective (RCCL: on the process group's own stream).  Pair with
+        :meth:`finish` before anything reads ``part``."""
+        return dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.enabled else None
+
+    @staticmethod
+    def finish(work) -> None:
+        if work is not None:
+            work.wait()  # RCCL: the current stream waits for the collective; the host does not block
+
     def mean_scalar(self, value: torch.Tensor) -> torch.Tensor:
         """``self.log(..., sync_dist=True)`` of the reference (flow_matching_module.py:524)."""
         if self.enabled:
@@ -90,6 +110,12 @@ class GradSync:
             dist.all_reduce(value, op=dist.ReduceOp.SUM, group=self.group)
             value /= self.world
         return value
+
+
+def early_linear(name: str) -> bool:
+    """Linears of the EPiC network without a 128x128 particle block: their weight gradient needs the backward's chain phase only."""
+    leaf = name.rsplit(".", 1)[-1]
+    return leaf in ("fc_l1", "fc_l3", "fc_g1", "fc_g2", "fc_global1", "fc_global2")
 
 
 class FusedEpicTables:
@@ -103,17 +129,25 @@ class FusedEpicTables:
         off = {id(p): o for p, o in zip(fp.params, fp.offsets)}
         named = dict(net.named_parameters())
         rows, bfrom, bsrc = [], [], []
-        for name, in_dim, out_dim in layout.linears:
+        # the Linears whose gradient is final after the backward's chain phase (no 128x128 particle block: pfm_hip.h,
+        # PFM_BWD_PHASE_CHAIN) first, so that each half of the backward has one contiguous run of table rows
+        lins = sorted(layout.linears, key=lambda l: not early_linear(l[0]))
+        n_early_rows = n_early_bias = 0
+        for name, in_dim, out_dim in lins:
             vo, go, bo = (off[id(named[f"{name}.{k}"])] for k in ("weight_v", "weight_g", "bias"))
             o = np.arange(out_dim)
             rows.append(np.stack([vo + o * in_dim, go + o, np.full(out_dim, in_dim), layout.w_off[name] + o * in_dim], 1))
             bfrom.append(bo + o)
             bsrc.append(layout.b_off[name] + o)
+            if early_linear(name):
+                n_early_rows += out_dim
+                n_early_bias += out_dim
         rows = np.concatenate(rows).astype(np.int32)
         bfrom = np.concatenate(bfrom).astype(np.int32)
         bsrc = np.concatenate(bsrc)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.rows, self.n_rows = t(rows), len(rows)
+        self.n_early_rows, self.n_early_bias = n_early_rows, n_early_bias
         self.dst1, self.dst2, self.gsrc = t(layout.src_dst1), t(layout.src_dst2), t(layout.src_gpos)
         self.bias_param = t(bfrom)                                  # flat-parameter offsets of the biases
         self.bias_blob = t(layout.src_dst1[bsrc].astype(np.int32))  # their place in the blob
@@ -139,7 +173,16 @@ class FusedFMTrainer:
         :func:`cosine_warmup`; None keeps the rate constant."""
         self.module = module
         self.lr_schedule = lr_schedule
-        self.fp = FlatParams(module.parameters())
+        # fully fused path (no autograd): single EPiC flow with an FM-OT / CFM loss.  The transformer's parameters are
+        # plain (no weight norm): its autograd node already is two launches + two gathers, so it takes the generic path
+        flows = getattr(module, "flows", None)
+        fusable = flows is not None and len(flows) == 1 and hasattr(flows[0], "net") and hasattr(flows[0].net, "source_vector") \
+            and not getattr(flows[0].net, "wide", False) and getattr(flows[0], "t_emb", None) != "gaussian" \
+            and not getattr(flows[0].net, "add_time_to_input", False)  # (its fc_l1 is a folded matrix: autograd path)
+        # the parameters whose gradient the backward finishes first lie in front of the flat buffers (FlatParams.n_first): the
+        # data-parallel step reduces that range while the dW GEMM of the others runs (fused_loss_and_grad)
+        early = {id(p) for n, p in flows[0].net.named_parameters() if early_linear(n.rsplit(".", 1)[0])} if fusable else None
+        self.fp = FlatParams(module.parameters(), first=early)
         dev = self.fp.flat.device
         if dev.type != "cuda":
             raise RuntimeError("FusedFMTrainer needs the module on a ROCm device (no CPU fallback)")
@@ -158,13 +201,12 @@ class FusedFMTrainer:
         self._t_ring = []
         self._t_next = 0
         self._fin_next = 0
-        # fully fused path (no autograd): single EPiC flow with an FM-OT / CFM loss.  The transformer's parameters are
-        # plain (no weight norm): its autograd node already is two launches + two gathers, so it takes the generic path
         self._fused = None
-        flows = getattr(module, "flows", None)
-        if flows is not None and len(flows) == 1 and hasattr(flows[0], "net") and hasattr(flows[0].net, "source_vector") \
-                and not getattr(flows[0].net, "wide", False) and getattr(flows[0], "t_emb", None) != "gaussian" \
-                and not getattr(flows[0].net, "add_time_to_input", False):  # (its fc_l1 is a folded matrix: autograd path)
+        # None: split the backward (and overlap the first half's all-reduce with the dW GEMM) whenever gradients are exchanged;
+        # True / False force it (True without a process group: the same two-phase launches, nothing to exchange -- for tests)
+        self.split_backward: Optional[bool] = None
+        self._grad_synced = False
+        if fusable:
             self._fused = {}
             flows[0].net._fast_pack = self.packed_blob  # sampling re-packs with one HIP launch instead of ~100 torch ops
 
@@ -276,7 +318,7 @@ class FusedFMTrainer:
             parts, count, saved = hip_ops.epic_diffusion_loss_forward(lay, blob, x, t, z, torch.stack([sr, nr], dim=1), cond, maskf,
                                                                       loss_mod.criterion)
             _lib.check(lib.pfm_loss_finish(P(parts), P(count), P(jet_w), B, P(fin), S), "pfm_loss_finish")
-            hip_ops.epic_loss_backward(lay, blob, condf, maskf, saved, fin[1:], st["one"], gblob, criterion=loss_mod.criterion, jet_w=jet_w)
+            bw_kw = dict(criterion=loss_mod.criterion, jet_w=jet_w)
         else:
             if kind == "CFM":
                 t, z, eps = loss_mod.draw(x, land=self._land)
@@ -284,11 +326,32 @@ class FusedFMTrainer:
                 (t, z), eps = loss_mod.draw(x, land=self._land), None
             parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x, t, z, cond, maskf, loss_mod.sigma, kind, eps)
             _lib.check(lib.pfm_loss_finish(P(parts), P(count), P(None), B, P(fin), S), "pfm_loss_finish")
-            hip_ops.epic_loss_backward(lay, blob, condf, maskf, saved, fin[1:], st["one"], gblob)
+            bw_kw = {}
         loss = fin[0]
         unpack = lib.pfm_wn_unpack_grad_set if tb.covers_all else lib.pfm_wn_unpack_grad
-        _lib.check(unpack(P(self.fp.flat), P(gblob), P(tb.rows), tb.n_rows, P(tb.gsrc), P(tb.bias_gblob),
-                          P(tb.bias_param), tb.n_bias, P(self.fp.grad), S), "pfm_wn_unpack_grad")
+
+        def unpack_rows(r0, r1, b0, b1):
+            _lib.check(unpack(P(self.fp.flat), P(gblob), P(tb.rows[r0:r1]), r1 - r0, P(tb.gsrc), P(tb.bias_gblob[b0:b1]),
+                              P(tb.bias_param[b0:b1]), b1 - b0, P(self.fp.grad), S), "pfm_wn_unpack_grad")
+
+        split = self.sync.enabled if self.split_backward is None else self.split_backward
+        nf = self.fp.n_first
+        if split and tb.covers_all and 0 < nf < self.fp.numel and B <= hip_ops.BWD_CHUNK_JETS:
+            # DDP's overlap of the gradient exchange with the backward (configs/trainer/ddp.yaml:4-9), two buckets: the chain phase
+            # finishes the gradients of the Linears without a 128x128 particle block -- they sit in front of the flat buffer -- and
+            # their all-reduce runs next to the dW GEMM of the others
+            hip_ops.epic_loss_backward_phase(lay, blob, condf, maskf, saved, fin[1:], st["one"], gblob, hip_ops.BWD_PHASE_CHAIN, **bw_kw)
+            unpack_rows(0, tb.n_early_rows, 0, tb.n_early_bias)
+            w_early = self.sync.start(self.fp.grad[:nf])
+            hip_ops.epic_loss_backward_phase(lay, blob, condf, maskf, saved, fin[1:], st["one"], gblob, hip_ops.BWD_PHASE_DW, **bw_kw)
+            unpack_rows(tb.n_early_rows, tb.n_rows, tb.n_early_bias, tb.n_bias)
+            w_late = self.sync.start(self.fp.grad[nf:])
+            self.sync.finish(w_early)
+            self.sync.finish(w_late)
+            self._grad_synced = True
+        else:
+            hip_ops.epic_loss_backward(lay, blob, condf, maskf, saved, fin[1:], st["one"], gblob, **bw_kw)
+            unpack_rows(0, tb.n_rows, 0, tb.n_bias)
         return loss
 
     def step(self, batch, fused: bool = True) -> torch.Tensor:
@@ -305,7 +368,11 @@ class FusedFMTrainer:
             self.fp.zero_grad()
             loss = self.module.loss(x, mask=mask, cond=cond)
             loss.backward()
-        mul = self.sync.sync(self.fp.grad)
+        if self._grad_synced:  # fused_loss_and_grad has exchanged the two halves already
+            self._grad_synced = False
+            mul = 1.0 / self.sync.world
+        else:
+            mul = self.sync.sync(self.fp.grad)
         self.optimizer_step(mul)
         return loss.detach()
 
@@ -343,13 +410,24 @@ class FusedFMTrainer:
     def load_state_dict(self, sd: Dict[str, object], load_hparams: bool = True) -> None:
         if not self.fp.is_intact():
             self._rebuild()
-        if list(sd["param_names"]) != self._names() or int(sd["numel"]) != self.fp.numel:
+        names = self._names()
+        if sorted(sd["param_names"]) != sorted(names):
             raise ValueError("trainer state was saved for a different parameter list")
         dev = self.fp.flat.device
-        self.exp_avg.copy_(sd["exp_avg"].to(dev))
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"].to(dev))
+
+        def load(dst: torch.Tensor, src: torch.Tensor):
+            if list(sd["param_names"]) == names and int(sd["numel"]) == self.fp.numel:
+                dst.copy_(src.to(dev))
+                return
+            # saved under another order of the flat buffer (an earlier build, or a module without the early / late grouping): by name
+            so = dict(zip(sd["param_names"], sd["offsets"]))
+            for n, p, off in zip(names, self.fp.params, self.fp.offsets):
+                dst[off:off + p.numel()].copy_(src[so[n]:so[n] + p.numel()].to(dev))
+
+        load(self.exp_avg, sd["exp_avg"])
+        load(self.exp_avg_sq, sd["exp_avg_sq"])
         if sd.get("ema") is not None and self.ema is not None:
-            self.ema.copy_(sd["ema"].to(dev))
+            load(self.ema, sd["ema"])
         self.step_count = int(sd["step_count"])
         if load_hparams:
             hp = sd["hparams"]

@@ -389,6 +389,27 @@ def epic_backward_scratch(layout: EpicLayout, B: int, device) -> torch.Tensor:
     return cache[key]
 
 
+BWD_PHASE_CHAIN, BWD_PHASE_DW = 1, 2  # PFM_BWD_PHASE_* (pfm_hip.h)
+
+
+def epic_loss_backward_phase(layout: EpicLayout, blob, cond, maskf, saved, inv_total, gscale, gblob, phases: int, *,
+                             criterion: Optional[str] = None, jet_w=None) -> None:
+    """One half (or both) of the backward, pfm_epic_fm_loss_backward_phases: BWD_PHASE_CHAIN leaves every gradient slot final except
+    the 128x128 particle blocks, BWD_PHASE_DW adds those.  One call's worth of jets (B <= BWD_CHUNK_JETS): the data-parallel trainer
+    uses it to start the all-reduce of the finished half while the dW GEMM runs."""
+    lib = _lib.load()
+    dev = blob.device
+    B = saved.shape[0]
+    if B > BWD_CHUNK_JETS:
+        raise ValueError(f"epic_loss_backward_phase: at most {BWD_CHUNK_JETS} jets per call (epic_loss_backward chunks larger batches)")
+    scr = epic_backward_scratch(layout, B, dev)
+    order = jet_order(maskf, B, layout.cfg.num_particles)
+    rc = lib.pfm_epic_fm_loss_backward_phases(ctypes.byref(layout.desc), _ptr(blob), _ptr(cond), _ptr(maskf), _ptr(saved), _ptr(inv_total),
+                                              _ptr(gscale), _ptr(gblob), {None: 0, "mse": 0, "huber": 1}[criterion],
+                                              _ptr(None if jet_w is None else jet_w), B, _ptr(scr), _ptr(order), int(phases), _stream_ptr(dev))
+    _lib.check(rc, "pfm_epic_fm_loss_backward_phases")
+
+
 def epic_loss_backward(layout: EpicLayout, blob, cond, maskf, saved, inv_total, gscale, gblob, *, criterion: Optional[str] = None,
                        jet_w=None, d_temb=None) -> None:
     """The atomics-free backward of the jet-resident EPiC loss (pfm_epic_fm_loss_backward / _temb / pfm_epic_diffusion_loss_backward):

@@ -52,6 +52,28 @@ def _worker(rank, world, port, out):
                 torch.testing.assert_close(p.grad, 0.5 * (g0[k] + g1[k]), atol=1e-7, rtol=1e-5)
             torch.testing.assert_close(mean_loss, 0.5 * (l0 + l1))
             assert fp.is_intact() and len(names) == 87
+        # the two-bucket exchange of the fused step (engine.FusedFMTrainer.fused_loss_and_grad): early group in front of the flat buffer,
+        # its all-reduce started (async) before the rest is there; same means as the one flat call
+        from particle_fm_amd.engine import early_linear
+        net = m.flows[0].net
+        early = {id(p) for n, p in net.named_parameters() if early_linear(n.rsplit(".", 1)[0])}
+        fp2 = FlatParams(m.parameters(), first=early)
+        assert 0 < fp2.n_first < fp2.numel
+        fp2.zero_grad()
+        for k, p in m.named_parameters():
+            if id(p) in early:
+                p.grad.copy_(grads[k])
+        w_early = sync.start(fp2.grad[: fp2.n_first])       # the late half is still zero on every rank
+        for k, p in m.named_parameters():
+            if id(p) not in early:
+                p.grad.copy_(grads[k])
+        w_late = sync.start(fp2.grad[fp2.n_first:])
+        sync.finish(w_early)
+        sync.finish(w_late)
+        fp2.grad.mul_(1.0 / sync.world)
+        if rank == 0:
+            for k, p in m.named_parameters():
+                torch.testing.assert_close(p.grad, 0.5 * (g0[k] + g1[k]), atol=1e-7, rtol=1e-5)
             out.put("ok")
     finally:
         dist.destroy_process_group()

@@ -123,10 +123,11 @@ def test_fused_trainer_matches_torch_adamw_clip_ema():
     k_list = [k for k in ref if ref[k].requires_grad]
     for k in k_list:
         torch.testing.assert_close(got[k].detach().cpu(), ref[k].detach(), atol=2e-6, rtol=2e-4, msg=lambda s: f"{k}: {s}")
-    # EMA buffer (flat, parameter order)
+    # EMA buffer (flat; the trainer lays the parameters out in its own order: by name)
     fp = tr.fp
-    for p, off, e in zip(fp.params, fp.offsets, ema):
-        torch.testing.assert_close(tr.ema[off:off + p.numel()].view_as(p).cpu(), e, atol=2e-6, rtol=2e-4)
+    ema_of = dict(zip(k_list, ema))
+    for name, p, off in zip(tr._names(), fp.params, fp.offsets):
+        torch.testing.assert_close(tr.ema[off:off + p.numel()].view_as(p).cpu(), ema_of[name], atol=2e-6, rtol=2e-4)
 
 
 def test_fused_step_equals_autograd_step():
