@@ -652,6 +652,89 @@ def gen_diffusion(ref, out_dir, B=4, seed=2468):
 
 
 # ----------------------------------------------------------------------------------------------
+# loss_type="diffusion" on the other model paths (flow_matching_module.py:452-458 builds DiffusionLoss for any `model`): the reduced
+# Full-Transformer / cross-attention / MDMA configurations with seed-derived weights (oracle/seeded.py), gradients sub-sampled
+# ----------------------------------------------------------------------------------------------
+DIFF_ROWS_CONFIGS = {
+    "tf": (lambda: dict(TF_CONFIGS["small"][0], loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02}), 3131),
+    "ca": (lambda: dict(CA_CONFIGS["small"][0], loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02}), 4242),
+    "mdma": (lambda: dict(MDMA_CONFIGS["small"][0], loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02}), 5353),
+}
+
+
+def gen_diffusion_rows(ref, prefix, out_dir, B=3):
+    import copy
+    import json
+
+    from oracle.seeded import seeded_state, subsample
+
+    mk_hp, seed = DIFF_ROWS_CONFIGS[prefix]
+    hp = mk_hp()
+    torch.manual_seed(seed)
+    cnf = ref.fmm.CNF(**copy.deepcopy(hp))
+    shapes = {k: tuple(v.shape) for k, v in cnf.state_dict().items() if k != "frequencies"}
+    new = seeded_state(shapes, seed)
+    sd = cnf.state_dict()
+    for k, v in new.items():
+        sd[k] = torch.from_numpy(v)
+    cnf.load_state_dict(sd)
+    flows = torch.nn.ModuleList([cnf])
+    N, Fe, Cg, dc = hp["num_particles"], hp["features"], hp["global_cond_dim"], hp["diff_config"]
+    out = {"_keys": np.array(["flows.0." + k for k in cnf.state_dict().keys()])}
+    out["_shapes_json"] = np.array(json.dumps({"flows.0." + k: list(s) for k, s in shapes.items()}))
+    out["seed"] = np.array(seed)
+    out["hp_json"] = np.array(json.dumps(hp))
+    out["freqs"] = (torch.arange(2 * hp["frequencies"]).exp() if hp["t_emb"] == "cosine" else cnf.frequencies.clone()).numpy()
+    out["abs_sum"] = np.array(sum(float(np.abs(v).sum(dtype=np.float64)) for v in new.values()))
+    gen = torch.Generator().manual_seed(seed + 1)
+    mk_cond = lambda: torch.randn(B, Cg, generator=gen) if Cg else None
+    put = lambda tag, **kw: out.update({tag + k: (np.zeros(0, np.float32) if v is None else v.numpy()) for k, v in kw.items()})
+    # ---- DiffusionLoss (losses.py:207-290), both criteria; draws replayed by seed (:241, :247) ----
+    for crit in ("huber", "mse"):
+        mask = make_mask(B, N, "f32", gen)
+        x = 2.0 * torch.randn(B, N, Fe, generator=gen) * mask
+        cond = mk_cond()
+        loss_mod = ref.losses.DiffusionLoss(flows=flows, criterion=crit, diff_config=dc)
+        torch.manual_seed(1357)
+        cnf.zero_grad()
+        loss = loss_mod(x, mask=mask, cond=cond)
+        loss.backward()
+        torch.manual_seed(1357)
+        t = torch.rand_like(torch.ones(B))
+        z = torch.randn_like(x) * mask
+        tag = f"loss_{crit}/"
+        put(tag, x=x, t=t, z=z, mask=mask, cond=cond, loss=loss.detach())
+        for k, p in cnf.named_parameters():
+            if p.grad is None:  # MDMA: Block.cond_cls is constructed but never used (mdma.py:30, 36)
+                continue
+            out[tag + "grad/flows.0." + k] = subsample(p.grad.detach().clone().numpy())
+    # ---- probability-flow ODE right-hand side (ode_wrapper, flow_matching_module.py:62-69), midpoint on it, DDIM, Euler-Maruyama ----
+    mask = make_mask(B, N, "f32", gen)
+    z = torch.randn(B, N, Fe, generator=gen)
+    cond = mk_cond()
+    wrapped = ref.fmm.ode_wrapper(model=cnf, mask=mask, cond=cond, loss_type="diffusion", diff_config=dc)
+    with torch.no_grad():
+        t0 = torch.tensor(0.37)
+        put("rhs/", t=t0, x=z * mask, mask=mask, cond=cond, f=wrapped(t0, z * mask))
+        for steps in (3, 10):
+            xe = midpoint_trajectory_end(wrapped, z * mask, torch.linspace(1.0, 0.0, steps))
+            put(f"midpoint_{steps}/", z=z, mask=mask, cond=cond, x_end=xe)
+        sched = ref.diffusion.VPDiffusionSchedule(**dc)
+        n_steps = 5
+        x_ddim, _ = ref.solver.ddim_sampler(cnf, sched, (z * mask).clone(), n_steps=n_steps, mask=mask, cond=cond)
+        put("ddim/", z=z, mask=mask, cond=cond, x_end=x_ddim)
+        torch.manual_seed(8642)
+        x_em, _ = ref.solver.euler_maruyama_sampler(cnf, sched, (z * mask).clone(), n_steps=n_steps, mask=mask, cond=cond)
+        torch.manual_seed(8642)
+        noise = torch.stack([torch.randn_like(z) for _ in range(n_steps)])
+        put("em/", z=z, mask=mask, cond=cond, noise=noise, x_end=x_em)
+    out["n_steps"] = np.array(n_steps)
+    path = os.path.join(out_dir, f"{prefix}_diffusion.npz")
+    np.savez(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
+
+
+# ----------------------------------------------------------------------------------------------
 # IterativeNormLayer (norm_layer.py): three training batches, then eval-mode forward / reverse
 # ----------------------------------------------------------------------------------------------
 def gen_norm_layer(ref, out_dir, seed=97531):
@@ -685,7 +768,7 @@ def gen_norm_layer(ref, out_dir, seed=97531):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,norm}; default all")
+    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,diffusion_rows,norm}; default all")
     ap.add_argument("--names", default="", help="with --only epic: comma list of configuration names (default all)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -702,6 +785,9 @@ def main():
         gen_diffusion(ref, args.out)
     if ap2 is None or "norm" in ap2:
         gen_norm_layer(ref, args.out)
+    for prefix in DIFF_ROWS_CONFIGS:
+        if ap2 is None or "diffusion_rows" in ap2:
+            gen_diffusion_rows(ref, prefix, args.out)
     for name, (hp, B) in WIDE_CONFIGS.items():
         if ap2 is None or "wide" in ap2:
             gen_epic_wide(ref, name, hp, B, args.out)

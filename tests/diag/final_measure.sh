@@ -9,8 +9,11 @@ python bench.py --batch 1024 --steps 12 --warmup 3 --no-cpu-baseline > $O/bench_
 python bench.py --overlap 1 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_line_overlap1.json 2>> $O/bench.err
 python bench_secondary.py > $O/secondary_lines.jsonl 2> $O/secondary.err
 python bench_secondary.py --workload jetnet30 --precision bf16 >> $O/secondary_lines.jsonl 2>> $O/secondary.err
+# bf16 operands on the row-matrix paths (PFM_{TF,EW,CA}_F_BF16): cfg 4, cfg 5, cross-attention
+for w in lhco_transformer jetclass lhco_crossattention; do python bench_secondary.py --workload $w --precision bf16 >> $O/secondary_lines.jsonl 2>> $O/secondary.err; done
 python tests/diag/train_time.py 256 40 > $O/train_time.txt 2>&1
 python tests/diag/train_time.py 1024 20 >> $O/train_time.txt 2>&1
+( cd /tmp && export TMPDIR=/tmp && for b in 256 1024; do rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/train_stats_b$b -o train -- python3 $GRAFT_REPO_ROOT/tests/diag/train_time.py $b 20 > /dev/null 2> $GRAFT_REPO_ROOT/$O/train_stats_b$b.err; rm -f $GRAFT_REPO_ROOT/$O/train_stats_b$b/*trace.csv; done )
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_line_rocprof.json 2> $GRAFT_REPO_ROOT/$O/stats.err; rm -f $GRAFT_REPO_ROOT/$O/stats/*trace.csv )
 python - <<'PY'
 import json
