@@ -662,14 +662,21 @@ __global__ __launch_bounds__(NT) void epic_cond_table_kernel(const float* __rest
 // One workgroup; B <= ORDER_MAX_JETS (larger batches keep the identity order).
 // ------------------------------------------------------------------------------------------------
 constexpr int ORDER_MAX_JETS = 8192;
-__global__ __launch_bounds__(1024) void epic_jet_order_kernel(const float* __restrict__ mask, int B, int N, int* __restrict__ order) {
+// (a) valid particles per jet, one WAVE per jet over a grid of workgroups (coalesced reads; the one-thread-per-jet walk of a single
+// workgroup this replaces took 134 us at 1024 jets x 150 particles -- twice per training step) -> cnt[jet];
+// (b) one workgroup ranks the counts (stable by jet index) in place: every count is in LDS before the first order entry is written.
+__global__ __launch_bounds__(1024) void epic_jet_count_kernel(const float* __restrict__ mask, int B, int N, int* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63, jet = blockIdx.x * 16 + (threadIdx.x >> 6);
+    if (jet >= B) return;
+    int c = 0;
+    for (int r = lane; r < N; r += 64) c += mask[(int64_t)jet * N + r] != 0.f;
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+    if (lane == 0) cnt[jet] = c;
+}
+__global__ __launch_bounds__(1024) void epic_jet_order_kernel(int B, int* __restrict__ order) {
     __shared__ int cnt[ORDER_MAX_JETS];
     const int tid = threadIdx.x;
-    for (int jet = tid; jet < B; jet += 1024) {
-        int c = 0;
-        for (int r = 0; r < N; ++r) c += mask[(int64_t)jet * N + r] != 0.f;
-        cnt[jet] = c;
-    }
+    for (int jet = tid; jet < B; jet += 1024) cnt[jet] = order[jet];  // (the counts, written there by epic_jet_count_kernel)
     __syncthreads();
     for (int jet = tid; jet < B; jet += 1024) {
         const int c = cnt[jet];
@@ -690,11 +697,12 @@ __global__ __launch_bounds__(1024) void epic_jet_pack_kernel(const float* __rest
     __shared__ int cnt[ORDER_MAX_JETS];
     __shared__ int sorted[ORDER_MAX_JETS];
     const int tid = threadIdx.x;
-    for (int jet = tid; jet < B; jet += 1024) {
+    for (int jet = tid >> 6; jet < B; jet += 16) {  // one wave per jet: coalesced reads (a thread per jet walked N strided floats)
         int last = -1;
-        for (int r = 0; r < N; ++r)
+        for (int r = tid & 63; r < N; r += 64)
             if (mask[(int64_t)jet * N + r] != 0.f) last = r;
-        cnt[jet] = last >= 0 ? last + 1 : N;  // no valid particle: every row is computed (NaN like the reference)
+        for (int m = 32; m >= 1; m >>= 1) last = max(last, __shfl_xor(last, m));
+        if ((tid & 63) == 0) cnt[jet] = last >= 0 ? last + 1 : N;  // no valid particle: every row is computed (NaN like the reference)
     }
     __syncthreads();
     for (int jet = tid; jet < B; jet += 1024) {
@@ -782,7 +790,8 @@ int pfm_epic_pack_a16(const pfm_epic_desc* d, float* blob, void* stream) {
 int pfm_epic_jet_order(const float* mask, int32_t B, int32_t n_points, int32_t* order, void* stream) {
     if (!mask || !order) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (B < 1 || B > ORDER_MAX_JETS) return set_err(PFM_E_BADARG, "1 <= B <= 8192 jets");
-    hipLaunchKernelGGL(epic_jet_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, n_points, order);
+    hipLaunchKernelGGL(epic_jet_count_kernel, dim3((B + 15) / 16), dim3(1024), 0, (hipStream_t)stream, mask, B, n_points, order);
+    hipLaunchKernelGGL(epic_jet_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, order);
     return check_hip(hipGetLastError(), "epic_jet_order_kernel launch");
 }
 
@@ -868,7 +877,8 @@ static const int* queue_jet_pack(const pfm_epic_desc* d, float* scratch, int64_t
 static const int* queue_jet_order(const pfm_epic_desc* d, float* scratch, int64_t table_floats, const float* mask, int B, hipStream_t s) {
     if (!scratch || !mask || B < 2 || B > ORDER_MAX_JETS) return nullptr;
     int* order = reinterpret_cast<int*>(scratch + table_floats);
-    hipLaunchKernelGGL(epic_jet_order_kernel, dim3(1), dim3(1024), 0, s, mask, B, d->n_points, order);
+    hipLaunchKernelGGL(epic_jet_count_kernel, dim3((B + 15) / 16), dim3(1024), 0, s, mask, B, d->n_points, order);
+    hipLaunchKernelGGL(epic_jet_order_kernel, dim3(1), dim3(1024), 0, s, B, order);
     return order;
 }
 

@@ -313,14 +313,23 @@ def epic_sample_midpoint(layout: EpicLayout, blob: torch.Tensor, z: torch.Tensor
 JET_ORDER_MIN_JETS = 384  # longest-first launch order of the training kernels from this batch size on (1.5 jets per CU of a 256-CU part)
 
 
+_ORDER_MEMO: dict = {}
+
+
 def jet_order(maskf: Optional[torch.Tensor], B: int, n_points: int):
     """order[rank] = jet in descending multiplicity for the loss forward / backward launches (one workgroup per jet, dispatched in
     order: with several jets per CU the short ones should fill the tail).  None for small batches, no mask, or more than 8192 jets."""
     if maskf is None or B < JET_ORDER_MIN_JETS or B > 8192:
         return None
+    # the loss forward and its backward ask for the order of the same mask tensor: computed once (the tensor's version counter
+    # tells an in-place change; one entry, replaced by the next mask)
+    key = (maskf.data_ptr(), maskf._version, B, int(n_points), _stream_ptr(maskf.device).value)
+    if _ORDER_MEMO.get("key") == key:
+        return _ORDER_MEMO["order"]
     order = torch.empty(B, device=maskf.device, dtype=torch.int32)
     rc = _lib.load().pfm_epic_jet_order(_ptr(maskf), B, int(n_points), _ptr(order), _stream_ptr(maskf.device))
     _lib.check(rc, "pfm_epic_jet_order")
+    _ORDER_MEMO.update(key=key, order=order, mask=maskf)  # (keeps the mask alive: its address cannot be reused while it is the key)
     return order
 
 
