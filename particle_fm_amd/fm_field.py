@@ -1,0 +1,135 @@
+"""The vector field v = f(t, x) of the row-matrix models (Full-Transformer, cross-attention, wide EPiC, MDMA) as ONE differentiable
+function of the parameters, for the objectives that have no fused loss kernel on these paths (loss_type="diffusion":
+losses.py:207-290 builds DiffusionLoss for any `model`, flow_matching_module.py:452-458).
+
+No new kernels: the loss entry points of each path are used as a forward-with-saved-activations and a backward-from-an-upstream-gradient.
+  forward : pfm_*_fm_loss_forward with kind "droid" and z = 0  ->  y = x + t * 0 = x, u = 0, v = f(t, x) and the saved activations
+  backward: the loss backward differentiates sum (v - u)^2 * gscale, i.e. starts from dv = 2 (v - u) gscale (times the output mask
+            where the network masks its output: wide EPiC, MDMA).  With u' = v - G / 2 and gscale = 1 that IS the upstream gradient G
+            (MDMA sums it over the broadcast features, as autograd does for its (B, N, 1) output), so the same call returns
+            d <G, v> / d parameters.
+Whatever is built on v -- criterion, masks, per-jet weights -- is a handful of element-wise torch ops on (B, N, F) device tensors whose
+autograd ends in this node.  The shipped FM-OT / CFM / droid objectives keep their fused loss kernels (fm_loss_*.py)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import hip_ops_ca, hip_ops_mdma, hip_ops_tf, hip_ops_wide
+
+
+def _freq_table(layout, freqs, default_freqs):
+    f = default_freqs(layout.cfg.t_dim, layout.cfg.t_emb) if freqs is None else freqs
+    if layout.cfg.t_emb == "sincos" and f.numel() == layout.cfg.frequencies:
+        f = torch.cat([f, f])
+    return f
+
+
+def _upstream(saved, G):
+    """saved (y, u, v, ...) with u replaced so that the loss backward starts from the upstream gradient G"""
+    y, u, v = saved[:3]
+    return (y, v - 0.5 * G.to(v.dtype).reshape(v.shape)) + tuple(saved[2:])
+
+
+class TfFieldFn(torch.autograd.Function):
+    """Full-Transformer (ops = hip_ops_tf) / cross-attention (ops = hip_ops_ca) field over the flat parameter vector."""
+
+    @staticmethod
+    def forward(ctx, flat_params, layout, freqs, ops, x, t, cond, mask):
+        dev = x.device
+        src = torch.cat([flat_params.to(torch.float32), freqs.to(dev, torch.float32), torch.zeros(1, device=dev)])
+        blob = src[layout.index_map_on(dev)]
+        fwd = ops.tf_fm_loss_forward if ops is hip_ops_tf else ops.ca_fm_loss_forward
+        _, saved = fwd(layout, blob, x, t, torch.zeros_like(x), cond, mask, 0.0, "droid", None)
+        ctx.layout, ctx.saved, ctx.blob, ctx.ops, ctx.t, ctx.cond = layout, saved, blob, ops, t, cond
+        ctx.mask = None if mask is None else mask.reshape(x.shape[0], -1).to(torch.float32).contiguous()
+        return saved[2].clone()
+
+    @staticmethod
+    def backward(ctx, G):
+        lay, ops = ctx.layout, ctx.ops
+        one = torch.ones((), device=G.device)
+        bwd = ops.tf_fm_loss_backward if ops is hip_ops_tf else ops.ca_fm_loss_backward
+        gblob = bwd(lay, ctx.blob, ctx.t, ctx.cond, ctx.mask, _upstream(ctx.saved, G.contiguous()), one) if ops is hip_ops_tf else \
+            bwd(lay, ctx.blob, ctx.cond, ctx.mask, _upstream(ctx.saved, G.contiguous()), one)
+        return (gblob[lay.grad_pos_on(gblob.device)],) + (None,) * 7
+
+
+def tf_field(layout, flat_params, t, x, cond=None, mask=None, freqs: Optional[torch.Tensor] = None):
+    from .layout_tf import default_freqs
+    return TfFieldFn.apply(flat_params, layout, _freq_table(layout, freqs, default_freqs), hip_ops_tf, x, t, cond, mask)
+
+
+def ca_field(layout, flat_params, t, x, cond=None, mask=None, freqs: Optional[torch.Tensor] = None):
+    from .layout_ca import default_freqs
+    return TfFieldFn.apply(flat_params, layout, _freq_table(layout, freqs, default_freqs), hip_ops_ca, x, t, cond, mask)
+
+
+class MdmaFieldFn(torch.autograd.Function):
+    """MDMA field, broadcast over the features as the reference's loss arithmetic does with its (B, N, 1) output."""
+
+    @staticmethod
+    def forward(ctx, flat_params, layout, freqs, x, t, mask):
+        dev = x.device
+        src = torch.cat([flat_params.to(torch.float32), freqs.to(dev, torch.float32), torch.zeros(1, device=dev)])
+        blob = src[layout.index_map_on(dev)]
+        _, saved = hip_ops_mdma.mdma_fm_loss_forward(layout, blob, x, t, torch.zeros_like(x), mask, 0.0, "droid", None)
+        ctx.layout, ctx.saved, ctx.blob = layout, saved, blob
+        return saved[2].clone()
+
+    @staticmethod
+    def backward(ctx, G):
+        lay = ctx.layout
+        gblob = hip_ops_mdma.mdma_fm_loss_backward(lay, ctx.blob, _upstream(ctx.saved, G.contiguous()), torch.ones((), device=G.device))
+        return (gblob[lay.grad_pos_on(gblob.device)],) + (None,) * 5
+
+
+def mdma_field(layout, flat_params, t, x, mask, freqs: Optional[torch.Tensor] = None):
+    from .layout_mdma import default_freqs
+    return MdmaFieldFn.apply(flat_params, layout, _freq_table(layout, freqs, default_freqs), x, t, mask)
+
+
+class EpicWideFieldFn(torch.autograd.Function):
+    """Wide (row-matrix) EPiC field over the layout's source vector (autograd continues through the weight-norm reparametrisation)."""
+
+    @staticmethod
+    def forward(ctx, src, layout, x, t, cond, mask):
+        from .fm_loss_wide import pack_blob_from_source
+        blob = pack_blob_from_source(layout, src)
+        _, saved = hip_ops_wide.ew_fm_loss_forward(layout, blob, x, t, torch.zeros_like(x), cond, mask, 0.0, "droid", None)
+        ctx.layout, ctx.saved, ctx.blob, ctx.n_source = layout, saved, blob, src.numel()
+        return saved[2].clone()
+
+    @staticmethod
+    def backward(ctx, G):
+        from .fm_loss_wide import _maps
+        lay = ctx.layout
+        gblob = hip_ops_wide.ew_fm_loss_backward(lay, ctx.blob, _upstream(ctx.saved, G.contiguous()), torch.ones((), device=G.device))
+        gpos = _maps(lay, gblob.device)[1]
+        d_src = torch.zeros(ctx.n_source, device=gblob.device, dtype=torch.float32)
+        d_src[: gpos.numel()] = gblob[gpos]
+        return (d_src,) + (None,) * 5
+
+
+def epic_wide_field(layout, src, t, x, cond=None, mask=None):
+    return EpicWideFieldFn.apply(src, layout, x, t, cond, mask)
+
+
+def diffusion_loss_from_field(v, z, mask, t, criterion: str, diff_config, mle_loss_weight: float = 0.001):
+    """DiffusionLoss.forward behind the network call (losses.py:272-288): v = predicted noise, z = the (masked) noise.
+    loss = sum crit(z, v) mask (1 + w beta / noise_rate) / sum mask, the rates in the reference's fp32 op order (hip_ops)."""
+    from .hip_ops import diffusion_schedule
+    _, nr, beta = diffusion_schedule(t.to(torch.float32), **dict(diff_config))
+    if criterion == "mse":
+        simple = (z - v).square()
+    elif criterion == "huber":
+        simple = torch.nn.functional.huber_loss(z, v, reduction="none")
+    else:
+        raise NotImplementedError(f"criterion {criterion} not supported")
+    simple = simple * mask
+    msum = mask.sum()
+    out = simple.sum() / msum
+    if mle_loss_weight:
+        out = out + mle_loss_weight * ((beta / nr).view(-1, 1, 1) * simple).sum() / msum
+    return out

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from .. import fm_field as _fm_field
 from .. import fm_loss as _fm_loss
 from .. import fm_loss_ca as _fm_loss_ca
 from .. import fm_loss_mdma as _fm_loss_mdma
@@ -278,9 +279,10 @@ class CNF(nn.Module):
     def _decode_diffusion(self, z, cond, mask, ode_solver, ode_steps, weights):
         """loss_type="diffusion" (:62-69, 301-325): the fixed-step ODE solvers integrate -0.5 beta (x - net / noise_rate);
         "ddim" / "em" are the samplers of models/components/solver.py (n_steps = ode_steps)."""
-        if self.is_transformer or self.is_cross_attention or self.is_mdma or self.t_emb == "gaussian":
-            raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' (configs/model/diffusion.yaml) with the "
-                                      "cosine / sincos time embeddings only")
+        if self.t_emb == "gaussian":
+            raise NotImplementedError("loss_type='diffusion' has a HIP path with the cosine / sincos time embeddings only")
+        if self.is_transformer or self.is_cross_attention or self.is_mdma:
+            return self._decode_diffusion_rows(z, cond, mask, ode_solver, ode_steps, weights)
         wide = self.net.is_wide(z.shape[1])
         lay = self.net.layout(z.shape[1])
         blob = weights if weights is not None else self.net.packed_weights(z.shape[1])
@@ -311,11 +313,90 @@ class CNF(nn.Module):
                                           noise=torch.randn_like(x))  # solver.py:131
         return data if ode_solver == "ddim" else x
 
+    def _field_rows(self, t, x, cond, mask):
+        """v = f(t, x) of the transformer / cross-attention / MDMA model as a differentiable function of the parameters (fm_field.py)."""
+        lay = self.net.layout(x.shape[1])
+        fl, fr = self.net.flat_parameters(lay), self.net.freq_tensor()
+        if self.is_transformer:
+            return _fm_field.tf_field(lay, fl, t, x, cond, mask, freqs=fr)
+        if self.is_cross_attention:
+            return _fm_field.ca_field(lay, fl, t, x, cond, mask, freqs=fr)
+        m = torch.ones(*x.shape[:2], 1, device=x.device) if mask is None else mask
+        return _fm_field.mdma_field(lay, fl, t, x, m, freqs=fr)
+
+    def _decode_diffusion_rows(self, z, cond, mask, ode_solver, ode_steps, weights):
+        """loss_type="diffusion" sampling for the transformer / cross-attention / MDMA models: the field is one HIP evaluation per
+        stage (net.vector_field); the probability-flow right-hand side -0.5 beta (x - v / noise_rate) (:62-69), the Runge-Kutta
+        combinations of torchdyn's fixed-step driver and the DDIM / Euler-Maruyama updates (solver.py:55-141) are element-wise
+        device ops between the evaluations, in the oracle's op order (oracle/fm_ref.py::rk_trajectory_end, diffusion_ref.py)."""
+        dc = dict(self.diff_config)
+        blob = weights if weights is not None else self.net.packed_weights(z.shape[1])
+        B = z.shape[0]
+        field = lambda tt, xx: self.net.vector_field(tt.to(z.device).expand(B), xx, cond, mask, blob=blob)
+        x = z.to(torch.float32).clone()
+        if ode_solver in ("midpoint", "euler", "rk4"):
+            c, a, b = hip_ops.RK_TABLEAUS[ode_solver]
+            f32 = lambda v: torch.tensor(v, dtype=torch.float32)
+            t_span = torch.linspace(1.0, 0.0, ode_steps)
+
+            def rhs(tt, xx):
+                _, nr, beta = hip_ops.diffusion_schedule(tt.reshape(1), **dc)
+                return (-0.5 * beta).to(z.device) * (xx - field(tt, xx) / nr.to(z.device))
+
+            t = t_span[0]
+            dt = t_span[1] - t
+            for k in range(1, ode_steps):
+                ks = []
+                for s in range(len(b)):
+                    if s == 0:
+                        ks.append(rhs(t, x))
+                        continue
+                    acc = f32(a[s][0]).to(z.device) * ks[0]
+                    for j in range(1, s):
+                        acc = acc + f32(a[s][j]).to(z.device) * ks[j]
+                    ks.append(rhs(t + f32(c[s]) * dt, x + dt.to(z.device) * acc))
+                acc = f32(b[0]).to(z.device) * ks[0]
+                for j in range(1, len(b)):
+                    acc = acc + f32(b[j]).to(z.device) * ks[j]
+                x = x + dt.to(z.device) * acc
+                t = t + dt
+                if k < ode_steps - 1:
+                    dt = t_span[k + 1] - t
+            return x
+        if ode_solver not in ("ddim", "em"):
+            raise NotImplementedError(f"Solver {ode_solver} has no HIP path in this build for loss_type='diffusion' "
+                                      "(midpoint, euler, rk4, ddim, em do).")
+        n = int(ode_steps)
+        times = [torch.ones(1)]
+        for _ in range(n):
+            times.append(times[-1] - 1 / n)
+        sr, nr, beta = hip_ops.diffusion_schedule(torch.cat(times), **dc)
+        data = torch.empty_like(x)
+        for k in range(n):
+            pred = field(times[k], x)
+            if pred.shape != x.shape:
+                pred = pred.expand_as(x).contiguous()
+            if ode_solver == "ddim":
+                hip_ops.diffusion_update_("ddim", x, pred, (nr[k], sr[k], sr[k + 1], nr[k + 1]), data_out=data)
+            else:
+                delta = 1 / n
+                hip_ops.diffusion_update_("em", x, pred, (nr[k], beta[k], delta, (beta[k] * delta).sqrt()),
+                                          noise=torch.randn_like(x))  # solver.py:131
+        return data if ode_solver == "ddim" else x
+
     def diffusion_loss(self, x, t, z, mask=None, cond=None, criterion: str = "huber", diff_config=None) -> Tensor:
         """DiffusionLoss body (losses.py:250-288) with the draws given; z is already multiplied by the mask."""
-        if self.is_transformer or self.is_cross_attention or self.is_mdma or self.t_emb == "gaussian":
-            raise NotImplementedError("loss_type='diffusion' has a HIP path for model='epic' (configs/model/diffusion.yaml) with the "
-                                      "cosine / sincos time embeddings only")
+        if self.t_emb == "gaussian":
+            raise NotImplementedError("loss_type='diffusion' has a HIP path with the cosine / sincos time embeddings only")
+        if self.is_transformer or self.is_cross_attention or self.is_mdma:
+            # no fused loss kernel on these paths: noisy = signal_rate x + noise_rate z and the criterion are element-wise device ops
+            # around the differentiable field (losses.py:257-288)
+            dc = dict(self.diff_config if diff_config is None else diff_config)
+            tt = t.to(x.device, torch.float32)
+            sr, nr, _ = hip_ops.diffusion_schedule(tt, **dc)
+            noisy = sr.view(-1, 1, 1) * x + nr.view(-1, 1, 1) * z
+            v = self._field_rows(tt, noisy, cond, mask)
+            return _fm_field.diffusion_loss_from_field(v, z, mask, tt, criterion, dc)
         lay = self.net.layout(x.shape[1])
         if self.net.is_wide(x.shape[1]):
             return _fm_loss_wide.epic_wide_diffusion_loss(lay, self.net.source_vector(lay), x, t, z, cond=cond, mask=mask,

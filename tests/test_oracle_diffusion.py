@@ -51,3 +51,47 @@ def test_ddim_and_euler_maruyama():
     torch.testing.assert_close(dr.ddim_sample(vf, z * mask, cond, mask, n, dc), g.get("ddim/x_end"), rtol=1e-4, atol=5e-5)
     z, mask, cond, noise = (g.get("em/" + k) for k in ("z", "mask", "cond", "noise"))
     torch.testing.assert_close(dr.em_sample(vf, z * mask, cond, mask, n, dc, noise), g.get("em/x_end"), rtol=1e-4, atol=5e-5)
+
+
+# ---- the same recordings for the Full-Transformer / cross-attention / MDMA models (tests/golden/{tf,ca,mdma}_diffusion.npz) ----
+def _rows(path):
+    from tests.conftest import load_ca_golden, load_mdma_golden, load_tf_golden
+    g = {"tf": load_tf_golden, "ca": load_ca_golden, "mdma": load_mdma_golden}[path]("diffusion")
+    if path == "tf":
+        from oracle.tf_ref import TransformerVectorField as VF
+    elif path == "ca":
+        from oracle.ca_ref import CrossAttentionVectorField as VF
+    else:
+        from oracle.mdma_ref import MdmaVectorField
+        base = MdmaVectorField(g.state, "flows.0.", g.hp, freqs=g.freqs)
+        return g, (lambda t, x, mask=None, cond=None: base(t, x, cond, mask))
+    return g, VF(g.state, "flows.0.", g.hp, freqs=g.freqs)
+
+
+def _c(g, tag):
+    c = g.get(tag + "cond")
+    return None if c is None or c.numel() == 0 else c
+
+
+@pytest.mark.parametrize("path", ["tf", "ca", "mdma"])
+def test_row_models_loss_rhs_and_samplers(path):
+    g, vf = _rows(path)
+    dc, n = g.hp["diff_config"], int(g.z["n_steps"])
+    for crit in ("huber", "mse"):
+        tag = f"loss_{crit}/"
+        x, t, z, mask = (g.get(tag + k) for k in ("x", "t", "z", "mask"))
+        with torch.no_grad():
+            loss, *_ = dr.diffusion_loss(vf, x, mask, _c(g, tag), t, z, crit, dc)
+        torch.testing.assert_close(loss, g.get(tag + "loss"), rtol=2e-5, atol=1e-6)
+    t, x, mask = (g.get("rhs/" + k) for k in ("t", "x", "mask"))
+    with torch.no_grad():
+        f = dr.diffusion_rhs(vf, t, x, _c(g, "rhs/"), mask, dc)
+        torch.testing.assert_close(f.expand_as(g.get("rhs/f")), g.get("rhs/f"), rtol=1e-4, atol=1e-4)
+        for steps in (3, 10):
+            tag = f"midpoint_{steps}/"
+            z, mask = g.get(tag + "z"), g.get(tag + "mask")
+            cond = _c(g, tag)
+            xe = midpoint_trajectory_end(lambda tt, xx: dr.diffusion_rhs(vf, tt, xx, cond, mask, dc), z * mask, torch.linspace(1.0, 0.0, steps))
+            torch.testing.assert_close(xe, g.get(tag + "x_end"), rtol=1e-3, atol=2e-4)
+        z, mask = g.get("ddim/z"), g.get("ddim/mask")
+        torch.testing.assert_close(dr.ddim_sample(vf, z * mask, _c(g, "ddim/"), mask, n, dc), g.get("ddim/x_end"), rtol=1e-3, atol=2e-4)
