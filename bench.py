@@ -354,6 +354,23 @@ def main():
         t1e.record(main)
     torch.cuda.synchronize(dev)
     train_alone_ms = t0e.elapsed_time(t1e) / TRAIN_ALONE_REPS
+    # N > 1: the same with ONE flat all-reduce behind the whole backward (the default splits the backward and overlaps the first
+    # bucket's all-reduce with the dW GEMM: engine.FusedFMTrainer.fused_loss_and_grad) -- the comparison SURVEY 5.8 asks for
+    train_alone_flat_ms = None
+    if world > 1:
+        with stage("train step with the flat all-reduce", 300):
+            keep = trainer.split_backward
+            trainer.split_backward = False
+            with torch.cuda.stream(main):
+                for _ in range(3):
+                    trainer.step((x, mask, cond))
+                t0e.record(main)
+                for _ in range(TRAIN_ALONE_REPS):
+                    trainer.step((x, mask, cond))
+                t1e.record(main)
+            torch.cuda.synchronize(dev)
+            train_alone_flat_ms = t0e.elapsed_time(t1e) / TRAIN_ALONE_REPS
+            trainer.split_backward = keep
     # the gradient exchange alone (N > 1): the flat 2.2 MB all-reduce on the train stream, 10 in a row
     allreduce_alone_ms = 0.0
     if world > 1:
@@ -427,6 +444,12 @@ def main():
                 "multiplicity": "U{30..150} per jet (masked tail tiles are skipped; results identical)",
             },
             "train_ms": train_ms, "sample_ms": sample_ms, "train_ms_alone": train_alone_ms, "allreduce_ms_alone": allreduce_alone_ms,
+            "grad_exchange": None if world == 1 else {
+                "mode": "two buckets (RCCL all-reduce, SUM then x 1/world in the optimiser kernel): the gradients the backward's chain "
+                        "phase finishes (51 % of the parameters) are reduced next to the dW GEMM of the rest; PFM_DP_OVERLAP=0 = one flat "
+                        "all-reduce behind the whole backward",
+                "overlapped": bool(trainer.sync.enabled if trainer.split_backward is None else trainer.split_backward),
+                "train_ms_alone_flat_allreduce": train_alone_flat_ms},
             "per_rank": {"train_ms_alone": [float(v) for v in per_rank[:, 0]], "allreduce_ms_alone": [float(v) for v in per_rank[:, 1]],
                          "train_ms_in_timed_region": [float(v) for v in per_rank[:, 2]],
                          "sample_ms_in_timed_region": [float(v) for v in per_rank[:, 3]],

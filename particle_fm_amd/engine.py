@@ -203,8 +203,10 @@ class FusedFMTrainer:
         self._fin_next = 0
         self._fused = None
         # None: split the backward (and overlap the first half's all-reduce with the dW GEMM) whenever gradients are exchanged;
-        # True / False force it (True without a process group: the same two-phase launches, nothing to exchange -- for tests)
-        self.split_backward: Optional[bool] = None
+        # True / False force it (True without a process group: the same two-phase launches, nothing to exchange -- for tests;
+        # PFM_DP_OVERLAP=0 / 1 in the environment sets the default: 0 = one flat all-reduce behind the whole backward)
+        import os
+        self.split_backward: Optional[bool] = {"0": False, "1": True}.get(os.environ.get("PFM_DP_OVERLAP", ""), None)
         self._grad_synced = False
         if fusable:
             self._fused = {}
