@@ -276,6 +276,15 @@ int pfm_epic_fm_loss_backward_phases(const pfm_epic_desc *desc, const float *blo
                                      int32_t criterion, const float *jet_weight, int32_t B, float *scratch, const int32_t *order,
                                      int32_t phases, void *stream);
 
+/* The same backward, also returning grad_y[B][N][F] = d(loss)/d(y) * grad_scale, the gradient w.r.t. the network's particle input
+ * (rows behind a jet's last valid particle: 0): for a caller that chains several flows (n_transforms > 1, flow_matching_module.py:421-443;
+ * losses.py:66-69 feeds each flow's output to the next one).  The head of a jet's `saved` record is y | v | u, each round4(N * F)
+ * floats (then the activations): a caller that wants the backward to start from an upstream gradient G instead of the loss's own
+ * 2 (v - u) writes u := v - G / 2 there and passes inv_mask_total = grad_scale = 1. */
+int pfm_epic_fm_loss_backward_dx(const pfm_epic_desc *desc, const float *blob, const float *cond, const float *mask,
+                                 const float *saved, const float *inv_mask_total, const float *grad_scale, float *grad_blob,
+                                 float *grad_y, int32_t B, float *scratch, const int32_t *order, void *stream);
+
 /* The same two with the time embedding supplied by the caller, temb[B][T] (t_emb="gaussian": a small trainable network in front of
  * the field, flow_matching_module.py:178-181, 213-221; t is still needed for the interpolation y, u): the backward also returns
  * grad_temb[B][T] = d(loss)/d(temb) * grad_scale, from which the caller's autograd continues into that network. */

@@ -735,6 +735,75 @@ def gen_diffusion_rows(ref, prefix, out_dir, B=3):
 
 
 # ----------------------------------------------------------------------------------------------
+# n_transforms = 2 (flow_matching_module.py:421-443): two EPiC flows; the losses feed the first flow's output to the second at the
+# same time t (losses.py:66-69), forward(reverse=True) decodes through the flows in reverse order (:485-487)
+# ----------------------------------------------------------------------------------------------
+CHAIN_HP = dict(BASE, num_particles=30, layers=2, global_cond_dim=2, local_cond_dim=2)
+
+
+def gen_chain(ref, out_dir, B=4, seed=1212):
+    import json
+
+    hp = CHAIN_HP
+    gen = torch.Generator().manual_seed(seed + 1)
+    cnfs = []
+    for i in range(2):
+        torch.manual_seed(seed + 10 * i)
+        cnf = ref.fmm.CNF(**hp)
+        with torch.no_grad():
+            for k, p in cnf.named_parameters():
+                if k.endswith("weight_g"):
+                    p.mul_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+                elif k.endswith("bias"):
+                    p.add_(0.05 * torch.randn(p.shape, generator=gen))
+        cnfs.append(cnf)
+    flows = torch.nn.ModuleList(cnfs)
+    state = {f"flows.{i}.{k}": v.detach().clone() for i, c in enumerate(cnfs) for k, v in c.state_dict().items()}
+    N, Fe, Cg = hp["num_particles"], hp["features"], hp["global_cond_dim"]
+    out = {"_keys": np.array(list(state.keys()))}
+    for k, v in state.items():
+        out["sd/" + k] = v.numpy()
+    out["hp_json"] = np.array(json.dumps(dict(hp, n_transforms=2)))
+    out["freqs"] = torch.arange(2 * hp["frequencies"]).exp().numpy()
+    losses = {"fm": (ref.losses.FlowMatchingLoss, 3), "cfm": (ref.losses.ConditionalFlowMatchingLoss, 3)}
+    for name, (cls, _) in losses.items():
+        mask = make_mask(B, N, "f32", gen)
+        x = torch.randn(B, N, Fe, generator=gen) * mask
+        cond = torch.randn(B, Cg, generator=gen)
+        loss_mod = cls(flows=flows, sigma=1e-4)
+        torch.manual_seed(2468)
+        flows.zero_grad()
+        loss = loss_mod(x, mask=mask, cond=cond)
+        loss.backward()
+        torch.manual_seed(2468)
+        t = torch.rand_like(torch.ones(B))
+        a = torch.randn_like(x)
+        tag = f"loss_{name}/"
+        out[tag + "x"], out[tag + "t"], out[tag + "a"] = x.numpy(), t.numpy(), a.numpy()
+        if name == "cfm":
+            out[tag + "eps"] = torch.randn_like(x).numpy()  # losses.py:116, the third draw
+        out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
+        for i, c in enumerate(cnfs):
+            for k, p in c.named_parameters():
+                out[tag + f"grad/flows.{i}." + k] = p.grad.detach().clone().numpy()
+    # ---- the composed field and sampling: forward(reverse=True) = for f in reversed(flows): x = f.decode(x, ...) ----
+    mask = make_mask(B, N, "f32", gen)
+    z = torch.randn(B, N, Fe, generator=gen)
+    cond = torch.randn(B, Cg, generator=gen)
+    with torch.no_grad():
+        x = z * mask
+        for steps in (3, 10):
+            xe = x
+            for c in reversed(cnfs):
+                xe = midpoint_trajectory_end(lambda tt, xx: c(tt, xx, mask=mask, cond=cond), xe, torch.linspace(1.0, 0.0, steps))
+            tag = f"midpoint_{steps}/"
+            out[tag + "z"], out[tag + "mask"], out[tag + "cond"], out[tag + "x_end"] = z.numpy(), mask.numpy(), cond.numpy(), xe.numpy()
+    path = os.path.join(out_dir, "epic_chain2.npz")
+    np.savez(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
+
+
+# ----------------------------------------------------------------------------------------------
 # IterativeNormLayer (norm_layer.py): three training batches, then eval-mode forward / reverse
 # ----------------------------------------------------------------------------------------------
 def gen_norm_layer(ref, out_dir, seed=97531):
@@ -768,7 +837,7 @@ def gen_norm_layer(ref, out_dir, seed=97531):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,diffusion_rows,norm}; default all")
+    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,diffusion_rows,chain,norm}; default all")
     ap.add_argument("--names", default="", help="with --only epic: comma list of configuration names (default all)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -785,6 +854,8 @@ def main():
         gen_diffusion(ref, args.out)
     if ap2 is None or "norm" in ap2:
         gen_norm_layer(ref, args.out)
+    if ap2 is None or "chain" in ap2:
+        gen_chain(ref, args.out)
     for prefix in DIFF_ROWS_CONFIGS:
         if ap2 is None or "diffusion_rows" in ap2:
             gen_diffusion_rows(ref, prefix, args.out)

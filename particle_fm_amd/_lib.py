@@ -48,6 +48,8 @@ SYMBOLS = {
     "pfm_loss_finish": (c_int, [_fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_epic_fm_loss_backward": (
         c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
+    "pfm_epic_fm_loss_backward_dx": (
+        c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
     "pfm_epic_fm_loss_backward_phases": (
         c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_int32, _fp, _fp, c_int32, c_void_p]),
     "pfm_optim_step": (

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
     const float* __restrict__ mask, const float* __restrict__ saved, const float* __restrict__ inv_mask_total,
     const float* __restrict__ grad_scale, float* __restrict__ work, BwdWork bw, int crit, const float* __restrict__ jet_w,
     float* __restrict__ dtemb,        // dtemb (or NULL): [B][T] gradient w.r.t. a caller-supplied time embedding
-    const int* __restrict__ order) {  // order (or NULL): launch order of the jets, longest first (pfm_epic_jet_order)
+    const int* __restrict__ order,    // order (or NULL): launch order of the jets, longest first (pfm_epic_jet_order)
+    float* __restrict__ dy = nullptr) {  // dy (or NULL): [B][N][F] gradient w.r.t. the network's particle input (chained flows)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
     const JetDims j = dims_of(d);
@@ -419,6 +420,27 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
                 const f32x4 s4 = colsum16(acc[jf]);
                 if (pl == 0) *reinterpret_cast<f32x4*>(rec + br.dWx + (f0 + jf) * H + 4 * oslot) = s4;
             }
+        }
+    }
+    if (dy) {
+        // d loss / d y[p][f] = sum_o Wx[f][o] da1s[p][o]  (fc_l1's particle block, epic.py:360-362): what a flow in front of this one
+        // needs (n_transforms > 1, flow_matching_module.py:421-443; losses.py:66-69 feeds each flow's output to the next).  da1s is
+        // still in Hb; rows behind the last computed particle (and masked rows: their da1s is 0) get 0.
+        __syncthreads();
+        for (int i = tid; i < j.F * H; i += NT) lds[c.w3 + i] = blob[d.l1x.W + i];  // K-major [F][H]; w3 is dead since the head
+        __syncthreads();
+        float* dyj = dy + (size_t)jet * j.N * j.F;
+        for (int i = tid; i < j.N * j.F; i += NT) {
+            const int p = i / j.F, f = i - p * j.F;
+            float a = 0.f;
+            if (p < n_rows) {
+                f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+                for (int s4 = 0; s4 < H / 4; ++s4)
+                    a4 += *reinterpret_cast<const f32x4*>(Hb + lds_off(p, s4)) * *reinterpret_cast<const f32x4*>(lds + c.w3 + f * H + 4 * s4);
+                a = (a4.x + a4.y) + (a4.z + a4.w);
+            }
+            dyj[i] = a;
         }
     }
     PFM_BSTAMP(30);

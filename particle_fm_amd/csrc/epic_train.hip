@@ -174,7 +174,7 @@ extern "C" int pfm_epic_diffusion_loss_forward(const pfm_epic_desc* d, const flo
 static int loss_backward(const pfm_epic_desc* d, const float* blob, const float* cond, const float* mask, const float* saved,
                          const float* inv_mask_total, const float* grad_scale, float* grad_blob, int crit, const float* jet_w,
                          int B, float* scratch, const int32_t* order, void* stream, float* dtemb = nullptr,
-                         int phases = PFM_BWD_PHASE_CHAIN | PFM_BWD_PHASE_DW) {
+                         int phases = PFM_BWD_PHASE_CHAIN | PFM_BWD_PHASE_DW, float* dy = nullptr) {
     int rc = validate(d);
     if (rc) return rc;
     const int64_t lds = (int64_t)make_bcarve(d->n_points, d->features).total * 4;
@@ -206,10 +206,10 @@ static int loss_backward(const pfm_epic_desc* d, const float* blob, const float*
         // 1. per-jet chain: gradient rows + rank-1 operands -> scratch
         if (bf16)
             hipLaunchKernelGGL(epic_fm_loss_backward_kernel<true>, dim3(B), dim3(NT), (int)lds, s, blob, d->blob_floats, cond, mask, saved,
-                               inv_mask_total, grad_scale, scratch, bw, crit, jet_w, dtemb, order);
+                               inv_mask_total, grad_scale, scratch, bw, crit, jet_w, dtemb, order, dy);
         else
             hipLaunchKernelGGL(epic_fm_loss_backward_kernel<false>, dim3(B), dim3(NT), (int)lds, s, blob, d->blob_floats, cond, mask, saved,
-                               inv_mask_total, grad_scale, scratch, bw, crit, jet_w, dtemb, order);
+                               inv_mask_total, grad_scale, scratch, bw, crit, jet_w, dtemb, order, dy);
         if ((rc = check_hip(hipGetLastError(), "epic_fm_loss_backward_kernel launch"))) return rc;
         if (!whole) {  // the sums that need the chain's records only: rank-1 sums over jets, the F-wide particle blocks
             ra.item0 = ra.n_tile;
@@ -292,6 +292,14 @@ extern "C" int pfm_epic_fm_loss_backward_phases(const pfm_epic_desc* d, const fl
         return set_err(PFM_E_BADARG, "phases must be PFM_BWD_PHASE_CHAIN, PFM_BWD_PHASE_DW or both");
     return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, criterion, jet_weight, B, scratch, order, stream,
                          nullptr, phases);
+}
+
+extern "C" int pfm_epic_fm_loss_backward_dx(const pfm_epic_desc* d, const float* blob, const float* cond, const float* mask,
+                                            const float* saved, const float* inv_mask_total, const float* grad_scale, float* grad_blob,
+                                            float* grad_y, int32_t B, float* scratch, const int32_t* order, void* stream) {
+    if (!grad_y) return set_err(PFM_E_BADARG, "grad_y is NULL");
+    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, 0, nullptr, B, scratch, order, stream, nullptr,
+                         PFM_BWD_PHASE_CHAIN | PFM_BWD_PHASE_DW, grad_y);
 }
 
 extern "C" int pfm_epic_fm_loss_backward_temb(const pfm_epic_desc* d, const float* blob, const float* cond, const float* mask,

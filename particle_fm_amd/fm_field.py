@@ -116,6 +116,52 @@ def epic_wide_field(layout, src, t, x, cond=None, mask=None):
     return EpicWideFieldFn.apply(src, layout, x, t, cond, mask)
 
 
+class EpicFieldFn(torch.autograd.Function):
+    """Jet-resident EPiC field over the layout's source vector, differentiable w.r.t. the parameters AND the particle input x
+    (pfm_epic_fm_loss_backward_dx): the building block of n_transforms > 1 (losses.py:66-69 feeds each flow's output to the next).
+    The saved record of a jet starts with y | v | u (pfm_hip.h): the upstream gradient goes in as u := v - G / 2."""
+
+    @staticmethod
+    def forward(ctx, src, x, layout, t, cond, mask):
+        from .fm_loss import pack_blob_from_source
+        from . import hip_ops
+        blob = pack_blob_from_source(layout, src)
+        _, _, saved = hip_ops.epic_fm_loss_forward(layout, blob, x, t, torch.zeros_like(x), cond, mask, 0.0, "droid", None)
+        B, N, F = x.shape
+        ctx.layout, ctx.cond, ctx.mask, ctx.n_source, ctx.shape = layout, cond, mask, src.numel(), (B, N, F)
+        ctx.save_for_backward(blob, saved)
+        r4 = (N * F + 3) & ~3
+        v = saved[:, r4:r4 + N * F].reshape(B, N, F)
+        # rows behind a jet's last valid particle are never computed (nor written): the field is 0 there (epic.py:391)
+        return v.clone() if mask is None else torch.where(mask.reshape(B, N, 1) != 0, v, torch.zeros((), device=v.device))
+
+    @staticmethod
+    def backward(ctx, G):
+        from .fm_loss import _Maps
+        from . import hip_ops
+        layout = ctx.layout
+        blob, saved = ctx.saved_tensors
+        B, N, F = ctx.shape
+        dev = blob.device
+        r4 = (N * F + 3) & ~3
+        sv = saved.clone()  # (the node may be differentiated twice: leave the forward's record alone)
+        sv[:, 2 * r4:2 * r4 + N * F] = sv[:, r4:r4 + N * F] - 0.5 * G.reshape(B, N * F).to(torch.float32)
+        cond = None if (ctx.cond is None or layout.cfg.global_cond_dim == 0) else ctx.cond.to(torch.float32).contiguous()
+        maskf = None if ctx.mask is None else ctx.mask.reshape(B, -1).to(torch.float32).contiguous()
+        one = torch.ones(1, device=dev)
+        gblob = torch.zeros_like(blob)
+        d_y = torch.empty(B, N, F, device=dev, dtype=torch.float32)
+        hip_ops.epic_loss_backward(layout, blob, cond, maskf, sv, one, one, gblob, d_y=d_y)
+        _, gpos, _ = _Maps.get(layout, dev)
+        d_src = torch.zeros(ctx.n_source, device=dev, dtype=torch.float32)
+        d_src[: gpos.numel()] = gblob[gpos]
+        return d_src, d_y, None, None, None, None
+
+
+def epic_field(layout, src, t, x, cond=None, mask=None):
+    return EpicFieldFn.apply(src, x, layout, t, cond, mask)
+
+
 def diffusion_loss_from_field(v, z, mask, t, criterion: str, diff_config, mle_loss_weight: float = 0.001):
     """DiffusionLoss.forward behind the network call (losses.py:272-288): v = predicted noise, z = the (masked) noise.
     loss = sum crit(z, v) mask (1 + w beta / noise_rate) / sum mask, the rates in the reference's fp32 op order (hip_ops)."""

@@ -420,13 +420,14 @@ def epic_loss_backward_phase(layout: EpicLayout, blob, cond, maskf, saved, inv_t
 
 
 def epic_loss_backward(layout: EpicLayout, blob, cond, maskf, saved, inv_total, gscale, gblob, *, criterion: Optional[str] = None,
-                       jet_w=None, d_temb=None) -> None:
+                       jet_w=None, d_temb=None, d_y=None) -> None:
     """The atomics-free backward of the jet-resident EPiC loss (pfm_epic_fm_loss_backward / _temb / pfm_epic_diffusion_loss_backward):
     WRITES every gradient slot of ``gblob`` (layout.src_gpos) -- nothing has to be zeroed by the caller.  Batches beyond
     BWD_CHUNK_JETS run in chunks (each chunk's gradient is written to a second blob and added in chunk order: still a pure function
     of the inputs), so neither the 8192-jet limit of one call nor its B-proportional scratch bounds the batch size.
     cond / maskf: float32 (B,C) / (B,N) or None; inv_total, gscale: 1-element device tensors; criterion: None (FM-OT / CFM / droid)
-    or "mse" / "huber" (diffusion, with jet_w (B,)); d_temb: (B,T) out, or None."""
+    or "mse" / "huber" (diffusion, with jet_w (B,)); d_temb: (B,T) out, or None; d_y: (B,N,F) out (gradient w.r.t. the network's
+    particle input, pfm_epic_fm_loss_backward_dx), or None."""
     lib = _lib.load()
     dev = blob.device
     B = saved.shape[0]
@@ -449,6 +450,10 @@ def epic_loss_backward(layout: EpicLayout, blob, cond, maskf, saved, inv_total, 
                                                       P(jet_w[c0:c1]), P(cc), P(mm), P(sv), P(inv_total), P(gscale), P(out), n, P(scr),
                                                       P(order), S)
             _lib.check(rc, "pfm_epic_diffusion_loss_backward")
+        elif d_y is not None:
+            rc = lib.pfm_epic_fm_loss_backward_dx(ctypes.byref(layout.desc), P(blob), P(cc), P(mm), P(sv), P(inv_total), P(gscale),
+                                                  P(out), P(d_y[c0:c1]), n, P(scr), P(order), S)
+            _lib.check(rc, "pfm_epic_fm_loss_backward_dx")
         elif d_temb is not None:
             rc = lib.pfm_epic_fm_loss_backward_temb(ctypes.byref(layout.desc), P(blob), P(cc), P(mm), P(sv), P(inv_total), P(gscale),
                                                     P(out), P(d_temb[c0:c1]), n, P(scr), P(order), S)

@@ -21,8 +21,31 @@ def _to_device(t_cpu: torch.Tensor, x: torch.Tensor, land=None) -> torch.Tensor:
 
 def _single_flow(flows):
     if len(flows) != 1:
-        raise NotImplementedError("n_transforms > 1 is not implemented on the HIP path (every shipped config uses 1)")
+        raise NotImplementedError("n_transforms > 1: this objective has a chained-flow path for FM-OT / CFM / droid only")
     return flows[0]
+
+
+def _chained_loss(flows, kind: str, x, t, a, eps, mask, cond, sigma: float) -> torch.Tensor:
+    """n_transforms > 1 (flow_matching_module.py:421-443): the reference feeds each flow's output to the next one at the SAME time t
+    (losses.py:66-69, 125-128, 337-340) and compares the last output with the target.  No fused loss kernel for a chain: every flow is
+    the differentiable field of fm_field.py (one HIP forward with saved activations; its backward returns the gradient w.r.t. the
+    parameters AND w.r.t. the particle input, which the flow in front of it consumes); interpolation, target and the squared error
+    are element-wise device ops in the reference's own expressions."""
+    tt = t.to(x.device, torch.float32).view(-1, 1, 1)
+    m = torch.ones_like(x[..., :1]) if mask is None else mask.to(x.dtype)
+    if kind == "FM-OT":    # losses.py:56-62
+        y = (1 - tt) * x + (sigma + (1 - sigma) * tt) * a
+        u = ((1 - sigma) * a - x) * m
+    elif kind == "CFM":    # losses.py:115-119
+        y = (1 - tt) * x + tt * a + sigma * eps
+        u = (a - x) * m
+    else:                  # droid, losses.py:332-336
+        y = x + tt * a
+        u = a * m
+    temp = y
+    for f in flows:
+        temp = f.field(t, temp, cond=cond, mask=mask)
+    return (temp - u).square().sum() / m.sum()
 
 
 class FlowMatchingLoss(nn.Module):
@@ -48,6 +71,8 @@ class FlowMatchingLoss(nn.Module):
         if x.dim() != 3:
             raise NotImplementedError("the HIP loss handles set data (B, N, F)")
         t, z = self.draw(x)
+        if len(self.flows) > 1:
+            return _chained_loss(self.flows, "FM-OT", x, t, z, None, mask, cond, self.sigma)
         return _single_flow(self.flows).fm_loss(x, t, z, mask=mask, cond=cond, sigma=self.sigma, kind="FM-OT")
 
 
@@ -70,6 +95,8 @@ class ConditionalFlowMatchingLoss(nn.Module):
         if mask is None:
             raise TypeError("ConditionalFlowMatchingLoss needs a mask (losses.py:119 multiplies by it)")
         t, x0, eps = self.draw(x)
+        if len(self.flows) > 1:
+            return _chained_loss(self.flows, "CFM", x, t, x0, eps, mask, cond, self.sigma)
         return _single_flow(self.flows).fm_loss(x, t, x0, mask=mask, cond=cond, sigma=self.sigma, kind="CFM", eps=eps)
 
 
@@ -93,6 +120,8 @@ class DroidLoss(nn.Module):
         if mask is None:
             raise TypeError("DroidLoss needs a mask (losses.py:339 multiplies by it)")
         t, z = self.draw(x)
+        if len(self.flows) > 1:
+            return _chained_loss(self.flows, "droid", x, t, z, None, mask, cond, self.sigma)
         return _single_flow(self.flows).fm_loss(x, t, z, mask=mask, cond=cond, sigma=self.sigma, kind="droid")
 
 

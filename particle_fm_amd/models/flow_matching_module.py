@@ -313,6 +313,15 @@ class CNF(nn.Module):
                                           noise=torch.randn_like(x))  # solver.py:131
         return data if ode_solver == "ddim" else x
 
+    def field(self, t, x, cond=None, mask=None) -> Tensor:
+        """v = f(t, x), differentiable w.r.t. the parameters AND the particle input x: what a chain of flows (n_transforms > 1) is
+        built from (losses._chained_loss).  Jet-resident EPiC kernels only (pfm_epic_fm_loss_backward_dx returns d / d x)."""
+        if self.is_transformer or self.is_cross_attention or self.is_mdma or self.t_emb == "gaussian" or self.net.is_wide(x.shape[1]):
+            raise NotImplementedError("n_transforms > 1 has a HIP path for model='epic' at hidden_dim 128 with sets that fit the "
+                                      "jet-resident kernel (cosine / sincos time embedding): no other kernel returns d loss / d input")
+        lay = self.net.layout(x.shape[1])
+        return _fm_field.epic_field(lay, self.net.source_vector(lay), self._per_jet_time(t, x).to(x.device, torch.float32), x, cond, mask)
+
     def _field_rows(self, t, x, cond, mask):
         """v = f(t, x) of the transformer / cross-attention / MDMA model as a differentiable function of the parameters (fm_field.py)."""
         lay = self.net.layout(x.shape[1])

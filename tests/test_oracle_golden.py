@@ -113,3 +113,28 @@ def test_weight_norm_rowwise():
     st = {"l." + k: v.detach() for k, v in lin.state_dict().items()}
     x = torch.randn(3, 7)
     torch.testing.assert_close(wn_linear(st, "l", x), lin(x).detach())
+
+
+def test_chained_flows_fixture_is_reproduced_by_the_oracle():
+    """tests/golden/epic_chain2.npz (n_transforms = 2, flow_matching_module.py:421-443): the oracle's field composed as the reference's
+    losses compose it (losses.py:66-69) reproduces the recorded FM-OT loss and the reverse-order midpoint samples."""
+    from oracle.fm_ref import EpicVectorField, fm_ot_targets, midpoint_trajectory_end
+    from tests.conftest import load_golden
+    g = load_golden("chain2")
+    vfs = [EpicVectorField(g.state, f"flows.{i}.net", g.hp, freqs=g.freqs) for i in range(2)]
+    tag = "loss_fm/"
+    x, t, z, mask, cond = (g.get(tag + k) for k in ("x", "t", "a", "mask", "cond"))
+    with torch.no_grad():
+        tt, y, u, m = fm_ot_targets(x, mask, t, z, 1e-4)
+        temp = y
+        for vf in vfs:
+            temp = vf(tt.squeeze(-1), temp, mask=m, cond=cond)
+        loss = (temp - u).square().sum() / m.sum()
+        torch.testing.assert_close(loss, g.get(tag + "loss"), rtol=1e-5, atol=1e-6)
+        for steps in (3, 10):
+            tag = f"midpoint_{steps}/"
+            z, mk, c = (g.get(tag + k) for k in ("z", "mask", "cond"))
+            xe = z * mk
+            for vf in reversed(vfs):
+                xe = midpoint_trajectory_end(lambda tq, xx: vf(tq, xx, mask=mk, cond=c), xe, torch.linspace(1.0, 0.0, steps))
+            torch.testing.assert_close(xe, g.get(tag + "x_end"), rtol=1e-4, atol=2e-5)
