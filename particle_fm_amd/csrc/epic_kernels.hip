@@ -674,15 +674,26 @@ __global__ __launch_bounds__(1024) void epic_jet_count_kernel(const float* __res
     if (lane == 0) cnt[jet] = c;
 }
 __global__ __launch_bounds__(1024) void epic_jet_order_kernel(int B, int* __restrict__ order) {
-    __shared__ int cnt[ORDER_MAX_JETS];
+    __shared__ __attribute__((aligned(16))) int cnt[ORDER_MAX_JETS + 4];
     const int tid = threadIdx.x;
     for (int jet = tid; jet < B; jet += 1024) cnt[jet] = order[jet];  // (the counts, written there by epic_jet_count_kernel)
+    if (tid < 4) cnt[B + tid] = -1;                                   // pad to a multiple of 4: never larger than a real count
     __syncthreads();
+    const int B4 = (B + 3) >> 2;
     for (int jet = tid; jet < B; jet += 1024) {
         const int c = cnt[jet];
-        int rank = 0;
-        for (int k = 0; k < B; ++k) rank += (cnt[k] > c) || (cnt[k] == c && k < jet);
-        order[rank] = jet;
+        // rank = jets with a larger count + jets with the same count and a smaller index; four counts per (broadcast) LDS read, two
+        // accumulators (the scalar walk of rounds 2-3 took 42 us at 1024 jets)
+        int r0 = 0, r1 = 0;
+        for (int k4 = 0; k4 < B4; ++k4) {
+            const int4 v = *reinterpret_cast<const int4*>(cnt + 4 * k4);
+            const int k = 4 * k4;
+            r0 += (v.x > c) || (v.x == c && k < jet);
+            r1 += (v.y > c) || (v.y == c && k + 1 < jet);
+            r0 += (v.z > c) || (v.z == c && k + 2 < jet);
+            r1 += (v.w > c) || (v.w == c && k + 3 < jet);
+        }
+        order[r0 + r1] = jet;
     }
 }
 
