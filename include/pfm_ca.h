@@ -30,6 +30,7 @@ extern "C" {
 #define PFM_CA_MAX_TOKENS 8
 #define PFM_CA_F_F16X3 1        /* split-fp16 Linears, see PFM_TF_F_F16X3 */
 #define PFM_CA_F_BF16 32        /* bf16 operands in the particle-side Linears (forward and dX), see PFM_TF_F_BF16; tokens, attention, dW: fp32 */
+#define PFM_CA_F_TEMB_GIVEN 64  /* the `t` arguments hold the time EMBEDDING, see PFM_TF_F_TEMB_GIVEN (pfm_tf.h); no graph replay then */
 #define PFM_CA_F_TEMB_SINCOS 2  /* see PFM_TF_F_TEMB_SINCOS */
 #define PFM_CA_F_VALID_ROWS 4    /* see PFM_TF_F_VALID_ROWS: inference over the valid particles only */
 #define PFM_CA_F_GRAPH_STEPS 8   /* pfm_ca_sample_midpoint on a non-null stream: step 0 is launched directly, the step body is captured
@@ -78,6 +79,10 @@ int64_t pfm_ca_backward_scratch_floats(const pfm_ca_desc *desc, int32_t n_jets);
 int pfm_ca_fm_loss_backward(const pfm_ca_desc *desc, const float *blob, const float *cond, const float *mask,
                             const float *y, const float *u, const float *v, const float *gscale, float *gblob,
                             int32_t n_jets, float *workspace, float *scratch, void *stream);
+
+/* PFM_CA_F_TEMB_GIVEN: dtemb[n_jets][t_dim] = d(loss)/d(temb) * gscale of the pfm_ca_fm_loss_backward call that has just filled
+ * `scratch` (as pfm_tf_backward_dtemb). */
+int pfm_ca_backward_dtemb(const pfm_ca_desc *desc, const float *blob, const float *scratch, int32_t n_jets, float *dtemb, void *stream);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,13 @@ extern "C" {
                           * v_mfma_f32_16x16x32_bf16 with both operands rounded to bf16, fp32 accumulate, fp32 activations: what
                           * trainer.precision="bf16-mixed" (configs/trainer/default.yaml:11-12: autocast around the same modules) asks of
                           * the nn.Linear layers.  Bar: no further from the fp32 vectors than the oracle under torch.autocast(bfloat16) */
+#define PFM_TF_F_TEMB_GIVEN 64 /* desc.flags: the caller supplies the time EMBEDDING (t_emb="gaussian": a small trainable network in front of
+                                * the field, flow_matching_module.py:178-181, 213-221) through the `t` argument of every entry point:
+                                *   forward / loss forward: t = temb[n_jets][t_dim] (t_stride = 1) or one row for all jets (t_stride = 0);
+                                *   samplers: t_eval = the table [t_dim][evaluations], TRANSPOSED (evaluation e starts at t_eval + e);
+                                *   the loss forward's interpolation must then not depend on t: kind "droid" with a = 0, i.e. y = x -- the
+                                *   forward-with-saved-activations of particle_fm_amd/fm_field.py, whose backward starts from an upstream
+                                *   gradient; pfm_tf_backward_dtemb returns d loss / d temb from that backward's scratch. */
 #define PFM_TF_F_F16X3 1 /* desc.flags: every Linear (forward and dX) as three fp16 MFMAs on (hi, lo) splits of both operands,
                             fp32 accumulate: fp32-grade products (see PFM_F_F16X3_MFMA in pfm_hip.h); needs |x| < 65504 */
 
@@ -157,6 +164,10 @@ int64_t pfm_tf_backward_scratch_floats(const pfm_tf_desc *desc, int32_t n_jets);
 int pfm_tf_fm_loss_backward(const pfm_tf_desc *desc, const float *blob, const float *t, const float *cond,
                             const float *mask, const float *y, const float *u, const float *v, const float *gscale,
                             float *gblob, int32_t n_jets, float *workspace, float *scratch, void *stream);
+
+/* PFM_TF_F_TEMB_GIVEN: dtemb[n_jets][t_dim] = d(loss)/d(temb) * gscale of the pfm_tf_fm_loss_backward call that has just filled
+ * `scratch` (same descriptor, blob and n_jets): through the context network's first Linear and the time columns of node_embd. */
+int pfm_tf_backward_dtemb(const pfm_tf_desc *desc, const float *blob, const float *scratch, int32_t n_jets, float *dtemb, void *stream);
 
 #ifdef __cplusplus
 }

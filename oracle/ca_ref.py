@@ -19,7 +19,7 @@ from typing import Mapping
 
 import torch
 
-from .fm_ref import time_embedding
+from .fm_ref import gaussian_time_embedding, time_embedding
 from .tf_ref import _lin, _ln, dense_network
 
 
@@ -69,7 +69,10 @@ class CrossAttentionVectorField:
 
     def __call__(self, t, x, cond=None, mask=None):
         hp = self.hp
-        temb = time_embedding(t, x, hp, self.freqs)
+        if hp.get("t_emb", "cosine") == "gaussian":  # flow_matching_module.py:178-181, 213-221: a trainable embedding network of the CNF
+            temb = gaussian_time_embedding(t, x, self.state, self.prefix, hp.get("activation", "leaky_relu"))
+        else:
+            temb = time_embedding(t, x, hp, self.freqs)
         if hp.get("add_time_to_input", True):
             x = torch.cat((temb, x), dim=-1)
         cae = hp["net_config"]["cae_config"]

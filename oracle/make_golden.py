@@ -303,6 +303,8 @@ TF_CONFIGS = {
     "lhco": (dict(TF_BASE, num_particles=279, global_cond_dim=5, net_config=tf_net_config(256, 3, 16)), 2, False),
     "sincos": (dict(TF_BASE, num_particles=20, global_cond_dim=2, t_emb="sincos", frequencies=6,
                     net_config=tf_net_config(128, 1, 8)), 3, False),
+    # t_emb="gaussian" (flow_matching_module.py:178-181, 213-221): the CNF's trainable embedding network in front of the field
+    "gauss": (dict(TF_BASE, num_particles=24, global_cond_dim=2, t_emb="gaussian", hidden_dim=64, net_config=tf_net_config(128, 1, 8)), 3, False),
 }
 
 
@@ -554,6 +556,7 @@ CA_CONFIGS = {
     "small": (dict(CA_BASE, num_particles=40, global_cond_dim=3, net_config=ca_net_config(128, 2, 16, 256)), 4, False),
     # the yaml's own sizes with experiment/lhco/jets_crossattention.yaml:28-29
     "lhco": (dict(CA_BASE, num_particles=279, global_cond_dim=5, net_config=ca_net_config(128, 8, 16, 256)), 2, False),
+    "gauss": (dict(CA_BASE, num_particles=24, global_cond_dim=2, t_emb="gaussian", hidden_dim=64, net_config=ca_net_config(128, 1, 16, 256)), 3, False),
 }
 
 
@@ -838,7 +841,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
     ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,diffusion_rows,chain,norm}; default all")
-    ap.add_argument("--names", default="", help="with --only epic: comma list of configuration names (default all)")
+    ap.add_argument("--names", default="", help="with --only epic / tf / ca: comma list of configuration names (default all)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
@@ -863,10 +866,10 @@ def main():
         if ap2 is None or "wide" in ap2:
             gen_epic_wide(ref, name, hp, B, args.out)
     for name, (hp, B, store_all) in TF_CONFIGS.items():
-        if ap2 is None or "tf" in ap2:
+        if (ap2 is None or "tf" in ap2) and (names is None or name in names):
             gen_transformer(ref, name, hp, B, store_all, args.out)
     for name, (hp, B, store_all) in CA_CONFIGS.items():
-        if ap2 is None or "ca" in ap2:
+        if (ap2 is None or "ca" in ap2) and (names is None or name in names):
             gen_transformer(ref, name, hp, B, store_all, args.out, seed=4048, file_prefix="ca")
     for name, (hp, B, store_all) in MDMA_CONFIGS.items():
         if ap2 is None or "mdma" in ap2:

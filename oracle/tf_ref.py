@@ -26,7 +26,7 @@ from typing import Mapping, Optional
 import torch
 import torch.nn.functional as F
 
-from .fm_ref import time_embedding
+from .fm_ref import gaussian_time_embedding, time_embedding
 
 LRLU_SLOPE = 0.1  # droid_transformer.py:1022
 
@@ -110,7 +110,10 @@ class TransformerVectorField:
 
     def __call__(self, t, x, cond=None, mask=None, intermediates=None):
         hp = self.hp
-        temb = time_embedding(t, x, hp, self.freqs)
+        if hp.get("t_emb", "cosine") == "gaussian":  # flow_matching_module.py:178-181, 213-221: a trainable embedding network of the CNF
+            temb = gaussian_time_embedding(t, x, self.state, self.prefix, hp.get("activation", "leaky_relu"))
+        else:
+            temb = time_embedding(t, x, hp, self.freqs)
         if hp.get("add_time_to_input", True):
             x = torch.cat((temb, x), dim=-1)
         te = hp["net_config"]["te_config"]

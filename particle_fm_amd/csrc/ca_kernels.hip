@@ -83,6 +83,7 @@ struct Plan {
     Ws w;
     int n_jets, M, Mt;
     hipStream_t s;
+    int temb_k = 0;  // PFM_CA_F_TEMB_GIVEN: floats between the elements of a time-embedding row in the `t` argument (0: `t` holds times)
     // valid-rows-only evaluation (PFM_CA_F_VALID_ROWS, inference): the particle rows are the valid particles
     const int *rowsrc = nullptr, *rowjet = nullptr, *off = nullptr, *m_dev = nullptr, *cnt = nullptr, *order = nullptr;
 };
@@ -346,7 +347,8 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         CtxtArgs a;
         a.blob = p.blob; a.t = t; a.cond = cond;
         a.temb = ws + w.temb; a.chid = ws + w.chid; a.ctxt = ws + w.ctxt; a.jb = ws + w.jb;
-        a.t_stride = t_stride; a.T = d.t_dim; a.C = d.cond_dim; a.CH = d.ctxt_hidden; a.CO = d.ctxt_dim; a.Hd = Hd; a.nb = nb;
+        a.t_stride = p.temb_k ? (t_stride ? d.t_dim : 0) : t_stride; a.temb_k = p.temb_k;
+        a.T = d.t_dim; a.C = d.cond_dim; a.CH = d.ctxt_hidden; a.CO = d.ctxt_dim; a.Hd = Hd; a.nb = nb;
         a.slope = d.neg_slope; a.eps = d.ln_eps; a.sincos = (d.flags & PFM_CA_F_TEMB_SINCOS) ? 1 : 0;
         a.freqs = d.freqs; a.c1W = d.c1.W; a.c1b = d.c1.b; a.cg = d.c_norm.gamma; a.cb = d.c_norm.beta;
         a.c2W = d.c2.W; a.c2b = d.c2.b; a.n1Wt = d.time_in_input ? d.n1.Wt : -1;
@@ -452,6 +454,7 @@ int make_plan(Plan& p, const pfm_ca_desc* d, const float* blob, float* ws, int n
     p.d = d; p.blob = blob; p.ws = ws; p.n_jets = n_jets; p.M = n_jets * d->n_points; p.Mt = n_jets * d->tokens;
     p.s = (hipStream_t)stream;
     p.w = make_ws(*d, n_jets, train);
+    p.temb_k = (d->flags & PFM_CA_F_TEMB_GIVEN) ? 1 : 0;  // rows [jet][T]; the samplers switch to their [T][evaluations] table
     return 0;
 }
 
@@ -741,6 +744,7 @@ int pfm_ca_sample_midpoint(const pfm_ca_desc* d, const float* blob, const float*
     if (!blob || !t_eval || !dt || !z || !x_out || !state || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (n_steps < 0) return set_err(PFM_E_BADARG, "n_steps < 0");
     if (d->cond_dim > 0 && !cond) return set_err(PFM_E_BADARG, "cond_dim > 0 but cond is NULL");
+    if (p.temb_k) p.temb_k = 2 * n_steps;  // t_eval = the embedding table [T][2 n_steps]: evaluation e starts at t_eval + e
     const int64_t n = (int64_t)p.M * d->features;
     float* xs = state;
     float* xm = state + n;
@@ -759,7 +763,8 @@ int pfm_ca_sample_midpoint(const pfm_ca_desc* d, const float* blob, const float*
     };
     int k = 0;
     // the legacy null stream cannot be captured; two steps or fewer are not worth a graph
-    tf::ParkedGraph* gs = ((d->flags & PFM_CA_F_GRAPH_STEPS) && p.s != nullptr && n_steps > 2) ? tf::park_graph(p.s) : nullptr;
+    // (a caller-supplied embedding table is addressed through t_eval itself: the replayed step body reads t from a staging slot: no graph)
+    tf::ParkedGraph* gs = ((d->flags & PFM_CA_F_GRAPH_STEPS) && p.s != nullptr && n_steps > 2 && !p.temb_k) ? tf::park_graph(p.s) : nullptr;
     if (gs) {
         // step 0 runs directly: whatever the first launch of a kernel does lazily (module load, the 128-row Linear's LDS opt-in)
         // happens outside the capture
@@ -798,6 +803,7 @@ int pfm_ca_sample_rk(const pfm_ca_desc* d, const float* blob, const pfm_rk_table
                        d->features);
     if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
     if ((rc = ca::setup_valid_rows(p, mask))) return rc;
+    if (p.temb_k) p.temb_k = n_steps * tab->stages;  // t_eval = the embedding table [T][n_steps * stages]
     rc = tf::sample_rk_rows(*tab, t_eval, dt, n_steps, state, n, p.s, [&](const float* t, const float* x, float* v) {
         tf::HeadArgs h{};
         h.dst = v;
@@ -850,6 +856,19 @@ int pfm_ca_fm_loss_backward(const pfm_ca_desc* d, const float* blob, const float
     B.sc = scratch;
     B.b = ca::make_bs(*d, n_jets);
     return ca::run_backward(B, cond, mask, y, u, v, gscale);
+}
+
+int pfm_ca_backward_dtemb(const pfm_ca_desc* d, const float* blob, const float* scratch, int32_t n_jets, float* dtemb, void* stream) {
+    int rc = ca::validate(d);
+    if (rc) return rc;
+    if (!(d->flags & PFM_CA_F_TEMB_GIVEN)) return set_err(PFM_E_BADARG, "pfm_ca_backward_dtemb: the descriptor has no PFM_CA_F_TEMB_GIVEN");
+    if (n_jets <= 0) return 0;
+    if (!blob || !scratch || !dtemb) return set_err(PFM_E_BADARG, "NULL device pointer");
+    const ca::Bs b = ca::make_bs(*d, n_jets);
+    hipLaunchKernelGGL(tf::tf_dtemb_kernel, dim3(n_jets), dim3(64), 0, (hipStream_t)stream, blob, scratch + b.dpre, scratch + b.djb, dtemb,
+                       d->c1.W, d->time_in_input ? d->n1.Wt : (int64_t)-1, d->t_dim, d->ctxt_hidden, d->hidden,
+                       (int64_t)(2 * d->layers + 2) * d->hidden);
+    return check_hip(hipGetLastError(), "tf_dtemb_kernel launch (ca)");
 }
 
 }  // extern "C"

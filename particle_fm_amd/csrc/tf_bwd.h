@@ -830,6 +830,30 @@ static __global__ __launch_bounds__(256) void tf_outer_rows_kernel(OuterRowsArgs
     a.gblob[(bias ? a.gb[c] : a.gW[c]) + e] += s;
 }
 
+// d loss / d temb[jet][k] = sum_o c1W[k][o] dpre[jet][o] + sum_o n1Wt[k][o] djb[jet][0][o]: the gradient a caller-supplied time embedding
+// (PFM_*_F_TEMB_GIVEN) receives through the context network's first Linear and the time columns of node_embd.  One workgroup per jet.
+static __global__ __launch_bounds__(64) void tf_dtemb_kernel(const float* __restrict__ blob, const float* __restrict__ dpre,
+                                                             const float* __restrict__ djb, float* __restrict__ dtemb, int64_t c1W,
+                                                             int64_t n1Wt, int T, int CH, int Hd, int64_t jbs) {
+    const int jet = blockIdx.x, k = threadIdx.x;
+    if (k >= T) return;
+    float a0 = 0.f, a1 = 0.f;
+    const float* dp = dpre + (int64_t)jet * CH;
+    for (int o = 0; o + 1 < CH; o += 2) {
+        a0 = fmaf(blob[c1W + (int64_t)k * CH + o], dp[o], a0);
+        a1 = fmaf(blob[c1W + (int64_t)k * CH + o + 1], dp[o + 1], a1);
+    }
+    if (CH & 1) a0 = fmaf(blob[c1W + (int64_t)k * CH + CH - 1], dp[CH - 1], a0);
+    if (n1Wt >= 0) {
+        const float* dj = djb + (int64_t)jet * jbs;
+        for (int o = 0; o + 1 < Hd; o += 2) {
+            a0 = fmaf(blob[n1Wt + (int64_t)k * Hd + o], dj[o], a0);
+            a1 = fmaf(blob[n1Wt + (int64_t)k * Hd + o + 1], dj[o + 1], a1);
+        }
+    }
+    dtemb[(int64_t)jet * T + k] = a0 + a1;
+}
+
 // Parameter gradients of the per-jet context path in two launches: the jet-bias rows (Wc, bias of every Linear that
 // takes the context) and the context network itself (+ the time columns of node_embd).
 struct CtxtGradIn {

@@ -55,6 +55,7 @@ struct CtxtArgs {
     const float* cond;
     float *temb, *chid, *ctxt, *jb;
     int t_stride, T, C, CH, CO, Hd, nb, sincos;
+    int temb_k = 0;  // > 0 (PFM_*_F_TEMB_GIVEN): `t` holds the time EMBEDDING -- element k of a jet's row at t[jet * t_stride + k * temb_k]
     float slope, eps;
     int64_t freqs, c1W, c1b, cg, cb, c2W, c2b, n1Wt;
     int64_t Wc[CTXT_MAX_NB], bb[CTXT_MAX_NB];
@@ -69,9 +70,14 @@ static __global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
     const float* __restrict__ blob = a.blob;
     if (tid < a.T) {
         // time_emb.py:90-96, exact fp32 op order ((t + min) * f) * pi / (max + min)
+        float e;
+        if (a.temb_k > 0) {  // a caller-supplied embedding (t_emb="gaussian": a small trainable network in front of the field)
+            e = a.t[(int64_t)jet * a.t_stride + (int64_t)tid * a.temb_k];
+            cin[tid] = e;
+            a.temb[(int64_t)jet * 64 + tid] = e;
+        } else {
         const float t = a.t[(int64_t)jet * a.t_stride];
         const float f = blob[a.freqs + tid];
-        float e;
         if (a.sincos) {  // flow_matching_module.py:208-211 (table = [f ; f], f = 2^k pi)
             const float arg = __fmul_rn(f, t);
             e = 2 * tid < a.T ? cosf(arg) : sinf(arg);
@@ -80,6 +86,7 @@ static __global__ __launch_bounds__(512) void tf_ctxt_kernel(CtxtArgs a) {
         }
         cin[tid] = e;
         a.temb[(int64_t)jet * 64 + tid] = e;
+        }
     } else if (tid < a.T + a.C) {
         cin[tid] = a.cond[(int64_t)jet * a.C + tid - a.T];
     }

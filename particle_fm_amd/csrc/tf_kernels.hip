@@ -39,6 +39,7 @@ struct Plan {
     Ws w;
     int n_jets, M;
     hipStream_t s;
+    int temb_k = 0;  // PFM_TF_F_TEMB_GIVEN: floats between the elements of a time-embedding row in the `t` argument (0: `t` holds times)
     // valid-rows-only evaluation (PFM_TF_F_VALID_ROWS, inference): rows are the valid particles in (jet, particle) order
     const int *rowsrc = nullptr, *rowjet = nullptr, *off = nullptr, *m_dev = nullptr, *cnt = nullptr, *order = nullptr;
 };
@@ -98,7 +99,8 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         CtxtArgs a;
         a.blob = p.blob; a.t = t; a.cond = cond;
         a.temb = ws + w.temb; a.chid = ws + w.chid; a.ctxt = ws + w.ctxt; a.jb = ws + w.jb;
-        a.t_stride = t_stride; a.T = d.t_dim; a.C = d.cond_dim; a.CH = d.ctxt_hidden; a.CO = d.ctxt_dim; a.Hd = Hd; a.nb = nb;
+        a.t_stride = p.temb_k ? (t_stride ? d.t_dim : 0) : t_stride; a.temb_k = p.temb_k;
+        a.T = d.t_dim; a.C = d.cond_dim; a.CH = d.ctxt_hidden; a.CO = d.ctxt_dim; a.Hd = Hd; a.nb = nb;
         a.slope = d.neg_slope; a.eps = d.ln_eps; a.sincos = (d.flags & PFM_TF_F_TEMB_SINCOS) ? 1 : 0;
         a.freqs = d.freqs; a.c1W = d.c1.W; a.c1b = d.c1.b; a.cg = d.c_norm.gamma; a.cb = d.c_norm.beta;
         a.c2W = d.c2.W; a.c2b = d.c2.b; a.n1Wt = d.time_in_input ? d.n1.Wt : -1;
@@ -155,6 +157,7 @@ int make_plan(Plan& p, const pfm_tf_desc* d, const float* blob, float* ws, int n
     if ((rc = set_attn_lds())) return rc;
     p.d = d; p.blob = blob; p.ws = ws; p.n_jets = n_jets; p.M = n_jets * d->n_points; p.s = (hipStream_t)stream;
     p.w = make_ws(*d, n_jets, train);
+    p.temb_k = (d->flags & PFM_TF_F_TEMB_GIVEN) ? 1 : 0;  // rows [jet][T]; the samplers switch to their [T][evaluations] table
     return 0;
 }
 
@@ -456,6 +459,7 @@ int pfm_tf_sample_midpoint(const pfm_tf_desc* d, const float* blob, const float*
             const int j0 = i ? n_a : 0, nj = parts == 1 ? n_jets : (i ? n_jets - n_a : n_a);
             float* ws = workspace + (i ? make_ws(*d, n_a, false).total : 0);
             if ((rc = make_plan(p[i], d, blob, ws, nj, false, ss ? (void*)(i ? ss->s2 : ss->s) : stream))) return rc;
+            if (p[i].temb_k) p[i].temb_k = 2 * n_steps;  // t_eval = the embedding table [T][2 n_steps]: evaluation e starts at t_eval + e
             r0[i] = (int64_t)j0 * d->n_points;
             n[i] = (int64_t)p[i].M * d->features;
             xs[i] = state + 2 * r0[i] * d->features;
@@ -494,6 +498,7 @@ static int tf_sample_rk_part(const pfm_tf_desc* d, const float* blob, const pfm_
     Plan p;
     int rc = make_plan(p, d, blob, workspace, nj, false, stream);
     if (rc) return rc;
+    if (p.temb_k) p.temb_k = n_steps * tab->stages;  // t_eval = the embedding table [T][n_steps * stages]
     const int64_t r0 = (int64_t)j0 * d->n_points, n = (int64_t)p.M * d->features;
     const float* cnd = cond ? cond + (int64_t)j0 * d->cond_dim : nullptr;
     const float* msk = mask ? mask + r0 : nullptr;
@@ -583,6 +588,19 @@ int pfm_tf_fm_loss_backward(const pfm_tf_desc* d, const float* blob, const float
     B.sc = scratch;
     B.b = make_bs(*d, n_jets);
     return run_backward(B, cond, mask, y, u, v, gscale);
+}
+
+int pfm_tf_backward_dtemb(const pfm_tf_desc* d, const float* blob, const float* scratch, int32_t n_jets, float* dtemb, void* stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    if (!(d->flags & PFM_TF_F_TEMB_GIVEN)) return set_err(PFM_E_BADARG, "pfm_tf_backward_dtemb: the descriptor has no PFM_TF_F_TEMB_GIVEN");
+    if (n_jets <= 0) return 0;
+    if (!blob || !scratch || !dtemb) return set_err(PFM_E_BADARG, "NULL device pointer");
+    const Bs b = make_bs(*d, n_jets);
+    hipLaunchKernelGGL(tf::tf_dtemb_kernel, dim3(n_jets), dim3(64), 0, (hipStream_t)stream, blob, scratch + b.dpre, scratch + b.djb, dtemb,
+                       d->c1.W, d->time_in_input ? d->n1.Wt : (int64_t)-1, d->t_dim, d->ctxt_hidden, d->hidden,
+                       (int64_t)(d->layers + 2) * d->hidden);
+    return check_hip(hipGetLastError(), "tf_dtemb_kernel launch");
 }
 
 }  // extern "C"

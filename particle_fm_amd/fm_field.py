@@ -33,37 +33,45 @@ def _upstream(saved, G):
 
 
 class TfFieldFn(torch.autograd.Function):
-    """Full-Transformer (ops = hip_ops_tf) / cross-attention (ops = hip_ops_ca) field over the flat parameter vector."""
+    """Full-Transformer (ops = hip_ops_tf) / cross-attention (ops = hip_ops_ca) field over the flat parameter vector.  ``t``: the times
+    (B,), or -- a layout with t_emb="gaussian" (PFM_*_F_TEMB_GIVEN) -- the time EMBEDDING rows (B, T), then a differentiable input: the
+    backward also returns d / d temb (pfm_*_backward_dtemb), from which autograd continues into the CNF's embedding network."""
 
     @staticmethod
-    def forward(ctx, flat_params, layout, freqs, ops, x, t, cond, mask):
+    def forward(ctx, flat_params, t, layout, freqs, ops, x, cond, mask):
         dev = x.device
         src = torch.cat([flat_params.to(torch.float32), freqs.to(dev, torch.float32), torch.zeros(1, device=dev)])
         blob = src[layout.index_map_on(dev)]
         fwd = ops.tf_fm_loss_forward if ops is hip_ops_tf else ops.ca_fm_loss_forward
-        _, saved = fwd(layout, blob, x, t, torch.zeros_like(x), cond, mask, 0.0, "droid", None)
-        ctx.layout, ctx.saved, ctx.blob, ctx.ops, ctx.t, ctx.cond = layout, saved, blob, ops, t, cond
+        _, saved = fwd(layout, blob, x, t.detach(), torch.zeros_like(x), cond, mask, 0.0, "droid", None)
+        ctx.layout, ctx.saved, ctx.blob, ctx.ops, ctx.t, ctx.cond = layout, saved, blob, ops, t.detach(), cond
         ctx.mask = None if mask is None else mask.reshape(x.shape[0], -1).to(torch.float32).contiguous()
+        ctx.temb_given = getattr(layout.cfg, "t_emb", "cosine") == "gaussian"
         return saved[2].clone()
 
     @staticmethod
     def backward(ctx, G):
         lay, ops = ctx.layout, ctx.ops
         one = torch.ones((), device=G.device)
-        bwd = ops.tf_fm_loss_backward if ops is hip_ops_tf else ops.ca_fm_loss_backward
-        gblob = bwd(lay, ctx.blob, ctx.t, ctx.cond, ctx.mask, _upstream(ctx.saved, G.contiguous()), one) if ops is hip_ops_tf else \
-            bwd(lay, ctx.blob, ctx.cond, ctx.mask, _upstream(ctx.saved, G.contiguous()), one)
-        return (gblob[lay.grad_pos_on(gblob.device)],) + (None,) * 7
+        if ops is hip_ops_tf:
+            gblob = ops.tf_fm_loss_backward(lay, ctx.blob, ctx.t, ctx.cond, ctx.mask, _upstream(ctx.saved, G.contiguous()), one)
+        else:
+            gblob = ops.ca_fm_loss_backward(lay, ctx.blob, ctx.cond, ctx.mask, _upstream(ctx.saved, G.contiguous()), one)
+        d_t = None
+        if ctx.temb_given and ctx.needs_input_grad[1]:
+            dtemb = ops.tf_backward_dtemb if ops is hip_ops_tf else ops.ca_backward_dtemb
+            d_t = dtemb(lay, ctx.blob, G.shape[0], G.device).reshape(ctx.t.shape)
+        return (gblob[lay.grad_pos_on(gblob.device)], d_t) + (None,) * 6
 
 
 def tf_field(layout, flat_params, t, x, cond=None, mask=None, freqs: Optional[torch.Tensor] = None):
     from .layout_tf import default_freqs
-    return TfFieldFn.apply(flat_params, layout, _freq_table(layout, freqs, default_freqs), hip_ops_tf, x, t, cond, mask)
+    return TfFieldFn.apply(flat_params, t, layout, _freq_table(layout, freqs, default_freqs), hip_ops_tf, x, cond, mask)
 
 
 def ca_field(layout, flat_params, t, x, cond=None, mask=None, freqs: Optional[torch.Tensor] = None):
     from .layout_ca import default_freqs
-    return TfFieldFn.apply(flat_params, layout, _freq_table(layout, freqs, default_freqs), hip_ops_ca, x, t, cond, mask)
+    return TfFieldFn.apply(flat_params, t, layout, _freq_table(layout, freqs, default_freqs), hip_ops_ca, x, cond, mask)
 
 
 class MdmaFieldFn(torch.autograd.Function):
@@ -160,6 +168,26 @@ class EpicFieldFn(torch.autograd.Function):
 
 def epic_field(layout, src, t, x, cond=None, mask=None):
     return EpicFieldFn.apply(src, x, layout, t, cond, mask)
+
+
+def fm_loss_from_field(field, kind: str, x, t, a, eps, mask, sigma: float):
+    """FM-OT / CFM / droid (losses.py:56-76, 115-130, 332-341) around a differentiable field(y) -> v: interpolation, target and the
+    squared error as element-wise device ops in the reference's own expressions.  Used where no fused loss kernel applies (a
+    caller-supplied time embedding on the transformer paths; chained flows: models/components/losses.py)."""
+    tt = t.to(x.device, torch.float32).view(-1, 1, 1)
+    m = torch.ones_like(x[..., :1]) if mask is None else mask.to(x.dtype)
+    if kind == "FM-OT":
+        y = (1 - tt) * x + (sigma + (1 - sigma) * tt) * a
+        u = ((1 - sigma) * a - x) * m
+    elif kind == "CFM":
+        y = (1 - tt) * x + tt * a + sigma * eps
+        u = (a - x) * m
+    elif kind == "droid":
+        y = x + tt * a
+        u = a * m
+    else:
+        raise NotImplementedError(f"loss kind {kind}")
+    return (field(y) - u).square().sum() / m.sum()
 
 
 def diffusion_loss_from_field(v, z, mask, t, criterion: str, diff_config, mle_loss_weight: float = 0.001):

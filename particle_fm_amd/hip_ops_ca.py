@@ -14,6 +14,39 @@ from .hip_ops_tf import _KINDS, _prep
 from .layout_ca import CaLayout
 
 
+def _time_arg(layout, t, B, dev, per_jet: bool = False):
+    """The `t` argument of the entry points: times -- (B,) one per jet, or 0-dim / (1,) shared -- or, for a layout with
+    t_emb="gaussian" (PFM_*_F_TEMB_GIVEN), the time EMBEDDING rows (B, T) or one shared row (T,) / (1, T).  Returns (tensor, t_stride)."""
+    T = layout.cfg.t_dim
+    if getattr(layout.cfg, "t_emb", "cosine") == "gaussian":
+        t = _dev_f32("temb", t.reshape(-1, T), dev)
+        if t.shape[0] not in (1, B) or (per_jet and t.shape[0] != B):
+            raise ValueError(f"the time embedding has {t.shape[0]} rows, expected {'' if per_jet else '1 or '}{B}")
+        return t, 1 if (t.shape[0] == B and (B > 1 or per_jet)) else 0
+    t = _dev_f32("t", t.reshape(-1), dev)
+    if t.numel() not in (1, B) or (per_jet and t.numel() != B):
+        raise ValueError(f"t has {t.numel()} elements, expected {'' if per_jet else '1 or '}{B}")
+    return t, 1 if (t.numel() == B and (B > 1 or per_jet)) else 0
+
+
+def _temb_table(temb_fn, ts: torch.Tensor, dev) -> torch.Tensor:
+    """The samplers' embedding table for a PFM_*_F_TEMB_GIVEN layout: temb_fn(ts) -> (n_evaluations, T), handed over TRANSPOSED
+    ([T][n_evaluations]: evaluation e starts at table + e, like the time grid it replaces)."""
+    tab = temb_fn(ts.to(dev))
+    return tab.to(torch.float32).t().contiguous()
+
+
+def ca_backward_dtemb(layout, blob, B: int, dev) -> torch.Tensor:
+    """d loss / d temb (B, T) of the loss backward that has just run for this layout and batch size (pfm_ca_backward_dtemb reads that
+    backward's scratch: call it right behind ca_fm_loss_backward, same stream)."""
+    lib = _lib.load()
+    scratch = layout.__dict__["_bscratch"][(B, str(dev))]
+    out = torch.empty(B, layout.cfg.t_dim, device=dev, dtype=torch.float32)
+    rc = lib.pfm_ca_backward_dtemb(ctypes.byref(layout.desc), _ptr(blob), _ptr(scratch), B, _ptr(out), _stream_ptr(dev))
+    _lib.check(rc, "pfm_ca_backward_dtemb")
+    return out
+
+
 def workspace(layout: CaLayout, n_jets: int, device, train: bool = False) -> torch.Tensor:
     """Activation workspace; cached per (n_jets, train) on the layout (the kernels fully overwrite what they read)."""
     lib = _lib.load()
@@ -43,19 +76,17 @@ def ca_forward(layout: CaLayout, blob, t, x, cond=None, mask=None) -> torch.Tens
     """v = FullCrossAttentionEncoder(t, x, cond, mask).  t: (B,) one time per jet, or 0-dim / (1,) for one shared time."""
     lib = _lib.load()
     dev, B, blob, x, cond, mask = _prep(layout, blob, x, cond, mask)
-    t = _dev_f32("t", t.reshape(-1), dev)
-    if t.numel() not in (1, B):
-        raise ValueError(f"t has {t.numel()} elements, expected 1 or {B}")
+    t, t_per_jet = _time_arg(layout, t, B, dev)
     v = torch.empty_like(x)
     ws = workspace(layout, B, dev)
-    rc = lib.pfm_ca_forward(ctypes.byref(layout.desc), _ptr(blob), _ptr(t), 1 if (t.numel() == B and B > 1) else 0, _ptr(x),
+    rc = lib.pfm_ca_forward(ctypes.byref(layout.desc), _ptr(blob), _ptr(t), t_per_jet, _ptr(x),
                             _ptr(cond), _ptr(mask), _ptr(v), B, _ptr(ws), _stream_ptr(dev))
     _lib.check(rc, "pfm_ca_forward")
     return v
 
 
 def ca_sample_midpoint(layout: CaLayout, blob, z, cond=None, mask=None, ode_steps: int = 100,
-                       premask: bool = True) -> torch.Tensor:
+                       premask: bool = True, temb_fn=None) -> torch.Tensor:
     """x(0) from x(1) = z (*mask) by ode_steps-1 explicit-midpoint intervals (2 NFE each), all launches queued on
     the current stream without a host sync."""
     lib = _lib.load()
@@ -63,6 +94,8 @@ def ca_sample_midpoint(layout: CaLayout, blob, z, cond=None, mask=None, ode_step
     if ode_steps < 2:
         raise ValueError("ode_steps must be >= 2")
     ts, dts = midpoint_grid(ode_steps, dev)
+    if getattr(layout.cfg, "t_emb", "cosine") == "gaussian":  # the table of embeddings replaces the time grid (PFM_*_F_TEMB_GIVEN)
+        ts = _temb_table(temb_fn, ts, dev)
     out = torch.empty_like(z)
     state = torch.empty(2 * z.numel(), device=dev, dtype=torch.float32)
     ws = workspace(layout, B, dev)
@@ -74,7 +107,7 @@ def ca_sample_midpoint(layout: CaLayout, blob, z, cond=None, mask=None, ode_step
 
 
 def ca_sample_rk(layout: CaLayout, blob, z, cond=None, mask=None, ode_steps: int = 100, solver: str = "rk4",
-                 premask: bool = True, t0: float = 1.0, t1: float = 0.0) -> torch.Tensor:
+                 premask: bool = True, t0: float = 1.0, t1: float = 0.0, temb_fn=None) -> torch.Tensor:
     """x(t1) from x(t0) = z (*mask) with the fixed-step explicit Runge-Kutta scheme ``solver`` ("euler", "midpoint", "rk4" =
     torchdyn's 3/8 rule) over linspace(t0, t1, ode_steps); all launches queued on the current stream."""
     lib = _lib.load()
@@ -84,6 +117,8 @@ def ca_sample_rk(layout: CaLayout, blob, z, cond=None, mask=None, ode_steps: int
     tab = rk_tableau(solver)
     ts, dts = rk_grid(ode_steps, solver, t0, t1)
     ts, dts = ts.to(dev), dts.to(dev)
+    if getattr(layout.cfg, "t_emb", "cosine") == "gaussian":
+        ts = _temb_table(temb_fn, ts, dev)
     out = torch.empty_like(z)
     state = torch.empty((2 + tab.stages) * z.numel(), device=dev, dtype=torch.float32)
     rc = lib.pfm_ca_sample_rk(ctypes.byref(layout.desc), _ptr(blob), ctypes.byref(tab), _ptr(ts), _ptr(dts), ode_steps - 1,
@@ -101,7 +136,7 @@ def ca_fm_loss_forward(layout: CaLayout, blob, x, t, a, cond=None, mask=None, si
     dev, B, blob, x, cond, mask = _prep(layout, blob, x, cond, mask)
     if kind not in _KINDS:
         raise NotImplementedError(f"loss kind {kind} has no HIP kernel")
-    t = _dev_f32("t", t, dev, (B,))
+    t, _ = _time_arg(layout, t, B, dev, per_jet=True)
     a = _dev_f32("a", a, dev, tuple(x.shape))
     if kind == "CFM":
         if eps is None:

@@ -206,7 +206,7 @@ class CaLayout(TfLayout):
         d.n_points, d.features, d.model_dim, d.hidden, d.layers = cfg.num_particles, F, D, Hd, cfg.num_layers
         d.heads, d.head_dim, d.tokens, d.t_dim, d.cond_dim = cfg.num_heads, cfg.head_dim, cfg.num_tokens, T, cfg.global_cond_dim
         d.ctxt_dim, d.ctxt_hidden, d.time_in_input = CO, cfg.ctxt_hidden, int(cfg.add_time_to_input)
-        d.flags = self.flags | (PFM_CA_F_TEMB_SINCOS if cfg.t_emb == "sincos" else 0)
+        d.flags = self.flags | (PFM_CA_F_TEMB_SINCOS if cfg.t_emb == "sincos" else 0) | (64 if cfg.t_emb == "gaussian" else 0)  # 64: PFM_*_F_TEMB_GIVEN
         d.neg_slope, d.ln_eps = 0.1, 1e-5
         d.freqs = self._put(self.freq_off + np.arange(T), primary=False)
         d.global_tokens = self._put(self.p_off["net.cae.global_tokens"] + np.arange(cfg.num_tokens * D))

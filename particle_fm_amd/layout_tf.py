@@ -240,7 +240,7 @@ class TfLayout:
         d.abi_version = PFM_TF_ABI_VERSION
         d.n_points, d.features, d.model_dim, d.hidden, d.layers = cfg.num_particles, F, D, Hd, cfg.num_layers
         d.heads, d.head_dim, d.t_dim, d.cond_dim = cfg.num_heads, HEAD_DIM, T, cfg.global_cond_dim
-        d.ctxt_dim, d.ctxt_hidden, d.time_in_input, d.flags = CO, cfg.ctxt_hidden, int(cfg.add_time_to_input), self.flags | (PFM_TF_F_TEMB_SINCOS if cfg.t_emb == "sincos" else 0)
+        d.ctxt_dim, d.ctxt_hidden, d.time_in_input, d.flags = CO, cfg.ctxt_hidden, int(cfg.add_time_to_input), self.flags | (PFM_TF_F_TEMB_SINCOS if cfg.t_emb == "sincos" else 0) | (64 if cfg.t_emb == "gaussian" else 0)  # 64: PFM_*_F_TEMB_GIVEN
         d.neg_slope, d.ln_eps = 0.1, 1e-5
         d.freqs = self._put(self.freq_off + np.arange(T), primary=False)
 

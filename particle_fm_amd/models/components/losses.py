@@ -31,21 +31,15 @@ def _chained_loss(flows, kind: str, x, t, a, eps, mask, cond, sigma: float) -> t
     the differentiable field of fm_field.py (one HIP forward with saved activations; its backward returns the gradient w.r.t. the
     parameters AND w.r.t. the particle input, which the flow in front of it consumes); interpolation, target and the squared error
     are element-wise device ops in the reference's own expressions."""
-    tt = t.to(x.device, torch.float32).view(-1, 1, 1)
-    m = torch.ones_like(x[..., :1]) if mask is None else mask.to(x.dtype)
-    if kind == "FM-OT":    # losses.py:56-62
-        y = (1 - tt) * x + (sigma + (1 - sigma) * tt) * a
-        u = ((1 - sigma) * a - x) * m
-    elif kind == "CFM":    # losses.py:115-119
-        y = (1 - tt) * x + tt * a + sigma * eps
-        u = (a - x) * m
-    else:                  # droid, losses.py:332-336
-        y = x + tt * a
-        u = a * m
-    temp = y
-    for f in flows:
-        temp = f.field(t, temp, cond=cond, mask=mask)
-    return (temp - u).square().sum() / m.sum()
+    from ... import fm_field
+
+    def chain(y):
+        temp = y
+        for f in flows:
+            temp = f.field(t, temp, cond=cond, mask=mask)
+        return temp
+
+    return fm_field.fm_loss_from_field(chain, kind, x, t, a, eps, mask, sigma)
 
 
 class FlowMatchingLoss(nn.Module):

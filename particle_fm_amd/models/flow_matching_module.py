@@ -128,13 +128,13 @@ class CNF(nn.Module):
                                               ctxt_dim=global_cond_dim + 2 * frequencies, **net_config,
                                               num_points=num_particles, frequencies=frequencies,
                                               add_time_to_input=add_time_to_input,
-                                              t_emb=t_emb if t_emb in ("cosine", "sincos") else "cosine")
+                                              t_emb=t_emb if t_emb in ("cosine", "sincos", "gaussian") else "cosine")
         elif model == "droid_fullcrossattention":  # flow_matching_module.py:159-165
             self.net = FullCrossAttentionEncoder(inpt_dim=input_dim, outp_dim=features,
                                                  ctxt_dim=global_cond_dim + 2 * frequencies, **net_config,
                                                  num_points=num_particles, frequencies=frequencies,
                                                  add_time_to_input=add_time_to_input,
-                                                 t_emb=t_emb if t_emb in ("cosine", "sincos") else "cosine")
+                                                 t_emb=t_emb if t_emb in ("cosine", "sincos", "gaussian") else "cosine")
         elif model == "mdma":  # flow_matching_module.py:163-167
             if t_emb not in ("cosine", "sincos"):
                 raise NotImplementedError("model='mdma' has a HIP path for the cosine / sincos time embeddings only")
@@ -160,8 +160,11 @@ class CNF(nn.Module):
             # flow_matching_module.py:178-181: random Fourier features -> Linear -> activation -> Linear(2 frequencies), trainable.
             # O(B * hidden) per call: host-side torch ops on the device; its output (B, T) goes to the kernels as the time
             # embedding (pfm_epic_*_temb) and the loss backward returns d loss / d temb, so the four tensors train exactly.
-            if model != "epic":
-                raise NotImplementedError("t_emb='gaussian' has a HIP path for model='epic' only")
+            # (the transformer / cross-attention kernels take the embedding through their `t` argument, PFM_*_F_TEMB_GIVEN, and
+            # pfm_*_backward_dtemb returns its gradient; MDMA and the row-matrix EPiC path embed in-kernel only)
+            if model not in ("epic", "droid_fulltransformer", "droid_fullcrossattention"):
+                raise NotImplementedError("t_emb='gaussian' has a HIP path for model='epic', 'droid_fulltransformer' and "
+                                          "'droid_fullcrossattention'")
             self.embed = nn.Sequential(GaussianFourierProjection(embed_dim=hidden_dim), nn.Linear(hidden_dim, hidden_dim))
             self.linear = nn.Linear(hidden_dim, 2 * frequencies)
         else:
@@ -186,7 +189,16 @@ class CNF(nn.Module):
         e = getattr(torch.nn.functional, self.activation, lambda v: v)(e)
         return self.linear(e)
 
+    def _temb_table_fn(self, device):
+        """ts (n_evaluations,) -> (n_evaluations, T): the embedding table a sampler evaluates the field with (every jet sees the same times)"""
+        def fn(ts):
+            with torch.no_grad():
+                return self._gaussian_temb(ts.to(device, torch.float32))
+        return fn
+
     def _check_gaussian_path(self, n_points: int):
+        if self.is_transformer or self.is_cross_attention:
+            return
         if self.net.is_wide(n_points):
             raise NotImplementedError("t_emb='gaussian' has a HIP path for model='epic' at hidden_dim 128 with sets that fit the "
                                       "LDS tile only (the row-matrix path embeds the time in-kernel)")
@@ -212,12 +224,18 @@ class CNF(nn.Module):
         if self.t_emb == "gaussian":
             self._check_gaussian_path(x.shape[1])
             temb = self._gaussian_temb(self._per_jet_time(t, x))  # (B, T)
+            if self.is_transformer or self.is_cross_attention:
+                return self.net.vector_field(temb, x, cond, mask)  # the layout carries PFM_*_F_TEMB_GIVEN: `t` = the embedding rows
             return self.net.forward(temb, x, cond, mask)
         return self.net.vector_field(self._per_jet_time(t, x), x, cond, mask)
 
     def fm_loss(self, x, t, z, mask=None, cond=None, sigma: float = 1e-4, kind: str = "FM-OT", eps=None) -> Tensor:
         """Differentiable FM / CFM loss with the draws given (the body of losses.py:38-77 / 101-136)."""
         lay = self.net.layout(x.shape[1])
+        if self.t_emb == "gaussian" and (self.is_transformer or self.is_cross_attention):
+            # no fused loss kernel with a caller-supplied embedding: interpolation / target / squared error around the differentiable
+            # field (fm_field.py), whose backward also returns d loss / d temb for the CNF's embedding network
+            return _fm_field.fm_loss_from_field(lambda y: self._field_rows(t, y, cond, mask), kind, x, t, z, eps, mask, sigma)
         if self.is_transformer:
             return _fm_loss_tf.tf_fm_loss(lay, self.net.flat_parameters(lay), x, t, z, cond=cond, mask=mask, sigma=sigma,
                                           kind=kind, eps=eps, freqs=self.net.freq_tensor())
@@ -249,12 +267,13 @@ class CNF(nn.Module):
             blob = weights if weights is not None else self.net.packed_weights(z.shape[1])
             if self.is_mdma:
                 return self._sample_rk(blob, z, cond, mask, ode_steps, "midpoint", 1.0, 0.0)
+            temb_fn = self._temb_table_fn(z.device) if self.t_emb == "gaussian" else None
             if self.is_transformer:
                 return hip_ops_tf.tf_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
-                                                     ode_steps=ode_steps, premask=False)
+                                                     ode_steps=ode_steps, premask=False, temb_fn=temb_fn)
             if self.is_cross_attention:
                 return hip_ops_ca.ca_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
-                                                     ode_steps=ode_steps, premask=False)
+                                                     ode_steps=ode_steps, premask=False, temb_fn=temb_fn)
             if self.t_emb == "gaussian":
                 self._check_gaussian_path(z.shape[1])
                 ts, _ = hip_ops.midpoint_grid(ode_steps, z.device)
@@ -326,6 +345,8 @@ class CNF(nn.Module):
         """v = f(t, x) of the transformer / cross-attention / MDMA model as a differentiable function of the parameters (fm_field.py)."""
         lay = self.net.layout(x.shape[1])
         fl, fr = self.net.flat_parameters(lay), self.net.freq_tensor()
+        if self.t_emb == "gaussian":  # the (B, T) embedding rows, a differentiable input of the field
+            t = self._gaussian_temb(self._per_jet_time(t, x))
         if self.is_transformer:
             return _fm_field.tf_field(lay, fl, t, x, cond, mask, freqs=fr)
         if self.is_cross_attention:
@@ -419,6 +440,8 @@ class CNF(nn.Module):
         if self.is_mdma:
             m = torch.ones(*z.shape[:2], 1, device=z.device) if mask is None else mask
             return hip_ops_mdma.mdma_sample_rk(lay, blob, z, m, premask=False, **kw)
+        if (self.is_transformer or self.is_cross_attention) and self.t_emb == "gaussian":
+            kw["temb_fn"] = self._temb_table_fn(z.device)
         if self.is_transformer:
             return hip_ops_tf.tf_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
         if self.is_cross_attention:

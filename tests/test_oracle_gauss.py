@@ -55,3 +55,31 @@ def test_midpoint(g, steps):
     z, mask, cond = (g.get(tag + k) for k in ("z", "mask", "cond"))
     vf = EpicVectorField(g.state, "flows.0.net", g.hp)
     torch.testing.assert_close(sample_midpoint(vf, z, cond, mask, ode_steps=steps), g.get(tag + "x_end"), atol=5e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("path", ["tf", "ca"])
+def test_gaussian_embedding_on_the_transformer_fields(path):
+    """tests/golden/{tf,ca}_gauss.npz: the oracle's transformer / cross-attention fields with the CNF's gaussian time-embedding network
+    reproduce the reference's recorded forward vectors, FM-OT loss and midpoint samples."""
+    from oracle.fm_ref import fm_ot_loss, midpoint_trajectory_end
+    from tests.conftest import load_ca_golden, load_tf_golden
+    if path == "tf":
+        from oracle.tf_ref import TransformerVectorField as VF
+        g = load_tf_golden("gauss")
+    else:
+        from oracle.ca_ref import CrossAttentionVectorField as VF
+        g = load_ca_golden("gauss")
+    vf = VF(g.state, "flows.0.", g.hp, freqs=g.freqs)
+    with torch.no_grad():
+        tag = "nfe_f32/"
+        x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))
+        v = vf(t[:, None].expand(-1, x.shape[1]), x, cond=cond, mask=mask)
+        torch.testing.assert_close(v, g.get(tag + "v_vec_t"), atol=1e-5, rtol=1e-4)
+        tag = "loss_f32/"
+        x, t, z, mask, cond = (g.get(tag + k) for k in ("x", "t", "z", "mask", "cond"))
+        loss, *_ = fm_ot_loss(vf, x, mask, cond, t, z, sigma=1e-4)
+        torch.testing.assert_close(loss, g.get(tag + "loss"), rtol=1e-5, atol=1e-6)
+        tag = "midpoint_10/"
+        z, mask, cond = (g.get(tag + k) for k in ("z", "mask", "cond"))
+        xe = midpoint_trajectory_end(lambda tt, xx: vf(tt, xx, mask=mask, cond=cond), z * mask, torch.linspace(1.0, 0.0, 10))
+        torch.testing.assert_close(xe, g.get(tag + "x_end"), atol=5e-5, rtol=1e-3)
