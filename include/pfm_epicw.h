@@ -37,6 +37,9 @@ extern "C" {
 #define PFM_EW_F_F16X3 1 /* desc.flags: as PFM_TF_F_F16X3 (pfm_tf.h) */
 #define PFM_EW_F_BF16 32 /* desc.flags: as PFM_TF_F_BF16 (pfm_tf.h): the particle Linears (forward and dX) on bf16 operands; the per-jet chain,
                           * the pooling and the dW GEMMs stay fp32 */
+#define PFM_EW_F_TEMB_GIVEN 64 /* desc.flags: as PFM_TF_F_TEMB_GIVEN (pfm_tf.h): the caller supplies the time EMBEDDING rows through `t`
+                                * (forward / loss forward: temb[n_jets][t_dim]; samplers: the transposed table [t_dim][evaluations]); the
+                                * loss backward then also accumulates d loss / d temb in its scratch (pfm_ew_backward_dtemb) */
 
 typedef struct { int64_t W, b, WT; } pfm_ew_lin; /* MFMA_AK weights, bias (-1: none), MFMA_AKT copy (-1: none) */
 
@@ -81,6 +84,11 @@ int64_t pfm_ew_backward_scratch_floats(const pfm_ew_desc *desc, int32_t n_jets);
 int pfm_ew_fm_loss_backward(const pfm_ew_desc *desc, const float *blob, const float *mask, const float *y,
                             const float *u, const float *v, const float *gscale, float *gblob, int32_t n_jets,
                             float *workspace, float *scratch, void *stream);
+
+/* PFM_EW_F_TEMB_GIVEN: dtemb[n_jets][t_dim] = d(loss)/d(temb) * gscale of the pfm_ew_fm_loss_backward call that has just filled `scratch`
+ * (same descriptor and n_jets): the time columns of every per-jet Linear (fc_l1 / fc_l2 / fc_l3 biases, fc_g1 / fc_g2 and, per layer,
+ * fc_global1 / fc_global2 / fc_local1 / fc_local2), summed in launch order. */
+int pfm_ew_backward_dtemb(const pfm_ew_desc *desc, const float *scratch, int32_t n_jets, float *dtemb, void *stream);
 
 /* loss_type="diffusion" on this path (DiffusionLoss, models/components/losses.py:207-290; see pfm_epic_diffusion_loss_* in pfm_hip.h):
  * noisy = rates[b][0] x + rates[b][1] z, the field predicts z; loss_sums[0] = sum_b jet_weight[b] sum_n,f criterion(v - z),

@@ -445,6 +445,8 @@ WIDE_CONFIGS = {
     # configs/experiment/lhco/x_jet.yaml:26-29 (y_jet.yaml the same): flow_matching.yaml at its default width with 279 particles and
     # 4 + 4 conditioning values -- hidden 128, but the set no longer fits the jet-resident kernel's LDS tile: row-matrix path
     "lhco128": (dict(BASE, num_particles=279, global_cond_dim=4, local_cond_dim=4), 2),
+    # t_emb="gaussian" (flow_matching_module.py:178-181, 213-221) on the row-matrix path: the trainable embedding network in front
+    "gauss": (dict(WIDE_BASE, num_particles=24, layers=2, t_emb="gaussian", local_cond_dim=12), 3),
 }
 
 
@@ -502,7 +504,8 @@ def gen_epic_wide(ref, name, hp, B, out_dir, seed=777):
     out[tag + "x"], out[tag + "t"], out[tag + "z"] = x.numpy(), t.numpy(), z.numpy()
     out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
     for k, p in cnf.named_parameters():
-        out[tag + "grad/flows.0." + k] = subsample(p.grad.detach().clone().numpy())
+        if p.grad is not None:  # (the random Fourier frequencies of t_emb="gaussian" are a frozen parameter, time_emb.py:18)
+            out[tag + "grad/flows.0." + k] = subsample(p.grad.detach().clone().numpy())
     for steps in (3, 10):
         mask = make_mask(B, N, "f32", gen)
         cond = torch.randn(B, Cg, generator=gen)
@@ -529,7 +532,7 @@ def gen_epic_wide(ref, name, hp, B, out_dir, seed=777):
     tag = "droid/"
     out[tag + "x"], out[tag + "t"], out[tag + "z"] = x.numpy(), t.numpy(), z.numpy()
     out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
-    for k, p in list(cnf.named_parameters())[:6]:
+    for k, p in [kp for kp in cnf.named_parameters() if kp[1].grad is not None][:6]:
         out[tag + "grad/flows.0." + k] = subsample(p.grad.detach().clone().numpy())
     path = os.path.join(out_dir, f"epicw_{name}.npz")
     np.savez(path, **out)
@@ -841,7 +844,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
     ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,diffusion_rows,chain,norm}; default all")
-    ap.add_argument("--names", default="", help="with --only epic / tf / ca: comma list of configuration names (default all)")
+    ap.add_argument("--names", default="", help="with --only epic / wide / tf / ca: comma list of configuration names (default all)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
@@ -863,7 +866,7 @@ def main():
         if ap2 is None or "diffusion_rows" in ap2:
             gen_diffusion_rows(ref, prefix, args.out)
     for name, (hp, B) in WIDE_CONFIGS.items():
-        if ap2 is None or "wide" in ap2:
+        if (ap2 is None or "wide" in ap2) and (names is None or name in names):
             gen_epic_wide(ref, name, hp, B, args.out)
     for name, (hp, B, store_all) in TF_CONFIGS.items():
         if (ap2 is None or "tf" in ap2) and (names is None or name in names):

@@ -19,12 +19,14 @@ using namespace pfm::tf;
 // P[jet][0 .. 256 + Hp) = [temb | cond | 0 ; 0 (g) ; 0 (g1)]
 __global__ __launch_bounds__(256) void ew_prep_kernel(const float* __restrict__ blob, int64_t freqs, const float* __restrict__ t,
                                                       int t_stride, const float* __restrict__ cond, float* __restrict__ P, int T,
-                                                      int C, int ldp, int64_t pstride, int sincos) {
+                                                      int C, int ldp, int64_t pstride, int sincos, int temb_k) {
     const int jet = blockIdx.x;
     float* row = P + (int64_t)blockIdx.y * pstride + (int64_t)jet * ldp;  // blockIdx.y: stage copy (train layout)
     for (int c = threadIdx.x; c < ldp; c += 256) {
         float v = 0.f;
-        if (c < T) {
+        if (c < T && temb_k) {  // PFM_EW_F_TEMB_GIVEN: `t` holds the embedding, element c of the jet's row at c * temb_k
+            v = t[(int64_t)jet * t_stride + (int64_t)c * temb_k];
+        } else if (c < T) {
             // time_emb.py:90-96, exact fp32 op order ((t + min) * f) * pi / (max + min)
             const float tj = t[(int64_t)jet * t_stride], f = blob[freqs + c];
             if (sincos) {  // flow_matching_module.py:208-211 (table = [f ; f], f = 2^k pi)
@@ -417,6 +419,7 @@ struct Plan {
     const int *rowsrc = nullptr, *rowjet = nullptr, *off = nullptr, *m_dev = nullptr;
     float* part = nullptr;  // split-K partial sums of the per-jet GEMMs
     int64_t part_floats = 0;
+    int temb_k = 0;  // PFM_EW_F_TEMB_GIVEN: floats between the elements of a time-embedding row in `t` (0: `t` holds times)
 };
 
 // out[Mrows][ldo] = epi(A (+A2) W^T + b / jb)
@@ -459,8 +462,9 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
     auto Xst = [&](int s) { return ws + w.X + w.xstride * s; };
     int rc;
     const int stages = w.pstride ? d.layers + 1 : 1;
-    hipLaunchKernelGGL(ew_prep_kernel, dim3(B, stages), dim3(256), 0, p.s, p.blob, d.freqs, t, t_stride, cond, Pst(0), d.t_dim,
-                       d.cond_global, ldp, w.pstride, (d.flags & PFM_EW_F_TEMB_SINCOS) ? 1 : 0);
+    hipLaunchKernelGGL(ew_prep_kernel, dim3(B, stages), dim3(256), 0, p.s, p.blob, d.freqs, t,
+                       p.temb_k ? (t_stride ? d.t_dim : 0) : t_stride, cond, Pst(0), d.t_dim, d.cond_global, ldp, w.pstride,
+                       (d.flags & PFM_EW_F_TEMB_SINCOS) ? 1 : 0, p.temb_k);
     PFM_TRY(check_hip(hipGetLastError(), "ew_prep_kernel launch"));
     PFM_TRY(linear(p, B, Pst(0), ldp, 256, nullptr, 0, 256, d.sjb, 2 * Hp + 128, nullptr, 0, 1, nullptr, 0, SJB, (int)sjbs, 0));
     // stem: fc_l1 (F columns on the VALU), fc_l2 (residual inside the activation, epic.py:327-328)
@@ -600,8 +604,13 @@ __global__ __launch_bounds__(256) void ew_pool_bwd_kernel(const float* __restric
     }
 }
 
+__global__ __launch_bounds__(256) void ew_temb_acc_kernel(const float* __restrict__ dP, int ld, float* __restrict__ acc, int64_t n, int T) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) acc[i] += dP[(i / T) * ld + i % T];
+}
+
 struct Bs {
-    int64_t dX, dZ, dT, dpre, DJB, DSJB, dPj, dP2, dP1, dG, dZg2, dZg1, zeros, dwpart, total;
+    int64_t dX, dZ, dT, dpre, DJB, DSJB, dPj, dP2, dP1, dG, dZg2, dZg1, zeros, dwpart, dtemb, total;
 };
 
 Bs make_bs(const pfm_ew_desc& d, int n_jets) {
@@ -614,6 +623,7 @@ Bs make_bs(const pfm_ew_desc& d, int n_jets) {
     b.dP2 = take(B * (256 + Hp)); b.dP1 = take(B * (256 + 2 * Hp)); b.dG = take(B * 128);
     b.dZg2 = take(B * 128); b.dZg1 = take(B * Hp); b.zeros = take(B * Hp);
     b.dwpart = take((int64_t)DW_MAX_PARTS * 16384);
+    b.dtemb = take((d.flags & PFM_EW_F_TEMB_GIVEN) ? B * d.t_dim : 0);
     b.total = o;
     return b;
 }
@@ -657,6 +667,13 @@ struct Bwd {
         t.W = lin.WT;
         t.b = -1;
         return linear(p, Mrows, Z, ldz, NO, nullptr, 0, NO, t, K, nullptr, 0, 1, R, ldr, out, ldo, Y ? 3 : 0, Y, ldy);
+    }
+    // PFM_EW_F_TEMB_GIVEN: dtemb[jet][:T] += dP[jet][:T] (the time columns lead every P-row Linear's input)
+    int temb_acc(const float* dP, int ld) const {
+        if (!(p.d->flags & PFM_EW_F_TEMB_GIVEN)) return 0;
+        const int64_t n = (int64_t)p.n_jets * p.d->t_dim;
+        hipLaunchKernelGGL(ew_temb_acc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, dP, ld, sc + b.dtemb, n, p.d->t_dim);
+        return check_hip(hipGetLastError(), "ew_temb_acc_kernel launch");
     }
     int actbwd(const float* a, int lda, const float* bb, int ldb, const float* y, int ldy, float* out, int ldo, int64_t rows, int cols) const {
         const int64_t n = rows * cols;
@@ -712,16 +729,19 @@ int run_backward(const Bwd& W, const float* mask, const float* y, const float* u
         PFM_TRY(W.dw(B, DJB, 2 * Hp, 2 * Hp, Pout, ldp, 256, nullptr, 0, 256, L.jb.W));
         PFM_TRY(W.colsum(DJB, 2 * Hp, 2 * Hp, B, 16, nullptr, 0, nullptr, 0, L.jb.b));
         PFM_TRY(W.dx(B, DJB, 2 * Hp, 2 * Hp, L.jb, 256, nullptr, 0, nullptr, 0, dPj, 256));
+        PFM_TRY(W.temb_acc(dPj, 256));
         // fc_global2: g_new = lrelu(W [P | g1] + b + g_old)
         PFM_TRY(W.actbwd(dG, 128, dPj + 128, 256, Pout + 128, ldp, dZg2, 128, B, 128));
         PFM_TRY(W.dw(B, dZg2, 128, 128, Pout, ldp, ldp, nullptr, 0, ldp, L.g2.W));
         PFM_TRY(W.colsum(dZg2, 128, 128, B, 16, nullptr, 0, nullptr, 0, L.g2.b));
         PFM_TRY(W.dx(B, dZg2, 128, 128, L.g2, ldp, nullptr, 0, nullptr, 0, dP2, ldp));
+        PFM_TRY(W.temb_acc(dP2, ldp));
         // fc_global1: g1 = lrelu(W [P256 | Q] + b)
         PFM_TRY(W.actbwd(dP2 + 256, ldp, nullptr, 0, Pout + 256, ldp, dZg1, Hp, B, Hp));
         PFM_TRY(W.dw(B, dZg1, Hp, Hp, Pin, ldp, 256, Qst(l), 2 * Hp, 256 + 2 * Hp, L.g1.W));
         PFM_TRY(W.colsum(dZg1, Hp, Hp, B, 16, nullptr, 0, nullptr, 0, L.g1.b));
         PFM_TRY(W.dx(B, dZg1, Hp, Hp, L.g1, 256 + 2 * Hp, nullptr, 0, nullptr, 0, dP1, 256 + 2 * Hp));
+        PFM_TRY(W.temb_acc(dP1, 256 + 2 * Hp));
         PFM_TRY(W.actbwd(dZg2, 128, dP1 + 128, 256 + 2 * Hp, nullptr, 0, dG, 128, B, 128));                   // d g_old
         hipLaunchKernelGGL(ew_pool_bwd_kernel, dim3(B), dim3(256), 0, p.s, (const float*)(dP1 + 256), 256 + 2 * Hp, mask, dX, N, Hp,
                            d.sum_scale);
@@ -734,10 +754,12 @@ int run_backward(const Bwd& W, const float* mask, const float* y, const float* u
         PFM_TRY(W.dw(B, dZg2, 128, 128, P0, ldp, ldp, nullptr, 0, ldp, d.sg2.W));
         PFM_TRY(W.colsum(dZg2, 128, 128, B, 16, nullptr, 0, nullptr, 0, d.sg2.b));
         PFM_TRY(W.dx(B, dZg2, 128, 128, d.sg2, ldp, nullptr, 0, nullptr, 0, dP2, ldp));
+        PFM_TRY(W.temb_acc(dP2, ldp));
         PFM_TRY(W.actbwd(dP2 + 256, ldp, nullptr, 0, P0 + 256, ldp, dZg1, Hp, B, Hp));
         PFM_TRY(W.dw(B, dZg1, Hp, Hp, P0, ldp, 256, Qst(0), 2 * Hp, 256 + 2 * Hp, d.sg1.W));
         PFM_TRY(W.colsum(dZg1, Hp, Hp, B, 16, nullptr, 0, nullptr, 0, d.sg1.b));
         PFM_TRY(W.dx(B, dZg1, Hp, Hp, d.sg1, 256 + 2 * Hp, nullptr, 0, nullptr, 0, dP1, 256 + 2 * Hp));
+        PFM_TRY(W.temb_acc(dP1, 256 + 2 * Hp));
         hipLaunchKernelGGL(ew_pool_bwd_kernel, dim3(B), dim3(256), 0, p.s, (const float*)(dP1 + 256), 256 + 2 * Hp, mask, dX, N, Hp,
                            d.sum_scale);
         PFM_TRY(check_hip(hipGetLastError(), "ew_pool_bwd_kernel launch"));
@@ -759,6 +781,10 @@ int run_backward(const Bwd& W, const float* mask, const float* y, const float* u
     // static jet-bias GEMM (the 112 padding columns of the fc_l3 block of DSJB were never written: clear them first)
     PFM_TRY(W.dw(B, DSJB, (int)sjbs, 2 * Hp + 128, Pst(0), ldp, 256, nullptr, 0, 256, d.sjb.W));
     PFM_TRY(W.colsum(DSJB, (int)sjbs, 2 * Hp + 128, B, 16, nullptr, 0, nullptr, 0, d.sjb.b));
+    if (d.flags & PFM_EW_F_TEMB_GIVEN) {  // the time columns of fc_l1 / fc_l2 / fc_l3 (nobody else needs d P of the static jet biases)
+        PFM_TRY(W.dx(B, DSJB, (int)sjbs, 2 * Hp + 128, d.sjb, 256, nullptr, 0, nullptr, 0, dPj, 256));
+        PFM_TRY(W.temb_acc(dPj, 256));
+    }
     return 0;
 }
 
@@ -769,6 +795,7 @@ int make_plan(Plan& p, const pfm_ew_desc* d, const float* blob, float* ws, int n
     p.w = make_ws(*d, n_jets, train);
     p.part = ws + p.w.part;
     p.part_floats = p.w.part_floats;
+    p.temb_k = (d->flags & PFM_EW_F_TEMB_GIVEN) ? 1 : 0;  // rows [jet][T]; the samplers switch to their [T][evaluations] table
     return 0;
 }
 
@@ -839,6 +866,7 @@ int pfm_ew_sample_midpoint(const pfm_ew_desc* d, const float* blob, const float*
             const int j0 = i ? n_a : 0, nj = parts == 1 ? n_jets : (i ? n_jets - n_a : n_a);
             float* ws = workspace + (i ? ew::make_ws(*d, n_a, false).total : 0);
             if ((rc = ew::make_plan(p[i], d, blob, ws, nj, false, ss ? (void*)(i ? ss->s2 : ss->s) : stream))) return rc;
+            if (p[i].temb_k) p[i].temb_k = 2 * n_steps;  // t_eval = the embedding table [T][2 n_steps]: evaluation e starts at t_eval + e
             r0[i] = (int64_t)j0 * d->n_points;
             n[i] = (int64_t)p[i].M * d->features;
             xs[i] = state + 2 * r0[i] * d->features;
@@ -878,6 +906,8 @@ static int ew_sample_rk(const pfm_ew_desc* d, const float* blob, const pfm_rk_ta
     if (!blob || !t_eval || !dt || !z || !x_out || !state || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (n_steps < 0) return set_err(PFM_E_BADARG, "n_steps < 0");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
+    if (p.temb_k && rhs) return set_err(PFM_E_BADARG, "the diffusion right-hand side is indexed by the time grid: no PFM_EW_F_TEMB_GIVEN");
+    if (p.temb_k) p.temb_k = n_steps * tab->stages;  // t_eval = the embedding table [T][n_steps * stages]
     const int64_t n = (int64_t)p.M * d->features;
     hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, state, n,
                        d->features);
@@ -974,6 +1004,9 @@ static int ew_loss_backward(const pfm_ew_desc* d, const float* blob, const float
     if ((rc = check_hip(hipMemsetAsync(scratch + W.b.DSJB, 0, (size_t)n_jets * (2 * d->hidden_pad + 128) * sizeof(float),
                                        (hipStream_t)stream), "memset DSJB")))
         return rc;
+    if ((d->flags & PFM_EW_F_TEMB_GIVEN) &&
+        (rc = check_hip(hipMemsetAsync(scratch + W.b.dtemb, 0, (size_t)n_jets * d->t_dim * sizeof(float), (hipStream_t)stream), "memset dtemb")))
+        return rc;
     return ew::run_backward(W, mask, y, u, v, gscale, crit, jet_w);
 }
 
@@ -981,6 +1014,16 @@ int pfm_ew_fm_loss_backward(const pfm_ew_desc* d, const float* blob, const float
                             const float* v, const float* gscale, float* gblob, int32_t n_jets, float* workspace,
                             float* scratch, void* stream) {
     return ew_loss_backward(d, blob, mask, y, u, v, gscale, gblob, n_jets, workspace, scratch, stream, 0, nullptr);
+}
+
+int pfm_ew_backward_dtemb(const pfm_ew_desc* d, const float* scratch, int32_t n_jets, float* dtemb, void* stream) {
+    int rc = ew::validate(d);
+    if (rc) return rc;
+    if (!(d->flags & PFM_EW_F_TEMB_GIVEN)) return set_err(PFM_E_BADARG, "pfm_ew_backward_dtemb: the descriptor has no PFM_EW_F_TEMB_GIVEN");
+    if (n_jets <= 0) return 0;
+    if (!scratch || !dtemb) return set_err(PFM_E_BADARG, "NULL device pointer");
+    return check_hip(hipMemcpyAsync(dtemb, scratch + ew::make_bs(*d, n_jets).dtemb, (size_t)n_jets * d->t_dim * sizeof(float),
+                                    hipMemcpyDeviceToDevice, (hipStream_t)stream), "copy dtemb");
 }
 
 int pfm_ew_diffusion_loss_backward(const pfm_ew_desc* d, const float* blob, int32_t criterion, const float* jet_weight,

@@ -46,7 +46,7 @@ class TfFieldFn(torch.autograd.Function):
         _, saved = fwd(layout, blob, x, t.detach(), torch.zeros_like(x), cond, mask, 0.0, "droid", None)
         ctx.layout, ctx.saved, ctx.blob, ctx.ops, ctx.t, ctx.cond = layout, saved, blob, ops, t.detach(), cond
         ctx.mask = None if mask is None else mask.reshape(x.shape[0], -1).to(torch.float32).contiguous()
-        ctx.temb_given = getattr(layout.cfg, "t_emb", "cosine") == "gaussian"
+        ctx.temb_given = hip_ops_tf.temb_given(layout)
         return saved[2].clone()
 
     @staticmethod
@@ -99,14 +99,17 @@ def mdma_field(layout, flat_params, t, x, mask, freqs: Optional[torch.Tensor] = 
 
 
 class EpicWideFieldFn(torch.autograd.Function):
-    """Wide (row-matrix) EPiC field over the layout's source vector (autograd continues through the weight-norm reparametrisation)."""
+    """Wide (row-matrix) EPiC field over the layout's source vector (autograd continues through the weight-norm reparametrisation).
+    ``t``: the times (B,), or -- a layout with t_emb="gaussian" (PFM_EW_F_TEMB_GIVEN) -- the time EMBEDDING rows (B, T), then a
+    differentiable input (pfm_ew_backward_dtemb)."""
 
     @staticmethod
     def forward(ctx, src, layout, x, t, cond, mask):
         from .fm_loss_wide import pack_blob_from_source
         blob = pack_blob_from_source(layout, src)
-        _, saved = hip_ops_wide.ew_fm_loss_forward(layout, blob, x, t, torch.zeros_like(x), cond, mask, 0.0, "droid", None)
+        _, saved = hip_ops_wide.ew_fm_loss_forward(layout, blob, x, t.detach(), torch.zeros_like(x), cond, mask, 0.0, "droid", None)
         ctx.layout, ctx.saved, ctx.blob, ctx.n_source = layout, saved, blob, src.numel()
+        ctx.temb_shape = tuple(t.shape) if hip_ops_tf.temb_given(layout) else None
         return saved[2].clone()
 
     @staticmethod
@@ -117,7 +120,10 @@ class EpicWideFieldFn(torch.autograd.Function):
         gpos = _maps(lay, gblob.device)[1]
         d_src = torch.zeros(ctx.n_source, device=gblob.device, dtype=torch.float32)
         d_src[: gpos.numel()] = gblob[gpos]
-        return (d_src,) + (None,) * 5
+        d_t = None
+        if ctx.temb_shape is not None and ctx.needs_input_grad[3]:
+            d_t = hip_ops_wide.ew_backward_dtemb(lay, G.shape[0], G.device).reshape(ctx.temb_shape)
+        return (d_src, None, None, d_t, None, None)
 
 
 def epic_wide_field(layout, src, t, x, cond=None, mask=None):

@@ -10,30 +10,8 @@ import torch
 
 from . import _lib
 from .hip_ops import _dev_f32, _ptr, _stream_ptr, midpoint_grid, rk_grid, rk_tableau
-from .hip_ops_tf import _KINDS, _prep
+from .hip_ops_tf import _KINDS, _prep, _temb_table, _time_arg, temb_given
 from .layout_ca import CaLayout
-
-
-def _time_arg(layout, t, B, dev, per_jet: bool = False):
-    """The `t` argument of the entry points: times -- (B,) one per jet, or 0-dim / (1,) shared -- or, for a layout with
-    t_emb="gaussian" (PFM_*_F_TEMB_GIVEN), the time EMBEDDING rows (B, T) or one shared row (T,) / (1, T).  Returns (tensor, t_stride)."""
-    T = layout.cfg.t_dim
-    if getattr(layout.cfg, "t_emb", "cosine") == "gaussian":
-        t = _dev_f32("temb", t.reshape(-1, T), dev)
-        if t.shape[0] not in (1, B) or (per_jet and t.shape[0] != B):
-            raise ValueError(f"the time embedding has {t.shape[0]} rows, expected {'' if per_jet else '1 or '}{B}")
-        return t, 1 if (t.shape[0] == B and (B > 1 or per_jet)) else 0
-    t = _dev_f32("t", t.reshape(-1), dev)
-    if t.numel() not in (1, B) or (per_jet and t.numel() != B):
-        raise ValueError(f"t has {t.numel()} elements, expected {'' if per_jet else '1 or '}{B}")
-    return t, 1 if (t.numel() == B and (B > 1 or per_jet)) else 0
-
-
-def _temb_table(temb_fn, ts: torch.Tensor, dev) -> torch.Tensor:
-    """The samplers' embedding table for a PFM_*_F_TEMB_GIVEN layout: temb_fn(ts) -> (n_evaluations, T), handed over TRANSPOSED
-    ([T][n_evaluations]: evaluation e starts at table + e, like the time grid it replaces)."""
-    tab = temb_fn(ts.to(dev))
-    return tab.to(torch.float32).t().contiguous()
 
 
 def ca_backward_dtemb(layout, blob, B: int, dev) -> torch.Tensor:
@@ -94,7 +72,7 @@ def ca_sample_midpoint(layout: CaLayout, blob, z, cond=None, mask=None, ode_step
     if ode_steps < 2:
         raise ValueError("ode_steps must be >= 2")
     ts, dts = midpoint_grid(ode_steps, dev)
-    if getattr(layout.cfg, "t_emb", "cosine") == "gaussian":  # the table of embeddings replaces the time grid (PFM_*_F_TEMB_GIVEN)
+    if temb_given(layout):  # the table of embeddings replaces the time grid (PFM_*_F_TEMB_GIVEN)
         ts = _temb_table(temb_fn, ts, dev)
     out = torch.empty_like(z)
     state = torch.empty(2 * z.numel(), device=dev, dtype=torch.float32)
@@ -117,7 +95,7 @@ def ca_sample_rk(layout: CaLayout, blob, z, cond=None, mask=None, ode_steps: int
     tab = rk_tableau(solver)
     ts, dts = rk_grid(ode_steps, solver, t0, t1)
     ts, dts = ts.to(dev), dts.to(dev)
-    if getattr(layout.cfg, "t_emb", "cosine") == "gaussian":
+    if temb_given(layout):
         ts = _temb_table(temb_fn, ts, dev)
     out = torch.empty_like(z)
     state = torch.empty((2 + tab.stages) * z.numel(), device=dev, dtype=torch.float32)

@@ -34,11 +34,16 @@ def _prep(layout: TfLayout, blob, x, cond, mask):
     return dev, B, blob, x, cond, mask
 
 
+def temb_given(layout) -> bool:
+    """PFM_*_F_TEMB_GIVEN (64 in pfm_tf.h / pfm_ca.h / pfm_epicw.h): the entry points take the time embedding through `t`."""
+    return bool(layout.desc.flags & 64)
+
+
 def _time_arg(layout, t, B, dev, per_jet: bool = False):
     """The `t` argument of the entry points: times -- (B,) one per jet, or 0-dim / (1,) shared -- or, for a layout with
     t_emb="gaussian" (PFM_*_F_TEMB_GIVEN), the time EMBEDDING rows (B, T) or one shared row (T,) / (1, T).  Returns (tensor, t_stride)."""
     T = layout.cfg.t_dim
-    if getattr(layout.cfg, "t_emb", "cosine") == "gaussian":
+    if temb_given(layout):
         t = _dev_f32("temb", t.reshape(-1, T), dev)
         if t.shape[0] not in (1, B) or (per_jet and t.shape[0] != B):
             raise ValueError(f"the time embedding has {t.shape[0]} rows, expected {'' if per_jet else '1 or '}{B}")
@@ -114,7 +119,7 @@ def tf_sample_midpoint(layout: TfLayout, blob, z, cond=None, mask=None, ode_step
     if ode_steps < 2:
         raise ValueError("ode_steps must be >= 2")
     ts, dts = midpoint_grid(ode_steps, dev)
-    if getattr(layout.cfg, "t_emb", "cosine") == "gaussian":  # the table of embeddings replaces the time grid (PFM_*_F_TEMB_GIVEN)
+    if temb_given(layout):  # the table of embeddings replaces the time grid (PFM_*_F_TEMB_GIVEN)
         ts = _temb_table(temb_fn, ts, dev)
     out = torch.empty_like(z)
     state = torch.empty(2 * z.numel(), device=dev, dtype=torch.float32)
@@ -137,7 +142,7 @@ def tf_sample_rk(layout: TfLayout, blob, z, cond=None, mask=None, ode_steps: int
     tab = rk_tableau(solver)
     ts, dts = rk_grid(ode_steps, solver, t0, t1)
     ts, dts = ts.to(dev), dts.to(dev)
-    if getattr(layout.cfg, "t_emb", "cosine") == "gaussian":
+    if temb_given(layout):
         ts = _temb_table(temb_fn, ts, dev)
     out = torch.empty_like(z)
     state = torch.empty((2 + tab.stages) * z.numel(), device=dev, dtype=torch.float32)

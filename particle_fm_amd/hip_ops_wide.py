@@ -7,6 +7,7 @@ import torch
 
 from . import _lib
 from .hip_ops import _dev_f32, _prep_common, _ptr, _stream_ptr, midpoint_grid, rk_grid, rk_tableau
+from .hip_ops_tf import _temb_table, _time_arg, temb_given
 from .layout_wide import EpicWideLayout
 
 
@@ -35,25 +36,37 @@ def workspace(layout: EpicWideLayout, n_jets: int, device, train: bool = False) 
 
 
 def ew_forward(layout: EpicWideLayout, blob, t, x, cond=None, mask=None) -> torch.Tensor:
-    """v = EPiC(t, x, cond, mask).  t: (B,) one time per jet, or a single element for one shared time."""
+    """v = EPiC(t, x, cond, mask).  t: (B,) one time per jet, or a single element for one shared time; a layout with t_emb="gaussian"
+    (PFM_EW_F_TEMB_GIVEN) takes the time EMBEDDING rows (B, T) / one shared row instead."""
     lib = _lib.load()
     dev, B, blob, x, cond, mask = _prep_common(layout, blob, x, cond, mask)
-    t = _dev_f32("t", t.reshape(-1), dev)
-    if t.numel() not in (1, B):
-        raise ValueError(f"t has {t.numel()} elements, expected 1 or {B}")
+    t, t_per_jet = _time_arg(layout, t, B, dev)
     v = torch.empty_like(x)
-    rc = lib.pfm_ew_forward(ctypes.byref(layout.desc), _ptr(blob), _ptr(t), 1 if (t.numel() == B and B > 1) else 0, _ptr(x),
+    rc = lib.pfm_ew_forward(ctypes.byref(layout.desc), _ptr(blob), _ptr(t), t_per_jet, _ptr(x),
                             _ptr(cond), _ptr(mask), _ptr(v), B, _ptr(workspace(layout, B, dev)), _stream_ptr(dev))
     _lib.check(rc, "pfm_ew_forward")
     return v
 
 
-def ew_sample_midpoint(layout: EpicWideLayout, blob, z, cond=None, mask=None, ode_steps: int = 100, premask: bool = True):
+def ew_backward_dtemb(layout, B: int, dev) -> torch.Tensor:
+    """d loss / d temb (B, T) of the loss backward that has just run for this layout and batch size (pfm_ew_backward_dtemb reads that
+    backward's scratch: call it right behind ew_fm_loss_backward, same stream)."""
+    lib = _lib.load()
+    scratch = layout.__dict__["_bscratch"][(B, str(dev))]
+    out = torch.empty(B, layout.cfg.t_dim, device=dev, dtype=torch.float32)
+    rc = lib.pfm_ew_backward_dtemb(ctypes.byref(layout.desc), _ptr(scratch), B, _ptr(out), _stream_ptr(dev))
+    _lib.check(rc, "pfm_ew_backward_dtemb")
+    return out
+
+
+def ew_sample_midpoint(layout: EpicWideLayout, blob, z, cond=None, mask=None, ode_steps: int = 100, premask: bool = True, temb_fn=None):
     lib = _lib.load()
     dev, B, blob, z, cond, mask = _prep_common(layout, blob, z, cond, mask)
     if ode_steps < 2:
         raise ValueError("ode_steps must be >= 2")
     ts, dts = midpoint_grid(ode_steps, dev)
+    if temb_given(layout):  # the table of embeddings replaces the time grid (PFM_EW_F_TEMB_GIVEN)
+        ts = _temb_table(temb_fn, ts, dev)
     out = torch.empty_like(z)
     state = torch.empty(2 * z.numel(), device=dev, dtype=torch.float32)
     rc = lib.pfm_ew_sample_midpoint(ctypes.byref(layout.desc), _ptr(blob), _ptr(ts), _ptr(dts), ode_steps - 1, _ptr(z),
@@ -64,7 +77,7 @@ def ew_sample_midpoint(layout: EpicWideLayout, blob, z, cond=None, mask=None, od
 
 
 def ew_sample_rk(layout: EpicWideLayout, blob, z, cond=None, mask=None, ode_steps: int = 100, solver: str = "rk4", diff_config=None,
-                 premask: bool = True, t0: float = 1.0, t1: float = 0.0) -> torch.Tensor:
+                 premask: bool = True, t0: float = 1.0, t1: float = 0.0, temb_fn=None) -> torch.Tensor:
     """x(t1) from x(t0) = z (*mask) with the fixed-step explicit Runge-Kutta scheme ``solver`` ("euler", "midpoint", "rk4" =
     torchdyn's 3/8 rule) over linspace(t0, t1, ode_steps); all launches queued on the current stream."""
     lib = _lib.load()
@@ -76,6 +89,10 @@ def ew_sample_rk(layout: EpicWideLayout, blob, z, cond=None, mask=None, ode_step
     ts, dts = ts.to(dev), dts.to(dev)
     out = torch.empty_like(z)
     state = torch.empty((2 + tab.stages) * z.numel(), device=dev, dtype=torch.float32)
+    if temb_given(layout):
+        if diff_config is not None:
+            raise NotImplementedError("loss_type='diffusion' with t_emb='gaussian' has no HIP sampler on the row-matrix EPiC path")
+        ts = _temb_table(temb_fn, ts, dev)
     if diff_config is not None:  # loss_type="diffusion": the probability-flow ODE of a noise-predicting network
         from .hip_ops import diffusion_schedule
         _, nr, beta = diffusion_schedule(ts, **diff_config)
@@ -102,7 +119,10 @@ def ew_fm_loss_forward(layout: EpicWideLayout, blob, x, t, a, cond=None, mask=No
     dev, B, blob, x, cond, mask = _prep_common(layout, blob, x, cond, mask)
     if kind not in _KINDS:
         raise NotImplementedError(f"loss kind {kind} has no HIP kernel")
-    t = _dev_f32("t", t, dev, (B,))
+    if temb_given(layout):  # (the interpolation must not depend on t: fm_field.py's forward-with-saved-activations, kind "droid", a = 0)
+        t = _dev_f32("temb", t, dev, (B, layout.cfg.t_dim))
+    else:
+        t = _dev_f32("t", t, dev, (B,))
     a = _dev_f32("a", a, dev, tuple(x.shape))
     if kind == "CFM":
         if eps is None:

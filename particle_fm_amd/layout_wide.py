@@ -20,6 +20,7 @@ PFM_EW_ABI_VERSION = 1
 PFM_EW_MAX_LAYERS = 24
 PFM_EW_F_F16X3 = 1
 PFM_EW_F_TEMB_SINCOS = 2
+PFM_EW_F_TEMB_GIVEN = 64
 
 
 class EwLin(ctypes.Structure):
@@ -158,7 +159,8 @@ class EpicWideLayout(EpicLayout):
         d = EwDesc()
         d.abi_version = PFM_EW_ABI_VERSION
         d.n_points, d.features, d.hidden, d.hidden_pad, d.latent, d.layers = cfg.num_particles, F, H, Hp, L, cfg.layers
-        d.t_dim, d.cond_global, d.cond_local, d.flags = T, Cg, Cl, self.flags | (PFM_EW_F_TEMB_SINCOS if cfg.t_emb == "sincos" else 0)
+        d.t_dim, d.cond_global, d.cond_local, d.flags = (
+            T, Cg, Cl, self.flags | (PFM_EW_F_TEMB_SINCOS if cfg.t_emb == "sincos" else 0) | (PFM_EW_F_TEMB_GIVEN if cfg.t_emb == "gaussian" else 0))
         d.sum_scale, d.neg_slope = cfg.sum_scale, cfg.neg_slope
         d.freqs = self._put(self.freq_off + np.arange(T), primary=False)
         ar = np.arange

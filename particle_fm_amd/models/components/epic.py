@@ -154,11 +154,13 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
                           global_cond_dim=self.global_cond_dim, local_cond_dim=self.local_cond_dim,
                           sum_scale=self.sum_scale, t_emb=self.t_emb, add_time_to_input=self.add_time_to_input)
 
-    def layout(self, num_points: Optional[int] = None) -> EpicLayout:
+    def layout(self, num_points: Optional[int] = None, temb_given: bool = False) -> EpicLayout:
+        """``temb_given`` (row-matrix path): the descriptor with PFM_EW_F_TEMB_GIVEN -- same blob, the entry points take the time
+        EMBEDDING through `t` (a t_emb="gaussian" configuration always does; the jet-resident path has pfm_epic_*_temb entry points)."""
         n = num_points or self.num_points
         wide = self.is_wide(n)
-        if wide:  # row-matrix GEMM path: PFM_EW_F_F16X3 / PFM_EW_F_BF16
-            mode = {"fp32": 0, "f16x3": 1, "bf16": 32}[self.mfma_dtype]
+        if wide:  # row-matrix GEMM path: PFM_EW_F_F16X3 / PFM_EW_F_BF16 / PFM_EW_F_TEMB_GIVEN
+            mode = {"fp32": 0, "f16x3": 1, "bf16": 32}[self.mfma_dtype] | (64 if temb_given else 0)
         else:
             mode = {"fp32": 0, "bf16": 2, "f16x3": 4}[self.mfma_dtype] | (16 if self.pack_jets else 0)
         lay = self._layouts.get((n, mode))
@@ -214,10 +216,8 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
     def forward(self, t_in: torch.Tensor = None, x_local: torch.Tensor = None,
                 global_cond_in: torch.Tensor = None, mask: torch.Tensor = None) -> torch.Tensor:
         self._check_inputs(t_in, x_local, global_cond_in)
-        if self.is_wide(x_local.shape[1]):
-            raise NotImplementedError("EPiC_encoder.forward(t_emb, ...) on the row-matrix path (hid_d != 128 or a set beyond the LDS "
-                                      "tile): that path embeds the time in-kernel; call vector_field(t, x, cond, mask) (CNF.forward does)")
-        lay = self.layout(x_local.shape[1])
+        wide = self.is_wide(x_local.shape[1])
+        lay = self.layout(x_local.shape[1], temb_given=wide)
         B = x_local.shape[0]
         if self.add_time_to_input and x_local.shape[-1] == self.input_dim:
             # the reference's caller passes cat(time embedding, x) (flow_matching_module.py:199-200); the kernels take the particle
@@ -230,6 +230,8 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
             temb = torch.zeros(B, lay.cfg.t_dim, device=x_local.device)
         else:
             temb = t_in[:, 0, :] if t_in.dim() == 3 else t_in  # epic.py:342: one embedding per jet
+        if wide:  # the row-matrix path takes the embedding rows through its `t` argument
+            return hip_ops_wide.ew_forward(lay, self.packed_weights(x_local.shape[1]), temb.expand(B, -1), x_local, global_cond_in, mask)
         return hip_ops.epic_forward_temb(lay, self.packed_weights(x_local.shape[1]), temb, x_local, global_cond_in, mask)
 
     def vector_field(self, t: torch.Tensor, x_local: torch.Tensor, global_cond_in: torch.Tensor = None,

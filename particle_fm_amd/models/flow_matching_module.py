@@ -146,6 +146,7 @@ class CNF(nn.Module):
         self.is_transformer = model == "droid_fulltransformer"
         self.is_cross_attention = model == "droid_fullcrossattention"
         self.is_mdma = model == "mdma"
+        self.is_epic = model == "epic"
         self.register_buffer("frequencies", 2 ** torch.arange(frequencies) * torch.pi)  # :172
         self.activation = activation
         self.t_emb = t_emb
@@ -160,8 +161,8 @@ class CNF(nn.Module):
             # flow_matching_module.py:178-181: random Fourier features -> Linear -> activation -> Linear(2 frequencies), trainable.
             # O(B * hidden) per call: host-side torch ops on the device; its output (B, T) goes to the kernels as the time
             # embedding (pfm_epic_*_temb) and the loss backward returns d loss / d temb, so the four tensors train exactly.
-            # (the transformer / cross-attention kernels take the embedding through their `t` argument, PFM_*_F_TEMB_GIVEN, and
-            # pfm_*_backward_dtemb returns its gradient; MDMA and the row-matrix EPiC path embed in-kernel only)
+            # (the transformer / cross-attention / row-matrix EPiC kernels take the embedding through their `t` argument,
+            # PFM_*_F_TEMB_GIVEN, and pfm_*_backward_dtemb returns its gradient; MDMA embeds in-kernel only)
             if model not in ("epic", "droid_fulltransformer", "droid_fullcrossattention"):
                 raise NotImplementedError("t_emb='gaussian' has a HIP path for model='epic', 'droid_fulltransformer' and "
                                           "'droid_fullcrossattention'")
@@ -189,19 +190,17 @@ class CNF(nn.Module):
         e = getattr(torch.nn.functional, self.activation, lambda v: v)(e)
         return self.linear(e)
 
+    def _epic_wide_layout(self, n_points: int):
+        """The row-matrix EPiC descriptor of this CNF: with t_emb="gaussian" the one that takes the embedding rows through `t`
+        (PFM_EW_F_TEMB_GIVEN; same blob)."""
+        return self.net.layout(n_points, temb_given=self.t_emb == "gaussian")
+
     def _temb_table_fn(self, device):
         """ts (n_evaluations,) -> (n_evaluations, T): the embedding table a sampler evaluates the field with (every jet sees the same times)"""
         def fn(ts):
             with torch.no_grad():
                 return self._gaussian_temb(ts.to(device, torch.float32))
         return fn
-
-    def _check_gaussian_path(self, n_points: int):
-        if self.is_transformer or self.is_cross_attention:
-            return
-        if self.net.is_wide(n_points):
-            raise NotImplementedError("t_emb='gaussian' has a HIP path for model='epic' at hidden_dim 128 with sets that fit the "
-                                      "LDS tile only (the row-matrix path embeds the time in-kernel)")
 
     def time_embedding(self, t: Tensor, x: Tensor, t_emb: str = "cosine") -> Tensor:
         if t_emb == "gaussian":  # :213-221
@@ -222,17 +221,16 @@ class CNF(nn.Module):
     def forward(self, t: Tensor, x: Tensor, cond: Tensor = None, mask: Tensor = None) -> Tensor:
         """v = f(t, x) (flow_matching_module.py:191-204); one HIP launch, embedding included."""
         if self.t_emb == "gaussian":
-            self._check_gaussian_path(x.shape[1])
             temb = self._gaussian_temb(self._per_jet_time(t, x))  # (B, T)
             if self.is_transformer or self.is_cross_attention:
                 return self.net.vector_field(temb, x, cond, mask)  # the layout carries PFM_*_F_TEMB_GIVEN: `t` = the embedding rows
-            return self.net.forward(temb, x, cond, mask)
+            return self.net.forward(temb, x, cond, mask)  # EPiC_encoder.forward takes the embedding (epic.py:304), either path
         return self.net.vector_field(self._per_jet_time(t, x), x, cond, mask)
 
     def fm_loss(self, x, t, z, mask=None, cond=None, sigma: float = 1e-4, kind: str = "FM-OT", eps=None) -> Tensor:
         """Differentiable FM / CFM loss with the draws given (the body of losses.py:38-77 / 101-136)."""
         lay = self.net.layout(x.shape[1])
-        if self.t_emb == "gaussian" and (self.is_transformer or self.is_cross_attention):
+        if self.t_emb == "gaussian" and (self.is_transformer or self.is_cross_attention or self.net.is_wide(x.shape[1])):
             # no fused loss kernel with a caller-supplied embedding: interpolation / target / squared error around the differentiable
             # field (fm_field.py), whose backward also returns d loss / d temb for the CNF's embedding network
             return _fm_field.fm_loss_from_field(lambda y: self._field_rows(t, y, cond, mask), kind, x, t, z, eps, mask, sigma)
@@ -248,7 +246,6 @@ class CNF(nn.Module):
                                               freqs=self.net.freq_tensor())
         src = self.net.source_vector(lay)
         if self.t_emb == "gaussian":
-            self._check_gaussian_path(x.shape[1])
             return _fm_loss.epic_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps,
                                          temb=self._gaussian_temb(t.to(x.device, torch.float32)))
         if self.net.is_wide(x.shape[1]):
@@ -274,16 +271,15 @@ class CNF(nn.Module):
             if self.is_cross_attention:
                 return hip_ops_ca.ca_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
                                                      ode_steps=ode_steps, premask=False, temb_fn=temb_fn)
+            if self.net.is_wide(z.shape[1]):
+                return hip_ops_wide.ew_sample_midpoint(self._epic_wide_layout(z.shape[1]), blob, z, cond, mask,
+                                                       ode_steps=ode_steps, premask=False, temb_fn=temb_fn)
             if self.t_emb == "gaussian":
-                self._check_gaussian_path(z.shape[1])
                 ts, _ = hip_ops.midpoint_grid(ode_steps, z.device)
                 with torch.no_grad():
                     tab = self._gaussian_temb(ts)  # (2 (ode_steps - 1), T): every jet is evaluated at the same times
                 return hip_ops.epic_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask, ode_steps=ode_steps,
                                                     premask=False, temb_tab=tab)
-            if self.net.is_wide(z.shape[1]):
-                return hip_ops_wide.ew_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
-                                                       ode_steps=ode_steps, premask=False)
             return hip_ops.epic_sample_midpoint(self.net.layout(z.shape[1]), blob, z, cond, mask,
                                                 ode_steps=ode_steps, premask=False)
         if ode_solver in ("euler", "rk4"):  # torchdyn fixed-step solvers over the same t_span (:261-282)
@@ -342,11 +338,15 @@ class CNF(nn.Module):
         return _fm_field.epic_field(lay, self.net.source_vector(lay), self._per_jet_time(t, x).to(x.device, torch.float32), x, cond, mask)
 
     def _field_rows(self, t, x, cond, mask):
-        """v = f(t, x) of the transformer / cross-attention / MDMA model as a differentiable function of the parameters (fm_field.py)."""
-        lay = self.net.layout(x.shape[1])
-        fl, fr = self.net.flat_parameters(lay), self.net.freq_tensor()
+        """v = f(t, x) of the transformer / cross-attention / MDMA / row-matrix EPiC model as a differentiable function of the
+        parameters (fm_field.py)."""
         if self.t_emb == "gaussian":  # the (B, T) embedding rows, a differentiable input of the field
             t = self._gaussian_temb(self._per_jet_time(t, x))
+        if self.is_epic:
+            lay = self._epic_wide_layout(x.shape[1])
+            return _fm_field.epic_wide_field(lay, self.net.source_vector(lay), t, x, cond, mask)
+        lay = self.net.layout(x.shape[1])
+        fl, fr = self.net.flat_parameters(lay), self.net.freq_tensor()
         if self.is_transformer:
             return _fm_field.tf_field(lay, fl, t, x, cond, mask, freqs=fr)
         if self.is_cross_attention:
@@ -440,14 +440,14 @@ class CNF(nn.Module):
         if self.is_mdma:
             m = torch.ones(*z.shape[:2], 1, device=z.device) if mask is None else mask
             return hip_ops_mdma.mdma_sample_rk(lay, blob, z, m, premask=False, **kw)
-        if (self.is_transformer or self.is_cross_attention) and self.t_emb == "gaussian":
+        if self.t_emb == "gaussian" and (self.is_transformer or self.is_cross_attention or self.net.is_wide(z.shape[1])):
             kw["temb_fn"] = self._temb_table_fn(z.device)
         if self.is_transformer:
             return hip_ops_tf.tf_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
         if self.is_cross_attention:
             return hip_ops_ca.ca_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
         if self.net.is_wide(z.shape[1]):
-            return hip_ops_wide.ew_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
+            return hip_ops_wide.ew_sample_rk(self._epic_wide_layout(z.shape[1]), blob, z, cond, mask, premask=False, **kw)
         if self.t_emb == "gaussian":
             def temb_fn(ts):
                 with torch.no_grad():

@@ -1,8 +1,8 @@
 """t_emb="gaussian" (flow_matching_module.py:178-181, 213-221: a small trainable network of the CNF in front of the field) on the
-Full-Transformer and cross-attention models: the kernels take the embedding rows through their `t` argument (PFM_*_F_TEMB_GIVEN),
-pfm_*_backward_dtemb returns d loss / d temb and autograd continues into embed.1.* / linear.*.  Against vectors recorded from the
-reference (tests/golden/{tf,ca}_gauss.npz): forward (vector and scalar t), FM-OT / CFM loss + sub-sampled gradients of every tensor
-including the embedding network, midpoint 3 / 10."""
+Full-Transformer, cross-attention and row-matrix EPiC ("ew": hidden 300) models: the kernels take the embedding rows through their
+`t` argument (PFM_*_F_TEMB_GIVEN), pfm_*_backward_dtemb returns d loss / d temb and autograd continues into embed.1.* / linear.*.
+Against vectors recorded from the reference (tests/golden/{tf,ca,epicw}_gauss.npz): forward (vector and scalar t), FM-OT / CFM loss
++ sub-sampled gradients of every tensor including the embedding network, midpoint 3 / 10."""
 import copy
 
 import pytest
@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _load(path):
-    from tests.conftest import load_ca_golden, load_tf_golden
-    return {"tf": load_tf_golden, "ca": load_ca_golden}[path]("gauss")
+    from tests.conftest import load_ca_golden, load_tf_golden, load_wide_golden
+    return {"tf": load_tf_golden, "ca": load_ca_golden, "ew": load_wide_golden}[path]("gauss")
 
 
 def _module(g):
@@ -25,26 +25,29 @@ def _module(g):
     return m.cuda()
 
 
-@pytest.mark.parametrize("path", ["tf", "ca"])
+@pytest.mark.parametrize("path", ["tf", "ca", "ew"])
 def test_forward_matches_reference_vectors(path):
     g = _load(path)
     m = _module(g)
-    for mk in ("f32", "int64", "ones"):
+    for mk in ("f32", "int64", "none" if path == "ew" else "ones"):
         tag = f"nfe_{mk}/"
         x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))
         N = x.shape[1]
         tt = t.unsqueeze(-1).repeat_interleave(N, dim=1)
+        dmask = None if mask is None else mask.cuda()
         with torch.no_grad():
-            v = m.flows[0](tt.cuda(), x.cuda(), cond=cond.cuda(), mask=mask.cuda()).cpu()
-            vs = m.flows[0](t[0].cuda(), x.cuda(), cond=cond.cuda(), mask=mask.cuda()).cpu()
+            v = m.flows[0](tt.cuda(), x.cuda(), cond=cond.cuda(), mask=dmask).cpu()
+            vs = m.flows[0](t[0].cuda(), x.cuda(), cond=cond.cuda(), mask=dmask).cpu()
         torch.testing.assert_close(v, g.get(tag + "v_vec_t"), atol=2e-5, rtol=2e-4)
         torch.testing.assert_close(vs, g.get(tag + "v_scalar_t"), atol=2e-5, rtol=2e-4)
 
 
-@pytest.mark.parametrize("path", ["tf", "ca"])
+@pytest.mark.parametrize("path", ["tf", "ca", "ew"])
 @pytest.mark.parametrize("kind", ["FM-OT", "CFM"])
 def test_loss_and_gradients_including_the_embedding_network(path, kind):
     g = _load(path)
+    if path == "ew" and kind == "CFM":
+        pytest.skip("the epicw recorder holds FM-OT and droid losses")
     m = _module(g)
     tag = "loss_f32/" if kind == "FM-OT" else "cfm/"
     x, t, mask, cond = (g.get(tag + k).cuda() for k in ("x", "t", "mask", "cond"))
@@ -71,7 +74,7 @@ def test_loss_and_gradients_including_the_embedding_network(path, kind):
     assert named["embed.0.W"].grad is None  # GaussianFourierProjection.W is frozen (time_emb.py:15)
 
 
-@pytest.mark.parametrize("path", ["tf", "ca"])
+@pytest.mark.parametrize("path", ["tf", "ca", "ew"])
 def test_samplers_and_training_step(path):
     g = _load(path)
     m = _module(g)
@@ -85,9 +88,13 @@ def test_samplers_and_training_step(path):
     from oracle.fm_ref import sample_fixed_step
     if path == "tf":
         from oracle.tf_ref import TransformerVectorField as VF
-    else:
+    elif path == "ca":
         from oracle.ca_ref import CrossAttentionVectorField as VF
-    vf = VF(g.state, "flows.0.", g.hp, freqs=g.freqs)
+    if path == "ew":
+        from oracle.fm_ref import EpicVectorField
+        vf = EpicVectorField(g.state, "flows.0.net", g.hp)
+    else:
+        vf = VF(g.state, "flows.0.", g.hp, freqs=g.freqs)
     z, mask, cond = (g.get("midpoint_10/" + k) for k in ("z", "mask", "cond"))
     for solver in ("euler", "rk4"):
         out = m((z * mask).cuda(), cond=cond.cuda(), mask=mask.cuda(), reverse=True, ode_solver=solver, ode_steps=6).cpu()
@@ -100,3 +107,31 @@ def test_samplers_and_training_step(path):
     loss.backward()
     for k in ("embed.1.weight", "linear.bias"):
         assert dict(m.flows[0].named_parameters())[k].grad.abs().max() > 0
+
+
+def test_droid_loss_and_the_encoder_forward_with_a_given_embedding_on_the_row_matrix_path():
+    """(a) DroidLoss (losses.py:304-342) with the gaussian embedding on the row-matrix EPiC path, against the recorded loss and
+    gradients; (b) EPiC_encoder.forward(t_emb, x, cond, mask) (epic.py:304: the reference's own signature takes the EMBEDDING) on the
+    row-matrix path of a cosine configuration equals vector_field(t, ...) with the in-kernel embedding."""
+    g = _load("ew")
+    m = _module(g)
+    tag = "droid/"
+    x, t, z, mask, cond = (g.get(tag + k).cuda() for k in ("x", "t", "z", "mask", "cond"))
+    loss = m.flows[0].fm_loss(x, t, z, mask=mask, cond=cond, sigma=1e-4, kind="droid")
+    torch.testing.assert_close(loss.detach().cpu(), g.get(tag + "loss"), rtol=3e-5, atol=1e-6)
+    loss.backward()
+    named = dict(m.flows[0].named_parameters())
+    for k, want in g.grads(tag).items():
+        got = g.pick(named[k[len("flows.0."):]].grad.cpu())
+        assert float((got - want).norm()) / max(float(want.norm()), 1e-12) < 2e-3, k
+    from tests.conftest import load_wide_golden
+    from tests.test_hip_wide_modules import _module as wide_module
+    gc = load_wide_golden("small")
+    mc = wide_module(gc)
+    net = mc.flows[0].net
+    x, t, mask, cond = (gc.get("nfe_f32/" + k).cuda() for k in ("x", "t", "mask", "cond"))
+    with torch.no_grad():
+        want = net.vector_field(t, x, cond, mask)
+        temb = mc.flows[0].time_embedding(t[:, None].expand(-1, x.shape[1]), x, "cosine")  # (B, N, T), as CNF.forward hands it over
+        got = net(temb, x, cond, mask)
+    torch.testing.assert_close(got, want, atol=2e-6, rtol=1e-5)

@@ -83,3 +83,34 @@ def test_gaussian_embedding_on_the_transformer_fields(path):
         z, mask, cond = (g.get(tag + k) for k in ("z", "mask", "cond"))
         xe = midpoint_trajectory_end(lambda tt, xx: vf(tt, xx, mask=mask, cond=cond), z * mask, torch.linspace(1.0, 0.0, 10))
         torch.testing.assert_close(xe, g.get(tag + "x_end"), atol=5e-5, rtol=1e-3)
+
+
+def test_gaussian_embedding_on_the_wide_epic_field():
+    """tests/golden/epicw_gauss.npz (hidden 300: the row-matrix path's width): the oracle's EPiC field behind the CNF's gaussian
+    embedding network reproduces the reference's recorded forward vectors, FM-OT loss + gradients and midpoint samples."""
+    from tests.conftest import load_wide_golden
+    g = load_wide_golden("gauss")
+    assert g.hp["t_emb"] == "gaussian" and g.hp["hidden_dim"] == 300
+    vf = EpicVectorField(g.state, "flows.0.net", g.hp)
+    with torch.no_grad():
+        for mk in ("f32", "none"):
+            tag = f"nfe_{mk}/"
+            x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))
+            v = vf(t[:, None].expand(-1, x.shape[1]), x, cond=cond, mask=mask)
+            torch.testing.assert_close(v, g.get(tag + "v_vec_t"), atol=1e-5, rtol=1e-4)
+            torch.testing.assert_close(vf(t[0], x, cond=cond, mask=mask), g.get(tag + "v_scalar_t"), atol=1e-5, rtol=1e-4)
+        tag = "midpoint_10/"
+        z, mask, cond = (g.get(tag + k) for k in ("z", "mask", "cond"))
+        torch.testing.assert_close(sample_midpoint(vf, z, cond, mask, ode_steps=10), g.get(tag + "x_end"), atol=5e-5, rtol=1e-3)
+    tag = "loss_f32/"
+    x, t, z, mask, cond = (g.get(tag + k) for k in ("x", "t", "z", "mask", "cond"))
+    st = {k: v.clone().requires_grad_(v.is_floating_point() and "frequencies" not in k and not k.endswith("embed.0.W"))
+          for k, v in g.state.items()}
+    loss, *_ = fm_ot_loss(EpicVectorField(st, "flows.0.net", g.hp), x, mask, cond, t, z, sigma=1e-4)
+    torch.testing.assert_close(loss.detach(), g.get(tag + "loss"), atol=1e-6, rtol=1e-5)
+    loss.backward()
+    ref = g.grads(tag)
+    assert {"flows.0.embed.1.weight", "flows.0.embed.1.bias", "flows.0.linear.weight", "flows.0.linear.bias"} <= set(ref)
+    for k, gref in ref.items():
+        scale = max(gref.abs().max().item(), 1e-8)
+        assert (g.pick(st[k].grad) - gref).abs().max().item() / scale <= 5e-5, k
