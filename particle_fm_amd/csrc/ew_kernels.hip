@@ -81,7 +81,18 @@ __global__ __launch_bounds__(256) void ew_pool_compact_kernel(const float* __res
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const bool c0 = cg < nc4, c1 = cg + 64 < nc4;
     int r = r0 + rg;
-    for (; r + 12 < r1; r += 16) {  // four rows in flight per thread
+    for (; r + 28 < r1; r += 32) {  // eight rows in flight per thread
+        f32x4 v[8][2];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* xp = X + (int64_t)(r + 4 * u) * Hp + 4 * cg;
+            v[u][0] = c0 ? *reinterpret_cast<const f32x4*>(xp) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v[u][1] = c1 ? *reinterpret_cast<const f32x4*>(xp + 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        acc[0] += ((v[0][0] + v[1][0]) + (v[2][0] + v[3][0])) + ((v[4][0] + v[5][0]) + (v[6][0] + v[7][0]));
+        acc[1] += ((v[0][1] + v[1][1]) + (v[2][1] + v[3][1])) + ((v[4][1] + v[5][1]) + (v[6][1] + v[7][1]));
+    }
+    for (; r + 12 < r1; r += 16) {  // four
         f32x4 v[4][2];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -109,206 +120,169 @@ __global__ __launch_bounds__(256) void ew_pool_compact_kernel(const float* __res
     }
 }
 // ------------------------------------------------------------------------------------------------
-// The per-jet chain of a stage in ONE launch (inference): pool -> fc_global1 -> fc_global2 -> jet-bias rows, one workgroup per jet.
-//   Q  = [masked mean | masked sum * scale] of the jet's rows of X                      epic.py:108-117 / :331-339
+// The per-jet chain of a stage at inference: pool -> fc_global1 -> fc_global2 -> jet-bias rows, on the matrix pipe, 16 jets per tile.
+//   Q  = [masked mean | masked sum * scale] of the jet's rows of X   (ew_pool*_kernel)   epic.py:108-117 / :331-339
 //   g1 = lrelu(Wg1 . [P256 | Q] + b)                                                    epic.py:180-182 / :375-377
-//   g  = lrelu(Wg2 . [P256 | g1] + b (+ g))  -> P[128 ..)                               epic.py:184-186 / :378-380
+//   g  = lrelu(Wg2 . [P256 | g1] + b (+ g))                                             epic.py:184-186 / :378-380
 //   JB = Wjb . P256 + b   (the time / conditioning / broadcast-g columns of fc_local1 | fc_local2 for this jet)
-// As row GEMMs over the B per-jet rows these were 6-7 launches per layer (three split-K GEMMs with their epilogues and the
-// pooling), each a few workgroups and ~5 us of launch + ramp latency: 126 of the 191 launches of a JetClass evaluation and 23 % of
-// its time (profiles/round1_cfg5_nfe_kernel_stats.csv).  Here every jet walks the chain on its own CU as GEMVs straight on the
-// MFMA_AK blocks (pfm_tf.h): a wave takes a 16-output block, lane (i, q) multiplies the float4 it would feed the matrix pipe with
-// (row 16 ob + i, k = 64 st + 16 kt + 4 q ..) by the matching float4 of the input vector in LDS -- coalesced 1 KB loads, no second
-// weight copy -- and the four q-partials meet by two wave shuffles.  Floor: the ~1.9 MB of weights per jet and layer crossing the
-// CU's 64 B/clk path (~13 us); measured 25 us per launch at 256 jets (every jet on its own CU), the same with 16 waves or deeper
-// load batches, 38 us with two jets per workgroup: the LDS operand reads and FMAs of a jet do not hide behind its loads.
-// STEM: the stem's chain (fc_g1 / fc_g2: no g input, no residual) runs first and the first layer's chain right behind it on the same
-// pooled vector (epic.py:369-385: the first layer pools the same x).
+// History: as row GEMMs over the B per-jet rows these were 6-7 launches per layer (round 1); round 2 gave every jet its own workgroup
+// that ran the whole chain on the VALU (one launch, but each workgroup streamed the chain's ~1.9 MB of weights for ONE input vector:
+// 25 us on as many CUs as there are jets, 29 % of cfg 5's wall time by a timing-only build without it).  Here the jets are the 16 columns of the MFMA's
+// B operand: lane (n, q) of a wave reads 4 consecutive inputs of jet n straight from the jet's rows in global memory (16 columns of
+// K = one "unit" = 4 v_mfma_f32_16x16x4_f32 on one MFMA_AK float4 of weights), no LDS staging, no barrier:
+//   ew_g1_kernel    fc_global1 (fc_g1):  grid (jet groups, Hp / 64); two waves share a 16-output block, half of K each;
+//                   K = [P256 | mean | sum] with the all-zero units of P256 skipped (only ceil((T + C) / 16) + ceil(latent / 16) of its
+//                   16 units hold values);
+//   ew_g2jb_kernel  fc_global2 (fc_g2) for the group -- its one to eight 16-output blocks, K split over the four waves, partials joined
+//                   in wave order through LDS -- and the jet-bias rows of a slice of 128 outputs: the accumulator layout of fc_global2's
+//                   result (lane (n, q): outputs 4 q .. 4 q + 3 of jet n) IS the B-operand layout of the unit that feeds it into the
+//                   jet-bias GEMM, so the new latent vector never leaves registers.
+// The latent state g lives in two [B][128] buffers (read G[l & 1], write G[(l + 1) & 1]: the workgroups of a group all read g_old while
+// one of them writes g_new); the pooled vector comes from ew_pool*_kernel.  Three small launches per layer instead of one long one: the
+// CUs stay free for the other half-batch's particle Linears.  A jet's values depend on its own column only: batch-independent bits.
 // ------------------------------------------------------------------------------------------------
-struct ChainArgs {
-    const float *blob, *X, *mask;
-    const int* off;  // compacted rows: the jet's rows are [off[jet], off[jet+1]); nullptr: dense rows with `mask` (or all valid)
-    float *P, *JB;
-    pfm_ew_lin sg1, sg2, g1, g2, jb;
-    int Hp, N, ldp, nob_latent, B;  // nob_latent: 16-output blocks of fc_global2 that hold real outputs; B: jets of the launch
-    float scale, slope;
+struct SkArgs {
+    const float *blob, *P, *Q;  // P [B][ldp]: the prep row (temb | cond | 0 ...) and, from column 256 on, fc_global1's output; Q [B][2 Hp]
+    const float* Gin;           // [B][128] latent state (nullptr: none -- the stem)
+    float *Gout, *JB;
+    pfm_ew_lin lin1, lin2, jb;
+    int B, Hp, ldp, n_tc, nl, residual, do_jb;  // n_tc = ceil((T + C) / 16), nl = ceil(latent / 16)
+    float slope;
 };
 
-constexpr int CT = 512;       // threads of a chain workgroup (1024 measured the same 25 us)
-constexpr int CW = CT / 64;   // waves
-constexpr int JPW = 1;        // jets per workgroup (2: every weight float4 serves two jets -- measured 38 us against 25 us: the chain is
-                              // bound by the latency of each wave's dependent load -> FMA batches, not by L2 or the 64 B/clk path)
-constexpr int KQ = 4;         // K splits of fc_global1 (work items = output blocks x KQ)
-constexpr int VIN = 256 + 1024, VIN2 = 256 + 512;
+#define PFM_SK_MFMA4(acc, wv, iv)                                             \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32((wv).x, (iv).x, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32((wv).y, (iv).y, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32((wv).z, (iv).z, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32((wv).w, (iv).w, acc, 0, 0, 0);
 
-// NS k-steps of one output block for JPW input vectors: all 4 NS weight loads (1 KB per wave each) in flight before the first FMA
-template <int NS>
-__device__ __forceinline__ void chain_steps(f32x4 (&acc)[JPW][2], const float* __restrict__ wp, const float* __restrict__ xp, int xs) {
-    f32x4 wv[4 * NS];
+constexpr int G1U = 24;  // units a wave of ew_g1_kernel holds in registers: half of K <= 16 + 2 * 512 / 16 units -> Hp <= 256 in one pass
+__global__ __launch_bounds__(512) void ew_g1_kernel(SkArgs a) {
+    // eight waves: wave w and wave w + 4 share output block 4 blockIdx.y + (w & 3), each takes half of the K units with ALL of its
+    // operand loads in flight before the first MFMA (the launch is one load round trip + ~100 MFMAs long); the upper half's partial
+    // sums cross through LDS
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, q = lane >> 4;
+    const int ob = 4 * blockIdx.y + (w & 3), half = w >> 2;
+    const int jet0 = 16 * blockIdx.x + n, jet = min(jet0, a.B - 1);
+    const int ks = (256 + 2 * a.Hp) >> 6;
+    const float* wrow = a.blob + a.lin1.W + (int64_t)ob * ks * 1024 + lane * 4;
+    const float* pP = a.P + (int64_t)jet * a.ldp + 4 * q;
+    const float* pG = a.Gin ? a.Gin + (int64_t)jet * 128 + 4 * q : nullptr;
+    const float* pQ = a.Q + (int64_t)jet * 2 * a.Hp + 4 * q;
+    const int u1 = a.n_tc, u2 = u1 + (pG ? a.nl : 0), NU = u2 + (a.Hp >> 3);
+    const int per = (NU + 1) >> 1, ua = half * per, ub = min(NU, ua + per);  // this wave's units [ua, ub)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (!half) acc0 = *reinterpret_cast<const f32x4*>(a.blob + a.lin1.b + 16 * ob + 4 * q);
+#pragma unroll 1
+    for (int u0 = ua; u0 < ub; u0 += G1U) {
+        f32x4 wv[G1U], iv[G1U];
 #pragma unroll
-    for (int i = 0; i < 4 * NS; ++i) wv[i] = *reinterpret_cast<const f32x4*>(wp + 256 * i);
-#pragma unroll
-    for (int i = 0; i < 4 * NS; ++i)
-#pragma unroll
-        for (int jj = 0; jj < JPW; ++jj) acc[jj][i & 1] += wv[i] * *reinterpret_cast<const f32x4*>(xp + jj * xs + 16 * i);
-}
-
-// partial dot products of output block ob over the k-steps [st0, st1) of an MFMA_AK matrix with K = 64 * ksteps, for the JPW
-// input vectors vin + jj * xs: out[jj] = in every lane, the sum for output row 16 ob + (lane & 15)
-__device__ __forceinline__ void chain_block(float (&out)[JPW], const float* __restrict__ blob, int64_t W, int ksteps, int ob, int st0,
-                                            int st1, const float* __restrict__ vin, int xs, int lane) {
-    const int q = lane >> 4;
-    const float* wp = blob + W + ((int64_t)ob * ksteps + st0) * 1024 + lane * 4;
-    const float* xp = vin + 64 * st0 + 4 * q;
-    f32x4 acc[JPW][2];
-#pragma unroll
-    for (int jj = 0; jj < JPW; ++jj) acc[jj][0] = acc[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int n = st1 - st0;
-    for (; n >= 4; n -= 4, wp += 4096, xp += 256) chain_steps<4>(acc, wp, xp, xs);
-    if (n & 2) { chain_steps<2>(acc, wp, xp, xs); wp += 2048; xp += 128; }
-    if (n & 1) chain_steps<1>(acc, wp, xp, xs);
-#pragma unroll
-    for (int jj = 0; jj < JPW; ++jj) {
-        const f32x4 t = acc[jj][0] + acc[jj][1];
-        float v = (t.x + t.y) + (t.z + t.w);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        out[jj] = v;
-    }
-}
-
-// masked mean | masked sum * scale of one jet's rows of X into q[0 .. 2 Hp); ends behind a barrier
-__device__ __forceinline__ void chain_pool(const ChainArgs& a, int jet, float* __restrict__ q, float* __restrict__ red,
-                                           float* __restrict__ cnt) {
-    const int tid = threadIdx.x, cg = tid & 63, rg = tid >> 6;
-    const int Hp = a.Hp, nc4 = Hp >> 2;
-    const bool c0 = cg < nc4, c1 = cg + 64 < nc4;
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    float n = 0.f;
-    if (a.off) {
-        const int r0 = a.off[jet], r1 = a.off[jet + 1];
-        int r = r0 + rg;
-        for (; r + 3 * CW < r1; r += 4 * CW) {  // four rows in flight per thread
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            f32x4 u[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float* xr = a.X + (int64_t)(r + CW * i) * Hp + 4 * cg;
-                u[i][0] = c0 ? *reinterpret_cast<const f32x4*>(xr) : z;
-                u[i][1] = c1 ? *reinterpret_cast<const f32x4*>(xr + 256) : z;
-            }
-            acc[0] += (u[0][0] + u[1][0]) + (u[2][0] + u[3][0]);
-            acc[1] += (u[0][1] + u[1][1]) + (u[2][1] + u[3][1]);
+        for (int i = 0; i < G1U; ++i) {
+            const int u = u0 + i;  // wave-uniform
+            if (u >= ub) continue;
+            int cu;
+            const float* ip;
+            if (u < u1) { cu = u; ip = pP + 16 * u; }
+            else if (u < u2) { cu = 8 + (u - u1); ip = pG + 16 * (u - u1); }
+            else { cu = 16 + (u - u2); ip = pQ + 16 * (u - u2); }
+            wv[i] = *reinterpret_cast<const f32x4*>(wrow + cu * 256);
+            iv[i] = *reinterpret_cast<const f32x4*>(ip);
         }
-        for (; r < r1; r += CW) {
-            const float* x0 = a.X + (int64_t)r * Hp + 4 * cg;
-            if (c0) acc[0] += *reinterpret_cast<const f32x4*>(x0);
-            if (c1) acc[1] += *reinterpret_cast<const f32x4*>(x0 + 256);
-        }
-        n = (float)(r1 - r0);  // every group knows the count
-    } else {
-        for (int r = rg; r < a.N; r += CW) {
-            const int64_t row = (int64_t)jet * a.N + r;
-            const float wgt = a.mask ? a.mask[row] : 1.0f;
-            n += wgt;
-            if (c0) acc[0] += wgt * *reinterpret_cast<const f32x4*>(a.X + row * Hp + 4 * cg);
-            if (c1) acc[1] += wgt * *reinterpret_cast<const f32x4*>(a.X + row * Hp + 4 * (cg + 64));
+#pragma unroll
+        for (int i = 0; i < G1U; i += 2) {
+            if (u0 + i < ub) { PFM_SK_MFMA4(acc0, wv[i], iv[i]) }
+            if (u0 + i + 1 < ub) { PFM_SK_MFMA4(acc1, wv[i + 1], iv[i + 1]) }
         }
     }
-    if (c0) *reinterpret_cast<f32x4*>(red + rg * 512 + 4 * cg) = acc[0];
-    if (c1) *reinterpret_cast<f32x4*>(red + rg * 512 + 4 * (cg + 64)) = acc[1];
-    if (cg == 0) cnt[rg] = n;
+    acc0 += acc1;
+    if (half) red[w & 3][lane] = acc0;
     __syncthreads();
-    float nv = cnt[0];
-    if (!a.off)
-        for (int g = 1; g < CW; ++g) nv += cnt[g];
-    for (int c = tid; c < Hp; c += CT) {
-        float s = red[c];
-        for (int g = 1; g < CW; ++g) s += red[g * 512 + c];
-        q[c] = s / nv;
-        q[Hp + c] = s * a.scale;
-    }
-    __syncthreads();
+    if (!half && jet0 < a.B)
+        *reinterpret_cast<f32x4*>(const_cast<float*>(a.P) + (int64_t)jet * a.ldp + 256 + 16 * ob + 4 * q) = lrelu4(acc0 + red[w][lane], a.slope);
 }
 
-template <bool STEM>
-__global__ __launch_bounds__(CT) void ew_chain_kernel(ChainArgs a) {
-    __shared__ __attribute__((aligned(16))) float vin[JPW * VIN];     // per jet [P256 | Q]
-    __shared__ __attribute__((aligned(16))) float vin2[JPW * VIN2];   // per jet [P256 | g1]
-    __shared__ __attribute__((aligned(16))) float red[CW * 512];      // pooling partials; then GEMV partials
-    __shared__ float cnt[CW];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int Hp = a.Hp, nob = Hp >> 4;
-    // the workgroup's jets; an odd batch ends with a workgroup whose second jet repeats the first (same values stored twice)
-    int jets[JPW];
+template <int NL>
+__global__ __launch_bounds__(256) void ew_g2jb_kernel(SkArgs a) {
+    __shared__ f32x4 red[NL][4][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, q = lane >> 4;
+    const int jet0 = 16 * blockIdx.x + n, jet = min(jet0, a.B - 1);
+    const float* pP = a.P + (int64_t)jet * a.ldp + 4 * q;
+    // the jet-bias GEMM's first operands do not depend on fc_global2: requested ahead of it
+    const int nob_jb = a.Hp >> 3;  // 2 Hp / 16
+    const int ob0 = 8 * blockIdx.y + 2 * w;
+    f32x4 jw[2][8], ji[8], jacc[2];
+    if (a.do_jb) {
 #pragma unroll
-    for (int jj = 0; jj < JPW; ++jj) jets[jj] = min((int)blockIdx.x * JPW + jj, a.B - 1);
-    // ---- P256 = [temb | cond | 0 ; g | 0], pooled vector ----
+        for (int u = 0; u < 8; ++u)
+            if (u < a.n_tc) ji[u] = *reinterpret_cast<const f32x4*>(pP + 16 * u);
 #pragma unroll
-    for (int jj = 0; jj < JPW; ++jj) {
-        if (tid < 256) {
-            const float v = a.P[(int64_t)jets[jj] * a.ldp + tid];
-            vin[jj * VIN + tid] = v;
-            vin2[jj * VIN2 + tid] = v;
+        for (int bi = 0; bi < 2; ++bi) {
+            const int ob = min(ob0 + bi, nob_jb - 1);
+            const float* wrow = a.blob + a.jb.W + (int64_t)ob * 4 * 1024 + lane * 4;
+            jacc[bi] = *reinterpret_cast<const f32x4*>(a.blob + a.jb.b + 16 * ob + 4 * q);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < a.n_tc) jw[bi][u] = *reinterpret_cast<const f32x4*>(wrow + u * 256);
         }
-        chain_pool(a, jets[jj], vin + jj * VIN + 256, red, cnt);
     }
-    const int ks1 = (256 + 2 * Hp) >> 6, ks2 = a.ldp >> 6;
-    for (int pass = STEM ? 0 : 1; pass < 2; ++pass) {
-        const bool stem = pass == 0;
-        const pfm_ew_lin& L1 = stem ? a.sg1 : a.g1;
-        const pfm_ew_lin& L2 = stem ? a.sg2 : a.g2;
-        // ---- fc_global1: items (output block, K quarter), partials red[jj][quarter][Hp] ----
-        for (int item = w; item < KQ * nob; item += CW) {
-            const int ob = item / KQ, h = item - ob * KQ;
-            float v[JPW];
-            chain_block(v, a.blob, L1.W, ks1, ob, ks1 * h / KQ, ks1 * (h + 1) / KQ, vin, VIN, lane);
+    // ---- fc_global2: units = n_tc of the prep row + Hp / 16 of fc_global1's output; wave w takes units w, w + 4, ... ----
+    const int ks2 = a.ldp >> 6, NU2 = a.n_tc + (a.Hp >> 4);
 #pragma unroll
-            for (int jj = 0; jj < JPW; ++jj)
-                if (lane < 16) red[(jj * KQ + h) * 512 + 16 * ob + lane] = v[jj];
-        }
-        __syncthreads();
-        for (int c = tid; c < JPW * Hp; c += CT) {
-            const int jj = c / Hp, o = c - jj * Hp;
-            const float* r = red + (jj * KQ) * 512 + o;
-            vin2[jj * VIN2 + 256 + o] = lrelu(((r[0] + r[512]) + (r[1024] + r[1536])) + a.blob[L1.b + o], a.slope);
-        }
-        __syncthreads();
-        // ---- fc_global2: the blocks that hold real outputs, K split over the waves by k-step; partials red[jj][st][128] ----
-        for (int item = w; item < a.nob_latent * ks2; item += CW) {
-            const int ob = item / ks2, st = item - ob * ks2;
-            float v[JPW];
-            chain_block(v, a.blob, L2.W, ks2, ob, st, st + 1, vin2, VIN2, lane);
+    for (int lb = 0; lb < NL; ++lb) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (lb < a.nl) {
+            const float* wrow = a.blob + a.lin2.W + (int64_t)lb * ks2 * 1024 + lane * 4;
+#pragma unroll 1
+            for (int u0 = w; u0 < NU2; u0 += 16) {
+                f32x4 wv[4], iv[4];
 #pragma unroll
-            for (int jj = 0; jj < JPW; ++jj)
-                if (lane < 16) red[(jj * 16 + st) * 128 + 16 * ob + lane] = v[jj];
-        }
-        __syncthreads();
-        if (tid < JPW * 128) {
-            const int jj = tid >> 7, o = tid & 127;
-            if (o < 16 * a.nob_latent) {
-                float v = red[(jj * 16) * 128 + o];
-                for (int st = 1; st < ks2; ++st) v += red[(jj * 16 + st) * 128 + o];
-                v += a.blob[L2.b + o];
-                if (!stem) v += vin[jj * VIN + 128 + o];  // residual before the activation, epic.py:184-186
-                v = lrelu(v, a.slope);
-                vin[jj * VIN + 128 + o] = v;   // the g the next Linear sees (and the next pass's g_old)
-                vin2[jj * VIN2 + 128 + o] = v;
-                if (!STEM || !stem) a.P[(int64_t)jets[jj] * a.ldp + 128 + o] = v;  // the next layer's chain reads it back
+                for (int i = 0; i < 4; ++i) {
+                    const int u = u0 + 4 * i;
+                    if (u >= NU2) continue;
+                    const int cu = u < a.n_tc ? u : 16 + (u - a.n_tc);
+                    wv[i] = *reinterpret_cast<const f32x4*>(wrow + cu * 256);
+                    iv[i] = *reinterpret_cast<const f32x4*>(pP + 16 * cu);  // (column 16 cu of the row: 256 + ... for fc_global1's output)
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (u0 + 4 * i < NU2) { PFM_SK_MFMA4(acc, wv[i], iv[i]) }
             }
         }
-        __syncthreads();
+        red[lb][w][lane] = acc;
     }
-    // ---- jet-bias rows: JB[jet] = Wjb . P256 + b, 2 Hp outputs, K = 256 ----
-    for (int ob = w; ob < 2 * nob; ob += CW) {
-        float v[JPW];
-        chain_block(v, a.blob, a.jb.W, 4, ob, 0, 4, vin, VIN, lane);
-        const float b = a.blob[a.jb.b + 16 * ob + (lane & 15)];
+    __syncthreads();
+    f32x4 g[NL];
 #pragma unroll
-        for (int jj = 0; jj < JPW; ++jj)
-            if (lane < 16) a.JB[(int64_t)jets[jj] * 2 * Hp + 16 * ob + lane] = v[jj] + b;
+    for (int lb = 0; lb < NL; ++lb) {
+        if (lb >= a.nl) continue;
+        f32x4 v = (red[lb][0][lane] + red[lb][1][lane]) + (red[lb][2][lane] + red[lb][3][lane]);
+        v += *reinterpret_cast<const f32x4*>(a.blob + a.lin2.b + 16 * lb + 4 * q);
+        if (a.residual) v += *reinterpret_cast<const f32x4*>(a.Gin + (int64_t)jet * 128 + 16 * lb + 4 * q);  // epic.py:184-186
+        g[lb] = lrelu4(v, a.slope);
+        if (blockIdx.y == 0 && w == 0 && jet0 < a.B) *reinterpret_cast<f32x4*>(a.Gout + (int64_t)jet * 128 + 16 * lb + 4 * q) = g[lb];
+    }
+    if (!a.do_jb) return;
+    // ---- jet-bias rows: JB[jet] = Wjb . [temb | cond ; g_new] + b, two 16-output blocks per wave ----
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+        const int ob = ob0 + bi;
+        if (ob >= nob_jb) continue;
+        const float* wrow = a.blob + a.jb.W + (int64_t)ob * 4 * 1024 + lane * 4;
+        f32x4 gw[NL];
+#pragma unroll
+        for (int lb = 0; lb < NL; ++lb)
+            if (lb < a.nl) gw[lb] = *reinterpret_cast<const f32x4*>(wrow + (8 + lb) * 256);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < a.n_tc) { PFM_SK_MFMA4(jacc[bi], jw[bi][u], ji[u]) }
+#pragma unroll
+        for (int lb = 0; lb < NL; ++lb)
+            if (lb < a.nl) { PFM_SK_MFMA4(jacc[bi], gw[lb], g[lb]) }
+        if (jet0 < a.B) *reinterpret_cast<f32x4*>(a.JB + (int64_t)jet * 2 * a.Hp + 16 * ob + 4 * q) = jacc[bi];
     }
 }
+#undef PFM_SK_MFMA4
 
 // masked rows of the output: 0 (or the state they start from), NaN for a jet without any valid particle (the
 // reference's 0/0 mean poisons the whole jet, epic.py:331-339)
@@ -366,7 +340,7 @@ __global__ __launch_bounds__(256) void ew_head_kernel(HeadArgs a) {
 // Workspace (floats).  Inference: one P row set, one Q, one X / L1.  Train: every stage keeps its own copies
 // (stage 0 = stem, stage l+1 = layer l): P_s, Q_s (pool of X_s), X_s, L1_l -- what the backward re-reads.
 struct Ws {
-    int64_t P, pstride, Q, qstride, SJB, JB, X1, X, xstride, L1, lstride, imaps, part, part_floats, total;  // imaps: int32 cnt[B] off[B+1] m[1] rowsrc[M] rowjet[M]
+    int64_t P, pstride, Q, qstride, SJB, JB, G, step, X1, X, xstride, L1, lstride, imaps, part, part_floats, total;  // G: two [B][128] latent states (inference); step: tf_common.h step_args_kernel; imaps: int32 cnt[B] off[B+1] m[1] rowsrc[M] rowjet[M]
 };
 
 __host__ inline Ws make_ws(const pfm_ew_desc& d, int n_jets, bool train) {
@@ -381,6 +355,8 @@ __host__ inline Ws make_ws(const pfm_ew_desc& d, int n_jets, bool train) {
     w.Q = take((int64_t)n_jets * 2 * Hp); o += w.qstride * (stages - 1);
     w.SJB = take((int64_t)n_jets * (2 * Hp + 128));
     w.JB = take((int64_t)n_jets * 2 * Hp);
+    w.G = take(train ? 0 : 2 * (int64_t)n_jets * 128);
+    w.step = take(STEP_SLOT_FLOATS);
     w.X1 = take(M * Hp);
     w.xstride = train ? round64(M * Hp) : 0;
     w.X = take(M * Hp); o += w.xstride * (stages - 1);
@@ -440,6 +416,9 @@ int linear(const Plan& p, int Mrows, const float* A, int lda, int K1, const floa
         while (nstep % ks) --ks;
         if (ks > 1 && (int64_t)ks * Mrows * NO <= p.part_floats) { a.part = p.part; a.ksplit = ks; }
     }
+    // particle-row GEMMs whose width is not a multiple of 128 outputs (H = 300 -> 320: 128 + 128 + 64): five equal 64-output workgroups
+    // per row tile instead of two full ones and a half one -- more, smaller workgroups per CU (cfg 5: 50 -> 42 us per launch)
+    if (jb && NO % BN != 0) a.bn = 64;
     launch_linear_kernel(a, 0, (p.d->flags & PFM_EW_F_F16X3) ? 1 : ((p.d->flags & PFM_EW_F_BF16) ? 2 : 0), num_cus(), p.s);
     int rc = check_hip(hipGetLastError(), "tf_linear_kernel launch (epicw)");
     if (rc || a.ksplit == 1) return rc;
@@ -479,21 +458,41 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
             hipLaunchKernelGGL(ew_pool_kernel, dim3(B), dim3(256), 0, p.s, (const float*)Xst(s), mask, Qst(s), N, Hp, d.sum_scale);
         return check_hip(hipGetLastError(), "ew_pool_kernel launch");
     };
-    // inference: the per-jet chain of a stage is ONE launch (ew_chain_kernel); training keeps the row GEMMs, whose per-stage P / Q the
-    // backward re-reads
-    const bool fused_chain = !w.pstride && B <= 65535;
+    // inference: the per-jet chain of a stage on 16-jet MFMA tiles (ew_g1_kernel, ew_g2jb_kernel); training keeps the row GEMMs, whose
+    // per-stage P / Q the backward re-reads
+#ifdef PFM_EW_AB_ROWCHAIN  // (diagnostic build: the per-jet chain as row GEMMs over the jets, the training path's launches)
+    const bool fused_chain = false;
+#else
+    const bool fused_chain = !w.pstride;
+#endif
+    float* const G = ws + w.G;
+    const int nl = (d.latent + 15) / 16, groups = (B + 15) / 16;
+    // fc_global1 / fc_global2 (+ the jet-bias rows) of one stage; stage -1 = the stem (fc_g1 / fc_g2: no latent input, no residual, no
+    // jet-bias rows).  The latent state alternates between the two halves of G.
     auto chain = [&](int l) {
-        const pfm_ew_layer& L = d.layer[l];
-        ChainArgs a;
-        a.blob = p.blob; a.X = Xst(0); a.mask = p.off ? nullptr : mask; a.off = p.off; a.P = Pst(0); a.JB = JB;
-        a.sg1 = d.sg1; a.sg2 = d.sg2; a.g1 = L.g1; a.g2 = L.g2; a.jb = L.jb;
-        a.Hp = Hp; a.N = N; a.ldp = ldp; a.nob_latent = (d.latent + 15) / 16; a.B = B; a.scale = d.sum_scale; a.slope = d.neg_slope;
-        const dim3 grid((B + JPW - 1) / JPW);
-        if (l == 0) hipLaunchKernelGGL(ew_chain_kernel<true>, grid, dim3(CT), 0, p.s, a);
-        else hipLaunchKernelGGL(ew_chain_kernel<false>, grid, dim3(CT), 0, p.s, a);
-        return check_hip(hipGetLastError(), "ew_chain_kernel launch");
+        SkArgs a;
+        a.blob = p.blob; a.P = Pst(0); a.Q = Qst(0); a.JB = JB;
+        a.B = B; a.Hp = Hp; a.ldp = ldp; a.n_tc = (d.t_dim + d.cond_global + 15) / 16; a.nl = nl; a.slope = d.neg_slope;
+        const bool stem = l < 0;
+        a.lin1 = stem ? d.sg1 : d.layer[l].g1;
+        a.lin2 = stem ? d.sg2 : d.layer[l].g2;
+        a.jb = stem ? d.sjb : d.layer[l].jb;
+        a.Gin = stem ? nullptr : G + (int64_t)(l & 1) * B * 128;
+        a.Gout = G + (int64_t)(stem ? 0 : (l + 1) & 1) * B * 128;
+        a.residual = stem ? 0 : 1;
+        a.do_jb = stem ? 0 : 1;
+        hipLaunchKernelGGL(ew_g1_kernel, dim3(groups, Hp / 64), dim3(512), 0, p.s, a);
+        const dim3 g2(groups, stem ? 1 : (2 * Hp / 16 + 7) / 8);
+        if (nl == 1) hipLaunchKernelGGL(ew_g2jb_kernel<1>, g2, dim3(256), 0, p.s, a);
+        else if (nl == 2) hipLaunchKernelGGL(ew_g2jb_kernel<2>, g2, dim3(256), 0, p.s, a);
+        else if (nl <= 4) hipLaunchKernelGGL(ew_g2jb_kernel<4>, g2, dim3(256), 0, p.s, a);
+        else hipLaunchKernelGGL(ew_g2jb_kernel<8>, g2, dim3(256), 0, p.s, a);
+        return check_hip(hipGetLastError(), "ew_g1_kernel / ew_g2jb_kernel launch");
     };
-    if (!fused_chain || d.layers == 0) {
+    if (fused_chain && d.layers > 0) {
+        PFM_TRY(pool(0));
+        PFM_TRY(chain(-1));
+    } else {
         PFM_TRY(pool(0));
         PFM_TRY(linear(p, B, Pst(0), ldp, 256, Qst(0), 2 * Hp, 256 + 2 * Hp, d.sg1, Hp, nullptr, 0, 1, nullptr, 0, Pst(0) + 256, ldp, 1));
         PFM_TRY(linear(p, B, Pst(0), ldp, ldp, nullptr, 0, ldp, d.sg2, 128, nullptr, 0, 1, nullptr, 0, Pst(0) + 128, ldp, 1));
@@ -502,7 +501,10 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         const pfm_ew_layer& L = d.layer[l];
         float *Pin = Pst(l), *Pout = Pst(l + 1);  // the same row set at inference
         if (fused_chain) {
+#ifndef PFM_EW_AB_NOCHAIN  // (timing-only diagnostic build, tests/diag/build_ew_ab.sh: what the sampler costs without its per-jet chains)
+            if (l) PFM_TRY(pool(l));
             PFM_TRY(chain(l));
+#endif
         } else {
             if (l) PFM_TRY(pool(l));
             PFM_TRY(linear(p, B, Pin, ldp, 256, Qst(l), 2 * Hp, 256 + 2 * Hp, L.g1, Hp, nullptr, 0, 1, nullptr, 0, Pout + 256, ldp, 1));
@@ -817,11 +819,7 @@ extern "C" {
 
 int64_t pfm_ew_workspace_floats(const pfm_ew_desc* d, int32_t n_jets, int32_t train) {
     if (ew::validate(d)) return -1;
-    const int n = n_jets < 1 ? 1 : n_jets;
-    const int64_t whole = ew::make_ws(*d, n, train != 0).total;
-    if (train || n < 2) return whole;
-    const int64_t halves = ew::make_ws(*d, n / 2, false).total + ew::make_ws(*d, n - n / 2, false).total;  // two-stream samplers
-    return whole > halves ? whole : halves;
+    return ew::make_ws(*d, n_jets < 1 ? 1 : n_jets, train != 0).total;
 }
 
 int pfm_ew_forward(const pfm_ew_desc* d, const float* blob, const float* t, int32_t t_stride, const float* x,
@@ -841,58 +839,58 @@ int pfm_ew_forward(const pfm_ew_desc* d, const float* blob, const float* t, int3
 int pfm_ew_sample_midpoint(const pfm_ew_desc* d, const float* blob, const float* t_eval, const float* dt,
                            int32_t n_steps, const float* z, const float* cond, const float* mask, float* x_out,
                            int32_t n_jets, int32_t premask, float* state, float* workspace, void* stream) {
-    int rc = ew::validate(d);
+    ew::Plan p;
+    int rc = ew::make_plan(p, d, blob, workspace, n_jets, false, stream);
     if (rc) return rc;
     if (n_jets <= 0) return 0;
     if (!blob || !t_eval || !dt || !z || !x_out || !state || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (n_steps < 0) return set_err(PFM_E_BADARG, "n_steps < 0");
     if (d->cond_global > 0 && !cond) return set_err(PFM_E_BADARG, "cond_global > 0 but cond is NULL");
-    // Two half-batches on two streams, their launches interleaved evaluation by evaluation (tf_common.h: side_stream)
-    const int n_a = split_point(n_jets, 32);
-    SideStream* ss = n_a ? side_stream((hipStream_t)stream) : nullptr;
-    const int parts = ss ? 2 : 1;
-    ew::Plan p[2];
-    float *xs[2], *xm[2];
-    const float *cnd[2], *msk[2];
-    int64_t n[2], r0[2];
-    // both halves run on the two side streams of this caller stream (never on one hardware queue together); the caller's stream forks and joins
-    if (ss && (hipEventRecord(ss->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess ||
-               hipStreamWaitEvent(ss->s2, ss->fork, 0) != hipSuccess))
-        return set_err(PFM_E_BADARG, "side stream fork failed");
-    // everything between fork and join: an error return still joins (the caller stream must not overtake the side streams' work)
-    rc = [&]() -> int {
-        int rc = 0;
-        for (int i = 0; i < parts; ++i) {
-            const int j0 = i ? n_a : 0, nj = parts == 1 ? n_jets : (i ? n_jets - n_a : n_a);
-            float* ws = workspace + (i ? ew::make_ws(*d, n_a, false).total : 0);
-            if ((rc = ew::make_plan(p[i], d, blob, ws, nj, false, ss ? (void*)(i ? ss->s2 : ss->s) : stream))) return rc;
-            if (p[i].temb_k) p[i].temb_k = 2 * n_steps;  // t_eval = the embedding table [T][2 n_steps]: evaluation e starts at t_eval + e
-            r0[i] = (int64_t)j0 * d->n_points;
-            n[i] = (int64_t)p[i].M * d->features;
-            xs[i] = state + 2 * r0[i] * d->features;
-            xm[i] = xs[i] + n[i];
-            cnd[i] = cond ? cond + (int64_t)j0 * d->cond_global : nullptr;
-            msk[i] = mask ? mask + r0[i] : nullptr;
-            hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n[i] + 255) / 256)), dim3(256), 0, p[i].s, z + r0[i] * d->features,
-                               premask ? msk[i] : nullptr, xs[i], n[i], d->features);
-            if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
-            if (mask && (rc = ew::setup_compaction(p[i], msk[i]))) return rc;
-        }
-        for (int k = 0; k < n_steps; ++k)
-            for (int stage = 0; stage < 2; ++stage)
-                for (int i = 0; i < parts; ++i) {
-                    ew::HeadArgs h{};
-                    h.base = xs[i]; h.dt = dt + k; h.coef = stage ? 1.0f : 0.5f; h.dst = stage ? xs[i] : xm[i];
-                    if ((rc = ew::run_nfe(p[i], t_eval + 2 * k + stage, 0, stage ? xm[i] : xs[i], cnd[i], msk[i], h))) return rc;
-                }
-        for (int i = 0; i < parts; ++i)
-            if ((rc = check_hip(hipMemcpyAsync(x_out + r0[i] * d->features, xs[i], n[i] * sizeof(float), hipMemcpyDeviceToDevice, p[i].s),
-                                "copy x_out")))
-                return rc;
-        return 0;
-    }();
-    side_join(ss, (hipStream_t)stream);
-    return rc;
+    if (p.temb_k) p.temb_k = 2 * n_steps;  // t_eval = the embedding table [T][2 n_steps]: evaluation e starts at t_eval + e
+    // (Rounds 1-2 ran a call as two half-batches on two side streams.  With the per-jet chain on 16-jet MFMA tiles the halves fall into
+    // lockstep -- both in their chains, then both in their particle Linears -- and one stream with 64-output workgroups is faster:
+    // tests/diag/ew_sweep.sh, 256 jets x 100 steps, two calls in flight: 400 ms per call against 480-536 ms split.)
+    const int64_t n = (int64_t)p.M * d->features;
+    float *xs = state, *xm = state + n;
+    hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : nullptr, xs, n,
+                       d->features);
+    if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch"))) return rc;
+    if (mask && (rc = ew::setup_compaction(p, mask))) return rc;
+    // evaluation `stage` of a step, its time and step size behind the given addresses
+    auto eval = [&](int stage, const float* t, const float* h_dt) -> int {
+        ew::HeadArgs h{};
+        h.base = xs; h.dt = h_dt; h.coef = stage ? 1.0f : 0.5f; h.dst = stage ? xs : xm;
+        return ew::run_nfe(p, t, 0, stage ? xm : xs, cond, mask, h);
+    };
+    int k = 0;
+    // Graph replay of the step body (tf_common.h: step_args_kernel): a step is ~210 launches of 5-45 us and the host needs ~9 us to
+    // enqueue each (tests/diag/ew_host_rate.py: 370 ms of enqueueing for a 100-step sample of 256 jets) -- the enqueueing thread would
+    // set the pace.  Step 0 runs directly (lazy first-launch work stays outside the capture); the body is captured once with its three
+    // scalars behind a slot and replayed.  Not for the legacy stream, short solves, or a caller-supplied embedding table (addressed
+    // through t_eval itself).  PFM_EW_GRAPH=0: direct launches (diagnostics).
+    static const bool graph_on = [] { const char* e = getenv("PFM_EW_GRAPH"); return !e || atoi(e) != 0; }();
+    ParkedGraph* gs = (graph_on && n_steps > 3 && !p.temb_k && p.s != nullptr) ? park_graph(p.s) : nullptr;
+    if (gs) {
+        for (int stage = 0; stage < 2; ++stage)
+            if ((rc = eval(stage, t_eval + stage, dt))) return rc;
+        float* slot = p.ws + p.w.step;
+        if ((rc = check_hip(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(slot + 4), 1, 1, p.s), "step counter"))) return rc;
+        if ((rc = check_hip(hipStreamBeginCapture(p.s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture"))) return rc;
+        hipLaunchKernelGGL(step_args_kernel, dim3(1), dim3(1), 0, p.s, t_eval, dt, slot);
+        rc = eval(0, slot, slot + 2);
+        if (rc == 0) rc = eval(1, slot + 1, slot + 2);
+        const hipError_t ce = hipStreamEndCapture(p.s, &gs->graph);  // always end the capture, also after a failed launch
+        if (rc == 0) rc = check_hip(ce, "hipStreamEndCapture");
+        if (rc == 0) rc = check_hip(hipGraphInstantiate(&gs->exec, gs->graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+        for (k = 1; rc == 0 && k < n_steps; ++k) rc = check_hip(hipGraphLaunch(gs->exec, p.s), "hipGraphLaunch");
+        const hipError_t re = hipEventRecord(gs->done, p.s);  // behind the last launch: park_graph's retire waits for it
+        if (rc == 0) rc = check_hip(re, "hipEventRecord (graph replay)");
+        if (rc) return rc;
+    }
+    for (; k < n_steps; ++k)
+        for (int stage = 0; stage < 2; ++stage)
+            if ((rc = eval(stage, t_eval + 2 * k + stage, dt + k))) return rc;
+    return check_hip(hipMemcpyAsync(x_out, xs, n * sizeof(float), hipMemcpyDeviceToDevice, p.s), "copy x_out");
 }
 
 static int ew_sample_rk(const pfm_ew_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,

@@ -305,6 +305,7 @@ struct LinArgs {
     int diag = 0;       // tests/diag/tf_panel_stamps.py: this launch records s_memtime stamps of wave 0 of every 8th workgroup
 #endif
     int pre_act = 0;    // 1: the input rows pass through LeakyReLU(slope) on their way into LDS (MDMA: fc0(act(x)), mdma.py:65)
+    int bn = BN;        // outputs per workgroup: BN (two 16-output operands per wave) or 64 (one): see launch_linear_kernel
 };
 
 // row statistics of a BM-row tile: 16 lanes per row, two-pass (mean, then centred sum of squares)
@@ -373,7 +374,7 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
     const int tid = threadIdx.x, lane = tid & 63, pl = lane & 15, q = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the weight-block offsets below become SGPR offsets of the buffer loads
     const int row0 = rt * RB;
-    const int ob = ch * BN + 16 * NS * w;  // this wave: outputs [ob, ob + 16 NS) as NS 16-row A operands
+    const int ob = ch * a.bn + 16 * NS * w;  // this wave: outputs [ob, ob + 16 NS) as NS 16-row A operands
     const blob_rsrc rs = make_blob_rsrc(a.blob, a.blob_floats);
     // NO is a multiple of 32: in a partial last column chunk the waves past NO only help staging
     const bool active = ob < a.NO;
@@ -606,12 +607,12 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int rt, ch;
     const int ks = a.ksplit > 1 ? blockIdx.x % a.ksplit : 0;
-    if (!tile_of_block(a.ksplit > 1 ? blockIdx.x / a.ksplit : blockIdx.x, a.row_tiles, (a.NO + BN - 1) / BN, rt, ch)) return;
+    if (!tile_of_block(a.ksplit > 1 ? blockIdx.x / a.ksplit : blockIdx.x, a.row_tiles, (a.NO + a.bn - 1) / a.bn, rt, ch)) return;
     if (a.m_dev) {
         a.M = *a.m_dev;
         if (rt * 16 * TPW >= a.M) return;
     }
-    if (a.NO - ch * BN <= 64) tf_linear_body<NI, TPW, MODE, 1>(a, lds, rt, ch, ks);
+    if (a.NO - ch * a.bn <= 64 || a.bn == 64) tf_linear_body<NI, TPW, MODE, 1>(a, lds, rt, ch, ks);
     else tf_linear_body<NI, TPW, MODE, 2>(a, lds, rt, ch, ks);
 }
 
@@ -1245,9 +1246,13 @@ inline int launch_linear_kernel(LinArgs& a, int ni, int mode, int cus, hipStream
             return 0;
         }
     }
-    const int rb = pick_row_tile(a.M, chunks * a.ksplit, cus, !x3);
+    static int bn_env = -1;
+    if (bn_env < 0) { const char* e = getenv("PFM_TF_BN"); bn_env = e ? atoi(e) : 0; }  // diagnostics only (tests/diag): 64 or 128
+    if (bn_env == 64 || bn_env == BN) a.bn = bn_env;
+    const int chunks_bn = (a.NO + a.bn - 1) / a.bn;
+    const int rb = pick_row_tile(a.M, chunks_bn * a.ksplit, cus, !x3 && a.bn == BN);
     a.row_tiles = (a.M + rb - 1) / rb;
-    const int grid = ((a.row_tiles + 7) / 8) * 8 * chunks * a.ksplit;
+    const int grid = ((a.row_tiles + 7) / 8) * 8 * chunks_bn * a.ksplit;
     const size_t lds = x3 ? (size_t)rb * X3ROW * 2 * 2 * 2 + 2 * rb * sizeof(float) : (size_t)(rb * 128 + 2 * rb) * sizeof(float);
 #define PFM_LAUNCH_LIN(NI)                                                                                  \
     if (mode == 2) {                                                                                        \
