@@ -85,6 +85,13 @@ int pfm_ew_fm_loss_backward(const pfm_ew_desc *desc, const float *blob, const fl
                             const float *u, const float *v, const float *gscale, float *gblob, int32_t n_jets,
                             float *workspace, float *scratch, void *stream);
 
+/* pfm_ew_fm_loss_backward that also returns grad_y[n_jets][N][F] = d(loss)/d(y) * gscale, the gradient w.r.t. the network's particle input
+ * (through fc_l1's particle columns): what a chain of flows needs (n_transforms > 1, flow_matching_module.py:421-443; losses.py:66-69 feeds
+ * each flow's output to the next); see pfm_epic_fm_loss_backward_dx in pfm_hip.h. */
+int pfm_ew_fm_loss_backward_dx(const pfm_ew_desc *desc, const float *blob, const float *mask, const float *y, const float *u,
+                               const float *v, const float *gscale, float *gblob, float *grad_y, int32_t n_jets, float *workspace,
+                               float *scratch, void *stream);
+
 /* PFM_EW_F_TEMB_GIVEN: dtemb[n_jets][t_dim] = d(loss)/d(temb) * gscale of the pfm_ew_fm_loss_backward call that has just filled `scratch`
  * (same descriptor and n_jets): the time columns of every per-jet Linear (fc_l1 / fc_l2 / fc_l3 biases, fc_g1 / fc_g2 and, per layer,
  * fc_global1 / fc_global2 / fc_local1 / fc_local2), summed in launch order. */

@@ -747,10 +747,14 @@ def gen_diffusion_rows(ref, prefix, out_dir, B=3):
 CHAIN_HP = dict(BASE, num_particles=30, layers=2, global_cond_dim=2, local_cond_dim=2)
 
 
-def gen_chain(ref, out_dir, B=4, seed=1212):
+# the same two-flow chain at a width the jet-resident kernel does not take (hidden 136 -> the row-matrix path, padded to 192)
+CHAIN_WIDE_HP = dict(CHAIN_HP, hidden_dim=136, layers=1, num_particles=24, latent=12)
+
+
+def gen_chain(ref, out_dir, B=4, seed=1212, hp=None, file_name="epic_chain2.npz"):
     import json
 
-    hp = CHAIN_HP
+    hp = hp or CHAIN_HP
     gen = torch.Generator().manual_seed(seed + 1)
     cnfs = []
     for i in range(2):
@@ -804,7 +808,7 @@ def gen_chain(ref, out_dir, B=4, seed=1212):
                 xe = midpoint_trajectory_end(lambda tt, xx: c(tt, xx, mask=mask, cond=cond), xe, torch.linspace(1.0, 0.0, steps))
             tag = f"midpoint_{steps}/"
             out[tag + "z"], out[tag + "mask"], out[tag + "cond"], out[tag + "x_end"] = z.numpy(), mask.numpy(), cond.numpy(), xe.numpy()
-    path = os.path.join(out_dir, "epic_chain2.npz")
+    path = os.path.join(out_dir, file_name)
     np.savez(path, **out)
     print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
 
@@ -843,7 +847,7 @@ def gen_norm_layer(ref, out_dir, seed=97531):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,diffusion_rows,chain,norm}; default all")
+    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,diffusion_rows,chain,chain_wide,norm}; default all")
     ap.add_argument("--names", default="", help="with --only epic / wide / tf / ca: comma list of configuration names (default all)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -862,6 +866,8 @@ def main():
         gen_norm_layer(ref, args.out)
     if ap2 is None or "chain" in ap2:
         gen_chain(ref, args.out)
+    if ap2 is None or "chain_wide" in ap2:
+        gen_chain(ref, args.out, B=3, seed=3434, hp=CHAIN_WIDE_HP, file_name="epic_chain2w.npz")
     for prefix in DIFF_ROWS_CONFIGS:
         if ap2 is None or "diffusion_rows" in ap2:
             gen_diffusion_rows(ref, prefix, args.out)

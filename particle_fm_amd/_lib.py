@@ -89,6 +89,7 @@ SYMBOLS = {
         c_int, [POINTER(EwDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_ew_backward_scratch_floats": (c_int64, [POINTER(EwDesc), c_int32]),
     "pfm_ew_backward_dtemb": (c_int, [POINTER(EwDesc), _fp, c_int32, _fp, c_void_p]),
+    "pfm_ew_fm_loss_backward_dx": (c_int, [POINTER(EwDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
     "pfm_ew_diffusion_loss_forward": (
         c_int, [POINTER(EwDesc), _fp, c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_ew_diffusion_loss_backward": (

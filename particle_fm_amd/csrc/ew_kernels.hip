@@ -611,6 +611,29 @@ __global__ __launch_bounds__(256) void ew_temb_acc_kernel(const float* __restric
     if (i < n) acc[i] += dP[(i / T) * ld + i % T];
 }
 
+// d loss / d y[row][f] = sum_h dZ1[row][h] * Wl1x[f][h] (fc_l1's particle columns, KMAJOR [F][Hp]): 16 lanes per row, 16 rows per workgroup
+__global__ __launch_bounds__(256) void ew_dy_kernel(const float* __restrict__ dZ1, const float* __restrict__ blob, int64_t l1x,
+                                                    float* __restrict__ dy, int64_t M, int F, int Hp) {
+    const int tid = threadIdx.x, pl = tid & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (tid >> 4);
+    if (row >= M) return;  // (whole 16-lane groups leave together: the DPP row sums below stay inside a group)
+    float acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) acc[f] = 0.f;
+    for (int h = 4 * pl; h < Hp; h += 64) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dZ1 + row * Hp + h);
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+            if (f < F) acc[f] += hsum4(g * *reinterpret_cast<const f32x4*>(blob + l1x + (int64_t)f * Hp + h));
+    }
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+        if (f < F) {
+            const float s = row_sum16(acc[f]);
+            if (pl == 0) dy[row * F + f] = s;
+        }
+}
+
 struct Bs {
     int64_t dX, dZ, dT, dpre, DJB, DSJB, dPj, dP2, dP1, dG, dZg2, dZg1, zeros, dwpart, dtemb, total;
 };
@@ -686,7 +709,7 @@ struct Bwd {
 };
 
 int run_backward(const Bwd& W, const float* mask, const float* y, const float* u, const float* v, const float* gscale,
-                 int crit = 0, const float* jet_w = nullptr) {
+                 int crit = 0, const float* jet_w = nullptr, float* dy = nullptr) {
     const Plan& p = W.p;
     const pfm_ew_desc& d = *p.d;
     const Ws& w = p.w;
@@ -772,6 +795,10 @@ int run_backward(const Bwd& W, const float* mask, const float* y, const float* u
     PFM_TRY(W.dw(M, dZ, Hp, Hp, X1, Hp, Hp, nullptr, 0, Hp, d.l2.W));
     PFM_TRY(W.dx(M, dZ, Hp, Hp, d.l2, Hp, dZ, Hp, X1, Hp, dT, Hp));                                           // (dZ W + dZ) lrelu'(X1)
     PFM_TRY(W.colsum(dT, Hp, Hp, M, N, nullptr, 0, DSJB, sjbs, -1));
+    if (dy) {  // the gradient w.r.t. the particle input (a chain of flows, n_transforms > 1: the next flow's backward starts from it)
+        hipLaunchKernelGGL(ew_dy_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, p.s, (const float*)dT, p.blob, d.l1x, dy, (int64_t)M, F, Hp);
+        PFM_TRY(check_hip(hipGetLastError(), "ew_dy_kernel launch"));
+    }
     {
         ColsumArgs a;  // d fc_l1 particle columns [F][Hp] = sum_rows y[row][f] dZ1[row][:]
         a.Z = dT; a.X = y; a.jet_out = nullptr; a.gblob = W.gblob; a.gb = d.l1x; a.jet_stride = 0; a.ldz = Hp; a.NO = Hp; a.N = N; a.F = F; a.rows = 0;
@@ -989,7 +1016,7 @@ int64_t pfm_ew_backward_scratch_floats(const pfm_ew_desc* d, int32_t n_jets) {
 
 static int ew_loss_backward(const pfm_ew_desc* d, const float* blob, const float* mask, const float* y, const float* u,
                             const float* v, const float* gscale, float* gblob, int32_t n_jets, float* workspace,
-                            float* scratch, void* stream, int crit, const float* jet_w) {
+                            float* scratch, void* stream, int crit, const float* jet_w, float* dy = nullptr) {
     ew::Bwd W;
     int rc = ew::make_plan(W.p, d, blob, workspace, n_jets, true, stream);
     if (rc) return rc;
@@ -1005,13 +1032,20 @@ static int ew_loss_backward(const pfm_ew_desc* d, const float* blob, const float
     if ((d->flags & PFM_EW_F_TEMB_GIVEN) &&
         (rc = check_hip(hipMemsetAsync(scratch + W.b.dtemb, 0, (size_t)n_jets * d->t_dim * sizeof(float), (hipStream_t)stream), "memset dtemb")))
         return rc;
-    return ew::run_backward(W, mask, y, u, v, gscale, crit, jet_w);
+    return ew::run_backward(W, mask, y, u, v, gscale, crit, jet_w, dy);
 }
 
 int pfm_ew_fm_loss_backward(const pfm_ew_desc* d, const float* blob, const float* mask, const float* y, const float* u,
                             const float* v, const float* gscale, float* gblob, int32_t n_jets, float* workspace,
                             float* scratch, void* stream) {
     return ew_loss_backward(d, blob, mask, y, u, v, gscale, gblob, n_jets, workspace, scratch, stream, 0, nullptr);
+}
+
+int pfm_ew_fm_loss_backward_dx(const pfm_ew_desc* d, const float* blob, const float* mask, const float* y, const float* u,
+                               const float* v, const float* gscale, float* gblob, float* grad_y, int32_t n_jets, float* workspace,
+                               float* scratch, void* stream) {
+    if (!grad_y) return set_err(PFM_E_BADARG, "grad_y is NULL");
+    return ew_loss_backward(d, blob, mask, y, u, v, gscale, gblob, n_jets, workspace, scratch, stream, 0, nullptr, grad_y);
 }
 
 int pfm_ew_backward_dtemb(const pfm_ew_desc* d, const float* scratch, int32_t n_jets, float* dtemb, void* stream) {

@@ -101,7 +101,7 @@ def mdma_field(layout, flat_params, t, x, mask, freqs: Optional[torch.Tensor] = 
 class EpicWideFieldFn(torch.autograd.Function):
     """Wide (row-matrix) EPiC field over the layout's source vector (autograd continues through the weight-norm reparametrisation).
     ``t``: the times (B,), or -- a layout with t_emb="gaussian" (PFM_EW_F_TEMB_GIVEN) -- the time EMBEDDING rows (B, T), then a
-    differentiable input (pfm_ew_backward_dtemb)."""
+    differentiable input (pfm_ew_backward_dtemb).  Also differentiable w.r.t. the particle input x (pfm_ew_fm_loss_backward_dx): chains."""
 
     @staticmethod
     def forward(ctx, src, layout, x, t, cond, mask):
@@ -116,14 +116,15 @@ class EpicWideFieldFn(torch.autograd.Function):
     def backward(ctx, G):
         from .fm_loss_wide import _maps
         lay = ctx.layout
-        gblob = hip_ops_wide.ew_fm_loss_backward(lay, ctx.blob, _upstream(ctx.saved, G.contiguous()), torch.ones((), device=G.device))
+        d_x = torch.empty_like(G) if ctx.needs_input_grad[2] else None
+        gblob = hip_ops_wide.ew_fm_loss_backward(lay, ctx.blob, _upstream(ctx.saved, G.contiguous()), torch.ones((), device=G.device), d_y=d_x)
         gpos = _maps(lay, gblob.device)[1]
         d_src = torch.zeros(ctx.n_source, device=gblob.device, dtype=torch.float32)
         d_src[: gpos.numel()] = gblob[gpos]
         d_t = None
         if ctx.temb_shape is not None and ctx.needs_input_grad[3]:
             d_t = hip_ops_wide.ew_backward_dtemb(lay, G.shape[0], G.device).reshape(ctx.temb_shape)
-        return (d_src, None, None, d_t, None, None)
+        return (d_src, None, d_x, d_t, None, None)
 
 
 def epic_wide_field(layout, src, t, x, cond=None, mask=None):

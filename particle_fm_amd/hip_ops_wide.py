@@ -159,9 +159,10 @@ def ew_diffusion_loss_forward(layout: EpicWideLayout, blob, x, t, z, rates, jet_
     return sums, (y, u, v, ws, mask)
 
 
-def ew_fm_loss_backward(layout: EpicWideLayout, blob, saved, gscale: torch.Tensor, criterion=None, jet_w=None) -> torch.Tensor:
+def ew_fm_loss_backward(layout: EpicWideLayout, blob, saved, gscale: torch.Tensor, criterion=None, jet_w=None, d_y=None) -> torch.Tensor:
     """Gradient blob (layout.blob_total floats); gscale: 0-dim device tensor grad_output / sum(mask).
-    criterion / jet_w: the diffusion loss's (None: the flow-matching losses)."""
+    criterion / jet_w: the diffusion loss's (None: the flow-matching losses).  d_y: (B, N, F) tensor that receives d loss / d y * gscale
+    (pfm_ew_fm_loss_backward_dx; flow-matching losses only)."""
     lib = _lib.load()
     y, u, v, ws, mask = saved
     dev, B = y.device, y.shape[0]
@@ -179,6 +180,11 @@ def ew_fm_loss_backward(layout: EpicWideLayout, blob, saved, gscale: torch.Tenso
                                                 _ptr(mask), _ptr(y), _ptr(u), _ptr(v), _ptr(gs), _ptr(gblob), B, _ptr(ws),
                                                 _ptr(cache[key]), _stream_ptr(dev))
         _lib.check(rc, "pfm_ew_diffusion_loss_backward")
+        return gblob
+    if d_y is not None:
+        rc = lib.pfm_ew_fm_loss_backward_dx(ctypes.byref(layout.desc), _ptr(blob), _ptr(mask), _ptr(y), _ptr(u), _ptr(v), _ptr(gs),
+                                            _ptr(gblob), _ptr(d_y), B, _ptr(ws), _ptr(cache[key]), _stream_ptr(dev))
+        _lib.check(rc, "pfm_ew_fm_loss_backward_dx")
         return gblob
     rc = lib.pfm_ew_fm_loss_backward(ctypes.byref(layout.desc), _ptr(blob), _ptr(mask), _ptr(y), _ptr(u), _ptr(v), _ptr(gs),
                                      _ptr(gblob), B, _ptr(ws), _ptr(cache[key]), _stream_ptr(dev))

@@ -330,12 +330,15 @@ class CNF(nn.Module):
 
     def field(self, t, x, cond=None, mask=None) -> Tensor:
         """v = f(t, x), differentiable w.r.t. the parameters AND the particle input x: what a chain of flows (n_transforms > 1) is
-        built from (losses._chained_loss).  Jet-resident EPiC kernels only (pfm_epic_fm_loss_backward_dx returns d / d x)."""
-        if self.is_transformer or self.is_cross_attention or self.is_mdma or self.t_emb == "gaussian" or self.net.is_wide(x.shape[1]):
-            raise NotImplementedError("n_transforms > 1 has a HIP path for model='epic' at hidden_dim 128 with sets that fit the "
-                                      "jet-resident kernel (cosine / sincos time embedding): no other kernel returns d loss / d input")
+        built from (losses._chained_loss).  EPiC kernels only (pfm_epic_fm_loss_backward_dx / pfm_ew_fm_loss_backward_dx return d / d x)."""
+        if self.is_transformer or self.is_cross_attention or self.is_mdma or self.t_emb == "gaussian":
+            raise NotImplementedError("n_transforms > 1 has a HIP path for model='epic' (cosine / sincos time embedding): no other "
+                                      "kernel returns d loss / d input")
+        tt = self._per_jet_time(t, x).to(x.device, torch.float32)
         lay = self.net.layout(x.shape[1])
-        return _fm_field.epic_field(lay, self.net.source_vector(lay), self._per_jet_time(t, x).to(x.device, torch.float32), x, cond, mask)
+        if self.net.is_wide(x.shape[1]):
+            return _fm_field.epic_wide_field(lay, self.net.source_vector(lay), tt, x, cond, mask)
+        return _fm_field.epic_field(lay, self.net.source_vector(lay), tt, x, cond, mask)
 
     def _field_rows(self, t, x, cond, mask):
         """v = f(t, x) of the transformer / cross-attention / MDMA / row-matrix EPiC model as a differentiable function of the

@@ -1,7 +1,8 @@
 """n_transforms = 2 (flow_matching_module.py:421-443): two EPiC flows.  The losses feed the first flow's output to the second at the same
 time t (losses.py:66-69, 125-128), sampling decodes through the flows in reverse order (:485-487).  No fused loss kernel for a chain:
 every flow is the differentiable field of fm_field.py, whose backward (pfm_epic_fm_loss_backward_dx) returns the gradient w.r.t. the
-parameters and w.r.t. the particle input.  Against vectors recorded from the reference (tests/golden/epic_chain2.npz)."""
+parameters and w.r.t. the particle input.  Against vectors recorded from the reference (tests/golden/epic_chain2.npz; epic_chain2w.npz: the
+same chain at hidden 136, i.e. on the row-matrix EPiC kernels, pfm_ew_fm_loss_backward_dx)."""
 import copy
 
 import pytest
@@ -24,11 +25,13 @@ def _module(g):
     return m
 
 
-def test_field_gradient_wrt_input_matches_the_oracle():
+@pytest.mark.parametrize("fixture", ["chain2", "chain2w"])
+def test_field_gradient_wrt_input_matches_the_oracle(fixture):
     """d <G, f(t, x)> / d x and / d parameters of ONE flow against the oracle's autograd (the piece the chain is built from)."""
     from oracle.fm_ref import EpicVectorField
-    g = load_golden("chain2")
+    g = load_golden(fixture)
     m = _module(g)
+    assert m.flows[1].net.is_wide(g.hp["num_particles"]) == (fixture == "chain2w")
     tag = "loss_fm/"
     x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))
     gen = torch.Generator().manual_seed(3)
@@ -52,9 +55,10 @@ def test_field_gradient_wrt_input_matches_the_oracle():
         assert float((got - p.grad).norm()) <= 5e-4 * float(p.grad.norm()) + 1e-6, k
 
 
+@pytest.mark.parametrize("fixture", ["chain2", "chain2w"])
 @pytest.mark.parametrize("name", ["fm", "cfm"])
-def test_chained_loss_and_all_parameter_gradients(name):
-    g = load_golden("chain2")
+def test_chained_loss_and_all_parameter_gradients(name, fixture):
+    g = load_golden(fixture)
     m = _module(g)
     assert len(m.flows) == 2
     tag = f"loss_{name}/"
@@ -72,11 +76,12 @@ def test_chained_loss_and_all_parameter_gradients(name):
         if not rel < 1e-3:
             bad.append((k, rel))
     assert not bad, bad[:8]
-    assert len(g.grads(tag)) == 2 * 39  # every parameter of both flows
+    assert len(g.grads(tag)) == 2 * len(list(m.flows[0].parameters()))  # every parameter of both flows
 
 
-def test_training_step_and_sampling_through_both_flows():
-    g = load_golden("chain2")
+@pytest.mark.parametrize("fixture", ["chain2", "chain2w"])
+def test_training_step_and_sampling_through_both_flows(fixture):
+    g = load_golden(fixture)
     m = _module(g)
     tag = "loss_fm/"
     x, mask, cond = (g.get(tag + k).cuda() for k in ("x", "mask", "cond"))

@@ -115,12 +115,14 @@ def test_weight_norm_rowwise():
     torch.testing.assert_close(wn_linear(st, "l", x), lin(x).detach())
 
 
-def test_chained_flows_fixture_is_reproduced_by_the_oracle():
-    """tests/golden/epic_chain2.npz (n_transforms = 2, flow_matching_module.py:421-443): the oracle's field composed as the reference's
-    losses compose it (losses.py:66-69) reproduces the recorded FM-OT loss and the reverse-order midpoint samples."""
+@pytest.mark.parametrize("fixture", ["chain2", "chain2w"])
+def test_chained_flows_fixture_is_reproduced_by_the_oracle(fixture):
+    """tests/golden/epic_chain2.npz, epic_chain2w.npz (n_transforms = 2, flow_matching_module.py:421-443; hidden 128 / 136): the oracle's
+    field composed as the reference's losses compose it (losses.py:66-69) reproduces the recorded FM-OT loss and the reverse-order
+    midpoint samples."""
     from oracle.fm_ref import EpicVectorField, fm_ot_targets, midpoint_trajectory_end
     from tests.conftest import load_golden
-    g = load_golden("chain2")
+    g = load_golden(fixture)
     vfs = [EpicVectorField(g.state, f"flows.{i}.net", g.hp, freqs=g.freqs) for i in range(2)]
     tag = "loss_fm/"
     x, t, z, mask, cond = (g.get(tag + k) for k in ("x", "t", "a", "mask", "cond"))
