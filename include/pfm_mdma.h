@@ -12,9 +12,12 @@
  * (fc1 on cat(particle, token) + residual).  The head is Linear(hidden, 1): the field has ONE output per particle, which
  * the reference's loss and solver broadcast over the features -- `v_out` below is that broadcast, [n_jets][N][F].
  *
- * Built: t_local_cat = t_global_cat = local_cat_cond = global_cat_cond = False, net_config.global_cond_dim = 0 (the
- * shipped yaml); hidden a multiple of 128 (<= 512) with head_dim = hidden / num_heads in {8, 16}; latent a multiple of 4
- * (<= 64).  `cond` is not an argument: with these switches MDMA.forward never reads it.
+ * Built: local_cat_cond = global_cat_cond = False, net_config.global_cond_dim = 0 (the shipped yaml); t_local_cat / t_global_cat
+ * either way (desc.t_cat: the yaml has them off, MDMA.__init__'s own defaults on, mdma.py:101-102): the time embedding is the same
+ * for every particle of a jet, so behind a particle Linear (embed, Block.fc0) its columns are a per-jet bias row (mdma_time_kernel),
+ * behind a class-token Linear (fc0_cls, fc1_cls, fc2_cls) extra rows of the per-jet GEMV; hidden a multiple of 128 (<= 512) with
+ * head_dim = hidden / num_heads in {8, 16}; latent a multiple of 4 (<= 64).  `cond` is not an argument: with these switches
+ * MDMA.forward never reads it.
  *
  * Weight formats (float offsets into one blob, gathered from the state_dict by particle_fm_amd/layout_mdma.py):
  *   MFMA_AK / MFMA_AKT: as include/pfm_tf.h.  KMAJOR [K][NO]: element (k, o) at k * NO + o.
@@ -31,21 +34,21 @@
 extern "C" {
 #endif
 
-#define PFM_MDMA_ABI_VERSION 1
+#define PFM_MDMA_ABI_VERSION 2
 #define PFM_MDMA_MAX_LAYERS 16
 #define PFM_MDMA_F_BF16 32u /* bf16 operands in the particle-stream Linears (forward and dX), see PFM_TF_F_BF16 (pfm_tf.h) */
 #define PFM_MDMA_F_TEMB_SINCOS 2u /* t_emb = "sincos" (flow_matching_module.py:208-211) instead of "cosine" */
 
 typedef struct {
-    pfm_tf_lin fc0;     /* Block.fc0      [H][H] MFMA_AK (+ WT) */
+    pfm_tf_lin fc0;     /* Block.fc0 columns 0..H [H][H] MFMA_AK (+ WT); Wt = its time columns H..H+T KMAJOR [T][H] (t_local, else -1) */
     pfm_tf_lin kv;      /* attn.in_proj rows H..3H (k | v) [2H][H] MFMA_AK (+ WT), bias in_proj_bias[H..3H] */
     pfm_tf_lin fc1;     /* Block.fc1: W = columns 0..H MFMA_AK (+ WT); Wc = columns H..H+L KMAJOR [L][H]; b */
-    int64_t fc0c_W, fc0c_b; /* fc0_cls  KMAJOR [L][H], [H] */
+    int64_t fc0c_W, fc0c_b; /* fc0_cls  KMAJOR [L (+ T: t_global)][H], [H] */
     int64_t ln_g, ln_b;     /* ln       [H] */
     int64_t q_W, q_b;       /* attn.in_proj rows 0..H: KMAJOR [H][H], [H] */
     int64_t o_W, o_b;       /* attn.out_proj KMAJOR [H][H], [H] */
-    int64_t fc1c_W, fc1c_b; /* fc1_cls  KMAJOR [H + 1][L] (rows: attention output, particle count), [L] */
-    int64_t fc2c_W, fc2c_b; /* fc2_cls  KMAJOR [L][L], [L] */
+    int64_t fc1c_W, fc1c_b; /* fc1_cls  KMAJOR [H + 1 (+ T: t_global)][L] (rows: attention output, particle count, time embedding), [L] */
+    int64_t fc2c_W, fc2c_b; /* fc2_cls  KMAJOR [L (+ T: t_global)][L], [L] */
 } pfm_mdma_block;
 
 typedef struct {
@@ -59,7 +62,8 @@ typedef struct {
     int32_t t_dim;          /* 2 * frequencies of the CNF's time embedding (<= 64) */
     int32_t time_in_input;  /* add_time_to_input: the embedding Linear sees cat(temb, x) */
     uint32_t flags;
-    int32_t pad_;
+    int32_t t_cat;          /* bit 0: t_local_cat (the time embedding concatenated to the inputs of embed and of every Block.fc0), bit 1:
+                             * t_global_cat (to the class-token Linears fc0_cls, fc1_cls, fc2_cls); mdma.py:56-59, 71-78, 155-156 */
     float neg_slope; /* nn.LeakyReLU() default 0.01 */
     float ln_eps;
     float avg_n;     /* MDMA.avg_n: the particle sum is divided by it */
@@ -67,6 +71,7 @@ typedef struct {
     int64_t blob_floats;
     int64_t freqs;                  /* [t_dim] */
     int64_t emb_Wx, emb_Wt, emb_b;  /* MDMA.embed: KMAJOR [F][H], KMAJOR [t_dim][H] (-1 without time_in_input), [H] */
+    int64_t emb_Wt2;                /* MDMA.embed's trailing time columns KMAJOR [t_dim][H] (t_local, else -1) */
     int64_t ecls_W, ecls_b;         /* embbed_cls KMAJOR [H + 1][L], [L] */
     int64_t cond_W, cond_b;         /* MDMA.cond  KMAJOR [1][L], [L] */
     int64_t out_W, out_b;           /* MDMA.out   [H], [1] */

@@ -579,6 +579,13 @@ MDMA_CONFIGS = {
     "small": (dict(MDMA_BASE, num_particles=40, net_config=mdma_net_config(2)), 4, False),
     # the yaml's own sizes with experiment/jetnet/fm_mdma.yaml:27 (150 particles) and calo_challenge/fm_mdma.yaml:26 (4 features)
     "yaml": (dict(MDMA_BASE, num_particles=150, features=4, net_config=mdma_net_config(4)), 2, False),
+    # MDMA.__init__'s own defaults (mdma.py:101-102): the time embedding concatenated to the particle and to the class-token Linears
+    # (net_config.frequencies must then be the CNF's: the Linears are sized by it, the embedding by the CNF's)
+    "tcat": (dict(MDMA_BASE, num_particles=40, net_config=dict(mdma_net_config(2), frequencies=16, t_local_cat=True, t_global_cat=True)), 3, False),
+    "tloc": (dict(MDMA_BASE, num_particles=24, add_time_to_input=False, frequencies=6,
+                  net_config=dict(mdma_net_config(1), frequencies=6, t_local_cat=True, t_global_cat=False)), 3, False),
+    "tglob": (dict(MDMA_BASE, num_particles=24, add_time_to_input=False, frequencies=6, t_emb="sincos",
+                   net_config=dict(mdma_net_config(1), frequencies=6, t_local_cat=False, t_global_cat=True)), 3, False),
 }
 
 
@@ -848,7 +855,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
     ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,diffusion_rows,chain,chain_wide,norm}; default all")
-    ap.add_argument("--names", default="", help="with --only epic / wide / tf / ca: comma list of configuration names (default all)")
+    ap.add_argument("--names", default="", help="with --only epic / wide / tf / ca / mdma: comma list of configuration names (default all)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
@@ -881,7 +888,7 @@ def main():
         if (ap2 is None or "ca" in ap2) and (names is None or name in names):
             gen_transformer(ref, name, hp, B, store_all, args.out, seed=4048, file_prefix="ca")
     for name, (hp, B, store_all) in MDMA_CONFIGS.items():
-        if ap2 is None or "mdma" in ap2:
+        if (ap2 is None or "mdma" in ap2) and (names is None or name in names):
             gen_transformer(ref, name, hp, B, store_all, args.out, seed=6061, file_prefix="mdma")
 
 

@@ -3,7 +3,8 @@
 TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  PINNED: checked against vectors recorded from the reference's own
 modules (tests/golden/mdma_*.npz, written by oracle/make_golden.py).
 
-Follows (switches as shipped: t_local_cat = t_global_cat = local_cat_cond = global_cat_cond = False, global_cond_dim = 0):
+Follows (local_cat_cond = global_cat_cond = False, global_cond_dim = 0 as shipped; t_local_cat / t_global_cat either way -- the
+yaml has them False, MDMA.__init__'s own defaults are True: mdma.py:101-102, 56-59, 71-78, 155-156):
   * mdma.py:142-176  MDMA.forward: embed + LeakyReLU, padded particles zeroed, class token from (sum / avg_n, count) through
                      embbed_cls, gated (F.glu) by cond(count); the blocks; out(LeakyReLU(x)) * mask -- ONE output per particle
   * mdma.py:53-84    Block.forward: x = fc0(act(x)); x_cls = ln(fc0_cls(act(x_cls))); x_cls = attn(x_cls, x, x, padded keys masked);
@@ -45,23 +46,33 @@ def one_query_attention(state, key: str, q_in, kv_in, key_pad, num_heads: int):
     return _lin(state, key + ".out_proj", a)
 
 
-def mdma_block(state, key: str, x, x_cls, cond, mask_bool, num_heads: int):
-    """Block.forward (mdma.py:53-84); mask_bool (B,N,1)."""
+def mdma_block(state, key: str, x, x_cls, cond, mask_bool, num_heads: int, t_in=None, t_local: bool = False, t_global: bool = False):
+    """Block.forward (mdma.py:53-84); mask_bool (B,N,1); t_in (B,N,T) the time embedding (t_local_cat / t_global_cat)."""
     res = x
+    if t_local:  # :56-57 (the activation below covers the concatenated embedding too)
+        x = torch.cat((x, t_in), dim=-1)
+    if t_global:  # :58-59
+        x_cls = torch.cat((x_cls, t_in[:, :1, :]), dim=-1)
     x = _lin(state, key + ".fc0", F.leaky_relu(x, NEG_SLOPE))
     x_cls = F.layer_norm(_lin(state, key + ".fc0_cls", F.leaky_relu(x_cls, NEG_SLOPE)), (x.shape[-1],),
                          state[key + ".ln.weight"], state[key + ".ln.bias"], 1e-5)
     x_cls = one_query_attention(state, key + ".attn", x_cls, x, ~mask_bool.squeeze(-1), num_heads)
-    x_cls = _lin(state, key + ".fc1_cls", torch.cat((x_cls, cond), dim=-1))
+    x_cls = torch.cat((x_cls, cond) + ((t_in[:, :1, :],) if t_global else ()), dim=-1)  # :70-74
+    x_cls = _lin(state, key + ".fc1_cls", x_cls)
+    if t_global:  # :78
+        x_cls = torch.cat((x_cls, t_in[:, :1, :]), dim=-1)
     x_cls = _lin(state, key + ".fc2_cls", x_cls)
     x = _lin(state, key + ".fc1", torch.cat((x, x_cls.expand(-1, x.shape[1], -1)), dim=-1)) + res
     return x, x_cls
 
 
-def mdma_forward(state: Mapping[str, torch.Tensor], prefix: str, x, mask, *, num_layers: int, num_heads: int, avg_n: float):
+def mdma_forward(state: Mapping[str, torch.Tensor], prefix: str, x, mask, *, num_layers: int, num_heads: int, avg_n: float, t_in=None,
+                 t_local: bool = False, t_global: bool = False):
     """MDMA.forward (mdma.py:142-176) on the already time-concatenated input; returns (B, N, 1)."""
     p = prefix
     mb = mask.bool()
+    if t_local:  # :155-156
+        x = torch.cat((x, t_in), dim=-1)
     x = F.leaky_relu(_lin(state, p + "embed", x), NEG_SLOPE)
     x = x * mb.to(x.dtype)  # x[~mask] = 0
     n_valid = mask.sum(1, keepdim=True).reshape(-1, 1, 1).to(x.dtype)
@@ -70,7 +81,7 @@ def mdma_forward(state: Mapping[str, torch.Tensor], prefix: str, x, mask, *, num
     cond = n_valid
     x_cls = F.glu(torch.cat((x_cls, _lin(state, p + "cond", cond)), dim=-1))
     for l in range(num_layers):
-        x, x_cls = mdma_block(state, f"{p}encoder.{l}", x, x_cls, cond, mb, num_heads)
+        x, x_cls = mdma_block(state, f"{p}encoder.{l}", x, x_cls, cond, mb, num_heads, t_in, t_local, t_global)
     return _lin(state, p + "out", F.leaky_relu(x, NEG_SLOPE)) * mask
 
 
@@ -83,10 +94,12 @@ class MdmaVectorField:
     def __call__(self, t, x, cond=None, mask=None):
         hp = self.hp
         nc = hp.get("net_config") or {}
+        temb = time_embedding(t, x, hp, self.freqs)
         if hp.get("add_time_to_input", True):
-            x = torch.cat((time_embedding(t, x, hp, self.freqs), x), dim=-1)
+            x = torch.cat((temb, x), dim=-1)
         return mdma_forward(self.state, self.prefix + "net.", x, mask, num_layers=int(nc.get("layers", 16)),
-                            num_heads=int(nc.get("num_heads", 8)), avg_n=float(nc.get("avg_n", 30)))
+                            num_heads=int(nc.get("num_heads", 8)), avg_n=float(nc.get("avg_n", 30)), t_in=temb,
+                            t_local=bool(nc.get("t_local_cat", True)), t_global=bool(nc.get("t_global_cat", True)))
 
 
 def broadcast_field(vf):

@@ -39,6 +39,7 @@ int validate(const pfm_mdma_desc* d) {
     if (d->features < 1 || d->features > 16) return set_err(PFM_E_BADARG, "features must be in 1..16");
     if (d->t_dim < 0 || d->t_dim > 64) return set_err(PFM_E_BADARG, "t_dim out of range");
     if (d->time_in_input && d->t_dim < 1) return set_err(PFM_E_BADARG, "time_in_input needs t_dim >= 1");
+    if (d->t_cat < 0 || d->t_cat > 3 || (d->t_cat && d->t_dim < 1)) return set_err(PFM_E_BADARG, "t_cat must be 0..3 (and needs t_dim >= 1)");
     if (d->n_points < 1) return set_err(PFM_E_BADARG, "n_points must be >= 1");
     if (!(d->avg_n > 0.f)) return set_err(PFM_E_BADARG, "avg_n must be positive");
     return 0;
@@ -102,34 +103,52 @@ __device__ __forceinline__ float lrelu_d(float x, float slope) { return x > 0.f 
 // ------------------------------------------------------------------------------------------------
 // forward kernels
 // ------------------------------------------------------------------------------------------------
-// time embedding (time_emb.py:90-96 / flow_matching_module.py:208-211) and the per-jet bias of MDMA.embed:
-// jbt[jet][:] = b + Wt . temb   (x = cat(temb, x): the time columns are the same for every particle of a jet)
-static __global__ __launch_bounds__(128) void mdma_time_kernel(const float* __restrict__ blob, const float* __restrict__ t, int t_stride,
-                                                              int T, int sincos, int64_t freqs, int64_t Wt, int64_t b, int H,
-                                                              float* __restrict__ temb, float* __restrict__ jbt) {
-    __shared__ float te[64];
-    const int tid = threadIdx.x, jet = blockIdx.x;
+// time embedding (time_emb.py:90-96 / flow_matching_module.py:208-211) and the per-jet bias rows it gives the particle Linears:
+// jbt[jet][:] = b + Wt . temb   (MDMA.embed; x = cat(temb, x): the time columns are the same for every particle of a jet)
+struct TimeArgs {
+    const float *blob, *t;
+    float *temb, *tact, *jbt, *jb0;  // temb / tact [B][64]: the embedding and LeakyReLU of it; jbt [B][H]; jb0 [layers][B][H] (t_local)
+    int64_t freqs, Wt, Wt2, b, fc0_Wt[PFM_MDMA_MAX_LAYERS], fc0_b[PFM_MDMA_MAX_LAYERS];
+    int t_stride, T, sincos, H, layers, B;  // layers: 0 without t_local
+    float slope;
+};
+static __global__ __launch_bounds__(128) void mdma_time_kernel(TimeArgs a) {
+    __shared__ float te[64], ta[64];
+    const int tid = threadIdx.x, jet = blockIdx.x, T = a.T, H = a.H;
     if (tid < T) {
-        const float tv = t[(int64_t)jet * t_stride];
-        const float f = blob[freqs + tid];
+        const float tv = a.t[(int64_t)jet * a.t_stride];
+        const float f = a.blob[a.freqs + tid];
         float e;
-        if (sincos) {
+        if (a.sincos) {
             const float arg = __fmul_rn(f, tv);
             e = 2 * tid < T ? cosf(arg) : sinf(arg);
         } else {
             e = cosf(__fdiv_rn(__fmul_rn(__fmul_rn(__fadd_rn(tv, 0.0f), f), 3.14159274101257324f), 1.0f));
         }
         te[tid] = e;
-        temb[(int64_t)jet * 64 + tid] = e;
+        ta[tid] = lrelu(e, a.slope);
+        a.temb[(int64_t)jet * 64 + tid] = e;
+        a.tact[(int64_t)jet * 64 + tid] = ta[tid];
     }
     __syncthreads();
     for (int o = tid; o < H; o += 128) {
-        float acc = blob[b + o];
-        if (Wt >= 0)
+        float acc = a.blob[a.b + o];
+        if (a.Wt >= 0)
 #pragma unroll 8
-            for (int k = 0; k < T; ++k) acc = fmaf(blob[Wt + (int64_t)k * H + o], te[k], acc);
-        jbt[(int64_t)jet * H + o] = acc;
+            for (int k = 0; k < T; ++k) acc = fmaf(a.blob[a.Wt + (int64_t)k * H + o], te[k], acc);
+        if (a.Wt2 >= 0)  // x = cat(x, t_in) in front of MDMA.embed (mdma.py:155-156): a second block of time columns
+#pragma unroll 8
+            for (int k = 0; k < T; ++k) acc = fmaf(a.blob[a.Wt2 + (int64_t)k * H + o], te[k], acc);
+        a.jbt[(int64_t)jet * H + o] = acc;
     }
+    // Block.fc0(act(cat(x, t_in))) (mdma.py:56-57, 65): the time columns give every particle of the jet the same bias row
+    for (int l = 0; l < a.layers; ++l)
+        for (int o = tid; o < H; o += 128) {
+            float acc = a.blob[a.fc0_b[l] + o];
+#pragma unroll 8
+            for (int k = 0; k < T; ++k) acc = fmaf(a.blob[a.fc0_Wt[l] + (int64_t)k * H + o], ta[k], acc);
+            a.jb0[((int64_t)l * a.B + jet) * H + o] = acc;
+        }
 }
 
 // x = act(embed(cat(temb, x))); x[~mask] = 0   (mdma.py:150-151)
@@ -195,18 +214,19 @@ static __global__ __launch_bounds__(JT) void mdma_cls_init_kernel(ClsInitArgs a)
 
 // before the attention: x_cls = ln(fc0_cls(act(x_cls))); q = in_proj[:H] x_cls + b   (mdma.py:67 and the query half of :68)
 struct ClsPreArgs {
-    const float *blob, *xc_in;
+    const float *blob, *xc_in, *tact;  // tact: LeakyReLU(time embedding) [B][64] (t_global: Tg > 0)
     float *pre, *c, *q;
     int64_t fc0c_W, fc0c_b, ln_g, ln_b, q_W, q_b;
-    int H, L;
+    int H, L, Tg;
     float slope, eps;
 };
 static __global__ __launch_bounds__(JT) void mdma_cls_pre_kernel(ClsPreArgs a) {
-    __shared__ float al[MAXL], pre[MAXH], c[MAXH], q[MAXH], part[JT], red[4];
+    __shared__ float al[MAXL + 64], pre[MAXH], c[MAXH], q[MAXH], part[JT], red[4];
     const int tid = threadIdx.x, jet = blockIdx.x;
     if (tid < a.L) al[tid] = lrelu(a.xc_in[(int64_t)jet * a.L + tid], a.slope);
+    else if (tid < a.L + a.Tg) al[tid] = a.tact[(int64_t)jet * 64 + tid - a.L];  // act(cat(x_cls, t_in[:, :1])) (mdma.py:58-59, 67)
     __syncthreads();
-    jet_gemv(a.blob, a.fc0c_W, a.fc0c_b, a.L, a.H, al, pre, part);
+    jet_gemv(a.blob, a.fc0c_W, a.fc0c_b, a.L + a.Tg, a.H, al, pre, part);
     float s = 0.f;
     for (int k = tid; k < a.H; k += JT) s += pre[k];
     const float mean = block_sum256(s, red) / (float)a.H;
@@ -230,22 +250,27 @@ static __global__ __launch_bounds__(JT) void mdma_cls_pre_kernel(ClsPreArgs a) {
 // after the attention: out_proj, fc1_cls(cat(x_cls, n_valid)), fc2_cls, and the token columns of fc1 as the jet's bias row
 // (mdma.py:68-81: x = fc1(cat(x, x_cls.expand)) + res  ->  fc1.W[:, :H] x + (fc1.W[:, H:] x_cls + b))
 struct ClsPostArgs {
-    const float *blob, *att, *nv;
+    const float *blob, *att, *nv, *temb;  // temb: the time embedding [B][64] (t_global: Tg > 0)
     float *o, *c2, *xc_out, *jb;
     int64_t o_W, o_b, fc1c_W, fc1c_b, fc2c_W, fc2c_b, W1c, b1;
-    int H, L;
+    int H, L, Tg;
 };
 static __global__ __launch_bounds__(JT) void mdma_cls_post_kernel(ClsPostArgs a) {
-    __shared__ float att[MAXH], o[MAXH + 4], c2[MAXL], xo[MAXL], jb[MAXH], part[JT];
+    __shared__ float att[MAXH], o[MAXH + 4 + 64], c2[MAXL + 64], xo[MAXL], jb[MAXH], part[JT];
     const int tid = threadIdx.x, jet = blockIdx.x;
     for (int k = tid; k < a.H; k += JT) att[k] = a.att[(int64_t)jet * a.H + k];
     __syncthreads();
     jet_gemv(a.blob, a.o_W, a.o_b, a.H, a.H, att, o, part);
     if (tid == 0) o[a.H] = a.nv[jet];
+    if (tid < a.Tg) {  // cat(x_cls, cond, t_in[:, :1]) in front of fc1_cls, cat(x_cls, t_in[:, :1]) in front of fc2_cls (mdma.py:70-78)
+        const float e = a.temb[(int64_t)jet * 64 + tid];
+        o[a.H + 1 + tid] = e;
+        c2[a.L + tid] = e;
+    }
     for (int k = tid; k < a.H; k += JT) a.o[(int64_t)jet * a.H + k] = o[k];
     __syncthreads();
-    jet_gemv(a.blob, a.fc1c_W, a.fc1c_b, a.H + 1, a.L, o, c2, part);
-    jet_gemv(a.blob, a.fc2c_W, a.fc2c_b, a.L, a.L, c2, xo, part);
+    jet_gemv(a.blob, a.fc1c_W, a.fc1c_b, a.H + 1 + a.Tg, a.L, o, c2, part);
+    jet_gemv(a.blob, a.fc2c_W, a.fc2c_b, a.L + a.Tg, a.L, c2, xo, part);
     if (tid < a.L) {
         a.c2[(int64_t)jet * a.L + tid] = c2[tid];
         a.xc_out[(int64_t)jet * a.L + tid] = xo[tid];
@@ -443,7 +468,7 @@ static __global__ __launch_bounds__(256) void mdma_embed_bwd_kernel(const float*
 // host side
 // ------------------------------------------------------------------------------------------------
 struct Ws {
-    int64_t temb, jbt, nv, pooled, ea, eg, xc, X, xstride, layer0, lstride;
+    int64_t temb, tact, jbt, jb0, nv, pooled, ea, eg, xc, X, xstride, layer0, lstride;  // jb0: [layers][B][H] fc0 jet-bias rows (t_local)
     int64_t o_h, o_kv, o_pre, o_c, o_q, o_att, o_o, o_c2, o_jb, total;
 };
 
@@ -452,7 +477,8 @@ Ws make_ws(const pfm_mdma_desc& d, int n_jets, bool train) {
     const int64_t B = n_jets, M = B * d.n_points, H = d.hidden, L = d.latent;
     int64_t o = 0;
     auto take = [&](int64_t n) { const int64_t at = o; o += round64(n); return at; };
-    w.temb = take(B * 64); w.jbt = take(B * H); w.nv = take(B); w.pooled = take(B * H);
+    w.temb = take(B * 64); w.tact = take(B * 64); w.jbt = take(B * H); w.nv = take(B); w.pooled = take(B * H);
+    w.jb0 = take((d.t_cat & 1) ? (int64_t)d.layers * B * H : 0);
     w.ea = take(B * L); w.eg = take(B * L);
     w.xc = take((int64_t)(d.layers + 1) * round64(B * L));
     w.xstride = train ? round64(M * H) : 0;
@@ -526,9 +552,16 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
     float* ws = p.ws;
     const int H = d.hidden, L = d.latent, N = d.n_points, B = p.n_jets;
     int rc;
-    hipLaunchKernelGGL(mdma_time_kernel, dim3(B), dim3(128), 0, p.s, p.blob, t, t_stride, d.time_in_input ? d.t_dim : 0,
-                       (d.flags & PFM_MDMA_F_TEMB_SINCOS) ? 1 : 0, d.freqs, d.time_in_input ? d.emb_Wt : (int64_t)-1, d.emb_b, H,
-                       ws + w.temb, ws + w.jbt);
+    const int Tl = (d.t_cat & 1) ? d.t_dim : 0, Tg = (d.t_cat & 2) ? d.t_dim : 0;
+    {
+        TimeArgs a;
+        a.blob = p.blob; a.t = t; a.temb = ws + w.temb; a.tact = ws + w.tact; a.jbt = ws + w.jbt; a.jb0 = ws + w.jb0;
+        a.freqs = d.freqs; a.Wt = d.time_in_input ? d.emb_Wt : (int64_t)-1; a.Wt2 = Tl ? d.emb_Wt2 : (int64_t)-1; a.b = d.emb_b;
+        a.t_stride = t_stride; a.T = (d.time_in_input || d.t_cat) ? d.t_dim : 0; a.sincos = (d.flags & PFM_MDMA_F_TEMB_SINCOS) ? 1 : 0;
+        a.H = H; a.layers = Tl ? d.layers : 0; a.B = B; a.slope = d.neg_slope;
+        for (int l = 0; l < a.layers; ++l) { a.fc0_Wt[l] = d.block[l].fc0.Wt; a.fc0_b[l] = d.block[l].fc0.b; }
+        hipLaunchKernelGGL(mdma_time_kernel, dim3(B), dim3(128), 0, p.s, a);
+    }
     PFM_TRY(check_hip(hipGetLastError(), "mdma_time_kernel launch"));
     hipLaunchKernelGGL(mdma_embed_kernel, dim3((p.M + 31) / 32), dim3(256), 0, p.s, p.blob, d.emb_Wx, x, (const float*)(ws + w.jbt), mask,
                        p.X(0), p.M, N, d.features, H, d.neg_slope);
@@ -547,10 +580,10 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         float* lb = p.lay(l);
         const float* Xin = p.X(l);
         float* Xout = p.X(l + 1);
-        PFM_TRY(linear(p, Xin, H, k.fc0.W, k.fc0.b, H, nullptr, nullptr, nullptr, lb + w.o_h, 0, true));
+        PFM_TRY(linear(p, Xin, H, k.fc0.W, k.fc0.b, H, Tl ? ws + w.jb0 + (int64_t)l * B * H : nullptr, nullptr, nullptr, lb + w.o_h, 0, true));
         {
             ClsPreArgs a;
-            a.blob = p.blob; a.xc_in = p.xc(l); a.pre = lb + w.o_pre; a.c = lb + w.o_c; a.q = lb + w.o_q;
+            a.blob = p.blob; a.xc_in = p.xc(l); a.tact = ws + w.tact; a.Tg = Tg; a.pre = lb + w.o_pre; a.c = lb + w.o_c; a.q = lb + w.o_q;
             a.fc0c_W = k.fc0c_W; a.fc0c_b = k.fc0c_b; a.ln_g = k.ln_g; a.ln_b = k.ln_b; a.q_W = k.q_W; a.q_b = k.q_b;
             a.H = H; a.L = L; a.slope = d.neg_slope; a.eps = d.ln_eps;
             hipLaunchKernelGGL(mdma_cls_pre_kernel, dim3(B), dim3(JT), 0, p.s, a);
@@ -562,7 +595,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_from_kernel launch (mdma)"));
         {
             ClsPostArgs a;
-            a.blob = p.blob; a.att = lb + w.o_att; a.nv = ws + w.nv;
+            a.blob = p.blob; a.att = lb + w.o_att; a.nv = ws + w.nv; a.temb = ws + w.temb; a.Tg = Tg;
             a.o = lb + w.o_o; a.c2 = lb + w.o_c2; a.xc_out = p.xc(l + 1); a.jb = lb + w.o_jb;
             a.o_W = k.o_W; a.o_b = k.o_b; a.fc1c_W = k.fc1c_W; a.fc1c_b = k.fc1c_b; a.fc2c_W = k.fc2c_W; a.fc2c_b = k.fc2c_b;
             a.W1c = k.fc1.Wc; a.b1 = k.fc1.b; a.H = H; a.L = L;
@@ -652,6 +685,8 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
     const int H = d.hidden, L = d.latent, N = d.n_points, B = p.n_jets, F = d.features;
     float *gX = sc + b.gX, *gH = sc + b.gH, *gkv = sc + b.gkv, *djb = sc + b.djb;
     float* gxc[2] = {sc + b.gxc, sc + b.gxc + round64((int64_t)B * L)};
+    const int Tl = (d.t_cat & 1) ? d.t_dim : 0, Tg = (d.t_cat & 2) ? d.t_dim : 0;
+    const float *temb = ws + w.temb, *tact = ws + w.tact;
     int rc;
     PFM_MDMA_NI(mdma_head_bwd_kernel, dim3((p.M + 15) / 16), (const float*)p.X(d.layers), v, u, mask, gscale, p.blob, d.out_W, Bw.gblob,
                 d.out_b, sc + b.dvrow, sc + b.zact, gX, p.M, F, d.neg_slope, sc + b.dwpart);
@@ -711,8 +746,24 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
             J.add(nullptr, 0, 1, sc + b.dpre, H, H, k.fc0c_b);
             PFM_TRY(J.launch(B, p.s));
         }
+        if (Tg) {  // the time rows of the class-token Linears (KMAJOR: behind their other input rows)
+            Jobs J;
+            J.gblob = Bw.gblob;
+            J.add(temb, 64, Tg, sc + b.gxo, L, L, k.fc2c_W + (int64_t)L * L);
+            J.add(temb, 64, Tg, sc + b.dc2, L, L, k.fc1c_W + (int64_t)(H + 1) * L);
+            J.add(tact, 64, Tg, sc + b.dpre, H, H, k.fc0c_W + (int64_t)L * H);
+            PFM_TRY(J.launch(B, p.s));
+        }
         cur ^= 1;
         // h = fc0(act(x_in))
+        if (Tl) {  // per-jet bias rows b + Wt . act(temb): the bias and the time columns get sums over the jets of per-jet column sums
+            PFM_TRY(Bw.colsum(gH, H, nullptr, 0, djb, -1));
+            Jobs J;
+            J.gblob = Bw.gblob;
+            J.add(nullptr, 0, 1, djb, H, H, k.fc0.b);
+            J.add(tact, 64, Tl, djb, H, H, k.fc0.Wt);
+            PFM_TRY(J.launch(B, p.s));
+        } else
         PFM_TRY(Bw.colsum(gH, H, nullptr, 0, nullptr, k.fc0.b));
         PFM_TRY(Bw.dw(gH, H, Xin, H, k.fc0.W, true));
         PFM_TRY(linear(p, gH, H, k.fc0.WT, -1, H, nullptr, gX, Xin, gX, 4, false));
@@ -742,7 +793,8 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
         J.add(nv, 1, 1, sc + b.dg, L, L, d.cond_W);
         J.add(nullptr, 0, 1, sc + b.dg, L, L, d.cond_b);
         J.add(nullptr, 0, 1, sc + b.djbt, H, H, d.emb_b);
-        if (d.time_in_input) J.add(ws + w.temb, 64, d.t_dim, sc + b.djbt, H, H, d.emb_Wt);
+        if (d.time_in_input) J.add(temb, 64, d.t_dim, sc + b.djbt, H, H, d.emb_Wt);
+        if (Tl) J.add(temb, 64, Tl, sc + b.djbt, H, H, d.emb_Wt2);
         PFM_TRY(J.launch(B, p.s));
     }
     return 0;

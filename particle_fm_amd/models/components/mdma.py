@@ -3,9 +3,9 @@
 Same class names, constructor keywords, parameter names / shapes / registration order (hence the same ``state_dict`` keys and,
 under a fixed seed, bit-identical default initialisation) as the reference (mdma.py:7-45, 87-140).  The blocks own parameters
 only: one evaluation of the network is a fixed sequence of HIP launches (``vector_field``; include/pfm_mdma.h), there is no
-per-block PyTorch compute and no CPU fallback.  Switch combinations without kernels raise NotImplementedError at
-construction: the time / condition concatenations (t_local_cat, t_global_cat, local_cat_cond, global_cat_cond) and
-global_cond_dim > 0 -- configs/model/flow_matching_mdma.yaml sets all of them off.
+per-block PyTorch compute and no CPU fallback.  The time concatenations (t_local_cat, t_global_cat: off in
+configs/model/flow_matching_mdma.yaml, on by MDMA's own defaults) have kernels; the condition concatenations (local_cat_cond,
+global_cat_cond) and global_cond_dim > 0 -- off in the yaml -- raise NotImplementedError at construction.
 """
 from __future__ import annotations
 
@@ -56,8 +56,7 @@ class MDMA(_FusedEncoder):
                  local_cat_cond: bool = False, global_cat_cond: bool = False, **kwargs):
         cnf = dict(kwargs.pop("_cnf", None) or {})
         super().__init__()
-        for flag, on in (("t_local_cat", t_local_cat), ("t_global_cat", t_global_cat), ("local_cat_cond", local_cat_cond),
-                         ("global_cat_cond", global_cat_cond)):
+        for flag, on in (("local_cat_cond", local_cat_cond), ("global_cat_cond", global_cat_cond)):
             if on:
                 raise NotImplementedError(f"MDMA({flag}=True) has no HIP kernels (configs/model/flow_matching_mdma.yaml sets it False)")
         if global_cond_dim:
@@ -83,12 +82,16 @@ class MDMA(_FusedEncoder):
         self.features = int(cnf.get("features", input_dim - (2 * cnf_freq if add_time else 0)))
         if self.features + (2 * cnf_freq if add_time else 0) != input_dim:
             raise ValueError(f"input_dim {input_dim} is not features {self.features} + time columns {2 * cnf_freq if add_time else 0}")
+        if (t_local_cat or t_global_cat) and cnf and frequencies != cnf_freq:
+            raise ValueError(f"MDMA(t_local_cat / t_global_cat): frequencies {frequencies} sizes the Linears, the CNF's {cnf_freq} the "
+                             "embedding they receive (mdma.py:25-36, flow_matching_module.py:208-221): the two must agree")
         self._init_fused(int(cnf.get("num_particles", num_points)), cnf_freq, add_time, str(cnf.get("t_emb", "cosine")))
 
     def config(self, num_points: Optional[int] = None) -> MdmaConfig:
         return MdmaConfig(num_particles=num_points or self.num_points, features=self.features, hidden=self.hidden_dim,
                           latent=self.latent, num_layers=self.num_layers, num_heads=self.num_heads, avg_n=float(self.avg_n),
-                          frequencies=self.frequencies, add_time_to_input=self.add_time_to_input, t_emb=self.t_emb)
+                          frequencies=self.frequencies, add_time_to_input=self.add_time_to_input, t_emb=self.t_emb,
+                          t_local_cat=bool(self.t_local_cat), t_global_cat=bool(self.t_global_cat))
 
     def layout(self, num_points: Optional[int] = None):
         n = num_points or self.num_points

@@ -22,14 +22,19 @@ def forward(desc, blob, t, x, mask):
         return w
 
     jbt = vec(blob, d.emb_b, H).expand(B, H)
-    if d.time_in_input:
+    Tl, Tg = (T if d.t_cat & 1 else 0), (T if d.t_cat & 2 else 0)
+    if d.time_in_input or d.t_cat:
         freqs = vec(blob, d.freqs, T)
         if d.flags & 2:
             a = freqs * t[:, None]
             temb = torch.cat([a[:, :T // 2].cos(), a[:, T // 2:].sin()], -1)
         else:
             temb = torch.cos(t[:, None] * freqs * math.pi)
+        tact = F.leaky_relu(temb, sl)
+    if d.time_in_input:
         jbt = jbt + temb @ kmajor(blob, d.emb_Wt, T, H).t()
+    if Tl:
+        jbt = jbt + temb @ kmajor(blob, d.emb_Wt2, T, H).t()
     X = F.leaky_relu(x @ kmajor(blob, d.emb_Wx, Fe, H).t() + jbt[:, None, :], sl) * (mask != 0)[..., None]
     nv = mask.sum(1, keepdim=True)
     pooled = torch.cat([X.sum(1) / d.avg_n, nv], -1)
@@ -40,7 +45,10 @@ def forward(desc, blob, t, x, mask):
     for l in range(d.layers):
         k = d.block[l]
         Hh = F.leaky_relu(X, sl) @ W(k.fc0, H, H).t() + vec(blob, k.fc0.b, H)
-        pre = F.leaky_relu(xc, sl) @ kmajor(blob, k.fc0c_W, L, H).t() + vec(blob, k.fc0c_b, H)
+        if Tl:
+            Hh = Hh + (tact @ kmajor(blob, k.fc0.Wt, T, H).t())[:, None, :]
+        al = torch.cat([F.leaky_relu(xc, sl), tact], -1) if Tg else F.leaky_relu(xc, sl)
+        pre = al @ kmajor(blob, k.fc0c_W, L + Tg, H).t() + vec(blob, k.fc0c_b, H)
         c = F.layer_norm(pre, (H,), vec(blob, k.ln_g, H), vec(blob, k.ln_b, H), d.ln_eps)
         q = c @ kmajor(blob, k.q_W, H, H).t() + vec(blob, k.q_b, H)
         kk, vv = (Hh @ W(k.kv, 2 * H, H).t() + vec(blob, k.kv.b, 2 * H)).chunk(2, -1)
@@ -49,8 +57,9 @@ def forward(desc, blob, t, x, mask):
         s = qh @ kh.transpose(-2, -1) / math.sqrt(d.head_dim) + pad[:, None]
         att = (torch.softmax(s, -1) @ vh).reshape(B, H)
         o = att @ kmajor(blob, k.o_W, H, H).t() + vec(blob, k.o_b, H)
-        c2 = torch.cat([o, nv], -1) @ kmajor(blob, k.fc1c_W, H + 1, L).t() + vec(blob, k.fc1c_b, L)
-        xc = c2 @ kmajor(blob, k.fc2c_W, L, L).t() + vec(blob, k.fc2c_b, L)
+        tg = [temb] if Tg else []
+        c2 = torch.cat([o, nv] + tg, -1) @ kmajor(blob, k.fc1c_W, H + 1 + Tg, L).t() + vec(blob, k.fc1c_b, L)
+        xc = torch.cat([c2] + tg, -1) @ kmajor(blob, k.fc2c_W, L + Tg, L).t() + vec(blob, k.fc2c_b, L)
         jb = xc @ kmajor(blob, k.fc1.Wc, L, H).t() + vec(blob, k.fc1.b, H)
         X = Hh @ W(k.fc1, H, H).t() + jb[:, None, :] + X
     return (F.leaky_relu(X, sl) @ vec(blob, d.out_W, H) + vec(blob, d.out_b, 1)) * mask

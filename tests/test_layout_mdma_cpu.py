@@ -39,9 +39,16 @@ def test_grad_pos_is_a_bijection_onto_primary_slots(mdma_golden):
 def test_unsupported_configs_are_rejected():
     hp = dict(num_particles=30, features=3, frequencies=16, net_config=dict(hidden_dim=128, layers=2, t_local_cat=False, t_global_cat=False))
     MdmaLayout(MdmaConfig.from_hparams(hp))
-    for bad in (dict(t_local_cat=True), dict(t_global_cat=True), dict(global_cond_dim=1), dict(local_cat_cond=True), dict(hidden_dim=64),
-                dict(num_heads=2), dict(latent=10)):
+    for bad in (dict(global_cond_dim=1), dict(local_cat_cond=True), dict(hidden_dim=64), dict(num_heads=2), dict(latent=10)):
         with pytest.raises(NotImplementedError):
             MdmaLayout(MdmaConfig.from_hparams(dict(hp, net_config=dict(hp["net_config"], **bad))))
-    with pytest.raises(NotImplementedError):  # MDMA's own defaults concatenate the time embedding (mdma.py:103-104)
+    # MDMA's own defaults concatenate the time embedding (mdma.py:101-102): its Linears are sized by net_config.frequencies (default 6),
+    # the embedding by the model's -- as in the reference, the two have to agree
+    with pytest.raises(ValueError, match="frequencies"):
         MdmaConfig.from_hparams(dict(hp, net_config=dict(hidden_dim=128)))
+    cfg = MdmaConfig.from_hparams(dict(hp, net_config=dict(hidden_dim=128, frequencies=16)))
+    assert cfg.t_local_cat and cfg.t_global_cat
+    shapes = dict(cfg.param_shapes())
+    assert shapes["net.embed.weight"] == (128, 3 + 32 + 32) and shapes["net.encoder.0.fc0.weight"] == (128, 128 + 32)
+    assert shapes["net.encoder.0.fc0_cls.weight"] == (128, 16 + 32) and shapes["net.encoder.0.fc1_cls.weight"] == (16, 128 + 1 + 32)
+    assert shapes["net.encoder.0.fc2_cls.weight"] == (16, 16 + 32)

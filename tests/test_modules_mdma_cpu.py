@@ -54,12 +54,16 @@ def test_errors():
         m.flows[0].decode(x, None, None, ode_solver="dopri5")
     with pytest.raises(RuntimeError, match="fused"):
         m.flows[0].net.encoder[0](x, None, None, None)
-    for bad in (dict(t_local_cat=True), dict(t_global_cat=True), dict(global_cond_dim=1), dict(global_cat_cond=True),
-                dict(local_cat_cond=True), dict(hidden_dim=96), dict(num_heads=2), dict(latent=10), dict(dropout=0.1)):
+    for bad in (dict(global_cond_dim=1), dict(global_cat_cond=True), dict(local_cat_cond=True), dict(hidden_dim=96), dict(num_heads=2),
+                dict(latent=10), dict(dropout=0.1)):
         with pytest.raises(NotImplementedError):
             SetFlowMatchingLitModule(**base, net_config=dict(nc, **bad))
-    with pytest.raises(NotImplementedError):  # MDMA's own defaults concatenate the time embedding (mdma.py:103-104)
+    # MDMA's own defaults concatenate the time embedding (mdma.py:101-102) with Linears sized by net_config.frequencies (default 6):
+    # like the reference, that only works when it equals the model's frequencies
+    with pytest.raises(ValueError, match="frequencies"):
         SetFlowMatchingLitModule(**base, net_config=dict(hidden_dim=128))
+    m2 = SetFlowMatchingLitModule(**base, net_config=dict(hidden_dim=128, frequencies=16, layers=1))
+    assert m2.flows[0].net.t_local_cat and m2.flows[0].net.encoder[0].fc0.weight.shape == (128, 128 + 32)
     with pytest.raises(NotImplementedError):
         SetFlowMatchingLitModule(**dict(base, t_emb="gaussian"), net_config=dict(nc))
     with pytest.raises(RuntimeError, match="ROCm device|no CPU"):  # loss_type="diffusion" has a HIP path on this model (round 3), not a CPU one
