@@ -60,7 +60,7 @@ def test_lit_module_surface():
     (dict(criterion="l1"), NotImplementedError),                # losses.py:36
     (dict(use_normaliser=True, normaliser_config={"extra_dims": (0,)}), NotImplementedError),
     (dict(loss_type="CFM-OT"), NotImplementedError),
-    (dict(model="mdma"), NotImplementedError),
+    (dict(model="mdma"), ValueError),  # MDMA's defaults concatenate the time embedding with Linears sized by ITS frequencies (6), not the model's (16)
     (dict(model="droid_fulltransformer", net_config={"te_config": {"model_dim": 64, "mha_config": {"num_heads": 4}}}),
      NotImplementedError),
 ])
