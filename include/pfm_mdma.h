@@ -38,6 +38,10 @@ extern "C" {
 #define PFM_MDMA_MAX_LAYERS 16
 #define PFM_MDMA_F_BF16 32u /* bf16 operands in the particle-stream Linears (forward and dX), see PFM_TF_F_BF16 (pfm_tf.h) */
 #define PFM_MDMA_F_TEMB_SINCOS 2u /* t_emb = "sincos" (flow_matching_module.py:208-211) instead of "cosine" */
+#define PFM_MDMA_F_TEMB_GIVEN 64u /* as PFM_TF_F_TEMB_GIVEN (pfm_tf.h; t_emb = "gaussian"): the caller supplies the time EMBEDDING through `t` --
+                                   * forward / loss forward: temb[n_jets][t_dim] (per_jet_t = 1) or one row for all jets; pfm_mdma_sample_rk:
+                                   * the transposed table [t_dim][n_steps * stages]; the loss backward then also accumulates d loss / d temb in
+                                   * its scratch (pfm_mdma_backward_dtemb) */
 
 typedef struct {
     pfm_tf_lin fc0;     /* Block.fc0 columns 0..H [H][H] MFMA_AK (+ WT); Wt = its time columns H..H+T KMAJOR [T][H] (t_local, else -1) */
@@ -103,6 +107,10 @@ int pfm_mdma_fm_loss_forward(const pfm_mdma_desc *desc, const float *blob, int32
 int pfm_mdma_fm_loss_backward(const pfm_mdma_desc *desc, const float *blob, const float *mask, const float *y,
                               const float *u, const float *v, const float *gscale, float *gblob, int32_t n_jets,
                               float *workspace, float *scratch, void *stream);
+
+/* PFM_MDMA_F_TEMB_GIVEN: dtemb[n_jets][t_dim] = d(loss)/d(temb) * gscale of the pfm_mdma_fm_loss_backward call that has just filled
+ * `scratch` (same descriptor and n_jets): through the time columns of embed and -- t_cat -- of Block.fc0 / fc0_cls / fc1_cls / fc2_cls. */
+int pfm_mdma_backward_dtemb(const pfm_mdma_desc *desc, const float *scratch, int32_t n_jets, float *dtemb, void *stream);
 
 #ifdef __cplusplus
 }

@@ -584,6 +584,9 @@ MDMA_CONFIGS = {
     "tcat": (dict(MDMA_BASE, num_particles=40, net_config=dict(mdma_net_config(2), frequencies=16, t_local_cat=True, t_global_cat=True)), 3, False),
     "tloc": (dict(MDMA_BASE, num_particles=24, add_time_to_input=False, frequencies=6,
                   net_config=dict(mdma_net_config(1), frequencies=6, t_local_cat=True, t_global_cat=False)), 3, False),
+    # t_emb="gaussian" (flow_matching_module.py:178-181, 213-221) in front of an MDMA that concatenates the embedding everywhere
+    "gauss": (dict(MDMA_BASE, num_particles=24, t_emb="gaussian", hidden_dim=64, frequencies=6,
+                   net_config=dict(mdma_net_config(2), frequencies=6, t_local_cat=True, t_global_cat=True)), 3, False),
     "tglob": (dict(MDMA_BASE, num_particles=24, add_time_to_input=False, frequencies=6, t_emb="sincos",
                    net_config=dict(mdma_net_config(1), frequencies=6, t_local_cat=False, t_global_cat=True)), 3, False),
 }

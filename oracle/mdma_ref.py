@@ -23,7 +23,7 @@ from typing import Mapping
 import torch
 import torch.nn.functional as F
 
-from .fm_ref import time_embedding
+from .fm_ref import gaussian_time_embedding, time_embedding
 
 NEG_SLOPE = 0.01  # nn.LeakyReLU() default (mdma.py:46, 138)
 
@@ -94,7 +94,10 @@ class MdmaVectorField:
     def __call__(self, t, x, cond=None, mask=None):
         hp = self.hp
         nc = hp.get("net_config") or {}
-        temb = time_embedding(t, x, hp, self.freqs)
+        if hp.get("t_emb", "cosine") == "gaussian":  # flow_matching_module.py:178-181, 213-221: a trainable embedding network of the CNF
+            temb = gaussian_time_embedding(t, x, self.state, self.prefix, hp.get("activation", "leaky_relu"))
+        else:
+            temb = time_embedding(t, x, hp, self.freqs)
         if hp.get("add_time_to_input", True):
             x = torch.cat((temb, x), dim=-1)
         return mdma_forward(self.state, self.prefix + "net.", x, mask, num_layers=int(nc.get("layers", 16)),

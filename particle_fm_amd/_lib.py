@@ -110,6 +110,7 @@ SYMBOLS = {
     # include/pfm_mdma.h
     "pfm_mdma_workspace_floats": (c_int64, [POINTER(MdmaDesc), c_int32, c_int32]),
     "pfm_mdma_backward_scratch_floats": (c_int64, [POINTER(MdmaDesc), c_int32]),
+    "pfm_mdma_backward_dtemb": (c_int, [POINTER(MdmaDesc), _fp, c_int32, _fp, c_void_p]),
     "pfm_mdma_forward": (c_int, [POINTER(MdmaDesc), _fp, _fp, c_int32, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_mdma_sample_rk": (
         c_int, [POINTER(MdmaDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),

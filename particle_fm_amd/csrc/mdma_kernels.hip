@@ -110,16 +110,19 @@ struct TimeArgs {
     float *temb, *tact, *jbt, *jb0;  // temb / tact [B][64]: the embedding and LeakyReLU of it; jbt [B][H]; jb0 [layers][B][H] (t_local)
     int64_t freqs, Wt, Wt2, b, fc0_Wt[PFM_MDMA_MAX_LAYERS], fc0_b[PFM_MDMA_MAX_LAYERS];
     int t_stride, T, sincos, H, layers, B;  // layers: 0 without t_local
+    int temb_k;  // PFM_MDMA_F_TEMB_GIVEN: floats between the elements of an embedding row in `t` (0: `t` holds times)
     float slope;
 };
 static __global__ __launch_bounds__(128) void mdma_time_kernel(TimeArgs a) {
     __shared__ float te[64], ta[64];
     const int tid = threadIdx.x, jet = blockIdx.x, T = a.T, H = a.H;
     if (tid < T) {
-        const float tv = a.t[(int64_t)jet * a.t_stride];
+        const float tv = a.temb_k ? 0.f : a.t[(int64_t)jet * a.t_stride];
         const float f = a.blob[a.freqs + tid];
         float e;
-        if (a.sincos) {
+        if (a.temb_k) {
+            e = a.t[(int64_t)jet * a.t_stride + (int64_t)tid * a.temb_k];
+        } else if (a.sincos) {
             const float arg = __fmul_rn(f, tv);
             e = 2 * tid < T ? cosf(arg) : sinf(arg);
         } else {
@@ -347,11 +350,12 @@ __global__ __launch_bounds__(256) void mdma_head_bwd_kernel(const float* __restr
 struct ClsPostBwdArgs {
     const float *blob, *djb, *gxc_next;
     float *gxo, *dc2, *dout, *datt;
+    float* dtemb;  // PFM_MDMA_F_TEMB_GIVEN with t_global: [B][64], += the time rows of fc2_cls / fc1_cls times their output gradients
     int64_t W1c, fc2c_W, fc1c_W, o_W;
-    int H, L;
+    int H, L, Tg;
 };
 static __global__ __launch_bounds__(JT) void mdma_cls_post_bwd_kernel(ClsPostBwdArgs a) {
-    __shared__ float djb[MAXH], gxo[MAXL], dc2[MAXL], dov[MAXH + 4], datt[MAXH];
+    __shared__ float djb[MAXH], gxo[MAXL], dc2[MAXL], dov[MAXH + 4], datt[MAXH], dte[2][64];
     const int tid = threadIdx.x, jet = blockIdx.x;
     for (int k = tid; k < a.H; k += JT) djb[k] = a.djb[(int64_t)jet * a.H + k];
     __syncthreads();
@@ -363,6 +367,11 @@ static __global__ __launch_bounds__(JT) void mdma_cls_post_bwd_kernel(ClsPostBwd
     __syncthreads();
     jet_gemv_t(a.blob, a.fc2c_W, a.L, a.L, gxo, dc2);
     if (tid < a.L) a.dc2[(int64_t)jet * a.L + tid] = dc2[tid];
+    if (a.dtemb && a.Tg) {
+        jet_gemv_t(a.blob, a.fc2c_W + (int64_t)a.L * a.L, a.Tg, a.L, gxo, dte[0]);
+        jet_gemv_t(a.blob, a.fc1c_W + (int64_t)(a.H + 1) * a.L, a.Tg, a.L, dc2, dte[1]);
+        if (tid < a.Tg) a.dtemb[(int64_t)jet * 64 + tid] += dte[0][tid] + dte[1][tid];
+    }
     jet_gemv_t(a.blob, a.fc1c_W, a.H + 1, a.L, dc2, dov);  // row H (the particle count) has no upstream
     for (int k = tid; k < a.H; k += JT) a.dout[(int64_t)jet * a.H + k] = dov[k];
     jet_gemv_t(a.blob, a.o_W, a.H, a.H, dov, datt);
@@ -372,14 +381,15 @@ static __global__ __launch_bounds__(JT) void mdma_cls_post_bwd_kernel(ClsPostBwd
 // the token path before the attention, backwards.  In: gq = d loss / d q.  Out, per jet: dc = d / d ln output (= the ln.bias
 // term), dgx = dc * xhat (the ln.weight term), dpre = d / d fc0_cls output, al = act(x_cls_in), gxc_in = d / d x_cls_in.
 struct ClsPreBwdArgs {
-    const float *blob, *gq, *pre, *xc_in;
+    const float *blob, *gq, *pre, *xc_in, *temb;
     float *dc, *dgx, *dpre, *al, *gxc_in;
+    float* dtemb;  // PFM_MDMA_F_TEMB_GIVEN with t_global: [B][64], += LeakyReLU'(temb) * (the time rows of fc0_cls times dpre)
     int64_t q_W, ln_g, fc0c_W;
-    int H, L;
+    int H, L, Tg;
     float slope, eps;
 };
 static __global__ __launch_bounds__(JT) void mdma_cls_pre_bwd_kernel(ClsPreBwdArgs a) {
-    __shared__ float gq[MAXH], dc[MAXH], dpre[MAXH], da[MAXL], red[4];
+    __shared__ float gq[MAXH], dc[MAXH], dpre[MAXH], da[MAXL], red[4], dte[64];
     const int tid = threadIdx.x, jet = blockIdx.x;
     for (int k = tid; k < a.H; k += JT) gq[k] = a.gq[(int64_t)jet * a.H + k];
     __syncthreads();
@@ -413,6 +423,10 @@ static __global__ __launch_bounds__(JT) void mdma_cls_pre_bwd_kernel(ClsPreBwdAr
         a.dgx[(int64_t)jet * a.H + k] = dc[k] * xh;
     }
     __syncthreads();
+    if (a.dtemb && a.Tg) {
+        jet_gemv_t(a.blob, a.fc0c_W + (int64_t)a.L * a.H, a.Tg, a.H, dpre, dte);
+        if (tid < a.Tg) a.dtemb[(int64_t)jet * 64 + tid] += dte[tid] * lrelu_d(a.temb[(int64_t)jet * 64 + tid], a.slope);
+    }
     jet_gemv_t(a.blob, a.fc0c_W, a.L, a.H, dpre, da);
     if (tid < a.L) {
         const float xv = a.xc_in[(int64_t)jet * a.L + tid];
@@ -443,6 +457,23 @@ static __global__ __launch_bounds__(JT) void mdma_cls_init_bwd_kernel(ClsInitBwd
     __syncthreads();
     jet_gemv_t(a.blob, a.ecls_W, a.H, a.L, da, dp);
     for (int k = tid; k < a.H; k += JT) a.dpool[(int64_t)jet * a.H + k] = __fdiv_rn(dp[k], a.avg_n);
+}
+
+// PFM_MDMA_F_TEMB_GIVEN: dtemb[jet][k] += f'(temb[jet][k]) * sum_o (W1[k][o] + W2[k][o]) g[jet][o] -- the time columns (KMAJOR [T][H]) of a
+// particle Linear whose per-jet bias row they feed (embed: W1, W2 = its two time blocks, f = id; Block.fc0: f = LeakyReLU)
+static __global__ __launch_bounds__(JT) void mdma_dtemb_kernel(const float* __restrict__ blob, int64_t W1, int64_t W2, const float* __restrict__ g,
+                                                               const float* __restrict__ temb, float* __restrict__ dtemb, int T, int H,
+                                                               int act, float slope) {
+    __shared__ float gv[MAXH], o1[64], o2[64];
+    const int tid = threadIdx.x, jet = blockIdx.x;
+    for (int k = tid; k < H; k += JT) gv[k] = g[(int64_t)jet * H + k];
+    __syncthreads();
+    if (W1 >= 0) jet_gemv_t(blob, W1, T, H, gv, o1);
+    if (W2 >= 0) jet_gemv_t(blob, W2, T, H, gv, o2);
+    if (tid < T) {
+        const float s = (W1 >= 0 ? o1[tid] : 0.f) + (W2 >= 0 ? o2[tid] : 0.f);
+        dtemb[(int64_t)jet * 64 + tid] += act ? s * lrelu_d(temb[(int64_t)jet * 64 + tid], slope) : s;
+    }
 }
 
 // d loss / d (embed output before the activation): the particle stream's gradient plus the pooled sum's, through the mask
@@ -502,6 +533,7 @@ struct Plan {
     Ws w;
     int n_jets, M;
     hipStream_t s;
+    int temb_k = 0;  // PFM_MDMA_F_TEMB_GIVEN: 1 (rows [jet][T]); the sampler switches to its [T][evaluations] table
     float* X(int l) const { return ws + w.X + w.xstride * l; }
     float* xc(int l) const { return ws + w.xc + round64((int64_t)n_jets * d->latent) * l; }
     float* lay(int l) const { return ws + w.layer0 + w.lstride * l; }
@@ -512,6 +544,7 @@ int make_plan(Plan& p, const pfm_mdma_desc* d, const float* blob, float* ws, int
     if (rc) return rc;
     p.d = d; p.blob = blob; p.ws = ws; p.n_jets = n_jets; p.M = n_jets * d->n_points; p.s = (hipStream_t)stream;
     p.w = make_ws(*d, n_jets, train);
+    p.temb_k = (d->flags & PFM_MDMA_F_TEMB_GIVEN) ? 1 : 0;
     return 0;
 }
 
@@ -557,7 +590,8 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         TimeArgs a;
         a.blob = p.blob; a.t = t; a.temb = ws + w.temb; a.tact = ws + w.tact; a.jbt = ws + w.jbt; a.jb0 = ws + w.jb0;
         a.freqs = d.freqs; a.Wt = d.time_in_input ? d.emb_Wt : (int64_t)-1; a.Wt2 = Tl ? d.emb_Wt2 : (int64_t)-1; a.b = d.emb_b;
-        a.t_stride = t_stride; a.T = (d.time_in_input || d.t_cat) ? d.t_dim : 0; a.sincos = (d.flags & PFM_MDMA_F_TEMB_SINCOS) ? 1 : 0;
+        a.t_stride = p.temb_k ? (t_stride ? d.t_dim : 0) : t_stride; a.temb_k = p.temb_k;
+        a.T = (d.time_in_input || d.t_cat) ? d.t_dim : 0; a.sincos = (d.flags & PFM_MDMA_F_TEMB_SINCOS) ? 1 : 0;
         a.H = H; a.layers = Tl ? d.layers : 0; a.B = B; a.slope = d.neg_slope;
         for (int l = 0; l < a.layers; ++l) { a.fc0_Wt[l] = d.block[l].fc0.Wt; a.fc0_b[l] = d.block[l].fc0.b; }
         hipLaunchKernelGGL(mdma_time_kernel, dim3(B), dim3(128), 0, p.s, a);
@@ -611,7 +645,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
 
 // ---- backward ------------------------------------------------------------------------------------------
 struct Bs {
-    int64_t dvrow, zact, gX, gH, gkv, djb, gxc, gxo, dc2, dout, datt, gq, dc, dgx, dpre, al, da, dg, dpool, djbt, dwpart, total;
+    int64_t dvrow, zact, gX, gH, gkv, djb, gxc, gxo, dc2, dout, datt, gq, dc, dgx, dpre, al, da, dg, dpool, djbt, dwpart, dtemb, total;
 };
 
 Bs make_bs(const pfm_mdma_desc& d, int n_jets) {
@@ -624,6 +658,7 @@ Bs make_bs(const pfm_mdma_desc& d, int n_jets) {
     b.dout = take(B * H); b.datt = take(B * H); b.gq = take(B * H); b.dc = take(B * H); b.dgx = take(B * H); b.dpre = take(B * H);
     b.al = take(B * L); b.da = take(B * L); b.dg = take(B * L); b.dpool = take(B * H); b.djbt = take(B * H);
     b.dwpart = take((int64_t)DW_MAX_PARTS * 16384);
+    b.dtemb = take((d.flags & PFM_MDMA_F_TEMB_GIVEN) ? B * 64 : 0);
     b.total = o;
     return b;
 }
@@ -687,6 +722,7 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
     float* gxc[2] = {sc + b.gxc, sc + b.gxc + round64((int64_t)B * L)};
     const int Tl = (d.t_cat & 1) ? d.t_dim : 0, Tg = (d.t_cat & 2) ? d.t_dim : 0;
     const float *temb = ws + w.temb, *tact = ws + w.tact;
+    float* dtemb = (d.flags & PFM_MDMA_F_TEMB_GIVEN) ? sc + b.dtemb : nullptr;  // (zeroed by the caller of run_backward)
     int rc;
     PFM_MDMA_NI(mdma_head_bwd_kernel, dim3((p.M + 15) / 16), (const float*)p.X(d.layers), v, u, mask, gscale, p.blob, d.out_W, Bw.gblob,
                 d.out_b, sc + b.dvrow, sc + b.zact, gX, p.M, F, d.neg_slope, sc + b.dwpart);
@@ -707,7 +743,7 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
             ClsPostBwdArgs a;
             a.blob = p.blob; a.djb = djb; a.gxc_next = (l == d.layers - 1) ? nullptr : gxc[cur];
             a.gxo = sc + b.gxo; a.dc2 = sc + b.dc2; a.dout = sc + b.dout; a.datt = sc + b.datt;
-            a.W1c = k.fc1.Wc; a.fc2c_W = k.fc2c_W; a.fc1c_W = k.fc1c_W; a.o_W = k.o_W; a.H = H; a.L = L;
+            a.W1c = k.fc1.Wc; a.fc2c_W = k.fc2c_W; a.fc1c_W = k.fc1c_W; a.o_W = k.o_W; a.H = H; a.L = L; a.Tg = Tg; a.dtemb = dtemb;
             hipLaunchKernelGGL(mdma_cls_post_bwd_kernel, dim3(B), dim3(JT), 0, p.s, a);
             PFM_TRY(check_hip(hipGetLastError(), "mdma_cls_post_bwd_kernel launch"));
         }
@@ -722,6 +758,7 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
             a.blob = p.blob; a.gq = sc + b.gq; a.pre = lb + w.o_pre; a.xc_in = p.xc(l);
             a.dc = sc + b.dc; a.dgx = sc + b.dgx; a.dpre = sc + b.dpre; a.al = sc + b.al; a.gxc_in = gxc[cur ^ 1];
             a.q_W = k.q_W; a.ln_g = k.ln_g; a.fc0c_W = k.fc0c_W; a.H = H; a.L = L; a.slope = d.neg_slope; a.eps = d.ln_eps;
+            a.temb = temb; a.Tg = Tg; a.dtemb = dtemb;
             hipLaunchKernelGGL(mdma_cls_pre_bwd_kernel, dim3(B), dim3(JT), 0, p.s, a);
             PFM_TRY(check_hip(hipGetLastError(), "mdma_cls_pre_bwd_kernel launch"));
         }
@@ -763,6 +800,11 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
             J.add(nullptr, 0, 1, djb, H, H, k.fc0.b);
             J.add(tact, 64, Tl, djb, H, H, k.fc0.Wt);
             PFM_TRY(J.launch(B, p.s));
+            if (dtemb) {
+                hipLaunchKernelGGL(mdma_dtemb_kernel, dim3(B), dim3(JT), 0, p.s, p.blob, k.fc0.Wt, (int64_t)-1, (const float*)djb, temb, dtemb,
+                                   Tl, H, 1, d.neg_slope);
+                PFM_TRY(check_hip(hipGetLastError(), "mdma_dtemb_kernel launch (fc0)"));
+            }
         } else
         PFM_TRY(Bw.colsum(gH, H, nullptr, 0, nullptr, k.fc0.b));
         PFM_TRY(Bw.dw(gH, H, Xin, H, k.fc0.W, true));
@@ -796,6 +838,11 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
         if (d.time_in_input) J.add(temb, 64, d.t_dim, sc + b.djbt, H, H, d.emb_Wt);
         if (Tl) J.add(temb, 64, Tl, sc + b.djbt, H, H, d.emb_Wt2);
         PFM_TRY(J.launch(B, p.s));
+    }
+    if (dtemb && (d.time_in_input || Tl)) {
+        hipLaunchKernelGGL(mdma_dtemb_kernel, dim3(B), dim3(JT), 0, p.s, p.blob, d.time_in_input ? d.emb_Wt : (int64_t)-1,
+                           Tl ? d.emb_Wt2 : (int64_t)-1, (const float*)(sc + b.djbt), temb, dtemb, d.t_dim, H, 0, d.neg_slope);
+        PFM_TRY(check_hip(hipGetLastError(), "mdma_dtemb_kernel launch (embed)"));
     }
     return 0;
 }
@@ -843,6 +890,7 @@ int pfm_mdma_sample_rk(const pfm_mdma_desc* d, const float* blob, const pfm_rk_t
     hipLaunchKernelGGL(tf_premask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.s, z, premask ? mask : (const float*)nullptr, state,
                        n, d->features);
     if ((rc = check_hip(hipGetLastError(), "tf_premask_kernel launch (mdma)"))) return rc;
+    if (p.temb_k) p.temb_k = n_steps * tab->stages;  // t_eval = the embedding table [T][n_steps * stages]: evaluation e starts at t_eval + e
     rc = sample_rk_rows(*tab, t_eval, dt, n_steps, state, n, p.s,
                         [&](const float* tt, const float* xin, float* vout) { return run_nfe(p, tt, 0, xin, mask, vout); });
     if (rc) return rc;
@@ -881,7 +929,22 @@ int pfm_mdma_fm_loss_backward(const pfm_mdma_desc* d, const float* blob, const f
     B.gblob = gblob;
     B.sc = scratch;
     B.b = make_bs(*d, n_jets);
+    if ((d->flags & PFM_MDMA_F_TEMB_GIVEN) &&
+        (rc = check_hip(hipMemsetAsync(scratch + B.b.dtemb, 0, (size_t)n_jets * 64 * sizeof(float), (hipStream_t)stream), "memset dtemb")))
+        return rc;
     return run_backward(B, mask, y, u, v, gscale);
+}
+
+int pfm_mdma_backward_dtemb(const pfm_mdma_desc* d, const float* scratch, int32_t n_jets, float* dtemb, void* stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    if (!(d->flags & PFM_MDMA_F_TEMB_GIVEN)) return set_err(PFM_E_BADARG, "pfm_mdma_backward_dtemb: the descriptor has no PFM_MDMA_F_TEMB_GIVEN");
+    if (n_jets <= 0) return 0;
+    if (!scratch || !dtemb) return set_err(PFM_E_BADARG, "NULL device pointer");
+    // the scratch rows are 64 floats apart, the caller's t_dim
+    return check_hip(hipMemcpy2DAsync(dtemb, (size_t)d->t_dim * sizeof(float), scratch + make_bs(*d, n_jets).dtemb, 64 * sizeof(float),
+                                      (size_t)d->t_dim * sizeof(float), (size_t)n_jets, hipMemcpyDeviceToDevice, (hipStream_t)stream),
+                     "copy dtemb");
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@ import torch
 
 from . import _lib
 from .hip_ops import _dev_f32, _ptr, _stream_ptr, rk_grid, rk_tableau
+from .hip_ops_tf import _temb_table, _time_arg, temb_given
 from .hip_ops_tf import _KINDS
 from .layout_mdma import MdmaLayout
 
@@ -54,21 +55,31 @@ def workspace(layout: MdmaLayout, n_jets: int, device, train: bool = False) -> t
 
 
 def mdma_forward(layout: MdmaLayout, blob, t, x, mask) -> torch.Tensor:
-    """(B, N, F) broadcast of MDMA(t, x, mask).  t: (B,) one time per jet, or 0-dim / (1,) for one shared time."""
+    """(B, N, F) broadcast of MDMA(t, x, mask).  t: (B,) one time per jet, or 0-dim / (1,) for one shared time; a layout with
+    t_emb="gaussian" (PFM_MDMA_F_TEMB_GIVEN) takes the time EMBEDDING rows (B, T) / one shared row instead."""
     lib = _lib.load()
     dev, B, blob, x, mask = _prep(layout, blob, x, mask)
-    t = _dev_f32("t", t.reshape(-1), dev)
-    if t.numel() not in (1, B):
-        raise ValueError(f"t has {t.numel()} elements, expected 1 or {B}")
+    t, t_per_jet = _time_arg(layout, t, B, dev)
     v = torch.empty_like(x)
-    rc = lib.pfm_mdma_forward(ctypes.byref(layout.desc), _ptr(blob), _ptr(t), 1 if (t.numel() == B and B > 1) else 0, _ptr(x),
+    rc = lib.pfm_mdma_forward(ctypes.byref(layout.desc), _ptr(blob), _ptr(t), t_per_jet, _ptr(x),
                               _ptr(mask), _ptr(v), B, _ptr(workspace(layout, B, dev)), _stream_ptr(dev))
     _lib.check(rc, "pfm_mdma_forward")
     return v
 
 
+def mdma_backward_dtemb(layout, B: int, dev) -> torch.Tensor:
+    """d loss / d temb (B, T) of the loss backward that has just run for this layout and batch size (pfm_mdma_backward_dtemb reads that
+    backward's scratch: call it right behind mdma_fm_loss_backward, same stream)."""
+    lib = _lib.load()
+    scratch = layout.__dict__["_bscratch"][(B, str(dev))]
+    out = torch.empty(B, layout.cfg.t_dim, device=dev, dtype=torch.float32)
+    rc = lib.pfm_mdma_backward_dtemb(ctypes.byref(layout.desc), _ptr(scratch), B, _ptr(out), _stream_ptr(dev))
+    _lib.check(rc, "pfm_mdma_backward_dtemb")
+    return out
+
+
 def mdma_sample_rk(layout: MdmaLayout, blob, z, mask, ode_steps: int = 100, solver: str = "midpoint", premask: bool = True,
-                   t0: float = 1.0, t1: float = 0.0) -> torch.Tensor:
+                   t0: float = 1.0, t1: float = 0.0, temb_fn=None) -> torch.Tensor:
     """x(t1) from x(t0) = z (*mask) with the fixed-step explicit Runge-Kutta scheme ``solver`` ("euler", "midpoint", "rk4" =
     torchdyn's 3/8 rule) over linspace(t0, t1, ode_steps); all launches queued on the current stream."""
     lib = _lib.load()
@@ -78,6 +89,8 @@ def mdma_sample_rk(layout: MdmaLayout, blob, z, mask, ode_steps: int = 100, solv
     tab = rk_tableau(solver)
     ts, dts = rk_grid(ode_steps, solver, t0, t1)
     ts, dts = ts.to(dev), dts.to(dev)
+    if temb_given(layout):  # the table of embeddings replaces the time grid (PFM_MDMA_F_TEMB_GIVEN)
+        ts = _temb_table(temb_fn, ts, dev)
     out = torch.empty_like(z)
     state = torch.empty((2 + tab.stages) * z.numel(), device=dev, dtype=torch.float32)
     rc = lib.pfm_mdma_sample_rk(ctypes.byref(layout.desc), _ptr(blob), ctypes.byref(tab), _ptr(ts), _ptr(dts), ode_steps - 1,
@@ -95,7 +108,10 @@ def mdma_fm_loss_forward(layout: MdmaLayout, blob, x, t, a, mask, sigma: float =
     dev, B, blob, x, mask = _prep(layout, blob, x, mask)
     if kind not in _KINDS:
         raise NotImplementedError(f"loss kind {kind} has no HIP kernel")
-    t = _dev_f32("t", t, dev, (B,))
+    if temb_given(layout):  # (the interpolation must not depend on t: fm_field.py's forward-with-saved-activations, kind "droid", a = 0)
+        t = _dev_f32("temb", t, dev, (B, layout.cfg.t_dim))
+    else:
+        t = _dev_f32("t", t, dev, (B,))
     a = _dev_f32("a", a, dev, tuple(x.shape))
     if kind == "CFM":
         if eps is None:

@@ -193,7 +193,7 @@ class MdmaLayout(TfLayout):
         d.heads, d.head_dim, d.t_dim, d.time_in_input = cfg.num_heads, cfg.head_dim, T, int(cfg.add_time_to_input)
         d.t_cat = int(cfg.t_local_cat) | (2 * int(cfg.t_global_cat))
         Tl, Tg = cfg.t_l, cfg.t_g
-        d.flags = self.flags | (PFM_MDMA_F_TEMB_SINCOS if cfg.t_emb == "sincos" else 0)
+        d.flags = self.flags | (PFM_MDMA_F_TEMB_SINCOS if cfg.t_emb == "sincos" else 0) | (64 if cfg.t_emb == "gaussian" else 0)  # 64: PFM_*_F_TEMB_GIVEN
         d.neg_slope, d.ln_eps, d.avg_n = 0.01, 1e-5, cfg.avg_n
         d.freqs = self._put(self.freq_off + np.arange(T), primary=False)
         t0 = T if cfg.add_time_to_input else 0  # x = cat(temb, x): the time columns come first (flow_matching_module.py:201)

@@ -136,8 +136,6 @@ class CNF(nn.Module):
                                                  add_time_to_input=add_time_to_input,
                                                  t_emb=t_emb if t_emb in ("cosine", "sincos", "gaussian") else "cosine")
         elif model == "mdma":  # flow_matching_module.py:163-167
-            if t_emb not in ("cosine", "sincos"):
-                raise NotImplementedError("model='mdma' has a HIP path for the cosine / sincos time embeddings only")
             self.net = MDMA(input_dim=input_dim, **net_config,
                             _cnf=dict(features=features, num_particles=num_particles, frequencies=frequencies,
                                       add_time_to_input=add_time_to_input, t_emb=t_emb))
@@ -161,11 +159,8 @@ class CNF(nn.Module):
             # flow_matching_module.py:178-181: random Fourier features -> Linear -> activation -> Linear(2 frequencies), trainable.
             # O(B * hidden) per call: host-side torch ops on the device; its output (B, T) goes to the kernels as the time
             # embedding (pfm_epic_*_temb) and the loss backward returns d loss / d temb, so the four tensors train exactly.
-            # (the transformer / cross-attention / row-matrix EPiC kernels take the embedding through their `t` argument,
-            # PFM_*_F_TEMB_GIVEN, and pfm_*_backward_dtemb returns its gradient; MDMA embeds in-kernel only)
-            if model not in ("epic", "droid_fulltransformer", "droid_fullcrossattention"):
-                raise NotImplementedError("t_emb='gaussian' has a HIP path for model='epic', 'droid_fulltransformer' and "
-                                          "'droid_fullcrossattention'")
+            # (the transformer / cross-attention / MDMA / row-matrix EPiC kernels take the embedding through their `t` argument,
+            # PFM_*_F_TEMB_GIVEN, and pfm_*_backward_dtemb returns its gradient)
             self.embed = nn.Sequential(GaussianFourierProjection(embed_dim=hidden_dim), nn.Linear(hidden_dim, hidden_dim))
             self.linear = nn.Linear(hidden_dim, 2 * frequencies)
         else:
@@ -222,7 +217,7 @@ class CNF(nn.Module):
         """v = f(t, x) (flow_matching_module.py:191-204); one HIP launch, embedding included."""
         if self.t_emb == "gaussian":
             temb = self._gaussian_temb(self._per_jet_time(t, x))  # (B, T)
-            if self.is_transformer or self.is_cross_attention:
+            if self.is_transformer or self.is_cross_attention or self.is_mdma:
                 return self.net.vector_field(temb, x, cond, mask)  # the layout carries PFM_*_F_TEMB_GIVEN: `t` = the embedding rows
             return self.net.forward(temb, x, cond, mask)  # EPiC_encoder.forward takes the embedding (epic.py:304), either path
         return self.net.vector_field(self._per_jet_time(t, x), x, cond, mask)
@@ -230,7 +225,7 @@ class CNF(nn.Module):
     def fm_loss(self, x, t, z, mask=None, cond=None, sigma: float = 1e-4, kind: str = "FM-OT", eps=None) -> Tensor:
         """Differentiable FM / CFM loss with the draws given (the body of losses.py:38-77 / 101-136)."""
         lay = self.net.layout(x.shape[1])
-        if self.t_emb == "gaussian" and (self.is_transformer or self.is_cross_attention or self.net.is_wide(x.shape[1])):
+        if self.t_emb == "gaussian" and (self.is_transformer or self.is_cross_attention or self.is_mdma or self.net.is_wide(x.shape[1])):
             # no fused loss kernel with a caller-supplied embedding: interpolation / target / squared error around the differentiable
             # field (fm_field.py), whose backward also returns d loss / d temb for the CNF's embedding network
             return _fm_field.fm_loss_from_field(lambda y: self._field_rows(t, y, cond, mask), kind, x, t, z, eps, mask, sigma)
@@ -440,11 +435,11 @@ class CNF(nn.Module):
     def _sample_rk(self, blob, z, cond, mask, ode_steps, solver, t0, t1):
         lay = self.net.layout(z.shape[1])
         kw = dict(ode_steps=ode_steps, solver=solver, t0=t0, t1=t1)
+        if self.t_emb == "gaussian" and (self.is_transformer or self.is_cross_attention or self.is_mdma or self.net.is_wide(z.shape[1])):
+            kw["temb_fn"] = self._temb_table_fn(z.device)
         if self.is_mdma:
             m = torch.ones(*z.shape[:2], 1, device=z.device) if mask is None else mask
             return hip_ops_mdma.mdma_sample_rk(lay, blob, z, m, premask=False, **kw)
-        if self.t_emb == "gaussian" and (self.is_transformer or self.is_cross_attention or self.net.is_wide(z.shape[1])):
-            kw["temb_fn"] = self._temb_table_fn(z.device)
         if self.is_transformer:
             return hip_ops_tf.tf_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
         if self.is_cross_attention:

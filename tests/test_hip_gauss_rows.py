@@ -135,3 +135,62 @@ def test_droid_loss_and_the_encoder_forward_with_a_given_embedding_on_the_row_ma
         temb = mc.flows[0].time_embedding(t[:, None].expand(-1, x.shape[1]), x, "cosine")  # (B, N, T), as CNF.forward hands it over
         got = net(temb, x, cond, mask)
     torch.testing.assert_close(got, want, atol=2e-6, rtol=1e-5)
+
+
+def test_mdma_with_the_gaussian_embedding_and_every_time_concatenation():
+    """tests/golden/mdma_gauss.npz: t_emb="gaussian" in front of an MDMA with t_local_cat = t_global_cat = True and add_time_to_input --
+    the embedding reaches embed twice, every Block.fc0 and the three class-token Linears of every block; pfm_mdma_backward_dtemb
+    collects d loss / d temb from all of them.  Forward, FM-OT / CFM loss + every gradient (embedding network included), midpoint vs the
+    reference's vectors; euler / rk4 vs the oracle."""
+    from oracle.fm_ref import sample_fixed_step
+    from oracle.mdma_ref import MdmaVectorField, broadcast_field
+    from tests.conftest import load_mdma_golden
+    g = load_mdma_golden("gauss")
+    m = _module(g)
+    cnf = m.flows[0]
+    for mk in ("f32", "int64", "ones"):
+        tag = f"nfe_{mk}/"
+        x, t, mask = (g.get(tag + k) for k in ("x", "t", "mask"))
+        tt = t.unsqueeze(-1).repeat_interleave(x.shape[1], dim=1)
+        with torch.no_grad():
+            v = cnf(tt.cuda(), x.cuda(), mask=mask.cuda()).cpu()
+            vs = cnf(t[0].cuda(), x.cuda(), mask=mask.cuda()).cpu()
+        torch.testing.assert_close(v, g.get(tag + "v_vec_t"), atol=2e-5, rtol=2e-4)
+        torch.testing.assert_close(vs, g.get(tag + "v_scalar_t"), atol=2e-5, rtol=2e-4)
+    for kind, tag in (("FM-OT", "loss_f32/"), ("CFM", "cfm/")):
+        x, t, mask = (g.get(tag + k).cuda() for k in ("x", "t", "mask"))
+        a, eps = (g.get(tag + "z").cuda(), None) if kind == "FM-OT" else (g.get(tag + "x0").cuda(), g.get(tag + "eps").cuda())
+        m.zero_grad()
+        loss = cnf.fm_loss(x, t, a, mask=mask, sigma=1e-4, kind=kind, eps=eps)
+        torch.testing.assert_close(loss.detach().cpu(), g.get(tag + "loss"), rtol=3e-5, atol=1e-6)
+        loss.backward()
+        named = dict(cnf.named_parameters())
+        ref = g.grads(tag)
+        assert all(("flows.0." + k) in ref for k in ("embed.1.weight", "embed.1.bias", "linear.weight", "linear.bias"))
+        bad = []
+        for k, want in ref.items():
+            got = named[k[len("flows.0."):]].grad
+            if got is None:
+                assert "cond_cls" in k, k  # (constructed and never used, mdma.py:37)
+                continue
+            got = g.pick(got.cpu())
+            if float(want.abs().max()) < 2e-6:
+                assert float(got.abs().max()) < 1e-5, k
+                continue
+            l2 = float((got - want).norm()) / max(float(want.norm()), 1e-12)
+            if not l2 < 2e-3:
+                bad.append((k, l2))
+        assert not bad, bad[:8]
+    vf = broadcast_field(MdmaVectorField(g.state, "flows.0.", g.hp, freqs=g.freqs))
+    for steps in (3, 10):
+        tag = f"midpoint_{steps}/"
+        z, mask = (g.get(tag + k) for k in ("z", "mask"))
+        out = m((z * mask).cuda(), mask=mask.cuda(), reverse=True, ode_solver="midpoint", ode_steps=steps).cpu()
+        torch.testing.assert_close(out, g.get(tag + "x_end"), atol=2e-4, rtol=1e-3)
+    z, mask = (g.get("midpoint_10/" + k) for k in ("z", "mask"))
+    for solver in ("euler", "rk4"):
+        out = m((z * mask).cuda(), mask=mask.cuda(), reverse=True, ode_solver=solver, ode_steps=6).cpu()
+        torch.testing.assert_close(out, sample_fixed_step(vf, z, None, mask, ode_steps=6, solver=solver), atol=2e-4, rtol=1e-3)
+    x, mask = (g.get("loss_f32/" + k).cuda() for k in ("x", "mask"))
+    loss = m.training_step((x, mask, None), 0)["loss"]
+    assert torch.isfinite(loss)

@@ -64,7 +64,7 @@ def test_errors():
         SetFlowMatchingLitModule(**base, net_config=dict(hidden_dim=128))
     m2 = SetFlowMatchingLitModule(**base, net_config=dict(hidden_dim=128, frequencies=16, layers=1))
     assert m2.flows[0].net.t_local_cat and m2.flows[0].net.encoder[0].fc0.weight.shape == (128, 128 + 32)
-    with pytest.raises(NotImplementedError):
-        SetFlowMatchingLitModule(**dict(base, t_emb="gaussian"), net_config=dict(nc))
+    mg = SetFlowMatchingLitModule(**dict(base, t_emb="gaussian"), net_config=dict(nc))  # (round 3: the embedding rows go in through `t`)
+    assert mg.flows[0].net.layout().desc.flags & 64 and mg.flows[0].linear.weight.shape == (32, 128)
     with pytest.raises(RuntimeError, match="ROCm device|no CPU"):  # loss_type="diffusion" has a HIP path on this model (round 3), not a CPU one
         SetFlowMatchingLitModule(**base, net_config=dict(nc), loss_type="diffusion").flows[0].decode(x, None, torch.ones(2, 30, 1), ode_solver="ddim")

@@ -57,18 +57,22 @@ def test_midpoint(g, steps):
     torch.testing.assert_close(sample_midpoint(vf, z, cond, mask, ode_steps=steps), g.get(tag + "x_end"), atol=5e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("path", ["tf", "ca"])
+@pytest.mark.parametrize("path", ["tf", "ca", "mdma"])
 def test_gaussian_embedding_on_the_transformer_fields(path):
-    """tests/golden/{tf,ca}_gauss.npz: the oracle's transformer / cross-attention fields with the CNF's gaussian time-embedding network
-    reproduce the reference's recorded forward vectors, FM-OT loss and midpoint samples."""
+    """tests/golden/{tf,ca,mdma}_gauss.npz: the oracle's transformer / cross-attention / MDMA fields (the latter with every time
+    concatenation on) with the CNF's gaussian time-embedding network reproduce the reference's recorded forward vectors, FM-OT loss and
+    midpoint samples."""
     from oracle.fm_ref import fm_ot_loss, midpoint_trajectory_end
-    from tests.conftest import load_ca_golden, load_tf_golden
+    from tests.conftest import load_ca_golden, load_mdma_golden, load_tf_golden
     if path == "tf":
         from oracle.tf_ref import TransformerVectorField as VF
         g = load_tf_golden("gauss")
-    else:
+    elif path == "ca":
         from oracle.ca_ref import CrossAttentionVectorField as VF
         g = load_ca_golden("gauss")
+    else:
+        from oracle.mdma_ref import MdmaVectorField as VF
+        g = load_mdma_golden("gauss")
     vf = VF(g.state, "flows.0.", g.hp, freqs=g.freqs)
     with torch.no_grad():
         tag = "nfe_f32/"
