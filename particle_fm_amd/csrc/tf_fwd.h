@@ -602,7 +602,9 @@ __device__ __forceinline__ void tf_linear_body(LinArgs& a, float* __restrict__ l
     }
 }
 
-template <int NI, int TPW = 4, int MODE = 0>  // MODE: 0 fp32 MFMA, 1 split-fp16 (X3), 2 bf16 operands
+// B64: the launch runs 64-output workgroups only (LinArgs.bn = 64): an instantiation without the two-operand body, whose registers would
+// otherwise set the kernel's occupancy
+template <int NI, int TPW = 4, int MODE = 0, bool B64 = false>  // MODE: 0 fp32 MFMA, 1 split-fp16 (X3), 2 bf16 operands
 __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int rt, ch;
@@ -612,8 +614,12 @@ __global__ __launch_bounds__(LT, 2) void tf_linear_kernel(LinArgs a) {
         a.M = *a.m_dev;
         if (rt * 16 * TPW >= a.M) return;
     }
-    if (a.NO - ch * a.bn <= 64 || a.bn == 64) tf_linear_body<NI, TPW, MODE, 1>(a, lds, rt, ch, ks);
-    else tf_linear_body<NI, TPW, MODE, 2>(a, lds, rt, ch, ks);
+    if constexpr (B64) {
+        tf_linear_body<NI, TPW, MODE, 1>(a, lds, rt, ch, ks);
+    } else {
+        if (a.NO - ch * a.bn <= 64 || a.bn == 64) tf_linear_body<NI, TPW, MODE, 1>(a, lds, rt, ch, ks);
+        else tf_linear_body<NI, TPW, MODE, 2>(a, lds, rt, ch, ks);
+    }
 }
 
 #ifdef PFM_TF_DIAG
@@ -1193,13 +1199,16 @@ inline bool launch_panel2(const LinArgs& l1, const LinArgs& l2, int cus, hipStre
 // 2 x CU workgroup slots.  Work per round ~ rows x cost-per-row of the tile: a 128-row tile reads every weight block
 // from L2 once per 128 rows instead of once per 64 (the L2 -> register weight stream is what limits the 64-row kernel),
 // a 32-row tile fills the tail of launches that are only a little over a whole number of rounds.
-inline int pick_row_tile(int64_t M, int chunks, int cus, bool allow128) {
+inline int pick_row_tile(int64_t M, int chunks, int cus, bool allow128, bool b64 = false) {
     static int forced = -1;
     if (forced < 0) {
         const char* e = getenv("PFM_TF_ROWTILE");  // diagnostics only (tests/diag): 32, 64 or 128
         forced = e ? atoi(e) : 0;
     }
     if (forced == 32 || forced == 64 || (forced == 128 && allow128)) return forced;
+    // 64-output workgroups: 32 rows (84 VGPRs: five workgroups per CU) measured ahead of 64 (113: four) -- cfg 5, 256 jets x 100 steps:
+    // 441 against 473 ms one call alone, 698 against 689 jets/s with three in flight
+    if (b64) return 32;
     const int64_t slots = 2 * (int64_t)cus;
     auto rounds = [&](int rb) { return ((M + rb - 1) / rb * chunks + slots - 1) / slots; };
     static double f128 = 0.0;
@@ -1250,7 +1259,7 @@ inline int launch_linear_kernel(LinArgs& a, int ni, int mode, int cus, hipStream
     if (bn_env < 0) { const char* e = getenv("PFM_TF_BN"); bn_env = e ? atoi(e) : 0; }  // diagnostics only (tests/diag): 64 or 128
     if (bn_env == 64 || bn_env == BN) a.bn = bn_env;
     const int chunks_bn = (a.NO + a.bn - 1) / a.bn;
-    const int rb = pick_row_tile(a.M, chunks_bn * a.ksplit, cus, !x3 && a.bn == BN);
+    const int rb = pick_row_tile(a.M, chunks_bn * a.ksplit, cus, !x3 && a.bn == BN, a.bn == 64 && ni == 0);
     a.row_tiles = (a.M + rb - 1) / rb;
     const int grid = ((a.row_tiles + 7) / 8) * 8 * chunks_bn * a.ksplit;
     const size_t lds = x3 ? (size_t)rb * X3ROW * 2 * 2 * 2 + 2 * rb * sizeof(float) : (size_t)(rb * 128 + 2 * rb) * sizeof(float);
@@ -1271,6 +1280,17 @@ inline int launch_linear_kernel(LinArgs& a, int ni, int mode, int cus, hipStream
             big = true;                                                                                     \
         }                                                                                                   \
         hipLaunchKernelGGL((tf_linear_kernel<NI, 8>), dim3(grid), dim3(LT), lds, s, a);                     \
+    }
+    if (a.bn == 64 && ni == 0 && rb <= 64) {  // (the row-matrix EPiC path's particle Linears)
+        if (mode == 2) {
+            if (rb == 32) hipLaunchKernelGGL((tf_linear_kernel<0, 2, 2, true>), dim3(grid), dim3(LT), lds, s, a);
+            else hipLaunchKernelGGL((tf_linear_kernel<0, 4, 2, true>), dim3(grid), dim3(LT), lds, s, a);
+        } else if (x3) {
+            if (rb == 32) hipLaunchKernelGGL((tf_linear_kernel<0, 2, 1, true>), dim3(grid), dim3(LT), lds, s, a);
+            else hipLaunchKernelGGL((tf_linear_kernel<0, 4, 1, true>), dim3(grid), dim3(LT), lds, s, a);
+        } else if (rb == 32) hipLaunchKernelGGL((tf_linear_kernel<0, 2, 0, true>), dim3(grid), dim3(LT), lds, s, a);
+        else hipLaunchKernelGGL((tf_linear_kernel<0, 4, 0, true>), dim3(grid), dim3(LT), lds, s, a);
+        return 0;
     }
     switch (ni) {
         case 0: PFM_LAUNCH_LIN(0) break;
