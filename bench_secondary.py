@@ -143,8 +143,9 @@ def run(name, args):
     # sampler calls in flight: 2 everywhere, 3 for the cross-attention path (its ~200 short launches per step leave most CUs idle,
     # a third call still finds room: 443 jets/s one call at a time, 621 with two, 708 with three in flight).  From two calls on the
     # host's launch rate, not the GPU, would set the pace (485 with two): the sampler then replays its captured step body
-    # (cfg 5 likewise: 105 launches per evaluation, a dependent launch costs ~5 us whatever it does: 533 / 645 / 670 jets/s with 1 / 2 / 3)
-    overlap = args.overlap if args.overlap is not None else (3 if hp["model"] == "droid_fullcrossattention" or name == "jetclass" else 2)
+    # (cfg 5 likewise: 105 launches per evaluation, a dependent launch costs ~5 us whatever it does: 533 / 645 / 670 jets/s with 1 / 2 / 3;
+    # cfg 4: 728 / 746 with 2 / 3).  cfg 2's jet-resident sampler is one launch per call: two in flight, like bench.py
+    overlap = args.overlap if args.overlap is not None else (2 if hp["model"] == "epic" and name != "jetclass" else 3)
     graph = overlap > 1 and getattr(net, "_GRAPH_FLAG", 0) != 0 and not args.no_graph
     if graph:
         net.set_graph_replay(True)
