@@ -16,8 +16,8 @@
  * either way (desc.t_cat: the yaml has them off, MDMA.__init__'s own defaults on, mdma.py:101-102): the time embedding is the same
  * for every particle of a jet, so behind a particle Linear (embed, Block.fc0) its columns are a per-jet bias row (mdma_time_kernel),
  * behind a class-token Linear (fc0_cls, fc1_cls, fc2_cls) extra rows of the per-jet GEMV; hidden a multiple of 128 (<= 512) with
- * head_dim = hidden / num_heads in {8, 16}; latent a multiple of 4 (<= 64).  `cond` is not an argument: with these switches
- * MDMA.forward never reads it.
+ * head_dim = hidden / num_heads in {8, 16}; latent a multiple of 4 (<= 64).  `cond` [n_jets] is the conditional variant's
+ * ONE value per jet (desc.c_cat; mdma.py:157-169 appends global_cond_in.unsqueeze(-1)); NULL otherwise (the network never reads it).
  *
  * Weight formats (float offsets into one blob, gathered from the state_dict by particle_fm_amd/layout_mdma.py):
  *   MFMA_AK / MFMA_AKT: as include/pfm_tf.h.  KMAJOR [K][NO]: element (k, o) at k * NO + o.
@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PFM_MDMA_ABI_VERSION 2
+#define PFM_MDMA_ABI_VERSION 3
 #define PFM_MDMA_MAX_LAYERS 16
 #define PFM_MDMA_F_BF16 32u /* bf16 operands in the particle-stream Linears (forward and dX), see PFM_TF_F_BF16 (pfm_tf.h) */
 #define PFM_MDMA_F_TEMB_SINCOS 2u /* t_emb = "sincos" (flow_matching_module.py:208-211) instead of "cosine" */
@@ -44,9 +44,11 @@ extern "C" {
                                    * its scratch (pfm_mdma_backward_dtemb) */
 
 typedef struct {
-    pfm_tf_lin fc0;     /* Block.fc0 columns 0..H [H][H] MFMA_AK (+ WT); Wt = its time columns H..H+T KMAJOR [T][H] (t_local, else -1) */
+    pfm_tf_lin fc0;     /* Block.fc0 columns 0..H [H][H] MFMA_AK (+ WT); Wt = its time columns H..H+T KMAJOR [T][H] (t_local, else -1);
+                         * Wc = its condition column KMAJOR [1][H] behind them (local_cat_cond, else -1) */
     pfm_tf_lin kv;      /* attn.in_proj rows H..3H (k | v) [2H][H] MFMA_AK (+ WT), bias in_proj_bias[H..3H] */
-    pfm_tf_lin fc1;     /* Block.fc1: W = columns 0..H MFMA_AK (+ WT); Wc = columns H..H+L KMAJOR [L][H]; b */
+    pfm_tf_lin fc1;     /* Block.fc1: W = columns 0..H MFMA_AK (+ WT); Wc = its class-token columns KMAJOR [L][H]; Wt = its condition column
+                         * KMAJOR [1][H] (local_cat_cond: column H, the token columns then start at H + 1; else -1); b */
     int64_t fc0c_W, fc0c_b; /* fc0_cls  KMAJOR [L (+ T: t_global)][H], [H] */
     int64_t ln_g, ln_b;     /* ln       [H] */
     int64_t q_W, q_b;       /* attn.in_proj rows 0..H: KMAJOR [H][H], [H] */
@@ -71,11 +73,15 @@ typedef struct {
     float neg_slope; /* nn.LeakyReLU() default 0.01 */
     float ln_eps;
     float avg_n;     /* MDMA.avg_n: the particle sum is divided by it */
-    float pad2_;
+    int32_t c_cat;   /* the conditional variant (one condition value c per jet, `cond` [n_jets]; mdma.py:60-63, 79-82, 157-174): bit 0
+                      * net_config.global_cond_dim = 1 (c behind the particle count in the inputs of embbed_cls, cond and fc1_cls), bit 1
+                      * global_cat_cond (cl appended to the inputs of fc0_cls and fc2_cls), bit 2 local_cat_cond (c appended to the inputs of
+                      * embed and out, cl to those of fc0 and fc1); cl = cond[..., -1:] = c with bit 0 or 1, else the particle count */
     int64_t blob_floats;
     int64_t freqs;                  /* [t_dim] */
     int64_t emb_Wx, emb_Wt, emb_b;  /* MDMA.embed: KMAJOR [F][H], KMAJOR [t_dim][H] (-1 without time_in_input), [H] */
     int64_t emb_Wt2;                /* MDMA.embed's trailing time columns KMAJOR [t_dim][H] (t_local, else -1) */
+    int64_t emb_Wc, out_Wc;         /* local_cat_cond: embed's condition column KMAJOR [1][H], out's condition weight [1] (else -1) */
     int64_t ecls_W, ecls_b;         /* embbed_cls KMAJOR [H + 1][L], [L] */
     int64_t cond_W, cond_b;         /* MDMA.cond  KMAJOR [1][L], [L] */
     int64_t out_W, out_b;           /* MDMA.out   [H], [1] */
@@ -89,18 +95,18 @@ int64_t pfm_mdma_backward_scratch_floats(const pfm_mdma_desc *desc, int32_t n_je
 /* v_out[n_jets][N][F] = broadcast over F of MDMA(t, x, mask).  t: [n_jets] (per_jet_t != 0) or one shared value.
  * mask [n_jets][N] must be given (MDMA.forward indexes with it, mdma.py:151). */
 int pfm_mdma_forward(const pfm_mdma_desc *desc, const float *blob, const float *t, int32_t per_jet_t, const float *x,
-                     const float *mask, float *v_out, int32_t n_jets, float *workspace, void *stream);
+                     const float *cond, const float *mask, float *v_out, int32_t n_jets, float *workspace, void *stream);
 
 /* Fixed-step explicit Runge-Kutta sampler (as pfm_tf_sample_rk): t_eval [n_steps * stages], dt [n_steps];
  * state: (2 + stages) * n_jets * N * F floats. */
 int pfm_mdma_sample_rk(const pfm_mdma_desc *desc, const float *blob, const pfm_rk_tableau *tab, const float *t_eval,
-                       const float *dt, int32_t n_steps, const float *z, const float *mask, float *x_out, int32_t n_jets,
-                       int32_t premask, float *state, float *workspace, void *stream);
+                       const float *dt, int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
+                       int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);
 
 /* Loss forward with the draws given (kind 0 FM-OT: a = z; 1 CFM: a = x0, b = eps; 2 droid: a = z).
  * loss_sums[0] += sum (v - u)^2 over [n_jets][N][F], loss_sums[1] += sum mask. */
 int pfm_mdma_fm_loss_forward(const pfm_mdma_desc *desc, const float *blob, int32_t kind, float sigma, const float *t,
-                             const float *x, const float *a, const float *b, const float *mask, float *y_out,
+                             const float *x, const float *a, const float *b, const float *cond, const float *mask, float *y_out,
                              float *u_out, float *v_out, float *loss_sums, int32_t n_jets, float *workspace, void *stream);
 
 /* gblob[blob_floats] += d(gscale * loss_sums[0]) / d blob, from the workspace the forward left behind. */

@@ -587,6 +587,15 @@ MDMA_CONFIGS = {
     # t_emb="gaussian" (flow_matching_module.py:178-181, 213-221) in front of an MDMA that concatenates the embedding everywhere
     "gauss": (dict(MDMA_BASE, num_particles=24, t_emb="gaussian", hidden_dim=64, frequencies=6,
                    net_config=dict(mdma_net_config(2), frequencies=6, t_local_cat=True, t_global_cat=True)), 3, False),
+    # the conditional variant (mdma.py:60-63, 79-82, 157-174: one condition value per jet, global_cond_in (B, 1)): as the class token's and
+    # `cond`'s extra input (net_config.global_cond_dim = 1), appended to the class-token Linears (global_cat_cond) and to the particle
+    # Linears (local_cat_cond; without global_cond_dim the blocks append the particle COUNT, cond[..., -1:], the ends the condition)
+    "cond": (dict(MDMA_BASE, num_particles=24, global_cond_dim=1, net_config=dict(mdma_net_config(2), global_cond_dim=1)), 3, False),
+    "condcat": (dict(MDMA_BASE, num_particles=24, global_cond_dim=1, frequencies=6,
+                     net_config=dict(mdma_net_config(2), frequencies=6, global_cond_dim=1, t_local_cat=True, t_global_cat=True,
+                                     local_cat_cond=True, global_cat_cond=True)), 3, False),
+    "lcat": (dict(MDMA_BASE, num_particles=24, global_cond_dim=1, add_time_to_input=False, frequencies=6,
+                  net_config=dict(mdma_net_config(1), frequencies=6, local_cat_cond=True)), 3, False),
     "tglob": (dict(MDMA_BASE, num_particles=24, add_time_to_input=False, frequencies=6, t_emb="sincos",
                    net_config=dict(mdma_net_config(1), frequencies=6, t_local_cat=False, t_global_cat=True)), 3, False),
 }

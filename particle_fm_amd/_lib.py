@@ -111,11 +111,11 @@ SYMBOLS = {
     "pfm_mdma_workspace_floats": (c_int64, [POINTER(MdmaDesc), c_int32, c_int32]),
     "pfm_mdma_backward_scratch_floats": (c_int64, [POINTER(MdmaDesc), c_int32]),
     "pfm_mdma_backward_dtemb": (c_int, [POINTER(MdmaDesc), _fp, c_int32, _fp, c_void_p]),
-    "pfm_mdma_forward": (c_int, [POINTER(MdmaDesc), _fp, _fp, c_int32, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+    "pfm_mdma_forward": (c_int, [POINTER(MdmaDesc), _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_mdma_sample_rk": (
-        c_int, [POINTER(MdmaDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),
+        c_int, [POINTER(MdmaDesc), _fp, c_void_p, _fp, _fp, c_int32, _fp, _fp, _fp, _fp, c_int32, c_int32, _fp, _fp, c_void_p]),
     "pfm_mdma_fm_loss_forward": (
-        c_int, [POINTER(MdmaDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
+        c_int, [POINTER(MdmaDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_mdma_fm_loss_backward": (c_int, [POINTER(MdmaDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
     "pfm_tf_fm_loss_forward": (
         c_int, [POINTER(TfDesc), _fp, c_int32, c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_void_p]),

@@ -40,6 +40,8 @@ int validate(const pfm_mdma_desc* d) {
     if (d->t_dim < 0 || d->t_dim > 64) return set_err(PFM_E_BADARG, "t_dim out of range");
     if (d->time_in_input && d->t_dim < 1) return set_err(PFM_E_BADARG, "time_in_input needs t_dim >= 1");
     if (d->t_cat < 0 || d->t_cat > 3 || (d->t_cat && d->t_dim < 1)) return set_err(PFM_E_BADARG, "t_cat must be 0..3 (and needs t_dim >= 1)");
+    if (d->c_cat < 0 || d->c_cat > 7 || ((d->c_cat & 2) && !(d->c_cat & 1)))
+        return set_err(PFM_E_BADARG, "c_cat must be 0..7, global_cat_cond (bit 1) only with global_cond_dim = 1 (bit 0)");
     if (d->n_points < 1) return set_err(PFM_E_BADARG, "n_points must be >= 1");
     if (!(d->avg_n > 0.f)) return set_err(PFM_E_BADARG, "avg_n must be positive");
     return 0;
@@ -106,16 +108,32 @@ __device__ __forceinline__ float lrelu_d(float x, float slope) { return x > 0.f 
 // time embedding (time_emb.py:90-96 / flow_matching_module.py:208-211) and the per-jet bias rows it gives the particle Linears:
 // jbt[jet][:] = b + Wt . temb   (MDMA.embed; x = cat(temb, x): the time columns are the same for every particle of a jet)
 struct TimeArgs {
-    const float *blob, *t;
-    float *temb, *tact, *jbt, *jb0;  // temb / tact [B][64]: the embedding and LeakyReLU of it; jbt [B][H]; jb0 [layers][B][H] (t_local)
-    int64_t freqs, Wt, Wt2, b, fc0_Wt[PFM_MDMA_MAX_LAYERS], fc0_b[PFM_MDMA_MAX_LAYERS];
-    int t_stride, T, sincos, H, layers, B;  // layers: 0 without t_local
+    const float *blob, *t, *cond, *mask;  // cond [B] (c_cat), mask [B][N]
+    float *temb, *tact, *jbt, *jb0;  // temb / tact [B][64]: the embedding and LeakyReLU of it; jbt [B][H]; jb0 [layers][B][H] (t_local / local_cat_cond)
+    float *cj, *hb;                  // cj [B][4] = c, cl, LeakyReLU(c), LeakyReLU(cl) (c_cat); hb [B]: the head's bias per jet (local_cat_cond)
+    int64_t freqs, Wt, Wt2, Wc, b, out_b, out_Wc, fc0_Wt[PFM_MDMA_MAX_LAYERS], fc0_Wc[PFM_MDMA_MAX_LAYERS], fc0_b[PFM_MDMA_MAX_LAYERS];
+    int c_cat, N;
+    int t_stride, T, sincos, H, layers, B;  // layers: 0 without t_local / local_cat_cond
     int temb_k;  // PFM_MDMA_F_TEMB_GIVEN: floats between the elements of an embedding row in `t` (0: `t` holds times)
     float slope;
 };
 static __global__ __launch_bounds__(128) void mdma_time_kernel(TimeArgs a) {
-    __shared__ float te[64], ta[64];
+    __shared__ float te[64], ta[64], red2[2], cs[4];
     const int tid = threadIdx.x, jet = blockIdx.x, T = a.T, H = a.H;
+    if (a.c_cat) {  // the jet's condition value c and cl = cond[..., -1:] of the reference: c, or the particle count without global_cond_dim
+        float m = 0.f;
+        for (int n = tid; n < a.N; n += 128) m += a.mask[(int64_t)jet * a.N + n];
+        m = wave_sum(m);
+        if ((tid & 63) == 0) red2[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+            const float c = a.cond[jet], cl = (a.c_cat & 3) ? c : red2[0] + red2[1];
+            cs[0] = c; cs[1] = cl; cs[2] = lrelu(c, a.slope); cs[3] = lrelu(cl, a.slope);
+            if (a.out_Wc >= 0) a.hb[jet] = fmaf(a.blob[a.out_Wc], cs[2], a.blob[a.out_b]);  // out(act(cat(x, c))) (mdma.py:173-175)
+        }
+        __syncthreads();
+        if (tid < 4) a.cj[(int64_t)jet * 4 + tid] = cs[tid];
+    }
     if (tid < T) {
         const float tv = a.temb_k ? 0.f : a.t[(int64_t)jet * a.t_stride];
         const float f = a.blob[a.freqs + tid];
@@ -142,14 +160,17 @@ static __global__ __launch_bounds__(128) void mdma_time_kernel(TimeArgs a) {
         if (a.Wt2 >= 0)  // x = cat(x, t_in) in front of MDMA.embed (mdma.py:155-156): a second block of time columns
 #pragma unroll 8
             for (int k = 0; k < T; ++k) acc = fmaf(a.blob[a.Wt2 + (int64_t)k * H + o], te[k], acc);
+        if (a.Wc >= 0) acc = fmaf(a.blob[a.Wc + o], cs[0], acc);  // ... and cat(x, c) (mdma.py:157-158)
         a.jbt[(int64_t)jet * H + o] = acc;
     }
     // Block.fc0(act(cat(x, t_in))) (mdma.py:56-57, 65): the time columns give every particle of the jet the same bias row
     for (int l = 0; l < a.layers; ++l)
         for (int o = tid; o < H; o += 128) {
             float acc = a.blob[a.fc0_b[l] + o];
+            if (a.fc0_Wt[l] >= 0)
 #pragma unroll 8
-            for (int k = 0; k < T; ++k) acc = fmaf(a.blob[a.fc0_Wt[l] + (int64_t)k * H + o], ta[k], acc);
+                for (int k = 0; k < T; ++k) acc = fmaf(a.blob[a.fc0_Wt[l] + (int64_t)k * H + o], ta[k], acc);
+            if (a.fc0_Wc[l] >= 0) acc = fmaf(a.blob[a.fc0_Wc[l] + o], cs[3], acc);  // act(cat(x, t_in, cond[..., -1:])) (mdma.py:62-65)
             a.jb0[((int64_t)l * a.B + jet) * H + o] = acc;
         }
 }
@@ -181,10 +202,10 @@ static __global__ __launch_bounds__(256) void mdma_embed_kernel(const float* __r
 
 // the class token: x_cls = glu(cat(embbed_cls(cat(sum_n x / avg_n, n_valid)), cond(n_valid)))   (mdma.py:152-162)
 struct ClsInitArgs {
-    const float *blob, *X0, *mask;
+    const float *blob, *X0, *mask, *cj;  // cj: the jet's condition scalars (global_cond_dim: gcd = 1)
     float *pooled, *nv, *ea, *eg, *xc0;
     int64_t ecls_W, ecls_b, cond_W, cond_b;
-    int N, H, L;
+    int N, H, L, gcd;
     float avg_n;
 };
 static __global__ __launch_bounds__(JT) void mdma_cls_init_kernel(ClsInitArgs a) {
@@ -203,12 +224,14 @@ static __global__ __launch_bounds__(JT) void mdma_cls_init_kernel(ClsInitArgs a)
     float m = 0.f;
     for (int n = tid; n < a.N; n += JT) m += a.mask[(int64_t)jet * a.N + n];
     const float nv = block_sum256(m, red);
-    if (tid == 0) { xin[a.H] = nv; a.nv[jet] = nv; }
+    const float cv = a.gcd ? a.cj[(int64_t)jet * 4] : 0.f;
+    if (tid == 0) { xin[a.H] = nv; xin[a.H + 1] = cv; a.nv[jet] = nv; }
     __syncthreads();
-    jet_gemv(a.blob, a.ecls_W, a.ecls_b, a.H + 1, a.L, xin, y, part);
+    jet_gemv(a.blob, a.ecls_W, a.ecls_b, a.H + 1 + a.gcd, a.L, xin, y, part);
     if (tid < a.L) {
         const float av = y[tid];
-        const float g = fmaf(a.blob[a.cond_W + tid], nv, a.blob[a.cond_b + tid]);
+        float g = fmaf(a.blob[a.cond_W + tid], nv, a.blob[a.cond_b + tid]);
+        if (a.gcd) g = fmaf(a.blob[a.cond_W + a.L + tid], cv, g);  // cond(cat(n_valid, c)) (mdma.py:168-170)
         a.ea[(int64_t)jet * a.L + tid] = av;
         a.eg[(int64_t)jet * a.L + tid] = g;
         a.xc0[(int64_t)jet * a.L + tid] = av * (1.0f / (1.0f + __expf(-g)));
@@ -217,19 +240,20 @@ static __global__ __launch_bounds__(JT) void mdma_cls_init_kernel(ClsInitArgs a)
 
 // before the attention: x_cls = ln(fc0_cls(act(x_cls))); q = in_proj[:H] x_cls + b   (mdma.py:67 and the query half of :68)
 struct ClsPreArgs {
-    const float *blob, *xc_in, *tact;  // tact: LeakyReLU(time embedding) [B][64] (t_global: Tg > 0)
+    const float *blob, *xc_in, *tact, *cj;  // tact: LeakyReLU(time embedding) [B][64] (t_global: Tg > 0); cj: condition scalars (gcc)
     float *pre, *c, *q;
     int64_t fc0c_W, fc0c_b, ln_g, ln_b, q_W, q_b;
-    int H, L, Tg;
+    int H, L, Tg, gcc;
     float slope, eps;
 };
 static __global__ __launch_bounds__(JT) void mdma_cls_pre_kernel(ClsPreArgs a) {
-    __shared__ float al[MAXL + 64], pre[MAXH], c[MAXH], q[MAXH], part[JT], red[4];
+    __shared__ float al[MAXL + 64 + 4], pre[MAXH], c[MAXH], q[MAXH], part[JT], red[4];
     const int tid = threadIdx.x, jet = blockIdx.x;
     if (tid < a.L) al[tid] = lrelu(a.xc_in[(int64_t)jet * a.L + tid], a.slope);
     else if (tid < a.L + a.Tg) al[tid] = a.tact[(int64_t)jet * 64 + tid - a.L];  // act(cat(x_cls, t_in[:, :1])) (mdma.py:58-59, 67)
+    else if (tid == a.L + a.Tg && a.gcc) al[tid] = a.cj[(int64_t)jet * 4 + 3];   // ... cat(.., cond[..., -1:]) (mdma.py:60-61)
     __syncthreads();
-    jet_gemv(a.blob, a.fc0c_W, a.fc0c_b, a.L + a.Tg, a.H, al, pre, part);
+    jet_gemv(a.blob, a.fc0c_W, a.fc0c_b, a.L + a.Tg + a.gcc, a.H, al, pre, part);
     float s = 0.f;
     for (int k = tid; k < a.H; k += JT) s += pre[k];
     const float mean = block_sum256(s, red) / (float)a.H;
@@ -253,39 +277,45 @@ static __global__ __launch_bounds__(JT) void mdma_cls_pre_kernel(ClsPreArgs a) {
 // after the attention: out_proj, fc1_cls(cat(x_cls, n_valid)), fc2_cls, and the token columns of fc1 as the jet's bias row
 // (mdma.py:68-81: x = fc1(cat(x, x_cls.expand)) + res  ->  fc1.W[:, :H] x + (fc1.W[:, H:] x_cls + b))
 struct ClsPostArgs {
-    const float *blob, *att, *nv, *temb;  // temb: the time embedding [B][64] (t_global: Tg > 0)
+    const float *blob, *att, *nv, *temb, *cj;  // temb: the time embedding [B][64] (t_global: Tg > 0); cj: condition scalars (c_cat)
     float *o, *c2, *xc_out, *jb;
-    int64_t o_W, o_b, fc1c_W, fc1c_b, fc2c_W, fc2c_b, W1c, b1;
-    int H, L, Tg;
+    int64_t o_W, o_b, fc1c_W, fc1c_b, fc2c_W, fc2c_b, W1c, b1, W1k;  // W1k: fc1's condition column [H] (local_cat_cond, else -1)
+    int H, L, Tg, gcd, gcc;
 };
 static __global__ __launch_bounds__(JT) void mdma_cls_post_kernel(ClsPostArgs a) {
-    __shared__ float att[MAXH], o[MAXH + 4 + 64], c2[MAXL + 64], xo[MAXL], jb[MAXH], part[JT];
+    __shared__ float att[MAXH], o[MAXH + 4 + 64], c2[MAXL + 64 + 4], xo[MAXL], jb[MAXH], part[JT];
     const int tid = threadIdx.x, jet = blockIdx.x;
     for (int k = tid; k < a.H; k += JT) att[k] = a.att[(int64_t)jet * a.H + k];
     __syncthreads();
     jet_gemv(a.blob, a.o_W, a.o_b, a.H, a.H, att, o, part);
-    if (tid == 0) o[a.H] = a.nv[jet];
+    if (tid == 0) {
+        o[a.H] = a.nv[jet];
+        if (a.gcd) o[a.H + 1] = a.cj[(int64_t)jet * 4];             // cond = cat(n_valid, c) (mdma.py:168-169)
+        if (a.gcc) c2[a.L + a.Tg] = a.cj[(int64_t)jet * 4 + 1];     // cat(x_cls, t_in[:, :1], cond[..., -1:]) in front of fc2_cls (:78-79)
+    }
     if (tid < a.Tg) {  // cat(x_cls, cond, t_in[:, :1]) in front of fc1_cls, cat(x_cls, t_in[:, :1]) in front of fc2_cls (mdma.py:70-78)
         const float e = a.temb[(int64_t)jet * 64 + tid];
-        o[a.H + 1 + tid] = e;
+        o[a.H + 1 + a.gcd + tid] = e;
         c2[a.L + tid] = e;
     }
     for (int k = tid; k < a.H; k += JT) a.o[(int64_t)jet * a.H + k] = o[k];
     __syncthreads();
-    jet_gemv(a.blob, a.fc1c_W, a.fc1c_b, a.H + 1 + a.Tg, a.L, o, c2, part);
-    jet_gemv(a.blob, a.fc2c_W, a.fc2c_b, a.L + a.Tg, a.L, c2, xo, part);
+    jet_gemv(a.blob, a.fc1c_W, a.fc1c_b, a.H + 1 + a.gcd + a.Tg, a.L, o, c2, part);
+    jet_gemv(a.blob, a.fc2c_W, a.fc2c_b, a.L + a.Tg + a.gcc, a.L, c2, xo, part);
     if (tid < a.L) {
         a.c2[(int64_t)jet * a.L + tid] = c2[tid];
         a.xc_out[(int64_t)jet * a.L + tid] = xo[tid];
     }
     jet_gemv(a.blob, a.W1c, a.b1, a.L, a.H, xo, jb, part);
-    for (int k = tid; k < a.H; k += JT) a.jb[(int64_t)jet * a.H + k] = jb[k];
+    const float cl = a.W1k >= 0 ? a.cj[(int64_t)jet * 4 + 1] : 0.f;  // fc1(cat(x, cond[..., -1:], x_cls.expand)) (mdma.py:81-83)
+    for (int k = tid; k < a.H; k += JT) a.jb[(int64_t)jet * a.H + k] = a.W1k >= 0 ? fmaf(a.blob[a.W1k + k], cl, jb[k]) : jb[k];
 }
 
 // v = out(act(x)) * mask, written F times (the reference's loss / solver broadcast the single output over the features)
 template <int NI>
 __global__ __launch_bounds__(256) void mdma_head_kernel(const float* __restrict__ X, const float* __restrict__ blob, int64_t W, int64_t b,
-                                                        const float* __restrict__ mask, float* __restrict__ dst, int M, int F, float slope) {
+                                                        const float* __restrict__ mask, float* __restrict__ dst, int M, int F, float slope,
+                                                        const float* __restrict__ hb, int N) {  // hb: the bias per jet (local_cat_cond) or nullptr
     constexpr int H = 64 * NI;
     const int tid = threadIdx.x, pl = tid & 15;
     const int row = blockIdx.x * 16 + (tid >> 4);
@@ -297,7 +327,7 @@ __global__ __launch_bounds__(256) void mdma_head_kernel(const float* __restrict_
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(blob + W + 4 * pl + 64 * i);
         d += hsum4(xv * w4);
     }
-    d = (row_sum16(d) + blob[b]) * mask[rowc];
+    d = (row_sum16(d) + (hb ? hb[rowc / N] : blob[b])) * mask[rowc];
     if (row < M && pl < F) dst[(int64_t)row * F + pl] = d;
 }
 
@@ -352,7 +382,7 @@ struct ClsPostBwdArgs {
     float *gxo, *dc2, *dout, *datt;
     float* dtemb;  // PFM_MDMA_F_TEMB_GIVEN with t_global: [B][64], += the time rows of fc2_cls / fc1_cls times their output gradients
     int64_t W1c, fc2c_W, fc1c_W, o_W;
-    int H, L, Tg;
+    int H, L, Tg, gcd;
 };
 static __global__ __launch_bounds__(JT) void mdma_cls_post_bwd_kernel(ClsPostBwdArgs a) {
     __shared__ float djb[MAXH], gxo[MAXL], dc2[MAXL], dov[MAXH + 4], datt[MAXH], dte[2][64];
@@ -369,7 +399,7 @@ static __global__ __launch_bounds__(JT) void mdma_cls_post_bwd_kernel(ClsPostBwd
     if (tid < a.L) a.dc2[(int64_t)jet * a.L + tid] = dc2[tid];
     if (a.dtemb && a.Tg) {
         jet_gemv_t(a.blob, a.fc2c_W + (int64_t)a.L * a.L, a.Tg, a.L, gxo, dte[0]);
-        jet_gemv_t(a.blob, a.fc1c_W + (int64_t)(a.H + 1) * a.L, a.Tg, a.L, dc2, dte[1]);
+        jet_gemv_t(a.blob, a.fc1c_W + (int64_t)(a.H + 1 + a.gcd) * a.L, a.Tg, a.L, dc2, dte[1]);
         if (tid < a.Tg) a.dtemb[(int64_t)jet * 64 + tid] += dte[0][tid] + dte[1][tid];
     }
     jet_gemv_t(a.blob, a.fc1c_W, a.H + 1, a.L, dc2, dov);  // row H (the particle count) has no upstream
@@ -459,6 +489,14 @@ static __global__ __launch_bounds__(JT) void mdma_cls_init_bwd_kernel(ClsInitBwd
     for (int k = tid; k < a.H; k += JT) a.dpool[(int64_t)jet * a.H + k] = __fdiv_rn(dp[k], a.avg_n);
 }
 
+// out[jet] = sum of the jet's N values of v (local_cat_cond: the head's per-row output gradients, for its condition weight)
+static __global__ __launch_bounds__(64) void mdma_jetsum_kernel(const float* __restrict__ v, float* __restrict__ out, int N) {
+    float s = 0.f;
+    for (int n = threadIdx.x; n < N; n += 64) s += v[(int64_t)blockIdx.x * N + n];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
 // PFM_MDMA_F_TEMB_GIVEN: dtemb[jet][k] += f'(temb[jet][k]) * sum_o (W1[k][o] + W2[k][o]) g[jet][o] -- the time columns (KMAJOR [T][H]) of a
 // particle Linear whose per-jet bias row they feed (embed: W1, W2 = its two time blocks, f = id; Block.fc0: f = LeakyReLU)
 static __global__ __launch_bounds__(JT) void mdma_dtemb_kernel(const float* __restrict__ blob, int64_t W1, int64_t W2, const float* __restrict__ g,
@@ -499,7 +537,7 @@ static __global__ __launch_bounds__(256) void mdma_embed_bwd_kernel(const float*
 // host side
 // ------------------------------------------------------------------------------------------------
 struct Ws {
-    int64_t temb, tact, jbt, jb0, nv, pooled, ea, eg, xc, X, xstride, layer0, lstride;  // jb0: [layers][B][H] fc0 jet-bias rows (t_local)
+    int64_t temb, tact, jbt, jb0, cj, hb, nv, pooled, ea, eg, xc, X, xstride, layer0, lstride;  // jb0: [layers][B][H] fc0 jet-bias rows (t_local / local_cat_cond)
     int64_t o_h, o_kv, o_pre, o_c, o_q, o_att, o_o, o_c2, o_jb, total;
 };
 
@@ -509,7 +547,8 @@ Ws make_ws(const pfm_mdma_desc& d, int n_jets, bool train) {
     int64_t o = 0;
     auto take = [&](int64_t n) { const int64_t at = o; o += round64(n); return at; };
     w.temb = take(B * 64); w.tact = take(B * 64); w.jbt = take(B * H); w.nv = take(B); w.pooled = take(B * H);
-    w.jb0 = take((d.t_cat & 1) ? (int64_t)d.layers * B * H : 0);
+    w.jb0 = take(((d.t_cat & 1) || (d.c_cat & 4)) ? (int64_t)d.layers * B * H : 0);
+    w.cj = take(d.c_cat ? B * 4 : 0); w.hb = take((d.c_cat & 4) ? B : 0);
     w.ea = take(B * L); w.eg = take(B * L);
     w.xc = take((int64_t)(d.layers + 1) * round64(B * L));
     w.xstride = train ? round64(M * H) : 0;
@@ -534,6 +573,7 @@ struct Plan {
     int n_jets, M;
     hipStream_t s;
     int temb_k = 0;  // PFM_MDMA_F_TEMB_GIVEN: 1 (rows [jet][T]); the sampler switches to its [T][evaluations] table
+    const float* cond = nullptr;  // [n_jets] condition values (desc.c_cat)
     float* X(int l) const { return ws + w.X + w.xstride * l; }
     float* xc(int l) const { return ws + w.xc + round64((int64_t)n_jets * d->latent) * l; }
     float* lay(int l) const { return ws + w.layer0 + w.lstride * l; }
@@ -586,14 +626,21 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
     const int H = d.hidden, L = d.latent, N = d.n_points, B = p.n_jets;
     int rc;
     const int Tl = (d.t_cat & 1) ? d.t_dim : 0, Tg = (d.t_cat & 2) ? d.t_dim : 0;
+    const int gcd = d.c_cat & 1, gcc = (d.c_cat >> 1) & 1, lcc = (d.c_cat >> 2) & 1;
+    if (d.c_cat && !p.cond) return set_err(PFM_E_BADARG, "the conditional MDMA (desc.c_cat) needs cond");
+    const float* cj = ws + w.cj;
     {
         TimeArgs a;
         a.blob = p.blob; a.t = t; a.temb = ws + w.temb; a.tact = ws + w.tact; a.jbt = ws + w.jbt; a.jb0 = ws + w.jb0;
+        a.cond = p.cond; a.mask = mask; a.cj = ws + w.cj; a.hb = ws + w.hb; a.c_cat = d.c_cat; a.N = N;
+        a.Wc = lcc ? d.emb_Wc : (int64_t)-1; a.out_b = d.out_b; a.out_Wc = lcc ? d.out_Wc : (int64_t)-1;
         a.freqs = d.freqs; a.Wt = d.time_in_input ? d.emb_Wt : (int64_t)-1; a.Wt2 = Tl ? d.emb_Wt2 : (int64_t)-1; a.b = d.emb_b;
         a.t_stride = p.temb_k ? (t_stride ? d.t_dim : 0) : t_stride; a.temb_k = p.temb_k;
         a.T = (d.time_in_input || d.t_cat) ? d.t_dim : 0; a.sincos = (d.flags & PFM_MDMA_F_TEMB_SINCOS) ? 1 : 0;
-        a.H = H; a.layers = Tl ? d.layers : 0; a.B = B; a.slope = d.neg_slope;
-        for (int l = 0; l < a.layers; ++l) { a.fc0_Wt[l] = d.block[l].fc0.Wt; a.fc0_b[l] = d.block[l].fc0.b; }
+        a.H = H; a.layers = (Tl || lcc) ? d.layers : 0; a.B = B; a.slope = d.neg_slope;
+        for (int l = 0; l < a.layers; ++l) {
+            a.fc0_Wt[l] = Tl ? d.block[l].fc0.Wt : (int64_t)-1; a.fc0_Wc[l] = lcc ? d.block[l].fc0.Wc : (int64_t)-1; a.fc0_b[l] = d.block[l].fc0.b;
+        }
         hipLaunchKernelGGL(mdma_time_kernel, dim3(B), dim3(128), 0, p.s, a);
     }
     PFM_TRY(check_hip(hipGetLastError(), "mdma_time_kernel launch"));
@@ -605,7 +652,7 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         a.blob = p.blob; a.X0 = p.X(0); a.mask = mask;
         a.pooled = ws + w.pooled; a.nv = ws + w.nv; a.ea = ws + w.ea; a.eg = ws + w.eg; a.xc0 = p.xc(0);
         a.ecls_W = d.ecls_W; a.ecls_b = d.ecls_b; a.cond_W = d.cond_W; a.cond_b = d.cond_b;
-        a.N = N; a.H = H; a.L = L; a.avg_n = d.avg_n;
+        a.N = N; a.H = H; a.L = L; a.avg_n = d.avg_n; a.cj = cj; a.gcd = gcd;
         hipLaunchKernelGGL(mdma_cls_init_kernel, dim3(B), dim3(JT), 0, p.s, a);
         PFM_TRY(check_hip(hipGetLastError(), "mdma_cls_init_kernel launch"));
     }
@@ -614,10 +661,10 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         float* lb = p.lay(l);
         const float* Xin = p.X(l);
         float* Xout = p.X(l + 1);
-        PFM_TRY(linear(p, Xin, H, k.fc0.W, k.fc0.b, H, Tl ? ws + w.jb0 + (int64_t)l * B * H : nullptr, nullptr, nullptr, lb + w.o_h, 0, true));
+        PFM_TRY(linear(p, Xin, H, k.fc0.W, k.fc0.b, H, (Tl || lcc) ? ws + w.jb0 + (int64_t)l * B * H : nullptr, nullptr, nullptr, lb + w.o_h, 0, true));
         {
             ClsPreArgs a;
-            a.blob = p.blob; a.xc_in = p.xc(l); a.tact = ws + w.tact; a.Tg = Tg; a.pre = lb + w.o_pre; a.c = lb + w.o_c; a.q = lb + w.o_q;
+            a.blob = p.blob; a.xc_in = p.xc(l); a.tact = ws + w.tact; a.Tg = Tg; a.cj = cj; a.gcc = gcc; a.pre = lb + w.o_pre; a.c = lb + w.o_c; a.q = lb + w.o_q;
             a.fc0c_W = k.fc0c_W; a.fc0c_b = k.fc0c_b; a.ln_g = k.ln_g; a.ln_b = k.ln_b; a.q_W = k.q_W; a.q_b = k.q_b;
             a.H = H; a.L = L; a.slope = d.neg_slope; a.eps = d.ln_eps;
             hipLaunchKernelGGL(mdma_cls_pre_kernel, dim3(B), dim3(JT), 0, p.s, a);
@@ -629,7 +676,8 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         PFM_TRY(check_hip(hipGetLastError(), "ca_attn_from_kernel launch (mdma)"));
         {
             ClsPostArgs a;
-            a.blob = p.blob; a.att = lb + w.o_att; a.nv = ws + w.nv; a.temb = ws + w.temb; a.Tg = Tg;
+            a.blob = p.blob; a.att = lb + w.o_att; a.nv = ws + w.nv; a.temb = ws + w.temb; a.Tg = Tg; a.cj = cj; a.gcd = gcd; a.gcc = gcc;
+            a.W1k = lcc ? k.fc1.Wt : (int64_t)-1;
             a.o = lb + w.o_o; a.c2 = lb + w.o_c2; a.xc_out = p.xc(l + 1); a.jb = lb + w.o_jb;
             a.o_W = k.o_W; a.o_b = k.o_b; a.fc1c_W = k.fc1c_W; a.fc1c_b = k.fc1c_b; a.fc2c_W = k.fc2c_W; a.fc2c_b = k.fc2c_b;
             a.W1c = k.fc1.Wc; a.b1 = k.fc1.b; a.H = H; a.L = L;
@@ -639,13 +687,13 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
         PFM_TRY(linear(p, lb + w.o_h, H, k.fc1.W, -1, H, lb + w.o_jb, Xin, nullptr, Xout, 0, false));
     }
     PFM_MDMA_NI(mdma_head_kernel, dim3((p.M + 15) / 16), (const float*)p.X(d.layers), p.blob, d.out_W, d.out_b, mask, v_out, p.M,
-                d.features, d.neg_slope);
+                d.features, d.neg_slope, (d.c_cat & 4) ? (const float*)(ws + w.hb) : (const float*)nullptr, N);
     return check_hip(hipGetLastError(), "mdma_head_kernel launch");
 }
 
 // ---- backward ------------------------------------------------------------------------------------------
 struct Bs {
-    int64_t dvrow, zact, gX, gH, gkv, djb, gxc, gxo, dc2, dout, datt, gq, dc, dgx, dpre, al, da, dg, dpool, djbt, dwpart, dtemb, total;
+    int64_t dvrow, zact, gX, gH, gkv, djb, gxc, gxo, dc2, dout, datt, gq, dc, dgx, dpre, al, da, dg, dpool, djbt, dwpart, dtemb, dvj, total;
 };
 
 Bs make_bs(const pfm_mdma_desc& d, int n_jets) {
@@ -659,6 +707,7 @@ Bs make_bs(const pfm_mdma_desc& d, int n_jets) {
     b.al = take(B * L); b.da = take(B * L); b.dg = take(B * L); b.dpool = take(B * H); b.djbt = take(B * H);
     b.dwpart = take((int64_t)DW_MAX_PARTS * 16384);
     b.dtemb = take((d.flags & PFM_MDMA_F_TEMB_GIVEN) ? B * 64 : 0);
+    b.dvj = take((d.c_cat & 4) ? B : 0);
     b.total = o;
     return b;
 }
@@ -722,6 +771,8 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
     float* gxc[2] = {sc + b.gxc, sc + b.gxc + round64((int64_t)B * L)};
     const int Tl = (d.t_cat & 1) ? d.t_dim : 0, Tg = (d.t_cat & 2) ? d.t_dim : 0;
     const float *temb = ws + w.temb, *tact = ws + w.tact;
+    const int gcd = d.c_cat & 1, gcc = (d.c_cat >> 1) & 1, lcc = (d.c_cat >> 2) & 1;
+    const float* cj = ws + w.cj;  // [B][4] = c, cl, LeakyReLU(c), LeakyReLU(cl) of the forward
     float* dtemb = (d.flags & PFM_MDMA_F_TEMB_GIVEN) ? sc + b.dtemb : nullptr;  // (zeroed by the caller of run_backward)
     int rc;
     PFM_MDMA_NI(mdma_head_bwd_kernel, dim3((p.M + 15) / 16), (const float*)p.X(d.layers), v, u, mask, gscale, p.blob, d.out_W, Bw.gblob,
@@ -729,6 +780,14 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
     launch_ordered_sum(p.s, sc + b.dwpart, (p.M + 15) / 16, 1, 1, Bw.gblob + d.out_b, 1, nullptr);
     PFM_TRY(check_hip(hipGetLastError(), "mdma_head_bwd_kernel launch"));
     PFM_TRY(Bw.colsum(sc + b.zact, H, sc + b.dvrow, 1, nullptr, d.out_W));
+    if (lcc) {  // out(act(cat(x, c))): d W[H] = sum_jets LeakyReLU(c) * (sum of the jet's output gradients)
+        hipLaunchKernelGGL(mdma_jetsum_kernel, dim3(B), dim3(64), 0, p.s, (const float*)(sc + b.dvrow), sc + b.dvj, N);
+        PFM_TRY(check_hip(hipGetLastError(), "mdma_jetsum_kernel launch"));
+        Jobs J;
+        J.gblob = Bw.gblob;
+        J.add(cj + 2, 4, 1, sc + b.dvj, 1, 1, d.out_Wc);
+        PFM_TRY(J.launch(B, p.s));
+    }
     int cur = 0;  // gxc[cur]: d loss / d x_cls_out of the block being processed (none for the last block)
     for (int l = d.layers - 1; l >= 0; --l) {
         const pfm_mdma_block& k = d.block[l];
@@ -743,7 +802,7 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
             ClsPostBwdArgs a;
             a.blob = p.blob; a.djb = djb; a.gxc_next = (l == d.layers - 1) ? nullptr : gxc[cur];
             a.gxo = sc + b.gxo; a.dc2 = sc + b.dc2; a.dout = sc + b.dout; a.datt = sc + b.datt;
-            a.W1c = k.fc1.Wc; a.fc2c_W = k.fc2c_W; a.fc1c_W = k.fc1c_W; a.o_W = k.o_W; a.H = H; a.L = L; a.Tg = Tg; a.dtemb = dtemb;
+            a.W1c = k.fc1.Wc; a.fc2c_W = k.fc2c_W; a.fc1c_W = k.fc1c_W; a.o_W = k.o_W; a.H = H; a.L = L; a.Tg = Tg; a.gcd = gcd; a.dtemb = dtemb;
             hipLaunchKernelGGL(mdma_cls_post_bwd_kernel, dim3(B), dim3(JT), 0, p.s, a);
             PFM_TRY(check_hip(hipGetLastError(), "mdma_cls_post_bwd_kernel launch"));
         }
@@ -783,24 +842,33 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
             J.add(nullptr, 0, 1, sc + b.dpre, H, H, k.fc0c_b);
             PFM_TRY(J.launch(B, p.s));
         }
-        if (Tg) {  // the time rows of the class-token Linears (KMAJOR: behind their other input rows)
+        if (Tg || d.c_cat) {  // the time / condition rows of the class-token Linears (KMAJOR: behind their other input rows) and fc1's condition column
             Jobs J;
             J.gblob = Bw.gblob;
-            J.add(temb, 64, Tg, sc + b.gxo, L, L, k.fc2c_W + (int64_t)L * L);
-            J.add(temb, 64, Tg, sc + b.dc2, L, L, k.fc1c_W + (int64_t)(H + 1) * L);
-            J.add(tact, 64, Tg, sc + b.dpre, H, H, k.fc0c_W + (int64_t)L * H);
-            PFM_TRY(J.launch(B, p.s));
+            if (Tg) {
+                J.add(temb, 64, Tg, sc + b.gxo, L, L, k.fc2c_W + (int64_t)L * L);
+                J.add(temb, 64, Tg, sc + b.dc2, L, L, k.fc1c_W + (int64_t)(H + 1 + gcd) * L);
+                J.add(tact, 64, Tg, sc + b.dpre, H, H, k.fc0c_W + (int64_t)L * H);
+            }
+            if (gcd) J.add(cj, 4, 1, sc + b.dc2, L, L, k.fc1c_W + (int64_t)(H + 1) * L);
+            if (gcc) {
+                J.add(cj + 1, 4, 1, sc + b.gxo, L, L, k.fc2c_W + (int64_t)(L + Tg) * L);
+                J.add(cj + 3, 4, 1, sc + b.dpre, H, H, k.fc0c_W + (int64_t)(L + Tg) * H);
+            }
+            if (lcc) J.add(cj + 1, 4, 1, djb, H, H, k.fc1.Wt);
+            if (J.n) PFM_TRY(J.launch(B, p.s));
         }
         cur ^= 1;
         // h = fc0(act(x_in))
-        if (Tl) {  // per-jet bias rows b + Wt . act(temb): the bias and the time columns get sums over the jets of per-jet column sums
+        if (Tl || lcc) {  // per-jet bias rows b + Wt . act(temb) + Wc act(cl): bias, time and condition columns get sums over the jets of per-jet column sums
             PFM_TRY(Bw.colsum(gH, H, nullptr, 0, djb, -1));
             Jobs J;
             J.gblob = Bw.gblob;
             J.add(nullptr, 0, 1, djb, H, H, k.fc0.b);
-            J.add(tact, 64, Tl, djb, H, H, k.fc0.Wt);
+            if (Tl) J.add(tact, 64, Tl, djb, H, H, k.fc0.Wt);
+            if (lcc) J.add(cj + 3, 4, 1, djb, H, H, k.fc0.Wc);
             PFM_TRY(J.launch(B, p.s));
-            if (dtemb) {
+            if (dtemb && Tl) {
                 hipLaunchKernelGGL(mdma_dtemb_kernel, dim3(B), dim3(JT), 0, p.s, p.blob, k.fc0.Wt, (int64_t)-1, (const float*)djb, temb, dtemb,
                                    Tl, H, 1, d.neg_slope);
                 PFM_TRY(check_hip(hipGetLastError(), "mdma_dtemb_kernel launch (fc0)"));
@@ -837,6 +905,11 @@ int run_backward(const Bwd& Bw, const float* mask, const float* y, const float* 
         J.add(nullptr, 0, 1, sc + b.djbt, H, H, d.emb_b);
         if (d.time_in_input) J.add(temb, 64, d.t_dim, sc + b.djbt, H, H, d.emb_Wt);
         if (Tl) J.add(temb, 64, Tl, sc + b.djbt, H, H, d.emb_Wt2);
+        if (lcc) J.add(cj, 4, 1, sc + b.djbt, H, H, d.emb_Wc);
+        if (gcd) {
+            J.add(cj, 4, 1, sc + b.da, L, L, d.ecls_W + (int64_t)(H + 1) * L);
+            J.add(cj, 4, 1, sc + b.dg, L, L, d.cond_W + L);
+        }
         PFM_TRY(J.launch(B, p.s));
     }
     if (dtemb && (d.time_in_input || Tl)) {
@@ -865,22 +938,24 @@ int64_t pfm_mdma_backward_scratch_floats(const pfm_mdma_desc* d, int32_t n_jets)
     return make_bs(*d, n_jets < 1 ? 1 : n_jets).total;
 }
 
-int pfm_mdma_forward(const pfm_mdma_desc* d, const float* blob, const float* t, int32_t per_jet_t, const float* x, const float* mask,
-                     float* v_out, int32_t n_jets, float* workspace, void* stream) {
+int pfm_mdma_forward(const pfm_mdma_desc* d, const float* blob, const float* t, int32_t per_jet_t, const float* x, const float* cond,
+                     const float* mask, float* v_out, int32_t n_jets, float* workspace, void* stream) {
     Plan p;
     int rc = make_plan(p, d, blob, workspace, n_jets, false, stream);
     if (rc) return rc;
+    p.cond = cond;
     if (n_jets <= 0) return 0;
     if (!blob || !t || !x || !mask || !v_out || !workspace) return set_err(PFM_E_BADARG, "NULL device pointer (MDMA needs the mask)");
     return run_nfe(p, t, per_jet_t ? 1 : 0, x, mask, v_out);
 }
 
 int pfm_mdma_sample_rk(const pfm_mdma_desc* d, const float* blob, const pfm_rk_tableau* tab, const float* t_eval, const float* dt,
-                       int32_t n_steps, const float* z, const float* mask, float* x_out, int32_t n_jets, int32_t premask, float* state,
-                       float* workspace, void* stream) {
+                       int32_t n_steps, const float* z, const float* cond, const float* mask, float* x_out, int32_t n_jets, int32_t premask,
+                       float* state, float* workspace, void* stream) {
     Plan p;
     int rc = make_plan(p, d, blob, workspace, n_jets, false, stream);
     if (rc) return rc;
+    p.cond = cond;
     if (const char* e = rk_tableau_error(tab)) return set_err(PFM_E_BADARG, e);
     if (n_jets <= 0) return 0;
     if (n_steps < 1) return set_err(PFM_E_BADARG, "n_steps must be >= 1");
@@ -898,11 +973,12 @@ int pfm_mdma_sample_rk(const pfm_mdma_desc* d, const float* blob, const pfm_rk_t
 }
 
 int pfm_mdma_fm_loss_forward(const pfm_mdma_desc* d, const float* blob, int32_t kind, float sigma, const float* t, const float* x,
-                             const float* a, const float* b, const float* mask, float* y_out, float* u_out, float* v_out,
+                             const float* a, const float* b, const float* cond, const float* mask, float* y_out, float* u_out, float* v_out,
                              float* loss_sums, int32_t n_jets, float* workspace, void* stream) {
     Plan p;
     int rc = make_plan(p, d, blob, workspace, n_jets, true, stream);
     if (rc) return rc;
+    p.cond = cond;
     if (n_jets <= 0) return 0;
     if (kind < 0 || kind > 2) return set_err(PFM_E_BADARG, "kind must be 0 (FM-OT), 1 (CFM) or 2 (droid)");
     if (!blob || !t || !x || !a || !mask || !y_out || !u_out || !v_out || !loss_sums || !workspace)

@@ -79,11 +79,11 @@ class MdmaFieldFn(torch.autograd.Function):
     (B,), or -- a layout with t_emb="gaussian" (PFM_MDMA_F_TEMB_GIVEN) -- the time EMBEDDING rows (B, T), then a differentiable input."""
 
     @staticmethod
-    def forward(ctx, flat_params, layout, freqs, x, t, mask):
+    def forward(ctx, flat_params, layout, freqs, x, t, mask, cond=None):
         dev = x.device
         src = torch.cat([flat_params.to(torch.float32), freqs.to(dev, torch.float32), torch.zeros(1, device=dev)])
         blob = src[layout.index_map_on(dev)]
-        _, saved = hip_ops_mdma.mdma_fm_loss_forward(layout, blob, x, t.detach(), torch.zeros_like(x), mask, 0.0, "droid", None)
+        _, saved = hip_ops_mdma.mdma_fm_loss_forward(layout, blob, x, t.detach(), torch.zeros_like(x), mask, 0.0, "droid", None, cond=cond)
         ctx.layout, ctx.saved, ctx.blob = layout, saved, blob
         ctx.temb_shape = tuple(t.shape) if hip_ops_tf.temb_given(layout) else None
         return saved[2].clone()
@@ -95,12 +95,12 @@ class MdmaFieldFn(torch.autograd.Function):
         d_t = None
         if ctx.temb_shape is not None and ctx.needs_input_grad[4]:
             d_t = hip_ops_mdma.mdma_backward_dtemb(lay, G.shape[0], G.device).reshape(ctx.temb_shape)
-        return (gblob[lay.grad_pos_on(gblob.device)], None, None, None, d_t, None)
+        return (gblob[lay.grad_pos_on(gblob.device)], None, None, None, d_t, None, None)
 
 
-def mdma_field(layout, flat_params, t, x, mask, freqs: Optional[torch.Tensor] = None):
+def mdma_field(layout, flat_params, t, x, mask, freqs: Optional[torch.Tensor] = None, cond=None):
     from .layout_mdma import default_freqs
-    return MdmaFieldFn.apply(flat_params, layout, _freq_table(layout, freqs, default_freqs), x, t, mask)
+    return MdmaFieldFn.apply(flat_params, layout, _freq_table(layout, freqs, default_freqs), x, t, mask, cond)
 
 
 class EpicWideFieldFn(torch.autograd.Function):

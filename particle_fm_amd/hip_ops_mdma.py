@@ -17,6 +17,15 @@ from .hip_ops_tf import _KINDS
 from .layout_mdma import MdmaLayout
 
 
+def _cond_arg(layout: MdmaLayout, cond, B: int, dev):
+    """The conditional variant's ONE value per jet (desc.c_cat; mdma.py:157-169) as a (B,) device tensor; None otherwise (never read)."""
+    if not layout.cfg.needs_cond:
+        return None
+    if cond is None:
+        raise ValueError("this MDMA configuration (global_cond_dim / local_cat_cond / global_cat_cond) needs the condition, one value per jet")
+    return _dev_f32("cond", cond.reshape(-1), dev, (B,))
+
+
 def _prep(layout: MdmaLayout, blob, x, mask):
     cfg = layout.cfg
     if not x.is_cuda:
@@ -54,14 +63,15 @@ def workspace(layout: MdmaLayout, n_jets: int, device, train: bool = False) -> t
     return cache[key]
 
 
-def mdma_forward(layout: MdmaLayout, blob, t, x, mask) -> torch.Tensor:
+def mdma_forward(layout: MdmaLayout, blob, t, x, mask, cond=None) -> torch.Tensor:
     """(B, N, F) broadcast of MDMA(t, x, mask).  t: (B,) one time per jet, or 0-dim / (1,) for one shared time; a layout with
     t_emb="gaussian" (PFM_MDMA_F_TEMB_GIVEN) takes the time EMBEDDING rows (B, T) / one shared row instead."""
     lib = _lib.load()
     dev, B, blob, x, mask = _prep(layout, blob, x, mask)
     t, t_per_jet = _time_arg(layout, t, B, dev)
+    cond = _cond_arg(layout, cond, B, dev)
     v = torch.empty_like(x)
-    rc = lib.pfm_mdma_forward(ctypes.byref(layout.desc), _ptr(blob), _ptr(t), t_per_jet, _ptr(x),
+    rc = lib.pfm_mdma_forward(ctypes.byref(layout.desc), _ptr(blob), _ptr(t), t_per_jet, _ptr(x), _ptr(cond),
                               _ptr(mask), _ptr(v), B, _ptr(workspace(layout, B, dev)), _stream_ptr(dev))
     _lib.check(rc, "pfm_mdma_forward")
     return v
@@ -79,7 +89,7 @@ def mdma_backward_dtemb(layout, B: int, dev) -> torch.Tensor:
 
 
 def mdma_sample_rk(layout: MdmaLayout, blob, z, mask, ode_steps: int = 100, solver: str = "midpoint", premask: bool = True,
-                   t0: float = 1.0, t1: float = 0.0, temb_fn=None) -> torch.Tensor:
+                   t0: float = 1.0, t1: float = 0.0, temb_fn=None, cond=None) -> torch.Tensor:
     """x(t1) from x(t0) = z (*mask) with the fixed-step explicit Runge-Kutta scheme ``solver`` ("euler", "midpoint", "rk4" =
     torchdyn's 3/8 rule) over linspace(t0, t1, ode_steps); all launches queued on the current stream."""
     lib = _lib.load()
@@ -91,17 +101,18 @@ def mdma_sample_rk(layout: MdmaLayout, blob, z, mask, ode_steps: int = 100, solv
     ts, dts = ts.to(dev), dts.to(dev)
     if temb_given(layout):  # the table of embeddings replaces the time grid (PFM_MDMA_F_TEMB_GIVEN)
         ts = _temb_table(temb_fn, ts, dev)
+    cond = _cond_arg(layout, cond, B, dev)
     out = torch.empty_like(z)
     state = torch.empty((2 + tab.stages) * z.numel(), device=dev, dtype=torch.float32)
     rc = lib.pfm_mdma_sample_rk(ctypes.byref(layout.desc), _ptr(blob), ctypes.byref(tab), _ptr(ts), _ptr(dts), ode_steps - 1,
-                                _ptr(z), _ptr(mask), _ptr(out), B, int(bool(premask)), _ptr(state),
+                                _ptr(z), _ptr(cond), _ptr(mask), _ptr(out), B, int(bool(premask)), _ptr(state),
                                 _ptr(workspace(layout, B, dev)), _stream_ptr(dev))
     _lib.check(rc, "pfm_mdma_sample_rk")
     return out
 
 
 def mdma_fm_loss_forward(layout: MdmaLayout, blob, x, t, a, mask, sigma: float = 1e-4, kind: str = "FM-OT",
-                         eps: Optional[torch.Tensor] = None):
+                         eps: Optional[torch.Tensor] = None, cond=None):
     """Loss forward with the draws given (a = z for FM-OT / droid; a = x0, eps for CFM).
     Returns (sums (2,) = [sum (v-u)^2 over (B, N, F), sum mask], saved = (y, u, v, workspace))."""
     lib = _lib.load()
@@ -117,11 +128,12 @@ def mdma_fm_loss_forward(layout: MdmaLayout, blob, x, t, a, mask, sigma: float =
         if eps is None:
             raise ValueError("CFM needs the second noise draw eps")
         eps = _dev_f32("eps", eps, dev, tuple(x.shape))
+    cond = _cond_arg(layout, cond, B, dev)
     y, u, v = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
     sums = torch.zeros(2, device=dev, dtype=torch.float32)
     ws = workspace(layout, B, dev, train=True)
     rc = lib.pfm_mdma_fm_loss_forward(ctypes.byref(layout.desc), _ptr(blob), _KINDS[kind], float(sigma), _ptr(t), _ptr(x), _ptr(a),
-                                      _ptr(eps), _ptr(mask), _ptr(y), _ptr(u), _ptr(v), _ptr(sums), B, _ptr(ws), _stream_ptr(dev))
+                                      _ptr(eps), _ptr(cond), _ptr(mask), _ptr(y), _ptr(u), _ptr(v), _ptr(sums), B, _ptr(ws), _stream_ptr(dev))
     _lib.check(rc, "pfm_mdma_fm_loss_forward")
     return sums, (y, u, v, ws, mask)
 

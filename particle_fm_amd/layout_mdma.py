@@ -19,7 +19,7 @@ import numpy as np
 
 from .layout_tf import TfLayout, TfLin, default_freqs  # noqa: F401  (default_freqs re-exported)
 
-PFM_MDMA_ABI_VERSION = 2
+PFM_MDMA_ABI_VERSION = 3
 PFM_MDMA_MAX_LAYERS = 16
 PFM_MDMA_F_TEMB_SINCOS = 2
 
@@ -36,9 +36,10 @@ class MdmaDesc(ctypes.Structure):
         ("abi_version", ctypes.c_int32), ("n_points", ctypes.c_int32), ("features", ctypes.c_int32), ("hidden", ctypes.c_int32),
         ("latent", ctypes.c_int32), ("layers", ctypes.c_int32), ("heads", ctypes.c_int32), ("head_dim", ctypes.c_int32),
         ("t_dim", ctypes.c_int32), ("time_in_input", ctypes.c_int32), ("flags", ctypes.c_uint32), ("t_cat", ctypes.c_int32),
-        ("neg_slope", ctypes.c_float), ("ln_eps", ctypes.c_float), ("avg_n", ctypes.c_float), ("pad2_", ctypes.c_float),
+        ("neg_slope", ctypes.c_float), ("ln_eps", ctypes.c_float), ("avg_n", ctypes.c_float), ("c_cat", ctypes.c_int32),
         ("blob_floats", ctypes.c_int64), ("freqs", ctypes.c_int64),
         ("emb_Wx", ctypes.c_int64), ("emb_Wt", ctypes.c_int64), ("emb_b", ctypes.c_int64), ("emb_Wt2", ctypes.c_int64),
+        ("emb_Wc", ctypes.c_int64), ("out_Wc", ctypes.c_int64),
         ("ecls_W", ctypes.c_int64), ("ecls_b", ctypes.c_int64), ("cond_W", ctypes.c_int64), ("cond_b", ctypes.c_int64),
         ("out_W", ctypes.c_int64), ("out_b", ctypes.c_int64),
         ("block", MdmaBlock * PFM_MDMA_MAX_LAYERS),
@@ -62,6 +63,9 @@ class MdmaConfig:
     t_emb: str = "cosine"
     t_local_cat: bool = False       # mdma.py:56-57, 155-156: the time embedding concatenated to the inputs of embed and of every Block.fc0
     t_global_cat: bool = False      # mdma.py:58-59, 71-78: ... to the class-token Linears fc0_cls, fc1_cls, fc2_cls
+    global_cond_dim: int = 0        # net_config's (0 or 1): one condition value per jet behind the particle count (mdma.py:164-169, 70-74)
+    global_cat_cond: bool = False   # mdma.py:60-61, 79: cond[..., -1:] appended to the inputs of fc0_cls and fc2_cls
+    local_cat_cond: bool = False    # mdma.py:62-63, 81-82, 157-158, 173-174: ... of fc0 and fc1 (the condition itself for embed and out)
 
     @property
     def t_dim(self) -> int:
@@ -70,8 +74,6 @@ class MdmaConfig:
     @property
     def head_dim(self) -> int:
         return self.hidden // self.num_heads
-
-    global_cond_dim = 0  # MDMA never reads the condition with the switches this build supports (the time concatenations do not)
 
     @property
     def input_dim(self) -> int:
@@ -85,28 +87,32 @@ class MdmaConfig:
     def t_g(self) -> int:
         return self.t_dim if self.t_global_cat else 0
 
+    @property
+    def needs_cond(self) -> bool:
+        return bool(self.global_cond_dim or self.global_cat_cond or self.local_cat_cond)
+
     @staticmethod
     def from_hparams(hp: Mapping) -> "MdmaConfig":
         nc = dict(hp.get("net_config") or {})
-        for flag in ("local_cat_cond", "global_cat_cond"):
-            if nc.get(flag, False):
-                raise NotImplementedError(f"MDMA net_config.{flag}=True has no HIP kernels (the shipped flow_matching_mdma.yaml sets it False)")
+        gcd, gcc, lcc = int(nc.get("global_cond_dim", 0)), bool(nc.get("global_cat_cond", False)), bool(nc.get("local_cat_cond", False))
+        if gcd not in (0, 1) or (gcc and gcd != 1):
+            # MDMA.forward appends global_cond_in.unsqueeze(-1), ONE value per jet (mdma.py:164-169), and sizes embbed_cls by global_cond_dim
+            raise NotImplementedError("MDMA net_config.global_cond_dim must be 0 or 1 (1 with global_cat_cond): the reference's own shapes")
+        if (gcd or gcc or lcc) and int(hp.get("global_cond_dim", 0)) != 1:
+            raise ValueError("the conditional MDMA reads ONE condition value per jet (global_cond_in.unsqueeze(-1), mdma.py:158-169): "
+                             "the model's global_cond_dim must be 1")
         # MDMA.__init__'s own defaults (mdma.py:101-102): the time concatenations default to True; its Linears are sized by
         # net_config.frequencies, the embedding by the CNF's frequencies: the reference itself only runs when the two agree
         tl, tg = bool(nc.get("t_local_cat", True)), bool(nc.get("t_global_cat", True))
         if (tl or tg) and int(nc.get("frequencies", 6)) != int(hp.get("frequencies", 6)):
             raise ValueError("MDMA with t_local_cat / t_global_cat: net_config.frequencies must equal the model's frequencies "
                              "(mdma.py:25-36 sizes the Linears by the former, flow_matching_module.py:208-221 the embedding by the latter)")
-        if int(nc.get("global_cond_dim", 0)) != 0:
-            raise NotImplementedError("MDMA net_config.global_cond_dim > 0 has no HIP kernels (flow_matching_mdma.yaml: 0)")
-        if float(nc.get("dropout", 0.0)) != 0.0:
-            raise NotImplementedError("MDMA dropout has no HIP kernels")
         return MdmaConfig(
             num_particles=int(hp["num_particles"]), features=int(hp.get("features", 3)), hidden=int(nc.get("hidden_dim", 256)),
             latent=int(nc.get("latent", 16)), num_layers=int(nc.get("layers", 16)), num_heads=int(nc.get("num_heads", 8)),
             avg_n=float(nc.get("avg_n", 30)), frequencies=int(hp.get("frequencies", 6)),
             add_time_to_input=bool(hp.get("add_time_to_input", True)), t_emb=str(hp.get("t_emb", "sincos")),
-            t_local_cat=tl, t_global_cat=tg,
+            t_local_cat=tl, t_global_cat=tg, global_cond_dim=gcd, global_cat_cond=gcc, local_cat_cond=lcc,
         )
 
     def param_shapes(self) -> List[Tuple[str, Tuple[int, ...]]]:
@@ -118,21 +124,22 @@ class MdmaConfig:
             out.extend([(k + ".weight", (o, i)), (k + ".bias", (o,))])
 
         Tl, Tg = self.t_l, self.t_g
-        lin("net.embed", H, self.input_dim + Tl)
-        lin("net.embbed_cls", L, H + 1)
+        gcd, gcc, lcc = self.global_cond_dim, int(self.global_cat_cond), int(self.local_cat_cond)
+        lin("net.embed", H, self.input_dim + Tl + lcc)
+        lin("net.embbed_cls", L, H + 1 + gcd)
         for l in range(self.num_layers):
             p = f"net.encoder.{l}."
-            lin(p + "fc0", H, H + Tl)
-            lin(p + "fc0_cls", H, L + Tg)
-            lin(p + "fc1", H, H + L)
-            lin(p + "fc1_cls", L, H + 1 + Tg)
-            lin(p + "fc2_cls", L, L + Tg)
-            lin(p + "cond_cls", H, 0)
+            lin(p + "fc0", H, H + Tl + lcc)
+            lin(p + "fc0_cls", H, L + Tg + gcc)
+            lin(p + "fc1", H, H + L + lcc)
+            lin(p + "fc1_cls", L, H + 1 + gcd + Tg)
+            lin(p + "fc2_cls", L, L + Tg + gcc)
+            lin(p + "cond_cls", H, gcd)
             out.extend([(p + "attn.in_proj_weight", (3 * H, H)), (p + "attn.in_proj_bias", (3 * H,))])
             lin(p + "attn.out_proj", H, H)
             out.extend([(p + "ln.weight", (H,)), (p + "ln.bias", (H,))])
-        lin("net.out", 1, H)
-        lin("net.cond", L, 1)
+        lin("net.out", 1, H + lcc)
+        lin("net.cond", L, 1 + gcd)
         return out
 
     def param_count(self) -> int:
@@ -193,6 +200,8 @@ class MdmaLayout(TfLayout):
         d.heads, d.head_dim, d.t_dim, d.time_in_input = cfg.num_heads, cfg.head_dim, T, int(cfg.add_time_to_input)
         d.t_cat = int(cfg.t_local_cat) | (2 * int(cfg.t_global_cat))
         Tl, Tg = cfg.t_l, cfg.t_g
+        gcd, gcc, lcc = cfg.global_cond_dim, int(cfg.global_cat_cond), int(cfg.local_cat_cond)
+        d.c_cat = gcd | (2 * gcc) | (4 * lcc)
         d.flags = self.flags | (PFM_MDMA_F_TEMB_SINCOS if cfg.t_emb == "sincos" else 0) | (64 if cfg.t_emb == "gaussian" else 0)  # 64: PFM_*_F_TEMB_GIVEN
         d.neg_slope, d.ln_eps, d.avg_n = 0.01, 1e-5, cfg.avg_n
         d.freqs = self._put(self.freq_off + np.arange(T), primary=False)
@@ -200,28 +209,34 @@ class MdmaLayout(TfLayout):
         d.emb_Wx = self._km("net.embed.weight", 0, H, t0, F)
         d.emb_Wt = self._km("net.embed.weight", 0, H, 0, T) if cfg.add_time_to_input else -1
         d.emb_Wt2 = self._km("net.embed.weight", 0, H, t0 + F, T) if Tl else -1  # x = cat(x, t_in) (mdma.py:155-156)
+        d.emb_Wc = self._km("net.embed.weight", 0, H, t0 + F + Tl, 1) if lcc else -1
         d.emb_b = self._v("net.embed.bias")
-        d.ecls_W = self._km("net.embbed_cls.weight", 0, L, 0, H + 1)
+        d.ecls_W = self._km("net.embbed_cls.weight", 0, L, 0, H + 1 + gcd)
         d.ecls_b = self._v("net.embbed_cls.bias")
-        d.cond_W = self._km("net.cond.weight", 0, L, 0, 1)
+        d.cond_W = self._km("net.cond.weight", 0, L, 0, 1 + gcd)
         d.cond_b = self._v("net.cond.bias")
         d.out_W = self._v("net.out.weight", 0, H)  # [1][H] row
+        d.out_Wc = self._v("net.out.weight", H, 1) if lcc else -1
         d.out_b = self._v("net.out.bias")
         for l in range(cfg.num_layers):
             p = f"net.encoder.{l}."
             B = d.block[l]
             k = p + "fc0.weight"
-            B.fc0 = TfLin(self._ak(k, 0, H, 0, H), -1, self._km(k, 0, H, H, T) if Tl else -1, self._v(p + "fc0.bias"), self._ak(k, 0, H, 0, H, True))
+            B.fc0 = TfLin(self._ak(k, 0, H, 0, H), self._km(k, 0, H, H + Tl, 1) if lcc else -1, self._km(k, 0, H, H, T) if Tl else -1,
+                          self._v(p + "fc0.bias"), self._ak(k, 0, H, 0, H, True))
             k = p + "attn.in_proj_weight"
             B.kv = TfLin(self._ak(k, H, 2 * H, 0, H), -1, -1, self._v(p + "attn.in_proj_bias", H, 2 * H), self._ak(k, H, 2 * H, 0, H, True))
             B.q_W = self._km(k, 0, H, 0, H)
             B.q_b = self._v(p + "attn.in_proj_bias", 0, H)
             k = p + "fc1.weight"
-            B.fc1 = TfLin(self._ak(k, 0, H, 0, H), self._km(k, 0, H, H, L), -1, self._v(p + "fc1.bias"), self._ak(k, 0, H, 0, H, True))
-            B.fc0c_W, B.fc0c_b = self._km(p + "fc0_cls.weight", 0, H, 0, L + Tg), self._v(p + "fc0_cls.bias")
+            B.fc1 = TfLin(self._ak(k, 0, H, 0, H), self._km(k, 0, H, H + lcc, L), self._km(k, 0, H, H, 1) if lcc else -1, self._v(p + "fc1.bias"),
+                          self._ak(k, 0, H, 0, H, True))
+            B.fc0c_W, B.fc0c_b = self._km(p + "fc0_cls.weight", 0, H, 0, L + Tg + gcc), self._v(p + "fc0_cls.bias")
             B.ln_g, B.ln_b = self._v(p + "ln.weight"), self._v(p + "ln.bias")
             B.o_W, B.o_b = self._km(p + "attn.out_proj.weight", 0, H, 0, H), self._v(p + "attn.out_proj.bias")
-            B.fc1c_W, B.fc1c_b = self._km(p + "fc1_cls.weight", 0, L, 0, H + 1 + Tg), self._v(p + "fc1_cls.bias")
-            B.fc2c_W, B.fc2c_b = self._km(p + "fc2_cls.weight", 0, L, 0, L + Tg), self._v(p + "fc2_cls.bias")
+            B.fc1c_W, B.fc1c_b = self._km(p + "fc1_cls.weight", 0, L, 0, H + 1 + gcd + Tg), self._v(p + "fc1_cls.bias")
+            B.fc2c_W, B.fc2c_b = self._km(p + "fc2_cls.weight", 0, L, 0, L + Tg + gcc), self._v(p + "fc2_cls.bias")
             self._v(p + "cond_cls.bias")  # unused by the network (see the module docstring)
+            if gcd:
+                self._km(p + "cond_cls.weight", 0, H, 0, gcd)  # likewise (a slot for every parameter element)
         self._finish(d)

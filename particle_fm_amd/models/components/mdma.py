@@ -4,8 +4,8 @@ Same class names, constructor keywords, parameter names / shapes / registration 
 under a fixed seed, bit-identical default initialisation) as the reference (mdma.py:7-45, 87-140).  The blocks own parameters
 only: one evaluation of the network is a fixed sequence of HIP launches (``vector_field``; include/pfm_mdma.h), there is no
 per-block PyTorch compute and no CPU fallback.  The time concatenations (t_local_cat, t_global_cat: off in
-configs/model/flow_matching_mdma.yaml, on by MDMA's own defaults) have kernels; the condition concatenations (local_cat_cond,
-global_cat_cond) and global_cond_dim > 0 -- off in the yaml -- raise NotImplementedError at construction.
+configs/model/flow_matching_mdma.yaml, on by MDMA's own defaults) and the conditional variant (global_cond_dim = 1, local_cat_cond,
+global_cat_cond: one condition value per jet, off in the yaml) have kernels; `dropout` is ignored as in the reference (mdma.py:121-135 builds the blocks with dropout=0).
 """
 from __future__ import annotations
 
@@ -56,13 +56,10 @@ class MDMA(_FusedEncoder):
                  local_cat_cond: bool = False, global_cat_cond: bool = False, **kwargs):
         cnf = dict(kwargs.pop("_cnf", None) or {})
         super().__init__()
-        for flag, on in (("local_cat_cond", local_cat_cond), ("global_cat_cond", global_cat_cond)):
-            if on:
-                raise NotImplementedError(f"MDMA({flag}=True) has no HIP kernels (configs/model/flow_matching_mdma.yaml sets it False)")
-        if global_cond_dim:
-            raise NotImplementedError("MDMA(global_cond_dim > 0) has no HIP kernels (flow_matching_mdma.yaml: net_config.global_cond_dim 0)")
-        if dropout:
-            raise NotImplementedError("MDMA dropout has no HIP kernels")
+        if global_cond_dim not in (0, 1) or (global_cat_cond and global_cond_dim != 1):
+            # MDMA.forward appends global_cond_in.unsqueeze(-1) -- ONE value per jet (mdma.py:157-169) -- and sizes embbed_cls by global_cond_dim
+            raise NotImplementedError("MDMA(global_cond_dim) must be 0 or 1 (1 with global_cat_cond): the reference's own shapes")
+        # (`dropout` is accepted and ignored, as in the reference: MDMA builds its blocks with dropout=0 and Block never reads it, mdma.py:121-135)
         self.t_local_cat, self.t_global_cat = t_local_cat, t_global_cat
         self.embed = nn.Linear(input_dim + 2 * frequencies * t_local_cat + local_cat_cond, hidden_dim)
         self.embbed_cls = nn.Linear(hidden_dim + 1 + global_cond_dim, latent)
@@ -76,6 +73,7 @@ class MDMA(_FusedEncoder):
         self.local_cat_cond, self.global_cat_cond = local_cat_cond, global_cat_cond
         self.cond = nn.Linear(global_cond_dim + 1, latent)
         self.global_cond = global_cond_dim > 0
+        self.global_cond_dim = global_cond_dim
         self.latent, self.hidden_dim, self.num_layers, self.num_heads = latent, hidden_dim, layers, num_heads
         add_time = bool(cnf.get("add_time_to_input", False))
         cnf_freq = int(cnf.get("frequencies", 0))
@@ -91,7 +89,9 @@ class MDMA(_FusedEncoder):
         return MdmaConfig(num_particles=num_points or self.num_points, features=self.features, hidden=self.hidden_dim,
                           latent=self.latent, num_layers=self.num_layers, num_heads=self.num_heads, avg_n=float(self.avg_n),
                           frequencies=self.frequencies, add_time_to_input=self.add_time_to_input, t_emb=self.t_emb,
-                          t_local_cat=bool(self.t_local_cat), t_global_cat=bool(self.t_global_cat))
+                          t_local_cat=bool(self.t_local_cat), t_global_cat=bool(self.t_global_cat),
+                          global_cond_dim=int(self.global_cond_dim), global_cat_cond=bool(self.global_cat_cond),
+                          local_cat_cond=bool(self.local_cat_cond))
 
     def layout(self, num_points: Optional[int] = None):
         n = num_points or self.num_points
@@ -110,5 +110,5 @@ class MDMA(_FusedEncoder):
 
     @staticmethod
     def _forward_op(lay, blob, t, x, cond, mask):
-        # `cond` is not read: with global_cond_dim = 0 MDMA.forward never touches global_cond_in (mdma.py:153-160)
-        return hip_ops_mdma.mdma_forward(lay, blob, t, x, mask)[..., :1].contiguous()
+        # `cond` is read by the conditional variant only (global_cond_dim = 1 / the *_cat_cond switches: one value per jet, mdma.py:157-169)
+        return hip_ops_mdma.mdma_forward(lay, blob, t, x, mask, cond=cond if lay.cfg.needs_cond else None)[..., :1].contiguous()

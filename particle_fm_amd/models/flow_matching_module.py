@@ -238,7 +238,7 @@ class CNF(nn.Module):
         if self.is_mdma:  # the (B, N, 1) field broadcast over the features, as losses.py:74 does implicitly; cond is not read
             m = torch.ones(*x.shape[:2], 1, device=x.device) if mask is None else mask  # losses.py:42-43
             return _fm_loss_mdma.mdma_fm_loss(lay, self.net.flat_parameters(lay), x, t, z, m, sigma=sigma, kind=kind, eps=eps,
-                                              freqs=self.net.freq_tensor())
+                                              freqs=self.net.freq_tensor(), cond=cond if lay.cfg.needs_cond else None)
         src = self.net.source_vector(lay)
         if self.t_emb == "gaussian":
             return _fm_loss.epic_fm_loss(lay, src, x, t, z, cond=cond, mask=mask, sigma=sigma, kind=kind, eps=eps,
@@ -350,7 +350,7 @@ class CNF(nn.Module):
         if self.is_cross_attention:
             return _fm_field.ca_field(lay, fl, t, x, cond, mask, freqs=fr)
         m = torch.ones(*x.shape[:2], 1, device=x.device) if mask is None else mask
-        return _fm_field.mdma_field(lay, fl, t, x, m, freqs=fr)
+        return _fm_field.mdma_field(lay, fl, t, x, m, freqs=fr, cond=cond if lay.cfg.needs_cond else None)
 
     def _decode_diffusion_rows(self, z, cond, mask, ode_solver, ode_steps, weights):
         """loss_type="diffusion" sampling for the transformer / cross-attention / MDMA models: the field is one HIP evaluation per
@@ -439,7 +439,7 @@ class CNF(nn.Module):
             kw["temb_fn"] = self._temb_table_fn(z.device)
         if self.is_mdma:
             m = torch.ones(*z.shape[:2], 1, device=z.device) if mask is None else mask
-            return hip_ops_mdma.mdma_sample_rk(lay, blob, z, m, premask=False, **kw)
+            return hip_ops_mdma.mdma_sample_rk(lay, blob, z, m, premask=False, cond=cond if lay.cfg.needs_cond else None, **kw)
         if self.is_transformer:
             return hip_ops_tf.tf_sample_rk(lay, blob, z, cond, mask, premask=False, **kw)
         if self.is_cross_attention:

@@ -136,7 +136,7 @@ def load_mdma_golden(name):
     return _cache[key]
 
 
-@pytest.fixture(params=["small", "yaml", "tcat", "tloc", "tglob"])
+@pytest.fixture(params=["small", "yaml", "tcat", "tloc", "tglob", "cond", "condcat", "lcat"])
 def mdma_golden(request):
     return load_mdma_golden(request.param)
 

@@ -36,12 +36,12 @@ def test_forward_matches_reference_vectors(ops, mdma_golden, mk):
     g = mdma_golden
     lay, blob = _setup(g)
     tag = f"nfe_{mk}/"
-    x, t, mask = (g.get(tag + k) for k in ("x", "t", "mask"))
-    v = ops.mdma_forward(lay, blob, _dev(t), _dev(x), _dev(mask)).cpu()
+    x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))  # cond: the conditional fixtures' one value per jet
+    v = ops.mdma_forward(lay, blob, _dev(t), _dev(x), _dev(mask), cond=_dev(cond)).cpu()
     want = g.get(tag + "v_vec_t")  # (B, N, 1): the library returns it broadcast over the features
     torch.testing.assert_close(v, want.expand_as(v), atol=ATOL, rtol=RTOL)
     assert torch.equal(v[..., :1].expand_as(v), v)
-    vs = ops.mdma_forward(lay, blob, _dev(t[0]), _dev(x), _dev(mask)).cpu()  # 0-dim t of sampling
+    vs = ops.mdma_forward(lay, blob, _dev(t[0]), _dev(x), _dev(mask), cond=_dev(cond)).cpu()  # 0-dim t of sampling
     torch.testing.assert_close(vs, g.get(tag + "v_scalar_t").expand_as(vs), atol=ATOL, rtol=RTOL)
 
 
@@ -50,8 +50,8 @@ def test_midpoint_matches_reference_vectors(ops, mdma_golden, steps):
     g = mdma_golden
     tag = f"midpoint_{steps}/"
     lay, blob = _setup(g)
-    z, mask = (g.get(tag + k) for k in ("z", "mask"))
-    xe = ops.mdma_sample_rk(lay, blob, _dev(z), _dev(mask), ode_steps=steps, solver="midpoint").cpu()
+    z, mask, cond = (g.get(tag + k) for k in ("z", "mask", "cond"))
+    xe = ops.mdma_sample_rk(lay, blob, _dev(z), _dev(mask), ode_steps=steps, solver="midpoint", cond=_dev(cond)).cpu()
     torch.testing.assert_close(xe, g.get(tag + "x_end"), atol=2e-4, rtol=1e-3)
 
 
@@ -180,7 +180,7 @@ def test_loss_and_all_parameter_gradients(mdma_golden, kind):
         a, eps = g.get(tag + "x0").cuda(), g.get(tag + "eps").cuda()
     else:
         a, eps = g.get(tag + "z").cuda(), None
-    loss = mdma_fm_loss(lay, flat, x, t, a, mask, 1e-4, kind, eps, freqs=g.freqs)
+    loss = mdma_fm_loss(lay, flat, x, t, a, mask, 1e-4, kind, eps, freqs=g.freqs, cond=_dev(g.get(tag + "cond")))
     torch.testing.assert_close(loss.detach().cpu(), g.get(tag + "loss"), rtol=2e-5, atol=1e-6)
     loss.backward()
     _check_grads(g, lay, flat.grad.cpu(), tag)

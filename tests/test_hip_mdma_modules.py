@@ -31,21 +31,22 @@ def test_cnf_forward_reference_signature(mdma_golden):
     g = mdma_golden
     m = _module(g)
     tag = "nfe_int64/"
-    x, t, mask = (g.get(tag + k) for k in ("x", "t", "mask"))
+    x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))  # cond: the conditional fixtures' (B, 1)
     N = x.shape[1]
     vf = _oracle(g)
     with torch.no_grad():
-        ref = vf(t[:, None].expand(-1, N), x, mask=mask)
-        ref_s = vf(t[0], x, mask=mask)
+        ref = vf(t[:, None].expand(-1, N), x, cond=cond, mask=mask)
+        ref_s = vf(t[0], x, cond=cond, mask=mask)
     tt = t.unsqueeze(-1).repeat_interleave(N, dim=1)  # losses.py:47 shape (B,N)
-    v = m.flows[0](tt.cuda(), x.cuda(), cond=torch.zeros(x.shape[0], 0).cuda(), mask=mask.cuda()).cpu()
+    dcond = torch.zeros(x.shape[0], 0).cuda() if cond is None else cond.cuda()
+    v = m.flows[0](tt.cuda(), x.cuda(), cond=dcond, mask=mask.cuda()).cpu()
     assert v.shape == (x.shape[0], N, 1)  # ONE output per particle, like the reference
     torch.testing.assert_close(v, ref, atol=2e-5, rtol=2e-4)
-    vs = m.flows[0](t[0].cuda(), x.cuda(), mask=mask.cuda()).cpu()  # 0-dim t (sampling)
+    vs = m.flows[0](t[0].cuda(), x.cuda(), cond=None if cond is None else dcond, mask=mask.cuda()).cpu()  # 0-dim t (sampling)
     torch.testing.assert_close(vs, ref_s, atol=2e-5, rtol=2e-4)
     # with the recording host's frequency table the recorded vectors themselves come back
     m.set_freq_table(g.freqs)
-    v = m.flows[0](tt.cuda(), x.cuda(), mask=mask.cuda()).cpu()
+    v = m.flows[0](tt.cuda(), x.cuda(), cond=None if cond is None else dcond, mask=mask.cuda()).cpu()
     torch.testing.assert_close(v, g.get(tag + "v_vec_t"), atol=2e-5, rtol=2e-4)
 
 
@@ -79,12 +80,13 @@ def test_training_step_replays_reference_draws(mdma_golden):
     m = _module(g)
     tag = "loss_f32/"
     x, mask = g.get(tag + "x").cuda(), g.get(tag + "mask").cuda()
+    cond = g.get(tag + "cond")
     torch.manual_seed(77)
-    loss = m.training_step((x, mask, None), 0)["loss"]
+    loss = m.training_step((x, mask, None if cond is None else cond.cuda()), 0)["loss"]
     torch.manual_seed(77)
     t = torch.rand_like(torch.ones(x.shape[0]))
     z = torch.randn_like(x).cpu()
-    ref, *_ = fm_ot_loss(broadcast_field(_oracle(g)), x.cpu(), mask.cpu(), None, t, z, 1e-4)
+    ref, *_ = fm_ot_loss(broadcast_field(_oracle(g)), x.cpu(), mask.cpu(), cond, t, z, 1e-4)
     torch.testing.assert_close(loss.detach().cpu(), ref, rtol=2e-5, atol=1e-6)
     loss.backward()
     for k, p in m.flows[0].net.named_parameters():

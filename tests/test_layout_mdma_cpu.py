@@ -24,8 +24,8 @@ def test_blob_evaluates_to_reference(mdma_golden):
     assert blob.numel() == lay.blob_total
     for mk in ("f32", "ones"):
         tag = f"nfe_{mk}/"
-        x, t, mask = (g.get(tag + k) for k in ("x", "t", "mask"))
-        v = mdma_blob_interp.forward(lay.desc, blob, t, x, mask.reshape(x.shape[0], -1).float())
+        x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))
+        v = mdma_blob_interp.forward(lay.desc, blob, t, x, mask.reshape(x.shape[0], -1).float(), cond)
         torch.testing.assert_close(v.unsqueeze(-1), g.get(tag + "v_vec_t"), rtol=2e-4, atol=2e-5)
 
 
@@ -39,9 +39,13 @@ def test_grad_pos_is_a_bijection_onto_primary_slots(mdma_golden):
 def test_unsupported_configs_are_rejected():
     hp = dict(num_particles=30, features=3, frequencies=16, net_config=dict(hidden_dim=128, layers=2, t_local_cat=False, t_global_cat=False))
     MdmaLayout(MdmaConfig.from_hparams(hp))
-    for bad in (dict(global_cond_dim=1), dict(local_cat_cond=True), dict(hidden_dim=64), dict(num_heads=2), dict(latent=10)):
+    for bad in (dict(global_cond_dim=2), dict(global_cat_cond=True), dict(hidden_dim=64), dict(num_heads=2), dict(latent=10)):
         with pytest.raises(NotImplementedError):
             MdmaLayout(MdmaConfig.from_hparams(dict(hp, net_config=dict(hp["net_config"], **bad))))
+    # the conditional variant reads ONE value per jet (mdma.py:157-169): the model's global_cond_dim has to be 1
+    with pytest.raises(ValueError, match="global_cond_dim"):
+        MdmaConfig.from_hparams(dict(hp, net_config=dict(hp["net_config"], local_cat_cond=True)))
+    assert MdmaConfig.from_hparams(dict(hp, global_cond_dim=1, net_config=dict(hp["net_config"], global_cond_dim=1))).needs_cond
     # MDMA's own defaults concatenate the time embedding (mdma.py:101-102): its Linears are sized by net_config.frequencies (default 6),
     # the embedding by the model's -- as in the reference, the two have to agree
     with pytest.raises(ValueError, match="frequencies"):

@@ -54,8 +54,7 @@ def test_errors():
         m.flows[0].decode(x, None, None, ode_solver="dopri5")
     with pytest.raises(RuntimeError, match="fused"):
         m.flows[0].net.encoder[0](x, None, None, None)
-    for bad in (dict(global_cond_dim=1), dict(global_cat_cond=True), dict(local_cat_cond=True), dict(hidden_dim=96), dict(num_heads=2),
-                dict(latent=10), dict(dropout=0.1)):
+    for bad in (dict(global_cond_dim=2), dict(global_cat_cond=True), dict(hidden_dim=96), dict(num_heads=2), dict(latent=10)):
         with pytest.raises(NotImplementedError):
             SetFlowMatchingLitModule(**base, net_config=dict(nc, **bad))
     # MDMA's own defaults concatenate the time embedding (mdma.py:101-102) with Linears sized by net_config.frequencies (default 6):

@@ -15,27 +15,27 @@ def test_nfe(mdma_golden):
     vf = _vf(g)
     for mk in ("f32", "int64", "ones"):
         tag = f"nfe_{mk}/"
-        x, t, mask = (g.get(tag + k) for k in ("x", "t", "mask"))
+        x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))  # cond: None unless the model is conditional
         tt = t.unsqueeze(-1).repeat_interleave(x.shape[1], dim=1)
         want = g.get(tag + "v_vec_t")
         assert want.shape == (*x.shape[:2], 1)  # ONE output per particle (mdma.py:136: Linear(hidden, 1))
         with torch.no_grad():
-            torch.testing.assert_close(vf(tt, x, mask=mask), want, rtol=2e-4, atol=2e-5)
-            torch.testing.assert_close(vf(t[0], x, mask=mask), g.get(tag + "v_scalar_t"), rtol=2e-4, atol=2e-5)
+            torch.testing.assert_close(vf(tt, x, cond=cond, mask=mask), want, rtol=2e-4, atol=2e-5)
+            torch.testing.assert_close(vf(t[0], x, cond=cond, mask=mask), g.get(tag + "v_scalar_t"), rtol=2e-4, atol=2e-5)
 
 
 def test_losses_and_grads(mdma_golden):
     g = mdma_golden
     for tag, fn in (("loss_f32/", "fm"), ("cfm/", "cfm"), ("droid/", "droid")):
         state = {k: v.clone().requires_grad_(True) for k, v in g.state.items() if k != "flows.0.frequencies"}
-        x, t, mask = (g.get(tag + k) for k in ("x", "t", "mask"))
+        x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))
         vf = broadcast_field(_vf(g, state))
         if fn == "fm":
-            loss, *_ = fm_ot_loss(vf, x, mask, None, t, g.get(tag + "z"), 1e-4)
+            loss, *_ = fm_ot_loss(vf, x, mask, cond, t, g.get(tag + "z"), 1e-4)
         elif fn == "cfm":
-            loss, *_ = cfm_loss(vf, x, mask, None, t, g.get(tag + "x0"), g.get(tag + "eps"), 1e-4)
+            loss, *_ = cfm_loss(vf, x, mask, cond, t, g.get(tag + "x0"), g.get(tag + "eps"), 1e-4)
         else:
-            loss, *_ = droid_loss(vf, x, mask, None, t, g.get(tag + "z"))
+            loss, *_ = droid_loss(vf, x, mask, cond, t, g.get(tag + "z"))
         torch.testing.assert_close(loss.detach(), g.get(tag + "loss"), rtol=1e-5, atol=1e-6)
         loss.backward()
         ref = g.grads(tag)
@@ -49,6 +49,6 @@ def test_midpoint(mdma_golden):
     g = mdma_golden
     for steps in (3, 10):
         tag = f"midpoint_{steps}/"
-        z, mask = (g.get(tag + k) for k in ("z", "mask"))
-        got = sample_midpoint(broadcast_field(_vf(g)), z, None, mask, steps)
+        z, mask, cond = (g.get(tag + k) for k in ("z", "mask", "cond"))
+        got = sample_midpoint(broadcast_field(_vf(g)), z, cond, mask, steps)
         torch.testing.assert_close(got, g.get(tag + "x_end"), rtol=1e-3, atol=1e-4)
