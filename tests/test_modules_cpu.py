@@ -166,12 +166,12 @@ def test_mdma_desc_mirror_matches_the_c_struct(tmp_path):
     from particle_fm_amd.layout_mdma import MdmaBlock, MdmaConfig, MdmaDesc, MdmaLayout
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pfm_mdma.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
-                   'sizeof(pfm_mdma_desc), offsetof(pfm_mdma_desc, block), sizeof(pfm_mdma_block), offsetof(pfm_mdma_desc, avg_n),'
+                   'sizeof(pfm_mdma_desc), offsetof(pfm_mdma_desc, block), sizeof(pfm_mdma_block), offsetof(pfm_mdma_desc, c_cat),'
                    'offsetof(pfm_mdma_desc, out_b), offsetof(pfm_mdma_block, fc2c_b));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", f"{ROOT}/include", str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
-    assert got == [ctypes.sizeof(MdmaDesc), MdmaDesc.block.offset, ctypes.sizeof(MdmaBlock), MdmaDesc.avg_n.offset,
+    assert got == [ctypes.sizeof(MdmaDesc), MdmaDesc.block.offset, ctypes.sizeof(MdmaBlock), MdmaDesc.c_cat.offset,
                    MdmaDesc.out_b.offset, MdmaBlock.fc2c_b.offset]
     lib = _lib.load()
     lay = MdmaLayout(MdmaConfig(num_particles=150, hidden=128, num_layers=4, frequencies=16))
@@ -180,7 +180,7 @@ def test_mdma_desc_mirror_matches_the_c_struct(tmp_path):
     assert lib.pfm_mdma_backward_scratch_floats(ctypes.byref(lay.desc), 128) > 0
     lay.desc.latent = 10
     assert lib.pfm_mdma_workspace_floats(ctypes.byref(lay.desc), 1, 0) == -1
-    rc = lib.pfm_mdma_forward(ctypes.byref(lay.desc), None, None, 0, None, None, None, 1, None, None)
+    rc = lib.pfm_mdma_forward(ctypes.byref(lay.desc), None, None, 0, None, None, None, None, 1, None, None)
     assert rc == 10001 and b"latent" in lib.pfm_last_error()
 
 
