@@ -63,7 +63,9 @@ int64_t pfm_ew_workspace_floats(const pfm_ew_desc *desc, int32_t n_jets, int32_t
 int pfm_ew_forward(const pfm_ew_desc *desc, const float *blob, const float *t, int32_t t_stride, const float *x,
                    const float *cond, const float *mask, float *v, int32_t n_jets, float *workspace, void *stream);
 
-/* see pfm_tf_sample_midpoint */
+/* see pfm_tf_sample_midpoint, except that a call stays on `stream` (no half-batch split) and, from the second step on, replays its
+ * captured step body as a hipGraph (the host cannot enqueue ~210 launches per step fast enough); PFM_EW_GRAPH=0 in the environment:
+ * direct launches (diagnostics) */
 int pfm_ew_sample_midpoint(const pfm_ew_desc *desc, const float *blob, const float *t_eval, const float *dt,
                            int32_t n_steps, const float *z, const float *cond, const float *mask, float *x_out,
                            int32_t n_jets, int32_t premask, float *state, float *workspace, void *stream);

@@ -172,7 +172,7 @@ int dense_block(const Plan& p, int rows, int per_jet, float* mid, int D, int Hd,
 //   q   = q_linear(LN_1(tok))       of the NEXT pair's tokens <- particles layer (if any)
 // As row GEMMs over the 4 n_jets token rows these were five launches of a few workgroups each, ~7 us of launch + ramp latency
 // apiece (40 of the ~100 launches of an evaluation).  Here the jet's Tk <= 8 token rows live in LDS and every Linear is a GEMV
-// group straight on the MFMA_AK blocks (as ew_chain_kernel of ew_kernels.hip): a wave takes a 16-output block, lane (i, q)
+// group straight on the MFMA_AK blocks (round 2's per-jet chain of the row-matrix EPiC path worked the same way): a wave takes a 16-output block, lane (i, q)
 // multiplies the weight float4 it would feed the matrix pipe with by the matching float4 of each token row.
 // ------------------------------------------------------------------------------------------------
 constexpr int TKLD = MAXK + 8;          // floats per LDS row
