@@ -79,6 +79,10 @@ int64_t pfm_ca_backward_scratch_floats(const pfm_ca_desc *desc, int32_t n_jets);
 int pfm_ca_fm_loss_backward(const pfm_ca_desc *desc, const float *blob, const float *cond, const float *mask,
                             const float *y, const float *u, const float *v, const float *gscale, float *gblob,
                             int32_t n_jets, float *workspace, float *scratch, void *stream);
+/* the same, and grad_y[n_jets][N][F] = d(loss)/d(y) * gscale (see pfm_tf_fm_loss_backward_dx) */
+int pfm_ca_fm_loss_backward_dx(const pfm_ca_desc *desc, const float *blob, const float *cond, const float *mask, const float *y,
+                               const float *u, const float *v, const float *gscale, float *gblob, float *grad_y, int32_t n_jets,
+                               float *workspace, float *scratch, void *stream);
 
 /* PFM_CA_F_TEMB_GIVEN: dtemb[n_jets][t_dim] = d(loss)/d(temb) * gscale of the pfm_ca_fm_loss_backward call that has just filled
  * `scratch` (as pfm_tf_backward_dtemb). */

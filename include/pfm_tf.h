@@ -164,6 +164,12 @@ int64_t pfm_tf_backward_scratch_floats(const pfm_tf_desc *desc, int32_t n_jets);
 int pfm_tf_fm_loss_backward(const pfm_tf_desc *desc, const float *blob, const float *t, const float *cond,
                             const float *mask, const float *y, const float *u, const float *v, const float *gscale,
                             float *gblob, int32_t n_jets, float *workspace, float *scratch, void *stream);
+/* the same, and grad_y[n_jets][N][F] = d(loss)/d(y) * gscale: the gradient w.r.t. the network's particle input through node_embd's particle
+ * columns -- what a chain of flows needs (n_transforms > 1, flow_matching_module.py:421-443; losses.py:66-69 feeds each flow's output to the
+ * next); see pfm_epic_fm_loss_backward_dx in pfm_hip.h */
+int pfm_tf_fm_loss_backward_dx(const pfm_tf_desc *desc, const float *blob, const float *cond, const float *mask, const float *y,
+                               const float *u, const float *v, const float *gscale, float *gblob, float *grad_y, int32_t n_jets,
+                               float *workspace, float *scratch, void *stream);
 
 /* PFM_TF_F_TEMB_GIVEN: dtemb[n_jets][t_dim] = d(loss)/d(temb) * gscale of the pfm_tf_fm_loss_backward call that has just filled
  * `scratch` (same descriptor, blob and n_jets): through the context network's first Linear and the time columns of node_embd. */

@@ -833,6 +833,75 @@ def gen_chain(ref, out_dir, B=4, seed=1212, hp=None, file_name="epic_chain2.npz"
 
 
 # ----------------------------------------------------------------------------------------------
+# n_transforms = 2 on the Full-Transformer / cross-attention models (flow_matching_module.py:421-443): two flows with seed-derived
+# weights, the losses of losses.py:66-69 / 125-128 (each flow's output is the next one's input, same t), sampling through both in reverse
+# ----------------------------------------------------------------------------------------------
+def gen_chain_rows(ref, prefix, out_dir, B=3, seed=8181):
+    import copy
+    import json
+
+    from oracle.seeded import seeded_state, subsample
+
+    hp = copy.deepcopy({"tf": TF_CONFIGS, "ca": CA_CONFIGS}[prefix]["small"][0])
+    cnfs = []
+    for i in range(2):
+        torch.manual_seed(seed + i)
+        cnfs.append(ref.fmm.CNF(**copy.deepcopy(hp)))
+    shapes = {f"flows.{i}.{k}": tuple(v.shape) for i, c in enumerate(cnfs) for k, v in c.state_dict().items() if k != "frequencies"}
+    new = seeded_state(shapes, seed)
+    for i, c in enumerate(cnfs):
+        sd = c.state_dict()
+        for k in list(sd):
+            if k != "frequencies":
+                sd[k] = torch.from_numpy(new[f"flows.{i}.{k}"])
+        c.load_state_dict(sd)
+    flows = torch.nn.ModuleList(cnfs)
+    N, Fe, Cg = hp["num_particles"], hp["features"], hp["global_cond_dim"]
+    out = {"_keys": np.array([f"flows.{i}.{k}" for i, c in enumerate(cnfs) for k in c.state_dict().keys()])}
+    out["_shapes_json"] = np.array(json.dumps({k: list(v) for k, v in shapes.items()}))
+    out["seed"] = np.array(seed)
+    out["hp_json"] = np.array(json.dumps(dict(hp, n_transforms=2)))
+    out["freqs"] = (torch.arange(2 * hp["frequencies"]).exp() if hp["t_emb"] == "cosine" else cnfs[0].frequencies.clone()).numpy()
+    out["abs_sum"] = np.array(sum(float(np.abs(v).sum(dtype=np.float64)) for v in new.values()))
+    gen = torch.Generator().manual_seed(seed + 1)
+    for name, cls in (("fm", ref.losses.FlowMatchingLoss), ("cfm", ref.losses.ConditionalFlowMatchingLoss)):
+        mask = make_mask(B, N, "f32", gen)
+        x = torch.randn(B, N, Fe, generator=gen) * mask
+        cond = torch.randn(B, Cg, generator=gen)
+        loss_mod = cls(flows=flows, sigma=1e-4)
+        torch.manual_seed(2468)
+        flows.zero_grad()
+        loss = loss_mod(x, mask=mask, cond=cond)
+        loss.backward()
+        torch.manual_seed(2468)
+        t = torch.rand_like(torch.ones(B))
+        a = torch.randn_like(x)
+        tag = f"loss_{name}/"
+        out[tag + "x"], out[tag + "t"], out[tag + "a"] = x.numpy(), t.numpy(), a.numpy()
+        if name == "cfm":
+            out[tag + "eps"] = torch.randn_like(x).numpy()
+        out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
+        for i, c in enumerate(cnfs):
+            for k, p in c.named_parameters():
+                if p.grad is not None:
+                    out[tag + f"grad/flows.{i}." + k] = subsample(p.grad.detach().clone().numpy())
+    mask = make_mask(B, N, "f32", gen)
+    z = torch.randn(B, N, Fe, generator=gen)
+    cond = torch.randn(B, Cg, generator=gen)
+    with torch.no_grad():
+        for steps in (3, 10):
+            xe = z * mask
+            for c in reversed(cnfs):
+                wrapped = ref.fmm.ode_wrapper(model=c, cond=cond, mask=mask, loss_type="FM-OT")
+                xe = midpoint_trajectory_end(wrapped, xe, torch.linspace(1.0, 0.0, steps))
+            tag = f"midpoint_{steps}/"
+            out[tag + "z"], out[tag + "mask"], out[tag + "cond"], out[tag + "x_end"] = z.numpy(), mask.numpy(), cond.numpy(), xe.numpy()
+    path = os.path.join(out_dir, f"{prefix}_chain2.npz")
+    np.savez(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
+
+
+# ----------------------------------------------------------------------------------------------
 # IterativeNormLayer (norm_layer.py): three training batches, then eval-mode forward / reverse
 # ----------------------------------------------------------------------------------------------
 def gen_norm_layer(ref, out_dir, seed=97531):
@@ -866,7 +935,7 @@ def gen_norm_layer(ref, out_dir, seed=97531):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,diffusion_rows,chain,chain_wide,norm}; default all")
+    ap.add_argument("--only", default="", help="comma list of {epic,no_sets,tf,wide,ca,mdma,diffusion,diffusion_rows,chain,chain_wide,chain_rows,norm}; default all")
     ap.add_argument("--names", default="", help="with --only epic / wide / tf / ca / mdma: comma list of configuration names (default all)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -885,6 +954,9 @@ def main():
         gen_norm_layer(ref, args.out)
     if ap2 is None or "chain" in ap2:
         gen_chain(ref, args.out)
+    for prefix in ("tf", "ca"):
+        if ap2 is None or "chain_rows" in ap2:
+            gen_chain_rows(ref, prefix, args.out)
     if ap2 is None or "chain_wide" in ap2:
         gen_chain(ref, args.out, B=3, seed=3434, hp=CHAIN_WIDE_HP, file_name="epic_chain2w.npz")
     for prefix in DIFF_ROWS_CONFIGS:

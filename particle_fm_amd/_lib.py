@@ -107,6 +107,7 @@ SYMBOLS = {
     "pfm_ca_backward_scratch_floats": (c_int64, [POINTER(CaDesc), c_int32]),
     "pfm_ca_backward_dtemb": (c_int, [POINTER(CaDesc), _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_ca_fm_loss_backward": (c_int, [POINTER(CaDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
+    "pfm_ca_fm_loss_backward_dx": (c_int, [POINTER(CaDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
     # include/pfm_mdma.h
     "pfm_mdma_workspace_floats": (c_int64, [POINTER(MdmaDesc), c_int32, c_int32]),
     "pfm_mdma_backward_scratch_floats": (c_int64, [POINTER(MdmaDesc), c_int32]),
@@ -122,6 +123,8 @@ SYMBOLS = {
     "pfm_tf_backward_scratch_floats": (c_int64, [POINTER(TfDesc), c_int32]),
     "pfm_tf_backward_dtemb": (c_int, [POINTER(TfDesc), _fp, _fp, c_int32, _fp, c_void_p]),
     "pfm_tf_fm_loss_backward": (
+        c_int, [POINTER(TfDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
+    "pfm_tf_fm_loss_backward_dx": (
         c_int, [POINTER(TfDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
 }
 

@@ -611,29 +611,6 @@ __global__ __launch_bounds__(256) void ew_temb_acc_kernel(const float* __restric
     if (i < n) acc[i] += dP[(i / T) * ld + i % T];
 }
 
-// d loss / d y[row][f] = sum_h dZ1[row][h] * Wl1x[f][h] (fc_l1's particle columns, KMAJOR [F][Hp]): 16 lanes per row, 16 rows per workgroup
-__global__ __launch_bounds__(256) void ew_dy_kernel(const float* __restrict__ dZ1, const float* __restrict__ blob, int64_t l1x,
-                                                    float* __restrict__ dy, int64_t M, int F, int Hp) {
-    const int tid = threadIdx.x, pl = tid & 15;
-    const int64_t row = (int64_t)blockIdx.x * 16 + (tid >> 4);
-    if (row >= M) return;  // (whole 16-lane groups leave together: the DPP row sums below stay inside a group)
-    float acc[16];
-#pragma unroll
-    for (int f = 0; f < 16; ++f) acc[f] = 0.f;
-    for (int h = 4 * pl; h < Hp; h += 64) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(dZ1 + row * Hp + h);
-#pragma unroll
-        for (int f = 0; f < 16; ++f)
-            if (f < F) acc[f] += hsum4(g * *reinterpret_cast<const f32x4*>(blob + l1x + (int64_t)f * Hp + h));
-    }
-#pragma unroll
-    for (int f = 0; f < 16; ++f)
-        if (f < F) {
-            const float s = row_sum16(acc[f]);
-            if (pl == 0) dy[row * F + f] = s;
-        }
-}
-
 struct Bs {
     int64_t dX, dZ, dT, dpre, DJB, DSJB, dPj, dP2, dP1, dG, dZg2, dZg1, zeros, dwpart, dtemb, total;
 };
@@ -796,8 +773,8 @@ int run_backward(const Bwd& W, const float* mask, const float* y, const float* u
     PFM_TRY(W.dx(M, dZ, Hp, Hp, d.l2, Hp, dZ, Hp, X1, Hp, dT, Hp));                                           // (dZ W + dZ) lrelu'(X1)
     PFM_TRY(W.colsum(dT, Hp, Hp, M, N, nullptr, 0, DSJB, sjbs, -1));
     if (dy) {  // the gradient w.r.t. the particle input (a chain of flows, n_transforms > 1: the next flow's backward starts from it)
-        hipLaunchKernelGGL(ew_dy_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, p.s, (const float*)dT, p.blob, d.l1x, dy, (int64_t)M, F, Hp);
-        PFM_TRY(check_hip(hipGetLastError(), "ew_dy_kernel launch"));
+        hipLaunchKernelGGL(tf_dy_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, p.s, (const float*)dT, p.blob, d.l1x, dy, (int64_t)M, F, Hp);
+        PFM_TRY(check_hip(hipGetLastError(), "tf_dy_kernel launch (epicw)"));
     }
     {
         ColsumArgs a;  // d fc_l1 particle columns [F][Hp] = sum_rows y[row][f] dZ1[row][:]

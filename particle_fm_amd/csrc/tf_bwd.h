@@ -790,6 +790,32 @@ __device__ __forceinline__ float outer_sum_elem(const float* __restrict__ U, int
 }
 
 // a list of independent outer sums in one launch: grid (blocks of the largest job, jobs)
+// d loss / d y[row][f] = sum_h dZ1[row][h] * Wx[f][h]: the gradient w.r.t. the network's particle input through the particle columns (KMAJOR [F][Hp])
+// of its first Linear (EPiC fc_l1, node_embd.input_block) -- what a chain of flows (n_transforms > 1) hands to the flow in front; 16 lanes per row,
+// 16 rows per workgroup
+static __global__ __launch_bounds__(256) void tf_dy_kernel(const float* __restrict__ dZ1, const float* __restrict__ blob, int64_t l1x,
+                                                    float* __restrict__ dy, int64_t M, int F, int Hp) {
+    const int tid = threadIdx.x, pl = tid & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (tid >> 4);
+    if (row >= M) return;  // (whole 16-lane groups leave together: the DPP row sums below stay inside a group)
+    float acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) acc[f] = 0.f;
+    for (int h = 4 * pl; h < Hp; h += 64) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dZ1 + row * Hp + h);
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+            if (f < F) acc[f] += hsum4(g * *reinterpret_cast<const f32x4*>(blob + l1x + (int64_t)f * Hp + h));
+    }
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+        if (f < F) {
+            const float s = row_sum16(acc[f]);
+            if (pl == 0) dy[row * F + f] = s;
+        }
+}
+
+
 struct OuterJob {
     const float* U;
     const float* V;

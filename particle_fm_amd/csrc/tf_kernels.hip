@@ -206,6 +206,7 @@ struct Bwd {
     float* gblob;
     float* sc;
     Bs b;
+    float* dy = nullptr;  // pfm_tf_fm_loss_backward_dx: also d loss / d y (chains of flows)
 
     int colsum(const float* Z, int ldz, int NO, const float* X, int F, float* jet_out, int64_t gb) const {
         ColsumArgs a;
@@ -362,6 +363,10 @@ int run_backward(const Bwd& B, const float* cond, const float* mask, const float
     PFM_TRY(B.lnbwd(ws + w.h1, Hd, gh2, nullptr, gh, d.n_norm, true));
     PFM_TRY(B.colsum(gh, Hd, Hd, nullptr, 0, djb, -1));
     PFM_TRY(B.colsum(gh, Hd, Hd, y, F, nullptr, d.n1.W));
+    if (B.dy) {
+        hipLaunchKernelGGL(tf_dy_kernel, dim3((unsigned)((p.M + 15) / 16)), dim3(256), 0, p.s, (const float*)gh, p.blob, d.n1.W, B.dy, (int64_t)p.M, F, Hd);
+        PFM_TRY(check_hip(hipGetLastError(), "tf_dy_kernel launch"));
+    }
     // ---- context path ----
     {
         CtxtBwdArgs a;
@@ -573,11 +578,11 @@ int64_t pfm_tf_backward_scratch_floats(const pfm_tf_desc* d, int32_t n_jets) {
     return make_bs(*d, n_jets < 1 ? 1 : n_jets).total;
 }
 
-int pfm_tf_fm_loss_backward(const pfm_tf_desc* d, const float* blob, const float* t, const float* cond,
-                            const float* mask, const float* y, const float* u, const float* v, const float* gscale,
-                            float* gblob, int32_t n_jets, float* workspace, float* scratch, void* stream) {
-    (void)t;  // the time embedding is part of the workspace
+static int tf_loss_backward(const pfm_tf_desc* d, const float* blob, const float* cond, const float* mask, const float* y, const float* u,
+                            const float* v, const float* gscale, float* gblob, float* grad_y, int32_t n_jets, float* workspace, float* scratch,
+                            void* stream) {
     Bwd B;
+    B.dy = grad_y;
     int rc = make_plan(B.p, d, blob, workspace, n_jets, true, stream);
     if (rc) return rc;
     if (n_jets <= 0) return 0;
@@ -588,6 +593,20 @@ int pfm_tf_fm_loss_backward(const pfm_tf_desc* d, const float* blob, const float
     B.sc = scratch;
     B.b = make_bs(*d, n_jets);
     return run_backward(B, cond, mask, y, u, v, gscale);
+}
+
+int pfm_tf_fm_loss_backward(const pfm_tf_desc* d, const float* blob, const float* t, const float* cond,
+                            const float* mask, const float* y, const float* u, const float* v, const float* gscale,
+                            float* gblob, int32_t n_jets, float* workspace, float* scratch, void* stream) {
+    (void)t;  // the time embedding is part of the workspace
+    return tf_loss_backward(d, blob, cond, mask, y, u, v, gscale, gblob, nullptr, n_jets, workspace, scratch, stream);
+}
+
+int pfm_tf_fm_loss_backward_dx(const pfm_tf_desc* d, const float* blob, const float* cond, const float* mask, const float* y, const float* u,
+                               const float* v, const float* gscale, float* gblob, float* grad_y, int32_t n_jets, float* workspace,
+                               float* scratch, void* stream) {
+    if (!grad_y) return set_err(PFM_E_BADARG, "grad_y is NULL");
+    return tf_loss_backward(d, blob, cond, mask, y, u, v, gscale, gblob, grad_y, n_jets, workspace, scratch, stream);
 }
 
 int pfm_tf_backward_dtemb(const pfm_tf_desc* d, const float* blob, const float* scratch, int32_t n_jets, float* dtemb, void* stream) {

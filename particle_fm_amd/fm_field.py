@@ -35,7 +35,8 @@ def _upstream(saved, G):
 class TfFieldFn(torch.autograd.Function):
     """Full-Transformer (ops = hip_ops_tf) / cross-attention (ops = hip_ops_ca) field over the flat parameter vector.  ``t``: the times
     (B,), or -- a layout with t_emb="gaussian" (PFM_*_F_TEMB_GIVEN) -- the time EMBEDDING rows (B, T), then a differentiable input: the
-    backward also returns d / d temb (pfm_*_backward_dtemb), from which autograd continues into the CNF's embedding network."""
+    backward also returns d / d temb (pfm_*_backward_dtemb), from which autograd continues into the CNF's embedding network.  Also
+    differentiable w.r.t. the particle input x (pfm_{tf,ca}_fm_loss_backward_dx): chains of flows."""
 
     @staticmethod
     def forward(ctx, flat_params, t, layout, freqs, ops, x, cond, mask):
@@ -53,15 +54,16 @@ class TfFieldFn(torch.autograd.Function):
     def backward(ctx, G):
         lay, ops = ctx.layout, ctx.ops
         one = torch.ones((), device=G.device)
+        d_x = torch.empty_like(G) if ctx.needs_input_grad[5] else None
         if ops is hip_ops_tf:
-            gblob = ops.tf_fm_loss_backward(lay, ctx.blob, ctx.t, ctx.cond, ctx.mask, _upstream(ctx.saved, G.contiguous()), one)
+            gblob = ops.tf_fm_loss_backward(lay, ctx.blob, ctx.t, ctx.cond, ctx.mask, _upstream(ctx.saved, G.contiguous()), one, d_y=d_x)
         else:
-            gblob = ops.ca_fm_loss_backward(lay, ctx.blob, ctx.cond, ctx.mask, _upstream(ctx.saved, G.contiguous()), one)
+            gblob = ops.ca_fm_loss_backward(lay, ctx.blob, ctx.cond, ctx.mask, _upstream(ctx.saved, G.contiguous()), one, d_y=d_x)
         d_t = None
         if ctx.temb_given and ctx.needs_input_grad[1]:
             dtemb = ops.tf_backward_dtemb if ops is hip_ops_tf else ops.ca_backward_dtemb
             d_t = dtemb(lay, ctx.blob, G.shape[0], G.device).reshape(ctx.t.shape)
-        return (gblob[lay.grad_pos_on(gblob.device)], d_t) + (None,) * 6
+        return (gblob[lay.grad_pos_on(gblob.device)], d_t, None, None, None, d_x, None, None)
 
 
 def tf_field(layout, flat_params, t, x, cond=None, mask=None, freqs: Optional[torch.Tensor] = None):

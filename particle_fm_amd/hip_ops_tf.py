@@ -182,9 +182,9 @@ def tf_fm_loss_forward(layout: TfLayout, blob, x, t, a, cond=None, mask=None, si
     return sums, (y, u, v, ws)
 
 
-def tf_fm_loss_backward(layout: TfLayout, blob, t, cond, mask, saved, gscale: torch.Tensor) -> torch.Tensor:
+def tf_fm_loss_backward(layout: TfLayout, blob, t, cond, mask, saved, gscale: torch.Tensor, d_y=None) -> torch.Tensor:
     """Gradient blob (layout.blob_total floats) of loss * gscale-normalisation; gscale: 0-dim device tensor
-    grad_output / sum(mask)."""
+    grad_output / sum(mask).  d_y: (B, N, F) tensor that receives d loss / d y * gscale (pfm_tf_fm_loss_backward_dx: chains of flows)."""
     lib = _lib.load()
     y, u, v, ws = saved
     dev, B = y.device, y.shape[0]
@@ -196,6 +196,11 @@ def tf_fm_loss_backward(layout: TfLayout, blob, t, cond, mask, saved, gscale: to
         cache[key] = torch.empty(n, device=dev, dtype=torch.float32)
     gblob = torch.zeros(layout.blob_total, device=dev, dtype=torch.float32)
     gs = gscale.to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+    if d_y is not None:
+        rc = lib.pfm_tf_fm_loss_backward_dx(ctypes.byref(layout.desc), _ptr(blob), _ptr(cond), _ptr(mask), _ptr(y), _ptr(u), _ptr(v),
+                                            _ptr(gs), _ptr(gblob), _ptr(d_y), B, _ptr(ws), _ptr(cache[key]), _stream_ptr(dev))
+        _lib.check(rc, "pfm_tf_fm_loss_backward_dx")
+        return gblob
     rc = lib.pfm_tf_fm_loss_backward(ctypes.byref(layout.desc), _ptr(blob), _ptr(t), _ptr(cond), _ptr(mask), _ptr(y), _ptr(u),
                                      _ptr(v), _ptr(gs), _ptr(gblob), B, _ptr(ws), _ptr(cache[key]), _stream_ptr(dev))
     _lib.check(rc, "pfm_tf_fm_loss_backward")

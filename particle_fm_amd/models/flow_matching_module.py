@@ -325,10 +325,18 @@ class CNF(nn.Module):
 
     def field(self, t, x, cond=None, mask=None) -> Tensor:
         """v = f(t, x), differentiable w.r.t. the parameters AND the particle input x: what a chain of flows (n_transforms > 1) is
-        built from (losses._chained_loss).  EPiC kernels only (pfm_epic_fm_loss_backward_dx / pfm_ew_fm_loss_backward_dx return d / d x)."""
-        if self.is_transformer or self.is_cross_attention or self.is_mdma or self.t_emb == "gaussian":
-            raise NotImplementedError("n_transforms > 1 has a HIP path for model='epic' (cosine / sincos time embedding): no other "
-                                      "kernel returns d loss / d input")
+        built from (losses._chained_loss).  EPiC, Full-Transformer and cross-attention kernels (pfm_{epic,ew,tf,ca}_fm_loss_backward_dx
+        return d / d x); MDMA's one-output field cannot feed a next flow in the reference either (mdma.py:139: Linear(hidden, 1))."""
+        if self.is_mdma:
+            raise NotImplementedError("n_transforms > 1 with model='mdma': its field has one output per particle (mdma.py:139), the next "
+                                      "flow expects `features` inputs -- the reference's own chain does not run for it")
+        if self.is_transformer or self.is_cross_attention:
+            return self._field_rows(t, x, cond, mask)
+        if self.t_emb == "gaussian":
+            if self.net.is_wide(x.shape[1]):
+                return self._field_rows(t, x, cond, mask)
+            raise NotImplementedError("n_transforms > 1 with t_emb='gaussian' on the jet-resident EPiC kernels: the field with a "
+                                      "caller-supplied embedding returns no input gradient there")
         tt = self._per_jet_time(t, x).to(x.device, torch.float32)
         lay = self.net.layout(x.shape[1])
         if self.net.is_wide(x.shape[1]):

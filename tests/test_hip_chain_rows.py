@@ -1,0 +1,96 @@
+"""n_transforms = 2 (flow_matching_module.py:421-443) on the Full-Transformer and cross-attention models: the loss backward also returns
+d loss / d y (pfm_{tf,ca}_fm_loss_backward_dx: through node_embd's particle columns), every flow is the differentiable field of
+fm_field.py and FM-OT / CFM chain the flows at the same t (losses.py:66-69, 125-128); sampling decodes through the flows in reverse
+order.  Against vectors recorded from the reference (tests/golden/{tf,ca}_chain2.npz) and the oracle's autograd."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(path):
+    from tests.conftest import load_ca_golden, load_tf_golden
+    return {"tf": load_tf_golden, "ca": load_ca_golden}[path]("chain2")
+
+
+def _module(g):
+    from particle_fm_amd.models import SetFlowMatchingLitModule
+    m = SetFlowMatchingLitModule(optimizer=None, sigma=1e-4, **copy.deepcopy(g.hp))
+    state = dict(g.state)
+    state["flows.1.frequencies"] = state["flows.0.frequencies"]
+    full = dict(state)
+    full.update({"loss." + k: v for k, v in state.items()})
+    m.load_state_dict(full)
+    m = m.cuda()
+    m.set_freq_table(g.freqs)
+    return m
+
+
+@pytest.mark.parametrize("path", ["tf", "ca"])
+def test_field_gradient_wrt_input_matches_the_oracle(path):
+    if path == "tf":
+        from oracle.tf_ref import TransformerVectorField as VF
+    else:
+        from oracle.ca_ref import CrossAttentionVectorField as VF
+    g = _load(path)
+    m = _module(g)
+    assert len(m.flows) == 2
+    tag = "loss_fm/"
+    x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))
+    G = torch.randn(x.shape, generator=torch.Generator().manual_seed(3)) * mask  # (padded rows carry no upstream gradient in a chain: the next flow never reads them)
+    xr = x.clone().requires_grad_(True)
+    vf = VF(g.state, "flows.1.", g.hp, freqs=g.freqs)
+    v_ref = vf(t[:, None].expand(-1, x.shape[1]), xr, cond=cond, mask=mask)
+    (v_ref * G).sum().backward()
+    xc = x.cuda().requires_grad_(True)
+    v = m.flows[1].field(t.cuda(), xc, cond=cond.cuda(), mask=mask.cuda())
+    keep = mask.squeeze(-1) != 0
+    torch.testing.assert_close(v.detach().cpu()[keep], v_ref.detach()[keep], atol=2e-5, rtol=2e-4)
+    (v * G.cuda()).sum().backward()
+    torch.testing.assert_close(xc.grad.cpu()[keep], xr.grad[keep], atol=2e-5, rtol=2e-3)
+
+
+@pytest.mark.parametrize("path", ["tf", "ca"])
+@pytest.mark.parametrize("name", ["fm", "cfm"])
+def test_chained_loss_and_parameter_gradients(path, name):
+    from particle_fm_amd.models.components.losses import _chained_loss
+    g = _load(path)
+    m = _module(g)
+    tag = f"loss_{name}/"
+    x, t, a, mask, cond = (g.get(tag + k).cuda() for k in ("x", "t", "a", "mask", "cond"))
+    eps = g.get(tag + "eps").cuda() if name == "cfm" else None
+    loss = _chained_loss(m.flows, {"fm": "FM-OT", "cfm": "CFM"}[name], x, t, a, eps, mask, cond, 1e-4)
+    torch.testing.assert_close(loss.detach().cpu(), g.get(tag + "loss"), rtol=3e-5, atol=1e-6)
+    loss.backward()
+    named = dict(m.flows.named_parameters())
+    bad = []
+    ref = g.grads(tag)
+    assert any(k.startswith("flows.0.") for k in ref) and any(k.startswith("flows.1.") for k in ref)
+    for k, want in ref.items():
+        got = g.pick(named[k[len("flows."):]].grad.cpu())
+        if float(want.abs().max()) < 2e-6:  # (a k_linear bias: zero in exact arithmetic)
+            assert float(got.abs().max()) < 1e-5, k
+            continue
+        rel = float((got - want).norm()) / max(float(want.norm()), 1e-12)
+        if not rel < 2e-3:
+            bad.append((k, rel))
+    assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("path", ["tf", "ca"])
+def test_training_step_and_sampling_through_both_flows(path):
+    g = _load(path)
+    m = _module(g)
+    x, mask, cond = (g.get("loss_fm/" + k).cuda() for k in ("x", "mask", "cond"))
+    loss = m.training_step((x, mask, cond), 0)["loss"]
+    assert torch.isfinite(loss)
+    loss.backward()
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.flows.parameters())
+    for steps in (3, 10):
+        tag = f"midpoint_{steps}/"
+        z, mk, c = (g.get(tag + k) for k in ("z", "mask", "cond"))
+        out = m((z * mk).cuda(), cond=c.cuda(), mask=mk.cuda(), reverse=True, ode_solver="midpoint", ode_steps=steps).cpu()
+        keep = mk.squeeze(-1) != 0
+        torch.testing.assert_close(out[keep], g.get(tag + "x_end")[keep], atol=2e-4, rtol=1e-3)

@@ -140,3 +140,34 @@ def test_chained_flows_fixture_is_reproduced_by_the_oracle(fixture):
             for vf in reversed(vfs):
                 xe = midpoint_trajectory_end(lambda tq, xx: vf(tq, xx, mask=mk, cond=c), xe, torch.linspace(1.0, 0.0, steps))
             torch.testing.assert_close(xe, g.get(tag + "x_end"), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("path", ["tf", "ca"])
+def test_chained_transformer_flows_fixture_is_reproduced_by_the_oracle(path):
+    """tests/golden/{tf,ca}_chain2.npz (n_transforms = 2 on the Full-Transformer / cross-attention models): the oracle's fields composed as
+    losses.py:66-69 composes them reproduce the recorded FM-OT loss and the reverse-order midpoint samples."""
+    from oracle.fm_ref import fm_ot_targets, midpoint_trajectory_end
+    from tests.conftest import load_ca_golden, load_tf_golden
+    if path == "tf":
+        from oracle.tf_ref import TransformerVectorField as VF
+        g = load_tf_golden("chain2")
+    else:
+        from oracle.ca_ref import CrossAttentionVectorField as VF
+        g = load_ca_golden("chain2")
+    vfs = [VF(g.state, f"flows.{i}.", g.hp, freqs=g.freqs) for i in range(2)]
+    tag = "loss_fm/"
+    x, t, z, mask, cond = (g.get(tag + k) for k in ("x", "t", "a", "mask", "cond"))
+    with torch.no_grad():
+        tt, y, u, m = fm_ot_targets(x, mask, t, z, 1e-4)
+        temp = y
+        for vf in vfs:
+            temp = vf(tt.squeeze(-1), temp, mask=m, cond=cond)
+        loss = (temp - u).square().sum() / m.sum()
+        torch.testing.assert_close(loss, g.get(tag + "loss"), rtol=1e-5, atol=1e-6)
+        tag = "midpoint_10/"
+        z, mk, c = (g.get(tag + k) for k in ("z", "mask", "cond"))
+        xe = z * mk
+        for vf in reversed(vfs):
+            xe = midpoint_trajectory_end(lambda tq, xx: vf(tq, xx, mask=mk, cond=c), xe, torch.linspace(1.0, 0.0, 10))
+        keep = mk.squeeze(-1) != 0
+        torch.testing.assert_close(xe[keep], g.get(tag + "x_end")[keep], rtol=1e-3, atol=5e-5)
