@@ -684,6 +684,12 @@ DIFF_ROWS_CONFIGS = {
     "tf": (lambda: dict(TF_CONFIGS["small"][0], loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02}), 3131),
     "ca": (lambda: dict(CA_CONFIGS["small"][0], loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02}), 4242),
     "mdma": (lambda: dict(MDMA_CONFIGS["small"][0], loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02}), 5353),
+    # ... with t_emb="gaussian" (the CNF builds both for any model): every model path, both EPiC paths (files <model>_diffusion_gauss.npz)
+    "tf_gauss": (lambda: dict(TF_CONFIGS["gauss"][0], loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02}), 3132),
+    "ca_gauss": (lambda: dict(CA_CONFIGS["gauss"][0], loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02}), 4243),
+    "mdma_gauss": (lambda: dict(MDMA_CONFIGS["gauss"][0], loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02}), 5354),
+    "epic_gauss": (lambda: dict(CONFIGS["gauss"], loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02}), 6465),
+    "epicw_gauss": (lambda: dict(WIDE_CONFIGS["gauss"][0], loss_type="diffusion", diff_config={"max_sr": 0.999, "min_sr": 0.02}), 7576),
 }
 
 
@@ -754,7 +760,7 @@ def gen_diffusion_rows(ref, prefix, out_dir, B=3):
         noise = torch.stack([torch.randn_like(z) for _ in range(n_steps)])
         put("em/", z=z, mask=mask, cond=cond, noise=noise, x_end=x_em)
     out["n_steps"] = np.array(n_steps)
-    path = os.path.join(out_dir, f"{prefix}_diffusion.npz")
+    path = os.path.join(out_dir, f"{prefix[:-6]}_diffusion_gauss.npz" if prefix.endswith("_gauss") else f"{prefix}_diffusion.npz")
     np.savez(path, **out)
     print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
 
@@ -960,7 +966,7 @@ def main():
     if ap2 is None or "chain_wide" in ap2:
         gen_chain(ref, args.out, B=3, seed=3434, hp=CHAIN_WIDE_HP, file_name="epic_chain2w.npz")
     for prefix in DIFF_ROWS_CONFIGS:
-        if ap2 is None or "diffusion_rows" in ap2:
+        if (ap2 is None or "diffusion_rows" in ap2) and (names is None or prefix in names):
             gen_diffusion_rows(ref, prefix, args.out)
     for name, (hp, B) in WIDE_CONFIGS.items():
         if (ap2 is None or "wide" in ap2) and (names is None or name in names):

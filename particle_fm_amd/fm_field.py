@@ -141,16 +141,20 @@ def epic_wide_field(layout, src, t, x, cond=None, mask=None):
 class EpicFieldFn(torch.autograd.Function):
     """Jet-resident EPiC field over the layout's source vector, differentiable w.r.t. the parameters AND the particle input x
     (pfm_epic_fm_loss_backward_dx): the building block of n_transforms > 1 (losses.py:66-69 feeds each flow's output to the next).
-    The saved record of a jet starts with y | v | u (pfm_hip.h): the upstream gradient goes in as u := v - G / 2."""
+    The saved record of a jet starts with y | v | u (pfm_hip.h): the upstream gradient goes in as u := v - G / 2.
+    ``temb`` (B, T): a caller-supplied time embedding (t_emb="gaussian"), then a differentiable input in place of x
+    (pfm_epic_fm_loss_backward_temb returns d / d temb, not d / d x)."""
 
     @staticmethod
-    def forward(ctx, src, x, layout, t, cond, mask):
+    def forward(ctx, src, x, layout, t, cond, mask, temb=None):
         from .fm_loss import pack_blob_from_source
         from . import hip_ops
         blob = pack_blob_from_source(layout, src)
-        _, _, saved = hip_ops.epic_fm_loss_forward(layout, blob, x, t, torch.zeros_like(x), cond, mask, 0.0, "droid", None)
+        _, _, saved = hip_ops.epic_fm_loss_forward(layout, blob, x, t, torch.zeros_like(x), cond, mask, 0.0, "droid", None,
+                                                   temb=None if temb is None else temb.detach())
         B, N, F = x.shape
         ctx.layout, ctx.cond, ctx.mask, ctx.n_source, ctx.shape = layout, cond, mask, src.numel(), (B, N, F)
+        ctx.temb_shape = None if temb is None else tuple(temb.shape)
         ctx.save_for_backward(blob, saved)
         r4 = (N * F + 3) & ~3
         v = saved[:, r4:r4 + N * F].reshape(B, N, F)
@@ -172,16 +176,24 @@ class EpicFieldFn(torch.autograd.Function):
         maskf = None if ctx.mask is None else ctx.mask.reshape(B, -1).to(torch.float32).contiguous()
         one = torch.ones(1, device=dev)
         gblob = torch.zeros_like(blob)
-        d_y = torch.empty(B, N, F, device=dev, dtype=torch.float32)
-        hip_ops.epic_loss_backward(layout, blob, cond, maskf, sv, one, one, gblob, d_y=d_y)
+        d_y = d_temb = None
+        if ctx.temb_shape is not None:
+            if ctx.needs_input_grad[1]:
+                raise NotImplementedError("the jet-resident EPiC field with a caller-supplied embedding returns d / d temb, not d / d x")
+            d_temb = torch.empty(B, layout.cfg.t_dim, device=dev, dtype=torch.float32)
+            hip_ops.epic_loss_backward(layout, blob, cond, maskf, sv, one, one, gblob, d_temb=d_temb)
+            d_temb = d_temb.reshape(ctx.temb_shape)
+        else:
+            d_y = torch.empty(B, N, F, device=dev, dtype=torch.float32)
+            hip_ops.epic_loss_backward(layout, blob, cond, maskf, sv, one, one, gblob, d_y=d_y)
         _, gpos, _ = _Maps.get(layout, dev)
         d_src = torch.zeros(ctx.n_source, device=dev, dtype=torch.float32)
         d_src[: gpos.numel()] = gblob[gpos]
-        return d_src, d_y, None, None, None, None
+        return d_src, d_y, None, None, None, None, d_temb
 
 
-def epic_field(layout, src, t, x, cond=None, mask=None):
-    return EpicFieldFn.apply(src, x, layout, t, cond, mask)
+def epic_field(layout, src, t, x, cond=None, mask=None, temb=None):
+    return EpicFieldFn.apply(src, x, layout, t, cond, mask, temb)
 
 
 def fm_loss_from_field(field, kind: str, x, t, a, eps, mask, sigma: float):

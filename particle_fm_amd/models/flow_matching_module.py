@@ -289,9 +289,7 @@ class CNF(nn.Module):
     def _decode_diffusion(self, z, cond, mask, ode_solver, ode_steps, weights):
         """loss_type="diffusion" (:62-69, 301-325): the fixed-step ODE solvers integrate -0.5 beta (x - net / noise_rate);
         "ddim" / "em" are the samplers of models/components/solver.py (n_steps = ode_steps)."""
-        if self.t_emb == "gaussian":
-            raise NotImplementedError("loss_type='diffusion' has a HIP path with the cosine / sincos time embeddings only")
-        if self.is_transformer or self.is_cross_attention or self.is_mdma:
+        if self.is_transformer or self.is_cross_attention or self.is_mdma or self.t_emb == "gaussian":
             return self._decode_diffusion_rows(z, cond, mask, ode_solver, ode_steps, weights)
         wide = self.net.is_wide(z.shape[1])
         lay = self.net.layout(z.shape[1])
@@ -361,14 +359,18 @@ class CNF(nn.Module):
         return _fm_field.mdma_field(lay, fl, t, x, m, freqs=fr, cond=cond if lay.cfg.needs_cond else None)
 
     def _decode_diffusion_rows(self, z, cond, mask, ode_solver, ode_steps, weights):
-        """loss_type="diffusion" sampling for the transformer / cross-attention / MDMA models: the field is one HIP evaluation per
+        """loss_type="diffusion" sampling for the transformer / cross-attention / MDMA models (and, with t_emb="gaussian", the EPiC
+        ones: the fused samplers index their schedule by the time grid): the field is one HIP evaluation per
         stage (net.vector_field); the probability-flow right-hand side -0.5 beta (x - v / noise_rate) (:62-69), the Runge-Kutta
         combinations of torchdyn's fixed-step driver and the DDIM / Euler-Maruyama updates (solver.py:55-141) are element-wise
         device ops between the evaluations, in the oracle's op order (oracle/fm_ref.py::rk_trajectory_end, diffusion_ref.py)."""
         dc = dict(self.diff_config)
         blob = weights if weights is not None else self.net.packed_weights(z.shape[1])
         B = z.shape[0]
-        field = lambda tt, xx: self.net.vector_field(tt.to(z.device).expand(B), xx, cond, mask, blob=blob)
+        if self.t_emb == "gaussian":  # CNF.forward embeds (embed / linear on the device) and hands the rows to the kernels
+            field = lambda tt, xx: self.forward(tt.to(z.device).reshape(1).expand(B), xx, cond, mask)
+        else:
+            field = lambda tt, xx: self.net.vector_field(tt.to(z.device).expand(B), xx, cond, mask, blob=blob)
         x = z.to(torch.float32).clone()
         if ode_solver in ("midpoint", "euler", "rk4"):
             c, a, b = hip_ops.RK_TABLEAUS[ode_solver]
@@ -422,16 +424,18 @@ class CNF(nn.Module):
 
     def diffusion_loss(self, x, t, z, mask=None, cond=None, criterion: str = "huber", diff_config=None) -> Tensor:
         """DiffusionLoss body (losses.py:250-288) with the draws given; z is already multiplied by the mask."""
-        if self.t_emb == "gaussian":
-            raise NotImplementedError("loss_type='diffusion' has a HIP path with the cosine / sincos time embeddings only")
-        if self.is_transformer or self.is_cross_attention or self.is_mdma:
-            # no fused loss kernel on these paths: noisy = signal_rate x + noise_rate z and the criterion are element-wise device ops
-            # around the differentiable field (losses.py:257-288)
+        if self.is_transformer or self.is_cross_attention or self.is_mdma or self.t_emb == "gaussian":
+            # no fused loss kernel on these paths (nor with a caller-supplied embedding on the EPiC ones): noisy = signal_rate x +
+            # noise_rate z and the criterion are element-wise device ops around the differentiable field (losses.py:257-288)
             dc = dict(self.diff_config if diff_config is None else diff_config)
             tt = t.to(x.device, torch.float32)
             sr, nr, _ = hip_ops.diffusion_schedule(tt, **dc)
             noisy = sr.view(-1, 1, 1) * x + nr.view(-1, 1, 1) * z
-            v = self._field_rows(tt, noisy, cond, mask)
+            if self.is_epic and not self.net.is_wide(x.shape[1]):  # jet-resident kernels: the embedding rows go in beside the times
+                lay = self.net.layout(x.shape[1])
+                v = _fm_field.epic_field(lay, self.net.source_vector(lay), tt, noisy, cond, mask, temb=self._gaussian_temb(tt))
+            else:
+                v = self._field_rows(tt, noisy, cond, mask)
             return _fm_field.diffusion_loss_from_field(v, z, mask, tt, criterion, dc)
         lay = self.net.layout(x.shape[1])
         if self.net.is_wide(x.shape[1]):

@@ -105,6 +105,20 @@ def wide_golden(request):
     return load_wide_golden(request.param)
 
 
+class EpicSeededGolden(TfGolden):
+    """tests/golden/epic_<name>.npz in the seed-derived format (weights re-derived from the stored seed): jet-resident EPiC configurations
+    recorded by the generic recorders of oracle/make_golden.py."""
+
+    FILE = "epic_{}.npz"
+
+
+def load_epic_seeded_golden(name):
+    key = "epics_" + name
+    if key not in _cache:
+        _cache[key] = EpicSeededGolden(name)
+    return _cache[key]
+
+
 class CaGolden(TfGolden):
     """tests/golden/ca_<name>.npz: the cross-attention encoder (model "droid_fullcrossattention"), seed-derived weights."""
 

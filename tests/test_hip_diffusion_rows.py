@@ -2,7 +2,9 @@
 DiffusionLoss for any `model`): no fused loss kernel there -- the field is a differentiable function of the parameters built from the
 paths' loss entry points (particle_fm_amd/fm_field.py), criterion / rates / masks are element-wise device ops.  Against the
 reference's recorded vectors (tests/golden/{tf,ca,mdma}_diffusion.npz, oracle/make_golden.py --only diffusion_rows): DiffusionLoss +
-sub-sampled parameter gradients for both criteria, the probability-flow right-hand side, midpoint on it, DDIM, Euler-Maruyama."""
+sub-sampled parameter gradients for both criteria, the probability-flow right-hand side, midpoint on it, DDIM, Euler-Maruyama.
+The "_gauss" paths: the same with t_emb="gaussian" (tests/golden/{tf,ca,mdma,epic,epicw}_diffusion_gauss.npz) -- there the EPiC models
+(jet-resident "epic", row-matrix "epicw") take this route too: their fused diffusion kernels embed the time themselves."""
 import copy
 
 import pytest
@@ -11,9 +13,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+ALL = ["tf", "ca", "mdma", "tf_gauss", "ca_gauss", "mdma_gauss", "epic_gauss", "epicw_gauss"]
+
+
 def _load(path):
-    from tests.conftest import load_ca_golden, load_mdma_golden, load_tf_golden
-    return {"tf": load_tf_golden, "ca": load_ca_golden, "mdma": load_mdma_golden}[path]("diffusion")
+    from tests.conftest import load_ca_golden, load_epic_seeded_golden, load_mdma_golden, load_tf_golden, load_wide_golden
+    base, _, gauss = path.partition("_")
+    loader = {"tf": load_tf_golden, "ca": load_ca_golden, "mdma": load_mdma_golden, "epic": load_epic_seeded_golden, "epicw": load_wide_golden}[base]
+    return loader("diffusion_gauss" if gauss else "diffusion")
 
 
 def _module(g):
@@ -30,12 +37,13 @@ def _cond(g, tag):
     return None if c is None or c.numel() == 0 else c
 
 
-@pytest.mark.parametrize("path", ["tf", "ca", "mdma"])
+@pytest.mark.parametrize("path", ALL)
 @pytest.mark.parametrize("crit", ["huber", "mse"])
 def test_loss_and_parameter_gradients(path, crit):
     g = _load(path)
     m = _module(g)
-    m.set_freq_table(g.freqs)  # the table of the recording machine (the embedding is bit-sensitive to it: DESIGN 2)
+    if not path.endswith("_gauss"):  # (a learned embedding reads no frequency table)
+        m.set_freq_table(g.freqs)  # the table of the recording machine (the embedding is bit-sensitive to it: DESIGN 2)
     tag = f"loss_{crit}/"
     x, t, z, mask = (g.get(tag + k).cuda() for k in ("x", "t", "z", "mask"))
     cond = _cond(g, tag)
@@ -59,11 +67,12 @@ def test_loss_and_parameter_gradients(path, crit):
     assert not bad, bad[:8]
 
 
-@pytest.mark.parametrize("path", ["tf", "ca", "mdma"])
+@pytest.mark.parametrize("path", ALL)
 def test_samplers_match_reference_vectors(path):
     g = _load(path)
     m = _module(g)
-    m.set_freq_table(g.freqs)  # the table of the recording machine (the embedding is bit-sensitive to it: DESIGN 2)
+    if not path.endswith("_gauss"):  # (a learned embedding reads no frequency table)
+        m.set_freq_table(g.freqs)  # the table of the recording machine (the embedding is bit-sensitive to it: DESIGN 2)
     n = int(g.z["n_steps"])
     dev = lambda a: None if a is None else a.cuda()
     for steps in (3, 10):
@@ -93,12 +102,16 @@ def test_samplers_match_reference_vectors(path):
 
 
 def _oracle(path, g):
-    if path == "tf":
+    base = path.partition("_")[0]
+    if base == "tf":
         from oracle.tf_ref import TransformerVectorField
         return TransformerVectorField(g.state, "flows.0.", g.hp, freqs=g.freqs)
-    if path == "ca":
+    if base == "ca":
         from oracle.ca_ref import CrossAttentionVectorField
         return CrossAttentionVectorField(g.state, "flows.0.", g.hp, freqs=g.freqs)
+    if base in ("epic", "epicw"):
+        from oracle.fm_ref import EpicVectorField
+        return EpicVectorField(g.state, "flows.0.net", g.hp, freqs=g.freqs)
     from oracle.mdma_ref import MdmaVectorField
     return MdmaVectorField(g.state, "flows.0.", g.hp, freqs=g.freqs)
 
@@ -108,7 +121,8 @@ def test_training_step_replays_reference_draws(path):
     from oracle import diffusion_ref as dr
     g = _load(path)
     m = _module(g)
-    m.set_freq_table(g.freqs)  # the table of the recording machine (the embedding is bit-sensitive to it: DESIGN 2)
+    if not path.endswith("_gauss"):  # (a learned embedding reads no frequency table)
+        m.set_freq_table(g.freqs)  # the table of the recording machine (the embedding is bit-sensitive to it: DESIGN 2)
     tag = "loss_huber/"
     x, mask = g.get(tag + "x").cuda(), g.get(tag + "mask").cuda()
     cond = _cond(g, tag)

@@ -55,8 +55,16 @@ def test_ddim_and_euler_maruyama():
 
 # ---- the same recordings for the Full-Transformer / cross-attention / MDMA models (tests/golden/{tf,ca,mdma}_diffusion.npz) ----
 def _rows(path):
-    from tests.conftest import load_ca_golden, load_mdma_golden, load_tf_golden
-    g = {"tf": load_tf_golden, "ca": load_ca_golden, "mdma": load_mdma_golden}[path]("diffusion")
+    """path: "tf" / "ca" / "mdma", or with "_gauss" the t_emb="gaussian" recordings (<model>_diffusion_gauss.npz; there also "epic" -- the
+    jet-resident configuration -- and "epicw")."""
+    from tests.conftest import load_ca_golden, load_epic_seeded_golden, load_mdma_golden, load_tf_golden, load_wide_golden
+    base, _, gauss = path.partition("_")
+    loader = {"tf": load_tf_golden, "ca": load_ca_golden, "mdma": load_mdma_golden, "epic": load_epic_seeded_golden, "epicw": load_wide_golden}[base]
+    g = loader("diffusion_gauss" if gauss else "diffusion")
+    path = base
+    if path in ("epic", "epicw"):
+        from oracle.fm_ref import EpicVectorField
+        return g, EpicVectorField(g.state, "flows.0.net", g.hp, freqs=g.freqs)
     if path == "tf":
         from oracle.tf_ref import TransformerVectorField as VF
     elif path == "ca":
@@ -73,7 +81,7 @@ def _c(g, tag):
     return None if c is None or c.numel() == 0 else c
 
 
-@pytest.mark.parametrize("path", ["tf", "ca", "mdma"])
+@pytest.mark.parametrize("path", ["tf", "ca", "mdma", "tf_gauss", "ca_gauss", "mdma_gauss", "epic_gauss", "epicw_gauss"])
 def test_row_models_loss_rhs_and_samplers(path):
     g, vf = _rows(path)
     dc, n = g.hp["diff_config"], int(g.z["n_steps"])
