@@ -284,6 +284,10 @@ int pfm_epic_fm_loss_backward_phases(const pfm_epic_desc *desc, const float *blo
 int pfm_epic_fm_loss_backward_dx(const pfm_epic_desc *desc, const float *blob, const float *cond, const float *mask,
                                  const float *saved, const float *inv_mask_total, const float *grad_scale, float *grad_blob,
                                  float *grad_y, int32_t B, float *scratch, const int32_t *order, void *stream);
+/* ... for a `saved` record of pfm_epic_fm_loss_forward_temb (caller-supplied time embedding, below): grad_y and grad_temb[B][T] together */
+int pfm_epic_fm_loss_backward_dx_temb(const pfm_epic_desc *desc, const float *blob, const float *cond, const float *mask,
+                                      const float *saved, const float *inv_mask_total, const float *grad_scale, float *grad_blob,
+                                      float *grad_y, float *grad_temb, int32_t B, float *scratch, const int32_t *order, void *stream);
 
 /* The same two with the time embedding supplied by the caller, temb[B][T] (t_emb="gaussian": a small trainable network in front of
  * the field, flow_matching_module.py:178-181, 213-221; t is still needed for the interpolation y, u): the backward also returns

@@ -848,7 +848,9 @@ def gen_chain_rows(ref, prefix, out_dir, B=3, seed=8181):
 
     from oracle.seeded import seeded_state, subsample
 
-    hp = copy.deepcopy({"tf": TF_CONFIGS, "ca": CA_CONFIGS}[prefix]["small"][0])
+    # "epic_gauss" / "epicw_gauss": both EPiC paths with t_emb="gaussian" (the fields then return d / d temb beside d / d x)
+    hp = copy.deepcopy({"tf": lambda: TF_CONFIGS["small"][0], "ca": lambda: CA_CONFIGS["small"][0], "epic_gauss": lambda: CONFIGS["gauss"],
+                        "epicw_gauss": lambda: WIDE_CONFIGS["gauss"][0]}[prefix]())
     cnfs = []
     for i in range(2):
         torch.manual_seed(seed + i)
@@ -902,7 +904,7 @@ def gen_chain_rows(ref, prefix, out_dir, B=3, seed=8181):
                 xe = midpoint_trajectory_end(wrapped, xe, torch.linspace(1.0, 0.0, steps))
             tag = f"midpoint_{steps}/"
             out[tag + "z"], out[tag + "mask"], out[tag + "cond"], out[tag + "x_end"] = z.numpy(), mask.numpy(), cond.numpy(), xe.numpy()
-    path = os.path.join(out_dir, f"{prefix}_chain2.npz")
+    path = os.path.join(out_dir, f"{prefix[:-6]}_chain2_gauss.npz" if prefix.endswith("_gauss") else f"{prefix}_chain2.npz")
     np.savez(path, **out)
     print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
 
@@ -960,8 +962,8 @@ def main():
         gen_norm_layer(ref, args.out)
     if ap2 is None or "chain" in ap2:
         gen_chain(ref, args.out)
-    for prefix in ("tf", "ca"):
-        if ap2 is None or "chain_rows" in ap2:
+    for prefix in ("tf", "ca", "epic_gauss", "epicw_gauss"):
+        if (ap2 is None or "chain_rows" in ap2) and (names is None or prefix in names):
             gen_chain_rows(ref, prefix, args.out)
     if ap2 is None or "chain_wide" in ap2:
         gen_chain(ref, args.out, B=3, seed=3434, hp=CHAIN_WIDE_HP, file_name="epic_chain2w.npz")

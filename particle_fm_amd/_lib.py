@@ -50,6 +50,8 @@ SYMBOLS = {
         c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
     "pfm_epic_fm_loss_backward_dx": (
         c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
+    "pfm_epic_fm_loss_backward_dx_temb": (
+        c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, _fp, c_void_p]),
     "pfm_epic_fm_loss_backward_phases": (
         c_int, [POINTER(EpicDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, c_int32, _fp, c_int32, _fp, _fp, c_int32, c_void_p]),
     "pfm_optim_step": (

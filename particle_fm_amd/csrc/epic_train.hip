@@ -302,6 +302,15 @@ extern "C" int pfm_epic_fm_loss_backward_dx(const pfm_epic_desc* d, const float*
                          PFM_BWD_PHASE_CHAIN | PFM_BWD_PHASE_DW, grad_y);
 }
 
+extern "C" int pfm_epic_fm_loss_backward_dx_temb(const pfm_epic_desc* d, const float* blob, const float* cond, const float* mask,
+                                                 const float* saved, const float* inv_mask_total, const float* grad_scale, float* grad_blob,
+                                                 float* grad_y, float* grad_temb, int32_t B, float* scratch, const int32_t* order,
+                                                 void* stream) {
+    if (!grad_y || !grad_temb) return set_err(PFM_E_BADARG, "grad_y / grad_temb is NULL");
+    return loss_backward(d, blob, cond, mask, saved, inv_mask_total, grad_scale, grad_blob, 0, nullptr, B, scratch, order, stream, grad_temb,
+                         PFM_BWD_PHASE_CHAIN | PFM_BWD_PHASE_DW, grad_y);
+}
+
 extern "C" int pfm_epic_fm_loss_backward_temb(const pfm_epic_desc* d, const float* blob, const float* cond, const float* mask,
                                               const float* saved, const float* inv_mask_total, const float* grad_scale,
                                               float* grad_blob, float* grad_temb, int32_t B, float* scratch, const int32_t* order,

@@ -142,8 +142,8 @@ class EpicFieldFn(torch.autograd.Function):
     """Jet-resident EPiC field over the layout's source vector, differentiable w.r.t. the parameters AND the particle input x
     (pfm_epic_fm_loss_backward_dx): the building block of n_transforms > 1 (losses.py:66-69 feeds each flow's output to the next).
     The saved record of a jet starts with y | v | u (pfm_hip.h): the upstream gradient goes in as u := v - G / 2.
-    ``temb`` (B, T): a caller-supplied time embedding (t_emb="gaussian"), then a differentiable input in place of x
-    (pfm_epic_fm_loss_backward_temb returns d / d temb, not d / d x)."""
+    ``temb`` (B, T): a caller-supplied time embedding (t_emb="gaussian"), then a differentiable input too
+    (pfm_epic_fm_loss_backward_temb / _dx_temb return d / d temb)."""
 
     @staticmethod
     def forward(ctx, src, x, layout, t, cond, mask, temb=None):
@@ -176,16 +176,11 @@ class EpicFieldFn(torch.autograd.Function):
         maskf = None if ctx.mask is None else ctx.mask.reshape(B, -1).to(torch.float32).contiguous()
         one = torch.ones(1, device=dev)
         gblob = torch.zeros_like(blob)
-        d_y = d_temb = None
-        if ctx.temb_shape is not None:
-            if ctx.needs_input_grad[1]:
-                raise NotImplementedError("the jet-resident EPiC field with a caller-supplied embedding returns d / d temb, not d / d x")
-            d_temb = torch.empty(B, layout.cfg.t_dim, device=dev, dtype=torch.float32)
-            hip_ops.epic_loss_backward(layout, blob, cond, maskf, sv, one, one, gblob, d_temb=d_temb)
+        d_temb = None if ctx.temb_shape is None else torch.empty(B, layout.cfg.t_dim, device=dev, dtype=torch.float32)
+        d_y = torch.empty(B, N, F, device=dev, dtype=torch.float32) if (ctx.temb_shape is None or ctx.needs_input_grad[1]) else None
+        hip_ops.epic_loss_backward(layout, blob, cond, maskf, sv, one, one, gblob, d_temb=d_temb, d_y=d_y)
+        if d_temb is not None:
             d_temb = d_temb.reshape(ctx.temb_shape)
-        else:
-            d_y = torch.empty(B, N, F, device=dev, dtype=torch.float32)
-            hip_ops.epic_loss_backward(layout, blob, cond, maskf, sv, one, one, gblob, d_y=d_y)
         _, gpos, _ = _Maps.get(layout, dev)
         d_src = torch.zeros(ctx.n_source, device=dev, dtype=torch.float32)
         d_src[: gpos.numel()] = gblob[gpos]

@@ -450,6 +450,10 @@ def epic_loss_backward(layout: EpicLayout, blob, cond, maskf, saved, inv_total, 
                                                       P(jet_w[c0:c1]), P(cc), P(mm), P(sv), P(inv_total), P(gscale), P(out), n, P(scr),
                                                       P(order), S)
             _lib.check(rc, "pfm_epic_diffusion_loss_backward")
+        elif d_y is not None and d_temb is not None:
+            rc = lib.pfm_epic_fm_loss_backward_dx_temb(ctypes.byref(layout.desc), P(blob), P(cc), P(mm), P(sv), P(inv_total), P(gscale),
+                                                       P(out), P(d_y[c0:c1]), P(d_temb[c0:c1]), n, P(scr), P(order), S)
+            _lib.check(rc, "pfm_epic_fm_loss_backward_dx_temb")
         elif d_y is not None:
             rc = lib.pfm_epic_fm_loss_backward_dx(ctypes.byref(layout.desc), P(blob), P(cc), P(mm), P(sv), P(inv_total), P(gscale),
                                                   P(out), P(d_y[c0:c1]), n, P(scr), P(order), S)

@@ -330,12 +330,12 @@ class CNF(nn.Module):
                                       "flow expects `features` inputs -- the reference's own chain does not run for it")
         if self.is_transformer or self.is_cross_attention:
             return self._field_rows(t, x, cond, mask)
+        tt = self._per_jet_time(t, x).to(x.device, torch.float32)
         if self.t_emb == "gaussian":
             if self.net.is_wide(x.shape[1]):
                 return self._field_rows(t, x, cond, mask)
-            raise NotImplementedError("n_transforms > 1 with t_emb='gaussian' on the jet-resident EPiC kernels: the field with a "
-                                      "caller-supplied embedding returns no input gradient there")
-        tt = self._per_jet_time(t, x).to(x.device, torch.float32)
+            lay = self.net.layout(x.shape[1])
+            return _fm_field.epic_field(lay, self.net.source_vector(lay), tt, x, cond, mask, temb=self._gaussian_temb(tt))
         lay = self.net.layout(x.shape[1])
         if self.net.is_wide(x.shape[1]):
             return _fm_field.epic_wide_field(lay, self.net.source_vector(lay), tt, x, cond, mask)

@@ -10,9 +10,26 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+PATHS = ["tf", "ca", "epic_gauss", "epicw_gauss"]  # the last two: both EPiC paths with t_emb="gaussian" (d / d x and d / d temb together)
+
+
 def _load(path):
-    from tests.conftest import load_ca_golden, load_tf_golden
-    return {"tf": load_tf_golden, "ca": load_ca_golden}[path]("chain2")
+    from tests.conftest import load_ca_golden, load_epic_seeded_golden, load_tf_golden, load_wide_golden
+    base, _, gauss = path.partition("_")
+    loader = {"tf": load_tf_golden, "ca": load_ca_golden, "epic": load_epic_seeded_golden, "epicw": load_wide_golden}[base]
+    return loader("chain2_gauss" if gauss else "chain2")
+
+
+def _oracle(path, g, i, state=None):
+    base = path.partition("_")[0]
+    if base == "tf":
+        from oracle.tf_ref import TransformerVectorField as VF
+    elif base == "ca":
+        from oracle.ca_ref import CrossAttentionVectorField as VF
+    else:
+        from oracle.fm_ref import EpicVectorField
+        return EpicVectorField(state or g.state, f"flows.{i}.net", g.hp, freqs=g.freqs)
+    return VF(state or g.state, f"flows.{i}.", g.hp, freqs=g.freqs)
 
 
 def _module(g):
@@ -24,16 +41,13 @@ def _module(g):
     full.update({"loss." + k: v for k, v in state.items()})
     m.load_state_dict(full)
     m = m.cuda()
-    m.set_freq_table(g.freqs)
+    if g.hp["t_emb"] != "gaussian":
+        m.set_freq_table(g.freqs)
     return m
 
 
-@pytest.mark.parametrize("path", ["tf", "ca"])
+@pytest.mark.parametrize("path", PATHS)
 def test_field_gradient_wrt_input_matches_the_oracle(path):
-    if path == "tf":
-        from oracle.tf_ref import TransformerVectorField as VF
-    else:
-        from oracle.ca_ref import CrossAttentionVectorField as VF
     g = _load(path)
     m = _module(g)
     assert len(m.flows) == 2
@@ -41,7 +55,7 @@ def test_field_gradient_wrt_input_matches_the_oracle(path):
     x, t, mask, cond = (g.get(tag + k) for k in ("x", "t", "mask", "cond"))
     G = torch.randn(x.shape, generator=torch.Generator().manual_seed(3)) * mask  # (padded rows carry no upstream gradient in a chain: the next flow never reads them)
     xr = x.clone().requires_grad_(True)
-    vf = VF(g.state, "flows.1.", g.hp, freqs=g.freqs)
+    vf = _oracle(path, g, 1)
     v_ref = vf(t[:, None].expand(-1, x.shape[1]), xr, cond=cond, mask=mask)
     (v_ref * G).sum().backward()
     xc = x.cuda().requires_grad_(True)
@@ -52,7 +66,7 @@ def test_field_gradient_wrt_input_matches_the_oracle(path):
     torch.testing.assert_close(xc.grad.cpu()[keep], xr.grad[keep], atol=2e-5, rtol=2e-3)
 
 
-@pytest.mark.parametrize("path", ["tf", "ca"])
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("name", ["fm", "cfm"])
 def test_chained_loss_and_parameter_gradients(path, name):
     from particle_fm_amd.models.components.losses import _chained_loss
@@ -79,7 +93,7 @@ def test_chained_loss_and_parameter_gradients(path, name):
     assert not bad, bad[:8]
 
 
-@pytest.mark.parametrize("path", ["tf", "ca"])
+@pytest.mark.parametrize("path", PATHS)
 def test_training_step_and_sampling_through_both_flows(path):
     g = _load(path)
     m = _module(g)

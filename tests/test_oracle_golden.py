@@ -142,18 +142,22 @@ def test_chained_flows_fixture_is_reproduced_by_the_oracle(fixture):
             torch.testing.assert_close(xe, g.get(tag + "x_end"), rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("path", ["tf", "ca"])
+@pytest.mark.parametrize("path", ["tf", "ca", "epic_gauss", "epicw_gauss"])
 def test_chained_transformer_flows_fixture_is_reproduced_by_the_oracle(path):
     """tests/golden/{tf,ca}_chain2.npz (n_transforms = 2 on the Full-Transformer / cross-attention models): the oracle's fields composed as
     losses.py:66-69 composes them reproduce the recorded FM-OT loss and the reverse-order midpoint samples."""
     from oracle.fm_ref import fm_ot_targets, midpoint_trajectory_end
-    from tests.conftest import load_ca_golden, load_tf_golden
+    from tests.conftest import load_ca_golden, load_epic_seeded_golden, load_tf_golden, load_wide_golden
     if path == "tf":
         from oracle.tf_ref import TransformerVectorField as VF
         g = load_tf_golden("chain2")
-    else:
+    elif path == "ca":
         from oracle.ca_ref import CrossAttentionVectorField as VF
         g = load_ca_golden("chain2")
+    else:  # both EPiC paths with t_emb="gaussian"
+        from oracle.fm_ref import EpicVectorField
+        g = (load_epic_seeded_golden if path == "epic_gauss" else load_wide_golden)("chain2_gauss")
+        VF = lambda st, pre, hp, freqs=None: EpicVectorField(st, pre + "net", hp, freqs=freqs)
     vfs = [VF(g.state, f"flows.{i}.", g.hp, freqs=g.freqs) for i in range(2)]
     tag = "loss_fm/"
     x, t, z, mask, cond = (g.get(tag + k) for k in ("x", "t", "a", "mask", "cond"))
