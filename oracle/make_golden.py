@@ -850,7 +850,7 @@ def gen_chain_rows(ref, prefix, out_dir, B=3, seed=8181):
 
     # "epic_gauss" / "epicw_gauss": both EPiC paths with t_emb="gaussian" (the fields then return d / d temb beside d / d x)
     hp = copy.deepcopy({"tf": lambda: TF_CONFIGS["small"][0], "ca": lambda: CA_CONFIGS["small"][0], "epic_gauss": lambda: CONFIGS["gauss"],
-                        "epicw_gauss": lambda: WIDE_CONFIGS["gauss"][0]}[prefix]())
+                        "epicw_gauss": lambda: WIDE_CONFIGS["gauss"][0], "epic_diff": lambda: DIFF_HP}[prefix]())
     cnfs = []
     for i in range(2):
         torch.manual_seed(seed + i)
@@ -872,10 +872,29 @@ def gen_chain_rows(ref, prefix, out_dir, B=3, seed=8181):
     out["freqs"] = (torch.arange(2 * hp["frequencies"]).exp() if hp["t_emb"] == "cosine" else cnfs[0].frequencies.clone()).numpy()
     out["abs_sum"] = np.array(sum(float(np.abs(v).sum(dtype=np.float64)) for v in new.values()))
     gen = torch.Generator().manual_seed(seed + 1)
-    for name, cls in (("fm", ref.losses.FlowMatchingLoss), ("cfm", ref.losses.ConditionalFlowMatchingLoss)):
+    diffusion = hp.get("loss_type") == "diffusion"  # "epic_diff": DiffusionLoss through both flows (losses.py:264-267), both criteria
+    kinds = (("huber", None), ("mse", None)) if diffusion else (("fm", ref.losses.FlowMatchingLoss), ("cfm", ref.losses.ConditionalFlowMatchingLoss))
+    for name, cls in kinds:
         mask = make_mask(B, N, "f32", gen)
         x = torch.randn(B, N, Fe, generator=gen) * mask
         cond = torch.randn(B, Cg, generator=gen)
+        if diffusion:
+            loss_mod = ref.losses.DiffusionLoss(flows=flows, criterion=name, diff_config=hp["diff_config"])
+            torch.manual_seed(2468)
+            flows.zero_grad()
+            loss = loss_mod(2.0 * x, mask=mask, cond=cond)
+            loss.backward()
+            torch.manual_seed(2468)
+            t = torch.rand_like(torch.ones(B))
+            a = torch.randn_like(x) * mask  # losses.py:247
+            tag = f"loss_{name}/"
+            out[tag + "x"], out[tag + "t"], out[tag + "a"] = (2.0 * x).numpy(), t.numpy(), a.numpy()
+            out[tag + "mask"], out[tag + "cond"], out[tag + "loss"] = mask.numpy(), cond.numpy(), loss.detach().numpy()
+            for i, c in enumerate(cnfs):
+                for k, p in c.named_parameters():
+                    if p.grad is not None:
+                        out[tag + f"grad/flows.{i}." + k] = subsample(p.grad.detach().clone().numpy())
+            continue
         loss_mod = cls(flows=flows, sigma=1e-4)
         torch.manual_seed(2468)
         flows.zero_grad()
@@ -900,11 +919,13 @@ def gen_chain_rows(ref, prefix, out_dir, B=3, seed=8181):
         for steps in (3, 10):
             xe = z * mask
             for c in reversed(cnfs):
-                wrapped = ref.fmm.ode_wrapper(model=c, cond=cond, mask=mask, loss_type="FM-OT")
+                wrapped = ref.fmm.ode_wrapper(model=c, cond=cond, mask=mask, loss_type="diffusion" if diffusion else "FM-OT",
+                                              **({"diff_config": hp["diff_config"]} if diffusion else {}))
                 xe = midpoint_trajectory_end(wrapped, xe, torch.linspace(1.0, 0.0, steps))
             tag = f"midpoint_{steps}/"
             out[tag + "z"], out[tag + "mask"], out[tag + "cond"], out[tag + "x_end"] = z.numpy(), mask.numpy(), cond.numpy(), xe.numpy()
-    path = os.path.join(out_dir, f"{prefix[:-6]}_chain2_gauss.npz" if prefix.endswith("_gauss") else f"{prefix}_chain2.npz")
+    fname = f"{prefix[:-6]}_chain2_gauss.npz" if prefix.endswith("_gauss") else ("epic_chain2_diffusion.npz" if diffusion else f"{prefix}_chain2.npz")
+    path = os.path.join(out_dir, fname)
     np.savez(path, **out)
     print(f"wrote {path}: {os.path.getsize(path)/1e6:.2f} MB, {len(out)} arrays")
 
@@ -962,7 +983,7 @@ def main():
         gen_norm_layer(ref, args.out)
     if ap2 is None or "chain" in ap2:
         gen_chain(ref, args.out)
-    for prefix in ("tf", "ca", "epic_gauss", "epicw_gauss"):
+    for prefix in ("tf", "ca", "epic_gauss", "epicw_gauss", "epic_diff"):
         if (ap2 is None or "chain_rows" in ap2) and (names is None or prefix in names):
             gen_chain_rows(ref, prefix, args.out)
     if ap2 is None or "chain_wide" in ap2:

@@ -19,10 +19,17 @@ def _to_device(t_cpu: torch.Tensor, x: torch.Tensor, land=None) -> torch.Tensor:
     return t_cpu.type_as(x)
 
 
-def _single_flow(flows):
-    if len(flows) != 1:
-        raise NotImplementedError("n_transforms > 1: this objective has a chained-flow path for FM-OT / CFM / droid only")
-    return flows[0]
+def _chained_diffusion_loss(flows, x, t, z, mask, cond, criterion: str, diff_config) -> torch.Tensor:
+    """DiffusionLoss with n_transforms > 1 (losses.py:264-267: the noisy particles pass through every flow at the same t; the last
+    output is the predicted noise): the flows as differentiable fields (see _chained_loss), rates / criterion / weights as device ops."""
+    from ... import fm_field, hip_ops
+    dc = dict(diff_config)
+    tt = t.to(x.device, torch.float32)
+    sr, nr, _ = hip_ops.diffusion_schedule(tt, **dc)
+    temp = sr.view(-1, 1, 1) * x + nr.view(-1, 1, 1) * z
+    for f in flows:
+        temp = f.field(tt, temp, cond=cond, mask=mask)
+    return fm_field.diffusion_loss_from_field(temp, z, mask, tt, criterion, dc)
 
 
 def _chained_loss(flows, kind: str, x, t, a, eps, mask, cond, sigma: float) -> torch.Tensor:
@@ -143,5 +150,6 @@ class DiffusionLoss(nn.Module):
         if mask is None:
             raise TypeError("DiffusionLoss needs a mask (losses.py:247 multiplies the noise by it)")
         t, z = self.draw(x, mask)
-        return _single_flow(self.flows).diffusion_loss(x, t, z, mask=mask, cond=cond, criterion=self.criterion,
-                                                       diff_config=self.diff_config)
+        if len(self.flows) > 1:
+            return _chained_diffusion_loss(self.flows, x, t, z, mask, cond, self.criterion, self.diff_config)
+        return self.flows[0].diffusion_loss(x, t, z, mask=mask, cond=cond, criterion=self.criterion, diff_config=self.diff_config)

@@ -108,3 +108,45 @@ def test_training_step_and_sampling_through_both_flows(path):
         out = m((z * mk).cuda(), cond=c.cuda(), mask=mk.cuda(), reverse=True, ode_solver="midpoint", ode_steps=steps).cpu()
         keep = mk.squeeze(-1) != 0
         torch.testing.assert_close(out[keep], g.get(tag + "x_end")[keep], atol=2e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("crit", ["huber", "mse"])
+def test_chained_diffusion_loss_and_sampling(crit):
+    """loss_type="diffusion" with n_transforms = 2 (losses.py:264-267: the noisy particles pass through both flows at the same t) on the
+    jet-resident EPiC kernels (tests/golden/epic_chain2_diffusion.npz): DiffusionLoss + sub-sampled gradients of both flows, and
+    sampling -- each flow's probability-flow ODE, the flows in reverse order."""
+    from particle_fm_amd.models import SetFlowMatchingLitModule
+    from particle_fm_amd.models.components.losses import _chained_diffusion_loss
+    from tests.conftest import load_epic_seeded_golden
+    g = load_epic_seeded_golden("chain2_diffusion")
+    m = SetFlowMatchingLitModule(optimizer=None, criterion=crit, **copy.deepcopy(g.hp))
+    state = dict(g.state)
+    state["flows.1.frequencies"] = state["flows.0.frequencies"]
+    full = dict(state)
+    full.update({"loss." + k: v for k, v in state.items()})
+    m.load_state_dict(full, strict=False)
+    m = m.cuda()
+    m.set_freq_table(g.freqs)
+    assert len(m.flows) == 2
+    tag = f"loss_{crit}/"
+    x, t, z, mask, cond = (g.get(tag + k).cuda() for k in ("x", "t", "a", "mask", "cond"))
+    loss = _chained_diffusion_loss(m.flows, x, t, z, mask, cond, crit, g.hp["diff_config"])
+    torch.testing.assert_close(loss.detach().cpu(), g.get(tag + "loss"), rtol=3e-5, atol=1e-6)
+    loss.backward()
+    named = dict(m.flows.named_parameters())
+    bad = []
+    for k, want in g.grads(tag).items():
+        got = g.pick(named[k[len("flows."):]].grad.cpu())
+        rel = float((got - want).norm()) / max(float(want.norm()), 1e-12)
+        if not rel < 2e-3:
+            bad.append((k, rel))
+    assert not bad, bad[:8]
+    if crit == "huber":
+        for steps in (3, 10):
+            tg = f"midpoint_{steps}/"
+            zz, mk, c = (g.get(tg + k) for k in ("z", "mask", "cond"))
+            out = m((zz * mk).cuda(), cond=c.cuda(), mask=mk.cuda(), reverse=True, ode_solver="midpoint", ode_steps=steps).cpu()
+            torch.testing.assert_close(out, g.get(tg + "x_end"), atol=3e-4, rtol=1e-3)
+        torch.manual_seed(5)
+        l2 = m.training_step((x, mask, cond), 0)["loss"]
+        assert torch.isfinite(l2)

@@ -103,3 +103,31 @@ def test_row_models_loss_rhs_and_samplers(path):
             torch.testing.assert_close(xe, g.get(tag + "x_end"), rtol=1e-3, atol=2e-4)
         z, mask = g.get("ddim/z"), g.get("ddim/mask")
         torch.testing.assert_close(dr.ddim_sample(vf, z * mask, _c(g, "ddim/"), mask, n, dc), g.get("ddim/x_end"), rtol=1e-3, atol=2e-4)
+
+
+def test_chained_diffusion_fixture_is_reproduced_by_the_oracle():
+    """tests/golden/epic_chain2_diffusion.npz (n_transforms = 2 under DiffusionLoss, losses.py:264-267): the oracle's fields composed the
+    same way reproduce the recorded losses and the reverse-order midpoint samples."""
+    from oracle.fm_ref import EpicVectorField
+    from tests.conftest import load_epic_seeded_golden
+    g = load_epic_seeded_golden("chain2_diffusion")
+    dc = g.hp["diff_config"]
+    vfs = [EpicVectorField(g.state, f"flows.{i}.net", g.hp, freqs=g.freqs) for i in range(2)]
+
+    def chain(t, x, mask=None, cond=None):
+        for vf in vfs:
+            x = vf(t, x, mask=mask, cond=cond)
+        return x
+
+    with torch.no_grad():
+        for crit in ("huber", "mse"):
+            tag = f"loss_{crit}/"
+            x, t, z, mask, cond = (g.get(tag + k) for k in ("x", "t", "a", "mask", "cond"))
+            loss, *_ = dr.diffusion_loss(chain, x, mask, cond, t, z, crit, dc)
+            torch.testing.assert_close(loss, g.get(tag + "loss"), rtol=2e-5, atol=1e-6)
+        tag = "midpoint_10/"
+        z, mask, cond = (g.get(tag + k) for k in ("z", "mask", "cond"))
+        xe = z * mask
+        for vf in reversed(vfs):
+            xe = midpoint_trajectory_end(lambda tt, xx: dr.diffusion_rhs(vf, tt, xx, cond, mask, dc), xe, torch.linspace(1.0, 0.0, 10))
+        torch.testing.assert_close(xe, g.get(tag + "x_end"), rtol=1e-3, atol=2e-4)
