@@ -74,7 +74,7 @@ class FlowMatchingLoss(nn.Module):
         t, z = self.draw(x)
         if len(self.flows) > 1:
             return _chained_loss(self.flows, "FM-OT", x, t, z, None, mask, cond, self.sigma)
-        return _single_flow(self.flows).fm_loss(x, t, z, mask=mask, cond=cond, sigma=self.sigma, kind="FM-OT")
+        return self.flows[0].fm_loss(x, t, z, mask=mask, cond=cond, sigma=self.sigma, kind="FM-OT")
 
 
 class ConditionalFlowMatchingLoss(nn.Module):
@@ -98,7 +98,7 @@ class ConditionalFlowMatchingLoss(nn.Module):
         t, x0, eps = self.draw(x)
         if len(self.flows) > 1:
             return _chained_loss(self.flows, "CFM", x, t, x0, eps, mask, cond, self.sigma)
-        return _single_flow(self.flows).fm_loss(x, t, x0, mask=mask, cond=cond, sigma=self.sigma, kind="CFM", eps=eps)
+        return self.flows[0].fm_loss(x, t, x0, mask=mask, cond=cond, sigma=self.sigma, kind="CFM", eps=eps)
 
 
 class DroidLoss(nn.Module):
@@ -123,7 +123,7 @@ class DroidLoss(nn.Module):
         t, z = self.draw(x)
         if len(self.flows) > 1:
             return _chained_loss(self.flows, "droid", x, t, z, None, mask, cond, self.sigma)
-        return _single_flow(self.flows).fm_loss(x, t, z, mask=mask, cond=cond, sigma=self.sigma, kind="droid")
+        return self.flows[0].fm_loss(x, t, z, mask=mask, cond=cond, sigma=self.sigma, kind="droid")
 
 
 class DiffusionLoss(nn.Module):
