@@ -32,9 +32,10 @@ def wn_linear(state: Mapping[str, torch.Tensor], prefix: str, inp: torch.Tensor)
     return F.linear(inp, w, b)
 
 
-def _act(x: torch.Tensor) -> torch.Tensor:
-    # epic.py:180 -- getattr(F, "leaky_relu") with the default slope 0.01
-    return F.leaky_relu(x)
+def _act(x: torch.Tensor, activation: str = "leaky_relu") -> torch.Tensor:
+    # epic.py:180 -- getattr(F, activation, lambda x: x): "leaky_relu" (default slope 0.01) in every shipped config; a name torch.nn.functional
+    # does not know means NO activation
+    return getattr(F, activation, lambda v: v)(x)
 
 
 def epic_layer(
@@ -48,6 +49,7 @@ def epic_layer(
     cond_l: Optional[torch.Tensor],
     mask: torch.Tensor,
     sum_scale: float,
+    activation: str = "leaky_relu",
 ):
     """One EPiC layer (epic.py:159-203).  Returns (x_global, x_local)."""
     n = x_local.shape[1]
@@ -56,14 +58,14 @@ def epic_layer(
     pooled_mean = pooled_sum / mask.sum(1)
     pooled_sum = pooled_sum * sum_scale
     parts = [p for p in (t_global, pooled_mean, pooled_sum, x_global, cond_g) if p is not None]
-    g1 = _act(wn_linear(state, prefix + ".fc_global1", torch.cat(parts, -1)))  # :180-182
+    g1 = _act(wn_linear(state, prefix + ".fc_global1", torch.cat(parts, -1)), activation)  # :180-182
     parts = [p for p in (t_global, g1, cond_g) if p is not None]
-    x_global = _act(wn_linear(state, prefix + ".fc_global2", torch.cat(parts, -1)) + x_global)  # :184-186
+    x_global = _act(wn_linear(state, prefix + ".fc_global2", torch.cat(parts, -1)) + x_global, activation)  # :184-186
     g2l = x_global.unsqueeze(1).expand(-1, n, -1)  # :189 (repeat_interleave over points)
     parts = [p for p in (t_local, x_local, g2l, cond_l) if p is not None]
-    l1 = _act(wn_linear(state, prefix + ".fc_local1", torch.cat(parts, -1)))  # :194-196
+    l1 = _act(wn_linear(state, prefix + ".fc_local1", torch.cat(parts, -1)), activation)  # :194-196
     parts = [p for p in (t_local, l1, cond_l) if p is not None]
-    x_local = _act(wn_linear(state, prefix + ".fc_local2", torch.cat(parts, -1)) + x_local)  # :198-200
+    x_local = _act(wn_linear(state, prefix + ".fc_local2", torch.cat(parts, -1)) + x_local, activation)  # :198-200
     return x_global, x_local
 
 
@@ -81,6 +83,7 @@ def epic_encoder(
     global_cond_dim: int = 0,
     local_cond_dim: int = 0,
     sum_scale: float = 1e-2,
+    activation: str = "leaky_relu",
 ) -> torch.Tensor:
     """EPiC_encoder.forward (epic.py:304-391).
 
@@ -104,25 +107,25 @@ def epic_encoder(
     cond_l = cond.unsqueeze(1).expand(-1, n, -1) if local_cond_dim > 0 else None  # :353-354
 
     parts = [q for q in (t_local, x, cond_l) if q is not None]
-    h = _act(wn_linear(state, p + "fc_l1", torch.cat(parts, -1)))  # :360-362
+    h = _act(wn_linear(state, p + "fc_l1", torch.cat(parts, -1)), activation)  # :360-362
     parts = [q for q in (t_local, h, cond_l) if q is not None]
-    h = _act(wn_linear(state, p + "fc_l2", torch.cat(parts, -1)) + h)  # :364-366
+    h = _act(wn_linear(state, p + "fc_l2", torch.cat(parts, -1)) + h, activation)  # :364-366
 
     z_sum = (h * mask).sum(1)  # :369
     z_mean = z_sum / mask.sum(1)  # :370  (NaN for an all-masked jet, as the reference)
     z_sum = z_sum * sum_scale  # :371
     parts = [q for q in (t_global, z_sum, z_mean, cond_g) if q is not None]  # (sum, mean) order :373
-    g = _act(wn_linear(state, p + "fc_g1", torch.cat(parts, -1)))  # :375-377
+    g = _act(wn_linear(state, p + "fc_g1", torch.cat(parts, -1)), activation)  # :375-377
     parts = [q for q in (t_global, g, cond_g) if q is not None]
-    g = _act(wn_linear(state, p + "fc_g2", torch.cat(parts, -1)))  # :378-380
+    g = _act(wn_linear(state, p + "fc_g2", torch.cat(parts, -1)), activation)  # :378-380
 
     for k in range(layers):  # :382-385
         g, h = epic_layer(
-            state, f"{p}nn_list.{k}", t_local, t_global, g, h, cond_g, cond_l, mask, sum_scale
+            state, f"{p}nn_list.{k}", t_local, t_global, g, h, cond_g, cond_l, mask, sum_scale, activation
         )
 
     parts = [q for q in (t_local, h, cond_l) if q is not None]
-    out = _act(wn_linear(state, p + "fc_l3", torch.cat(parts, -1)))  # :387-389
+    out = _act(wn_linear(state, p + "fc_l3", torch.cat(parts, -1)), activation)  # :387-389
     return out * mask  # :391
 
 

@@ -111,6 +111,7 @@ class EpicVectorField:
             global_cond_dim=hp.get("global_cond_dim", 0),
             local_cond_dim=hp.get("local_cond_dim", 0),
             sum_scale=hp.get("sum_scale", 1e-2),
+            activation=hp.get("activation", "leaky_relu"),
         )
 
 

@@ -104,6 +104,9 @@ CONFIGS = {
     # t_emb="gaussian" (flow_matching_module.py:178-181, 213-221; time_emb.py:9-22): a learned time embedding -- random Fourier
     # features -> Linear -> activation -> Linear(2 * frequencies) -- whose parameters train with the network
     "gauss": dict(BASE, num_particles=24, layers=2, t_emb="gaussian", global_cond_dim=2, local_cond_dim=2),
+    # activation (epic.py:180: getattr(F, activation, lambda x: x)): "relu", and a name torch.nn.functional does not have = none
+    "relu": dict(BASE, num_particles=24, layers=2, activation="relu", global_cond_dim=2),
+    "noact": dict(BASE, num_particles=24, layers=1, activation="none"),
     # add_time_to_input=True for model "epic" (flow_matching_module.py:126, 199-200: the network sees cat(time embedding, x); the class
     # default, off in configs/model/flow_matching.yaml): with t_local_cat (fc_l1 then has TWO time blocks) and without
     "addtime": dict(BASE, num_particles=24, layers=2, add_time_to_input=True, global_cond_dim=2, local_cond_dim=2),

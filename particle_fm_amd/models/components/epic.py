@@ -53,9 +53,21 @@ class WNLinear(nn.Module):
         return f"in_features={self.in_features}, out_features={self.out_features}, weight_norm=True"
 
 
+def activation_slope(activation: str) -> float:
+    """The reference applies ``getattr(F, activation, lambda x: x)`` (epic.py:180): the kernels' activation is max(x, slope * x) with the
+    slope in the descriptor -- 0.01 for "leaky_relu" (F.leaky_relu's default, every shipped config), 0 for "relu", 1 (no activation)
+    for a name torch.nn.functional does not know, as there; any other function of torch.nn.functional has no HIP path."""
+    if activation == "leaky_relu":
+        return 0.01
+    if activation == "relu":
+        return 0.0
+    if not hasattr(torch.nn.functional, activation):
+        return 1.0
+    raise NotImplementedError(f"activation={activation!r}: the HIP kernels implement max(x, slope x): leaky_relu, relu, or none")
+
+
 def _check_supported(activation: str, wrapper_func: str, dropout: float):
-    if activation != "leaky_relu":
-        raise NotImplementedError(f"activation={activation!r}: the HIP kernels implement leaky_relu (slope 0.01)")
+    activation_slope(activation)
     if wrapper_func != "weight_norm":
         raise NotImplementedError(f"wrapper_func={wrapper_func!r}: the HIP path expects weight_norm Linears")
     if dropout != 0.0:
@@ -94,6 +106,7 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
                  dropout: float = 0.0, sum_scale: float = 1e-2, t_emb: str = "cosine"):
         super().__init__()
         _check_supported(activation, wrapper_func, dropout)
+        self.neg_slope = activation_slope(activation)
         self.t_emb = t_emb  # what CNF embeds the time with: the kernels embed in place of CNF.time_embedding
         # add_time_to_input (flow_matching_module.py:126, 199-200): CNF hands the network cat(time embedding, x), so fc_l1 has
         # 2 * frequencies more input columns.  The kernels fold them into fc_l1's time block (layout.EpicConfig.add_time_to_input).
@@ -152,7 +165,8 @@ class EPiC_encoder(FreqTableMixin, nn.Module):
                           latent=self.latent, layers=self.equiv_layers, frequencies=self.frequencies,
                           t_local_cat=self.t_local_cat, t_global_cat=self.t_global_cat,
                           global_cond_dim=self.global_cond_dim, local_cond_dim=self.local_cond_dim,
-                          sum_scale=self.sum_scale, t_emb=self.t_emb, add_time_to_input=self.add_time_to_input)
+                          sum_scale=self.sum_scale, t_emb=self.t_emb, add_time_to_input=self.add_time_to_input,
+                          neg_slope=self.neg_slope)
 
     def layout(self, num_points: Optional[int] = None, temb_given: bool = False) -> EpicLayout:
         """``temb_given`` (row-matrix path): the descriptor with PFM_EW_F_TEMB_GIVEN -- same blob, the entry points take the time

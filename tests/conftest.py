@@ -48,7 +48,7 @@ def load_golden(name):
     return _cache[name]
 
 
-@pytest.fixture(params=["jetnet30", "jetnet150", "cond_gl", "cond_jetclass", "addtime", "addtime_notl"])
+@pytest.fixture(params=["jetnet30", "jetnet150", "cond_gl", "cond_jetclass", "addtime", "addtime_notl", "relu", "noact"])
 def golden(request):
     return load_golden(request.param)
 

@@ -18,6 +18,7 @@ def cfg_of(hp):
         t_local_cat=hp["t_local_cat"], t_global_cat=hp["t_global_cat"],
         global_cond_dim=hp["global_cond_dim"], local_cond_dim=hp["local_cond_dim"], sum_scale=hp["sum_scale"],
         t_emb=hp.get("t_emb", "cosine"), add_time_to_input=bool(hp.get("add_time_to_input", False)),
+        neg_slope={"leaky_relu": 0.01, "relu": 0.0}.get(hp.get("activation", "leaky_relu"), 1.0),  # (epic.py:180; components/epic.py::activation_slope)
     )
 
 
