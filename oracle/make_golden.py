@@ -308,6 +308,9 @@ TF_CONFIGS = {
                     net_config=tf_net_config(128, 1, 8)), 3, False),
     # t_emb="gaussian" (flow_matching_module.py:178-181, 213-221): the CNF's trainable embedding network in front of the field
     "gauss": (dict(TF_BASE, num_particles=24, global_cond_dim=2, t_emb="gaussian", hidden_dim=64, net_config=tf_net_config(128, 1, 8)), 3, False),
+    # no conditioning, a smooth time embedding: the network CNF.log_prob can evaluate (flow_matching_module.py:337: self(t, x)) and an
+    # adaptive solver converges on
+    "plain": (dict(TF_BASE, num_particles=20, global_cond_dim=0, t_emb="sincos", frequencies=6, net_config=tf_net_config(128, 1, 8)), 3, False),
 }
 
 
@@ -450,6 +453,9 @@ WIDE_CONFIGS = {
     "lhco128": (dict(BASE, num_particles=279, global_cond_dim=4, local_cond_dim=4), 2),
     # t_emb="gaussian" (flow_matching_module.py:178-181, 213-221) on the row-matrix path: the trainable embedding network in front
     "gauss": (dict(WIDE_BASE, num_particles=24, layers=2, t_emb="gaussian", local_cond_dim=12), 3),
+    # no conditioning, a smooth time embedding (CNF.log_prob, see TF_CONFIGS["plain"]): hidden 128 = the jet-resident kernels, 136 = the row-matrix ones
+    "plain": (dict(BASE, num_particles=24, layers=2, t_emb="sincos", frequencies=6), 3),
+    "plainw": (dict(BASE, num_particles=24, layers=1, hidden_dim=136, latent=12, t_emb="sincos", frequencies=6), 3),
 }
 
 
@@ -563,6 +569,7 @@ CA_CONFIGS = {
     # the yaml's own sizes with experiment/lhco/jets_crossattention.yaml:28-29
     "lhco": (dict(CA_BASE, num_particles=279, global_cond_dim=5, net_config=ca_net_config(128, 8, 16, 256)), 2, False),
     "gauss": (dict(CA_BASE, num_particles=24, global_cond_dim=2, t_emb="gaussian", hidden_dim=64, net_config=ca_net_config(128, 1, 16, 256)), 3, False),
+    "plain": (dict(CA_BASE, num_particles=20, global_cond_dim=0, t_emb="sincos", frequencies=6, net_config=ca_net_config(128, 1, 16, 256)), 3, False),
 }
 
 

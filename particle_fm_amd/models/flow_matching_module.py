@@ -500,8 +500,49 @@ class CNF(nn.Module):
                              "network cannot be encoded")
         return self._sample_rk(self.net.packed_weights(x.shape[1]), x, None, mask, 100, "rk4", 0.0, 1.0)
 
-    def log_prob(self, *args, **kwargs):
-        raise NotImplementedError("CNF.log_prob (zuko adaptive solver) has no HIP path in this build")
+    def field_and_trace(self, t, x):
+        """flow_matching_module.py:334-343 (``augmented``): dx = self(t, x) -- no cond, no mask -- and, per particle, the sum over the
+        features f of the batched vector-Jacobian products with the cotangents e_f (ones in feature f of EVERY particle, :331-332):
+        trace[b, n] = sum_f d (sum_n' dx[b, n', f]) / d x[b, n, f].  One HIP forward + input-gradient backward per feature
+        (fm_field.py's differentiable fields, pfm_*_fm_loss_backward_dx)."""
+        tr = torch.zeros(x.shape[:-1], device=x.device, dtype=torch.float32)
+        dx = None
+        with torch.enable_grad():
+            for f in range(x.shape[-1]):
+                xr = x.detach().clone().requires_grad_(True)
+                dx = self.field(t, xr, None, None)
+                e = torch.zeros_like(dx)
+                e[..., f] = 1.0
+                (g,) = torch.autograd.grad(dx, xr, e)
+                tr += g[..., f]
+        return dx.detach(), tr
+
+    def log_prob(self, x: Tensor, atol: float = 1e-6, rtol: float = 1e-5) -> Tensor:
+        """flow_matching_module.py:330-347: the instantaneous change of variables, integrated data -> latent over t in [0, 1] by an
+        adaptive Dormand-Prince 5(4) (zuko.utils.odeint's method and default tolerances; particle_fm_amd/ode.py -- parity unpinned,
+        zuko is not in the image) on the state (x, ladj) with d ladj / dt = trace * 1e-2; returns
+        Normal(0, 1).log_prob(z).sum(-1) + ladj * 1e2, one value per particle (B, N), like the reference."""
+        from ..ode import dopri5
+        if self.is_mdma:
+            raise NotImplementedError("CNF.log_prob with model='mdma': its field has one output per particle (mdma.py:139), the reference's "
+                                      "batched vector-Jacobian product (:339) does not run for it")
+        if self.is_transformer or self.is_cross_attention:
+            raise NotImplementedError("CNF.log_prob evaluates the network with mask=None (flow_matching_module.py:337); the reference's "
+                                      "transformer encoders dereference the mask (droid_transformer.py:539): no log_prob for them there either")
+        if self.net.layout(x.shape[1]).cfg.global_cond_dim > 0:
+            raise ValueError("CNF.log_prob evaluates the network with cond=None (flow_matching_module.py:337); a conditioned network "
+                             "has no log_prob")
+        F = x.shape[-1]
+        x = x.to(torch.float32)
+
+        def rhs(t, s):
+            dx, tr = self.field_and_trace(t, s[..., :F].contiguous())
+            return torch.cat([dx, (tr * 1e-2).unsqueeze(-1)], dim=-1)
+
+        with torch.no_grad():
+            s1 = dopri5(rhs, torch.cat([x, torch.zeros_like(x[..., :1])], dim=-1), 0.0, 1.0, atol=atol, rtol=rtol)
+        z, ladj = s1[..., :F], s1[..., F]
+        return torch.distributions.Normal(0.0, z.new_tensor(1.0)).log_prob(z).sum(dim=-1) + ladj * 1e2
 
 
 class SetFlowMatchingLitModule(_LitBase):

@@ -100,7 +100,7 @@ def load_wide_golden(name):
     return _cache[key]
 
 
-@pytest.fixture(params=["small", "jetclass", "sincos", "lhco128"])
+@pytest.fixture(params=["small", "jetclass", "sincos", "lhco128", "plain", "plainw"])
 def wide_golden(request):
     return load_wide_golden(request.param)
 
@@ -132,7 +132,7 @@ def load_ca_golden(name):
     return _cache[key]
 
 
-@pytest.fixture(params=["small", "lhco"])
+@pytest.fixture(params=["small", "lhco", "plain"])
 def ca_golden(request):
     return load_ca_golden(request.param)
 
@@ -162,6 +162,6 @@ def load_tf_golden(name):
     return _cache[key]
 
 
-@pytest.fixture(params=["small", "lhco", "sincos"])
+@pytest.fixture(params=["small", "lhco", "sincos", "plain"])
 def tf_golden(request):
     return load_tf_golden(request.param)
