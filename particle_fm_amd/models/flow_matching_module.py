@@ -282,19 +282,19 @@ class CNF(nn.Module):
             return self._sample_rk(blob, z, cond, mask, ode_steps, ode_solver, 1.0, 0.0)
         if ode_solver in ("em", "ddim"):
             raise SyntaxError(f"Solver {ode_solver} is only implemented for diffusion loss")  # :326
-        if ode_solver in ("dopri5_zuko", "dopri5"):
+        if ode_solver in ("dopri5_zuko", "dopri5", "tsit5"):
             return self._decode_adaptive(z, cond, mask, ode_solver, ode_steps)
-        if ode_solver in ("tsit5", "ieuler", "alf"):
+        if ode_solver in ("ieuler", "alf"):
             raise NotImplementedError(f"Solver {ode_solver} has no HIP path in this build (fixed-step 'midpoint', 'euler', 'rk4' and the "
-                                      "adaptive 'dopri5_zuko' / 'dopri5' do).")
+                                      "adaptive 'dopri5_zuko' / 'dopri5' / 'tsit5' do).")
         raise NotImplementedError(f"Solver {ode_solver} not implemented")  # :328
 
     def _decode_adaptive(self, z, cond, mask, ode_solver, ode_steps):
-        """ode_solver "dopri5_zuko" (:260-261, the reference's DEFAULT: zuko.utils.odeint at its atol 1e-6 / rtol 1e-5) and "dopri5"
+        """ode_solver "tsit5" (:288-292: Tsitouras 5(4) on the same controller), "dopri5_zuko" (:260-261, the reference's DEFAULT: zuko.utils.odeint at its atol 1e-6 / rtol 1e-5) and "dopri5"
         (:267-277: torchdyn at atol = rtol = 1e-4 over linspace(1, 0, ode_steps)): adaptive Dormand-Prince 5(4) around one HIP evaluation
         of the field per stage (particle_fm_amd/ode.py -- parity unpinned: neither library is in the image).  With loss_type="diffusion"
         the right-hand side is the probability-flow ODE's (:62-69)."""
-        from ..ode import dopri5
+        from ..ode import dopri5, tsit5
         B = z.shape[0]
         m = None if mask is None else mask.to(z.device, torch.float32).reshape(B, -1, 1)
 
@@ -309,12 +309,15 @@ class CNF(nn.Module):
         with torch.no_grad():
             if ode_solver == "dopri5_zuko":
                 return dopri5(f, z, 1.0, 0.0, atol=1e-6, rtol=1e-5)
-            return dopri5(f, z, 1.0, 0.0, atol=1e-4, rtol=1e-4, checkpoints=torch.linspace(1.0, 0.0, ode_steps)[1:-1].tolist())
+            grid = torch.linspace(1.0, 0.0, ode_steps)[1:-1].tolist()
+            if ode_solver == "tsit5":  # :288-292, torchdyn's default tolerances
+                return tsit5(f, z, 1.0, 0.0, checkpoints=grid)
+            return dopri5(f, z, 1.0, 0.0, atol=1e-4, rtol=1e-4, checkpoints=grid)
 
     def _decode_diffusion(self, z, cond, mask, ode_solver, ode_steps, weights):
         """loss_type="diffusion" (:62-69, 301-325): the fixed-step ODE solvers integrate -0.5 beta (x - net / noise_rate);
         "ddim" / "em" are the samplers of models/components/solver.py (n_steps = ode_steps)."""
-        if ode_solver in ("dopri5_zuko", "dopri5"):
+        if ode_solver in ("dopri5_zuko", "dopri5", "tsit5"):
             return self._decode_adaptive(z, cond, mask, ode_solver, ode_steps)
         if self.is_transformer or self.is_cross_attention or self.is_mdma or self.t_emb == "gaussian":
             return self._decode_diffusion_rows(z, cond, mask, ode_solver, ode_steps, weights)

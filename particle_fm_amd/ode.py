@@ -31,6 +31,23 @@ _A = (
 _B5 = _A[6] + (0.0,)
 _B4 = (5179 / 57600, 0.0, 7571 / 16695, 393 / 640, -92097 / 339200, 187 / 2100, 1 / 40)
 _E = tuple(b5 - b4 for b5, b4 in zip(_B5, _B4))
+DOPRI5 = (_C, _A, _B5, _E)
+
+# Tsitouras 5(4) (Ch. Tsitouras, Comput. Math. Appl. 62 (2011) 770-775), FSAL: torchdyn's "tsit5" (flow_matching_module.py:288-292).  The
+# published coefficients, held to their order conditions by tests/test_ode_cpu.py.
+_TC = (0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0)
+_TA = (
+    (),
+    (0.161,),
+    (-0.008480655492356989, 0.335480655492357),
+    (2.8971530571054935, -6.359448489975075, 4.3622954328695815),
+    (5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525),
+    (5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383),
+    (0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774),
+)
+_TE = (-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629, 0.5823571654525552,
+       -0.45808210592918697, 1 / 66)  # b - b_hat
+TSIT5 = (_TC, _TA, _TA[6] + (0.0,), _TE)
 
 
 def _rms(v: torch.Tensor) -> torch.Tensor:
@@ -38,9 +55,10 @@ def _rms(v: torch.Tensor) -> torch.Tensor:
 
 
 def dopri5(f: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], x0: torch.Tensor, t0: float, t1: float, atol: float = 1e-6,
-           rtol: float = 1e-5, checkpoints: Optional[Sequence[float]] = None, max_steps: int = 2000) -> torch.Tensor:
+           rtol: float = 1e-5, checkpoints: Optional[Sequence[float]] = None, max_steps: int = 2000, tableau=DOPRI5) -> torch.Tensor:
     """x(t1) from x(t0) = x0.  f(t, x): t a 0-dim float32 device tensor.  checkpoints: times the integrator lands on exactly on its way
-    (torchdyn's adaptive odeint does with its t_span); the state at t1 is returned either way."""
+    (torchdyn's adaptive odeint does with its t_span); the state at t1 is returned either way.  tableau: a 7-stage FSAL 5(4) pair."""
+    _C, _A, _B5, _E = tableau
     dev = x0.device
     sign = 1.0 if t1 >= t0 else -1.0
     stops = [float(c) for c in (checkpoints or []) if (c - t0) * sign > 0 and (t1 - c) * sign > 0] + [float(t1)]
@@ -75,3 +93,9 @@ def dopri5(f: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], x0: torch.Te
                 t, x, k1 = t + hh, x_new, ks[6]
             h = abs(hh) * min(10.0, max(0.2, 0.9 * (ratio if ratio > 1e-10 else 1e-10) ** -0.2))
     return x
+
+
+def tsit5(f, x0, t0, t1, atol: float = 1e-3, rtol: float = 1e-3, checkpoints=None, max_steps: int = 2000) -> torch.Tensor:
+    """The same controller around Tsitouras' 5(4) pair: ``ode_solver="tsit5"`` (flow_matching_module.py:288-292: torchdyn's NeuralODE with
+    its own default tolerances -- [recalled] atol = rtol = 1e-3 in torchdyn 1.0; unpinned like everything at that boundary)."""
+    return dopri5(f, x0, t0, t1, atol=atol, rtol=rtol, checkpoints=checkpoints, max_steps=max_steps, tableau=TSIT5)

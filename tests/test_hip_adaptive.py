@@ -1,5 +1,5 @@
-"""ode_solver="dopri5_zuko" (the reference's DEFAULT, flow_matching_module.py:250, 260-261) and "dopri5" (:267-277): adaptive
-Dormand-Prince 5(4) around HIP evaluations of the field (particle_fm_amd/ode.py).  PARITY UNPINNED -- neither zuko nor torchdyn is in
+"""ode_solver="dopri5_zuko" (the reference's DEFAULT, flow_matching_module.py:250, 260-261), "dopri5" (:267-277) and "tsit5" (:288-292):
+adaptive Dormand-Prince / Tsitouras 5(4) around HIP evaluations of the field (particle_fm_amd/ode.py).  PARITY UNPINNED -- neither zuko nor torchdyn is in
 the image and the reference holds no vector of these solvers -- so the bar is the ODE itself: the result agrees with a far finer
 fixed-step rk4 solution of the ORACLE's field to the solver's tolerance, on every model family and under loss_type="diffusion"."""
 import copy
@@ -70,6 +70,8 @@ def test_default_solver_reaches_the_fine_solution(family):
     torch.testing.assert_close(out[keep], want[keep], atol=2e-3, rtol=1e-2)
     out = m((z * mask).cuda(), cond=dev(cond), mask=mask.cuda(), reverse=True, ode_solver="dopri5", ode_steps=20).cpu()
     torch.testing.assert_close(out[keep], want[keep], atol=2e-2, rtol=5e-2)  # (atol = rtol = 1e-4 per step)
+    out = m((z * mask).cuda(), cond=dev(cond), mask=mask.cuda(), reverse=True, ode_solver="tsit5", ode_steps=20).cpu()
+    torch.testing.assert_close(out[keep], want[keep], atol=2e-2, rtol=5e-2)  # (Tsitouras 5(4) at 1e-3 per step; measured <= 6e-3)
 
 
 def test_default_solver_under_the_diffusion_loss():

@@ -70,7 +70,7 @@ def test_sample_matches_oracle():
                 want = rk_trajectory_end(lambda tt, xx: vf(tt, xx, None, mask), z * mask, torch.linspace(1.0, 0.0, steps), solver)
         torch.testing.assert_close(out, want, atol=2e-4, rtol=1e-3)
     with pytest.raises(NotImplementedError):
-        m.sample(B, mask=mask, ode_solver="tsit5")
+        m.sample(B, mask=mask, ode_solver="ieuler")
 
 
 def test_training_step_replays_reference_draws(mdma_golden):

@@ -56,7 +56,7 @@ def test_errors():
     with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
         m.flows[0].decode(x, None, None, ode_solver="rk4")  # has a HIP path, not a CPU one
     with pytest.raises(NotImplementedError):
-        m.flows[0].decode(x, None, None, ode_solver="tsit5")
+        m.flows[0].decode(x, None, None, ode_solver="ieuler")
     for patch in (("cae_config", "mha_config", "num_heads", 4),          # head_dim 32
                   ("cae_config", "mha_config", "do_layer_norm", False),
                   ("cae_config", "num_tokens", 9),

@@ -82,7 +82,7 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
         m.flows[0].decode(x, None, None, ode_solver="rk4")  # has a HIP path, not a CPU one
     with pytest.raises(NotImplementedError):
-        m.flows[0].decode(x, None, None, ode_solver="tsit5")
+        m.flows[0].decode(x, None, None, ode_solver="ieuler")
     with pytest.raises(NotImplementedError):
         m.flows[0].decode(x, None, None, ode_solver="bogus")
     with pytest.raises(SyntaxError):

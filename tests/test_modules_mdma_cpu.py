@@ -51,7 +51,7 @@ def test_errors():
     with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
         m.flows[0].decode(x, None, torch.ones(2, 30, 1), ode_solver="rk4")  # has a HIP path, not a CPU one
     with pytest.raises(NotImplementedError):
-        m.flows[0].decode(x, None, None, ode_solver="tsit5")
+        m.flows[0].decode(x, None, None, ode_solver="ieuler")
     with pytest.raises(RuntimeError, match="fused"):
         m.flows[0].net.encoder[0](x, None, None, None)
     for bad in (dict(global_cond_dim=2), dict(global_cat_cond=True), dict(hidden_dim=96), dict(num_heads=2), dict(latent=10)):

@@ -53,7 +53,7 @@ def test_errors():
     with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
         m.flows[0].decode(x, None, None, ode_solver="rk4")  # has a HIP path, not a CPU one
     with pytest.raises(NotImplementedError):
-        m.flows[0].decode(x, None, None, ode_solver="tsit5")
+        m.flows[0].decode(x, None, None, ode_solver="ieuler")
     for patch in (("te_config", "mha_config", "num_heads", 4),          # head_dim 32
                   ("te_config", "mha_config", "do_layer_norm", False),
                   ("node_embd_config", "act_h", "relu"),
