@@ -1,13 +1,15 @@
 """Fills the @@...@@ placeholders of a DESIGN.md template from the measurement files of tests/diag/final_measure.sh.
-    python tests/diag/design_tables.py <template> <dir with the json lines> > DESIGN.md"""
+    python tests/diag/design_tables.py <template> <dir with the json lines> > DESIGN.md
+    python tests/diag/design_tables.py profiles/DESIGN_template.md profiles/round3_ > DESIGN.md     (the committed copies: a file-name prefix)"""
 import json
 import sys
 
 tmpl, d = open(sys.argv[1]).read(), sys.argv[2]
+prefix = not d.endswith("/") and d.endswith("_")  # profiles/roundN_<name> instead of <dir>/<name>
 
 
 def line(name):
-    return json.loads(open(f"{d}/{name}.json").read().strip().splitlines()[-1])
+    return json.loads(open(f"{d}{name}.json" if prefix else f"{d}/{name}.json").read().strip().splitlines()[-1])
 
 
 b50, b20, b1k, o1 = line("bench_line"), line("bench_line_steps20"), line("bench_line_batch1024"), line("bench_line_overlap1")
@@ -30,7 +32,7 @@ rows = [
 tmpl = tmpl.replace("@@HEADLINE_TABLE@@", "\n".join(rows))
 tmpl = tmpl.replace("@@MS20@@", f"{b20['ms_per_step']:.2f}")
 tmpl = tmpl.replace("@@BUSY_WALL@@", f"{33.70e9 / (1024 * b20['ms_per_step'] * 1e-3 * 2.29e9):.2f}")
-sec = [json.loads(l) for l in open(f"{d}/secondary_lines.jsonl") if l.strip().startswith("{")]
+sec = [json.loads(l) for l in open(f"{d}secondary_bench_lines.jsonl" if prefix else f"{d}/secondary_lines.jsonl") if l.strip().startswith("{")]
 prev = {("cfg 2", "f32"): ("21.6 k", "34.5 k"), ("cfg 2", "bf16"): ("27.6 k", "51.9 k"), ("cfg 4", "f32"): ("633", "720"),
         ("cfg 5", "f32"): ("463", "560"), ("SURVEY", "f32"): ("706", "901")}
 rows = ["| BASELINE config | round 1 | round 2 | **round 3** | CPU oracle | `roofline.frac` (executed) |", "|---|---|---|---|---|---|"]
