@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _fine(vf, z, cond, mask, steps=240):
+def _fine(vf, z, cond, mask, steps=160):
     from oracle.fm_ref import sample_fixed_step
     return sample_fixed_step(vf, z, cond, mask, ode_steps=steps, solver="rk4")
 
@@ -60,11 +60,11 @@ def _mdma():
 def test_default_solver_reaches_the_fine_solution(family):
     g, m, vf = {"epic": _epic, "epicw": _epicw, "tf": _tf, "mdma": _mdma}[family]()
     tag = "midpoint_10/"
-    z, mask, cond = (g.get(tag + k) for k in ("z", "mask", "cond"))
+    z, mask, cond = (None if g.get(tag + k) is None else g.get(tag + k)[:2] for k in ("z", "mask", "cond"))  # (two jets: the CPU oracle sets the run time)
     dev = lambda a: None if a is None else a.cuda()
     want = _fine(vf, z, cond, mask)
     keep = mask.squeeze(-1) != 0
-    assert (want - _fine(vf, z, cond, mask, steps=120))[keep].abs().max() < 5e-4  # the yardstick itself has converged
+    assert (want - _fine(vf, z, cond, mask, steps=80))[keep].abs().max() < 5e-4  # the yardstick itself has converged
     out = m((z * mask).cuda(), cond=dev(cond), mask=mask.cuda(), reverse=True).cpu()  # forward(reverse=True)'s default: "dopri5_zuko"
     # local tolerances atol 1e-6 / rtol 1e-5 per step; the global error after the ~100 accepted steps is a few hundred times that
     torch.testing.assert_close(out[keep], want[keep], atol=2e-3, rtol=1e-2)
