@@ -919,6 +919,11 @@ __global__ __launch_bounds__(LT, 3) void tf_mlp_panel_kernel(MlpArgs m) {
 
     int n1 = NI1, n2 = NI2;
     asm volatile("" : "+s"(n1), "+s"(n2));  // the step loops stay loops
+    // Residual rows are requested BEFORE the MFMA loop whose epilogue adds them (every workgroup of a launch starts at once and walks the same
+    // phases: a load issued in an epilogue is a round trip to L2 / HBM with the matrix pipes of the whole CU idle), and the rows stage 0 makes
+    // stay in registers for stage 2's residual instead of being read back (same thread, same values): cross-attention 894 -> 912 jets/s.
+    f32x4 resv[NS][TPW];
+    bool mid_kept = false;
     if constexpr (PRE) {
         // ---- stage 0: mid = R0 + W0 LN0(A0) + b0 (NI1 columns = one chunk), to l0.out and, raw, into the H region ----------------------------
         const LinArgs& z = m.l0;
@@ -928,6 +933,13 @@ __global__ __launch_bounds__(LT, 3) void tf_mlp_panel_kernel(MlpArgs m) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
                 acc[s][t] = z.b >= 0 ? *reinterpret_cast<const f32x4*>(a.blob + z.b + ob + 16 * s + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (z.R) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    resv[s][t] = *reinterpret_cast<const f32x4*>(z.R + (int64_t)min(row0 + 16 * t + pl, a.M - 1) * z.ldr + ob + 16 * s + 4 * q);
+        }
 #pragma unroll 1
         for (int step = 0; step < n1; step += 2) {
             request(afB, z.W, NI1, 0, step + 1);
@@ -943,8 +955,9 @@ __global__ __launch_bounds__(LT, 3) void tf_mlp_panel_kernel(MlpArgs m) {
             for (int t = 0; t < TPW; ++t) {
                 const int r = 16 * t + pl, row = min(row0 + r, a.M - 1);
                 f32x4 v = acc[s][t];
-                if (z.R) v += *reinterpret_cast<const f32x4*>(z.R + (int64_t)row * z.ldr + o);
+                if (z.R) v += resv[s][t];
                 if (row0 + r < a.M) *reinterpret_cast<f32x4*>(z.out + (int64_t)row * z.ldo + o) = v;
+                resv[s][t] = v;
                 *reinterpret_cast<f32x4*>(H + (o >> 6) * (RB * 64) + r * 64 + ((((o & 63) >> 2) ^ (r & 15)) << 2)) = v;
             }
         }
@@ -952,6 +965,7 @@ __global__ __launch_bounds__(LT, 3) void tf_mlp_panel_kernel(MlpArgs m) {
         normalise([&](int r, int i) { return *reinterpret_cast<const f32x4*>(H + i * (RB * 64) + r * 64 + ((pl ^ (r & 15)) << 2)); }, X,
                   std::integral_constant<int, NI1>{}, a.gamma, a.beta, a.eps);
         __syncthreads();
+        mid_kept = b.R == z.out && b.ldr == z.ldo && b.NO == BN;  // (one output chunk: stage 2's (s, t) are stage 0's)
     }
     // ---- stage 1: hidden = lrelu(W1 LN1(mid) + jet bias), into H ------------------------------------------------------------------------
     const int nc1 = a.NO / BN;
@@ -1012,6 +1026,13 @@ __global__ __launch_bounds__(LT, 3) void tf_mlp_panel_kernel(MlpArgs m) {
             for (int t = 0; t < TPW; ++t)
                 acc[s][t] = b.b >= 0 ? *reinterpret_cast<const f32x4*>(a.blob + b.b + o) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if (b.R && !mid_kept) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    resv[s][t] = *reinterpret_cast<const f32x4*>(b.R + (int64_t)min(row0 + 16 * t + pl, a.M - 1) * b.ldr + ob + 16 * s + 4 * q);
+        }
 #pragma unroll 1
         for (int step = 0; step < n2; step += 2) {
             request(afB, b.W, NI2, c, step + 1);
@@ -1028,7 +1049,7 @@ __global__ __launch_bounds__(LT, 3) void tf_mlp_panel_kernel(MlpArgs m) {
                 const int row = row0 + 16 * t + pl;
                 if (row >= a.M) continue;
                 f32x4 v = acc[s][t];
-                if (b.R) v += *reinterpret_cast<const f32x4*>(b.R + (int64_t)row * b.ldr + o);
+                if (b.R) v += resv[s][t];
                 *reinterpret_cast<f32x4*>(b.out + (int64_t)row * b.ldo + o) = v;
             }
         }
