@@ -315,13 +315,20 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    if rehearsal and world > 1:  # data-parallel invariant: identical replicas after K synchronised steps (bitwise)
+
+    def check_replicas(where):
+        """data-parallel invariant (rehearsal only): identical replicas after synchronised steps (bitwise)"""
+        if not (rehearsal and world > 1):
+            return
+        torch.cuda.synchronize(dev)
         flat = trainer.fp.flat.detach()
         lo, hi = flat.clone(), flat.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         if not torch.equal(lo, hi):
-            raise SystemExit(f"rank {rank}: parameter replicas diverged (max spread {float((hi - lo).abs().max()):.3e})")
+            raise SystemExit(f"rank {rank}: parameter replicas diverged {where} (max spread {float((hi - lo).abs().max()):.3e})")
+
+    check_replicas("after the timed region")
     train_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     sample_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / args.steps  # on the stream the sampler was launched on
     assert torch.isfinite(out).all()
@@ -354,23 +361,26 @@ def main():
         t1e.record(main)
     torch.cuda.synchronize(dev)
     train_alone_ms = t0e.elapsed_time(t1e) / TRAIN_ALONE_REPS
-    # N > 1: the same with ONE flat all-reduce behind the whole backward (the default splits the backward and overlaps the first
-    # bucket's all-reduce with the dW GEMM: engine.FusedFMTrainer.fused_loss_and_grad) -- the comparison SURVEY 5.8 asks for
-    train_alone_flat_ms = None
+    # N > 1: the train step alone under BOTH gradient exchanges -- one flat all-reduce behind the whole backward (the default) and
+    # the two-bucket exchange whose first all-reduce runs next to the dW GEMM (PFM_DP_OVERLAP=1, engine.FusedFMTrainer
+    # .fused_loss_and_grad) -- so that a SCALE record separates overlap gain from collective cost (the comparison SURVEY 5.8 asks for)
+    train_alone_modes = {}
     if world > 1:
-        with stage("train step with the flat all-reduce", 300):
-            keep = trainer.split_backward
-            trainer.split_backward = False
-            with torch.cuda.stream(main):
-                for _ in range(3):
-                    trainer.step((x, mask, cond))
-                t0e.record(main)
-                for _ in range(TRAIN_ALONE_REPS):
-                    trainer.step((x, mask, cond))
-                t1e.record(main)
-            torch.cuda.synchronize(dev)
-            train_alone_flat_ms = t0e.elapsed_time(t1e) / TRAIN_ALONE_REPS
-            trainer.split_backward = keep
+        keep = trainer.split_backward
+        for mode, split in (("flat_allreduce", False), ("bucketed_overlap", True)):
+            with stage(f"train step alone, gradient exchange: {mode}", 300):
+                trainer.split_backward = split
+                with torch.cuda.stream(main):
+                    for _ in range(3):
+                        trainer.step((x, mask, cond))
+                    t0e.record(main)
+                    for _ in range(TRAIN_ALONE_REPS):
+                        trainer.step((x, mask, cond))
+                    t1e.record(main)
+                torch.cuda.synchronize(dev)
+                train_alone_modes[mode] = t0e.elapsed_time(t1e) / TRAIN_ALONE_REPS
+            check_replicas(f"after {3 + TRAIN_ALONE_REPS} steps with the {mode} exchange")
+        trainer.split_backward = keep
     # the gradient exchange alone (N > 1): the flat 2.2 MB all-reduce on the train stream, 10 in a row
     allreduce_alone_ms = 0.0
     if world > 1:
@@ -445,11 +455,13 @@ def main():
             },
             "train_ms": train_ms, "sample_ms": sample_ms, "train_ms_alone": train_alone_ms, "allreduce_ms_alone": allreduce_alone_ms,
             "grad_exchange": None if world == 1 else {
-                "mode": "two buckets (RCCL all-reduce, SUM then x 1/world in the optimiser kernel): the gradients the backward's chain "
-                        "phase finishes (51 % of the parameters) are reduced next to the dW GEMM of the rest; PFM_DP_OVERLAP=0 = one flat "
-                        "all-reduce behind the whole backward",
-                "overlapped": bool(trainer.sync.enabled if trainer.split_backward is None else trainer.split_backward),
-                "train_ms_alone_flat_allreduce": train_alone_flat_ms},
+                "mode": "timed region: " + ("two buckets, the first all-reduce next to the dW GEMM (PFM_DP_OVERLAP=1)" if trainer.split_backward
+                                            else "one flat RCCL all-reduce (SUM, then x 1/world in the optimiser kernel) behind the whole "
+                                                 "backward (default; PFM_DP_OVERLAP=1 = two buckets, the gradients the backward's chain phase "
+                                                 "finishes -- 51 % of the parameters -- reduced next to the dW GEMM of the rest)"),
+                "overlapped": bool(trainer.split_backward),
+                "train_ms_alone_flat_allreduce": train_alone_modes.get("flat_allreduce"),
+                "train_ms_alone_bucketed_overlap": train_alone_modes.get("bucketed_overlap")},
             "per_rank": {"train_ms_alone": [float(v) for v in per_rank[:, 0]], "allreduce_ms_alone": [float(v) for v in per_rank[:, 1]],
                          "train_ms_in_timed_region": [float(v) for v in per_rank[:, 2]],
                          "sample_ms_in_timed_region": [float(v) for v in per_rank[:, 3]],

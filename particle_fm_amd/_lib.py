@@ -14,8 +14,18 @@ from .layout_tf import TfDesc
 from .layout_wide import EwDesc
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# PFM_LIB_PATH: diagnostics only (tests/diag A/B timing of library variants); the product loads the in-tree build
-LIB_PATH = os.environ.get("PFM_LIB_PATH") or os.path.join(_PKG, "libpfm_hip.so")
+IN_TREE_LIB = os.path.join(_PKG, "libpfm_hip.so")
+# PFM_LIB_PATH: diagnostics only (tests/diag A/B timing of library variants), and only together with PFM_DIAG=1 -- a variable left
+# over from an A/B session must not swap the library under the tests or bench.py.  The product loads the in-tree build.
+LIB_PATH = IN_TREE_LIB
+if os.environ.get("PFM_LIB_PATH"):
+    if os.environ.get("PFM_DIAG") == "1":
+        LIB_PATH = os.environ["PFM_LIB_PATH"]
+        import sys
+        print(f"[particle_fm_amd] PFM_DIAG=1: loading {LIB_PATH} instead of the in-tree library", file=sys.stderr)
+    else:
+        import warnings
+        warnings.warn("PFM_LIB_PATH is set but PFM_DIAG != 1: ignored, the in-tree libpfm_hip.so is used")
 
 _lib = None
 

@@ -202,11 +202,12 @@ class FusedFMTrainer:
         self._t_next = 0
         self._fin_next = 0
         self._fused = None
-        # None: split the backward (and overlap the first half's all-reduce with the dW GEMM) whenever gradients are exchanged;
-        # True / False force it (True without a process group: the same two-phase launches, nothing to exchange -- for tests;
-        # PFM_DP_OVERLAP=0 / 1 in the environment sets the default: 0 = one flat all-reduce behind the whole backward)
+        # False (default): ONE flat all-reduce behind the whole backward -- the exchange that has run on RCCL.  True (opt-in,
+        # PFM_DP_OVERLAP=1): split the backward and overlap the first bucket's all-reduce with the dW GEMM (DDP's bucketed overlap);
+        # bit-identical by tests/test_hip_trainer_split.py and the gloo world-2 tests, but no N > 1 RCCL record exists for it yet, so
+        # it is not the default (True without a process group: the same two-phase launches, nothing to exchange -- for tests).
         import os
-        self.split_backward: Optional[bool] = {"0": False, "1": True}.get(os.environ.get("PFM_DP_OVERLAP", ""), None)
+        self.split_backward: bool = os.environ.get("PFM_DP_OVERLAP", "0") == "1"
         self._grad_synced = False
         if fusable:
             self._fused = {}
@@ -310,7 +311,7 @@ class FusedFMTrainer:
         ring = st.get("fin")
         if ring is None:
             ring = st["fin"] = torch.empty(16, 2, device=x.device, dtype=torch.float32)  # [loss, 1 / sum(mask)] of the last 16 steps
-        fin = ring[self._fin_next % 16]  # the returned loss is a view into the ring: valid until 16 more steps have been queued
+        fin = ring[self._fin_next % 16]  # the backward reads 1 / sum(mask) from here; the caller gets a COPY of the loss (below)
         self._fin_next += 1
         if kind == "diffusion":
             from .fm_loss import MLE_LOSS_WEIGHT
@@ -329,14 +330,15 @@ class FusedFMTrainer:
             parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x, t, z, cond, maskf, loss_mod.sigma, kind, eps)
             _lib.check(lib.pfm_loss_finish(P(parts), P(count), P(None), B, P(fin), S), "pfm_loss_finish")
             bw_kw = {}
-        loss = fin[0]
+        # a copy, not the ring view: a caller may keep per-step losses for an epoch mean (one 4-byte launch against a 0.6 ms step)
+        loss = fin[0].clone()
         unpack = lib.pfm_wn_unpack_grad_set if tb.covers_all else lib.pfm_wn_unpack_grad
 
         def unpack_rows(r0, r1, b0, b1):
             _lib.check(unpack(P(self.fp.flat), P(gblob), P(tb.rows[r0:r1]), r1 - r0, P(tb.gsrc), P(tb.bias_gblob[b0:b1]),
                               P(tb.bias_param[b0:b1]), b1 - b0, P(self.fp.grad), S), "pfm_wn_unpack_grad")
 
-        split = self.sync.enabled if self.split_backward is None else self.split_backward
+        split = bool(self.split_backward)
         nf = self.fp.n_first
         if split and tb.covers_all and 0 < nf < self.fp.numel and B <= hip_ops.BWD_CHUNK_JETS:
             # DDP's overlap of the gradient exchange with the backward (configs/trainer/ddp.yaml:4-9), two buckets: the chain phase

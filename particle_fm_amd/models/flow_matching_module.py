@@ -298,8 +298,15 @@ class CNF(nn.Module):
         B = z.shape[0]
         m = None if mask is None else mask.to(z.device, torch.float32).reshape(B, -1, 1)
 
+        # the kernel blob once per call, not once per stage (packed_weights re-runs the weight-norm pack: ~100 torch launches without
+        # a FusedFMTrainer attached); the gaussian embedding's own network still runs per stage inside self.forward
+        blob = None if self.t_emb == "gaussian" else self.net.packed_weights(z.shape[1])
+
         def f(t, x):
-            v = self.forward(t.reshape(1).expand(B), x, cond, mask)
+            if blob is None:
+                v = self.forward(t.reshape(1).expand(B), x, cond, mask)
+            else:
+                v = self.net.vector_field(self._per_jet_time(t.reshape(1).expand(B), x), x, cond, mask, blob=blob)
             if self.loss_type == "diffusion":
                 _, nr, beta = hip_ops.diffusion_schedule(t.reshape(1), **dict(self.diff_config))
                 v = (-0.5 * beta) * (x - v / nr)

@@ -59,6 +59,11 @@ def test_two_rank_launch_rehearsal():
     pr = d["per_rank"]
     assert len(pr["train_ms_alone"]) == 2 and len(pr["allreduce_ms_alone"]) == 2 and all(v > 0 for v in pr["allreduce_ms_alone"])
     assert "rendezvous" in res.stderr and "first all-reduce" in res.stderr and "first step done" in res.stderr
+    # both gradient exchanges ran (23 synchronised steps each, replicas compared bitwise after each: bench.check_replicas): the
+    # flat all-reduce (default) and the two-bucket exchange whose async work handles are waited for behind the queued dW GEMM
+    ge = d["grad_exchange"]
+    assert ge["overlapped"] is False and ge["train_ms_alone_flat_allreduce"] > 0 and ge["train_ms_alone_bucketed_overlap"] > 0
+    assert "bucketed_overlap" in res.stderr and "flat_allreduce" in res.stderr
 
 
 def test_a_stage_that_hangs_ends_the_process_with_a_non_zero_code():

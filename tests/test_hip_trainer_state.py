@@ -107,3 +107,19 @@ def test_lr_schedule_is_applied():
     torch.manual_seed(2); torch.cuda.manual_seed_all(2)
     tr2.step(batch)
     assert torch.equal(tr1.fp.flat, tr2.fp.flat)
+
+
+def test_a_loss_kept_across_many_steps_keeps_its_value():
+    """step() hands out a COPY of the loss scalar, not a view into the trainer's 16-slot ring of [loss, 1 / sum(mask)] pairs: a
+    caller that collects per-step losses for an epoch mean (more than 16 steps later) still reads each step's own number."""
+    batch = _batch()
+    m, tr = _make()
+    kept, now = [], []
+    for _ in range(40):
+        l = tr.step(batch)
+        kept.append(l)
+        now.append(float(l))
+    later = [float(l) for l in kept]
+    assert later == now
+    assert len(set(now)) > 30  # the loss does move from step to step (fresh t, z draws and updated weights)
+    assert abs(float(torch.stack(kept).mean()) - sum(now) / len(now)) < 1e-5
