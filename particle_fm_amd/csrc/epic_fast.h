@@ -179,7 +179,7 @@ __device__ __forceinline__ void fast_chain_stem(const JetDims& j, float* __restr
         p[s] = reduce_pt(p[s]);
         if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].vin2 + TC + 4 * og) = lrelu4(p[s] + bg1, j.slope);
     }
-    __syncthreads();
+    wave_lds_sync();  // fc_g2 below reads the 16 values of g1 THIS wave has just written (rows 16 w .. 16 w + 15): no workgroup barrier
     const f32x4 bg2 = *reinterpret_cast<const f32x4*>(tbl + TBL_G2 + 4 * o4);  // before the next chain's rows replace these
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
@@ -232,7 +232,9 @@ __device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __rest
         p[s] = reduce_pt(p[s]);
         if (pt == 0) *reinterpret_cast<f32x4*>(lds + sv[s].vin2 + TC + 4 * og) = lrelu4(p[s] + bg1, j.slope);
     }
-    __syncthreads();
+    // fc_global2's rows are split over the waves exactly as fc_global1's outputs are: wave w multiplies g1[16 w .. 16 w + 15], the
+    // values its own lanes have just written.  LDS operations of one wave execute in order: no workgroup barrier here (round 4).
+    wave_lds_sync();
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         f32x4 gp = L.w2 * lds[sv[s].vin2 + TC + 16 * w + pt];

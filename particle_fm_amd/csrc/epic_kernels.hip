@@ -169,7 +169,10 @@ static __device__ __forceinline__ Segs epic_pair_setup(const pfm_epic_desc& d, c
     sg.n1 = (int)lB + 1;
     sg.r1 = (sg.n0 + TILE - 1) / TILE * TILE;
     sg.rows = sg.r1 + sg.n1;
-    if (tid == 0) { lds[v0.misc] = sA; lds[v0.misc + 1] = lA; lds[v1.misc] = sB; }
+    if (tid == 0) {
+        lds[v0.misc] = sA; lds[v0.misc + 1] = lA; lds[v1.misc] = sB;
+        lds[v0.misc + 2] = 1.0f / sA; lds[v1.misc + 2] = 1.0f / sB;  // pool_finish's reciprocals
+    }
     const int F = j.F;
     const float* zA = z + (size_t)jetA * j.N * F;
     const float* zB = z + (size_t)jetB * j.N * F;
@@ -392,7 +395,10 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_quad_kernel(
         lds[c.maskf + tid] = m;
         float cnt = m;
         for (int sh = 16; sh >= 1; sh >>= 1) cnt += __shfl_xor(cnt, sh);  // over the jet's 32 lanes
-        if (p == 0) lds[quad_view(c, s).misc] = cnt;
+        if (p == 0) {
+            lds[quad_view(c, s).misc] = cnt;
+            lds[quad_view(c, s).misc + 2] = 1.0f / cnt;  // pool_finish's reciprocal
+        }
     }
     for (int i = tid; i < QUAD_TILE_ROWS * F; i += NT) {
         const int r = i / F, f = i - r * F, s = r >> 5, p = r & 31;

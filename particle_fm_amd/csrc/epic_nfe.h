@@ -238,6 +238,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
     const int pl = lane & 15, q = lane >> 4;
     const int oslot = 4 * w + q;  // 16-byte slot of this lane's 4 output features
     const float slope = j.slope;
+    const f32x2 slope2 = {slope, slope};  // wave-uniform: an SGPR pair
     const f32x4 bias = *reinterpret_cast<const f32x4*>(bj + 4 * oslot);
     f32x4 biasB = bias, psumB = {0.f, 0.f, 0.f, 0.f};
     if (NSEG == 2) biasB = *reinterpret_cast<const f32x4*>(s2.bj + 4 * oslot);
@@ -302,8 +303,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
     }
     // epilogue of an INTERIOR pair: all 32 rows are < n_rows, no predication at all
     auto epilogue_full = [&](f32x4 e0, f32x4 e1, int pair, f32x4& ps) {  // ps: the pool sum this pair adds to
-        e0 = lrelu4(e0, slope);
-        e1 = lrelu4(e1, slope);
+        lrelu8_pk(e0, e1, slope2);  // packed, no canonicalising copies: pfm_common.h
         float* d0 = dst + pair * 2 * TILE * H + ooff;
         *reinterpret_cast<f32x4*>(d0) = e0;
         *reinterpret_cast<f32x4*>(d0 + TILE * H) = e1;
@@ -322,8 +322,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
                 ps += e0 * (mp[0] - q0);
                 ps += e1 * (mp[TILE] - q1);
             } else {
-                ps += e0 * mp[0];
-                ps += e1 * mp[TILE];
+                pool2_pk(ps, e0, e1, mp[0], mp[TILE]);  // ps = fma(e1, m1, fma(e0, m0, ps)): the same two FMAs per element
             }
         }
     };
@@ -331,8 +330,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
     auto epilogue = [&](f32x4 e0, f32x4 e1, int pair) {
         const int p0 = pair * 2 * TILE + pl, p1 = p0 + TILE;
         const bool v0 = p0 < n_rows, v1 = p1 < n_rows;
-        e0 = lrelu4(e0, slope);
-        e1 = lrelu4(e1, slope);
+        lrelu8_pk(e0, e1, slope2);
         float* d0 = v0 ? dst + pair * 2 * TILE * H + ooff : sink;
         float* d1 = v1 ? dst + (pair * 2 + 1) * TILE * H + ooff : sink;
         *reinterpret_cast<f32x4*>(d0) = e0;
@@ -814,10 +812,23 @@ __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float*
                                             int oslot, int pl, float* __restrict__ save_pool) {
     psum = row_sum16(psum);
     if (pl == 0) {
-        const float nvalid = lds[misc_off];
+        const float nvalid = lds[misc_off], rinv = lds[misc_off + 2];
         const int TC = j.T + j.C;
+        // mean = sum / n_valid (epic.py:161/:370), correctly rounded like the reference's division, without the 12-instruction
+        // v_div_scale / v_div_fmas / v_div_fixup sequence per element: q = RN(a r) with r = RN(1 / n), one residual step
+        // q' = RN(q + r RN(a - n q)) (Markstein: q' is the correctly rounded quotient when r is the correctly rounded reciprocal;
+        // checked exhaustively over n = 1 .. 160 on 3.2 M random numerators, tests/test_x3_emulation_cpu.py::test_markstein_quotient).
+        // n = 0 (no valid particle): r = inf, a = 0 -> NaN, as the reference's 0 / 0.
         f32x4 mean;
-        mean.x = psum.x / nvalid; mean.y = psum.y / nvalid; mean.z = psum.z / nvalid; mean.w = psum.w / nvalid;  // epic.py:161/:370
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#ifdef PFM_AB_OLD_DIV  // (diagnostic A/B builds only)
+            mean[i] = psum[i] / nvalid;
+            continue;
+#endif
+            const float q = __fmul_rn(psum[i], rinv);
+            mean[i] = __builtin_fmaf(__builtin_fmaf(-q, nvalid, psum[i]), rinv, q);
+        }
         *reinterpret_cast<f32x4*>(lds + vin_off + TC + 4 * oslot) = mean;
         *reinterpret_cast<f32x4*>(lds + vin_off + TC + H + 4 * oslot) = psum * j.sscale;  // epic.py:162/:371
         if (SAVE) *reinterpret_cast<f32x4*>(save_pool + 4 * oslot) = psum;
@@ -1086,6 +1097,7 @@ __device__ __forceinline__ int epic_jet_setup(const pfm_epic_desc& d, const JetD
         for (int i = 0; i < NW; ++i) { s += red[i]; l = fmaxf(l, red[8 + i]); }
         lds[c.misc] = s;
         lds[c.misc + 1] = l;
+        lds[c.misc + 2] = 1.0f / s;  // correctly rounded reciprocal of the valid count, for pool_finish's quotient
     }
     __syncthreads();
     int n_rows = j.N;

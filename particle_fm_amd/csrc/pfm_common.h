@@ -132,6 +132,14 @@ __device__ __forceinline__ int launder(int v) {
     return v;
 }
 
+// LDS hand-over between lanes of ONE wave (a value written by some lanes, read by others of the same wave): the LDS unit executes a
+// wave's operations in issue order, so all that is needed is that the compiler keeps the write in front of the read.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- DPP row reductions: sum over the 16 lanes of a DPP row with four v_add_f32_dpp (no LDS, no address math)
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
@@ -235,7 +243,68 @@ __device__ __forceinline__ int lds_off(int p, int slot) { return p * H + ((slot 
 __device__ __forceinline__ float lrelu(float x, float slope) { return fmaxf(x, x * slope); }
 
 __device__ __forceinline__ f32x4 lrelu4(f32x4 v, float s) {
-    return __builtin_elementwise_max(v, v * s);  // two v_pk_mul_f32 + four v_max_f32
+    return __builtin_elementwise_max(v, v * s);  // two v_pk_mul_f32 + four v_max_f32 (+ four canonicalising v_max_f32 v, v, v)
+}
+
+// ---- packed-fp32 epilogue of the MFMA particle phases, as inline asm ------------------------------------------------------
+// Why asm.  VALU work does not co-issue with v_mfma_f32_16x16x4_f32 (tests/diag/mfma_coissue.hip: the times add), so every VALU
+// instruction of a pair body is matrix-pipe time -- and hipcc emits twice as many as the arithmetic needs (tests/diag/isa_mix.py on
+// the round-3 build: 25 - 63 VALU instructions per 64 MFMAs):
+//   * llvm.maxnum quiets signalling NaNs, and an MFMA result is not known to be canonical: every max(x, s x) comes with a
+//     `v_max_f32 x, x, x` in front (8 per tile pair);
+//   * the pre-emit peephole UNPACKS v_pk_mul / v_pk_add / v_pk_fma_f32 that sit in the shadow of an MFMA into two VOP3 instructions
+//     each ("so that they may co-issue with the matrix pipe": true for the XDL shapes, not for the fp32 one).
+// The hazards the compiler cannot see through an asm statement are handled by construction:
+//   * MFMA write -> VALU read of the accumulators needs 10 wait states for the 8-pass v_mfma_f32_16x16x4_f32 (7 for the 4-pass XDL
+//     shapes): lrelu8_pk starts with `s_nop 11` and multiplies all eight inputs in ONE statement, every later statement consumes its
+//     outputs (in-order issue: whatever follows a dependent instruction is past the window too);
+//   * nothing here feeds an MFMA operand: results go to LDS / global stores and to VALU sums.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vmax_raw(float a, float b) {  // v_max_f32 without the canonicalising copy (inputs: VALU results)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// e0, e1 <- max(e, s e) of two accumulator tiles fresh from the matrix pipe; s2 = (s, s) in an SGPR pair.  4 v_pk_mul + 8 v_max.
+__device__ __forceinline__ void lrelu8_pk(f32x4& e0, f32x4& e1, f32x2 s2) {
+#ifdef PFM_AB_OLD_LRELU  // (diagnostic A/B builds only)
+    e0 = lrelu4(e0, s2.x); e1 = lrelu4(e1, s2.x);
+    return;
+#endif
+    f32x2 m0, m1, m2, m3;
+    const f32x2 a0 = {e0.x, e0.y}, a1 = {e0.z, e0.w}, a2 = {e1.x, e1.y}, a3 = {e1.z, e1.w};
+    asm("s_nop 11\n\t"
+        "v_pk_mul_f32 %0, %4, %8\n\t"
+        "v_pk_mul_f32 %1, %5, %8\n\t"
+        "v_pk_mul_f32 %2, %6, %8\n\t"
+        "v_pk_mul_f32 %3, %7, %8"
+        : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(s2));
+    e0 = f32x4{vmax_raw(a0.x, m0.x), vmax_raw(a0.y, m0.y), vmax_raw(a1.x, m1.x), vmax_raw(a1.y, m1.y)};
+    e1 = f32x4{vmax_raw(a2.x, m2.x), vmax_raw(a2.y, m2.y), vmax_raw(a3.x, m3.x), vmax_raw(a3.y, m3.y)};
+}
+// ps += e0 * m0 + e1 * m1 (masked pool sum of two tiles; e0 / e1: outputs of lrelu8_pk): four v_pk_fma_f32.  Each mask value sits in
+// the LOW half of a register pair of its own and is broadcast by op_sel_hi:[1,0,1], the form hipcc itself emits (the high halves are
+// never read: left undefined, no copy).  NOT one pair (m0, m1) with the high half selected by op_sel:[0,1,0] op_sel_hi:[1,1,1]: that form
+// passes in isolation (tests/diag/pk_opsel.hip) and gave run-to-run different pool sums inside the quad kernel (tests/diag/ab_quad.py;
+// explicit (m, m) pairs or this form: bit-identical to the compiler's code) -- cause not found, form avoided.
+__device__ __forceinline__ void pool2_pk(f32x4& ps, const f32x4& e0, const f32x4& e1, float m0, float m1) {
+#ifdef PFM_AB_OLD_POOL  // (diagnostic A/B builds only)
+    ps += e0 * m0; ps += e1 * m1;
+    return;
+#endif
+    f32x2 lo = {ps.x, ps.y}, hi = {ps.z, ps.w};
+    const f32x2 a0 = {e0.x, e0.y}, a1 = {e0.z, e0.w}, a2 = {e1.x, e1.y}, a3 = {e1.z, e1.w};
+    f32x2 p0, p1;  // .y deliberately not set
+    p0.x = m0;
+    p1.x = m1;
+    asm("v_pk_fma_f32 %0, %2, %6, %0 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %3, %6, %1 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %4, %7, %0 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %5, %7, %1 op_sel_hi:[1,0,1]"
+        : "+v"(lo), "+v"(hi)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(p0), "v"(p1));
+    ps = f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 
 }  // namespace pfm

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 if len(sys.argv) == 3:
     outs = []
     for lib in sys.argv[1:3]:
-        env = dict(os.environ, PFM_LIB_PATH=lib, PFM_AB_OUT=f"/tmp/ab_bwd_{len(outs)}.npz")
+        env = dict(os.environ, PFM_LIB_PATH=lib, PFM_DIAG="1", PFM_AB_OUT=f"/tmp/ab_bwd_{len(outs)}.npz")
         outs.append(subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True))
         if outs[-1].returncode:
             print(outs[-1].stdout, outs[-1].stderr)

@@ -9,7 +9,7 @@ import numpy as np
 if sys.argv[1] != "child":
     n = sys.argv[3]
     for i, lib in enumerate(sys.argv[1:3]):
-        env = dict(os.environ, PFM_LIB_PATH=lib)
+        env = dict(os.environ, PFM_LIB_PATH=lib, PFM_DIAG="1")
         r = subprocess.run([sys.executable, __file__, "child", n, f"/tmp/abdump{i}.npy"], env=env, capture_output=True, text=True)
         print(r.stdout[-2000:], r.stderr[-2000:])
     a, b = np.load("/tmp/abdump0.npy"), np.load("/tmp/abdump1.npy")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Diagnostic library variants of the row-matrix EPiC path (timing only): the shipped objects (build/obj; run __graft_entry__.build() first) with
-# ew_kernels.hip recompiled under $PFM_DEFS (e.g. -DPFM_EW_AB_NOCHAIN) -> tests/diag/libew_ab.so; use with PFM_LIB_PATH.  CPU container.
+# ew_kernels.hip recompiled under $PFM_DEFS (e.g. -DPFM_EW_AB_NOCHAIN) -> tests/diag/libew_ab.so; use with PFM_DIAG=1 PFM_LIB_PATH=...  CPU container.
 set -e
 R=$(cd "$(dirname "$0")/../.." && pwd)
 O=$R/build/obj

@@ -1,5 +1,5 @@
 """Diagnostic: where workgroup 0 of the backward chain kernel spends its cycles (s_memtime stamps; library built in the CPU container by
-tests/diag/build_bwd_stamps.sh: epic_train.hip under -DPFM_BDIAG).   PFM_LIB_PATH=tests/diag/libtr_stamps.so python tests/diag/bwd_stamps.py [n_particles]"""
+tests/diag/build_bwd_stamps.sh: epic_train.hip under -DPFM_BDIAG).   PFM_DIAG=1 PFM_LIB_PATH=tests/diag/libtr_stamps.so python tests/diag/bwd_stamps.py [n_particles]"""
 import ctypes
 import os
 import sys

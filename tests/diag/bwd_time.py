@@ -1,5 +1,5 @@
 """Diagnostic: the three backward launches (chain, dW GEMM, reduce) of the jet-resident EPiC loss on the bench batch, HIP events.
-    [PFM_LIB_PATH=tests/diag/libtr_X.so] python tests/diag/bwd_time.py [B] [reps]"""
+    [PFM_DIAG=1 PFM_LIB_PATH=tests/diag/libtr_X.so] python tests/diag/bwd_time.py [B] [reps]"""
 import os
 import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))

@@ -57,3 +57,20 @@ def test_what_does_not_work(patched):
     patched(torch.bfloat16, 3)       # split bf16 (16 significant bits): an order of magnitude worse than split fp16
     e = _errors(g)[0]
     assert 2e-6 < e < 1e-4
+
+
+def test_markstein_quotient():
+    """pool_finish (csrc/epic_nfe.h) forms mean = sum / n_valid as q = RN(a r), q' = RN(q + r RN(a - n q)) with r = RN(1 / n) instead of
+    the hardware's 12-instruction division sequence.  The claim: q' IS the correctly rounded quotient (what the reference's `/`, epic.py:161,
+    computes) for every valid count a jet can have.  Emulated in float64, where the products of two fp32 numbers and the cancelling
+    difference a - n q are exact."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for n in range(1, 161):
+        nf = np.float32(n)
+        r = np.float32(1.0) / nf
+        a = (rng.standard_normal(4000) * 10.0 ** rng.uniform(-6, 6, 4000)).astype(np.float32)
+        q = a * r
+        e = (a.astype(np.float64) - q.astype(np.float64) * np.float64(n)).astype(np.float32)
+        q2 = (q.astype(np.float64) + e.astype(np.float64) * np.float64(r)).astype(np.float32)
+        assert np.array_equal(q2, a / nf), n
