@@ -413,7 +413,9 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     float* tbl = lds + c.total;  // TBL_FLOATS behind the carve (fast_path_ok: it fits)
     // the stem chain's own loads, two phases ahead of their use (conditioned jets: with fc_l2's bias row for c.bj2)
     ChainLoads L = fast_chain_loads(rs, d.g2.W, w2r0, tbS, TB_SG1, TB_SG1, TB_SG2, ctS, TB_SJ2);
+#ifndef PFM_AB_NOL1  // (PFM_AB_*: timing-only ablation builds of tests/diag/fixed_cost_table.sh; results are garbage)
     fast_stem_l1(j, lds, c, n_rows, cy.aw, cy.sj1);
+#endif
     if (COND || L2LDS) {  // fc_l2 reads its per-jet bias (time (+ conditioning) term) from LDS: in place before the barrier in front of it
         fast_chain_publish(L, tbl);
         fast_chain_publish_l2(L, lds + c.bj2);
@@ -434,6 +436,16 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     {
         const pfm_epic_layer& l0 = d.layer[0];
         ChainLoads L0;
+#ifdef PFM_AB_NOCHAIN
+        {
+            Prefetch<NGL, 1> pf{rs, gl, wbA, nullptr, nullptr, seg_panels(l0.gl1.W, FTP, tid), seg_panels(l0.lc1.We, FTP, tid), {}, {}};
+            pf.template issue_range<0, NGL + 1>();
+            load_afrag_lin<BF16>(cy.a1, rs, l0.lc1, w, lane);
+            L0 = fast_chain_loads(rs, l0.gl2.W, w2r0, tbE, TB_G1, TB_L1, TB_G2, COND ? ct : nullptr, TB_L2);
+            fast_chain_publish(L0, tbl);
+            __syncthreads();
+        }
+#else
         fast_chain_stem<NSEG, COND>(j, lds, sv, gl, L, tbl, [&]() {
             // the first layer's windows, phase-1 weights and chain loads: no particle phase to ride on; they land behind the rest of the stem chain
             Prefetch<NGL, 1> pf{rs, gl, wbA, nullptr, nullptr, seg_panels(l0.gl1.W, FTP, tid), seg_panels(l0.lc1.We, FTP, tid), {}, {}};
@@ -441,6 +453,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
             load_afrag_lin<BF16>(cy.a1, rs, l0.lc1, w, lane);
             L0 = fast_chain_loads(rs, l0.gl2.W, w2r0, tbE, TB_G1, TB_L1, TB_G2, COND ? ct : nullptr, TB_L2);
         }, [&]() { fast_chain_publish(L0, tbl); });
+#endif
         L = L0;
     }
     f32x4 b3 = {0.f, 0.f, 0.f, 0.f};  // head bias (zero for f >= F): requested in front of the last particle phase
@@ -451,7 +464,11 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         const float* tbK = tbE + (size_t)k * TB_SLOT;
         const float* tbN = tbE + (size_t)(last ? k : k + 1) * TB_SLOT;
         PFM_STAMP(10);
+#ifndef PFM_AB_NOCHAIN
         fast_chain_layer<NSEG, COND>(j, lds, c, sv, gl, wbA[0], L, tbl);
+#else
+        if (COND || L2LDS) fast_chain_publish_l2(L, lds + c.bj2);
+#endif
         PFM_STAMP(12);
         // phase 1: bufA = lrelu(W1 . bufB + bj1)   epic.py:194-196.  Riders: phase 2's weights and ALL per-jet windows of the next
         // layer (gl / wbA were consumed by the chain above), so that nothing the next chain waits for is requested late
@@ -461,7 +478,9 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
             gemm_phase<false, false, false, BF16, decltype(pf), NSEG>(cy.a1, bufB, bufA, nullptr, lds + c.bj1, maskf, j, lds, c, nullptr,
                                                                        nullptr, n_rows, pf, s2p, &qp1);
         }
+#ifndef PFM_AB_NOBAR
         __syncthreads();
+#endif
         PFM_STAMP(13);
         // the next chain's loads, a phase ahead
         L = fast_chain_loads(rs, nx.gl2.W, w2r0, tbN, TB_G1, TB_L1, TB_G2, COND ? ct + (size_t)(last ? k : k + 1) * TB_SLOT : nullptr, TB_L2);
@@ -484,11 +503,15 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
             fast_chain_publish(L, tbl);
             pf.issue_tail(NSEG == 4 ? n_rows / (2 * TILE) : phase_full_pairs<BF16>(n_rows));
         }
+#ifndef PFM_AB_NOBAR
         __syncthreads();
+#endif
     }
     PFM_STAMP(20);
     fast_carry_request(cy, d, rs, tbE_next + (size_t)j.layers * TB_SLOT, ctS);  // lands behind the head
+#ifndef PFM_AB_NOHEAD
     fast_head<AF>(j, lds, c, n_rows, cy.a1, b3, emit);
+#endif
 }
 
 }  // namespace pfm

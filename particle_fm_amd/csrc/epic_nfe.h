@@ -163,6 +163,9 @@ struct Prefetch {
     PfSeg s0, s1, s2, s3;
     template <int I>
     __device__ __forceinline__ void issue() const {
+#ifdef PFM_AB_NOPF  // (timing-only ablation: no weight loads at all; stale registers)
+        return;
+#endif
         if constexpr (I < N0) r0[I] = bload4(rs, s0.off + (int64_t)I * s0.stride, s0.lane_bytes);
         else if constexpr (I < N0 + N1) r1[I - N0] = bload4(rs, s1.off + (int64_t)(I - N0) * s1.stride, s1.lane_bytes);
         else if constexpr (I < N0 + N1 + N2) r2[I - N0 - N1] = bload4(rs, s2.off + (int64_t)(I - N0 - N1) * s2.stride, s2.lane_bytes);
@@ -302,8 +305,15 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
         r1 = *reinterpret_cast<const f32x4*>(resid + TILE * H + ooff);
     }
     // epilogue of an INTERIOR pair: all 32 rows are < n_rows, no predication at all
-    auto epilogue_full = [&](f32x4 e0, f32x4 e1, int pair, f32x4& ps) {  // ps: the pool sum this pair adds to
-        lrelu8_pk(e0, e1, slope2);  // packed, no canonicalising copies: pfm_common.h
+    auto epilogue_full = [&](f32x4 e0, f32x4 e1, int pair, f32x4& ps, auto late_tag) {  // ps: the pool sum this pair adds to
+        constexpr bool late = decltype(late_tag)::value;
+#ifdef PFM_AB_NOEPI  // (timing-only ablation: results dropped, the accumulators kept alive)
+        asm volatile("" ::"v"(e0), "v"(e1));
+        return;
+#endif
+        // packed, no canonicalising copies (pfm_common.h).  Interior pairs (LATE): called behind the first K-quarter of the next pair
+        if (late) lrelu8_pk<false>(e0, e1, slope2);
+        else lrelu8_pk<true>(e0, e1, slope2);
         float* d0 = dst + pair * 2 * TILE * H + ooff;
         *reinterpret_cast<f32x4*>(d0) = e0;
         *reinterpret_cast<f32x4*>(d0 + TILE * H) = e1;
@@ -330,6 +340,10 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
     auto epilogue = [&](f32x4 e0, f32x4 e1, int pair) {
         const int p0 = pair * 2 * TILE + pl, p1 = p0 + TILE;
         const bool v0 = p0 < n_rows, v1 = p1 < n_rows;
+#ifdef PFM_AB_NOEPI
+        asm volatile("" ::"v"(e0), "v"(e1));
+        return;
+#endif
         lrelu8_pk(e0, e1, slope2);
         float* d0 = v0 ? dst + pair * 2 * TILE * H + ooff : sink;
         float* d1 = v1 ? dst + (pair * 2 + 1) * TILE * H + ooff : sink;
@@ -362,7 +376,6 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
         const float* s0 = src + pair * 2 * TILE * H;                                                            \
         PFM_LOADQ(Y0, Y1, s0, 1);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        if (pair > 0) epilogue_full(pacc0, pacc1, pair - 1, PFM_PSUM_OF(pair - 1)); /* pair - 1 <= npairs - 2: every row valid */ \
         f32x4 acc0 = bias, acc1 = bias;                                                                         \
         if (NSEG == 2) { /* wave-uniform: which jet each of the two tiles belongs to */                         \
             if (2 * pair >= t1) acc0 = biasB;                                                                   \
@@ -376,6 +389,10 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
         PFI(0);                                                                                                 \
         PFM_LOADQ(X0, X1, s0, 2);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
+        /* the epilogue of pair - 1 (<= npairs - 2: every row valid) HERE, behind this pair's first K-quarter: its accumulators are   \
+           16 MFMAs old (no hazard nop, nothing waits for the matrix pipe) and its ~20 VALU / LDS instructions issue between the     \
+           MFMAs of quarter 1 instead of in front of an idle pipe (round 4: tests/diag/fixed_cost_table.py) */                  \
+        if (pair > 0) epilogue_full(pacc0, pacc1, pair - 1, PFM_PSUM_OF(pair - 1), std::true_type{});                 \
         MF(Y0, Y1, 1);                                                                                          \
         PFI(1);                                                                                                 \
         PFM_LOADQ(Y0, Y1, s0, 3);                                                                               \
@@ -436,15 +453,19 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
     if constexpr (NSEG == 4) {
         // the last jet's slot: every row of a slot is computed (holes carry zero input and zero mask), so no predication; the
         // branch is wave-uniform and the pool sum's index static in each arm
-        if (npairs == 1) epilogue_full(pacc0, pacc1, 0, psq[0]);
-        else if (npairs == 2) epilogue_full(pacc0, pacc1, 1, psq[1]);
-        else if (npairs == 3) epilogue_full(pacc0, pacc1, 2, psq[2]);
-        else epilogue_full(pacc0, pacc1, 3, psq[3]);
+        if (npairs == 1) epilogue_full(pacc0, pacc1, 0, psq[0], std::false_type{});
+        else if (npairs == 2) epilogue_full(pacc0, pacc1, 1, psq[1], std::false_type{});
+        else if (npairs == 3) epilogue_full(pacc0, pacc1, 2, psq[2], std::false_type{});
+        else epilogue_full(pacc0, pacc1, 3, psq[3], std::false_type{});
     } else {
         epilogue(pacc0, pacc1, npairs - 1);
     }
     // the part of the prefetch list a short jet had no pairs for
     if (TAIL) pf.issue_tail(nfull);
+#ifdef PFM_AB_NOPOOLFIN
+    asm volatile("" ::"v"(psum));
+    return;
+#endif
     if (POOL) {
         if constexpr (NSEG == 4) {
 #pragma unroll

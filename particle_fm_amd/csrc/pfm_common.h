@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "pfm_hip.h"
 
@@ -265,7 +266,11 @@ __device__ __forceinline__ float vmax_raw(float a, float b) {  // v_max_f32 with
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-// e0, e1 <- max(e, s e) of two accumulator tiles fresh from the matrix pipe; s2 = (s, s) in an SGPR pair.  4 v_pk_mul + 8 v_max.
+// e0, e1 <- max(e, s e) of two accumulator tiles; s2 = (s, s) in an SGPR pair.  4 v_pk_mul + 8 v_max.
+// FRESH = true: the accumulators may come straight from the matrix pipe (s_nop 11 in front).  FRESH = false: the CALLER guarantees that
+// at least ten wait states of other instructions (e.g. a K-quarter of MFMAs of another accumulator) lie between the MFMA that wrote
+// them and this call -- gemm_phase's interior pairs, whose epilogue sits behind the first K-quarter of the next pair.
+template <bool FRESH = true>
 __device__ __forceinline__ void lrelu8_pk(f32x4& e0, f32x4& e1, f32x2 s2) {
 #ifdef PFM_AB_OLD_LRELU  // (diagnostic A/B builds only)
     e0 = lrelu4(e0, s2.x); e1 = lrelu4(e1, s2.x);
@@ -273,13 +278,22 @@ __device__ __forceinline__ void lrelu8_pk(f32x4& e0, f32x4& e1, f32x2 s2) {
 #endif
     f32x2 m0, m1, m2, m3;
     const f32x2 a0 = {e0.x, e0.y}, a1 = {e0.z, e0.w}, a2 = {e1.x, e1.y}, a3 = {e1.z, e1.w};
-    asm("s_nop 11\n\t"
-        "v_pk_mul_f32 %0, %4, %8\n\t"
-        "v_pk_mul_f32 %1, %5, %8\n\t"
-        "v_pk_mul_f32 %2, %6, %8\n\t"
-        "v_pk_mul_f32 %3, %7, %8"
-        : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3)
-        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(s2));
+    if constexpr (FRESH) {
+        asm("s_nop 11\n\t"
+            "v_pk_mul_f32 %0, %4, %8\n\t"
+            "v_pk_mul_f32 %1, %5, %8\n\t"
+            "v_pk_mul_f32 %2, %6, %8\n\t"
+            "v_pk_mul_f32 %3, %7, %8"
+            : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(s2));
+    } else {
+        asm("v_pk_mul_f32 %0, %4, %8\n\t"
+            "v_pk_mul_f32 %1, %5, %8\n\t"
+            "v_pk_mul_f32 %2, %6, %8\n\t"
+            "v_pk_mul_f32 %3, %7, %8"
+            : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(s2));
+    }
     e0 = f32x4{vmax_raw(a0.x, m0.x), vmax_raw(a0.y, m0.y), vmax_raw(a1.x, m1.x), vmax_raw(a1.y, m1.y)};
     e1 = f32x4{vmax_raw(a2.x, m2.x), vmax_raw(a2.y, m2.y), vmax_raw(a3.x, m3.x), vmax_raw(a3.y, m3.y)};
 }
