@@ -171,7 +171,8 @@ def run(name, args):
         main.wait_event(done[s])
         if ev:
             ev[0].record(main)
-        trainer.step((x, mask, cond))
+        if not args.sample_only:
+            trainer.step((x, mask, cond))
         with torch.no_grad():
             blob = net.packed_weights(N)  # this step's weights, packed on the training stream
         if ev:
@@ -211,6 +212,30 @@ def run(name, args):
     # the dense MFMA peak of the operand type (MI355X_MICROARCH.md): bf16 / fp16 ~2.5 PFLOP/s; f16x3 runs 3 fp16 MFMAs per product
     # block, so its useful-FLOP peak is a third of that
     peak = {"fp32": FP32_MFMA_PEAK, "bf16": 2500e12, "f16x3": 2500e12 / 3}[args.precision]
+    # the kernel the sampler really launches for this descriptor, and its HBM traffic from the committed rocprofv3 --pmc passes
+    kernel = "sampling launches (tf_linear_kernel dominates)"
+    if name == "jetnet30":
+        from particle_fm_amd import hip_ops
+        from particle_fm_amd.layout import PFM_F_QUAD_JETS
+        lay30 = net.layout(N)
+        big = hip_ops.packed_layout(lay30, N)
+        mode = {"fp32": 0, "bf16": 1, "f16x3": 2}[args.precision]
+        if big is not None and int(big.desc.flags) & PFM_F_QUAD_JETS:
+            kernel = f"epic_sample_midpoint_quad_kernel<{mode}>"
+        elif args.precision == "f16x3":
+            kernel = "epic_sample_midpoint_kernel<2, true>"
+        else:
+            kernel = f"epic_sample_midpoint_fast_kernel<{mode}, {'true' if packed else 'false'}, false>"
+    traffic, traffic_note = None, "no rocprofv3 --pmc pass on file for this workload / precision"
+    pmc_path = os.path.join(ROOT, "profiles", f"round4_pmc_{name}_{args.precision}.json")
+    if os.path.exists(pmc_path):
+        tot = json.load(open(pmc_path)).get("_totals", {})
+        if tot.get("hbm_bytes_per_evaluation"):
+            traffic = tot["hbm_bytes_per_evaluation"] * n_nfe
+            traffic_note = (f"traffic = HBM-side bytes of ONE sampler call ({n_nfe} evaluations): (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over every "
+                            f"launch of a sampling-only run of {tot.get('evaluations')} evaluations under rocprofv3 --pmc (separate passes, gfx950 "
+                            f"correction; tests/diag/collect_pmc_rowmatrix.sh), per evaluation x {n_nfe}: profiles/{os.path.basename(pmc_path)}; "
+                            f"algorithmic bytes per call (inputs, outputs, masks, ONE read of the weights): {tot.get('algorithmic_note', 'see DESIGN.md section 5')}")
     res = {
         "metric": "jets/sec (train step + 100-step ODE sample)", "value": B * args.steps / elapsed, "unit": "jets/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -225,9 +250,9 @@ def run(name, args):
                    "jets_per_workgroup": 2 if packed else 1},
         "train_ms": train_ms, "sample_ms": sample_ms, "train_jets_per_s": B / (train_ms * 1e-3),
         "sample_jets_per_s": B / (sample_ms * 1e-3),
-        "roofline": {"bound": "mfma", "kernel": "sampling launches (tf_linear_kernel dominates)" if name != "jetnet30" else "epic_sample_midpoint_fast_kernel",
+        "roofline": {"bound": "mfma", "kernel": kernel,
                      "achieved": executed / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": executed / peak,
-                     "traffic": None, "concurrent_launches": D, "valid_row_fraction": float(nv.mean()) / N,
+                     "traffic": traffic, "traffic_note": traffic_note, "concurrent_launches": D, "valid_row_fraction": float(nv.mean()) / N,
                      "executed_share_of_dense": exec_share,
                      "dense_equiv_over_peak": dense_launch / peak,
                      "dense_equiv_over_peak_aggregate": dense_aggregate / peak,
@@ -261,6 +286,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="cross-attention path: enqueue every launch of the sampler from the host "
                     "instead of replaying the captured step body (hipGraph)")
     ap.add_argument("--dense-rows", action="store_true", help="transformer paths: sample all N rows like the reference (padded included)")
+    ap.add_argument("--sample-only", action="store_true", help="diagnostics (tests/diag/collect_pmc_rowmatrix.sh): no train step, so that every "
+                    "launch of the run belongs to the sampler; the line it prints is NOT a benchmark line")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_secondary.py needs an MI355X (the HIP path has no CPU fallback)")

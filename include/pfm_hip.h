@@ -37,6 +37,12 @@
  *                    that thread t of 512 reads float4 number t of a panel: element (k, o) lives at float
  *                    ((k>>4)*32 + (o>>2))*64 + (k&15)*4 + (o&3).  Used for every per-jet GEMV with 128 outputs.
  *   KP16             [K16][16]: K-major with the OUT <= 16 outputs zero-padded to 16 columns, rows to a multiple of 16.
+ *   KQ16             (round 4; the lean sampler's per-jet chains) OUT = 128, 16-row panels of 2048 floats, element (k, o) of panel
+ *                    p = k >> 4 at float  p*2048 + o*16 + (k&15): thread t of 512 reads float4 number t of a panel and holds FOUR
+ *                    CONSECUTIVE k of ONE output, W[o = t>>2][16p + 4(t&3) .. + 3] -- a thread's partial sum needs one add and a
+ *                    4-lane (quad) reduction instead of a 16-lane tree over four accumulators.
+ *   WQ16             the same idea for OUT <= 16, K = 128: float (k>>4)*256 + o*16 + (k&15); wave w reads chunk w, lane l float4
+ *                    number l = W[o = l>>2][16w + 4(l&3) .. + 3]  (outputs >= OUT are zero).
  *   MFMA_A           the H x H block that multiplies the per-particle activations, pre-arranged as the
  *                    A operand of v_mfma_f32_16x16x4_f32: float4 at ((w*8 + kt)*64 + lane) holds
  *                    W[16*w + (lane&15)][16*kt + 4*(lane>>4) + r], r = 0..3   (w = output slice 0..7).
@@ -68,7 +74,8 @@ extern "C" {
 
 /* 2 (round 3): the loss forward / backward entry points take a jet launch order; pfm_local_lin.A16 / pfm_epic_desc.l3_A16 (bf16 copies of the particle blocks in the blob); pfm_epic_fm_loss_backward / pfm_epic_diffusion_loss_backward take a `scratch` pointer in front of `stream` and WRITE
  * grad_blob (round 2 changed both under version 1: a caller or a stale library built against that header must be refused) */
-#define PFM_ABI_VERSION 2
+/* 3 (round 4): pfm_epic_desc carries the KQ16 / WQ16 copies of the per-jet GEMV blocks (q_*) */
+#define PFM_ABI_VERSION 3
 #define PFM_MAX_LAYERS 24
 #define PFM_HIDDEN 128
 
@@ -143,6 +150,13 @@ typedef struct pfm_epic_desc {
     int64_t l3_A;        /* fc_l3 particle block as ONE 16-row MFMA_A panel: float4 at (kt*64 + lane) holds
                             W3[lane&15][16*kt + 4*(lane>>4) + r] (rows >= F are zero), 2048 floats */
     int64_t l3_A16;      /* the same panel as MFMA_A16 (one output slice), 1024 floats */
+    /* round 4: second copies of the per-jet GEMV blocks WITHOUT their time / conditioning rows, for the lean sampler's chains
+       (csrc/epic_fast.h: unconditioned jets; the time rows are tabulated per evaluation) */
+    int64_t q_g1;                    /* fc_g1      rows [mean ; sum]     : KQ16, 16 panels */
+    int64_t q_g2;                    /* fc_g2      rows of g1 (128)      : WQ16 */
+    int64_t q_gl1[PFM_MAX_LAYERS];   /* fc_global1 rows [mean ; sum ; g] : KQ16, 17 panels (g zero-padded to 16 rows) */
+    int64_t q_gl2[PFM_MAX_LAYERS];   /* fc_global2 rows of g1            : WQ16 */
+    int64_t q_we1[PFM_MAX_LAYERS];   /* fc_local1  extras rows of g      : KQ16, 1 panel */
 } pfm_epic_desc;
 
 #define PFM_DESC_FLOATS ((int64_t)((sizeof(pfm_epic_desc) + 15) / 16 * 4))

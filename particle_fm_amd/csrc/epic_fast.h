@@ -32,6 +32,9 @@
 
 namespace pfm {
 
+#ifndef PFM_QCHAIN_MINSEG
+#define PFM_QCHAIN_MINSEG 1   // jets per workgroup from which the chains run on the KQ16 / WQ16 copies (diagnostic builds: 2, 5 = never)
+#endif
 constexpr int FT = 32;        // time-embedding width the fast path is built for
 constexpr int FTP = FT / 16;  // time panels of every per-jet block (tabulated, skipped)
 constexpr int FNG = 17;       // fc_global1 panels behind the time rows: [mean(128) ; sum(128) ; g(16)]
@@ -272,6 +275,179 @@ __device__ __forceinline__ void fast_chain_layer(const JetDims& j, float* __rest
     if (COND || L2LDS) fast_chain_publish_l2(L, lds + c.bj2);
 }
 
+// ---- round 4: the chains of UNCONDITIONED jets on the KQ16 / WQ16 copies of the per-jet blocks (include/pfm_hip.h) ------------------
+// Why.  tests/diag/fixed_cost_table.py: the seven chains are 29 % (10 tiles) .. 53 % (2 tiles) of what an evaluation spends outside
+// the matrix pipe, and 38 % of the whole cfg-2 bf16 sampler (four jets per workgroup: every VALU instruction of a chain runs once per
+// jet).  In the KM16 layout a thread holds FOUR outputs of ONE input row: four accumulators, a 16-lane reduction tree over each
+// (16 v_add_f32_dpp), a broadcast copy per second panel, LeakyReLU on four values -- ~137 VALU instructions per chain and jet, of which
+// 34 are the packed FMAs that do the work.  KQ16: thread (o = t >> 2, kq = t & 3) holds four CONSECUTIVE input rows of ONE output, the
+// input vector comes as a float4 (ds_read_b128), two packed FMAs per panel with both operands as vectors, ONE add and a quad
+// reduction (2 DPP adds), LeakyReLU on one value: ~65.  Same weights, another summation order than fast_chain_* / per_jet_phase
+// (fp32 re-association; inside every parity bar, and identical for one, two or four jets per workgroup).
+__device__ __forceinline__ float quad_sum(float v) {  // every lane of a quad ends with the quad's sum
+    v += dpp_move<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);  // quad_perm [2,3,0,1]
+    return v;
+}
+// w . x over this thread's four rows: (w.x x.x + w.z x.z) + (w.y x.y + w.w x.w), packed
+__device__ __forceinline__ f32x2 pk_dot_step(f32x2 acc, const f32x4& wv, const f32x4& x) {
+    acc = __builtin_elementwise_fma(f32x2{wv.x, wv.y}, f32x2{x.x, x.y}, acc);
+    return __builtin_elementwise_fma(f32x2{wv.z, wv.w}, f32x2{x.z, x.w}, acc);
+}
+// the chain's loads that are not register windows: this thread's float4 of fc_global2 (WQ16: chunk w, float4 lane) and the staged
+// table rows (as fast_chain_loads)
+__device__ __forceinline__ ChainLoads fastq_chain_loads(blob_rsrc rs, int64_t q_gl2, const float* __restrict__ slot, int o_g1, int o_l1,
+                                                        int o_g2, int o_l2) {
+    const int tid = launder(threadIdx.x);
+    ChainLoads L;
+    L.w2 = bload4(rs, q_gl2, tid * 16);
+    L.stg = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 100) {
+        const int off = tid < 32 ? o_g1 + 4 * tid : (tid < 64 ? o_l1 + 4 * (tid - 32) : (tid < 68 ? o_g2 + 4 * (tid - 64) : o_l2 + 4 * (tid - 68)));
+        L.stg = *reinterpret_cast<const f32x4*>(slot + off);
+    }
+    return L;
+}
+// g1 = lrelu(W1 . v + t1) for NP panels of v (from vin + FT), written to vin2 + FT by the quad's first lane; wave w produces g1[16 w ..]
+// Four jets per workgroup: the input vectors come through a two-deep register pipeline of one panel per jet (32 VGPRs); left to
+// itself hipcc requests all 4 x 17 float4s up front.
+template <int NSEG, int NP, int NSV, int S0 = 0>
+__device__ __forceinline__ void fastq_g1_part(const JetDims& j, float* __restrict__ lds, const SegView (&sva)[NSV], const f32x4 (&gl)[FNG],
+                                              const float* __restrict__ tbl) {
+    const SegView* sv = sva + S0;  // jets S0 .. S0 + NSEG - 1 of the workgroup
+    const int tid = launder(threadIdx.x), o = tid >> 2, kq = tid & 3;
+    constexpr int G = NSEG == 4 ? 1 : (NSEG == 2 ? 2 : 4), NG = (NP + G - 1) / G;
+    f32x4 xa[NSEG][G], xb[NSEG][G];
+    f32x2 acc[NSEG];
+    const float* vp[NSEG];
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        acc[s] = f32x2{0.f, 0.f};
+        vp[s] = lds + sv[s].vin + FT + 4 * kq;
+    }
+#define PFM_Q_LOAD(X, g)                                                                            \
+    _Pragma("unroll") for (int s = 0; s < NSEG; ++s)                                                \
+        _Pragma("unroll") for (int i = 0; i < G; ++i)                                               \
+            if ((g) * G + i < NP) X[s][i] = *reinterpret_cast<const f32x4*>(vp[s] + 16 * ((g) * G + i));
+#define PFM_Q_FMA(X, g)                                                                             \
+    _Pragma("unroll") for (int s = 0; s < NSEG; ++s)                                                \
+        _Pragma("unroll") for (int i = 0; i < G; ++i)                                               \
+            if ((g) * G + i < NP) acc[s] = pk_dot_step(acc[s], gl[(g) * G + i], X[s][i]);
+    if constexpr (NSEG <= 2) {  // one or two jets: all reads up front is what hipcc does by itself, and it fits (measured: the
+                                // pipeline's scheduling fences cost a 2-tile jet 3 %)
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s)
+#pragma unroll
+            for (int u = 0; u < NP; ++u) acc[s] = pk_dot_step(acc[s], gl[u], *reinterpret_cast<const f32x4*>(vp[s] + 16 * u));
+    } else {
+        PFM_Q_LOAD(xa, 0)
+#pragma unroll
+        for (int g = 0; g < NG; g += 2) {
+            if (g + 1 < NG) { PFM_Q_LOAD(xb, g + 1) }
+            __builtin_amdgcn_sched_barrier(0);
+            PFM_Q_FMA(xa, g)
+            if (g + 2 < NG) { PFM_Q_LOAD(xa, g + 2) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < NG) { PFM_Q_FMA(xb, g + 1) }
+        }
+    }
+#undef PFM_Q_LOAD
+#undef PFM_Q_FMA
+    const float bg1 = tbl[TBL_G1 + o];
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        const float g1 = lrelu(quad_sum(acc[s].x + acc[s].y) + bg1, j.slope);
+        if (kq == 0) lds[sv[s].vin2 + FT + o] = g1;
+    }
+    // fc_global2's rows are split over the waves exactly as these outputs are (wave w: g1[16 w .. 16 w + 15]): wave-local hand-over
+    wave_lds_sync();
+}
+// four jets: two passes of two (the four-jet instantiation of the loop above put 400 bytes per lane into scratch)
+template <int NSEG, int NP, int NSV>
+__device__ __forceinline__ void fastq_g1(const JetDims& j, float* __restrict__ lds, const SegView (&sv)[NSV], const f32x4 (&gl)[FNG],
+                                         const float* __restrict__ tbl) {
+    if constexpr (NSEG == 4) {
+        fastq_g1_part<2, NP, NSV, 0>(j, lds, sv, gl, tbl);
+        __builtin_amdgcn_sched_barrier(0);
+        fastq_g1_part<2, NP, NSV, 2>(j, lds, sv, gl, tbl);
+    } else {
+        fastq_g1_part<NSEG, NP, NSV, 0>(j, lds, sv, gl, tbl);
+    }
+}
+// wave partial of fc_global2 over this wave's 16 rows of g1 -> g2p[w][o2]
+template <int NSEG, int NSV>
+__device__ __forceinline__ void fastq_g2_partial(float* __restrict__ lds, const SegView (&sv)[NSV], const f32x4& w2) {
+    const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6, kq = tid & 3, o2 = lane >> 2;
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(lds + sv[s].vin2 + FT + 16 * w + 4 * kq);
+        const f32x2 acc = pk_dot_step(f32x2{0.f, 0.f}, w2, x);
+        const float p = quad_sum(acc.x + acc.y);
+        if (kq == 0) lds[sv[s].g2p + MAXL * w + o2] = p;
+    }
+}
+// the eight wave partials of output (lane & 15), added in wave order; all eight reads in flight before the first add
+__device__ __forceinline__ float fastq_sum_partials(const float* __restrict__ g2p_o) {
+    float part[NW];
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) part[ww] = g2p_o[MAXL * ww];
+    __builtin_amdgcn_sched_barrier(0);
+    float gn = part[0];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) gn += part[ww];
+    return gn;
+}
+
+// Stem chain on the KQ16 / WQ16 copies (see fast_chain_stem for the contract): gl = the 16 [mean ; sum] panels of q_g1.
+template <int NSEG, int NSV, typename After, typename Publish>
+__device__ __forceinline__ void fastq_chain_stem(const JetDims& j, float* __restrict__ lds, const SegView (&sv)[NSV], const f32x4 (&gl)[FNG],
+                                                 const ChainLoads& L, const float* __restrict__ tbl, After after_fc1, Publish publish_next) {
+    const int tid = launder(threadIdx.x), lane = tid & 63;
+    fastq_g1<NSEG, FNGS>(j, lds, sv, gl, tbl);
+    after_fc1();
+    const float bg2 = tbl[TBL_G2 + (lane & 15)];  // before the next chain's rows replace these
+    fastq_g2_partial<NSEG>(lds, sv, L.w2);
+    __syncthreads();
+    publish_next();  // every read of this chain's table rows lies before the barrier above
+    if (tid < 16) {
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) lds[sv[s].vin + FT + 2 * H + tid] = lrelu(fastq_sum_partials(lds + sv[s].g2p + tid) + bg2, j.slope);
+    }
+    __syncthreads();
+}
+
+// Layer chain on the KQ16 / WQ16 copies (see fast_chain_layer for the contract): gl = the 17 [mean ; sum ; g] panels of q_gl1,
+// wbA = this thread's float4 of q_we1 (the g rows of local linear 1's extras).
+template <int NSEG, int NSV>
+__device__ __forceinline__ void fastq_chain_layer(const JetDims& j, float* __restrict__ lds, const Carve& c, const SegView (&sv)[NSV],
+                                                  const f32x4 (&gl)[FNG], const f32x4& wbA, const ChainLoads& L, const float* __restrict__ tbl) {
+    const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6, o = tid >> 2, kq = tid & 3;
+    float gold[NSEG];
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) gold[s] = lds[sv[s].vin + FT + 2 * H + (lane & 15)];  // g_old, before anyone overwrites it
+    fastq_g1<NSEG, FNG>(j, lds, sv, gl, tbl);
+    fastq_g2_partial<NSEG>(lds, sv, L.w2);
+    __syncthreads();
+    const float bg2 = tbl[TBL_G2 + (lane & 15)], bl1 = tbl[TBL_L1 + o];
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+        float gn = fastq_sum_partials(lds + sv[s].g2p + (lane & 15));
+        gn += bg2;
+        gn += gold[s];  // residual before the activation, epic.py:184-186
+        gn = lrelu(gn, j.slope);
+        // every wave keeps its own copy of g_new (the input of its slice of the bias GEMV); wave 0's copy is vin.g, the next stage's input.
+        // Entries >= L are lrelu(0) = 0 (zero-padded weights and biases).
+        float* gcopy = (w == 0) ? lds + sv[s].vin + FT + 2 * H : lds + sv[s].gcopy + MAXL * w;
+        if (lane < 16) gcopy[lane] = gn;
+        wave_lds_sync();
+        const f32x2 acc = pk_dot_step(f32x2{0.f, 0.f}, wbA, *reinterpret_cast<const f32x4*>(gcopy + 4 * kq));
+        const float p1 = quad_sum(acc.x + acc.y);
+        if (kq == 0) lds[sv[s].bj1 + o] = p1 + bl1;  // wave w: bj1[16 w .. 16 w + 15], the slice its own particle phase reads
+    }
+    if (L2LDS) fast_chain_publish_l2(L, lds + c.bj2);
+    wave_lds_sync();
+}
+
 // fc_l3 head with its per-jet bias from the table and its weights already in registers (requested during the last particle
 // phase).  emit(p, f, lrelu(b3[f] + W3[f].x[p]) * mask[p]) for the rows p < n_rows ONLY: the sampler's state rows behind a jet's
 // last valid particle start as z * mask = 0 and an update by 0 would leave them there.  epic.py:387-391
@@ -377,6 +553,13 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     static_assert(NSEG != 4 || L2LDS, "quad mode reads the shared biases from c.bj2");
     constexpr int NGL = COND ? FNGC : FNG, NGLS = COND ? FNGS + 1 : FNGS;
     constexpr int AF = FastCarry<BF16>::AF;
+    // Chains on the KQ16 / WQ16 copies (fastq_chain_*) for every unconditioned instantiation.  Same-box A/B (tests/diag/ab_cfg2.py,
+    // ab_time.py; libraries built with -DPFM_QCHAIN_MINSEG=1 / 5): two jets per workgroup (cfg-2 fp32) 28.3 -> 27.0 ms; four jets
+    // unchanged in time but without the scratch the KM16 chain's four-jet instantiation needed (44 B per lane bf16, 192 B fp32 -> 0);
+    // ONE jet 1.4 % slower at 2 tiles, equal from 4 tiles on, +0.2 % on the bench mix: a single jet's chain is bound by its LDS
+    // round trips, not by its instruction count, and the float4 reads move four times the bytes.  All of them take it, because one,
+    // two and four jets per workgroup must give the same bits (tests/test_hip_packed.py).
+    constexpr bool QCH = !COND && NSEG >= PFM_QCHAIN_MINSEG;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr int NSV = NSEG == 4 ? 4 : 2;
     SegView sv[NSV];
@@ -411,8 +594,24 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     f32x4 gl[NGL], wbA[1];
     PFM_STAMP(1);
     float* tbl = lds + c.total;  // TBL_FLOATS behind the carve (fast_path_ok: it fits)
+    // Unconditioned jets run their chains on the KQ16 / WQ16 copies of the per-jet blocks (fastq_chain_*, round 4), conditioned ones on
+    // the KM16 / KP16 blocks behind the time panels (fast_chain_*): where a chain's register windows and loads come from
+    auto gl1_seg = [&](int k) {
+        if constexpr (!QCH) return seg_panels(d.layer[k].gl1.W, FTP, tid);
+        else return seg_panels(d.q_gl1[k], 0, tid);
+    };
+    auto we1_seg = [&](int k) {
+        if constexpr (!QCH) return seg_panels(d.layer[k].lc1.We, FTP, tid);
+        else return seg_panels(d.q_we1[k], 0, tid);
+    };
+    auto layer_chain_loads = [&](int k, const float* __restrict__ tb) {
+        if constexpr (!QCH) return fast_chain_loads(rs, d.layer[k].gl2.W, w2r0, tb, TB_G1, TB_L1, TB_G2, COND ? ct + (size_t)k * TB_SLOT : nullptr, TB_L2);
+        else return fastq_chain_loads(rs, d.q_gl2[k], tb, TB_G1, TB_L1, TB_G2, TB_L2);
+    };
     // the stem chain's own loads, two phases ahead of their use (conditioned jets: with fc_l2's bias row for c.bj2)
-    ChainLoads L = fast_chain_loads(rs, d.g2.W, w2r0, tbS, TB_SG1, TB_SG1, TB_SG2, ctS, TB_SJ2);
+    ChainLoads L;
+    if constexpr (!QCH) L = fast_chain_loads(rs, d.g2.W, w2r0, tbS, TB_SG1, TB_SG1, TB_SG2, ctS, TB_SJ2);
+    else L = fastq_chain_loads(rs, d.q_g2, tbS, TB_SG1, TB_SG1, TB_SG2, TB_SJ2);
 #ifndef PFM_AB_NOL1  // (PFM_AB_*: timing-only ablation builds of tests/diag/fixed_cost_table.sh; results are garbage)
     fast_stem_l1(j, lds, c, n_rows, cy.aw, cy.sj1);
 #endif
@@ -424,7 +623,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     PFM_STAMP(3);
     // ---- fc_l2: bufB = lrelu(W.bufA + bj2 + bufA), pooled -> vin   epic.py:364-371; carries the stem chain's fc_g1 rows
     {
-        Prefetch<NGLS> pf{rs, gl, nullptr, nullptr, nullptr, seg_panels(d.g1.W, FTP, tid), {}, {}, {}};
+        Prefetch<NGLS> pf{rs, gl, nullptr, nullptr, nullptr, !QCH ? seg_panels(d.g1.W, FTP, tid) : seg_panels(d.q_g1, 0, tid), {}, {}, {}};
         const float* bj = (COND || L2LDS) ? lds + c.bj2 : tbS + TB_SJ2;
         s2t.bj = bj;
         gemm_phase<true, true, false, BF16, decltype(pf), NSEG>(cy.a2, bufA, bufB, bufA, bj, maskf, j, lds, c, nullptr, nullptr, n_rows, pf,
@@ -436,23 +635,20 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     {
         const pfm_epic_layer& l0 = d.layer[0];
         ChainLoads L0;
+        // the first layer's windows, phase-1 weights and chain loads: no particle phase to ride on; they land behind the rest of the stem chain
+        auto first_layer_requests = [&]() {
+            Prefetch<NGL, 1> pf{rs, gl, wbA, nullptr, nullptr, gl1_seg(0), we1_seg(0), {}, {}};
+            pf.template issue_range<0, NGL + 1>();
+            load_afrag_lin<BF16>(cy.a1, rs, l0.lc1, w, lane);
+            L0 = layer_chain_loads(0, tbE);
+        };
 #ifdef PFM_AB_NOCHAIN
-        {
-            Prefetch<NGL, 1> pf{rs, gl, wbA, nullptr, nullptr, seg_panels(l0.gl1.W, FTP, tid), seg_panels(l0.lc1.We, FTP, tid), {}, {}};
-            pf.template issue_range<0, NGL + 1>();
-            load_afrag_lin<BF16>(cy.a1, rs, l0.lc1, w, lane);
-            L0 = fast_chain_loads(rs, l0.gl2.W, w2r0, tbE, TB_G1, TB_L1, TB_G2, COND ? ct : nullptr, TB_L2);
-            fast_chain_publish(L0, tbl);
-            __syncthreads();
-        }
+        first_layer_requests();
+        fast_chain_publish(L0, tbl);
+        __syncthreads();
 #else
-        fast_chain_stem<NSEG, COND>(j, lds, sv, gl, L, tbl, [&]() {
-            // the first layer's windows, phase-1 weights and chain loads: no particle phase to ride on; they land behind the rest of the stem chain
-            Prefetch<NGL, 1> pf{rs, gl, wbA, nullptr, nullptr, seg_panels(l0.gl1.W, FTP, tid), seg_panels(l0.lc1.We, FTP, tid), {}, {}};
-            pf.template issue_range<0, NGL + 1>();
-            load_afrag_lin<BF16>(cy.a1, rs, l0.lc1, w, lane);
-            L0 = fast_chain_loads(rs, l0.gl2.W, w2r0, tbE, TB_G1, TB_L1, TB_G2, COND ? ct : nullptr, TB_L2);
-        }, [&]() { fast_chain_publish(L0, tbl); });
+        if constexpr (!QCH) fast_chain_stem<NSEG, COND>(j, lds, sv, gl, L, tbl, first_layer_requests, [&]() { fast_chain_publish(L0, tbl); });
+        else fastq_chain_stem<NSEG>(j, lds, sv, gl, L, tbl, first_layer_requests, [&]() { fast_chain_publish(L0, tbl); });
 #endif
         L = L0;
     }
@@ -460,12 +656,14 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     for (int k = 0; k < j.layers; ++k) {
         const pfm_epic_layer ly = d.layer[k];  // by value: the offset dwords in one batch of scalar loads
         const bool last = k + 1 == j.layers;
-        const pfm_epic_layer& nx = d.layer[last ? k : k + 1];  // last layer: its own blocks again (harmless, hidden)
+        const int kn = last ? k : k + 1;                       // last layer: its own blocks again (harmless, hidden)
+        const pfm_epic_layer& nx = d.layer[kn];
         const float* tbK = tbE + (size_t)k * TB_SLOT;
         const float* tbN = tbE + (size_t)(last ? k : k + 1) * TB_SLOT;
         PFM_STAMP(10);
 #ifndef PFM_AB_NOCHAIN
-        fast_chain_layer<NSEG, COND>(j, lds, c, sv, gl, wbA[0], L, tbl);
+        if constexpr (!QCH) fast_chain_layer<NSEG, COND>(j, lds, c, sv, gl, wbA[0], L, tbl);
+        else fastq_chain_layer<NSEG>(j, lds, c, sv, gl, wbA[0], L, tbl);
 #else
         if (COND || L2LDS) fast_chain_publish_l2(L, lds + c.bj2);
 #endif
@@ -473,8 +671,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         // phase 1: bufA = lrelu(W1 . bufB + bj1)   epic.py:194-196.  Riders: phase 2's weights and ALL per-jet windows of the next
         // layer (gl / wbA were consumed by the chain above), so that nothing the next chain waits for is requested late
         {
-            Prefetch<AF, NGL, 1> pf{rs, cy.a2, gl, wbA, nullptr, seg_afrag_lin<BF16>(ly.lc2, w, lane), seg_panels(nx.gl1.W, FTP, tid),
-                                   seg_panels(nx.lc1.We, FTP, tid), {}};
+            Prefetch<AF, NGL, 1> pf{rs, cy.a2, gl, wbA, nullptr, seg_afrag_lin<BF16>(ly.lc2, w, lane), gl1_seg(kn), we1_seg(kn), {}};
             gemm_phase<false, false, false, BF16, decltype(pf), NSEG>(cy.a1, bufB, bufA, nullptr, lds + c.bj1, maskf, j, lds, c, nullptr,
                                                                        nullptr, n_rows, pf, s2p, &qp1);
         }
@@ -483,7 +680,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
 #endif
         PFM_STAMP(13);
         // the next chain's loads, a phase ahead
-        L = fast_chain_loads(rs, nx.gl2.W, w2r0, tbN, TB_G1, TB_L1, TB_G2, COND ? ct + (size_t)(last ? k : k + 1) * TB_SLOT : nullptr, TB_L2);
+        L = layer_chain_loads(kn, tbN);
         if (last) {
             b3 = *reinterpret_cast<const f32x4*>(tbS + TB_SB3 + 4 * (lane >> 4));
             if (COND) b3 += *reinterpret_cast<const f32x4*>(ctS + TB_SB3 + 4 * (lane >> 4));

@@ -200,7 +200,6 @@ class FusedFMTrainer:
         # staging buffers + asynchronous copies keeps the host a few steps ahead (same numbers: the draw itself is unchanged).
         self._t_ring = []
         self._t_next = 0
-        self._fin_next = 0
         self._fused = None
         # False (default): ONE flat all-reduce behind the whole backward -- the exchange that has run on RCCL.  True (opt-in,
         # PFM_DP_OVERLAP=1): split the backward and overlap the first bucket's all-reduce with the dW GEMM (DDP's bucketed overlap);
@@ -308,11 +307,10 @@ class FusedFMTrainer:
         B = x.shape[0]
         condf = None if lay.cfg.global_cond_dim == 0 else cond.to(torch.float32).contiguous()
         maskf = None if mask is None else mask.reshape(B, -1).to(torch.float32).contiguous()  # converted once, used by both kernels
-        ring = st.get("fin")
-        if ring is None:
-            ring = st["fin"] = torch.empty(16, 2, device=x.device, dtype=torch.float32)  # [loss, 1 / sum(mask)] of the last 16 steps
-        fin = ring[self._fin_next % 16]  # the backward reads 1 / sum(mask) from here; the caller gets a COPY of the loss (below)
-        self._fin_next += 1
+        # [loss, 1 / sum(mask)] of THIS step in a buffer of its own (the caching allocator hands one out without a launch): the caller may
+        # keep the returned loss -- a view of it -- as long as it likes (tests/test_hip_trainer_state.py holds 40 of them), and the step
+        # needs neither a copy of the scalar nor a ring whose slots come round again
+        fin = torch.empty(2, device=x.device, dtype=torch.float32)
         if kind == "diffusion":
             from .fm_loss import MLE_LOSS_WEIGHT
             t, z = loss_mod.draw(x, mask, land=self._land)
@@ -330,8 +328,7 @@ class FusedFMTrainer:
             parts, count, saved = hip_ops.epic_fm_loss_forward(lay, blob, x, t, z, cond, maskf, loss_mod.sigma, kind, eps)
             _lib.check(lib.pfm_loss_finish(P(parts), P(count), P(None), B, P(fin), S), "pfm_loss_finish")
             bw_kw = {}
-        # a copy, not the ring view: a caller may keep per-step losses for an epoch mean (one 4-byte launch against a 0.6 ms step)
-        loss = fin[0].clone()
+        loss = fin[0]
         unpack = lib.pfm_wn_unpack_grad_set if tb.covers_all else lib.pfm_wn_unpack_grad
 
         def unpack_rows(r0, r1, b0, b1):

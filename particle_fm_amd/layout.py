@@ -23,7 +23,7 @@ from typing import Dict, List, Mapping, Sequence, Tuple
 import numpy as np
 import torch
 
-PFM_ABI_VERSION = 2
+PFM_ABI_VERSION = 3
 PFM_MAX_LAYERS = 24
 PFM_HIDDEN = 128
 PFM_F_SKIP_MASKED_TAIL = 1
@@ -77,6 +77,11 @@ class EpicDesc(ctypes.Structure):
         ("l3_b", ctypes.c_int64),
         ("l3_A", ctypes.c_int64),
         ("l3_A16", ctypes.c_int64),
+        ("q_g1", ctypes.c_int64),
+        ("q_g2", ctypes.c_int64),
+        ("q_gl1", ctypes.c_int64 * PFM_MAX_LAYERS),
+        ("q_gl2", ctypes.c_int64 * PFM_MAX_LAYERS),
+        ("q_we1", ctypes.c_int64 * PFM_MAX_LAYERS),
     ]
 
 
@@ -251,6 +256,40 @@ class EpicLayout:
         self._put(off, flat)
         return off
 
+    def _kq16(self, name: str, cols: Sequence[int]) -> int:
+        """KQ16 (include/pfm_hip.h): OUT = 128, 16-row panels [o][16 k]; a forward-only second copy (no gradient slot)."""
+        OUT = self._out[name]
+        assert OUT == PFM_HIDDEN
+        cols = list(cols)
+        cols += [-1] * ((-len(cols)) % 16)
+        cols = np.asarray(cols, dtype=np.int64)
+        K16 = len(cols)
+        k = np.arange(K16)[:, None]
+        o = np.arange(OUT)[None, :]
+        pos = (k >> 4) * 2048 + o * 16 + (k & 15)
+        src = self._w(name, o + 0 * k, cols[:, None] + 0 * o)
+        flat = np.empty(K16 * OUT, dtype=np.int64)
+        flat[pos.reshape(-1)] = src.reshape(-1)
+        off = self._alloc(K16 * OUT)
+        self._put(off, flat)
+        self._fwd_only.append((off, K16 * OUT))
+        return off
+
+    def _wq16(self, name: str, cols: Sequence[int]) -> int:
+        """WQ16 (include/pfm_hip.h): OUT <= 16, K = 128: float (k>>4)*256 + o*16 + (k&15); forward-only second copy."""
+        OUT = self._out[name]
+        cols = np.asarray(list(cols), dtype=np.int64)
+        assert OUT <= 16 and len(cols) == PFM_HIDDEN
+        flat = np.full(PFM_HIDDEN * 16, self.zero_off, dtype=np.int64)
+        k = np.arange(PFM_HIDDEN)[:, None]
+        o = np.arange(OUT)[None, :]
+        pos = (k >> 4) * 256 + o * 16 + (k & 15)
+        flat[pos.reshape(-1)] = self._w(name, o + 0 * k, cols[:, None] + 0 * o).reshape(-1)
+        off = self._alloc(PFM_HIDDEN * 16)
+        self._put(off, flat)
+        self._fwd_only.append((off, PFM_HIDDEN * 16))
+        return off
+
     def _plain_kmajor(self, name: str, cols: Sequence[int]) -> int:
         """plain K-major [K][OUT] (fc_l1's particle block, fc_l3's extras)"""
         OUT = self._out[name]
@@ -304,6 +343,7 @@ class EpicLayout:
         self._segments: List[Tuple[int, np.ndarray]] = []
         self._local_blocks: List[Tuple[str, int, int, int]] = []
         self._a16_blocks: List[Tuple[int, int, int]] = []  # (fp32 MFMA_A offset, MFMA_A16 offset, output slices w)
+        self._fwd_only: List[Tuple[int, int]] = []  # (offset, floats) of second copies that carry no gradient (KQ16 / WQ16)
         d = EpicDesc()
         d.abi_version = PFM_ABI_VERSION
         d.n_points, d.features, d.hidden, d.latent, d.layers = cfg.num_particles, F, H, L, cfg.layers
@@ -332,6 +372,9 @@ class EpicLayout:
         # fc_g2: [t_g ; g(H) ; c_g] -> [temb ; cond ; g1]
         d.g2.W = self._kmajor("fc_g2", tcols(Tg) + list(range(Tg + H, Tg + H + Cg)) + list(range(Tg, Tg + H)))
         d.g2.b = self._bias("fc_g2")
+        # the lean sampler's copies (KQ16 / WQ16) without the time / conditioning rows: [mean ; sum], g1
+        d.q_g1 = self._kq16("fc_g1", list(range(Tg + H, Tg + 2 * H)) + list(range(Tg, Tg + H)))
+        d.q_g2 = self._wq16("fc_g2", range(Tg, Tg + H))
         for k in range(cfg.layers):
             p = f"nn_list.{k}."
             ly = d.layer[k]
@@ -351,6 +394,9 @@ class EpicLayout:
             )
             # fc_local2: [t_l ; l1(H) ; c_l]
             ly.lc2 = self._local(p + "fc_local2", tcols(Tl), Tl, range(Tl + H, Tl + H + Cl))
+            d.q_gl1[k] = self._kq16(p + "fc_global1", range(Tg, Tg + 2 * H + L))   # [mean ; sum ; g]
+            d.q_gl2[k] = self._wq16(p + "fc_global2", range(Tg, Tg + H))
+            d.q_we1[k] = self._kq16(p + "fc_local1", range(Tl + H, Tl + H + L))     # the g rows of the extras
         # fc_l3: [t_l ; x(H) ; c_l]; particle block row-major [F][H]
         d.l3_W = self._alloc(F * H)
         self._put(d.l3_W, self._w("fc_l3", np.arange(F)[:, None], Tl + np.arange(H)[None, :]))
@@ -390,6 +436,8 @@ class EpicLayout:
             if offAT >= 0:
                 gmap[offAT : offAT + H * H] = self.zero_off
         gmap[d.l3_A : d.l3_A + 2048] = self.zero_off  # forward-only copy of fc_l3's particle block
+        for off, n in self._fwd_only:  # KQ16 / WQ16 copies
+            gmap[off : off + n] = self.zero_off
         self.grad_index_map = gmap
         # inverse maps, per source element (weights then biases): where it lands in the blob (one or two places:
         # MFMA_A and MFMA_AT), and the single place of the gradient blob that carries its gradient

@@ -61,10 +61,23 @@ for k in sorted(acc):
     if "SQ_LDS_BANK_CONFLICT" in e and e.get("SQ_BUSY_CYCLES", 0) > 0:
         e["lds_conflict_share_of_busy"] = e["SQ_LDS_BANK_CONFLICT"] / e["SQ_BUSY_CYCLES"]
     out[k] = e
+# whole-run totals (sampling-only runs of collect_pmc_rowmatrix.sh: PFM_PMC_EVALS = network evaluations of the profiled call)
+tot_f = sum(acc[k].get("FETCH_SIZE", 0.0) for k in acc)
+tot_w = sum(acc[k].get("WRITE_SIZE", 0.0) for k in acc)
+if tot_f or tot_w:
+    evals = int(os.environ.get("PFM_PMC_EVALS", "0"))
+    out["_totals"] = {"FETCH_SIZE_KiB": tot_f, "WRITE_SIZE_KiB": tot_w, "hbm_bytes": (2 * tot_f + tot_w) * 1024.0,
+                      "launches": int(sum(cnt[k].get("FETCH_SIZE", 0) for k in cnt)),
+                      "duration_ns": sum(acc[k].get("duration_ns", 0.0) for k in acc) / max(1, len([c for c in ("a", "b", "c", "d") if os.path.isdir(os.path.join(root, c))])),
+                      "evaluations": evals,
+                      "hbm_bytes_per_evaluation": (2 * tot_f + tot_w) * 1024.0 / evals if evals else None,
+                      "note": "sums over EVERY pfm:: launch of the run (HBM-side bytes = 2 x FETCH_SIZE + WRITE_SIZE KiB, gfx950 correction)"}
 out["_note"] = ("averages per launch over the launches of `python3 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline` under "
                 "rocprofv3 --pmc (tests/diag/collect_pmc_sq.sh; dispatches serialised: every launch alone on the GPU).  Units and the "
                 "derived fields: tests/diag/pmc_sq_summary.py")
 json.dump(out, open(os.path.join(root, "pmc_sq_summary.json"), "w"), indent=1, sort_keys=True)
+if "_totals" in out:
+    print("_totals", out["_totals"])
 for k, e in out.items():
     if k.startswith("_"):
         continue

@@ -82,3 +82,29 @@ def test_blob_gradient_reaches_weight_norm_params(golden):
             continue
         scale = max(st2[k].grad.abs().max().item(), 1e-8)
         assert (state[k].grad - st2[k].grad).abs().max().item() <= 5e-5 * scale + 1e-7, k
+
+
+def test_kq16_wq16_copies_hold_the_same_weights_as_the_km16_blocks(golden):
+    """The lean sampler's chains read second copies of the per-jet GEMV blocks (KQ16 / WQ16, include/pfm_hip.h): element for element
+    the weights the KM16 / KP16 blocks carry behind their time (and conditioning) rows; forward-only (no gradient slot points there)."""
+    lay = EpicLayout(cfg_of(golden.hp))
+    blob = lay.pack_blob(golden.state, "flows.0.net.", freqs=golden.freqs).numpy()
+    d, cfg = lay.desc, lay.cfg
+    T, C, H, L = cfg.t_dim, cfg.global_cond_dim, 128, cfg.latent
+    km16 = lambda off, k, o: blob[off + ((k >> 4) * 32 + (o >> 2)) * 64 + (k & 15) * 4 + (o & 3)]
+    kq16 = lambda off, k, o: blob[off + (k >> 4) * 2048 + o * 16 + (k & 15)]
+    kp16 = lambda off, k, o: blob[off + k * 16 + o]
+    wq16 = lambda off, k, o: blob[off + (k >> 4) * 256 + o * 16 + (k & 15)]
+    k272, o128 = np.arange(2 * H + 16)[:, None], np.arange(H)[None, :]
+    k128, o16 = np.arange(H)[:, None], np.arange(16)[None, :]
+    assert np.array_equal(kq16(d.q_g1, k272[: 2 * H], o128), km16(d.g1.W, T + C + k272[: 2 * H], o128))
+    assert np.array_equal(wq16(d.q_g2, k128, o16), kp16(d.g2.W, T + C + k128, o16))
+    for layer in range(d.layers):
+        ly = d.layer[layer]
+        assert np.array_equal(kq16(d.q_gl1[layer], k272[: 2 * H + L], o128), km16(ly.gl1.W, T + C + k272[: 2 * H + L], o128))
+        assert np.array_equal(wq16(d.q_gl2[layer], k128, o16), kp16(ly.gl2.W, T + C + k128, o16))
+        kg = np.arange(L)[:, None]
+        assert np.array_equal(kq16(d.q_we1[layer], kg, o128), km16(ly.lc1.We, T + cfg.local_cond_dim + kg, o128))
+        assert np.any(kq16(d.q_gl1[layer], k272, o128) != 0) and np.all(kq16(d.q_gl1[layer], k272[2 * H + L:], o128) == 0)  # g padded to 16 rows
+    for off in (d.q_g1, d.q_g2, d.q_gl1[0], d.q_gl2[0], d.q_we1[0]):
+        assert off % 4 == 0 and np.all(lay.grad_index_map[off: off + 2048] == lay.zero_off)

@@ -101,7 +101,8 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.pfm_abi_version() == 2
+    from particle_fm_amd.layout import PFM_ABI_VERSION
+    assert lib.pfm_abi_version() == PFM_ABI_VERSION == 3
     from particle_fm_amd.layout import EpicConfig, EpicDesc, EpicLayout
     lay = EpicLayout(EpicConfig(num_particles=150, features=3, latent=10, layers=6, frequencies=16, t_local_cat=True,
                                 t_global_cat=True))
