@@ -41,6 +41,11 @@
  *                    p = k >> 4 at float  p*2048 + o*16 + (k&15): thread t of 512 reads float4 number t of a panel and holds FOUR
  *                    CONSECUTIVE k of ONE output, W[o = t>>2][16p + 4(t&3) .. + 3] -- a thread's partial sum needs one add and a
  *                    4-lane (quad) reduction instead of a 16-lane tree over four accumulators.
+ *   CH16             (round 4; bf16 descriptors) the per-jet blocks once more as bf16 A operands of v_mfma_f32_16x16x32_bf16 for the
+ *                    lean bf16 sampler's chains, which run on the matrix pipe with the workgroup's JETS as the B operand's columns:
+ *                    16-byte unit ((w*NK + kt)*64 + lane) holds W[16w + (lane&15)][32kt + 8(lane>>4) + e], e = 0..7 (rows >= K zero),
+ *                    w = output slice (8 for OUT = 128, 1 for OUT <= 16), NK = ceil(K / 32).  Filled from the KQ16 / WQ16 copies by
+ *                    pfm_epic_pack_a16 (round-to-nearest-even).
  *   WQ16             the same idea for OUT <= 16, K = 128: float (k>>4)*256 + o*16 + (k&15); wave w reads chunk w, lane l float4
  *                    number l = W[o = l>>2][16w + 4(l&3) .. + 3]  (outputs >= OUT are zero).
  *   MFMA_A           the H x H block that multiplies the per-particle activations, pre-arranged as the
@@ -157,6 +162,9 @@ typedef struct pfm_epic_desc {
     int64_t q_gl1[PFM_MAX_LAYERS];   /* fc_global1 rows [mean ; sum ; g] : KQ16, 17 panels (g zero-padded to 16 rows) */
     int64_t q_gl2[PFM_MAX_LAYERS];   /* fc_global2 rows of g1            : WQ16 */
     int64_t q_we1[PFM_MAX_LAYERS];   /* fc_local1  extras rows of g      : KQ16, 1 panel */
+    /* the same five blocks as CH16 (bf16 descriptors; 0 floats used otherwise): NK = 8 / 4 / 9 / 4 / 1 */
+    int64_t b_g1, b_g2;
+    int64_t b_gl1[PFM_MAX_LAYERS], b_gl2[PFM_MAX_LAYERS], b_we1[PFM_MAX_LAYERS];
 } pfm_epic_desc;
 
 #define PFM_DESC_FLOATS ((int64_t)((sizeof(pfm_epic_desc) + 15) / 16 * 4))

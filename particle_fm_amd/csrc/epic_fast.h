@@ -32,6 +32,9 @@
 
 namespace pfm {
 
+#ifndef PFM_BCHAIN
+#define PFM_BCHAIN 1          // bf16 descriptors: the lean sampler's chains on the matrix pipe (diagnostic builds: 0 = the fp32 VALU chains)
+#endif
 #ifndef PFM_QCHAIN_MINSEG
 #define PFM_QCHAIN_MINSEG 1   // jets per workgroup from which the chains run on the KQ16 / WQ16 copies (diagnostic builds: 2, 5 = never)
 #endif
@@ -131,13 +134,15 @@ __device__ __forceinline__ ChainLoads fast_chain_loads(blob_rsrc rs, int64_t gl2
     return L;
 }
 // a barrier must separate this from the previous chain's last read of tbl, and another one from the next chain's reads
-__device__ __forceinline__ void fast_chain_publish(const ChainLoads& L, float* __restrict__ tbl) {
+template <typename CL>
+__device__ __forceinline__ void fast_chain_publish(const CL& L, float* __restrict__ tbl) {
     const int tid = launder(threadIdx.x);
     if (tid < 68) *reinterpret_cast<f32x4*>(tbl + (tid < 64 ? 4 * tid : TBL_G2 + 4 * (tid - 64))) = L.stg;
 }
 // conditioned jets: the local-linear-2 bias row of threads 68..99 -> bj2.  Readers (the particle phase) must lie behind a later barrier,
 // the previous phase's reads of bj2 behind an earlier one.
-__device__ __forceinline__ void fast_chain_publish_l2(const ChainLoads& L, float* __restrict__ bj2) {
+template <typename CL>
+__device__ __forceinline__ void fast_chain_publish_l2(const CL& L, float* __restrict__ bj2) {
     const int tid = launder(threadIdx.x);
     if (tid >= 68 && tid < 100) *reinterpret_cast<f32x4*>(bj2 + 4 * (tid - 68)) = L.stg;
 }
@@ -448,6 +453,139 @@ __device__ __forceinline__ void fastq_chain_layer(const JetDims& j, float* __res
     wave_lds_sync();
 }
 
+// ---- round 4: the chains of the bf16 flavour ON THE MATRIX PIPE, the workgroup's jets as columns (CH16 blocks, include/pfm_hip.h) ---------
+// tests/diag/ab_cfg2.py: the seven chains were 4.3 of the 11.4 ms of the cfg-2 bf16 sampler (four jets per workgroup: every VALU
+// instruction of a chain once per jet, its LDS round trips once per step).  Under the reference's bf16-mixed precision every nn.Linear
+// runs in bf16 -- the global MLP's too -- so for bf16 descriptors the three per-jet Linears of a chain are v_mfma_f32_16x16x32_bf16
+// products  out^T [16 outputs x 16 columns] += W [16 x 32 k] . v [32 k x 16 columns]  with column c = jet c of the workgroup (one, two or
+// four real columns; the others repeat them and are never stored): fc_global1 is 9 MFMAs per wave for ALL jets instead of 34 packed FMAs +
+// a 16-lane reduction tree per jet, fc_global2 4 MFMAs (every wave computes all 16 outputs: no wave partials), the bias GEMV 1.  A column's
+// result does not depend on the others: one, two and four jets per workgroup give the same bits (tests/test_hip_packed.py).
+// Operand vectors live in LDS as bf16 (fp32 accumulate; bias, residual, LeakyReLU in fp32):
+//   vin  + [0, 144) floats : [mean (128) ; sum (128) ; g (16) ; 0 (16)] bf16, mean / sum written by pool_finish<.., VB16>, g by the chain
+//   vin  + FT + 2H         : g as fp32 (the residual of the next chain)
+//   vin2 + [0, 64)         : g1 (128) bf16
+//   gcopy + 16 w + [0, 8)  : wave w's copy of g_new (16) bf16
+constexpr int FNB = 9, FNBS = 8;  // K tiles of fc_global1 ([mean ; sum ; g] = 272 -> 288 rows) / fc_g1 ([mean ; sum] = 256 rows)
+struct ChainLoadsB {
+    f32x4 w2[4];  // fc_global2 as CH16: unit kt * 64 + lane (the same for every wave)
+    f32x4 stg;    // as ChainLoads
+};
+__device__ __forceinline__ ChainLoadsB fastb_chain_loads(blob_rsrc rs, int64_t b_gl2, const float* __restrict__ slot, int o_g1, int o_l1,
+                                                        int o_g2, int o_l2) {
+    const int tid = launder(threadIdx.x), lane = tid & 63;
+    ChainLoadsB L;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) L.w2[kt] = bload4(rs, b_gl2 + kt * 256, lane * 16);
+    L.stg = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 100) {
+        const int off = tid < 32 ? o_g1 + 4 * tid : (tid < 64 ? o_l1 + 4 * (tid - 32) : (tid < 68 ? o_g2 + 4 * (tid - 64) : o_l2 + 4 * (tid - 68)));
+        L.stg = *reinterpret_cast<const f32x4*>(slot + off);
+    }
+    return L;
+}
+// LDS float offsets of the jet this lane's column stands for (column c -> jet c & (NSEG - 1)), and whether the column is a real one
+struct ColView {
+    int vin, vin2, gcopy, bj1;
+    bool real;
+};
+template <int NSEG, int NSV>
+__device__ __forceinline__ ColView fastb_col_view(const SegView (&sv)[NSV]) {
+    const int col = launder(threadIdx.x) & 15;
+    ColView v{sv[0].vin, sv[0].vin2, sv[0].gcopy, sv[0].bj1, col < NSEG};
+    if constexpr (NSEG == 2) {
+        if (col & 1) { v.vin = sv[1].vin; v.vin2 = sv[1].vin2; v.gcopy = sv[1].gcopy; v.bj1 = sv[1].bj1; }
+    } else if constexpr (NSEG == 4) {
+        // the views of jets 1 .. 3 are equally spaced (quad_view): arithmetic, not a select chain over sv[] -- hipcc turns that into a
+        // lane-indexed load of the array and the views end up in scratch memory
+        const int s = col & 3, st = sv[2].vin - sv[1].vin, k = (s > 0 ? s - 1 : 0) * st;
+        if (s > 0) { v.vin = sv[1].vin + k; v.vin2 = sv[1].vin2 + k; v.gcopy = sv[1].gcopy + k; v.bj1 = sv[1].bj1 + k; }
+    }
+    return v;
+}
+// g1 = lrelu(W1 . v + t1) -> vin2 (bf16); NK K-tiles from `gl` (CH16 fragments of this wave's 16 outputs)
+template <int NK>
+__device__ __forceinline__ void fastb_g1(const JetDims& j, float* __restrict__ lds, const ColView& cv, const f32x4 (&gl)[FNB],
+                                         const float* __restrict__ tbl) {
+    const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6, q = lane >> 4;
+    const float* vb = lds + cv.vin + 4 * q;  // bf16 element 32 kt + 8 q = float 16 kt + 4 q
+    bf16x8 b[NK];
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) b[kt] = *reinterpret_cast<const bf16x8*>(vb + 16 * kt);
+    f32x4 acc0 = *reinterpret_cast<const f32x4*>(tbl + TBL_G1 + 16 * w + 4 * q), acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: a dependent MFMA waits
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+        if (kt & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gl[kt]), b[kt], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gl[kt]), b[kt], acc0, 0, 0, 0);
+    }
+    const f32x4 g1 = lrelu4(acc0 + acc1, j.slope);
+    if (cv.real) *reinterpret_cast<s16x4*>(lds + cv.vin2 + 8 * w + 2 * q) = pack_bf16(g1);  // bf16 element 16 w + 4 q
+}
+// W2 . g1 + t2 for this lane's four outputs (4 q ..) of its column's jet; every wave computes all sixteen
+__device__ __forceinline__ f32x4 fastb_g2(float* __restrict__ lds, const ColView& cv, const f32x4 (&w2)[4], const f32x4& t2) {
+    const int q = (launder(threadIdx.x) & 63) >> 4;
+    const float* gb = lds + cv.vin2 + 4 * q;
+    bf16x8 b[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) b[kt] = *reinterpret_cast<const bf16x8*>(gb + 16 * kt);
+    f32x4 acc0 = t2, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        if (kt & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2[kt]), b[kt], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2[kt]), b[kt], acc0, 0, 0, 0);
+    }
+    return acc0 + acc1;
+}
+// wave 0 publishes g_new: fp32 (next residual) and bf16 (next fc_global1 operand)
+__device__ __forceinline__ void fastb_publish_g(float* __restrict__ lds, const ColView& cv, const f32x4& gn) {
+    const int tid = launder(threadIdx.x), q = (tid & 63) >> 4;
+    if (tid < 64 && cv.real) {
+        *reinterpret_cast<f32x4*>(lds + cv.vin + FT + 2 * H + 4 * q) = gn;
+        *reinterpret_cast<s16x4*>(lds + cv.vin + 128 + 2 * q) = pack_bf16(gn);  // bf16 element 256 + 4 q
+    }
+}
+
+// Stem chain on the matrix pipe (contract: fast_chain_stem).  gl = the 8 K-tiles of b_g1.
+template <int NSEG, int NSV, typename After, typename Publish>
+__device__ __forceinline__ void fastb_chain_stem(const JetDims& j, float* __restrict__ lds, const SegView (&sv)[NSV], const f32x4 (&gl)[FNB],
+                                                 const ChainLoadsB& L, const float* __restrict__ tbl, After after_fc1, Publish publish_next) {
+    const ColView cv = fastb_col_view<NSEG>(sv);
+    const f32x4 t2 = *reinterpret_cast<const f32x4*>(tbl + TBL_G2 + 4 * ((launder(threadIdx.x) & 63) >> 4));  // every read of this chain's
+    fastb_g1<FNBS>(j, lds, cv, gl, tbl);                                                                       // table rows: before the barrier
+    after_fc1();
+    __syncthreads();  // every wave's slice of g1
+    publish_next();
+    fastb_publish_g(lds, cv, lrelu4(fastb_g2(lds, cv, L.w2, t2), j.slope));
+    __syncthreads();
+}
+
+// Layer chain on the matrix pipe (contract: fast_chain_layer).  gl = the 9 K-tiles of b_gl1, wbA = this wave's unit of b_we1.
+template <int NSEG, int NSV>
+__device__ __forceinline__ void fastb_chain_layer(const JetDims& j, float* __restrict__ lds, const Carve& c, const SegView (&sv)[NSV],
+                                                  const f32x4 (&gl)[FNB], const f32x4& wbA, const ChainLoadsB& L, const float* __restrict__ tbl) {
+    const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6, q = lane >> 4;
+    const ColView cv = fastb_col_view<NSEG>(sv);
+    const f32x4 gold = *reinterpret_cast<const f32x4*>(lds + cv.vin + FT + 2 * H + 4 * q);  // before wave 0 overwrites it (behind the barrier)
+    const f32x4 t2 = *reinterpret_cast<const f32x4*>(tbl + TBL_G2 + 4 * q);
+    f32x4 bl = *reinterpret_cast<const f32x4*>(tbl + TBL_L1 + 16 * w + 4 * q);
+    fastb_g1<FNB>(j, lds, cv, gl, tbl);
+    __syncthreads();  // every wave's slice of g1 -- the chain's only barrier
+    f32x4 gn = fastb_g2(lds, cv, L.w2, t2);
+    gn += gold;  // residual before the activation, epic.py:184-186 (t2 is the accumulator's start value)
+    gn = lrelu4(gn, j.slope);
+    fastb_publish_g(lds, cv, gn);
+    // this wave's copy of g_new as the bias GEMV's operand: k = 8 q .. 8 q + 7 for q < 2, zeros behind row 16
+    float* gc = lds + cv.gcopy + MAXL * w;
+    if (cv.real) *reinterpret_cast<s16x4*>(gc + 2 * q) = pack_bf16(gn);
+    wave_lds_sync();
+    f32x4 braw = *reinterpret_cast<const f32x4*>(gc + 4 * (q & 1));
+    if (q >= 2) braw = f32x4{0.f, 0.f, 0.f, 0.f};
+    bl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wbA), __builtin_bit_cast(bf16x8, braw), bl, 0, 0, 0);
+    if (cv.real) *reinterpret_cast<f32x4*>(lds + cv.bj1 + 16 * w + 4 * q) = bl;  // wave w: bj1[16 w ..], the slice its own particle phase reads
+    if (L2LDS) fast_chain_publish_l2(L, lds + c.bj2);
+    wave_lds_sync();
+}
+
 // fc_l3 head with its per-jet bias from the table and its weights already in registers (requested during the last particle
 // phase).  emit(p, f, lrelu(b3[f] + W3[f].x[p]) * mask[p]) for the rows p < n_rows ONLY: the sampler's state rows behind a jet's
 // last valid particle start as z * mask = 0 and an update by 0 would leave them there.  epic.py:387-391
@@ -551,15 +689,17 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
                                           const float* __restrict__ ct = nullptr) {
     static_assert(!(COND && NSEG != 1), "conditioned jets: one jet per workgroup");
     static_assert(NSEG != 4 || L2LDS, "quad mode reads the shared biases from c.bj2");
-    constexpr int NGL = COND ? FNGC : FNG, NGLS = COND ? FNGS + 1 : FNGS;
+    constexpr bool BCH = BF16 && !COND && PFM_BCHAIN;  // bf16 descriptors: the chains on the matrix pipe (fastb_chain_*)
+    constexpr int NGL = COND ? FNGC : (BCH ? FNB : FNG), NGLS = COND ? FNGS + 1 : (BCH ? FNBS : FNGS);
     constexpr int AF = FastCarry<BF16>::AF;
+    using CLoads = std::conditional_t<BCH, ChainLoadsB, ChainLoads>;
     // Chains on the KQ16 / WQ16 copies (fastq_chain_*) for every unconditioned instantiation.  Same-box A/B (tests/diag/ab_cfg2.py,
     // ab_time.py; libraries built with -DPFM_QCHAIN_MINSEG=1 / 5): two jets per workgroup (cfg-2 fp32) 28.3 -> 27.0 ms; four jets
     // unchanged in time but without the scratch the KM16 chain's four-jet instantiation needed (44 B per lane bf16, 192 B fp32 -> 0);
     // ONE jet 1.4 % slower at 2 tiles, equal from 4 tiles on, +0.2 % on the bench mix: a single jet's chain is bound by its LDS
     // round trips, not by its instruction count, and the float4 reads move four times the bytes.  All of them take it, because one,
     // two and four jets per workgroup must give the same bits (tests/test_hip_packed.py).
-    constexpr bool QCH = !COND && NSEG >= PFM_QCHAIN_MINSEG;
+    constexpr bool QCH = !COND && !BCH && NSEG >= PFM_QCHAIN_MINSEG;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr int NSV = NSEG == 4 ? 4 : 2;
     SegView sv[NSV];
@@ -594,23 +734,32 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     f32x4 gl[NGL], wbA[1];
     PFM_STAMP(1);
     float* tbl = lds + c.total;  // TBL_FLOATS behind the carve (fast_path_ok: it fits)
+    if constexpr (BCH) {  // rows 272 .. 287 of every jet's bf16 chain vector: zero weights there, but 0 x (stale NaN bits) is NaN
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s)  // (static indices only: a lane-indexed sv[] would put the views into scratch memory)
+            if ((tid >> 3) == s) lds[sv[s].vin + 136 + (tid & 7)] = 0.f;
+    }
     // Unconditioned jets run their chains on the KQ16 / WQ16 copies of the per-jet blocks (fastq_chain_*, round 4), conditioned ones on
     // the KM16 / KP16 blocks behind the time panels (fast_chain_*): where a chain's register windows and loads come from
     auto gl1_seg = [&](int k) {
-        if constexpr (!QCH) return seg_panels(d.layer[k].gl1.W, FTP, tid);
+        if constexpr (BCH) return PfSeg{d.b_gl1[k], 256, ((w * FNB) * 64 + lane) * 16};
+        else if constexpr (!QCH) return seg_panels(d.layer[k].gl1.W, FTP, tid);
         else return seg_panels(d.q_gl1[k], 0, tid);
     };
     auto we1_seg = [&](int k) {
-        if constexpr (!QCH) return seg_panels(d.layer[k].lc1.We, FTP, tid);
+        if constexpr (BCH) return PfSeg{d.b_we1[k], 256, (w * 64 + lane) * 16};
+        else if constexpr (!QCH) return seg_panels(d.layer[k].lc1.We, FTP, tid);
         else return seg_panels(d.q_we1[k], 0, tid);
     };
     auto layer_chain_loads = [&](int k, const float* __restrict__ tb) {
-        if constexpr (!QCH) return fast_chain_loads(rs, d.layer[k].gl2.W, w2r0, tb, TB_G1, TB_L1, TB_G2, COND ? ct + (size_t)k * TB_SLOT : nullptr, TB_L2);
+        if constexpr (BCH) return fastb_chain_loads(rs, d.b_gl2[k], tb, TB_G1, TB_L1, TB_G2, TB_L2);
+        else if constexpr (!QCH) return fast_chain_loads(rs, d.layer[k].gl2.W, w2r0, tb, TB_G1, TB_L1, TB_G2, COND ? ct + (size_t)k * TB_SLOT : nullptr, TB_L2);
         else return fastq_chain_loads(rs, d.q_gl2[k], tb, TB_G1, TB_L1, TB_G2, TB_L2);
     };
     // the stem chain's own loads, two phases ahead of their use (conditioned jets: with fc_l2's bias row for c.bj2)
-    ChainLoads L;
-    if constexpr (!QCH) L = fast_chain_loads(rs, d.g2.W, w2r0, tbS, TB_SG1, TB_SG1, TB_SG2, ctS, TB_SJ2);
+    CLoads L;
+    if constexpr (BCH) L = fastb_chain_loads(rs, d.b_g2, tbS, TB_SG1, TB_SG1, TB_SG2, TB_SJ2);
+    else if constexpr (!QCH) L = fast_chain_loads(rs, d.g2.W, w2r0, tbS, TB_SG1, TB_SG1, TB_SG2, ctS, TB_SJ2);
     else L = fastq_chain_loads(rs, d.q_g2, tbS, TB_SG1, TB_SG1, TB_SG2, TB_SJ2);
 #ifndef PFM_AB_NOL1  // (PFM_AB_*: timing-only ablation builds of tests/diag/fixed_cost_table.sh; results are garbage)
     fast_stem_l1(j, lds, c, n_rows, cy.aw, cy.sj1);
@@ -623,10 +772,10 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     PFM_STAMP(3);
     // ---- fc_l2: bufB = lrelu(W.bufA + bj2 + bufA), pooled -> vin   epic.py:364-371; carries the stem chain's fc_g1 rows
     {
-        Prefetch<NGLS> pf{rs, gl, nullptr, nullptr, nullptr, !QCH ? seg_panels(d.g1.W, FTP, tid) : seg_panels(d.q_g1, 0, tid), {}, {}, {}};
+        Prefetch<NGLS> pf{rs, gl, nullptr, nullptr, nullptr, BCH ? PfSeg{d.b_g1, 256, ((w * FNBS) * 64 + lane) * 16} : (!QCH ? seg_panels(d.g1.W, FTP, tid) : seg_panels(d.q_g1, 0, tid)), {}, {}, {}};
         const float* bj = (COND || L2LDS) ? lds + c.bj2 : tbS + TB_SJ2;
         s2t.bj = bj;
-        gemm_phase<true, true, false, BF16, decltype(pf), NSEG>(cy.a2, bufA, bufB, bufA, bj, maskf, j, lds, c, nullptr, nullptr, n_rows, pf,
+        gemm_phase<true, true, false, BF16, decltype(pf), NSEG, true, AF, BCH>(cy.a2, bufA, bufB, bufA, bj, maskf, j, lds, c, nullptr, nullptr, n_rows, pf,
                                                                  s2t, &qpt);
     }
     if (!(COND || L2LDS)) fast_chain_publish(L, tbl);  // (the previous evaluation's last chain read tbl many barriers ago)
@@ -634,7 +783,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     PFM_STAMP(4);
     {
         const pfm_epic_layer& l0 = d.layer[0];
-        ChainLoads L0;
+        CLoads L0;
         // the first layer's windows, phase-1 weights and chain loads: no particle phase to ride on; they land behind the rest of the stem chain
         auto first_layer_requests = [&]() {
             Prefetch<NGL, 1> pf{rs, gl, wbA, nullptr, nullptr, gl1_seg(0), we1_seg(0), {}, {}};
@@ -647,7 +796,8 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         fast_chain_publish(L0, tbl);
         __syncthreads();
 #else
-        if constexpr (!QCH) fast_chain_stem<NSEG, COND>(j, lds, sv, gl, L, tbl, first_layer_requests, [&]() { fast_chain_publish(L0, tbl); });
+        if constexpr (BCH) fastb_chain_stem<NSEG>(j, lds, sv, gl, L, tbl, first_layer_requests, [&]() { fast_chain_publish(L0, tbl); });
+        else if constexpr (!QCH) fast_chain_stem<NSEG, COND>(j, lds, sv, gl, L, tbl, first_layer_requests, [&]() { fast_chain_publish(L0, tbl); });
         else fastq_chain_stem<NSEG>(j, lds, sv, gl, L, tbl, first_layer_requests, [&]() { fast_chain_publish(L0, tbl); });
 #endif
         L = L0;
@@ -662,7 +812,8 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         const float* tbN = tbE + (size_t)(last ? k : k + 1) * TB_SLOT;
         PFM_STAMP(10);
 #ifndef PFM_AB_NOCHAIN
-        if constexpr (!QCH) fast_chain_layer<NSEG, COND>(j, lds, c, sv, gl, wbA[0], L, tbl);
+        if constexpr (BCH) fastb_chain_layer<NSEG>(j, lds, c, sv, gl, wbA[0], L, tbl);
+        else if constexpr (!QCH) fast_chain_layer<NSEG, COND>(j, lds, c, sv, gl, wbA[0], L, tbl);
         else fastq_chain_layer<NSEG>(j, lds, c, sv, gl, wbA[0], L, tbl);
 #else
         if (COND || L2LDS) fast_chain_publish_l2(L, lds + c.bj2);
@@ -693,7 +844,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
             Prefetch<AF> pf{rs, cy.a1, nullptr, nullptr, nullptr, sa, {}, {}, {}};
             const float* bj = (COND || L2LDS) ? lds + c.bj2 : tbK + TB_L2;
             s2t.bj = bj;
-            gemm_phase<true, true, false, BF16, decltype(pf), NSEG, false>(cy.a2, bufA, bufB, bufB, bj, maskf, j, lds, c, nullptr, nullptr, n_rows,
+            gemm_phase<true, true, false, BF16, decltype(pf), NSEG, false, AF, BCH>(cy.a2, bufA, bufB, bufB, bj, maskf, j, lds, c, nullptr, nullptr, n_rows,
                                                                             pf, s2t, &qpt);
             // this layer's chain read tbl two barriers ago; the next one reads it behind the barrier below.  The publish waits for the
             // staged row with a vmcnt that covers every load issued before it: the riders a short jet had no K-quarter for go behind it

@@ -768,6 +768,35 @@ __global__ __launch_bounds__(NT) void epic_a16_pack_kernel(float* __restrict__ b
     }
 }
 
+// CH16 copies (pfm_hip.h) of the per-jet blocks, from their KQ16 / WQ16 copies: grid 2 + 3 layers (fc_g1, fc_g2, then fc_global1,
+// fc_global2 and the g rows of fc_local1's extras of every layer); 512 threads.
+__global__ __launch_bounds__(NT) void epic_ch16_pack_kernel(float* __restrict__ blob, int64_t desc_off) {
+    const pfm_epic_desc& d = *reinterpret_cast<const pfm_epic_desc*>(blob + desc_off);
+    const int b = blockIdx.x;
+    int64_t src, dst;
+    int rows, nk, nw;
+    bool kq;
+    if (b == 0) { src = d.q_g1; dst = d.b_g1; rows = 2 * H; nk = 8; nw = 8; kq = true; }
+    else if (b == 1) { src = d.q_g2; dst = d.b_g2; rows = H; nk = 4; nw = 1; kq = false; }
+    else {
+        const int k = (b - 2) / 3, which = (b - 2) % 3;
+        if (which == 0) { src = d.q_gl1[k]; dst = d.b_gl1[k]; rows = 2 * H + 16; nk = 9; nw = 8; kq = true; }
+        else if (which == 1) { src = d.q_gl2[k]; dst = d.b_gl2[k]; rows = H; nk = 4; nw = 1; kq = false; }
+        else { src = d.q_we1[k]; dst = d.b_we1[k]; rows = 16; nk = 1; nw = 8; kq = true; }
+    }
+    for (int u = threadIdx.x; u < nw * nk * 64; u += NT) {  // u = (w * nk + kt) * 64 + lane
+        const int lane = u & 63, wk = u >> 6, w = wk / nk, kt = wk - w * nk;
+        const int o = 16 * w + (lane & 15), k0 = 32 * kt + 8 * (lane >> 4);  // eight consecutive rows: inside one 16-row panel
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+        if (k0 < rows) {
+            const float* p = blob + src + (kq ? (int64_t)(k0 >> 4) * 2048 + o * 16 + (k0 & 15) : (int64_t)(k0 >> 4) * 256 + o * 16 + (k0 & 15));
+            lo = *reinterpret_cast<const f32x4*>(p);
+            hi = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+        *reinterpret_cast<bf16x8*>(blob + dst + (int64_t)u * 4) = pack_bf16x8(lo, hi);
+    }
+}
+
 // which matrix-pipe flavour the inference kernels use (descriptor flags): 0 fp32, 1 bf16 operands, 2 split fp16
 int mfma_mode(const pfm_epic_desc* d) {
     if (!d) return 0;
@@ -801,6 +830,8 @@ int pfm_epic_pack_a16(const pfm_epic_desc* d, float* blob, void* stream) {
     if (!blob) return set_err(PFM_E_BADARG, "NULL device pointer");
     if (d->l2.A16 <= 0 || d->l3_A16 <= 0) return set_err(PFM_E_BADARG, "descriptor without MFMA_A16 offsets");
     hipLaunchKernelGGL(epic_a16_pack_kernel, dim3(2 * d->layers + 2), dim3(NT), 0, (hipStream_t)stream, blob, d->blob_floats);
+    if (d->b_g1 > 0)
+        hipLaunchKernelGGL(epic_ch16_pack_kernel, dim3(2 + 3 * d->layers), dim3(NT), 0, (hipStream_t)stream, blob, d->blob_floats);
     return check_hip(hipGetLastError(), "epic_a16_pack_kernel launch");
 }
 

@@ -121,7 +121,7 @@ __device__ __forceinline__ void load_afrag_m(f32x4 (&a)[8], blob_rsrc rs, int64_
 }
 
 
-template <bool SAVE>
+template <bool SAVE, bool VB16 = false>
 __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float* __restrict__ lds, int vin_off, int misc_off,
                                             int oslot, int pl, float* __restrict__ save_pool);
 
@@ -226,7 +226,7 @@ __device__ __forceinline__ int phase_full_pairs(int n_rows) {
 // TAIL = false: the caller issues pf.issue_tail(phase_full_pairs<BF16>(n_rows)) itself (behind work of its own that must not wait for
 // those loads: a vmcnt wait covers every load issued before it)
 // AF: float4 registers of the A operand: 8 (fp32 MFMA_A fragment; BF16: rounded here) or, BF16 only, 4 (an MFMA_A16 fragment)
-template <bool RESID, bool POOL, bool SAVE, bool BF16 = false, typename PF = PfNone, int NSEG = 1, bool TAIL = true, int AF = 8>
+template <bool RESID, bool POOL, bool SAVE, bool BF16 = false, typename PF = PfNone, int NSEG = 1, bool TAIL = true, int AF = 8, bool VB16 = false>
 __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __restrict__ src,
                                            float* __restrict__ dst, const float* __restrict__ resid,
                                            const float* __restrict__ bj, const float* __restrict__ maskf,
@@ -470,10 +470,10 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
         if constexpr (NSEG == 4) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                if (s < npairs) pool_finish<false>(psq[s], j, lds, qp->vin[s], qp->misc[s], oslot, pl, nullptr);
+                if (s < npairs) pool_finish<false, VB16>(psq[s], j, lds, qp->vin[s], qp->misc[s], oslot, pl, nullptr);
         } else {
-            pool_finish<SAVE>(psum, j, lds, c.vin, c.misc, oslot, pl, save_pool);
-            if (NSEG == 2) pool_finish<false>(psumB, j, lds, s2.vin1, s2.misc1, oslot, pl, nullptr);
+            pool_finish<SAVE, VB16>(psum, j, lds, c.vin, c.misc, oslot, pl, save_pool);
+            if (NSEG == 2) pool_finish<false, VB16>(psumB, j, lds, s2.vin1, s2.misc1, oslot, pl, nullptr);
         }
     }
 }
@@ -828,7 +828,9 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
 }
 
 // masked pooling tail of a particle phase: 16-lane tree, then mean / scaled sum straight into vin
-template <bool SAVE>
+// VB16 (the lean bf16 sampler's MFMA chains, epic_fast.h): mean / scaled sum go as bf16 into the jet's chain vector [mean (128) ; sum
+// (128) ; g (16) ; 0 (16)] at vin_off (it takes the place of the fp32 [temb ; cond ; mean ; sum] slots, which that path does not read)
+template <bool SAVE, bool VB16>
 __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float* __restrict__ lds, int vin_off, int misc_off,
                                             int oslot, int pl, float* __restrict__ save_pool) {
     psum = row_sum16(psum);
@@ -850,8 +852,13 @@ __device__ __forceinline__ void pool_finish(f32x4 psum, const JetDims& j, float*
             const float q = __fmul_rn(psum[i], rinv);
             mean[i] = __builtin_fmaf(__builtin_fmaf(-q, nvalid, psum[i]), rinv, q);
         }
-        *reinterpret_cast<f32x4*>(lds + vin_off + TC + 4 * oslot) = mean;
-        *reinterpret_cast<f32x4*>(lds + vin_off + TC + H + 4 * oslot) = psum * j.sscale;  // epic.py:162/:371
+        if constexpr (VB16) {
+            *reinterpret_cast<s16x4*>(lds + vin_off + 2 * oslot) = pack_bf16(mean);                  // bf16 element 4 oslot ..
+            *reinterpret_cast<s16x4*>(lds + vin_off + H / 2 + 2 * oslot) = pack_bf16(psum * j.sscale);  // bf16 element 128 + 4 oslot ..
+        } else {
+            *reinterpret_cast<f32x4*>(lds + vin_off + TC + 4 * oslot) = mean;
+            *reinterpret_cast<f32x4*>(lds + vin_off + TC + H + 4 * oslot) = psum * j.sscale;  // epic.py:162/:371
+        }
         if (SAVE) *reinterpret_cast<f32x4*>(save_pool + 4 * oslot) = psum;
     }
 }

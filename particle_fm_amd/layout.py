@@ -82,6 +82,11 @@ class EpicDesc(ctypes.Structure):
         ("q_gl1", ctypes.c_int64 * PFM_MAX_LAYERS),
         ("q_gl2", ctypes.c_int64 * PFM_MAX_LAYERS),
         ("q_we1", ctypes.c_int64 * PFM_MAX_LAYERS),
+        ("b_g1", ctypes.c_int64),
+        ("b_g2", ctypes.c_int64),
+        ("b_gl1", ctypes.c_int64 * PFM_MAX_LAYERS),
+        ("b_gl2", ctypes.c_int64 * PFM_MAX_LAYERS),
+        ("b_we1", ctypes.c_int64 * PFM_MAX_LAYERS),
     ]
 
 
@@ -273,6 +278,7 @@ class EpicLayout:
         off = self._alloc(K16 * OUT)
         self._put(off, flat)
         self._fwd_only.append((off, K16 * OUT))
+        self._ch16_rows[off] = K16  # rows the block really has (a CH16 copy pads to a multiple of 32 with zeros)
         return off
 
     def _wq16(self, name: str, cols: Sequence[int]) -> int:
@@ -288,6 +294,14 @@ class EpicLayout:
         off = self._alloc(PFM_HIDDEN * 16)
         self._put(off, flat)
         self._fwd_only.append((off, PFM_HIDDEN * 16))
+        return off
+
+    def _ch16(self, src_off: int, kind: str, K: int) -> int:
+        """CH16 (include/pfm_hip.h): bf16 A-operand copy of a KQ16 (kind "kq", OUT = 128) or WQ16 (kind "wq", OUT <= 16) block with K
+        real rows; like MFMA_A16 not part of the gather map: finish_blob / pfm_epic_pack_a16 fill it from the fp32 copy."""
+        nw, nk = (8 if kind == "kq" else 1), (K + 31) // 32
+        off = self._alloc(nw * nk * 64 * 4)
+        self._ch16_blocks.append((int(src_off), int(off), kind, nk))
         return off
 
     def _plain_kmajor(self, name: str, cols: Sequence[int]) -> int:
@@ -343,6 +357,8 @@ class EpicLayout:
         self._segments: List[Tuple[int, np.ndarray]] = []
         self._local_blocks: List[Tuple[str, int, int, int]] = []
         self._a16_blocks: List[Tuple[int, int, int]] = []  # (fp32 MFMA_A offset, MFMA_A16 offset, output slices w)
+        self._ch16_rows: Dict[int, int] = {}
+        self._ch16_blocks: List[Tuple[int, int, str, int]] = []  # (fp32 KQ16 / WQ16 offset, CH16 offset, "kq" | "wq", K tiles)
         self._fwd_only: List[Tuple[int, int]] = []  # (offset, floats) of second copies that carry no gradient (KQ16 / WQ16)
         d = EpicDesc()
         d.abi_version = PFM_ABI_VERSION
@@ -375,6 +391,8 @@ class EpicLayout:
         # the lean sampler's copies (KQ16 / WQ16) without the time / conditioning rows: [mean ; sum], g1
         d.q_g1 = self._kq16("fc_g1", list(range(Tg + H, Tg + 2 * H)) + list(range(Tg, Tg + H)))
         d.q_g2 = self._wq16("fc_g2", range(Tg, Tg + H))
+        d.b_g1 = self._ch16(d.q_g1, "kq", 2 * H)
+        d.b_g2 = self._ch16(d.q_g2, "wq", H)
         for k in range(cfg.layers):
             p = f"nn_list.{k}."
             ly = d.layer[k]
@@ -397,6 +415,9 @@ class EpicLayout:
             d.q_gl1[k] = self._kq16(p + "fc_global1", range(Tg, Tg + 2 * H + L))   # [mean ; sum ; g]
             d.q_gl2[k] = self._wq16(p + "fc_global2", range(Tg, Tg + H))
             d.q_we1[k] = self._kq16(p + "fc_local1", range(Tl + H, Tl + H + L))     # the g rows of the extras
+            d.b_gl1[k] = self._ch16(d.q_gl1[k], "kq", 2 * H + 16)
+            d.b_gl2[k] = self._ch16(d.q_gl2[k], "wq", H)
+            d.b_we1[k] = self._ch16(d.q_we1[k], "kq", 16)
         # fc_l3: [t_l ; x(H) ; c_l]; particle block row-major [F][H]
         d.l3_W = self._alloc(F * H)
         self._put(d.l3_W, self._w("fc_l3", np.arange(F)[:, None], Tl + np.arange(H)[None, :]))
@@ -547,4 +568,21 @@ class EpicLayout:
                 a = blob[offA: offA + nw * 2048].detach().reshape(nw, 4, 2, 64, 4)   # [w][kt2][h][lane][r]
                 a16 = a.permute(0, 1, 3, 2, 4).contiguous().to(torch.bfloat16)      # [w][kt2][lane][h][r]: 8 bf16 = one 16-byte unit
                 blob[off16: off16 + nw * 1024] = a16.reshape(-1, 2).view(torch.float32).reshape(-1)
+            for src, dst, kind, nk in self._ch16_blocks:
+                nw = 8 if kind == "kq" else 1
+                w = torch.arange(nw).view(nw, 1, 1, 1)
+                kt = torch.arange(nk).view(1, nk, 1, 1)
+                lane = torch.arange(64).view(1, 1, 64, 1)
+                e = torch.arange(8).view(1, 1, 1, 8)
+                o = 16 * w + (lane & 15)
+                k = 32 * kt + 8 * (lane >> 4) + e
+                if kind == "kq":   # KQ16: float (k >> 4) * 2048 + o * 16 + (k & 15); panels beyond the block's own read as zero
+                    idx = (k >> 4) * 2048 + o * 16 + (k & 15)
+                    size = self._ch16_rows[src]
+                    val = torch.where(k < size, blob[src + torch.where(k < size, idx, torch.zeros_like(idx))].detach(), torch.zeros(()))
+                else:              # WQ16: float (k >> 4) * 256 + o * 16 + (k & 15), K = 128
+                    idx = (k >> 4) * 256 + o * 16 + (k & 15)
+                    val = blob[src + idx].detach()
+                b16 = (val + torch.zeros(nw, nk, 64, 8)).to(torch.bfloat16).contiguous()
+                blob[dst: dst + nw * nk * 256] = b16.reshape(-1, 2).view(torch.float32).reshape(-1)
         return blob
