@@ -34,7 +34,7 @@ NFE_FLOP_PER_JET = 84.22e6     # algorithmic fwd FLOP / jet, den
 FP32_MFMA_PEAK = 157.3e12      # MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
 # profiles/: rocprofv3 --pmc passes of this command, newest first (tests/diag/collect_pmc_sq.sh: SQ / GRBM / TCC counters per launch;
 # tests/diag/collect_bench_profiles.sh: FETCH_SIZE / WRITE_SIZE only)
-PMC_SUMMARIES = ("round3_pmc_summary.json", "round2_fast_pmc_hbm_summary.json", "round2_pmc_hbm_summary.json", "round1_pmc_hbm_summary.json")
+PMC_SUMMARIES = ("round4_pmc_summary.json", "round3_pmc_summary.json", "round2_fast_pmc_hbm_summary.json", "round2_pmc_hbm_summary.json", "round1_pmc_hbm_summary.json")
 HP = dict(model="epic", features=3, hidden_dim=128, num_particles=150, frequencies=16, layers=6, latent=10,
           activation="leaky_relu", wrapper_func="weight_norm", t_local_cat=True, t_global_cat=True,
           add_time_to_input=False, t_emb="cosine", loss_type="FM-OT", sigma=1e-4, global_cond_dim=0,
@@ -512,8 +512,9 @@ def main():
                      "significant bits each), fp32 accumulate / activations in two fp16 planes; passes the SAME fp32 parity "
                      "tests as the fp32-MFMA kernel (tests/test_hip_f16x3.py)"),
                     ("bf16", "bf16_mfma_sampler",
-                     "particle Linears on v_mfma_f32_16x16x16_bf16 (operands rounded to bf16, fp32 accumulate, fp32 "
-                     "activations); tests/test_hip_bf16.py bounds it by the reference's autocast-bf16 error"),
+                     "particle Linears AND the per-jet chains on v_mfma_f32_16x16x32_bf16 (operands rounded to bf16, fp32 accumulate, fp32 "
+                     "activations; what the reference's bf16-mixed precision does to every nn.Linear); tests/test_hip_bf16.py bounds it by "
+                     "the reference's autocast-bf16 error"),
                 ):
                     net.set_precision(prec)
                     o = model(z, cond=None, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=args.ode_steps)

@@ -301,8 +301,9 @@ __device__ __forceinline__ f32x2 pk_dot_step(f32x2 acc, const f32x4& wv, const f
 }
 // the chain's loads that are not register windows: this thread's float4 of fc_global2 (WQ16: chunk w, float4 lane) and the staged
 // table rows (as fast_chain_loads)
+// ct (conditioned jets, or nullptr): the jet's cond-table slot with the same row offsets, added to every row (as fast_chain_loads)
 __device__ __forceinline__ ChainLoads fastq_chain_loads(blob_rsrc rs, int64_t q_gl2, const float* __restrict__ slot, int o_g1, int o_l1,
-                                                        int o_g2, int o_l2) {
+                                                        int o_g2, int o_l2, const float* __restrict__ ct = nullptr) {
     const int tid = launder(threadIdx.x);
     ChainLoads L;
     L.w2 = bload4(rs, q_gl2, tid * 16);
@@ -310,6 +311,7 @@ __device__ __forceinline__ ChainLoads fastq_chain_loads(blob_rsrc rs, int64_t q_
     if (tid < 100) {
         const int off = tid < 32 ? o_g1 + 4 * tid : (tid < 64 ? o_l1 + 4 * (tid - 32) : (tid < 68 ? o_g2 + 4 * (tid - 64) : o_l2 + 4 * (tid - 68)));
         L.stg = *reinterpret_cast<const f32x4*>(slot + off);
+        if (ct) L.stg += *reinterpret_cast<const f32x4*>(ct + off);
     }
     return L;
 }
@@ -683,15 +685,17 @@ __device__ __forceinline__ void fast_carry_request(FastCarry<BF16>& cy, const pf
 // for both, so only the chains (pooled vectors, g, bj1) run per jet.
 // COND: ct = the jet's cond table ((layers + 1) slots, stem slot last); see fast_path_ok.
 template <bool BF16, int NSEG, bool COND, typename Emit>
-__device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims& j, const float* __restrict__ blob,
+__device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims& j_in, const float* __restrict__ blob,
                                           float* __restrict__ lds, const Carve& c, int n_rows, const float* __restrict__ tbE,
                                           const float* __restrict__ tbE_next, FastCarry<BF16>& cy, Emit emit, const Segs* sg = nullptr,
                                           const float* __restrict__ ct = nullptr) {
     static_assert(!(COND && NSEG != 1), "conditioned jets: one jet per workgroup");
     static_assert(NSEG != 4 || L2LDS, "quad mode reads the shared biases from c.bj2");
     constexpr bool BCH = BF16 && !COND && PFM_BCHAIN;  // bf16 descriptors: the chains on the matrix pipe (fastb_chain_*)
-    constexpr int NGL = COND ? FNGC : (BCH ? FNB : FNG), NGLS = COND ? FNGS + 1 : (BCH ? FNBS : FNGS);
+    constexpr int NGL = BCH ? FNB : FNG, NGLS = BCH ? FNBS : FNGS;
     constexpr int AF = FastCarry<BF16>::AF;
+    JetDims j = j_in;
+    j.C = 0;  // (see QCH below: the lean path's per-jet vectors have no conditioning slots)
     using CLoads = std::conditional_t<BCH, ChainLoadsB, ChainLoads>;
     // Chains on the KQ16 / WQ16 copies (fastq_chain_*) for every unconditioned instantiation.  Same-box A/B (tests/diag/ab_cfg2.py,
     // ab_time.py; libraries built with -DPFM_QCHAIN_MINSEG=1 / 5): two jets per workgroup (cfg-2 fp32) 28.3 -> 27.0 ms; four jets
@@ -699,7 +703,12 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     // ONE jet 1.4 % slower at 2 tiles, equal from 4 tiles on, +0.2 % on the bench mix: a single jet's chain is bound by its LDS
     // round trips, not by its instruction count, and the float4 reads move four times the bytes.  All of them take it, because one,
     // two and four jets per workgroup must give the same bits (tests/test_hip_packed.py).
-    constexpr bool QCH = !COND && !BCH && NSEG >= PFM_QCHAIN_MINSEG;
+    // Conditioned jets (round 4): the same chains -- the KQ16 / WQ16 copies carry neither time nor conditioning rows, the conditioning
+    // terms come from the jet's cond table like the time terms from the time table, and the per-jet vectors are laid out as if C = 0
+    // (`j` below: the pooled vectors start at vin + FT).  One panel less in the register window: the conditioned fp32 kernel builds
+    // without scratch (round 3: 20 bytes per lane).
+    constexpr bool QCH = !BCH && (COND || NSEG >= PFM_QCHAIN_MINSEG);
+    static_assert(QCH || BCH || !COND, "the KM16 chains (fast_chain_*) serve diagnostic builds of unconditioned jets only");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr int NSV = NSEG == 4 ? 4 : 2;
     SegView sv[NSV];
@@ -729,7 +738,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     const float* maskf = lds + c.maskf;
     const float* tbS = tbE + (size_t)j.layers * TB_SLOT;
     const float* ctS = COND ? ct + (size_t)j.layers * TB_SLOT : nullptr;
-    const int w2r0 = COND ? FT + j.C : FT;  // fc_global2's 128-row window starts behind the (zeroed) conditioning rows
+    const int w2r0 = FT;  // (KM16 chains of diagnostic builds) fc_global2's 128-row window starts behind the time rows
     const blob_rsrc rs = make_blob_rsrc(blob, d.blob_floats + PFM_DESC_FLOATS);
     f32x4 gl[NGL], wbA[1];
     PFM_STAMP(1);
@@ -753,14 +762,14 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     };
     auto layer_chain_loads = [&](int k, const float* __restrict__ tb) {
         if constexpr (BCH) return fastb_chain_loads(rs, d.b_gl2[k], tb, TB_G1, TB_L1, TB_G2, TB_L2);
-        else if constexpr (!QCH) return fast_chain_loads(rs, d.layer[k].gl2.W, w2r0, tb, TB_G1, TB_L1, TB_G2, COND ? ct + (size_t)k * TB_SLOT : nullptr, TB_L2);
-        else return fastq_chain_loads(rs, d.q_gl2[k], tb, TB_G1, TB_L1, TB_G2, TB_L2);
+        else if constexpr (!QCH) return fast_chain_loads(rs, d.layer[k].gl2.W, w2r0, tb, TB_G1, TB_L1, TB_G2, nullptr, TB_L2);
+        else return fastq_chain_loads(rs, d.q_gl2[k], tb, TB_G1, TB_L1, TB_G2, TB_L2, COND ? ct + (size_t)k * TB_SLOT : nullptr);
     };
     // the stem chain's own loads, two phases ahead of their use (conditioned jets: with fc_l2's bias row for c.bj2)
     CLoads L;
     if constexpr (BCH) L = fastb_chain_loads(rs, d.b_g2, tbS, TB_SG1, TB_SG1, TB_SG2, TB_SJ2);
-    else if constexpr (!QCH) L = fast_chain_loads(rs, d.g2.W, w2r0, tbS, TB_SG1, TB_SG1, TB_SG2, ctS, TB_SJ2);
-    else L = fastq_chain_loads(rs, d.q_g2, tbS, TB_SG1, TB_SG1, TB_SG2, TB_SJ2);
+    else if constexpr (!QCH) L = fast_chain_loads(rs, d.g2.W, w2r0, tbS, TB_SG1, TB_SG1, TB_SG2, nullptr, TB_SJ2);
+    else L = fastq_chain_loads(rs, d.q_g2, tbS, TB_SG1, TB_SG1, TB_SG2, TB_SJ2, ctS);
 #ifndef PFM_AB_NOL1  // (PFM_AB_*: timing-only ablation builds of tests/diag/fixed_cost_table.sh; results are garbage)
     fast_stem_l1(j, lds, c, n_rows, cy.aw, cy.sj1);
 #endif
@@ -797,7 +806,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         __syncthreads();
 #else
         if constexpr (BCH) fastb_chain_stem<NSEG>(j, lds, sv, gl, L, tbl, first_layer_requests, [&]() { fast_chain_publish(L0, tbl); });
-        else if constexpr (!QCH) fast_chain_stem<NSEG, COND>(j, lds, sv, gl, L, tbl, first_layer_requests, [&]() { fast_chain_publish(L0, tbl); });
+        else if constexpr (!QCH) fast_chain_stem<NSEG, false>(j, lds, sv, gl, L, tbl, first_layer_requests, [&]() { fast_chain_publish(L0, tbl); });
         else fastq_chain_stem<NSEG>(j, lds, sv, gl, L, tbl, first_layer_requests, [&]() { fast_chain_publish(L0, tbl); });
 #endif
         L = L0;
@@ -813,7 +822,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         PFM_STAMP(10);
 #ifndef PFM_AB_NOCHAIN
         if constexpr (BCH) fastb_chain_layer<NSEG>(j, lds, c, sv, gl, wbA[0], L, tbl);
-        else if constexpr (!QCH) fast_chain_layer<NSEG, COND>(j, lds, c, sv, gl, wbA[0], L, tbl);
+        else if constexpr (!QCH) fast_chain_layer<NSEG, false>(j, lds, c, sv, gl, wbA[0], L, tbl);
         else fastq_chain_layer<NSEG>(j, lds, c, sv, gl, wbA[0], L, tbl);
 #else
         if (COND || L2LDS) fast_chain_publish_l2(L, lds + c.bj2);
