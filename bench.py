@@ -231,9 +231,14 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="jets per GPU (BASELINE config: 256)")
     ap.add_argument("--ode-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pack-jets", dest="pack_jets", action="store_false",
+                    help="sampler: one jet per workgroup.  Default (round 4): two jets share a workgroup where their rows fit the LDS tile "
+                         "together (PFM_F_PACK_JETS: the k-th longest jet takes the shortest remaining one that fits, 64 pairs in the bench "
+                         "batch; one weight stream, one set of phases and barriers for both; workgroups dispatched by their total tiles) -- "
+                         "same results bit for bit (tests/test_hip_packed.py), 20.6 -> 19.9 ms per step")
     ap.add_argument("--overlap", type=int, default=2,
                     help="sampling launches in flight: step i's sample runs on its own HIP stream with a weight snapshot "
-                         "while step i+1 trains and the next sample starts (default 2: +13 % jets/s on one MI355X -- a launch lasts "
+                         "while step i+1 trains and the next sample starts (default 2: +13 %% jets/s on one MI355X -- a launch lasts "
                          "as long as its largest jet, the CUs that finish early pick up the next launch's jets; 1 = strictly "
                          "sequential, one launch at a time)")
     args = ap.parse_args()
@@ -276,6 +281,8 @@ def main():
     model = SetFlowMatchingLitModule(optimizer=None, **HP).to(dev)
     state_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if k.startswith("flows.")}
     trainer = FusedFMTrainer(model, lr=1e-3, weight_decay=5e-5, max_grad_norm=0.5, ema_decay=0.999)
+    if args.pack_jets:
+        model.flows[0].net.set_jet_packing(True)
     B, N, F = args.batch, HP["num_particles"], HP["features"]
     x, mask, cond = synthetic_batch(B, N, F, 12345 + rank)
     x, mask, cond = x.to(dev), mask.to(dev), cond.to(dev)
@@ -422,8 +429,8 @@ def main():
         import ctypes
         from particle_fm_amd import _lib
         lay = model.flows[0].net.layout()
-        sampler_kernel = ("epic_sample_midpoint_fast_kernel<0, false, false>" if _lib.load().pfm_epic_sample_is_fast(ctypes.byref(lay.desc))
-                          else "epic_sample_midpoint_kernel<0, true>")
+        sampler_kernel = ((f"epic_sample_midpoint_fast_kernel<0, {'true' if args.pack_jets else 'false'}, false>")
+                          if _lib.load().pfm_epic_sample_is_fast(ctypes.byref(lay.desc)) else "epic_sample_midpoint_kernel<0, true>")
         mfma_busy, sq_file = None, None
         for cand in PMC_SUMMARIES:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
             try:
@@ -452,6 +459,8 @@ def main():
                 "overlap": f"{D} sampling launches in flight (sample of step i on its own HIP stream with a weight "
                            "snapshot while step i+1 trains); every launch of the K steps is inside the timed region",
                 "multiplicity": "U{30..150} per jet (masked tail tiles are skipped; results identical)",
+                "jets_per_workgroup": "1 or 2 (PFM_F_PACK_JETS: two jets whose rows fit the 150-row LDS tile together share a workgroup; "
+                                      "bit-identical results)" if args.pack_jets else "1",
             },
             "train_ms": train_ms, "sample_ms": sample_ms, "train_ms_alone": train_alone_ms, "allreduce_ms_alone": allreduce_alone_ms,
             "grad_exchange": None if world == 1 else {

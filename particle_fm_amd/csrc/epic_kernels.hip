@@ -711,22 +711,25 @@ __global__ __launch_bounds__(1024) void epic_jet_order_kernel(int B, int* __rest
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void epic_jet_pack_kernel(const float* __restrict__ mask, int B, int N, int pair_ok,
                                                              int* __restrict__ pack) {
-    __shared__ int cnt[ORDER_MAX_JETS];
-    __shared__ int sorted[ORDER_MAX_JETS];
+    // 56 KB of static LDS: rows per jet (<= 160: a byte), jets in descending order / tiles per workgroup, the workgroup list
+    __shared__ unsigned char cnt[ORDER_MAX_JETS];
+    __shared__ unsigned short sorted[ORDER_MAX_JETS];
+    __shared__ unsigned short pa[ORDER_MAX_JETS], pb[ORDER_MAX_JETS];  // pb = 0xFFFF: alone
+    __shared__ int nwg_s;
     const int tid = threadIdx.x;
     for (int jet = tid >> 6; jet < B; jet += 16) {  // one wave per jet: coalesced reads (a thread per jet walked N strided floats)
         int last = -1;
         for (int r = tid & 63; r < N; r += 64)
             if (mask[(int64_t)jet * N + r] != 0.f) last = r;
         for (int m = 32; m >= 1; m >>= 1) last = max(last, __shfl_xor(last, m));
-        if ((tid & 63) == 0) cnt[jet] = last >= 0 ? last + 1 : N;  // no valid particle: every row is computed (NaN like the reference)
+        if ((tid & 63) == 0) cnt[jet] = (unsigned char)(last >= 0 ? last + 1 : N);  // no valid particle: every row is computed (NaN like the reference)
     }
     __syncthreads();
     for (int jet = tid; jet < B; jet += 1024) {
         const int c = cnt[jet];
         int rank = 0;
         for (int k = 0; k < B; ++k) rank += (cnt[k] > c) || (cnt[k] == c && k < jet);
-        sorted[rank] = jet;
+        sorted[rank] = (unsigned short)jet;
     }
     __syncthreads();
     if (tid == 0) {
@@ -734,16 +737,34 @@ __global__ __launch_bounds__(1024) void epic_jet_pack_kernel(const float* __rest
         int i = 0, jj = B - 1, nwg = 0;
         while (i <= jj) {
             const int a = sorted[i++];
-            int b = -1;
+            int b = 0xFFFF;
             if (pair_ok && i <= jj) {
                 const int cand = sorted[jj];
                 if ((cnt[a] + TILE - 1) / TILE * TILE + cnt[cand] <= cap) { b = cand; --jj; }
             }
-            pack[1 + 2 * nwg] = a;
-            pack[2 + 2 * nwg] = b;
+            pa[nwg] = (unsigned short)a;
+            pb[nwg] = (unsigned short)b;
             ++nwg;
         }
         pack[0] = nwg;
+        nwg_s = nwg;
+    }
+    // Workgroups are dispatched in list order and a pair's run time goes with the rows of BOTH its jets: the list is ordered by 16-row
+    // tiles of the whole workgroup, most first, ties in pairing order (every thread ranks its workgroups against all others, like the jets
+    // above), so that a 9-tile pair does not start behind the 6-tile singles (round 4).  `sorted` is free again: it holds the tile counts.
+    __syncthreads();
+    const int nwg = nwg_s;
+    for (int k = tid; k < nwg; k += 1024) {
+        const int a = pa[k], b = pb[k];
+        sorted[k] = (unsigned short)((cnt[a] + TILE - 1) / TILE + (b != 0xFFFF ? (cnt[b] + TILE - 1) / TILE : 0));
+    }
+    __syncthreads();
+    for (int k = tid; k < nwg; k += 1024) {
+        const int t = sorted[k];
+        int rank = 0;
+        for (int m = 0; m < nwg; ++m) rank += (sorted[m] > t) || (sorted[m] == t && m < k);
+        pack[1 + 2 * rank] = pa[k];
+        pack[2 + 2 * rank] = pb[k] == 0xFFFF ? -1 : (int)pb[k];
     }
 }
 
