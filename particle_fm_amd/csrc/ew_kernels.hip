@@ -296,6 +296,176 @@ __global__ __launch_bounds__(256) void ew_fill_masked_kernel(const float* __rest
     dst[i] = cnt[row / N] == 0 ? __builtin_nanf("") : (base ? base[i] : 0.f);
 }
 
+// ------------------------------------------------------------------------------------------------
+// ew_pair_kernel (round 4): the two local Linears of an EPiC layer for a 32-row tile in ONE workgroup (inference, fp32 operands)
+//     l1 = lrelu(W1 x + jb1[jet]),   x' = lrelu(W2 l1 + jb2[jet] + x)                         epic.py:194-200
+// Both are row-local, so the hidden rows never leave the CU: x sits in an LDS panel (the residual comes from there too), l1 in a second one.
+// The two tf_linear_kernel launches it replaces spent 41 us each on 3.9 GFLOP (0.61 of the fp32 MFMA peak: 64-output workgroups, one
+// 16-row A operand per wave -- 8 MFMAs per pair of operand reads -- and the hidden tensor's round trip through HBM between them).  Here a
+// wave owns NSW = Hp / 64 sixteen-output groups (w, w + 4, ...) of both Linears: per 16 k it reads TWO B operands (the tile's two 16-row
+// halves) and issues 8 NSW MFMAs, with the A operands of the next 16 k requested a step ahead (two register sets, static indices).
+// Same products and sums in the same order as the two launches (accumulators start from the jet bias, k ascending): bit-identical.
+// LDS: 2 x 32 x Hp floats (80 KB at Hp = 320: two workgroups per CU).  Weights: MFMA_AK blocks (pfm_tf.h).
+// ------------------------------------------------------------------------------------------------
+struct PairArgs {
+    const float* blob;
+    const float* X;      // [M][ldx] input rows (and the residual)
+    float* out;          // [M][ldx] (may be X: a workgroup reads its rows before it writes them)
+    const float* jb;     // [jets][jb_stride]: jb1 at 0, jb2 at Hp
+    const int* rowjet;   // row -> jet (compacted rows) or nullptr: jet = row / N
+    const int* m_dev;    // device-side row count or nullptr
+    int64_t blob_floats, W1, W2, jb_stride;
+    int ldx, M, N;
+    float slope;
+};
+
+template <int NSW, int TPW>
+__global__ __launch_bounds__(256, TPW == 1 ? 3 : 2) void ew_pair_kernel(PairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int RB = 16 * TPW, Hp = 64 * NSW, NKT = Hp / 16, NST = Hp / 64;
+    float* const XP = lds;                  // NSW slices of RB x 64, 16-byte slots XOR-swizzled with (row & 15)
+    float* const HP_ = lds + NSW * RB * 64;  // the hidden rows, same layout
+    const int tid = threadIdx.x, lane = tid & 63, pl = lane & 15, q = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = a.m_dev ? *a.m_dev : a.M;
+    const int row0 = blockIdx.x * RB;
+    if (row0 >= M) return;
+    const blob_rsrc rs = make_blob_rsrc(a.blob, a.blob_floats);
+    // A operand (g, kt): 16 outputs 16 g .. x k = 16 kt .. 16 kt + 15 of an MFMA_AK block
+    auto request = [&](f32x4 (&af)[NSW], int64_t W, int kt) {
+#pragma unroll
+        for (int s = 0; s < NSW; ++s) af[s] = bload4(rs, W + ((int64_t)((w + 4 * s) * NST + (kt >> 2)) * 4 + (kt & 3)) * 256, lane * 16);
+    };
+    // FOUR operand sets, each requested three 16-k steps ahead of its use: with two (one step ahead) hipcc sank the requests into the middle
+    // of the step before -- the set's previous reader is the MFMA block just issued -- and every step began with vmcnt waits
+    f32x4 af[4][NSW];
+    request(af[0], a.W1, 0);
+    request(af[1], a.W1, 1);
+    request(af[2], a.W1, 2);
+    // ---- the tile's rows -> XP (coalesced float4 reads; rows past M repeat the last one, their results are never stored) ----
+    for (int u = tid; u < RB * (Hp / 4); u += 256) {
+        const int r = u / (Hp / 4), c4 = u - r * (Hp / 4);  // float4 c4 of row r: slice c4 >> 4, slot c4 & 15
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + (int64_t)min(row0 + r, M - 1) * a.ldx + 4 * c4);
+        *reinterpret_cast<f32x4*>(XP + (c4 >> 4) * (RB * 64) + r * 64 + (((c4 & 15) ^ (r & 15)) << 2)) = v;
+    }
+    // jet of this lane's rows (tile parts t = 0 .. TPW - 1)
+    int jet[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int row = min(row0 + 16 * t + pl, M - 1);
+        jet[t] = a.rowjet ? a.rowjet[row] : row / a.N;
+    }
+    f32x4 acc[NSW][TPW];
+    auto init = [&](int col0) {  // accumulators start from the jet-bias rows (they carry the bias)
+#pragma unroll
+        for (int s = 0; s < NSW; ++s)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                acc[s][t] = *reinterpret_cast<const f32x4*>(a.jb + (int64_t)jet[t] * a.jb_stride + col0 + 16 * (w + 4 * s) + 4 * q);
+    };
+    auto bfrag = [&](f32x4 (&B)[TPW], const float* P, int kt) {
+        const float* p0 = P + (kt >> 2) * (RB * 64) + pl * 64 + (((4 * (kt & 3) + q) ^ pl) << 2);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) B[t] = *reinterpret_cast<const f32x4*>(p0 + t * 16 * 64);
+    };
+    auto mma = [&](const f32x4 (&af)[NSW], const f32x4 (&B)[TPW]) {
+#define PFM_EW_STEP(c)                                                                                                                   \
+    _Pragma("unroll") for (int s = 0; s < NSW; ++s)                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < TPW; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s].c, B[t].c, acc[s][t], 0, 0, 0);
+        PFM_EW_STEP(x) PFM_EW_STEP(y) PFM_EW_STEP(z) PFM_EW_STEP(w)
+#undef PFM_EW_STEP
+    };
+    // one Linear over the panel P: k ascending in steps of 16; on entry af[0..2] hold steps 0..2 of W.  Wnext (or -1): the block whose steps
+    // 0..2 are requested behind the last ones of this
+    static_assert(NKT % 4 == 0, "the step loop is unrolled by the four operand sets");
+    auto gemm = [&](const float* P, int64_t W, int64_t Wnext) {
+        f32x4 Ba[TPW], Bb[TPW];
+        bfrag(Ba, P, 0);
+#pragma unroll 1
+        for (int kt = 0; kt < NKT; kt += 4) {
+            const bool more = kt + 4 < NKT;
+            request(af[3], W, kt + 3);
+            bfrag(Bb, P, kt + 1);
+            mma(af[0], Ba);
+            if (more) request(af[0], W, kt + 4); else if (Wnext >= 0) request(af[0], Wnext, 0);
+            bfrag(Ba, P, kt + 2);
+            mma(af[1], Bb);
+            if (more) request(af[1], W, kt + 5); else if (Wnext >= 0) request(af[1], Wnext, 1);
+            bfrag(Bb, P, kt + 3);
+            mma(af[2], Ba);
+            if (more) { request(af[2], W, kt + 6); bfrag(Ba, P, kt + 4); } else if (Wnext >= 0) request(af[2], Wnext, 2);
+            mma(af[3], Bb);
+        }
+    };
+    init(0);
+    __syncthreads();  // XP complete
+    gemm(XP, a.W1, a.W2);
+    // ---- hidden rows -> HP_ ----
+#pragma unroll
+    for (int s = 0; s < NSW; ++s) {
+        const int o = 16 * (w + 4 * s) + 4 * q;  // 4 consecutive hidden columns: slice o >> 6, slot (o & 63) >> 2
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int r = 16 * t + pl;
+            *reinterpret_cast<f32x4*>(HP_ + (o >> 6) * (RB * 64) + r * 64 + ((((o & 63) >> 2) ^ (r & 15)) << 2)) = lrelu4(acc[s][t], a.slope);
+        }
+    }
+    init(Hp);
+    __syncthreads();  // HP_ complete
+    gemm(HP_, a.W2, -1);
+    // ---- x' = lrelu(acc + x): the residual from the X panel ----
+#pragma unroll
+    for (int s = 0; s < NSW; ++s) {
+        const int o = 16 * (w + 4 * s) + 4 * q;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int r = 16 * t + pl, row = row0 + r;
+            f32x4 v = acc[s][t] + *reinterpret_cast<const f32x4*>(XP + (o >> 6) * (RB * 64) + r * 64 + ((((o & 63) >> 2) ^ (r & 15)) << 2));
+            v = lrelu4(v, a.slope);
+            if (row < M) *reinterpret_cast<f32x4*>(a.out + (int64_t)row * a.ldx + o) = v;
+        }
+    }
+}
+
+// the fused pair where it applies (inference, fp32 operands, Hp a multiple of 64 up to 512, enough row tiles to fill the chip); false: the
+// caller launches the two Linears.  PFM_EW_PAIR=0 (diagnostics) switches it off.
+inline bool launch_pair(const PairArgs& a, int Hp, int cus, hipStream_t s) {
+    static int on = -1, tpw_env = 0;
+    if (on < 0) {
+        const char* e = getenv("PFM_EW_PAIR");      // diagnostics: 0 = the two launches
+        const char* t = getenv("PFM_EW_PAIR_TPW");  // diagnostics: 1 / 2 = 16- / 32-row tiles
+        on = e ? atoi(e) : 1;
+        tpw_env = t ? atoi(t) : 0;
+    }
+    if (!on || Hp % 64 != 0 || (int64_t)(a.M + 31) / 32 < 2 * (int64_t)cus) return false;
+    const int tpw = tpw_env ? tpw_env : 1;
+    const dim3 grid((a.M + 16 * tpw - 1) / (16 * tpw)), block(256);
+    const int lds = 2 * 16 * tpw * Hp * 4;
+#define PFM_EW_PAIR_LAUNCH(NSW, TPW)                                                                                                       \
+    {                                                                                                                                      \
+        static bool attr = false;                                                                                                          \
+        if (!attr) {                                                                                                                       \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(ew_pair_kernel<NSW, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            attr = true;                                                                                                                   \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL((ew_pair_kernel<NSW, TPW>), grid, block, lds, s, a);                                                            \
+        return true;                                                                                                                       \
+    }
+#define PFM_EW_PAIR_CASE(NSW) \
+    case NSW:                 \
+        if (tpw == 1) PFM_EW_PAIR_LAUNCH(NSW, 1) else PFM_EW_PAIR_LAUNCH(NSW, 2)
+    switch (Hp / 64) {
+        PFM_EW_PAIR_CASE(2)
+        PFM_EW_PAIR_CASE(3)
+        PFM_EW_PAIR_CASE(4)
+        PFM_EW_PAIR_CASE(5)
+        default: return false;
+    }
+#undef PFM_EW_PAIR_CASE
+#undef PFM_EW_PAIR_LAUNCH
+}
+
+
 // v[row][f] = lrelu( W3[f] . X[row] + jb3[jet][f] ) * mask[row]   (epic.py:386-389); optional fused state update
 struct HeadArgs {
     const float *X, *blob, *jb, *mask, *base, *dt;
@@ -512,6 +682,18 @@ int run_nfe(const Plan& p, const float* t, int t_stride, const float* x, const f
             PFM_TRY(linear(p, B, Pout, ldp, 256, nullptr, 0, 256, L.jb, 2 * Hp, nullptr, 0, 1, nullptr, 0, JB, 2 * Hp, 0));
         }
         float* L1 = ws + w.L1 + w.lstride * l;
+        // inference, fp32 operands: both local Linears of a 32-row tile in one launch (ew_pair_kernel); training keeps the two launches
+        // (the backward re-reads the hidden rows), as do the split-fp16 / bf16 flavours
+        if (!w.lstride && !(d.flags & (PFM_EW_F_F16X3 | PFM_EW_F_BF16))) {
+            PairArgs pa;
+            pa.blob = p.blob; pa.X = Xst(l); pa.out = Xst(l + 1); pa.jb = JB; pa.rowjet = p.rowjet; pa.m_dev = p.m_dev;
+            pa.blob_floats = d.blob_floats; pa.W1 = L.l1.W; pa.W2 = L.l2.W; pa.jb_stride = 2 * Hp; pa.ldx = Hp; pa.M = p.M; pa.N = N;
+            pa.slope = d.neg_slope;
+            if (launch_pair(pa, Hp, num_cus(), p.s)) {
+                PFM_TRY(check_hip(hipGetLastError(), "ew_pair_kernel launch"));
+                continue;
+            }
+        }
         PFM_TRY(linear(p, p.M, Xst(l), Hp, Hp, nullptr, 0, Hp, L.l1, Hp, JB, 2 * Hp, N, nullptr, 0, L1, Hp, 1));
         PFM_TRY(linear(p, p.M, L1, Hp, Hp, nullptr, 0, Hp, L.l2, Hp, JB + Hp, 2 * Hp, N, Xst(l), Hp, Xst(l + 1), Hp, 2));
     }
