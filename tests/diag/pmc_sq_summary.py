@@ -72,9 +72,11 @@ if tot_f or tot_w:
                       "evaluations": evals,
                       "hbm_bytes_per_evaluation": (2 * tot_f + tot_w) * 1024.0 / evals if evals else None,
                       "note": "sums over EVERY pfm:: launch of the run (HBM-side bytes = 2 x FETCH_SIZE + WRITE_SIZE KiB, gfx950 correction)"}
-out["_note"] = ("averages per launch over the launches of `python3 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline` under "
-                "rocprofv3 --pmc (tests/diag/collect_pmc_sq.sh; dispatches serialised: every launch alone on the GPU).  Units and the "
-                "derived fields: tests/diag/pmc_sq_summary.py")
+out["_note"] = (("averages per launch over the launches of one `python3 bench_secondary.py --sample-only --steps 1 --warmup 0` call under "
+                "rocprofv3 --pmc (tests/diag/collect_pmc_rowmatrix.sh; " if os.environ.get("PFM_PMC_EVALS") else
+                "averages per launch over the launches of `python3 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline` under "
+                "rocprofv3 --pmc (tests/diag/collect_pmc_sq.sh; ") +
+                "dispatches serialised: every launch alone on the GPU).  Units and the derived fields: tests/diag/pmc_sq_summary.py")
 json.dump(out, open(os.path.join(root, "pmc_sq_summary.json"), "w"), indent=1, sort_keys=True)
 if "_totals" in out:
     print("_totals", out["_totals"])
