@@ -431,15 +431,18 @@ def main():
         lay = model.flows[0].net.layout()
         sampler_kernel = ((f"epic_sample_midpoint_fast_kernel<0, {'true' if args.pack_jets else 'false'}, false>")
                           if _lib.load().pfm_epic_sample_is_fast(ctypes.byref(lay.desc)) else "epic_sample_midpoint_kernel<0, true>")
-        mfma_busy, sq_file = None, None
+        mfma_busy, mfma_busy_step, sq_file = None, None, None
         for cand in PMC_SUMMARIES:  # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 correction)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                pmc = next(v for k, v in pmc.items() if k.startswith("pfm::" + sampler_kernel.split("<")[0] + "<0"))
+                pmc = pmc["pfm::" + sampler_kernel] if "pfm::" + sampler_kernel in pmc else next(
+                    v for k, v in pmc.items() if k.startswith("pfm::" + sampler_kernel.split("<")[0] + "<0"))
                 if traffic is None and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                     traffic, pmc_file = (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0, cand
                 if mfma_busy is None and "mfma_busy" in pmc:
                     mfma_busy, sq_file = pmc["mfma_busy"], cand
+                    if "cycles" in pmc and pmc.get("duration_ns"):  # busy cycles of one launch over the cycles of one timed step
+                        mfma_busy_step = pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * pmc["cycles"] / pmc["duration_ns"] * 1e9 * elapsed / args.steps)
             except Exception:
                 continue
         res = {
@@ -493,13 +496,18 @@ def main():
                 "kernel_ms_in_timed_region": sample_ms, "kernel_alone_ms": excl_ms, "concurrent_launches": D,
                 "algorithmic_dense_flop_per_launch": dense_sample,
                 "dense_equiv_over_peak": dense_sample / (excl_ms * 1e-3) / FP32_MFMA_PEAK,
-                "mfma_busy": mfma_busy,
+                "mfma_busy": mfma_busy, "mfma_busy_per_timed_step": mfma_busy_step,
                 "dense_flop_not_executed_share": 1.0 - exec_sample / dense_sample,
                 "note": "frac = achieved / peak with achieved = FLOP the matrix cores EXECUTE (13 Linears of 128x128 per evaluation on "
                         "the 16-row tiles up to each jet's last valid particle; sampler launches + train steps, train = 3x forward) "
                         "over the timed wall time: it cannot exceed 1.  mfma_busy = the hardware's own count for ONE sampler launch alone on "
                         f"the GPU: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of profiles/{sq_file} (rocprofv3 --pmc, "
-                        "tests/diag/collect_pmc_sq.sh; null if that file has no SQ pass for this kernel).  dense_equiv_over_peak (NOT a "
+                        "tests/diag/collect_pmc_sq.sh; null if that file has no SQ pass for this kernel); mfma_busy_per_timed_step (derived, two runs combined) = that launch's "
+                        "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x the cycles of ONE timed step at the clock of the counter run): the share of "
+                        "the matrix pipes' cycles one sampler launch keeps busy when launches overlap as in the timed region (alone, a launch "
+                        "with two jets per workgroup occupies 192 of the 256 CUs: the second launch in flight uses the rest); the train "
+                        "step's MFMAs are not in it.  "
+                        "dense_equiv_over_peak (NOT a "
                         "utilisation: it may exceed 1) = SURVEY 8d's dense count "
                         f"({NFE_FLOP_PER_JET/1e6:.2f} MFLOP/jet/NFE x {n_nfe} NFE x {B} jets: padded N, concatenated t/cond/g columns "
                         "counted) / duration of ONE launch alone on the GPU (kernel_alone_ms) / peak; dense_flop_not_executed_share of "

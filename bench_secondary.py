@@ -213,7 +213,10 @@ def run(name, args):
     # block, so its useful-FLOP peak is a third of that
     peak = {"fp32": FP32_MFMA_PEAK, "bf16": 2500e12, "f16x3": 2500e12 / 3}[args.precision]
     # the kernel the sampler really launches for this descriptor, and its HBM traffic from the committed rocprofv3 --pmc passes
-    kernel = "sampling launches (tf_linear_kernel dominates)"
+    kernel = {"lhco_transformer": "sampling launches (tf_linear_panel_kernel<4, 2> dominates)",
+              "lhco_crossattention": "sampling launches (tf_mlp_panel_kernel<2, 4, true> dominates)",
+              "jetclass": "sampling launches (ew_pair_kernel<5, 1> dominates)" if args.precision == "fp32"
+                          else "sampling launches (tf_linear_kernel<0, 2, 0, true> dominates)"}.get(name, "sampling launches")
     if name == "jetnet30":
         from particle_fm_amd import hip_ops
         from particle_fm_amd.layout import PFM_F_QUAD_JETS
@@ -229,7 +232,14 @@ def run(name, args):
     traffic, traffic_note = None, "no rocprofv3 --pmc pass on file for this workload / precision"
     pmc_path = os.path.join(ROOT, "profiles", f"round4_pmc_{name}_{args.precision}.json")
     if os.path.exists(pmc_path):
-        tot = json.load(open(pmc_path)).get("_totals", {})
+        pmc = json.load(open(pmc_path))
+        tot = pmc.get("_totals", {})
+        if name != "jetnet30":  # the launch that takes the largest share of an evaluation, by the profiler's own durations
+            per = {k: v["duration_ns"] * v["launches_seen"] for k, v in pmc.items()
+                   if isinstance(v, dict) and "launches_seen" in v and "duration_ns" in v and "spin_kernel" not in k}
+            if per:
+                top = max(per, key=per.get)
+                kernel = f"sampling launches ({top.split('::')[-1]} dominates: {100.0 * per[top] / sum(per.values()):.0f} % of an evaluation's kernel time)"
         if tot.get("hbm_bytes_per_evaluation"):
             traffic = tot["hbm_bytes_per_evaluation"] * n_nfe
             traffic_note = (f"traffic = HBM-side bytes of ONE sampler call ({n_nfe} evaluations): (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over every "

@@ -10,7 +10,7 @@ from particle_fm_amd import build as B
 
 # The stamps live in epic_kernels.hip only, which is self-contained: one translation unit, no -fgpu-rdc.  Built here (CPU container,
 # `python tests/diag/stamps.py --build-only`) so that the GPU box does not spend its minutes compiling; rebuilt when stale.
-out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpfm_diag.so")
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("PFM_DIAG_LIB", "libpfm_diag.so"))  # PFM_DIAG_LIB + PFM_DEFS: variants side by side
 src = os.path.join(B.CSRC, "epic_kernels.hip")
 deps = [src] + [os.path.join(B.CSRC, f) for f in os.listdir(B.CSRC) if f.endswith(".h")]
 if not os.path.exists(out) or any(os.path.getmtime(d_) > os.path.getmtime(out) for d_ in deps):
