@@ -257,7 +257,7 @@ def run(name, args):
                    "multiplicity": f"U{{{n_min}..{N}}} per jet",
                    "sampler_rows": "valid particles only" if (valid_rows or hp["model"] == "epic") else "all N rows (padded included)",
                    "sampler_launches": "step body captured once per call, replayed as a hipGraph" if graph else "every launch enqueued by the host",
-                   "jets_per_workgroup": 2 if packed else 1},
+                   "jets_per_workgroup": 4 if "quad" in kernel else (2 if packed else 1)},
         "train_ms": train_ms, "sample_ms": sample_ms, "train_jets_per_s": B / (train_ms * 1e-3),
         "sample_jets_per_s": B / (sample_ms * 1e-3),
         "roofline": {"bound": "mfma", "kernel": kernel,

@@ -110,8 +110,8 @@ def test_lr_schedule_is_applied():
 
 
 def test_a_loss_kept_across_many_steps_keeps_its_value():
-    """step() hands out a COPY of the loss scalar, not a view into the trainer's 16-slot ring of [loss, 1 / sum(mask)] pairs: a
-    caller that collects per-step losses for an epoch mean (more than 16 steps later) still reads each step's own number."""
+    """The loss step() returns lives in a buffer of that step's own ([loss, 1 / sum(mask)], allocated per step; round 3 handed out a view
+    into a 16-slot ring): a caller that collects per-step losses for an epoch mean still reads each step's own number 40 steps later."""
     batch = _batch()
     m, tr = _make()
     kept, now = [], []
