@@ -35,6 +35,9 @@ namespace pfm {
 #ifndef PFM_BCHAIN
 #define PFM_BCHAIN 1          // bf16 descriptors: the lean sampler's chains on the matrix pipe (diagnostic builds: 0 = the fp32 VALU chains)
 #endif
+#ifndef PFM_QG1_BATCH
+#define PFM_QG1_BATCH 9       // fc_global1 of the KQ16 chains: input panels read per batch and jet (one jet; two jets: half); 0 = hipcc's own order
+#endif
 #ifndef PFM_QCHAIN_MINSEG
 #define PFM_QCHAIN_MINSEG 1   // jets per workgroup from which the chains run on the KQ16 / WQ16 copies (diagnostic builds: 2, 5 = never)
 #endif
@@ -340,12 +343,35 @@ __device__ __forceinline__ void fastq_g1_part(const JetDims& j, float* __restric
     _Pragma("unroll") for (int s = 0; s < NSEG; ++s)                                                \
         _Pragma("unroll") for (int i = 0; i < G; ++i)                                               \
             if ((g) * G + i < NP) acc[s] = pk_dot_step(acc[s], gl[(g) * G + i], X[s][i]);
-    if constexpr (NSEG <= 2) {  // one or two jets: all reads up front is what hipcc does by itself, and it fits (measured: the
-                                // pipeline's scheduling fences cost a 2-tile jet 3 %)
+    if constexpr (NSEG <= 2) {
+        // One or two jets: the input panels in batches of QB float4 per jet, every read of a batch requested before its first FMA
+        // (a scheduling fence pins that).  Left to itself hipcc (round 4, at 244 VGPRs) reuses ONE register quad for all 17 panels --
+        // ds_read_b128, s_waitcnt lgkmcnt(0), two FMAs, 17 times over: 17 dependent LDS round trips, ~1.5 k of a chain's 2.7 k cycles
+        // (tests/diag/isa_mix.py listing; the stamps of profiles/round4_chain_rider_experiment.txt).
+        constexpr int QB = PFM_QG1_BATCH > 0 ? (NSEG == 1 ? PFM_QG1_BATCH : (PFM_QG1_BATCH + 1) / 2) : NP;
+        if constexpr (PFM_QG1_BATCH > 0) {
+            f32x4 xq[NSEG][QB];
 #pragma unroll
-        for (int s = 0; s < NSEG; ++s)
+            for (int u0 = 0; u0 < NP; u0 += QB) {
 #pragma unroll
-            for (int u = 0; u < NP; ++u) acc[s] = pk_dot_step(acc[s], gl[u], *reinterpret_cast<const f32x4*>(vp[s] + 16 * u));
+                for (int s = 0; s < NSEG; ++s)
+#pragma unroll
+                    for (int i = 0; i < QB; ++i)
+                        if (u0 + i < NP) xq[s][i] = *reinterpret_cast<const f32x4*>(vp[s] + 16 * (u0 + i));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < NSEG; ++s)
+#pragma unroll
+                    for (int i = 0; i < QB; ++i)
+                        if (u0 + i < NP) acc[s] = pk_dot_step(acc[s], gl[u0 + i], xq[s][i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NSEG; ++s)
+#pragma unroll
+                for (int u = 0; u < NP; ++u) acc[s] = pk_dot_step(acc[s], gl[u], *reinterpret_cast<const f32x4*>(vp[s] + 16 * u));
+        }
     } else {
         PFM_Q_LOAD(xa, 0)
 #pragma unroll
@@ -515,6 +541,9 @@ __device__ __forceinline__ void fastb_g1(const JetDims& j, float* __restrict__ l
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) b[kt] = *reinterpret_cast<const bf16x8*>(vb + 16 * kt);
     f32x4 acc0 = *reinterpret_cast<const f32x4*>(tbl + TBL_G1 + 16 * w + 4 * q), acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: a dependent MFMA waits
+#if PFM_QG1_BATCH > 0
+    __builtin_amdgcn_sched_barrier(0);  // every operand read requested before the first MFMA (hipcc sinks each ds_read to its use: NK dependent LDS round trips)
+#endif
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) {
         if (kt & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gl[kt]), b[kt], acc1, 0, 0, 0);
@@ -531,6 +560,9 @@ __device__ __forceinline__ f32x4 fastb_g2(float* __restrict__ lds, const ColView
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) b[kt] = *reinterpret_cast<const bf16x8*>(gb + 16 * kt);
     f32x4 acc0 = t2, acc1 = {0.f, 0.f, 0.f, 0.f};
+#if PFM_QG1_BATCH > 0
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
         if (kt & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2[kt]), b[kt], acc1, 0, 0, 0);
