@@ -312,23 +312,52 @@ __host__ __device__ inline BwdWork make_bwd_work(int N, int layers, int B) {
 // each), v a 128-vector in LDS, out in LDS.  Wave w takes the panels p_lo + w, + 8, ...: a panel is 512 float4 = 8 coalesced
 // 1-KiB loads per wave (lane l, step s: row l & 15, outputs 4 (4 s + (l >> 4)) ..+3); the 4 DPP rows of a wave are summed with two
 // shuffles, so no cross-wave reduction and no barrier inside.  The caller puts a barrier before reading `out`.
+#ifndef PFM_TGEMV_DB
+#define PFM_TGEMV_DB 0  // (1 = the next panel's weights requested before this panel's FMAs: 15 VGPRs over the budget of the backward chain kernel, and no faster: 0.575 vs 0.572 ms per step)
+#endif
 __device__ __forceinline__ void km16_tgemv(const float* __restrict__ W, int p_lo, int p_hi, const float* __restrict__ v,
                                            float* __restrict__ out) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const f32x4* Wp = reinterpret_cast<const f32x4*>(W);
-    for (int p = p_lo + w; p <= p_hi; p += NW) {
-        f32x4 wv[8];
+    // The vector's float4s of this lane are read per panel in two batches of four, each batch requested before its first use (hipcc
+    // sinks a ds_read to its use: eight dependent LDS round trips per panel before round 4).  PFM_TGEMV_DB = 1 would also keep two
+    // panels of weights in flight (the next panel's eight loads in front of this panel's FMAs): measured, not faster, and over the
+    // register budget of the backward chain kernel.
+    int p = p_lo + w;
+    f32x4 wv[8], wn[8];
+    if (p <= p_hi) {
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) wv[s8] = Wp[(size_t)p * 512 + s8 * 64 + lane];
+    }
+    for (; p <= p_hi; p += NW) {
+        const bool more = PFM_TGEMV_DB && p + NW <= p_hi;
+        if (more) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) wn[s8] = Wp[(size_t)(p + NW) * 512 + s8 * 64 + lane];
+        }
         float a = 0.f;
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(v + 4 * (4 * s8 + (lane >> 4)));
-            a += (wv[s8].x * dv.x + wv[s8].y * dv.y) + (wv[s8].z * dv.z + wv[s8].w * dv.w);
+        for (int h = 0; h < 2; ++h) {
+            f32x4 dv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dv[i] = *reinterpret_cast<const f32x4*>(v + 4 * (4 * (4 * h + i) + (lane >> 4)));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 ww = wv[4 * h + i];
+                a += (ww.x * dv[i].x + ww.y * dv[i].y) + (ww.z * dv[i].z + ww.w * dv[i].w);
+            }
         }
         a += __shfl_xor(a, 16);
         a += __shfl_xor(a, 32);
         if (lane < 16) out[(p - p_lo) * 16 + lane] = a;
+        if (more) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) wv[s8] = wn[s8];
+        } else if (!PFM_TGEMV_DB && p + NW <= p_hi) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) wv[s8] = Wp[(size_t)(p + NW) * 512 + s8 * 64 + lane];
+        }
     }
 }
 
@@ -383,14 +412,24 @@ __device__ __forceinline__ void global_backward(const JetDims& j, const float* _
     __syncthreads();
     // (dW_gl2 = sum_jets vin2 (x) dag2, db_gl2 = sum dag2: epic_bwd_reduce_kernel)   dg1 = W_gl2[g1 rows] . dag2
     if (tid < H) {
-        const float* dq = lds + c.dag2;
+        // dag2 as four float4s read up front, entries >= L selected to zero (the KP16 row is zero-padded there; the guarded form was a
+        // branch + a dependent ds_read_b32 round trip per term).  Same terms in the same order: fma(w, 0, a) = a.
+        const f32x4* dq4 = reinterpret_cast<const f32x4*>(lds + c.dag2);
+        f32x4 d0 = dq4[0], d1 = dq4[1], d2 = dq4[2], d3 = dq4[3];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            d0[jj] = jj < j.L ? d0[jj] : 0.f;
+            d1[jj] = 4 + jj < j.L ? d1[jj] : 0.f;
+            d2[jj] = 8 + jj < j.L ? d2[jj] : 0.f;
+            d3[jj] = 12 + jj < j.L ? d3[jj] : 0.f;
+        }
         float a = 0.f;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            if (jj < j.L) a = fmaf(w0[jj], dq[jj], a);
-            if (4 + jj < j.L) a = fmaf(w1[jj], dq[4 + jj], a);
-            if (8 + jj < j.L) a = fmaf(w2[jj], dq[8 + jj], a);
-            if (12 + jj < j.L) a = fmaf(w3[jj], dq[12 + jj], a);
+            a = fmaf(w0[jj], d0[jj], a);
+            a = fmaf(w1[jj], d1[jj], a);
+            a = fmaf(w2[jj], d2[jj], a);
+            a = fmaf(w3[jj], d3[jj], a);
         }
         lds[c.dag1 + tid] = a * dlrelu(g1v, j.slope);  // dag1 = dg1 * phi'(g1)
     }

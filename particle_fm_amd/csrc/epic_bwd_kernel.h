@@ -119,23 +119,26 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         for (int f0 = 0; f0 < j.F; f0 += 4) {
             const int k = tid & (H - 1), pt = tid >> 7;
             float a[4] = {0.f, 0.f, 0.f, 0.f};
-            // (eight rows' loads in flight per step: one row at a time this loop was a chain of ~40 exposed L2 round trips per jet)
-            int p = pt;
-            for (; p + 28 < n_rows; p += 32) {
-                float hv[8];
+            // Eight rows per step, their saved activations (global) AND their da3 entries (LDS) requested before the first FMA; rows
+            // behind n_rows and features behind F are selected to zero instead of branched around (round 4: the guarded form was a
+            // branch + a dependent ds_read_b32 round trip per term, ~24 in a row per step).  fma(0, h, a) = a: same sums, same order.
+            for (int p = pt; p < n_rows; p += 32) {
+                float hv[8], dv[8][4];
+                bool ok[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) hv[u] = hL[(p + 4 * u) * H + k];
+                for (int u = 0; u < 8; ++u) {
+                    const int row = p + 4 * u;
+                    ok[u] = row < n_rows;
+                    const int rc = ok[u] ? row : p;
+                    hv[u] = hL[rc * H + k];
+#pragma unroll
+                    for (int jf = 0; jf < 4; ++jf) dv[u][jf] = lds[c.da3 + rc * j.F + f0 + jf];  // (reads past a row's F entries stay inside the carve)
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
 #pragma unroll
-                    for (int jf = 0; jf < 4; ++jf)
-                        if (f0 + jf < j.F) a[jf] = fmaf(lds[c.da3 + (p + 4 * u) * j.F + f0 + jf], hv[u], a[jf]);
-            }
-            for (; p < n_rows; p += 4) {
-                const float hv = hL[p * H + k];
-#pragma unroll
-                for (int jf = 0; jf < 4; ++jf)
-                    if (f0 + jf < j.F) a[jf] = fmaf(lds[c.da3 + p * j.F + f0 + jf], hv, a[jf]);
+                    for (int jf = 0; jf < 4; ++jf) a[jf] = fmaf((ok[u] && f0 + jf < j.F) ? dv[u][jf] : 0.f, hv[u], a[jf]);
             }
 #pragma unroll
             for (int jf = 0; jf < 4; ++jf) Hb[(jf * 4 + pt) * H + k] = a[jf];
@@ -164,8 +167,18 @@ __global__ __launch_bounds__(NT, 2) void epic_fm_loss_backward_kernel(
         const int slot = tid & 31;
         for (int p = tid >> 5; p < n_rows; p += NT / 32) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int f = 0; f < j.F; ++f)
-                acc += *reinterpret_cast<const f32x4*>(lds + c.w3 + f * H + 4 * slot) * lds[c.da3 + p * j.F + f];
+            for (int f0 = 0; f0 < j.F; f0 += 4) {  // four features per step, all eight reads up front, features >= F selected to zero
+                f32x4 wr[4];
+                float dq[4];
+#pragma unroll
+                for (int jf = 0; jf < 4; ++jf) {
+                    wr[jf] = *reinterpret_cast<const f32x4*>(lds + c.w3 + min(f0 + jf, j.F - 1) * H + 4 * slot);
+                    dq[jf] = lds[c.da3 + p * j.F + f0 + jf];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jf = 0; jf < 4; ++jf) acc += wr[jf] * (f0 + jf < j.F ? dq[jf] : 0.f);
+            }
             *reinterpret_cast<f32x4*>(G + lds_off(p, slot)) = acc;
         }
     }

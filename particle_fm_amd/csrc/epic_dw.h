@@ -134,10 +134,18 @@ __global__ __launch_bounds__(DW_T, 2) void epic_dw_kernel(const float* __restric
         }
         __syncthreads();
         if (pc + 4 < p1) load_step(pc + 4);  // the next step's rows fly while this step's 256 MFMAs per wave issue
+        // operands of k-step ks + 1 requested in front of the 16 MFMAs of ks (a fence pins that: hipcc sinks each ds_read_b128 down to
+        // its first use, i.e. an LDS round trip in front of every MFMA block -- 12 of the 16 k-steps waited like that in round 3)
+        f32x4 dz = *reinterpret_cast<const f32x4*>(zt + q * DW_S + 64 * wo + 4 * pl);
+        f32x4 an = *reinterpret_cast<const f32x4*>(at + q * DW_S + 64 * wk + 4 * pl);
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            const f32x4 dz = *reinterpret_cast<const f32x4*>(zt + (4 * ks + q) * DW_S + 64 * wo + 4 * pl);
-            const f32x4 an = *reinterpret_cast<const f32x4*>(at + (4 * ks + q) * DW_S + 64 * wk + 4 * pl);
+            f32x4 dzn = dz, ann = an;
+            if (ks + 1 < 16) {
+                dzn = *reinterpret_cast<const f32x4*>(zt + (4 * (ks + 1) + q) * DW_S + 64 * wo + 4 * pl);
+                ann = *reinterpret_cast<const f32x4*>(at + (4 * (ks + 1) + q) * DW_S + 64 * wk + 4 * pl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #define PFM_DW_ROW(c, zc)                                                                   \
     acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc, an.x, acc[c][0], 0, 0, 0);         \
     acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc, an.y, acc[c][1], 0, 0, 0);         \
@@ -145,6 +153,9 @@ __global__ __launch_bounds__(DW_T, 2) void epic_dw_kernel(const float* __restric
     acc[c][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc, an.w, acc[c][3], 0, 0, 0);
             PFM_DW_ROW(0, dz.x) PFM_DW_ROW(1, dz.y) PFM_DW_ROW(2, dz.z) PFM_DW_ROW(3, dz.w)
 #undef PFM_DW_ROW
+            __builtin_amdgcn_sched_barrier(0);
+            dz = dzn;
+            an = ann;
         }
     }
     // partial tile -> scratch in accumulator order: float4 (e = 0..3) at (((w*4 + c)*4 + r)*64 + lane) holds
