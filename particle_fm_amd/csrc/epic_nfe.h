@@ -731,11 +731,17 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
         const float* vin = lds + sv[s].vin;
         float* vin2 = lds + sv[s].vin2;
         // ---- fc_global1 ----
+        // (round 4) the window's inputs read unconditionally and all before the first FMA, rows >= K1 selected to zero: the guarded
+        // form `k < K1 ? vin[k] : 0` compiled to a branch + a dependent ds_read_b32 round trip per panel (tests/diag/isa_mix.py)
         f32x4 p = {0.f, 0.f, 0.f, 0.f};
+        float xg[NGLu];
+#pragma unroll
+        for (int u = 0; u < NGLu; ++u) xg[u] = vin[16 * (tp + u) + pt];  // (< VIN_FLOATS: the windows cover whole 16-row panels)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < NGLu; ++u) {
             const int k = 16 * (tp + u) + pt;
-            p += gl[u] * (k < K1 ? vin[k] : 0.f);
+            p += gl[u] * (k < K1 ? xg[u] : 0.f);
         }
         for (int base = NGLu + tp; 16 * base < K1; base += 4) {  // wider models: the rest the slow way
             f32x4 wa[4];
@@ -753,10 +759,13 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
         if (!STEM) {
             f32x4 p2 = {0.f, 0.f, 0.f, 0.f};
             if (has_b) {
+                float xb[KBp];
+#pragma unroll
+                for (int u = 0; u < KBp; ++u) xb[u] = vin[16 * (tp + u) + pt];
 #pragma unroll
                 for (int u = 0; u < KBp; ++u) {
                     const int k = 16 * (tp + u) + pt;
-                    p2 += wbB[u] * (k < Ke ? vin[k] : 0.f);
+                    p2 += wbB[u] * (k < Ke ? xb[u] : 0.f);
                 }
                 for (int base = KBp + tp; 16 * base < Ke; base += 1) {
                     f32x4 wx[1];
@@ -775,8 +784,9 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         const float* vin2 = lds + sv[s].vin2;
-        f32x4 gp = w2a * (r0 < K2 ? vin2[r0] : 0.f);
-        gp += w2b * (r1 < K2 ? vin2[r1] : 0.f);
+        const float v2a = vin2[r0], v2b = vin2[min(r1, VIN2_FLOATS - 1)];  // unconditional reads, selected below
+        f32x4 gp = w2a * (r0 < K2 ? v2a : 0.f);
+        gp += w2b * (r1 < K2 ? v2b : 0.f);
         gp.x = row_sum_stride4(gp.x); gp.y = row_sum_stride4(gp.y); gp.z = row_sum_stride4(gp.z); gp.w = row_sum_stride4(gp.w);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -789,9 +799,13 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
         const float* vin = lds + sv[s].vin;
-        f32x4 gn = *reinterpret_cast<const f32x4*>(lds + sv[s].g2p + 4 * o4r);
+        f32x4 gpart[NW];  // the eight wave partials requested together, added in wave order
 #pragma unroll
-        for (int ww = 1; ww < NW; ++ww) gn += *reinterpret_cast<const f32x4*>(lds + sv[s].g2p + MAXL * ww + 4 * o4r);
+        for (int ww = 0; ww < NW; ++ww) gpart[ww] = *reinterpret_cast<const f32x4*>(lds + sv[s].g2p + MAXL * ww + 4 * o4r);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 gn = gpart[0];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) gn += gpart[ww];
         if (!STEM && s == 0) PFM_MARK(5);
         gn += bg2;
         if (!STEM) gn += gold[s];  // residual before the activation, epic.py:184-186
@@ -810,7 +824,8 @@ __device__ __forceinline__ void per_jet_phase(const JetDims& j, const float* __r
 #pragma unroll
             for (int i = 0; i < KA; ++i) {
                 const int k = 16 * (i + tp) + pt;
-                const float x = k < Ke ? vin[k] : (k < Ka ? gcopy[k - Ke] : 0.f);
+                const float xv = vin[k], xc = gcopy[min(max(k - Ke, 0), MAXL - 1)];  // both read unconditionally, one selected
+                const float x = k < Ke ? xv : (k < Ka ? xc : 0.f);
                 p1 += wbA[i] * x;
             }
             for (int base = KA + tp; 16 * base < Ka; ++base) {  // wider extras than the register window
