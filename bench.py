@@ -473,7 +473,8 @@ def main():
                                                  "finishes -- 51 % of the parameters -- reduced next to the dW GEMM of the rest)"),
                 "overlapped": bool(trainer.split_backward),
                 "train_ms_alone_flat_allreduce": train_alone_modes.get("flat_allreduce"),
-                "train_ms_alone_bucketed_overlap": train_alone_modes.get("bucketed_overlap")},
+                "train_ms_alone_bucketed_overlap": train_alone_modes.get("bucketed_overlap"),
+                "two_phase_direct": None},  # filled by the last leg of the run (below)
             "per_rank": {"train_ms_alone": [float(v) for v in per_rank[:, 0]], "allreduce_ms_alone": [float(v) for v in per_rank[:, 1]],
                          "train_ms_in_timed_region": [float(v) for v in per_rank[:, 2]],
                          "sample_ms_in_timed_region": [float(v) for v in per_rank[:, 3]],
@@ -551,8 +552,64 @@ def main():
             log("cpu baseline (oracle on the host cores) ...")
             res["cpu_baseline"] = cpu_baseline(state_cpu, freqs, args.ode_steps)
             log("cpu baseline done")
-        print(json.dumps(res))
+    # N > 1, LAST leg of the run, informational: the direct two-phase gradient exchange (engine.GradSync.two_phase_sum: all-to-all of 1/N
+    # slices over the point-to-point links, local sum, all-gather; SURVEY 5.8 / 8e's comparison against RCCL's ring at 2.2 MB) -- the
+    # exchange alone and the train step alone with it.  It has never run on more than one RCCL rank, so it comes behind everything the
+    # line depends on and cannot cost the line: an exception is recorded in it, and if the leg has not finished after 90 s rank 0 prints
+    # the line without it and every rank ends with exit code 0.
     if world > 1:
+        import threading
+        two_phase = {"train_ms_alone": None, "exchange_ms_alone": None, "error": None,
+                     "note": "informational, outside the timed region: all-to-all of 1/N slices + local sum + all-gather "
+                             "(PFM_DP_EXCHANGE=two_phase) instead of the ring all-reduce; exchange_ms_alone compares with "
+                             "allreduce_ms_alone, train_ms_alone with grad_exchange.train_ms_alone_flat_allreduce"}
+
+        def give_up():
+            if rank == 0:
+                two_phase["error"] = "did not finish within 90 s"
+                res["grad_exchange"]["two_phase_direct"] = two_phase
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+
+        guard = threading.Timer(float(os.environ.get("PFM_BENCH_TWO_PHASE_TIMEOUT", 90)), give_up)
+        guard.daemon = True
+        guard.start()
+        keep_x = trainer.sync.exchange
+        try:
+            log(f"rank {rank}: two-phase exchange timing ...")
+            trainer.sync.exchange = "two_phase"
+            with torch.cuda.stream(main):
+                trainer.sync.sync(trainer.fp.grad)
+                t0e.record(main)
+                for _ in range(10):
+                    trainer.sync.sync(trainer.fp.grad)
+                t1e.record(main)
+            torch.cuda.synchronize(dev)
+            two_phase["exchange_ms_alone"] = t0e.elapsed_time(t1e) / 10
+            with torch.cuda.stream(main):
+                for _ in range(3):
+                    trainer.step((x, mask, cond))
+                t0e.record(main)
+                for _ in range(TRAIN_ALONE_REPS):
+                    trainer.step((x, mask, cond))
+                t1e.record(main)
+            torch.cuda.synchronize(dev)
+            two_phase["train_ms_alone"] = t0e.elapsed_time(t1e) / TRAIN_ALONE_REPS
+            check_replicas(f"after {3 + TRAIN_ALONE_REPS} steps with the two-phase exchange")
+        except SystemExit:
+            raise
+        except Exception as exc:  # noqa: BLE001 -- diagnostic leg only
+            two_phase["error"] = f"{type(exc).__name__}: {exc}"[:300]
+        finally:
+            trainer.sync.exchange = keep_x
+            guard.cancel()
+        if rank == 0:
+            res["grad_exchange"]["two_phase_direct"] = two_phase
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        if two_phase["error"]:
+            os._exit(0)  # ranks may be out of step behind a failed collective: do not wait for each other in the teardown
         dist.destroy_process_group()
 
 

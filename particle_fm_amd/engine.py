@@ -81,16 +81,58 @@ class GradSync:
     """Gradient exchange of the data-parallel step: one all-reduce of the flat buffer.  Backend "nccl" is RCCL
     on ROCm; "gloo" serves the CPU tests."""
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, exchange: Optional[str] = None):
+        import os
         self.group = process_group
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         self.world = dist.get_world_size(process_group) if self.enabled else 1
+        self.rank = dist.get_rank(process_group) if self.enabled else 0
+        # "allreduce" (default): one RCCL all-reduce (a ring: 2 (N - 1) steps of 1/N of the buffer each).
+        # "two_phase" (opt-in, PFM_DP_EXCHANGE=two_phase): the direct exchange SURVEY 5.8 / 8e names for the 2.2 MB gradient on
+        # point-to-point xGMI -- (1) every rank sends slice r of its buffer straight to rank r (one all-to-all: all 7 links of a GPU at
+        # once, 1/N of the buffer per link), (2) rank r adds the N copies of its slice (one reduction kernel), (3) one all-gather hands the summed
+        # slices round: two communication steps instead of 2 (N - 1).  Each slice is summed by exactly one rank, so every replica receives
+        # the same bits.  Never run on more than one RCCL rank (no multi-GPU node in this pool): covered by the gloo world-2 test and
+        # timed next to the all-reduce by bench.py --gpus N, not used in its timed region.
+        self.exchange = exchange or os.environ.get("PFM_DP_EXCHANGE", "allreduce")
+        if self.exchange not in ("allreduce", "two_phase"):
+            raise ValueError(f"PFM_DP_EXCHANGE / exchange: 'allreduce' or 'two_phase', not {self.exchange!r}")
+        self._tp = None
 
     def sync(self, flat_grad: torch.Tensor) -> float:
         """Sums the buffer over ranks in place; returns the factor (1/world) that turns it into the mean."""
         if self.enabled:
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            if self.exchange == "two_phase":
+                self.two_phase_sum(flat_grad)
+            else:
+                dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         return 1.0 / self.world
+
+    def two_phase_sum(self, flat: torch.Tensor) -> None:
+        """flat <- sum over ranks, by all-to-all of slices + local sum + all-gather (see __init__)."""
+        W, n = self.world, flat.numel()
+        per = ((n + W - 1) // W + 3) // 4 * 4  # floats per slice (16-byte multiples; the padding behind n stays zero)
+        key = (n, flat.device, flat.dtype)
+        if self._tp is None or self._tp[0] != key:
+            self._tp = (key, torch.zeros(W * per, device=flat.device, dtype=flat.dtype), torch.empty(W * per, device=flat.device, dtype=flat.dtype),
+                        torch.empty(per, device=flat.device, dtype=flat.dtype))
+        _, send, recv, shard = self._tp
+        send[:n].copy_(flat)
+        if dist.get_backend(self.group) == "gloo":  # (CPU tests; gloo has no all_to_all_single: the same slices by way of an all_gather)
+            every = [torch.empty_like(send) for _ in range(W)]
+            dist.all_gather(every, send, group=self.group)
+            for s_ in range(W):
+                recv.view(W, per)[s_].copy_(every[s_].view(W, per)[self.rank])
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)  # recv[s] = slice `rank` of rank s's buffer
+        torch.sum(recv.view(W, per), dim=0, out=shard)              # one kernel; only this rank sums this slice
+        if dist.get_backend(self.group) == "gloo":
+            parts = [torch.empty_like(shard) for _ in range(W)]
+            dist.all_gather(parts, shard, group=self.group)
+            torch.cat(parts, out=send)
+        else:
+            dist.all_gather_into_tensor(send, shard, group=self.group)
+        flat.copy_(send[:n])
 
     def start(self, part: torch.Tensor):
         """Begins the sum of one contiguous part of the flat gradient (ordered behind what the current stream has queued so far) and

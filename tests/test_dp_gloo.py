@@ -74,6 +74,20 @@ def _worker(rank, world, port, out):
         if rank == 0:
             for k, p in m.named_parameters():
                 torch.testing.assert_close(p.grad, 0.5 * (g0[k] + g1[k]), atol=1e-7, rtol=1e-5)
+        # the direct two-phase exchange (PFM_DP_EXCHANGE=two_phase: all-to-all of slices, local sum, all-gather): the same means, and
+        # the SAME BITS on every rank (each slice is summed by exactly one rank)
+        tp = GradSync(exchange="two_phase")
+        fp.zero_grad()
+        for k, p in m.named_parameters():
+            p.grad.copy_(grads[k])
+        mul = tp.sync(fp.grad)
+        fp.grad.mul_(mul)
+        both = [torch.empty_like(fp.grad) for _ in range(world)]
+        dist.all_gather(both, fp.grad)
+        assert torch.equal(both[0], both[1])
+        if rank == 0:
+            for k, p in m.named_parameters():
+                torch.testing.assert_close(p.grad, 0.5 * (g0[k] + g1[k]), atol=1e-7, rtol=1e-5)
             out.put("ok")
     finally:
         dist.destroy_process_group()

@@ -64,6 +64,10 @@ def test_two_rank_launch_rehearsal():
     ge = d["grad_exchange"]
     assert ge["overlapped"] is False and ge["train_ms_alone_flat_allreduce"] > 0 and ge["train_ms_alone_bucketed_overlap"] > 0
     assert "bucketed_overlap" in res.stderr and "flat_allreduce" in res.stderr
+    # ... and, as the last leg of the run, the direct two-phase exchange (all-to-all of slices + local sum + all-gather; under gloo by way
+    # of all_gather): timed, replicas still bit-identical, no error recorded
+    tp = ge["two_phase_direct"]
+    assert tp["error"] is None and tp["exchange_ms_alone"] > 0 and tp["train_ms_alone"] > 0, tp
 
 
 def test_a_stage_that_hangs_ends_the_process_with_a_non_zero_code():
