@@ -16,6 +16,8 @@ model = SetFlowMatchingLitModule(optimizer=None, **bench.HP).to(dev)
 tr = FusedFMTrainer(model, lr=1e-3, weight_decay=5e-5, max_grad_norm=0.5, ema_decay=0.999)
 x, mask, cond = (a.to(dev) for a in bench.synthetic_batch(256, 150, 3, 12345))
 z = (torch.randn(256, 150, 3, generator=torch.Generator().manual_seed(9999)) * mask.cpu()).to(dev)
+if os.environ.get('PFM_PACK', '1') == '1':
+    model.flows[0].net.set_jet_packing(True)  # (what bench.py does by default)
 blobs = [tr.snapshot_blob(150) for _ in range(2)]
 streams = concurrent_streams(4, dev)
 
@@ -31,5 +33,6 @@ def run(nstreams, nblobs):
 
 for _ in range(2):
     run(2, 2)
-for name, ns, nb in (("one stream", 1, 1), ("two streams, one blob", 2, 1), ("two streams, two blobs", 2, 2), ("two streams, one blob", 2, 1), ("two streams, two blobs", 2, 2), ("three streams", 3, 2), ("four streams", 4, 2), ("three streams", 3, 2)):
+CASES = (("one stream", 1, 1),) if os.environ.get("PFM_ONLY_ONE") else None
+for name, ns, nb in CASES or (("one stream", 1, 1), ("two streams, one blob", 2, 1), ("two streams, two blobs", 2, 2), ("two streams, one blob", 2, 1), ("two streams, two blobs", 2, 2), ("three streams", 3, 2), ("four streams", 4, 2), ("three streams", 3, 2)):
     print(f"{name:26s} {run(ns, nb):8.3f} ms per sample of 256 jets", flush=True)
