@@ -24,6 +24,40 @@ extern "C" int pfm_diag_read_stamps(unsigned long long* out, int* n) {
 }
 #endif
 
+// Diagnostic build only (-DPFM_WGT, tests/diag/wg_times.py; never the shipped library): every workgroup of the lean midpoint sampler
+// records its start and end on the 100 MHz constant clock -- is a pipeline of launches short of its CU-time bound because workgroups
+// wait for a CU, or because they run longer next to each other?
+#ifdef PFM_WGT
+namespace pfm {
+constexpr int WGT_MAX = 32768;
+__device__ unsigned long long g_pfm_wgt[2 * WGT_MAX];
+__device__ int g_pfm_nwgt;
+}
+extern "C" int pfm_diag_read_wgt(unsigned long long* out, int cap, int* n) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(n, HIP_SYMBOL(pfm::g_pfm_nwgt), sizeof(int));
+    const int m = *n < cap ? *n : cap;
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(pfm::g_pfm_wgt), sizeof(unsigned long long) * 2 * (m < pfm::WGT_MAX ? m : pfm::WGT_MAX));
+    int zero = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(pfm::g_pfm_nwgt), &zero, sizeof(int));
+    return 0;
+}
+#define PFM_WGT_BEGIN                                         \
+    unsigned long long wgt0_ = 0;                             \
+    if (threadIdx.x == 0) wgt0_ = __builtin_amdgcn_s_memrealtime();
+#define PFM_WGT_END                                                       \
+    if (threadIdx.x == 0) {                                               \
+        const int i_ = atomicAdd(&g_pfm_nwgt, 1);                         \
+        if (i_ < WGT_MAX) {                                               \
+            g_pfm_wgt[2 * i_] = wgt0_;                                    \
+            g_pfm_wgt[2 * i_ + 1] = __builtin_amdgcn_s_memrealtime();     \
+        }                                                                 \
+    }
+#else
+#define PFM_WGT_BEGIN
+#define PFM_WGT_END
+#endif
+
 namespace pfm {
 
 thread_local char g_err[512] = "";
@@ -303,6 +337,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
         jetA = pack[1 + 2 * blockIdx.x];
         jetB = pack[2 + 2 * blockIdx.x];
     }
+    PFM_WGT_BEGIN
     float* xs = lds + c.xs;
     float* yin = lds + c.yin;
     const int F = j.F;
@@ -333,6 +368,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
             oA[i] = p < sg.n0 ? xs[i] : 0.f;  // rows behind a jet's last valid particle are masked: 0
             oB[i] = p < sg.n1 ? xs[sg.r1 * F + i] : 0.f;
         }
+        PFM_WGT_END
         return;
     }
     const int jet = jetA;
@@ -368,6 +404,7 @@ __global__ __launch_bounds__(NT, 2) void epic_sample_midpoint_fast_kernel(
     }
     float* oj = x_out + (size_t)jet * j.N * j.F;
     for (int i = tid; i < j.N * j.F; i += NT) oj[i] = xs[i];
+    PFM_WGT_END
 }
 
 // ------------------------------------------------------------------------------------------------
