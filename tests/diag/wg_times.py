@@ -53,3 +53,33 @@ print(f"one launch alone: {m} workgroups, wall {wall:.2f} ms, span {span:.2f} ms
 wall, m, tot, span, dur = run(K, NS)
 print(f"{K} launches on {NS} streams: {m} workgroups, wall {wall / K:.3f} ms per launch, sum of workgroup durations / 256 = {tot / 256 / K:.3f} ms per launch "
       f"(CU time really spent), span {span / K:.3f}; idle share {1 - tot / 256 / span:.3f}")
+
+# busy-CU count over time (every workgroup holds one CU: 160 KB of LDS), sampled every 0.25 ms over the steady part of the run
+lib.pfm_diag_read_wgt(buf, CAP, ctypes.byref(n))
+torch.cuda.synchronize()
+with torch.no_grad():
+    for i in range(K):
+        with torch.cuda.stream(streams[i % NS]):
+            model(z, cond=None, mask=mask, reverse=True, ode_solver="midpoint", ode_steps=100, weights=blobs[i % 2])
+torch.cuda.synchronize()
+lib.pfm_diag_read_wgt(buf, CAP, ctypes.byref(n))
+m = min(n.value, CAP)
+iv = sorted((buf[2 * i], buf[2 * i + 1]) for i in range(m))
+t0 = min(a for a, _ in iv)
+T1 = max(b for _, b in iv)
+step = 25_000  # 0.25 ms at 100 MHz
+lo, hi = t0 + (T1 - t0) // 4, t0 + 3 * (T1 - t0) // 4
+counts = []
+t = lo
+while t < hi:
+    counts.append(sum(1 for a, b in iv if a <= t < b))
+    t += step
+import collections
+hist = collections.Counter((c // 8) * 8 for c in counts)
+print("busy CUs (middle half of the run), share of samples per bucket of 8:")
+for k_ in sorted(hist):
+    print(f"  {k_:3d}-{k_ + 7:3d}: {hist[k_] / len(counts):6.3f}")
+print("mean busy", sum(counts) / len(counts))
+# gaps: for every workgroup start, how long had the longest-idle CU been free?  (approximation: time since the (busy-256)th last end)
+line = " ".join(f"{c:3d}" for c in counts[:160])
+print("first 40 ms of the window, one sample per 0.25 ms:\n" + line)
