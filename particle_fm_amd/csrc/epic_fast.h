@@ -35,6 +35,9 @@ namespace pfm {
 #ifndef PFM_BCHAIN
 #define PFM_BCHAIN 1          // bf16 descriptors: the lean sampler's chains on the matrix pipe (diagnostic builds: 0 = the fp32 VALU chains)
 #endif
+#ifndef PFM_RB16
+#define PFM_RB16 1            // bf16 lean samplers: 1 = activations resident as bf16 planes (gemm_phase<.., RB16>); 0 (diagnostic builds) = fp32 rows, converted at every read
+#endif
 #ifndef PFM_QG1_BATCH
 #define PFM_QG1_BATCH 9       // fc_global1 of the KQ16 chains: input panels read per batch and jet (one jet; two jets: half); 0 = hipcc's own order
 #endif
@@ -89,6 +92,9 @@ __device__ __forceinline__ float fast_l1_weight(const pfm_epic_desc& d, const Je
     const int pl = lane & 15, q = lane >> 4;
     return q < j.F ? blob[d.l1x.W + q * H + 16 * w + pl] : 0.f;  // A[i = pl][k = q] = Wx[k][16 w + i]
 }
+// RB16 (bf16-resident activations, gemm_phase): x1 goes as fp32 to bufB (fc_l2's residual input, overwritten in place by its output) and
+// as bf16 to plane A (fc_l2's matrix operand).
+template <bool RB16 = false>
 __device__ __forceinline__ void fast_stem_l1(const JetDims& j, float* __restrict__ lds, const Carve& c, int n_rows, float aw, f32x4 bias) {
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
     const int pl = lane & 15, q = lane >> 4;
@@ -101,7 +107,14 @@ __device__ __forceinline__ void fast_stem_l1(const JetDims& j, float* __restrict
         const float bv = (kf && p < n_rows) ? yin[p * j.F + q] : 0.f;  // B[k = q][j = pl]
         f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv, bias, 0, 0, 0);
         acc = lrelu4(acc, j.slope);
-        if (p < n_rows) *reinterpret_cast<f32x4*>(lds + c.bufA + lds_off(p, oslot)) = acc;
+        if (p < n_rows) {
+            if constexpr (RB16) {
+                *reinterpret_cast<f32x4*>(lds + c.bufB + lds_off(p, oslot)) = acc;
+                *reinterpret_cast<s16x4*>(lds + c.bufA + p * (H / 2) + (((4 * (w >> 1) + q) ^ pl) << 2) + 2 * (w & 1)) = pack_bf16(acc);
+            } else {
+                *reinterpret_cast<f32x4*>(lds + c.bufA + lds_off(p, oslot)) = acc;
+            }
+        }
     }
 }
 
@@ -624,7 +637,7 @@ __device__ __forceinline__ void fastb_chain_layer(const JetDims& j, float* __res
 // phase).  emit(p, f, lrelu(b3[f] + W3[f].x[p]) * mask[p]) for the rows p < n_rows ONLY: the sampler's state rows behind a jet's
 // last valid particle start as z * mask = 0 and an update by 0 would leave them there.  epic.py:387-391
 // AF == 4: the panel's MFMA_A16 copy on the bf16 pipe (four v_mfma_f32_16x16x32_bf16 per tile)
-template <int AF, typename Emit>
+template <int AF, bool RB16 = false, typename Emit>
 __device__ __forceinline__ void fast_head(const JetDims& j, float* __restrict__ lds, const Carve& c, int n_rows,
                                           const f32x4 (&a)[AF], f32x4 b3, Emit emit) {
     const int tid = launder(threadIdx.x), lane = tid & 63, w = tid >> 6;
@@ -638,17 +651,30 @@ __device__ __forceinline__ void fast_head(const JetDims& j, float* __restrict__ 
         const int p = tile * TILE + pl;
         const float* s0 = bufB + tile * TILE * H;
         f32x4 b[8];
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt) b[kt] = *reinterpret_cast<const f32x4*>(s0 + koff[kt]);
         // two accumulator chains over the K halves (a dependent fp32 MFMA waits 40 cycles, the pipe issues one every 32)
         f32x4 acc0 = b3, acc1 = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (AF == 4) {
+        if constexpr (AF == 4 && !RB16) {
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) b[kt] = *reinterpret_cast<const f32x4*>(s0 + koff[kt]);
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[kt2]), pack_bf16x8(b[2 * kt2], b[2 * kt2 + 1]), acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[kt2 + 2]), pack_bf16x8(b[2 * kt2 + 4], b[2 * kt2 + 5]), acc1, 0, 0, 0);
             }
+        } else if constexpr (AF == 4) {
+            // bf16-resident activations (gemm_phase<.., RB16>): the last local linear 2 left its rows as bf16 in plane B, one 16-byte
+            // unit per K-quarter and lane
+            const float* pb = lds + c.bufA + (c.bufB - c.bufA) / 2 + (tile * TILE + pl) * (H / 2);
+#pragma unroll
+            for (int kt2 = 0; kt2 < 4; ++kt2) b[kt2] = *reinterpret_cast<const f32x4*>(pb + (((4 * kt2 + q) ^ pl) << 2));
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[kt2]), __builtin_bit_cast(bf16x8, b[kt2]), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[kt2 + 2]), __builtin_bit_cast(bf16x8, b[kt2 + 2]), acc1, 0, 0, 0);
+            }
         } else {
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) b[kt] = *reinterpret_cast<const f32x4*>(s0 + koff[kt]);
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt].x, b[kt].x, acc0, 0, 0, 0);
@@ -767,6 +793,12 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     }
     float* bufA = lds + c.bufA;
     float* bufB = lds + c.bufB;
+    // bf16 flavour: the activations the MFMAs read live as BF16 PLANES (gemm_phase<.., RB16>): bufA's N x 128 floats hold two of them --
+    // plane A (what local linear 1 / fc_l1 writes: read by the following phase only) and plane B (the bf16 copy of bufB's fp32 rows, the
+    // residual stream x_local).  Same LDS bytes as before, half the operand reads, an eighth of the conversions.
+    constexpr bool RB16 = BF16 && PFM_RB16;
+    float* planeA = bufA;
+    float* planeB = bufA + (c.bufB - c.bufA) / 2;
     const float* maskf = lds + c.maskf;
     const float* tbS = tbE + (size_t)j.layers * TB_SLOT;
     const float* ctS = COND ? ct + (size_t)j.layers * TB_SLOT : nullptr;
@@ -803,7 +835,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     else if constexpr (!QCH) L = fast_chain_loads(rs, d.g2.W, w2r0, tbS, TB_SG1, TB_SG1, TB_SG2, nullptr, TB_SJ2);
     else L = fastq_chain_loads(rs, d.q_g2, tbS, TB_SG1, TB_SG1, TB_SG2, TB_SJ2, ctS);
 #ifndef PFM_AB_NOL1  // (PFM_AB_*: timing-only ablation builds of tests/diag/fixed_cost_table.sh; results are garbage)
-    fast_stem_l1(j, lds, c, n_rows, cy.aw, cy.sj1);
+    fast_stem_l1<RB16>(j, lds, c, n_rows, cy.aw, cy.sj1);
 #endif
     if (COND || L2LDS) {  // fc_l2 reads its per-jet bias (time (+ conditioning) term) from LDS: in place before the barrier in front of it
         fast_chain_publish(L, tbl);
@@ -816,8 +848,12 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         Prefetch<NGLS> pf{rs, gl, nullptr, nullptr, nullptr, BCH ? PfSeg{d.b_g1, 256, ((w * FNBS) * 64 + lane) * 16} : (!QCH ? seg_panels(d.g1.W, FTP, tid) : seg_panels(d.q_g1, 0, tid)), {}, {}, {}};
         const float* bj = (COND || L2LDS) ? lds + c.bj2 : tbS + TB_SJ2;
         s2t.bj = bj;
-        gemm_phase<true, true, false, BF16, decltype(pf), NSEG, true, AF, BCH>(cy.a2, bufA, bufB, bufA, bj, maskf, j, lds, c, nullptr, nullptr, n_rows, pf,
-                                                                 s2t, &qpt);
+        if constexpr (RB16)
+            gemm_phase<true, true, false, BF16, decltype(pf), NSEG, true, AF, BCH, true>(cy.a2, planeA, planeB, bufB, bj, maskf, j, lds, c, nullptr, nullptr,
+                                                                                         n_rows, pf, s2t, &qpt, bufB);
+        else
+            gemm_phase<true, true, false, BF16, decltype(pf), NSEG, true, AF, BCH>(cy.a2, bufA, bufB, bufA, bj, maskf, j, lds, c, nullptr, nullptr, n_rows, pf,
+                                                                                   s2t, &qpt);
     }
     if (!(COND || L2LDS)) fast_chain_publish(L, tbl);  // (the previous evaluation's last chain read tbl many barriers ago)
     __syncthreads();
@@ -864,8 +900,12 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
         // layer (gl / wbA were consumed by the chain above), so that nothing the next chain waits for is requested late
         {
             Prefetch<AF, NGL, 1> pf{rs, cy.a2, gl, wbA, nullptr, seg_afrag_lin<BF16>(ly.lc2, w, lane), gl1_seg(kn), we1_seg(kn), {}};
-            gemm_phase<false, false, false, BF16, decltype(pf), NSEG>(cy.a1, bufB, bufA, nullptr, lds + c.bj1, maskf, j, lds, c, nullptr,
-                                                                       nullptr, n_rows, pf, s2p, &qp1);
+            if constexpr (RB16)
+                gemm_phase<false, false, false, BF16, decltype(pf), NSEG, true, AF, false, true>(cy.a1, planeB, planeA, nullptr, lds + c.bj1, maskf, j, lds, c,
+                                                                                                 nullptr, nullptr, n_rows, pf, s2p, &qp1);
+            else
+                gemm_phase<false, false, false, BF16, decltype(pf), NSEG>(cy.a1, bufB, bufA, nullptr, lds + c.bj1, maskf, j, lds, c, nullptr,
+                                                                           nullptr, n_rows, pf, s2p, &qp1);
         }
 #ifndef PFM_AB_NOBAR
         __syncthreads();
@@ -885,8 +925,12 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
             Prefetch<AF> pf{rs, cy.a1, nullptr, nullptr, nullptr, sa, {}, {}, {}};
             const float* bj = (COND || L2LDS) ? lds + c.bj2 : tbK + TB_L2;
             s2t.bj = bj;
-            gemm_phase<true, true, false, BF16, decltype(pf), NSEG, false, AF, BCH>(cy.a2, bufA, bufB, bufB, bj, maskf, j, lds, c, nullptr, nullptr, n_rows,
-                                                                            pf, s2t, &qpt);
+            if constexpr (RB16)
+                gemm_phase<true, true, false, BF16, decltype(pf), NSEG, false, AF, BCH, true>(cy.a2, planeA, planeB, bufB, bj, maskf, j, lds, c, nullptr, nullptr,
+                                                                                              n_rows, pf, s2t, &qpt, bufB);
+            else
+                gemm_phase<true, true, false, BF16, decltype(pf), NSEG, false, AF, BCH>(cy.a2, bufA, bufB, bufB, bj, maskf, j, lds, c, nullptr, nullptr, n_rows,
+                                                                                pf, s2t, &qpt);
             // this layer's chain read tbl two barriers ago; the next one reads it behind the barrier below.  The publish waits for the
             // staged row with a vmcnt that covers every load issued before it: the riders a short jet had no K-quarter for go behind it
             fast_chain_publish(L, tbl);
@@ -899,7 +943,7 @@ __device__ __forceinline__ void fast_eval(const pfm_epic_desc& d, const JetDims&
     PFM_STAMP(20);
     fast_carry_request(cy, d, rs, tbE_next + (size_t)j.layers * TB_SLOT, ctS);  // lands behind the head
 #ifndef PFM_AB_NOHEAD
-    fast_head<AF>(j, lds, c, n_rows, cy.a1, b3, emit);
+    fast_head<AF, RB16>(j, lds, c, n_rows, cy.a1, b3, emit);
 #endif
 }
 

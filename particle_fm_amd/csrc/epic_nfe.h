@@ -226,13 +226,24 @@ __device__ __forceinline__ int phase_full_pairs(int n_rows) {
 // TAIL = false: the caller issues pf.issue_tail(phase_full_pairs<BF16>(n_rows)) itself (behind work of its own that must not wait for
 // those loads: a vmcnt wait covers every load issued before it)
 // AF: float4 registers of the A operand: 8 (fp32 MFMA_A fragment; BF16: rounded here) or, BF16 only, 4 (an MFMA_A16 fragment)
-template <bool RESID, bool POOL, bool SAVE, bool BF16 = false, typename PF = PfNone, int NSEG = 1, bool TAIL = true, int AF = 8, bool VB16 = false>
+// RB16 (the lean bf16 samplers, round 4 -- "resident bf16"): src and dst are BF16 PLANES -- rows of 128 bf16 = 16 sixteen-byte slots,
+// slot s of row r at float offset r * 64 + ((s ^ (r & 15)) << 2), slot 4 kt2 + q = the eight k (32 kt2 + 16 h + 4 q + r) a lane (row, q)
+// feeds v_mfma_f32_16x16x32_bf16 for K-quarter kt2 (pack_bf16x8's order) -- written by the PRODUCING phase's epilogue (one
+// v_cvt_pk_bf16_f32 pair + ds_write_b64 per tile and lane) and read as ONE ds_read_b128 per tile and quarter, no conversion: every
+// activation was rounded eight times over before (once per consuming wave), 32 v_cvt_pk per tile pair and wave against 8 MFMAs.  dst32
+// (or nullptr): where the same rows also go as fp32 (the residual input of the next local linear 2).  Same roundings of the same
+// numbers: bit-identical to the fp32-resident bf16 flavour.
+template <bool RESID, bool POOL, bool SAVE, bool BF16 = false, typename PF = PfNone, int NSEG = 1, bool TAIL = true, int AF = 8, bool VB16 = false,
+          bool RB16 = false>
 __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __restrict__ src,
                                            float* __restrict__ dst, const float* __restrict__ resid,
                                            const float* __restrict__ bj, const float* __restrict__ maskf,
                                            const JetDims& j, float* __restrict__ lds, const Carve& c,
                                            float* __restrict__ save, float* __restrict__ save_pool, int n_rows,
-                                           const PF& pf = PF{}, const Seg2Phase& s2 = Seg2Phase{}, const QuadPhase* qp = nullptr) {
+                                           const PF& pf = PF{}, const Seg2Phase& s2 = Seg2Phase{}, const QuadPhase* qp = nullptr,
+                                           float* __restrict__ dst32 = nullptr) {
+    static_assert(!RB16 || (BF16 && !SAVE), "bf16-resident activations: the lean bf16 samplers");
+    constexpr int SROW = RB16 ? H / 2 : H;  // floats per activation row of src / dst
     static_assert(NSEG == 1 || NSEG == 2 || NSEG == 4, "one jet, a packed pair, or four 32-row slots");
     static_assert(!(NSEG == 4 && SAVE), "quad mode: inference only");
     static_assert(AF == 8 || (BF16 && AF == 4), "A operand: 8 fp32 float4s, or 4 pre-packed bf16 ones for the bf16 pipe");
@@ -258,18 +269,25 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
     // kt >= 4 is slot 4 (kt - 4) + q plus 16 (pl < 16 never touches bit 4), i.e. 64 floats further: an immediate in the ds_read
     int koff4[4];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) koff4[kt] = pl * H + (((4 * kt + q) ^ pl) << 2);
+    for (int kt = 0; kt < 4; ++kt) koff4[kt] = RB16 ? pl * SROW + (((4 * kt + q) ^ pl) << 2) : pl * H + (((4 * kt + q) ^ pl) << 2);
 #define PFM_KOFF(kt) (koff4[(kt) & 3] + 64 * ((kt) >> 2))
     const int ooff = pl * H + ((oslot ^ pl) << 2);
+    // RB16: where this lane's four output features (16 w + 4 q ..) go in a bf16 plane: slot 4 (w >> 1) + q, half w & 1 (8 bytes = 2 floats)
+    const int oofb = pl * SROW + (((4 * (w >> 1) + q) ^ pl) << 2) + 2 * (w & 1);
     float* const sink = lds + c.dummy;
     // operand staging: two register sets X / Y of one K-quarter (2 kt x 2 tiles = 16 VGPRs each)
     f32x4 X0[2], X1[2], Y0[2], Y1[2];
     f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
     f32x4 pacc0 = {0.f, 0.f, 0.f, 0.f}, pacc1 = {0.f, 0.f, 0.f, 0.f};
 #define PFM_LOADQ(B0, B1, base, qq)                                                        \
+    if constexpr (RB16) { /* one 16-byte unit = the quarter's eight bf16 of this lane */   \
+        B0[0] = *reinterpret_cast<const f32x4*>((base) + koff4[(qq)]);                     \
+        B1[0] = *reinterpret_cast<const f32x4*>((base) + TILE * SROW + koff4[(qq)]);       \
+    } else {                                                                               \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                    \
         B0[kk] = *reinterpret_cast<const f32x4*>((base) + PFM_KOFF(2 * (qq) + kk));            \
         B1[kk] = *reinterpret_cast<const f32x4*>((base) + TILE * H + PFM_KOFF(2 * (qq) + kk)); \
+    }                                                                                      \
     }
     // bf16 pipe: one v_mfma_f32_16x16x32_bf16 per tile and K-quarter (32 k: the two float4s of the quarter, see pack_bf16x8)
     bf16x8 ab[4];
@@ -281,7 +299,10 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
         }
     }
 #define PFM_MFMAQ(B0, B1, qq)                                                                                  \
-    if constexpr (BF16) {                                                                                      \
+    if constexpr (RB16) {                                                                                      \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[(qq)], __builtin_bit_cast(bf16x8, B0[0]), acc0, 0, 0, 0); \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[(qq)], __builtin_bit_cast(bf16x8, B1[0]), acc1, 0, 0, 0); \
+    } else if constexpr (BF16) {                                                                               \
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[(qq)], pack_bf16x8(B0[0], B0[1]), acc0, 0, 0, 0);    \
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[(qq)], pack_bf16x8(B1[0], B1[1]), acc1, 0, 0, 0);    \
     } else {                                                                                                   \
@@ -314,9 +335,20 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
         // packed, no canonicalising copies (pfm_common.h).  Interior pairs (LATE): called behind the first K-quarter of the next pair
         if (late) lrelu8_pk<false>(e0, e1, slope2);
         else lrelu8_pk<true>(e0, e1, slope2);
-        float* d0 = dst + pair * 2 * TILE * H + ooff;
-        *reinterpret_cast<f32x4*>(d0) = e0;
-        *reinterpret_cast<f32x4*>(d0 + TILE * H) = e1;
+        if constexpr (RB16) {
+            float* db = dst + pair * 2 * TILE * SROW + oofb;
+            *reinterpret_cast<s16x4*>(db) = pack_bf16(e0);
+            *reinterpret_cast<s16x4*>(db + TILE * SROW) = pack_bf16(e1);
+            if (dst32) {
+                float* d0 = dst32 + pair * 2 * TILE * H + ooff;
+                *reinterpret_cast<f32x4*>(d0) = e0;
+                *reinterpret_cast<f32x4*>(d0 + TILE * H) = e1;
+            }
+        } else {
+            float* d0 = dst + pair * 2 * TILE * H + ooff;
+            *reinterpret_cast<f32x4*>(d0) = e0;
+            *reinterpret_cast<f32x4*>(d0 + TILE * H) = e1;
+        }
         if (SAVE) {
             const int p0 = pair * 2 * TILE + pl;
             *reinterpret_cast<f32x4*>(save + p0 * H + 4 * oslot) = e0;
@@ -345,10 +377,23 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
         return;
 #endif
         lrelu8_pk(e0, e1, slope2);
+        if constexpr (RB16) {
+            float* b0 = v0 ? dst + pair * 2 * TILE * SROW + oofb : sink;
+            float* b1 = v1 ? dst + (pair * 2 + 1) * TILE * SROW + oofb : sink;
+            *reinterpret_cast<s16x4*>(b0) = pack_bf16(e0);
+            *reinterpret_cast<s16x4*>(b1) = pack_bf16(e1);
+            if (dst32) {
+                float* d0 = v0 ? dst32 + pair * 2 * TILE * H + ooff : sink;
+                float* d1 = v1 ? dst32 + (pair * 2 + 1) * TILE * H + ooff : sink;
+                *reinterpret_cast<f32x4*>(d0) = e0;
+                *reinterpret_cast<f32x4*>(d1) = e1;
+            }
+        } else {
         float* d0 = v0 ? dst + pair * 2 * TILE * H + ooff : sink;
         float* d1 = v1 ? dst + (pair * 2 + 1) * TILE * H + ooff : sink;
         *reinterpret_cast<f32x4*>(d0) = e0;
         *reinterpret_cast<f32x4*>(d1) = e1;
+        }
         if (SAVE) {
             if (v0) *reinterpret_cast<f32x4*>(save + p0 * H + 4 * oslot) = e0;
             if (v1) *reinterpret_cast<f32x4*>(save + p1 * H + 4 * oslot) = e1;
@@ -373,7 +418,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
     // PFM_PAIR_BODY(MF, PFI): `pair` in scope; PFI(q) issues the prefetch load that rides behind quarter q.
 #define PFM_PAIR_BODY(MF, PFI)                                                                                  \
     {                                                                                                           \
-        const float* s0 = src + pair * 2 * TILE * H;                                                            \
+        const float* s0 = src + pair * 2 * TILE * SROW;                                                         \
         PFM_LOADQ(Y0, Y1, s0, 1);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         f32x4 acc0 = bias, acc1 = bias;                                                                         \
@@ -400,7 +445,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
         MF(X0, X1, 2);                                                                                          \
         PFI(2);                                                                                                 \
         /* first quarter of the NEXT pair (one pair past the end on the last iteration: inside the LDS window) */ \
-        PFM_LOADQ(X0, X1, s0 + 2 * TILE * H, 0);                                                                \
+        PFM_LOADQ(X0, X1, s0 + 2 * TILE * SROW, 0);                                                             \
         if (RESID) {                                                                                            \
             const float* rn = resid + (pair + 1) * 2 * TILE * H;                                                \
             r0 = *reinterpret_cast<const f32x4*>(rn + ooff);                                                    \
