@@ -464,8 +464,12 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
     // the pool sum pair P adds to: the jet's own in quad mode (P is a constant expression at every use)
 #define PFM_PSUM_OF(P) (NSEG == 4 ? psq[NSEG == 4 ? ((P) > 0 ? (P) : 0) : 0] : psum)
 #define PFM_NOPF(q)
+    /* Quad mode runs ALL four pair bodies whatever the number of jets in the workgroup (only a call's last workgroup holds fewer than
+       four): a missing jet's slot holds stale rows whose results stay inside that slot -- rows never mix in a particle phase, its pool sum is
+       its own and never finished -- and the bodies become one straight-line block: the run-time `P < npairs` tests cost ~30 register
+       copies per body at the merge points (psq[], the staged operands), as much VALU work as the bf16 body itself. */
 #define PFM_PAIR_AT(P)                                                                                          \
-    if ((P) < nfull) {                                                                                          \
+    if (NSEG == 4 ? (P) < 4 : (P) < nfull) {                                                                    \
         constexpr int pair = (P);                                                                               \
         PFM_PAIR_BODY(PFM_MFMAQ, PFM_PFI_##P)                                                                   \
     }
@@ -498,10 +502,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
     if constexpr (NSEG == 4) {
         // the last jet's slot: every row of a slot is computed (holes carry zero input and zero mask), so no predication; the
         // branch is wave-uniform and the pool sum's index static in each arm
-        if (npairs == 1) epilogue_full(pacc0, pacc1, 0, psq[0], std::false_type{});
-        else if (npairs == 2) epilogue_full(pacc0, pacc1, 1, psq[1], std::false_type{});
-        else if (npairs == 3) epilogue_full(pacc0, pacc1, 2, psq[2], std::false_type{});
-        else epilogue_full(pacc0, pacc1, 3, psq[3], std::false_type{});
+        epilogue_full(pacc0, pacc1, 3, psq[3], std::false_type{});
     } else {
         epilogue(pacc0, pacc1, npairs - 1);
     }
