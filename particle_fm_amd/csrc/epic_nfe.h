@@ -233,6 +233,9 @@ __device__ __forceinline__ int phase_full_pairs(int n_rows) {
 // activation was rounded eight times over before (once per consuming wave), 32 v_cvt_pk per tile pair and wave against 8 MFMAs.  dst32
 // (or nullptr): where the same rows also go as fp32 (the residual input of the next local linear 2).  Same roundings of the same
 // numbers: bit-identical to the fp32-resident bf16 flavour.
+#ifndef PFM_PAIR_NEST
+#define PFM_PAIR_NEST 1
+#endif
 template <bool RESID, bool POOL, bool SAVE, bool BF16 = false, typename PF = PfNone, int NSEG = 1, bool TAIL = true, int AF = 8, bool VB16 = false,
           bool RB16 = false>
 __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __restrict__ src,
@@ -468,11 +471,24 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
        four): a missing jet's slot holds stale rows whose results stay inside that slot -- rows never mix in a particle phase, its pool sum is
        its own and never finished -- and the bodies become one straight-line block: the run-time `P < npairs` tests cost ~30 register
        copies per body at the merge points (psq[], the staged operands), as much VALU work as the bf16 body itself. */
+    // (PFM_PAIR_NEST: body P + 1 sits INSIDE the `if` of body P -- control leaves the chain once, at its end, instead of re-joining
+    // behind every body: the register copies of the merge points run once per phase, not once per pair)
+#if PFM_PAIR_NEST
+#define PFM_PAIR_AT(P)                                                                                          \
+    if (NSEG == 4 ? (P) < 4 : (P) < nfull) {                                                                    \
+        {                                                                                                       \
+            constexpr int pair = (P);                                                                           \
+            PFM_PAIR_BODY(PFM_MFMAQ, PFM_PFI_##P)                                                               \
+        }
+#define PFM_PAIR_END }
+#else
 #define PFM_PAIR_AT(P)                                                                                          \
     if (NSEG == 4 ? (P) < 4 : (P) < nfull) {                                                                    \
         constexpr int pair = (P);                                                                               \
         PFM_PAIR_BODY(PFM_MFMAQ, PFM_PFI_##P)                                                                   \
     }
+#define PFM_PAIR_END
+#endif
 #define PFM_PFI_0(q) pf.template issue_slot<0 + (q)>()
 #define PFM_PFI_1(q) pf.template issue_slot<4 + (q)>()
 #define PFM_PFI_2(q) pf.template issue_slot<8 + (q)>()
@@ -480,6 +496,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
 #define PFM_PFI_4(q) pf.template issue_slot<16 + (q)>()
     static_assert(MAXPAIRS == 5, "unroll PFM_PAIR_AT to MAXPAIRS");
     PFM_PAIR_AT(0) PFM_PAIR_AT(1) PFM_PAIR_AT(2) PFM_PAIR_AT(3) PFM_PAIR_AT(4)
+    PFM_PAIR_END PFM_PAIR_END PFM_PAIR_END PFM_PAIR_END PFM_PAIR_END
     if constexpr (NSEG != 4) {
         if (nfull < npairs) {  // odd tile count: one real tile in the last pair
             const int pair = nfull;
@@ -492,6 +509,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
 #undef PFM_PFI_3
 #undef PFM_PFI_4
 #undef PFM_PAIR_AT
+#undef PFM_PAIR_END
 #undef PFM_PSUM_OF
 #undef PFM_NOPF
 #undef PFM_PAIR_BODY
