@@ -342,7 +342,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
             float* db = dst + pair * 2 * TILE * SROW + oofb;
             *reinterpret_cast<s16x4*>(db) = pack_bf16(e0);
             *reinterpret_cast<s16x4*>(db + TILE * SROW) = pack_bf16(e1);
-            if (dst32) {
+            if constexpr (RESID) {  // (RB16: the phases with a residual input are the ones whose rows also stay as fp32: dst32 != nullptr)
                 float* d0 = dst32 + pair * 2 * TILE * H + ooff;
                 *reinterpret_cast<f32x4*>(d0) = e0;
                 *reinterpret_cast<f32x4*>(d0 + TILE * H) = e1;
@@ -385,7 +385,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4 (&a)[AF], const float* __
             float* b1 = v1 ? dst + (pair * 2 + 1) * TILE * SROW + oofb : sink;
             *reinterpret_cast<s16x4*>(b0) = pack_bf16(e0);
             *reinterpret_cast<s16x4*>(b1) = pack_bf16(e1);
-            if (dst32) {
+            if constexpr (RESID) {  // (RB16: the phases with a residual input are the ones whose rows also stay as fp32: dst32 != nullptr)
                 float* d0 = v0 ? dst32 + pair * 2 * TILE * H + ooff : sink;
                 float* d1 = v1 ? dst32 + (pair * 2 + 1) * TILE * H + ooff : sink;
                 *reinterpret_cast<f32x4*>(d0) = e0;
